@@ -1,0 +1,202 @@
+/* integration/vamd_pack_setup.c -- the reference-side half of the boundary.
+ *
+ * This file is what a libvorbis maintainer adds to lib/ (next to block.c): it
+ * compiles against libvorbis' own internal headers and serialises the lookups
+ * vorbis_analysis_init() built (reference lib/block.c:170-293,296-311) into the
+ * POD blob of include/vamd_setup.h.  The GPU layer (libvorbis_amd.so) never sees
+ * a libvorbis struct.  It is also compiled into oracle/_ref/libvorbis_ref.so so
+ * tests and the committed setup blobs are produced by exactly this code.
+ *
+ *   long vamd_pack_setup(vorbis_dsp_state *vd, void *dst, long cap)
+ *     returns the blob size in bytes (call with dst==NULL to size it),
+ *     or a negative OV_* code: OV_EINVAL (not an analysis state),
+ *     OV_EIMPL (a setup the GPU path does not cover yet).
+ */
+#include <string.h>
+#include <stdint.h>
+#include "vorbis/codec.h"
+#include "codec_internal.h"
+#include "registry.h"
+#include "window.h"
+#include "mdct.h"
+#include "smallft.h"
+#include "psy.h"
+#include "misc.h"
+#include "vamd_setup.h"
+
+static uint32_t place(uint32_t *cursor, uint32_t bytes) {
+  uint32_t at = (*cursor + 15u) & ~15u;
+  *cursor = at + bytes;
+  return at;
+}
+
+static void put(void *dst, uint32_t off, const void *src, uint32_t bytes) {
+  if (dst) memcpy((char *)dst + off, src, bytes);
+}
+
+long vamd_pack_setup(vorbis_dsp_state *vd, void *dst, long cap) {
+  vorbis_info *vi;
+  codec_setup_info *ci;
+  private_state *b;
+  vamd_setup_header h;
+  uint32_t cur = sizeof(vamd_setup_header);
+  int W, p, i, j;
+
+  if (!vd || !vd->analysisp || !vd->vi || !vd->backend_state) return OV_EINVAL;
+  vi = vd->vi;
+  ci = (codec_setup_info *)vi->codec_setup;
+  b = (private_state *)vd->backend_state;
+  if (!ci || ci->psys != 4) return OV_EINVAL;
+  if (vi->channels < 1 || vi->channels > VAMD_MAX_CH) return OV_EIMPL;
+
+  /* a sizing pass (dst == NULL) always runs before anything is written */
+  if (dst) {
+    long need = vamd_pack_setup(vd, NULL, 0);
+    if (need < 0) return need;
+    if (cap < need) return OV_EINVAL;
+    memset(dst, 0, (size_t)need);
+  }
+  memset(&h, 0, sizeof(h));
+  h.magic = VAMD_SETUP_MAGIC;
+  h.version = VAMD_SETUP_VERSION;
+  h.channels = vi->channels;
+  h.rate = (int32_t)vi->rate;
+  h.blocksizes[0] = (int32_t)ci->blocksizes[0];
+  h.blocksizes[1] = (int32_t)ci->blocksizes[1];
+  h.managed = b->bms.managed ? 1 : 0;
+
+  for (W = 0; W < 2; W++) {
+    vamd_xform_tab *x = &h.xform[W];
+    mdct_lookup *m = (mdct_lookup *)b->transform[W][0];
+    drft_lookup *f = &b->fft_look[W];
+    int n = m->n;
+    x->n = n;
+    x->log2n = m->log2n;
+    x->mdct_scale = m->scale;
+    x->fft_nf = f->splitcache[1];
+    if (x->fft_nf > 16 || f->n != n) return OV_EIMPL;
+    for (i = 0; i < x->fft_nf; i++) x->fft_fac[i] = f->splitcache[2 + i];
+    x->off_mdct_trig = place(&cur, (uint32_t)(n + n / 4) * 4u);
+    put(dst, x->off_mdct_trig, m->trig, (uint32_t)(n + n / 4) * 4u);
+    x->off_mdct_bitrev = place(&cur, (uint32_t)(n / 4) * 4u);
+    put(dst, x->off_mdct_bitrev, m->bitrev, (uint32_t)(n / 4) * 4u);
+    x->off_fft_wa = place(&cur, (uint32_t)(2 * n) * 4u);
+    put(dst, x->off_fft_wa, f->trigcache + n, (uint32_t)(2 * n) * 4u);
+    x->off_window = place(&cur, (uint32_t)(n / 2) * 4u);
+    /* b->window[W] indexes vwin[] exactly as _vorbis_apply_window does
+       (lib/window.c:2102-2110) */
+    put(dst, x->off_window, _vorbis_window_get(b->window[W]), (uint32_t)(n / 2) * 4u);
+  }
+
+  for (p = 0; p < 4; p++) {
+    vamd_psy_tab *t = &h.psy[p];
+    vorbis_look_psy *l = b->psy + p;
+    vorbis_info_psy *pi = l->vi;
+    int n = l->n;
+    uint32_t off;
+    t->n = n;
+    t->blockflag = pi->blockflag;
+    t->firstoc = (int32_t)l->firstoc;
+    t->shiftoc = (int32_t)l->shiftoc;
+    t->eighth_octave_lines = l->eighth_octave_lines;
+    t->total_octave_lines = l->total_octave_lines;
+    t->m_val = l->m_val;
+    t->ath_adjatt = pi->ath_adjatt;
+    t->ath_maxatt = pi->ath_maxatt;
+    for (i = 0; i < P_NOISECURVES; i++) t->tone_masteratt[i] = pi->tone_masteratt[i];
+    t->tone_abs_limit = pi->tone_abs_limit;
+    t->noisemaxsupp = pi->noisemaxsupp;
+    t->noisewindowfixed = pi->noisewindowfixed;
+    t->max_curve_dB = pi->max_curve_dB;
+    for (i = 0; i < NOISE_COMPAND_LEVELS; i++) t->noisecompand[i] = pi->noisecompand[i];
+    t->normal_p = pi->normal_p;
+    t->normal_start = pi->normal_start;
+    t->normal_partition = pi->normal_partition;
+    t->normal_thresh = pi->normal_thresh;
+
+    t->off_ath = place(&cur, (uint32_t)n * 4u);
+    put(dst, t->off_ath, l->ath, (uint32_t)n * 4u);
+
+    /* octave[] and bark[] are `long` in the reference; their values fit int32 */
+    t->off_octave = place(&cur, (uint32_t)n * 4u);
+    t->off_bark = place(&cur, (uint32_t)n * 4u);
+    if (dst)
+      for (i = 0; i < n; i++) {
+        int32_t oc = (int32_t)l->octave[i], bk = (int32_t)l->bark[i];
+        memcpy((char *)dst + t->off_octave + 4u * i, &oc, 4);
+        memcpy((char *)dst + t->off_bark + 4u * i, &bk, 4);
+      }
+
+    t->off_noiseoffset = place(&cur, (uint32_t)(P_NOISECURVES * n) * 4u);
+    for (i = 0; i < P_NOISECURVES; i++)
+      put(dst, t->off_noiseoffset + (uint32_t)(i * n) * 4u, l->noiseoffset[i], (uint32_t)n * 4u);
+
+    off = t->off_tonecurves = place(&cur, (uint32_t)(P_BANDS * P_LEVELS * (EHMER_MAX + 2)) * 4u);
+    for (i = 0; i < P_BANDS; i++)
+      for (j = 0; j < P_LEVELS; j++) {
+        put(dst, off, l->tonecurves[i][j], (EHMER_MAX + 2) * 4u);
+        off += (EHMER_MAX + 2) * 4u;
+      }
+  }
+
+  {
+    vorbis_info_psy_global *g = &ci->psy_g_param;
+    h.psy_g.ampmax_att_per_sec = g->ampmax_att_per_sec;
+    for (i = 0; i < PACKETBLOBS; i++) {
+      h.psy_g.coupling_pointlimit[0][i] = g->coupling_pointlimit[0][i];
+      h.psy_g.coupling_pointlimit[1][i] = g->coupling_pointlimit[1][i];
+      h.psy_g.coupling_prepointamp[i] = g->coupling_prepointamp[i];
+      h.psy_g.coupling_postpointamp[i] = g->coupling_postpointamp[i];
+      h.psy_g.sliding_lowpass[0][i] = g->sliding_lowpass[0][i];
+      h.psy_g.sliding_lowpass[1][i] = g->sliding_lowpass[1][i];
+    }
+  }
+
+  for (W = 0; W < 2; W++) {
+    /* mode number == W in every libvorbisenc setup (lib/mapping0.c:248) */
+    vamd_mode_tab *m = &h.mode[W];
+    vorbis_info_mapping0 *map;
+    vorbis_look_floor1 *fl;
+    vorbis_info_floor1 *fi;
+    int fidx;
+    if (W >= ci->modes) return OV_EIMPL;
+    if (ci->map_type[ci->mode_param[W]->mapping] != 0) return OV_EIMPL;
+    map = (vorbis_info_mapping0 *)ci->map_param[ci->mode_param[W]->mapping];
+    m->submaps = map->submaps;
+    m->coupling_steps = map->coupling_steps;
+    if (map->submaps != 1 || map->coupling_steps > 1) return OV_EIMPL;
+    if (map->coupling_steps == 1) {
+      m->coupling_mag = map->coupling_mag[0];
+      m->coupling_ang = map->coupling_ang[0];
+    }
+    fidx = map->floorsubmap[0];
+    if (ci->floor_type[fidx] != 1) return OV_EIMPL; /* lib/mapping0.c:498 */
+    fl = (vorbis_look_floor1 *)b->flr[fidx];
+    fi = fl->vi;
+    m->floor.posts = fl->posts;
+    m->floor.look_n = fl->n;
+    m->floor.quant_q = fl->quant_q;
+    m->floor.mult = fi->mult;
+    m->floor.info_n = fi->n;
+    m->floor.maxover = fi->maxover;
+    m->floor.maxunder = fi->maxunder;
+    m->floor.maxerr = fi->maxerr;
+    m->floor.twofitweight = fi->twofitweight;
+    m->floor.twofitatten = fi->twofitatten;
+    for (i = 0; i < fl->posts && i < VAMD_POSIT; i++) {
+      m->floor.postlist[i] = fi->postlist[i];
+      m->floor.sorted_index[i] = fl->sorted_index[i];
+      m->floor.forward_index[i] = fl->forward_index[i];
+      m->floor.reverse_index[i] = fl->reverse_index[i];
+    }
+    for (i = 0; i < fl->posts - 2 && i < VIF_POSIT; i++) {
+      m->floor.hineighbor[i] = fl->hineighbor[i];
+      m->floor.loneighbor[i] = fl->loneighbor[i];
+    }
+  }
+
+  cur = (cur + 15u) & ~15u;
+  h.total_bytes = cur;
+  if (dst) memcpy(dst, &h, sizeof(h));
+  return (long)cur;
+}

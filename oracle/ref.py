@@ -1,0 +1,240 @@
+"""oracle/ref.py -- TEST INFRASTRUCTURE ONLY.
+
+ctypes binding to oracle/_ref/libvorbis_ref.so: the unmodified reference
+libvorbis sources (compiled in place from /root/reference by oracle/Makefile)
+plus oracle/ref_harness.c.  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this module; the product (vorbis_amd/) never does.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_ref", "libvorbis_ref.so")
+
+BLOCKTYPE_IMPULSE = 0
+BLOCKTYPE_PADDING = 1
+BLOCKTYPE_TRANSITION = 0
+BLOCKTYPE_LONG = 1
+
+_f32p = C.POINTER(C.c_float)
+_i32p = C.POINTER(C.c_int)
+_u8p = C.POINTER(C.c_ubyte)
+
+
+class _Taps(C.Structure):
+    _fields_ = [
+        ("windowed", _f32p), ("mdct_raw", _f32p), ("fft_packed", _f32p), ("logfft", _f32p),
+        ("logmdct", _f32p), ("noise", _f32p), ("tone", _f32p), ("logmask", _f32p), ("mdct", _f32p),
+        ("posts", _i32p), ("post_valid", _i32p), ("ilogmask", _i32p), ("iwork", _i32p),
+        ("nonzero", _i32p), ("local_ampmax", _f32p), ("ampmax_out", _f32p),
+        ("packet", _u8p), ("packet_cap", C.c_long), ("packet_bytes", C.c_long),
+        ("packet_matches_real", C.c_int),
+    ]
+
+
+class _BlockRec(C.Structure):
+    _fields_ = [
+        ("lW", C.c_int), ("W", C.c_int), ("nW", C.c_int), ("blocktype", C.c_int),
+        ("ampmax_in", C.c_float), ("ampmax_out", C.c_float),
+        ("pcm_offset", C.c_long), ("packet_offset", C.c_long), ("packet_bytes", C.c_long),
+    ]
+
+
+def available():
+    return os.path.exists(LIB_PATH)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not available():
+            raise RuntimeError("oracle/_ref/libvorbis_ref.so missing: run `make -C oracle ref` "
+                               "(needs /root/reference)")
+        L = C.CDLL(LIB_PATH)
+        L.ref_open.restype = C.c_void_p
+        L.ref_open.argtypes = [C.c_int, C.c_long, C.c_float]
+        L.ref_close.argtypes = [C.c_void_p]
+        L.ref_pack_setup.restype = C.c_long
+        L.ref_pack_setup.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
+        L.ref_blocksize.argtypes = [C.c_void_p, C.c_int]
+        L.ref_floor_posts.argtypes = [C.c_void_p, C.c_int]
+        L.ref_apply_window.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int]
+        L.ref_mdct_forward.argtypes = [C.c_void_p, C.c_int, _f32p, _f32p]
+        L.ref_drft_forward.argtypes = [C.c_void_p, C.c_int, _f32p]
+        L.ref_noisemask.argtypes = [C.c_void_p, C.c_int, _f32p, _f32p]
+        L.ref_tonemask.argtypes = [C.c_void_p, C.c_int, _f32p, _f32p, C.c_float, C.c_float]
+        L.ref_ampmax_decay.restype = C.c_float
+        L.ref_ampmax_decay.argtypes = [C.c_void_p, C.c_float, C.c_int]
+        L.ref_real_block.restype = C.c_long
+        L.ref_real_block.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                     _u8p, C.c_long, _f32p]
+        L.ref_tap_block.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                    C.POINTER(_Taps)]
+        L.ref_encode_stream.restype = C.c_long
+        L.ref_encode_stream.argtypes = [C.c_void_p, _f32p, C.c_long, C.POINTER(_BlockRec), C.c_long,
+                                        _f32p, C.c_long, _u8p, C.c_long]
+        L.ref_time_analysis.restype = C.c_double
+        L.ref_time_analysis.argtypes = [C.c_void_p, _f32p, C.c_long, C.c_int]
+        L.ref_time_dsp.restype = C.c_double
+        L.ref_time_dsp.argtypes = [C.c_void_p, _f32p, C.c_long, C.c_int]
+        _lib = L
+    return _lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(_f32p)
+
+
+def _ip(a):
+    return a.ctypes.data_as(_i32p)
+
+
+class RefEncoder:
+    """One reference encoder state (vorbis_info + vorbis_dsp_state + a vorbis_block)."""
+
+    def __init__(self, channels=2, rate=44100, quality=0.4):
+        self.L = lib()
+        self.h = self.L.ref_open(channels, rate, quality)
+        if not self.h:
+            raise RuntimeError("vorbis_encode_init_vbr failed")
+        self.channels, self.rate, self.quality = channels, rate, quality
+
+    def close(self):
+        if self.h:
+            self.L.ref_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def blocksize(self, W):
+        return self.L.ref_blocksize(self.h, W)
+
+    def floor_posts(self, W):
+        return self.L.ref_floor_posts(self.h, W)
+
+    def pack_setup(self):
+        need = self.L.ref_pack_setup(self.h, None, 0)
+        if need < 0:
+            raise RuntimeError("vamd_pack_setup failed: %d" % need)
+        buf = np.zeros(need, dtype=np.uint8)
+        got = self.L.ref_pack_setup(self.h, buf.ctypes.data_as(C.c_void_p), need)
+        assert got == need
+        return buf
+
+    # ---- function-level taps ----
+    def apply_window(self, d, lW, W, nW):
+        d = np.ascontiguousarray(d, dtype=np.float32).copy()
+        self.L.ref_apply_window(self.h, _fp(d), lW, W, nW)
+        return d
+
+    def mdct_forward(self, W, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty(x.shape[-1] // 2, dtype=np.float32)
+        self.L.ref_mdct_forward(self.h, W, _fp(x), _fp(out))
+        return out
+
+    def drft_forward(self, W, x):
+        x = np.ascontiguousarray(x, dtype=np.float32).copy()
+        self.L.ref_drft_forward(self.h, W, _fp(x))
+        return x
+
+    def noisemask(self, psy, logmdct):
+        logmdct = np.ascontiguousarray(logmdct, dtype=np.float32)
+        out = np.empty_like(logmdct)
+        self.L.ref_noisemask(self.h, psy, _fp(logmdct), _fp(out))
+        return out
+
+    def tonemask(self, psy, logfft, global_ampmax, local_ampmax):
+        logfft = np.ascontiguousarray(logfft, dtype=np.float32)
+        out = np.empty_like(logfft)
+        self.L.ref_tonemask(self.h, psy, _fp(logfft), _fp(out), global_ampmax, local_ampmax)
+        return out
+
+    def ampmax_decay(self, amp, W):
+        return float(self.L.ref_ampmax_decay(self.h, amp, W))
+
+    # ---- block-level ----
+    def real_block(self, pcm, lW=1, W=1, nW=1, blocktype=BLOCKTYPE_LONG, ampmax_in=-9999.0):
+        """The real vorbis_analysis() on one pre-cut block -> (packet bytes, ampmax_out)."""
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        pkt = np.zeros(1 << 17, dtype=np.uint8)
+        amp = C.c_float(0)
+        nb = self.L.ref_real_block(self.h, _fp(pcm), lW, W, nW, blocktype, ampmax_in,
+                                   pkt.ctypes.data_as(_u8p), pkt.size, C.byref(amp))
+        if nb < 0:
+            raise RuntimeError("vorbis_analysis failed: %d" % nb)
+        return bytes(pkt[:nb]), amp.value
+
+    def tap_block(self, pcm, lW=1, W=1, nW=1, blocktype=BLOCKTYPE_LONG, ampmax_in=-9999.0):
+        """All mapping0_forward intermediates for one block pcm[ch][n] (dict of arrays)."""
+        ch = self.channels
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        n = self.blocksize(W)
+        assert pcm.shape == (ch, n), pcm.shape
+        n2 = n // 2
+        o = {
+            "windowed": np.empty((ch, n), np.float32), "mdct_raw": np.empty((ch, n2), np.float32),
+            "fft_packed": np.empty((ch, n), np.float32), "logfft": np.empty((ch, n2), np.float32),
+            "logmdct": np.empty((ch, n2), np.float32), "noise": np.empty((ch, n2), np.float32),
+            "tone": np.empty((ch, n2), np.float32), "logmask": np.empty((ch, n2), np.float32),
+            "mdct": np.empty((ch, n2), np.float32), "posts": np.zeros((ch, 65), np.int32),
+            "post_valid": np.zeros(ch, np.int32), "ilogmask": np.empty((ch, n2), np.int32),
+            "iwork": np.empty((ch, n2), np.int32), "nonzero": np.zeros(ch, np.int32),
+            "local_ampmax": np.empty(ch, np.float32), "ampmax_out": np.empty(1, np.float32),
+        }
+        pkt = np.zeros(1 << 17, dtype=np.uint8)
+        t = _Taps()
+        for k, v in o.items():
+            setattr(t, k, _fp(v) if v.dtype == np.float32 else _ip(v))
+        t.packet = pkt.ctypes.data_as(_u8p)
+        t.packet_cap = pkt.size
+        ret = self.L.ref_tap_block(self.h, _fp(pcm), lW, W, nW, blocktype, ampmax_in, C.byref(t))
+        if ret:
+            raise RuntimeError("ref_tap_block failed: %d" % ret)
+        o["packet"] = bytes(pkt[:t.packet_bytes])
+        o["packet_matches_real"] = bool(t.packet_matches_real)
+        o["ampmax_out"] = float(o["ampmax_out"][0])
+        return o
+
+    def encode_stream(self, pcm, max_blocks=1 << 16):
+        """Run the whole application loop over planar pcm[ch][frames].  Consumes this
+        encoder state.  Returns a list of dicts (lW,W,nW,blocktype,ampmax_in,ampmax_out,pcm,packet)."""
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        ch, frames = pcm.shape
+        assert ch == self.channels
+        recs = (_BlockRec * max_blocks)()
+        pcm_cap = (frames * 2 + 8 * self.blocksize(1)) * ch * 2
+        pcm_out = np.zeros(pcm_cap, np.float32)
+        pk_cap = max(1 << 20, frames * ch)
+        pk_out = np.zeros(pk_cap, np.uint8)
+        nb = self.L.ref_encode_stream(self.h, _fp(pcm), frames, recs, max_blocks, _fp(pcm_out), pcm_cap,
+                                      pk_out.ctypes.data_as(_u8p), pk_cap)
+        if nb < 0:
+            raise RuntimeError("ref_encode_stream failed: %d" % nb)
+        out = []
+        for k in range(min(nb, max_blocks)):
+            r = recs[k]
+            n = self.blocksize(r.W)
+            d = dict(lW=r.lW, W=r.W, nW=r.nW, blocktype=r.blocktype, ampmax_in=r.ampmax_in,
+                     ampmax_out=r.ampmax_out)
+            d["pcm"] = pcm_out[r.pcm_offset:r.pcm_offset + ch * n].reshape(ch, n).copy() if r.pcm_offset >= 0 else None
+            d["packet"] = bytes(pk_out[r.packet_offset:r.packet_offset + r.packet_bytes]) if r.packet_offset >= 0 else None
+            out.append(d)
+        return out
+
+    def time_analysis(self, blocks, reps=1):
+        blocks = np.ascontiguousarray(blocks, dtype=np.float32)
+        return float(self.L.ref_time_analysis(self.h, _fp(blocks), blocks.shape[0], reps))
+
+    def time_dsp(self, blocks, reps=1):
+        blocks = np.ascontiguousarray(blocks, dtype=np.float32)
+        return float(self.L.ref_time_dsp(self.h, _fp(blocks), blocks.shape[0], reps))

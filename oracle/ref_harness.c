@@ -1,0 +1,465 @@
+/* oracle/ref_harness.c -- TEST INFRASTRUCTURE ONLY (never linked into the product).
+ *
+ * Thin C entry points over the UNMODIFIED reference sources, which
+ * oracle/Makefile compiles in place from /root/reference/lib into
+ * oracle/_ref/libvorbis_ref.so.  Three jobs:
+ *
+ *  1. ref_open()/ref_pack_setup(): run the reference's own libvorbisenc +
+ *     vorbis_analysis_init() and serialise the derived lookups with the
+ *     reference-side packer (integration/vamd_pack_setup.c).
+ *  2. ref_tap_block(): re-state mapping0_forward's VBR call sequence
+ *     (reference lib/mapping0.c:230-696) using only the reference's *extern*
+ *     functions, copying every intermediate out ("taps" at the #if 0
+ *     _analysis_output sites), and cross-check the resulting
+ *     packet bytes against the real vorbis_analysis() on the same block.
+ *  3. ref_encode_stream(): the application loop of
+ *     examples/encoder_example.c:179-236 (minus libogg framing) recording the
+ *     genuine per-block (lW,W,nW,blocktype,ampmax_in) sequence and packets.
+ *
+ * Plain C types only so Python ctypes / the C tests can call it.
+ */
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include <math.h>
+#include <time.h>
+#include "vorbis/codec.h"
+#include "vorbis/vorbisenc.h"
+#include "codec_internal.h"
+#include "registry.h"
+#include "window.h"
+#include "mdct.h"
+#include "smallft.h"
+#include "psy.h"
+#include "scales.h"
+#include "misc.h"
+
+extern long vamd_pack_setup(vorbis_dsp_state *vd, void *dst, long cap);
+
+typedef struct ref_enc {
+  vorbis_info vi;
+  vorbis_dsp_state vd;
+  vorbis_block vb;    /* used for tap / real single-block analysis */
+  int channels;
+  float quality;
+} ref_enc;
+
+ref_enc *ref_open(int channels, long rate, float quality) {
+  ref_enc *e = (ref_enc *)calloc(1, sizeof(*e));
+  if (!e) return NULL;
+  vorbis_info_init(&e->vi);
+  if (vorbis_encode_init_vbr(&e->vi, channels, rate, quality)) {
+    vorbis_info_clear(&e->vi);
+    free(e);
+    return NULL;
+  }
+  vorbis_analysis_init(&e->vd, &e->vi);
+  vorbis_block_init(&e->vd, &e->vb);
+  e->channels = channels;
+  e->quality = quality;
+  return e;
+}
+
+void ref_close(ref_enc *e) {
+  if (!e) return;
+  vorbis_block_clear(&e->vb);
+  vorbis_dsp_clear(&e->vd);
+  vorbis_info_clear(&e->vi);
+  free(e);
+}
+
+long ref_pack_setup(ref_enc *e, void *dst, long cap) { return vamd_pack_setup(&e->vd, dst, cap); }
+
+int ref_blocksize(ref_enc *e, int W) {
+  codec_setup_info *ci = (codec_setup_info *)e->vi.codec_setup;
+  return (int)ci->blocksizes[W];
+}
+
+int ref_floor_posts(ref_enc *e, int W) {
+  codec_setup_info *ci = (codec_setup_info *)e->vi.codec_setup;
+  private_state *b = (private_state *)e->vd.backend_state;
+  vorbis_info_mapping0 *info = (vorbis_info_mapping0 *)ci->map_param[W];
+  return ((vorbis_look_floor1 *)b->flr[info->floorsubmap[0]])->posts;
+}
+
+/* ---- single-function taps (unit-level parity) ---------------------------- */
+
+void ref_apply_window(ref_enc *e, float *d, int lW, int W, int nW) {
+  codec_setup_info *ci = (codec_setup_info *)e->vi.codec_setup;
+  private_state *b = (private_state *)e->vd.backend_state;
+  _vorbis_apply_window(d, b->window, ci->blocksizes, lW, W, nW);
+}
+
+void ref_mdct_forward(ref_enc *e, int W, const float *in, float *out) {
+  private_state *b = (private_state *)e->vd.backend_state;
+  int n = ref_blocksize(e, W);
+  float *tmp = (float *)malloc(sizeof(float) * n);
+  memcpy(tmp, in, sizeof(float) * n);
+  mdct_forward((mdct_lookup *)b->transform[W][0], tmp, out);
+  free(tmp);
+}
+
+void ref_drft_forward(ref_enc *e, int W, float *data) {
+  private_state *b = (private_state *)e->vd.backend_state;
+  drft_forward(&b->fft_look[W], data);
+}
+
+void ref_noisemask(ref_enc *e, int psy, const float *logmdct, float *noise) {
+  private_state *b = (private_state *)e->vd.backend_state;
+  int n = b->psy[psy].n;
+  float *tmp = (float *)malloc(sizeof(float) * n);
+  memcpy(tmp, logmdct, sizeof(float) * n);
+  _vp_noisemask(b->psy + psy, tmp, noise);
+  free(tmp);
+}
+
+void ref_tonemask(ref_enc *e, int psy, const float *logfft, float *tone, float global_ampmax,
+                  float local_ampmax) {
+  private_state *b = (private_state *)e->vd.backend_state;
+  int n = b->psy[psy].n;
+  float *tmp = (float *)malloc(sizeof(float) * n);
+  memcpy(tmp, logfft, sizeof(float) * n);
+  _vp_tonemask(b->psy + psy, tmp, tone, global_ampmax, local_ampmax);
+  free(tmp);
+}
+
+float ref_ampmax_decay(ref_enc *e, float amp, int W) {
+  long save = e->vd.W;
+  float r;
+  e->vd.W = W;
+  r = _vp_ampmax_decay(amp, &e->vd);
+  e->vd.W = save;
+  return r;
+}
+
+/* ---- whole-block taps ----------------------------------------------------- */
+
+typedef struct ref_taps {
+  /* all optional (NULL = skip); float/int arrays are [ch][...] contiguous */
+  float *windowed;     /* [ch][n]   after _vorbis_apply_window */
+  float *mdct_raw;     /* [ch][n/2] mdct_forward output (pre AoTuV-M1) */
+  float *fft_packed;   /* [ch][n]   drft_forward output, FFTPACK order */
+  float *logfft;       /* [ch][n/2] */
+  float *logmdct;      /* [ch][n/2] */
+  float *noise;        /* [ch][n/2] */
+  float *tone;         /* [ch][n/2] */
+  float *logmask;      /* [ch][n/2] after _vp_offset_and_mix(select 1) */
+  float *mdct;         /* [ch][n/2] post-M1 spectrum (what gets quantised) */
+  int *posts;          /* [ch][65]  floor1_fit output (bit 15 = unused flag) */
+  int *post_valid;     /* [ch]      0 when floor1_fit returned NULL */
+  int *ilogmask;       /* [ch][n/2] integer floor curve from floor1_encode */
+  int *iwork;          /* [ch][n/2] quantised + coupled residue */
+  int *nonzero;        /* [ch]      after the coupling fix-up */
+  float *local_ampmax; /* [ch] */
+  float *ampmax_out;   /* [1] */
+  unsigned char *packet; /* packet bytes of the tap run */
+  long packet_cap;
+  long packet_bytes;   /* out */
+  int packet_matches_real; /* out: 1 when the real vorbis_analysis() produced identical bytes+ampmax */
+} ref_taps;
+
+static void load_block(ref_enc *e, const float *pcm, int lW, int W, int nW, int blocktype,
+                       float ampmax_in) {
+  vorbis_block *vb = &e->vb;
+  vorbis_block_internal *vbi = (vorbis_block_internal *)vb->internal;
+  int n = ref_blocksize(e, W), i;
+  /* what vorbis_analysis_blockout does to hand a block over, lib/block.c:592-643 */
+  _vorbis_block_ripcord(vb);
+  vb->lW = lW;
+  vb->W = W;
+  vb->nW = nW;
+  vbi->blocktype = blocktype;
+  vb->vd = &e->vd;
+  vb->pcmend = n;
+  vb->eofflag = 0;
+  vbi->ampmax = ampmax_in;
+  vb->pcm = (float **)_vorbis_block_alloc(vb, sizeof(*vb->pcm) * e->channels);
+  for (i = 0; i < e->channels; i++) {
+    vb->pcm[i] = (float *)_vorbis_block_alloc(vb, n * sizeof(float));
+    memcpy(vb->pcm[i], pcm + (size_t)i * n, n * sizeof(float));
+  }
+}
+
+/* the real thing on one pre-cut block; returns packet bytes (or <0) */
+long ref_real_block(ref_enc *e, const float *pcm, int lW, int W, int nW, int blocktype,
+                    float ampmax_in, unsigned char *pkt, long cap, float *ampmax_out) {
+  ogg_packet op;
+  int ret;
+  load_block(e, pcm, lW, W, nW, blocktype, ampmax_in);
+  ret = vorbis_analysis(&e->vb, &op);
+  if (ret) return ret;
+  if (ampmax_out) *ampmax_out = ((vorbis_block_internal *)e->vb.internal)->ampmax;
+  if (pkt) {
+    if (op.bytes > cap) return -1;
+    memcpy(pkt, op.packet, op.bytes);
+  }
+  return op.bytes;
+}
+
+/* mapping0_forward restated over the reference's extern functions, VBR branch only */
+static int tap_core(ref_enc *e, const float *pcm, int lW, int W, int nW, int blocktype,
+                    float ampmax_in, ref_taps *t, int with_residue) {
+  vorbis_block *vb = &e->vb;
+  vorbis_info *vi = &e->vi;
+  codec_setup_info *ci = (codec_setup_info *)vi->codec_setup;
+  private_state *b = (private_state *)e->vd.backend_state;
+  vorbis_block_internal *vbi = (vorbis_block_internal *)vb->internal;
+  int ch = vi->channels, n = (int)ci->blocksizes[W], n2 = n / 2;
+  int i, j, k = PACKETBLOBS / 2;
+  vorbis_info_mapping0 *info = (vorbis_info_mapping0 *)ci->map_param[W];
+  vorbis_look_psy *psy_look = b->psy + blocktype + (W ? 2 : 0);
+  float global_ampmax = ampmax_in;
+  float local_ampmax[8];
+  int nonzero[8];
+  float *gmdct[8];
+  int *iwork[8];
+  int *posts[8];
+  float *noise, *tone;
+  oggpack_buffer *opb;
+
+  if (vorbis_bitrate_managed(vb) || ch > 8) return OV_EIMPL;
+
+  load_block(e, pcm, lW, W, nW, blocktype, ampmax_in);
+  for (i = 0; i < PACKETBLOBS; i++) oggpack_reset(vbi->packetblob[i]);
+  vb->mode = W;
+  opb = vbi->packetblob[k];
+
+  for (i = 0; i < ch; i++) {
+    float scale = 4.f / n;
+    float scale_dB;
+    float *p = vb->pcm[i];
+    float *logfft = p;
+    iwork[i] = (int *)_vorbis_block_alloc(vb, n2 * sizeof(int));
+    gmdct[i] = (float *)_vorbis_block_alloc(vb, n2 * sizeof(float));
+    scale_dB = todB(&scale) + .345;
+    _vorbis_apply_window(p, b->window, ci->blocksizes, lW, W, nW);
+    if (t->windowed) memcpy(t->windowed + (size_t)i * n, p, n * sizeof(float));
+    mdct_forward((mdct_lookup *)b->transform[W][0], p, gmdct[i]);
+    if (t->mdct_raw) memcpy(t->mdct_raw + (size_t)i * n2, gmdct[i], n2 * sizeof(float));
+    drft_forward(&b->fft_look[W], p);
+    if (t->fft_packed) memcpy(t->fft_packed + (size_t)i * n, p, n * sizeof(float));
+    logfft[0] = scale_dB + todB(p) + .345;
+    local_ampmax[i] = logfft[0];
+    for (j = 1; j < n - 1; j += 2) {
+      float temp = p[j] * p[j] + p[j + 1] * p[j + 1];
+      temp = logfft[(j + 1) >> 1] = scale_dB + .5f * todB(&temp) + .345;
+      if (temp > local_ampmax[i]) local_ampmax[i] = temp;
+    }
+    if (local_ampmax[i] > 0.f) local_ampmax[i] = 0.f;
+    if (local_ampmax[i] > global_ampmax) global_ampmax = local_ampmax[i];
+    if (t->logfft) memcpy(t->logfft + (size_t)i * n2, logfft, n2 * sizeof(float));
+    if (t->local_ampmax) t->local_ampmax[i] = local_ampmax[i];
+  }
+
+  noise = (float *)_vorbis_block_alloc(vb, n2 * sizeof(float));
+  tone = (float *)_vorbis_block_alloc(vb, n2 * sizeof(float));
+  for (i = 0; i < ch; i++) {
+    int submap = info->chmuxlist[i];
+    float *mdct = gmdct[i];
+    float *logfft = vb->pcm[i];
+    float *logmdct = logfft + n2;
+    float *logmask = logfft;
+    for (j = 0; j < n2; j++) logmdct[j] = todB(mdct + j) + .345;
+    if (t->logmdct) memcpy(t->logmdct + (size_t)i * n2, logmdct, n2 * sizeof(float));
+    _vp_noisemask(psy_look, logmdct, noise);
+    if (t->noise) memcpy(t->noise + (size_t)i * n2, noise, n2 * sizeof(float));
+    _vp_tonemask(psy_look, logfft, tone, global_ampmax, local_ampmax[i]);
+    if (t->tone) memcpy(t->tone + (size_t)i * n2, tone, n2 * sizeof(float));
+    _vp_offset_and_mix(psy_look, noise, tone, 1, logmask, mdct, logmdct);
+    if (t->logmask) memcpy(t->logmask + (size_t)i * n2, logmask, n2 * sizeof(float));
+    if (t->mdct) memcpy(t->mdct + (size_t)i * n2, mdct, n2 * sizeof(float));
+    if (ci->floor_type[info->floorsubmap[submap]] != 1) return -1;
+    posts[i] = floor1_fit(vb, (vorbis_look_floor1 *)b->flr[info->floorsubmap[submap]], logmdct, logmask);
+    if (t->post_valid) t->post_valid[i] = posts[i] ? 1 : 0;
+    if (t->posts) {
+      int np = ((vorbis_look_floor1 *)b->flr[info->floorsubmap[submap]])->posts;
+      memset(t->posts + (size_t)i * 65, 0, 65 * sizeof(int));
+      if (posts[i]) memcpy(t->posts + (size_t)i * 65, posts[i], np * sizeof(int));
+    }
+  }
+  vbi->ampmax = global_ampmax;
+  if (t->ampmax_out) *t->ampmax_out = global_ampmax;
+
+  oggpack_write(opb, 0, 1);
+  oggpack_write(opb, W, b->modebits);
+  if (W) {
+    oggpack_write(opb, lW, 1);
+    oggpack_write(opb, nW, 1);
+  }
+  for (i = 0; i < ch; i++) {
+    int submap = info->chmuxlist[i];
+    nonzero[i] = floor1_encode(opb, vb, (vorbis_look_floor1 *)b->flr[info->floorsubmap[submap]],
+                               posts[i], iwork[i]);
+    if (t->ilogmask) memcpy(t->ilogmask + (size_t)i * n2, iwork[i], n2 * sizeof(int));
+  }
+  _vp_couple_quantize_normalize(k, &ci->psy_g_param, psy_look, info, gmdct, iwork, nonzero,
+                                ci->psy_g_param.sliding_lowpass[W][k], ch);
+  for (i = 0; i < ch; i++) {
+    if (t->iwork) memcpy(t->iwork + (size_t)i * n2, iwork[i], n2 * sizeof(int));
+    if (t->nonzero) t->nonzero[i] = nonzero[i];
+  }
+  if (with_residue) {
+    int **couple_bundle = (int **)alloca(sizeof(*couple_bundle) * ch);
+    int *zerobundle = (int *)alloca(sizeof(*zerobundle) * ch);
+    for (i = 0; i < info->submaps; i++) {
+      int ch_in_bundle = 0;
+      long **classifications;
+      int resnum = info->residuesubmap[i];
+      for (j = 0; j < ch; j++)
+        if (info->chmuxlist[j] == i) {
+          zerobundle[ch_in_bundle] = nonzero[j] ? 1 : 0;
+          couple_bundle[ch_in_bundle++] = iwork[j];
+        }
+      classifications = _residue_P[ci->residue_type[resnum]]->class(vb, b->residue[resnum], couple_bundle,
+                                                                   zerobundle, ch_in_bundle);
+      ch_in_bundle = 0;
+      for (j = 0; j < ch; j++)
+        if (info->chmuxlist[j] == i) couple_bundle[ch_in_bundle++] = iwork[j];
+      _residue_P[ci->residue_type[resnum]]->forward(opb, vb, b->residue[resnum], couple_bundle, zerobundle,
+                                                     ch_in_bundle, classifications, i);
+    }
+  }
+  t->packet_bytes = oggpack_bytes(opb);
+  if (t->packet && t->packet_cap >= t->packet_bytes)
+    memcpy(t->packet, oggpack_get_buffer(opb), t->packet_bytes);
+  return 0;
+}
+
+int ref_tap_block(ref_enc *e, const float *pcm, int lW, int W, int nW, int blocktype,
+                  float ampmax_in, ref_taps *t) {
+  /* run the real analysis first so its packet can be compared */
+  unsigned char *realpkt = (unsigned char *)malloc(1 << 17);
+  float real_ampmax = 0.f, tap_ampmax = 0.f;
+  float *user_ampmax = t->ampmax_out;
+  long realbytes = ref_real_block(e, pcm, lW, W, nW, blocktype, ampmax_in, realpkt, 1 << 17, &real_ampmax);
+  int ret;
+  if (realbytes < 0) { free(realpkt); return (int)realbytes; }
+  t->ampmax_out = &tap_ampmax;
+  ret = tap_core(e, pcm, lW, W, nW, blocktype, ampmax_in, t, 1);
+  t->ampmax_out = user_ampmax;
+  if (user_ampmax) *user_ampmax = tap_ampmax;
+  if (ret == 0) {
+    vorbis_block_internal *vbi = (vorbis_block_internal *)e->vb.internal;
+    oggpack_buffer *opb = vbi->packetblob[PACKETBLOBS / 2];
+    t->packet_matches_real = (t->packet_bytes == realbytes && real_ampmax == tap_ampmax &&
+                              memcmp(oggpack_get_buffer(opb), realpkt, realbytes) == 0);
+  }
+  free(realpkt);
+  return ret;
+}
+
+/* ---- the application loop ------------------------------------------------- */
+
+typedef struct ref_block_rec {
+  int lW, W, nW, blocktype;
+  float ampmax_in, ampmax_out;
+  long pcm_offset;     /* offset (floats) of this block's [ch][n] PCM in pcm_out */
+  long packet_offset;  /* offset of this block's packet in packets_out */
+  long packet_bytes;
+} ref_block_rec;
+
+/* Feed planar PCM pcm[ch][frames] in 1024-frame chunks through
+ * vorbis_analysis_buffer/_wrote/_blockout/vorbis_analysis exactly as
+ * examples/encoder_example.c:179-236 does; record each block.  Returns the
+ * number of blocks (may exceed max_blocks: then only the first max_blocks are
+ * recorded), or <0 on error.  The encoder state is consumed: open a fresh
+ * ref_enc per stream. */
+long ref_encode_stream(ref_enc *e, const float *pcm, long frames, ref_block_rec *recs, long max_blocks,
+                       float *pcm_out, long pcm_cap, unsigned char *packets_out, long packets_cap) {
+  vorbis_block vb;
+  long fed = 0, nblocks = 0, pcm_used = 0, pkt_used = 0;
+  int ch = e->channels, eos = 0, i;
+  vorbis_block_init(&e->vd, &vb);
+  while (!eos) {
+    long chunk = frames - fed;
+    if (chunk > 1024) chunk = 1024;
+    if (chunk > 0) {
+      float **buf = vorbis_analysis_buffer(&e->vd, 1024);
+      for (i = 0; i < ch; i++) memcpy(buf[i], pcm + (size_t)i * frames + fed, chunk * sizeof(float));
+      vorbis_analysis_wrote(&e->vd, (int)chunk);
+      fed += chunk;
+    } else {
+      vorbis_analysis_wrote(&e->vd, 0);
+    }
+    while (vorbis_analysis_blockout(&e->vd, &vb) == 1) {
+      ogg_packet op;
+      vorbis_block_internal *vbi = (vorbis_block_internal *)vb.internal;
+      int n = vb.pcmend;
+      float ampmax_in = vbi->ampmax;
+      int ret;
+      if (nblocks < max_blocks && recs) {
+        ref_block_rec *r = recs + nblocks;
+        r->lW = (int)vb.lW; r->W = (int)vb.W; r->nW = (int)vb.nW; r->blocktype = vbi->blocktype;
+        r->ampmax_in = ampmax_in;
+        r->pcm_offset = -1;
+        if (pcm_out && pcm_used + (long)ch * n <= pcm_cap) {
+          r->pcm_offset = pcm_used;
+          for (i = 0; i < ch; i++) memcpy(pcm_out + pcm_used + (size_t)i * n, vb.pcm[i], n * sizeof(float));
+          pcm_used += (long)ch * n;
+        }
+      }
+      ret = vorbis_analysis(&vb, &op);
+      if (ret) { vorbis_block_clear(&vb); return ret; }
+      if (nblocks < max_blocks && recs) {
+        ref_block_rec *r = recs + nblocks;
+        r->ampmax_out = vbi->ampmax;
+        r->packet_bytes = op.bytes;
+        r->packet_offset = -1;
+        if (packets_out && pkt_used + op.bytes <= packets_cap) {
+          r->packet_offset = pkt_used;
+          memcpy(packets_out + pkt_used, op.packet, op.bytes);
+          pkt_used += op.bytes;
+        }
+      }
+      nblocks++;
+      if (vb.eofflag) eos = 1;
+    }
+    if (chunk <= 0 && e->vd.eofflag == -1) eos = 1;
+    if (chunk <= 0 && !eos && e->vd.eofflag == 0) eos = 1; /* defensive: nothing more will come */
+  }
+  vorbis_block_clear(&vb);
+  return nblocks;
+}
+
+/* ---- CPU baseline timing ---------------------------------------------------- */
+
+/* Time `reps` passes of the real vorbis_analysis() over `nblocks` pre-cut
+ * blocks pcm[nblocks][ch][n] (all (lW,W,nW)=(1,1,1), LONG, ampmax_in=-9999 -- the C3/C4
+ * batch convention).  Returns seconds of wall-clock for the analysis calls. */
+double ref_time_analysis(ref_enc *e, const float *pcm, long nblocks, int reps) {
+  struct timespec t0, t1;
+  int n = ref_blocksize(e, 1), r;
+  long k;
+  ogg_packet op;
+  double total = 0.;
+  for (r = 0; r < reps; r++)
+    for (k = 0; k < nblocks; k++) {
+      load_block(e, pcm + (size_t)k * e->channels * n, 1, 1, 1, BLOCKTYPE_LONG, -9999.f);
+      clock_gettime(CLOCK_MONOTONIC, &t0);
+      vorbis_analysis(&e->vb, &op);
+      clock_gettime(CLOCK_MONOTONIC, &t1);
+      total += (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+    }
+  return total;
+}
+
+/* Time the DSP part only: the tap sequence up to and including
+ * _vp_couple_quantize_normalize (what the GPU path computes), skipping the
+ * residue VQ / Huffman bit-writing that stays on the host. */
+double ref_time_dsp(ref_enc *e, const float *pcm, long nblocks, int reps) {
+  struct timespec t0, t1;
+  int n = ref_blocksize(e, 1), r;
+  long k;
+  ref_taps t;
+  double total = 0.;
+  memset(&t, 0, sizeof(t));
+  for (r = 0; r < reps; r++)
+    for (k = 0; k < nblocks; k++) {
+      const float *blk = pcm + (size_t)k * e->channels * n;
+      clock_gettime(CLOCK_MONOTONIC, &t0);
+      tap_core(e, blk, 1, 1, 1, BLOCKTYPE_LONG, -9999.f, &t, 0);
+      clock_gettime(CLOCK_MONOTONIC, &t1);
+      total += (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+    }
+  return total;
+}
