@@ -1,0 +1,144 @@
+/* vorbis_amd.h -- C ABI of libvorbis_amd.so, the MI355X (gfx950) implementation of
+ * libvorbis' per-block encode analysis.
+ *
+ * Drop-in boundary: libvorbis reaches the analysis
+ * through vorbis_analysis() (reference lib/analysis.c:29-63) ->
+ * _mapping_P[0]->forward == mapping0_forward() (lib/mapping0.c:230-696).  The
+ * entry points below replace the numeric section of mapping0_forward
+ * (lib/mapping0.c:254-576 and the floor-render + couple/quantise half of
+ * :613-646); the host keeps blockout, the Huffman/VQ bit-writing and bitrate
+ * management.  INTEGRATION.md shows the patch a libvorbis maintainer applies.
+ *
+ * Conventions follow libvorbis: plain C types, caller-allocated outputs, int
+ * return codes with the OV_* values of include/vorbis/codec.h:221-235, no
+ * callbacks, no exceptions.  A vamd_ctx, like a vorbis_dsp_state, must not be
+ * used from two threads at once; distinct contexts are independent.
+ */
+#ifndef VORBIS_AMD_H
+#define VORBIS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "vamd_setup.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* return codes == libvorbis OV_* (include/vorbis/codec.h:221-235) */
+#define VAMD_OK        0
+#define VAMD_EFAULT   (-129) /* OV_EFAULT: HIP runtime failure; see vamd_last_error() */
+#define VAMD_EIMPL    (-130) /* OV_EIMPL: setup/feature outside the covered path */
+#define VAMD_EINVAL   (-131) /* OV_EINVAL: bad argument */
+#define VAMD_EVERSION (-134) /* OV_EVERSION: setup blob version mismatch */
+
+/* lib/codec_internal.h:23-26 */
+#define VAMD_BLOCKTYPE_IMPULSE    0
+#define VAMD_BLOCKTYPE_PADDING    1
+#define VAMD_BLOCKTYPE_TRANSITION 0
+#define VAMD_BLOCKTYPE_LONG       1
+
+#define VAMD_POSTS_STRIDE 32   /* ints per channel in the posts[] output (>= 29 posts at 44.1 kHz) */
+#define VAMD_AMPMAX_FLOOR (-9999.f) /* a fresh vorbis_block's ampmax, lib/block.c:86 */
+
+typedef struct vamd_ctx vamd_ctx;
+
+/* Replaces the table-building half of vorbis_analysis_init() for the GPU side
+ * (lib/block.c:296-311 -> _vds_shared_init :170-293): validates the setup blob
+ * produced by vamd_pack_setup() (integration/vamd_pack_setup.c), copies it to
+ * HBM on `device` and derives the static index tables the kernels use.
+ * `device` < 0 keeps the calling thread's current HIP device. */
+int vamd_create(vamd_ctx **ctx, const void *setup_blob, size_t blob_bytes, int device);
+
+/* Counterpart of vorbis_dsp_clear() (lib/block.c:340-388) for the GPU state. */
+void vamd_destroy(vamd_ctx *ctx);
+
+/* Text of the last failure on this context ("" if none). */
+const char *vamd_last_error(const vamd_ctx *ctx);
+
+/* All launches of this context go to `hip_stream` (a hipStream_t; NULL = the
+ * null stream).  The caller owns the stream. */
+int vamd_set_stream(vamd_ctx *ctx, void *hip_stream);
+
+/* Pre-size the internal HBM workspace for batches of up to `max_blocks` blocks
+ * of size class W so that no allocation happens inside a timed region. */
+int vamd_reserve(vamd_ctx *ctx, int W, long max_blocks);
+
+int vamd_channels(const vamd_ctx *ctx);
+int vamd_blocksize(const vamd_ctx *ctx, int W);
+int vamd_posts(const vamd_ctx *ctx, int W);
+
+/* ---- batched device API (all pointers are DEVICE pointers) ------------------
+ *
+ * One batch = `nblocks` blocks of the same size class W, block-major:
+ * pcm[nblocks][ch][n], every per-bin output [nblocks][ch][n/2].
+ */
+
+/* mdct_forward(lookup,in,out), reference lib/mdct.c:492-562, for `nframes`
+ * independent n-sample frames (no window applied; BASELINE config 2).
+ * in[nframes][n] -> out[nframes][n/2]. */
+int vamd_mdct_forward_batch(vamd_ctx *ctx, int W, const float *in, float *out, long nframes);
+
+/* Per-block descriptors.  The arrays (device, length nblocks) may be NULL, in
+ * which case the uniform_* value applies to every block. */
+typedef struct vamd_batch_desc {
+  int         W;                 /* size class of every block in the batch (vb->W) */
+  long        nblocks;
+  const int32_t *lW, *nW;        /* vb->lW, vb->nW (lib/block.c:593-595) */
+  const int32_t *blocktype;      /* vbi->blocktype (lib/block.c:597-615) */
+  const float   *ampmax_in;      /* vbi->ampmax on entry (lib/mapping0.c:244) */
+  int         uniform_lW, uniform_nW, uniform_blocktype;
+  float       uniform_ampmax_in;
+} vamd_batch_desc;
+
+/* Outputs; any pointer may be NULL (that tensor is then kept internal or not
+ * produced).  Names follow mapping0_forward's variables / its #if 0
+ * _analysis_output taps (lib/mapping0.c:279-657). */
+typedef struct vamd_batch_io {
+  const float *pcm;       /* in  [nb][ch][n]   vb->pcm, un-windowed; not modified */
+  float   *mdct_raw;      /* out [nb][ch][n/2] mdct_forward output (tap "mdct", pre-M1) */
+  float   *logfft;        /* out [nb][ch][n/2] (tap "fft") */
+  float   *logmdct;       /* out [nb][ch][n/2] (tap "mdct" in dB) */
+  float   *noise;         /* out [nb][ch][n/2] _vp_noisemask (tap "noise") */
+  float   *tone;          /* out [nb][ch][n/2] _vp_tonemask (tap "tone") */
+  float   *logmask;       /* out [nb][ch][n/2] _vp_offset_and_mix select 1 (tap "mask1") */
+  float   *mdct;          /* out [nb][ch][n/2] gmdct after AoTuV-M1: the spectrum that is quantised */
+  int32_t *posts;         /* out [nb][ch][VAMD_POSTS_STRIDE] floor1_fit result, bit 15 = unused flag */
+  int32_t *post_valid;    /* out [nb][ch] 0 where floor1_fit returns NULL (all-zero floor) */
+  int32_t *ilogmask;      /* out [nb][ch][n/2] integer floor curve of floor1_encode (tap "maskI") */
+  int32_t *iwork;         /* out [nb][ch][n/2] quantised, coupled residue (tap "res") */
+  int32_t *nonzero;       /* out [nb][ch] after _vp_couple_quantize_normalize's fix-up */
+  float   *local_ampmax;  /* out [nb][ch] */
+  float   *ampmax_out;    /* out [nb] vbi->ampmax on exit (lib/mapping0.c:576) */
+} vamd_batch_io;
+
+/* how far down mapping0_forward the batch runs */
+#define VAMD_LEVEL_TRANSFORM 1 /* window, MDCT, FFT, logfft/logmdct, local ampmax (lib/mapping0.c:254-360,384) */
+#define VAMD_LEVEL_PSY       2 /* + _vp_noisemask, _vp_tonemask (:417-440)           [BASELINE config 3] */
+#define VAMD_LEVEL_FULL      3 /* + offset_and_mix, floor1_fit, floor render, couple/quantise (:463-646) [config 4] */
+
+int vamd_analyze_batch(vamd_ctx *ctx, const vamd_batch_desc *desc, const vamd_batch_io *io, int level);
+
+/* A real stream: blocks in stream order whose ampmax chains from block to block
+ * (lib/block.c:626-628, lib/psy.c:837-848, lib/mapping0.c:244,346,576).  Same
+ * as vamd_analyze_batch(level FULL) except desc->ampmax_in is ignored: block 0
+ * starts from `ampmax_state` (host float, in/out: vorbis_look_psy_global.ampmax
+ * semantics) and block k+1 receives decay(ampmax_out[k]).  W of block k is
+ * desc->W (one size class per call); mixed streams are issued as consecutive
+ * calls per run of equal W. */
+int vamd_analyze_stream(vamd_ctx *ctx, const vamd_batch_desc *desc, const vamd_batch_io *io,
+                        float *ampmax_state);
+
+/* ---- per-block host API: the compatibility path behind vorbis_analysis() -----
+ * Host pointers.  pcm[ch] -> n samples each (vb->pcm); outputs sized as above for
+ * nblocks == 1.  Latency-bound by design (one launch sequence + two PCIe
+ * copies per block); throughput users batch. */
+int vamd_analyze_block(vamd_ctx *ctx, const float *const *pcm, int lW, int W, int nW, int blocktype,
+                       float ampmax_in, float *mdct /*[ch][n/2]*/, float *logmask /*[ch][n/2] or NULL*/,
+                       int32_t *posts /*[ch][VAMD_POSTS_STRIDE]*/, int32_t *post_valid /*[ch]*/,
+                       int32_t *iwork /*[ch][n/2]*/, int32_t *nonzero /*[ch]*/, float *ampmax_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VORBIS_AMD_H */

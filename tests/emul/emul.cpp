@@ -1,0 +1,123 @@
+// tests/emul/emul.cpp -- TEST BUILD ONLY: the kernel bodies of vorbis_amd/csrc
+// (k_*.h) compiled by the host C++ compiler with LANE=0 / NLANES=1
+// (vamd_wave.h), so that every stage's arithmetic can be checked bit-for-bit
+// against the reference on a machine without a GPU.  Nothing in the product
+// links or loads this file; the product fails loudly without its HIP library.
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "vamd_bind.h"
+#include "k_transform.h"
+#include "k_noise.h"
+#include "k_tone.h"
+#include "k_floor.h"
+#include "k_couple.h"
+
+using namespace vamd;
+
+struct Emul {
+  std::vector<unsigned char> image;
+  std::vector<uint32_t> doff;
+  std::vector<PsyDerived> derived;
+  Bound B;
+  std::string err;
+};
+
+struct EmulTaps {  // arrays [ch][...], any may be null
+  float *mdct_raw, *logfft, *logmdct, *noise, *tone, *logmask, *mdct;
+  int *posts, *post_valid, *ilogmask, *iwork, *nonzero;
+  float *local_ampmax, *ampmax_out;
+};
+
+extern "C" {
+
+void *emul_open(const void *blob, size_t bytes) {
+  Emul *e = new Emul;
+  if (build_image(blob, bytes, &e->image, &e->doff, &e->derived, &e->err) != VAMD_OK) {
+    delete e;
+    return nullptr;
+  }
+  bind_params(e->image, e->doff, e->derived, e->image.data(), &e->B);
+  return e;
+}
+void emul_close(void *h) { delete (Emul *)h; }
+
+int emul_mdct_forward(void *h, int W, const float *in, float *out) {
+  Emul *e = (Emul *)h;
+  const XformP &P = e->B.xf[W];
+  std::vector<float> A(P.n), Bw(P.n);
+  load_windowed(P, W, 1, 1, in, A.data(), false);
+  mdct_forward_wave(P, A.data(), Bw.data(), Bw.data() + P.n / 2);
+  memcpy(out, Bw.data() + P.n / 2, sizeof(float) * (P.n / 2));
+  return 0;
+}
+
+int emul_analyze_block(void *h, const float *pcm, int lW, int W, int nW, int blocktype, float ampmax_in,
+                       EmulTaps *t) {
+  Emul *e = (Emul *)h;
+  const Bound &B = e->B;
+  const int ch = B.channels, n = B.bs[W], n2 = n / 2;
+  const XformP &X = B.xf[W];
+  const PsyP &P = B.psy[blocktype + (W ? 2 : 0)];
+  const FloorP &F = B.floor[W];
+  const CoupleP &C = B.couple[W];
+  std::vector<float> A(n), Bw(n);
+  std::vector<float> mdct_raw(ch * n2), logfft(ch * n2), logmdct(ch * n2), noise(ch * n2), tone(ch * n2),
+      logmask(ch * n2), mdct(ch * n2), lmd(n2), mask(n2);
+  std::vector<int> posts(ch * VAMD_POSTS_STRIDE), post_valid(ch), ilogmask(ch * n2), iwork(ch * n2), nonzero(ch);
+  std::vector<float> local(ch);
+  float global = ampmax_in;
+  for (int i = 0; i < ch; i++) {
+    local[i] = transform_block(X, W, lW, nW, pcm + (size_t)i * n, A.data(), Bw.data(), &mdct_raw[i * n2],
+                               &logmdct[i * n2], &logfft[i * n2]);
+    if (local[i] > global) global = local[i];
+  }
+  {
+    std::vector<float> S(5 * n2), nz(n2), wk(n2), seed(P.total_octave_lines), ampstack(P.total_octave_lines),
+        flr(n2);
+    std::vector<int> posstack(P.total_octave_lines);
+    FloorScratch sc;
+    for (int i = 0; i < ch; i++) {
+      noisemask_block(P, &logmdct[i * n2], &noise[i * n2], S.data(), nz.data(), wk.data());
+      tonemask_block(P, &logfft[i * n2], &tone[i * n2], global, local[i], seed.data(), posstack.data(),
+                     ampstack.data(), flr.data());
+      offset_and_mix_wave(P, &noise[i * n2], &tone[i * n2], &logmdct[i * n2], &mdct_raw[i * n2], &mdct[i * n2],
+                          mask.data(), lmd.data());
+      memcpy(&logmask[i * n2], mask.data(), sizeof(float) * n2);
+      nonzero[i] = floor_fit_render_block(F, n2, mask.data(), lmd.data(), &sc, &posts[i * VAMD_POSTS_STRIDE],
+                                          &post_valid[i], &ilogmask[i * n2]);
+    }
+  }
+  {
+    std::vector<float> cand(n2), key(n2), sgn(n2);
+    CoupleLds L = {cand.data(), key.data(), sgn.data()};
+    const float *mp[VAMD_MAX_CH];
+    const int *ip[VAMD_MAX_CH];
+    int *op[VAMD_MAX_CH];
+    for (int i = 0; i < ch; i++) {
+      mp[i] = &mdct[i * n2];
+      ip[i] = &ilogmask[i * n2];
+      op[i] = &iwork[i * n2];
+    }
+    couple_block(C, P, n2, mp, ip, op, nonzero.data(), L);
+  }
+#define OUT(name, vec, type) \
+  if (t->name) memcpy(t->name, vec.data(), sizeof(type) * vec.size())
+  OUT(mdct_raw, mdct_raw, float);
+  OUT(logfft, logfft, float);
+  OUT(logmdct, logmdct, float);
+  OUT(noise, noise, float);
+  OUT(tone, tone, float);
+  OUT(logmask, logmask, float);
+  OUT(mdct, mdct, float);
+  OUT(posts, posts, int);
+  OUT(post_valid, post_valid, int);
+  OUT(ilogmask, ilogmask, int);
+  OUT(iwork, iwork, int);
+  OUT(nonzero, nonzero, int);
+  OUT(local_ampmax, local, float);
+  if (t->ampmax_out) *t->ampmax_out = global;
+  return 0;
+}
+}

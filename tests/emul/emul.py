@@ -1,0 +1,78 @@
+"""ctypes wrapper of tests/emul/libvamd_emul.so (host-compiled kernel bodies; test build only)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(os.path.dirname(_HERE))
+LIB = os.path.join(_HERE, "libvamd_emul.so")
+_f32p = C.POINTER(C.c_float)
+_i32p = C.POINTER(C.c_int)
+
+POSTS_STRIDE = 32
+
+
+class _Taps(C.Structure):
+    _fields_ = [(k, _f32p) for k in ("mdct_raw", "logfft", "logmdct", "noise", "tone", "logmask", "mdct")] + \
+               [(k, _i32p) for k in ("posts", "post_valid", "ilogmask", "iwork", "nonzero")] + \
+               [("local_ampmax", _f32p), ("ampmax_out", _f32p)]
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, "emul.cpp")] + [os.path.join(_ROOT, "vorbis_amd", "csrc", f)
+                                                 for f in os.listdir(os.path.join(_ROOT, "vorbis_amd", "csrc"))
+                                                 if f.endswith(".h")] + \
+           [os.path.join(_ROOT, "include", f) for f in os.listdir(os.path.join(_ROOT, "include"))]
+    if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(s) for s in srcs):
+        return LIB
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wno-unknown-pragmas",
+           "-I" + os.path.join(_ROOT, "include"), "-I" + os.path.join(_ROOT, "vorbis_amd", "csrc"),
+           "-shared", "-o", LIB, os.path.join(_HERE, "emul.cpp")]
+    subprocess.check_call(cmd)
+    return LIB
+
+
+class Emul:
+    def __init__(self, blob):
+        self.L = C.CDLL(build())
+        self.L.emul_open.restype = C.c_void_p
+        self.L.emul_open.argtypes = [C.c_void_p, C.c_size_t]
+        self.L.emul_close.argtypes = [C.c_void_p]
+        self.L.emul_mdct_forward.argtypes = [C.c_void_p, C.c_int, _f32p, _f32p]
+        self.L.emul_analyze_block.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                              C.POINTER(_Taps)]
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        self.h = self.L.emul_open(blob.ctypes.data_as(C.c_void_p), blob.size)
+        if not self.h:
+            raise RuntimeError("emul_open failed")
+        hdr = np.frombuffer(blob.tobytes()[:40], dtype=np.int32)
+        self.channels, self.bs = int(hdr[4]), (int(hdr[6]), int(hdr[7]))
+
+    def mdct_forward(self, W, x):
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.empty(x.size // 2, np.float32)
+        self.L.emul_mdct_forward(self.h, W, x.ctypes.data_as(_f32p), out.ctypes.data_as(_f32p))
+        return out
+
+    def analyze_block(self, pcm, lW=1, W=1, nW=1, blocktype=1, ampmax_in=-9999.0):
+        ch, n = self.channels, self.bs[W]
+        n2 = n // 2
+        pcm = np.ascontiguousarray(pcm, np.float32)
+        assert pcm.shape == (ch, n)
+        o = {k: np.zeros((ch, n2), np.float32) for k in ("mdct_raw", "logfft", "logmdct", "noise", "tone", "logmask", "mdct")}
+        o["posts"] = np.zeros((ch, POSTS_STRIDE), np.int32)
+        o["post_valid"] = np.zeros(ch, np.int32)
+        o["ilogmask"] = np.zeros((ch, n2), np.int32)
+        o["iwork"] = np.zeros((ch, n2), np.int32)
+        o["nonzero"] = np.zeros(ch, np.int32)
+        o["local_ampmax"] = np.zeros(ch, np.float32)
+        o["ampmax_out"] = np.zeros(1, np.float32)
+        t = _Taps()
+        for k, v in o.items():
+            setattr(t, k, v.ctypes.data_as(_f32p if v.dtype == np.float32 else _i32p))
+        r = self.L.emul_analyze_block(self.h, pcm.ctypes.data_as(_f32p), lW, W, nW, blocktype, ampmax_in, C.byref(t))
+        assert r == 0
+        o["ampmax_out"] = float(o["ampmax_out"][0])
+        return o

@@ -1,0 +1,360 @@
+// k_floor.h -- _vp_offset_and_mix (reference lib/psy.c:779-835), floor1_fit
+// (lib/floor1.c:576-729) and the post-quantise + render_line0 half of
+// floor1_encode (lib/floor1.c:766-831,923-946); SURVEY.md 8a rows a11-a13.  One
+// wavefront per channel-block.
+//
+// Parallel form: the mix is per bin.  accumulate_fit's integer sums take one
+// lane per post interval.  The greedy split loop is inherently ordered (each
+// decision moves the neighbours of later posts); every lane runs it uniformly
+// with the small state in LDS, while inspect_error -- the only part that
+// touches O(n) bins -- is evaluated by all 64 lanes at once: the Bresenham line
+// has the closed form y(x) = y0 + k*base + sgn*floor(k*ady'/adx), the squared
+// error is an integer wave sum and the early-outs are an any().  fit_line's
+// fp64 sums run in the reference's term order on every lane.
+//
+// LDS: mask[n], lmd[n] (logmask / logmdct), FloorScratch.
+#pragma once
+#include "vamd_wave.h"
+#include "vamd_params.h"
+
+namespace vamd {
+
+#define VAMD_MAXPOSTS 32
+
+struct FitAcc {  // lsfit_acc, lib/floor1.c:32-49 (x0/x1 come from sorted_index)
+  int xa, ya, x2a, y2a, xya, an;
+  int xb, yb, x2b, y2b, xyb, bn;
+};
+
+struct FloorScratch {
+  FitAcc acc[VAMD_MAXPOSTS];
+  int fitA[VAMD_MAXPOSTS], fitB[VAMD_MAXPOSTS];
+  int lon[VAMD_MAXPOSTS], hin[VAMD_MAXPOSTS], memo[VAMD_MAXPOSTS];
+  int out[VAMD_MAXPOSTS];   // floor1_fit's result
+  int post[VAMD_MAXPOSTS];  // floor1_encode's mutated copy
+  int segx[VAMD_MAXPOSTS + 1], segy[VAMD_MAXPOSTS + 1];
+  int nseg;
+  int nonzero;
+};
+
+// _vp_offset_and_mix with offset_select == 1 (the only select the VBR path uses)
+VAMD_DEV void offset_and_mix_wave(const PsyP &P, const float *__restrict__ noise, const float *__restrict__ tone,
+                                  const float *__restrict__ logmdct_in, float *__restrict__ mdct_io_src,
+                                  float *__restrict__ mdct_out, float *mask, float *lmd) {
+  const int n = P.n;
+  const float toneatt = P.tone_masteratt1;
+  const float cx = P.m_val;
+  const float coeffi = -17.2f;  // float coeffi = -17.2 (lib/psy.c:808)
+  WAVE_FOR(i, n) {
+    float val = noise[i] + P.noiseoffset1[i];
+    if (val > P.noisemaxsupp) val = P.noisemaxsupp;
+    const float t = tone[i] + toneatt;
+    mask[i] = (val < t) ? t : val;  // max(val, tone+toneatt), lib/psy.c:795 with os.h:78 max()
+    const float lm = logmdct_in[i];
+    lmd[i] = lm;
+    // AoTuV M1, lib/psy.c:807-832: double-promoted by the 1.0 / 0.005 / 0.0003 literals
+    val = val - lm;
+    float de;
+    if (val > coeffi) {
+      de = (float)(1.0 - ((double)(val - coeffi) * 0.005 * (double)cx));
+      if (de < 0) de = 0.0001f;
+    } else {
+      de = (float)(1.0 - ((double)(val - coeffi) * 0.0003 * (double)cx));
+    }
+    mdct_out[i] = mdct_io_src[i] * de;
+  }
+  WAVE_SYNC();
+}
+
+// accumulate_fit, lib/floor1.c:406-454, interval [x0, x1] inclusive
+VAMD_DEV int accumulate_fit_one(const float *flr, const float *mdct, int x0, int x1, FitAcc *a, int n,
+                                float twofitatten) {
+  int xa = 0, ya = 0, x2a = 0, y2a = 0, xya = 0, na = 0, xb = 0, yb = 0, x2b = 0, y2b = 0, xyb = 0, nb = 0;
+  if (x1 >= n) x1 = n - 1;
+  for (int i = x0; i <= x1; i++) {
+    const int q = dBquant(flr[i]);
+    if (q) {
+      if (mdct[i] + twofitatten >= flr[i]) {
+        xa += i; ya += q; x2a += i * i; y2a += q * q; xya += i * q; na++;
+      } else {
+        xb += i; yb += q; x2b += i * i; y2b += q * q; xyb += i * q; nb++;
+      }
+    }
+  }
+  a->xa = xa; a->ya = ya; a->x2a = x2a; a->y2a = y2a; a->xya = xya; a->an = na;
+  a->xb = xb; a->yb = yb; a->x2b = x2b; a->y2b = y2b; a->xyb = xyb; a->bn = nb;
+  return na;
+}
+
+// fit_line, lib/floor1.c:456-514.  a[0..fits) are consecutive intervals whose
+// outer x range is [x0, x1] (sorted_index of the first / one past the last).
+VAMD_DEV int fit_line(const FitAcc *a, int fits, int x0, int x1, int *y0, int *y1, float twofitweight) {
+  double xb = 0, yb = 0, x2b = 0, y2b = 0, xyb = 0, bn = 0;
+  for (int i = 0; i < fits; i++) {
+    const double weight = (double)((float)(a[i].bn + a[i].an) * twofitweight / (float)(a[i].an + 1)) + 1.;
+    xb += a[i].xb + a[i].xa * weight;
+    yb += a[i].yb + a[i].ya * weight;
+    x2b += a[i].x2b + a[i].x2a * weight;
+    y2b += a[i].y2b + a[i].y2a * weight;
+    xyb += a[i].xyb + a[i].xya * weight;
+    bn += a[i].bn + a[i].an * weight;
+  }
+  if (*y0 >= 0) {
+    xb += x0; yb += *y0; x2b += x0 * x0; y2b += *y0 * *y0; xyb += *y0 * x0; bn++;
+  }
+  if (*y1 >= 0) {
+    xb += x1; yb += *y1; x2b += x1 * x1; y2b += *y1 * *y1; xyb += *y1 * x1; bn++;
+  }
+  (void)y2b;
+  const double denom = (bn * x2b - xb * xb);
+  if (denom > 0.) {
+    const double aa = (yb * x2b - xyb * xb) / denom;
+    const double bb = (bn * xyb - xb * yb) / denom;
+    *y0 = (int)rint(aa + bb * x0);
+    *y1 = (int)rint(aa + bb * x1);
+    if (*y0 > 1023) *y0 = 1023;
+    if (*y1 > 1023) *y1 = 1023;
+    if (*y0 < 0) *y0 = 0;
+    if (*y1 < 0) *y1 = 0;
+    return 0;
+  }
+  *y0 = 0;
+  *y1 = 0;
+  return 1;
+}
+
+struct LineStep {  // Bresenham constants shared by inspect_error / render_line0
+  int base, sgn, ady, adx;
+};
+VAMD_DEV LineStep line_step(int x0, int x1, int y0, int y1) {
+  LineStep s;
+  const int dy = y1 - y0;
+  s.adx = x1 - x0;
+  int ady = dy < 0 ? -dy : dy;
+  s.base = dy / s.adx;
+  s.sgn = dy < 0 ? -1 : 1;  // sy - base
+  const int bb = s.base * s.adx;
+  s.ady = ady - (bb < 0 ? -bb : bb);
+  return s;
+}
+VAMD_DEV int line_y(const LineStep &s, int y0, int k) { return y0 + k * s.base + s.sgn * ((k * s.ady) / s.adx); }
+
+// inspect_error, lib/floor1.c:516-565, wave-parallel over x in [x0, x1)
+VAMD_DEV int inspect_error_wave(int x0, int x1, int y0, int y1, const float *mask, const float *mdct,
+                                const FloorP &F) {
+  const LineStep s = line_step(x0, x1, y0, y1);
+  const int cnt = (x1 - x0) > 1 ? (x1 - x0) : 1;  // points visited: x0, then x0+1 .. x1-1
+  int mse = 0, bad = 0;
+  WAVE_FOR(k, cnt) {
+    const int x = x0 + k;
+    const int y = line_y(s, y0, k);
+    const int val = dBquant(mask[x]);
+    mse += (y - val) * (y - val);
+    if (mdct[x] + F.twofitatten >= mask[x]) {
+      if (k == 0 || val) {  // the first point is checked even when val == 0 (lib/floor1.c:536-539)
+        if ((float)y + F.maxover < (float)val) bad = 1;
+        if ((float)y - F.maxunder > (float)val) bad = 1;
+      }
+    }
+  }
+  if (wave_any(bad)) return 1;
+  mse = wave_sum(mse);
+  if (F.maxover * F.maxover / (float)cnt > F.maxerr) return 0;
+  if (F.maxunder * F.maxunder / (float)cnt > F.maxerr) return 0;
+  if ((float)(mse / cnt) > F.maxerr) return 1;
+  return 0;
+}
+
+VAMD_DEV int post_Y(const int *A, const int *B, int pos) {
+  if (A[pos] < 0) return B[pos];
+  if (B[pos] < 0) return A[pos];
+  return (A[pos] + B[pos]) >> 1;
+}
+
+// render_point, lib/floor1.c:257-271
+VAMD_DEV int render_point(int x0, int x1, int y0, int y1, int x) {
+  y0 &= 0x7fff;
+  y1 &= 0x7fff;
+  const int dy = y1 - y0, adx = x1 - x0;
+  const int ady = dy < 0 ? -dy : dy;
+  const int off = ady * (x - x0) / adx;
+  return dy < 0 ? y0 - off : y0 + off;
+}
+
+// floor1_fit + the curve half of floor1_encode for one channel-block.
+//   mask/lmd  LDS [n2]   logmask, logmdct
+//   posts_out HBM [VAMD_POSTS_STRIDE] floor1_fit's return (untouched by encode)
+//   ilogmask  HBM [n2]
+// Returns floor1_encode's nonzero flag (1 = non-trivial floor).
+VAMD_DEV int floor_fit_render_block(const FloorP &F, int n2, const float *mask, const float *lmd,
+                                    FloorScratch *sc, int *__restrict__ posts_out, int *__restrict__ post_valid,
+                                    int *__restrict__ ilogmask) {
+  const int posts = F.posts, n = F.look_n;
+
+  WAVE_FOR(i, posts) {
+    sc->fitA[i] = -200;
+    sc->fitB[i] = -200;
+    sc->lon[i] = 0;
+    sc->hin[i] = 1;
+    sc->memo[i] = -1;
+  }
+  // one lane per post interval
+  int nz = 0;
+  WAVE_FOR(i, posts - 1)
+    nz += accumulate_fit_one(mask, lmd, F.sorted_index[i], F.sorted_index[i + 1], &sc->acc[i], n, F.twofitatten);
+  nz = wave_sum(nz);
+  WAVE_SYNC();
+
+  if (!nz) {
+    // floor1_fit returns NULL; floor1_encode writes a zero curve (lib/floor1.c:948-952)
+    WAVE_FOR(i, VAMD_POSTS_STRIDE) if (posts_out) posts_out[i] = 0;
+    if (post_valid && LANE == 0) *post_valid = 0;
+    WAVE_FOR(i, n2) if (ilogmask) ilogmask[i] = 0;
+    WAVE_SYNC();
+    return 0;
+  }
+
+  // ---- greedy progressive split, lib/floor1.c:610-698.  Uniform across lanes;
+  // every lane performs identical LDS updates, so no exchange is needed.
+  {
+    int y0 = -200, y1 = -200;
+    fit_line(sc->acc, posts - 1, F.sorted_index[0], F.sorted_index[posts - 1], &y0, &y1, F.twofitweight);
+    sc->fitA[0] = y0;
+    sc->fitB[0] = y0;
+    sc->fitB[1] = y1;
+    sc->fitA[1] = y1;
+  }
+  for (int i = 2; i < posts; i++) {
+    const int sortpos = F.reverse_index[i];
+    const int ln = sc->lon[sortpos];
+    const int hn = sc->hin[sortpos];
+    if (sc->memo[ln] != hn) {
+      const int lsortpos = F.reverse_index[ln];
+      const int hsortpos = F.reverse_index[hn];
+      sc->memo[ln] = hn;
+      const int lx = F.postlist[ln], hx = F.postlist[hn];
+      const int ly = post_Y(sc->fitA, sc->fitB, ln);
+      const int hy = post_Y(sc->fitA, sc->fitB, hn);
+      // (ly == -1 || hy == -1 => exit(1) in the reference: unreachable, fits are >= 0 or -200)
+      if (inspect_error_wave(lx, hx, ly, hy, mask, lmd, F)) {
+        int ly0 = -200, ly1 = -200, hy0 = -200, hy1 = -200;
+        const int ret0 = fit_line(sc->acc + lsortpos, sortpos - lsortpos, F.sorted_index[lsortpos],
+                                  F.sorted_index[sortpos], &ly0, &ly1, F.twofitweight);
+        const int ret1 = fit_line(sc->acc + sortpos, hsortpos - sortpos, F.sorted_index[sortpos],
+                                  F.sorted_index[hsortpos], &hy0, &hy1, F.twofitweight);
+        if (ret0) {
+          ly0 = ly;
+          ly1 = hy0;
+        }
+        if (ret1) {
+          hy0 = ly1;
+          hy1 = hy;
+        }
+        if (ret0 && ret1) {
+          sc->fitA[i] = -200;
+          sc->fitB[i] = -200;
+        } else {
+          sc->fitB[ln] = ly0;
+          if (ln == 0) sc->fitA[ln] = ly0;
+          sc->fitA[i] = ly1;
+          sc->fitB[i] = hy0;
+          sc->fitA[hn] = hy1;
+          if (hn == 1) sc->fitB[hn] = hy1;
+          if (ly1 >= 0 || hy0 >= 0) {
+            for (int j = sortpos - 1; j >= 0; j--)
+              if (sc->hin[j] == hn)
+                sc->hin[j] = i;
+              else
+                break;
+            for (int j = sortpos + 1; j < posts; j++)
+              if (sc->lon[j] == ln)
+                sc->lon[j] = i;
+              else
+                break;
+          }
+        }
+      } else {
+        sc->fitA[i] = -200;
+        sc->fitB[i] = -200;
+      }
+    }
+  }
+
+  // ---- posts out, lib/floor1.c:700-724
+  sc->out[0] = post_Y(sc->fitA, sc->fitB, 0);
+  sc->out[1] = post_Y(sc->fitA, sc->fitB, 1);
+  for (int i = 2; i < posts; i++) {
+    const int ln = F.loneighbor[i - 2], hn = F.hineighbor[i - 2];
+    const int predicted =
+        render_point(F.postlist[ln], F.postlist[hn], sc->out[ln], sc->out[hn], F.postlist[i]);
+    const int vx = post_Y(sc->fitA, sc->fitB, i);
+    if (vx >= 0 && predicted != vx)
+      sc->out[i] = vx;
+    else
+      sc->out[i] = predicted | 0x8000;
+  }
+  WAVE_FOR(i, VAMD_POSTS_STRIDE) if (posts_out) posts_out[i] = i < posts ? sc->out[i] : 0;
+  if (post_valid && LANE == 0) *post_valid = 1;
+
+  // ---- floor1_encode, value half: quantise by mult, predict, settle the
+  // "unused" flags (lib/floor1.c:766-831).  The Huffman writes stay on the host.
+  for (int i = 0; i < posts; i++) {
+    int val = sc->out[i] & 0x7fff;
+    switch (F.mult) {
+      case 1: val >>= 2; break;
+      case 2: val >>= 3; break;
+      case 3: val /= 12; break;
+      case 4: val >>= 4; break;
+    }
+    sc->post[i] = val | (sc->out[i] & 0x8000);
+  }
+  for (int i = 2; i < posts; i++) {
+    const int ln = F.loneighbor[i - 2], hn = F.hineighbor[i - 2];
+    const int predicted =
+        render_point(F.postlist[ln], F.postlist[hn], sc->post[ln], sc->post[hn], F.postlist[i]);
+    if ((sc->post[i] & 0x8000) || (predicted == sc->post[i])) {
+      sc->post[i] = predicted | 0x8000;
+    } else {
+      sc->post[ln] &= 0x7fff;
+      sc->post[hn] &= 0x7fff;
+    }
+  }
+
+  // ---- render the integer curve, lib/floor1.c:923-946: segment list of the
+  // used posts in x order, then every bin evaluates its segment's line.
+  {
+    int ns = 0;
+    sc->segx[0] = 0;
+    sc->segy[0] = sc->post[0] * F.mult;
+    for (int j = 1; j < posts; j++) {
+      const int cur = F.forward_index[j];
+      const int hy = sc->post[cur] & 0x7fff;
+      if (hy == sc->post[cur]) {
+        ns++;
+        sc->segx[ns] = F.postlist[cur];
+        sc->segy[ns] = hy * F.mult;
+      }
+    }
+    sc->nseg = ns;
+  }
+  WAVE_SYNC();
+  if (ilogmask) {
+    const int ns = sc->nseg;
+    WAVE_FOR(x, n2) {
+      int v;
+      if (x >= sc->segx[ns]) {
+        v = sc->segy[ns];
+      } else {
+        int s = 0;
+        while (x >= sc->segx[s + 1]) s++;
+        const LineStep st = line_step(sc->segx[s], sc->segx[s + 1], sc->segy[s], sc->segy[s + 1]);
+        v = line_y(st, sc->segy[s], x - sc->segx[s]);
+      }
+      ilogmask[x] = v;
+    }
+  }
+  WAVE_SYNC();
+  return 1;
+}
+
+}  // namespace vamd

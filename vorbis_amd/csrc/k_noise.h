@@ -1,0 +1,149 @@
+// k_noise.h -- _vp_noisemask (reference lib/psy.c:706-752) with its two
+// bark_noise_hybridmp passes (lib/psy.c:547-704); SURVEY.md 8a row a9.  One
+// wavefront per channel-block.
+//
+// What is parallel and what is not: the per-bin terms y, w, w*x, w*x*x, w*y,
+// w*x*y and the windowed line evaluation are independent per bin and are spread
+// over the 64 lanes.  The five running sums N, X, XX, Y, XY are fp32
+// accumulations *in index order* in the reference; windowed differences of them
+// feed a division, so any re-association moves the answer by up to 5e-3
+// (SURVEY.md Appendix A).  They are therefore accumulated serially, one lane
+// per array, out of LDS -- five lanes busy for n steps.  The regime boundaries
+// of the window loops depend only on the static bark[] table and are
+// precomputed by vamd_create().
+//
+// LDS: S[5][n] running sums, nz[n] (noise curve), wk[n] (work).
+#pragma once
+#include "vamd_wave.h"
+#include "vamd_params.h"
+
+namespace vamd {
+
+struct LineFit {
+  float A, B, D;
+};
+
+// A, B, D of one windowed least-squares line, from (tN,tX,tXX,tY,tXY); the
+// expression order is the reference's (lib/psy.c:619-621)
+VAMD_DEV LineFit fit_from_sums(float tN, float tX, float tXX, float tY, float tXY) {
+  LineFit r;
+  r.A = tY * tXX - tX * tXY;
+  r.B = tN * tXY - tX * tY;
+  r.D = tN * tXX - tX * tX;
+  return r;
+}
+
+// window sums with a mirrored low edge (lo < 0 in the reference: lib/psy.c:613-617,666-670)
+VAMD_DEV LineFit fit_mirrored(const float *S, int n, int hi, int mlo /* = -lo */) {
+  const float *N = S, *X = S + n, *XX = S + 2 * n, *Y = S + 3 * n, *XY = S + 4 * n;
+  return fit_from_sums(N[hi] + N[mlo], X[hi] - X[mlo], XX[hi] + XX[mlo], Y[hi] + Y[mlo], XY[hi] - XY[mlo]);
+}
+// plain window differences (lib/psy.c:635-639,687-691)
+VAMD_DEV LineFit fit_plain(const float *S, int n, int hi, int lo) {
+  const float *N = S, *X = S + n, *XX = S + 2 * n, *Y = S + 3 * n, *XY = S + 4 * n;
+  return fit_from_sums(N[hi] - N[lo], X[hi] - X[lo], XX[hi] - XX[lo], Y[hi] - Y[lo], XY[hi] - XY[lo]);
+}
+
+VAMD_DEV LineFit bark_fit_at(const PsyP &P, const float *S, int i) {
+  const int n = P.n;
+  const int b = P.bark[i];
+  const int lo = b >> 16, hi = b & 0xffff;
+  return (i < P.bark_i1) ? fit_mirrored(S, n, hi, -lo) : fit_plain(S, n, hi, lo);
+}
+VAMD_DEV LineFit fixed_fit_at(const PsyP &P, const float *S, int i, int fixed) {
+  const int n = P.n;
+  const int hi = i + fixed / 2, lo = hi - fixed;
+  return (i < P.fix_i1) ? fit_mirrored(S, n, hi, -lo) : fit_plain(S, n, hi, lo);
+}
+
+// bark_noise_hybridmp(n, bark, f, noise, offset, fixed)
+VAMD_DEV void bark_noise_wave(const PsyP &P, const float *f, float *noise, const float offset, const int fixed,
+                              float *S) {
+  const int n = P.n;
+  float *N = S, *X = S + n, *XX = S + 2 * n, *Y = S + 3 * n, *XY = S + 4 * n;
+
+  // per-bin terms (lib/psy.c:571-597)
+  WAVE_FOR(i, n) {
+    float y = f[i] + offset;
+    if (y < 1.f) y = 1.f;
+    if (i == 0) {
+      const float w = (float)((double)(y * y) * .5);
+      N[0] = w;
+      X[0] = w;  // sic: the reference adds w, not w*x, at bin 0 (lib/psy.c:577)
+      XX[0] = 0.f;
+      Y[0] = w * y;
+      XY[0] = 0.f;
+    } else {
+      const float x = (float)i;
+      const float w = y * y;
+      N[i] = w;
+      X[i] = w * x;
+      XX[i] = w * x * x;
+      Y[i] = w * y;
+      XY[i] = w * x * y;
+    }
+  }
+  WAVE_SYNC();
+
+  // the five running sums, in index order, one lane each (lib/psy.c:576-603)
+  WAVE_FOR(a, 5) {
+    float *p = S + a * n;
+    float acc = 0.f;
+    for (int i = 0; i < n; i++) {
+      acc += p[i];
+      p[i] = acc;
+    }
+  }
+  WAVE_SYNC();
+
+  // line evaluation; three regimes split at the static indices i1 <= i2
+  // (lib/psy.c:606-656).  Beyond i2 the last fitted line is extended.
+  LineFit last;
+  last.A = 0.f;
+  last.B = 0.f;
+  last.D = 1.f;
+  if (P.bark_i2 > 0) last = bark_fit_at(P, S, P.bark_i2 - 1);
+  WAVE_FOR(i, n) {
+    const LineFit L = (i < P.bark_i2) ? bark_fit_at(P, S, i) : last;
+    const float x = (float)i;
+    float R = (L.A + x * L.B) / L.D;
+    if (R < 0.f) R = 0.f;
+    noise[i] = R - offset;
+  }
+  if (fixed <= 0) {
+    WAVE_SYNC();
+    return;
+  }
+
+  // fixed-width window pass: keep the lower of the two curves (lib/psy.c:660-703)
+  if (P.fix_i2 > 0) last = fixed_fit_at(P, S, P.fix_i2 - 1, fixed);
+  WAVE_FOR(i, n) {
+    const LineFit L = (i < P.fix_i2) ? fixed_fit_at(P, S, i, fixed) : last;
+    const float x = (float)i;
+    const float R = (L.A + x * L.B) / L.D;
+    if (R - offset < noise[i]) noise[i] = R - offset;
+  }
+  WAVE_SYNC();
+}
+
+// _vp_noisemask(p, logmdct, logmask)
+//   logmdct  [n] input (HBM or LDS)
+//   out      [n] HBM
+VAMD_DEV void noisemask_block(const PsyP &P, const float *__restrict__ logmdct, float *__restrict__ out, float *S,
+                              float *nz, float *wk) {
+  const int n = P.n;
+  bark_noise_wave(P, logmdct, nz, 140.f, -1, S);
+  WAVE_FOR(i, n) wk[i] = logmdct[i] - nz[i];
+  WAVE_SYNC();
+  bark_noise_wave(P, wk, nz, 0.f, P.noisewindowfixed, S);
+  WAVE_FOR(i, n) {
+    const float w = logmdct[i] - wk[i];
+    int dB = (int)((double)nz[i] + .5);
+    if (dB >= VAMD_NOISE_COMPAND_LEVELS) dB = VAMD_NOISE_COMPAND_LEVELS - 1;
+    if (dB < 0) dB = 0;
+    out[i] = w + P.noisecompand[dB];
+  }
+  WAVE_SYNC();
+}
+
+}  // namespace vamd

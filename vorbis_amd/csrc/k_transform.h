@@ -1,0 +1,420 @@
+// k_transform.h -- stage 1 of the per-block analysis, one wavefront per
+// channel-block: window -> forward MDCT -> real FFT -> logfft / logmdct / local
+// ampmax.  Covers SURVEY.md 8a rows a1, a3, a5, a6, a7
+// (reference lib/mapping0.c:254-360,384-385).
+//
+// Exactness: every butterfly is the reference's expression tree evaluated in
+// fp32 with no contraction (build flag -ffp-contract=off); all trig/twiddle/
+// window values come from the host-built tables in the setup blob.  Only the
+// *schedule* differs: each stage's independent butterflies are spread across
+// the 64 lanes with the work vectors in LDS.
+//
+// LDS: A[n] (PCM -> windowed -> FFT buffer "c"), B[n] (MDCT work "w", then FFT
+// buffer "ch").
+#pragma once
+#include "vamd_wave.h"
+#include "vamd_params.h"
+
+namespace vamd {
+
+// _vorbis_apply_window, lib/window.c:2102-2135, fused with the load of the
+// block from HBM.  lW/nW are already forced to 0 for short blocks by the caller.
+VAMD_DEV void load_windowed(const XformP &P, int W, int lW, int nW, const float *__restrict__ pcm, float *A,
+                            bool apply_window) {
+  const int n = P.n;
+  if (!apply_window) {
+    WAVE_FOR(i, n) A[i] = pcm[i];
+    return;
+  }
+  lW = W ? lW : 0;
+  nW = W ? nW : 0;
+  const int ln = lW ? P.bs1 : P.bs0;
+  const int rn = nW ? P.bs1 : P.bs0;
+  const float *winL = lW ? P.win_long : P.win_short;
+  const float *winR = nW ? P.win_long : P.win_short;
+  const int leftbegin = n / 4 - ln / 4, leftend = leftbegin + ln / 2;
+  const int rightbegin = n / 2 + n / 4 - rn / 4, rightend = rightbegin + rn / 2;
+  WAVE_FOR(i, n) {
+    float v = pcm[i];
+    if (i < leftbegin)
+      v = 0.f;
+    else if (i < leftend)
+      v *= winL[i - leftbegin];
+    else if (i >= rightend)
+      v = 0.f;
+    else if (i >= rightbegin)
+      v *= winR[rn / 2 - 1 - (i - rightbegin)];
+    A[i] = v;
+  }
+}
+
+// cPI*_8 of lib/mdct.h:43-45
+#define VAMD_C1 .92387953251128675613F
+#define VAMD_C2 .70710678118654752441F
+#define VAMD_C3 .38268343236508977175F
+
+// mdct_butterfly_8, lib/mdct.c:93-114 (in registers)
+VAMD_DEV void bfly8(float *x) {
+  float r0 = x[6] + x[2], r1 = x[6] - x[2], r2 = x[4] + x[0], r3 = x[4] - x[0];
+  x[6] = r0 + r2;
+  x[4] = r0 - r2;
+  r0 = x[5] - x[1];
+  r2 = x[7] - x[3];
+  x[0] = r1 + r0;
+  x[2] = r1 - r0;
+  r0 = x[5] + x[1];
+  r1 = x[7] + x[3];
+  x[3] = r2 + r3;
+  x[1] = r2 - r3;
+  x[7] = r1 + r0;
+  x[5] = r1 - r0;
+}
+
+// mdct_butterfly_16, lib/mdct.c:117-149
+VAMD_DEV void bfly16(float *x) {
+  float r0 = x[1] - x[9], r1 = x[0] - x[8];
+  x[8] += x[0];
+  x[9] += x[1];
+  x[0] = (r0 + r1) * VAMD_C2;
+  x[1] = (r0 - r1) * VAMD_C2;
+  r0 = x[3] - x[11];
+  r1 = x[10] - x[2];
+  x[10] += x[2];
+  x[11] += x[3];
+  x[2] = r0;
+  x[3] = r1;
+  r0 = x[12] - x[4];
+  r1 = x[13] - x[5];
+  x[12] += x[4];
+  x[13] += x[5];
+  x[4] = (r0 - r1) * VAMD_C2;
+  x[5] = (r0 + r1) * VAMD_C2;
+  r0 = x[14] - x[6];
+  r1 = x[15] - x[7];
+  x[14] += x[6];
+  x[15] += x[7];
+  x[6] = r0;
+  x[7] = r1;
+  bfly8(x);
+  bfly8(x + 8);
+}
+
+// mdct_butterfly_32, lib/mdct.c:152-213
+VAMD_DEV void bfly32(float *x) {
+  float r0 = x[30] - x[14], r1 = x[31] - x[15];
+  x[30] += x[14];
+  x[31] += x[15];
+  x[14] = r0;
+  x[15] = r1;
+  r0 = x[28] - x[12];
+  r1 = x[29] - x[13];
+  x[28] += x[12];
+  x[29] += x[13];
+  x[12] = r0 * VAMD_C1 - r1 * VAMD_C3;
+  x[13] = r0 * VAMD_C3 + r1 * VAMD_C1;
+  r0 = x[26] - x[10];
+  r1 = x[27] - x[11];
+  x[26] += x[10];
+  x[27] += x[11];
+  x[10] = (r0 - r1) * VAMD_C2;
+  x[11] = (r0 + r1) * VAMD_C2;
+  r0 = x[24] - x[8];
+  r1 = x[25] - x[9];
+  x[24] += x[8];
+  x[25] += x[9];
+  x[8] = r0 * VAMD_C3 - r1 * VAMD_C1;
+  x[9] = r1 * VAMD_C3 + r0 * VAMD_C1;
+  r0 = x[22] - x[6];
+  r1 = x[7] - x[23];
+  x[22] += x[6];
+  x[23] += x[7];
+  x[6] = r1;
+  x[7] = r0;
+  r0 = x[4] - x[20];
+  r1 = x[5] - x[21];
+  x[20] += x[4];
+  x[21] += x[5];
+  x[4] = r1 * VAMD_C1 + r0 * VAMD_C3;
+  x[5] = r1 * VAMD_C3 - r0 * VAMD_C1;
+  r0 = x[2] - x[18];
+  r1 = x[3] - x[19];
+  x[18] += x[2];
+  x[19] += x[3];
+  x[2] = (r1 + r0) * VAMD_C2;
+  x[3] = (r1 - r0) * VAMD_C2;
+  r0 = x[0] - x[16];
+  r1 = x[1] - x[17];
+  x[16] += x[0];
+  x[17] += x[1];
+  x[0] = r1 * VAMD_C3 + r0 * VAMD_C1;
+  x[1] = r1 * VAMD_C1 - r0 * VAMD_C3;
+  bfly16(x);
+  bfly16(x + 16);
+}
+
+// mdct_forward, lib/mdct.c:492-562.  `in` = A (windowed block, LDS), work w = B.
+// Leaves the n/2 spectrum in B[0..n/2) *unscaled order as the reference's `out`*
+// by writing it to `out` (LDS or HBM pointer supplied by the caller).
+VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in, float *w, float *out_lds) {
+  const int n = P.n, n2 = n >> 1, n4 = n >> 2, n8 = n >> 3;
+  const float *__restrict__ trig = P.trig;
+  float *w2 = w + n2;
+
+  // fold + pre-twiddle ("window + rotate + step 1"), lib/mdct.c:506-544.
+  // Pair p writes w2[2p], w2[2p+1]; the three loops differ in which input
+  // quarter is folded with which sign.
+  WAVE_FOR(p, n4) {
+    const float *T = trig + n2 - 2 * (p + 1);
+    float r0, r1;
+    if (2 * p < n8) {
+      const float *x0 = in + n2 + n4 - 4 * (p + 1);
+      const float *x1 = in + n2 + n4 + 1 + 4 * p;
+      r0 = x0[2] + x1[0];
+      r1 = x0[0] + x1[2];
+    } else if (2 * p < n2 - n8) {
+      const float *x0 = in + n2 + n4 - 4 * (p + 1);
+      const float *x1 = in + 1 + 4 * (p - n8 / 2);
+      r0 = x0[2] - x1[0];
+      r1 = x0[0] - x1[2];
+    } else {
+      const float *x0 = in + n - 4 * (p - (n2 - n8) / 2 + 1);
+      const float *x1 = in + 1 + 4 * (p - n8 / 2);
+      r0 = -x0[2] - x1[0];
+      r1 = -x0[0] - x1[2];
+    }
+    w2[2 * p] = r1 * T[1] + r0 * T[0];
+    w2[2 * p + 1] = r1 * T[0] - r0 * T[1];
+  }
+  WAVE_SYNC();
+
+  // mdct_butterflies, lib/mdct.c:316-336, on x = w2, points = n2.
+  // Stage s (s = 0 is mdct_butterfly_first, s >= 1 the generic passes) splits
+  // x into 2^s sub-blocks of n2>>s points; butterfly q of a sub-block pairs
+  // x[pts-2-2q] with x[pts/2-2-2q] and uses T[(4<<s)*q].  n2/4 = n/8 butterflies per
+  // stage in total, all independent.
+  const int nstages = P.log2n - 6;  // first + (log2n-7) generic passes
+  for (int s = 0; s < nstages; s++) {
+    const int pts = n2 >> s, per = pts >> 2, tstride = 4 << s;
+    WAVE_FOR(g, n8) {
+      const int j = g / per, q = g - j * per;
+      float *a = w2 + pts * j + pts - 2 - 2 * q;
+      float *b = w2 + pts * j + (pts >> 1) - 2 - 2 * q;
+      const float *T = trig + tstride * q;
+      float r0 = a[0] - b[0], r1 = a[1] - b[1];
+      a[0] += b[0];
+      a[1] += b[1];
+      b[0] = r1 * T[1] + r0 * T[0];
+      b[1] = r1 * T[0] - r0 * T[1];
+    }
+    WAVE_SYNC();
+  }
+  // 32-point butterflies, one group per lane, in registers
+  WAVE_FOR(g, n2 / 32) {
+    float v[32];
+#pragma unroll
+    for (int k = 0; k < 32; k++) v[k] = w2[32 * g + k];
+    bfly32(v);
+#pragma unroll
+    for (int k = 0; k < 32; k++) w2[32 * g + k] = v[k];
+  }
+  WAVE_SYNC();
+
+  // mdct_bitreverse, lib/mdct.c:346-394: reads x = w2 (upper half), writes the
+  // lower half w[0..n2).  Unit u produces w[2u], w[2u+1], w[n2-2u-2], w[n2-2u-1].
+  const int *__restrict__ bit = P.bitrev;
+  WAVE_FOR(u, n8) {
+    const float *x0 = w2 + bit[2 * u];
+    const float *x1 = w2 + bit[2 * u + 1];
+    const float T0 = trig[n + 2 * u], T1 = trig[n + 2 * u + 1];
+    float r0 = x0[1] - x1[1];
+    float r1 = x0[0] + x1[0];
+    float r2 = r1 * T0 + r0 * T1;
+    float r3 = r1 * T1 - r0 * T0;
+    r0 = (x0[1] + x1[1]) * .5f;
+    r1 = (x0[0] - x1[0]) * .5f;
+    w[2 * u] = r0 + r2;
+    w[2 * u + 1] = r1 + r3;
+    w[n2 - 2 * u - 2] = r0 - r2;
+    w[n2 - 2 * u - 1] = r3 - r1;
+  }
+  WAVE_SYNC();
+
+  // final rotate * scale, lib/mdct.c:552-561 -> out[n2] (placed in w2 region,
+  // which is dead now)
+  WAVE_FOR(i, n4) {
+    const float *T = trig + n2 + 2 * i;
+    const float a = w[2 * i], b = w[2 * i + 1];
+    out_lds[i] = (a * T[0] + b * T[1]) * P.mdct_scale;
+    out_lds[n2 - 1 - i] = (a * T[1] - b * T[0]) * P.mdct_scale;
+  }
+  WAVE_SYNC();
+}
+
+// dradf4, lib/smallft.c:168-268: one radix-4 pass cc -> ch.  wa1/2/3 are the
+// reference's 1-based-offset twiddle pointers (wa+iw-1 etc.).
+VAMD_DEV void radf4_wave(int ido, int l1, const float *cc, float *ch, const float *__restrict__ wa1,
+                         const float *__restrict__ wa2, const float *__restrict__ wa3) {
+  const float hsqt2 = .70710678118654752f;
+  const int t0 = l1 * ido;
+  WAVE_FOR(k, l1) {
+    const int t1 = t0 + k * ido, t2 = 3 * t0 + k * ido, t3 = k * ido, t4 = 2 * t0 + k * ido;
+    const float tr1 = cc[t1] + cc[t2];
+    const float tr2 = cc[t3] + cc[t4];
+    int t5 = t3 << 2;
+    ch[t5] = tr1 + tr2;
+    ch[(ido << 2) + t5 - 1] = tr2 - tr1;
+    t5 += ido << 1;
+    ch[t5 - 1] = cc[t3] - cc[t4];
+    ch[t5] = cc[t2] - cc[t1];
+  }
+  if (ido < 2) return;
+  if (ido > 2) {
+    const int half = (ido - 1) >> 1;  // i = 2,4,..,< ido
+    WAVE_FOR(g, l1 * half) {
+      const int k = g / half, m = g - k * half + 1, i = 2 * m;
+      const int t1 = k * ido;
+      const int t2 = t1 + i;
+      const int t4 = (t1 << 2) + i;
+      const int t6 = ido << 1;
+      const int t5 = t6 + (t1 << 2) - i;
+      int t3 = t2 + t0;
+      const float cr2 = wa1[i - 2] * cc[t3 - 1] + wa1[i - 1] * cc[t3];
+      const float ci2 = wa1[i - 2] * cc[t3] - wa1[i - 1] * cc[t3 - 1];
+      t3 += t0;
+      const float cr3 = wa2[i - 2] * cc[t3 - 1] + wa2[i - 1] * cc[t3];
+      const float ci3 = wa2[i - 2] * cc[t3] - wa2[i - 1] * cc[t3 - 1];
+      t3 += t0;
+      const float cr4 = wa3[i - 2] * cc[t3 - 1] + wa3[i - 1] * cc[t3];
+      const float ci4 = wa3[i - 2] * cc[t3] - wa3[i - 1] * cc[t3 - 1];
+      const float tr1 = cr2 + cr4, tr4 = cr4 - cr2, ti1 = ci2 + ci4, ti4 = ci2 - ci4;
+      const float ti2 = cc[t2] + ci3, ti3 = cc[t2] - ci3;
+      const float tr2 = cc[t2 - 1] + cr3, tr3 = cc[t2 - 1] - cr3;
+      ch[t4 - 1] = tr1 + tr2;
+      ch[t4] = ti1 + ti2;
+      ch[t5 - 1] = tr3 - ti4;
+      ch[t5] = tr4 - ti3;
+      ch[t4 + t6 - 1] = ti4 + tr3;
+      ch[t4 + t6] = tr4 + ti3;
+      ch[t5 + t6 - 1] = tr2 - tr1;
+      ch[t5 + t6] = ti1 - ti2;
+    }
+    if (ido & 1) return;
+  }
+  WAVE_FOR(k, l1) {
+    const int t1 = t0 + ido - 1 + k * ido, t2 = t1 + (t0 << 1);
+    const int t4 = ido + k * (ido << 2), t5 = ido << 1, t6 = ido + k * ido;
+    const float ti1 = -hsqt2 * (cc[t1] + cc[t2]);
+    const float tr1 = hsqt2 * (cc[t1] - cc[t2]);
+    ch[t4 - 1] = tr1 + cc[t6 - 1];
+    ch[t4 + t5 - 1] = cc[t6 - 1] - tr1;
+    ch[t4] = ti1 - cc[t1 + t0];
+    ch[t4 + t5] = ti1 + cc[t1 + t0];
+  }
+}
+
+// dradf2, lib/smallft.c:113-166
+VAMD_DEV void radf2_wave(int ido, int l1, const float *cc, float *ch, const float *__restrict__ wa1) {
+  const int t0 = l1 * ido;
+  WAVE_FOR(k, l1) {
+    const int t1 = k * ido, t2 = t0 + k * ido;
+    ch[t1 << 1] = cc[t1] + cc[t2];
+    ch[(t1 << 1) + (ido << 1) - 1] = cc[t1] - cc[t2];
+  }
+  if (ido < 2) return;
+  if (ido > 2) {
+    const int half = (ido - 1) >> 1;
+    WAVE_FOR(g, l1 * half) {
+      const int k = g / half, m = g - k * half + 1, i = 2 * m;
+      const int t1 = k * ido, t2 = t0 + k * ido;
+      const int t3 = t2 + i, t4 = (t1 << 1) + (ido << 1) - i, t5 = t1 + i, t6 = (t1 << 1) + i;
+      const float tr2 = wa1[i - 2] * cc[t3 - 1] + wa1[i - 1] * cc[t3];
+      const float ti2 = wa1[i - 2] * cc[t3] - wa1[i - 1] * cc[t3 - 1];
+      ch[t6] = cc[t5] + ti2;
+      ch[t4] = ti2 - cc[t5];
+      ch[t6 - 1] = cc[t5 - 1] + tr2;
+      ch[t4 - 1] = cc[t5 - 1] - tr2;
+    }
+    if (ido % 2 == 1) return;
+  }
+  WAVE_FOR(k, l1) {
+    const int t1 = ido + k * (ido << 1), t2 = ido - 1 + t0 + k * ido, t3 = ido - 1 + k * ido;
+    ch[t1] = -cc[t2];
+    ch[t1 - 1] = cc[t3];
+  }
+}
+
+// drftf1, lib/smallft.c:572-631: in-place (c) unnormalised real FFT with the
+// reference's pass order and c<->ch ping-pong.  Returns with the packed
+// spectrum R0,R1,I1,...,R(n/2) in c.
+VAMD_DEV void drft_forward_wave(const XformP &P, float *c, float *ch) {
+  const int n = P.n, nf = P.fft_nf;
+  const float *__restrict__ wa = P.wa;
+  int na = 1, l2 = n, iw = n;
+  for (int k1 = 0; k1 < nf; k1++) {
+    const int ip = P.fft_fac[nf - k1 - 1];
+    const int l1 = l2 / ip, ido = n / l2;
+    iw -= (ip - 1) * ido;
+    na = 1 - na;
+    const float *src = na ? ch : c;
+    float *dst = na ? c : ch;
+    if (ip == 4) {
+      const int ix2 = iw + ido, ix3 = ix2 + ido;
+      radf4_wave(ido, l1, src, dst, wa + iw - 1, wa + ix2 - 1, wa + ix3 - 1);
+    } else {
+      radf2_wave(ido, l1, src, dst, wa + iw - 1);
+    }
+    WAVE_SYNC();
+    l2 = l1;
+  }
+  if (na == 1) return;
+  WAVE_FOR(i, n) c[i] = ch[i];
+  WAVE_SYNC();
+}
+
+// The whole stage for one channel-block.
+//   pcm      HBM [n]           un-windowed block (vb->pcm[i])
+//   A, B     LDS [n] each
+//   outputs  HBM, each may be null
+// Returns the channel's local_ampmax (all lanes).
+VAMD_DEV float transform_block(const XformP &P, int W, int lW, int nW, const float *__restrict__ pcm, float *A,
+                               float *B, float *__restrict__ mdct_out, float *__restrict__ logmdct_out,
+                               float *__restrict__ logfft_out) {
+  const int n = P.n, n2 = n >> 1;
+  load_windowed(P, W, lW, nW, pcm, A, true);
+  WAVE_SYNC();
+
+  // MDCT: spectrum lands in B[n2..n) (LDS), then goes out with its dB twin
+  mdct_forward_wave(P, A, B, B + n2);
+  WAVE_FOR(j, n2) {
+    const float m = B[n2 + j];
+    if (mdct_out) mdct_out[j] = m;
+    if (logmdct_out) logmdct_out[j] = todB_345(m);  // lib/mapping0.c:384-385
+  }
+  WAVE_SYNC();
+
+  // FFT of the same windowed block, in place in A
+  drft_forward_wave(P, A, B);
+
+  // logfft + local ampmax, lib/mapping0.c:255-346
+  const float scale = 4.f / n;
+  const float scale_dB = todB_345(scale);
+  float amp = -1e30f;
+  WAVE_FOR(k, n2) {
+    float v;
+    if (k == 0) {
+      v = (float)((double)(scale_dB + todB(A[0])) + .345);
+    } else {
+      const float re = A[2 * k - 1], im = A[2 * k];
+      const float temp = re * re + im * im;
+      v = (float)((double)(scale_dB + .5f * todB(temp)) + .345);
+    }
+    if (logfft_out) logfft_out[k] = v;
+    amp = fmaxf(amp, v);
+  }
+  amp = wave_max(amp);
+  if (amp > 0.f) amp = 0.f;
+  WAVE_SYNC();
+  return amp;
+}
+
+}  // namespace vamd

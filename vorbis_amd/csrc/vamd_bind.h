@@ -1,0 +1,222 @@
+// vamd_bind.h -- host-side: validate a setup blob, append the derived index
+// tables (vamd_derive.h) and bind the kernel parameter structs to a base
+// address (the HBM copy for the product, the host copy for tests/emul).
+#pragma once
+#include <stddef.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "vamd_derive.h"
+#include "vamd_params.h"
+#include "vorbis_amd.h"
+
+namespace vamd {
+
+struct Bound {
+  int channels, rate;
+  int bs[2];
+  XformP xf[2];
+  PsyP psy[4];
+  FloorP floor[2];
+  CoupleP couple[2];
+  float ampmax_att_per_sec;
+};
+
+// Checks the blob and produces `image` = blob + derived tables (what gets copied to HBM).
+// Returns VAMD_OK or an OV_*-valued error with `err` set.
+inline int build_image(const void *blob_v, size_t bytes, std::vector<unsigned char> *image,
+                       std::vector<uint32_t> *derived_off /* per psy: run_start, seed_span */,
+                       std::vector<PsyDerived> *derived, std::string *err) {
+  const unsigned char *blob = (const unsigned char *)blob_v;
+  if (!blob || bytes < sizeof(vamd_setup_header)) {
+    *err = "setup blob missing or truncated";
+    return VAMD_EINVAL;
+  }
+  vamd_setup_header h;
+  memcpy(&h, blob, sizeof(h));
+  if (h.magic != VAMD_SETUP_MAGIC) {
+    *err = "setup blob: bad magic";
+    return VAMD_EINVAL;
+  }
+  if (h.version != VAMD_SETUP_VERSION) {
+    *err = "setup blob: version mismatch";
+    return VAMD_EVERSION;
+  }
+  if (h.total_bytes > bytes) {
+    *err = "setup blob: total_bytes exceeds buffer";
+    return VAMD_EINVAL;
+  }
+  if (h.channels < 1 || h.channels > VAMD_MAX_CH) {
+    *err = "channel count not covered (1 or 2)";
+    return VAMD_EIMPL;
+  }
+  if (h.managed) {
+    *err = "bitrate-managed setups (15 packet blobs) are not covered";
+    return VAMD_EIMPL;
+  }
+  for (int W = 0; W < 2; W++) {
+    const vamd_xform_tab &x = h.xform[W];
+    if (x.n != h.blocksizes[W] || x.n < 64 || x.n > 8192 || (x.n & (x.n - 1))) {
+      *err = "block size must be a power of two in [64, 8192]";
+      return VAMD_EINVAL;
+    }
+    if (x.fft_nf < 1 || x.fft_nf > 8) {
+      *err = "unsupported FFT factorisation";
+      return VAMD_EIMPL;
+    }
+    for (int i = 0; i < x.fft_nf; i++)
+      if (x.fft_fac[i] != 2 && x.fft_fac[i] != 4) {
+        *err = "FFT radix other than 2/4 (dradfg) is not covered";
+        return VAMD_EIMPL;
+      }
+    const vamd_mode_tab &m = h.mode[W];
+    if (m.submaps != 1 || m.coupling_steps < 0 || m.coupling_steps > 1) {
+      *err = "only single-submap mappings with at most one coupling step are covered";
+      return VAMD_EIMPL;
+    }
+    if (m.floor.posts < 2 || m.floor.posts > VAMD_POSTS_STRIDE) {
+      *err = "floor1 post count out of range";
+      return VAMD_EIMPL;
+    }
+    if (m.floor.look_n > x.n / 2) {
+      *err = "floor1 range exceeds the block";
+      return VAMD_EINVAL;
+    }
+  }
+  for (int p = 0; p < 4; p++) {
+    const vamd_psy_tab &t = h.psy[p];
+    if (t.n != h.blocksizes[p >> 1] / 2) {
+      *err = "psy look size does not match its block size";
+      return VAMD_EINVAL;
+    }
+    const uint64_t need[] = {(uint64_t)t.off_ath + 4ull * t.n, (uint64_t)t.off_octave + 4ull * t.n,
+                             (uint64_t)t.off_bark + 4ull * t.n, (uint64_t)t.off_noiseoffset + 12ull * t.n,
+                             (uint64_t)t.off_tonecurves + 4ull * 17 * 8 * 58};
+    for (uint64_t e : need)
+      if (e > h.total_bytes) {
+        *err = "setup blob: table offset out of range";
+        return VAMD_EINVAL;
+      }
+    if (t.total_octave_lines < 1 || t.total_octave_lines > 4096) {
+      *err = "total_octave_lines out of range";
+      return VAMD_EINVAL;
+    }
+  }
+
+  image->assign(blob, blob + h.total_bytes);
+  derived->clear();
+  derived_off->clear();
+  for (int p = 0; p < 4; p++) {
+    PsyDerived d = derive_psy(h.psy[p], blob);
+    while (image->size() & 15) image->push_back(0);
+    derived_off->push_back((uint32_t)image->size());
+    const unsigned char *a = (const unsigned char *)d.run_start.data();
+    image->insert(image->end(), a, a + 4 * d.run_start.size());
+    while (image->size() & 15) image->push_back(0);
+    derived_off->push_back((uint32_t)image->size());
+    const unsigned char *b = (const unsigned char *)d.seed_span.data();
+    image->insert(image->end(), b, b + 4 * d.seed_span.size());
+    derived->push_back(d);
+  }
+  while (image->size() & 15) image->push_back(0);
+  return VAMD_OK;
+}
+
+// Bind parameter structs to `base` (address of the image in the memory space
+// the kernels will read: device pointer for HIP, host pointer for tests/emul).
+inline void bind_params(const std::vector<unsigned char> &image, const std::vector<uint32_t> &derived_off,
+                        const std::vector<PsyDerived> &derived, const unsigned char *base, Bound *B) {
+  vamd_setup_header h;
+  memcpy(&h, image.data(), sizeof(h));
+  B->channels = h.channels;
+  B->rate = h.rate;
+  B->bs[0] = h.blocksizes[0];
+  B->bs[1] = h.blocksizes[1];
+  B->ampmax_att_per_sec = h.psy_g.ampmax_att_per_sec;
+  for (int W = 0; W < 2; W++) {
+    const vamd_xform_tab &x = h.xform[W];
+    XformP &X = B->xf[W];
+    X.n = x.n;
+    X.log2n = x.log2n;
+    X.mdct_scale = x.mdct_scale;
+    X.trig = (const float *)(base + x.off_mdct_trig);
+    X.bitrev = (const int *)(base + x.off_mdct_bitrev);
+    X.wa = (const float *)(base + x.off_fft_wa);
+    X.win_long = (const float *)(base + h.xform[1].off_window);
+    X.win_short = (const float *)(base + h.xform[0].off_window);
+    X.bs0 = h.blocksizes[0];
+    X.bs1 = h.blocksizes[1];
+    X.fft_nf = x.fft_nf;
+    for (int i = 0; i < 8; i++) X.fft_fac[i] = i < x.fft_nf ? x.fft_fac[i] : 0;
+
+    const vamd_floor1_tab &f = h.mode[W].floor;
+    FloorP &F = B->floor[W];
+    F.posts = f.posts;
+    F.look_n = f.look_n;
+    F.quant_q = f.quant_q;
+    F.mult = f.mult;
+    F.maxover = f.maxover;
+    F.maxunder = f.maxunder;
+    F.maxerr = f.maxerr;
+    F.twofitweight = f.twofitweight;
+    F.twofitatten = f.twofitatten;
+    const size_t fo = offsetof(vamd_setup_header, mode) + sizeof(vamd_mode_tab) * W + offsetof(vamd_mode_tab, floor);
+    F.postlist = (const int *)(base + fo + offsetof(vamd_floor1_tab, postlist));
+    F.sorted_index = (const int *)(base + fo + offsetof(vamd_floor1_tab, sorted_index));
+    F.forward_index = (const int *)(base + fo + offsetof(vamd_floor1_tab, forward_index));
+    F.reverse_index = (const int *)(base + fo + offsetof(vamd_floor1_tab, reverse_index));
+    F.hineighbor = (const int *)(base + fo + offsetof(vamd_floor1_tab, hineighbor));
+    F.loneighbor = (const int *)(base + fo + offsetof(vamd_floor1_tab, loneighbor));
+
+    CoupleP &C = B->couple[W];
+    const int blob_k = VAMD_PACKETBLOBS / 2;
+    C.ch = h.channels;
+    C.coupling_steps = h.mode[W].coupling_steps;
+    C.mag = h.mode[W].coupling_mag;
+    C.ang = h.mode[W].coupling_ang;
+    // lib/psy.c:1027-1029,1056-1057; blockflag of the psy looks of this W is W
+    C.pointlimit = h.psy_g.coupling_pointlimit[W][blob_k];
+    C.prepoint = stereo_threshold(h.psy_g.coupling_prepointamp[blob_k], false);
+    C.postpoint = stereo_threshold(h.psy_g.coupling_postpointamp[blob_k], (x.n / 2) > 1000);
+    C.sliding_lowpass = h.psy_g.sliding_lowpass[W][blob_k];
+  }
+  for (int p = 0; p < 4; p++) {
+    const vamd_psy_tab &t = h.psy[p];
+    PsyP &P = B->psy[p];
+    P.n = t.n;
+    P.firstoc = t.firstoc;
+    P.shiftoc = t.shiftoc;
+    P.eighth_octave_lines = t.eighth_octave_lines;
+    P.total_octave_lines = t.total_octave_lines;
+    P.m_val = t.m_val;
+    P.ath_adjatt = t.ath_adjatt;
+    P.ath_maxatt = t.ath_maxatt;
+    P.tone_masteratt1 = t.tone_masteratt[1];
+    P.tone_abs_limit = t.tone_abs_limit;
+    P.noisemaxsupp = t.noisemaxsupp;
+    P.noisewindowfixed = t.noisewindowfixed;
+    P.max_curve_dB = t.max_curve_dB;
+    P.ath = (const float *)(base + t.off_ath);
+    P.octave = (const int *)(base + t.off_octave);
+    P.bark = (const int *)(base + t.off_bark);
+    P.noiseoffset1 = (const float *)(base + t.off_noiseoffset) + t.n;
+    P.tonecurves = (const float *)(base + t.off_tonecurves);
+    P.noisecompand = (const float *)(base + offsetof(vamd_setup_header, psy) + sizeof(vamd_psy_tab) * p +
+                                     offsetof(vamd_psy_tab, noisecompand));
+    const PsyDerived &d = derived[p];
+    P.bark_i1 = d.bark_i1;
+    P.bark_i2 = d.bark_i2;
+    P.fix_i1 = d.fix_i1;
+    P.fix_i2 = d.fix_i2;
+    P.run_start = (const int *)(base + derived_off[2 * p]);
+    P.nruns = (int)d.run_start.size() - 1;
+    P.seed_span = (const int *)(base + derived_off[2 * p + 1]);
+    P.tail_linpos = d.tail_linpos;
+    P.normal_p = t.normal_p;
+    P.normal_start = t.normal_start;
+    P.normal_partition = t.normal_partition;
+    P.normal_thresh = t.normal_thresh;
+  }
+}
+
+}  // namespace vamd

@@ -1,0 +1,99 @@
+// vamd_derive.h -- host-side, once per context: static index tables that the
+// reference re-discovers with data-independent loops on every block.  They
+// depend only on the setup blob (octave[], bark[], n, window widths), never on
+// audio, so vamd_create() computes them once and ships them to HBM next to the
+// blob.  Pure integer walks; each cites the loop it freezes.
+#pragma once
+#include <stdint.h>
+#include <vector>
+#include "vamd_setup.h"
+
+namespace vamd {
+
+struct PsyDerived {
+  int bark_i1, bark_i2;  // lib/psy.c:606-656
+  int fix_i1, fix_i2;    // lib/psy.c:660-703
+  std::vector<int32_t> run_start;  // nruns+1 entries, lib/psy.c:429-435
+  std::vector<int32_t> seed_span;  // [n][2], lib/psy.c:522-537
+  int tail_linpos;                 // lib/psy.c:539-543
+};
+
+inline PsyDerived derive_psy(const vamd_psy_tab &t, const unsigned char *blob) {
+  PsyDerived d;
+  const int n = t.n;
+  const int32_t *bark = (const int32_t *)(blob + t.off_bark);
+  const int32_t *octave = (const int32_t *)(blob + t.off_octave);
+
+  // bark_noise_hybridmp pass 1: first loop runs while lo<0 && -lo<n && hi<n,
+  // second while 0<=lo<n && hi<n, the rest extends the last line.
+  int i = 0;
+  for (; i < n; i++) {
+    const int lo = bark[i] >> 16, hi = bark[i] & 0xffff;
+    if (lo >= 0 || -lo >= n) break;
+    if (hi >= n) break;
+  }
+  d.bark_i1 = i;
+  for (; i < n; i++) {
+    const int lo = bark[i] >> 16, hi = bark[i] & 0xffff;
+    if (lo < 0 || lo >= n) break;
+    if (hi >= n) break;
+  }
+  d.bark_i2 = i;
+
+  // fixed-width pass: hi = i + fixed/2, lo = hi - fixed
+  const int fixed = t.noisewindowfixed;
+  d.fix_i1 = d.fix_i2 = 0;
+  if (fixed > 0) {
+    for (i = 0; i < n; i++) {
+      const int hi = i + fixed / 2, lo = hi - fixed;
+      if (hi >= n) break;
+      if (lo >= 0) break;
+    }
+    d.fix_i1 = i;
+    for (; i < n; i++) {
+      const int hi = i + fixed / 2, lo = hi - fixed;
+      if (hi >= n) break;
+      if (lo < 0) break;
+    }
+    d.fix_i2 = i;
+  }
+
+  // seed_loop: maximal runs of equal octave[] values
+  for (i = 0; i < n;) {
+    d.run_start.push_back(i);
+    int j = i;
+    while (j + 1 < n && octave[j + 1] == octave[i]) j++;
+    i = j + 1;
+  }
+  d.run_start.push_back(n);
+
+  // max_seeds: replay the (pos, linpos) walk; record per bin the seed-line span
+  // [p0, p1] whose fold gives that bin's minV.
+  d.seed_span.assign((size_t)2 * n, 0);
+  {
+    const int linesper = t.eighth_octave_lines;
+    long linpos = 0;
+    long pos = octave[0] - t.firstoc - (linesper >> 1);
+    while (linpos + 1 < n) {
+      const long p0 = pos;
+      long end = ((octave[linpos] + octave[linpos + 1]) >> 1) - t.firstoc;
+      while (pos + 1 <= end) pos++;
+      end = pos + t.firstoc;
+      for (; linpos < n && octave[linpos] <= end; linpos++) {
+        d.seed_span[2 * linpos] = (int32_t)p0;
+        d.seed_span[2 * linpos + 1] = (int32_t)pos;
+      }
+    }
+    d.tail_linpos = (int)linpos;
+  }
+  return d;
+}
+
+// stereo_threshholds / _limited, lib/psy.c:32-33
+inline float stereo_threshold(int idx, bool limited) {
+  static const double a[] = {0.0, .5, 1.0, 1.5, 2.5, 4.5, 8.5, 16.5, 9e10};
+  static const double b[] = {0.0, .5, 1.0, 1.5, 2.0, 2.5, 4.5, 8.5, 9e10};
+  return (float)(limited ? b[idx] : a[idx]);
+}
+
+}  // namespace vamd

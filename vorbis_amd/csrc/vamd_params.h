@@ -1,0 +1,74 @@
+// vamd_params.h -- by-value kernel parameter structs: pointers into the setup
+// blob resident in HBM (include/vamd_setup.h) plus the scalars each stage reads.
+#pragma once
+#include <stdint.h>
+#include "vamd_setup.h"
+
+namespace vamd {
+
+// window + MDCT + FFT tables for one size class W
+struct XformP {
+  int n;                 // block size
+  int log2n;
+  float mdct_scale;      // 4/n
+  const float *trig;     // [n + n/4]   mdct_lookup.trig   (lib/mdct.c:64-73)
+  const int *bitrev;     // [n/4]       mdct_lookup.bitrev (lib/mdct.c:77-88)
+  const float *wa;       // [2n]        drft_lookup.trigcache + n
+  const float *win_long; // [blocksizes[1]/2] rising half window of the long size
+  const float *win_short;// [blocksizes[0]/2]
+  int bs0, bs1;          // blocksizes
+  int fft_nf;
+  int fft_fac[8];
+};
+
+// one vorbis_look_psy (+ the vorbis_info_psy scalars)
+struct PsyP {
+  int n;
+  int firstoc, shiftoc, eighth_octave_lines, total_octave_lines;
+  float m_val;
+  float ath_adjatt, ath_maxatt;
+  float tone_masteratt1;     // tone_masteratt[1]: VBR uses offset_select 1 only
+  float tone_abs_limit;
+  float noisemaxsupp;
+  int noisewindowfixed;
+  float max_curve_dB;
+  const float *ath;          // [n]
+  const int *octave;         // [n]
+  const int *bark;           // [n]
+  const float *noiseoffset1; // [n]  noiseoffset[1]
+  const float *tonecurves;   // [17][8][58]
+  const float *noisecompand; // [40] (inside the blob header copy in HBM)
+  // derived at vamd_create() from the static tables (host, once):
+  int bark_i1, bark_i2;      // regime boundaries of bark_noise_hybridmp pass 1 (lib/psy.c:606-656)
+  int fix_i1, fix_i2;        // same for the fixed-window pass (lib/psy.c:660-703)
+  const int *run_start;      // [nruns+1] starts of runs of equal octave[] (lib/psy.c:429-435)
+  int nruns;
+  const int *seed_span;      // [n][2] octave-line span (pos0,pos1) each bin folds in max_seeds (lib/psy.c:524-537)
+  int tail_linpos;           // first bin handled by max_seeds' tail loop (lib/psy.c:539-543)
+  int normal_p, normal_start, normal_partition;
+  double normal_thresh;
+};
+
+struct FloorP {
+  int posts, look_n, quant_q, mult;
+  float maxover, maxunder, maxerr, twofitweight, twofitatten;
+  const int *postlist, *sorted_index, *forward_index, *reverse_index, *hineighbor, *loneighbor;
+};
+
+struct CoupleP {
+  int ch;
+  int coupling_steps, mag, ang;
+  int pointlimit;        // coupling_pointlimit[blockflag][PACKETBLOBS/2]
+  float prepoint, postpoint;
+  int sliding_lowpass;   // sliding_lowpass[W][PACKETBLOBS/2]
+};
+
+// per-block descriptor source (arrays may be null -> uniform value)
+struct DescP {
+  const int *lW, *nW, *blocktype;
+  const float *ampmax_in;
+  int u_lW, u_nW, u_blocktype;
+  float u_ampmax_in;
+};
+
+}  // namespace vamd

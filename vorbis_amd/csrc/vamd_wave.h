@@ -1,0 +1,105 @@
+// vamd_wave.h -- the execution vocabulary every kernel body is written in.
+//
+// One 64-lane wavefront owns one channel-block (or one stereo block).  A kernel
+// body is a sequence of *phases*; inside a phase the lanes stride over
+// independent work items (WAVE_FOR), and WAVE_SYNC() separates phases that
+// communicate through LDS.  Written this way the same body compiles two ways:
+//
+//   * hipcc / gfx950: LANE = threadIdx.x of a 64-thread workgroup, WAVE_SYNC =
+//     workgroup barrier (a single wave, so it is only an LDS fence + s_barrier),
+//     reductions are DPP/ds_swizzle-lowered __shfl_xor trees.
+//   * a plain host C++ compiler (tests/emul): LANE = 0, NLANES = 1 -- the phases
+//     run as ordinary serial loops.  This is a *test build only*: it lets the
+//     arithmetic of every kernel be checked bit-for-bit against the reference on
+//     a machine without a GPU.  It is never part of the product library.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+#define VAMD_GPU 1
+#elif defined(__HIPCC__)
+#define VAMD_GPU 1
+#else
+#define VAMD_GPU 0
+#endif
+
+#if VAMD_GPU
+#include <hip/hip_runtime.h>
+#define VAMD_DEV __device__ __forceinline__
+#define VAMD_DEV_NOINLINE __device__ __noinline__
+#define LANE ((int)threadIdx.x)
+#define NLANES 64
+#define WAVE_SYNC() __syncthreads()
+#else
+#include <math.h>
+#define VAMD_DEV static inline
+#define VAMD_DEV_NOINLINE static
+#define LANE 0
+#define NLANES 1
+#define WAVE_SYNC() ((void)0)
+#endif
+
+// lanes stride over [0, count)
+#define WAVE_FOR(i, count) for (int i = LANE; i < (count); i += NLANES)
+
+namespace vamd {
+
+#if VAMD_GPU
+VAMD_DEV float wave_max(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+  return v;
+}
+VAMD_DEV int wave_sum(int v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+VAMD_DEV int wave_any(int pred) { return __any(pred); }
+VAMD_DEV float f_from_bits(uint32_t u) { return __uint_as_float(u); }
+VAMD_DEV uint32_t f_bits(float f) { return __float_as_uint(f); }
+// order-free float max into LDS (seed scatter): classic sign-split integer trick
+VAMD_DEV void lds_atomic_max(float *p, float v) {
+  if (v >= 0.f)
+    atomicMax((int *)p, __float_as_int(v));
+  else
+    atomicMin((unsigned int *)p, __float_as_uint(v));
+}
+VAMD_DEV void lds_atomic_add(int *p, int v) { atomicAdd(p, v); }
+VAMD_DEV void lds_atomic_or(int *p, int v) { atomicOr(p, v); }
+#else
+VAMD_DEV float wave_max(float v) { return v; }
+VAMD_DEV int wave_sum(int v) { return v; }
+VAMD_DEV int wave_any(int pred) { return pred != 0; }
+VAMD_DEV float f_from_bits(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+VAMD_DEV uint32_t f_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+VAMD_DEV void lds_atomic_max(float *p, float v) { if (*p < v) *p = v; }
+VAMD_DEV void lds_atomic_add(int *p, int v) { *p += v; }
+VAMD_DEV void lds_atomic_or(int *p, int v) { *p |= v; }
+#endif
+
+// ---- scalar helpers shared by all stages ------------------------------------
+
+// todB(): reference lib/scales.h:43-51.  An integer-bit-trick log, not log10:
+// the float's magnitude bits, converted to float, scaled and offset.  fp32 ops.
+VAMD_DEV float todB(float x) {
+  uint32_t i = f_bits(x) & 0x7fffffffu;
+  return (float)i * 7.17711438e-7f - 764.6161886f;
+}
+// "todB(x) + .345" as the reference writes it: the .345 literal is a double
+// (lib/mapping0.c:264,310,327,385), so the add is done in fp64 then rounded.
+VAMD_DEV float todB_345(float x) { return (float)((double)todB(x) + .345); }
+
+// unitnorm(): lib/scales.h:32-40 (+-1 with the sign of x)
+VAMD_DEV float unitnorm(float x) { return f_from_bits((f_bits(x) & 0x80000000u) | 0x3f800000u); }
+
+// vorbis_dBquant(): lib/floor1.c:273-278
+VAMD_DEV int dBquant(float x) {
+  int i = (int)(x * 7.3142857f + 1023.5f);
+  if (i > 1023) return 1023;
+  if (i < 0) return 0;
+  return i;
+}
+
+}  // namespace vamd
