@@ -64,6 +64,15 @@ int vamd_set_stream(vamd_ctx *ctx, void *hip_stream);
  * of size class W so that no allocation happens inside a timed region. */
 int vamd_reserve(vamd_ctx *ctx, int W, long max_blocks);
 
+/* Measurement hook (no libvorbis counterpart): when enabled, a HIP event is
+ * recorded on the context's stream before each stage kernel and after the last.
+ * vamd_stage_ms() synchronises the stream and returns, per stage, the summed
+ * elapsed milliseconds of all batches issued since the last call (stage order:
+ * 0 transform, 1 ampmax, 2 noisemask, 3 tonemask, 4 floor, 5 couple) and the
+ * number of batches in *runs. */
+int vamd_profile(vamd_ctx *ctx, int enable);
+int vamd_stage_ms(vamd_ctx *ctx, float *ms, int nstages, int *runs);
+
 int vamd_channels(const vamd_ctx *ctx);
 int vamd_blocksize(const vamd_ctx *ctx, int W);
 int vamd_posts(const vamd_ctx *ctx, int W);

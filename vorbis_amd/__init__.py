@@ -1,0 +1,15 @@
+"""vorbis_amd -- MI355X-native per-block Vorbis encode analysis (libvorbis' mapping0_forward
+numeric path) behind a C ABI (include/vorbis_amd.h).
+
+This package is only plumbing: it loads libvorbis_amd.so (hand-written HIP for gfx950, built by
+`__graft_entry__.build()` / `make -C vorbis_amd/csrc`), hands it device pointers of torch tensors and
+mirrors the C entry points one-to-one.  There is no CPU fallback: without the HIP library, or
+without a GPU, every compute call raises.
+"""
+from .api import (Analyzer, VamdError, load_library, library_path, default_setup_blob, LEVEL_TRANSFORM,
+                  LEVEL_PSY, LEVEL_FULL, POSTS_STRIDE, BLOCKTYPE_IMPULSE, BLOCKTYPE_PADDING,
+                  BLOCKTYPE_TRANSITION, BLOCKTYPE_LONG, EXPORTED_SYMBOLS)
+
+__all__ = ["Analyzer", "VamdError", "load_library", "library_path", "default_setup_blob", "LEVEL_TRANSFORM",
+           "LEVEL_PSY", "LEVEL_FULL", "POSTS_STRIDE", "BLOCKTYPE_IMPULSE", "BLOCKTYPE_PADDING",
+           "BLOCKTYPE_TRANSITION", "BLOCKTYPE_LONG", "EXPORTED_SYMBOLS"]

@@ -1,0 +1,269 @@
+"""ctypes mirror of include/vorbis_amd.h.  Names and argument meaning follow the C ABI, which in
+turn follows libvorbis (mapping0_forward's variables and OV_* return codes)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+VAMD_OK, VAMD_EFAULT, VAMD_EIMPL, VAMD_EINVAL, VAMD_EVERSION = 0, -129, -130, -131, -134
+LEVEL_TRANSFORM, LEVEL_PSY, LEVEL_FULL = 1, 2, 3
+POSTS_STRIDE = 32
+BLOCKTYPE_IMPULSE, BLOCKTYPE_PADDING, BLOCKTYPE_TRANSITION, BLOCKTYPE_LONG = 0, 1, 0, 1
+
+# every symbol include/vorbis_amd.h declares
+EXPORTED_SYMBOLS = ["vamd_create", "vamd_destroy", "vamd_last_error", "vamd_set_stream", "vamd_reserve",
+                    "vamd_channels", "vamd_blocksize", "vamd_posts", "vamd_mdct_forward_batch",
+                    "vamd_analyze_batch", "vamd_analyze_stream", "vamd_analyze_block", "vamd_profile",
+                    "vamd_stage_ms"]
+
+_vp = C.c_void_p
+
+
+class _Desc(C.Structure):
+    _fields_ = [("W", C.c_int), ("nblocks", C.c_long), ("lW", _vp), ("nW", _vp), ("blocktype", _vp),
+                ("ampmax_in", _vp), ("uniform_lW", C.c_int), ("uniform_nW", C.c_int),
+                ("uniform_blocktype", C.c_int), ("uniform_ampmax_in", C.c_float)]
+
+
+_IO_FIELDS = ["pcm", "mdct_raw", "logfft", "logmdct", "noise", "tone", "logmask", "mdct", "posts", "post_valid",
+              "ilogmask", "iwork", "nonzero", "local_ampmax", "ampmax_out"]
+
+
+class _IO(C.Structure):
+    _fields_ = [(k, _vp) for k in _IO_FIELDS]
+
+
+class VamdError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("vorbis_amd error %d: %s" % (code, msg))
+        self.code = code
+
+
+def library_path():
+    return os.path.join(_HERE, "libvorbis_amd.so")
+
+
+_lib = None
+
+
+def load_library():
+    """Load libvorbis_amd.so.  Raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise ImportError("vorbis_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; "
+                          "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback." % path)
+    L = C.CDLL(path)
+    L.vamd_create.argtypes = [C.POINTER(_vp), _vp, C.c_size_t, C.c_int]
+    L.vamd_destroy.argtypes = [_vp]
+    L.vamd_destroy.restype = None
+    L.vamd_last_error.argtypes = [_vp]
+    L.vamd_last_error.restype = C.c_char_p
+    L.vamd_set_stream.argtypes = [_vp, _vp]
+    L.vamd_reserve.argtypes = [_vp, C.c_int, C.c_long]
+    L.vamd_channels.argtypes = [_vp]
+    L.vamd_blocksize.argtypes = [_vp, C.c_int]
+    L.vamd_posts.argtypes = [_vp, C.c_int]
+    L.vamd_mdct_forward_batch.argtypes = [_vp, C.c_int, _vp, _vp, C.c_long]
+    L.vamd_analyze_batch.argtypes = [_vp, C.POINTER(_Desc), C.POINTER(_IO), C.c_int]
+    L.vamd_analyze_stream.argtypes = [_vp, C.POINTER(_Desc), C.POINTER(_IO), C.POINTER(C.c_float)]
+    L.vamd_analyze_block.argtypes = [_vp, C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _vp, _vp,
+                                     _vp, _vp, _vp, _vp, C.POINTER(C.c_float)]
+    L.vamd_profile.argtypes = [_vp, C.c_int]
+    L.vamd_stage_ms.argtypes = [_vp, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]
+    _lib = L
+    return L
+
+
+def default_setup_blob(name="44k_stereo_q4"):
+    """A committed setup blob (vorbis_amd/data/setup_<name>.bin), produced by the reference's own
+    libvorbisenc + vorbis_analysis_init through integration/vamd_pack_setup.c (tools/make_setup_blobs.py)."""
+    path = os.path.join(_HERE, "data", "setup_%s.bin" % name)
+    return np.fromfile(path, dtype=np.uint8)
+
+
+_FLOAT_OUT = ("mdct_raw", "logfft", "logmdct", "noise", "tone", "logmask", "mdct")
+_INT_OUT = ("ilogmask", "iwork")
+
+
+class Analyzer:
+    """One vamd_ctx: the GPU-side counterpart of a vorbis_dsp_state's lookups."""
+
+    def __init__(self, setup_blob, device=None):
+        import torch
+        self.torch = torch
+        self.L = load_library()
+        if not torch.cuda.is_available():
+            raise RuntimeError("vorbis_amd needs a ROCm GPU (torch.cuda.is_available() is False); no CPU fallback")
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        blob = np.ascontiguousarray(np.frombuffer(bytes(setup_blob), dtype=np.uint8) if not isinstance(setup_blob, np.ndarray)
+                                    else setup_blob.astype(np.uint8))
+        h = _vp()
+        r = self.L.vamd_create(C.byref(h), blob.ctypes.data_as(_vp), blob.size, self.device)
+        if r != VAMD_OK:
+            raise VamdError(r, "vamd_create failed (see stderr)")
+        self.h = h
+        self.channels = self.L.vamd_channels(h)
+        self.blocksizes = (self.L.vamd_blocksize(h, 0), self.L.vamd_blocksize(h, 1))
+        self.posts = (self.L.vamd_posts(h, 0), self.L.vamd_posts(h, 1))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.vamd_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, r):
+        if r != VAMD_OK:
+            raise VamdError(r, self.L.vamd_last_error(self.h).decode())
+
+    def _dev(self):
+        return self.torch.device("cuda", self.device)
+
+    def _bind_stream(self):
+        s = self.torch.cuda.current_stream(self.device)
+        self._check(self.L.vamd_set_stream(self.h, _vp(s.cuda_stream)))
+
+    STAGES = ("transform", "ampmax", "noisemask", "tonemask", "floor", "couple")
+
+    def profile(self, enable=True):
+        self._bind_stream()
+        self._check(self.L.vamd_profile(self.h, 1 if enable else 0))
+
+    def stage_ms(self):
+        """(dict stage -> summed ms, number of batches) since the last call; synchronises."""
+        ms = (C.c_float * 6)()
+        runs = C.c_int(0)
+        self._check(self.L.vamd_stage_ms(self.h, ms, 6, C.byref(runs)))
+        return dict(zip(self.STAGES, [float(x) for x in ms])), runs.value
+
+    def reserve(self, W, max_blocks):
+        self._check(self.L.vamd_reserve(self.h, W, max_blocks))
+
+    # mdct_forward(lookup, in, out) batched -- BASELINE config 2
+    def mdct_forward(self, W, frames, out=None):
+        t = self.torch
+        n = self.blocksizes[W]
+        assert frames.is_cuda and frames.dtype == t.float32 and frames.is_contiguous() and frames.shape[-1] == n
+        nf = frames.numel() // n
+        if out is None:
+            out = t.empty(frames.shape[:-1] + (n // 2,), dtype=t.float32, device=frames.device)
+        self._bind_stream()
+        self._check(self.L.vamd_mdct_forward_batch(self.h, W, _vp(frames.data_ptr()), _vp(out.data_ptr()), nf))
+        return out
+
+    def _desc(self, W, nb, lW, nW, blocktype, ampmax_in, keep):
+        t = self.torch
+        d = _Desc()
+        d.W, d.nblocks = W, nb
+
+        def arr(v, dtype, name, uni):
+            if t.is_tensor(v):
+                assert v.is_cuda and v.dtype == dtype and v.is_contiguous() and v.numel() == nb, name
+                keep.append(v)
+                setattr(d, name, _vp(v.data_ptr()))
+            else:
+                setattr(d, name, None)
+                setattr(d, uni, v)
+        arr(lW, t.int32, "lW", "uniform_lW")
+        arr(nW, t.int32, "nW", "uniform_nW")
+        arr(blocktype, t.int32, "blocktype", "uniform_blocktype")
+        arr(ampmax_in, t.float32, "ampmax_in", "uniform_ampmax_in")
+        return d
+
+    def alloc_outputs(self, W, nb, want):
+        """Output tensors for `want` (names from vamd_batch_io)."""
+        t = self.torch
+        ch, n2 = self.channels, self.blocksizes[W] // 2
+        dev = self._dev()
+        o = {}
+        for k in want:
+            if k in _FLOAT_OUT:
+                o[k] = t.empty((nb, ch, n2), dtype=t.float32, device=dev)
+            elif k in _INT_OUT:
+                o[k] = t.empty((nb, ch, n2), dtype=t.int32, device=dev)
+            elif k == "posts":
+                o[k] = t.empty((nb, ch, POSTS_STRIDE), dtype=t.int32, device=dev)
+            elif k in ("post_valid", "nonzero"):
+                o[k] = t.empty((nb, ch), dtype=t.int32, device=dev)
+            elif k == "local_ampmax":
+                o[k] = t.empty((nb, ch), dtype=t.float32, device=dev)
+            elif k == "ampmax_out":
+                o[k] = t.empty((nb,), dtype=t.float32, device=dev)
+            else:
+                raise KeyError(k)
+        return o
+
+    def _io(self, pcm, outs):
+        io = _IO()
+        io.pcm = _vp(pcm.data_ptr())
+        for k, v in outs.items():
+            assert v.is_cuda and v.is_contiguous()
+            setattr(io, k, _vp(v.data_ptr()))
+        return io
+
+    _DEFAULT_WANT = {LEVEL_TRANSFORM: ("mdct_raw", "logfft", "logmdct", "local_ampmax"),
+                     LEVEL_PSY: ("mdct_raw", "noise", "tone"),
+                     LEVEL_FULL: ("mdct", "logmask", "posts", "post_valid", "iwork", "nonzero", "ampmax_out")}
+
+    def analyze(self, pcm, W=1, lW=1, nW=1, blocktype=BLOCKTYPE_LONG, ampmax_in=-9999.0, level=LEVEL_FULL,
+                want=None, outs=None):
+        """vamd_analyze_batch.  pcm: cuda float32 [nblocks, ch, n].  Returns dict name -> tensor."""
+        t = self.torch
+        n = self.blocksizes[W]
+        assert pcm.is_cuda and pcm.dtype == t.float32 and pcm.is_contiguous()
+        assert pcm.dim() == 3 and pcm.shape[1] == self.channels and pcm.shape[2] == n, tuple(pcm.shape)
+        nb = pcm.shape[0]
+        if outs is None:
+            outs = self.alloc_outputs(W, nb, self._DEFAULT_WANT[level] if want is None else want)
+        keep = []
+        d = self._desc(W, nb, lW, nW, blocktype, ampmax_in, keep)
+        io = self._io(pcm, outs)
+        self._bind_stream()
+        self._check(self.L.vamd_analyze_batch(self.h, C.byref(d), C.byref(io), level))
+        return outs
+
+    def analyze_stream(self, pcm, ampmax_state, W=1, lW=1, nW=1, blocktype=BLOCKTYPE_LONG, want=None, outs=None):
+        """vamd_analyze_stream.  Returns (outs, new ampmax_state)."""
+        n = self.blocksizes[W]
+        nb = pcm.shape[0]
+        assert pcm.is_cuda and pcm.is_contiguous() and pcm.shape[1:] == (self.channels, n)
+        if outs is None:
+            outs = self.alloc_outputs(W, nb, self._DEFAULT_WANT[LEVEL_FULL] if want is None else want)
+        keep = []
+        d = self._desc(W, nb, lW, nW, blocktype, 0.0, keep)
+        io = self._io(pcm, outs)
+        st = C.c_float(ampmax_state)
+        self._bind_stream()
+        self._check(self.L.vamd_analyze_stream(self.h, C.byref(d), C.byref(io), C.byref(st)))
+        return outs, st.value
+
+    def analyze_block(self, pcm, lW=1, W=1, nW=1, blocktype=BLOCKTYPE_LONG, ampmax_in=-9999.0):
+        """vamd_analyze_block: host numpy pcm[ch][n] in, host numpy results out (the per-block
+        compatibility path that sits behind vorbis_analysis())."""
+        ch, n = self.channels, self.blocksizes[W]
+        n2 = n // 2
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        assert pcm.shape == (ch, n)
+        ptrs = (_vp * ch)(*[_vp(pcm[i].ctypes.data) for i in range(ch)])
+        o = dict(mdct=np.empty((ch, n2), np.float32), logmask=np.empty((ch, n2), np.float32),
+                 posts=np.empty((ch, POSTS_STRIDE), np.int32), post_valid=np.empty(ch, np.int32),
+                 iwork=np.empty((ch, n2), np.int32), nonzero=np.empty(ch, np.int32))
+        amp = C.c_float(0)
+        self._bind_stream()
+        self._check(self.L.vamd_analyze_block(self.h, ptrs, lW, W, nW, blocktype, ampmax_in,
+                                              _vp(o["mdct"].ctypes.data), _vp(o["logmask"].ctypes.data),
+                                              _vp(o["posts"].ctypes.data), _vp(o["post_valid"].ctypes.data),
+                                              _vp(o["iwork"].ctypes.data), _vp(o["nonzero"].ctypes.data),
+                                              C.byref(amp)))
+        o["ampmax_out"] = amp.value
+        return o

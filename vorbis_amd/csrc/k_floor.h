@@ -39,7 +39,7 @@ struct FloorScratch {
 
 // _vp_offset_and_mix with offset_select == 1 (the only select the VBR path uses)
 VAMD_DEV void offset_and_mix_wave(const PsyP &P, const float *__restrict__ noise, const float *__restrict__ tone,
-                                  const float *__restrict__ logmdct_in, float *__restrict__ mdct_io_src,
+                                  const float *__restrict__ logmdct_in, const float *__restrict__ mdct_io_src,
                                   float *__restrict__ mdct_out, float *mask, float *lmd) {
   const int n = P.n;
   const float toneatt = P.tone_masteratt1;

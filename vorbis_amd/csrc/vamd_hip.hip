@@ -1,0 +1,536 @@
+// vamd_hip.hip -- libvorbis_amd.so: the gfx950 kernels (thin __global__ shells
+// around the wave-level bodies in k_*.h) and the C ABI of include/vorbis_amd.h.
+//
+// Launch geometry: one 64-lane wavefront per workgroup, one workgroup per
+// channel-block (per block for the coupling stage).  A 65 536-block stereo batch
+// is 131 072 workgroups per stage -- ~500 per CU -- so the chip is filled many
+// times over and the per-wave latency of the ordered sections (running sums,
+// seed_chase, the greedy floor split) is hidden by the other resident waves.
+// Intermediates between stages live in an HBM workspace owned by the context;
+// a tensor the caller asked for is written straight to the caller's buffer.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (mandatory: the
+// reference's results depend on separately rounded mul/add).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "vorbis_amd.h"
+#include "vamd_bind.h"
+#include "k_transform.h"
+#include "k_noise.h"
+#include "k_tone.h"
+#include "k_floor.h"
+#include "k_couple.h"
+
+using namespace vamd;
+
+// ---------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------
+extern __shared__ __attribute__((aligned(16))) unsigned char vamd_smem[];
+
+__device__ __forceinline__ int d_lW(const DescP &d, long b) { return d.lW ? d.lW[b] : d.u_lW; }
+__device__ __forceinline__ int d_nW(const DescP &d, long b) { return d.nW ? d.nW[b] : d.u_nW; }
+__device__ __forceinline__ int d_bt(const DescP &d, long b) { return d.blocktype ? d.blocktype[b] : d.u_blocktype; }
+__device__ __forceinline__ float d_amp(const DescP &d, long b) { return d.ampmax_in ? d.ampmax_in[b] : d.u_ampmax_in; }
+
+// mdct_forward only (BASELINE config 2): in[nframes][n] -> out[nframes][n/2]
+__global__ __launch_bounds__(64) void k_mdct_only(XformP P, int W, const float *__restrict__ in,
+                                                  float *__restrict__ out) {
+  float *A = (float *)vamd_smem, *B = A + P.n;
+  const long f = blockIdx.x;
+  const int n2 = P.n >> 1;
+  load_windowed(P, W, 1, 1, in + f * P.n, A, false);
+  WAVE_SYNC();
+  mdct_forward_wave(P, A, B, B + n2);
+  WAVE_FOR(j, n2) out[f * n2 + j] = B[n2 + j];
+}
+
+// stage 1: window + MDCT + FFT + logs, one wave per channel-block
+__global__ __launch_bounds__(64) void k_transform(XformP P, int W, DescP d, int ch, const float *__restrict__ pcm,
+                                                  float *__restrict__ mdct_raw, float *__restrict__ logmdct,
+                                                  float *__restrict__ logfft, float *__restrict__ local_ampmax) {
+  float *A = (float *)vamd_smem, *B = A + P.n;
+  const long cb = blockIdx.x;  // channel-block index = block*ch + channel
+  const long blk = cb / ch;
+  const int n = P.n, n2 = n >> 1;
+  const float amp = transform_block(P, W, d_lW(d, blk), d_nW(d, blk), pcm + cb * n, A, B, mdct_raw + cb * n2,
+                                    logmdct + cb * n2, logfft + cb * n2);
+  if (LANE == 0) local_ampmax[cb] = amp;
+}
+
+// stage 2: _vp_noisemask
+__global__ __launch_bounds__(64) void k_noise(PsyP P0, PsyP P1, DescP d, int ch, const float *__restrict__ logmdct,
+                                              float *__restrict__ noise) {
+  const long cb = blockIdx.x;
+  const long blk = cb / ch;
+  const PsyP &P = d_bt(d, blk) ? P1 : P0;
+  const int n2 = P.n;
+  float *S = (float *)vamd_smem, *nz = S + 5 * n2, *wk = nz + n2;
+  noisemask_block(P, logmdct + cb * n2, noise + cb * n2, S, nz, wk);
+}
+
+// block-level ampmax: global = max(ampmax_in, local[0..ch)); one thread per block
+__global__ void k_ampmax(DescP d, int ch, long nblocks, const float *__restrict__ local_ampmax,
+                         float *__restrict__ ampmax_glob) {
+  const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nblocks) return;
+  float g = d_amp(d, b);
+  for (int c = 0; c < ch; c++) {
+    const float l = local_ampmax[b * ch + c];
+    if (l > g) g = l;  // lib/mapping0.c:346
+  }
+  ampmax_glob[b] = g;  // becomes vbi->ampmax, lib/mapping0.c:576
+}
+
+// stream mode: the ampmax recurrence across blocks, serial in fp32:
+// in_k = max(out_{k-1} + secs*att, -9999), out_k = max(in_k, locals_k)
+__global__ void k_ampmax_stream(int ch, long nblocks, float secs, float att, float state,
+                                const float *__restrict__ local_ampmax, float *__restrict__ ampmax_in,
+                                float *__restrict__ ampmax_glob) {
+  if (blockIdx.x || threadIdx.x) return;
+  float amp = state;
+  for (long b = 0; b < nblocks; b++) {
+    amp += secs * att;  // _vp_ampmax_decay, lib/psy.c:837-848
+    if (amp < -9999) amp = -9999;
+    ampmax_in[b] = amp;
+    for (int c = 0; c < ch; c++) {
+      const float l = local_ampmax[b * ch + c];
+      if (l > amp) amp = l;
+    }
+    ampmax_glob[b] = amp;
+  }
+}
+
+// stage 3: _vp_tonemask
+__global__ __launch_bounds__(64) void k_tone(PsyP P0, PsyP P1, DescP d, int ch, const float *__restrict__ logfft,
+                                             const float *__restrict__ local_ampmax,
+                                             const float *__restrict__ ampmax_glob, float *__restrict__ tone) {
+  const long cb = blockIdx.x;
+  const long blk = cb / ch;
+  const PsyP &P = d_bt(d, blk) ? P1 : P0;
+  const int n2 = P.n, nl = P.total_octave_lines;
+  float *seed = (float *)vamd_smem;
+  float *ampstack = seed + nl;
+  int *posstack = (int *)(ampstack + nl);
+  float *flr = (float *)(posstack + nl);
+  tonemask_block(P, logfft + cb * n2, tone + cb * n2, ampmax_glob[blk], local_ampmax[cb], seed, posstack, ampstack,
+                 flr);
+}
+
+// stage 4: offset_and_mix + floor1_fit + floor curve
+__global__ __launch_bounds__(64) void k_floor(PsyP P0, PsyP P1, FloorP F, DescP d, int ch,
+                                              const float *__restrict__ noise, const float *__restrict__ tone,
+                                              const float *__restrict__ logmdct, const float *__restrict__ mdct_raw,
+                                              float *__restrict__ mdct, float *__restrict__ logmask_out,
+                                              int *__restrict__ posts, int *__restrict__ post_valid,
+                                              int *__restrict__ ilogmask, int *__restrict__ nonzero) {
+  const long cb = blockIdx.x;
+  const long blk = cb / ch;
+  const PsyP &P = d_bt(d, blk) ? P1 : P0;
+  const int n2 = P.n;
+  float *mask = (float *)vamd_smem, *lmd = mask + n2;
+  FloorScratch *sc = (FloorScratch *)(lmd + n2);
+  offset_and_mix_wave(P, noise + cb * n2, tone + cb * n2, logmdct + cb * n2, mdct_raw + cb * n2, mdct + cb * n2, mask,
+                      lmd);
+  if (logmask_out) WAVE_FOR(i, n2) logmask_out[cb * n2 + i] = mask[i];
+  const int nzf = floor_fit_render_block(F, n2, mask, lmd, sc, posts + cb * VAMD_POSTS_STRIDE, post_valid + cb,
+                                         ilogmask + cb * n2);
+  if (LANE == 0) nonzero[cb] = nzf;
+}
+
+// stage 5: couple / quantise / normalise, one wave per block (all channels)
+__global__ __launch_bounds__(64) void k_couple(PsyP P0, PsyP P1, CoupleP C, DescP d, const float *__restrict__ mdct,
+                                               const int *__restrict__ ilogmask, int *__restrict__ iwork,
+                                               int *__restrict__ nonzero) {
+  const long blk = blockIdx.x;
+  const PsyP &P = d_bt(d, blk) ? P1 : P0;
+  const int n2 = P.n, ch = C.ch;
+  CoupleLds L;
+  L.cand = (float *)vamd_smem;
+  L.key = L.cand + n2;
+  L.sgn = L.key + n2;
+  const float *mp[VAMD_MAX_CH];
+  const int *ip[VAMD_MAX_CH];
+  int *op[VAMD_MAX_CH];
+  int nz[VAMD_MAX_CH];
+  for (int c = 0; c < ch; c++) {
+    mp[c] = mdct + (blk * ch + c) * n2;
+    ip[c] = ilogmask + (blk * ch + c) * n2;
+    op[c] = iwork + (blk * ch + c) * n2;
+    nz[c] = nonzero[blk * ch + c];
+  }
+  WAVE_SYNC();  // every lane has read nonzero[] before lane 0 rewrites it
+  couple_block(C, P, n2, mp, ip, op, nz, L);
+  if (LANE == 0)
+    for (int c = 0; c < ch; c++) nonzero[blk * ch + c] = nz[c];
+}
+
+// ---------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------
+struct DevBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+};
+
+struct vamd_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  Bound B;                 // parameter structs bound to the HBM image
+  unsigned char *d_image = nullptr;
+  size_t image_bytes = 0;
+  std::string err;
+  // workspace, grown on demand (vamd_reserve to pre-size)
+  enum { WS_MDCT_RAW, WS_LOGMDCT, WS_LOGFFT, WS_NOISE, WS_TONE, WS_MDCT, WS_ILOGMASK, WS_IWORK, WS_POSTS, WS_POSTVALID,
+         WS_NONZERO, WS_LOCAL, WS_AMPIN, WS_AMPGLOB, WS_PCM, WS_COUNT };
+  DevBuf ws[WS_COUNT];
+  // pinned staging for the per-block host API
+  void *h_stage = nullptr;
+  size_t h_stage_bytes = 0;
+  // optional per-stage timing (vamd_profile): one event before each stage + one after the last
+  bool profile = false;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+  std::vector<int> ev_runs;  // number of stages of each recorded run
+};
+
+static void prof_mark(vamd_ctx *c) {
+  if (!c->profile) return;
+  if (c->ev_used == c->ev_pool.size()) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    c->ev_pool.push_back(e);
+  }
+  (void)hipEventRecord(c->ev_pool[c->ev_used++], c->stream);
+}
+
+static int fail(vamd_ctx *c, int code, const char *what, hipError_t e = hipSuccess) {
+  if (c) {
+    c->err = what;
+    if (e != hipSuccess) {
+      c->err += ": ";
+      c->err += hipGetErrorString(e);
+    }
+  }
+  return code;
+}
+
+#define HIP_TRY(c, expr)                                              \
+  do {                                                                \
+    hipError_t e__ = (expr);                                          \
+    if (e__ != hipSuccess) return fail((c), VAMD_EFAULT, #expr, e__); \
+  } while (0)
+
+static int ws_get(vamd_ctx *c, int which, size_t bytes, void **out) {
+  DevBuf &b = c->ws[which];
+  if (b.bytes < bytes) {
+    if (b.p) HIP_TRY(c, hipFree(b.p));
+    b.p = nullptr;
+    b.bytes = 0;
+    HIP_TRY(c, hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+  }
+  *out = b.p;
+  return VAMD_OK;
+}
+
+extern "C" {
+
+int vamd_create(vamd_ctx **out, const void *setup_blob, size_t blob_bytes, int device) {
+  if (!out) return VAMD_EINVAL;
+  *out = nullptr;
+  vamd_ctx *c = new (std::nothrow) vamd_ctx;
+  if (!c) return VAMD_EFAULT;
+  std::vector<unsigned char> image;
+  std::vector<uint32_t> doff;
+  std::vector<PsyDerived> derived;
+  int r = build_image(setup_blob, blob_bytes, &image, &doff, &derived, &c->err);
+  if (r != VAMD_OK) {
+    fprintf(stderr, "vamd_create: %s\n", c->err.c_str());
+    delete c;
+    return r;
+  }
+  hipError_t e = hipSuccess;
+  if (device >= 0) e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipGetDevice(&c->device);
+  if (e == hipSuccess) e = hipMalloc((void **)&c->d_image, image.size());
+  if (e == hipSuccess) e = hipMemcpy(c->d_image, image.data(), image.size(), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    fprintf(stderr, "vamd_create: HIP failure: %s\n", hipGetErrorString(e));
+    if (c->d_image) (void)hipFree(c->d_image);
+    delete c;
+    return VAMD_EFAULT;
+  }
+  c->image_bytes = image.size();
+  bind_params(image, doff, derived, c->d_image, &c->B);
+  *out = c;
+  return VAMD_OK;
+}
+
+void vamd_destroy(vamd_ctx *c) {
+  if (!c) return;
+  for (int i = 0; i < vamd_ctx::WS_COUNT; i++)
+    if (c->ws[i].p) (void)hipFree(c->ws[i].p);
+  if (c->h_stage) (void)hipHostFree(c->h_stage);
+  for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+  if (c->d_image) (void)hipFree(c->d_image);
+  delete c;
+}
+
+const char *vamd_last_error(const vamd_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int vamd_set_stream(vamd_ctx *c, void *s) {
+  if (!c) return VAMD_EINVAL;
+  c->stream = (hipStream_t)s;
+  return VAMD_OK;
+}
+
+int vamd_profile(vamd_ctx *c, int enable) {
+  if (!c) return VAMD_EINVAL;
+  c->profile = enable != 0;
+  c->ev_used = 0;
+  c->ev_runs.clear();
+  return VAMD_OK;
+}
+
+int vamd_stage_ms(vamd_ctx *c, float *ms, int nstages, int *runs) {
+  if (!c || !ms || nstages < 1) return VAMD_EINVAL;
+  for (int i = 0; i < nstages; i++) ms[i] = 0.f;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  size_t at = 0;
+  int nr = 0;
+  for (int st : c->ev_runs) {
+    for (int i = 0; i < st && i < nstages; i++) {
+      float t = 0.f;
+      HIP_TRY(c, hipEventElapsedTime(&t, c->ev_pool[at + i], c->ev_pool[at + i + 1]));
+      ms[i] += t;
+    }
+    at += st + 1;
+    nr++;
+  }
+  if (runs) *runs = nr;
+  c->ev_used = 0;
+  c->ev_runs.clear();
+  return VAMD_OK;
+}
+
+int vamd_channels(const vamd_ctx *c) { return c ? c->B.channels : VAMD_EINVAL; }
+int vamd_blocksize(const vamd_ctx *c, int W) { return (c && (W == 0 || W == 1)) ? c->B.bs[W] : VAMD_EINVAL; }
+int vamd_posts(const vamd_ctx *c, int W) { return (c && (W == 0 || W == 1)) ? c->B.floor[W].posts : VAMD_EINVAL; }
+
+struct WsPlan {
+  float *mdct_raw, *logmdct, *logfft, *noise, *tone, *mdct, *local, *ampin, *ampglob;
+  int32_t *ilogmask, *iwork, *posts, *post_valid, *nonzero;
+};
+
+// Resolve every inter-stage tensor: the caller's buffer when given, otherwise workspace.
+static int plan(vamd_ctx *c, int W, long nb, const vamd_batch_io *io, int level, WsPlan *p) {
+  const size_t ch = c->B.channels, n2 = c->B.bs[W] / 2;
+  const size_t per = (size_t)nb * ch * n2 * 4;
+  void *v;
+#define PICK(field, user, slot, bytes)                  \
+  if (user) {                                           \
+    p->field = user;                                    \
+  } else {                                              \
+    int r__ = ws_get(c, vamd_ctx::slot, (bytes), &v);   \
+    if (r__) return r__;                                \
+    p->field = (decltype(p->field))v;                   \
+  }
+  PICK(mdct_raw, io ? io->mdct_raw : nullptr, WS_MDCT_RAW, per);
+  PICK(logmdct, io ? io->logmdct : nullptr, WS_LOGMDCT, per);
+  PICK(logfft, io ? io->logfft : nullptr, WS_LOGFFT, per);
+  PICK(local, io ? io->local_ampmax : nullptr, WS_LOCAL, (size_t)nb * ch * 4);
+  PICK(ampglob, io ? io->ampmax_out : nullptr, WS_AMPGLOB, (size_t)nb * 4);
+  PICK(ampin, (float *)nullptr, WS_AMPIN, (size_t)nb * 4);
+  if (level >= VAMD_LEVEL_PSY) {
+    PICK(noise, io ? io->noise : nullptr, WS_NOISE, per);
+    PICK(tone, io ? io->tone : nullptr, WS_TONE, per);
+  }
+  if (level >= VAMD_LEVEL_FULL) {
+    PICK(mdct, io ? io->mdct : nullptr, WS_MDCT, per);
+    PICK(ilogmask, io ? io->ilogmask : nullptr, WS_ILOGMASK, per);
+    PICK(iwork, io ? io->iwork : nullptr, WS_IWORK, per);
+    PICK(posts, io ? io->posts : nullptr, WS_POSTS, (size_t)nb * ch * VAMD_POSTS_STRIDE * 4);
+    PICK(post_valid, io ? io->post_valid : nullptr, WS_POSTVALID, (size_t)nb * ch * 4);
+    PICK(nonzero, io ? io->nonzero : nullptr, WS_NONZERO, (size_t)nb * ch * 4);
+  }
+#undef PICK
+  return VAMD_OK;
+}
+
+int vamd_reserve(vamd_ctx *c, int W, long max_blocks) {
+  if (!c || (W != 0 && W != 1) || max_blocks < 1) return VAMD_EINVAL;
+  WsPlan p;
+  return plan(c, W, max_blocks, nullptr, VAMD_LEVEL_FULL, &p);
+}
+
+int vamd_mdct_forward_batch(vamd_ctx *c, int W, const float *in, float *out, long nframes) {
+  if (!c || (W != 0 && W != 1) || !in || !out || nframes < 0) return VAMD_EINVAL;
+  if (nframes == 0) return VAMD_OK;
+  if (nframes > 0x7fffffffL) return fail(c, VAMD_EINVAL, "too many frames for one launch");
+  const XformP &P = c->B.xf[W];
+  hipLaunchKernelGGL(k_mdct_only, dim3((unsigned)nframes), dim3(64), (size_t)P.n * 8, c->stream, P, W, in, out);
+  HIP_TRY(c, hipGetLastError());
+  return VAMD_OK;
+}
+
+static int check_desc(vamd_ctx *c, const vamd_batch_desc *d, const vamd_batch_io *io) {
+  if (!c) return VAMD_EINVAL;
+  if (!d || !io || !io->pcm) return fail(c, VAMD_EINVAL, "null descriptor / io / pcm");
+  if (d->W != 0 && d->W != 1) return fail(c, VAMD_EINVAL, "W must be 0 or 1");
+  if (d->nblocks < 0 || d->nblocks * (long)c->B.channels > 0x7fffffffL)
+    return fail(c, VAMD_EINVAL, "nblocks out of range");
+  if (!d->blocktype && (d->uniform_blocktype != 0 && d->uniform_blocktype != 1))
+    return fail(c, VAMD_EINVAL, "blocktype must be 0 or 1");
+  if (!d->lW && (d->uniform_lW & ~1)) return fail(c, VAMD_EINVAL, "lW must be 0 or 1");
+  if (!d->nW && (d->uniform_nW & ~1)) return fail(c, VAMD_EINVAL, "nW must be 0 or 1");
+  return VAMD_OK;
+}
+
+// the launch sequence shared by batch and stream mode
+static int run_batch(vamd_ctx *c, const vamd_batch_desc *desc, const vamd_batch_io *io, int level, bool stream_mode,
+                     float *ampmax_state) {
+  const int W = desc->W, ch = c->B.channels;
+  const long nb = desc->nblocks;
+  if (nb == 0) return VAMD_OK;
+  WsPlan p;
+  memset(&p, 0, sizeof(p));
+  int r = plan(c, W, nb, io, level, &p);
+  if (r) return r;
+  const XformP &X = c->B.xf[W];
+  const PsyP &P0 = c->B.psy[2 * W], &P1 = c->B.psy[2 * W + 1];
+  const int n = X.n, n2 = n / 2, nl = P0.total_octave_lines > P1.total_octave_lines ? P0.total_octave_lines
+                                                                                     : P1.total_octave_lines;
+  DescP d;
+  d.lW = desc->lW;
+  d.nW = desc->nW;
+  d.blocktype = desc->blocktype;
+  d.ampmax_in = desc->ampmax_in;
+  d.u_lW = desc->uniform_lW;
+  d.u_nW = desc->uniform_nW;
+  d.u_blocktype = desc->uniform_blocktype;
+  d.u_ampmax_in = desc->uniform_ampmax_in;
+  const unsigned gcb = (unsigned)(nb * ch), gb = (unsigned)nb;
+  hipStream_t s = c->stream;
+
+  int nst = 0;
+  prof_mark(c);
+  hipLaunchKernelGGL(k_transform, dim3(gcb), dim3(64), (size_t)n * 8, s, X, W, d, ch, io->pcm, p.mdct_raw, p.logmdct,
+                     p.logfft, p.local);
+  prof_mark(c), nst++;
+  if (stream_mode) {
+    const float secs = (float)n2 / (float)c->B.rate;  // lib/psy.c:842-843
+    hipLaunchKernelGGL(k_ampmax_stream, dim3(1), dim3(1), 0, s, ch, nb, secs, c->B.ampmax_att_per_sec, *ampmax_state,
+                       p.local, p.ampin, p.ampglob);
+    d.ampmax_in = p.ampin;
+  } else {
+    hipLaunchKernelGGL(k_ampmax, dim3((gb + 255) / 256), dim3(256), 0, s, d, ch, nb, p.local, p.ampglob);
+  }
+  prof_mark(c), nst++;
+  if (level >= VAMD_LEVEL_PSY) {
+    hipLaunchKernelGGL(k_noise, dim3(gcb), dim3(64), (size_t)n2 * 7 * 4, s, P0, P1, d, ch, p.logmdct, p.noise);
+    prof_mark(c), nst++;
+    hipLaunchKernelGGL(k_tone, dim3(gcb), dim3(64), (size_t)(3 * nl + n2) * 4, s, P0, P1, d, ch, p.logfft, p.local,
+                       p.ampglob, p.tone);
+    prof_mark(c), nst++;
+  }
+  if (level >= VAMD_LEVEL_FULL) {
+    hipLaunchKernelGGL(k_floor, dim3(gcb), dim3(64), (size_t)n2 * 8 + sizeof(FloorScratch), s, P0, P1, c->B.floor[W],
+                       d, ch, p.noise, p.tone, p.logmdct, p.mdct_raw, p.mdct, io->logmask, p.posts, p.post_valid,
+                       p.ilogmask, p.nonzero);
+    prof_mark(c), nst++;
+    hipLaunchKernelGGL(k_couple, dim3(gb), dim3(64), (size_t)n2 * 12, s, P0, P1, c->B.couple[W], d, p.mdct, p.ilogmask,
+                       p.iwork, p.nonzero);
+    prof_mark(c), nst++;
+  }
+  if (c->profile) c->ev_runs.push_back(nst);
+  HIP_TRY(c, hipGetLastError());
+  if (stream_mode) {
+    // new state = ampmax_out of the last block
+    HIP_TRY(c, hipMemcpyAsync(ampmax_state, p.ampglob + (nb - 1), sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+  }
+  return VAMD_OK;
+}
+
+int vamd_analyze_batch(vamd_ctx *c, const vamd_batch_desc *desc, const vamd_batch_io *io, int level) {
+  int r = check_desc(c, desc, io);
+  if (r) return r;
+  if (level < VAMD_LEVEL_TRANSFORM || level > VAMD_LEVEL_FULL) return fail(c, VAMD_EINVAL, "bad level");
+  return run_batch(c, desc, io, level, false, nullptr);
+}
+
+int vamd_analyze_stream(vamd_ctx *c, const vamd_batch_desc *desc, const vamd_batch_io *io, float *ampmax_state) {
+  int r = check_desc(c, desc, io);
+  if (r) return r;
+  if (!ampmax_state) return fail(c, VAMD_EINVAL, "null ampmax_state");
+  return run_batch(c, desc, io, VAMD_LEVEL_FULL, true, ampmax_state);
+}
+
+int vamd_analyze_block(vamd_ctx *c, const float *const *pcm, int lW, int W, int nW, int blocktype, float ampmax_in,
+                       float *mdct, float *logmask, int32_t *posts, int32_t *post_valid, int32_t *iwork,
+                       int32_t *nonzero, float *ampmax_out) {
+  if (!c) return VAMD_EINVAL;
+  if (!pcm || (W != 0 && W != 1)) return fail(c, VAMD_EINVAL, "bad pcm / W");
+  const int ch = c->B.channels, n = c->B.bs[W], n2 = n / 2;
+  // one pinned + one device arena: [pcm | mdct | logmask | iwork | posts | post_valid | nonzero | ampmax]
+  const size_t o_pcm = 0, o_mdct = o_pcm + (size_t)ch * n * 4, o_mask = o_mdct + (size_t)ch * n2 * 4,
+               o_iwork = o_mask + (size_t)ch * n2 * 4, o_posts = o_iwork + (size_t)ch * n2 * 4,
+               o_valid = o_posts + (size_t)ch * VAMD_POSTS_STRIDE * 4, o_nz = o_valid + (size_t)ch * 4,
+               o_amp = o_nz + (size_t)ch * 4, total = o_amp + 16;
+  if (c->h_stage_bytes < total) {
+    if (c->h_stage) HIP_TRY(c, hipHostFree(c->h_stage));
+    c->h_stage = nullptr;
+    c->h_stage_bytes = 0;
+    HIP_TRY(c, hipHostMalloc(&c->h_stage, total, hipHostMallocDefault));
+    c->h_stage_bytes = total;
+  }
+  void *dv;
+  int r = ws_get(c, vamd_ctx::WS_PCM, total, &dv);
+  if (r) return r;
+  unsigned char *hs = (unsigned char *)c->h_stage, *ds = (unsigned char *)dv;
+  for (int i = 0; i < ch; i++) {
+    if (!pcm[i]) return fail(c, VAMD_EINVAL, "null channel pointer");
+    memcpy(hs + o_pcm + (size_t)i * n * 4, pcm[i], (size_t)n * 4);
+  }
+  hipStream_t s = c->stream;
+  HIP_TRY(c, hipMemcpyAsync(ds + o_pcm, hs + o_pcm, (size_t)ch * n * 4, hipMemcpyHostToDevice, s));
+  vamd_batch_desc d;
+  memset(&d, 0, sizeof(d));
+  d.W = W;
+  d.nblocks = 1;
+  d.uniform_lW = lW;
+  d.uniform_nW = nW;
+  d.uniform_blocktype = blocktype;
+  d.uniform_ampmax_in = ampmax_in;
+  vamd_batch_io io;
+  memset(&io, 0, sizeof(io));
+  io.pcm = (const float *)(ds + o_pcm);
+  io.mdct = (float *)(ds + o_mdct);
+  io.logmask = (float *)(ds + o_mask);
+  io.iwork = (int32_t *)(ds + o_iwork);
+  io.posts = (int32_t *)(ds + o_posts);
+  io.post_valid = (int32_t *)(ds + o_valid);
+  io.nonzero = (int32_t *)(ds + o_nz);
+  io.ampmax_out = (float *)(ds + o_amp);
+  r = vamd_analyze_batch(c, &d, &io, VAMD_LEVEL_FULL);
+  if (r) return r;
+  HIP_TRY(c, hipMemcpyAsync(hs + o_mdct, ds + o_mdct, total - o_mdct, hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  if (mdct) memcpy(mdct, hs + o_mdct, (size_t)ch * n2 * 4);
+  if (logmask) memcpy(logmask, hs + o_mask, (size_t)ch * n2 * 4);
+  if (iwork) memcpy(iwork, hs + o_iwork, (size_t)ch * n2 * 4);
+  if (posts) memcpy(posts, hs + o_posts, (size_t)ch * VAMD_POSTS_STRIDE * 4);
+  if (post_valid) memcpy(post_valid, hs + o_valid, (size_t)ch * 4);
+  if (nonzero) memcpy(nonzero, hs + o_nz, (size_t)ch * 4);
+  if (ampmax_out) memcpy(ampmax_out, hs + o_amp, 4);
+  return VAMD_OK;
+}
+
+}  // extern "C"
