@@ -1,0 +1,238 @@
+#!/usr/bin/env python
+"""bench.py -- throughput of the per-block Vorbis encode analysis on MI355X.
+
+A "step" is one pass of the hot path over one batch of synthetic 44.1 kHz stereo white-noise
+blocks that is already resident in HBM.  Default workload (BASELINE.json config 4, per-GPU
+shard): 131 072 stereo 2048-sample blocks per GPU through the FULL mapping0_forward analysis
+(window + MDCT + FFT + noise/tone masking + floor1 fit + couple/quantise), q=0.4 tables,
+(lW,W,nW)=(1,1,1), blocktype LONG, ampmax_in=-9999 for every block (SURVEY.md 8d "C4").
+`--workload c3` stops after the masking curves (config 3), `--workload c2` is mdct_forward only
+(config 2).
+
+  python bench.py --gpus 1 --steps 10 --warmup 2
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: one process per GPU; rank 0 loads the setup blob and broadcasts its bytes over
+RCCL (the only collective: blocks are independent); every rank then analyses its
+own shard (weak scaling).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+
+# algorithmic HBM bytes per unit, fp32/int32, every tensor touched once, tables excluded
+# (restated in DESIGN.md 5)
+ALG_BYTES = {
+    "c2": 12288,   # per channel-frame: 8192 in + 4096 out
+    "c3": 40960,   # per stereo block: 16384 in + mdct 8192 + noise 8192 + tone 8192
+    "c4": 41216,   # per stereo block: 16384 in + mdct 8192 + logmask 8192 + iwork 8192 + 256 posts/flags
+}
+# what each stage kernel of the unfused pipeline itself must move per stereo block
+STAGE_BYTES = {
+    "transform": 16384 + 3 * 8192 + 8, "ampmax": 12, "noisemask": 2 * 8192, "tonemask": 2 * 8192 + 12,
+    "floor": 4 * 8192 + 3 * 8192 + 256 + 16, "couple": 3 * 8192 + 16,
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", choices=("c2", "c3", "c4"), default="c4")
+    ap.add_argument("--blocks", type=int, default=None, help="stereo blocks per GPU (default 131072; c2/c3: 65536)")
+    ap.add_argument("--setup", default="44k_stereo_q4")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(setup_name, seconds):
+    """Reference libvorbis (oracle/_ref, unmodified sources) -- or the C port if the prebuilt
+    reference is absent -- timed on this box's host cores, one encoder state per thread, on a
+    bounded sample of the same white-noise workload.  Reported, not a target."""
+    from tests import checker
+    from oracle import ref
+    ch, rate, q = checker.SETUPS[setup_name]
+    cores = os.cpu_count() or 1
+    nthreads = min(cores, 64)
+    sample_blocks = 256
+    rng = np.random.default_rng(99)
+    pcm = (rng.random((sample_blocks, ch, 2048), dtype=np.float32) - 0.5).astype(np.float32)
+    if ref.available():
+        kind = "reference"
+        make = lambda: ref.RefEncoder(ch, rate, q)  # noqa: E731
+    else:
+        from oracle import port
+        kind = "port"
+        blob = np.fromfile(os.path.join(ROOT, "vorbis_amd", "data", "setup_%s.bin" % setup_name), dtype=np.uint8)
+        make = lambda: port.PortEncoder(blob)  # noqa: E731
+    encs = [make() for _ in range(nthreads)]
+    done = [0] * nthreads
+    cpu_time = [0.0] * nthreads
+    deadline = time.time() + seconds
+
+    def work(i):
+        e = encs[i]
+        while time.time() < deadline:
+            cpu_time[i] += e.time_dsp(pcm, 1)
+            done[i] += sample_blocks
+
+    t0 = time.time()
+    th = [threading.Thread(target=work, args=(i,)) for i in range(nthreads)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    wall = time.time() - t0
+    total = sum(done)
+    return {
+        "value": total / wall, "unit": "stereo blocks/s", "cores": nthreads, "kind": kind,
+        "per_core": total / max(sum(cpu_time), 1e-9),
+        "sample": "%d threads x repeated passes over %d seeded white-noise stereo 2048-blocks for %.0f s wall "
+                  "(%d blocks total); window+MDCT+FFT+psy+floor1 fit/encode+couple/quantise of "
+                  "mapping0_forward (the part the GPU path computes; residue VQ/Huffman excluded)"
+                  % (nthreads, sample_blocks, wall, total),
+    }
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    import vorbis_amd
+    # rank 0 owns the setup blob; everyone else receives it over RCCL
+    if rank == 0:
+        blob = torch.from_numpy(vorbis_amd.default_setup_blob(a.setup).copy()).to(dev)
+        size = torch.tensor([blob.numel()], dtype=torch.int64, device=dev)
+    else:
+        size = torch.zeros(1, dtype=torch.int64, device=dev)
+    if dist:
+        dist.broadcast(size, 0)
+        if rank != 0:
+            blob = torch.empty(int(size.item()), dtype=torch.uint8, device=dev)
+        dist.broadcast(blob, 0)
+    an = vorbis_amd.Analyzer(blob.cpu().numpy(), device=dev.index)
+    ch = an.channels
+    n = an.blocksizes[1]
+
+    nb = a.blocks or (131072 if a.workload == "c4" else 65536)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    if a.workload == "c2":
+        frames = torch.rand((nb, n), generator=g, device=dev, dtype=torch.float32) - 0.5
+        out = torch.empty((nb, n // 2), device=dev, dtype=torch.float32)
+
+        def step():
+            an.mdct_forward(1, frames, out=out)
+        units, unit_name = nb, "2048-sample frames/s"
+    else:
+        pcm = torch.rand((nb, ch, n), generator=g, device=dev, dtype=torch.float32) - 0.5
+        level = vorbis_amd.LEVEL_FULL if a.workload == "c4" else vorbis_amd.LEVEL_PSY
+        want = ("mdct", "logmask", "posts", "post_valid", "iwork", "nonzero", "ampmax_out") if a.workload == "c4" \
+            else ("mdct_raw", "noise", "tone")
+        outs = an.alloc_outputs(1, nb, want)
+        an.reserve(1, nb)
+
+        def step():
+            an.analyze(pcm, W=1, lW=1, nW=1, blocktype=1, ampmax_in=-9999.0, level=level, outs=outs)
+        units, unit_name = nb, "stereo blocks/s"
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    if a.workload != "c2":
+        an.profile(True)
+    else:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    if a.workload == "c2":
+        ev0.record()
+    for _ in range(a.steps):
+        step()
+    if a.workload == "c2":
+        ev1.record()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # per-kernel durations from HIP events recorded on the launch stream inside the timed region
+    if a.workload != "c2":
+        ms, runs = an.stage_ms()
+        stage_ms = {k: v / max(runs, 1) for k, v in ms.items() if v > 0}
+        an.profile(False)
+    else:
+        stage_ms = {"mdct_forward": ev0.elapsed_time(ev1) / a.steps}
+
+    if rank == 0:
+        value = world * units * a.steps / elapsed
+        kernels_ms = sum(stage_ms.values())
+        dom = max(stage_ms, key=stage_ms.get)
+        alg = ALG_BYTES[a.workload] * units                      # bytes per step per GPU, algorithmic
+        achieved = alg / (kernels_ms * 1e-3) / 1e9                # GB/s over the path's kernels
+        dom_bytes = (STAGE_BYTES.get(dom, ALG_BYTES["c2"]) * units)
+        roof = {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "definition": "algorithmic bytes of the whole path per step (%d B/unit x %d units) / summed "
+                          "HIP-event duration of the path's stage kernels per step" % (ALG_BYTES[a.workload], units),
+            "kernels_ms_per_step": stage_ms,
+            "dominant_kernel": {"name": dom, "ms": stage_ms[dom], "own_bytes_per_step": dom_bytes,
+                                "own_GBps": dom_bytes / (stage_ms[dom] * 1e-3) / 1e9},
+        }
+        line = {
+            "metric": "audio blocks/s (2048-sample MDCT+psy) @1/2/4/8 GPU; % HBM roofline",
+            "value": value, "unit": unit_name, "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": {"c4": "C4 full mapping0_forward analysis (window+MDCT+FFT+noise/tone mask+floor1 fit+"
+                                   "couple/quantise), %d stereo 2048-blocks per GPU, 44.1 kHz q=0.4 tables, "
+                                   "white noise, independent frames, inputs resident in HBM" % nb,
+                             "c3": "C3 MDCT + _vp_noisemask/_vp_tonemask, %d stereo 2048-blocks per GPU" % nb,
+                             "c2": "C2 batched mdct_forward only, %d x n=2048 frames per GPU" % nb}[a.workload],
+                "blocks_per_gpu": nb, "setup": a.setup, "parallelism": "blocks sharded x%d, no data-path collective" % world,
+            },
+            "roofline": roof,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(a.setup, a.cpu_seconds)
+            except Exception as e:  # a missing checker must not lose the GPU number
+                line["cpu_baseline"] = {"value": None, "error": repr(e)}
+        print(json.dumps(line))
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

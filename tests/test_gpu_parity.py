@@ -1,0 +1,214 @@
+"""GPU suite (-m gpu): the HIP path, called through the C ABI, against the oracle.
+
+Everything is bit-exact: the integer outputs by definition, the float outputs because the
+kernels evaluate the reference's own expression trees in fp32/fp64 without contraction (the
+1e-5 relative tolerance of BASELINE.json is therefore met with margin zero).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from tests import checker, golden_io
+
+pytestmark = pytest.mark.gpu
+ROOT = checker.ROOT
+ALL = ("mdct_raw", "logfft", "logmdct", "noise", "tone", "logmask", "mdct", "posts", "post_valid", "ilogmask",
+       "iwork", "nonzero", "local_ampmax", "ampmax_out")
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def analyzer(name):
+    import vorbis_amd
+    return vorbis_amd.Analyzer(vorbis_amd.default_setup_blob(name), device=0)
+
+
+def bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint32) if a.dtype == np.float32 else a
+
+
+def run_blocks(torch, an, blocks, W):
+    sel = [b for b in blocks if b["W"] == W]
+    if not sel:
+        return [], {}
+    P = torch.from_numpy(np.stack([b["pcm"] for b in sel])).cuda()
+    dv = lambda k, dt: torch.tensor([b[k] for b in sel], dtype=dt).cuda()  # noqa: E731
+    outs = an.analyze(P, W=W, lW=dv("lW", torch.int32), nW=dv("nW", torch.int32),
+                      blocktype=dv("blocktype", torch.int32), ampmax_in=dv("ampmax_in", torch.float32), want=ALL)
+    torch.cuda.synchronize()
+    return sel, {k: v.cpu().numpy() for k, v in outs.items()}
+
+
+def test_library_is_the_hip_build(torch_mod):
+    import vorbis_amd
+    L = vorbis_amd.load_library()
+    assert os.path.samefile(vorbis_amd.library_path(), os.path.join(ROOT, "vorbis_amd", "libvorbis_amd.so"))
+    assert L.vamd_create and L.vamd_analyze_batch
+
+
+@pytest.mark.parametrize("name", list(checker.SETUPS))
+def test_golden_blocks(torch_mod, name):
+    """Committed fixtures from the reference: long/short/transition windows, impulse/padding block
+    types, chained ampmax, silence, a pure tone; q 0.1 exercises noise normalisation's sort."""
+    blocks, posts, fn = golden_io.load(name)
+    an = analyzer(name)
+    for W in (0, 1):
+        x = torch_mod.from_numpy(fn["mdct%d_in" % W][None, :].copy()).cuda()
+        y = an.mdct_forward(W, x).cpu().numpy()[0]
+        assert np.array_equal(bits(y), bits(fn["mdct%d_out" % W]))
+        sel, outs = run_blocks(torch_mod, an, blocks, W)
+        for i, b in enumerate(sel):
+            got = {k: v[i] for k, v in outs.items()}
+            assert checker.compare_block(b, got, posts[W], verbose=True) == 0
+
+
+@pytest.mark.parametrize("name", ["44k_stereo_q4", "44k_stereo_q9", "44k_stereo_q1", "44k_mono_q5"])
+def test_random_blocks_vs_oracle(torch_mod, name):
+    torch = torch_mod
+    chk = checker.Checker(name)
+    an = analyzer(name)
+    ch = an.channels
+    rng = np.random.default_rng(31337)
+    nb = 96
+    amps = np.array([0.5, 0.01, 1.0, 1e-4, 0.2, 0.05])[np.arange(nb) % 6].astype(np.float32)
+    pcm = ((rng.random((nb, ch, 2048), dtype=np.float32) - 0.5) * 2 * amps[:, None, None]).astype(np.float32)
+    if ch == 2:
+        pcm[5::7, 1] = pcm[5::7, 0] * 0.5     # correlated channels
+        pcm[3::11, 1] = 0                       # one silent channel: zero floor + coupling fix-up
+    pcm[17] = 0                                 # digital silence
+    amp_in = np.where(np.arange(nb) % 3 == 0, -9999.0, -35.0).astype(np.float32)
+    outs = an.analyze(torch.from_numpy(pcm).cuda(), W=1, ampmax_in=torch.from_numpy(amp_in).cuda(), want=ALL)
+    torch.cuda.synchronize()
+    outs = {k: v.cpu().numpy() for k, v in outs.items()}
+    bad = 0
+    for b in range(nb):
+        ref = chk.tap_block(pcm[b], ampmax_in=float(amp_in[b]))
+        bad += checker.compare_block(ref, {k: v[b] for k, v in outs.items()}, an.posts[1], verbose=bad < 5)
+    assert bad == 0, "checker=%s" % chk.kind
+
+
+def test_mdct_forward_batch(torch_mod):
+    torch = torch_mod
+    chk = checker.Checker("44k_stereo_q4")
+    an = analyzer("44k_stereo_q4")
+    for W, nf in ((1, 4096), (0, 4096)):
+        n = an.blocksizes[W]
+        x = torch.rand((nf, n), device="cuda") - 0.5
+        y = an.mdct_forward(W, x)
+        torch.cuda.synchronize()
+        xs, ys = x.cpu().numpy(), y.cpu().numpy()
+        for i in list(range(0, nf, 97)) + [nf - 1]:
+            assert np.array_equal(bits(ys[i]), bits(chk.mdct_forward(W, xs[i])))
+    # empty batch is a no-op
+    e = torch.empty((0, an.blocksizes[1]), device="cuda")
+    assert an.mdct_forward(1, e).shape == (0, an.blocksizes[1] // 2)
+
+
+def test_levels_and_workspace_vs_user_buffers(torch_mod):
+    """LEVEL_TRANSFORM / LEVEL_PSY stop early; tensors kept in the internal workspace give the
+    same downstream results as tensors written to caller buffers."""
+    torch = torch_mod
+    import vorbis_amd
+    an = analyzer("44k_stereo_q4")
+    pcm = torch.rand((64, 2, 2048), device="cuda") - 0.5
+    full = an.analyze(pcm, want=ALL)
+    lean = an.analyze(pcm, want=("iwork", "nonzero", "posts"))
+    psy = an.analyze(pcm, level=vorbis_amd.LEVEL_PSY, want=("mdct_raw", "noise", "tone"))
+    tr = an.analyze(pcm, level=vorbis_amd.LEVEL_TRANSFORM, want=("mdct_raw", "logfft", "logmdct", "local_ampmax"))
+    torch.cuda.synchronize()
+    for k in ("iwork", "nonzero", "posts"):
+        assert torch.equal(full[k], lean[k])
+    for k in ("mdct_raw", "noise", "tone"):
+        assert torch.equal(full[k], psy[k])
+    for k in ("mdct_raw", "logfft", "logmdct", "local_ampmax"):
+        assert torch.equal(full[k], tr[k])
+
+
+def test_host_block_api_matches_batch(torch_mod):
+    torch = torch_mod
+    an = analyzer("44k_stereo_q4")
+    chk = checker.Checker("44k_stereo_q4")
+    rng = np.random.default_rng(9)
+    for W, lW, nW, bt in ((1, 1, 1, 1), (1, 0, 1, 0), (0, 0, 0, 1), (0, 0, 0, 0)):
+        n = an.blocksizes[W]
+        pcm = (rng.random((2, n), dtype=np.float32) - 0.5).astype(np.float32)
+        o = an.analyze_block(pcm, lW, W, nW, bt, -50.0)
+        ref = chk.tap_block(pcm, lW, W, nW, bt, -50.0)
+        assert checker.compare_block(ref, o, an.posts[W], keys=("mdct", "logmask", "post_valid", "iwork", "nonzero"),
+                                     verbose=True) == 0
+
+
+def test_stream_mode_ampmax_chain(torch_mod):
+    """vamd_analyze_stream reproduces the blockout->analysis ampmax recurrence (lib/block.c:626-628)."""
+    torch = torch_mod
+    chk = checker.Checker("44k_stereo_q4")
+    an = analyzer("44k_stereo_q4")
+    rng = np.random.default_rng(21)
+    nb = 40
+    gains = np.concatenate([np.full(10, 0.5), np.full(20, 0.001), np.full(10, 0.1)]).astype(np.float32)
+    pcm = ((rng.random((nb, 2, 2048), dtype=np.float32) - 0.5) * 2 * gains[:, None, None]).astype(np.float32)
+    outs, state = an.analyze_stream(torch.from_numpy(pcm).cuda(), -9999.0, want=("iwork", "ampmax_out", "posts", "nonzero"))
+    torch.cuda.synchronize()
+    amp = -9999.0
+    enc = chk.enc
+    got_amp = outs["ampmax_out"].cpu().numpy()
+    iw = outs["iwork"].cpu().numpy()
+    for b in range(nb):
+        amp_in = enc.ampmax_decay(amp, 1)
+        ref = chk.tap_block(pcm[b], ampmax_in=amp_in)
+        amp = ref["ampmax_out"]
+        assert np.float32(got_amp[b]) == np.float32(amp), b
+        assert np.array_equal(iw[b], ref["iwork"]), b
+    assert np.float32(state) == np.float32(amp)
+
+
+def test_full_size_properties(torch_mod):
+    """BASELINE size (65 536 stereo blocks): size-independent properties instead of an oracle run.
+    (1) determinism, (2) block k of a big batch == the same block analysed alone,
+    (3) a batch made by tiling 64 oracle-verified blocks reproduces the verified outputs in
+        every tile (checksum per tile), (4) MDCT linearity within fp32 rounding."""
+    torch = torch_mod
+    an = analyzer("44k_stereo_q4")
+    chk = checker.Checker("44k_stereo_q4")
+    nb = 65536
+    g = torch.Generator(device="cuda"); g.manual_seed(7)
+    base = torch.rand((64, 2, 2048), generator=g, device="cuda") - 0.5
+    want = ("mdct", "logmask", "iwork", "posts", "nonzero", "ampmax_out")
+    small = an.analyze(base, want=want)
+    torch.cuda.synchronize()
+    b0 = base.cpu().numpy()
+    for i in (0, 31, 63):
+        ref = chk.tap_block(b0[i])
+        assert checker.compare_block(ref, {k: v[i].cpu().numpy() for k, v in small.items()}, an.posts[1],
+                                     keys=("mdct", "logmask", "iwork", "nonzero"), verbose=True) == 0
+    big_in = base.repeat(nb // 64, 1, 1).contiguous()
+    big = an.analyze(big_in, want=want)
+    big2 = an.analyze(big_in, want=want)
+    torch.cuda.synchronize()
+    for k in want:
+        assert torch.equal(big[k], big2[k]), k                                   # (1)
+        tiles = big[k].reshape((nb // 64, 64) + tuple(big[k].shape[1:]))
+        assert bool((tiles == small[k].unsqueeze(0)).all()), k                  # (2),(3)
+    x = torch.rand((4096, 2048), device="cuda") - 0.5
+    y = torch.rand((4096, 2048), device="cuda") - 0.5
+    lhs = an.mdct_forward(1, (x + y).contiguous())
+    rhs = an.mdct_forward(1, x) + an.mdct_forward(1, y)
+    assert float((lhs - rhs).abs().max()) < 2e-6                                # (4)
+
+
+def test_argument_errors(torch_mod):
+    import vorbis_amd
+    an = analyzer("44k_stereo_q4")
+    pcm = torch_mod.rand((4, 2, 2048), device="cuda")
+    with pytest.raises(vorbis_amd.VamdError) as ei:
+        an.analyze(pcm, blocktype=3)
+    assert ei.value.code == -131  # OV_EINVAL
+    with pytest.raises(vorbis_amd.VamdError):
+        an.analyze(pcm, level=7)

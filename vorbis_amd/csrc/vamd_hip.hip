@@ -371,8 +371,9 @@ int vamd_reserve(vamd_ctx *c, int W, long max_blocks) {
 }
 
 int vamd_mdct_forward_batch(vamd_ctx *c, int W, const float *in, float *out, long nframes) {
-  if (!c || (W != 0 && W != 1) || !in || !out || nframes < 0) return VAMD_EINVAL;
+  if (!c || (W != 0 && W != 1) || nframes < 0) return VAMD_EINVAL;
   if (nframes == 0) return VAMD_OK;
+  if (!in || !out) return fail(c, VAMD_EINVAL, "null frame buffer");
   if (nframes > 0x7fffffffL) return fail(c, VAMD_EINVAL, "too many frames for one launch");
   const XformP &P = c->B.xf[W];
   hipLaunchKernelGGL(k_mdct_only, dim3((unsigned)nframes), dim3(64), (size_t)P.n * 8, c->stream, P, W, in, out);
