@@ -73,6 +73,12 @@ int vamd_reserve(vamd_ctx *ctx, int W, long max_blocks);
 int vamd_profile(vamd_ctx *ctx, int enable);
 int vamd_stage_ms(vamd_ctx *ctx, float *ms, int nstages, int *runs);
 
+/* Finer measurement hook: arm (enable=1) / disarm (0) an in-kernel stopwatch; while armed lane 0
+ * of every wave adds the shader-clock ticks each phase took to one of 80 slots (16 per stage:
+ * transform 0.., noisemask 16.., tonemask 32.., floor 48.., couple 64..).  If out80 is non-NULL
+ * the slots accumulated so far are copied out first. */
+int vamd_debug_cycles(vamd_ctx *ctx, int enable, unsigned long long *out80);
+
 int vamd_channels(const vamd_ctx *ctx);
 int vamd_blocksize(const vamd_ctx *ctx, int W);
 int vamd_posts(const vamd_ctx *ctx, int W);

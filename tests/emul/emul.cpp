@@ -47,8 +47,10 @@ int emul_mdct_forward(void *h, int W, const float *in, float *out) {
   Emul *e = (Emul *)h;
   const XformP &P = e->B.xf[W];
   std::vector<float> A(P.n), Bw(P.n);
+  PhaseClock pc;
+  pc.start(nullptr);
   load_windowed(P, W, 1, 1, in, A.data(), false);
-  mdct_forward_wave(P, A.data(), Bw.data(), Bw.data() + P.n / 2);
+  mdct_forward_wave(P, A.data(), Bw.data(), Bw.data() + P.n / 2, pc);
   memcpy(out, Bw.data() + P.n / 2, sizeof(float) * (P.n / 2));
   return 0;
 }
@@ -68,25 +70,28 @@ int emul_analyze_block(void *h, const float *pcm, int lW, int W, int nW, int blo
   std::vector<int> posts(ch * VAMD_POSTS_STRIDE), post_valid(ch), ilogmask(ch * n2), iwork(ch * n2), nonzero(ch);
   std::vector<float> local(ch);
   float global = ampmax_in;
+  PhaseClock pc;
+  pc.start(nullptr);
   for (int i = 0; i < ch; i++) {
     local[i] = transform_block(X, W, lW, nW, pcm + (size_t)i * n, A.data(), Bw.data(), &mdct_raw[i * n2],
-                               &logmdct[i * n2], &logfft[i * n2]);
+                               &logmdct[i * n2], &logfft[i * n2], pc);
     if (local[i] > global) global = local[i];
   }
   {
-    std::vector<float> S(5 * n2), nz(n2), wk(n2), seed(P.total_octave_lines), ampstack(P.total_octave_lines),
-        flr(n2);
-    std::vector<int> posstack(P.total_octave_lines);
+    const int nlp = (P.total_octave_lines + 15) & ~15;
+    std::vector<float> S(5 * n2), nz(n2), wk(n2), seed(nlp, -9999.f), ampstack(nlp), flr(n2), ring_amp(VAMD_RING);
+    std::vector<int> posstack(nlp), ring_pos(VAMD_RING);
+    std::vector<unsigned short> surv(nlp);
     FloorScratch sc;
     for (int i = 0; i < ch; i++) {
-      noisemask_block(P, &logmdct[i * n2], &noise[i * n2], S.data(), nz.data(), wk.data());
+      noisemask_block(P, &logmdct[i * n2], &noise[i * n2], S.data(), nz.data(), wk.data(), pc);
       tonemask_block(P, &logfft[i * n2], &tone[i * n2], global, local[i], seed.data(), posstack.data(),
-                     ampstack.data(), flr.data());
+                     ampstack.data(), flr.data(), ring_amp.data(), ring_pos.data(), surv.data(), pc);
       offset_and_mix_wave(P, &noise[i * n2], &tone[i * n2], &logmdct[i * n2], &mdct_raw[i * n2], &mdct[i * n2],
-                          mask.data(), lmd.data());
+                          mask.data(), lmd.data(), pc);
       memcpy(&logmask[i * n2], mask.data(), sizeof(float) * n2);
       nonzero[i] = floor_fit_render_block(F, n2, mask.data(), lmd.data(), &sc, &posts[i * VAMD_POSTS_STRIDE],
-                                          &post_valid[i], &ilogmask[i * n2]);
+                                          &post_valid[i], &ilogmask[i * n2], pc);
     }
   }
   {
@@ -100,7 +105,7 @@ int emul_analyze_block(void *h, const float *pcm, int lW, int W, int nW, int blo
       ip[i] = &ilogmask[i * n2];
       op[i] = &iwork[i * n2];
     }
-    couple_block(C, P, n2, mp, ip, op, nonzero.data(), L);
+    couple_block(C, P, n2, mp, ip, op, nonzero.data(), L, pc);
   }
 #define OUT(name, vec, type) \
   if (t->name) memcpy(t->name, vec.data(), sizeof(type) * vec.size())

@@ -16,7 +16,7 @@ BLOCKTYPE_IMPULSE, BLOCKTYPE_PADDING, BLOCKTYPE_TRANSITION, BLOCKTYPE_LONG = 0, 
 EXPORTED_SYMBOLS = ["vamd_create", "vamd_destroy", "vamd_last_error", "vamd_set_stream", "vamd_reserve",
                     "vamd_channels", "vamd_blocksize", "vamd_posts", "vamd_mdct_forward_batch",
                     "vamd_analyze_batch", "vamd_analyze_stream", "vamd_analyze_block", "vamd_profile",
-                    "vamd_stage_ms"]
+                    "vamd_stage_ms", "vamd_debug_cycles"]
 
 _vp = C.c_void_p
 
@@ -73,6 +73,7 @@ def load_library():
     L.vamd_analyze_stream.argtypes = [_vp, C.POINTER(_Desc), C.POINTER(_IO), C.POINTER(C.c_float)]
     L.vamd_analyze_block.argtypes = [_vp, C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _vp, _vp,
                                      _vp, _vp, _vp, _vp, C.POINTER(C.c_float)]
+    L.vamd_debug_cycles.argtypes = [_vp, C.c_int, _vp]
     L.vamd_profile.argtypes = [_vp, C.c_int]
     L.vamd_stage_ms.argtypes = [_vp, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]
     _lib = L
@@ -145,6 +146,12 @@ class Analyzer:
         runs = C.c_int(0)
         self._check(self.L.vamd_stage_ms(self.h, ms, 6, C.byref(runs)))
         return dict(zip(self.STAGES, [float(x) for x in ms])), runs.value
+
+    def debug_cycles(self, enable=True, read=False):
+        """Arm/disarm the in-kernel phase stopwatch; with read=True returns the 5x16 tick sums first."""
+        out = np.zeros(80, dtype=np.uint64)
+        self._check(self.L.vamd_debug_cycles(self.h, 1 if enable else 0, _vp(out.ctypes.data) if read else None))
+        return out.reshape(5, 16)
 
     def reserve(self, W, max_blocks):
         self._check(self.L.vamd_reserve(self.h, W, max_blocks))

@@ -78,7 +78,7 @@ VAMD_DEV void noise_norm_partition(const PsyP &P, const CoupleLds &L, int b0, in
 // iwork[k]     HBM [n2]  out: quantised (and coupled) residue
 // nonzero      [ch] in: floor1_encode's return per channel; out: after the coupling fix-up
 VAMD_DEV void couple_block(const CoupleP &C, const PsyP &P, int n2, const float *const *mdct,
-                           const int *const *ilogmask, int *const *iwork, int *nonzero, const CoupleLds &L) {
+                           const int *const *ilogmask, int *const *iwork, int *nonzero, const CoupleLds &L, PhaseClock &pc) {
   const int ch = C.ch;
   const int partition = P.normal_p ? P.normal_partition : 16;
   const int nstart = P.normal_p ? P.normal_start : 0x7fffffff;  // first bin subject to noise norm
@@ -126,6 +126,7 @@ VAMD_DEV void couple_block(const CoupleP &C, const PsyP &P, int n2, const float 
     }
   }
 
+  pc.mark(0);
   // ---- coupling (one step: magnitude Mi, angle Ai), lib/psy.c:1111-1201
   if (C.coupling_steps == 1 && (nz[C.mag] || nz[C.ang])) {
     const int Mi = C.mag, Ai = C.ang;
@@ -218,6 +219,7 @@ VAMD_DEV void couple_block(const CoupleP &C, const PsyP &P, int n2, const float 
     nz[Mi] = nz[Ai] = 1;
   }
   for (int k = 0; k < ch; k++) nonzero[k] = nz[k];
+  pc.mark(1);
 }
 
 }  // namespace vamd

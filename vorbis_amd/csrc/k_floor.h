@@ -35,12 +35,16 @@ struct FloorScratch {
   int segx[VAMD_MAXPOSTS + 1], segy[VAMD_MAXPOSTS + 1];
   int nseg;
   int nonzero;
+  // the floor's static index tables, staged once per block: the ordered sections
+  // below chase them serially and must not pay an HBM/L2 round trip per step
+  int postlist[VAMD_MAXPOSTS], sorted_index[VAMD_MAXPOSTS], forward_index[VAMD_MAXPOSTS],
+      reverse_index[VAMD_MAXPOSTS], hineighbor[VAMD_MAXPOSTS], loneighbor[VAMD_MAXPOSTS];
 };
 
 // _vp_offset_and_mix with offset_select == 1 (the only select the VBR path uses)
 VAMD_DEV void offset_and_mix_wave(const PsyP &P, const float *__restrict__ noise, const float *__restrict__ tone,
                                   const float *__restrict__ logmdct_in, const float *__restrict__ mdct_io_src,
-                                  float *__restrict__ mdct_out, float *mask, float *lmd) {
+                                  float *__restrict__ mdct_out, float *mask, float *lmd, PhaseClock &pc) {
   const int n = P.n;
   const float toneatt = P.tone_masteratt1;
   const float cx = P.m_val;
@@ -64,6 +68,7 @@ VAMD_DEV void offset_and_mix_wave(const PsyP &P, const float *__restrict__ noise
     mdct_out[i] = mdct_io_src[i] * de;
   }
   WAVE_SYNC();
+  pc.mark(0);
 }
 
 // accumulate_fit, lib/floor1.c:406-454, interval [x0, x1] inclusive
@@ -188,10 +193,16 @@ VAMD_DEV int render_point(int x0, int x1, int y0, int y1, int x) {
 // Returns floor1_encode's nonzero flag (1 = non-trivial floor).
 VAMD_DEV int floor_fit_render_block(const FloorP &F, int n2, const float *mask, const float *lmd,
                                     FloorScratch *sc, int *__restrict__ posts_out, int *__restrict__ post_valid,
-                                    int *__restrict__ ilogmask) {
+                                    int *__restrict__ ilogmask, PhaseClock &pc) {
   const int posts = F.posts, n = F.look_n;
 
   WAVE_FOR(i, posts) {
+    sc->postlist[i] = F.postlist[i];
+    sc->sorted_index[i] = F.sorted_index[i];
+    sc->forward_index[i] = F.forward_index[i];
+    sc->reverse_index[i] = F.reverse_index[i];
+    sc->hineighbor[i] = F.hineighbor[i];
+    sc->loneighbor[i] = F.loneighbor[i];
     sc->fitA[i] = -200;
     sc->fitB[i] = -200;
     sc->lon[i] = 0;
@@ -204,6 +215,7 @@ VAMD_DEV int floor_fit_render_block(const FloorP &F, int n2, const float *mask, 
     nz += accumulate_fit_one(mask, lmd, F.sorted_index[i], F.sorted_index[i + 1], &sc->acc[i], n, F.twofitatten);
   nz = wave_sum(nz);
   WAVE_SYNC();
+  pc.mark(1);
 
   if (!nz) {
     // floor1_fit returns NULL; floor1_encode writes a zero curve (lib/floor1.c:948-952)
@@ -218,30 +230,30 @@ VAMD_DEV int floor_fit_render_block(const FloorP &F, int n2, const float *mask, 
   // every lane performs identical LDS updates, so no exchange is needed.
   {
     int y0 = -200, y1 = -200;
-    fit_line(sc->acc, posts - 1, F.sorted_index[0], F.sorted_index[posts - 1], &y0, &y1, F.twofitweight);
+    fit_line(sc->acc, posts - 1, sc->sorted_index[0], sc->sorted_index[posts - 1], &y0, &y1, F.twofitweight);
     sc->fitA[0] = y0;
     sc->fitB[0] = y0;
     sc->fitB[1] = y1;
     sc->fitA[1] = y1;
   }
   for (int i = 2; i < posts; i++) {
-    const int sortpos = F.reverse_index[i];
+    const int sortpos = sc->reverse_index[i];
     const int ln = sc->lon[sortpos];
     const int hn = sc->hin[sortpos];
     if (sc->memo[ln] != hn) {
-      const int lsortpos = F.reverse_index[ln];
-      const int hsortpos = F.reverse_index[hn];
+      const int lsortpos = sc->reverse_index[ln];
+      const int hsortpos = sc->reverse_index[hn];
       sc->memo[ln] = hn;
-      const int lx = F.postlist[ln], hx = F.postlist[hn];
+      const int lx = sc->postlist[ln], hx = sc->postlist[hn];
       const int ly = post_Y(sc->fitA, sc->fitB, ln);
       const int hy = post_Y(sc->fitA, sc->fitB, hn);
       // (ly == -1 || hy == -1 => exit(1) in the reference: unreachable, fits are >= 0 or -200)
       if (inspect_error_wave(lx, hx, ly, hy, mask, lmd, F)) {
         int ly0 = -200, ly1 = -200, hy0 = -200, hy1 = -200;
-        const int ret0 = fit_line(sc->acc + lsortpos, sortpos - lsortpos, F.sorted_index[lsortpos],
-                                  F.sorted_index[sortpos], &ly0, &ly1, F.twofitweight);
-        const int ret1 = fit_line(sc->acc + sortpos, hsortpos - sortpos, F.sorted_index[sortpos],
-                                  F.sorted_index[hsortpos], &hy0, &hy1, F.twofitweight);
+        const int ret0 = fit_line(sc->acc + lsortpos, sortpos - lsortpos, sc->sorted_index[lsortpos],
+                                  sc->sorted_index[sortpos], &ly0, &ly1, F.twofitweight);
+        const int ret1 = fit_line(sc->acc + sortpos, hsortpos - sortpos, sc->sorted_index[sortpos],
+                                  sc->sorted_index[hsortpos], &hy0, &hy1, F.twofitweight);
         if (ret0) {
           ly0 = ly;
           ly1 = hy0;
@@ -280,13 +292,14 @@ VAMD_DEV int floor_fit_render_block(const FloorP &F, int n2, const float *mask, 
     }
   }
 
+  pc.mark(2);
   // ---- posts out, lib/floor1.c:700-724
   sc->out[0] = post_Y(sc->fitA, sc->fitB, 0);
   sc->out[1] = post_Y(sc->fitA, sc->fitB, 1);
   for (int i = 2; i < posts; i++) {
-    const int ln = F.loneighbor[i - 2], hn = F.hineighbor[i - 2];
+    const int ln = sc->loneighbor[i - 2], hn = sc->hineighbor[i - 2];
     const int predicted =
-        render_point(F.postlist[ln], F.postlist[hn], sc->out[ln], sc->out[hn], F.postlist[i]);
+        render_point(sc->postlist[ln], sc->postlist[hn], sc->out[ln], sc->out[hn], sc->postlist[i]);
     const int vx = post_Y(sc->fitA, sc->fitB, i);
     if (vx >= 0 && predicted != vx)
       sc->out[i] = vx;
@@ -309,9 +322,9 @@ VAMD_DEV int floor_fit_render_block(const FloorP &F, int n2, const float *mask, 
     sc->post[i] = val | (sc->out[i] & 0x8000);
   }
   for (int i = 2; i < posts; i++) {
-    const int ln = F.loneighbor[i - 2], hn = F.hineighbor[i - 2];
+    const int ln = sc->loneighbor[i - 2], hn = sc->hineighbor[i - 2];
     const int predicted =
-        render_point(F.postlist[ln], F.postlist[hn], sc->post[ln], sc->post[hn], F.postlist[i]);
+        render_point(sc->postlist[ln], sc->postlist[hn], sc->post[ln], sc->post[hn], sc->postlist[i]);
     if ((sc->post[i] & 0x8000) || (predicted == sc->post[i])) {
       sc->post[i] = predicted | 0x8000;
     } else {
@@ -327,17 +340,18 @@ VAMD_DEV int floor_fit_render_block(const FloorP &F, int n2, const float *mask, 
     sc->segx[0] = 0;
     sc->segy[0] = sc->post[0] * F.mult;
     for (int j = 1; j < posts; j++) {
-      const int cur = F.forward_index[j];
+      const int cur = sc->forward_index[j];
       const int hy = sc->post[cur] & 0x7fff;
       if (hy == sc->post[cur]) {
         ns++;
-        sc->segx[ns] = F.postlist[cur];
+        sc->segx[ns] = sc->postlist[cur];
         sc->segy[ns] = hy * F.mult;
       }
     }
     sc->nseg = ns;
   }
   WAVE_SYNC();
+  pc.mark(3);
   if (ilogmask) {
     const int ns = sc->nseg;
     WAVE_FOR(x, n2) {
@@ -354,6 +368,7 @@ VAMD_DEV int floor_fit_render_block(const FloorP &F, int n2, const float *mask, 
     }
   }
   WAVE_SYNC();
+  pc.mark(4);
   return 1;
 }
 

@@ -56,9 +56,41 @@ VAMD_DEV LineFit fixed_fit_at(const PsyP &P, const float *S, int i, int fixed) {
   return (i < P.fix_i1) ? fit_mirrored(S, n, hi, -lo) : fit_plain(S, n, hi, lo);
 }
 
+// In-place running sum p[i] = p[0] + ... + p[i], strictly left to right in fp32
+// (the reference's tN/tX/... accumulators, lib/psy.c:576-603).  One lane; n is a
+// multiple of 16 (block sizes are powers of two >= 64).  The next 16 values are
+// fetched from LDS while the current 16 are being added, so the dependent add
+// chain -- the irreducible part -- is the only thing on the critical path.
+VAMD_DEV void running_sum_inplace(float *p, int n) {
+  F4 *q = (F4 *)p;
+  float acc = 0.f;
+  F4 c0 = q[0], c1 = q[1], c2 = q[2], c3 = q[3];
+  for (int b = 0; b < n / 16; b++) {
+    F4 n0 = c0, n1 = c1, n2 = c2, n3 = c3;
+    if (b + 1 < n / 16) {
+      n0 = q[4 * b + 4];
+      n1 = q[4 * b + 5];
+      n2 = q[4 * b + 6];
+      n3 = q[4 * b + 7];
+    }
+    acc += c0.x; c0.x = acc; acc += c0.y; c0.y = acc; acc += c0.z; c0.z = acc; acc += c0.w; c0.w = acc;
+    acc += c1.x; c1.x = acc; acc += c1.y; c1.y = acc; acc += c1.z; c1.z = acc; acc += c1.w; c1.w = acc;
+    acc += c2.x; c2.x = acc; acc += c2.y; c2.y = acc; acc += c2.z; c2.z = acc; acc += c2.w; c2.w = acc;
+    acc += c3.x; c3.x = acc; acc += c3.y; c3.y = acc; acc += c3.z; c3.z = acc; acc += c3.w; c3.w = acc;
+    q[4 * b] = c0;
+    q[4 * b + 1] = c1;
+    q[4 * b + 2] = c2;
+    q[4 * b + 3] = c3;
+    c0 = n0;
+    c1 = n1;
+    c2 = n2;
+    c3 = n3;
+  }
+}
+
 // bark_noise_hybridmp(n, bark, f, noise, offset, fixed)
 VAMD_DEV void bark_noise_wave(const PsyP &P, const float *f, float *noise, const float offset, const int fixed,
-                              float *S) {
+                              float *S, PhaseClock &pc, int slot) {
   const int n = P.n;
   float *N = S, *X = S + n, *XX = S + 2 * n, *Y = S + 3 * n, *XY = S + 4 * n;
 
@@ -84,17 +116,12 @@ VAMD_DEV void bark_noise_wave(const PsyP &P, const float *f, float *noise, const
     }
   }
   WAVE_SYNC();
+  pc.mark(slot);
 
   // the five running sums, in index order, one lane each (lib/psy.c:576-603)
-  WAVE_FOR(a, 5) {
-    float *p = S + a * n;
-    float acc = 0.f;
-    for (int i = 0; i < n; i++) {
-      acc += p[i];
-      p[i] = acc;
-    }
-  }
+  WAVE_FOR(a, 5) running_sum_inplace(S + a * n, n);
   WAVE_SYNC();
+  pc.mark(slot + 1);
 
   // line evaluation; three regimes split at the static indices i1 <= i2
   // (lib/psy.c:606-656).  Beyond i2 the last fitted line is extended.
@@ -112,6 +139,7 @@ VAMD_DEV void bark_noise_wave(const PsyP &P, const float *f, float *noise, const
   }
   if (fixed <= 0) {
     WAVE_SYNC();
+    pc.mark(slot + 2);
     return;
   }
 
@@ -124,18 +152,20 @@ VAMD_DEV void bark_noise_wave(const PsyP &P, const float *f, float *noise, const
     if (R - offset < noise[i]) noise[i] = R - offset;
   }
   WAVE_SYNC();
+  pc.mark(slot + 2);
 }
 
 // _vp_noisemask(p, logmdct, logmask)
 //   logmdct  [n] input (HBM or LDS)
 //   out      [n] HBM
 VAMD_DEV void noisemask_block(const PsyP &P, const float *__restrict__ logmdct, float *__restrict__ out, float *S,
-                              float *nz, float *wk) {
+                              float *nz, float *wk, PhaseClock &pc) {
   const int n = P.n;
-  bark_noise_wave(P, logmdct, nz, 140.f, -1, S);
+  bark_noise_wave(P, logmdct, nz, 140.f, -1, S, pc, 0);
   WAVE_FOR(i, n) wk[i] = logmdct[i] - nz[i];
   WAVE_SYNC();
-  bark_noise_wave(P, wk, nz, 0.f, P.noisewindowfixed, S);
+  pc.mark(3);
+  bark_noise_wave(P, wk, nz, 0.f, P.noisewindowfixed, S, pc, 4);
   WAVE_FOR(i, n) {
     const float w = logmdct[i] - wk[i];
     int dB = (int)((double)nz[i] + .5);
@@ -144,6 +174,7 @@ VAMD_DEV void noisemask_block(const PsyP &P, const float *__restrict__ logmdct, 
     out[i] = w + P.noisecompand[dB];
   }
   WAVE_SYNC();
+  pc.mark(7);
 }
 
 }  // namespace vamd

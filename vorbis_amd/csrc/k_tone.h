@@ -7,12 +7,21 @@
 //    vamd_create() lists them, lanes take one run each, find the run's peak and
 //    scatter the chosen tone curve into seed[] with an LDS float max (max is
 //    order-free, so the result equals the reference's sequential update).
-//  * seed_chase is NOT a sliding-window max (SURVEY.md 0.8 iv): its stack
-//    discipline is restated literally and walked by one lane.
+//  * seed_chase is NOT a sliding-window max (SURVEY.md 0.8 iv).  Its first half
+//    (the stack discipline) is restated literally and walked by one lane, with
+//    the two top-of-stack entries held in registers so the common path never
+//    waits on LDS; its second half (painting each surviving entry over its span)
+//    is a prefix-max over the entries' end positions and is done by all lanes.
 //  * max_seeds' pointer walk over (octave line, bin) is static too: per bin the
 //    span of seed lines it folds is precomputed, every lane folds its own bins.
 //
-// LDS: seed[total_octave_lines], stack_pos[total], stack_amp[total].
+// The stage is three kernels so that the ordered stack walk -- one useful lane if a
+// wave owned a single block -- can instead run with one *lane* per channel-block
+// (64 walks per wave instruction):
+//   tone_seed_block   wave per block   : scatter -> seed[] to HBM
+//   tone_chase_thread thread per block : stack walk -> list of surviving lines
+//   tone_fold_block   wave per block   : paint + max_seeds fold -> tone curve
+// tonemask_block() composes the same three pieces for one block (test build).
 #pragma once
 #include "vamd_wave.h"
 #include "vamd_params.h"
@@ -21,87 +30,134 @@ namespace vamd {
 
 #define VAMD_NEGINF (-9999.f)
 
-// seed_curve, lib/psy.c:390-415
+// seed_curve, lib/psy.c:390-415.  The reference walks i = posts[0] .. post1-1 with
+// seedptr advancing by linesper and stops once seedptr >= n; point i therefore
+// lands on line oc + (i-16)*linesper - linesper/2 and is applied iff that line is
+// in (0, n).  Written as a fixed 56-trip predicated loop so the curve loads of
+// several points are in flight together.
 VAMD_DEV void seed_curve_scatter(float *seed, const float *__restrict__ curves /*[8][58] of one band*/, float amp,
                                  int oc, int nlines, int linesper, float dBoffset) {
   int choice = (int)(((double)(amp + dBoffset) - 30.) * (double).1f);
   choice = choice < 0 ? 0 : choice;
   choice = choice > VAMD_P_LEVELS - 1 ? VAMD_P_LEVELS - 1 : choice;
-  const float *posts = curves + choice * (VAMD_EHMER_MAX + 2);
-  const float *curve = posts + 2;
-  const int post1 = (int)posts[1];
-  int seedptr = (int)((float)oc + (posts[0] - (float)VAMD_EHMER_OFFSET) * (float)linesper - (float)(linesper >> 1));
-  for (int i = (int)posts[0]; i < post1; i++) {
-    if (seedptr > 0) {
-      const float lin = amp + curve[i];
-      lds_atomic_max(seed + seedptr, lin);
-    }
-    seedptr += linesper;
-    if (seedptr >= nlines) break;
+  const float *__restrict__ posts = curves + choice * (VAMD_EHMER_MAX + 2);
+  const int i0 = (int)posts[0], i1 = (int)posts[1];
+  const int base = oc - VAMD_EHMER_OFFSET * linesper - (linesper >> 1);
+#if VAMD_GPU
+#pragma unroll 8
+#endif
+  for (int i = 0; i < VAMD_EHMER_MAX; i++) {
+    const int seedptr = base + i * linesper;
+    const float c = posts[2 + i];
+    if (i >= i0 && i < i1 && seedptr > 0 && seedptr < nlines) lds_atomic_max(seed + seedptr, amp + c);
   }
 }
 
-// seed_chase, lib/psy.c:454-508 -- literal, single lane
-VAMD_DEV void seed_chase_serial(float *seeds, int linesper, int n, int *posstack, float *ampstack) {
-  int stack = 0;
-  for (int i = 0; i < n; i++) {
-    const float s = seeds[i];
-    if (stack < 2) {
-      posstack[stack] = i;
-      ampstack[stack++] = s;
-    } else {
-      while (1) {
-        if (s < ampstack[stack - 1]) {
-          posstack[stack] = i;
-          ampstack[stack++] = s;
-          break;
-        } else {
-          if (i < posstack[stack - 1] + linesper) {
-            if (stack > 1 && ampstack[stack - 1] <= ampstack[stack - 2] && i < posstack[stack - 2] + linesper) {
-              stack--;  // fully overlapped: stack-1 is irrelevant
-              continue;
-            }
+// seed_chase part 2, lib/psy.c:489-503: entry k paints [start_k, end_k) where
+// end_k = next.pos if the next entry is louder else pos_k + linesper + 1 (clipped
+// to n) and start_k = max(end_0 .. end_{k-1}) because the reference's write
+// pointer only moves forward.  Spans are disjoint, so all lanes paint at once.
+VAMD_DEV void seed_chase_paint(float *seeds, int linesper, int n, int stack, const int *posstack,
+                               const float *ampstack) {
+  int carry = 0;
+  for (int base = 0; base < stack; base += NLANES) {
+    const int k = base + LANE;
+    int endpos = 0;
+    float a = 0.f;
+    if (k < stack) {
+      a = ampstack[k];
+      if (k < stack - 1 && ampstack[k + 1] > a)
+        endpos = posstack[k + 1];
+      else
+        endpos = posstack[k] + linesper + 1;
+      if (endpos > n) endpos = n;
+    }
+    const int incl = wave_scan_max(endpos);
+    int start = wave_shift_up1(incl, 0);
+    if (start < carry) start = carry;
+    if (k < stack)
+      for (int p = start; p < endpos; p++) seeds[p] = a;
+    const int last = wave_last(incl);
+    if (last > carry) carry = last;
+  }
+}
+
+// Thread-per-block form of seed_chase part 1.  Only the top ~9 stack entries can
+// ever be popped or inspected (an entry more than `linesper` lines behind the
+// current line fails both position tests for good), so the stack lives in a
+// 16-slot ring per lane; an entry pushed out of the ring is final and its line
+// index is appended to the survivor list.  Ring layout [slot][lane] keeps the 64
+// lanes on distinct LDS banks.
+//   seeds   this block's seed[] (HBM, read 16 lines at a time)
+//   surv    out: surviving line indices, ascending (uint16), returns their count
+#define VAMD_RING 16
+VAMD_DEV int tone_chase_thread(const float *__restrict__ seeds, int linesper, int n, float *ring_amp, int *ring_pos,
+                               int rstride, int rlane, unsigned short *__restrict__ surv) {
+  int stack = 0, hmax = 0;  // hmax = highest stack index ever written
+  float a1 = 0.f, a2 = 0.f;
+  int p1 = 0, p2 = 0;
+  const F4 *q = (const F4 *)seeds;
+  for (int b = 0; b < ((n + 15) >> 4); b++) {
+    const F4 v0 = q[4 * b], v1 = q[4 * b + 1], v2 = q[4 * b + 2], v3 = q[4 * b + 3];  // row is padded to 16
+    const float blk[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w,
+                           v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+#if VAMD_GPU
+#pragma unroll
+#endif
+    for (int j = 0; j < 16; j++) {
+      const int i = (b << 4) + j;
+      if (i < n) {
+        const float s = blk[j];
+        if (stack >= 2) {
+          while (!(s < a1) && i < p1 + linesper && a1 <= a2 && i < p2 + linesper) {
+            stack--;
+            a1 = a2;
+            p1 = p2;
+            if (stack < 2) break;
+            const int slot = (stack - 2) & (VAMD_RING - 1);
+            a2 = ring_amp[slot * rstride + rlane];
+            p2 = ring_pos[slot * rstride + rlane];
           }
-          posstack[stack] = i;
-          ampstack[stack++] = s;
-          break;
         }
+        const int slot = stack & (VAMD_RING - 1);
+        if (stack == hmax) {
+          // first write of this index: the entry one ring-length below is final, emit it
+          // before its slot is reused (re-pushes of an index already seen emit nothing)
+          if (stack >= VAMD_RING) surv[stack - VAMD_RING] = (unsigned short)ring_pos[slot * rstride + rlane];
+          hmax++;
+        }
+        ring_amp[slot * rstride + rlane] = s;
+        ring_pos[slot * rstride + rlane] = i;
+        stack++;
+        a2 = a1;
+        p2 = p1;
+        a1 = s;
+        p1 = i;
       }
     }
   }
-  int pos = 0;
-  for (int i = 0; i < stack; i++) {
-    int endpos;
-    if (i < stack - 1 && ampstack[i + 1] > ampstack[i])
-      endpos = posstack[i + 1];
-    else
-      endpos = posstack[i] + linesper + 1;
-    if (endpos > n) endpos = n;
-    const float a = ampstack[i];
-    for (; pos < endpos; pos++) seeds[pos] = a;
-  }
+  for (int k = hmax > VAMD_RING ? hmax - VAMD_RING : 0; k < stack; k++)
+    surv[k] = (unsigned short)ring_pos[(k & (VAMD_RING - 1)) * rstride + rlane];
+  return stack;
 }
 
-// _vp_tonemask(p, logfft, logmask, global_specmax, local_specmax)
-VAMD_DEV void tonemask_block(const PsyP &P, const float *__restrict__ logfft, float *__restrict__ out,
-                             float global_ampmax, float local_ampmax, float *seed, int *posstack, float *ampstack,
-                             float *flr /* LDS [n] */) {
+// scatter half: seed[] for one channel-block (LDS), lib/psy.c:417-452,762-771
+VAMD_DEV void tone_seed_block(const PsyP &P, const float *__restrict__ logfft, float global_ampmax,
+                              float local_ampmax, float *seed, float *fft, PhaseClock &pc) {
   const int n = P.n, nlines = P.total_octave_lines;
   float att = local_ampmax + P.ath_adjatt;
   if (att < P.ath_maxatt) att = P.ath_maxatt;
-
   WAVE_FOR(i, nlines) seed[i] = VAMD_NEGINF;
-  WAVE_FOR(i, n) flr[i] = P.ath[i] + att;
+  WAVE_FOR(q, n >> 2)((F4 *)fft)[q] = ((const F4 *)logfft)[q];
   WAVE_SYNC();
-
-  // seed_loop, lib/psy.c:417-452
+  pc.mark(0);
   const float dBoffset = P.max_curve_dB - global_ampmax;
   WAVE_FOR(r, P.nruns) {
     const int s = P.run_start[r], e = P.run_start[r + 1];  // bins [s, e)
-    float mx = logfft[s];
+    float mx = fft[s];
     for (int i = s + 1; i < e; i++)
-      if (logfft[i] > mx) mx = logfft[i];
-    if (mx + 6.f > flr[e - 1]) {
+      if (fft[i] > mx) mx = fft[i];
+    if (mx + 6.f > P.ath[e - 1] + att) {
       const int ocv = P.octave[s];
       int band = ocv >> P.shiftoc;
       if (band >= VAMD_P_BANDS) band = VAMD_P_BANDS - 1;
@@ -111,9 +167,25 @@ VAMD_DEV void tonemask_block(const PsyP &P, const float *__restrict__ logfft, fl
     }
   }
   WAVE_SYNC();
+  pc.mark(1);
+}
 
-  WAVE_FOR(z, 1) seed_chase_serial(seed, P.eighth_octave_lines, nlines, posstack, ampstack);
+// paint + fold half: seed[] (LDS, unpainted), the survivor list -> tone curve
+//   posstack/ampstack LDS [nlines]
+VAMD_DEV void tone_fold_block(const PsyP &P, float local_ampmax, float *seed, const unsigned short *__restrict__ surv,
+                              int nsurv, int *posstack, float *ampstack, float *__restrict__ out, PhaseClock &pc) {
+  const int n = P.n, nlines = P.total_octave_lines;
+  float att = local_ampmax + P.ath_adjatt;
+  if (att < P.ath_maxatt) att = P.ath_maxatt;
+  WAVE_FOR(k, nsurv) {
+    const int pos = surv[k];
+    posstack[k] = pos;
+    ampstack[k] = seed[pos];
+  }
   WAVE_SYNC();
+  seed_chase_paint(seed, P.eighth_octave_lines, nlines, nsurv, posstack, ampstack);
+  WAVE_SYNC();
+  pc.mark(3);
 
   // max_seeds' fold, lib/psy.c:522-543, per bin over its precomputed line span
   WAVE_FOR(i, n) {
@@ -129,11 +201,24 @@ VAMD_DEV void tonemask_block(const PsyP &P, const float *__restrict__ logfft, fl
         if ((s > VAMD_NEGINF && s < minV) || minV == VAMD_NEGINF) minV = s;
       }
     }
-    float v = flr[i];
+    float v = P.ath[i] + att;
     if (v < minV) v = minV;
     out[i] = v;
   }
   WAVE_SYNC();
+  pc.mark(4);
+}
+
+// _vp_tonemask(p, logfft, logmask, global_specmax, local_specmax), one block end to
+// end (the test build; the GPU runs the three pieces as separate launches)
+//   seed LDS [nlines padded to 16], fft LDS [n], posstack/ampstack LDS [nlines],
+//   ring_amp/ring_pos [VAMD_RING], surv [nlines]
+VAMD_DEV void tonemask_block(const PsyP &P, const float *__restrict__ logfft, float *__restrict__ out,
+                             float global_ampmax, float local_ampmax, float *seed, int *posstack, float *ampstack,
+                             float *fft, float *ring_amp, int *ring_pos, unsigned short *surv, PhaseClock &pc) {
+  tone_seed_block(P, logfft, global_ampmax, local_ampmax, seed, fft, pc);
+  const int nsurv = tone_chase_thread(seed, P.eighth_octave_lines, P.total_octave_lines, ring_amp, ring_pos, 1, 0, surv);
+  tone_fold_block(P, local_ampmax, seed, surv, nsurv, posstack, ampstack, out, pc);
 }
 
 }  // namespace vamd

@@ -155,7 +155,7 @@ VAMD_DEV void bfly32(float *x) {
 // mdct_forward, lib/mdct.c:492-562.  `in` = A (windowed block, LDS), work w = B.
 // Leaves the n/2 spectrum in B[0..n/2) *unscaled order as the reference's `out`*
 // by writing it to `out` (LDS or HBM pointer supplied by the caller).
-VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in, float *w, float *out_lds) {
+VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in, float *w, float *out_lds, PhaseClock &pc) {
   const int n = P.n, n2 = n >> 1, n4 = n >> 2, n8 = n >> 3;
   const float *__restrict__ trig = P.trig;
   float *w2 = w + n2;
@@ -186,6 +186,7 @@ VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in, float *w, floa
     w2[2 * p + 1] = r1 * T[0] - r0 * T[1];
   }
   WAVE_SYNC();
+  pc.mark(1);
 
   // mdct_butterflies, lib/mdct.c:316-336, on x = w2, points = n2.
   // Stage s (s = 0 is mdct_butterfly_first, s >= 1 the generic passes) splits
@@ -208,6 +209,7 @@ VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in, float *w, floa
     }
     WAVE_SYNC();
   }
+  pc.mark(2);
   // 32-point butterflies, one group per lane, in registers
   WAVE_FOR(g, n2 / 32) {
     float v[32];
@@ -218,6 +220,7 @@ VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in, float *w, floa
     for (int k = 0; k < 32; k++) w2[32 * g + k] = v[k];
   }
   WAVE_SYNC();
+  pc.mark(3);
 
   // mdct_bitreverse, lib/mdct.c:346-394: reads x = w2 (upper half), writes the
   // lower half w[0..n2).  Unit u produces w[2u], w[2u+1], w[n2-2u-2], w[n2-2u-1].
@@ -238,6 +241,7 @@ VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in, float *w, floa
     w[n2 - 2 * u - 1] = r3 - r1;
   }
   WAVE_SYNC();
+  pc.mark(4);
 
   // final rotate * scale, lib/mdct.c:552-561 -> out[n2] (placed in w2 region,
   // which is dead now)
@@ -378,13 +382,14 @@ VAMD_DEV void drft_forward_wave(const XformP &P, float *c, float *ch) {
 // Returns the channel's local_ampmax (all lanes).
 VAMD_DEV float transform_block(const XformP &P, int W, int lW, int nW, const float *__restrict__ pcm, float *A,
                                float *B, float *__restrict__ mdct_out, float *__restrict__ logmdct_out,
-                               float *__restrict__ logfft_out) {
+                               float *__restrict__ logfft_out, PhaseClock &pc) {
   const int n = P.n, n2 = n >> 1;
   load_windowed(P, W, lW, nW, pcm, A, true);
   WAVE_SYNC();
+  pc.mark(0);
 
   // MDCT: spectrum lands in B[n2..n) (LDS), then goes out with its dB twin
-  mdct_forward_wave(P, A, B, B + n2);
+  mdct_forward_wave(P, A, B, B + n2, pc);
   WAVE_FOR(j, n2) {
     const float m = B[n2 + j];
     if (mdct_out) mdct_out[j] = m;
@@ -392,8 +397,10 @@ VAMD_DEV float transform_block(const XformP &P, int W, int lW, int nW, const flo
   }
   WAVE_SYNC();
 
+  pc.mark(5);
   // FFT of the same windowed block, in place in A
   drft_forward_wave(P, A, B);
+  pc.mark(6);
 
   // logfft + local ampmax, lib/mapping0.c:255-346
   const float scale = 4.f / n;
@@ -414,6 +421,7 @@ VAMD_DEV float transform_block(const XformP &P, int W, int lW, int nW, const flo
   amp = wave_max(amp);
   if (amp > 0.f) amp = 0.f;
   WAVE_SYNC();
+  pc.mark(7);
   return amp;
 }
 

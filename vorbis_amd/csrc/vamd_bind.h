@@ -97,6 +97,11 @@ inline int build_image(const void *blob_v, size_t bytes, std::vector<unsigned ch
         *err = "setup blob: table offset out of range";
         return VAMD_EINVAL;
       }
+    if (t.total_octave_lines != h.psy[p & ~1].total_octave_lines ||
+        t.eighth_octave_lines != h.psy[p & ~1].eighth_octave_lines) {
+      *err = "psy looks of one size class must share their octave-line geometry";
+      return VAMD_EIMPL;
+    }
     if (t.total_octave_lines < 1 || t.total_octave_lines > 4096) {
       *err = "total_octave_lines out of range";
       return VAMD_EINVAL;

@@ -45,9 +45,11 @@ __global__ __launch_bounds__(64) void k_mdct_only(XformP P, int W, const float *
   float *A = (float *)vamd_smem, *B = A + P.n;
   const long f = blockIdx.x;
   const int n2 = P.n >> 1;
+  PhaseClock pc;
+  pc.start(nullptr);
   load_windowed(P, W, 1, 1, in + f * P.n, A, false);
   WAVE_SYNC();
-  mdct_forward_wave(P, A, B, B + n2);
+  mdct_forward_wave(P, A, B, B + n2, pc);
   WAVE_FOR(j, n2) out[f * n2 + j] = B[n2 + j];
 }
 
@@ -59,8 +61,10 @@ __global__ __launch_bounds__(64) void k_transform(XformP P, int W, DescP d, int 
   const long cb = blockIdx.x;  // channel-block index = block*ch + channel
   const long blk = cb / ch;
   const int n = P.n, n2 = n >> 1;
+  PhaseClock pc;
+  pc.start(d.dbg);
   const float amp = transform_block(P, W, d_lW(d, blk), d_nW(d, blk), pcm + cb * n, A, B, mdct_raw + cb * n2,
-                                    logmdct + cb * n2, logfft + cb * n2);
+                                    logmdct + cb * n2, logfft + cb * n2, pc);
   if (LANE == 0) local_ampmax[cb] = amp;
 }
 
@@ -72,7 +76,9 @@ __global__ __launch_bounds__(64) void k_noise(PsyP P0, PsyP P1, DescP d, int ch,
   const PsyP &P = d_bt(d, blk) ? P1 : P0;
   const int n2 = P.n;
   float *S = (float *)vamd_smem, *nz = S + 5 * n2, *wk = nz + n2;
-  noisemask_block(P, logmdct + cb * n2, noise + cb * n2, S, nz, wk);
+  PhaseClock pc;
+  pc.start(d.dbg ? d.dbg + 16 : nullptr);
+  noisemask_block(P, logmdct + cb * n2, noise + cb * n2, S, nz, wk, pc);
 }
 
 // block-level ampmax: global = max(ampmax_in, local[0..ch)); one thread per block
@@ -107,20 +113,54 @@ __global__ void k_ampmax_stream(int ch, long nblocks, float secs, float att, flo
   }
 }
 
-// stage 3: _vp_tonemask
-__global__ __launch_bounds__(64) void k_tone(PsyP P0, PsyP P1, DescP d, int ch, const float *__restrict__ logfft,
-                                             const float *__restrict__ local_ampmax,
-                                             const float *__restrict__ ampmax_glob, float *__restrict__ tone) {
+// stage 3: _vp_tonemask, in three launches (k_tone.h).  nlp = octave lines padded to 16.
+__global__ __launch_bounds__(64) void k_tone_seed(PsyP P0, PsyP P1, DescP d, int ch, int nlp,
+                                                  const float *__restrict__ logfft,
+                                                  const float *__restrict__ local_ampmax,
+                                                  const float *__restrict__ ampmax_glob, float *__restrict__ seed_g) {
   const long cb = blockIdx.x;
   const long blk = cb / ch;
   const PsyP &P = d_bt(d, blk) ? P1 : P0;
   const int n2 = P.n, nl = P.total_octave_lines;
+  float *fft = (float *)vamd_smem;
+  float *seed = fft + n2;
+  PhaseClock pc;
+  pc.start(d.dbg ? d.dbg + 32 : nullptr);
+  tone_seed_block(P, logfft + cb * n2, ampmax_glob[blk], local_ampmax[cb], seed, fft, pc);
+  WAVE_FOR(i, nlp) seed_g[cb * nlp + i] = i < nl ? seed[i] : VAMD_NEGINF;
+}
+
+// one THREAD per channel-block: the ordered stack walk of seed_chase
+__global__ __launch_bounds__(64) void k_tone_chase(int linesper, int nl, int nlp, long ncb, DescP d,
+                                                   const float *__restrict__ seed_g,
+                                                   unsigned short *__restrict__ surv, int *__restrict__ nsurv) {
+  float *ring_amp = (float *)vamd_smem;
+  int *ring_pos = (int *)(ring_amp + VAMD_RING * 64);
+  const long cb = (long)blockIdx.x * 64 + threadIdx.x;
+  PhaseClock pc;
+  pc.start(d.dbg ? d.dbg + 32 : nullptr);
+  if (cb < ncb)
+    nsurv[cb] = tone_chase_thread(seed_g + cb * nlp, linesper, nl, ring_amp, ring_pos, 64, threadIdx.x, surv + cb * nlp);
+  pc.mark(2);
+}
+
+__global__ __launch_bounds__(64) void k_tone_fold(PsyP P0, PsyP P1, DescP d, int ch, int nlp,
+                                                  const float *__restrict__ seed_g,
+                                                  const unsigned short *__restrict__ surv,
+                                                  const int *__restrict__ nsurv,
+                                                  const float *__restrict__ local_ampmax, float *__restrict__ tone) {
+  const long cb = blockIdx.x;
+  const long blk = cb / ch;
+  const PsyP &P = d_bt(d, blk) ? P1 : P0;
+  const int n2 = P.n;
   float *seed = (float *)vamd_smem;
-  float *ampstack = seed + nl;
-  int *posstack = (int *)(ampstack + nl);
-  float *flr = (float *)(posstack + nl);
-  tonemask_block(P, logfft + cb * n2, tone + cb * n2, ampmax_glob[blk], local_ampmax[cb], seed, posstack, ampstack,
-                 flr);
+  float *ampstack = seed + nlp;
+  int *posstack = (int *)(ampstack + nlp);
+  PhaseClock pc;
+  pc.start(d.dbg ? d.dbg + 32 : nullptr);
+  WAVE_FOR(q, nlp >> 2)((F4 *)seed)[q] = ((const F4 *)(seed_g + cb * nlp))[q];
+  WAVE_SYNC();
+  tone_fold_block(P, local_ampmax[cb], seed, surv + cb * nlp, nsurv[cb], posstack, ampstack, tone + cb * n2, pc);
 }
 
 // stage 4: offset_and_mix + floor1_fit + floor curve
@@ -136,11 +176,13 @@ __global__ __launch_bounds__(64) void k_floor(PsyP P0, PsyP P1, FloorP F, DescP 
   const int n2 = P.n;
   float *mask = (float *)vamd_smem, *lmd = mask + n2;
   FloorScratch *sc = (FloorScratch *)(lmd + n2);
+  PhaseClock pc;
+  pc.start(d.dbg ? d.dbg + 48 : nullptr);
   offset_and_mix_wave(P, noise + cb * n2, tone + cb * n2, logmdct + cb * n2, mdct_raw + cb * n2, mdct + cb * n2, mask,
-                      lmd);
+                      lmd, pc);
   if (logmask_out) WAVE_FOR(i, n2) logmask_out[cb * n2 + i] = mask[i];
   const int nzf = floor_fit_render_block(F, n2, mask, lmd, sc, posts + cb * VAMD_POSTS_STRIDE, post_valid + cb,
-                                         ilogmask + cb * n2);
+                                         ilogmask + cb * n2, pc);
   if (LANE == 0) nonzero[cb] = nzf;
 }
 
@@ -166,7 +208,9 @@ __global__ __launch_bounds__(64) void k_couple(PsyP P0, PsyP P1, CoupleP C, Desc
     nz[c] = nonzero[blk * ch + c];
   }
   WAVE_SYNC();  // every lane has read nonzero[] before lane 0 rewrites it
-  couple_block(C, P, n2, mp, ip, op, nz, L);
+  PhaseClock pc;
+  pc.start(d.dbg ? d.dbg + 64 : nullptr);
+  couple_block(C, P, n2, mp, ip, op, nz, L, pc);
   if (LANE == 0)
     for (int c = 0; c < ch; c++) nonzero[blk * ch + c] = nz[c];
 }
@@ -188,12 +232,13 @@ struct vamd_ctx {
   std::string err;
   // workspace, grown on demand (vamd_reserve to pre-size)
   enum { WS_MDCT_RAW, WS_LOGMDCT, WS_LOGFFT, WS_NOISE, WS_TONE, WS_MDCT, WS_ILOGMASK, WS_IWORK, WS_POSTS, WS_POSTVALID,
-         WS_NONZERO, WS_LOCAL, WS_AMPIN, WS_AMPGLOB, WS_PCM, WS_COUNT };
+         WS_NONZERO, WS_LOCAL, WS_AMPIN, WS_AMPGLOB, WS_PCM, WS_SEED, WS_SURV, WS_NSURV, WS_COUNT };
   DevBuf ws[WS_COUNT];
   // pinned staging for the per-block host API
   void *h_stage = nullptr;
   size_t h_stage_bytes = 0;
   // optional per-stage timing (vamd_profile): one event before each stage + one after the last
+  unsigned long long *d_dbg = nullptr;  // 80 phase-stopwatch slots when armed
   bool profile = false;
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
@@ -278,6 +323,7 @@ void vamd_destroy(vamd_ctx *c) {
   for (int i = 0; i < vamd_ctx::WS_COUNT; i++)
     if (c->ws[i].p) (void)hipFree(c->ws[i].p);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
+  if (c->d_dbg) (void)hipFree(c->d_dbg);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   if (c->d_image) (void)hipFree(c->d_image);
   delete c;
@@ -320,12 +366,30 @@ int vamd_stage_ms(vamd_ctx *c, float *ms, int nstages, int *runs) {
   return VAMD_OK;
 }
 
+int vamd_debug_cycles(vamd_ctx *c, int enable, unsigned long long *out80) {
+  if (!c) return VAMD_EINVAL;
+  if (out80 && c->d_dbg) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(out80, c->d_dbg, 80 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  }
+  if (enable) {
+    if (!c->d_dbg) HIP_TRY(c, hipMalloc((void **)&c->d_dbg, 80 * sizeof(unsigned long long)));
+    HIP_TRY(c, hipMemset(c->d_dbg, 0, 80 * sizeof(unsigned long long)));
+  } else if (c->d_dbg) {
+    HIP_TRY(c, hipFree(c->d_dbg));
+    c->d_dbg = nullptr;
+  }
+  return VAMD_OK;
+}
+
 int vamd_channels(const vamd_ctx *c) { return c ? c->B.channels : VAMD_EINVAL; }
 int vamd_blocksize(const vamd_ctx *c, int W) { return (c && (W == 0 || W == 1)) ? c->B.bs[W] : VAMD_EINVAL; }
 int vamd_posts(const vamd_ctx *c, int W) { return (c && (W == 0 || W == 1)) ? c->B.floor[W].posts : VAMD_EINVAL; }
 
 struct WsPlan {
-  float *mdct_raw, *logmdct, *logfft, *noise, *tone, *mdct, *local, *ampin, *ampglob;
+  float *mdct_raw, *logmdct, *logfft, *noise, *tone, *mdct, *local, *ampin, *ampglob, *seed;
+  unsigned short *surv;
+  int32_t *nsurv;
   int32_t *ilogmask, *iwork, *posts, *post_valid, *nonzero;
 };
 
@@ -351,6 +415,10 @@ static int plan(vamd_ctx *c, int W, long nb, const vamd_batch_io *io, int level,
   if (level >= VAMD_LEVEL_PSY) {
     PICK(noise, io ? io->noise : nullptr, WS_NOISE, per);
     PICK(tone, io ? io->tone : nullptr, WS_TONE, per);
+    const size_t nlp = ((size_t)c->B.psy[2 * W].total_octave_lines + 15) & ~(size_t)15;
+    PICK(seed, (float *)nullptr, WS_SEED, (size_t)nb * ch * nlp * 4);
+    PICK(surv, (unsigned short *)nullptr, WS_SURV, (size_t)nb * ch * nlp * 2);
+    PICK(nsurv, (int32_t *)nullptr, WS_NSURV, (size_t)nb * ch * 4);
   }
   if (level >= VAMD_LEVEL_FULL) {
     PICK(mdct, io ? io->mdct : nullptr, WS_MDCT, per);
@@ -417,6 +485,7 @@ static int run_batch(vamd_ctx *c, const vamd_batch_desc *desc, const vamd_batch_
   d.u_nW = desc->uniform_nW;
   d.u_blocktype = desc->uniform_blocktype;
   d.u_ampmax_in = desc->uniform_ampmax_in;
+  d.dbg = c->d_dbg;
   const unsigned gcb = (unsigned)(nb * ch), gb = (unsigned)nb;
   hipStream_t s = c->stream;
 
@@ -437,8 +506,15 @@ static int run_batch(vamd_ctx *c, const vamd_batch_desc *desc, const vamd_batch_
   if (level >= VAMD_LEVEL_PSY) {
     hipLaunchKernelGGL(k_noise, dim3(gcb), dim3(64), (size_t)n2 * 7 * 4, s, P0, P1, d, ch, p.logmdct, p.noise);
     prof_mark(c), nst++;
-    hipLaunchKernelGGL(k_tone, dim3(gcb), dim3(64), (size_t)(3 * nl + n2) * 4, s, P0, P1, d, ch, p.logfft, p.local,
-                       p.ampglob, p.tone);
+    {
+      const int nlp = (nl + 15) & ~15;
+      hipLaunchKernelGGL(k_tone_seed, dim3(gcb), dim3(64), (size_t)(n2 + nlp) * 4, s, P0, P1, d, ch, nlp, p.logfft,
+                         p.local, p.ampglob, p.seed);
+      hipLaunchKernelGGL(k_tone_chase, dim3((gcb + 63) / 64), dim3(64), (size_t)VAMD_RING * 64 * 8, s,
+                         P0.eighth_octave_lines, nl, nlp, (long)gcb, d, p.seed, p.surv, p.nsurv);
+      hipLaunchKernelGGL(k_tone_fold, dim3(gcb), dim3(64), (size_t)nlp * 12, s, P0, P1, d, ch, nlp, p.seed, p.surv,
+                         p.nsurv, p.local, p.tone);
+    }
     prof_mark(c), nst++;
   }
   if (level >= VAMD_LEVEL_FULL) {

@@ -69,6 +69,7 @@ struct DescP {
   const float *ampmax_in;
   int u_lW, u_nW, u_blocktype;
   float u_ampmax_in;
+  unsigned long long *dbg;  // phase stopwatch slots (null = off), 16 per stage kernel
 };
 
 }  // namespace vamd

@@ -40,8 +40,13 @@
 #define WAVE_SYNC() ((void)0)
 #endif
 
-// lanes stride over [0, count)
+// lanes stride over [0, count).  On the GPU the loop is unrolled x4 so that the
+// independent HBM/L2 loads of four iterations are in flight together.
+#if VAMD_GPU
+#define WAVE_FOR(i, count) _Pragma("unroll 4") for (int i = LANE; i < (count); i += NLANES)
+#else
 #define WAVE_FOR(i, count) for (int i = LANE; i < (count); i += NLANES)
+#endif
 
 namespace vamd {
 
@@ -57,6 +62,21 @@ VAMD_DEV int wave_sum(int v) {
   return v;
 }
 VAMD_DEV int wave_any(int pred) { return __any(pred); }
+// inclusive prefix max over the lanes of the wave
+VAMD_DEV int wave_scan_max(int v) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(v, d, 64);
+    if (LANE >= d) v = v > o ? v : o;
+  }
+  return v;
+}
+VAMD_DEV int wave_shift_up1(int v, int fill) {  // lane l gets lane l-1's value, lane 0 gets `fill`
+  const int o = __shfl_up(v, 1, 64);
+  return LANE == 0 ? fill : o;
+}
+VAMD_DEV int wave_last(int v) { return __shfl(v, 63, 64); }
+VAMD_DEV int wave_first(int v) { return __builtin_amdgcn_readfirstlane(v); }
 VAMD_DEV float f_from_bits(uint32_t u) { return __uint_as_float(u); }
 VAMD_DEV uint32_t f_bits(float f) { return __float_as_uint(f); }
 // order-free float max into LDS (seed scatter): classic sign-split integer trick
@@ -72,12 +92,46 @@ VAMD_DEV void lds_atomic_or(int *p, int v) { atomicOr(p, v); }
 VAMD_DEV float wave_max(float v) { return v; }
 VAMD_DEV int wave_sum(int v) { return v; }
 VAMD_DEV int wave_any(int pred) { return pred != 0; }
+VAMD_DEV int wave_scan_max(int v) { return v; }
+VAMD_DEV int wave_shift_up1(int v, int fill) { (void)v; return fill; }
+VAMD_DEV int wave_last(int v) { return v; }
+VAMD_DEV int wave_first(int v) { return v; }
 VAMD_DEV float f_from_bits(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 VAMD_DEV uint32_t f_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 VAMD_DEV void lds_atomic_max(float *p, float v) { if (*p < v) *p = v; }
 VAMD_DEV void lds_atomic_add(int *p, int v) { *p += v; }
 VAMD_DEV void lds_atomic_or(int *p, int v) { *p |= v; }
 #endif
+
+struct alignas(16) F4 {
+  float x, y, z, w;
+};
+struct alignas(16) I4 {
+  int x, y, z, w;
+};
+
+// Optional in-kernel stopwatch (measurement aid, off unless vamd_debug_cycles() armed it):
+// lane 0 of every wave adds the shader-clock ticks spent since the previous mark to a slot.
+struct PhaseClock {
+#if VAMD_GPU
+  unsigned long long *slots;
+  long long t;
+  VAMD_DEV void start(unsigned long long *s) {
+    slots = s;
+    if (slots) t = clock64();
+  }
+  VAMD_DEV void mark(int k) {
+    if (slots) {
+      const long long now = clock64();
+      if (LANE == 0) atomicAdd(slots + k, (unsigned long long)(now - t));
+      t = now;
+    }
+  }
+#else
+  VAMD_DEV void start(unsigned long long *) {}
+  VAMD_DEV void mark(int) {}
+#endif
+};
 
 // ---- scalar helpers shared by all stages ------------------------------------
 
