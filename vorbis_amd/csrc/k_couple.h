@@ -115,14 +115,14 @@ VAMD_DEV void couple_block(const CoupleP &C, const PsyP &P, int n2, const float 
         L.sgn[b] = sg;
       }
     }
-    WAVE_SYNC();
     if (norm_active && nz[k]) {
+      WAVE_SYNC_GLOBAL();  // iwork[] changes hands between lanes through HBM
       WAVE_FOR(p, nparts) {
         const int b0 = p * partition;
         const int jn = partition > n2 - b0 ? n2 - b0 : partition;
         noise_norm_partition(P, L, b0, jn, iwork[k]);
       }
-      WAVE_SYNC();
+      WAVE_SYNC_GLOBAL();
     }
   }
 
@@ -206,14 +206,14 @@ VAMD_DEV void couple_block(const CoupleP &C, const PsyP &P, int n2, const float 
         L.sgn[b] = re[0];
       }
     }
-    WAVE_SYNC();
     if (norm_active) {
+      WAVE_SYNC_GLOBAL();
       WAVE_FOR(p, nparts) {
         const int b0 = p * partition;
         const int jn = partition > n2 - b0 ? n2 - b0 : partition;
         noise_norm_partition(P, L, b0, jn, iwork[Mi]);
       }
-      WAVE_SYNC();
+      WAVE_SYNC_GLOBAL();
     }
     // lib/psy.c:1204-1212
     nz[Mi] = nz[Ai] = 1;

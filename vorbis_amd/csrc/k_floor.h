@@ -49,23 +49,35 @@ VAMD_DEV void offset_and_mix_wave(const PsyP &P, const float *__restrict__ noise
   const float toneatt = P.tone_masteratt1;
   const float cx = P.m_val;
   const float coeffi = -17.2f;  // float coeffi = -17.2 (lib/psy.c:808)
-  WAVE_FOR(i, n) {
-    float val = noise[i] + P.noiseoffset1[i];
-    if (val > P.noisemaxsupp) val = P.noisemaxsupp;
-    const float t = tone[i] + toneatt;
-    mask[i] = (val < t) ? t : val;  // max(val, tone+toneatt), lib/psy.c:795 with os.h:78 max()
-    const float lm = logmdct_in[i];
-    lmd[i] = lm;
-    // AoTuV M1, lib/psy.c:807-832: double-promoted by the 1.0 / 0.005 / 0.0003 literals
-    val = val - lm;
-    float de;
-    if (val > coeffi) {
-      de = (float)(1.0 - ((double)(val - coeffi) * 0.005 * (double)cx));
-      if (de < 0) de = 0.0001f;
-    } else {
-      de = (float)(1.0 - ((double)(val - coeffi) * 0.0003 * (double)cx));
+  WAVE_FOR(q, n >> 2) {
+    float nz[4], no[4], tn[4], lmv[4], md[4], mk[4];
+    f4_get(((const F4 *)noise)[q], nz);
+    f4_get(((const F4 *)P.noiseoffset1)[q], no);
+    f4_get(((const F4 *)tone)[q], tn);
+    f4_get(((const F4 *)logmdct_in)[q], lmv);
+    f4_get(((const F4 *)mdct_io_src)[q], md);
+#if VAMD_GPU
+#pragma unroll
+#endif
+    for (int c = 0; c < 4; c++) {
+      float val = nz[c] + no[c];
+      if (val > P.noisemaxsupp) val = P.noisemaxsupp;
+      const float t = tn[c] + toneatt;
+      mk[c] = (val < t) ? t : val;  // max(val, tone+toneatt), lib/psy.c:795 with os.h:78 max()
+      // AoTuV M1, lib/psy.c:807-832: double-promoted by the 1.0 / 0.005 / 0.0003 literals
+      val = val - lmv[c];
+      float de;
+      if (val > coeffi) {
+        de = (float)(1.0 - ((double)(val - coeffi) * 0.005 * (double)cx));
+        if (de < 0) de = 0.0001f;
+      } else {
+        de = (float)(1.0 - ((double)(val - coeffi) * 0.0003 * (double)cx));
+      }
+      md[c] *= de;
     }
-    mdct_out[i] = mdct_io_src[i] * de;
+    ((F4 *)mask)[q] = f4_make(mk);
+    ((F4 *)lmd)[q] = f4_make(lmv);
+    ((F4 *)mdct_out)[q] = f4_make(md);
   }
   WAVE_SYNC();
   pc.mark(0);
@@ -89,6 +101,19 @@ VAMD_DEV int accumulate_fit_one(const float *flr, const float *mdct, int x0, int
   a->xa = xa; a->ya = ya; a->x2a = x2a; a->y2a = y2a; a->xya = xya; a->an = na;
   a->xb = xb; a->yb = yb; a->x2b = x2b; a->y2b = y2b; a->xyb = xyb; a->bn = nb;
   return na;
+}
+
+// add a lane's private sums to an interval's accumulators and clear them
+VAMD_DEV void accumulate_flush(FitAcc *dst, FitAcc &t) {
+  if (t.an) {
+    lds_atomic_add(&dst->xa, t.xa); lds_atomic_add(&dst->ya, t.ya); lds_atomic_add(&dst->x2a, t.x2a);
+    lds_atomic_add(&dst->y2a, t.y2a); lds_atomic_add(&dst->xya, t.xya); lds_atomic_add(&dst->an, t.an);
+  }
+  if (t.bn) {
+    lds_atomic_add(&dst->xb, t.xb); lds_atomic_add(&dst->yb, t.yb); lds_atomic_add(&dst->x2b, t.x2b);
+    lds_atomic_add(&dst->y2b, t.y2b); lds_atomic_add(&dst->xyb, t.xyb); lds_atomic_add(&dst->bn, t.bn);
+  }
+  t.xa = t.ya = t.x2a = t.y2a = t.xya = t.an = t.xb = t.yb = t.x2b = t.y2b = t.xyb = t.bn = 0;
 }
 
 // fit_line, lib/floor1.c:456-514.  a[0..fits) are consecutive intervals whose
@@ -130,19 +155,23 @@ VAMD_DEV int fit_line(const FitAcc *a, int fits, int x0, int x1, int *y0, int *y
 
 struct LineStep {  // Bresenham constants shared by inspect_error / render_line0
   int base, sgn, ady, adx;
+  float rcp;  // 1/adx for div_small()
 };
 VAMD_DEV LineStep line_step(int x0, int x1, int y0, int y1) {
   LineStep s;
   const int dy = y1 - y0;
   s.adx = x1 - x0;
   int ady = dy < 0 ? -dy : dy;
-  s.base = dy / s.adx;
+  s.rcp = div_rcp(s.adx);
+  const int ab = div_small(ady, s.adx, s.rcp);  // |dy| / adx; C's dy/adx truncates toward zero
+  s.base = dy < 0 ? -ab : ab;
   s.sgn = dy < 0 ? -1 : 1;  // sy - base
-  const int bb = s.base * s.adx;
-  s.ady = ady - (bb < 0 ? -bb : bb);
+  s.ady = ady - ab * s.adx;
   return s;
 }
-VAMD_DEV int line_y(const LineStep &s, int y0, int k) { return y0 + k * s.base + s.sgn * ((k * s.ady) / s.adx); }
+VAMD_DEV int line_y(const LineStep &s, int y0, int k) {
+  return y0 + k * s.base + s.sgn * div_small(k * s.ady, s.adx, s.rcp);
+}
 
 // inspect_error, lib/floor1.c:516-565, wave-parallel over x in [x0, x1)
 VAMD_DEV int inspect_error_wave(int x0, int x1, int y0, int y1, const float *mask, const float *mdct,
@@ -166,7 +195,7 @@ VAMD_DEV int inspect_error_wave(int x0, int x1, int y0, int y1, const float *mas
   mse = wave_sum(mse);
   if (F.maxover * F.maxover / (float)cnt > F.maxerr) return 0;
   if (F.maxunder * F.maxunder / (float)cnt > F.maxerr) return 0;
-  if ((float)(mse / cnt) > F.maxerr) return 1;
+  if ((float)(mse / cnt) > F.maxerr) return 1;  // (one true integer divide per call; mse may exceed 2^24)
   return 0;
 }
 
@@ -182,7 +211,7 @@ VAMD_DEV int render_point(int x0, int x1, int y0, int y1, int x) {
   y1 &= 0x7fff;
   const int dy = y1 - y0, adx = x1 - x0;
   const int ady = dy < 0 ? -dy : dy;
-  const int off = ady * (x - x0) / adx;
+  const int off = div_small(ady * (x - x0), adx, div_rcp(adx));
   return dy < 0 ? y0 - off : y0 + off;
 }
 
@@ -209,10 +238,52 @@ VAMD_DEV int floor_fit_render_block(const FloorP &F, int n2, const float *mask, 
     sc->hin[i] = 1;
     sc->memo[i] = -1;
   }
-  // one lane per post interval
+  WAVE_FOR(i, (posts - 1) * 12)((int *)sc->acc)[i] = 0;
+  WAVE_SYNC();
+  // accumulate_fit for all post intervals at once: every lane takes quads of bins, sums
+  // them privately and adds the six integer sums of each class to the owning interval
+  // (integer adds commute, so the totals equal the reference's sequential sums)
   int nz = 0;
-  WAVE_FOR(i, posts - 1)
-    nz += accumulate_fit_one(mask, lmd, F.sorted_index[i], F.sorted_index[i + 1], &sc->acc[i], n, F.twofitatten);
+  WAVE_FOR(qd, (n + 3) >> 2) {
+    const int i0 = qd << 2;
+    float mk[4], lm[4];
+    f4_get(((const F4 *)mask)[qd], mk);
+    f4_get(((const F4 *)lmd)[qd], lm);
+    int jprev = -1;
+    FitAcc t;
+    t.xa = t.ya = t.x2a = t.y2a = t.xya = t.an = t.xb = t.yb = t.x2b = t.y2b = t.xyb = t.bn = 0;
+#if VAMD_GPU
+#pragma unroll
+#endif
+    for (int c = 0; c < 4; c++) {
+      const int i = i0 + c;
+      const int j = i < n ? (int)F.bin_interval[i] : 255;
+      const int q = j != 255 ? dBquant(mk[c]) : 0;
+      if (j != jprev) {
+        if (jprev >= 0) accumulate_flush(&sc->acc[jprev], t);
+        jprev = j == 255 ? -1 : j;
+      }
+      if (q) {
+        FitAcc b;
+        b.xa = b.ya = b.x2a = b.y2a = b.xya = b.an = b.xb = b.yb = b.x2b = b.y2b = b.xyb = b.bn = 0;
+        const bool cls_a = lm[c] + F.twofitatten >= mk[c];
+        if (cls_a) {
+          b.xa = i; b.ya = q; b.x2a = i * i; b.y2a = q * q; b.xya = i * q; b.an = 1;
+        } else {
+          b.xb = i; b.yb = q; b.x2b = i * i; b.y2b = q * q; b.xyb = i * q; b.bn = 1;
+        }
+        t.xa += b.xa; t.ya += b.ya; t.x2a += b.x2a; t.y2a += b.y2a; t.xya += b.xya; t.an += b.an;
+        t.xb += b.xb; t.yb += b.yb; t.x2b += b.x2b; t.y2b += b.y2b; t.xyb += b.xyb; t.bn += b.bn;
+        nz += b.an;
+        // a bin exactly on an interior post closes the previous interval too
+        if (j > 0 && i == sc->sorted_index[j]) {
+          accumulate_flush(&sc->acc[j - 1], b);
+          nz += b.an;
+        }
+      }
+    }
+    if (jprev >= 0) accumulate_flush(&sc->acc[jprev], t);
+  }
   nz = wave_sum(nz);
   WAVE_SYNC();
   pc.mark(1);
@@ -237,16 +308,18 @@ VAMD_DEV int floor_fit_render_block(const FloorP &F, int n2, const float *mask, 
     sc->fitA[1] = y1;
   }
   for (int i = 2; i < posts; i++) {
-    const int sortpos = sc->reverse_index[i];
-    const int ln = sc->lon[sortpos];
-    const int hn = sc->hin[sortpos];
-    if (sc->memo[ln] != hn) {
-      const int lsortpos = sc->reverse_index[ln];
-      const int hsortpos = sc->reverse_index[hn];
+    // every lane holds the same values here; wave_first() tells the compiler so (scalar
+    // branches and addresses instead of per-lane masks)
+    const int sortpos = wave_first(sc->reverse_index[i]);
+    const int ln = wave_first(sc->lon[sortpos]);
+    const int hn = wave_first(sc->hin[sortpos]);
+    if (wave_first(sc->memo[ln]) != hn) {
+      const int lsortpos = wave_first(sc->reverse_index[ln]);
+      const int hsortpos = wave_first(sc->reverse_index[hn]);
       sc->memo[ln] = hn;
-      const int lx = sc->postlist[ln], hx = sc->postlist[hn];
-      const int ly = post_Y(sc->fitA, sc->fitB, ln);
-      const int hy = post_Y(sc->fitA, sc->fitB, hn);
+      const int lx = wave_first(sc->postlist[ln]), hx = wave_first(sc->postlist[hn]);
+      const int ly = wave_first(post_Y(sc->fitA, sc->fitB, ln));
+      const int hy = wave_first(post_Y(sc->fitA, sc->fitB, hn));
       // (ly == -1 || hy == -1 => exit(1) in the reference: unreachable, fits are >= 0 or -200)
       if (inspect_error_wave(lx, hx, ly, hy, mask, lmd, F)) {
         int ly0 = -200, ly1 = -200, hy0 = -200, hy1 = -200;

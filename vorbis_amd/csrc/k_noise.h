@@ -12,7 +12,7 @@
 // of the window loops depend only on the static bark[] table and are
 // precomputed by vamd_create().
 //
-// LDS: S[5][n] running sums, nz[n] (noise curve), wk[n] (work).
+// LDS: S[5][n+4] running sums, nz[n] (noise curve), wk[n] (work).
 #pragma once
 #include "vamd_wave.h"
 #include "vamd_params.h"
@@ -35,12 +35,12 @@ VAMD_DEV LineFit fit_from_sums(float tN, float tX, float tXX, float tY, float tX
 
 // window sums with a mirrored low edge (lo < 0 in the reference: lib/psy.c:613-617,666-670)
 VAMD_DEV LineFit fit_mirrored(const float *S, int n, int hi, int mlo /* = -lo */) {
-  const float *N = S, *X = S + n, *XX = S + 2 * n, *Y = S + 3 * n, *XY = S + 4 * n;
+  const float *N = S, *X = S + (n + 4), *XX = S + 2 * (n + 4), *Y = S + 3 * (n + 4), *XY = S + 4 * (n + 4);
   return fit_from_sums(N[hi] + N[mlo], X[hi] - X[mlo], XX[hi] + XX[mlo], Y[hi] + Y[mlo], XY[hi] - XY[mlo]);
 }
 // plain window differences (lib/psy.c:635-639,687-691)
 VAMD_DEV LineFit fit_plain(const float *S, int n, int hi, int lo) {
-  const float *N = S, *X = S + n, *XX = S + 2 * n, *Y = S + 3 * n, *XY = S + 4 * n;
+  const float *N = S, *X = S + (n + 4), *XX = S + 2 * (n + 4), *Y = S + 3 * (n + 4), *XY = S + 4 * (n + 4);
   return fit_from_sums(N[hi] - N[lo], X[hi] - X[lo], XX[hi] - XX[lo], Y[hi] - Y[lo], XY[hi] - XY[lo]);
 }
 
@@ -92,7 +92,9 @@ VAMD_DEV void running_sum_inplace(float *p, int n) {
 VAMD_DEV void bark_noise_wave(const PsyP &P, const float *f, float *noise, const float offset, const int fixed,
                               float *S, PhaseClock &pc, int slot) {
   const int n = P.n;
-  float *N = S, *X = S + n, *XX = S + 2 * n, *Y = S + 3 * n, *XY = S + 4 * n;
+  // each array starts 16 bytes further round the banks so that the five scanning lanes'
+  // 16-byte accesses do not collide
+  float *N = S, *X = S + (n + 4), *XX = S + 2 * (n + 4), *Y = S + 3 * (n + 4), *XY = S + 4 * (n + 4);
 
   // per-bin terms (lib/psy.c:571-597)
   WAVE_FOR(i, n) {
@@ -119,7 +121,7 @@ VAMD_DEV void bark_noise_wave(const PsyP &P, const float *f, float *noise, const
   pc.mark(slot);
 
   // the five running sums, in index order, one lane each (lib/psy.c:576-603)
-  WAVE_FOR(a, 5) running_sum_inplace(S + a * n, n);
+  WAVE_FOR(a, 5) running_sum_inplace(S + a * (n + 4), n);
   WAVE_SYNC();
   pc.mark(slot + 1);
 

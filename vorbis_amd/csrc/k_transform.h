@@ -9,8 +9,8 @@
 // *schedule* differs: each stage's independent butterflies are spread across
 // the 64 lanes with the work vectors in LDS.
 //
-// LDS: A[n] (PCM -> windowed -> FFT buffer "c"), B[n] (MDCT work "w", then FFT
-// buffer "ch").
+// LDS: A[n] (PCM -> windowed -> FFT buffer "c"), B[n + n/32] (MDCT work "w" with its
+// padded butterfly half, then FFT buffer "ch").
 #pragma once
 #include "vamd_wave.h"
 #include "vamd_params.h"
@@ -23,7 +23,7 @@ VAMD_DEV void load_windowed(const XformP &P, int W, int lW, int nW, const float 
                             bool apply_window) {
   const int n = P.n;
   if (!apply_window) {
-    WAVE_FOR(i, n) A[i] = pcm[i];
+    WAVE_FOR(q, n >> 2)((F4 *)A)[q] = ((const F4 *)pcm)[q];
     return;
   }
   lW = W ? lW : 0;
@@ -34,17 +34,24 @@ VAMD_DEV void load_windowed(const XformP &P, int W, int lW, int nW, const float 
   const float *winR = nW ? P.win_long : P.win_short;
   const int leftbegin = n / 4 - ln / 4, leftend = leftbegin + ln / 2;
   const int rightbegin = n / 2 + n / 4 - rn / 4, rightend = rightbegin + rn / 2;
-  WAVE_FOR(i, n) {
-    float v = pcm[i];
-    if (i < leftbegin)
-      v = 0.f;
-    else if (i < leftend)
-      v *= winL[i - leftbegin];
-    else if (i >= rightend)
-      v = 0.f;
-    else if (i >= rightbegin)
-      v *= winR[rn / 2 - 1 - (i - rightbegin)];
-    A[i] = v;
+  // every boundary is a multiple of 4 (block sizes are powers of two >= 64), so a
+  // 16-byte quad never straddles two regions
+  WAVE_FOR(q, n >> 2) {
+    const int i = q << 2;
+    float v[4];
+    f4_get(((const F4 *)pcm)[q], v);
+    if (i < leftbegin || i >= rightend) {
+      v[0] = v[1] = v[2] = v[3] = 0.f;
+    } else if (i < leftend) {
+      float w[4];
+      f4_get(*(const F4 *)(winL + (i - leftbegin)), w);
+      v[0] *= w[0]; v[1] *= w[1]; v[2] *= w[2]; v[3] *= w[3];
+    } else if (i >= rightbegin) {
+      float w[4];  // falling slope = the rising half-window read backwards
+      f4_get(*(const F4 *)(winR + (rn / 2 - 4 - (i - rightbegin))), w);
+      v[0] *= w[3]; v[1] *= w[2]; v[2] *= w[1]; v[3] *= w[0];
+    }
+    ((F4 *)A)[q] = f4_make(v);
   }
 }
 
@@ -152,38 +159,49 @@ VAMD_DEV void bfly32(float *x) {
   bfly16(x + 16);
 }
 
-// mdct_forward, lib/mdct.c:492-562.  `in` = A (windowed block, LDS), work w = B.
-// Leaves the n/2 spectrum in B[0..n/2) *unscaled order as the reference's `out`*
-// by writing it to `out` (LDS or HBM pointer supplied by the caller).
+// The butterfly work vector lives in LDS with two floats of padding after every 32:
+// logical index p sits at PW(p).  Pairs (even p, p+1) stay adjacent and 8-byte
+// aligned, and the 32-point groups that one lane each pull into registers start 34
+// floats apart, which spreads the 64 lanes over all LDS banks (at a plain stride of
+// 32 every lane would hit the same bank).
+#define VAMD_PW(p) ((p) + (((p) >> 5) << 1))
+#define VAMD_PW_SIZE(n2) ((n2) + ((n2) >> 4))
+
+// mdct_forward, lib/mdct.c:492-562.  `in` = A (windowed block, LDS, n floats);
+// w = work buffer: w[0..n2) plain + padded butterfly vector at w + n2
+// (VAMD_PW_SIZE(n2) floats).  The n/2 spectrum is written to out_lds[0..n2).
 VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in, float *w, float *out_lds, PhaseClock &pc) {
   const int n = P.n, n2 = n >> 1, n4 = n >> 2, n8 = n >> 3;
   const float *__restrict__ trig = P.trig;
-  float *w2 = w + n2;
+  float *w2 = w + n2;  // padded: use VAMD_PW()
 
   // fold + pre-twiddle ("window + rotate + step 1"), lib/mdct.c:506-544.
   // Pair p writes w2[2p], w2[2p+1]; the three loops differ in which input
-  // quarter is folded with which sign.
+  // quarter is folded with which sign.  x0[0],x0[2] / x1[0],x1[2] of the reference
+  // are the .x,.z / .y,.w lanes of two aligned quads of the input.
   WAVE_FOR(p, n4) {
-    const float *T = trig + n2 - 2 * (p + 1);
+    const F2 T = *(const F2 *)(trig + n2 - 2 * (p + 1));
     float r0, r1;
     if (2 * p < n8) {
-      const float *x0 = in + n2 + n4 - 4 * (p + 1);
-      const float *x1 = in + n2 + n4 + 1 + 4 * p;
-      r0 = x0[2] + x1[0];
-      r1 = x0[0] + x1[2];
+      const F4 x0 = *(const F4 *)(in + n2 + n4 - 4 * (p + 1));
+      const F4 x1 = *(const F4 *)(in + n2 + n4 + 4 * p);
+      r0 = x0.z + x1.y;
+      r1 = x0.x + x1.w;
     } else if (2 * p < n2 - n8) {
-      const float *x0 = in + n2 + n4 - 4 * (p + 1);
-      const float *x1 = in + 1 + 4 * (p - n8 / 2);
-      r0 = x0[2] - x1[0];
-      r1 = x0[0] - x1[2];
+      const F4 x0 = *(const F4 *)(in + n2 + n4 - 4 * (p + 1));
+      const F4 x1 = *(const F4 *)(in + 4 * (p - n8 / 2));
+      r0 = x0.z - x1.y;
+      r1 = x0.x - x1.w;
     } else {
-      const float *x0 = in + n - 4 * (p - (n2 - n8) / 2 + 1);
-      const float *x1 = in + 1 + 4 * (p - n8 / 2);
-      r0 = -x0[2] - x1[0];
-      r1 = -x0[0] - x1[2];
+      const F4 x0 = *(const F4 *)(in + n - 4 * (p - (n2 - n8) / 2 + 1));
+      const F4 x1 = *(const F4 *)(in + 4 * (p - n8 / 2));
+      r0 = -x0.z - x1.y;
+      r1 = -x0.x - x1.w;
     }
-    w2[2 * p] = r1 * T[1] + r0 * T[0];
-    w2[2 * p + 1] = r1 * T[0] - r0 * T[1];
+    F2 o;
+    o.x = r1 * T.y + r0 * T.x;
+    o.y = r1 * T.x - r0 * T.y;
+    *(F2 *)(w2 + VAMD_PW(2 * p)) = o;
   }
   WAVE_SYNC();
   pc.mark(1);
@@ -195,17 +213,20 @@ VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in, float *w, floa
   // stage in total, all independent.
   const int nstages = P.log2n - 6;  // first + (log2n-7) generic passes
   for (int s = 0; s < nstages; s++) {
-    const int pts = n2 >> s, per = pts >> 2, tstride = 4 << s;
+    const int pts = n2 >> s, lper = P.log2n - 3 - s, tstride = 4 << s;  // per = pts/4 = 1 << lper
     WAVE_FOR(g, n8) {
-      const int j = g / per, q = g - j * per;
-      float *a = w2 + pts * j + pts - 2 - 2 * q;
-      float *b = w2 + pts * j + (pts >> 1) - 2 - 2 * q;
-      const float *T = trig + tstride * q;
-      float r0 = a[0] - b[0], r1 = a[1] - b[1];
-      a[0] += b[0];
-      a[1] += b[1];
-      b[0] = r1 * T[1] + r0 * T[0];
-      b[1] = r1 * T[0] - r0 * T[1];
+      const int j = g >> lper, q = g & ((1 << lper) - 1);
+      const int ia = pts * j + pts - 2 - 2 * q, ib = pts * j + (pts >> 1) - 2 - 2 * q;
+      F2 *pa = (F2 *)(w2 + VAMD_PW(ia)), *pb = (F2 *)(w2 + VAMD_PW(ib));
+      const F2 T = *(const F2 *)(trig + tstride * q);
+      F2 a = *pa, b = *pb;
+      const float r0 = a.x - b.x, r1 = a.y - b.y;
+      a.x += b.x;
+      a.y += b.y;
+      b.x = r1 * T.y + r0 * T.x;
+      b.y = r1 * T.x - r0 * T.y;
+      *pa = a;
+      *pb = b;
     }
     WAVE_SYNC();
   }
@@ -213,11 +234,25 @@ VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in, float *w, floa
   // 32-point butterflies, one group per lane, in registers
   WAVE_FOR(g, n2 / 32) {
     float v[32];
+    F2 *pg = (F2 *)(w2 + 34 * g);  // == VAMD_PW(32 g)
+#if VAMD_GPU
 #pragma unroll
-    for (int k = 0; k < 32; k++) v[k] = w2[32 * g + k];
+#endif
+    for (int k = 0; k < 16; k++) {
+      const F2 t = pg[k];
+      v[2 * k] = t.x;
+      v[2 * k + 1] = t.y;
+    }
     bfly32(v);
+#if VAMD_GPU
 #pragma unroll
-    for (int k = 0; k < 32; k++) w2[32 * g + k] = v[k];
+#endif
+    for (int k = 0; k < 16; k++) {
+      F2 t;
+      t.x = v[2 * k];
+      t.y = v[2 * k + 1];
+      pg[k] = t;
+    }
   }
   WAVE_SYNC();
   pc.mark(3);
@@ -226,30 +261,33 @@ VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in, float *w, floa
   // lower half w[0..n2).  Unit u produces w[2u], w[2u+1], w[n2-2u-2], w[n2-2u-1].
   const int *__restrict__ bit = P.bitrev;
   WAVE_FOR(u, n8) {
-    const float *x0 = w2 + bit[2 * u];
-    const float *x1 = w2 + bit[2 * u + 1];
-    const float T0 = trig[n + 2 * u], T1 = trig[n + 2 * u + 1];
-    float r0 = x0[1] - x1[1];
-    float r1 = x0[0] + x1[0];
-    float r2 = r1 * T0 + r0 * T1;
-    float r3 = r1 * T1 - r0 * T0;
-    r0 = (x0[1] + x1[1]) * .5f;
-    r1 = (x0[0] - x1[0]) * .5f;
-    w[2 * u] = r0 + r2;
-    w[2 * u + 1] = r1 + r3;
-    w[n2 - 2 * u - 2] = r0 - r2;
-    w[n2 - 2 * u - 1] = r3 - r1;
+    const I2 bi = *(const I2 *)(bit + 2 * u);
+    const F2 x0 = *(const F2 *)(w2 + VAMD_PW(bi.x));
+    const F2 x1 = *(const F2 *)(w2 + VAMD_PW(bi.y));
+    const F2 T = *(const F2 *)(trig + n + 2 * u);
+    float r0 = x0.y - x1.y;
+    float r1 = x0.x + x1.x;
+    const float r2 = r1 * T.x + r0 * T.y;
+    const float r3 = r1 * T.y - r0 * T.x;
+    r0 = (x0.y + x1.y) * .5f;
+    r1 = (x0.x - x1.x) * .5f;
+    F2 lo, hi;
+    lo.x = r0 + r2;
+    lo.y = r1 + r3;
+    hi.x = r0 - r2;
+    hi.y = r3 - r1;
+    *(F2 *)(w + 2 * u) = lo;
+    *(F2 *)(w + n2 - 2 * u - 2) = hi;
   }
   WAVE_SYNC();
   pc.mark(4);
 
-  // final rotate * scale, lib/mdct.c:552-561 -> out[n2] (placed in w2 region,
-  // which is dead now)
+  // final rotate * scale, lib/mdct.c:552-561 -> out[n2]
   WAVE_FOR(i, n4) {
-    const float *T = trig + n2 + 2 * i;
-    const float a = w[2 * i], b = w[2 * i + 1];
-    out_lds[i] = (a * T[0] + b * T[1]) * P.mdct_scale;
-    out_lds[n2 - 1 - i] = (a * T[1] - b * T[0]) * P.mdct_scale;
+    const F2 T = *(const F2 *)(trig + n2 + 2 * i);
+    const F2 ab = *(const F2 *)(w + 2 * i);
+    out_lds[i] = (ab.x * T.x + ab.y * T.y) * P.mdct_scale;
+    out_lds[n2 - 1 - i] = (ab.x * T.y - ab.y * T.x) * P.mdct_scale;
   }
   WAVE_SYNC();
 }

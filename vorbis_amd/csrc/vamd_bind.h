@@ -123,6 +123,12 @@ inline int build_image(const void *blob_v, size_t bytes, std::vector<unsigned ch
     image->insert(image->end(), b, b + 4 * d.seed_span.size());
     derived->push_back(d);
   }
+  for (int W = 0; W < 2; W++) {
+    std::vector<unsigned char> bi = derive_bin_interval(h.mode[W].floor, h.blocksizes[W] / 2);
+    while (image->size() & 15) image->push_back(0);
+    derived_off->push_back((uint32_t)image->size());
+    image->insert(image->end(), bi.begin(), bi.end());
+  }
   while (image->size() & 15) image->push_back(0);
   return VAMD_OK;
 }
@@ -172,6 +178,7 @@ inline void bind_params(const std::vector<unsigned char> &image, const std::vect
     F.reverse_index = (const int *)(base + fo + offsetof(vamd_floor1_tab, reverse_index));
     F.hineighbor = (const int *)(base + fo + offsetof(vamd_floor1_tab, hineighbor));
     F.loneighbor = (const int *)(base + fo + offsetof(vamd_floor1_tab, loneighbor));
+    F.bin_interval = base + derived_off[8 + W];
 
     CoupleP &C = B->couple[W];
     const int blob_k = VAMD_PACKETBLOBS / 2;

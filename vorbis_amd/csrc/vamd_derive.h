@@ -89,6 +89,20 @@ inline PsyDerived derive_psy(const vamd_psy_tab &t, const unsigned char *blob) {
   return d;
 }
 
+// accumulate_fit (lib/floor1.c:406-454) is called once per pair of neighbouring
+// posts with the inclusive bin range [sorted_index[j], sorted_index[j+1]] clipped to
+// look_n-1.  bin_interval[i] = the interval j whose range starts at or before bin i
+// (the last such j); a bin sitting exactly on an interior post also belongs to j-1.
+inline std::vector<unsigned char> derive_bin_interval(const vamd_floor1_tab &f, int n2) {
+  std::vector<unsigned char> t((size_t)n2, 255);
+  for (int j = 0; j + 1 < f.posts; j++) {
+    int x0 = f.sorted_index[j], x1 = f.sorted_index[j + 1];
+    if (x1 >= f.look_n) x1 = f.look_n - 1;
+    for (int i = x0; i <= x1 && i < n2; i++) t[i] = (unsigned char)j;
+  }
+  return t;
+}
+
 // stereo_threshholds / _limited, lib/psy.c:32-33
 inline float stereo_threshold(int idx, bool limited) {
   static const double a[] = {0.0, .5, 1.0, 1.5, 2.5, 4.5, 8.5, 16.5, 9e10};

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(64) void k_noise(PsyP P0, PsyP P1, DescP d, int ch,
   const long blk = cb / ch;
   const PsyP &P = d_bt(d, blk) ? P1 : P0;
   const int n2 = P.n;
-  float *S = (float *)vamd_smem, *nz = S + 5 * n2, *wk = nz + n2;
+  float *S = (float *)vamd_smem, *nz = S + 5 * (n2 + 4), *wk = nz + n2;
   PhaseClock pc;
   pc.start(d.dbg ? d.dbg + 16 : nullptr);
   noisemask_block(P, logmdct + cb * n2, noise + cb * n2, S, nz, wk, pc);
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(64) void k_couple(PsyP P0, PsyP P1, CoupleP C, Desc
     op[c] = iwork + (blk * ch + c) * n2;
     nz[c] = nonzero[blk * ch + c];
   }
-  WAVE_SYNC();  // every lane has read nonzero[] before lane 0 rewrites it
+  WAVE_SYNC_GLOBAL();  // every lane has read nonzero[] before lane 0 rewrites it
   PhaseClock pc;
   pc.start(d.dbg ? d.dbg + 64 : nullptr);
   couple_block(C, P, n2, mp, ip, op, nz, L, pc);
@@ -444,7 +444,8 @@ int vamd_mdct_forward_batch(vamd_ctx *c, int W, const float *in, float *out, lon
   if (!in || !out) return fail(c, VAMD_EINVAL, "null frame buffer");
   if (nframes > 0x7fffffffL) return fail(c, VAMD_EINVAL, "too many frames for one launch");
   const XformP &P = c->B.xf[W];
-  hipLaunchKernelGGL(k_mdct_only, dim3((unsigned)nframes), dim3(64), (size_t)P.n * 8, c->stream, P, W, in, out);
+  hipLaunchKernelGGL(k_mdct_only, dim3((unsigned)nframes), dim3(64), (size_t)(2 * P.n + P.n / 32) * 4, c->stream, P, W, in,
+                     out);
   HIP_TRY(c, hipGetLastError());
   return VAMD_OK;
 }
@@ -491,7 +492,7 @@ static int run_batch(vamd_ctx *c, const vamd_batch_desc *desc, const vamd_batch_
 
   int nst = 0;
   prof_mark(c);
-  hipLaunchKernelGGL(k_transform, dim3(gcb), dim3(64), (size_t)n * 8, s, X, W, d, ch, io->pcm, p.mdct_raw, p.logmdct,
+  hipLaunchKernelGGL(k_transform, dim3(gcb), dim3(64), (size_t)(2 * n + n / 32) * 4, s, X, W, d, ch, io->pcm, p.mdct_raw, p.logmdct,
                      p.logfft, p.local);
   prof_mark(c), nst++;
   if (stream_mode) {
@@ -504,7 +505,7 @@ static int run_batch(vamd_ctx *c, const vamd_batch_desc *desc, const vamd_batch_
   }
   prof_mark(c), nst++;
   if (level >= VAMD_LEVEL_PSY) {
-    hipLaunchKernelGGL(k_noise, dim3(gcb), dim3(64), (size_t)n2 * 7 * 4, s, P0, P1, d, ch, p.logmdct, p.noise);
+    hipLaunchKernelGGL(k_noise, dim3(gcb), dim3(64), (size_t)(n2 * 7 + 20) * 4, s, P0, P1, d, ch, p.logmdct, p.noise);
     prof_mark(c), nst++;
     {
       const int nlp = (nl + 15) & ~15;

@@ -53,6 +53,7 @@ struct FloorP {
   int posts, look_n, quant_q, mult;
   float maxover, maxunder, maxerr, twofitweight, twofitatten;
   const int *postlist, *sorted_index, *forward_index, *reverse_index, *hineighbor, *loneighbor;
+  const unsigned char *bin_interval;  // [n2] derived: accumulate_fit interval of each bin (255 = none)
 };
 
 struct CoupleP {

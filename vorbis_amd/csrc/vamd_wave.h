@@ -30,7 +30,19 @@
 #define VAMD_DEV_NOINLINE __device__ __noinline__
 #define LANE ((int)threadIdx.x)
 #define NLANES 64
-#define WAVE_SYNC() __syncthreads()
+// Phase boundary for data exchanged through LDS.  The workgroup IS one wavefront, and
+// the LDS unit executes a wave's DS instructions in issue order, so a later ds_read
+// already sees every lane's earlier ds_write: all that is needed is that the
+// compiler keeps the two sides apart.  Unlike __syncthreads() this does not drain
+// outstanding HBM loads/stores (s_waitcnt vmcnt(0)) at every phase.
+#define WAVE_SYNC()                                         \
+  do {                                                      \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  \
+    __builtin_amdgcn_wave_barrier();                        \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
+  } while (0)
+// Phase boundary for data exchanged through HBM between lanes of the wave.
+#define WAVE_SYNC_GLOBAL() __syncthreads()
 #else
 #include <math.h>
 #define VAMD_DEV static inline
@@ -38,6 +50,7 @@
 #define LANE 0
 #define NLANES 1
 #define WAVE_SYNC() ((void)0)
+#define WAVE_SYNC_GLOBAL() ((void)0)
 #endif
 
 // lanes stride over [0, count).  On the GPU the loop is unrolled x4 so that the
@@ -109,6 +122,12 @@ struct alignas(16) F4 {
 struct alignas(16) I4 {
   int x, y, z, w;
 };
+struct alignas(8) F2 {
+  float x, y;
+};
+struct alignas(8) I2 {
+  int x, y;
+};
 
 // Optional in-kernel stopwatch (measurement aid, off unless vamd_debug_cycles() armed it):
 // lane 0 of every wave adds the shader-clock ticks spent since the previous mark to a slot.
@@ -132,6 +151,20 @@ struct PhaseClock {
   VAMD_DEV void mark(int) {}
 #endif
 };
+
+// Exact floor(num/den) for 0 <= num < 2^24, 0 < den < 2^12 without the integer-divide
+// expansion: one fp32 multiply by a precomputed reciprocal, then a +-1 fix-up.
+VAMD_DEV float div_rcp(int den) { return 1.0f / (float)den; }
+VAMD_DEV int div_small(int num, int den, float rcp) {
+  int q = (int)((float)num * rcp);
+  const int r = num - q * den;
+  if (r < 0) q--;
+  if (r >= den) q++;
+  return q;
+}
+
+VAMD_DEV void f4_get(const F4 &v, float *a) { a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w; }
+VAMD_DEV F4 f4_make(const float *a) { F4 v; v.x = a[0]; v.y = a[1]; v.z = a[2]; v.w = a[3]; return v; }
 
 // ---- scalar helpers shared by all stages ------------------------------------
 
