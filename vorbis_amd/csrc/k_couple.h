@@ -73,12 +73,98 @@ VAMD_DEV void noise_norm_partition(const PsyP &P, const CoupleLds &L, int b0, in
   }
 }
 
+// per-bin state of one channel before coupling (lib/psy.c:1081-1109)
+struct ChanBin {
+  float re, qe, fl2;  // signed energy, energy, squared floor
+  int fg;             // flag_lossless
+  int out;            // first quantisation (valid unless `cand` >= 0)
+  float cand;         // noise-norm candidate energy, or -1
+};
+
+VAMD_DEV ChanBin chan_bin(int nzk, float m, int ilog, int b, int nstart, const CoupleP &C) {
+  ChanBin r;
+  r.out = 0;
+  r.cand = -1.f;
+  if (nzk) {
+    const float f = floor1_fromdB(ilog);
+    const float point = b >= C.pointlimit ? C.postpoint : C.prepoint;
+    const float rr = (float)(fabs((double)m) / (double)f);  // flag_lossless, lib/psy.c:928-933
+    r.fg = rr < point ? 0 : 1;
+    r.re = m * m;
+    r.qe = r.re;
+    if (m < 0.f) r.re *= -1.f;
+    r.fl2 = f * f;
+    const float ve = r.qe / r.fl2;
+    if (b < nstart || !(ve < .25f))
+      r.out = quant_energy(ve, r.re);
+    else
+      r.cand = ve;  // flags == NULL: every small bin past normal_start is a candidate
+  } else {
+    r.fl2 = 1e-10f;
+    r.re = 0.f;
+    r.qe = 0.f;
+    r.fg = 0;
+  }
+  return r;
+}
+
+// one bin of the coupling step (lib/psy.c:1129-1196) followed by the magnitude's
+// re-normalisation (noise_normalize with flags); M/A are updated in place, iM/iA
+// are the integers quantised so far.  Returns the magnitude's noise-norm
+// candidate energy or -1.
+VAMD_DEV float couple_bin(ChanBin &M, ChanBin &A, int &iM, int &iA, int b, int nstart, const CoupleP &C) {
+  if (b < C.sliding_lowpass) {
+    if (M.fg || A.fg) {
+      // lossless: square-polar coupling of the already quantised integers
+      M.re = (float)(fabs((double)M.re) + fabs((double)A.re));
+      M.qe = M.qe + A.qe;
+      M.fg = A.fg = 1;
+      const int a = iM, bb = iA;
+      const int aA = a < 0 ? -a : a, aB = bb < 0 ? -bb : bb;
+      if (aA > aB) {
+        iA = (a > 0 ? a - bb : bb - a);
+      } else {
+        iA = (bb > 0 ? a - bb : bb - a);
+        iM = bb;
+      }
+      if (iA >= (iM < 0 ? -iM : iM) * 2) {
+        iA = -iA;
+        iM = -iM;
+      }
+    } else {
+      // lossy point coupling
+      if (b < C.pointlimit) {
+        M.re += A.re;
+        M.qe = (float)fabs((double)M.re);
+      } else {
+        const float e = (float)(fabs((double)M.re) + fabs((double)A.re));
+        M.qe = e;
+        M.re = (M.re + A.re < 0) ? -e : e;
+      }
+      A.re = A.qe = 0.f;
+      A.fg = 1;
+      iA = 0;
+    }
+  }
+  M.fl2 = A.fl2 = M.fl2 + A.fl2;
+  float cand = -1.f;
+  if (!M.fg) {
+    const float ve = M.qe / M.fl2;
+    if (b < nstart || !(ve < .25f && b >= C.pointlimit))
+      iM = quant_energy(ve, M.re);
+    else
+      cand = ve;
+  }
+  return cand;
+}
+
 // mdct[k]      HBM [n2]  post-M1 spectrum of channel k
 // ilogmask[k]  HBM [n2]  integer floor curve (floor1_encode's output)
 // iwork[k]     HBM [n2]  out: quantised (and coupled) residue
 // nonzero      [ch] in: floor1_encode's return per channel; out: after the coupling fix-up
 VAMD_DEV void couple_block(const CoupleP &C, const PsyP &P, int n2, const float *const *mdct,
-                           const int *const *ilogmask, int *const *iwork, int *nonzero, const CoupleLds &L, PhaseClock &pc) {
+                           const int *const *ilogmask, int *const *iwork, int *nonzero, const CoupleLds &L,
+                           PhaseClock &pc) {
   const int ch = C.ch;
   const int partition = P.normal_p ? P.normal_partition : 16;
   const int nstart = P.normal_p ? P.normal_start : 0x7fffffff;  // first bin subject to noise norm
@@ -86,36 +172,65 @@ VAMD_DEV void couple_block(const CoupleP &C, const PsyP &P, int n2, const float 
   const int nparts = (n2 + partition - 1) / partition;
   int nz[VAMD_MAX_CH];
   for (int k = 0; k < ch; k++) nz[k] = nonzero[k];
+  const bool coupled = C.coupling_steps == 1 && (nz[C.mag] || nz[C.ang]);
 
-  // ---- per channel: floor lookup, lossless flags, energies, first quantisation
-  for (int k = 0; k < ch; k++) {
-    WAVE_FOR(b, n2) {
-      int out = 0;
-      float cand = -1.f, key = 0.f, sg = 0.f;
-      if (nz[k]) {
-        const float m = mdct[k][b];
-        const float fl = floor1_fromdB(ilogmask[k][b]);
-        float raw = m * m;
-        const float quant = raw;
-        if (m < 0.f) raw *= -1.f;
-        const float fl2 = fl * fl;
-        const float ve = quant / fl2;
-        if (b < nstart || !(ve < .25f)) {
-          out = quant_energy(ve, raw);
-        } else {
-          cand = ve;  // flags == NULL: every small bin past normal_start is a candidate
-          key = quant;
-          sg = raw;
-        }
+  if (!norm_active) {
+    // Common case (noise normalisation inactive in this block size, e.g. q >= 0.4 at
+    // 44.1 kHz): nothing is ordered, so each lane takes quads of bins straight through
+    // quantise -> couple -> re-normalise with one 16-byte load per input tensor.
+    const int Mi = C.coupling_steps == 1 ? C.mag : 0, Ai = C.coupling_steps == 1 ? C.ang : (ch > 1 ? 1 : 0);
+    WAVE_FOR(q, n2 >> 2) {
+      float m0[4], m1[4];
+      int l0[4], l1[4], o0[4], o1[4];
+      f4_get(((const F4 *)mdct[Mi])[q], m0);
+      const I4 t0 = ((const I4 *)ilogmask[Mi])[q];
+      l0[0] = t0.x; l0[1] = t0.y; l0[2] = t0.z; l0[3] = t0.w;
+      if (ch > 1) {
+        f4_get(((const F4 *)mdct[Ai])[q], m1);
+        const I4 t1 = ((const I4 *)ilogmask[Ai])[q];
+        l1[0] = t1.x; l1[1] = t1.y; l1[2] = t1.z; l1[3] = t1.w;
       }
-      iwork[k][b] = out;
-      if (norm_active) {
-        L.cand[b] = cand;
-        L.key[b] = key;
-        L.sgn[b] = sg;
+#if VAMD_GPU
+#pragma unroll
+#endif
+      for (int c = 0; c < 4; c++) {
+        const int b = (q << 2) + c;
+        ChanBin M = chan_bin(nz[Mi], m0[c], l0[c], b, nstart, C);
+        int iM = M.out, iA = 0;
+        if (ch > 1) {
+          ChanBin A = chan_bin(nz[Ai], m1[c], l1[c], b, nstart, C);
+          iA = A.out;
+          if (coupled) couple_bin(M, A, iM, iA, b, nstart, C);
+        }
+        o0[c] = iM;
+        o1[c] = iA;
+      }
+      I4 w0, w1;
+      w0.x = o0[0]; w0.y = o0[1]; w0.z = o0[2]; w0.w = o0[3];
+      ((I4 *)iwork[Mi])[q] = w0;
+      if (ch > 1) {
+        w1.x = o1[0]; w1.y = o1[1]; w1.z = o1[2]; w1.w = o1[3];
+        ((I4 *)iwork[Ai])[q] = w1;
       }
     }
-    if (norm_active && nz[k]) {
+    pc.mark(0);
+    if (coupled) nz[C.mag] = nz[C.ang] = 1;  // lib/psy.c:1204-1212
+    for (int k = 0; k < ch; k++) nonzero[k] = nz[k];
+    pc.mark(1);
+    return;
+  }
+
+  // ---- general path: noise normalisation's ordered sort may touch any partition.
+  // per channel: floor lookup, lossless flags, energies, first quantisation
+  for (int k = 0; k < ch; k++) {
+    WAVE_FOR(b, n2) {
+      const ChanBin B = chan_bin(nz[k], nz[k] ? mdct[k][b] : 0.f, nz[k] ? ilogmask[k][b] : 0, b, nstart, C);
+      iwork[k][b] = B.out;
+      L.cand[b] = B.cand;
+      L.key[b] = B.qe;
+      L.sgn[b] = B.re;
+    }
+    if (nz[k]) {
       WAVE_SYNC_GLOBAL();  // iwork[] changes hands between lanes through HBM
       WAVE_FOR(p, nparts) {
         const int b0 = p * partition;
@@ -125,98 +240,30 @@ VAMD_DEV void couple_block(const CoupleP &C, const PsyP &P, int n2, const float 
       WAVE_SYNC_GLOBAL();
     }
   }
-
   pc.mark(0);
   // ---- coupling (one step: magnitude Mi, angle Ai), lib/psy.c:1111-1201
-  if (C.coupling_steps == 1 && (nz[C.mag] || nz[C.ang])) {
+  if (coupled) {
     const int Mi = C.mag, Ai = C.ang;
     WAVE_FOR(b, n2) {
-      // rebuild the per-bin state pass A had (cheaper than keeping it in LDS)
-      float re[2], qe[2], fl[2];
-      int fg[2];
-      for (int s = 0; s < 2; s++) {
-        const int k = s ? Ai : Mi;
-        if (nz[k]) {
-          const float m = mdct[k][b];
-          const float f = floor1_fromdB(ilogmask[k][b]);
-          const float point = b >= C.pointlimit ? C.postpoint : C.prepoint;
-          const float r = (float)(fabs((double)m) / (double)f);  // flag_lossless, lib/psy.c:928-933
-          fg[s] = r < point ? 0 : 1;
-          re[s] = m * m;
-          qe[s] = re[s];
-          if (m < 0.f) re[s] *= -1.f;
-          fl[s] = f * f;
-        } else {
-          fl[s] = 1e-10f;
-          re[s] = 0.f;
-          qe[s] = 0.f;
-          fg[s] = 0;
-        }
-      }
+      // rebuild the per-bin state the first pass had (cheaper than keeping it in LDS)
+      ChanBin M = chan_bin(nz[Mi], nz[Mi] ? mdct[Mi][b] : 0.f, nz[Mi] ? ilogmask[Mi][b] : 0, b, nstart, C);
+      ChanBin A = chan_bin(nz[Ai], nz[Ai] ? mdct[Ai][b] : 0.f, nz[Ai] ? ilogmask[Ai][b] : 0, b, nstart, C);
       int iM = iwork[Mi][b], iA = iwork[Ai][b];
-      if (b < C.sliding_lowpass) {
-        if (fg[0] || fg[1]) {
-          // lossless: square-polar coupling of the already quantised integers
-          re[0] = (float)(fabs((double)re[0]) + fabs((double)re[1]));
-          qe[0] = qe[0] + qe[1];
-          fg[0] = fg[1] = 1;
-          const int A = iM, B = iA;
-          const int aA = A < 0 ? -A : A, aB = B < 0 ? -B : B;
-          if (aA > aB) {
-            iA = (A > 0 ? A - B : B - A);
-          } else {
-            iA = (B > 0 ? A - B : B - A);
-            iM = B;
-          }
-          if (iA >= (iM < 0 ? -iM : iM) * 2) {
-            iA = -iA;
-            iM = -iM;
-          }
-        } else {
-          // lossy point coupling
-          if (b < C.pointlimit) {
-            re[0] += re[1];
-            qe[0] = (float)fabs((double)re[0]);
-          } else {
-            const float e = (float)(fabs((double)re[0]) + fabs((double)re[1]));
-            qe[0] = e;
-            re[0] = (re[0] + re[1] < 0) ? -e : e;
-          }
-          re[1] = qe[1] = 0.f;
-          fg[1] = 1;
-          iA = 0;
-        }
-      }
-      fl[0] = fl[1] = fl[0] + fl[1];
-      // normalise the magnitude vector (noise_normalize with flags = fM)
-      float cand = -1.f;
-      if (!fg[0]) {
-        const float ve = qe[0] / fl[0];
-        if (b < nstart || !(ve < .25f && b >= C.pointlimit)) {
-          iM = quant_energy(ve, re[0]);
-        } else {
-          cand = ve;
-        }
-      }
+      const float cand = couple_bin(M, A, iM, iA, b, nstart, C);
       iwork[Mi][b] = iM;
       iwork[Ai][b] = iA;
-      if (norm_active) {
-        L.cand[b] = cand;
-        L.key[b] = qe[0];
-        L.sgn[b] = re[0];
-      }
+      L.cand[b] = cand;
+      L.key[b] = M.qe;
+      L.sgn[b] = M.re;
     }
-    if (norm_active) {
-      WAVE_SYNC_GLOBAL();
-      WAVE_FOR(p, nparts) {
-        const int b0 = p * partition;
-        const int jn = partition > n2 - b0 ? n2 - b0 : partition;
-        noise_norm_partition(P, L, b0, jn, iwork[Mi]);
-      }
-      WAVE_SYNC_GLOBAL();
+    WAVE_SYNC_GLOBAL();
+    WAVE_FOR(p, nparts) {
+      const int b0 = p * partition;
+      const int jn = partition > n2 - b0 ? n2 - b0 : partition;
+      noise_norm_partition(P, L, b0, jn, iwork[Mi]);
     }
-    // lib/psy.c:1204-1212
-    nz[Mi] = nz[Ai] = 1;
+    WAVE_SYNC_GLOBAL();
+    nz[Mi] = nz[Ai] = 1;  // lib/psy.c:1204-1212
   }
   for (int k = 0; k < ch; k++) nonzero[k] = nz[k];
   pc.mark(1);

@@ -26,7 +26,15 @@ struct FitAcc {  // lsfit_acc, lib/floor1.c:32-49 (x0/x1 come from sorted_index)
   int xb, yb, x2b, y2b, xyb, bn;
 };
 
+// fit_line's per-interval contribution (lib/floor1.c:463-472): depends only on the
+// interval's accumulators, so it is formed once (one lane per interval) and the
+// ordered fp64 summation over a range of intervals just adds these up
+struct FitTerm {
+  double xb, yb, x2b, xyb, bn;
+};
+
 struct FloorScratch {
+  FitTerm term[VAMD_MAXPOSTS];
   FitAcc acc[VAMD_MAXPOSTS];
   int fitA[VAMD_MAXPOSTS], fitB[VAMD_MAXPOSTS];
   int lon[VAMD_MAXPOSTS], hin[VAMD_MAXPOSTS], memo[VAMD_MAXPOSTS];
@@ -83,26 +91,6 @@ VAMD_DEV void offset_and_mix_wave(const PsyP &P, const float *__restrict__ noise
   pc.mark(0);
 }
 
-// accumulate_fit, lib/floor1.c:406-454, interval [x0, x1] inclusive
-VAMD_DEV int accumulate_fit_one(const float *flr, const float *mdct, int x0, int x1, FitAcc *a, int n,
-                                float twofitatten) {
-  int xa = 0, ya = 0, x2a = 0, y2a = 0, xya = 0, na = 0, xb = 0, yb = 0, x2b = 0, y2b = 0, xyb = 0, nb = 0;
-  if (x1 >= n) x1 = n - 1;
-  for (int i = x0; i <= x1; i++) {
-    const int q = dBquant(flr[i]);
-    if (q) {
-      if (mdct[i] + twofitatten >= flr[i]) {
-        xa += i; ya += q; x2a += i * i; y2a += q * q; xya += i * q; na++;
-      } else {
-        xb += i; yb += q; x2b += i * i; y2b += q * q; xyb += i * q; nb++;
-      }
-    }
-  }
-  a->xa = xa; a->ya = ya; a->x2a = x2a; a->y2a = y2a; a->xya = xya; a->an = na;
-  a->xb = xb; a->yb = yb; a->x2b = x2b; a->y2b = y2b; a->xyb = xyb; a->bn = nb;
-  return na;
-}
-
 // add a lane's private sums to an interval's accumulators and clear them
 VAMD_DEV void accumulate_flush(FitAcc *dst, FitAcc &t) {
   if (t.an) {
@@ -118,24 +106,32 @@ VAMD_DEV void accumulate_flush(FitAcc *dst, FitAcc &t) {
 
 // fit_line, lib/floor1.c:456-514.  a[0..fits) are consecutive intervals whose
 // outer x range is [x0, x1] (sorted_index of the first / one past the last).
-VAMD_DEV int fit_line(const FitAcc *a, int fits, int x0, int x1, int *y0, int *y1, float twofitweight) {
-  double xb = 0, yb = 0, x2b = 0, y2b = 0, xyb = 0, bn = 0;
+VAMD_DEV FitTerm fit_term(const FitAcc &a, float twofitweight) {
+  const double weight = (double)((float)(a.bn + a.an) * twofitweight / (float)(a.an + 1)) + 1.;
+  FitTerm t;
+  t.xb = a.xb + a.xa * weight;
+  t.yb = a.yb + a.ya * weight;
+  t.x2b = a.x2b + a.x2a * weight;
+  t.xyb = a.xyb + a.xya * weight;
+  t.bn = a.bn + a.an * weight;
+  return t;  // (the reference also sums y2b, which nothing reads)
+}
+
+VAMD_DEV int fit_line(const FitTerm *a, int fits, int x0, int x1, int *y0, int *y1) {
+  double xb = 0, yb = 0, x2b = 0, xyb = 0, bn = 0;
   for (int i = 0; i < fits; i++) {
-    const double weight = (double)((float)(a[i].bn + a[i].an) * twofitweight / (float)(a[i].an + 1)) + 1.;
-    xb += a[i].xb + a[i].xa * weight;
-    yb += a[i].yb + a[i].ya * weight;
-    x2b += a[i].x2b + a[i].x2a * weight;
-    y2b += a[i].y2b + a[i].y2a * weight;
-    xyb += a[i].xyb + a[i].xya * weight;
-    bn += a[i].bn + a[i].an * weight;
+    xb += a[i].xb;
+    yb += a[i].yb;
+    x2b += a[i].x2b;
+    xyb += a[i].xyb;
+    bn += a[i].bn;
   }
   if (*y0 >= 0) {
-    xb += x0; yb += *y0; x2b += x0 * x0; y2b += *y0 * *y0; xyb += *y0 * x0; bn++;
+    xb += x0; yb += *y0; x2b += x0 * x0; xyb += *y0 * x0; bn++;
   }
   if (*y1 >= 0) {
-    xb += x1; yb += *y1; x2b += x1 * x1; y2b += *y1 * *y1; xyb += *y1 * x1; bn++;
+    xb += x1; yb += *y1; x2b += x1 * x1; xyb += *y1 * x1; bn++;
   }
-  (void)y2b;
   const double denom = (bn * x2b - xb * xb);
   if (denom > 0.) {
     const double aa = (yb * x2b - xyb * xb) / denom;
@@ -244,47 +240,55 @@ VAMD_DEV int floor_fit_render_block(const FloorP &F, int n2, const float *mask, 
   // them privately and adds the six integer sums of each class to the owning interval
   // (integer adds commute, so the totals equal the reference's sequential sums)
   int nz = 0;
-  WAVE_FOR(qd, (n + 3) >> 2) {
-    const int i0 = qd << 2;
-    float mk[4], lm[4];
-    f4_get(((const F4 *)mask)[qd], mk);
-    f4_get(((const F4 *)lmd)[qd], lm);
+  // each lane owns 16 consecutive bins (4 quads), so it rarely crosses an interval
+  WAVE_FOR(span, (n + 15) >> 4) {
     int jprev = -1;
     FitAcc t;
     t.xa = t.ya = t.x2a = t.y2a = t.xya = t.an = t.xb = t.yb = t.x2b = t.y2b = t.xyb = t.bn = 0;
+    for (int qd = span << 2; qd < (span << 2) + 4 && (qd << 2) < n; qd++) {
+      const int i0 = qd << 2;
+      float mk[4], lm[4];
+      f4_get(((const F4 *)mask)[qd], mk);
+      f4_get(((const F4 *)lmd)[qd], lm);
+      const unsigned int jq = ((const unsigned int *)F.bin_interval)[qd];  // 4 bins' interval bytes
 #if VAMD_GPU
 #pragma unroll
 #endif
-    for (int c = 0; c < 4; c++) {
-      const int i = i0 + c;
-      const int j = i < n ? (int)F.bin_interval[i] : 255;
-      const int q = j != 255 ? dBquant(mk[c]) : 0;
-      if (j != jprev) {
-        if (jprev >= 0) accumulate_flush(&sc->acc[jprev], t);
-        jprev = j == 255 ? -1 : j;
-      }
-      if (q) {
-        FitAcc b;
-        b.xa = b.ya = b.x2a = b.y2a = b.xya = b.an = b.xb = b.yb = b.x2b = b.y2b = b.xyb = b.bn = 0;
-        const bool cls_a = lm[c] + F.twofitatten >= mk[c];
-        if (cls_a) {
-          b.xa = i; b.ya = q; b.x2a = i * i; b.y2a = q * q; b.xya = i * q; b.an = 1;
-        } else {
-          b.xb = i; b.yb = q; b.x2b = i * i; b.y2b = q * q; b.xyb = i * q; b.bn = 1;
+      for (int c = 0; c < 4; c++) {
+        const int i = i0 + c;
+        const int jb = (int)((jq >> (8 * c)) & 0xff);
+        const int j = (i < n && jb != 255) ? (jb & 0x7f) : 255;
+        const bool shared = jb != 255 && (jb & 0x80);
+        const int q = j != 255 ? dBquant(mk[c]) : 0;
+        if (j != jprev) {
+          if (jprev >= 0) accumulate_flush(&sc->acc[jprev], t);
+          jprev = j == 255 ? -1 : j;
         }
-        t.xa += b.xa; t.ya += b.ya; t.x2a += b.x2a; t.y2a += b.y2a; t.xya += b.xya; t.an += b.an;
-        t.xb += b.xb; t.yb += b.yb; t.x2b += b.x2b; t.y2b += b.y2b; t.xyb += b.xyb; t.bn += b.bn;
-        nz += b.an;
-        // a bin exactly on an interior post closes the previous interval too
-        if (j > 0 && i == sc->sorted_index[j]) {
-          accumulate_flush(&sc->acc[j - 1], b);
+        if (q) {
+          FitAcc b;
+          b.xa = b.ya = b.x2a = b.y2a = b.xya = b.an = b.xb = b.yb = b.x2b = b.y2b = b.xyb = b.bn = 0;
+          const bool cls_a = lm[c] + F.twofitatten >= mk[c];
+          if (cls_a) {
+            b.xa = i; b.ya = q; b.x2a = i * i; b.y2a = q * q; b.xya = i * q; b.an = 1;
+          } else {
+            b.xb = i; b.yb = q; b.x2b = i * i; b.y2b = q * q; b.xyb = i * q; b.bn = 1;
+          }
+          t.xa += b.xa; t.ya += b.ya; t.x2a += b.x2a; t.y2a += b.y2a; t.xya += b.xya; t.an += b.an;
+          t.xb += b.xb; t.yb += b.yb; t.x2b += b.x2b; t.y2b += b.y2b; t.xyb += b.xyb; t.bn += b.bn;
           nz += b.an;
+          // a bin exactly on an interior post closes the previous interval too
+          if (shared) {
+            accumulate_flush(&sc->acc[j - 1], b);
+            nz += b.an;
+          }
         }
       }
     }
     if (jprev >= 0) accumulate_flush(&sc->acc[jprev], t);
   }
   nz = wave_sum(nz);
+  WAVE_SYNC();
+  WAVE_FOR(i, posts - 1) sc->term[i] = fit_term(sc->acc[i], F.twofitweight);
   WAVE_SYNC();
   pc.mark(1);
 
@@ -301,7 +305,7 @@ VAMD_DEV int floor_fit_render_block(const FloorP &F, int n2, const float *mask, 
   // every lane performs identical LDS updates, so no exchange is needed.
   {
     int y0 = -200, y1 = -200;
-    fit_line(sc->acc, posts - 1, sc->sorted_index[0], sc->sorted_index[posts - 1], &y0, &y1, F.twofitweight);
+    fit_line(sc->term, posts - 1, sc->sorted_index[0], sc->sorted_index[posts - 1], &y0, &y1);
     sc->fitA[0] = y0;
     sc->fitB[0] = y0;
     sc->fitB[1] = y1;
@@ -323,10 +327,10 @@ VAMD_DEV int floor_fit_render_block(const FloorP &F, int n2, const float *mask, 
       // (ly == -1 || hy == -1 => exit(1) in the reference: unreachable, fits are >= 0 or -200)
       if (inspect_error_wave(lx, hx, ly, hy, mask, lmd, F)) {
         int ly0 = -200, ly1 = -200, hy0 = -200, hy1 = -200;
-        const int ret0 = fit_line(sc->acc + lsortpos, sortpos - lsortpos, sc->sorted_index[lsortpos],
-                                  sc->sorted_index[sortpos], &ly0, &ly1, F.twofitweight);
-        const int ret1 = fit_line(sc->acc + sortpos, hsortpos - sortpos, sc->sorted_index[sortpos],
-                                  sc->sorted_index[hsortpos], &hy0, &hy1, F.twofitweight);
+        const int ret0 = fit_line(sc->term + lsortpos, sortpos - lsortpos, sc->sorted_index[lsortpos],
+                                  sc->sorted_index[sortpos], &ly0, &ly1);
+        const int ret1 = fit_line(sc->term + sortpos, hsortpos - sortpos, sc->sorted_index[sortpos],
+                                  sc->sorted_index[hsortpos], &hy0, &hy1);
         if (ret0) {
           ly0 = ly;
           ly1 = hy0;

@@ -33,23 +33,28 @@ namespace vamd {
 // seed_curve, lib/psy.c:390-415.  The reference walks i = posts[0] .. post1-1 with
 // seedptr advancing by linesper and stops once seedptr >= n; point i therefore
 // lands on line oc + (i-16)*linesper - linesper/2 and is applied iff that line is
-// in (0, n).  Written as a fixed 56-trip predicated loop so the curve loads of
-// several points are in flight together.
-VAMD_DEV void seed_curve_scatter(float *seed, const float *__restrict__ curves /*[8][58] of one band*/, float amp,
+// in (0, n).  The chosen curve row (58 floats in a 64-float, 256-byte-aligned row) is
+// fetched with sixteen 16-byte loads issued together, then the 56 points are
+// applied from registers.
+VAMD_DEV void seed_curve_scatter(float *seed, const float *__restrict__ curves64 /*[8][64] of one band*/, float amp,
                                  int oc, int nlines, int linesper, float dBoffset) {
   int choice = (int)(((double)(amp + dBoffset) - 30.) * (double).1f);
   choice = choice < 0 ? 0 : choice;
   choice = choice > VAMD_P_LEVELS - 1 ? VAMD_P_LEVELS - 1 : choice;
-  const float *__restrict__ posts = curves + choice * (VAMD_EHMER_MAX + 2);
-  const int i0 = (int)posts[0], i1 = (int)posts[1];
+  const F4 *__restrict__ row = (const F4 *)(curves64 + choice * 64);
+  float c[64];
+#if VAMD_GPU
+#pragma unroll
+#endif
+  for (int k = 0; k < 15; k++) f4_get(row[k], c + 4 * k);  // floats 0..59 cover the 58 used
+  const int i0 = (int)c[0], i1 = (int)c[1];
   const int base = oc - VAMD_EHMER_OFFSET * linesper - (linesper >> 1);
 #if VAMD_GPU
-#pragma unroll 8
+#pragma unroll
 #endif
   for (int i = 0; i < VAMD_EHMER_MAX; i++) {
     const int seedptr = base + i * linesper;
-    const float c = posts[2 + i];
-    if (i >= i0 && i < i1 && seedptr > 0 && seedptr < nlines) lds_atomic_max(seed + seedptr, amp + c);
+    if (i >= i0 && i < i1 && seedptr > 0 && seedptr < nlines) lds_atomic_max(seed + seedptr, amp + c[2 + i]);
   }
 }
 
@@ -153,18 +158,14 @@ VAMD_DEV void tone_seed_block(const PsyP &P, const float *__restrict__ logfft, f
   pc.mark(0);
   const float dBoffset = P.max_curve_dB - global_ampmax;
   WAVE_FOR(r, P.nruns) {
-    const int s = P.run_start[r], e = P.run_start[r + 1];  // bins [s, e)
+    const I4 rec = ((const I4 *)P.runs)[r];
+    const int s = rec.x & 0xffff, e = rec.x >> 16;  // bins [s, e)
     float mx = fft[s];
     for (int i = s + 1; i < e; i++)
       if (fft[i] > mx) mx = fft[i];
-    if (mx + 6.f > P.ath[e - 1] + att) {
-      const int ocv = P.octave[s];
-      int band = ocv >> P.shiftoc;
-      if (band >= VAMD_P_BANDS) band = VAMD_P_BANDS - 1;
-      if (band < 0) band = 0;
-      seed_curve_scatter(seed, P.tonecurves + band * (VAMD_P_LEVELS * (VAMD_EHMER_MAX + 2)), mx, ocv - P.firstoc,
-                         nlines, P.eighth_octave_lines, dBoffset);
-    }
+    if (mx + 6.f > f_from_bits((uint32_t)rec.w) + att)
+      seed_curve_scatter(seed, P.curves64 + rec.z * (VAMD_P_LEVELS * 64), mx, rec.y, nlines, P.eighth_octave_lines,
+                         dBoffset);
   }
   WAVE_SYNC();
   pc.mark(1);
@@ -173,7 +174,8 @@ VAMD_DEV void tone_seed_block(const PsyP &P, const float *__restrict__ logfft, f
 // paint + fold half: seed[] (LDS, unpainted), the survivor list -> tone curve
 //   posstack/ampstack LDS [nlines]
 VAMD_DEV void tone_fold_block(const PsyP &P, float local_ampmax, float *seed, const unsigned short *__restrict__ surv,
-                              int nsurv, int *posstack, float *ampstack, float *__restrict__ out, PhaseClock &pc) {
+                              int nsurv, int *posstack, float *ampstack, float *gmin /* LDS [ngroups] */,
+                              float *__restrict__ out, PhaseClock &pc) {
   const int n = P.n, nlines = P.total_octave_lines;
   float att = local_ampmax + P.ath_adjatt;
   if (att < P.ath_maxatt) att = P.ath_maxatt;
@@ -187,23 +189,46 @@ VAMD_DEV void tone_fold_block(const PsyP &P, float local_ampmax, float *seed, co
   WAVE_SYNC();
   pc.mark(3);
 
-  // max_seeds' fold, lib/psy.c:522-543, per bin over its precomputed line span
-  WAVE_FOR(i, n) {
-    float minV;
-    if (i >= P.tail_linpos) {
-      minV = seed[nlines - 1];
-    } else {
-      const int p0 = P.seed_span[2 * i], p1 = P.seed_span[2 * i + 1];
-      minV = seed[p0];
-      if (minV > P.tone_abs_limit) minV = P.tone_abs_limit;
-      for (int p = p0 + 1; p <= p1; p++) {
-        const float s = seed[p];
-        if ((s > VAMD_NEGINF && s < minV) || minV == VAMD_NEGINF) minV = s;
+  // max_seeds' fold, lib/psy.c:522-543.  Each outer-loop iteration ("group") of the
+  // reference starts from seed[p0] (capped at tone_abs_limit) and then keeps the lowest
+  // real (> NEGINF) value among the lines it scans -- a min, hence order-free: every
+  // line is folded into its group with an LDS float min, then every bin combines its
+  // group's start value and scanned minimum.  Work is balanced over lines and bins
+  // instead of leaving the few low bins with 70-line spans to single lanes.
+  WAVE_FOR(g, P.ngroups) gmin[g] = f_from_bits(0x7f800000u);  // +inf = "no real value scanned"
+  WAVE_SYNC();
+  WAVE_FOR(p, nlines) {
+    const int g = P.line_group[p];
+    const float s = seed[p];
+    if (g != 0xffff && s > VAMD_NEGINF) lds_atomic_min(gmin + g, s);
+  }
+  WAVE_SYNC();
+  WAVE_FOR(q, n >> 2) {
+    const I4 bf = ((const I4 *)P.bin_fold)[q];
+    const int bfs[4] = {bf.x, bf.y, bf.z, bf.w};
+    float av[4], o[4];
+    f4_get(((const F4 *)P.ath)[q], av);
+#if VAMD_GPU
+#pragma unroll
+#endif
+    for (int c = 0; c < 4; c++) {
+      const int i = (q << 2) + c;
+      float minV;
+      if (i >= P.tail_linpos) {
+        minV = seed[nlines - 1];
+      } else {
+        minV = seed[bfs[c] & 0xffff];
+        if (minV > P.tone_abs_limit) minV = P.tone_abs_limit;
+        const float rest = gmin[bfs[c] >> 16];
+        if (rest < f_from_bits(0x7f800000u)) {
+          if (minV == VAMD_NEGINF || rest < minV) minV = rest;
+        }
       }
+      float v = av[c] + att;
+      if (v < minV) v = minV;
+      o[c] = v;
     }
-    float v = P.ath[i] + att;
-    if (v < minV) v = minV;
-    out[i] = v;
+    ((F4 *)out)[q] = f4_make(o);
   }
   WAVE_SYNC();
   pc.mark(4);
@@ -218,7 +243,7 @@ VAMD_DEV void tonemask_block(const PsyP &P, const float *__restrict__ logfft, fl
                              float *fft, float *ring_amp, int *ring_pos, unsigned short *surv, PhaseClock &pc) {
   tone_seed_block(P, logfft, global_ampmax, local_ampmax, seed, fft, pc);
   const int nsurv = tone_chase_thread(seed, P.eighth_octave_lines, P.total_octave_lines, ring_amp, ring_pos, 1, 0, surv);
-  tone_fold_block(P, local_ampmax, seed, surv, nsurv, posstack, ampstack, out, pc);
+  tone_fold_block(P, local_ampmax, seed, surv, nsurv, posstack, ampstack, fft /* reused as gmin */, out, pc);
 }
 
 }  // namespace vamd

@@ -123,6 +123,28 @@ inline int build_image(const void *blob_v, size_t bytes, std::vector<unsigned ch
     image->insert(image->end(), b, b + 4 * d.seed_span.size());
     derived->push_back(d);
   }
+  for (int p = 0; p < 4; p++) {  // slots 8..15: per psy RunRec[] and the re-strided tone curves
+    const PsyDerived &d = (*derived)[p];
+    while (image->size() & 255) image->push_back(0);
+    derived_off->push_back((uint32_t)image->size());
+    const unsigned char *a = (const unsigned char *)d.runs.data();
+    image->insert(image->end(), a, a + sizeof(RunRec) * d.runs.size());
+    while (image->size() & 255) image->push_back(0);
+    derived_off->push_back((uint32_t)image->size());
+    const unsigned char *b = (const unsigned char *)d.curves64.data();
+    image->insert(image->end(), b, b + 4 * d.curves64.size());
+  }
+  for (int p = 0; p < 4; p++) {  // slots 16..23: per psy bin_fold[] and line_group[]
+    const PsyDerived &d = (*derived)[p];
+    while (image->size() & 15) image->push_back(0);
+    derived_off->push_back((uint32_t)image->size());
+    const unsigned char *a = (const unsigned char *)d.bin_fold.data();
+    image->insert(image->end(), a, a + 4 * d.bin_fold.size());
+    while (image->size() & 15) image->push_back(0);
+    derived_off->push_back((uint32_t)image->size());
+    const unsigned char *b = (const unsigned char *)d.line_group.data();
+    image->insert(image->end(), b, b + 2 * d.line_group.size());
+  }
   for (int W = 0; W < 2; W++) {
     std::vector<unsigned char> bi = derive_bin_interval(h.mode[W].floor, h.blocksizes[W] / 2);
     while (image->size() & 15) image->push_back(0);
@@ -178,7 +200,7 @@ inline void bind_params(const std::vector<unsigned char> &image, const std::vect
     F.reverse_index = (const int *)(base + fo + offsetof(vamd_floor1_tab, reverse_index));
     F.hineighbor = (const int *)(base + fo + offsetof(vamd_floor1_tab, hineighbor));
     F.loneighbor = (const int *)(base + fo + offsetof(vamd_floor1_tab, loneighbor));
-    F.bin_interval = base + derived_off[8 + W];
+    F.bin_interval = base + derived_off[24 + W];  // slots 24, 25
 
     CoupleP &C = B->couple[W];
     const int blob_k = VAMD_PACKETBLOBS / 2;
@@ -223,6 +245,11 @@ inline void bind_params(const std::vector<unsigned char> &image, const std::vect
     P.run_start = (const int *)(base + derived_off[2 * p]);
     P.nruns = (int)d.run_start.size() - 1;
     P.seed_span = (const int *)(base + derived_off[2 * p + 1]);
+    P.runs = (const int *)(base + derived_off[8 + 2 * p]);
+    P.curves64 = (const float *)(base + derived_off[8 + 2 * p + 1]);
+    P.bin_fold = (const int *)(base + derived_off[16 + 2 * p]);
+    P.line_group = (const unsigned short *)(base + derived_off[16 + 2 * p + 1]);
+    P.ngroups = d.ngroups;
     P.tail_linpos = d.tail_linpos;
     P.normal_p = t.normal_p;
     P.normal_start = t.normal_start;

@@ -10,12 +10,28 @@
 
 namespace vamd {
 
+// one run of bins sharing an octave[] value, everything seed_loop needs about it that
+// does not depend on the audio (lib/psy.c:429-449), 16 bytes
+struct RunRec {
+  int32_t start_end;  // start | end << 16   (bins [start, end))
+  int32_t ocpos;      // octave[start] - firstoc
+  int32_t band;       // clamp(octave[start] >> shiftoc, 0, P_BANDS-1)
+  float ath_last;     // ath[end-1]
+};
+
 struct PsyDerived {
   int bark_i1, bark_i2;  // lib/psy.c:606-656
   int fix_i1, fix_i2;    // lib/psy.c:660-703
   std::vector<int32_t> run_start;  // nruns+1 entries, lib/psy.c:429-435
+  std::vector<RunRec> runs;        // nruns
+  std::vector<float> curves64;     // tonecurves re-strided [17][8][64] (rows 256-byte aligned)
   std::vector<int32_t> seed_span;  // [n][2], lib/psy.c:522-537
   int tail_linpos;                 // lib/psy.c:539-543
+  // the same walk, organised for a line-parallel fold: every iteration of max_seeds' outer
+  // loop is a "group" g that starts from seed[p0_g] and then scans lines (p0_g, p1_g]
+  std::vector<int32_t> bin_fold;     // [n]   p0 | group << 16  (bins below tail_linpos)
+  std::vector<uint16_t> line_group;  // [nl padded to 16] group whose scan covers the line, 0xffff = none
+  int ngroups;
 };
 
 inline PsyDerived derive_psy(const vamd_psy_tab &t, const unsigned char *blob) {
@@ -66,10 +82,32 @@ inline PsyDerived derive_psy(const vamd_psy_tab &t, const unsigned char *blob) {
     i = j + 1;
   }
   d.run_start.push_back(n);
+  {
+    const float *ath = (const float *)(blob + t.off_ath);
+    for (size_t r = 0; r + 1 < d.run_start.size(); r++) {
+      RunRec rr;
+      const int s = d.run_start[r], e = d.run_start[r + 1];
+      rr.start_end = s | (e << 16);
+      rr.ocpos = octave[s] - t.firstoc;
+      int band = octave[s] >> t.shiftoc;
+      if (band >= VAMD_P_BANDS) band = VAMD_P_BANDS - 1;
+      if (band < 0) band = 0;
+      rr.band = band;
+      rr.ath_last = ath[e - 1];
+      d.runs.push_back(rr);
+    }
+    const float *tc = (const float *)(blob + t.off_tonecurves);
+    d.curves64.assign((size_t)VAMD_P_BANDS * VAMD_P_LEVELS * 64, 0.f);
+    for (int bc = 0; bc < VAMD_P_BANDS * VAMD_P_LEVELS; bc++)
+      for (int k = 0; k < VAMD_EHMER_MAX + 2; k++) d.curves64[(size_t)bc * 64 + k] = tc[bc * (VAMD_EHMER_MAX + 2) + k];
+  }
 
   // max_seeds: replay the (pos, linpos) walk; record per bin the seed-line span
   // [p0, p1] whose fold gives that bin's minV.
   d.seed_span.assign((size_t)2 * n, 0);
+  d.bin_fold.assign((size_t)n, 0);
+  d.line_group.assign((size_t)((t.total_octave_lines + 15) & ~15), 0xffff);
+  d.ngroups = 0;
   {
     const int linesper = t.eighth_octave_lines;
     long linpos = 0;
@@ -79,10 +117,13 @@ inline PsyDerived derive_psy(const vamd_psy_tab &t, const unsigned char *blob) {
       long end = ((octave[linpos] + octave[linpos + 1]) >> 1) - t.firstoc;
       while (pos + 1 <= end) pos++;
       end = pos + t.firstoc;
+      for (long p = p0 + 1; p <= pos; p++) d.line_group[(size_t)p] = (uint16_t)d.ngroups;
       for (; linpos < n && octave[linpos] <= end; linpos++) {
         d.seed_span[2 * linpos] = (int32_t)p0;
         d.seed_span[2 * linpos + 1] = (int32_t)pos;
+        d.bin_fold[(size_t)linpos] = (int32_t)(p0 | ((long)d.ngroups << 16));
       }
+      d.ngroups++;
     }
     d.tail_linpos = (int)linpos;
   }
@@ -92,13 +133,14 @@ inline PsyDerived derive_psy(const vamd_psy_tab &t, const unsigned char *blob) {
 // accumulate_fit (lib/floor1.c:406-454) is called once per pair of neighbouring
 // posts with the inclusive bin range [sorted_index[j], sorted_index[j+1]] clipped to
 // look_n-1.  bin_interval[i] = the interval j whose range starts at or before bin i
-// (the last such j); a bin sitting exactly on an interior post also belongs to j-1.
+// (the last such j); a bin sitting exactly on an interior post also belongs to j-1,
+// which is flagged by bit 7.  255 = the bin belongs to no interval.
 inline std::vector<unsigned char> derive_bin_interval(const vamd_floor1_tab &f, int n2) {
-  std::vector<unsigned char> t((size_t)n2, 255);
+  std::vector<unsigned char> t((size_t)((n2 + 3) & ~3), 255);
   for (int j = 0; j + 1 < f.posts; j++) {
     int x0 = f.sorted_index[j], x1 = f.sorted_index[j + 1];
     if (x1 >= f.look_n) x1 = f.look_n - 1;
-    for (int i = x0; i <= x1 && i < n2; i++) t[i] = (unsigned char)j;
+    for (int i = x0; i <= x1 && i < n2; i++) t[i] = (unsigned char)(j | ((j > 0 && i == x0) ? 0x80 : 0));
   }
   return t;
 }

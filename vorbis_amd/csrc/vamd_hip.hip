@@ -156,11 +156,13 @@ __global__ __launch_bounds__(64) void k_tone_fold(PsyP P0, PsyP P1, DescP d, int
   float *seed = (float *)vamd_smem;
   float *ampstack = seed + nlp;
   int *posstack = (int *)(ampstack + nlp);
+  float *gmin = (float *)(posstack + nlp);
   PhaseClock pc;
   pc.start(d.dbg ? d.dbg + 32 : nullptr);
   WAVE_FOR(q, nlp >> 2)((F4 *)seed)[q] = ((const F4 *)(seed_g + cb * nlp))[q];
   WAVE_SYNC();
-  tone_fold_block(P, local_ampmax[cb], seed, surv + cb * nlp, nsurv[cb], posstack, ampstack, tone + cb * n2, pc);
+  tone_fold_block(P, local_ampmax[cb], seed, surv + cb * nlp, nsurv[cb], posstack, ampstack, gmin, tone + cb * n2,
+                  pc);
 }
 
 // stage 4: offset_and_mix + floor1_fit + floor curve
@@ -513,7 +515,7 @@ static int run_batch(vamd_ctx *c, const vamd_batch_desc *desc, const vamd_batch_
                          p.local, p.ampglob, p.seed);
       hipLaunchKernelGGL(k_tone_chase, dim3((gcb + 63) / 64), dim3(64), (size_t)VAMD_RING * 64 * 8, s,
                          P0.eighth_octave_lines, nl, nlp, (long)gcb, d, p.seed, p.surv, p.nsurv);
-      hipLaunchKernelGGL(k_tone_fold, dim3(gcb), dim3(64), (size_t)nlp * 12, s, P0, P1, d, ch, nlp, p.seed, p.surv,
+      hipLaunchKernelGGL(k_tone_fold, dim3(gcb), dim3(64), (size_t)(nlp * 3 + n2) * 4, s, P0, P1, d, ch, nlp, p.seed, p.surv,
                          p.nsurv, p.local, p.tone);
     }
     prof_mark(c), nst++;

@@ -43,7 +43,12 @@ struct PsyP {
   int fix_i1, fix_i2;        // same for the fixed-window pass (lib/psy.c:660-703)
   const int *run_start;      // [nruns+1] starts of runs of equal octave[] (lib/psy.c:429-435)
   int nruns;
+  const int *runs;           // [nruns][4] RunRec (vamd_derive.h)
+  const float *curves64;     // [17][8][64] tonecurves with 64-float rows
   const int *seed_span;      // [n][2] octave-line span (pos0,pos1) each bin folds in max_seeds (lib/psy.c:524-537)
+  const int *bin_fold;       // [n] p0 | group << 16
+  const unsigned short *line_group;  // [nl16] group of each octave line, 0xffff = none
+  int ngroups;
   int tail_linpos;           // first bin handled by max_seeds' tail loop (lib/psy.c:539-543)
   int normal_p, normal_start, normal_partition;
   double normal_thresh;

@@ -99,6 +99,12 @@ VAMD_DEV void lds_atomic_max(float *p, float v) {
   else
     atomicMin((unsigned int *)p, __float_as_uint(v));
 }
+VAMD_DEV void lds_atomic_min(float *p, float v) {
+  if (v >= 0.f)
+    atomicMin((int *)p, __float_as_int(v));
+  else
+    atomicMax((unsigned int *)p, __float_as_uint(v));
+}
 VAMD_DEV void lds_atomic_add(int *p, int v) { atomicAdd(p, v); }
 VAMD_DEV void lds_atomic_or(int *p, int v) { atomicOr(p, v); }
 #else
@@ -112,6 +118,7 @@ VAMD_DEV int wave_first(int v) { return v; }
 VAMD_DEV float f_from_bits(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 VAMD_DEV uint32_t f_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 VAMD_DEV void lds_atomic_max(float *p, float v) { if (*p < v) *p = v; }
+VAMD_DEV void lds_atomic_min(float *p, float v) { if (v < *p) *p = v; }
 VAMD_DEV void lds_atomic_add(int *p, int v) { *p += v; }
 VAMD_DEV void lds_atomic_or(int *p, int v) { *p |= v; }
 #endif
