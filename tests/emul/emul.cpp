@@ -84,7 +84,7 @@ int emul_analyze_block(void *h, const float *pcm, int lW, int W, int nW, int blo
     std::vector<unsigned short> surv(nlp);
     FloorScratch sc;
     for (int i = 0; i < ch; i++) {
-      noisemask_block(P, &logmdct[i * n2], &noise[i * n2], S.data(), nz.data(), wk.data(), pc);
+      noisemask_block(P, &logmdct[i * n2], &noise[i * n2], S.data(), pc);
       tonemask_block(P, &logfft[i * n2], &tone[i * n2], global, local[i], seed.data(), posstack.data(),
                      ampstack.data(), flr.data(), ring_amp.data(), ring_pos.data(), surv.data(), pc);
       offset_and_mix_wave(P, &noise[i * n2], &tone[i * n2], &logmdct[i * n2], &mdct_raw[i * n2], &mdct[i * n2],

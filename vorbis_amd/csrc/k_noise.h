@@ -12,7 +12,7 @@
 // of the window loops depend only on the static bark[] table and are
 // precomputed by vamd_create().
 //
-// LDS: S[5][n+4] running sums, nz[n] (noise curve), wk[n] (work).
+// LDS: S[5][n+4] running sums only; the noise curve and work vector stay in registers.
 #pragma once
 #include "vamd_wave.h"
 #include "vamd_params.h"
@@ -44,9 +44,8 @@ VAMD_DEV LineFit fit_plain(const float *S, int n, int hi, int lo) {
   return fit_from_sums(N[hi] - N[lo], X[hi] - X[lo], XX[hi] - XX[lo], Y[hi] - Y[lo], XY[hi] - XY[lo]);
 }
 
-VAMD_DEV LineFit bark_fit_at(const PsyP &P, const float *S, int i) {
+VAMD_DEV LineFit bark_fit_from(const PsyP &P, const float *S, int i, int b /* = bark[i] */) {
   const int n = P.n;
-  const int b = P.bark[i];
   const int lo = b >> 16, hi = b & 0xffff;
   return (i < P.bark_i1) ? fit_mirrored(S, n, hi, -lo) : fit_plain(S, n, hi, lo);
 }
@@ -88,34 +87,47 @@ VAMD_DEV void running_sum_inplace(float *p, int n) {
   }
 }
 
-// bark_noise_hybridmp(n, bark, f, noise, offset, fixed)
-VAMD_DEV void bark_noise_wave(const PsyP &P, const float *f, float *noise, const float offset, const int fixed,
-                              float *S, PhaseClock &pc, int slot) {
-  const int n = P.n;
+// bark_noise_hybridmp(n, bark, f, noise, offset, fixed).  f and noise are per-lane
+// register tiles: lane l owns the quads l, l+64, ... (LANE_QUADS), four bins each.
+VAMD_DEV void bark_noise_wave(const PsyP &P, const float (*f)[4], float (*noise)[4], const float offset,
+                              const int fixed, float *S, PhaseClock &pc, int slot) {
+  const int n = P.n, nq = n >> 2;
   // each array starts 16 bytes further round the banks so that the five scanning lanes'
   // 16-byte accesses do not collide
   float *N = S, *X = S + (n + 4), *XX = S + 2 * (n + 4), *Y = S + 3 * (n + 4), *XY = S + 4 * (n + 4);
 
   // per-bin terms (lib/psy.c:571-597)
-  WAVE_FOR(i, n) {
-    float y = f[i] + offset;
-    if (y < 1.f) y = 1.f;
-    if (i == 0) {
-      const float w = (float)((double)(y * y) * .5);
-      N[0] = w;
-      X[0] = w;  // sic: the reference adds w, not w*x, at bin 0 (lib/psy.c:577)
-      XX[0] = 0.f;
-      Y[0] = w * y;
-      XY[0] = 0.f;
-    } else {
-      const float x = (float)i;
-      const float w = y * y;
-      N[i] = w;
-      X[i] = w * x;
-      XX[i] = w * x * x;
-      Y[i] = w * y;
-      XY[i] = w * x * y;
+  LANE_QUADS(kq, q, nq) {
+    float tn[4], tx[4], txx[4], ty[4], txy[4];
+#if VAMD_GPU
+#pragma unroll
+#endif
+    for (int c = 0; c < 4; c++) {
+      const int i = (q << 2) + c;
+      float y = f[kq][c] + offset;
+      if (y < 1.f) y = 1.f;
+      if (i == 0) {
+        const float w = (float)((double)(y * y) * .5);
+        tn[c] = w;
+        tx[c] = w;  // sic: the reference adds w, not w*x, at bin 0 (lib/psy.c:577)
+        txx[c] = 0.f;
+        ty[c] = w * y;
+        txy[c] = 0.f;
+      } else {
+        const float x = (float)i;
+        const float w = y * y;
+        tn[c] = w;
+        tx[c] = w * x;
+        txx[c] = w * x * x;
+        ty[c] = w * y;
+        txy[c] = w * x * y;
+      }
     }
+    ((F4 *)N)[q] = f4_make(tn);
+    ((F4 *)X)[q] = f4_make(tx);
+    ((F4 *)XX)[q] = f4_make(txx);
+    ((F4 *)Y)[q] = f4_make(ty);
+    ((F4 *)XY)[q] = f4_make(txy);
   }
   WAVE_SYNC();
   pc.mark(slot);
@@ -131,51 +143,71 @@ VAMD_DEV void bark_noise_wave(const PsyP &P, const float *f, float *noise, const
   last.A = 0.f;
   last.B = 0.f;
   last.D = 1.f;
-  if (P.bark_i2 > 0) last = bark_fit_at(P, S, P.bark_i2 - 1);
-  WAVE_FOR(i, n) {
-    const LineFit L = (i < P.bark_i2) ? bark_fit_at(P, S, i) : last;
-    const float x = (float)i;
-    float R = (L.A + x * L.B) / L.D;
-    if (R < 0.f) R = 0.f;
-    noise[i] = R - offset;
+  if (P.bark_i2 > 0) last = bark_fit_from(P, S, P.bark_i2 - 1, P.bark[P.bark_i2 - 1]);
+  LANE_QUADS(kq, q, nq) {
+    const I4 bq = ((const I4 *)P.bark)[q];
+    const int bk[4] = {bq.x, bq.y, bq.z, bq.w};
+#if VAMD_GPU
+#pragma unroll
+#endif
+    for (int c = 0; c < 4; c++) {
+      const int i = (q << 2) + c;
+      const LineFit L = (i < P.bark_i2) ? bark_fit_from(P, S, i, bk[c]) : last;
+      const float x = (float)i;
+      float R = (L.A + x * L.B) / L.D;
+      if (R < 0.f) R = 0.f;
+      noise[kq][c] = R - offset;
+    }
   }
-  if (fixed <= 0) {
-    WAVE_SYNC();
-    pc.mark(slot + 2);
-    return;
+  if (fixed > 0) {
+    // fixed-width window pass: keep the lower of the two curves (lib/psy.c:660-703)
+    if (P.fix_i2 > 0) last = fixed_fit_at(P, S, P.fix_i2 - 1, fixed);
+    LANE_QUADS(kq, q, nq) {
+#if VAMD_GPU
+#pragma unroll
+#endif
+      for (int c = 0; c < 4; c++) {
+        const int i = (q << 2) + c;
+        const LineFit L = (i < P.fix_i2) ? fixed_fit_at(P, S, i, fixed) : last;
+        const float x = (float)i;
+        const float R = (L.A + x * L.B) / L.D;
+        if (R - offset < noise[kq][c]) noise[kq][c] = R - offset;
+      }
+    }
   }
-
-  // fixed-width window pass: keep the lower of the two curves (lib/psy.c:660-703)
-  if (P.fix_i2 > 0) last = fixed_fit_at(P, S, P.fix_i2 - 1, fixed);
-  WAVE_FOR(i, n) {
-    const LineFit L = (i < P.fix_i2) ? fixed_fit_at(P, S, i, fixed) : last;
-    const float x = (float)i;
-    const float R = (L.A + x * L.B) / L.D;
-    if (R - offset < noise[i]) noise[i] = R - offset;
-  }
-  WAVE_SYNC();
+  WAVE_SYNC();  // S is rewritten by the next pass
   pc.mark(slot + 2);
 }
 
 // _vp_noisemask(p, logmdct, logmask)
-//   logmdct  [n] input (HBM or LDS)
-//   out      [n] HBM
+//   logmdct  [n] input (HBM), out [n] (HBM); S = LDS [5][n+4]
+// The noise curve and the work vector never change hands between lanes, so they live in
+// registers (VAMD_QPL quads per lane: block sizes up to 2048 on the GPU).
 VAMD_DEV void noisemask_block(const PsyP &P, const float *__restrict__ logmdct, float *__restrict__ out, float *S,
-                              float *nz, float *wk, PhaseClock &pc) {
-  const int n = P.n;
-  bark_noise_wave(P, logmdct, nz, 140.f, -1, S, pc, 0);
-  WAVE_FOR(i, n) wk[i] = logmdct[i] - nz[i];
-  WAVE_SYNC();
+                              PhaseClock &pc) {
+  const int nq = P.n >> 2;
+  float lm[VAMD_QPL][4], nz[VAMD_QPL][4], wk[VAMD_QPL][4];
+  LANE_QUADS(kq, q, nq) f4_get(((const F4 *)logmdct)[q], lm[kq]);
+  bark_noise_wave(P, lm, nz, 140.f, -1, S, pc, 0);
+  LANE_QUADS(kq, q, nq) {
+    for (int c = 0; c < 4; c++) wk[kq][c] = lm[kq][c] - nz[kq][c];
+  }
   pc.mark(3);
   bark_noise_wave(P, wk, nz, 0.f, P.noisewindowfixed, S, pc, 4);
-  WAVE_FOR(i, n) {
-    const float w = logmdct[i] - wk[i];
-    int dB = (int)((double)nz[i] + .5);
-    if (dB >= VAMD_NOISE_COMPAND_LEVELS) dB = VAMD_NOISE_COMPAND_LEVELS - 1;
-    if (dB < 0) dB = 0;
-    out[i] = w + P.noisecompand[dB];
+  LANE_QUADS(kq, q, nq) {
+    float o[4];
+#if VAMD_GPU
+#pragma unroll
+#endif
+    for (int c = 0; c < 4; c++) {
+      const float w = lm[kq][c] - wk[kq][c];
+      int dB = (int)((double)nz[kq][c] + .5);
+      if (dB >= VAMD_NOISE_COMPAND_LEVELS) dB = VAMD_NOISE_COMPAND_LEVELS - 1;
+      if (dB < 0) dB = 0;
+      o[c] = w + P.noisecompand[dB];
+    }
+    ((F4 *)out)[q] = f4_make(o);
   }
-  WAVE_SYNC();
   pc.mark(7);
 }
 

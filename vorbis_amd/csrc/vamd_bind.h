@@ -12,6 +12,8 @@
 
 namespace vamd {
 
+#define VAMD_QPL_GPU 4  // must equal VAMD_QPL of the HIP build (vamd_wave.h)
+
 struct Bound {
   int channels, rate;
   int bs[2];
@@ -59,6 +61,10 @@ inline int build_image(const void *blob_v, size_t bytes, std::vector<unsigned ch
     if (x.n != h.blocksizes[W] || x.n < 64 || x.n > 8192 || (x.n & (x.n - 1))) {
       *err = "block size must be a power of two in [64, 8192]";
       return VAMD_EINVAL;
+    }
+    if (x.n > 8 * 64 * VAMD_QPL_GPU) {
+      *err = "block sizes above 2048 are not covered (per-lane register tiles hold 1024 bins)";
+      return VAMD_EIMPL;
     }
     if (x.fft_nf < 1 || x.fft_nf > 8) {
       *err = "unsupported FFT factorisation";

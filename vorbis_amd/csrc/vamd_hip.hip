@@ -75,10 +75,10 @@ __global__ __launch_bounds__(64) void k_noise(PsyP P0, PsyP P1, DescP d, int ch,
   const long blk = cb / ch;
   const PsyP &P = d_bt(d, blk) ? P1 : P0;
   const int n2 = P.n;
-  float *S = (float *)vamd_smem, *nz = S + 5 * (n2 + 4), *wk = nz + n2;
+  float *S = (float *)vamd_smem;
   PhaseClock pc;
   pc.start(d.dbg ? d.dbg + 16 : nullptr);
-  noisemask_block(P, logmdct + cb * n2, noise + cb * n2, S, nz, wk, pc);
+  noisemask_block(P, logmdct + cb * n2, noise + cb * n2, S, pc);
 }
 
 // block-level ampmax: global = max(ampmax_in, local[0..ch)); one thread per block
@@ -507,7 +507,7 @@ static int run_batch(vamd_ctx *c, const vamd_batch_desc *desc, const vamd_batch_
   }
   prof_mark(c), nst++;
   if (level >= VAMD_LEVEL_PSY) {
-    hipLaunchKernelGGL(k_noise, dim3(gcb), dim3(64), (size_t)(n2 * 7 + 20) * 4, s, P0, P1, d, ch, p.logmdct, p.noise);
+    hipLaunchKernelGGL(k_noise, dim3(gcb), dim3(64), (size_t)(n2 * 5 + 20) * 4, s, P0, P1, d, ch, p.logmdct, p.noise);
     prof_mark(c), nst++;
     {
       const int nlp = (nl + 15) & ~15;

@@ -53,6 +53,18 @@
 #define WAVE_SYNC_GLOBAL() ((void)0)
 #endif
 
+// Register tiles: a lane may keep "its" quads of a block in registers across phases.
+// Lane l owns quads l, l+64, ... (four consecutive bins each); VAMD_QPL bounds how
+// many (block sizes up to 2048 -> 1024 bins -> 4 quads per lane on the GPU; the
+// one-lane test build owns them all).
+#if VAMD_GPU
+#define VAMD_QPL 4
+#define LANE_QUADS(kq, q, nq) _Pragma("unroll") for (int kq = 0, q = LANE; kq < VAMD_QPL; kq++, q += NLANES) if (q < (nq))
+#else
+#define VAMD_QPL 1024
+#define LANE_QUADS(kq, q, nq) for (int kq = 0, q = LANE; kq < VAMD_QPL && q < (nq); kq++, q += NLANES)
+#endif
+
 // lanes stride over [0, count).  On the GPU the loop is unrolled x4 so that the
 // independent HBM/L2 loads of four iterations are in flight together.
 #if VAMD_GPU
