@@ -46,7 +46,7 @@ void emul_close(void *h) { delete (Emul *)h; }
 int emul_mdct_forward(void *h, int W, const float *in, float *out) {
   Emul *e = (Emul *)h;
   const XformP &P = e->B.xf[W];
-  std::vector<float> A(P.n), Bw(P.n + P.n / 32);
+  std::vector<float> A(P.n + 4), Bw(P.n + P.n / 32);
   PhaseClock pc;
   pc.start(nullptr);
   load_windowed(P, W, 1, 1, in, A.data(), false);
@@ -64,7 +64,7 @@ int emul_analyze_block(void *h, const float *pcm, int lW, int W, int nW, int blo
   const PsyP &P = B.psy[blocktype + (W ? 2 : 0)];
   const FloorP &F = B.floor[W];
   const CoupleP &C = B.couple[W];
-  std::vector<float> A(n), Bw(n + n / 32);
+  std::vector<float> A(n + 4), Bw(n + n / 32);
   std::vector<float> mdct_raw(ch * n2), logfft(ch * n2), logmdct(ch * n2), noise(ch * n2), tone(ch * n2),
       logmask(ch * n2), mdct(ch * n2), lmd(n2), mask(n2);
   std::vector<int> posts(ch * VAMD_POSTS_STRIDE), post_valid(ch), ilogmask(ch * n2), iwork(ch * n2), nonzero(ch);

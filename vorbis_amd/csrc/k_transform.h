@@ -9,8 +9,8 @@
 // *schedule* differs: each stage's independent butterflies are spread across
 // the 64 lanes with the work vectors in LDS.
 //
-// LDS: A[n] (PCM -> windowed -> FFT buffer "c"), B[n + n/32] (MDCT work "w" with its
-// padded butterfly half, then FFT buffer "ch").
+// LDS: A[n+4] (PCM -> windowed -> FFT buffer "c"), B[n + n/32] (MDCT work "w" with its
+// padded butterfly half, then FFT buffer "ch"; n/32 >= 4 covers the offset layout).
 #pragma once
 #include "vamd_wave.h"
 #include "vamd_params.h"
@@ -292,8 +292,31 @@ VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in, float *w, floa
   WAVE_SYNC();
 }
 
+// FFT buffers and the packed layout.  FFTPACK's half-complex packing puts every
+// (real, imag) pair at indices (2m-1, 2m): odd first.  Stored plainly that is never
+// 8-byte aligned, so each pair costs two LDS accesses.  Every pass therefore WRITES
+// its output one float into its buffer ("offset layout": logical index t lives at
+// base[t+1]); from the second pass on, sources and destinations are both offset and
+// every pair moves as one aligned 64-bit access.  Only the first pass reads the plain
+// windowed block (it has ido = 1 or touches single values only).
+template <bool AL>
+VAMD_DEV F2 ld_pair(const float *p, int t) {  // (p[t-1], p[t]) for even t
+  if (AL) return *(const F2 *)(p + t - 1);
+  F2 r;
+  r.x = p[t - 1];
+  r.y = p[t];
+  return r;
+}
+VAMD_DEV void st_pair(float *p, int t, float a, float b) {  // p[t-1] = a, p[t] = b, offset layout
+  F2 r;
+  r.x = a;
+  r.y = b;
+  *(F2 *)(p + t - 1) = r;
+}
+
 // dradf4, lib/smallft.c:168-268: one radix-4 pass cc -> ch.  wa1/2/3 are the
 // reference's 1-based-offset twiddle pointers (wa+iw-1 etc.).
+template <bool AL>
 VAMD_DEV void radf4_wave(int ido, int l1, const float *cc, float *ch, const float *__restrict__ wa1,
                          const float *__restrict__ wa2, const float *__restrict__ wa3) {
   const float hsqt2 = .70710678118654752f;
@@ -319,26 +342,22 @@ VAMD_DEV void radf4_wave(int ido, int l1, const float *cc, float *ch, const floa
       const int t4 = (t1 << 2) + i;
       const int t6 = ido << 1;
       const int t5 = t6 + (t1 << 2) - i;
-      int t3 = t2 + t0;
-      const float cr2 = wa1[i - 2] * cc[t3 - 1] + wa1[i - 1] * cc[t3];
-      const float ci2 = wa1[i - 2] * cc[t3] - wa1[i - 1] * cc[t3 - 1];
-      t3 += t0;
-      const float cr3 = wa2[i - 2] * cc[t3 - 1] + wa2[i - 1] * cc[t3];
-      const float ci3 = wa2[i - 2] * cc[t3] - wa2[i - 1] * cc[t3 - 1];
-      t3 += t0;
-      const float cr4 = wa3[i - 2] * cc[t3 - 1] + wa3[i - 1] * cc[t3];
-      const float ci4 = wa3[i - 2] * cc[t3] - wa3[i - 1] * cc[t3 - 1];
+      const F2 w1 = *(const F2 *)(wa1 + i - 2), w2 = *(const F2 *)(wa2 + i - 2), w3 = *(const F2 *)(wa3 + i - 2);
+      const F2 c0 = ld_pair<AL>(cc, t2), c1 = ld_pair<AL>(cc, t2 + t0), c2 = ld_pair<AL>(cc, t2 + 2 * t0),
+               c3 = ld_pair<AL>(cc, t2 + 3 * t0);
+      const float cr2 = w1.x * c1.x + w1.y * c1.y;
+      const float ci2 = w1.x * c1.y - w1.y * c1.x;
+      const float cr3 = w2.x * c2.x + w2.y * c2.y;
+      const float ci3 = w2.x * c2.y - w2.y * c2.x;
+      const float cr4 = w3.x * c3.x + w3.y * c3.y;
+      const float ci4 = w3.x * c3.y - w3.y * c3.x;
       const float tr1 = cr2 + cr4, tr4 = cr4 - cr2, ti1 = ci2 + ci4, ti4 = ci2 - ci4;
-      const float ti2 = cc[t2] + ci3, ti3 = cc[t2] - ci3;
-      const float tr2 = cc[t2 - 1] + cr3, tr3 = cc[t2 - 1] - cr3;
-      ch[t4 - 1] = tr1 + tr2;
-      ch[t4] = ti1 + ti2;
-      ch[t5 - 1] = tr3 - ti4;
-      ch[t5] = tr4 - ti3;
-      ch[t4 + t6 - 1] = ti4 + tr3;
-      ch[t4 + t6] = tr4 + ti3;
-      ch[t5 + t6 - 1] = tr2 - tr1;
-      ch[t5 + t6] = ti1 - ti2;
+      const float ti2 = c0.y + ci3, ti3 = c0.y - ci3;
+      const float tr2 = c0.x + cr3, tr3 = c0.x - cr3;
+      st_pair(ch, t4, tr1 + tr2, ti1 + ti2);
+      st_pair(ch, t5, tr3 - ti4, tr4 - ti3);
+      st_pair(ch, t4 + t6, ti4 + tr3, tr4 + ti3);
+      st_pair(ch, t5 + t6, tr2 - tr1, ti1 - ti2);
     }
     if (ido & 1) return;
   }
@@ -355,6 +374,7 @@ VAMD_DEV void radf4_wave(int ido, int l1, const float *cc, float *ch, const floa
 }
 
 // dradf2, lib/smallft.c:113-166
+template <bool AL>
 VAMD_DEV void radf2_wave(int ido, int l1, const float *cc, float *ch, const float *__restrict__ wa1) {
   const int t0 = l1 * ido;
   WAVE_FOR(k, l1) {
@@ -369,12 +389,12 @@ VAMD_DEV void radf2_wave(int ido, int l1, const float *cc, float *ch, const floa
       const int k = g / half, m = g - k * half + 1, i = 2 * m;
       const int t1 = k * ido, t2 = t0 + k * ido;
       const int t3 = t2 + i, t4 = (t1 << 1) + (ido << 1) - i, t5 = t1 + i, t6 = (t1 << 1) + i;
-      const float tr2 = wa1[i - 2] * cc[t3 - 1] + wa1[i - 1] * cc[t3];
-      const float ti2 = wa1[i - 2] * cc[t3] - wa1[i - 1] * cc[t3 - 1];
-      ch[t6] = cc[t5] + ti2;
-      ch[t4] = ti2 - cc[t5];
-      ch[t6 - 1] = cc[t5 - 1] + tr2;
-      ch[t4 - 1] = cc[t5 - 1] - tr2;
+      const F2 w1 = *(const F2 *)(wa1 + i - 2);
+      const F2 c3 = ld_pair<AL>(cc, t3), c5 = ld_pair<AL>(cc, t5);
+      const float tr2 = w1.x * c3.x + w1.y * c3.y;
+      const float ti2 = w1.x * c3.y - w1.y * c3.x;
+      st_pair(ch, t6, c5.x + tr2, c5.y + ti2);
+      st_pair(ch, t4, c5.x - tr2, ti2 - c5.y);
     }
     if (ido % 2 == 1) return;
   }
@@ -385,32 +405,41 @@ VAMD_DEV void radf2_wave(int ido, int l1, const float *cc, float *ch, const floa
   }
 }
 
-// drftf1, lib/smallft.c:572-631: in-place (c) unnormalised real FFT with the
-// reference's pass order and c<->ch ping-pong.  Returns with the packed
-// spectrum R0,R1,I1,...,R(n/2) in c.
-VAMD_DEV void drft_forward_wave(const XformP &P, float *c, float *ch) {
+// drftf1, lib/smallft.c:572-631: unnormalised real FFT with the reference's pass
+// order and c<->ch ping-pong.  `c` holds the windowed block (plain layout, n+4
+// floats available), `ch` is scratch (n+4 floats).  Returns the buffer (offset layout:
+// element t at ret[t]) that holds the packed spectrum R0,R1,I1,...,R(n/2).
+VAMD_DEV const float *drft_forward_wave(const XformP &P, float *c, float *ch) {
   const int n = P.n, nf = P.fft_nf;
   const float *__restrict__ wa = P.wa;
+  float *bufc = c + 1, *bufh = ch + 1;  // offset layouts of the two buffers
   int na = 1, l2 = n, iw = n;
   for (int k1 = 0; k1 < nf; k1++) {
     const int ip = P.fft_fac[nf - k1 - 1];
     const int l1 = l2 / ip, ido = n / l2;
     iw -= (ip - 1) * ido;
     na = 1 - na;
-    const float *src = na ? ch : c;
-    float *dst = na ? c : ch;
-    if (ip == 4) {
-      const int ix2 = iw + ido, ix3 = ix2 + ido;
-      radf4_wave(ido, l1, src, dst, wa + iw - 1, wa + ix2 - 1, wa + ix3 - 1);
+    float *dst = na ? bufc : bufh;
+    if (k1 == 0) {
+      // the first pass reads the plain (un-offset) block; ld_pair<false> covers the case
+      // where it has pairs to read (ido > 2)
+      if (ip == 4)
+        radf4_wave<false>(ido, l1, c, dst, wa + iw - 1, wa + iw + ido - 1, wa + iw + 2 * ido - 1);
+      else
+        radf2_wave<false>(ido, l1, c, dst, wa + iw - 1);
     } else {
-      radf2_wave(ido, l1, src, dst, wa + iw - 1);
+      const float *src = na ? bufh : bufc;
+      if (ip == 4)
+        radf4_wave<true>(ido, l1, src, dst, wa + iw - 1, wa + iw + ido - 1, wa + iw + 2 * ido - 1);
+      else
+        radf2_wave<true>(ido, l1, src, dst, wa + iw - 1);
     }
     WAVE_SYNC();
     l2 = l1;
   }
-  if (na == 1) return;
-  WAVE_FOR(i, n) c[i] = ch[i];
-  WAVE_SYNC();
+  // the reference copies ch back into c when the last pass landed in ch; the caller
+  // just reads whichever buffer holds the result
+  return na ? bufc : bufh;
 }
 
 // The whole stage for one channel-block.
@@ -436,8 +465,8 @@ VAMD_DEV float transform_block(const XformP &P, int W, int lW, int nW, const flo
   WAVE_SYNC();
 
   pc.mark(5);
-  // FFT of the same windowed block, in place in A
-  drft_forward_wave(P, A, B);
+  // FFT of the same windowed block (A), ping-ponging with B
+  const float *spec = drft_forward_wave(P, A, B);
   pc.mark(6);
 
   // logfft + local ampmax, lib/mapping0.c:255-346
@@ -447,10 +476,10 @@ VAMD_DEV float transform_block(const XformP &P, int W, int lW, int nW, const flo
   WAVE_FOR(k, n2) {
     float v;
     if (k == 0) {
-      v = (float)((double)(scale_dB + todB(A[0])) + .345);
+      v = (float)((double)(scale_dB + todB(spec[0])) + .345);
     } else {
-      const float re = A[2 * k - 1], im = A[2 * k];
-      const float temp = re * re + im * im;
+      const F2 z = *(const F2 *)(spec + 2 * k - 1);  // (Re_k, Im_k), aligned in the offset layout
+      const float temp = z.x * z.x + z.y * z.y;
       v = (float)((double)(scale_dB + .5f * todB(temp)) + .345);
     }
     if (logfft_out) logfft_out[k] = v;

@@ -39,33 +39,91 @@ __device__ __forceinline__ int d_nW(const DescP &d, long b) { return d.nW ? d.nW
 __device__ __forceinline__ int d_bt(const DescP &d, long b) { return d.blocktype ? d.blocktype[b] : d.u_blocktype; }
 __device__ __forceinline__ float d_amp(const DescP &d, long b) { return d.ampmax_in ? d.ampmax_in[b] : d.u_ampmax_in; }
 
+// ---- transform kernels: persistent workgroups with the tables staged in LDS -------
+// One workgroup per CU, VAMD_XF_WAVES independent waves each owning one channel-block
+// at a time and looping over the batch.  The window, MDCT trig/bit-reverse and FFT
+// twiddle tables (24.5 KB at n = 2048) are copied into LDS once per workgroup and every
+// butterfly of every block then reads them at LDS latency instead of going to L2.
+// Waves never synchronise with each other after the staging barrier (WAVE_SYNC is
+// wave-local), so they drift apart and overlap each other's memory phases.
+#define VAMD_XF_WAVES 8
+
+struct XformLds {
+  XformP P;       // table pointers rebound to the LDS copies
+  float *A, *B;   // this wave's work buffers
+};
+
+__device__ __forceinline__ XformLds stage_transform_tables(const XformP &G) {
+  const int n = G.n;
+  float *trig = (float *)vamd_smem;          // [n + n/4]
+  float *wa = trig + n + n / 4;              // [n]   (the twiddles the passes touch: wa[0 .. n-1))
+  float *winL = wa + n;                      // [bs1/2]
+  float *winS = winL + G.bs1 / 2;            // [bs0/2]
+  int *bitrev = (int *)(winS + G.bs0 / 2);   // [n/4]
+  float *work = (float *)(bitrev + n / 4);
+  for (int i = threadIdx.x; i < n + n / 4; i += blockDim.x) trig[i] = G.trig[i];
+  for (int i = threadIdx.x; i < n; i += blockDim.x) wa[i] = G.wa[i];
+  for (int i = threadIdx.x; i < G.bs1 / 2; i += blockDim.x) winL[i] = G.win_long[i];
+  for (int i = threadIdx.x; i < G.bs0 / 2; i += blockDim.x) winS[i] = G.win_short[i];
+  for (int i = threadIdx.x; i < n / 4; i += blockDim.x) bitrev[i] = G.bitrev[i];
+  __syncthreads();
+  XformLds L;
+  L.P = G;
+  L.P.trig = trig;
+  L.P.wa = wa;
+  L.P.win_long = winL;
+  L.P.win_short = winS;
+  L.P.bitrev = bitrev;
+  const int wave = threadIdx.x >> 6;
+  const int per_wave = (n + 4) + (n + n / 32);
+  L.A = work + wave * per_wave;
+  L.B = L.A + n + 4;
+  return L;
+}
+
+static size_t transform_lds_bytes(const XformP &P, int waves) {
+  const size_t tables = (size_t)(P.n + P.n / 4) + P.n + P.bs1 / 2 + P.bs0 / 2 + P.n / 4;
+  return (tables + (size_t)waves * ((P.n + 4) + (P.n + P.n / 32))) * 4;
+}
+
 // mdct_forward only (BASELINE config 2): in[nframes][n] -> out[nframes][n/2]
-__global__ __launch_bounds__(64) void k_mdct_only(XformP P, int W, const float *__restrict__ in,
-                                                  float *__restrict__ out) {
-  float *A = (float *)vamd_smem, *B = A + P.n;
-  const long f = blockIdx.x;
-  const int n2 = P.n >> 1;
+__global__ __launch_bounds__(64 * VAMD_XF_WAVES) void k_mdct_only(XformP G, int W, long nframes,
+                                                                 const float *__restrict__ in,
+                                                                 float *__restrict__ out) {
+  const XformLds L = stage_transform_tables(G);
+  const XformP &P = L.P;
+  const int n2 = P.n >> 1, nw = blockDim.x >> 6;
   PhaseClock pc;
   pc.start(nullptr);
-  load_windowed(P, W, 1, 1, in + f * P.n, A, false);
-  WAVE_SYNC();
-  mdct_forward_wave(P, A, B, B + n2, pc);
-  WAVE_FOR(j, n2) out[f * n2 + j] = B[n2 + j];
+  for (long f = (long)blockIdx.x * nw + (threadIdx.x >> 6); f < nframes; f += (long)gridDim.x * nw) {
+    load_windowed(P, W, 1, 1, in + f * P.n, L.A, false);
+    WAVE_SYNC();
+    mdct_forward_wave(P, L.A, L.B, L.B + n2, pc);
+    WAVE_FOR(q, n2 >> 2)((F4 *)(out + f * n2))[q] = ((const F4 *)(L.B + n2))[q];
+    WAVE_SYNC();
+  }
 }
 
 // stage 1: window + MDCT + FFT + logs, one wave per channel-block
-__global__ __launch_bounds__(64) void k_transform(XformP P, int W, DescP d, int ch, const float *__restrict__ pcm,
-                                                  float *__restrict__ mdct_raw, float *__restrict__ logmdct,
-                                                  float *__restrict__ logfft, float *__restrict__ local_ampmax) {
-  float *A = (float *)vamd_smem, *B = A + P.n;
-  const long cb = blockIdx.x;  // channel-block index = block*ch + channel
-  const long blk = cb / ch;
-  const int n = P.n, n2 = n >> 1;
+__global__ __launch_bounds__(64 * VAMD_XF_WAVES) void k_transform(XformP G, int W, DescP d, int ch, long ncb,
+                                                                 const float *__restrict__ pcm,
+                                                                 float *__restrict__ mdct_raw,
+                                                                 float *__restrict__ logmdct,
+                                                                 float *__restrict__ logfft,
+                                                                 float *__restrict__ local_ampmax) {
+  const XformLds L = stage_transform_tables(G);
+  const XformP &P = L.P;
+  const int n = P.n, n2 = n >> 1, nw = blockDim.x >> 6;
   PhaseClock pc;
   pc.start(d.dbg);
-  const float amp = transform_block(P, W, d_lW(d, blk), d_nW(d, blk), pcm + cb * n, A, B, mdct_raw + cb * n2,
-                                    logmdct + cb * n2, logfft + cb * n2, pc);
-  if (LANE == 0) local_ampmax[cb] = amp;
+  // cb = channel-block index = block*ch + channel
+  for (long cb = (long)blockIdx.x * nw + (threadIdx.x >> 6); cb < ncb; cb += (long)gridDim.x * nw) {
+    const long blk = cb / ch;
+    const float amp = transform_block(P, W, d_lW(d, blk), d_nW(d, blk), pcm + cb * n, L.A, L.B, mdct_raw + cb * n2,
+                                      logmdct + cb * n2, logfft + cb * n2, pc);
+    if (LANE == 0) local_ampmax[cb] = amp;
+  }
+  pc.flush();
 }
 
 // stage 2: _vp_noisemask
@@ -79,6 +137,7 @@ __global__ __launch_bounds__(64) void k_noise(PsyP P0, PsyP P1, DescP d, int ch,
   PhaseClock pc;
   pc.start(d.dbg ? d.dbg + 16 : nullptr);
   noisemask_block(P, logmdct + cb * n2, noise + cb * n2, S, pc);
+  pc.flush();
 }
 
 // block-level ampmax: global = max(ampmax_in, local[0..ch)); one thread per block
@@ -128,6 +187,7 @@ __global__ __launch_bounds__(64) void k_tone_seed(PsyP P0, PsyP P1, DescP d, int
   pc.start(d.dbg ? d.dbg + 32 : nullptr);
   tone_seed_block(P, logfft + cb * n2, ampmax_glob[blk], local_ampmax[cb], seed, fft, pc);
   WAVE_FOR(i, nlp) seed_g[cb * nlp + i] = i < nl ? seed[i] : VAMD_NEGINF;
+  pc.flush();
 }
 
 // one THREAD per channel-block: the ordered stack walk of seed_chase
@@ -142,6 +202,7 @@ __global__ __launch_bounds__(64) void k_tone_chase(int linesper, int nl, int nlp
   if (cb < ncb)
     nsurv[cb] = tone_chase_thread(seed_g + cb * nlp, linesper, nl, ring_amp, ring_pos, 64, threadIdx.x, surv + cb * nlp);
   pc.mark(2);
+  pc.flush();
 }
 
 __global__ __launch_bounds__(64) void k_tone_fold(PsyP P0, PsyP P1, DescP d, int ch, int nlp,
@@ -163,6 +224,7 @@ __global__ __launch_bounds__(64) void k_tone_fold(PsyP P0, PsyP P1, DescP d, int
   WAVE_SYNC();
   tone_fold_block(P, local_ampmax[cb], seed, surv + cb * nlp, nsurv[cb], posstack, ampstack, gmin, tone + cb * n2,
                   pc);
+  pc.flush();
 }
 
 // stage 4: offset_and_mix + floor1_fit + floor curve
@@ -186,6 +248,7 @@ __global__ __launch_bounds__(64) void k_floor(PsyP P0, PsyP P1, FloorP F, DescP 
   const int nzf = floor_fit_render_block(F, n2, mask, lmd, sc, posts + cb * VAMD_POSTS_STRIDE, post_valid + cb,
                                          ilogmask + cb * n2, pc);
   if (LANE == 0) nonzero[cb] = nzf;
+  pc.flush();
 }
 
 // stage 5: couple / quantise / normalise, one wave per block (all channels)
@@ -215,6 +278,7 @@ __global__ __launch_bounds__(64) void k_couple(PsyP P0, PsyP P1, CoupleP C, Desc
   couple_block(C, P, n2, mp, ip, op, nz, L, pc);
   if (LANE == 0)
     for (int c = 0; c < ch; c++) nonzero[blk * ch + c] = nz[c];
+  pc.flush();
 }
 
 // ---------------------------------------------------------------------------
@@ -227,6 +291,8 @@ struct DevBuf {
 
 struct vamd_ctx {
   int device = 0;
+  int num_cus = 256;
+  size_t lds_per_block = 160 * 1024;
   hipStream_t stream = nullptr;
   Bound B;                 // parameter structs bound to the HBM image
   unsigned char *d_image = nullptr;
@@ -255,6 +321,13 @@ static void prof_mark(vamd_ctx *c) {
     c->ev_pool.push_back(e);
   }
   (void)hipEventRecord(c->ev_pool[c->ev_used++], c->stream);
+}
+
+// waves per persistent transform workgroup: as many as fit beside the staged tables
+static int xf_waves(const vamd_ctx *c, const XformP &P) {
+  int w = VAMD_XF_WAVES;
+  while (w > 1 && transform_lds_bytes(P, w) > c->lds_per_block) w--;
+  return w;
 }
 
 static int fail(vamd_ctx *c, int code, const char *what, hipError_t e = hipSuccess) {
@@ -306,6 +379,23 @@ int vamd_create(vamd_ctx **out, const void *setup_blob, size_t blob_bytes, int d
   hipError_t e = hipSuccess;
   if (device >= 0) e = hipSetDevice(device);
   if (e == hipSuccess) e = hipGetDevice(&c->device);
+  if (e == hipSuccess) {
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, c->device);
+    if (e == hipSuccess) {
+      c->num_cus = prop.multiProcessorCount;
+      c->lds_per_block = prop.sharedMemPerBlock;
+      // opt in to the full LDS for the persistent transform kernels (a no-op where the
+      // runtime does not require it)
+      (void)hipFuncSetAttribute((const void *)k_transform, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)c->lds_per_block);
+      (void)hipFuncSetAttribute((const void *)k_mdct_only, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)c->lds_per_block);
+      (void)hipGetLastError();
+      if (getenv("VAMD_VERBOSE"))
+        fprintf(stderr, "vamd_create: %d CUs, %zu B LDS per workgroup\n", c->num_cus, c->lds_per_block);
+    }
+  }
   if (e == hipSuccess) e = hipMalloc((void **)&c->d_image, image.size());
   if (e == hipSuccess) e = hipMemcpy(c->d_image, image.data(), image.size(), hipMemcpyHostToDevice);
   if (e != hipSuccess) {
@@ -371,12 +461,17 @@ int vamd_stage_ms(vamd_ctx *c, float *ms, int nstages, int *runs) {
 int vamd_debug_cycles(vamd_ctx *c, int enable, unsigned long long *out80) {
   if (!c) return VAMD_EINVAL;
   if (out80 && c->d_dbg) {
+    std::vector<unsigned long long> all(64 * 80);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipMemcpy(out80, c->d_dbg, 80 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(all.data(), c->d_dbg, all.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 80; k++) {
+      out80[k] = 0;
+      for (int r = 0; r < 64; r++) out80[k] += all[(size_t)r * 80 + k];
+    }
   }
   if (enable) {
-    if (!c->d_dbg) HIP_TRY(c, hipMalloc((void **)&c->d_dbg, 80 * sizeof(unsigned long long)));
-    HIP_TRY(c, hipMemset(c->d_dbg, 0, 80 * sizeof(unsigned long long)));
+    if (!c->d_dbg) HIP_TRY(c, hipMalloc((void **)&c->d_dbg, 64 * 80 * sizeof(unsigned long long)));
+    HIP_TRY(c, hipMemset(c->d_dbg, 0, 64 * 80 * sizeof(unsigned long long)));
   } else if (c->d_dbg) {
     HIP_TRY(c, hipFree(c->d_dbg));
     c->d_dbg = nullptr;
@@ -446,7 +541,10 @@ int vamd_mdct_forward_batch(vamd_ctx *c, int W, const float *in, float *out, lon
   if (!in || !out) return fail(c, VAMD_EINVAL, "null frame buffer");
   if (nframes > 0x7fffffffL) return fail(c, VAMD_EINVAL, "too many frames for one launch");
   const XformP &P = c->B.xf[W];
-  hipLaunchKernelGGL(k_mdct_only, dim3((unsigned)nframes), dim3(64), (size_t)(2 * P.n + P.n / 32) * 4, c->stream, P, W, in,
+  const int waves = xf_waves(c, P);
+  const long groups = (nframes + waves - 1) / waves;
+  const unsigned grid = (unsigned)(groups < c->num_cus ? groups : c->num_cus);
+  hipLaunchKernelGGL(k_mdct_only, dim3(grid), dim3(64 * waves), transform_lds_bytes(P, waves), c->stream, P, W, nframes, in,
                      out);
   HIP_TRY(c, hipGetLastError());
   return VAMD_OK;
@@ -494,8 +592,13 @@ static int run_batch(vamd_ctx *c, const vamd_batch_desc *desc, const vamd_batch_
 
   int nst = 0;
   prof_mark(c);
-  hipLaunchKernelGGL(k_transform, dim3(gcb), dim3(64), (size_t)(2 * n + n / 32) * 4, s, X, W, d, ch, io->pcm, p.mdct_raw, p.logmdct,
-                     p.logfft, p.local);
+  {
+    const int waves = xf_waves(c, X);
+    const long groups = ((long)gcb + waves - 1) / waves;
+    const unsigned grid = (unsigned)(groups < c->num_cus ? groups : c->num_cus);
+    hipLaunchKernelGGL(k_transform, dim3(grid), dim3(64 * waves), transform_lds_bytes(X, waves), s, X, W, d, ch, (long)gcb,
+                       io->pcm, p.mdct_raw, p.logmdct, p.logfft, p.local);
+  }
   prof_mark(c), nst++;
   if (stream_mode) {
     const float secs = (float)n2 / (float)c->B.rate;  // lib/psy.c:842-843

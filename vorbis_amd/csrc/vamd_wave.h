@@ -28,7 +28,7 @@
 #include <hip/hip_runtime.h>
 #define VAMD_DEV __device__ __forceinline__
 #define VAMD_DEV_NOINLINE __device__ __noinline__
-#define LANE ((int)threadIdx.x)
+#define LANE ((int)(threadIdx.x & 63))  // a workgroup may hold several independent waves
 #define NLANES 64
 // Phase boundary for data exchanged through LDS.  The workgroup IS one wavefront, and
 // the LDS unit executes a wave's DS instructions in issue order, so a later ds_read
@@ -152,22 +152,37 @@ struct alignas(8) I2 {
 // lane 0 of every wave adds the shader-clock ticks spent since the previous mark to a slot.
 struct PhaseClock {
 #if VAMD_GPU
+  // ticks are summed in registers and flushed once per wave into one of 64 replicated
+  // slot sets (spread by workgroup id), so the stopwatch itself costs a handful of
+  // atomics per wave instead of one contended atomic per phase
   unsigned long long *slots;
   long long t;
+  unsigned int acc[8];
   VAMD_DEV void start(unsigned long long *s) {
     slots = s;
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc[k] = 0;
     if (slots) t = clock64();
   }
   VAMD_DEV void mark(int k) {
     if (slots) {
       const long long now = clock64();
-      if (LANE == 0) atomicAdd(slots + k, (unsigned long long)(now - t));
+      acc[k & 7] += (unsigned int)(now - t);
       t = now;
+    }
+  }
+  VAMD_DEV void flush() {
+    if (slots && LANE == 0) {
+      unsigned long long *dst = slots + (size_t)(blockIdx.x & 63) * 80;
+#pragma unroll
+      for (int k = 0; k < 8; k++)
+        if (acc[k]) atomicAdd(dst + k, (unsigned long long)acc[k]);
     }
   }
 #else
   VAMD_DEV void start(unsigned long long *) {}
   VAMD_DEV void mark(int) {}
+  VAMD_DEV void flush() {}
 #endif
 };
 
