@@ -12,7 +12,8 @@
 // error is an integer wave sum and the early-outs are an any().  fit_line's
 // fp64 sums run in the reference's term order on every lane.
 //
-// LDS: mask[n], lmd[n] (logmask / logmdct), FloorScratch.
+// LDS: mask[n], lmd[n] (logmask / logmdct), FloorScratch (interval accumulators + the
+// rendered segment list).
 #pragma once
 #include "vamd_wave.h"
 #include "vamd_params.h"
@@ -33,20 +34,13 @@ struct FitTerm {
   double xb, yb, x2b, xyb, bn;
 };
 
+// LDS scratch.  Everything the ordered sections chase serially (fit values, neighbour
+// maps, the floor's static index tables) is NOT here: it lives one entry per lane in
+// registers (LaneInts / LaneDoubles) and is read with v_readlane.
 struct FloorScratch {
-  FitTerm term[VAMD_MAXPOSTS];
   FitAcc acc[VAMD_MAXPOSTS];
-  int fitA[VAMD_MAXPOSTS], fitB[VAMD_MAXPOSTS];
-  int lon[VAMD_MAXPOSTS], hin[VAMD_MAXPOSTS], memo[VAMD_MAXPOSTS];
-  int out[VAMD_MAXPOSTS];   // floor1_fit's result
-  int post[VAMD_MAXPOSTS];  // floor1_encode's mutated copy
   int segx[VAMD_MAXPOSTS + 1], segy[VAMD_MAXPOSTS + 1];
   int nseg;
-  int nonzero;
-  // the floor's static index tables, staged once per block: the ordered sections
-  // below chase them serially and must not pay an HBM/L2 round trip per step
-  int postlist[VAMD_MAXPOSTS], sorted_index[VAMD_MAXPOSTS], forward_index[VAMD_MAXPOSTS],
-      reverse_index[VAMD_MAXPOSTS], hineighbor[VAMD_MAXPOSTS], loneighbor[VAMD_MAXPOSTS];
 };
 
 // _vp_offset_and_mix with offset_select == 1 (the only select the VBR path uses)
@@ -117,14 +111,18 @@ VAMD_DEV FitTerm fit_term(const FitAcc &a, float twofitweight) {
   return t;  // (the reference also sums y2b, which nothing reads)
 }
 
-VAMD_DEV int fit_line(const FitTerm *a, int fits, int x0, int x1, int *y0, int *y1) {
+struct FitTerms {  // FitTerm of interval i lives in lane i
+  LaneDoubles xb, yb, x2b, xyb, bn;
+};
+
+VAMD_DEV int fit_line(const FitTerms &T, int first, int fits, int x0, int x1, int *y0, int *y1) {
   double xb = 0, yb = 0, x2b = 0, xyb = 0, bn = 0;
-  for (int i = 0; i < fits; i++) {
-    xb += a[i].xb;
-    yb += a[i].yb;
-    x2b += a[i].x2b;
-    xyb += a[i].xyb;
-    bn += a[i].bn;
+  for (int i = first; i < first + fits; i++) {
+    xb += T.xb.get(i);
+    yb += T.yb.get(i);
+    x2b += T.x2b.get(i);
+    xyb += T.xyb.get(i);
+    bn += T.bn.get(i);
   }
   if (*y0 >= 0) {
     xb += x0; yb += *y0; x2b += x0 * x0; xyb += *y0 * x0; bn++;
@@ -195,10 +193,11 @@ VAMD_DEV int inspect_error_wave(int x0, int x1, int y0, int y1, const float *mas
   return 0;
 }
 
-VAMD_DEV int post_Y(const int *A, const int *B, int pos) {
-  if (A[pos] < 0) return B[pos];
-  if (B[pos] < 0) return A[pos];
-  return (A[pos] + B[pos]) >> 1;
+VAMD_DEV int post_Y(const LaneInts &A, const LaneInts &B, int pos) {
+  const int a = A.get(pos), b = B.get(pos);
+  if (a < 0) return b;
+  if (b < 0) return a;
+  return (a + b) >> 1;
 }
 
 // render_point, lib/floor1.c:257-271
@@ -221,19 +220,21 @@ VAMD_DEV int floor_fit_render_block(const FloorP &F, int n2, const float *mask, 
                                     int *__restrict__ ilogmask, PhaseClock &pc) {
   const int posts = F.posts, n = F.look_n;
 
-  WAVE_FOR(i, posts) {
-    sc->postlist[i] = F.postlist[i];
-    sc->sorted_index[i] = F.sorted_index[i];
-    sc->forward_index[i] = F.forward_index[i];
-    sc->reverse_index[i] = F.reverse_index[i];
-    sc->hineighbor[i] = F.hineighbor[i];
-    sc->loneighbor[i] = F.loneighbor[i];
-    sc->fitA[i] = -200;
-    sc->fitB[i] = -200;
-    sc->lon[i] = 0;
-    sc->hin[i] = 1;
-    sc->memo[i] = -1;
-  }
+  LaneInts postlist, sorted_index, forward_index, reverse_index, hineighbor, loneighbor;
+  postlist.load(F.postlist, posts);
+  sorted_index.load(F.sorted_index, posts);
+  forward_index.load(F.forward_index, posts);
+  reverse_index.load(F.reverse_index, posts);
+  hineighbor.load(F.hineighbor, posts);
+  loneighbor.load(F.loneighbor, posts);
+  LaneInts fitA, fitB, lon, hin, memo, outp, post;
+  fitA.fill(-200);
+  fitB.fill(-200);
+  lon.fill(0);
+  hin.fill(1);
+  memo.fill(-1);
+  outp.fill(0);
+  post.fill(0);
   WAVE_FOR(i, (posts - 1) * 12)((int *)sc->acc)[i] = 0;
   WAVE_SYNC();
   // accumulate_fit for all post intervals at once: every lane takes quads of bins, sums
@@ -288,8 +289,28 @@ VAMD_DEV int floor_fit_render_block(const FloorP &F, int n2, const float *mask, 
   }
   nz = wave_sum(nz);
   WAVE_SYNC();
-  WAVE_FOR(i, posts - 1) sc->term[i] = fit_term(sc->acc[i], F.twofitweight);
-  WAVE_SYNC();
+  FitTerms T;
+  {
+    // lane i forms interval i's fit_line contribution
+#if VAMD_GPU
+    FitAcc mine = sc->acc[LANE < posts - 1 ? LANE : 0];
+    const FitTerm ft = fit_term(mine, F.twofitweight);
+    T.xb.set_mine(ft.xb);
+    T.yb.set_mine(ft.yb);
+    T.x2b.set_mine(ft.x2b);
+    T.xyb.set_mine(ft.xyb);
+    T.bn.set_mine(ft.bn);
+#else
+    for (int i = 0; i < posts - 1; i++) {
+      const FitTerm ft = fit_term(sc->acc[i], F.twofitweight);
+      T.xb.a[i] = ft.xb;
+      T.yb.a[i] = ft.yb;
+      T.x2b.a[i] = ft.x2b;
+      T.xyb.a[i] = ft.xyb;
+      T.bn.a[i] = ft.bn;
+    }
+#endif
+  }
   pc.mark(1);
 
   if (!nz) {
@@ -301,36 +322,34 @@ VAMD_DEV int floor_fit_render_block(const FloorP &F, int n2, const float *mask, 
     return 0;
   }
 
-  // ---- greedy progressive split, lib/floor1.c:610-698.  Uniform across lanes;
-  // every lane performs identical LDS updates, so no exchange is needed.
+  // ---- greedy progressive split, lib/floor1.c:610-698.  Wave-uniform: every lane
+  // walks the same decisions; the state is in lane registers.
   {
     int y0 = -200, y1 = -200;
-    fit_line(sc->term, posts - 1, sc->sorted_index[0], sc->sorted_index[posts - 1], &y0, &y1);
-    sc->fitA[0] = y0;
-    sc->fitB[0] = y0;
-    sc->fitB[1] = y1;
-    sc->fitA[1] = y1;
+    fit_line(T, 0, posts - 1, sorted_index.get(0), sorted_index.get(posts - 1), &y0, &y1);
+    fitA.set(0, y0);
+    fitB.set(0, y0);
+    fitB.set(1, y1);
+    fitA.set(1, y1);
   }
   for (int i = 2; i < posts; i++) {
-    // every lane holds the same values here; wave_first() tells the compiler so (scalar
-    // branches and addresses instead of per-lane masks)
-    const int sortpos = wave_first(sc->reverse_index[i]);
-    const int ln = wave_first(sc->lon[sortpos]);
-    const int hn = wave_first(sc->hin[sortpos]);
-    if (wave_first(sc->memo[ln]) != hn) {
-      const int lsortpos = wave_first(sc->reverse_index[ln]);
-      const int hsortpos = wave_first(sc->reverse_index[hn]);
-      sc->memo[ln] = hn;
-      const int lx = wave_first(sc->postlist[ln]), hx = wave_first(sc->postlist[hn]);
-      const int ly = wave_first(post_Y(sc->fitA, sc->fitB, ln));
-      const int hy = wave_first(post_Y(sc->fitA, sc->fitB, hn));
+    const int sortpos = reverse_index.get(i);
+    const int ln = lon.get(sortpos);
+    const int hn = hin.get(sortpos);
+    if (memo.get(ln) != hn) {
+      const int lsortpos = reverse_index.get(ln);
+      const int hsortpos = reverse_index.get(hn);
+      memo.set(ln, hn);
+      const int lx = postlist.get(ln), hx = postlist.get(hn);
+      const int ly = post_Y(fitA, fitB, ln);
+      const int hy = post_Y(fitA, fitB, hn);
       // (ly == -1 || hy == -1 => exit(1) in the reference: unreachable, fits are >= 0 or -200)
       if (inspect_error_wave(lx, hx, ly, hy, mask, lmd, F)) {
         int ly0 = -200, ly1 = -200, hy0 = -200, hy1 = -200;
-        const int ret0 = fit_line(sc->term + lsortpos, sortpos - lsortpos, sc->sorted_index[lsortpos],
-                                  sc->sorted_index[sortpos], &ly0, &ly1);
-        const int ret1 = fit_line(sc->term + sortpos, hsortpos - sortpos, sc->sorted_index[sortpos],
-                                  sc->sorted_index[hsortpos], &hy0, &hy1);
+        const int ret0 = fit_line(T, lsortpos, sortpos - lsortpos, sorted_index.get(lsortpos),
+                                  sorted_index.get(sortpos), &ly0, &ly1);
+        const int ret1 = fit_line(T, sortpos, hsortpos - sortpos, sorted_index.get(sortpos),
+                                  sorted_index.get(hsortpos), &hy0, &hy1);
         if (ret0) {
           ly0 = ly;
           ly1 = hy0;
@@ -340,73 +359,70 @@ VAMD_DEV int floor_fit_render_block(const FloorP &F, int n2, const float *mask, 
           hy1 = hy;
         }
         if (ret0 && ret1) {
-          sc->fitA[i] = -200;
-          sc->fitB[i] = -200;
+          fitA.set(i, -200);
+          fitB.set(i, -200);
         } else {
-          sc->fitB[ln] = ly0;
-          if (ln == 0) sc->fitA[ln] = ly0;
-          sc->fitA[i] = ly1;
-          sc->fitB[i] = hy0;
-          sc->fitA[hn] = hy1;
-          if (hn == 1) sc->fitB[hn] = hy1;
+          fitB.set(ln, ly0);
+          if (ln == 0) fitA.set(ln, ly0);
+          fitA.set(i, ly1);
+          fitB.set(i, hy0);
+          fitA.set(hn, hy1);
+          if (hn == 1) fitB.set(hn, hy1);
           if (ly1 >= 0 || hy0 >= 0) {
-            for (int j = sortpos - 1; j >= 0; j--)
-              if (sc->hin[j] == hn)
-                sc->hin[j] = i;
-              else
-                break;
-            for (int j = sortpos + 1; j < posts; j++)
-              if (sc->lon[j] == ln)
-                sc->lon[j] = i;
-              else
-                break;
+            hin.replace_run_down(sortpos, hn, i);
+            lon.replace_run_up(sortpos + 1, posts, ln, i);
           }
         }
       } else {
-        sc->fitA[i] = -200;
-        sc->fitB[i] = -200;
+        fitA.set(i, -200);
+        fitB.set(i, -200);
       }
     }
   }
 
   pc.mark(2);
   // ---- posts out, lib/floor1.c:700-724
-  sc->out[0] = post_Y(sc->fitA, sc->fitB, 0);
-  sc->out[1] = post_Y(sc->fitA, sc->fitB, 1);
+  outp.set(0, post_Y(fitA, fitB, 0));
+  outp.set(1, post_Y(fitA, fitB, 1));
   for (int i = 2; i < posts; i++) {
-    const int ln = sc->loneighbor[i - 2], hn = sc->hineighbor[i - 2];
-    const int predicted =
-        render_point(sc->postlist[ln], sc->postlist[hn], sc->out[ln], sc->out[hn], sc->postlist[i]);
-    const int vx = post_Y(sc->fitA, sc->fitB, i);
+    const int ln = loneighbor.get(i - 2), hn = hineighbor.get(i - 2);
+    const int predicted = render_point(postlist.get(ln), postlist.get(hn), outp.get(ln), outp.get(hn), postlist.get(i));
+    const int vx = post_Y(fitA, fitB, i);
     if (vx >= 0 && predicted != vx)
-      sc->out[i] = vx;
+      outp.set(i, vx);
     else
-      sc->out[i] = predicted | 0x8000;
+      outp.set(i, predicted | 0x8000);
   }
-  WAVE_FOR(i, VAMD_POSTS_STRIDE) if (posts_out) posts_out[i] = i < posts ? sc->out[i] : 0;
+#if VAMD_GPU
+  if (posts_out && LANE < VAMD_POSTS_STRIDE) posts_out[LANE] = LANE < posts ? outp.mine() : 0;
+#else
+  for (int i = 0; i < VAMD_POSTS_STRIDE; i++)
+    if (posts_out) posts_out[i] = i < posts ? outp.get(i) : 0;
+#endif
   if (post_valid && LANE == 0) *post_valid = 1;
 
   // ---- floor1_encode, value half: quantise by mult, predict, settle the
   // "unused" flags (lib/floor1.c:766-831).  The Huffman writes stay on the host.
   for (int i = 0; i < posts; i++) {
-    int val = sc->out[i] & 0x7fff;
+    const int o = outp.get(i);
+    int val = o & 0x7fff;
     switch (F.mult) {
       case 1: val >>= 2; break;
       case 2: val >>= 3; break;
       case 3: val /= 12; break;
       case 4: val >>= 4; break;
     }
-    sc->post[i] = val | (sc->out[i] & 0x8000);
+    post.set(i, val | (o & 0x8000));
   }
   for (int i = 2; i < posts; i++) {
-    const int ln = sc->loneighbor[i - 2], hn = sc->hineighbor[i - 2];
-    const int predicted =
-        render_point(sc->postlist[ln], sc->postlist[hn], sc->post[ln], sc->post[hn], sc->postlist[i]);
-    if ((sc->post[i] & 0x8000) || (predicted == sc->post[i])) {
-      sc->post[i] = predicted | 0x8000;
+    const int ln = loneighbor.get(i - 2), hn = hineighbor.get(i - 2);
+    const int pi = post.get(i);
+    const int predicted = render_point(postlist.get(ln), postlist.get(hn), post.get(ln), post.get(hn), postlist.get(i));
+    if ((pi & 0x8000) || (predicted == pi)) {
+      post.set(i, predicted | 0x8000);
     } else {
-      sc->post[ln] &= 0x7fff;
-      sc->post[hn] &= 0x7fff;
+      post.set(ln, post.get(ln) & 0x7fff);
+      post.set(hn, post.get(hn) & 0x7fff);
     }
   }
 
@@ -415,13 +431,14 @@ VAMD_DEV int floor_fit_render_block(const FloorP &F, int n2, const float *mask, 
   {
     int ns = 0;
     sc->segx[0] = 0;
-    sc->segy[0] = sc->post[0] * F.mult;
+    sc->segy[0] = post.get(0) * F.mult;
     for (int j = 1; j < posts; j++) {
-      const int cur = sc->forward_index[j];
-      const int hy = sc->post[cur] & 0x7fff;
-      if (hy == sc->post[cur]) {
+      const int cur = forward_index.get(j);
+      const int pc_ = post.get(cur);
+      const int hy = pc_ & 0x7fff;
+      if (hy == pc_) {
         ns++;
-        sc->segx[ns] = sc->postlist[cur];
+        sc->segx[ns] = postlist.get(cur);
         sc->segy[ns] = hy * F.mult;
       }
     }

@@ -57,33 +57,43 @@ VAMD_DEV LineFit fixed_fit_at(const PsyP &P, const float *S, int i, int fixed) {
 
 // In-place running sum p[i] = p[0] + ... + p[i], strictly left to right in fp32
 // (the reference's tN/tX/... accumulators, lib/psy.c:576-603).  One lane; n is a
-// multiple of 16 (block sizes are powers of two >= 64).  The next 16 values are
+// multiple of 32 (block sizes are powers of two >= 64).  The next 16 values are
 // fetched from LDS while the current 16 are being added, so the dependent add
 // chain -- the irreducible part -- is the only thing on the critical path.
+#define VAMD_SCAN4(acc, v) \
+  acc += v.x; v.x = acc; acc += v.y; v.y = acc; acc += v.z; v.z = acc; acc += v.w; v.w = acc;
+
 VAMD_DEV void running_sum_inplace(float *p, int n) {
   F4 *q = (F4 *)p;
   float acc = 0.f;
-  F4 c0 = q[0], c1 = q[1], c2 = q[2], c3 = q[3];
-  for (int b = 0; b < n / 16; b++) {
-    F4 n0 = c0, n1 = c1, n2 = c2, n3 = c3;
-    if (b + 1 < n / 16) {
-      n0 = q[4 * b + 4];
-      n1 = q[4 * b + 5];
-      n2 = q[4 * b + 6];
-      n3 = q[4 * b + 7];
+  const int nblk = n >> 4;  // 16 values (4 quads) per block; nblk is even for n >= 32
+  // two register sets (a*, b*) alternate so that no value is ever copied: while one set
+  // is being summed the other set's loads are in flight and the previous stores drain
+  F4 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
+  F4 b0 = q[4], b1 = q[5], b2 = q[6], b3 = q[7];
+  for (int b = 0; b < nblk; b += 2) {
+    VAMD_SCAN4(acc, a0) VAMD_SCAN4(acc, a1) VAMD_SCAN4(acc, a2) VAMD_SCAN4(acc, a3)
+    q[4 * b] = a0;
+    q[4 * b + 1] = a1;
+    q[4 * b + 2] = a2;
+    q[4 * b + 3] = a3;
+    if (b + 2 < nblk) {
+      a0 = q[4 * b + 8];
+      a1 = q[4 * b + 9];
+      a2 = q[4 * b + 10];
+      a3 = q[4 * b + 11];
     }
-    acc += c0.x; c0.x = acc; acc += c0.y; c0.y = acc; acc += c0.z; c0.z = acc; acc += c0.w; c0.w = acc;
-    acc += c1.x; c1.x = acc; acc += c1.y; c1.y = acc; acc += c1.z; c1.z = acc; acc += c1.w; c1.w = acc;
-    acc += c2.x; c2.x = acc; acc += c2.y; c2.y = acc; acc += c2.z; c2.z = acc; acc += c2.w; c2.w = acc;
-    acc += c3.x; c3.x = acc; acc += c3.y; c3.y = acc; acc += c3.z; c3.z = acc; acc += c3.w; c3.w = acc;
-    q[4 * b] = c0;
-    q[4 * b + 1] = c1;
-    q[4 * b + 2] = c2;
-    q[4 * b + 3] = c3;
-    c0 = n0;
-    c1 = n1;
-    c2 = n2;
-    c3 = n3;
+    VAMD_SCAN4(acc, b0) VAMD_SCAN4(acc, b1) VAMD_SCAN4(acc, b2) VAMD_SCAN4(acc, b3)
+    q[4 * b + 4] = b0;
+    q[4 * b + 5] = b1;
+    q[4 * b + 6] = b2;
+    q[4 * b + 7] = b3;
+    if (b + 3 < nblk) {
+      b0 = q[4 * b + 12];
+      b1 = q[4 * b + 13];
+      b2 = q[4 * b + 14];
+      b3 = q[4 * b + 15];
+    }
   }
 }
 

@@ -27,6 +27,7 @@
 #if VAMD_GPU
 #include <hip/hip_runtime.h>
 #define VAMD_DEV __device__ __forceinline__
+#define VAMD_MEM __device__ __forceinline__
 #define VAMD_DEV_NOINLINE __device__ __noinline__
 #define LANE ((int)(threadIdx.x & 63))  // a workgroup may hold several independent waves
 #define NLANES 64
@@ -46,6 +47,7 @@
 #else
 #include <math.h>
 #define VAMD_DEV static inline
+#define VAMD_MEM inline
 #define VAMD_DEV_NOINLINE static
 #define LANE 0
 #define NLANES 1
@@ -183,6 +185,71 @@ struct PhaseClock {
   VAMD_DEV void start(unsigned long long *) {}
   VAMD_DEV void mark(int) {}
   VAMD_DEV void flush() {}
+#endif
+};
+
+// A small array (<= 64 entries) kept one entry per lane in a VGPR.  Reads with a
+// wave-uniform index are a single v_readlane (no LDS round trip), which is what the
+// ordered, wave-uniform sections (floor split loop, post settling) are bound by.
+struct LaneInts {
+#if VAMD_GPU
+  int v;
+  VAMD_MEM int get(int i) const { return __builtin_amdgcn_readlane(v, i); }
+  VAMD_MEM void set(int i, int x) { v = (LANE == i) ? x : v; }
+  VAMD_MEM void fill(int x) { v = x; }
+  VAMD_MEM void load(const int *__restrict__ p, int count) { v = LANE < count ? p[LANE] : 0; }
+  VAMD_MEM int mine() const { return v; }
+  // entries j = from-1, from-2, ... while == oldv become newv (the reference's "for(j=..;j>=0;j--)
+  // if(a[j]==old)a[j]=new; else break;")
+  VAMD_MEM void replace_run_down(int from, int oldv, int newv) {
+    const unsigned long long eq = __ballot(v == oldv);
+    const unsigned long long below = from >= 64 ? ~0ull : ((1ull << from) - 1ull);
+    const unsigned long long stop = ~eq & below;  // entries below `from` that end the run
+    const int first = stop ? 64 - __builtin_clzll(stop) : 0;
+    if (LANE >= first && LANE < from) v = newv;
+  }
+  // entries j = from, from+1, ... < count while == oldv become newv
+  VAMD_MEM void replace_run_up(int from, int count, int oldv, int newv) {
+    const unsigned long long eq = __ballot(v == oldv);
+    const unsigned long long range = (count >= 64 ? ~0ull : ((1ull << count) - 1ull)) & ~((1ull << from) - 1ull);
+    const unsigned long long stop = ~eq & range;
+    const int last = stop ? __builtin_ctzll(stop) : count;  // first entry that ends the run
+    if (LANE >= from && LANE < last) v = newv;
+  }
+#else
+  int a[64];
+  VAMD_MEM int get(int i) const { return a[i]; }
+  VAMD_MEM void set(int i, int x) { a[i] = x; }
+  VAMD_MEM void fill(int x) { for (int i = 0; i < 64; i++) a[i] = x; }
+  VAMD_MEM void load(const int *p, int count) { for (int i = 0; i < 64; i++) a[i] = i < count ? p[i] : 0; }
+  VAMD_MEM void replace_run_down(int from, int oldv, int newv) {
+    for (int j = from - 1; j >= 0; j--) {
+      if (a[j] != oldv) break;
+      a[j] = newv;
+    }
+  }
+  VAMD_MEM void replace_run_up(int from, int count, int oldv, int newv) {
+    for (int j = from; j < count; j++) {
+      if (a[j] != oldv) break;
+      a[j] = newv;
+    }
+  }
+#endif
+};
+
+struct LaneDoubles {
+#if VAMD_GPU
+  double v;
+  VAMD_MEM double get(int i) const {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), i);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), i);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+  }
+  VAMD_MEM void set_mine(double x) { v = x; }
+#else
+  double a[64];
+  VAMD_MEM double get(int i) const { return a[i]; }
 #endif
 };
 
