@@ -46,6 +46,22 @@ STAGE_BYTES = {
 }
 
 
+def measured_traffic(workload, units):
+    """HBM bytes per step from the committed PMC run (profiles/r01_pmc_traffic.json: rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950 calibration).
+    Returns (total bytes per step, per-stage dict) or (None, {})."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+    except Exception:
+        return None, {}
+    if workload == "c2":
+        return t["mdct_only_B_per_frame"] * units, {}
+    per = {k: (v["read_B_per_stereo_block"] + v["write_B_per_stereo_block"]) * units for k, v in t["per_kernel"].items()}
+    if workload == "c3":
+        per = {k: v for k, v in per.items() if k in ("k_transform", "k_noise", "k_tone_seed", "k_tone_chase", "k_tone_fold")}
+    return sum(per.values()), per
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -200,14 +216,20 @@ def main():
         alg = ALG_BYTES[a.workload] * units                      # bytes per step per GPU, algorithmic
         achieved = alg / (kernels_ms * 1e-3) / 1e9                # GB/s over the path's kernels
         dom_bytes = (STAGE_BYTES.get(dom, ALG_BYTES["c2"]) * units)
+        traffic, traffic_per = measured_traffic(a.workload, units)
+        stage_of = {"k_transform": "transform", "k_noise": "noisemask", "k_floor": "floor", "k_couple": "couple",
+                    "k_tone_seed": "tonemask", "k_tone_chase": "tonemask", "k_tone_fold": "tonemask"}
+        dom_traffic = sum(v for k, v in traffic_per.items() if stage_of.get(k) == dom) or None
         roof = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, "
+                              "separate passes; bytes per step of this workload)" if traffic else None,
             "definition": "algorithmic bytes of the whole path per step (%d B/unit x %d units) / summed "
                           "HIP-event duration of the path's stage kernels per step" % (ALG_BYTES[a.workload], units),
             "kernels_ms_per_step": stage_ms,
             "dominant_kernel": {"name": dom, "ms": stage_ms[dom], "own_bytes_per_step": dom_bytes,
-                                "own_GBps": dom_bytes / (stage_ms[dom] * 1e-3) / 1e9},
+                                "own_GBps": dom_bytes / (stage_ms[dom] * 1e-3) / 1e9, "traffic": dom_traffic},
         }
         line = {
             "metric": "audio blocks/s (2048-sample MDCT+psy) @1/2/4/8 GPU; % HBM roofline",

@@ -1,4 +1,4 @@
-"""Workload for rocprofv3: a few full-analysis steps (65 536 stereo blocks) + mdct-only."""
+"""Workload for rocprofv3: a few full-analysis steps + mdct-only + a calibration copy of known size."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,10 +8,16 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 an = vorbis_amd.Analyzer(vorbis_amd.default_setup_blob("44k_stereo_q4"), 0)
 pcm = torch.rand((nb, 2, 2048), device="cuda") - 0.5
 outs = an.alloc_outputs(1, nb, ("mdct", "logmask", "posts", "post_valid", "iwork", "nonzero", "ampmax_out"))
+an.reserve(1, nb)
 for _ in range(steps):
     an.analyze(pcm, outs=outs)
 x = pcm.reshape(nb * 2, 2048)
 y = torch.empty((nb * 2, 1024), device="cuda")
 for _ in range(steps):
     an.mdct_forward(1, x, out=y)
+# calibration: a device-to-device copy of exactly 1 GiB read + 1 GiB written (float4 elementwise kernel)
+a = torch.empty(256 * 1024 * 1024, dtype=torch.float32, device="cuda").normal_()
+b = torch.empty_like(a)
+for _ in range(steps):
+    b.copy_(a)
 torch.cuda.synchronize()

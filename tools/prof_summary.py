@@ -1,0 +1,39 @@
+"""Turn rocprofv3 rocpd sqlite outputs into the text summaries committed under profiles/."""
+import collections
+import sqlite3
+import sys
+
+
+def kernel_stats(db):
+    con = sqlite3.connect(db)
+    rows = con.execute("select name, total_calls, total_duration, average, percentage from top_kernels").fetchall()
+    print("%-46s %6s %14s %12s %7s" % ("kernel", "calls", "total_ns", "avg_ns", "pct"))
+    for n, c, t, a, p in rows:
+        print("%-46s %6d %14.0f %12.0f %6.2f%%" % (n.split("(")[0][:46], c, t, a, p))
+    try:
+        r = con.execute("select kernel_name, max(vgpr_count), max(sgpr_count), max(lds_block_size), max(workgroup_size), max(grid_size) "
+                        "from kernels group by kernel_name").fetchall()
+        print("\n%-46s %6s %6s %9s %6s %10s" % ("kernel", "vgpr", "sgpr", "lds_B", "wg", "grid"))
+        for n, v, s, l, w, g in r:
+            if n.startswith("k_"):
+                print("%-46s %6s %6s %9s %6s %10s" % (n.split("(")[0][:46], v, s, l, w, g))
+    except Exception as e:  # column names differ between rocprofv3 builds
+        print("(kernel resource table unavailable: %s)" % e)
+
+
+def pmc(db):
+    con = sqlite3.connect(db)
+    rows = con.execute("select kernel_name, counter_name, sum(value), count(*) from counters_collection "
+                       "group by kernel_name, counter_name").fetchall()
+    d = collections.defaultdict(dict)
+    for k, c, v, n in rows:
+        d[k.split("(")[0][:60]][c] = (v / n, n)
+    print("%-60s %-14s %16s %8s" % ("kernel", "counter", "avg_per_dispatch", "n"))
+    for k, v in d.items():
+        for c, (x, n) in sorted(v.items()):
+            print("%-60s %-14s %16.1f %8d" % (k, c, x, n))
+
+
+if __name__ == "__main__":
+    mode, db = sys.argv[1], sys.argv[2]
+    kernel_stats(db) if mode == "kt" else pmc(db)
