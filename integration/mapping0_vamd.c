@@ -1,0 +1,155 @@
+/* integration/mapping0_vamd.c -- the reference-side binding for the drop-in boundary.
+ *
+ * libvorbis has no runtime hook for the mapping back-end: _mapping_P[] and
+ * mapping0_exportbundle are const objects (reference lib/registry.c:42-44,
+ * lib/mapping0.c:802-808), so the hook is at link level.  This
+ * translation unit is what a maintainer builds INSTEAD of lib/mapping0.c:
+ *
+ *   - it pulls the reference's own mapping0.c in by path (pack/unpack/free_info/
+ *     inverse and the CPU forward stay exactly as they are; nothing is copied),
+ *     renaming only the exported bundle;
+ *   - it defines mapping0_forward_vamd(): the numeric section of mapping0_forward
+ *     (lib/mapping0.c:254-576 and the floor render + couple/quantise of :613-646)
+ *     is ONE call into libvorbis_amd.so; the bit-writing half (packet header,
+ *     floor1_encode's Huffman writes, res*_class / res*_forward) is the
+ *     reference's unchanged host code;
+ *   - it exports a mapping0_exportbundle whose .forward is that function.
+ *
+ * Everything else in libvorbis / libvorbisenc links unchanged.  oracle/Makefile
+ * builds exactly this into oracle/_ref/libvorbis_hybrid.so, and
+ * tests/test_gpu_dropin.py checks that an encode through the hybrid library
+ * emits byte-identical packets to the pure reference.
+ *
+ * Managed-bitrate setups (15 packet blobs) are outside the covered path: the
+ * binding falls through to the reference's CPU forward for them (host code
+ * choosing its own CPU implementation -- the GPU library itself has no CPU path).
+ */
+#define mapping0_exportbundle mapping0_exportbundle_cpu
+#include "mapping0.c" /* the reference's lib/mapping0.c, found through -I$(REF)/lib */
+#undef mapping0_exportbundle
+
+#include "vorbis_amd.h"
+
+extern long vamd_pack_setup(vorbis_dsp_state *vd, void *dst, long cap);
+
+/* one GPU context per vorbis_dsp_state, created on first use (vorbis_analysis_init has
+ * already built every lookup by then).  A real integration would hang the pointer off
+ * private_state and free it in vorbis_dsp_clear(); a side table keeps this file
+ * self-contained. */
+#define VAMD_MAX_STATES 64
+static struct {
+  vorbis_dsp_state *vd;
+  vamd_ctx *ctx;
+} vamd_states[VAMD_MAX_STATES];
+
+static vamd_ctx *vamd_ctx_for(vorbis_dsp_state *vd) {
+  int i;
+  for (i = 0; i < VAMD_MAX_STATES; i++)
+    if (vamd_states[i].vd == vd) return vamd_states[i].ctx;
+  for (i = 0; i < VAMD_MAX_STATES; i++)
+    if (!vamd_states[i].vd) {
+      long need = vamd_pack_setup(vd, NULL, 0);
+      void *blob;
+      vamd_ctx *ctx = NULL;
+      if (need < 0) return NULL;
+      blob = _ogg_malloc(need);
+      if (vamd_pack_setup(vd, blob, need) != need || vamd_create(&ctx, blob, (size_t)need, -1) != VAMD_OK)
+        ctx = NULL;
+      _ogg_free(blob);
+      if (ctx) {
+        vamd_states[i].vd = vd;
+        vamd_states[i].ctx = ctx;
+      }
+      return ctx;
+    }
+  return NULL;
+}
+
+/* call from vorbis_dsp_clear() */
+void vamd_release_state(vorbis_dsp_state *vd) {
+  int i;
+  for (i = 0; i < VAMD_MAX_STATES; i++)
+    if (vamd_states[i].vd == vd) {
+      vamd_destroy(vamd_states[i].ctx);
+      vamd_states[i].vd = NULL;
+      vamd_states[i].ctx = NULL;
+    }
+}
+
+static int mapping0_forward_vamd(vorbis_block *vb) {
+  vorbis_dsp_state *vd = vb->vd;
+  vorbis_info *vi = vd->vi;
+  codec_setup_info *ci = vi->codec_setup;
+  private_state *b = vb->vd->backend_state;
+  vorbis_block_internal *vbi = (vorbis_block_internal *)vb->internal;
+  const int n = vb->pcmend, ch = vi->channels, k = PACKETBLOBS / 2;
+  const int modenumber = vb->W;
+  vorbis_info_mapping0 *info = ci->map_param[modenumber];
+  vamd_ctx *ctx;
+  float *mdct;
+  int *iwork, *posts, *post_valid, *nonzero, *scratch;
+  float ampmax_out;
+  int i, j, ret;
+
+  if (vorbis_bitrate_managed(vb) || ch > VAMD_MAX_CH) return mapping0_forward(vb);
+  ctx = vamd_ctx_for(vd);
+  if (!ctx) return OV_EFAULT; /* no silent fallback: a missing GPU is an error */
+
+  vb->mode = modenumber;
+  mdct = _vorbis_block_alloc(vb, ch * (n / 2) * sizeof(*mdct));
+  iwork = _vorbis_block_alloc(vb, ch * (n / 2) * sizeof(*iwork));
+  scratch = _vorbis_block_alloc(vb, (n / 2) * sizeof(*scratch));
+  posts = _vorbis_block_alloc(vb, ch * VAMD_POSTS_STRIDE * sizeof(*posts));
+  post_valid = _vorbis_block_alloc(vb, ch * sizeof(*post_valid));
+  nonzero = _vorbis_block_alloc(vb, ch * sizeof(*nonzero));
+
+  /* ---- the numeric section: window, MDCT, FFT, masking, floor fit, floor curve,
+     couple/quantise -- one call (lib/mapping0.c:254-576,613-646) */
+  ret = vamd_analyze_block(ctx, (const float *const *)vb->pcm, vb->lW, vb->W, vb->nW, vbi->blocktype, vbi->ampmax,
+                           mdct, NULL, posts, post_valid, iwork, nonzero, &ampmax_out);
+  if (ret) return ret;
+  vbi->ampmax = ampmax_out; /* lib/mapping0.c:576 */
+
+  /* ---- the bit-writing half, unchanged host code (lib/mapping0.c:596-687, VBR: blob 7 only) */
+  {
+    oggpack_buffer *opb = vbi->packetblob[k];
+    int **couple_bundle = alloca(sizeof(*couple_bundle) * ch);
+    int *zerobundle = alloca(sizeof(*zerobundle) * ch);
+
+    oggpack_write(opb, 0, 1);
+    oggpack_write(opb, modenumber, b->modebits);
+    if (vb->W) {
+      oggpack_write(opb, vb->lW, 1);
+      oggpack_write(opb, vb->nW, 1);
+    }
+    for (i = 0; i < ch; i++) {
+      int submap = info->chmuxlist[i];
+      /* floor1_encode writes the floor's Huffman words from the posts the GPU fitted; the
+         integer curve it renders as a side effect is identical to the one the GPU already
+         divided out, and is discarded */
+      floor1_encode(opb, vb, b->flr[info->floorsubmap[submap]],
+                    post_valid[i] ? posts + i * VAMD_POSTS_STRIDE : NULL, scratch);
+    }
+    for (i = 0; i < info->submaps; i++) {
+      int ch_in_bundle = 0;
+      long **classifications;
+      int resnum = info->residuesubmap[i];
+      for (j = 0; j < ch; j++)
+        if (info->chmuxlist[j] == i) {
+          zerobundle[ch_in_bundle] = nonzero[j] ? 1 : 0; /* already carries the coupling fix-up */
+          couple_bundle[ch_in_bundle++] = iwork + j * (n / 2);
+        }
+      classifications = _residue_P[ci->residue_type[resnum]]->class(vb, b->residue[resnum], couple_bundle,
+                                                                   zerobundle, ch_in_bundle);
+      ch_in_bundle = 0;
+      for (j = 0; j < ch; j++)
+        if (info->chmuxlist[j] == i) couple_bundle[ch_in_bundle++] = iwork + j * (n / 2);
+      _residue_P[ci->residue_type[resnum]]->forward(opb, vb, b->residue[resnum], couple_bundle, zerobundle,
+                                                     ch_in_bundle, classifications, i);
+    }
+  }
+  return 0;
+}
+
+const vorbis_func_mapping mapping0_exportbundle = {&mapping0_pack, &mapping0_unpack, &mapping0_free_info,
+                                                   &mapping0_forward_vamd, &mapping0_inverse};

@@ -12,6 +12,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_ref", "libvorbis_ref.so")
+# the same reference objects with lib/mapping0.c swapped for integration/mapping0_vamd.c (GPU path)
+HYBRID_PATH = os.path.join(_HERE, "_ref", "libvorbis_hybrid.so")
 
 BLOCKTYPE_IMPULSE = 0
 BLOCKTYPE_PADDING = 1
@@ -46,16 +48,19 @@ def available():
     return os.path.exists(LIB_PATH)
 
 
-_lib = None
+def hybrid_available():
+    return os.path.exists(HYBRID_PATH)
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        if not available():
-            raise RuntimeError("oracle/_ref/libvorbis_ref.so missing: run `make -C oracle ref` "
-                               "(needs /root/reference)")
-        L = C.CDLL(LIB_PATH)
+_libs = {}
+
+
+def lib(hybrid=False):
+    path = HYBRID_PATH if hybrid else LIB_PATH
+    if path not in _libs:
+        if not os.path.exists(path):
+            raise RuntimeError("%s missing: run `make -C oracle` (needs /root/reference)" % path)
+        L = C.CDLL(path)
         L.ref_open.restype = C.c_void_p
         L.ref_open.argtypes = [C.c_int, C.c_long, C.c_float]
         L.ref_close.argtypes = [C.c_void_p]
@@ -82,8 +87,8 @@ def lib():
         L.ref_time_analysis.argtypes = [C.c_void_p, _f32p, C.c_long, C.c_int]
         L.ref_time_dsp.restype = C.c_double
         L.ref_time_dsp.argtypes = [C.c_void_p, _f32p, C.c_long, C.c_int]
-        _lib = L
-    return _lib
+        _libs[path] = L
+    return _libs[path]
 
 
 def _fp(a):
@@ -97,8 +102,8 @@ def _ip(a):
 class RefEncoder:
     """One reference encoder state (vorbis_info + vorbis_dsp_state + a vorbis_block)."""
 
-    def __init__(self, channels=2, rate=44100, quality=0.4):
-        self.L = lib()
+    def __init__(self, channels=2, rate=44100, quality=0.4, hybrid=False):
+        self.L = lib(hybrid)
         self.h = self.L.ref_open(channels, rate, quality)
         if not self.h:
             raise RuntimeError("vorbis_encode_init_vbr failed")

@@ -1,0 +1,45 @@
+"""GPU suite: the drop-in boundary end to end.
+
+oracle/_ref/libvorbis_hybrid.so is the reference's own libvorbis objects with lib/mapping0.c replaced
+by the binding integration/mapping0_vamd.c (numeric section -> libvorbis_amd.so, bit-writing half
+unchanged).  Driving the unmodified application loop (vorbis_analysis_buffer / _wrote / _blockout /
+vorbis_analysis, examples/encoder_example.c:179-236) through it must yield the very packets the
+pure CPU reference emits -- the strongest parity statement the domain offers: every float and integer
+the GPU produced went through the reference's Huffman/VQ back-end and came out as identical bytes.
+"""
+import numpy as np
+import pytest
+
+from oracle import ref
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not (ref.available() and ref.hybrid_available()),
+                                 reason="oracle/_ref libraries not built (needs /root/reference at build time)")]
+
+
+def _stream(ch, seconds, kind, seed):
+    rng = np.random.default_rng(seed)
+    frames = int(44100 * seconds)
+    x = (rng.random((ch, frames), dtype=np.float32) - 0.5)
+    if kind == "gated":   # transients -> short blocks, transitions (SURVEY.md 8d "C5")
+        t = np.arange(frames)
+        x *= 2 * np.where((t % 11025) < 1102, 0.5, 0.0005).astype(np.float32)
+    elif kind == "s16":   # encoder_example.c:197-202: s16 samples / 32768
+        x = np.round(x * 32767).astype(np.int16).astype(np.float32) / 32768.0
+    return np.ascontiguousarray(x, dtype=np.float32)
+
+
+@pytest.mark.parametrize("ch,q,kind", [(2, 0.4, "s16"), (2, 0.9, "gated"), (2, 0.1, "gated"), (1, 0.5, "gated")])
+def test_hybrid_encode_emits_reference_packets(ch, q, kind):
+    pcm = _stream(ch, 1.0 if kind == "s16" else 2.0, kind, seed=12345)
+    want = ref.RefEncoder(ch, 44100, q).encode_stream(pcm)
+    got = ref.RefEncoder(ch, 44100, q, hybrid=True).encode_stream(pcm)
+    assert len(want) == len(got) > 40
+    assert [(b["lW"], b["W"], b["nW"], b["blocktype"]) for b in want] == \
+           [(b["lW"], b["W"], b["nW"], b["blocktype"]) for b in got]
+    for k, (a, b) in enumerate(zip(want, got)):
+        assert np.float32(a["ampmax_in"]) == np.float32(b["ampmax_in"]), k     # the ampmax chain stays in step
+        assert np.float32(a["ampmax_out"]) == np.float32(b["ampmax_out"]), k
+        assert a["packet"] == b["packet"], "packet %d differs (W=%d)" % (k, a["W"])
+    if kind == "gated":
+        assert sum(1 for b in want if b["W"] == 0) > 10
