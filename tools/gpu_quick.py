@@ -49,3 +49,28 @@ names = ["transform", "noise", "tone", "floor", "couple"]
 for k in range(5):
     nw = nb * (1 if k == 4 else 2)
     print(names[k], "kcycles/wave per phase:", [round(float(c) / nw / 1e3, 1) for c in cyc[k][:8]], "sum", round(float(cyc[k].sum()) / nw / 1e3, 1))
+# per-block host API latency and a PCIe-inclusive batch rate
+blk = (np.random.default_rng(1).random((2, 2048), dtype=np.float32) - 0.5)
+an.analyze_block(blk)
+t0 = time.time()
+for _ in range(300):
+    an.analyze_block(blk)
+print("vamd_analyze_block: %.1f us/block" % ((time.time() - t0) / 300 * 1e6))
+nbp = 16384
+hp = torch.empty((nbp, 2, 2048), dtype=torch.float32).pin_memory(); hp.uniform_(-0.5, 0.5)
+want = ("mdct", "posts", "post_valid", "iwork", "nonzero", "ampmax_out")
+outs2 = an.alloc_outputs(1, nbp, want)
+host_out = {k: torch.empty(v.shape, dtype=v.dtype).pin_memory() for k, v in outs2.items()}
+dp = torch.empty((nbp, 2, 2048), device="cuda")
+def roundtrip():
+    dp.copy_(hp, non_blocking=True)
+    an.analyze(dp, outs=outs2)
+    for k in outs2:
+        host_out[k].copy_(outs2[k], non_blocking=True)
+    torch.cuda.synchronize()
+roundtrip()
+t0 = time.time()
+for _ in range(3):
+    roundtrip()
+dt = (time.time() - t0) / 3
+print("PCIe-inclusive (pinned H2D pcm + analysis + D2H mdct/posts/iwork): %.3f M stereo blocks/s" % (nbp / dt / 1e6))
