@@ -97,10 +97,38 @@ VAMD_DEV void running_sum_inplace(float *p, int n) {
   }
 }
 
+// Who runs the five running sums of a block.
+//  ScanSolo : the wave that owns the block (5 lanes busy) -- single-wave workgroups, tests.
+//  ScanGroup: the waves of a workgroup meet at a barrier and ONE wave walks the chains of
+//    every wave's block together (5 x waves lanes busy).  The scan is bound by the LDS store
+//    path -- a ds_write_b128 costs the same ~13 cycles whether 5 or 35 lanes carry data -- so
+//    sharing the instructions between blocks is what makes it cheaper.
+struct ScanSolo {
+  VAMD_MEM void operator()(float *S, int n) const {
+    WAVE_SYNC();
+    WAVE_FOR(a, 5) running_sum_inplace(S + a * (n + 4), n);
+    WAVE_SYNC();
+  }
+};
+#if VAMD_GPU
+struct ScanGroup {
+  float *S_all;  // the workgroup's LDS: chain c lives at S_all + c*(n+4)
+  int nchains;   // 5 x waves
+  VAMD_MEM void operator()(float *, int n) const {
+    __syncthreads();
+    if ((threadIdx.x >> 6) == 0) {
+      WAVE_FOR(c, nchains) running_sum_inplace(S_all + c * (n + 4), n);
+    }
+    __syncthreads();
+  }
+};
+#endif
+
 // bark_noise_hybridmp(n, bark, f, noise, offset, fixed).  f and noise are per-lane
 // register tiles: lane l owns the quads l, l+64, ... (LANE_QUADS), four bins each.
+template <class Scan>
 VAMD_DEV void bark_noise_wave(const PsyP &P, const float (*f)[4], float (*noise)[4], const float offset,
-                              const int fixed, float *S, PhaseClock &pc, int slot) {
+                              const int fixed, float *S, const Scan &scan, PhaseClock &pc, int slot) {
   const int n = P.n, nq = n >> 2;
   // each array starts 16 bytes further round the banks so that the five scanning lanes'
   // 16-byte accesses do not collide
@@ -139,12 +167,10 @@ VAMD_DEV void bark_noise_wave(const PsyP &P, const float (*f)[4], float (*noise)
     ((F4 *)Y)[q] = f4_make(ty);
     ((F4 *)XY)[q] = f4_make(txy);
   }
-  WAVE_SYNC();
   pc.mark(slot);
 
   // the five running sums, in index order, one lane each (lib/psy.c:576-603)
-  WAVE_FOR(a, 5) running_sum_inplace(S + a * (n + 4), n);
-  WAVE_SYNC();
+  scan(S, n);
   pc.mark(slot + 1);
 
   // line evaluation; three regimes split at the static indices i1 <= i2
@@ -189,23 +215,19 @@ VAMD_DEV void bark_noise_wave(const PsyP &P, const float (*f)[4], float (*noise)
   pc.mark(slot + 2);
 }
 
-// _vp_noisemask(p, logmdct, logmask)
-//   logmdct  [n] input (HBM), out [n] (HBM); S = LDS [5][n+4]
-// The noise curve and the work vector never change hands between lanes, so they live in
-// registers (VAMD_QPL quads per lane: block sizes up to 2048 on the GPU).
-VAMD_DEV void noisemask_block(const PsyP &P, const float *__restrict__ logmdct, float *__restrict__ out, float *S,
-                              PhaseClock &pc) {
+// _vp_noisemask on a block whose logmdct is already in a register tile
+template <class Scan>
+VAMD_DEV void noisemask_tile(const PsyP &P, const float (*lm)[4], float (*o)[4], float *S, const Scan &scan,
+                             PhaseClock &pc) {
   const int nq = P.n >> 2;
-  float lm[VAMD_QPL][4], nz[VAMD_QPL][4], wk[VAMD_QPL][4];
-  LANE_QUADS(kq, q, nq) f4_get(((const F4 *)logmdct)[q], lm[kq]);
-  bark_noise_wave(P, lm, nz, 140.f, -1, S, pc, 0);
+  float nz[VAMD_QPL][4], wk[VAMD_QPL][4];
+  bark_noise_wave(P, lm, nz, 140.f, -1, S, scan, pc, 0);
   LANE_QUADS(kq, q, nq) {
     for (int c = 0; c < 4; c++) wk[kq][c] = lm[kq][c] - nz[kq][c];
   }
   pc.mark(3);
-  bark_noise_wave(P, wk, nz, 0.f, P.noisewindowfixed, S, pc, 4);
+  bark_noise_wave(P, wk, nz, 0.f, P.noisewindowfixed, S, scan, pc, 4);
   LANE_QUADS(kq, q, nq) {
-    float o[4];
 #if VAMD_GPU
 #pragma unroll
 #endif
@@ -214,11 +236,23 @@ VAMD_DEV void noisemask_block(const PsyP &P, const float *__restrict__ logmdct, 
       int dB = (int)((double)nz[kq][c] + .5);
       if (dB >= VAMD_NOISE_COMPAND_LEVELS) dB = VAMD_NOISE_COMPAND_LEVELS - 1;
       if (dB < 0) dB = 0;
-      o[c] = w + P.noisecompand[dB];
+      o[kq][c] = w + P.noisecompand[dB];
     }
-    ((F4 *)out)[q] = f4_make(o);
   }
   pc.mark(7);
+}
+
+// _vp_noisemask(p, logmdct, logmask) for one block (single-wave form)
+//   logmdct  [n] input (HBM), out [n] (HBM); S = LDS [5][n+4]
+// The noise curve and the work vector never change hands between lanes, so they live in
+// registers (VAMD_QPL quads per lane: block sizes up to 2048 on the GPU).
+VAMD_DEV void noisemask_block(const PsyP &P, const float *__restrict__ logmdct, float *__restrict__ out, float *S,
+                              PhaseClock &pc) {
+  const int nq = P.n >> 2;
+  float lm[VAMD_QPL][4], o[VAMD_QPL][4];
+  LANE_QUADS(kq, q, nq) f4_get(((const F4 *)logmdct)[q], lm[kq]);
+  noisemask_tile(P, lm, o, S, ScanSolo(), pc);
+  LANE_QUADS(kq, q, nq)((F4 *)out)[q] = f4_make(o[kq]);
 }
 
 }  // namespace vamd

@@ -126,17 +126,36 @@ __global__ __launch_bounds__(64 * VAMD_XF_WAVES) void k_transform(XformP G, int 
   pc.flush();
 }
 
-// stage 2: _vp_noisemask
-__global__ __launch_bounds__(64) void k_noise(PsyP P0, PsyP P1, DescP d, int ch, const float *__restrict__ logmdct,
-                                              float *__restrict__ noise) {
-  const long cb = blockIdx.x;
-  const long blk = cb / ch;
-  const PsyP &P = d_bt(d, blk) ? P1 : P0;
-  const int n2 = P.n;
-  float *S = (float *)vamd_smem;
+// stage 2: _vp_noisemask.  Persistent workgroup of VAMD_NZ_WAVES waves per CU; every wave owns one
+// channel-block per round, and one wave runs the ordered running sums of the whole round
+// (ScanGroup, k_noise.h).
+#define VAMD_NZ_WAVES 7
+__global__ __launch_bounds__(64 * VAMD_NZ_WAVES) void k_noise(PsyP P0, PsyP P1, DescP d, int ch, long ncb,
+                                                             const float *__restrict__ logmdct,
+                                                             float *__restrict__ noise) {
+  const int nw = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  const int n2 = P0.n, nq = n2 >> 2;
+  float *S_all = (float *)vamd_smem;
+  float *S = S_all + wave * 5 * (n2 + 4);
+  ScanGroup scan;
+  scan.S_all = S_all;
+  scan.nchains = 5 * nw;
   PhaseClock pc;
   pc.start(d.dbg ? d.dbg + 16 : nullptr);
-  noisemask_block(P, logmdct + cb * n2, noise + cb * n2, S, pc);
+  const long stride = (long)gridDim.x * nw;
+  const long rounds = (ncb + stride - 1) / stride;  // identical for every wave: barriers inside
+  for (long r = 0; r < rounds; r++) {
+    const long cb_raw = r * stride + (long)blockIdx.x * nw + wave;
+    const bool live = cb_raw < ncb;
+    const long cb = live ? cb_raw : ncb - 1;  // idle waves shadow the last block (no store)
+    const PsyP &P = d_bt(d, cb / ch) ? P1 : P0;
+    float lm[VAMD_QPL][4], o[VAMD_QPL][4];
+    LANE_QUADS(kq, q, nq) f4_get(((const F4 *)(logmdct + cb * n2))[q], lm[kq]);
+    noisemask_tile(P, lm, o, S, scan, pc);
+    if (live) {
+      LANE_QUADS(kq, q, nq)((F4 *)(noise + cb * n2))[q] = f4_make(o[kq]);
+    }
+  }
   pc.flush();
 }
 
@@ -391,6 +410,8 @@ int vamd_create(vamd_ctx **out, const void *setup_blob, size_t blob_bytes, int d
                                 (int)c->lds_per_block);
       (void)hipFuncSetAttribute((const void *)k_mdct_only, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)c->lds_per_block);
+      (void)hipFuncSetAttribute((const void *)k_noise, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)c->lds_per_block);
       (void)hipGetLastError();
       if (getenv("VAMD_VERBOSE"))
         fprintf(stderr, "vamd_create: %d CUs, %zu B LDS per workgroup\n", c->num_cus, c->lds_per_block);
@@ -610,7 +631,14 @@ static int run_batch(vamd_ctx *c, const vamd_batch_desc *desc, const vamd_batch_
   }
   prof_mark(c), nst++;
   if (level >= VAMD_LEVEL_PSY) {
-    hipLaunchKernelGGL(k_noise, dim3(gcb), dim3(64), (size_t)(n2 * 5 + 20) * 4, s, P0, P1, d, ch, p.logmdct, p.noise);
+    {
+      int waves = VAMD_NZ_WAVES;
+      while (waves > 1 && (size_t)waves * 5 * (n2 + 4) * 4 > c->lds_per_block) waves--;
+      const long groups = ((long)gcb + waves - 1) / waves;
+      const unsigned grid = (unsigned)(groups < c->num_cus ? groups : c->num_cus);
+      hipLaunchKernelGGL(k_noise, dim3(grid), dim3(64 * waves), (size_t)waves * 5 * (n2 + 4) * 4, s, P0, P1, d, ch,
+                         (long)gcb, p.logmdct, p.noise);
+    }
     prof_mark(c), nst++;
     {
       const int nlp = (nl + 15) & ~15;
