@@ -144,6 +144,16 @@ int vamd_analyze_batch(vamd_ctx *ctx, const vamd_batch_desc *desc, const vamd_ba
 int vamd_analyze_stream(vamd_ctx *ctx, const vamd_batch_desc *desc, const vamd_batch_io *io,
                         float *ampmax_state);
 
+/* A real stream that mixes both block sizes (BASELINE config 5): the host's
+ * vorbis_analysis_blockout() decides (lW, W, nW, blocktype) per block as before; the blocks are
+ * handed over bucketed by size class, and `order[k]` (device, length nblocks_total) names the k-th
+ * block of the stream: bit 30 = its size class W, bits 0..29 = its index inside that class's
+ * batch.  The ampmax chain runs through the blocks in stream order with each block's own decay
+ * (lib/psy.c:842: secs = blocksize[W]/2/rate).  Either batch may be empty. */
+int vamd_analyze_stream_mixed(vamd_ctx *ctx, const vamd_batch_desc *desc_short, const vamd_batch_io *io_short,
+                              const vamd_batch_desc *desc_long, const vamd_batch_io *io_long, const int32_t *order,
+                              long nblocks_total, float *ampmax_state);
+
 /* ---- per-block host API: the compatibility path behind vorbis_analysis() -----
  * Host pointers.  pcm[ch] -> n samples each (vb->pcm); outputs sized as above for
  * nblocks == 1.  Latency-bound by design (one launch sequence + two PCIe

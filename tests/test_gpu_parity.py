@@ -169,6 +169,32 @@ def test_stream_mode_ampmax_chain(torch_mod):
     assert np.float32(state) == np.float32(amp)
 
 
+def test_mixed_size_stream(torch_mod):
+    """BASELINE config 5: a blockout-cut stream with interleaved short and long blocks; the GPU gets the
+    blocks bucketed by size and the stream order, and must reproduce every block of the reference run
+    (which includes the ampmax chain across size changes)."""
+    from oracle import ref
+    if not ref.available():
+        pytest.skip("needs the reference build to cut a genuine stream")
+    ch, rate, q = 2, 44100, 0.9
+    rng = np.random.default_rng(404)
+    frames = 44100 * 2
+    t = np.arange(frames)
+    gate = np.where((t % 11025) < 1102, 0.5, 0.0005).astype(np.float32)
+    pcm = ((rng.random((ch, frames), dtype=np.float32) - 0.5) * 2 * gate).astype(np.float32)
+    blocks = ref.RefEncoder(ch, rate, q).encode_stream(pcm)
+    assert sum(1 for b in blocks if b["W"] == 0) > 20 and sum(1 for b in blocks if b["W"] == 1) > 20
+    an = analyzer("44k_stereo_q9")
+    res, state = an.analyze_stream_mixed(blocks, -9999.0, want=("mdct", "posts", "post_valid", "iwork", "nonzero", "ampmax_out"))
+    chk = checker.Checker("44k_stereo_q9")
+    for k, (b, g) in enumerate(zip(blocks, res)):
+        r = chk.tap_block(b["pcm"], b["lW"], b["W"], b["nW"], b["blocktype"], b["ampmax_in"])
+        assert np.float32(g["ampmax_out"]) == np.float32(b["ampmax_out"]), k
+        assert checker.compare_block(r, g, an.posts[b["W"]], keys=("mdct", "post_valid", "iwork", "nonzero"),
+                                     verbose=True) == 0, k
+    assert np.float32(state) == np.float32(blocks[-1]["ampmax_out"])
+
+
 def test_full_size_properties(torch_mod):
     """BASELINE size (65 536 stereo blocks): size-independent properties instead of an oracle run.
     (1) determinism, (2) block k of a big batch == the same block analysed alone,

@@ -16,7 +16,7 @@ BLOCKTYPE_IMPULSE, BLOCKTYPE_PADDING, BLOCKTYPE_TRANSITION, BLOCKTYPE_LONG = 0, 
 EXPORTED_SYMBOLS = ["vamd_create", "vamd_destroy", "vamd_last_error", "vamd_set_stream", "vamd_reserve",
                     "vamd_channels", "vamd_blocksize", "vamd_posts", "vamd_mdct_forward_batch",
                     "vamd_analyze_batch", "vamd_analyze_stream", "vamd_analyze_block", "vamd_profile",
-                    "vamd_stage_ms", "vamd_debug_cycles"]
+                    "vamd_stage_ms", "vamd_debug_cycles", "vamd_analyze_stream_mixed"]
 
 _vp = C.c_void_p
 
@@ -74,6 +74,8 @@ def load_library():
     L.vamd_analyze_block.argtypes = [_vp, C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _vp, _vp,
                                      _vp, _vp, _vp, _vp, C.POINTER(C.c_float)]
     L.vamd_debug_cycles.argtypes = [_vp, C.c_int, _vp]
+    L.vamd_analyze_stream_mixed.argtypes = [_vp, C.POINTER(_Desc), C.POINTER(_IO), C.POINTER(_Desc), C.POINTER(_IO), _vp,
+                                            C.c_long, C.POINTER(C.c_float)]
     L.vamd_profile.argtypes = [_vp, C.c_int]
     L.vamd_stage_ms.argtypes = [_vp, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]
     _lib = L
@@ -253,6 +255,40 @@ class Analyzer:
         self._bind_stream()
         self._check(self.L.vamd_analyze_stream(self.h, C.byref(d), C.byref(io), C.byref(st)))
         return outs, st.value
+
+    def analyze_stream_mixed(self, blocks, ampmax_state, want=None):
+        """vamd_analyze_stream_mixed.  `blocks`: stream-ordered list of dicts with keys pcm (numpy
+        [ch][n]), W, lW, nW, blocktype.  Returns (per-block list of output dicts in stream order, state)."""
+        t = self.torch
+        want = self._DEFAULT_WANT[LEVEL_FULL] if want is None else want
+        idx = {0: [], 1: []}
+        order = []
+        for b in blocks:
+            order.append((b["W"] << 30) | len(idx[b["W"]]))
+            idx[b["W"]].append(b)
+        descs, ios, outs, keep = {}, {}, {}, []
+        for W in (0, 1):
+            sel = idx[W]
+            nb = len(sel)
+            n = self.blocksizes[W]
+            pcm = t.from_numpy(np.stack([b["pcm"] for b in sel]).astype(np.float32)).cuda() if nb else \
+                t.empty((0, self.channels, n), device=self._dev())
+            dv = lambda k: t.tensor([b[k] for b in sel], dtype=t.int32, device=self._dev()) if nb else 0  # noqa: E731
+            outs[W] = self.alloc_outputs(W, nb, want)
+            descs[W] = self._desc(W, nb, dv("lW"), dv("nW"), dv("blocktype"), 0.0, keep)
+            ios[W] = self._io(pcm, outs[W])
+            keep.append(pcm)
+        od = t.tensor(order, dtype=t.int32, device=self._dev())
+        st = C.c_float(ampmax_state)
+        self._bind_stream()
+        self._check(self.L.vamd_analyze_stream_mixed(self.h, C.byref(descs[0]), C.byref(ios[0]), C.byref(descs[1]),
+                                                     C.byref(ios[1]), _vp(od.data_ptr()), len(order), C.byref(st)))
+        host = {W: {k: v.cpu().numpy() for k, v in outs[W].items()} for W in (0, 1)}
+        res = []
+        for o in order:
+            W, i = (o >> 30) & 1, o & 0x3fffffff
+            res.append({k: v[i] for k, v in host[W].items()})
+        return res, st.value
 
     def analyze_block(self, pcm, lW=1, W=1, nW=1, blocktype=BLOCKTYPE_LONG, ampmax_in=-9999.0):
         """vamd_analyze_block: host numpy pcm[ch][n] in, host numpy results out (the per-block

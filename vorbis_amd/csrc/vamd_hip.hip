@@ -191,6 +191,30 @@ __global__ void k_ampmax_stream(int ch, long nblocks, float secs, float att, flo
   }
 }
 
+// a stream that mixes both size classes: order[k] = W << 30 | index inside W's batch
+__global__ void k_ampmax_stream_mixed(int ch, long ntotal, const int *__restrict__ order, float secs0, float secs1,
+                                      float att, float state, const float *__restrict__ local0,
+                                      const float *__restrict__ local1, float *__restrict__ in0,
+                                      float *__restrict__ in1, float *__restrict__ glob0, float *__restrict__ glob1,
+                                      float *__restrict__ state_out) {
+  if (blockIdx.x || threadIdx.x) return;
+  float amp = state;
+  for (long k = 0; k < ntotal; k++) {
+    const int o = order[k], W = (o >> 30) & 1;
+    const long b = o & 0x3fffffff;
+    amp += (W ? secs1 : secs0) * att;  // _vp_ampmax_decay with vd->W = this block's size class
+    if (amp < -9999) amp = -9999;
+    (W ? in1 : in0)[b] = amp;
+    const float *loc = W ? local1 : local0;
+    for (int c = 0; c < ch; c++) {
+      const float l = loc[b * ch + c];
+      if (l > amp) amp = l;
+    }
+    (W ? glob1 : glob0)[b] = amp;
+  }
+  *state_out = amp;
+}
+
 // stage 3: _vp_tonemask, in three launches (k_tone.h).  nlp = octave lines padded to 16.
 __global__ __launch_bounds__(64) void k_tone_seed(PsyP P0, PsyP P1, DescP d, int ch, int nlp,
                                                   const float *__restrict__ logfft,
@@ -319,8 +343,8 @@ struct vamd_ctx {
   std::string err;
   // workspace, grown on demand (vamd_reserve to pre-size)
   enum { WS_MDCT_RAW, WS_LOGMDCT, WS_LOGFFT, WS_NOISE, WS_TONE, WS_MDCT, WS_ILOGMASK, WS_IWORK, WS_POSTS, WS_POSTVALID,
-         WS_NONZERO, WS_LOCAL, WS_AMPIN, WS_AMPGLOB, WS_PCM, WS_SEED, WS_SURV, WS_NSURV, WS_COUNT };
-  DevBuf ws[WS_COUNT];
+         WS_NONZERO, WS_LOCAL, WS_AMPIN, WS_AMPGLOB, WS_PCM, WS_SEED, WS_SURV, WS_NSURV, WS_MISC, WS_COUNT };
+  DevBuf ws[2][WS_COUNT];  // per size class (a mixed stream keeps both batches in flight)
   // pinned staging for the per-block host API
   void *h_stage = nullptr;
   size_t h_stage_bytes = 0;
@@ -366,8 +390,8 @@ static int fail(vamd_ctx *c, int code, const char *what, hipError_t e = hipSucce
     if (e__ != hipSuccess) return fail((c), VAMD_EFAULT, #expr, e__); \
   } while (0)
 
-static int ws_get(vamd_ctx *c, int which, size_t bytes, void **out) {
-  DevBuf &b = c->ws[which];
+static int ws_get(vamd_ctx *c, int W, int which, size_t bytes, void **out) {
+  DevBuf &b = c->ws[W][which];
   if (b.bytes < bytes) {
     if (b.p) HIP_TRY(c, hipFree(b.p));
     b.p = nullptr;
@@ -433,8 +457,9 @@ int vamd_create(vamd_ctx **out, const void *setup_blob, size_t blob_bytes, int d
 
 void vamd_destroy(vamd_ctx *c) {
   if (!c) return;
-  for (int i = 0; i < vamd_ctx::WS_COUNT; i++)
-    if (c->ws[i].p) (void)hipFree(c->ws[i].p);
+  for (int W = 0; W < 2; W++)
+    for (int i = 0; i < vamd_ctx::WS_COUNT; i++)
+      if (c->ws[W][i].p) (void)hipFree(c->ws[W][i].p);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->d_dbg) (void)hipFree(c->d_dbg);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
@@ -520,7 +545,7 @@ static int plan(vamd_ctx *c, int W, long nb, const vamd_batch_io *io, int level,
   if (user) {                                           \
     p->field = user;                                    \
   } else {                                              \
-    int r__ = ws_get(c, vamd_ctx::slot, (bytes), &v);   \
+    int r__ = ws_get(c, W, vamd_ctx::slot, (bytes), &v); \
     if (r__) return r__;                                \
     p->field = (decltype(p->field))v;                   \
   }
@@ -584,21 +609,25 @@ static int check_desc(vamd_ctx *c, const vamd_batch_desc *d, const vamd_batch_io
   return VAMD_OK;
 }
 
-// the launch sequence shared by batch and stream mode
-static int run_batch(vamd_ctx *c, const vamd_batch_desc *desc, const vamd_batch_io *io, int level, bool stream_mode,
-                     float *ampmax_state) {
-  const int W = desc->W, ch = c->B.channels;
-  const long nb = desc->nblocks;
-  if (nb == 0) return VAMD_OK;
+// ---- the launch sequence ---------------------------------------------------------
+struct BatchRun {
+  int W;
+  long nb;
   WsPlan p;
-  memset(&p, 0, sizeof(p));
-  int r = plan(c, W, nb, io, level, &p);
-  if (r) return r;
-  const XformP &X = c->B.xf[W];
-  const PsyP &P0 = c->B.psy[2 * W], &P1 = c->B.psy[2 * W + 1];
-  const int n = X.n, n2 = n / 2, nl = P0.total_octave_lines > P1.total_octave_lines ? P0.total_octave_lines
-                                                                                     : P1.total_octave_lines;
   DescP d;
+  const vamd_batch_io *io;
+  int nst;  // stages launched (for vamd_profile)
+};
+
+static int prepare_run(vamd_ctx *c, const vamd_batch_desc *desc, const vamd_batch_io *io, int level, BatchRun *R) {
+  memset(R, 0, sizeof(*R));
+  R->W = desc->W;
+  R->nb = desc->nblocks;
+  R->io = io;
+  if (R->nb == 0) return VAMD_OK;
+  int r = plan(c, R->W, R->nb, io, level, &R->p);
+  if (r) return r;
+  DescP &d = R->d;
   d.lW = desc->lW;
   d.nW = desc->nW;
   d.blocktype = desc->blocktype;
@@ -608,28 +637,34 @@ static int run_batch(vamd_ctx *c, const vamd_batch_desc *desc, const vamd_batch_
   d.u_blocktype = desc->uniform_blocktype;
   d.u_ampmax_in = desc->uniform_ampmax_in;
   d.dbg = c->d_dbg;
-  const unsigned gcb = (unsigned)(nb * ch), gb = (unsigned)nb;
-  hipStream_t s = c->stream;
+  return VAMD_OK;
+}
 
-  int nst = 0;
+// stage 1 (window, MDCT, FFT, logs, local ampmax)
+static void launch_transform(vamd_ctx *c, BatchRun *R) {
+  if (R->nb == 0) return;
+  const int ch = c->B.channels;
+  const XformP &X = c->B.xf[R->W];
+  const unsigned gcb = (unsigned)(R->nb * ch);
+  const int waves = xf_waves(c, X);
+  const long groups = ((long)gcb + waves - 1) / waves;
+  const unsigned grid = (unsigned)(groups < c->num_cus ? groups : c->num_cus);
   prof_mark(c);
-  {
-    const int waves = xf_waves(c, X);
-    const long groups = ((long)gcb + waves - 1) / waves;
-    const unsigned grid = (unsigned)(groups < c->num_cus ? groups : c->num_cus);
-    hipLaunchKernelGGL(k_transform, dim3(grid), dim3(64 * waves), transform_lds_bytes(X, waves), s, X, W, d, ch, (long)gcb,
-                       io->pcm, p.mdct_raw, p.logmdct, p.logfft, p.local);
-  }
-  prof_mark(c), nst++;
-  if (stream_mode) {
-    const float secs = (float)n2 / (float)c->B.rate;  // lib/psy.c:842-843
-    hipLaunchKernelGGL(k_ampmax_stream, dim3(1), dim3(1), 0, s, ch, nb, secs, c->B.ampmax_att_per_sec, *ampmax_state,
-                       p.local, p.ampin, p.ampglob);
-    d.ampmax_in = p.ampin;
-  } else {
-    hipLaunchKernelGGL(k_ampmax, dim3((gb + 255) / 256), dim3(256), 0, s, d, ch, nb, p.local, p.ampglob);
-  }
-  prof_mark(c), nst++;
+  hipLaunchKernelGGL(k_transform, dim3(grid), dim3(64 * waves), transform_lds_bytes(X, waves), c->stream, X, R->W, R->d,
+                     ch, (long)gcb, R->io->pcm, R->p.mdct_raw, R->p.logmdct, R->p.logfft, R->p.local);
+  prof_mark(c), R->nst++;
+}
+
+// stages 2..5 (masking, floor, couple); R->d.ampmax_in / p.ampglob must be final
+static void launch_rest(vamd_ctx *c, BatchRun *R, int level) {
+  if (R->nb == 0) return;
+  const int W = R->W, ch = c->B.channels;
+  const WsPlan &p = R->p;
+  const DescP &d = R->d;
+  const PsyP &P0 = c->B.psy[2 * W], &P1 = c->B.psy[2 * W + 1];
+  const int n2 = c->B.xf[W].n / 2, nl = P0.total_octave_lines;
+  const unsigned gcb = (unsigned)(R->nb * ch), gb = (unsigned)R->nb;
+  hipStream_t s = c->stream;
   if (level >= VAMD_LEVEL_PSY) {
     {
       int waves = VAMD_NZ_WAVES;
@@ -639,7 +674,7 @@ static int run_batch(vamd_ctx *c, const vamd_batch_desc *desc, const vamd_batch_
       hipLaunchKernelGGL(k_noise, dim3(grid), dim3(64 * waves), (size_t)waves * 5 * (n2 + 4) * 4, s, P0, P1, d, ch,
                          (long)gcb, p.logmdct, p.noise);
     }
-    prof_mark(c), nst++;
+    prof_mark(c), R->nst++;
     {
       const int nlp = (nl + 15) & ~15;
       hipLaunchKernelGGL(k_tone_seed, dim3(gcb), dim3(64), (size_t)(n2 + nlp) * 4, s, P0, P1, d, ch, nlp, p.logfft,
@@ -649,22 +684,44 @@ static int run_batch(vamd_ctx *c, const vamd_batch_desc *desc, const vamd_batch_
       hipLaunchKernelGGL(k_tone_fold, dim3(gcb), dim3(64), (size_t)(nlp * 3 + n2) * 4, s, P0, P1, d, ch, nlp, p.seed, p.surv,
                          p.nsurv, p.local, p.tone);
     }
-    prof_mark(c), nst++;
+    prof_mark(c), R->nst++;
   }
   if (level >= VAMD_LEVEL_FULL) {
     hipLaunchKernelGGL(k_floor, dim3(gcb), dim3(64), (size_t)n2 * 8 + sizeof(FloorScratch), s, P0, P1, c->B.floor[W],
-                       d, ch, p.noise, p.tone, p.logmdct, p.mdct_raw, p.mdct, io->logmask, p.posts, p.post_valid,
+                       d, ch, p.noise, p.tone, p.logmdct, p.mdct_raw, p.mdct, R->io->logmask, p.posts, p.post_valid,
                        p.ilogmask, p.nonzero);
-    prof_mark(c), nst++;
+    prof_mark(c), R->nst++;
     hipLaunchKernelGGL(k_couple, dim3(gb), dim3(64), (size_t)n2 * 12, s, P0, P1, c->B.couple[W], d, p.mdct, p.ilogmask,
                        p.iwork, p.nonzero);
-    prof_mark(c), nst++;
+    prof_mark(c), R->nst++;
   }
-  if (c->profile) c->ev_runs.push_back(nst);
+}
+
+static int run_batch(vamd_ctx *c, const vamd_batch_desc *desc, const vamd_batch_io *io, int level, bool stream_mode,
+                     float *ampmax_state) {
+  BatchRun R;
+  int r = prepare_run(c, desc, io, level, &R);
+  if (r) return r;
+  if (R.nb == 0) return VAMD_OK;
+  const int ch = c->B.channels;
+  hipStream_t s = c->stream;
+  launch_transform(c, &R);
+  if (stream_mode) {
+    const float secs = (float)(c->B.xf[R.W].n / 2) / (float)c->B.rate;  // lib/psy.c:842-843
+    hipLaunchKernelGGL(k_ampmax_stream, dim3(1), dim3(1), 0, s, ch, R.nb, secs, c->B.ampmax_att_per_sec, *ampmax_state,
+                       R.p.local, R.p.ampin, R.p.ampglob);
+    R.d.ampmax_in = R.p.ampin;
+  } else {
+    hipLaunchKernelGGL(k_ampmax, dim3((unsigned)((R.nb + 255) / 256)), dim3(256), 0, s, R.d, ch, R.nb, R.p.local,
+                       R.p.ampglob);
+  }
+  prof_mark(c), R.nst++;
+  launch_rest(c, &R, level);
+  if (c->profile) c->ev_runs.push_back(R.nst);
   HIP_TRY(c, hipGetLastError());
   if (stream_mode) {
     // new state = ampmax_out of the last block
-    HIP_TRY(c, hipMemcpyAsync(ampmax_state, p.ampglob + (nb - 1), sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(ampmax_state, R.p.ampglob + (R.nb - 1), sizeof(float), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
   }
   return VAMD_OK;
@@ -682,6 +739,44 @@ int vamd_analyze_stream(vamd_ctx *c, const vamd_batch_desc *desc, const vamd_bat
   if (r) return r;
   if (!ampmax_state) return fail(c, VAMD_EINVAL, "null ampmax_state");
   return run_batch(c, desc, io, VAMD_LEVEL_FULL, true, ampmax_state);
+}
+
+int vamd_analyze_stream_mixed(vamd_ctx *c, const vamd_batch_desc *desc_short, const vamd_batch_io *io_short,
+                              const vamd_batch_desc *desc_long, const vamd_batch_io *io_long, const int32_t *order,
+                              long nblocks_total, float *ampmax_state) {
+  if (!c) return VAMD_EINVAL;
+  if (!desc_short || !desc_long || !ampmax_state) return fail(c, VAMD_EINVAL, "null argument");
+  if (desc_short->W != 0 || desc_long->W != 1) return fail(c, VAMD_EINVAL, "desc_short->W must be 0, desc_long->W 1");
+  if (nblocks_total != desc_short->nblocks + desc_long->nblocks || (nblocks_total && !order))
+    return fail(c, VAMD_EINVAL, "order[] must name every block of both batches exactly once");
+  int r;
+  if (desc_short->nblocks && (r = check_desc(c, desc_short, io_short))) return r;
+  if (desc_long->nblocks && (r = check_desc(c, desc_long, io_long))) return r;
+  if (nblocks_total == 0) return VAMD_OK;
+  BatchRun R[2];
+  if ((r = prepare_run(c, desc_short, io_short, VAMD_LEVEL_FULL, &R[0]))) return r;
+  if ((r = prepare_run(c, desc_long, io_long, VAMD_LEVEL_FULL, &R[1]))) return r;
+  // scratch for the chained state; an empty size class still needs valid (unused) pointers
+  void *misc = nullptr;
+  if ((r = ws_get(c, 0, vamd_ctx::WS_MISC, 256, &misc))) return r;
+  float *d_state = (float *)misc;
+  for (int W = 0; W < 2; W++)
+    if (R[W].nb == 0) R[W].p.ampin = R[W].p.ampglob = R[W].p.local = (float *)misc + 16;
+  hipStream_t s = c->stream;
+  launch_transform(c, &R[0]);
+  launch_transform(c, &R[1]);
+  const float secs0 = (float)(c->B.bs[0] / 2) / (float)c->B.rate, secs1 = (float)(c->B.bs[1] / 2) / (float)c->B.rate;
+  hipLaunchKernelGGL(k_ampmax_stream_mixed, dim3(1), dim3(1), 0, s, c->B.channels, nblocks_total, (const int *)order, secs0,
+                     secs1, c->B.ampmax_att_per_sec, *ampmax_state, R[0].p.local, R[1].p.local, R[0].p.ampin,
+                     R[1].p.ampin, R[0].p.ampglob, R[1].p.ampglob, d_state);
+  R[0].d.ampmax_in = R[0].p.ampin;
+  R[1].d.ampmax_in = R[1].p.ampin;
+  launch_rest(c, &R[0], VAMD_LEVEL_FULL);
+  launch_rest(c, &R[1], VAMD_LEVEL_FULL);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(ampmax_state, d_state, sizeof(float), hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  return VAMD_OK;
 }
 
 int vamd_analyze_block(vamd_ctx *c, const float *const *pcm, int lW, int W, int nW, int blocktype, float ampmax_in,
@@ -703,7 +798,7 @@ int vamd_analyze_block(vamd_ctx *c, const float *const *pcm, int lW, int W, int 
     c->h_stage_bytes = total;
   }
   void *dv;
-  int r = ws_get(c, vamd_ctx::WS_PCM, total, &dv);
+  int r = ws_get(c, W, vamd_ctx::WS_PCM, total, &dv);
   if (r) return r;
   unsigned char *hs = (unsigned char *)c->h_stage, *ds = (unsigned char *)dv;
   for (int i = 0; i < ch; i++) {
