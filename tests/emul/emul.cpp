@@ -49,7 +49,9 @@ int emul_mdct_forward(void *h, int W, const float *in, float *out) {
   std::vector<float> A(P.n + 4), Bw(P.n + P.n / 32);
   PhaseClock pc;
   pc.start(nullptr);
-  load_windowed(P, W, 1, 1, in, A.data(), false);
+  static PcmTile tile;
+  pcm_fetch(tile, in, P.n);
+  window_store(P, W, 1, 1, tile, A.data(), false);
   mdct_forward_wave(P, A.data(), Bw.data(), Bw.data() + P.n / 2, pc);
   memcpy(out, Bw.data() + P.n / 2, sizeof(float) * (P.n / 2));
   return 0;
@@ -73,8 +75,10 @@ int emul_analyze_block(void *h, const float *pcm, int lW, int W, int nW, int blo
   PhaseClock pc;
   pc.start(nullptr);
   for (int i = 0; i < ch; i++) {
-    local[i] = transform_block(X, W, lW, nW, pcm + (size_t)i * n, A.data(), Bw.data(), &mdct_raw[i * n2],
-                               &logmdct[i * n2], &logfft[i * n2], pc);
+    static PcmTile tile;
+    pcm_fetch(tile, pcm + (size_t)i * n, n);
+    transform_window(X, W, lW, nW, tile, A.data(), pc);
+    local[i] = transform_block(X, A.data(), Bw.data(), &mdct_raw[i * n2], &logmdct[i * n2], &logfft[i * n2], pc);
     if (local[i] > global) global = local[i];
   }
   {

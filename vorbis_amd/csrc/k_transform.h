@@ -17,13 +17,22 @@
 
 namespace vamd {
 
-// _vorbis_apply_window, lib/window.c:2102-2135, fused with the load of the
-// block from HBM.  lW/nW are already forced to 0 for short blocks by the caller.
-VAMD_DEV void load_windowed(const XformP &P, int W, int lW, int nW, const float *__restrict__ pcm, float *A,
-                            bool apply_window) {
+// A block of PCM held in registers (lane l owns quads l, l+64, ...): fetched from HBM one
+// block ahead of its use so that the load latency hides behind the previous block's
+// transforms (persistent kernels), then windowed on its way into LDS.
+struct PcmTile {
+  float v[VAMD_QPL2][4];
+};
+
+VAMD_DEV void pcm_fetch(PcmTile &t, const float *__restrict__ pcm, int n) {
+  LANE_QUADS2(kq, q, n >> 2) f4_get(((const F4 *)pcm)[q], t.v[kq]);
+}
+
+// _vorbis_apply_window, lib/window.c:2102-2135, applied while the tile is written to LDS.
+VAMD_DEV void window_store(const XformP &P, int W, int lW, int nW, const PcmTile &t, float *A, bool apply_window) {
   const int n = P.n;
   if (!apply_window) {
-    WAVE_FOR(q, n >> 2)((F4 *)A)[q] = ((const F4 *)pcm)[q];
+    LANE_QUADS2(kq, q, n >> 2)((F4 *)A)[q] = f4_make(t.v[kq]);
     return;
   }
   lW = W ? lW : 0;
@@ -36,10 +45,9 @@ VAMD_DEV void load_windowed(const XformP &P, int W, int lW, int nW, const float 
   const int rightbegin = n / 2 + n / 4 - rn / 4, rightend = rightbegin + rn / 2;
   // every boundary is a multiple of 4 (block sizes are powers of two >= 64), so a
   // 16-byte quad never straddles two regions
-  WAVE_FOR(q, n >> 2) {
+  LANE_QUADS2(kq, q, n >> 2) {
     const int i = q << 2;
-    float v[4];
-    f4_get(((const F4 *)pcm)[q], v);
+    float v[4] = {t.v[kq][0], t.v[kq][1], t.v[kq][2], t.v[kq][3]};
     if (i < leftbegin || i >= rightend) {
       v[0] = v[1] = v[2] = v[3] = 0.f;
     } else if (i < leftend) {
@@ -315,28 +323,56 @@ VAMD_DEV void st_pair(float *p, int t, float a, float b) {  // p[t-1] = a, p[t] 
 }
 
 // dradf4, lib/smallft.c:168-268: one radix-4 pass cc -> ch.  wa1/2/3 are the
-// reference's 1-based-offset twiddle pointers (wa+iw-1 etc.).
+// reference's 1-based-offset twiddle pointers (wa+iw-1 etc.).  The reference runs three
+// loops per pass: over k (the i = 0 column), over (k, i = 2,4,..) and over k again (the
+// i = ido column).  Here one flat loop over g = (k, m) with m in [0, ido/2) covers all
+// three: m = 0 does both k-only columns, m >= 1 the (k, i = 2m) butterfly.  ido is a power
+// of two (>= 4) for every pass but the first, so k and m are a shift and a mask.
 template <bool AL>
 VAMD_DEV void radf4_wave(int ido, int l1, const float *cc, float *ch, const float *__restrict__ wa1,
                          const float *__restrict__ wa2, const float *__restrict__ wa3) {
   const float hsqt2 = .70710678118654752f;
   const int t0 = l1 * ido;
-  WAVE_FOR(k, l1) {
-    const int t1 = t0 + k * ido, t2 = 3 * t0 + k * ido, t3 = k * ido, t4 = 2 * t0 + k * ido;
-    const float tr1 = cc[t1] + cc[t2];
-    const float tr2 = cc[t3] + cc[t4];
-    int t5 = t3 << 2;
-    ch[t5] = tr1 + tr2;
-    ch[(ido << 2) + t5 - 1] = tr2 - tr1;
-    t5 += ido << 1;
-    ch[t5 - 1] = cc[t3] - cc[t4];
-    ch[t5] = cc[t2] - cc[t1];
+  if (ido == 1) {
+    // first pass: four contiguous outputs per k -> one 16-byte store (offset layout: index 4k at +1)
+    WAVE_FOR(k, l1) {
+      const float c1 = cc[t0 + k], c2 = cc[3 * t0 + k], c3 = cc[k], c4 = cc[2 * t0 + k];
+      const float tr1 = c1 + c2, tr2 = c3 + c4;
+      float *o = ch + 4 * k;
+      o[0] = tr1 + tr2;
+      o[1] = c3 - c4;
+      o[2] = c2 - c1;
+      o[3] = tr2 - tr1;
+    }
+    return;
   }
-  if (ido < 2) return;
-  if (ido > 2) {
-    const int half = (ido - 1) >> 1;  // i = 2,4,..,< ido
-    WAVE_FOR(g, l1 * half) {
-      const int k = g / half, m = g - k * half + 1, i = 2 * m;
+  const int lh = 31 - __builtin_clz((unsigned)(ido >> 1));  // log2(ido/2)
+  WAVE_FOR(g, l1 << lh) {
+    const int k = g >> lh, m = g & ((1 << lh) - 1);
+    if (m == 0) {
+      {
+        const int t1 = t0 + k * ido, t2 = 3 * t0 + k * ido, t3 = k * ido, t4 = 2 * t0 + k * ido;
+        const float tr1 = cc[t1] + cc[t2];
+        const float tr2 = cc[t3] + cc[t4];
+        int t5 = t3 << 2;
+        ch[t5] = tr1 + tr2;
+        ch[(ido << 2) + t5 - 1] = tr2 - tr1;
+        t5 += ido << 1;
+        ch[t5 - 1] = cc[t3] - cc[t4];
+        ch[t5] = cc[t2] - cc[t1];
+      }
+      {
+        const int t1 = t0 + ido - 1 + k * ido, t2 = t1 + (t0 << 1);
+        const int t4 = ido + k * (ido << 2), t5 = ido << 1, t6 = ido + k * ido;
+        const float ti1 = -hsqt2 * (cc[t1] + cc[t2]);
+        const float tr1 = hsqt2 * (cc[t1] - cc[t2]);
+        ch[t4 - 1] = tr1 + cc[t6 - 1];
+        ch[t4 + t5 - 1] = cc[t6 - 1] - tr1;
+        ch[t4] = ti1 - cc[t1 + t0];
+        ch[t4 + t5] = ti1 + cc[t1 + t0];
+      }
+    } else {
+      const int i = 2 * m;
       const int t1 = k * ido;
       const int t2 = t1 + i;
       const int t4 = (t1 << 2) + i;
@@ -359,34 +395,36 @@ VAMD_DEV void radf4_wave(int ido, int l1, const float *cc, float *ch, const floa
       st_pair(ch, t4 + t6, ti4 + tr3, tr4 + ti3);
       st_pair(ch, t5 + t6, tr2 - tr1, ti1 - ti2);
     }
-    if (ido & 1) return;
-  }
-  WAVE_FOR(k, l1) {
-    const int t1 = t0 + ido - 1 + k * ido, t2 = t1 + (t0 << 1);
-    const int t4 = ido + k * (ido << 2), t5 = ido << 1, t6 = ido + k * ido;
-    const float ti1 = -hsqt2 * (cc[t1] + cc[t2]);
-    const float tr1 = hsqt2 * (cc[t1] - cc[t2]);
-    ch[t4 - 1] = tr1 + cc[t6 - 1];
-    ch[t4 + t5 - 1] = cc[t6 - 1] - tr1;
-    ch[t4] = ti1 - cc[t1 + t0];
-    ch[t4 + t5] = ti1 + cc[t1 + t0];
   }
 }
 
-// dradf2, lib/smallft.c:113-166
+// dradf2, lib/smallft.c:113-166, same flattening
 template <bool AL>
 VAMD_DEV void radf2_wave(int ido, int l1, const float *cc, float *ch, const float *__restrict__ wa1) {
   const int t0 = l1 * ido;
-  WAVE_FOR(k, l1) {
-    const int t1 = k * ido, t2 = t0 + k * ido;
-    ch[t1 << 1] = cc[t1] + cc[t2];
-    ch[(t1 << 1) + (ido << 1) - 1] = cc[t1] - cc[t2];
+  if (ido == 1) {
+    WAVE_FOR(k, l1) {
+      ch[2 * k] = cc[k] + cc[t0 + k];
+      ch[2 * k + 1] = cc[k] - cc[t0 + k];
+    }
+    return;
   }
-  if (ido < 2) return;
-  if (ido > 2) {
-    const int half = (ido - 1) >> 1;
-    WAVE_FOR(g, l1 * half) {
-      const int k = g / half, m = g - k * half + 1, i = 2 * m;
+  const int lh = 31 - __builtin_clz((unsigned)(ido >> 1));
+  WAVE_FOR(g, l1 << lh) {
+    const int k = g >> lh, m = g & ((1 << lh) - 1);
+    if (m == 0) {
+      {
+        const int t1 = k * ido, t2 = t0 + k * ido;
+        ch[t1 << 1] = cc[t1] + cc[t2];
+        ch[(t1 << 1) + (ido << 1) - 1] = cc[t1] - cc[t2];
+      }
+      {
+        const int t1 = ido + k * (ido << 1), t2 = ido - 1 + t0 + k * ido, t3 = ido - 1 + k * ido;
+        ch[t1] = -cc[t2];
+        ch[t1 - 1] = cc[t3];
+      }
+    } else {
+      const int i = 2 * m;
       const int t1 = k * ido, t2 = t0 + k * ido;
       const int t3 = t2 + i, t4 = (t1 << 1) + (ido << 1) - i, t5 = t1 + i, t6 = (t1 << 1) + i;
       const F2 w1 = *(const F2 *)(wa1 + i - 2);
@@ -396,12 +434,6 @@ VAMD_DEV void radf2_wave(int ido, int l1, const float *cc, float *ch, const floa
       st_pair(ch, t6, c5.x + tr2, c5.y + ti2);
       st_pair(ch, t4, c5.x - tr2, ti2 - c5.y);
     }
-    if (ido % 2 == 1) return;
-  }
-  WAVE_FOR(k, l1) {
-    const int t1 = ido + k * (ido << 1), t2 = ido - 1 + t0 + k * ido, t3 = ido - 1 + k * ido;
-    ch[t1] = -cc[t2];
-    ch[t1 - 1] = cc[t3];
   }
 }
 
@@ -447,13 +479,18 @@ VAMD_DEV const float *drft_forward_wave(const XformP &P, float *c, float *ch) {
 //   A, B     LDS [n] each
 //   outputs  HBM, each may be null
 // Returns the channel's local_ampmax (all lanes).
-VAMD_DEV float transform_block(const XformP &P, int W, int lW, int nW, const float *__restrict__ pcm, float *A,
-                               float *B, float *__restrict__ mdct_out, float *__restrict__ logmdct_out,
-                               float *__restrict__ logfft_out, PhaseClock &pc) {
-  const int n = P.n, n2 = n >> 1;
-  load_windowed(P, W, lW, nW, pcm, A, true);
+// `tile` holds the un-windowed block (pcm_fetch); it is consumed before anything else, so the
+// caller may refill it for the next block as soon as this returns from its first phase.
+VAMD_DEV void transform_window(const XformP &P, int W, int lW, int nW, const PcmTile &tile, float *A,
+                               PhaseClock &pc) {
+  window_store(P, W, lW, nW, tile, A, true);
   WAVE_SYNC();
   pc.mark(0);
+}
+
+VAMD_DEV float transform_block(const XformP &P, float *A, float *B, float *__restrict__ mdct_out,
+                               float *__restrict__ logmdct_out, float *__restrict__ logfft_out, PhaseClock &pc) {
+  const int n = P.n, n2 = n >> 1;
 
   // MDCT: spectrum lands in B[n2..n) (LDS), then goes out with its dB twin
   mdct_forward_wave(P, A, B, B + n2, pc);

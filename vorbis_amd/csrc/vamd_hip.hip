@@ -95,8 +95,10 @@ __global__ __launch_bounds__(64 * VAMD_XF_WAVES) void k_mdct_only(XformP G, int 
   const int n2 = P.n >> 1, nw = blockDim.x >> 6;
   PhaseClock pc;
   pc.start(nullptr);
+  // (no register prefetch here: this kernel is HBM-bound and measured faster loading each
+  // frame straight into LDS -- 246 vs 195 M frames/s)
   for (long f = (long)blockIdx.x * nw + (threadIdx.x >> 6); f < nframes; f += (long)gridDim.x * nw) {
-    load_windowed(P, W, 1, 1, in + f * P.n, L.A, false);
+    WAVE_FOR(q, P.n >> 2)((F4 *)L.A)[q] = ((const F4 *)(in + f * P.n))[q];
     WAVE_SYNC();
     mdct_forward_wave(P, L.A, L.B, L.B + n2, pc);
     WAVE_FOR(q, n2 >> 2)((F4 *)(out + f * n2))[q] = ((const F4 *)(L.B + n2))[q];
@@ -117,10 +119,15 @@ __global__ __launch_bounds__(64 * VAMD_XF_WAVES) void k_transform(XformP G, int 
   PhaseClock pc;
   pc.start(d.dbg);
   // cb = channel-block index = block*ch + channel
-  for (long cb = (long)blockIdx.x * nw + (threadIdx.x >> 6); cb < ncb; cb += (long)gridDim.x * nw) {
+  const long cstride = (long)gridDim.x * nw;
+  long cb = (long)blockIdx.x * nw + (threadIdx.x >> 6);
+  PcmTile tile;
+  if (cb < ncb) pcm_fetch(tile, pcm + cb * n, n);
+  for (; cb < ncb; cb += cstride) {
     const long blk = cb / ch;
-    const float amp = transform_block(P, W, d_lW(d, blk), d_nW(d, blk), pcm + cb * n, L.A, L.B, mdct_raw + cb * n2,
-                                      logmdct + cb * n2, logfft + cb * n2, pc);
+    transform_window(P, W, d_lW(d, blk), d_nW(d, blk), tile, L.A, pc);
+    if (cb + cstride < ncb) pcm_fetch(tile, pcm + (cb + cstride) * n, n);  // next block, one ahead
+    const float amp = transform_block(P, L.A, L.B, mdct_raw + cb * n2, logmdct + cb * n2, logfft + cb * n2, pc);
     if (LANE == 0) local_ampmax[cb] = amp;
   }
   pc.flush();

@@ -62,9 +62,14 @@
 #if VAMD_GPU
 #define VAMD_QPL 4
 #define LANE_QUADS(kq, q, nq) _Pragma("unroll") for (int kq = 0, q = LANE; kq < VAMD_QPL; kq++, q += NLANES) if (q < (nq))
+// the same for a whole n-sample block (2048 samples -> 8 quads per lane)
+#define VAMD_QPL2 8
+#define LANE_QUADS2(kq, q, nq) _Pragma("unroll") for (int kq = 0, q = LANE; kq < VAMD_QPL2; kq++, q += NLANES) if (q < (nq))
 #else
 #define VAMD_QPL 1024
 #define LANE_QUADS(kq, q, nq) for (int kq = 0, q = LANE; kq < VAMD_QPL && q < (nq); kq++, q += NLANES)
+#define VAMD_QPL2 2048
+#define LANE_QUADS2(kq, q, nq) for (int kq = 0, q = LANE; kq < VAMD_QPL2 && q < (nq); kq++, q += NLANES)
 #endif
 
 // lanes stride over [0, count).  On the GPU the loop is unrolled x4 so that the
