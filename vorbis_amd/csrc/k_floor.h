@@ -381,17 +381,29 @@ VAMD_DEV int floor_fit_render_block(const FloorP &F, int n2, const float *mask, 
   }
 
   pc.mark(2);
-  // ---- posts out, lib/floor1.c:700-724
-  outp.set(0, post_Y(fitA, fitB, 0));
-  outp.set(1, post_Y(fitA, fitB, 1));
-  for (int i = 2; i < posts; i++) {
-    const int ln = loneighbor.get(i - 2), hn = hineighbor.get(i - 2);
-    const int predicted = render_point(postlist.get(ln), postlist.get(hn), outp.get(ln), outp.get(hn), postlist.get(i));
-    const int vx = post_Y(fitA, fitB, i);
-    if (vx >= 0 && predicted != vx)
-      outp.set(i, vx);
-    else
-      outp.set(i, predicted | 0x8000);
+  // ---- posts out, lib/floor1.c:700-724.  Post i is settled from its two fixed neighbours, so
+  // the list order of the reference can be replaced by dependency levels: one lane per post.
+  LaneInts lo2, hi2, level;
+  lo2.load_shifted(F.loneighbor, 2, posts);
+  hi2.load_shifted(F.hineighbor, 2, posts);
+  level.load(F.level, posts);
+  WAVE_FOR(i, posts) {
+    if (i < 2) {
+      const int a = fitA.at(i), b = fitB.at(i);
+      outp.put(i, a < 0 ? b : (b < 0 ? a : (a + b) >> 1));
+    }
+  }
+  for (int L = 1; L <= F.nlevels; L++) {
+    WAVE_FOR(i, posts) {
+      const int ln = lo2.at(i), hn = hi2.at(i);
+      const int x0 = postlist.gather(ln), x1 = postlist.gather(hn), y0 = outp.gather(ln), y1 = outp.gather(hn);
+      if (i >= 2 && level.at(i) == L) {
+        const int predicted = render_point(x0, x1, y0, y1, postlist.at(i));
+        const int a = fitA.at(i), b = fitB.at(i);
+        const int vx = a < 0 ? b : (b < 0 ? a : (a + b) >> 1);
+        outp.put(i, (vx >= 0 && predicted != vx) ? vx : (predicted | 0x8000));
+      }
+    }
   }
 #if VAMD_GPU
   if (posts_out && LANE < VAMD_POSTS_STRIDE) posts_out[LANE] = LANE < posts ? outp.mine() : 0;
@@ -403,8 +415,10 @@ VAMD_DEV int floor_fit_render_block(const FloorP &F, int n2, const float *mask, 
 
   // ---- floor1_encode, value half: quantise by mult, predict, settle the
   // "unused" flags (lib/floor1.c:766-831).  The Huffman writes stay on the host.
-  for (int i = 0; i < posts; i++) {
-    const int o = outp.get(i);
+  // A post keeps its flag iff it is itself trivial (flagged by the fit, or equal to its
+  // prediction) and no non-trivial post names it as a neighbour; values again by level.
+  WAVE_FOR(i, posts) {
+    const int o = outp.at(i);
     int val = o & 0x7fff;
     switch (F.mult) {
       case 1: val >>= 2; break;
@@ -412,22 +426,48 @@ VAMD_DEV int floor_fit_render_block(const FloorP &F, int n2, const float *mask, 
       case 3: val /= 12; break;
       case 4: val >>= 4; break;
     }
-    post.set(i, val | (o & 0x8000));
+    post.put(i, val | (o & 0x8000));
   }
-  for (int i = 2; i < posts; i++) {
-    const int ln = loneighbor.get(i - 2), hn = hineighbor.get(i - 2);
-    const int pi = post.get(i);
-    const int predicted = render_point(postlist.get(ln), postlist.get(hn), post.get(ln), post.get(hn), postlist.get(i));
-    if ((pi & 0x8000) || (predicted == pi)) {
-      post.set(i, predicted | 0x8000);
-    } else {
-      post.set(ln, post.get(ln) & 0x7fff);
-      post.set(hn, post.get(hn) & 0x7fff);
+  unsigned long long needed = 3ull;  // posts 0 and 1 are always used
+  for (int L = 1; L <= F.nlevels; L++) {
+    WAVE_FOR(i, posts) {
+      const int ln = lo2.at(i), hn = hi2.at(i);
+      const int x0 = postlist.gather(ln), x1 = postlist.gather(hn), y0 = post.gather(ln), y1 = post.gather(hn);
+      if (i >= 2 && level.at(i) == L) {
+        const int pi = post.at(i);
+        const int predicted = render_point(x0, x1, y0, y1, postlist.at(i));
+        if ((pi & 0x8000) || predicted == pi) {
+          post.put(i, predicted | 0x8000);
+        } else {
+          needed |= (1ull << i) | (1ull << ln) | (1ull << hn);
+        }
+      }
     }
+  }
+  needed = wave_or64(needed);
+  WAVE_FOR(i, posts) {
+    if ((needed >> i) & 1) post.put(i, post.at(i) & 0x7fff);
   }
 
   // ---- render the integer curve, lib/floor1.c:923-946: segment list of the
   // used posts in x order, then every bin evaluates its segment's line.
+#if VAMD_GPU
+  {
+    // lane j looks at the j-th post in x order; used posts are compacted by rank
+    const int j = LANE;
+    const int cur = forward_index.at(j);
+    const int src = j < posts ? cur : 0;
+    const int pv = post.gather(src), px = postlist.gather(src);  // (gathers need every lane active)
+    const bool used = j < posts && (j == 0 || (pv & 0x8000) == 0);
+    const unsigned long long um = __ballot(used);
+    if (used) {
+      const int r = __builtin_popcountll(um & ((1ull << j) - 1ull));
+      sc->segx[r] = j == 0 ? 0 : px;
+      sc->segy[r] = (pv & 0x7fff) * F.mult;
+    }
+    if (LANE == 0) sc->nseg = __builtin_popcountll(um) - 1;
+  }
+#else
   {
     int ns = 0;
     sc->segx[0] = 0;
@@ -444,6 +484,7 @@ VAMD_DEV int floor_fit_render_block(const FloorP &F, int n2, const float *mask, 
     }
     sc->nseg = ns;
   }
+#endif
   WAVE_SYNC();
   pc.mark(3);
   if (ilogmask) {

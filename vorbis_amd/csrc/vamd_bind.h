@@ -157,6 +157,14 @@ inline int build_image(const void *blob_v, size_t bytes, std::vector<unsigned ch
     derived_off->push_back((uint32_t)image->size());
     image->insert(image->end(), bi.begin(), bi.end());
   }
+  for (int W = 0; W < 2; W++) {  // slots 26, 27: post levels
+    int nl = 0;
+    std::vector<int32_t> lv = derive_post_levels(h.mode[W].floor, &nl);
+    while (image->size() & 15) image->push_back(0);
+    derived_off->push_back((uint32_t)image->size());
+    const unsigned char *a = (const unsigned char *)lv.data();
+    image->insert(image->end(), a, a + 4 * lv.size());
+  }
   while (image->size() & 15) image->push_back(0);
   return VAMD_OK;
 }
@@ -207,6 +215,12 @@ inline void bind_params(const std::vector<unsigned char> &image, const std::vect
     F.hineighbor = (const int *)(base + fo + offsetof(vamd_floor1_tab, hineighbor));
     F.loneighbor = (const int *)(base + fo + offsetof(vamd_floor1_tab, loneighbor));
     F.bin_interval = base + derived_off[24 + W];  // slots 24, 25
+    F.level = (const int *)(base + derived_off[26 + W]);
+    {
+      int nl = 0;
+      derive_post_levels(f, &nl);
+      F.nlevels = nl;
+    }
 
     CoupleP &C = B->couple[W];
     const int blob_k = VAMD_PACKETBLOBS / 2;

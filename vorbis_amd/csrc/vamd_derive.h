@@ -145,6 +145,21 @@ inline std::vector<unsigned char> derive_bin_interval(const vamd_floor1_tab &f, 
   return t;
 }
 
+// floor1_fit / floor1_encode settle the posts in list order, each from its two neighbours
+// (lib/floor1.c:708-724,790-831).  The neighbours are fixed by the look, so posts can be
+// settled level by level: level[i] = 1 + max(level[lo], level[hi]), posts 0 and 1 at level 0.
+inline std::vector<int32_t> derive_post_levels(const vamd_floor1_tab &f, int *nlevels) {
+  std::vector<int32_t> lv(64, 0);
+  int mx = 0;
+  for (int i = 2; i < f.posts; i++) {
+    const int a = lv[f.loneighbor[i - 2]], b = lv[f.hineighbor[i - 2]];
+    lv[i] = 1 + (a > b ? a : b);
+    if (lv[i] > mx) mx = lv[i];
+  }
+  *nlevels = mx;
+  return lv;
+}
+
 // stereo_threshholds / _limited, lib/psy.c:32-33
 inline float stereo_threshold(int idx, bool limited) {
   static const double a[] = {0.0, .5, 1.0, 1.5, 2.5, 4.5, 8.5, 16.5, 9e10};

@@ -59,6 +59,8 @@ struct FloorP {
   float maxover, maxunder, maxerr, twofitweight, twofitatten;
   const int *postlist, *sorted_index, *forward_index, *reverse_index, *hineighbor, *loneighbor;
   const unsigned char *bin_interval;  // [n2] derived: accumulate_fit interval of each bin (255 = none)
+  const int *level;                   // [64] derived: dependency level of each post
+  int nlevels;
 };
 
 struct CoupleP {

@@ -94,6 +94,15 @@ VAMD_DEV int wave_sum(int v) {
   return v;
 }
 VAMD_DEV int wave_any(int pred) { return __any(pred); }
+VAMD_DEV unsigned long long wave_or64(unsigned long long v) {
+  unsigned int lo = (unsigned int)v, hi = (unsigned int)(v >> 32);
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    lo |= (unsigned int)__shfl_xor((int)lo, m, 64);
+    hi |= (unsigned int)__shfl_xor((int)hi, m, 64);
+  }
+  return ((unsigned long long)hi << 32) | lo;
+}
 // inclusive prefix max over the lanes of the wave
 VAMD_DEV int wave_scan_max(int v) {
 #pragma unroll
@@ -130,6 +139,7 @@ VAMD_DEV void lds_atomic_or(int *p, int v) { atomicOr(p, v); }
 VAMD_DEV float wave_max(float v) { return v; }
 VAMD_DEV int wave_sum(int v) { return v; }
 VAMD_DEV int wave_any(int pred) { return pred != 0; }
+VAMD_DEV unsigned long long wave_or64(unsigned long long v) { return v; }
 VAMD_DEV int wave_scan_max(int v) { return v; }
 VAMD_DEV int wave_shift_up1(int v, int fill) { (void)v; return fill; }
 VAMD_DEV int wave_last(int v) { return v; }
@@ -204,6 +214,14 @@ struct LaneInts {
   VAMD_MEM void fill(int x) { v = x; }
   VAMD_MEM void load(const int *__restrict__ p, int count) { v = LANE < count ? p[LANE] : 0; }
   VAMD_MEM int mine() const { return v; }
+  // lane-per-entry access: at/put touch the calling lane's own entry i (== LANE), gather
+  // reads any entry with a per-lane index (ds_bpermute)
+  VAMD_MEM int at(int) const { return v; }
+  VAMD_MEM void put(int, int x) { v = x; }
+  VAMD_MEM int gather(int idx) const { return __shfl(v, idx, 64); }
+  VAMD_MEM void load_shifted(const int *__restrict__ p, int shift, int count) {
+    v = (LANE >= shift && LANE < count) ? p[LANE - shift] : 0;
+  }
   // entries j = from-1, from-2, ... while == oldv become newv (the reference's "for(j=..;j>=0;j--)
   // if(a[j]==old)a[j]=new; else break;")
   VAMD_MEM void replace_run_down(int from, int oldv, int newv) {
@@ -227,6 +245,12 @@ struct LaneInts {
   VAMD_MEM void set(int i, int x) { a[i] = x; }
   VAMD_MEM void fill(int x) { for (int i = 0; i < 64; i++) a[i] = x; }
   VAMD_MEM void load(const int *p, int count) { for (int i = 0; i < 64; i++) a[i] = i < count ? p[i] : 0; }
+  VAMD_MEM int at(int i) const { return a[i]; }
+  VAMD_MEM void put(int i, int x) { a[i] = x; }
+  VAMD_MEM int gather(int idx) const { return a[idx]; }
+  VAMD_MEM void load_shifted(const int *p, int shift, int count) {
+    for (int i = 0; i < 64; i++) a[i] = (i >= shift && i < count) ? p[i - shift] : 0;
+  }
   VAMD_MEM void replace_run_down(int from, int oldv, int newv) {
     for (int j = from - 1; j >= 0; j--) {
       if (a[j] != oldv) break;
