@@ -88,7 +88,10 @@ VAMD_DEV ChanBin chan_bin(int nzk, float m, int ilog, int b, int nstart, const C
   if (nzk) {
     const float f = floor1_fromdB(ilog);
     const float point = b >= C.pointlimit ? C.postpoint : C.prepoint;
-    const float rr = (float)(fabs((double)m) / (double)f);  // flag_lossless, lib/psy.c:928-933
+    // flag_lossless, lib/psy.c:928-933: `float r = fabs(mdct)/floor` divides in fp64 and rounds to
+    // fp32; for fp32 operands that double rounding is innocuous (53 >= 2*24+2), i.e. it IS the
+    // correctly rounded fp32 quotient
+    const float rr = fabsf(m) / f;
     r.fg = rr < point ? 0 : 1;
     r.re = m * m;
     r.qe = r.re;

@@ -246,12 +246,29 @@ VAMD_DEV int floor_fit_render_block(const FloorP &F, int n2, const float *mask, 
     int jprev = -1;
     FitAcc t;
     t.xa = t.ya = t.x2a = t.y2a = t.xya = t.an = t.xb = t.yb = t.x2b = t.y2b = t.xyb = t.bn = 0;
-    for (int qd = span << 2; qd < (span << 2) + 4 && (qd << 2) < n; qd++) {
+    // the 16 bins' interval bytes arrive in one 16-byte load, the mask / logmdct values in
+    // four 16-byte LDS reads each
+    const I4 jw = ((const I4 *)F.bin_interval)[span];
+    const unsigned int jq4[4] = {(unsigned)jw.x, (unsigned)jw.y, (unsigned)jw.z, (unsigned)jw.w};
+    float mk4[4][4], lm4[4][4];
+#if VAMD_GPU
+#pragma unroll
+#endif
+    for (int u = 0; u < 4; u++) {
+      const int qd = (span << 2) + u;
+      if ((qd << 2) < n) {
+        f4_get(((const F4 *)mask)[qd], mk4[u]);
+        f4_get(((const F4 *)lmd)[qd], lm4[u]);
+      }
+    }
+#if VAMD_GPU
+#pragma unroll
+#endif
+    for (int u = 0; u < 4; u++) {
+      const int qd = (span << 2) + u;
+      if ((qd << 2) >= n) break;
       const int i0 = qd << 2;
-      float mk[4], lm[4];
-      f4_get(((const F4 *)mask)[qd], mk);
-      f4_get(((const F4 *)lmd)[qd], lm);
-      const unsigned int jq = ((const unsigned int *)F.bin_interval)[qd];  // 4 bins' interval bytes
+      const unsigned int jq = jq4[u];
 #if VAMD_GPU
 #pragma unroll
 #endif
@@ -260,7 +277,7 @@ VAMD_DEV int floor_fit_render_block(const FloorP &F, int n2, const float *mask, 
         const int jb = (int)((jq >> (8 * c)) & 0xff);
         const int j = (i < n && jb != 255) ? (jb & 0x7f) : 255;
         const bool shared = jb != 255 && (jb & 0x80);
-        const int q = j != 255 ? dBquant(mk[c]) : 0;
+        const int q = j != 255 ? dBquant(mk4[u][c]) : 0;
         if (j != jprev) {
           if (jprev >= 0) accumulate_flush(&sc->acc[jprev], t);
           jprev = j == 255 ? -1 : j;
@@ -268,7 +285,7 @@ VAMD_DEV int floor_fit_render_block(const FloorP &F, int n2, const float *mask, 
         if (q) {
           FitAcc b;
           b.xa = b.ya = b.x2a = b.y2a = b.xya = b.an = b.xb = b.yb = b.x2b = b.y2b = b.xyb = b.bn = 0;
-          const bool cls_a = lm[c] + F.twofitatten >= mk[c];
+          const bool cls_a = lm4[u][c] + F.twofitatten >= mk4[u][c];
           if (cls_a) {
             b.xa = i; b.ya = q; b.x2a = i * i; b.y2a = q * q; b.xya = i * q; b.an = 1;
           } else {

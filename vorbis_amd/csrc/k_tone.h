@@ -33,29 +33,31 @@ namespace vamd {
 // seed_curve, lib/psy.c:390-415.  The reference walks i = posts[0] .. post1-1 with
 // seedptr advancing by linesper and stops once seedptr >= n; point i therefore
 // lands on line oc + (i-16)*linesper - linesper/2 and is applied iff that line is
-// in (0, n).  The chosen curve row (58 floats in a 64-float, 256-byte-aligned row) is
-// fetched with sixteen 16-byte loads issued together, then the 56 points are
-// applied from registers.
-VAMD_DEV void seed_curve_scatter(float *seed, const float *__restrict__ curves64 /*[8][64] of one band*/, float amp,
-                                 int oc, int nlines, int linesper, float dBoffset) {
+// in (0, n).  Written branch-free: the curve rows (re-strided to 64 floats, 256-byte
+// aligned, vamd_derive.h) hold -inf outside [posts[0], posts[1]) so "amp + c" cannot
+// win there, and seed[] carries seed_pad_lo() floats in front and seed_pad_hi() behind so
+// that out-of-range lines land in padding nobody reads (line 0, which the reference
+// also skips, is reset by the caller).  Per point that leaves add, add, ds_max_f32.
+VAMD_HOSTDEV int seed_pad_lo(int linesper) { return (VAMD_EHMER_OFFSET * linesper + (linesper >> 1) + 3) & ~3; }
+VAMD_HOSTDEV int seed_pad_hi(int linesper) { return ((VAMD_EHMER_MAX - VAMD_EHMER_OFFSET) * linesper + 3) & ~3; }
+VAMD_DEV void seed_curve_scatter(float *seed, const float *__restrict__ band_rows /*[8] rows of one band*/,
+                                 int stride, float amp, int oc, int linesper, float dBoffset) {
   int choice = (int)(((double)(amp + dBoffset) - 30.) * (double).1f);
   choice = choice < 0 ? 0 : choice;
   choice = choice > VAMD_P_LEVELS - 1 ? VAMD_P_LEVELS - 1 : choice;
-  const F4 *__restrict__ row = (const F4 *)(curves64 + choice * 64);
-  float c[64];
+  const F4 *__restrict__ row = (const F4 *)(band_rows + choice * stride);
+  float c[VAMD_EHMER_MAX];
 #if VAMD_GPU
 #pragma unroll
 #endif
-  for (int k = 0; k < 15; k++) f4_get(row[k], c + 4 * k);  // floats 0..59 cover the 58 used
-  const int i0 = (int)c[0], i1 = (int)c[1];
-  const int base = oc - VAMD_EHMER_OFFSET * linesper - (linesper >> 1);
+  for (int k = 0; k < VAMD_EHMER_MAX / 4; k++) f4_get(row[k], c + 4 * k);
+  float *p = seed + (oc - VAMD_EHMER_OFFSET * linesper - (linesper >> 1));
+  // straight-line on purpose: skipping the points no lane of the wave reaches (a curve
+  // spans ~20 of the 56) was measured slower -- the branches cost more than the atomics
 #if VAMD_GPU
 #pragma unroll
 #endif
-  for (int i = 0; i < VAMD_EHMER_MAX; i++) {
-    const int seedptr = base + i * linesper;
-    if (i >= i0 && i < i1 && seedptr > 0 && seedptr < nlines) lds_atomic_max(seed + seedptr, amp + c[2 + i]);
-  }
+  for (int i = 0; i < VAMD_EHMER_MAX; i++) lds_atomic_max(p + i * linesper, amp + c[i]);
 }
 
 // seed_chase part 2, lib/psy.c:489-503: entry k paints [start_k, end_k) where
@@ -152,7 +154,7 @@ VAMD_DEV void tone_seed_block(const PsyP &P, const float *__restrict__ logfft, f
   const int n = P.n, nlines = P.total_octave_lines;
   float att = local_ampmax + P.ath_adjatt;
   if (att < P.ath_maxatt) att = P.ath_maxatt;
-  WAVE_FOR(i, nlines) seed[i] = VAMD_NEGINF;
+  WAVE_FOR(i, nlines) seed[i] = VAMD_NEGINF;  // (the padding either side is write-only)
   WAVE_FOR(q, n >> 2)((F4 *)fft)[q] = ((const F4 *)logfft)[q];
   WAVE_SYNC();
   pc.mark(0);
@@ -164,9 +166,11 @@ VAMD_DEV void tone_seed_block(const PsyP &P, const float *__restrict__ logfft, f
     for (int i = s + 1; i < e; i++)
       if (fft[i] > mx) mx = fft[i];
     if (mx + 6.f > f_from_bits((uint32_t)rec.w) + att)
-      seed_curve_scatter(seed, P.curves64 + rec.z * (VAMD_P_LEVELS * 64), mx, rec.y, nlines, P.eighth_octave_lines,
-                         dBoffset);
+      seed_curve_scatter(seed, P.curves64 + rec.z * (VAMD_P_LEVELS * P.curve_stride), P.curve_stride, mx, rec.y,
+                         P.eighth_octave_lines, dBoffset);
   }
+  WAVE_SYNC();
+  if (LANE == 0) seed[0] = VAMD_NEGINF;  // seedptr > 0, lib/psy.c:406
   WAVE_SYNC();
   pc.mark(1);
 }
@@ -236,7 +240,7 @@ VAMD_DEV void tone_fold_block(const PsyP &P, float local_ampmax, float *seed, co
 
 // _vp_tonemask(p, logfft, logmask, global_specmax, local_specmax), one block end to
 // end (the test build; the GPU runs the three pieces as separate launches)
-//   seed LDS [nlines padded to 16], fft LDS [n], posstack/ampstack LDS [nlines],
+//   seed LDS [seed_pad_lo | nlines padded to 16 | seed_pad_hi] (pointer at line 0), fft LDS [n], posstack/ampstack LDS [nlines],
 //   ring_amp/ring_pos [VAMD_RING], surv [nlines]
 VAMD_DEV void tonemask_block(const PsyP &P, const float *__restrict__ logfft, float *__restrict__ out,
                              float global_ampmax, float local_ampmax, float *seed, int *posstack, float *ampstack,

@@ -267,6 +267,7 @@ inline void bind_params(const std::vector<unsigned char> &image, const std::vect
     P.seed_span = (const int *)(base + derived_off[2 * p + 1]);
     P.runs = (const int *)(base + derived_off[8 + 2 * p]);
     P.curves64 = (const float *)(base + derived_off[8 + 2 * p + 1]);
+    P.curve_stride = 64;
     P.bin_fold = (const int *)(base + derived_off[16 + 2 * p]);
     P.line_group = (const unsigned short *)(base + derived_off[16 + 2 * p + 1]);
     P.ngroups = d.ngroups;

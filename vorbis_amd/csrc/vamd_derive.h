@@ -5,6 +5,7 @@
 // blob.  Pure integer walks; each cites the loop it freezes.
 #pragma once
 #include <stdint.h>
+#include <string.h>
 #include <vector>
 #include "vamd_setup.h"
 
@@ -24,7 +25,7 @@ struct PsyDerived {
   int fix_i1, fix_i2;    // lib/psy.c:660-703
   std::vector<int32_t> run_start;  // nruns+1 entries, lib/psy.c:429-435
   std::vector<RunRec> runs;        // nruns
-  std::vector<float> curves64;     // tonecurves re-strided [17][8][64] (rows 256-byte aligned)
+  std::vector<float> curves64;     // tone curve points re-strided [17][8][64] (rows 256-byte aligned)
   std::vector<int32_t> seed_span;  // [n][2], lib/psy.c:522-537
   int tail_linpos;                 // lib/psy.c:539-543
   // the same walk, organised for a line-parallel fold: every iteration of max_seeds' outer
@@ -97,9 +98,18 @@ inline PsyDerived derive_psy(const vamd_psy_tab &t, const unsigned char *blob) {
       d.runs.push_back(rr);
     }
     const float *tc = (const float *)(blob + t.off_tonecurves);
-    d.curves64.assign((size_t)VAMD_P_BANDS * VAMD_P_LEVELS * 64, 0.f);
-    for (int bc = 0; bc < VAMD_P_BANDS * VAMD_P_LEVELS; bc++)
-      for (int k = 0; k < VAMD_EHMER_MAX + 2; k++) d.curves64[(size_t)bc * 64 + k] = tc[bc * (VAMD_EHMER_MAX + 2) + k];
+    // row = the 56 curve points, -inf outside the fence posts [tc[0], tc[1]) that seed_curve
+    // (lib/psy.c:396-398) limits the walk to, so the scatter needs no range test
+    uint32_t ninf_bits = 0xff800000u;
+    float ninf;
+    memcpy(&ninf, &ninf_bits, 4);
+    d.curves64.assign((size_t)VAMD_P_BANDS * VAMD_P_LEVELS * 64, ninf);
+    for (int bc = 0; bc < VAMD_P_BANDS * VAMD_P_LEVELS; bc++) {
+      const float *row = tc + (size_t)bc * (VAMD_EHMER_MAX + 2);
+      const int i0 = (int)row[0], i1 = (int)row[1];
+      for (int k = 0; k < VAMD_EHMER_MAX; k++)
+        if (k >= i0 && k < i1) d.curves64[(size_t)bc * 64 + k] = row[2 + k];
+    }
   }
 
   // max_seeds: replay the (pos, linpos) walk; record per bin the seed-line span
@@ -136,7 +146,7 @@ inline PsyDerived derive_psy(const vamd_psy_tab &t, const unsigned char *blob) {
 // (the last such j); a bin sitting exactly on an interior post also belongs to j-1,
 // which is flagged by bit 7.  255 = the bin belongs to no interval.
 inline std::vector<unsigned char> derive_bin_interval(const vamd_floor1_tab &f, int n2) {
-  std::vector<unsigned char> t((size_t)((n2 + 3) & ~3), 255);
+  std::vector<unsigned char> t((size_t)((n2 + 15) & ~15), 255);
   for (int j = 0; j + 1 < f.posts; j++) {
     int x0 = f.sorted_index[j], x1 = f.sorted_index[j + 1];
     if (x1 >= f.look_n) x1 = f.look_n - 1;

@@ -44,7 +44,8 @@ struct PsyP {
   const int *run_start;      // [nruns+1] starts of runs of equal octave[] (lib/psy.c:429-435)
   int nruns;
   const int *runs;           // [nruns][4] RunRec (vamd_derive.h)
-  const float *curves64;     // [17][8][64] tonecurves with 64-float rows
+  const float *curves64;     // [17][8] tone-curve rows of 56 points, `curve_stride` floats apart
+  int curve_stride;          // 64 in HBM (256-byte rows); 60 for an LDS copy (rows staggered over the banks)
   const int *seed_span;      // [n][2] octave-line span (pos0,pos1) each bin folds in max_seeds (lib/psy.c:524-537)
   const int *bin_fold;       // [n] p0 | group << 16
   const unsigned short *line_group;  // [nl16] group of each octave line, 0xffff = none

@@ -27,6 +27,7 @@
 #if VAMD_GPU
 #include <hip/hip_runtime.h>
 #define VAMD_DEV __device__ __forceinline__
+#define VAMD_HOSTDEV __host__ __device__ __forceinline__
 #define VAMD_MEM __device__ __forceinline__
 #define VAMD_DEV_NOINLINE __device__ __noinline__
 #define LANE ((int)(threadIdx.x & 63))  // a workgroup may hold several independent waves
@@ -47,6 +48,7 @@
 #else
 #include <math.h>
 #define VAMD_DEV static inline
+#define VAMD_HOSTDEV static inline
 #define VAMD_MEM inline
 #define VAMD_DEV_NOINLINE static
 #define LANE 0
@@ -120,18 +122,13 @@ VAMD_DEV int wave_last(int v) { return __shfl(v, 63, 64); }
 VAMD_DEV int wave_first(int v) { return __builtin_amdgcn_readfirstlane(v); }
 VAMD_DEV float f_from_bits(uint32_t u) { return __uint_as_float(u); }
 VAMD_DEV uint32_t f_bits(float f) { return __float_as_uint(f); }
-// order-free float max into LDS (seed scatter): classic sign-split integer trick
+// order-free float max / min into LDS (seed scatter, fold minima): ds_max_f32 / ds_min_f32.
+// No NaNs reach these (dB values), so the result is the plain maximum whatever the order.
 VAMD_DEV void lds_atomic_max(float *p, float v) {
-  if (v >= 0.f)
-    atomicMax((int *)p, __float_as_int(v));
-  else
-    atomicMin((unsigned int *)p, __float_as_uint(v));
+  (void)__hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 VAMD_DEV void lds_atomic_min(float *p, float v) {
-  if (v >= 0.f)
-    atomicMin((int *)p, __float_as_int(v));
-  else
-    atomicMax((unsigned int *)p, __float_as_uint(v));
+  (void)__hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 VAMD_DEV void lds_atomic_add(int *p, int v) { atomicAdd(p, v); }
 VAMD_DEV void lds_atomic_or(int *p, int v) { atomicOr(p, v); }
