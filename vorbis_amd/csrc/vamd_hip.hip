@@ -137,6 +137,7 @@ __global__ __launch_bounds__(64 * VAMD_XF_WAVES) void k_transform(XformP G, int 
 // channel-block per round, and one wave runs the ordered running sums of the whole round
 // (ScanGroup, k_noise.h).
 #define VAMD_NZ_WAVES 7
+#define VAMD_NZ_WAVES_SHARED 6
 __global__ __launch_bounds__(64 * VAMD_NZ_WAVES) void k_noise(PsyP P0, PsyP P1, DescP d, int ch, long ncb,
                                                              const float *__restrict__ logmdct,
                                                              float *__restrict__ noise) {
@@ -237,50 +238,6 @@ __global__ __launch_bounds__(64) void k_tone_seed(PsyP P0, PsyP P1, DescP d, int
   pc.start(d.dbg ? d.dbg + 32 : nullptr);
   tone_seed_block(P, logfft + cb * n2, ampmax_glob[blk], local_ampmax[cb], seed, fft, pc);
   WAVE_FOR(i, nlp) seed_g[cb * nlp + i] = i < nl ? seed[i] : VAMD_NEGINF;
-  pc.flush();
-}
-
-// The same stage for batches whose blocks all use ONE psy look (uniform blocktype -- the
-// throughput case): persistent workgroup, the look's tone-curve rows (34.8 KB) and run
-// records staged in LDS once, so the sixteen 16-byte curve fetches of every run are LDS
-// reads instead of L2 round trips.
-#define VAMD_TS_WAVES 16
-#define VAMD_TS_ROW 60
-__global__ __launch_bounds__(64 * VAMD_TS_WAVES) void k_tone_seed_lds(PsyP G, int ch, int nlp, long ncb,
-                                                                     const float *__restrict__ logfft,
-                                                                     const float *__restrict__ local_ampmax,
-                                                                     const float *__restrict__ ampmax_glob,
-                                                                     float *__restrict__ seed_g, unsigned long long *dbg) {
-  const int n2 = G.n, nl = G.total_octave_lines, nw = blockDim.x >> 6, wave = threadIdx.x >> 6;
-  float *curves = (float *)vamd_smem;  // [17*8] rows of 56 points, 60 floats apart: 8 bank phases
-  int *runs = (int *)(curves + VAMD_P_BANDS * VAMD_P_LEVELS * VAMD_TS_ROW);  // [nruns][4]
-  float *work = (float *)(runs + 4 * G.nruns);
-  for (int i = threadIdx.x; i < VAMD_P_BANDS * VAMD_P_LEVELS * (VAMD_EHMER_MAX / 4); i += blockDim.x) {
-    const int row = i / (VAMD_EHMER_MAX / 4), q = i - row * (VAMD_EHMER_MAX / 4);
-    ((F4 *)(curves + row * VAMD_TS_ROW))[q] = ((const F4 *)(G.curves64 + row * G.curve_stride))[q];
-  }
-  for (int i = threadIdx.x; i < G.nruns; i += blockDim.x) ((I4 *)runs)[i] = ((const I4 *)G.runs)[i];
-  __syncthreads();
-  PsyP P = G;
-  P.curves64 = curves;
-  P.curve_stride = VAMD_TS_ROW;
-  P.runs = runs;
-  const int lp = G.eighth_octave_lines, per_wave = n2 + seed_pad_lo(lp) + nlp + seed_pad_hi(lp);
-  float *fft = work + (size_t)wave * per_wave;
-  float *seed = fft + n2 + seed_pad_lo(lp);
-  PhaseClock pc;
-  pc.start(dbg ? dbg + 32 : nullptr);
-  for (long cb = (long)blockIdx.x * nw + wave; cb < ncb; cb += (long)gridDim.x * nw) {
-    tone_seed_block(P, logfft + cb * n2, ampmax_glob[cb / ch], local_ampmax[cb], seed, fft, pc);
-    WAVE_FOR(q, nlp >> 2) {
-      float v[4];
-      f4_get(((const F4 *)seed)[q], v);
-      for (int c = 0; c < 4; c++)
-        if ((q << 2) + c >= nl) v[c] = VAMD_NEGINF;
-      ((F4 *)(seed_g + cb * nlp))[q] = f4_make(v);
-    }
-    WAVE_SYNC();
-  }
   pc.flush();
 }
 
@@ -388,6 +345,11 @@ struct vamd_ctx {
   int num_cus = 256;
   size_t lds_per_block = 160 * 1024;
   hipStream_t stream = nullptr;
+  // noise masking and tone masking read different inputs and write different outputs; the tone
+  // kernels run on this library-owned side stream, forked from / joined back into `stream`
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool overlap = true;
   Bound B;                 // parameter structs bound to the HBM image
   unsigned char *d_image = nullptr;
   size_t image_bytes = 0;
@@ -487,18 +449,23 @@ int vamd_create(vamd_ctx **out, const void *setup_blob, size_t blob_bytes, int d
                                 (int)c->lds_per_block);
       (void)hipFuncSetAttribute((const void *)k_noise, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)c->lds_per_block);
-      (void)hipFuncSetAttribute((const void *)k_tone_seed_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)c->lds_per_block);
       (void)hipGetLastError();
       if (getenv("VAMD_VERBOSE"))
         fprintf(stderr, "vamd_create: %d CUs, %zu B LDS per workgroup\n", c->num_cus, c->lds_per_block);
     }
   }
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+  c->overlap = getenv("VAMD_NO_OVERLAP") == nullptr;
   if (e == hipSuccess) e = hipMalloc((void **)&c->d_image, image.size());
   if (e == hipSuccess) e = hipMemcpy(c->d_image, image.data(), image.size(), hipMemcpyHostToDevice);
   if (e != hipSuccess) {
     fprintf(stderr, "vamd_create: HIP failure: %s\n", hipGetErrorString(e));
     if (c->d_image) (void)hipFree(c->d_image);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->side) (void)hipStreamDestroy(c->side);
     delete c;
     return VAMD_EFAULT;
   }
@@ -516,6 +483,9 @@ void vamd_destroy(vamd_ctx *c) {
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->d_dbg) (void)hipFree(c->d_dbg);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->side) (void)hipStreamDestroy(c->side);
   if (c->d_image) (void)hipFree(c->d_image);
   delete c;
 }
@@ -718,9 +688,15 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level) {
   const int n2 = c->B.xf[W].n / 2, nl = P0.total_octave_lines;
   const unsigned gcb = (unsigned)(R->nb * ch), gb = (unsigned)R->nb;
   hipStream_t s = c->stream;
+  const bool overlap = c->overlap;
   if (level >= VAMD_LEVEL_PSY) {
+    if (overlap) {  // fork: the tone chain needs only what is already queued on `stream`
+      (void)hipEventRecord(c->ev_fork, c->stream);
+      (void)hipStreamWaitEvent(c->side, c->ev_fork, 0);
+    }
     {
-      int waves = VAMD_NZ_WAVES;
+      // alone, 7 blocks' running sums fill the LDS; beside the tone kernels 6 leave those room
+      int waves = overlap ? VAMD_NZ_WAVES_SHARED : VAMD_NZ_WAVES;
       while (waves > 1 && (size_t)waves * 5 * (n2 + 4) * 4 > c->lds_per_block) waves--;
       const long groups = ((long)gcb + waves - 1) / waves;
       const unsigned grid = (unsigned)(groups < c->num_cus ? groups : c->num_cus);
@@ -728,27 +704,21 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level) {
                          (long)gcb, p.logmdct, p.noise);
     }
     prof_mark(c), R->nst++;
+    if (overlap) s = c->side;
     {
       const int nlp = (nl + 15) & ~15;
       const size_t seed_lds = (size_t)(n2 + seed_pad_lo(P0.eighth_octave_lines) + nlp + seed_pad_hi(P0.eighth_octave_lines)) * 4;
-      if (!d.blocktype) {
-        // one psy look for the whole batch: persistent kernel with the look's tables in LDS
-        const PsyP &P = d.u_blocktype ? P1 : P0;
-        const size_t tables = (size_t)VAMD_P_BANDS * VAMD_P_LEVELS * VAMD_TS_ROW * 4 + (size_t)P.nruns * 16;
-        int waves = VAMD_TS_WAVES;
-        while (waves > 1 && tables + (size_t)waves * seed_lds > c->lds_per_block) waves--;
-        const long groups = ((long)gcb + waves - 1) / waves;
-        const unsigned grid = (unsigned)(groups < c->num_cus ? groups : c->num_cus);
-        hipLaunchKernelGGL(k_tone_seed_lds, dim3(grid), dim3(64 * waves), tables + (size_t)waves * seed_lds, s, P, ch,
-                           nlp, (long)gcb, p.logfft, p.local, p.ampglob, p.seed, d.dbg);
-      } else {
-        hipLaunchKernelGGL(k_tone_seed, dim3(gcb), dim3(64), seed_lds, s, P0, P1, d, ch, nlp, p.logfft,
-                           p.local, p.ampglob, p.seed);
-      }
+      hipLaunchKernelGGL(k_tone_seed, dim3(gcb), dim3(64), seed_lds, s, P0, P1, d, ch, nlp, p.logfft, p.local,
+                         p.ampglob, p.seed);
       hipLaunchKernelGGL(k_tone_chase, dim3((gcb + 63) / 64), dim3(64), (size_t)VAMD_RING * 64 * 8, s,
                          P0.eighth_octave_lines, nl, nlp, (long)gcb, d, p.seed, p.surv, p.nsurv);
       hipLaunchKernelGGL(k_tone_fold, dim3(gcb), dim3(64), (size_t)(nlp * 3 + n2) * 4, s, P0, P1, d, ch, nlp, p.seed, p.surv,
                          p.nsurv, p.local, p.tone);
+    }
+    if (overlap) {  // join
+      (void)hipEventRecord(c->ev_join, c->side);
+      s = c->stream;
+      (void)hipStreamWaitEvent(s, c->ev_join, 0);
     }
     prof_mark(c), R->nst++;
   }
