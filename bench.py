@@ -226,7 +226,10 @@ def main():
             "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, "
                               "separate passes; bytes per step of this workload)" if traffic else None,
             "definition": "algorithmic bytes of the whole path per step (%d B/unit x %d units) / summed "
-                          "HIP-event duration of the path's stage kernels per step" % (ALG_BYTES[a.workload], units),
+                          "HIP-event segments of the path's stages on the launch stream per step; the tone-masking "
+                          "kernels run on a side stream beside k_noise, so 'noisemask' is k_noise's launch "
+                          "duration with them co-resident and 'tonemask' is only their tail after k_noise ends"
+                          % (ALG_BYTES[a.workload], units),
             "kernels_ms_per_step": stage_ms,
             "dominant_kernel": {"name": dom, "ms": stage_ms[dom], "own_bytes_per_step": dom_bytes,
                                 "own_GBps": dom_bytes / (stage_ms[dom] * 1e-3) / 1e9, "traffic": dom_traffic},
