@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define VAMD_SETUP_MAGIC   0x31544553444d4156ULL /* "VAMDSET1" little-endian */
-#define VAMD_SETUP_VERSION 2u
+#define VAMD_SETUP_VERSION 3u
 
 #define VAMD_PACKETBLOBS   15  /* lib/codec_internal.h:28 */
 #define VAMD_P_BANDS       17  /* lib/psy.h:28 */
@@ -37,6 +37,12 @@ extern "C" {
 #define VAMD_NOISE_COMPAND_LEVELS 40 /* lib/psy.h:33 */
 #define VAMD_POSIT         65  /* VIF_POSIT+2, lib/backends.h:57 */
 #define VAMD_MAX_CH        2   /* channel counts the kernels cover this round */
+#define VAMD_VE_BANDS      7   /* lib/envelope.h:28 */
+#define VAMD_VE_NEARDC     15  /* lib/envelope.h:29 */
+#define VAMD_VE_AMP        17  /* VE_PRE+VE_POST-1, lib/envelope.h:26 */
+#define VAMD_VE_MINSTRETCH 2   /* lib/envelope.h:31 */
+#define VAMD_VE_MAXSTRETCH 12  /* lib/envelope.h:32 */
+#define VAMD_VE_BANDWIN    8   /* widest band window, lib/envelope.c:52-58 */
 
 /* one per block size W (0 = short, 1 = long): mdct_lookup (lib/mdct.h:55-63),
  * drft_lookup (lib/smallft.h:22-26) and the vwin table (lib/window.c) */
@@ -117,6 +123,27 @@ typedef struct vamd_mode_tab {
   vamd_floor1_tab floor;
 } vamd_mode_tab;
 
+/* the block-switching detector: envelope_lookup (lib/envelope.h:54-74, built by
+ * _ve_envelope_init lib/envelope.c:30-74) + the vorbis_info_psy_global fields _ve_amp reads
+ * (lib/psy.h:69-72) */
+typedef struct vamd_envelope_tab {
+  int32_t  winlength;                       /* 128 */
+  int32_t  searchstep;                      /* 64 */
+  int32_t  log2n;
+  float    mdct_scale;
+  float    minenergy;                       /* gi->preecho_minenergy */
+  float    stretch_penalty;
+  float    preecho_thresh[VAMD_VE_BANDS];
+  float    postecho_thresh[VAMD_VE_BANDS];
+  int32_t  band_begin[VAMD_VE_BANDS];
+  int32_t  band_end[VAMD_VE_BANDS];
+  float    band_total[VAMD_VE_BANDS];       /* 1/sum(window) */
+  float    band_window[VAMD_VE_BANDS][VAMD_VE_BANDWIN];
+  uint32_t off_mdct_trig;                   /* float[n + n/4] */
+  uint32_t off_mdct_bitrev;                 /* int32[n/4] */
+  uint32_t off_window;                      /* float[n]  mdct_win = sin^2 */
+} vamd_envelope_tab;
+
 typedef struct vamd_setup_header {
   uint64_t magic;
   uint32_t version;
@@ -130,6 +157,7 @@ typedef struct vamd_setup_header {
   vamd_psy_tab        psy[4];
   vamd_psy_global_tab psy_g;
   vamd_mode_tab       mode[2];
+  vamd_envelope_tab   env;
 } vamd_setup_header;
 
 #ifdef __cplusplus

@@ -163,6 +163,41 @@ int vamd_analyze_block(vamd_ctx *ctx, const float *const *pcm, int lW, int W, in
                        int32_t *posts /*[ch][VAMD_POSTS_STRIDE]*/, int32_t *post_valid /*[ch]*/,
                        int32_t *iwork /*[ch][n/2]*/, int32_t *nonzero /*[ch]*/, float *ampmax_out);
 
+/* ---- the block-switching detector --------------------------------
+ * Replaces the step loop of _ve_envelope_search() (lib/envelope.c:217-262) with its _ve_amp()
+ * calls (:89-215): one detector step per `searchstep` (64) samples, each reading `winlength`
+ * (128) samples of every channel.  Per step the reference ORs three flags: 1|4 = pre-echo
+ * trigger, 2 = post-echo trigger; the caller applies them to ve->mark[] exactly as
+ * lib/envelope.c:241-258 does (INTEGRATION.md shows the binding) -- cursor/testW logic, which
+ * decides block sizes from the marks, stays host code.
+ *
+ * vamd_envelope_state carries what the reference keeps in envelope_filter_state + ve->stretch
+ * (lib/envelope.h:34-45,66), as plain histories: all-zero == a fresh stream (the reference
+ * calloc's its state).  A stream may be fed in calls of any length. */
+#define VAMD_VE_NEAR_HIST 30  /* near-DC terms a step can reach back to (two refresh periods of 15) */
+#define VAMD_VE_AMP_HIST  16  /* band amplitudes a step can reach back to (13), padded */
+typedef struct vamd_envelope_state {
+  int64_t steps;    /* detector steps consumed so far (nearptr == steps % 15) */
+  int32_t stretch;  /* ve->stretch */
+  int32_t pad;
+  float near_hist[VAMD_MAX_CH][VAMD_VE_NEAR_HIST];   /* oldest first */
+  float amp_hist[VAMD_MAX_CH][VAMD_VE_AMP_HIST][8];  /* oldest first; 7 bands + 1 pad */
+} vamd_envelope_state;
+
+/* Batch form, everything device-resident.  Stream s, channel c, step j reads
+ * pcm[s*stream_stride + c*channel_stride + j*searchstep .. + winlength).  `states` [nstreams]
+ * is read and updated in place; ret[s*nsteps + j] receives the step's flags (0..7). */
+int vamd_envelope_search_batch(vamd_ctx *ctx, const float *pcm, long stream_stride, long channel_stride,
+                               long nstreams, long nsteps, vamd_envelope_state *states, unsigned char *ret);
+
+/* One stream from host memory (the per-call compatibility form used by the libvorbis binding):
+ * pcm[c] points at the first sample of the first step; state and ret are host memory. */
+int vamd_envelope_search(vamd_ctx *ctx, const float *const *pcm, long nsteps, vamd_envelope_state *state,
+                         unsigned char *ret);
+
+/* winlength / searchstep of the detector (128 / 64 in every libvorbis setup). */
+int vamd_envelope_geometry(const vamd_ctx *ctx, int *winlength, int *searchstep);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,99 @@
+/* integration/envelope_vamd.c -- reference-side binding for the block-switching detector
+ * (SURVEY.md 8f rank 1).  A maintainer builds this INSTEAD of lib/envelope.c:
+ *
+ *   - the reference's own envelope.c is pulled in by path (init / mark / shift are untouched;
+ *     nothing is copied), with its _ve_envelope_search and _ve_envelope_clear renamed (clear is
+ *     wrapped only to release the GPU context with the state it belongs to);
+ *   - _ve_envelope_search() below keeps the reference's bookkeeping -- which steps are
+ *     due (lib/envelope.c:224-232), how a step's flags land in ve->mark[] (:241-258) and the
+ *     cursor walk that turns marks into a block-size decision (:262-325) -- but the
+ *     detector itself, _ve_amp() for every due step and channel (:89-215, :234-239), is ONE
+ *     call into libvorbis_amd.so.  The detector's running state (envelope_filter_state,
+ *     ve->stretch) lives in a vamd_envelope_state next to the GPU context.
+ *
+ * Linked into oracle/_ref/libvorbis_hybrid.so together with mapping0_vamd.c;
+ * tests/test_gpu_dropin.py checks that streams with transients (short blocks, transitions)
+ * still encode to byte-identical packets.
+ */
+#include <stdio.h>
+#define _ve_envelope_search _ve_envelope_search_cpu
+#define _ve_envelope_clear _ve_envelope_clear_cpu
+#include "envelope.c" /* the reference's lib/envelope.c, found through -I$(REF)/lib */
+#undef _ve_envelope_search
+#undef _ve_envelope_clear
+
+#include "vorbis_amd.h"
+
+/* mapping0_vamd.c owns the per-vorbis_dsp_state side table */
+extern vamd_ctx *vamd_ctx_for(vorbis_dsp_state *vd);
+extern vamd_envelope_state *vamd_envelope_state_for(vorbis_dsp_state *vd);
+extern void vamd_release_key(const void *key);
+
+/* vorbis_dsp_clear() tears the detector down here (lib/block.c:325-328): the GPU context that
+ * was created for this analysis state goes with it */
+void _ve_envelope_clear(envelope_lookup *e) {
+  vamd_release_key(e);
+  _ve_envelope_clear_cpu(e);
+}
+
+long _ve_envelope_search(vorbis_dsp_state *v) {
+  vorbis_info *vi = v->vi;
+  codec_setup_info *ci = vi->codec_setup;
+  envelope_lookup *ve = ((private_state *)(v->backend_state))->ve;
+  const long step = ve->searchstep;
+  long first = ve->current / step;
+  const long last = v->pcm_current / step - VE_WIN;
+  long j;
+
+  if (first < 0) first = 0;
+  if (last + VE_WIN + VE_POST > ve->storage) { /* :229-232 */
+    ve->storage = last + VE_WIN + VE_POST;
+    ve->mark = _ogg_realloc(ve->mark, ve->storage * sizeof(*ve->mark));
+  }
+
+  if (last > first) {
+    vamd_ctx *ctx = vamd_ctx_for(v);
+    vamd_envelope_state *st = vamd_envelope_state_for(v);
+    const long nsteps = last - first;
+    unsigned char *flags = _ogg_malloc(nsteps);
+    const float **chan = alloca(sizeof(*chan) * ve->ch);
+    int i, err = -1;
+    for (i = 0; i < ve->ch; i++) chan[i] = v->pcm[i] + step * first;
+    if (ctx && st) err = vamd_envelope_search(ctx, chan, nsteps, st, flags);
+    if (err) {
+      /* this entry point has no error return (1 / 0 / -1 all mean something); like the
+         reference's own exit(1) sites, refuse to continue rather than silently diverge */
+      fprintf(stderr, "vorbis_amd: envelope search failed (%d): %s\n", err, ctx ? vamd_last_error(ctx) : "no GPU context");
+      abort();
+    }
+    for (j = first; j < last; j++) { /* :241-258 */
+      const int ret = flags[j - first];
+      ve->mark[j + VE_POST] = 0;
+      if (ret & 1) {
+        ve->mark[j] = 1;
+        ve->mark[j + 1] = 1;
+      }
+      if (ret & 2) {
+        ve->mark[j] = 1;
+        if (j > 0) ve->mark[j - 1] = 1;
+      }
+    }
+    ve->stretch = st->stretch;
+    _ogg_free(flags);
+  }
+  ve->current = last * step;
+
+  { /* :262-325: first marked step between the cursor and the decision horizon */
+    const long centerW = v->centerW;
+    const long testW = centerW + ci->blocksizes[v->W] / 4 + ci->blocksizes[1] / 2 + ci->blocksizes[0] / 4;
+    for (j = ve->cursor; j < ve->current - step; j += step) {
+      if (j >= testW) return 1;
+      ve->cursor = j;
+      if (ve->mark[j / step] && j > centerW) {
+        ve->curmark = j;
+        return j >= testW ? 1 : 0;
+      }
+    }
+  }
+  return -1;
+}

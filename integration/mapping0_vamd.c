@@ -24,6 +24,7 @@
  * binding falls through to the reference's CPU forward for them (host code
  * choosing its own CPU implementation -- the GPU library itself has no CPU path).
  */
+#include <stdio.h>
 #define mapping0_exportbundle mapping0_exportbundle_cpu
 #include "mapping0.c" /* the reference's lib/mapping0.c, found through -I$(REF)/lib */
 #undef mapping0_exportbundle
@@ -32,49 +33,70 @@
 
 extern long vamd_pack_setup(vorbis_dsp_state *vd, void *dst, long cap);
 
-/* one GPU context per vorbis_dsp_state, created on first use (vorbis_analysis_init has
+/* one GPU context per analysis state, created on first use (vorbis_analysis_init has
  * already built every lookup by then).  A real integration would hang the pointer off
- * private_state and free it in vorbis_dsp_clear(); a side table keeps this file
- * self-contained. */
+ * private_state; a side table keeps this file self-contained.  The key is the state's
+ * envelope_lookup (private_state.ve, lib/block.c:304): it is allocated by
+ * vorbis_analysis_init and handed to _ve_envelope_clear() by vorbis_dsp_clear()
+ * (lib/block.c:325-328), which is where envelope_vamd.c releases the entry -- so an entry
+ * never outlives its stream even though no reference file is edited. */
 #define VAMD_MAX_STATES 64
 static struct {
-  vorbis_dsp_state *vd;
+  const void *vd; /* key: private_state.ve */
   vamd_ctx *ctx;
+  vamd_envelope_state env; /* the block-switching detector's running state (envelope_vamd.c) */
 } vamd_states[VAMD_MAX_STATES];
 
-static vamd_ctx *vamd_ctx_for(vorbis_dsp_state *vd) {
+static const void *vamd_key(vorbis_dsp_state *vd) { return ((private_state *)vd->backend_state)->ve; }
+
+vamd_ctx *vamd_ctx_for(vorbis_dsp_state *state) {
+  const void *vd = vamd_key(state);
   int i;
+  if (!vd) return NULL;
   for (i = 0; i < VAMD_MAX_STATES; i++)
     if (vamd_states[i].vd == vd) return vamd_states[i].ctx;
   for (i = 0; i < VAMD_MAX_STATES; i++)
     if (!vamd_states[i].vd) {
-      long need = vamd_pack_setup(vd, NULL, 0);
+      long need = vamd_pack_setup(state, NULL, 0);
       void *blob;
       vamd_ctx *ctx = NULL;
       if (need < 0) return NULL;
       blob = _ogg_malloc(need);
-      if (vamd_pack_setup(vd, blob, need) != need || vamd_create(&ctx, blob, (size_t)need, -1) != VAMD_OK)
+      if (vamd_pack_setup(state, blob, need) != need || vamd_create(&ctx, blob, (size_t)need, -1) != VAMD_OK)
         ctx = NULL;
       _ogg_free(blob);
       if (ctx) {
         vamd_states[i].vd = vd;
         vamd_states[i].ctx = ctx;
+        memset(&vamd_states[i].env, 0, sizeof(vamd_states[i].env)); /* fresh stream, lib/envelope.c:71 */
       }
       return ctx;
     }
   return NULL;
 }
 
-/* call from vorbis_dsp_clear() */
-void vamd_release_state(vorbis_dsp_state *vd) {
+vamd_envelope_state *vamd_envelope_state_for(vorbis_dsp_state *state) {
+  int i;
+  if (!vamd_ctx_for(state)) return NULL;
+  for (i = 0; i < VAMD_MAX_STATES; i++)
+    if (vamd_states[i].vd == vamd_key(state)) return &vamd_states[i].env;
+  return NULL;
+}
+
+/* called by _ve_envelope_clear() (envelope_vamd.c) with the envelope_lookup being torn down */
+void vamd_release_key(const void *key) {
   int i;
   for (i = 0; i < VAMD_MAX_STATES; i++)
-    if (vamd_states[i].vd == vd) {
+    if (key && vamd_states[i].vd == key) {
       vamd_destroy(vamd_states[i].ctx);
       vamd_states[i].vd = NULL;
       vamd_states[i].ctx = NULL;
     }
 }
+
+
+/* for a build WITHOUT envelope_vamd.c: call from vorbis_dsp_clear() before b->ve is freed */
+void vamd_release_state(vorbis_dsp_state *state) { vamd_release_key(vamd_key(state)); }
 
 static int mapping0_forward_vamd(vorbis_block *vb) {
   vorbis_dsp_state *vd = vb->vd;
@@ -107,7 +129,10 @@ static int mapping0_forward_vamd(vorbis_block *vb) {
      couple/quantise -- one call (lib/mapping0.c:254-576,613-646) */
   ret = vamd_analyze_block(ctx, (const float *const *)vb->pcm, vb->lW, vb->W, vb->nW, vbi->blocktype, vbi->ampmax,
                            mdct, NULL, posts, post_valid, iwork, nonzero, &ampmax_out);
-  if (ret) return ret;
+  if (ret) {
+    fprintf(stderr, "vorbis_amd: block analysis failed (%d): %s\n", ret, vamd_last_error(ctx));
+    return ret;
+  }
   vbi->ampmax = ampmax_out; /* lib/mapping0.c:576 */
 
   /* ---- the bit-writing half, unchanged host code (lib/mapping0.c:596-687, VBR: blob 7 only) */

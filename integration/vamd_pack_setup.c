@@ -21,6 +21,7 @@
 #include "mdct.h"
 #include "smallft.h"
 #include "psy.h"
+#include "envelope.h"
 #include "misc.h"
 #include "vamd_setup.h"
 
@@ -193,6 +194,38 @@ long vamd_pack_setup(vorbis_dsp_state *vd, void *dst, long cap) {
       m->floor.hineighbor[i] = fl->hineighbor[i];
       m->floor.loneighbor[i] = fl->loneighbor[i];
     }
+  }
+
+  {
+    /* the block-switching detector's lookup (lib/envelope.c:30-74) */
+    envelope_lookup *ve = b->ve;
+    vorbis_info_psy_global *g = &ci->psy_g_param;
+    vamd_envelope_tab *t = &h.env;
+    int n;
+    if (!ve) return OV_EINVAL;
+    n = ve->winlength;
+    if (n != ve->mdct.n || n < 64 || ve->ch != vi->channels) return OV_EIMPL;
+    t->winlength = n;
+    t->searchstep = ve->searchstep;
+    t->log2n = ve->mdct.log2n;
+    t->mdct_scale = ve->mdct.scale;
+    t->minenergy = ve->minenergy;
+    t->stretch_penalty = g->stretch_penalty;
+    for (i = 0; i < VE_BANDS; i++) {
+      t->preecho_thresh[i] = g->preecho_thresh[i];
+      t->postecho_thresh[i] = g->postecho_thresh[i];
+      t->band_begin[i] = ve->band[i].begin;
+      t->band_end[i] = ve->band[i].end;
+      t->band_total[i] = ve->band[i].total;
+      if (ve->band[i].end > VAMD_VE_BANDWIN || ve->band[i].begin + ve->band[i].end > n / 4) return OV_EIMPL;
+      for (j = 0; j < ve->band[i].end; j++) t->band_window[i][j] = ve->band[i].window[j];
+    }
+    t->off_mdct_trig = place(&cur, (uint32_t)(n + n / 4) * 4u);
+    put(dst, t->off_mdct_trig, ve->mdct.trig, (uint32_t)(n + n / 4) * 4u);
+    t->off_mdct_bitrev = place(&cur, (uint32_t)(n / 4) * 4u);
+    put(dst, t->off_mdct_bitrev, ve->mdct.bitrev, (uint32_t)(n / 4) * 4u);
+    t->off_window = place(&cur, (uint32_t)n * 4u);
+    put(dst, t->off_window, ve->mdct_win, (uint32_t)n * 4u);
   }
 
   cur = (cur + 15u) & ~15u;

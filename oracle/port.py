@@ -23,6 +23,15 @@ class _Taps(C.Structure):
                [("local_ampmax", _f32p), ("ampmax_out", _f32p)]
 
 
+class _PortEnvFilter(C.Structure):  # port_env_filter == envelope_filter_state (lib/envelope.h:34-45)
+    _fields_ = [("ampbuf", C.c_float * 17), ("ampptr", C.c_int), ("nearDC", C.c_float * 15),
+                ("nearDC_acc", C.c_float), ("nearDC_partialacc", C.c_float), ("nearptr", C.c_int)]
+
+
+class PortEnvState(C.Structure):  # all-zero = start of stream
+    _fields_ = [("stretch", C.c_int), ("f", _PortEnvFilter * 7 * 2)]
+
+
 _lib = None
 
 
@@ -48,6 +57,7 @@ def lib():
                                      C.POINTER(_Taps)]
         L.port_time_dsp.restype = C.c_double
         L.port_time_dsp.argtypes = [C.c_void_p, _f32p, C.c_long, C.c_int]
+        L.port_envelope_steps.argtypes = [C.c_void_p, C.POINTER(PortEnvState), _f32p, C.c_long, C.c_long, C.c_void_p]
         _lib = L
     return _lib
 
@@ -137,6 +147,18 @@ class PortEncoder:
             raise RuntimeError("port_tap_block failed: %d" % r)
         o["ampmax_out"] = float(o["ampmax_out"][0])
         return o
+
+    def envelope_steps(self, pcm, nsteps, state=None):
+        """The step loop of _ve_envelope_search over planar pcm[ch][len]; returns (flags uint8[nsteps], state)."""
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        if state is None:
+            state = PortEnvState()
+        ret = np.zeros(nsteps, np.uint8)
+        r = self.L.port_envelope_steps(self.h, C.byref(state), _fp(pcm), pcm.shape[1], nsteps,
+                                       ret.ctypes.data_as(C.c_void_p))
+        if r:
+            raise RuntimeError("port_envelope_steps failed: %d" % r)
+        return ret, state
 
     def time_dsp(self, blocks, reps=1):
         blocks = np.ascontiguousarray(blocks, dtype=np.float32)

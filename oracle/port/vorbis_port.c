@@ -244,11 +244,17 @@ static void bf_pass(const float *T, float *x, int points, int step) {
   }
 }
 
+static void mdct_fwd(int n, int log2n, float scale, const float *trig, const int32_t *rev, const float *in,
+                     float *out);
 void port_mdct_forward(const port_enc *e, int W, const float *in, float *out) {
   const vamd_xform_tab *x = &e->h.xform[W];
-  const int n = x->n, n2 = n >> 1, n4 = n >> 2, n8 = n >> 3;
-  const float *trig = tabf(e, x->off_mdct_trig);
-  const int32_t *rev = tabi(e, x->off_mdct_bitrev);
+  mdct_fwd(x->n, x->log2n, x->mdct_scale, tabf(e, x->off_mdct_trig), tabi(e, x->off_mdct_bitrev), in, out);
+}
+
+/* mdct_forward, lib/mdct.c:492-562, for any lookup (the block transforms and the detector's) */
+static void mdct_fwd(int n, int log2n, float scale, const float *trig, const int32_t *rev, const float *in,
+                     float *out) {
+  const int n2 = n >> 1, n4 = n >> 2, n8 = n >> 3;
   float *w = (float *)malloc(sizeof(float) * n), *w2 = w + n2;
   const float *T = trig + n2;
   const float *a = in + n2 + n4, *b = a + 1;
@@ -289,7 +295,7 @@ void port_mdct_forward(const port_enc *e, int W, const float *in, float *out) {
   }
 
   /* mdct_butterflies, lib/mdct.c:316-336 */
-  stages = x->log2n - 5;
+  stages = log2n - 5;
   if (--stages > 0) bf_pass(trig, w2, n2, 4);
   for (s = 1; --stages > 0; s++) {
     int j;
@@ -334,8 +340,8 @@ void port_mdct_forward(const port_enc *e, int W, const float *in, float *out) {
   /* final rotation and scale, lib/mdct.c:552-561 */
   T = trig + n2;
   for (i = 0; i < n4; i++) {
-    out[i] = (w[2 * i] * T[0] + w[2 * i + 1] * T[1]) * x->mdct_scale;
-    out[n2 - 1 - i] = (w[2 * i] * T[1] - w[2 * i + 1] * T[0]) * x->mdct_scale;
+    out[i] = (w[2 * i] * T[0] + w[2 * i + 1] * T[1]) * scale;
+    out[n2 - 1 - i] = (w[2 * i] * T[1] - w[2 * i + 1] * T[0]) * scale;
     T += 2;
   }
   free(w);
@@ -1244,6 +1250,119 @@ int port_tap_block(const port_enc *e, const float *pcm_in, int lW, int W, int nW
   free(iw);
   free(noise);
   free(tone);
+  return 0;
+}
+
+/* ---- the block-switching detector, lib/envelope.c:89-262 ------------------------------
+ * Kept in the reference's running-state form (rings, refreshed accumulator, ve->stretch),
+ * deliberately unlike the replay / all-stretch-values formulation of vorbis_amd/csrc/k_envelope.h.
+ * Pinned against the reference's own _ve_envelope_search by tests/test_envelope.py. */
+typedef struct port_env_filter { /* envelope_filter_state, lib/envelope.h:34-45 */
+  float ampbuf[VAMD_VE_AMP];
+  int ampptr;
+  float nearDC[VAMD_VE_NEARDC];
+  float nearDC_acc, nearDC_partialacc;
+  int nearptr;
+} port_env_filter;
+
+typedef struct port_env_state {
+  int stretch; /* ve->stretch */
+  port_env_filter f[VAMD_MAX_CH][VAMD_VE_BANDS];
+} port_env_state;
+
+/* _ve_amp, lib/envelope.c:89-215 */
+static int env_amp(const port_enc *e, const float *data, port_env_filter *filters, int ve_stretch) {
+  const vamd_envelope_tab *t = &e->h.env;
+  const int n = t->winlength;
+  float vec[1024];
+  const float *win = tabf(e, t->off_window);
+  int ret = 0, i, j;
+  float decay, minV = t->minenergy;
+  int stretch = VAMD_VE_MINSTRETCH > ve_stretch / 2 ? VAMD_VE_MINSTRETCH : ve_stretch / 2;
+  float penalty = t->stretch_penalty - (ve_stretch / 2 - VAMD_VE_MINSTRETCH);
+  if (penalty < 0.f) penalty = 0.f;
+  if (penalty > t->stretch_penalty) penalty = t->stretch_penalty;
+
+  for (i = 0; i < n; i++) vec[i] = data[i] * win[i];
+  mdct_fwd(n, t->log2n, t->mdct_scale, tabf(e, t->off_mdct_trig), tabi(e, t->off_mdct_bitrev), vec, vec);
+
+  { /* near-DC spreading, :120-144 */
+    float temp = vec[0] * vec[0] + .7 * vec[1] * vec[1] + .2 * vec[2] * vec[2];
+    int ptr = filters->nearptr;
+    if (ptr == 0) {
+      decay = filters->nearDC_acc = filters->nearDC_partialacc + temp;
+      filters->nearDC_partialacc = temp;
+    } else {
+      decay = filters->nearDC_acc += temp;
+      filters->nearDC_partialacc += temp;
+    }
+    filters->nearDC_acc -= filters->nearDC[ptr];
+    filters->nearDC[ptr] = temp;
+    decay *= (1. / (VAMD_VE_NEARDC + 1));
+    filters->nearptr++;
+    if (filters->nearptr >= VAMD_VE_NEARDC) filters->nearptr = 0;
+    decay = to_dB(decay) * .5 - 15.f;
+  }
+
+  for (i = 0; i < n / 2; i += 2) { /* :149-156 */
+    float val = vec[i] * vec[i] + vec[i + 1] * vec[i + 1];
+    val = to_dB(val) * .5f;
+    if (val < decay) val = decay;
+    if (val < minV) val = minV;
+    vec[i >> 1] = val;
+    decay -= 8.;
+  }
+
+  for (j = 0; j < VAMD_VE_BANDS; j++) { /* :161-205 */
+    float acc = 0.;
+    float valmax, valmin;
+    for (i = 0; i < t->band_end[j]; i++) acc += vec[i + t->band_begin[j]] * t->band_window[j][i];
+    acc *= t->band_total[j];
+    {
+      int p, this = filters[j].ampptr;
+      float postmax, postmin, premax = -99999.f, premin = 99999.f;
+      p = this;
+      p--;
+      if (p < 0) p += VAMD_VE_AMP;
+      postmax = acc > filters[j].ampbuf[p] ? acc : filters[j].ampbuf[p];
+      postmin = acc < filters[j].ampbuf[p] ? acc : filters[j].ampbuf[p];
+      for (i = 0; i < stretch; i++) {
+        p--;
+        if (p < 0) p += VAMD_VE_AMP;
+        premax = premax > filters[j].ampbuf[p] ? premax : filters[j].ampbuf[p];
+        premin = premin < filters[j].ampbuf[p] ? premin : filters[j].ampbuf[p];
+      }
+      valmin = postmin - premin;
+      valmax = postmax - premax;
+      filters[j].ampbuf[this] = acc;
+      filters[j].ampptr++;
+      if (filters[j].ampptr >= VAMD_VE_AMP) filters[j].ampptr = 0;
+    }
+    if (valmax > t->preecho_thresh[j] + penalty) {
+      ret |= 1;
+      ret |= 4;
+    }
+    if (valmin < t->postecho_thresh[j] - penalty) ret |= 2;
+  }
+  return ret;
+}
+
+/* the step loop of _ve_envelope_search, lib/envelope.c:234-259 (flags out; the mark[] update
+ * is the caller's).  pcm[ch][len], step j reads pcm[c][j*searchstep ..+winlength). */
+int port_envelope_steps(const port_enc *e, port_env_state *st, const float *pcm, long len, long nsteps,
+                        unsigned char *ret_out) {
+  const vamd_envelope_tab *t = &e->h.env;
+  long j;
+  int i;
+  if (t->winlength > 1024 || (nsteps - 1) * t->searchstep + t->winlength > len) return -1;
+  for (j = 0; j < nsteps; j++) {
+    int ret = 0;
+    st->stretch++;
+    if (st->stretch > VAMD_VE_MAXSTRETCH * 2) st->stretch = VAMD_VE_MAXSTRETCH * 2;
+    for (i = 0; i < e->h.channels; i++) ret |= env_amp(e, pcm + (size_t)i * len + t->searchstep * j, st->f[i], st->stretch);
+    ret_out[j] = (unsigned char)ret;
+    if (ret & 4) st->stretch = -1;
+  }
   return 0;
 }
 

@@ -44,6 +44,12 @@ class _BlockRec(C.Structure):
     ]
 
 
+class _EnvState(C.Structure):  # ref_env_state (ref_harness.c): envelope_filter_state x channels + ve->stretch
+    _fields_ = [("stretch", C.c_int), ("ampptr", C.c_int * 7 * 2), ("ampbuf", C.c_float * 17 * 7 * 2),
+                ("nearptr", C.c_int * 2), ("nearDC", C.c_float * 15 * 2), ("nearDC_acc", C.c_float * 2),
+                ("nearDC_partialacc", C.c_float * 2)]
+
+
 def available():
     return os.path.exists(LIB_PATH)
 
@@ -87,6 +93,11 @@ def lib(hybrid=False):
         L.ref_time_analysis.argtypes = [C.c_void_p, _f32p, C.c_long, C.c_int]
         L.ref_time_dsp.restype = C.c_double
         L.ref_time_dsp.argtypes = [C.c_void_p, _f32p, C.c_long, C.c_int]
+        L.ref_envelope_feed.restype = C.c_long
+        L.ref_envelope_feed.argtypes = [C.c_void_p, _f32p, C.c_long]
+        L.ref_envelope_get.restype = C.c_long
+        L.ref_envelope_get.argtypes = [C.c_void_p, _f32p, C.c_long, C.POINTER(C.c_long), _i32p, C.c_long,
+                                       C.POINTER(_EnvState)]
         _libs[path] = L
     return _libs[path]
 
@@ -235,6 +246,37 @@ class RefEncoder:
             d["packet"] = bytes(pk_out[r.packet_offset:r.packet_offset + r.packet_bytes]) if r.packet_offset >= 0 else None
             out.append(d)
         return out
+
+    def envelope_feed(self, pcm):
+        """Append planar pcm[ch][frames] (vorbis_analysis_buffer/_wrote) and run the reference's own
+        _ve_envelope_search over everything buffered.  Never shifts.  Returns a dict:
+        steps (detector steps done since the start), pcm (the PCM ring as the detector saw it, including
+        the centre padding / pre-extrapolation), marks [steps + 2], and the filter state in history form
+        (stretch, near = the last 15 near-DC terms oldest first, amp [ch][7][17] oldest first,
+        near_acc, near_partial)."""
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        ch, frames = pcm.shape
+        assert ch == self.channels
+        steps = self.L.ref_envelope_feed(self.h, _fp(pcm), frames)
+        if steps < 0:
+            raise RuntimeError("ref_envelope_feed failed")
+        n = C.c_long(0)
+        self.L.ref_envelope_get(self.h, None, 0, C.byref(n), None, 0, None)
+        seen = np.zeros((ch, n.value), np.float32)
+        marks = np.zeros(steps + 2, np.int32)
+        st = _EnvState()
+        self.L.ref_envelope_get(self.h, _fp(seen), n.value, C.byref(n), _ip(marks), steps + 2, C.byref(st))
+        amp = np.zeros((ch, 7, 17), np.float32)
+        near = np.zeros((ch, 15), np.float32)
+        for c in range(ch):
+            ring = np.array(st.nearDC[c][:], np.float32)
+            near[c] = np.roll(ring, -st.nearptr[c])          # nearptr = the oldest slot
+            for b in range(7):
+                a = np.array(st.ampbuf[c][b][:], np.float32)
+                amp[c, b] = np.roll(a, -st.ampptr[c][b])     # ampptr = the oldest slot
+        return dict(steps=int(steps), pcm=seen, marks=marks, stretch=int(st.stretch), near=near, amp=amp,
+                    near_acc=np.array(st.nearDC_acc[:ch], np.float32),
+                    near_partial=np.array(st.nearDC_partialacc[:ch], np.float32))
 
     def time_analysis(self, blocks, reps=1):
         blocks = np.ascontiguousarray(blocks, dtype=np.float32)

@@ -31,6 +31,7 @@
 #include "mdct.h"
 #include "smallft.h"
 #include "psy.h"
+#include "envelope.h"
 #include "scales.h"
 #include "misc.h"
 
@@ -419,6 +420,69 @@ long ref_encode_stream(ref_enc *e, const float *pcm, long frames, ref_block_rec 
   }
   vorbis_block_clear(&vb);
   return nblocks;
+}
+
+/* ---- the block-switching detector ------------------------------
+ * ref_envelope_feed(): append `frames` samples per channel exactly as an application does
+ * (vorbis_analysis_buffer + vorbis_analysis_wrote, which also runs the start-of-stream
+ * pre-extrapolation, lib/block.c:398-458), then run the reference's own
+ * _ve_envelope_search() (lib/envelope.c:217-327) over everything buffered so far.
+ * vorbis_analysis_blockout() is never called, so nothing is shifted out and ve->mark[j]
+ * stays addressable for every step j since the start of the stream.
+ * Returns the number of detector steps done so far (ve->current / ve->searchstep). */
+long ref_envelope_feed(ref_enc *e, const float *pcm, long frames) {
+  private_state *b = (private_state *)e->vd.backend_state;
+  int i;
+  if (frames > 0) {
+    float **buf = vorbis_analysis_buffer(&e->vd, (int)frames);
+    for (i = 0; i < e->channels; i++) memcpy(buf[i], pcm + (size_t)i * frames, frames * sizeof(float));
+    if (vorbis_analysis_wrote(&e->vd, (int)frames)) return -1;
+  }
+  _ve_envelope_search(&e->vd);
+  return b->ve->current / b->ve->searchstep;
+}
+
+typedef struct ref_env_state {
+  int stretch;
+  int ampptr[2][VE_BANDS];
+  float ampbuf[2][VE_BANDS][VE_AMP];
+  int nearptr[2];
+  float nearDC[2][VE_NEARDC];
+  float nearDC_acc[2], nearDC_partialacc[2];
+} ref_env_state;
+
+/* Copy out what the detector saw and decided: the PCM ring as it stands (pcm_seen[ch][cap],
+ * returns samples per channel via *pcm_len), the marks of steps [0, nmarks) and the filter
+ * state.  Returns ve->current / ve->searchstep. */
+long ref_envelope_get(ref_enc *e, float *pcm_seen, long cap, long *pcm_len, int *marks, long nmarks,
+                      ref_env_state *st) {
+  private_state *b = (private_state *)e->vd.backend_state;
+  envelope_lookup *ve = b->ve;
+  int i, j;
+  long n = e->vd.pcm_current;
+  if (pcm_len) *pcm_len = n;
+  if (pcm_seen) {
+    if (n > cap) n = cap;
+    for (i = 0; i < e->channels; i++) memcpy(pcm_seen + (size_t)i * cap, e->vd.pcm[i], n * sizeof(float));
+  }
+  if (marks)
+    for (j = 0; j < nmarks; j++) marks[j] = j < ve->storage ? ve->mark[j] : -1;
+  if (st) {
+    memset(st, 0, sizeof(*st));
+    st->stretch = ve->stretch;
+    for (i = 0; i < e->channels && i < 2; i++) {
+      envelope_filter_state *f = ve->filter + i * VE_BANDS;
+      st->nearptr[i] = f->nearptr;
+      st->nearDC_acc[i] = f->nearDC_acc;
+      st->nearDC_partialacc[i] = f->nearDC_partialacc;
+      memcpy(st->nearDC[i], f->nearDC, sizeof(f->nearDC));
+      for (j = 0; j < VE_BANDS; j++) {
+        st->ampptr[i][j] = f[j].ampptr;
+        memcpy(st->ampbuf[i][j], f[j].ampbuf, sizeof(f[j].ampbuf));
+      }
+    }
+  }
+  return ve->current / ve->searchstep;
 }
 
 /* ---- CPU baseline timing ---------------------------------------------------- */

@@ -13,6 +13,7 @@
 #include "k_tone.h"
 #include "k_floor.h"
 #include "k_couple.h"
+#include "k_envelope.h"
 
 using namespace vamd;
 
@@ -127,6 +128,50 @@ int emul_analyze_block(void *h, const float *pcm, int lW, int W, int nW, int blo
   OUT(nonzero, nonzero, int);
   OUT(local_ampmax, local, float);
   if (t->ampmax_out) *t->ampmax_out = global;
+  return 0;
+}
+// the block-switching detector, one stream: the same four stages the HIP library launches
+// (vamd_envelope_search_batch), run in order on the host.  pcm[ch][len].
+int emul_envelope_search(void *h, const float *pcm, long len, long nsteps, vamd_envelope_state *st,
+                         unsigned char *ret) {
+  Emul *e = (Emul *)h;
+  const EnvP &E = e->B.env;
+  const int ch = e->B.channels, n = E.mdct.n, n2 = n / 2;
+  if ((nsteps - 1) * E.searchstep + n > len) return -1;
+  std::vector<float> near((size_t)ch * (VAMD_VE_NEAR_HIST + nsteps)), raw((size_t)ch * nsteps * VAMD_VE_SPREAD),
+      amp((size_t)ch * (VAMD_VE_AMP_HIST + nsteps) * 8, 0.f);
+  std::vector<uint32_t> bits(nsteps);
+  std::vector<float> A(n), Wk(n2 + VAMD_PW_SIZE(n2)), spec(n2);
+  PhaseClock pc;
+  pc.start(nullptr);
+  for (int c = 0; c < ch; c++) {
+    float *nr = near.data() + (size_t)c * (VAMD_VE_NEAR_HIST + nsteps);
+    float *am = amp.data() + (size_t)c * (VAMD_VE_AMP_HIST + nsteps) * 8;
+    for (int i = 0; i < VAMD_VE_NEAR_HIST; i++) nr[i] = st->near_hist[c][i];
+    for (int i = 0; i < VAMD_VE_AMP_HIST * 8; i++) am[i] = st->amp_hist[c][i >> 3][i & 7];
+    for (long j = 0; j < nsteps; j++)
+      env_spectrum_wave(E, pcm + (size_t)c * len + j * E.searchstep, A.data(), Wk.data(), spec.data(),
+                        nr + VAMD_VE_NEAR_HIST + j, raw.data() + ((size_t)c * nsteps + j) * VAMD_VE_SPREAD, pc);
+    for (long j = 0; j < nsteps; j++) {
+      const float decay = env_decay(nr + VAMD_VE_NEAR_HIST + j, (long)st->steps + j);
+      for (int b = 0; b < VAMD_VE_BANDS; b++)
+        am[(VAMD_VE_AMP_HIST + j) * 8 + b] =
+            env_band_amp(E, raw.data() + ((size_t)c * nsteps + j) * VAMD_VE_SPREAD, decay, b);
+    }
+  }
+  for (long j = 0; j < nsteps; j++) {
+    const float *a[VAMD_MAX_CH];
+    for (int c = 0; c < ch; c++) a[c] = amp.data() + ((size_t)c * (VAMD_VE_AMP_HIST + nsteps) + VAMD_VE_AMP_HIST + j) * 8;
+    bits[j] = env_trigger_bits(E, a, ch, 8);
+  }
+  st->stretch = env_walk(bits.data(), nsteps, st->stretch, ret);
+  st->steps += nsteps;
+  for (int c = 0; c < ch; c++) {
+    const float *nt = near.data() + (size_t)c * (VAMD_VE_NEAR_HIST + nsteps) + nsteps;
+    for (int i = 0; i < VAMD_VE_NEAR_HIST; i++) st->near_hist[c][i] = nt[i];
+    const float *at = amp.data() + ((size_t)c * (VAMD_VE_AMP_HIST + nsteps) + nsteps) * 8;
+    for (int i = 0; i < VAMD_VE_AMP_HIST * 8; i++) st->amp_hist[c][i >> 3][i & 7] = at[i];
+  }
   return 0;
 }
 }

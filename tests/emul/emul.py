@@ -43,6 +43,7 @@ class Emul:
         self.L.emul_mdct_forward.argtypes = [C.c_void_p, C.c_int, _f32p, _f32p]
         self.L.emul_analyze_block.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                               C.POINTER(_Taps)]
+        self.L.emul_envelope_search.argtypes = [C.c_void_p, _f32p, C.c_long, C.c_long, C.c_void_p, C.c_void_p]
         blob = np.ascontiguousarray(blob, dtype=np.uint8)
         self.h = self.L.emul_open(blob.ctypes.data_as(C.c_void_p), blob.size)
         if not self.h:
@@ -76,3 +77,12 @@ class Emul:
         assert r == 0
         o["ampmax_out"] = float(o["ampmax_out"][0])
         return o
+
+    def envelope_search(self, pcm, nsteps, state):
+        """Same contract as Analyzer.envelope_search; `state` is a vorbis_amd.EnvelopeState."""
+        pcm = np.ascontiguousarray(pcm, np.float32)
+        ret = np.zeros(nsteps, np.uint8)
+        r = self.L.emul_envelope_search(self.h, pcm.ctypes.data_as(_f32p), pcm.shape[1], nsteps, C.byref(state),
+                                        ret.ctypes.data_as(C.c_void_p))
+        assert r == 0
+        return ret

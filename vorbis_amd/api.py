@@ -16,7 +16,8 @@ BLOCKTYPE_IMPULSE, BLOCKTYPE_PADDING, BLOCKTYPE_TRANSITION, BLOCKTYPE_LONG = 0, 
 EXPORTED_SYMBOLS = ["vamd_create", "vamd_destroy", "vamd_last_error", "vamd_set_stream", "vamd_reserve",
                     "vamd_channels", "vamd_blocksize", "vamd_posts", "vamd_mdct_forward_batch",
                     "vamd_analyze_batch", "vamd_analyze_stream", "vamd_analyze_block", "vamd_profile",
-                    "vamd_stage_ms", "vamd_debug_cycles", "vamd_analyze_stream_mixed"]
+                    "vamd_stage_ms", "vamd_debug_cycles", "vamd_analyze_stream_mixed", "vamd_envelope_search_batch",
+                    "vamd_envelope_search", "vamd_envelope_geometry"]
 
 _vp = C.c_void_p
 
@@ -76,6 +77,9 @@ def load_library():
     L.vamd_debug_cycles.argtypes = [_vp, C.c_int, _vp]
     L.vamd_analyze_stream_mixed.argtypes = [_vp, C.POINTER(_Desc), C.POINTER(_IO), C.POINTER(_Desc), C.POINTER(_IO), _vp,
                                             C.c_long, C.POINTER(C.c_float)]
+    L.vamd_envelope_search_batch.argtypes = [_vp, _vp, C.c_long, C.c_long, C.c_long, C.c_long, _vp, _vp]
+    L.vamd_envelope_search.argtypes = [_vp, C.POINTER(_vp), C.c_long, _vp, _vp]
+    L.vamd_envelope_geometry.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.vamd_profile.argtypes = [_vp, C.c_int]
     L.vamd_stage_ms.argtypes = [_vp, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]
     _lib = L
@@ -310,3 +314,70 @@ class Analyzer:
                                               C.byref(amp)))
         o["ampmax_out"] = amp.value
         return o
+
+    # ---- the block-switching detector (vamd_envelope_search*) ---------------------------------
+    def envelope_geometry(self):
+        w, s = C.c_int(0), C.c_int(0)
+        self._check(self.L.vamd_envelope_geometry(self.h, C.byref(w), C.byref(s)))
+        return w.value, s.value
+
+    def envelope_search(self, pcm, nsteps, state=None):
+        """vamd_envelope_search: host pcm[ch][>= (nsteps-1)*searchstep + winlength] -> (ret flags uint8[nsteps],
+        state).  `state` is an EnvelopeState (None = start of stream) and is updated in place."""
+        ch = self.channels
+        win, step = self.envelope_geometry()
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        assert pcm.ndim == 2 and pcm.shape[0] == ch and pcm.shape[1] >= (nsteps - 1) * step + win
+        if state is None:
+            state = EnvelopeState()
+        ret = np.zeros(nsteps, np.uint8)
+        ptrs = (_vp * ch)(*[_vp(pcm[i].ctypes.data) for i in range(ch)])
+        self._bind_stream()
+        self._check(self.L.vamd_envelope_search(self.h, ptrs, nsteps, C.byref(state), _vp(ret.ctypes.data)))
+        return ret, state
+
+    def envelope_search_batch(self, pcm, nsteps, states=None, ret=None):
+        """vamd_envelope_search_batch: cuda float32 pcm[nstreams][ch][len]; states = cuda uint8 tensor
+        [nstreams][sizeof(vamd_envelope_state)] (zeros = fresh streams), updated in place.
+        Returns (ret cuda uint8 [nstreams][nsteps], states)."""
+        t = self.torch
+        assert pcm.is_cuda and pcm.dtype == t.float32 and pcm.is_contiguous() and pcm.dim() == 3
+        ns, ch, ln = pcm.shape
+        assert ch == self.channels
+        win, step = self.envelope_geometry()
+        assert ln >= (nsteps - 1) * step + win
+        if states is None:
+            states = t.zeros((ns, C.sizeof(EnvelopeState)), dtype=t.uint8, device=pcm.device)
+        if ret is None:
+            ret = t.empty((ns, nsteps), dtype=t.uint8, device=pcm.device)
+        self._bind_stream()
+        self._check(self.L.vamd_envelope_search_batch(self.h, _vp(pcm.data_ptr()), ch * ln, ln, ns, nsteps,
+                                                      _vp(states.data_ptr()), _vp(ret.data_ptr())))
+        return ret, states
+
+
+class EnvelopeState(C.Structure):
+    """vamd_envelope_state (include/vorbis_amd.h); all-zero = start of a stream."""
+    _fields_ = [("steps", C.c_int64), ("stretch", C.c_int32), ("pad", C.c_int32),
+                ("near_hist", C.c_float * 30 * 2), ("amp_hist", C.c_float * 8 * 16 * 2)]
+
+
+def envelope_marks(ret, first=0, marks=None):
+    """Apply per-step flags to a mark array exactly as lib/envelope.c:241-258 does (host-side
+    integer logic of the binding): step j = first + index."""
+    n = first + len(ret) + 2
+    if marks is None:
+        marks = np.zeros(n, np.int32)
+    elif len(marks) < n:
+        marks = np.concatenate([marks, np.zeros(n - len(marks), np.int32)])
+    for k, r in enumerate(ret):
+        j = first + k
+        marks[j + 2] = 0
+        if r & 1:
+            marks[j] = 1
+            marks[j + 1] = 1
+        if r & 2:
+            marks[j] = 1
+            if j > 0:
+                marks[j - 1] = 1
+    return marks

@@ -1,0 +1,141 @@
+// k_envelope.h -- the block-switching detector: _ve_amp and the step loop of
+// _ve_envelope_search (reference lib/envelope.c:89-215, :217-262); SURVEY.md 8f rank 1.
+//
+// The reference runs one detector step every `searchstep` (64) samples per channel: a
+// sin^2-windowed 128-point MDCT, a near-DC smoother, a 32-value dB spread, seven band
+// amplitudes, and pre-/post-echo triggers against the band's recent history.  It keeps
+// all of that as running state, so it looks serial -- but only one integer is:
+//
+//  * the near-DC accumulator is "regularly refreshed from scratch" (lib/envelope.c:127-137):
+//    its value at step J depends on the terms of steps J-29 .. J only, in a fixed order, so
+//    every step can replay its own <= 44 adds (env_decay);
+//  * the band history is a plain ring of the last 17 amplitudes: step J reads steps
+//    J-1 .. J-13 (lib/envelope.c:171-187), which are outputs of the parallel stage;
+//  * ve->stretch (how far back the pre-echo window reaches, and the penalty) is the true
+//    recurrence: it is reset by a trigger and otherwise counts up.  It takes 13 distinct
+//    values of stretch/2, so the trigger bits are computed for all 13 in parallel and a
+//    single thread per stream then walks the steps picking 2 bits per step (env_walk).
+//
+// Stages (one launch each):
+//   env_spectrum_wave  wave   per (stream, channel, step): window, MDCT, near-DC term, raw dB pairs
+//   env_band_amp       thread per (stream, channel, step, band): decay replay, spread, band amplitude
+//   env_trigger_bits   thread per (stream, step): 13 x {pre-echo, post-echo} bits over channels and bands
+//   env_walk           thread per stream: the stretch recurrence -> ret flags (1|4 pre-echo, 2 post-echo)
+// Series carry a history prefix (the previous call's tail, zeros at stream start == the
+// reference's calloc'ed filter state) so a stream can be processed in calls of any size.
+#pragma once
+#include "vamd_wave.h"
+#include "vamd_params.h"
+#include "vorbis_amd.h"
+#include "k_transform.h"
+
+namespace vamd {
+
+// VAMD_VE_NEAR_HIST (30: two refresh periods) and VAMD_VE_AMP_HIST (16 >= 1 + VE_MAXSTRETCH) are
+// part of the state layout: include/vorbis_amd.h
+#define VAMD_VE_SPREAD 32     // winlength/4 spread values (winlength == 128 is enforced at bind time)
+#define VAMD_VE_HSTATES 13    // values of stretch/2: 0 .. VE_MAXSTRETCH
+
+// window + MDCT + the two per-step series that need the spectrum (lib/envelope.c:110-124,148-152)
+//   pcm   HBM, the step's `winlength` samples
+//   A LDS [n], Wk LDS [n/2 + VAMD_PW_SIZE(n/2)], spec LDS [n/2]
+//   near_out  the near-DC term `temp`;  raw_out [n/4]  todB(re^2+im^2)*.5f before limiting
+VAMD_DEV void env_spectrum_wave(const EnvP &E, const float *__restrict__ pcm, float *A, float *Wk, float *spec,
+                                float *__restrict__ near_out, float *__restrict__ raw_out, PhaseClock &pc) {
+  const int n = E.mdct.n;
+  WAVE_FOR(i, n) A[i] = pcm[i] * E.win[i];
+  WAVE_SYNC();
+  mdct_forward_wave(E.mdct, A, Wk, spec, pc);
+  if (LANE == 0) {
+    // float temp=vec[0]*vec[0]+.7*vec[1]*vec[1]+.2*vec[2]*vec[2];  the literals make it fp64
+    const float v0 = spec[0], v1 = spec[1], v2 = spec[2];
+    *near_out = (float)((double)(v0 * v0) + (.7 * (double)v1) * (double)v1 + (.2 * (double)v2) * (double)v2);
+  }
+  WAVE_FOR(k, n >> 2) {
+    const F2 z = *(const F2 *)(spec + 2 * k);
+    const float val = z.x * z.x + z.y * z.y;
+    raw_out[k] = todB(val) * .5f;
+  }
+  WAVE_SYNC();
+}
+
+// `decay` as _ve_amp leaves it at lib/envelope.c:143 for global step J.
+//   t  points at this step's near-DC term; t[-k] is the term k steps earlier (zeros before the stream)
+VAMD_DEV float env_decay(const float *__restrict__ t, long J) {
+  const int p = (int)(J % VAMD_VE_NEARDC);  // filters->nearptr at this step
+  const float *r = t - p;                   // the last refresh step (nearptr == 0)
+  float part = r[-VAMD_VE_NEARDC];          // nearDC_partialacc restarted one period before it...
+  for (int i = -VAMD_VE_NEARDC + 1; i <= -1; i++) part += r[i];  // ...and has summed that period
+  float acc = part + r[0];                  // :128  decay = nearDC_acc = nearDC_partialacc + temp
+  float decay = acc;
+  acc -= r[-VAMD_VE_NEARDC];                // :134  nearDC[ptr] still holds the term 15 steps back
+  for (int i = 1; i <= p; i++) {
+    acc += r[i];                            // :131  decay = nearDC_acc += temp
+    decay = acc;
+    acc -= r[i - VAMD_VE_NEARDC];
+  }
+  decay = (float)((double)decay * (1. / (VAMD_VE_NEARDC + 1)));
+  return (float)((double)todB(decay) * .5 - (double)15.f);
+}
+
+// One band's amplitude for one step (lib/envelope.c:148-165): limit the raw dB pairs the band
+// covers by the falling decay line and the energy floor, then the windowed mean.
+VAMD_DEV float env_band_amp(const EnvP &E, const float *__restrict__ raw /*[32] of this step*/, float decay, int b) {
+  const int begin = E.band_begin[b], end = E.band_end[b];
+  for (int k = 0; k < begin; k++) decay = (float)((double)decay - 8.);  // decay-=8. once per pair, in order
+  float acc = 0.f;
+  for (int i = 0; i < end; i++) {
+    float val = raw[begin + i];
+    if (val < decay) val = decay;
+    if (val < E.minenergy) val = E.minenergy;
+    acc += val * E.band_window[b][i];
+    decay = (float)((double)decay - 8.);
+  }
+  return acc * E.band_total[b];
+}
+
+// Trigger bits of one step for every value h of stretch/2 (lib/envelope.c:99-104,167-205):
+// bit 2h = pre-echo (ret |= 1|4), bit 2h+1 = post-echo (ret |= 2), OR-ed over channels and bands.
+//   amp[c]  points at this step's [VAMD_VE_BANDS+1] amplitudes of channel c; earlier steps sit
+//           `amp_stride` floats lower each
+VAMD_DEV uint32_t env_trigger_bits(const EnvP &E, const float *const *amp, int ch, long amp_stride) {
+  uint32_t bits = 0;
+  for (int c = 0; c < ch; c++)
+    for (int b = 0; b < VAMD_VE_BANDS; b++) {
+      const float *a = amp[c] + b;
+      const float acc = a[0], prev = a[-amp_stride];
+      const float postmax = acc > prev ? acc : prev;
+      const float postmin = acc < prev ? acc : prev;
+      float premax = -99999.f, premin = 99999.f;
+      for (int i = 0; i < VAMD_VE_MAXSTRETCH; i++) {
+        const float v = a[-(2 + i) * amp_stride];
+        premax = premax > v ? premax : v;
+        premin = premin < v ? premin : v;
+        const int w = i + 1;  // window length reached: the `stretch` of h = w (and of h = 0,1 when w == 2)
+        if (w < VAMD_VE_MINSTRETCH) continue;
+        const float valmin = postmin - premin, valmax = postmax - premax;
+        for (int h = (w == VAMD_VE_MINSTRETCH ? 0 : w); h <= w; h++) {
+          float penalty = E.stretch_penalty - (float)(h - VAMD_VE_MINSTRETCH);
+          if (penalty < 0.f) penalty = 0.f;
+          if (penalty > E.stretch_penalty) penalty = E.stretch_penalty;
+          if (valmax > E.preecho_thresh[b] + penalty) bits |= 1u << (2 * h);
+          if (valmin < E.postecho_thresh[b] - penalty) bits |= 2u << (2 * h);
+        }
+      }
+    }
+  return bits;
+}
+
+// The recurrence itself (lib/envelope.c:234-239,258): returns the updated ve->stretch.
+VAMD_DEV int env_walk(const uint32_t *__restrict__ bits, long nsteps, int stretch, unsigned char *__restrict__ ret) {
+  for (long j = 0; j < nsteps; j++) {
+    stretch++;
+    if (stretch > VAMD_VE_MAXSTRETCH * 2) stretch = VAMD_VE_MAXSTRETCH * 2;
+    const uint32_t two = (bits[j] >> (2 * (stretch / 2))) & 3u;
+    ret[j] = (unsigned char)((two & 1u ? 5 : 0) | (two & 2u ? 2 : 0));
+    if (two & 1u) stretch = -1;
+  }
+  return stretch;
+}
+
+}  // namespace vamd

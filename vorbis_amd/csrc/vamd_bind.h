@@ -21,6 +21,7 @@ struct Bound {
   PsyP psy[4];
   FloorP floor[2];
   CoupleP couple[2];
+  EnvP env;
   float ampmax_att_per_sec;
 };
 
@@ -112,6 +113,28 @@ inline int build_image(const void *blob_v, size_t bytes, std::vector<unsigned ch
       *err = "total_octave_lines out of range";
       return VAMD_EINVAL;
     }
+  }
+
+  {
+    const vamd_envelope_tab &e = h.env;
+    const int n = e.winlength;
+    if (n != 128 || (1 << e.log2n) != n || e.searchstep < 1 || e.searchstep > n) {
+      *err = "envelope detector: only the 128-sample window of lib/envelope.c:35 is covered";
+      return VAMD_EIMPL;
+    }
+    const uint64_t need[] = {(uint64_t)e.off_mdct_trig + 4ull * (n + n / 4), (uint64_t)e.off_mdct_bitrev + 4ull * (n / 4),
+                             (uint64_t)e.off_window + 4ull * n};
+    for (uint64_t x : need)
+      if (x > h.total_bytes) {
+        *err = "setup blob: envelope table offset out of range";
+        return VAMD_EINVAL;
+      }
+    for (int i = 0; i < VAMD_VE_BANDS; i++)
+      if (e.band_begin[i] < 0 || e.band_end[i] < 0 || e.band_end[i] > VAMD_VE_BANDWIN ||
+          e.band_begin[i] + e.band_end[i] > n / 4) {
+        *err = "envelope detector: band out of range";
+        return VAMD_EINVAL;
+      }
   }
 
   image->assign(blob, blob + h.total_bytes);
@@ -233,6 +256,28 @@ inline void bind_params(const std::vector<unsigned char> &image, const std::vect
     C.prepoint = stereo_threshold(h.psy_g.coupling_prepointamp[blob_k], false);
     C.postpoint = stereo_threshold(h.psy_g.coupling_postpointamp[blob_k], (x.n / 2) > 1000);
     C.sliding_lowpass = h.psy_g.sliding_lowpass[W][blob_k];
+  }
+  {
+    const vamd_envelope_tab &e = h.env;
+    EnvP &E = B->env;
+    memset(&E, 0, sizeof(E));
+    E.mdct.n = e.winlength;
+    E.mdct.log2n = e.log2n;
+    E.mdct.mdct_scale = e.mdct_scale;
+    E.mdct.trig = (const float *)(base + e.off_mdct_trig);
+    E.mdct.bitrev = (const int *)(base + e.off_mdct_bitrev);
+    E.win = (const float *)(base + e.off_window);
+    E.searchstep = e.searchstep;
+    E.minenergy = e.minenergy;
+    E.stretch_penalty = e.stretch_penalty;
+    for (int i = 0; i < VAMD_VE_BANDS; i++) {
+      E.preecho_thresh[i] = e.preecho_thresh[i];
+      E.postecho_thresh[i] = e.postecho_thresh[i];
+      E.band_begin[i] = e.band_begin[i];
+      E.band_end[i] = e.band_end[i];
+      E.band_total[i] = e.band_total[i];
+      for (int j = 0; j < VAMD_VE_BANDWIN; j++) E.band_window[i][j] = e.band_window[i][j];
+    }
   }
   for (int p = 0; p < 4; p++) {
     const vamd_psy_tab &t = h.psy[p];

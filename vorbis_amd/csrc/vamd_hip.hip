@@ -26,6 +26,7 @@
 #include "k_tone.h"
 #include "k_floor.h"
 #include "k_couple.h"
+#include "k_envelope.h"
 
 using namespace vamd;
 
@@ -335,6 +336,92 @@ __global__ __launch_bounds__(64) void k_couple(PsyP P0, PsyP P1, CoupleP C, Desc
 // ---------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------
+
+// ---- the block-switching detector (k_envelope.h).  Series layouts, s = stream, c = channel:
+//   near [s][c][VAMD_VE_NEAR_HIST + nsteps]        near-DC terms behind their history prefix
+//   raw  [s][c][nsteps][32]                        unlimited dB pairs
+//   amp  [s][c][VAMD_VE_AMP_HIST + nsteps][8]      band amplitudes behind their history prefix
+//   bits [s][nsteps]                               trigger bits for the 13 values of stretch/2
+__global__ void k_env_prolog(int ch, long nstreams, long nsteps, const vamd_envelope_state *__restrict__ st,
+                             float *__restrict__ near, float *__restrict__ amp) {
+  const long per = (long)ch * (VAMD_VE_NEAR_HIST + VAMD_VE_AMP_HIST * 8);
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nstreams * per) return;
+  const long s = t / per;
+  long r = t - s * per;
+  const int c = (int)(r / (VAMD_VE_NEAR_HIST + VAMD_VE_AMP_HIST * 8));
+  r -= (long)c * (VAMD_VE_NEAR_HIST + VAMD_VE_AMP_HIST * 8);
+  if (r < VAMD_VE_NEAR_HIST)
+    near[(s * ch + c) * (VAMD_VE_NEAR_HIST + nsteps) + r] = st[s].near_hist[c][r];
+  else {
+    r -= VAMD_VE_NEAR_HIST;
+    amp[(s * ch + c) * (VAMD_VE_AMP_HIST + nsteps) * 8 + r] = st[s].amp_hist[c][r >> 3][r & 7];
+  }
+}
+
+#define VAMD_ENV_WAVES 4
+__global__ __launch_bounds__(64 * VAMD_ENV_WAVES) void k_env_spectrum(EnvP E, int ch, long nstreams, long nsteps,
+                                                                      const float *__restrict__ pcm, long stream_stride,
+                                                                      long channel_stride, float *__restrict__ near,
+                                                                      float *__restrict__ raw) {
+  const int n = E.mdct.n, n2 = n >> 1, wave = threadIdx.x >> 6;
+  const int per_wave = n + n2 + VAMD_PW_SIZE(n2) + n2;
+  float *A = (float *)vamd_smem + (size_t)wave * per_wave;
+  float *Wk = A + n, *spec = Wk + n2 + VAMD_PW_SIZE(n2);
+  PhaseClock pc;
+  pc.start(nullptr);
+  const long items = nstreams * ch * nsteps;
+  for (long it = (long)blockIdx.x * VAMD_ENV_WAVES + wave; it < items; it += (long)gridDim.x * VAMD_ENV_WAVES) {
+    const long sc = it / nsteps, j = it - sc * nsteps;
+    const long s = sc / ch;
+    const int c = (int)(sc - s * ch);
+    env_spectrum_wave(E, pcm + s * stream_stride + c * channel_stride + j * E.searchstep, A, Wk, spec,
+                      near + sc * (VAMD_VE_NEAR_HIST + nsteps) + VAMD_VE_NEAR_HIST + j, raw + it * VAMD_VE_SPREAD, pc);
+  }
+}
+
+__global__ void k_env_amp(EnvP E, long nsc /* streams x channels */, long nsteps,
+                                  const vamd_envelope_state *__restrict__ st, int ch, const float *__restrict__ near, const float *__restrict__ raw,
+                          float *__restrict__ amp) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = (int)(t & 7);
+  const long it = t >> 3;
+  if (it >= nsc * nsteps) return;
+  const long sc = it / nsteps, j = it - sc * nsteps;
+  if (b >= VAMD_VE_BANDS) {  // the pad lane of the 8-float rows: keep the state deterministic
+    amp[(sc * (VAMD_VE_AMP_HIST + nsteps) + VAMD_VE_AMP_HIST + j) * 8 + b] = 0.f;
+    return;
+  }
+  const float decay = env_decay(near + sc * (VAMD_VE_NEAR_HIST + nsteps) + VAMD_VE_NEAR_HIST + j, (long)st[sc / ch].steps + j);
+  amp[(sc * (VAMD_VE_AMP_HIST + nsteps) + VAMD_VE_AMP_HIST + j) * 8 + b] = env_band_amp(E, raw + it * VAMD_VE_SPREAD, decay, b);
+}
+
+__global__ void k_env_bits(EnvP E, int ch, long nstreams, long nsteps, const float *__restrict__ amp,
+                           uint32_t *__restrict__ bits) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nstreams * nsteps) return;
+  const long s = t / nsteps, j = t - s * nsteps;
+  const float *a[VAMD_MAX_CH];
+  for (int c = 0; c < ch; c++) a[c] = amp + ((s * ch + c) * (VAMD_VE_AMP_HIST + nsteps) + VAMD_VE_AMP_HIST + j) * 8;
+  bits[t] = env_trigger_bits(E, a, ch, 8);
+}
+
+// the stretch recurrence, one thread per stream; then the state's histories roll forward
+__global__ void k_env_walk(int ch, long nstreams, long nsteps, const uint32_t *__restrict__ bits,
+                           const float *__restrict__ near, const float *__restrict__ amp,
+                           vamd_envelope_state *__restrict__ st, unsigned char *__restrict__ ret) {
+  const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nstreams) return;
+  st[s].stretch = env_walk(bits + s * nsteps, nsteps, st[s].stretch, ret + s * nsteps);
+  st[s].steps += nsteps;
+  for (int c = 0; c < ch; c++) {
+    const float *nt = near + (s * ch + c) * (VAMD_VE_NEAR_HIST + nsteps) + nsteps;  // the last NEAR_HIST entries
+    for (int i = 0; i < VAMD_VE_NEAR_HIST; i++) st[s].near_hist[c][i] = nt[i];
+    const float *at = amp + ((s * ch + c) * (VAMD_VE_AMP_HIST + nsteps) + nsteps) * 8;
+    for (int i = 0; i < VAMD_VE_AMP_HIST * 8; i++) st[s].amp_hist[c][i >> 3][i & 7] = at[i];
+  }
+}
+
 struct DevBuf {
   void *p = nullptr;
   size_t bytes = 0;
@@ -356,7 +443,8 @@ struct vamd_ctx {
   std::string err;
   // workspace, grown on demand (vamd_reserve to pre-size)
   enum { WS_MDCT_RAW, WS_LOGMDCT, WS_LOGFFT, WS_NOISE, WS_TONE, WS_MDCT, WS_ILOGMASK, WS_IWORK, WS_POSTS, WS_POSTVALID,
-         WS_NONZERO, WS_LOCAL, WS_AMPIN, WS_AMPGLOB, WS_PCM, WS_SEED, WS_SURV, WS_NSURV, WS_MISC, WS_COUNT };
+         WS_NONZERO, WS_LOCAL, WS_AMPIN, WS_AMPGLOB, WS_PCM, WS_SEED, WS_SURV, WS_NSURV, WS_MISC,
+         WS_ENV_NEAR, WS_ENV_RAW, WS_ENV_AMP, WS_ENV_BITS, WS_ENV_STAGE, WS_COUNT };
   DevBuf ws[2][WS_COUNT];  // per size class (a mixed stream keeps both batches in flight)
   // pinned staging for the per-block host API
   void *h_stage = nullptr;
@@ -872,6 +960,95 @@ int vamd_analyze_block(vamd_ctx *c, const float *const *pcm, int lW, int W, int 
   if (post_valid) memcpy(post_valid, hs + o_valid, (size_t)ch * 4);
   if (nonzero) memcpy(nonzero, hs + o_nz, (size_t)ch * 4);
   if (ampmax_out) memcpy(ampmax_out, hs + o_amp, 4);
+  return VAMD_OK;
+}
+
+int vamd_envelope_geometry(const vamd_ctx *c, int *winlength, int *searchstep) {
+  if (!c) return VAMD_EINVAL;
+  if (winlength) *winlength = c->B.env.mdct.n;
+  if (searchstep) *searchstep = c->B.env.searchstep;
+  return VAMD_OK;
+}
+
+int vamd_envelope_search_batch(vamd_ctx *c, const float *pcm, long stream_stride, long channel_stride, long nstreams,
+                               long nsteps, vamd_envelope_state *states, unsigned char *ret) {
+  if (!c) return VAMD_EINVAL;
+  if (nstreams < 0 || nsteps < 0) return fail(c, VAMD_EINVAL, "negative stream / step count");
+  if (nstreams == 0 || nsteps == 0) return VAMD_OK;
+  if (!pcm || !states || !ret) return fail(c, VAMD_EINVAL, "null pcm / states / ret");
+  const EnvP &E = c->B.env;
+  const int ch = c->B.channels, n = E.mdct.n, n2 = n / 2;
+  const long nsc = nstreams * ch;
+  void *v_near, *v_raw, *v_amp, *v_bits;
+  int r;
+  if ((r = ws_get(c, 0, vamd_ctx::WS_ENV_NEAR, (size_t)nsc * (VAMD_VE_NEAR_HIST + nsteps) * 4, &v_near))) return r;
+  if ((r = ws_get(c, 0, vamd_ctx::WS_ENV_RAW, (size_t)nsc * nsteps * VAMD_VE_SPREAD * 4, &v_raw))) return r;
+  if ((r = ws_get(c, 0, vamd_ctx::WS_ENV_AMP, (size_t)nsc * (VAMD_VE_AMP_HIST + nsteps) * 8 * 4, &v_amp))) return r;
+  if ((r = ws_get(c, 0, vamd_ctx::WS_ENV_BITS, (size_t)nstreams * nsteps * 4, &v_bits))) return r;
+  float *near = (float *)v_near, *raw = (float *)v_raw, *amp = (float *)v_amp;
+  uint32_t *bits = (uint32_t *)v_bits;
+  hipStream_t s = c->stream;
+  {
+    const long t = nsc * (VAMD_VE_NEAR_HIST + VAMD_VE_AMP_HIST * 8);
+    hipLaunchKernelGGL(k_env_prolog, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, ch, nstreams, nsteps, states,
+                       near, amp);
+  }
+  {
+    const long items = nsc * nsteps, groups = (items + VAMD_ENV_WAVES - 1) / VAMD_ENV_WAVES;
+    const long cap = (long)c->num_cus * 8;
+    const size_t lds = (size_t)VAMD_ENV_WAVES * (n + n2 + VAMD_PW_SIZE(n2) + n2) * 4;
+    hipLaunchKernelGGL(k_env_spectrum, dim3((unsigned)(groups < cap ? groups : cap)), dim3(64 * VAMD_ENV_WAVES), lds, s, E,
+                       ch, nstreams, nsteps, pcm, stream_stride, channel_stride, near, raw);
+  }
+  {
+    const long t = nsc * nsteps * 8;
+    hipLaunchKernelGGL(k_env_amp, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, E, nsc, nsteps, states, ch,
+                       near, raw, amp);
+  }
+  hipLaunchKernelGGL(k_env_bits, dim3((unsigned)((nstreams * nsteps + 255) / 256)), dim3(256), 0, s, E, ch, nstreams, nsteps,
+                     amp, bits);
+  hipLaunchKernelGGL(k_env_walk, dim3((unsigned)((nstreams + 63) / 64)), dim3(64), 0, s, ch, nstreams, nsteps, bits, near, amp,
+                     states, ret);
+  HIP_TRY(c, hipGetLastError());
+  return VAMD_OK;
+}
+
+int vamd_envelope_search(vamd_ctx *c, const float *const *pcm, long nsteps, vamd_envelope_state *state,
+                         unsigned char *ret) {
+  if (!c) return VAMD_EINVAL;
+  if (nsteps < 0) return fail(c, VAMD_EINVAL, "negative step count");
+  if (nsteps == 0) return VAMD_OK;
+  if (!pcm || !state || !ret) return fail(c, VAMD_EINVAL, "null pcm / state / ret");
+  const int ch = c->B.channels, n = c->B.env.mdct.n, step = c->B.env.searchstep;
+  const long len = (nsteps - 1) * step + n;  // samples per channel the steps read
+  const size_t o_pcm = 0, o_state = ((size_t)ch * len * 4 + 15) & ~(size_t)15,
+               o_ret = o_state + ((sizeof(vamd_envelope_state) + 15) & ~(size_t)15),
+               total = o_ret + (((size_t)nsteps + 15) & ~(size_t)15);
+  if (c->h_stage_bytes < total) {
+    if (c->h_stage) HIP_TRY(c, hipHostFree(c->h_stage));
+    c->h_stage = nullptr;
+    c->h_stage_bytes = 0;
+    HIP_TRY(c, hipHostMalloc(&c->h_stage, total, hipHostMallocDefault));
+    c->h_stage_bytes = total;
+  }
+  void *dv;
+  int r = ws_get(c, 0, vamd_ctx::WS_ENV_STAGE, total, &dv);
+  if (r) return r;
+  unsigned char *hs = (unsigned char *)c->h_stage, *ds = (unsigned char *)dv;
+  for (int i = 0; i < ch; i++) {
+    if (!pcm[i]) return fail(c, VAMD_EINVAL, "null channel pointer");
+    memcpy(hs + o_pcm + (size_t)i * len * 4, pcm[i], (size_t)len * 4);
+  }
+  memcpy(hs + o_state, state, sizeof(*state));
+  hipStream_t s = c->stream;
+  HIP_TRY(c, hipMemcpyAsync(ds, hs, o_ret, hipMemcpyHostToDevice, s));
+  r = vamd_envelope_search_batch(c, (const float *)(ds + o_pcm), (long)ch * len, len, 1, nsteps,
+                                 (vamd_envelope_state *)(ds + o_state), ds + o_ret);
+  if (r) return r;
+  HIP_TRY(c, hipMemcpyAsync(hs + o_state, ds + o_state, total - o_state, hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  memcpy(state, hs + o_state, sizeof(*state));
+  memcpy(ret, hs + o_ret, (size_t)nsteps);
   return VAMD_OK;
 }
 

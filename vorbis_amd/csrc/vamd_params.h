@@ -55,6 +55,18 @@ struct PsyP {
   double normal_thresh;
 };
 
+// the block-switching detector (_ve_amp / _ve_envelope_search, lib/envelope.c)
+struct EnvP {
+  XformP mdct;             // n = 128 MDCT tables only (no FFT, no vwin windows)
+  const float *win;        // [n] mdct_win
+  int searchstep;
+  float minenergy, stretch_penalty;
+  float preecho_thresh[VAMD_VE_BANDS], postecho_thresh[VAMD_VE_BANDS];
+  int band_begin[VAMD_VE_BANDS], band_end[VAMD_VE_BANDS];
+  float band_total[VAMD_VE_BANDS];
+  float band_window[VAMD_VE_BANDS][VAMD_VE_BANDWIN];
+};
+
 struct FloorP {
   int posts, look_n, quant_q, mult;
   float maxover, maxunder, maxerr, twofitweight, twofitatten;
