@@ -141,7 +141,8 @@ int emul_envelope_search(void *h, const float *pcm, long len, long nsteps, vamd_
   std::vector<float> near((size_t)ch * (VAMD_VE_NEAR_HIST + nsteps)), raw((size_t)ch * nsteps * VAMD_VE_SPREAD),
       amp((size_t)ch * (VAMD_VE_AMP_HIST + nsteps) * 8, 0.f);
   std::vector<uint32_t> bits(nsteps);
-  std::vector<float> A(n), Wk(n2 + VAMD_PW_SIZE(n2)), spec(n2);
+  const int LOGS = 2, S = 1 << LOGS;  // side-by-side transforms, as the HIP kernel runs them (it uses 16)
+  std::vector<float> A((size_t)n * S), Wk((size_t)(n2 + VAMD_PW_SIZE(n2)) * S), spec((size_t)n2 * S);
   PhaseClock pc;
   pc.start(nullptr);
   for (int c = 0; c < ch; c++) {
@@ -149,9 +150,10 @@ int emul_envelope_search(void *h, const float *pcm, long len, long nsteps, vamd_
     float *am = amp.data() + (size_t)c * (VAMD_VE_AMP_HIST + nsteps) * 8;
     for (int i = 0; i < VAMD_VE_NEAR_HIST; i++) nr[i] = st->near_hist[c][i];
     for (int i = 0; i < VAMD_VE_AMP_HIST * 8; i++) am[i] = st->amp_hist[c][i >> 3][i & 7];
-    for (long j = 0; j < nsteps; j++)
-      env_spectrum_wave(E, pcm + (size_t)c * len + j * E.searchstep, A.data(), Wk.data(), spec.data(),
-                        nr + VAMD_VE_NEAR_HIST + j, raw.data() + ((size_t)c * nsteps + j) * VAMD_VE_SPREAD, pc);
+    for (long j = 0; j < nsteps; j += S)
+      env_spectrum_wave<LOGS>(E, pcm + (size_t)c * len + j * E.searchstep, nsteps - j < S ? (int)(nsteps - j) : S, A.data(),
+                              Wk.data(), spec.data(), nr + VAMD_VE_NEAR_HIST + j,
+                              raw.data() + ((size_t)c * nsteps + j) * VAMD_VE_SPREAD, pc);
     for (long j = 0; j < nsteps; j++) {
       const float decay = env_decay(nr + VAMD_VE_NEAR_HIST + j, (long)st->steps + j);
       for (int b = 0; b < VAMD_VE_BANDS; b++)
@@ -164,7 +166,7 @@ int emul_envelope_search(void *h, const float *pcm, long len, long nsteps, vamd_
     for (int c = 0; c < ch; c++) a[c] = amp.data() + ((size_t)c * (VAMD_VE_AMP_HIST + nsteps) + VAMD_VE_AMP_HIST + j) * 8;
     bits[j] = env_trigger_bits(E, a, ch, 8);
   }
-  st->stretch = env_walk(bits.data(), nsteps, st->stretch, ret);
+  st->stretch = env_walk_wave(bits.data(), nsteps, st->stretch, ret);
   st->steps += nsteps;
   for (int c = 0; c < ch; c++) {
     const float *nt = near.data() + (size_t)c * (VAMD_VE_NEAR_HIST + nsteps) + nsteps;

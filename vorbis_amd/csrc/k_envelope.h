@@ -20,7 +20,7 @@
 //   env_spectrum_wave  wave   per (stream, channel, step): window, MDCT, near-DC term, raw dB pairs
 //   env_band_amp       thread per (stream, channel, step, band): decay replay, spread, band amplitude
 //   env_trigger_bits   thread per (stream, step): 13 x {pre-echo, post-echo} bits over channels and bands
-//   env_walk           thread per stream: the stretch recurrence -> ret flags (1|4 pre-echo, 2 post-echo)
+//   env_walk_wave      wave   per stream: the stretch recurrence -> ret flags (1|4 pre-echo, 2 post-echo)
 // Series carry a history prefix (the previous call's tail, zeros at stream start == the
 // reference's calloc'ed filter state) so a stream can be processed in calls of any size.
 #pragma once
@@ -36,25 +36,36 @@ namespace vamd {
 #define VAMD_VE_SPREAD 32     // winlength/4 spread values (winlength == 128 is enforced at bind time)
 #define VAMD_VE_HSTATES 13    // values of stretch/2: 0 .. VE_MAXSTRETCH
 
-// window + MDCT + the two per-step series that need the spectrum (lib/envelope.c:110-124,148-152)
-//   pcm   HBM, the step's `winlength` samples
-//   A LDS [n], Wk LDS [n/2 + VAMD_PW_SIZE(n/2)], spec LDS [n/2]
-//   near_out  the near-DC term `temp`;  raw_out [n/4]  todB(re^2+im^2)*.5f before limiting
-VAMD_DEV void env_spectrum_wave(const EnvP &E, const float *__restrict__ pcm, float *A, float *Wk, float *spec,
-                                float *__restrict__ near_out, float *__restrict__ raw_out, PhaseClock &pc) {
-  const int n = E.mdct.n;
-  WAVE_FOR(i, n) A[i] = pcm[i] * E.win[i];
-  WAVE_SYNC();
-  mdct_forward_wave(E.mdct, A, Wk, spec, pc);
-  if (LANE == 0) {
-    // float temp=vec[0]*vec[0]+.7*vec[1]*vec[1]+.2*vec[2]*vec[2];  the literals make it fp64
-    const float v0 = spec[0], v1 = spec[1], v2 = spec[2];
-    *near_out = (float)((double)(v0 * v0) + (.7 * (double)v1) * (double)v1 + (.2 * (double)v2) * (double)v2);
+// window + MDCT + the two per-step series that need the spectrum (lib/envelope.c:110-124,148-152),
+// for 2^LOGS consecutive steps of one channel at a time (their transforms run side by side, see
+// mdct_forward_wave): a 128-point transform alone would leave most of the wave idle.
+//   pcm    HBM, the first step's samples; step t starts t*searchstep further on
+//   count  steps actually wanted (<= 2^LOGS; the rest of the slots compute on zeros, unstored)
+//   A LDS [n] per step, Wk LDS [n/2 + VAMD_PW_SIZE(n/2)] per step, spec LDS [n/2] per step
+//   near_out [count] the near-DC terms `temp`;  raw_out [count][n/4]  todB(re^2+im^2)*.5f before limiting
+template <int LOGS>
+VAMD_DEV void env_spectrum_wave(const EnvP &E, const float *__restrict__ pcm, int count, float *A, float *Wk,
+                                float *spec, float *__restrict__ near_out, float *__restrict__ raw_out,
+                                PhaseClock &pc) {
+  const int n = E.mdct.n, n2 = n >> 1, ln = E.mdct.log2n;
+  WAVE_FOR(k, n << LOGS) {
+    const int t = k >> ln, i = k & (n - 1);
+    A[k] = t < count ? pcm[t * E.searchstep + i] * E.win[i] : 0.f;
   }
-  WAVE_FOR(k, n >> 2) {
-    const F2 z = *(const F2 *)(spec + 2 * k);
-    const float val = z.x * z.x + z.y * z.y;
-    raw_out[k] = todB(val) * .5f;
+  WAVE_SYNC();
+  mdct_forward_wave<LOGS>(E.mdct, A, Wk, spec, pc, n, n2 + VAMD_PW_SIZE(n2), n2);
+  WAVE_FOR(t, count) {
+    // float temp=vec[0]*vec[0]+.7*vec[1]*vec[1]+.2*vec[2]*vec[2];  the literals make it fp64
+    const float v0 = spec[t * n2], v1 = spec[t * n2 + 1], v2 = spec[t * n2 + 2];
+    near_out[t] = (float)((double)(v0 * v0) + (.7 * (double)v1) * (double)v1 + (.2 * (double)v2) * (double)v2);
+  }
+  WAVE_FOR(k, (n >> 2) << LOGS) {
+    const int t = k >> (ln - 2), kk = k & ((n >> 2) - 1);
+    if (t < count) {
+      const F2 z = *(const F2 *)(spec + t * n2 + 2 * kk);
+      const float val = z.x * z.x + z.y * z.y;
+      raw_out[t * (n >> 2) + kk] = todB(val) * .5f;
+    }
   }
   WAVE_SYNC();
 }
@@ -126,14 +137,25 @@ VAMD_DEV uint32_t env_trigger_bits(const EnvP &E, const float *const *amp, int c
   return bits;
 }
 
-// The recurrence itself (lib/envelope.c:234-239,258): returns the updated ve->stretch.
-VAMD_DEV int env_walk(const uint32_t *__restrict__ bits, long nsteps, int stretch, unsigned char *__restrict__ ret) {
-  for (long j = 0; j < nsteps; j++) {
-    stretch++;
-    if (stretch > VAMD_VE_MAXSTRETCH * 2) stretch = VAMD_VE_MAXSTRETCH * 2;
-    const uint32_t two = (bits[j] >> (2 * (stretch / 2))) & 3u;
-    ret[j] = (unsigned char)((two & 1u ? 5 : 0) | (two & 2u ? 2 : 0));
-    if (two & 1u) stretch = -1;
+// The recurrence itself (lib/envelope.c:234-239,258): returns the updated ve->stretch.  One wave
+// per stream: the lanes fetch 64 steps' bits together and write 64 flags together; in between
+// the chain runs on wave-uniform values (readlane + scalar integer ops), a handful of
+// instructions per step with no memory access on the dependent path.
+VAMD_DEV int env_walk_wave(const uint32_t *__restrict__ bits, long nsteps, int stretch, unsigned char *__restrict__ ret) {
+  for (long base = 0; base < nsteps; base += NLANES) {
+    const int cnt = nsteps - base < NLANES ? (int)(nsteps - base) : NLANES;
+    LaneInts v;
+    v.load((const int *)bits + base, cnt);
+    int mine = 0;
+    for (int i = 0; i < cnt; i++) {
+      stretch++;
+      if (stretch > VAMD_VE_MAXSTRETCH * 2) stretch = VAMD_VE_MAXSTRETCH * 2;
+      const uint32_t two = ((uint32_t)v.get(i) >> (2 * (stretch / 2))) & 3u;
+      const int r = (two & 1u ? 5 : 0) | (two & 2u ? 2 : 0);
+      if (i == LANE) mine = r;
+      if (two & 1u) stretch = -1;
+    }
+    if (LANE < cnt) ret[base + LANE] = (unsigned char)mine;
   }
   return stretch;
 }

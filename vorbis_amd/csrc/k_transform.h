@@ -178,16 +178,32 @@ VAMD_DEV void bfly32(float *x) {
 // mdct_forward, lib/mdct.c:492-562.  `in` = A (windowed block, LDS, n floats);
 // w = work buffer: w[0..n2) plain + padded butterfly vector at w + n2
 // (VAMD_PW_SIZE(n2) floats).  The n/2 spectrum is written to out_lds[0..n2).
-VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in, float *w, float *out_lds, PhaseClock &pc) {
+// LOGS > 0 runs 2^LOGS independent transforms of the same size side by side (transform t at
+// in + t*in_stride, w + t*w_stride, out_lds + t*out_stride): every loop then ranges over
+// (transform, item) so that small transforms -- the 128-point one of the block-switching
+// detector has only two 32-point groups -- still fill the wave.
+template <int LOGS = 0>
+VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in0, float *w0, float *out0, PhaseClock &pc,
+                                int in_stride = 0, int w_stride = 0, int out_stride = 0) {
   const int n = P.n, n2 = n >> 1, n4 = n >> 2, n8 = n >> 3;
   const float *__restrict__ trig = P.trig;
-  float *w2 = w + n2;  // padded: use VAMD_PW()
+// item index -> (transform t, item g) for a loop of `1 << lcount` items per transform
+#define VAMD_MDCT_SPLIT(gg, lcount)                            \
+  const int t_ = LOGS ? (gg) >> (lcount) : 0;                  \
+  const int g_ = LOGS ? (gg) & ((1 << (lcount)) - 1) : (gg);   \
+  const float *in = in0 + t_ * in_stride;                      \
+  float *w = w0 + t_ * w_stride;                               \
+  float *w2 = w + n2; /* padded: use VAMD_PW() */              \
+  float *out_lds = out0 + t_ * out_stride;                     \
+  (void)in; (void)w; (void)w2; (void)out_lds;
 
   // fold + pre-twiddle ("window + rotate + step 1"), lib/mdct.c:506-544.
   // Pair p writes w2[2p], w2[2p+1]; the three loops differ in which input
   // quarter is folded with which sign.  x0[0],x0[2] / x1[0],x1[2] of the reference
   // are the .x,.z / .y,.w lanes of two aligned quads of the input.
-  WAVE_FOR(p, n4) {
+  WAVE_FOR(pp, n4 << LOGS) {
+    VAMD_MDCT_SPLIT(pp, P.log2n - 2)
+    const int p = g_;
     const F2 T = *(const F2 *)(trig + n2 - 2 * (p + 1));
     float r0, r1;
     if (2 * p < n8) {
@@ -222,7 +238,9 @@ VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in, float *w, floa
   const int nstages = P.log2n - 6;  // first + (log2n-7) generic passes
   for (int s = 0; s < nstages; s++) {
     const int pts = n2 >> s, lper = P.log2n - 3 - s, tstride = 4 << s;  // per = pts/4 = 1 << lper
-    WAVE_FOR(g, n8) {
+    WAVE_FOR(gg, n8 << LOGS) {
+      VAMD_MDCT_SPLIT(gg, P.log2n - 3)
+      const int g = g_;
       const int j = g >> lper, q = g & ((1 << lper) - 1);
       const int ia = pts * j + pts - 2 - 2 * q, ib = pts * j + (pts >> 1) - 2 - 2 * q;
       F2 *pa = (F2 *)(w2 + VAMD_PW(ia)), *pb = (F2 *)(w2 + VAMD_PW(ib));
@@ -240,7 +258,9 @@ VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in, float *w, floa
   }
   pc.mark(2);
   // 32-point butterflies, one group per lane, in registers
-  WAVE_FOR(g, n2 / 32) {
+  WAVE_FOR(gg, (n2 / 32) << LOGS) {
+    VAMD_MDCT_SPLIT(gg, P.log2n - 6)
+    const int g = g_;
     float v[32];
     F2 *pg = (F2 *)(w2 + 34 * g);  // == VAMD_PW(32 g)
 #if VAMD_GPU
@@ -268,7 +288,9 @@ VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in, float *w, floa
   // mdct_bitreverse, lib/mdct.c:346-394: reads x = w2 (upper half), writes the
   // lower half w[0..n2).  Unit u produces w[2u], w[2u+1], w[n2-2u-2], w[n2-2u-1].
   const int *__restrict__ bit = P.bitrev;
-  WAVE_FOR(u, n8) {
+  WAVE_FOR(uu, n8 << LOGS) {
+    VAMD_MDCT_SPLIT(uu, P.log2n - 3)
+    const int u = g_;
     const I2 bi = *(const I2 *)(bit + 2 * u);
     const F2 x0 = *(const F2 *)(w2 + VAMD_PW(bi.x));
     const F2 x1 = *(const F2 *)(w2 + VAMD_PW(bi.y));
@@ -291,7 +313,9 @@ VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in, float *w, floa
   pc.mark(4);
 
   // final rotate * scale, lib/mdct.c:552-561 -> out[n2]
-  WAVE_FOR(i, n4) {
+  WAVE_FOR(ii, n4 << LOGS) {
+    VAMD_MDCT_SPLIT(ii, P.log2n - 2)
+    const int i = g_;
     const F2 T = *(const F2 *)(trig + n2 + 2 * i);
     const F2 ab = *(const F2 *)(w + 2 * i);
     out_lds[i] = (ab.x * T.x + ab.y * T.y) * P.mdct_scale;
@@ -299,6 +323,7 @@ VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in, float *w, floa
   }
   WAVE_SYNC();
 }
+#undef VAMD_MDCT_SPLIT
 
 // FFT buffers and the packed layout.  FFTPACK's half-complex packing puts every
 // (real, imag) pair at indices (2m-1, 2m): odd first.  Stored plainly that is never

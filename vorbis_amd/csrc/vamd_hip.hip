@@ -359,24 +359,29 @@ __global__ void k_env_prolog(int ch, long nstreams, long nsteps, const vamd_enve
   }
 }
 
+// a wave takes VAMD_ENV_STEPS consecutive steps of one (stream, channel) at a time
+#define VAMD_ENV_LOGS 2
+#define VAMD_ENV_STEPS (1 << VAMD_ENV_LOGS)
 #define VAMD_ENV_WAVES 4
 __global__ __launch_bounds__(64 * VAMD_ENV_WAVES) void k_env_spectrum(EnvP E, int ch, long nstreams, long nsteps,
                                                                       const float *__restrict__ pcm, long stream_stride,
                                                                       long channel_stride, float *__restrict__ near,
                                                                       float *__restrict__ raw) {
   const int n = E.mdct.n, n2 = n >> 1, wave = threadIdx.x >> 6;
-  const int per_wave = n + n2 + VAMD_PW_SIZE(n2) + n2;
-  float *A = (float *)vamd_smem + (size_t)wave * per_wave;
-  float *Wk = A + n, *spec = Wk + n2 + VAMD_PW_SIZE(n2);
+  const int per_step = n + n2 + VAMD_PW_SIZE(n2) + n2;
+  float *A = (float *)vamd_smem + (size_t)wave * per_step * VAMD_ENV_STEPS;
+  float *Wk = A + n * VAMD_ENV_STEPS, *spec = Wk + (n2 + VAMD_PW_SIZE(n2)) * VAMD_ENV_STEPS;
   PhaseClock pc;
   pc.start(nullptr);
-  const long items = nstreams * ch * nsteps;
+  const long groups = (nsteps + VAMD_ENV_STEPS - 1) / VAMD_ENV_STEPS, items = nstreams * ch * groups;
   for (long it = (long)blockIdx.x * VAMD_ENV_WAVES + wave; it < items; it += (long)gridDim.x * VAMD_ENV_WAVES) {
-    const long sc = it / nsteps, j = it - sc * nsteps;
+    const long sc = it / groups, j = (it - sc * groups) * VAMD_ENV_STEPS;
     const long s = sc / ch;
     const int c = (int)(sc - s * ch);
-    env_spectrum_wave(E, pcm + s * stream_stride + c * channel_stride + j * E.searchstep, A, Wk, spec,
-                      near + sc * (VAMD_VE_NEAR_HIST + nsteps) + VAMD_VE_NEAR_HIST + j, raw + it * VAMD_VE_SPREAD, pc);
+    const int count = nsteps - j < VAMD_ENV_STEPS ? (int)(nsteps - j) : VAMD_ENV_STEPS;
+    env_spectrum_wave<VAMD_ENV_LOGS>(E, pcm + s * stream_stride + c * channel_stride + j * E.searchstep, count, A, Wk,
+                                     spec, near + sc * (VAMD_VE_NEAR_HIST + nsteps) + VAMD_VE_NEAR_HIST + j,
+                                     raw + (sc * nsteps + j) * VAMD_VE_SPREAD, pc);
   }
 }
 
@@ -406,19 +411,22 @@ __global__ void k_env_bits(EnvP E, int ch, long nstreams, long nsteps, const flo
   bits[t] = env_trigger_bits(E, a, ch, 8);
 }
 
-// the stretch recurrence, one thread per stream; then the state's histories roll forward
-__global__ void k_env_walk(int ch, long nstreams, long nsteps, const uint32_t *__restrict__ bits,
-                           const float *__restrict__ near, const float *__restrict__ amp,
-                           vamd_envelope_state *__restrict__ st, unsigned char *__restrict__ ret) {
-  const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= nstreams) return;
-  st[s].stretch = env_walk(bits + s * nsteps, nsteps, st[s].stretch, ret + s * nsteps);
-  st[s].steps += nsteps;
+// the stretch recurrence, one wave per stream; then the state's histories roll forward
+__global__ __launch_bounds__(64) void k_env_walk(int ch, long nstreams, long nsteps, const uint32_t *__restrict__ bits,
+                                                 const float *__restrict__ near, const float *__restrict__ amp,
+                                                 vamd_envelope_state *__restrict__ st,
+                                                 unsigned char *__restrict__ ret) {
+  const long s = blockIdx.x;
+  const int stretch = env_walk_wave(bits + s * nsteps, nsteps, st[s].stretch, ret + s * nsteps);
+  if (LANE == 0) {
+    st[s].stretch = stretch;
+    st[s].steps += nsteps;
+  }
   for (int c = 0; c < ch; c++) {
     const float *nt = near + (s * ch + c) * (VAMD_VE_NEAR_HIST + nsteps) + nsteps;  // the last NEAR_HIST entries
-    for (int i = 0; i < VAMD_VE_NEAR_HIST; i++) st[s].near_hist[c][i] = nt[i];
+    WAVE_FOR(i, VAMD_VE_NEAR_HIST) st[s].near_hist[c][i] = nt[i];
     const float *at = amp + ((s * ch + c) * (VAMD_VE_AMP_HIST + nsteps) + nsteps) * 8;
-    for (int i = 0; i < VAMD_VE_AMP_HIST * 8; i++) st[s].amp_hist[c][i >> 3][i & 7] = at[i];
+    WAVE_FOR(i, VAMD_VE_AMP_HIST * 8) st[s].amp_hist[c][i >> 3][i & 7] = at[i];
   }
 }
 
@@ -994,9 +1002,10 @@ int vamd_envelope_search_batch(vamd_ctx *c, const float *pcm, long stream_stride
                        near, amp);
   }
   {
-    const long items = nsc * nsteps, groups = (items + VAMD_ENV_WAVES - 1) / VAMD_ENV_WAVES;
+    const long items = nsc * ((nsteps + VAMD_ENV_STEPS - 1) / VAMD_ENV_STEPS);
+    const long groups = (items + VAMD_ENV_WAVES - 1) / VAMD_ENV_WAVES;
     const long cap = (long)c->num_cus * 8;
-    const size_t lds = (size_t)VAMD_ENV_WAVES * (n + n2 + VAMD_PW_SIZE(n2) + n2) * 4;
+    const size_t lds = (size_t)VAMD_ENV_WAVES * VAMD_ENV_STEPS * (n + n2 + VAMD_PW_SIZE(n2) + n2) * 4;
     hipLaunchKernelGGL(k_env_spectrum, dim3((unsigned)(groups < cap ? groups : cap)), dim3(64 * VAMD_ENV_WAVES), lds, s, E,
                        ch, nstreams, nsteps, pcm, stream_stride, channel_stride, near, raw);
   }
@@ -1007,7 +1016,7 @@ int vamd_envelope_search_batch(vamd_ctx *c, const float *pcm, long stream_stride
   }
   hipLaunchKernelGGL(k_env_bits, dim3((unsigned)((nstreams * nsteps + 255) / 256)), dim3(256), 0, s, E, ch, nstreams, nsteps,
                      amp, bits);
-  hipLaunchKernelGGL(k_env_walk, dim3((unsigned)((nstreams + 63) / 64)), dim3(64), 0, s, ch, nstreams, nsteps, bits, near, amp,
+  hipLaunchKernelGGL(k_env_walk, dim3((unsigned)nstreams), dim3(64), 0, s, ch, nstreams, nsteps, bits, near, amp,
                      states, ret);
   HIP_TRY(c, hipGetLastError());
   return VAMD_OK;
