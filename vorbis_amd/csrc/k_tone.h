@@ -64,7 +64,7 @@ VAMD_DEV void seed_curve_scatter(float *seed, const float *__restrict__ band_row
 // end_k = next.pos if the next entry is louder else pos_k + linesper + 1 (clipped
 // to n) and start_k = max(end_0 .. end_{k-1}) because the reference's write
 // pointer only moves forward.  Spans are disjoint, so all lanes paint at once.
-VAMD_DEV void seed_chase_paint(float *seeds, int linesper, int n, int stack, const int *posstack,
+VAMD_DEV void seed_chase_paint(float *seeds, int linesper, int n, int stack, const unsigned short *posstack,
                                const float *ampstack) {
   int carry = 0;
   for (int base = 0; base < stack; base += NLANES) {
@@ -178,14 +178,14 @@ VAMD_DEV void tone_seed_block(const PsyP &P, const float *__restrict__ logfft, f
 // paint + fold half: seed[] (LDS, unpainted), the survivor list -> tone curve
 //   posstack/ampstack LDS [nlines]
 VAMD_DEV void tone_fold_block(const PsyP &P, float local_ampmax, float *seed, const unsigned short *__restrict__ surv,
-                              int nsurv, int *posstack, float *ampstack, float *gmin /* LDS [ngroups] */,
+                              int nsurv, unsigned short *posstack, float *ampstack, float *gmin /* LDS [ngroups] */,
                               float *__restrict__ out, PhaseClock &pc) {
   const int n = P.n, nlines = P.total_octave_lines;
   float att = local_ampmax + P.ath_adjatt;
   if (att < P.ath_maxatt) att = P.ath_maxatt;
   WAVE_FOR(k, nsurv) {
     const int pos = surv[k];
-    posstack[k] = pos;
+    posstack[k] = (unsigned short)pos;
     ampstack[k] = seed[pos];
   }
   WAVE_SYNC();
@@ -243,7 +243,8 @@ VAMD_DEV void tone_fold_block(const PsyP &P, float local_ampmax, float *seed, co
 //   seed LDS [seed_pad_lo | nlines padded to 16 | seed_pad_hi] (pointer at line 0), fft LDS [n], posstack/ampstack LDS [nlines],
 //   ring_amp/ring_pos [VAMD_RING], surv [nlines]
 VAMD_DEV void tonemask_block(const PsyP &P, const float *__restrict__ logfft, float *__restrict__ out,
-                             float global_ampmax, float local_ampmax, float *seed, int *posstack, float *ampstack,
+                             float global_ampmax, float local_ampmax, float *seed, unsigned short *posstack,
+                             float *ampstack,
                              float *fft, float *ring_amp, int *ring_pos, unsigned short *surv, PhaseClock &pc) {
   tone_seed_block(P, logfft, global_ampmax, local_ampmax, seed, fft, pc);
   const int nsurv = tone_chase_thread(seed, P.eighth_octave_lines, P.total_octave_lines, ring_amp, ring_pos, 1, 0, surv);

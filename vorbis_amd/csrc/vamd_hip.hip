@@ -268,8 +268,9 @@ __global__ __launch_bounds__(64) void k_tone_fold(PsyP P0, PsyP P1, DescP d, int
   const int n2 = P.n;
   float *seed = (float *)vamd_smem;
   float *ampstack = seed + nlp;
-  int *posstack = (int *)(ampstack + nlp);
-  float *gmin = (float *)(posstack + nlp);
+  float *gmin = ampstack + nlp;                                               // [ngroups rounded up to 4]
+  const int ng = P0.ngroups > P1.ngroups ? P0.ngroups : P1.ngroups;
+  unsigned short *posstack = (unsigned short *)(gmin + ((ng + 3) & ~3));  // [nlp]
   PhaseClock pc;
   pc.start(d.dbg ? d.dbg + 32 : nullptr);
   WAVE_FOR(q, nlp >> 2)((F4 *)seed)[q] = ((const F4 *)(seed_g + cb * nlp))[q];
@@ -290,14 +291,15 @@ __global__ __launch_bounds__(64) void k_floor(PsyP P0, PsyP P1, FloorP F, DescP 
   const long blk = cb / ch;
   const PsyP &P = d_bt(d, blk) ? P1 : P0;
   const int n2 = P.n;
-  float *mask = (float *)vamd_smem, *lmd = mask + n2;
-  FloorScratch *sc = (FloorScratch *)(lmd + n2);
+  float *mask = (float *)vamd_smem;
+  unsigned char *cls = (unsigned char *)(mask + n2);  // [n2 rounded up to 16]
+  FloorScratch *sc = (FloorScratch *)(cls + ((n2 + 15) & ~15));
   PhaseClock pc;
   pc.start(d.dbg ? d.dbg + 48 : nullptr);
   offset_and_mix_wave(P, noise + cb * n2, tone + cb * n2, logmdct + cb * n2, mdct_raw + cb * n2, mdct + cb * n2, mask,
-                      lmd, pc);
+                      cls, F.twofitatten, pc);
   if (logmask_out) WAVE_FOR(i, n2) logmask_out[cb * n2 + i] = mask[i];
-  const int nzf = floor_fit_render_block(F, n2, mask, lmd, sc, posts + cb * VAMD_POSTS_STRIDE, post_valid + cb,
+  const int nzf = floor_fit_render_block(F, n2, mask, cls, sc, posts + cb * VAMD_POSTS_STRIDE, post_valid + cb,
                                          ilogmask + cb * n2, pc);
   if (LANE == 0) nonzero[cb] = nzf;
   pc.flush();
@@ -808,7 +810,7 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level) {
                          p.ampglob, p.seed);
       hipLaunchKernelGGL(k_tone_chase, dim3((gcb + 63) / 64), dim3(64), (size_t)VAMD_RING * 64 * 8, s,
                          P0.eighth_octave_lines, nl, nlp, (long)gcb, d, p.seed, p.surv, p.nsurv);
-      hipLaunchKernelGGL(k_tone_fold, dim3(gcb), dim3(64), (size_t)(nlp * 3 + n2) * 4, s, P0, P1, d, ch, nlp, p.seed, p.surv,
+      hipLaunchKernelGGL(k_tone_fold, dim3(gcb), dim3(64), (size_t)(nlp * 2 + (((P0.ngroups > P1.ngroups ? P0.ngroups : P1.ngroups) + 3) & ~3)) * 4 + (size_t)nlp * 2, s, P0, P1, d, ch, nlp, p.seed, p.surv,
                          p.nsurv, p.local, p.tone);
     }
     if (overlap) {  // join
@@ -819,11 +821,14 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level) {
     prof_mark(c), R->nst++;
   }
   if (level >= VAMD_LEVEL_FULL) {
-    hipLaunchKernelGGL(k_floor, dim3(gcb), dim3(64), (size_t)n2 * 8 + sizeof(FloorScratch), s, P0, P1, c->B.floor[W],
+    hipLaunchKernelGGL(k_floor, dim3(gcb), dim3(64), (size_t)n2 * 4 + ((n2 + 15) & ~15) + sizeof(FloorScratch), s, P0, P1, c->B.floor[W],
                        d, ch, p.noise, p.tone, p.logmdct, p.mdct_raw, p.mdct, R->io->logmask, p.posts, p.post_valid,
                        p.ilogmask, p.nonzero);
     prof_mark(c), R->nst++;
-    hipLaunchKernelGGL(k_couple, dim3(gb), dim3(64), (size_t)n2 * 12, s, P0, P1, c->B.couple[W], d, p.mdct, p.ilogmask,
+    // the LDS arrays serve noise normalisation's sort only (lib/psy.c:941-1010); without it the
+    // stage is register-only and the CU holds twice as many of its waves
+    const bool norm0 = P0.normal_p && P0.normal_start < n2, norm1 = P1.normal_p && P1.normal_start < n2;
+    hipLaunchKernelGGL(k_couple, dim3(gb), dim3(64), (norm0 || norm1) ? (size_t)n2 * 12 : 0, s, P0, P1, c->B.couple[W], d, p.mdct, p.ilogmask,
                        p.iwork, p.nonzero);
     prof_mark(c), R->nst++;
   }

@@ -85,40 +85,58 @@
 namespace vamd {
 
 #if VAMD_GPU
-VAMD_DEV float wave_max(float v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
-  return v;
+// Full-wave reductions and scans on the VALU's DPP path.  (The __shfl family compiles to
+// ds_bpermute_b32, which occupies the CU's LDS pipe like any other LDS instruction; the ordered
+// phases call these dozens of times per block.)  Every lane must be active; results of the
+// reductions are wave-uniform.  Steps: Hillis-Steele inside each row of 16 (row_shr 1,2,4,8),
+// then row_bcast:15 into rows 1,3 and row_bcast:31 into rows 2,3 -- an inclusive scan whose
+// last lane holds the total.  Lanes without a source keep `ident`.
+#define VAMD_DPP_SCAN(v, ident, OP)                                                  \
+  v = OP(v, __builtin_amdgcn_update_dpp(ident, v, 0x111, 0xf, 0xf, false));          \
+  v = OP(v, __builtin_amdgcn_update_dpp(ident, v, 0x112, 0xf, 0xf, false));          \
+  v = OP(v, __builtin_amdgcn_update_dpp(ident, v, 0x114, 0xf, 0xf, false));          \
+  v = OP(v, __builtin_amdgcn_update_dpp(ident, v, 0x118, 0xf, 0xf, false));          \
+  v = OP(v, __builtin_amdgcn_update_dpp(ident, v, 0x142, 0xa, 0xf, false));          \
+  v = OP(v, __builtin_amdgcn_update_dpp(ident, v, 0x143, 0xc, 0xf, false));
+// idempotent operators (max, or): a lane without a source combines with itself, no identity needed
+#define VAMD_DPP_SCAN_SELF(v, OP)                                                    \
+  { int t_; \
+  t_ = __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false); v = OP(v, t_);     \
+  t_ = __builtin_amdgcn_update_dpp(v, v, 0x112, 0xf, 0xf, false); v = OP(v, t_);     \
+  t_ = __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xf, false); v = OP(v, t_);     \
+  t_ = __builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0xf, false); v = OP(v, t_);     \
+  t_ = __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false); v = OP(v, t_);     \
+  t_ = __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false); v = OP(v, t_); }
+#define VAMD_OP_ADD(a, b) ((a) + (b))
+#define VAMD_OP_OR(a, b) ((a) | (b))
+#define VAMD_OP_IMAX(a, b) ((a) > (b) ? (a) : (b))
+#define VAMD_OP_FMAXBITS(a, b) __float_as_int(fmaxf(__int_as_float(a), __int_as_float(b)))
+VAMD_DEV float wave_max(float x) {
+  int v = __float_as_int(x);
+  VAMD_DPP_SCAN_SELF(v, VAMD_OP_FMAXBITS)
+  return __int_as_float(__builtin_amdgcn_readlane(v, 63));
 }
 VAMD_DEV int wave_sum(int v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-  return v;
+  VAMD_DPP_SCAN(v, 0, VAMD_OP_ADD)
+  return __builtin_amdgcn_readlane(v, 63);
 }
 VAMD_DEV int wave_any(int pred) { return __any(pred); }
-VAMD_DEV unsigned long long wave_or64(unsigned long long v) {
-  unsigned int lo = (unsigned int)v, hi = (unsigned int)(v >> 32);
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) {
-    lo |= (unsigned int)__shfl_xor((int)lo, m, 64);
-    hi |= (unsigned int)__shfl_xor((int)hi, m, 64);
-  }
-  return ((unsigned long long)hi << 32) | lo;
+VAMD_DEV unsigned long long wave_or64(unsigned long long x) {
+  int lo = (int)(unsigned int)x, hi = (int)(unsigned int)(x >> 32);
+  VAMD_DPP_SCAN_SELF(lo, VAMD_OP_OR)
+  VAMD_DPP_SCAN_SELF(hi, VAMD_OP_OR)
+  return ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane(hi, 63) << 32) |
+         (unsigned int)__builtin_amdgcn_readlane(lo, 63);
 }
 // inclusive prefix max over the lanes of the wave
 VAMD_DEV int wave_scan_max(int v) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int o = __shfl_up(v, d, 64);
-    if (LANE >= d) v = v > o ? v : o;
-  }
+  VAMD_DPP_SCAN_SELF(v, VAMD_OP_IMAX)
   return v;
 }
 VAMD_DEV int wave_shift_up1(int v, int fill) {  // lane l gets lane l-1's value, lane 0 gets `fill`
-  const int o = __shfl_up(v, 1, 64);
-  return LANE == 0 ? fill : o;
+  return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false);  // wave_shr:1
 }
-VAMD_DEV int wave_last(int v) { return __shfl(v, 63, 64); }
+VAMD_DEV int wave_last(int v) { return __builtin_amdgcn_readlane(v, 63); }
 VAMD_DEV int wave_first(int v) { return __builtin_amdgcn_readfirstlane(v); }
 VAMD_DEV float f_from_bits(uint32_t u) { return __uint_as_float(u); }
 VAMD_DEV uint32_t f_bits(float f) { return __float_as_uint(f); }
