@@ -86,13 +86,12 @@ int emul_analyze_block(void *h, const float *pcm, int lW, int W, int nW, int blo
     const int nlp = (P.total_octave_lines + 15) & ~15;
     std::vector<float> S(5 * (n2 + 4)), nz(n2), wk(n2), seed(seed_pad_lo(P.eighth_octave_lines) + nlp + seed_pad_hi(P.eighth_octave_lines), -9999.f), ampstack(nlp), flr(n2), ring_amp(VAMD_RING);
     std::vector<int> ring_pos(VAMD_RING);
-    std::vector<unsigned short> posstack(nlp);
     std::vector<unsigned short> surv(nlp);
     FloorScratch sc;
     for (int i = 0; i < ch; i++) {
       noisemask_block(P, &logmdct[i * n2], &noise[i * n2], S.data(), pc);
-      tonemask_block(P, &logfft[i * n2], &tone[i * n2], global, local[i], seed.data() + seed_pad_lo(P.eighth_octave_lines), posstack.data(),
-                     ampstack.data(), flr.data(), ring_amp.data(), ring_pos.data(), surv.data(), pc);
+      tonemask_block(P, &logfft[i * n2], &tone[i * n2], global, local[i], seed.data() + seed_pad_lo(P.eighth_octave_lines), ampstack.data(),
+                     flr.data(), ring_amp.data(), ring_pos.data(), surv.data(), pc);
       offset_and_mix_wave(P, &noise[i * n2], &tone[i * n2], &logmdct[i * n2], &mdct_raw[i * n2], &mdct[i * n2],
                           mask.data(), (unsigned char *)lmd.data(), F.twofitatten, pc);
       memcpy(&logmask[i * n2], mask.data(), sizeof(float) * n2);

@@ -64,19 +64,24 @@ VAMD_DEV void seed_curve_scatter(float *seed, const float *__restrict__ band_row
 // end_k = next.pos if the next entry is louder else pos_k + linesper + 1 (clipped
 // to n) and start_k = max(end_0 .. end_{k-1}) because the reference's write
 // pointer only moves forward.  Spans are disjoint, so all lanes paint at once.
-VAMD_DEV void seed_chase_paint(float *seeds, int linesper, int n, int stack, const unsigned short *posstack,
-                               const float *ampstack) {
+//   seeds     LDS, painted in place;  src  the unpainted seed values (HBM copy): an entry's
+//             amplitude is src[its line], read there because painting may already have covered it
+//   posstack  the survivor list (HBM)
+VAMD_DEV void seed_chase_paint(float *seeds, const float *__restrict__ src, int linesper, int n, int stack,
+                               const unsigned short *__restrict__ posstack) {
   int carry = 0;
   for (int base = 0; base < stack; base += NLANES) {
     const int k = base + LANE;
     int endpos = 0;
     float a = 0.f;
     if (k < stack) {
-      a = ampstack[k];
-      if (k < stack - 1 && ampstack[k + 1] > a)
-        endpos = posstack[k + 1];
-      else
-        endpos = posstack[k] + linesper + 1;
+      const int pos = posstack[k];
+      a = src[pos];
+      endpos = pos + linesper + 1;
+      if (k < stack - 1) {
+        const int npos = posstack[k + 1];
+        if (src[npos] > a) endpos = npos;
+      }
       if (endpos > n) endpos = n;
     }
     const int incl = wave_scan_max(endpos);
@@ -149,13 +154,16 @@ VAMD_DEV int tone_chase_thread(const float *__restrict__ seeds, int linesper, in
 }
 
 // scatter half: seed[] for one channel-block (LDS), lib/psy.c:417-452,762-771
+// logfft is read straight from HBM: each lane walks the few bins of its own run, neighbouring
+// lanes walk neighbouring runs, and a copy in LDS would only cost the block its co-residency
 VAMD_DEV void tone_seed_block(const PsyP &P, const float *__restrict__ logfft, float global_ampmax,
-                              float local_ampmax, float *seed, float *fft, PhaseClock &pc) {
+                              float local_ampmax, float *seed, PhaseClock &pc) {
   const int n = P.n, nlines = P.total_octave_lines;
   float att = local_ampmax + P.ath_adjatt;
   if (att < P.ath_maxatt) att = P.ath_maxatt;
+  const float *__restrict__ fft = logfft;
+  (void)n;
   WAVE_FOR(i, nlines) seed[i] = VAMD_NEGINF;  // (the padding either side is write-only)
-  WAVE_FOR(q, n >> 2)((F4 *)fft)[q] = ((const F4 *)logfft)[q];
   WAVE_SYNC();
   pc.mark(0);
   const float dBoffset = P.max_curve_dB - global_ampmax;
@@ -175,21 +183,15 @@ VAMD_DEV void tone_seed_block(const PsyP &P, const float *__restrict__ logfft, f
   pc.mark(1);
 }
 
-// paint + fold half: seed[] (LDS, unpainted), the survivor list -> tone curve
-//   posstack/ampstack LDS [nlines]
-VAMD_DEV void tone_fold_block(const PsyP &P, float local_ampmax, float *seed, const unsigned short *__restrict__ surv,
-                              int nsurv, unsigned short *posstack, float *ampstack, float *gmin /* LDS [ngroups] */,
+// paint + fold half: seed[] (LDS, unpainted on entry), its unpainted HBM copy, the survivor
+// list -> tone curve
+VAMD_DEV void tone_fold_block(const PsyP &P, float local_ampmax, float *seed, const float *__restrict__ seed_src,
+                              const unsigned short *__restrict__ surv, int nsurv, float *gmin /* LDS [ngroups] */,
                               float *__restrict__ out, PhaseClock &pc) {
   const int n = P.n, nlines = P.total_octave_lines;
   float att = local_ampmax + P.ath_adjatt;
   if (att < P.ath_maxatt) att = P.ath_maxatt;
-  WAVE_FOR(k, nsurv) {
-    const int pos = surv[k];
-    posstack[k] = (unsigned short)pos;
-    ampstack[k] = seed[pos];
-  }
-  WAVE_SYNC();
-  seed_chase_paint(seed, P.eighth_octave_lines, nlines, nsurv, posstack, ampstack);
+  seed_chase_paint(seed, seed_src, P.eighth_octave_lines, nlines, nsurv, surv);
   WAVE_SYNC();
   pc.mark(3);
 
@@ -240,15 +242,16 @@ VAMD_DEV void tone_fold_block(const PsyP &P, float local_ampmax, float *seed, co
 
 // _vp_tonemask(p, logfft, logmask, global_specmax, local_specmax), one block end to
 // end (the test build; the GPU runs the three pieces as separate launches)
-//   seed LDS [seed_pad_lo | nlines padded to 16 | seed_pad_hi] (pointer at line 0), fft LDS [n], posstack/ampstack LDS [nlines],
+//   seed LDS [seed_pad_lo | nlines padded to 16 | seed_pad_hi] (pointer at line 0), fft LDS [n],
+//   seed_copy [nlines] scratch for the unpainted values, posstack/ampstack LDS [nlines],
 //   ring_amp/ring_pos [VAMD_RING], surv [nlines]
 VAMD_DEV void tonemask_block(const PsyP &P, const float *__restrict__ logfft, float *__restrict__ out,
-                             float global_ampmax, float local_ampmax, float *seed, unsigned short *posstack,
-                             float *ampstack,
+                             float global_ampmax, float local_ampmax, float *seed, float *seed_copy,
                              float *fft, float *ring_amp, int *ring_pos, unsigned short *surv, PhaseClock &pc) {
-  tone_seed_block(P, logfft, global_ampmax, local_ampmax, seed, fft, pc);
+  tone_seed_block(P, logfft, global_ampmax, local_ampmax, seed, pc);
   const int nsurv = tone_chase_thread(seed, P.eighth_octave_lines, P.total_octave_lines, ring_amp, ring_pos, 1, 0, surv);
-  tone_fold_block(P, local_ampmax, seed, surv, nsurv, posstack, ampstack, fft /* reused as gmin */, out, pc);
+  for (int i = 0; i < P.total_octave_lines; i++) seed_copy[i] = seed[i];  // (single-lane test build only)
+  tone_fold_block(P, local_ampmax, seed, seed_copy, surv, nsurv, fft /* reused as gmin */, out, pc);
 }
 
 }  // namespace vamd

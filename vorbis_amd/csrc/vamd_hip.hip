@@ -233,11 +233,11 @@ __global__ __launch_bounds__(64) void k_tone_seed(PsyP P0, PsyP P1, DescP d, int
   const long blk = cb / ch;
   const PsyP &P = d_bt(d, blk) ? P1 : P0;
   const int n2 = P.n, nl = P.total_octave_lines;
-  float *fft = (float *)vamd_smem;
-  float *seed = fft + n2 + seed_pad_lo(P.eighth_octave_lines);  // padded either side, see seed_curve_scatter
+  float *seed = (float *)vamd_smem + seed_pad_lo(P.eighth_octave_lines);  // padded either side, see seed_curve_scatter
+  (void)n2;
   PhaseClock pc;
   pc.start(d.dbg ? d.dbg + 32 : nullptr);
-  tone_seed_block(P, logfft + cb * n2, ampmax_glob[blk], local_ampmax[cb], seed, fft, pc);
+  tone_seed_block(P, logfft + cb * n2, ampmax_glob[blk], local_ampmax[cb], seed, pc);
   WAVE_FOR(i, nlp) seed_g[cb * nlp + i] = i < nl ? seed[i] : VAMD_NEGINF;
   pc.flush();
 }
@@ -266,17 +266,13 @@ __global__ __launch_bounds__(64) void k_tone_fold(PsyP P0, PsyP P1, DescP d, int
   const long blk = cb / ch;
   const PsyP &P = d_bt(d, blk) ? P1 : P0;
   const int n2 = P.n;
-  float *seed = (float *)vamd_smem;
-  float *ampstack = seed + nlp;
-  float *gmin = ampstack + nlp;                                               // [ngroups rounded up to 4]
-  const int ng = P0.ngroups > P1.ngroups ? P0.ngroups : P1.ngroups;
-  unsigned short *posstack = (unsigned short *)(gmin + ((ng + 3) & ~3));  // [nlp]
+  float *seed = (float *)vamd_smem;  // [nlp]
+  float *gmin = seed + nlp;          // [ngroups]
   PhaseClock pc;
   pc.start(d.dbg ? d.dbg + 32 : nullptr);
   WAVE_FOR(q, nlp >> 2)((F4 *)seed)[q] = ((const F4 *)(seed_g + cb * nlp))[q];
   WAVE_SYNC();
-  tone_fold_block(P, local_ampmax[cb], seed, surv + cb * nlp, nsurv[cb], posstack, ampstack, gmin, tone + cb * n2,
-                  pc);
+  tone_fold_block(P, local_ampmax[cb], seed, seed_g + cb * nlp, surv + cb * nlp, nsurv[cb], gmin, tone + cb * n2, pc);
   pc.flush();
 }
 
@@ -805,12 +801,12 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level) {
     if (overlap) s = c->side;
     {
       const int nlp = (nl + 15) & ~15;
-      const size_t seed_lds = (size_t)(n2 + seed_pad_lo(P0.eighth_octave_lines) + nlp + seed_pad_hi(P0.eighth_octave_lines)) * 4;
+      const size_t seed_lds = (size_t)(seed_pad_lo(P0.eighth_octave_lines) + nlp + seed_pad_hi(P0.eighth_octave_lines)) * 4;
       hipLaunchKernelGGL(k_tone_seed, dim3(gcb), dim3(64), seed_lds, s, P0, P1, d, ch, nlp, p.logfft, p.local,
                          p.ampglob, p.seed);
       hipLaunchKernelGGL(k_tone_chase, dim3((gcb + 63) / 64), dim3(64), (size_t)VAMD_RING * 64 * 8, s,
                          P0.eighth_octave_lines, nl, nlp, (long)gcb, d, p.seed, p.surv, p.nsurv);
-      hipLaunchKernelGGL(k_tone_fold, dim3(gcb), dim3(64), (size_t)(nlp * 2 + (((P0.ngroups > P1.ngroups ? P0.ngroups : P1.ngroups) + 3) & ~3)) * 4 + (size_t)nlp * 2, s, P0, P1, d, ch, nlp, p.seed, p.surv,
+      hipLaunchKernelGGL(k_tone_fold, dim3(gcb), dim3(64), (size_t)(nlp + (P0.ngroups > P1.ngroups ? P0.ngroups : P1.ngroups)) * 4, s, P0, P1, d, ch, nlp, p.seed, p.surv,
                          p.nsurv, p.local, p.tone);
     }
     if (overlap) {  // join
