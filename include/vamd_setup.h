@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define VAMD_SETUP_MAGIC   0x31544553444d4156ULL /* "VAMDSET1" little-endian */
-#define VAMD_SETUP_VERSION 3u
+#define VAMD_SETUP_VERSION 4u
 
 #define VAMD_PACKETBLOBS   15  /* lib/codec_internal.h:28 */
 #define VAMD_P_BANDS       17  /* lib/psy.h:28 */
@@ -144,6 +144,32 @@ typedef struct vamd_envelope_tab {
   uint32_t off_window;                      /* float[n]  mdct_win = sin^2 */
 } vamd_envelope_tab;
 
+/* residue back-end of one mode: vorbis_info_residue0 (lib/backends.h:103-118)
+ * with its book list expanded per class and stage as res0_look does (lib/res0.c:201-224) */
+#define VAMD_RES_MAXCLASS 64
+#define VAMD_RES_MAXSTAGE 8
+typedef struct vamd_residue_tab {
+  int32_t type;          /* ci->residue_type[]; the GPU covers type 2 (interleaved channels) */
+  int32_t begin, end;    /* in interleaved samples for type 2 */
+  int32_t grouping;      /* samples per partition */
+  int32_t partitions;    /* classes */
+  int32_t stages;        /* max ilog(secondstages[]) */
+  int32_t groupbook;     /* phrase book number */
+  int32_t groupbook_dim; /* partitions per phrase word */
+  int32_t secondstages[VAMD_RES_MAXCLASS];
+  int32_t classmetric1[VAMD_RES_MAXCLASS];
+  int32_t classmetric2[VAMD_RES_MAXCLASS];
+  int32_t partbooks[VAMD_RES_MAXCLASS][VAMD_RES_MAXSTAGE]; /* book number, -1 = none */
+} vamd_residue_tab;
+
+/* the encode side of one codebook (lib/codebook.h:57-71): a centred integer lattice */
+typedef struct vamd_book_tab {
+  int32_t  dim, entries;
+  int32_t  minval, delta, quantvals;
+  uint32_t off_lengths;  /* int8[entries] codeword lengths (<= 0: unused entry) */
+  int32_t  pad[2];
+} vamd_book_tab;
+
 typedef struct vamd_setup_header {
   uint64_t magic;
   uint32_t version;
@@ -158,6 +184,9 @@ typedef struct vamd_setup_header {
   vamd_psy_global_tab psy_g;
   vamd_mode_tab       mode[2];
   vamd_envelope_tab   env;
+  vamd_residue_tab    res[2];      /* per mode W */
+  int32_t             nbooks;      /* ci->books */
+  uint32_t            off_books;   /* vamd_book_tab[nbooks] */
 } vamd_setup_header;
 
 #ifdef __cplusplus

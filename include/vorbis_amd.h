@@ -125,7 +125,19 @@ typedef struct vamd_batch_io {
   int32_t *nonzero;       /* out [nb][ch] after _vp_couple_quantize_normalize's fix-up */
   float   *local_ampmax;  /* out [nb][ch] */
   float   *ampmax_out;    /* out [nb] vbi->ampmax on exit (lib/mapping0.c:576) */
+  /* residue back-end, level FULL only, all three or none: what res2_class
+   * decides and, in the order res2_forward emits them, the codebook entries its lattice search
+   * picks (lib/res0.c:479-532,783-809,534-640,322-410).  Available when vamd_residue_capacity() > 0. */
+  int32_t  *res_class;    /* out [nb][VAMD_RES_CLASS_STRIDE] class of each partition */
+  uint16_t *res_entries;  /* out [nb][vamd_residue_capacity(ctx, W)] entry numbers, (stage, partition, vector) order */
+  int32_t  *res_count;    /* out [nb][2] {partitions classified (0 = nothing to code), entries} */
 } vamd_batch_io;
+
+#define VAMD_RES_CLASS_STRIDE 64 /* ints per block in res_class[] (>= (end-begin)/grouping) */
+
+/* Entries one block of size class W can emit at most (the row length of res_entries), or 0 when the
+ * mode's residue is not covered on the GPU (type 2 over a 2-channel bundle and type 1 over one channel are). */
+int vamd_residue_capacity(const vamd_ctx *ctx, int W);
 
 /* how far down mapping0_forward the batch runs */
 #define VAMD_LEVEL_TRANSFORM 1 /* window, MDCT, FFT, logfft/logmdct, local ampmax (lib/mapping0.c:254-360,384) */
@@ -194,6 +206,14 @@ int vamd_envelope_search_batch(vamd_ctx *ctx, const float *pcm, long stream_stri
  * pcm[c] points at the first sample of the first step; state and ret are host memory. */
 int vamd_envelope_search(vamd_ctx *ctx, const float *const *pcm, long nsteps, vamd_envelope_state *state,
                          unsigned char *ret);
+
+/* vamd_analyze_block() plus the residue back-end's decisions for the block (host pointers; any may be
+ * NULL).  res_entries must hold vamd_residue_capacity(ctx, W) entries, res_class VAMD_RES_CLASS_STRIDE
+ * ints, res_count 2 ints.  Fails with VAMD_EIMPL when res_* are asked for a mode that is not covered. */
+int vamd_analyze_block_res(vamd_ctx *ctx, const float *const *pcm, int lW, int W, int nW, int blocktype,
+                           float ampmax_in, float *mdct, float *logmask, int32_t *posts, int32_t *post_valid,
+                           int32_t *iwork, int32_t *nonzero, float *ampmax_out, int32_t *res_class,
+                           uint16_t *res_entries, int32_t *res_count);
 
 /* winlength / searchstep of the detector (128 / 64 in every libvorbis setup). */
 int vamd_envelope_geometry(const vamd_ctx *ctx, int *winlength, int *searchstep);

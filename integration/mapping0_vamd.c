@@ -32,6 +32,9 @@
 #include "vorbis_amd.h"
 
 extern long vamd_pack_setup(vorbis_dsp_state *vd, void *dst, long cap);
+/* res0_vamd.c: res2_forward for classes / entries the GPU already chose */
+extern int vamd_res2_forward(oggpack_buffer *opb, vorbis_block *vb, vorbis_look_residue *vl, const int32_t *res_class,
+                             long partvals, const uint16_t *entries, long nentries);
 
 /* one GPU context per analysis state, created on first use (vorbis_analysis_init has
  * already built every lookup by then).  A real integration would hang the pointer off
@@ -110,8 +113,10 @@ static int mapping0_forward_vamd(vorbis_block *vb) {
   vamd_ctx *ctx;
   float *mdct;
   int *iwork, *posts, *post_valid, *nonzero, *scratch;
+  int32_t *res_class = NULL, res_count[2] = {0, 0};
+  uint16_t *res_entries = NULL;
   float ampmax_out;
-  int i, j, ret;
+  int i, j, ret, rescap;
 
   if (vorbis_bitrate_managed(vb) || ch > VAMD_MAX_CH) return mapping0_forward(vb);
   ctx = vamd_ctx_for(vd);
@@ -127,8 +132,16 @@ static int mapping0_forward_vamd(vorbis_block *vb) {
 
   /* ---- the numeric section: window, MDCT, FFT, masking, floor fit, floor curve,
      couple/quantise -- one call (lib/mapping0.c:254-576,613-646) */
-  ret = vamd_analyze_block(ctx, (const float *const *)vb->pcm, vb->lW, vb->W, vb->nW, vbi->blocktype, vbi->ampmax,
-                           mdct, NULL, posts, post_valid, iwork, nonzero, &ampmax_out);
+  /* where the mode's residue is covered (type 2 stereo / type 1 mono, one submap), its classification and lattice search
+     come back with the same call and the host only writes bits */
+  rescap = info->submaps == 1 ? vamd_residue_capacity(ctx, vb->W) : 0;
+  if (rescap > 0) {
+    res_class = _vorbis_block_alloc(vb, VAMD_RES_CLASS_STRIDE * sizeof(*res_class));
+    res_entries = _vorbis_block_alloc(vb, rescap * sizeof(*res_entries));
+  }
+  ret = vamd_analyze_block_res(ctx, (const float *const *)vb->pcm, vb->lW, vb->W, vb->nW, vbi->blocktype, vbi->ampmax,
+                               mdct, NULL, posts, post_valid, iwork, nonzero, &ampmax_out, res_class, res_entries,
+                               rescap > 0 ? res_count : NULL);
   if (ret) {
     fprintf(stderr, "vorbis_amd: block analysis failed (%d): %s\n", ret, vamd_last_error(ctx));
     return ret;
@@ -155,6 +168,12 @@ static int mapping0_forward_vamd(vorbis_block *vb) {
       floor1_encode(opb, vb, b->flr[info->floorsubmap[submap]],
                     post_valid[i] ? posts + i * VAMD_POSTS_STRIDE : NULL, scratch);
     }
+    if (rescap > 0) {
+      /* lib/mapping0.c:673-683 with the search done: the reference's _01forward writes the bits */
+      if (vamd_res2_forward(opb, vb, b->residue[info->residuesubmap[0]], res_class, res_count[0], res_entries,
+                            res_count[1]))
+        return OV_EFAULT;
+    } else
     for (i = 0; i < info->submaps; i++) {
       int ch_in_bundle = 0;
       long **classifications;

@@ -22,6 +22,7 @@
 #include "smallft.h"
 #include "psy.h"
 #include "envelope.h"
+#include "codebook.h"
 #include "misc.h"
 #include "vamd_setup.h"
 
@@ -226,6 +227,56 @@ long vamd_pack_setup(vorbis_dsp_state *vd, void *dst, long cap) {
     put(dst, t->off_mdct_bitrev, ve->mdct.bitrev, (uint32_t)(n / 4) * 4u);
     t->off_window = place(&cur, (uint32_t)n * 4u);
     put(dst, t->off_window, ve->mdct_win, (uint32_t)n * 4u);
+  }
+
+  {
+    /* residue back-ends and the codebooks they search (lib/res0.c:175-260, lib/sharedbook.c) */
+    vamd_book_tab *books = NULL;
+    if (ci->books < 0 || ci->books > 256) return OV_EIMPL;
+    h.nbooks = ci->books;
+    h.off_books = place(&cur, (uint32_t)(ci->books * sizeof(vamd_book_tab)));
+    if (dst) books = (vamd_book_tab *)((char *)dst + h.off_books);
+    for (i = 0; i < ci->books; i++) {
+      const codebook *cb = ci->fullbooks + i;
+      uint32_t off = place(&cur, (uint32_t)cb->entries);
+      if (dst) {
+        vamd_book_tab *t = books + i;
+        t->dim = (int32_t)cb->dim;
+        t->entries = (int32_t)cb->entries;
+        t->minval = cb->minval;
+        t->delta = cb->delta;
+        t->quantvals = cb->quantvals;
+        t->off_lengths = off;
+        for (j = 0; j < cb->entries; j++) ((signed char *)dst)[off + j] = (signed char)cb->c->lengthlist[j];
+      }
+    }
+    for (W = 0; W < 2; W++) {
+      vorbis_info_mapping0 *map = (vorbis_info_mapping0 *)ci->map_param[ci->mode_param[W]->mapping];
+      int resnum = map->residuesubmap[0], acc = 0, maxstage = 0;
+      vorbis_info_residue0 *ri = (vorbis_info_residue0 *)ci->residue_param[resnum];
+      vamd_residue_tab *t = &h.res[W];
+      t->type = ci->residue_type[resnum];
+      t->begin = (int32_t)ri->begin;
+      t->end = (int32_t)ri->end;
+      t->grouping = ri->grouping;
+      t->partitions = ri->partitions;
+      t->groupbook = ri->groupbook;
+      t->groupbook_dim = (int32_t)ci->fullbooks[ri->groupbook].dim;
+      if (ri->partitions > VAMD_RES_MAXCLASS) return OV_EIMPL;
+      for (i = 0; i < ri->partitions; i++) {
+        int stages = 0, v = ri->secondstages[i];
+        while (v) { stages++; v >>= 1; } /* ilog, lib/res0.c:210 */
+        if (stages > VAMD_RES_MAXSTAGE) return OV_EIMPL;
+        if (stages > maxstage) maxstage = stages;
+        t->secondstages[i] = ri->secondstages[i];
+        t->classmetric1[i] = ri->classmetric1[i];
+        t->classmetric2[i] = ri->classmetric2[i];
+        for (j = 0; j < VAMD_RES_MAXSTAGE; j++) t->partbooks[i][j] = -1;
+        for (j = 0; j < stages; j++)
+          if (ri->secondstages[i] & (1 << j)) t->partbooks[i][j] = ri->booklist[acc++]; /* lib/res0.c:214-222 */
+      }
+      t->stages = maxstage;
+    }
   }
 
   cur = (cur + 15u) & ~15u;

@@ -20,7 +20,9 @@ class _Taps(C.Structure):
     _fields_ = [(k, _f32p) for k in ("windowed", "mdct_raw", "fft_packed", "logfft", "logmdct", "noise", "tone",
                                      "logmask", "mdct")] + \
                [(k, _i32p) for k in ("posts", "post_valid", "ilogmask", "iwork", "nonzero")] + \
-               [("local_ampmax", _f32p), ("ampmax_out", _f32p)]
+               [("local_ampmax", _f32p), ("ampmax_out", _f32p)] + \
+               [("res_class", _i32p), ("res_class_cap", C.c_long), ("res_partvals", C.c_long),
+                ("res_entries", C.POINTER(C.c_ushort)), ("res_entries_cap", C.c_long), ("res_count", C.c_long)]
 
 
 class _PortEnvFilter(C.Structure):  # port_env_filter == envelope_filter_state (lib/envelope.h:34-45)
@@ -142,10 +144,16 @@ class PortEncoder:
         t = _Taps()
         for k, v in o.items():
             setattr(t, k, v.ctypes.data_as(_f32p if v.dtype == np.float32 else _i32p))
+        rcls = np.zeros(256, np.int32)
+        rent = np.zeros(1 << 15, np.uint16)
+        t.res_class, t.res_class_cap = rcls.ctypes.data_as(_i32p), rcls.size
+        t.res_entries, t.res_entries_cap = rent.ctypes.data_as(C.POINTER(C.c_ushort)), rent.size
         r = self.L.port_tap_block(self.h, _fp(pcm), lW, W, nW, blocktype, ampmax_in, C.byref(t))
         if r:
             raise RuntimeError("port_tap_block failed: %d" % r)
         o["ampmax_out"] = float(o["ampmax_out"][0])
+        o["res_class"] = rcls[:t.res_partvals].copy()
+        o["res_entries"] = rent[:t.res_count].copy()
         return o
 
     def envelope_steps(self, pcm, nsteps, state=None):

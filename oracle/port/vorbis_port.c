@@ -38,6 +38,11 @@ typedef struct port_taps {
   float *windowed, *mdct_raw, *fft_packed, *logfft, *logmdct, *noise, *tone, *logmask, *mdct;
   int *posts, *post_valid, *ilogmask, *iwork, *nonzero;
   float *local_ampmax, *ampmax_out;
+  /* residue back-end: classes per partition and the codebook entries in emission order */
+  int *res_class;
+  long res_class_cap, res_partvals;
+  unsigned short *res_entries;
+  long res_entries_cap, res_count;
 } port_taps;
 
 static const float *tabf(const port_enc *e, uint32_t off) { return (const float *)(e->blob + off); }
@@ -1179,6 +1184,128 @@ static void couple_quantize(const port_enc *e, int psy, int W, float **mdct, int
   }
 }
 
+/* ---- residue back-end, type 2 (lib/res0.c:322-382,479-532,534-640,766-809) ----------------
+ * What res2_class decides and which codebook entries res2_forward emits, in emission order
+ * (the Huffman/bit-packing of those entries is host code and not restated).  Sequential like
+ * the reference: one running work vector, stages outermost.  Integer arithmetic throughout. */
+static int book_besterror(const port_enc *e, const vamd_book_tab *bk, int *a) { /* local_book_besterror */
+  const signed char *len = (const signed char *)(e->blob + bk->off_lengths);
+  const int dim = bk->dim, minval = bk->minval, del = bk->delta, qv = bk->quantvals, ze = qv >> 1;
+  int i, j, o, index = 0;
+  int p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (del != 1) {
+    for (i = 0, o = dim; i < dim; i++) {
+      int v = (a[--o] - minval + (del >> 1)) / del;
+      int m = (v < ze ? ((ze - v) << 1) - 1 : ((v - ze) << 1));
+      index = index * qv + (m < 0 ? 0 : (m >= qv ? qv - 1 : m));
+      p[o] = v * del + minval;
+    }
+  } else {
+    for (i = 0, o = dim; i < dim; i++) {
+      int v = a[--o] - minval;
+      int m = (v < ze ? ((ze - v) << 1) - 1 : ((v - ze) << 1));
+      index = index * qv + (m < 0 ? 0 : (m >= qv ? qv - 1 : m));
+      p[o] = v * del + minval;
+    }
+  }
+  if (len[index] <= 0) { /* not a populated entry: exhaustive search over the lattice, :349-376 */
+    int best = -1;
+    int ev[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int maxval = minval + del * (qv - 1);
+    for (i = 0; i < bk->entries; i++) {
+      if (len[i] > 0) {
+        int this = 0;
+        for (j = 0; j < dim; j++) {
+          int val = ev[j] - a[j];
+          this += val * val;
+        }
+        if (best == -1 || this < best) {
+          memcpy(p, ev, sizeof(p));
+          best = this;
+          index = i;
+        }
+      }
+      j = 0;
+      while (ev[j] >= maxval) ev[j++] = 0;
+      if (ev[j] >= 0) ev[j] += del;
+      ev[j] = -ev[j];
+    }
+  }
+  if (index > -1)
+    for (i = 0; i < dim; i++) *a++ -= p[i];
+  return index;
+}
+
+/* Type 2 (any channel count, interleaved) and type 1 with a single channel (_01class :412-470,
+ * res1_class/res1_forward :729-755).  Returns 0, or -1 when the mode is not covered. */
+static int residue2(const port_enc *e, int W, int **in, const int *nonzero, port_taps *t) {
+  const vamd_residue_tab *r = &e->h.res[W];
+  const vamd_book_tab *books = (const vamd_book_tab *)(e->blob + e->h.off_books);
+  const int ch = e->h.channels, n2 = e->h.blocksizes[W] / 2;
+  const int spp = r->grouping, nparts = r->partitions, n = r->end - r->begin, partvals = n / spp;
+  int *work, *cls;
+  long i, j, k, l, s, used = 0;
+  t->res_partvals = 0;
+  t->res_count = 0;
+  if (!(r->type == 2 || (r->type == 1 && ch == 1))) return -1;
+  for (i = 0; i < ch; i++)
+    if (nonzero[i]) used++;
+  if (!used) return 0; /* res*_class returns NULL, res*_forward writes nothing */
+  cls = (int *)malloc(sizeof(int) * (partvals + 1));
+  if (r->type == 1) { /* _01class with one channel, :436-453 */
+    const float scale = 100. / spp;
+    for (i = 0; i < partvals; i++) {
+      const int offset = (int)(i * spp + r->begin);
+      int max = 0, ent = 0;
+      for (k = 0; k < spp; k++) {
+        if (abs(in[0][offset + k]) > max) max = abs(in[0][offset + k]);
+        ent += abs(in[0][offset + k]);
+      }
+      ent *= scale;
+      for (k = 0; k < nparts - 1; k++)
+        if (max <= r->classmetric1[k] && (r->classmetric2[k] < 0 || ent < r->classmetric2[k])) break;
+      cls[i] = (int)k;
+      if (t->res_class && i < t->res_class_cap) t->res_class[i] = (int)k;
+    }
+  } else
+  for (i = 0, l = r->begin / ch; i < partvals; i++) { /* _2class, :501-518 */
+    int magmax = 0, angmax = 0;
+    for (j = 0; j < spp; j += ch) {
+      if (abs(in[0][l]) > magmax) magmax = abs(in[0][l]);
+      for (k = 1; k < ch; k++)
+        if (abs(in[k][l]) > angmax) angmax = abs(in[k][l]);
+      l++;
+    }
+    for (j = 0; j < nparts - 1; j++)
+      if (magmax <= r->classmetric1[j] && angmax <= r->classmetric2[j]) break;
+    cls[i] = (int)j;
+    if (t->res_class && i < t->res_class_cap) t->res_class[i] = (int)j;
+  }
+  t->res_partvals = partvals;
+  work = (int *)malloc(sizeof(int) * ch * n2); /* res2_forward, :791-797 */
+  for (i = 0; i < ch; i++)
+    for (j = 0, k = i; j < n2; j++, k += ch) work[k] = in[i][j];
+  for (s = 0; s < r->stages; s++) /* _01forward with ch == 1, :585-636 (phrase words are host code) */
+    for (i = 0; i < partvals; i++) {
+      const long offset = i * spp + r->begin;
+      if (r->secondstages[cls[i]] & (1 << s)) {
+        const int bn = r->partbooks[cls[i]][s];
+        if (bn >= 0) {
+          const vamd_book_tab *bk = books + bn;
+          const int step = spp / bk->dim;
+          for (k = 0; k < step; k++) { /* _encodepart, :396-410 */
+            int entry = book_besterror(e, bk, work + offset + k * bk->dim);
+            if (t->res_entries && t->res_count < t->res_entries_cap) t->res_entries[t->res_count] = (unsigned short)entry;
+            t->res_count++;
+          }
+        }
+      }
+    }
+  free(work);
+  free(cls);
+  return 0;
+}
+
 /* ---- the block: mapping0_forward's VBR path, lib/mapping0.c:254-646 ------------------ */
 int port_tap_block(const port_enc *e, const float *pcm_in, int lW, int W, int nW, int blocktype, float ampmax_in,
                    port_taps *t) {
@@ -1245,6 +1372,7 @@ int port_tap_block(const port_enc *e, const float *pcm_in, int lW, int W, int nW
     if (t->iwork) memcpy(t->iwork + (size_t)i * n2, iwp[i], n2 * sizeof(int));
     if (t->nonzero) t->nonzero[i] = nonzero[i];
   }
+  residue2(e, W, iwp, nonzero, t);
   free(pcm);
   free(gm);
   free(iw);

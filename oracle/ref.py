@@ -33,6 +33,8 @@ class _Taps(C.Structure):
         ("nonzero", _i32p), ("local_ampmax", _f32p), ("ampmax_out", _f32p),
         ("packet", _u8p), ("packet_cap", C.c_long), ("packet_bytes", C.c_long),
         ("packet_matches_real", C.c_int),
+        ("res_class", _i32p), ("res_class_cap", C.c_long), ("res_partvals", C.c_long),
+        ("res_entries", C.POINTER(C.c_ushort)), ("res_entries_cap", C.c_long), ("res_count", C.c_long),
     ]
 
 
@@ -213,12 +215,20 @@ class RefEncoder:
             setattr(t, k, _fp(v) if v.dtype == np.float32 else _ip(v))
         t.packet = pkt.ctypes.data_as(_u8p)
         t.packet_cap = pkt.size
+        rcls = np.zeros(256, np.int32)
+        rent = np.zeros(1 << 15, np.uint16)
+        t.res_class, t.res_class_cap = _ip(rcls), rcls.size
+        t.res_entries, t.res_entries_cap = rent.ctypes.data_as(C.POINTER(C.c_ushort)), rent.size
         ret = self.L.ref_tap_block(self.h, _fp(pcm), lW, W, nW, blocktype, ampmax_in, C.byref(t))
         if ret:
             raise RuntimeError("ref_tap_block failed: %d" % ret)
         o["packet"] = bytes(pkt[:t.packet_bytes])
         o["packet_matches_real"] = bool(t.packet_matches_real)
         o["ampmax_out"] = float(o["ampmax_out"][0])
+        # residue back-end of submap 0: classes per partition, and every codebook entry in emission order
+        assert t.res_count <= rent.size
+        o["res_class"] = rcls[:t.res_partvals].copy()
+        o["res_entries"] = rent[:t.res_count].copy()
         return o
 
     def encode_stream(self, pcm, max_blocks=1 << 16):

@@ -157,7 +157,33 @@ typedef struct ref_taps {
   long packet_cap;
   long packet_bytes;   /* out */
   int packet_matches_real; /* out: 1 when the real vorbis_analysis() produced identical bytes+ampmax */
+  /* residue back-end (submap 0): what res*_class decided and, in call order, every codebook entry
+     res*_forward emitted through vorbis_book_encode() except the phrase-book words */
+  int *res_class;            /* [res_class_cap] partword[0][i] (channel 0 of the bundle) */
+  long res_class_cap;
+  long res_partvals;         /* out: partitions classified (0 when the class function returned NULL) */
+  unsigned short *res_entries;
+  long res_entries_cap;
+  long res_count;            /* out */
 } ref_taps;
+
+/* lib/res0.c is compiled with -Dvorbis_book_encode=ref_tap_book_encode (oracle/Makefile): the
+ * reference source is untouched, its calls to the bit-writer just pass through here first */
+#undef vorbis_book_encode
+extern int vorbis_book_encode(codebook *book, int a, oggpack_buffer *b);
+static struct {
+  int armed;
+  const codebook *skip; /* the phrase book */
+  unsigned short *out;
+  long cap, count;
+} res_tap;
+int ref_tap_book_encode(codebook *book, int a, oggpack_buffer *b) {
+  if (res_tap.armed && book != res_tap.skip) {
+    if (res_tap.out && res_tap.count < res_tap.cap) res_tap.out[res_tap.count] = (unsigned short)a;
+    res_tap.count++;
+  }
+  return vorbis_book_encode(book, a, b);
+}
 
 static void load_block(ref_enc *e, const float *pcm, int lW, int W, int nW, int blocktype,
                        float ampmax_in) {
@@ -313,11 +339,27 @@ static int tap_core(ref_enc *e, const float *pcm, int lW, int W, int nW, int blo
         }
       classifications = _residue_P[ci->residue_type[resnum]]->class(vb, b->residue[resnum], couple_bundle,
                                                                    zerobundle, ch_in_bundle);
+      if (i == 0) {
+        vorbis_info_residue0 *ri = (vorbis_info_residue0 *)ci->residue_param[resnum];
+        long pv = (ri->end - ri->begin) / ri->grouping, p;
+        t->res_partvals = classifications ? pv : 0;
+        if (classifications && t->res_class)
+          for (p = 0; p < pv && p < t->res_class_cap; p++) t->res_class[p] = (int)classifications[0][p];
+        res_tap.armed = 1;
+        res_tap.skip = ci->fullbooks + ri->groupbook;
+        res_tap.out = t->res_entries;
+        res_tap.cap = t->res_entries_cap;
+        res_tap.count = 0;
+      }
       ch_in_bundle = 0;
       for (j = 0; j < ch; j++)
         if (info->chmuxlist[j] == i) couple_bundle[ch_in_bundle++] = iwork[j];
       _residue_P[ci->residue_type[resnum]]->forward(opb, vb, b->residue[resnum], couple_bundle, zerobundle,
                                                      ch_in_bundle, classifications, i);
+      if (i == 0) {
+        res_tap.armed = 0;
+        t->res_count = res_tap.count;
+      }
     }
   }
   t->packet_bytes = oggpack_bytes(opb);

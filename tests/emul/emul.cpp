@@ -3,6 +3,7 @@
 // (vamd_wave.h), so that every stage's arithmetic can be checked bit-for-bit
 // against the reference on a machine without a GPU.  Nothing in the product
 // links or loads this file; the product fails loudly without its HIP library.
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <string>
@@ -14,6 +15,7 @@
 #include "k_floor.h"
 #include "k_couple.h"
 #include "k_envelope.h"
+#include "k_residue.h"
 
 using namespace vamd;
 
@@ -29,6 +31,9 @@ struct EmulTaps {  // arrays [ch][...], any may be null
   float *mdct_raw, *logfft, *logmdct, *noise, *tone, *logmask, *mdct;
   int *posts, *post_valid, *ilogmask, *iwork, *nonzero;
   float *local_ampmax, *ampmax_out;
+  int *res_class;               // [VAMD_RES_CLASS_STRIDE]
+  unsigned short *res_entries;  // [capacity of the mode]
+  int *res_count;               // [2]
 };
 
 extern "C" {
@@ -36,6 +41,7 @@ extern "C" {
 void *emul_open(const void *blob, size_t bytes) {
   Emul *e = new Emul;
   if (build_image(blob, bytes, &e->image, &e->doff, &e->derived, &e->err) != VAMD_OK) {
+    fprintf(stderr, "emul_open: %s\n", e->err.c_str());
     delete e;
     return nullptr;
   }
@@ -43,6 +49,7 @@ void *emul_open(const void *blob, size_t bytes) {
   return e;
 }
 void emul_close(void *h) { delete (Emul *)h; }
+int emul_residue_capacity(void *h, int W) { return ((Emul *)h)->B.res[W].covered ? ((Emul *)h)->B.res[W].cap : 0; }
 
 int emul_mdct_forward(void *h, int W, const float *in, float *out) {
   Emul *e = (Emul *)h;
@@ -111,6 +118,15 @@ int emul_analyze_block(void *h, const float *pcm, int lW, int W, int nW, int blo
       op[i] = &iwork[i * n2];
     }
     couple_block(C, P, n2, mp, ip, op, nonzero.data(), L, pc);
+  }
+  if (t->res_entries && t->res_class && t->res_count) {
+    const ResP &Rp = B.res[W];
+    if (!Rp.covered) return -130;
+    std::vector<int> work(ch * n2), cls(VAMD_RES_CLASS_STRIDE), off(B.res_stages[W] * B.res_partvals[W] + 1);
+    const int *ip[VAMD_MAX_CH];
+    for (int i = 0; i < ch; i++) ip[i] = &iwork[i * n2];
+    residue2_block(Rp, ch, n2, ip, nonzero.data(), work.data(), cls.data(), off.data(), t->res_class, t->res_entries,
+                   t->res_count, pc);
   }
 #define OUT(name, vec, type) \
   if (t->name) memcpy(t->name, vec.data(), sizeof(type) * vec.size())

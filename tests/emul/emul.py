@@ -17,7 +17,8 @@ POSTS_STRIDE = 32
 class _Taps(C.Structure):
     _fields_ = [(k, _f32p) for k in ("mdct_raw", "logfft", "logmdct", "noise", "tone", "logmask", "mdct")] + \
                [(k, _i32p) for k in ("posts", "post_valid", "ilogmask", "iwork", "nonzero")] + \
-               [("local_ampmax", _f32p), ("ampmax_out", _f32p)]
+               [("local_ampmax", _f32p), ("ampmax_out", _f32p)] + \
+               [("res_class", _i32p), ("res_entries", C.POINTER(C.c_ushort)), ("res_count", _i32p)]
 
 
 def build(force=False):
@@ -43,6 +44,7 @@ class Emul:
         self.L.emul_mdct_forward.argtypes = [C.c_void_p, C.c_int, _f32p, _f32p]
         self.L.emul_analyze_block.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                               C.POINTER(_Taps)]
+        self.L.emul_residue_capacity.argtypes = [C.c_void_p, C.c_int]
         self.L.emul_envelope_search.argtypes = [C.c_void_p, _f32p, C.c_long, C.c_long, C.c_void_p, C.c_void_p]
         blob = np.ascontiguousarray(blob, dtype=np.uint8)
         self.h = self.L.emul_open(blob.ctypes.data_as(C.c_void_p), blob.size)
@@ -73,9 +75,17 @@ class Emul:
         t = _Taps()
         for k, v in o.items():
             setattr(t, k, v.ctypes.data_as(_f32p if v.dtype == np.float32 else _i32p))
+        cap = self.L.emul_residue_capacity(self.h, W)
+        if cap > 0:
+            rcls, rent, rcnt = np.zeros(64, np.int32), np.zeros(cap, np.uint16), np.zeros(2, np.int32)
+            t.res_class, t.res_count = rcls.ctypes.data_as(_i32p), rcnt.ctypes.data_as(_i32p)
+            t.res_entries = rent.ctypes.data_as(C.POINTER(C.c_ushort))
         r = self.L.emul_analyze_block(self.h, pcm.ctypes.data_as(_f32p), lW, W, nW, blocktype, ampmax_in, C.byref(t))
         assert r == 0
         o["ampmax_out"] = float(o["ampmax_out"][0])
+        if cap > 0:
+            o["res_class"] = rcls[:rcnt[0]].copy()
+            o["res_entries"] = rent[:rcnt[1]].copy()
         return o
 
     def envelope_search(self, pcm, nsteps, state):

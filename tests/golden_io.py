@@ -5,7 +5,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TAPS = ("windowed", "mdct_raw", "fft_packed", "logfft", "logmdct", "noise", "tone", "logmask", "mdct", "posts",
-        "post_valid", "ilogmask", "iwork", "nonzero", "local_ampmax")
+        "post_valid", "ilogmask", "iwork", "nonzero", "local_ampmax", "res_class", "res_entries")
 
 
 def load(setup_name):

@@ -4,7 +4,8 @@ oracle/_ref/libvorbis_hybrid.so is the reference's own libvorbis objects with li
 by the binding integration/mapping0_vamd.c (numeric section -> libvorbis_amd.so, bit-writing half
 unchanged) and lib/envelope.c replaced by integration/envelope_vamd.c (the block-switching detector's
 steps -> libvorbis_amd.so, mark/cursor bookkeeping unchanged), so on the gated streams below the GPU
-also decides where the short blocks go.  Driving the unmodified application loop (vorbis_analysis_buffer / _wrote / _blockout /
+also decides where the short blocks go; and lib/res0.c replaced by integration/res0_vamd.c (partition
+classes and lattice-VQ entries come from libvorbis_amd.so, the reference's _01forward writes their bits).  Driving the unmodified application loop (vorbis_analysis_buffer / _wrote / _blockout /
 vorbis_analysis, examples/encoder_example.c:179-236) through it must yield the very packets the
 pure CPU reference emits -- the strongest parity statement the domain offers: every float and integer
 the GPU produced went through the reference's Huffman/VQ back-end and came out as identical bytes.
@@ -34,6 +35,7 @@ def _stream(ch, seconds, kind, seed):
 @pytest.mark.parametrize("ch,q,kind", [(2, 0.4, "s16"), (2, 0.9, "gated"), (2, 0.1, "gated"), (1, 0.5, "gated")])
 def test_hybrid_encode_emits_reference_packets(ch, q, kind):
     assert hasattr(ref.lib(hybrid=True), "_ve_envelope_search_cpu")  # the detector binding is linked in
+    assert hasattr(ref.lib(hybrid=True), "vamd_res2_forward")        # ... and the residue binding
     pcm = _stream(ch, 1.0 if kind == "s16" else 2.0, kind, seed=12345)
     want = ref.RefEncoder(ch, 44100, q).encode_stream(pcm)
     got = ref.RefEncoder(ch, 44100, q, hybrid=True).encode_stream(pcm)

@@ -1,0 +1,144 @@
+"""The residue back-end's numeric half (res*_class + the lattice-VQ search of res*_forward, reference
+lib/res0.c:322-640,729-809).
+
+What pins what:
+  * the reference's own decisions are tapped without editing it: lib/res0.c is compiled with
+    -Dvorbis_book_encode=ref_tap_book_encode (oracle/Makefile), so every codebook entry it emits passes
+    through the harness on its way to the real bit-writer; classes come from the extern class function.
+    tests/golden/blocks_*.npz carry both for every fixture block (tools/make_golden.py).
+  * oracle/port (sequential restatement) and the kernel bodies compiled for the host must reproduce
+    them exactly -- CPU suite; the HIP library must too, per block and batched -- GPU suite.
+  * end to end, tests/test_gpu_dropin.py: the hybrid libvorbis writes its residue bits from these
+    entries (integration/res0_vamd.c) and still emits byte-identical packets.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import vorbis_amd
+from oracle import port, ref
+from tests import checker, golden_io
+
+ROOT = checker.ROOT
+NAMES = list(checker.SETUPS)
+
+
+def blob_of(name):
+    return np.fromfile(os.path.join(ROOT, "vorbis_amd", "data", "setup_%s.bin" % name), dtype=np.uint8)
+
+
+def same(a, b):
+    return np.array_equal(a["res_class"], b["res_class"]) and np.array_equal(a["res_entries"], b["res_entries"])
+
+
+# ------------------------------------------------------------------------------------------
+# CPU suite
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", NAMES)
+def test_port_and_kernel_bodies_match_golden(name):
+    from tests.emul.emul import Emul
+    blocks, _, _ = golden_io.load(name)
+    p, em = port.PortEncoder(blob_of(name)), Emul(blob_of(name))
+    coded = 0
+    for b in blocks:
+        args = (b["pcm"], b["lW"], b["W"], b["nW"], b["blocktype"], b["ampmax_in"])
+        assert same(b, p.tap_block(*args)), ("port", b["W"], b["blocktype"])
+        assert same(b, em.analyze_block(*args)), ("kernel bodies", b["W"], b["blocktype"])
+        coded += len(b["res_entries"])
+    assert coded > 1000                                   # the fixtures do exercise the search
+    assert any(len(b["res_class"]) == 0 for b in blocks)  # ... and the nothing-to-code case (silence)
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built (needs /root/reference)")
+@pytest.mark.parametrize("quality", [-0.1, 0.1, 0.4, 0.7, 1.0])
+def test_against_reference_random_blocks(quality):
+    """Every libvorbisenc quality (different book sets, class tables, residue ends), both block sizes;
+    loud blocks push values off the lattice books' populated entries (the exhaustive-search branch)."""
+    from tests.emul.emul import Emul
+    r = ref.RefEncoder(2, 44100, quality)
+    blob = r.pack_setup()
+    p = port.PortEncoder(blob)
+    em = Emul(blob) if r.blocksize(1) <= 2048 else None  # the kernels cover block sizes up to 2048
+    rng = np.random.default_rng(int(quality * 100) + 77)
+    for it in range(6):
+        W = 0 if it == 5 else 1
+        n = r.blocksize(W)
+        amp = [0.5, 0.01, 1.0, 1e-4, 0.9, 0.7][it]
+        pcm = ((rng.random((2, n), dtype=np.float32) - 0.5) * 2 * amp).astype(np.float32)
+        if it == 4:
+            pcm[:, ::7] *= -1.0  # spiky: large isolated residues
+        args = (pcm, W, W, W, 1 if W else 0)
+        a = r.tap_block(*args)
+        assert a["packet_matches_real"]
+        assert same(a, p.tap_block(*args)), ("port", it)
+        if em is not None:
+            assert same(a, em.analyze_block(*args)), ("kernel bodies", it)
+
+
+def test_residue_tables_in_blob_are_consistent():
+    """Capacity bound: no class can emit more vectors per partition than the row length assumes."""
+    from tests.emul.emul import Emul
+    for name in NAMES:
+        em = Emul(blob_of(name))
+        for W in (0, 1):
+            cap = em.L.emul_residue_capacity(em.h, W)
+            assert cap > 0, (name, W)        # all four shipped setups are covered (type 2 stereo, type 1 mono)
+            assert cap <= 64 * 64
+
+
+# ------------------------------------------------------------------------------------------
+# GPU suite (through the C ABI)
+# ------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_gpu_block_api_matches_golden(name):
+    blocks, _, _ = golden_io.load(name)
+    an = vorbis_amd.Analyzer(blob_of(name), 0)
+    for b in blocks:
+        g = an.analyze_block(b["pcm"], b["lW"], b["W"], b["nW"], b["blocktype"], b["ampmax_in"])
+        assert same(b, g), (b["W"], b["blocktype"])
+        assert np.array_equal(g["iwork"], b["iwork"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["44k_stereo_q4", "44k_stereo_q9", "44k_stereo_q1", "44k_mono_q5"])
+def test_gpu_batch_matches_checker(name):
+    import torch
+    chk = checker.Checker(name)
+    an = vorbis_amd.Analyzer(blob_of(name), 0)
+    ch = an.channels
+    rng = np.random.default_rng(31)
+    for W, nb in ((1, 48), (0, 32)):
+        n = an.blocksizes[W]
+        amp = np.array([0.5, 0.01, 1.0, 0.0, 0.9])[np.arange(nb) % 5, None, None]
+        pcm = ((rng.random((nb, ch, n), dtype=np.float32) - 0.5) * 2 * amp).astype(np.float32)
+        o = an.analyze(torch.from_numpy(pcm).cuda(), W=W, lW=W, nW=W, blocktype=1 if W else 0,
+                       want=("iwork", "nonzero", "res_class", "res_entries", "res_count"))
+        torch.cuda.synchronize()
+        cnt = o["res_count"].cpu().numpy()
+        cls = o["res_class"].cpu().numpy()
+        ent = o["res_entries"].cpu().numpy().view(np.uint16)
+        assert cnt[:, 1].max() <= an.residue_capacity(W)
+        for k in range(nb):
+            a = chk.tap_block(pcm[k], W, W, W, 1 if W else 0)
+            assert np.array_equal(a["res_class"], cls[k, :cnt[k, 0]]), (W, k)
+            assert np.array_equal(a["res_entries"], ent[k, :cnt[k, 1]]), (W, k)
+        assert (cnt[:, 0] == 0).any() and (cnt[:, 1] > 0).any()
+
+
+@pytest.mark.gpu
+def test_gpu_residue_argument_errors():
+    import torch
+    an = vorbis_amd.Analyzer(blob_of("44k_stereo_q4"), 0)
+    pcm = torch.zeros((2, 2, 2048), device="cuda")
+    outs = an.alloc_outputs(1, 2, ("res_class", "res_entries", "res_count"))
+    with pytest.raises(vorbis_amd.VamdError) as e:   # residue outputs need the full analysis
+        an.analyze(pcm, level=vorbis_amd.LEVEL_PSY, outs=outs)
+    assert e.value.code == -131
+    del outs["res_count"]                            # the three outputs go together
+    with pytest.raises(vorbis_amd.VamdError) as e:
+        an.analyze(pcm, outs=outs)
+    assert e.value.code == -131
+    assert an.L.vamd_residue_capacity(None, 1) == 0

@@ -18,7 +18,7 @@ from oracle import ref  # noqa: E402
 from tests.checker import SETUPS  # noqa: E402
 
 TAPS = ("windowed", "mdct_raw", "fft_packed", "logfft", "logmdct", "noise", "tone", "logmask", "mdct", "posts",
-        "post_valid", "ilogmask", "iwork", "nonzero", "local_ampmax")
+        "post_valid", "ilogmask", "iwork", "nonzero", "local_ampmax", "res_class", "res_entries")
 
 
 def pick(blocks):

@@ -17,7 +17,7 @@ EXPORTED_SYMBOLS = ["vamd_create", "vamd_destroy", "vamd_last_error", "vamd_set_
                     "vamd_channels", "vamd_blocksize", "vamd_posts", "vamd_mdct_forward_batch",
                     "vamd_analyze_batch", "vamd_analyze_stream", "vamd_analyze_block", "vamd_profile",
                     "vamd_stage_ms", "vamd_debug_cycles", "vamd_analyze_stream_mixed", "vamd_envelope_search_batch",
-                    "vamd_envelope_search", "vamd_envelope_geometry"]
+                    "vamd_envelope_search", "vamd_envelope_geometry", "vamd_residue_capacity", "vamd_analyze_block_res"]
 
 _vp = C.c_void_p
 
@@ -29,7 +29,8 @@ class _Desc(C.Structure):
 
 
 _IO_FIELDS = ["pcm", "mdct_raw", "logfft", "logmdct", "noise", "tone", "logmask", "mdct", "posts", "post_valid",
-              "ilogmask", "iwork", "nonzero", "local_ampmax", "ampmax_out"]
+              "ilogmask", "iwork", "nonzero", "local_ampmax", "ampmax_out", "res_class", "res_entries", "res_count"]
+RES_CLASS_STRIDE = 64
 
 
 class _IO(C.Structure):
@@ -80,6 +81,8 @@ def load_library():
     L.vamd_envelope_search_batch.argtypes = [_vp, _vp, C.c_long, C.c_long, C.c_long, C.c_long, _vp, _vp]
     L.vamd_envelope_search.argtypes = [_vp, C.POINTER(_vp), C.c_long, _vp, _vp]
     L.vamd_envelope_geometry.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.vamd_residue_capacity.argtypes = [_vp, C.c_int]
+    L.vamd_analyze_block_res.argtypes = [_vp, C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_float] + [_vp] * 10
     L.vamd_profile.argtypes = [_vp, C.c_int]
     L.vamd_stage_ms.argtypes = [_vp, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]
     _lib = L
@@ -212,9 +215,19 @@ class Analyzer:
                 o[k] = t.empty((nb, ch), dtype=t.float32, device=dev)
             elif k == "ampmax_out":
                 o[k] = t.empty((nb,), dtype=t.float32, device=dev)
+            elif k == "res_class":
+                o[k] = t.zeros((nb, RES_CLASS_STRIDE), dtype=t.int32, device=dev)
+            elif k == "res_entries":
+                o[k] = t.zeros((nb, self.residue_capacity(W)), dtype=t.int16, device=dev)  # uint16 payload
+            elif k == "res_count":
+                o[k] = t.zeros((nb, 2), dtype=t.int32, device=dev)
             else:
                 raise KeyError(k)
         return o
+
+    def residue_capacity(self, W):
+        """Row length of res_entries for size class W; 0 when the GPU does not cover this mode's residue."""
+        return int(self.L.vamd_residue_capacity(self.h, W))
 
     def _io(self, pcm, outs):
         io = _IO()
@@ -307,11 +320,21 @@ class Analyzer:
                  iwork=np.empty((ch, n2), np.int32), nonzero=np.empty(ch, np.int32))
         amp = C.c_float(0)
         self._bind_stream()
-        self._check(self.L.vamd_analyze_block(self.h, ptrs, lW, W, nW, blocktype, ampmax_in,
-                                              _vp(o["mdct"].ctypes.data), _vp(o["logmask"].ctypes.data),
-                                              _vp(o["posts"].ctypes.data), _vp(o["post_valid"].ctypes.data),
-                                              _vp(o["iwork"].ctypes.data), _vp(o["nonzero"].ctypes.data),
-                                              C.byref(amp)))
+        cap = self.residue_capacity(W)
+        if cap > 0:  # the residue back-end's decisions ride along where the mode is covered
+            rcls, rent, rcnt = np.zeros(RES_CLASS_STRIDE, np.int32), np.zeros(cap, np.uint16), np.zeros(2, np.int32)
+            self._check(self.L.vamd_analyze_block_res(
+                self.h, ptrs, lW, W, nW, blocktype, ampmax_in, _vp(o["mdct"].ctypes.data), _vp(o["logmask"].ctypes.data),
+                _vp(o["posts"].ctypes.data), _vp(o["post_valid"].ctypes.data), _vp(o["iwork"].ctypes.data),
+                _vp(o["nonzero"].ctypes.data), C.cast(C.byref(amp), _vp), _vp(rcls.ctypes.data), _vp(rent.ctypes.data),
+                _vp(rcnt.ctypes.data)))
+            o["res_class"], o["res_entries"] = rcls[:rcnt[0]].copy(), rent[:rcnt[1]].copy()
+        else:
+            self._check(self.L.vamd_analyze_block(self.h, ptrs, lW, W, nW, blocktype, ampmax_in,
+                                                  _vp(o["mdct"].ctypes.data), _vp(o["logmask"].ctypes.data),
+                                                  _vp(o["posts"].ctypes.data), _vp(o["post_valid"].ctypes.data),
+                                                  _vp(o["iwork"].ctypes.data), _vp(o["nonzero"].ctypes.data),
+                                                  C.byref(amp)))
         o["ampmax_out"] = amp.value
         return o
 

@@ -1,0 +1,191 @@
+// k_residue.h -- the residue back-end's numeric half: partition classes and the lattice-VQ search
+// for type-2 residues (channels interleaved: res2_class / res2_forward) and single-channel type-1
+// residues (res1_class / res1_forward) (reference lib/res0.c: _2class :479-532, _01class :412-470,
+// res2_forward :783-809, _01forward :534-640, _encodepart :384-410, local_book_besterror :322-382);
+// SURVEY.md 8f rank 2.  What stays on the host is the serial
+// part: looking each chosen entry's codeword up and writing its bits (vorbis_book_encode), and
+// the phrase-book words.
+//
+// One wave per block.  A partition's class needs only its own 2 x 16 values; a (partition,
+// stage, vector) search touches only its own `dim` values of the running work vector and is
+// integer arithmetic, so within a stage all vectors of all partitions are searched at once and
+// the stages -- which refine the same values -- follow each other with a wave sync.  Entries are
+// written in the order _01forward emits them, (stage, partition, vector), at offsets from a
+// prefix sum over the static per-class vector counts, so the host walks one packed list.
+#pragma once
+#include "vamd_wave.h"
+#include "vamd_params.h"
+
+namespace vamd {
+
+// local_book_besterror, lib/res0.c:322-382.  `a` -> the vector in the work buffer (LDS).
+VAMD_DEV int residue_besterror(const ResP &R, const vamd_book_tab &bk, int *a) {
+  const signed char *len = (const signed char *)(R.base + bk.off_lengths);
+  const int dim = bk.dim, minval = bk.minval, del = bk.delta, qv = bk.quantvals, ze = qv >> 1;
+  const float rcp = div_rcp(del);
+  int index = 0;
+  int p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int av[8];
+#if VAMD_GPU
+#pragma unroll
+#endif
+  for (int i = 0; i < 8; i++) av[i] = i < dim ? a[i] : 0;
+#if VAMD_GPU
+#pragma unroll
+#endif
+  for (int o = 7; o >= 0; o--) {
+    if (o >= dim) continue;
+    // C's (a - minval + (del>>1)) / del truncates toward zero; del == 1 needs no division
+    const int num = av[o] - minval + (del != 1 ? (del >> 1) : 0);
+    int v;
+    if (del == 1) {
+      v = num;
+    } else {
+      const int mag = num < 0 ? -num : num;
+      const int q = mag < (1 << 24) ? div_small(mag, del, rcp) : mag / del;
+      v = num < 0 ? -q : q;
+    }
+    const int m = (v < ze ? ((ze - v) << 1) - 1 : ((v - ze) << 1));
+    index = index * qv + (m < 0 ? 0 : (m >= qv ? qv - 1 : m));
+    p[o] = v * del + minval;
+  }
+  if (len[index] <= 0) {
+    // the lattice point is not a populated entry: exhaustive nearest search, in entry order (:349-376)
+    int best = -1;
+    int ev[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int maxval = minval + del * (qv - 1);
+    for (int i = 0; i < bk.entries; i++) {
+      if (len[i] > 0) {
+        int dist = 0;
+        for (int j = 0; j < dim; j++) {
+          const int val = ev[j] - av[j];
+          dist += val * val;
+        }
+        if (best == -1 || dist < best) {
+          for (int j = 0; j < 8; j++) p[j] = ev[j];
+          best = dist;
+          index = i;
+        }
+      }
+      int j = 0;  // odometer over the lattice, lib/res0.c:371-375 (the guard only matters after the last entry)
+      while (j < 8 && ev[j] >= maxval) ev[j++] = 0;
+      if (j < 8) {
+        if (ev[j] >= 0) ev[j] += del;
+        ev[j] = -ev[j];
+      }
+    }
+  }
+#if VAMD_GPU
+#pragma unroll
+#endif
+  for (int i = 0; i < 8; i++)
+    if (i < dim) a[i] = av[i] - p[i];
+  return index;
+}
+
+// vectors the (class, stage) pair emits for one partition (0 = stage not coded)
+VAMD_DEV int residue_step(const ResP &R, int cls, int s) {
+  const vamd_residue_tab &t = *R.tab;
+  if (!((t.secondstages[cls] >> s) & 1)) return 0;
+  const int bn = t.partbooks[cls][s];
+  return bn >= 0 ? t.grouping / R.books[bn].dim : 0;
+}
+
+//   iwork[c]   HBM [n2]   quantised (and coupled) residue of channel c
+//   work       LDS [ch*n2]; cls LDS [partvals]; off LDS [stages*partvals + 1]
+//   class_out  HBM [VAMD_RES_CLASS_STRIDE]; entries_out HBM [R.cap]; count_out HBM [2] = {partvals, entries}
+VAMD_DEV void residue2_block(const ResP &R, int ch, int n2, const int *const *iwork, const int *nonzero, int *work,
+                             int *cls, int *off, int *__restrict__ class_out, unsigned short *__restrict__ entries_out,
+                             int *__restrict__ count_out, PhaseClock &pc) {
+  const vamd_residue_tab &t = *R.tab;
+  const int spp = t.grouping, nparts = t.partitions, partvals = (t.end - t.begin) / spp, stages = t.stages;
+  int used = 0;
+  for (int c = 0; c < ch; c++) used |= nonzero[c];
+  if (!used) {  // res2_class returns NULL and res2_forward writes nothing (:766-777,:799-808)
+    if (LANE == 0) {
+      count_out[0] = 0;
+      count_out[1] = 0;
+    }
+    return;
+  }
+  // the interleaved work vector of res2_forward (:791-797)
+  WAVE_FOR(j, n2)
+    for (int c = 0; c < ch; c++) work[j * ch + c] = iwork[c][j];
+  WAVE_SYNC();
+  // _01class with one channel (:436-453): peak against classmetric1, scaled mean against classmetric2
+  if (t.type == 1) {
+    const float scale = (float)(100. / spp);
+    WAVE_FOR(i, partvals) {
+      const int *w = work + t.begin + i * spp;
+      int mx = 0, ent = 0;
+      for (int k = 0; k < spp; k++) {
+        const int a = w[k] < 0 ? -w[k] : w[k];
+        if (a > mx) mx = a;
+        ent += a;
+      }
+      ent = (int)((float)ent * scale);  // "ent*=scale" with a float scale
+      int k = 0;
+      for (; k < nparts - 1; k++)
+        if (mx <= t.classmetric1[k] && (t.classmetric2[k] < 0 || ent < t.classmetric2[k])) break;
+      cls[i] = k;
+      class_out[i] = k;
+    }
+  }
+  // _2class (:501-518): channel 0 of the bundle against classmetric1, the rest against classmetric2
+  if (t.type != 1) WAVE_FOR(i, partvals) {
+    int magmax = 0, angmax = 0;
+    const int *w = work + t.begin + i * spp;  // begin/ch bins in, interleaved
+    for (int j = 0; j < spp; j += ch) {
+      const int m = w[j] < 0 ? -w[j] : w[j];
+      if (m > magmax) magmax = m;
+      for (int k = 1; k < ch; k++) {
+        const int a = w[j + k] < 0 ? -w[j + k] : w[j + k];
+        if (a > angmax) angmax = a;
+      }
+    }
+    int j = 0;
+    for (; j < nparts - 1; j++)
+      if (magmax <= t.classmetric1[j] && angmax <= t.classmetric2[j]) break;
+    cls[i] = j;
+    class_out[i] = j;
+  }
+  WAVE_SYNC();
+  // emission offsets: (stage, partition) order
+  const int items = stages * partvals;
+  WAVE_FOR(it, items) {
+    const int s = it / partvals, i = it - s * partvals;
+    off[it] = residue_step(R, cls[i], s);
+  }
+  WAVE_SYNC();
+  if (LANE == 0) {  // <= 8 x 64 small integers
+    int acc = 0;
+    for (int it = 0; it < items; it++) {
+      const int c = off[it];
+      off[it] = acc;
+      acc += c;
+    }
+    off[items] = acc;
+    count_out[0] = partvals;
+    count_out[1] = acc;
+  }
+  WAVE_SYNC();
+  pc.mark(0);
+  // the search, stage by stage (_01forward's s loop outermost, :585)
+  for (int s = 0; s < stages; s++) {
+    WAVE_FOR(it, partvals << R.log2_grouping) {
+      const int i = it >> R.log2_grouping, k = it & (spp - 1);
+      const int c = cls[i];
+      const int step = residue_step(R, c, s);
+      if (k < step) {
+        const vamd_book_tab &bk = R.books[t.partbooks[c][s]];
+        const int entry = residue_besterror(R, bk, work + t.begin + i * spp + k * bk.dim);
+        const int at = off[s * partvals + i] + k;
+        if (at < R.cap) entries_out[at] = (unsigned short)entry;
+      }
+    }
+    WAVE_SYNC();
+  }
+  pc.mark(1);
+}
+
+}  // namespace vamd

@@ -22,6 +22,8 @@ struct Bound {
   FloorP floor[2];
   CoupleP couple[2];
   EnvP env;
+  ResP res[2];
+  int res_stages[2], res_partvals[2];
   float ampmax_att_per_sec;
 };
 
@@ -135,6 +137,33 @@ inline int build_image(const void *blob_v, size_t bytes, std::vector<unsigned ch
         *err = "envelope detector: band out of range";
         return VAMD_EINVAL;
       }
+  }
+
+  if (h.nbooks < 0 || h.nbooks > 256 || (uint64_t)h.off_books + (uint64_t)h.nbooks * sizeof(vamd_book_tab) > h.total_bytes) {
+    *err = "setup blob: codebook table out of range";
+    return VAMD_EINVAL;
+  }
+  for (int i = 0; i < h.nbooks; i++) {
+    vamd_book_tab bk;
+    memcpy(&bk, blob + h.off_books + (size_t)i * sizeof(bk), sizeof(bk));
+    if (bk.dim < 1 || bk.entries < 0 || (uint64_t)bk.off_lengths + (uint64_t)bk.entries > h.total_bytes) {
+      *err = "setup blob: codebook out of range";
+      return VAMD_EINVAL;
+    }
+  }
+  for (int W = 0; W < 2; W++) {
+    const vamd_residue_tab &r = h.res[W];
+    if (r.partitions < 1 || r.partitions > VAMD_RES_MAXCLASS || r.stages < 0 || r.stages > VAMD_RES_MAXSTAGE ||
+        r.grouping < 1 || r.begin < 0 || r.end < r.begin) {
+      *err = "setup blob: residue table out of range";
+      return VAMD_EINVAL;
+    }
+    for (int c = 0; c < r.partitions; c++)
+      for (int s = 0; s < VAMD_RES_MAXSTAGE; s++)
+        if (r.partbooks[c][s] >= h.nbooks) {
+          *err = "setup blob: residue book number out of range";
+          return VAMD_EINVAL;
+        }
   }
 
   image->assign(blob, blob + h.total_bytes);
@@ -278,6 +307,36 @@ inline void bind_params(const std::vector<unsigned char> &image, const std::vect
       E.band_total[i] = e.band_total[i];
       for (int j = 0; j < VAMD_VE_BANDWIN; j++) E.band_window[i][j] = e.band_window[i][j];
     }
+  }
+  for (int W = 0; W < 2; W++) {
+    const vamd_residue_tab &r = h.res[W];
+    ResP &Rp = B->res[W];
+    Rp.tab = (const vamd_residue_tab *)(base + offsetof(vamd_setup_header, res) + sizeof(vamd_residue_tab) * W);
+    Rp.books = (const vamd_book_tab *)(base + h.off_books);
+    Rp.base = base;
+    Rp.log2_grouping = 0;
+    while ((1 << Rp.log2_grouping) < r.grouping) Rp.log2_grouping++;
+    // the GPU covers the interleaved (type 2) residue of a 2-channel bundle and the type-1 residue of a
+    // single channel, with partitions a power of two long that hold <= 8-dimensional vectors
+    bool ok = ((r.type == 2 && h.channels == 2) || (r.type == 1 && h.channels == 1)) &&
+              (1 << Rp.log2_grouping) == r.grouping && r.end <= h.channels * (h.blocksizes[W] / 2) &&
+              (r.begin % h.channels) == 0 && (r.end - r.begin) / r.grouping <= VAMD_RES_CLASS_STRIDE;
+    int worst = 0;
+    const vamd_book_tab *hb = (const vamd_book_tab *)(image.data() + h.off_books);
+    for (int c = 0; c < r.partitions && ok; c++) {
+      int per = 0;
+      for (int s = 0; s < r.stages; s++)
+        if (((r.secondstages[c] >> s) & 1) && r.partbooks[c][s] >= 0) {
+          const vamd_book_tab &bk = hb[r.partbooks[c][s]];
+          if (bk.dim > 8 || bk.dim > r.grouping || bk.entries > 65535 || r.grouping % bk.dim) ok = false;
+          else per += r.grouping / bk.dim;
+        }
+      if (per > worst) worst = per;
+    }
+    B->res_stages[W] = r.stages;
+    B->res_partvals[W] = (r.end - r.begin) / r.grouping;
+    Rp.covered = ok ? 1 : 0;
+    Rp.cap = ok ? worst * ((r.end - r.begin) / r.grouping) : 0;
   }
   for (int p = 0; p < 4; p++) {
     const vamd_psy_tab &t = h.psy[p];

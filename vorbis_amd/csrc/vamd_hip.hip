@@ -27,6 +27,7 @@
 #include "k_floor.h"
 #include "k_couple.h"
 #include "k_envelope.h"
+#include "k_residue.h"
 
 using namespace vamd;
 
@@ -328,6 +329,28 @@ __global__ __launch_bounds__(64) void k_couple(PsyP P0, PsyP P1, CoupleP C, Desc
   couple_block(C, P, n2, mp, ip, op, nz, L, pc);
   if (LANE == 0)
     for (int c = 0; c < ch; c++) nonzero[blk * ch + c] = nz[c];
+  pc.flush();
+}
+
+// stage 6 (optional): residue classification + lattice-VQ search, one wave per block (k_residue.h)
+__global__ __launch_bounds__(64) void k_residue(ResP R, DescP d, int ch, int n2, const int *__restrict__ iwork,
+                                                const int *__restrict__ nonzero, int *__restrict__ res_class,
+                                                unsigned short *__restrict__ res_entries,
+                                                int *__restrict__ res_count) {
+  const long blk = blockIdx.x;
+  int *work = (int *)vamd_smem;       // [ch*n2]
+  int *cls = work + ch * n2;          // [VAMD_RES_CLASS_STRIDE]
+  int *off = cls + VAMD_RES_CLASS_STRIDE;  // [stages*partvals + 1]
+  const int *ip[VAMD_MAX_CH];
+  int nz[VAMD_MAX_CH];
+  for (int c = 0; c < ch; c++) {
+    ip[c] = iwork + (blk * ch + c) * n2;
+    nz[c] = nonzero[blk * ch + c];
+  }
+  PhaseClock pc;
+  pc.start(d.dbg ? d.dbg + 72 : nullptr);
+  residue2_block(R, ch, n2, ip, nz, work, cls, off, res_class + blk * VAMD_RES_CLASS_STRIDE,
+                 res_entries + blk * (long)R.cap, res_count + blk * 2, pc);
   pc.flush();
 }
 
@@ -738,6 +761,12 @@ struct BatchRun {
 
 static int prepare_run(vamd_ctx *c, const vamd_batch_desc *desc, const vamd_batch_io *io, int level, BatchRun *R) {
   memset(R, 0, sizeof(*R));
+  if (io && (io->res_class || io->res_entries || io->res_count)) {
+    if (!(io->res_class && io->res_entries && io->res_count)) return fail(c, VAMD_EINVAL, "res_class / res_entries / res_count go together");
+    if (level < VAMD_LEVEL_FULL) return fail(c, VAMD_EINVAL, "residue outputs need level FULL");
+    if ((desc->W != 0 && desc->W != 1) || !c->B.res[desc->W].covered)
+      return fail(c, VAMD_EIMPL, "this mode's residue back-end is not covered on the GPU (type 2 stereo, type 1 mono)");
+  }
   R->W = desc->W;
   R->nb = desc->nblocks;
   R->io = io;
@@ -824,9 +853,18 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level) {
     // the LDS arrays serve noise normalisation's sort only (lib/psy.c:941-1010); without it the
     // stage is register-only and the CU holds twice as many of its waves
     const bool norm0 = P0.normal_p && P0.normal_start < n2, norm1 = P1.normal_p && P1.normal_start < n2;
+    const bool want_res = R->io && R->io->res_entries;
     hipLaunchKernelGGL(k_couple, dim3(gb), dim3(64), (norm0 || norm1) ? (size_t)n2 * 12 : 0, s, P0, P1, c->B.couple[W], d, p.mdct, p.ilogmask,
                        p.iwork, p.nonzero);
     prof_mark(c), R->nst++;
+    if (want_res) {
+      const ResP &Rp = c->B.res[W];
+      const int stages = c->B.res_stages[W], partvals = c->B.res_partvals[W];
+      const size_t lds = ((size_t)ch * n2 + VAMD_RES_CLASS_STRIDE + (size_t)stages * partvals + 1) * 4;
+      hipLaunchKernelGGL(k_residue, dim3(gb), dim3(64), lds, s, Rp, d, ch, n2, p.iwork, p.nonzero, R->io->res_class,
+                         R->io->res_entries, R->io->res_count);
+      prof_mark(c), R->nst++;
+    }
   }
 }
 
@@ -915,14 +953,27 @@ int vamd_analyze_stream_mixed(vamd_ctx *c, const vamd_batch_desc *desc_short, co
 int vamd_analyze_block(vamd_ctx *c, const float *const *pcm, int lW, int W, int nW, int blocktype, float ampmax_in,
                        float *mdct, float *logmask, int32_t *posts, int32_t *post_valid, int32_t *iwork,
                        int32_t *nonzero, float *ampmax_out) {
+  return vamd_analyze_block_res(c, pcm, lW, W, nW, blocktype, ampmax_in, mdct, logmask, posts, post_valid, iwork,
+                                nonzero, ampmax_out, nullptr, nullptr, nullptr);
+}
+
+int vamd_analyze_block_res(vamd_ctx *c, const float *const *pcm, int lW, int W, int nW, int blocktype,
+                           float ampmax_in, float *mdct, float *logmask, int32_t *posts, int32_t *post_valid,
+                           int32_t *iwork, int32_t *nonzero, float *ampmax_out, int32_t *res_class,
+                           uint16_t *res_entries, int32_t *res_count) {
   if (!c) return VAMD_EINVAL;
   if (!pcm || (W != 0 && W != 1)) return fail(c, VAMD_EINVAL, "bad pcm / W");
+  const bool want_res = res_class || res_entries || res_count;
+  if (want_res && !c->B.res[W].covered)
+    return fail(c, VAMD_EIMPL, "this mode's residue back-end is not covered on the GPU (type 2 stereo, type 1 mono)");
+  const size_t rcap = want_res ? (size_t)c->B.res[W].cap : 0;
   const int ch = c->B.channels, n = c->B.bs[W], n2 = n / 2;
   // one pinned + one device arena: [pcm | mdct | logmask | iwork | posts | post_valid | nonzero | ampmax]
   const size_t o_pcm = 0, o_mdct = o_pcm + (size_t)ch * n * 4, o_mask = o_mdct + (size_t)ch * n2 * 4,
                o_iwork = o_mask + (size_t)ch * n2 * 4, o_posts = o_iwork + (size_t)ch * n2 * 4,
                o_valid = o_posts + (size_t)ch * VAMD_POSTS_STRIDE * 4, o_nz = o_valid + (size_t)ch * 4,
-               o_amp = o_nz + (size_t)ch * 4, total = o_amp + 16;
+               o_amp = o_nz + (size_t)ch * 4, o_rcls = o_amp + 16, o_rcnt = o_rcls + VAMD_RES_CLASS_STRIDE * 4,
+               o_rent = o_rcnt + 16, total = o_rent + ((rcap * 2 + 15) & ~(size_t)15);
   if (c->h_stage_bytes < total) {
     if (c->h_stage) HIP_TRY(c, hipHostFree(c->h_stage));
     c->h_stage = nullptr;
@@ -958,6 +1009,11 @@ int vamd_analyze_block(vamd_ctx *c, const float *const *pcm, int lW, int W, int 
   io.post_valid = (int32_t *)(ds + o_valid);
   io.nonzero = (int32_t *)(ds + o_nz);
   io.ampmax_out = (float *)(ds + o_amp);
+  if (want_res) {
+    io.res_class = (int32_t *)(ds + o_rcls);
+    io.res_count = (int32_t *)(ds + o_rcnt);
+    io.res_entries = (uint16_t *)(ds + o_rent);
+  }
   r = vamd_analyze_batch(c, &d, &io, VAMD_LEVEL_FULL);
   if (r) return r;
   HIP_TRY(c, hipMemcpyAsync(hs + o_mdct, ds + o_mdct, total - o_mdct, hipMemcpyDeviceToHost, s));
@@ -969,7 +1025,19 @@ int vamd_analyze_block(vamd_ctx *c, const float *const *pcm, int lW, int W, int 
   if (post_valid) memcpy(post_valid, hs + o_valid, (size_t)ch * 4);
   if (nonzero) memcpy(nonzero, hs + o_nz, (size_t)ch * 4);
   if (ampmax_out) memcpy(ampmax_out, hs + o_amp, 4);
+  if (want_res) {
+    int32_t cnt[2];
+    memcpy(cnt, hs + o_rcnt, 8);
+    if (res_count) memcpy(res_count, cnt, 8);
+    if (res_class) memcpy(res_class, hs + o_rcls, VAMD_RES_CLASS_STRIDE * 4);
+    if (res_entries) memcpy(res_entries, hs + o_rent, (size_t)(cnt[1] < (int)rcap ? cnt[1] : (int)rcap) * 2);
+  }
   return VAMD_OK;
+}
+
+int vamd_residue_capacity(const vamd_ctx *c, int W) {
+  if (!c || (W != 0 && W != 1)) return 0;
+  return c->B.res[W].covered ? c->B.res[W].cap : 0;
 }
 
 int vamd_envelope_geometry(const vamd_ctx *c, int *winlength, int *searchstep) {

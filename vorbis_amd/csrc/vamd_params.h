@@ -67,6 +67,16 @@ struct EnvP {
   float band_window[VAMD_VE_BANDS][VAMD_VE_BANDWIN];
 };
 
+// residue back-end of one mode (type 2): tables stay in the HBM image
+struct ResP {
+  const vamd_residue_tab *tab;
+  const vamd_book_tab *books;
+  const unsigned char *base;  // image base: books[].off_lengths are relative to it
+  int log2_grouping;
+  int cap;                    // entries a block can emit at most (sizes the output rows)
+  int covered;                // 1 when the GPU handles this mode's residue (type 2, 2 channels)
+};
+
 struct FloorP {
   int posts, look_n, quant_q, mult;
   float maxover, maxunder, maxerr, twofitweight, twofitatten;
