@@ -122,10 +122,11 @@ int emul_analyze_block(void *h, const float *pcm, int lW, int W, int nW, int blo
   if (t->res_entries && t->res_class && t->res_count) {
     const ResP &Rp = B.res[W];
     if (!Rp.covered) return -130;
-    std::vector<int> work(ch * n2), cls(VAMD_RES_CLASS_STRIDE), off(B.res_stages[W] * B.res_partvals[W] + 1);
+    std::vector<int> work(ch * n2), cls(VAMD_RES_CLASS_STRIDE), off(B.res_stages[W] * B.res_partvals[W] + 1),
+        info(B.res_stages[W] * B.res_partvals[W] + 1);
     const int *ip[VAMD_MAX_CH];
     for (int i = 0; i < ch; i++) ip[i] = &iwork[i * n2];
-    residue2_block(Rp, ch, n2, ip, nonzero.data(), work.data(), cls.data(), off.data(), t->res_class, t->res_entries,
+    residue2_block(Rp, ch, n2, ip, nonzero.data(), work.data(), cls.data(), off.data(), info.data(), t->res_class, t->res_entries,
                    t->res_count, pc);
   }
 #define OUT(name, vec, type) \

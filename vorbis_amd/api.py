@@ -143,7 +143,7 @@ class Analyzer:
         s = self.torch.cuda.current_stream(self.device)
         self._check(self.L.vamd_set_stream(self.h, _vp(s.cuda_stream)))
 
-    STAGES = ("transform", "ampmax", "noisemask", "tonemask", "floor", "couple")
+    STAGES = ("transform", "ampmax", "noisemask", "tonemask", "floor", "couple", "residue")
 
     def profile(self, enable=True):
         self._bind_stream()
@@ -151,9 +151,9 @@ class Analyzer:
 
     def stage_ms(self):
         """(dict stage -> summed ms, number of batches) since the last call; synchronises."""
-        ms = (C.c_float * 6)()
+        ms = (C.c_float * 7)()
         runs = C.c_int(0)
-        self._check(self.L.vamd_stage_ms(self.h, ms, 6, C.byref(runs)))
+        self._check(self.L.vamd_stage_ms(self.h, ms, 7, C.byref(runs)))
         return dict(zip(self.STAGES, [float(x) for x in ms])), runs.value
 
     def debug_cycles(self, enable=True, read=False):

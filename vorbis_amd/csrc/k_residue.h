@@ -83,19 +83,11 @@ VAMD_DEV int residue_besterror(const ResP &R, const vamd_book_tab &bk, int *a) {
   return index;
 }
 
-// vectors the (class, stage) pair emits for one partition (0 = stage not coded)
-VAMD_DEV int residue_step(const ResP &R, int cls, int s) {
-  const vamd_residue_tab &t = *R.tab;
-  if (!((t.secondstages[cls] >> s) & 1)) return 0;
-  const int bn = t.partbooks[cls][s];
-  return bn >= 0 ? t.grouping / R.books[bn].dim : 0;
-}
-
 //   iwork[c]   HBM [n2]   quantised (and coupled) residue of channel c
-//   work       LDS [ch*n2]; cls LDS [partvals]; off LDS [stages*partvals + 1]
+//   work       LDS [ch*n2]; cls LDS [partvals]; off LDS [stages*partvals + 1]; info LDS [stages*partvals]
 //   class_out  HBM [VAMD_RES_CLASS_STRIDE]; entries_out HBM [R.cap]; count_out HBM [2] = {partvals, entries}
 VAMD_DEV void residue2_block(const ResP &R, int ch, int n2, const int *const *iwork, const int *nonzero, int *work,
-                             int *cls, int *off, int *__restrict__ class_out, unsigned short *__restrict__ entries_out,
+                             int *cls, int *off, int *info, int *__restrict__ class_out, unsigned short *__restrict__ entries_out,
                              int *__restrict__ count_out, PhaseClock &pc) {
   const vamd_residue_tab &t = *R.tab;
   const int spp = t.grouping, nparts = t.partitions, partvals = (t.end - t.begin) / spp, stages = t.stages;
@@ -150,38 +142,49 @@ VAMD_DEV void residue2_block(const ResP &R, int ch, int n2, const int *const *iw
     class_out[i] = j;
   }
   WAVE_SYNC();
-  // emission offsets: (stage, partition) order
+  // emission offsets, (stage, partition) order; `info` keeps each pair's book so that the search
+  // below never goes back to the class tables
   const int items = stages * partvals;
   WAVE_FOR(it, items) {
     const int s = it / partvals, i = it - s * partvals;
-    off[it] = residue_step(R, cls[i], s);
+    const int c = cls[i];
+    const int bn = ((t.secondstages[c] >> s) & 1) ? t.partbooks[c][s] : -1;
+    info[it] = bn;
+    off[it] = bn >= 0 ? spp / R.books[bn].dim : 0;
   }
   WAVE_SYNC();
-  if (LANE == 0) {  // <= 8 x 64 small integers
-    int acc = 0;
-    for (int it = 0; it < items; it++) {
-      const int c = off[it];
-      off[it] = acc;
-      acc += c;
+  {  // exclusive prefix sum over the <= 8 x 64 counts, a wave-width at a time
+    int carry = 0;
+    for (int base = 0; base < items; base += NLANES) {
+      const int it = base + LANE;
+      const int c = it < items ? off[it] : 0;
+      const int incl = wave_scan_sum(c);
+      if (it < items) off[it] = carry + incl - c;
+      carry += wave_last(incl);
     }
-    off[items] = acc;
-    count_out[0] = partvals;
-    count_out[1] = acc;
+    if (LANE == 0) {
+      off[items] = carry;
+      count_out[0] = partvals;
+      count_out[1] = carry;
+    }
   }
   WAVE_SYNC();
   pc.mark(0);
-  // the search, stage by stage (_01forward's s loop outermost, :585)
+  // the search, stage by stage (_01forward's s loop outermost, :585).  A stage's vectors are
+  // numbered densely (its slice of the emission order), so every lane has one to search.
   for (int s = 0; s < stages; s++) {
-    WAVE_FOR(it, partvals << R.log2_grouping) {
-      const int i = it >> R.log2_grouping, k = it & (spp - 1);
-      const int c = cls[i];
-      const int step = residue_step(R, c, s);
-      if (k < step) {
-        const vamd_book_tab &bk = R.books[t.partbooks[c][s]];
-        const int entry = residue_besterror(R, bk, work + t.begin + i * spp + k * bk.dim);
-        const int at = off[s * partvals + i] + k;
-        if (at < R.cap) entries_out[at] = (unsigned short)entry;
+    const int *so = off + s * partvals;
+    const int base = so[0], total = so[partvals] - base;  // (off[] is stage-major: the next stage starts there)
+    WAVE_FOR(v, total) {
+      int lo = 0, hi = partvals - 1;  // the partition whose vectors include v: last i with so[i] - base <= v
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (so[mid] - base <= v) lo = mid; else hi = mid - 1;
       }
+      const int i = lo, k = v - (so[i] - base);
+      const vamd_book_tab &bk = R.books[info[s * partvals + i]];
+      const int entry = residue_besterror(R, bk, work + t.begin + i * spp + k * bk.dim);
+      if (base + v < R.cap) entries_out[base + v] = (unsigned short)entry;
     }
     WAVE_SYNC();
   }

@@ -340,7 +340,8 @@ __global__ __launch_bounds__(64) void k_residue(ResP R, DescP d, int ch, int n2,
   const long blk = blockIdx.x;
   int *work = (int *)vamd_smem;       // [ch*n2]
   int *cls = work + ch * n2;          // [VAMD_RES_CLASS_STRIDE]
-  int *off = cls + VAMD_RES_CLASS_STRIDE;  // [stages*partvals + 1]
+  int *off = cls + VAMD_RES_CLASS_STRIDE;  // [stages*partvals + 1], then info [stages*partvals]
+  int *info = off + (R.tab->stages * ((R.tab->end - R.tab->begin) / R.tab->grouping) + 1);
   const int *ip[VAMD_MAX_CH];
   int nz[VAMD_MAX_CH];
   for (int c = 0; c < ch; c++) {
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(64) void k_residue(ResP R, DescP d, int ch, int n2,
   }
   PhaseClock pc;
   pc.start(d.dbg ? d.dbg + 72 : nullptr);
-  residue2_block(R, ch, n2, ip, nz, work, cls, off, res_class + blk * VAMD_RES_CLASS_STRIDE,
+  residue2_block(R, ch, n2, ip, nz, work, cls, off, info, res_class + blk * VAMD_RES_CLASS_STRIDE,
                  res_entries + blk * (long)R.cap, res_count + blk * 2, pc);
   pc.flush();
 }
@@ -860,7 +861,7 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level) {
     if (want_res) {
       const ResP &Rp = c->B.res[W];
       const int stages = c->B.res_stages[W], partvals = c->B.res_partvals[W];
-      const size_t lds = ((size_t)ch * n2 + VAMD_RES_CLASS_STRIDE + (size_t)stages * partvals + 1) * 4;
+      const size_t lds = ((size_t)ch * n2 + VAMD_RES_CLASS_STRIDE + 2 * (size_t)stages * partvals + 1) * 4;
       hipLaunchKernelGGL(k_residue, dim3(gb), dim3(64), lds, s, Rp, d, ch, n2, p.iwork, p.nonzero, R->io->res_class,
                          R->io->res_entries, R->io->res_count);
       prof_mark(c), R->nst++;

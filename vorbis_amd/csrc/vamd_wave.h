@@ -120,6 +120,10 @@ VAMD_DEV int wave_sum(int v) {
   VAMD_DPP_SCAN(v, 0, VAMD_OP_ADD)
   return __builtin_amdgcn_readlane(v, 63);
 }
+VAMD_DEV int wave_scan_sum(int v) {  // inclusive prefix sum over the lanes
+  VAMD_DPP_SCAN(v, 0, VAMD_OP_ADD)
+  return v;
+}
 VAMD_DEV int wave_any(int pred) { return __any(pred); }
 VAMD_DEV unsigned long long wave_or64(unsigned long long x) {
   int lo = (int)(unsigned int)x, hi = (int)(unsigned int)(x >> 32);
@@ -156,6 +160,7 @@ VAMD_DEV int wave_sum(int v) { return v; }
 VAMD_DEV int wave_any(int pred) { return pred != 0; }
 VAMD_DEV unsigned long long wave_or64(unsigned long long v) { return v; }
 VAMD_DEV int wave_scan_max(int v) { return v; }
+VAMD_DEV int wave_scan_sum(int v) { return v; }
 VAMD_DEV int wave_shift_up1(int v, int fill) { (void)v; return fill; }
 VAMD_DEV int wave_last(int v) { return v; }
 VAMD_DEV int wave_first(int v) { return v; }
