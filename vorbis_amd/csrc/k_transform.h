@@ -372,9 +372,9 @@ VAMD_DEV void radf4_wave(int ido, int l1, const float *cc, float *ch, const floa
     return;
   }
   const int lh = 31 - __builtin_clz((unsigned)(ido >> 1));  // log2(ido/2)
-  WAVE_FOR(g, l1 << lh) {
-    const int k = g >> lh, m = g & ((1 << lh) - 1);
-    if (m == 0) {
+  // the two k-only columns (i = 0 and i = ido), one lane per k
+  WAVE_FOR(k, l1) {
+    {
       {
         const int t1 = t0 + k * ido, t2 = 3 * t0 + k * ido, t3 = k * ido, t4 = 2 * t0 + k * ido;
         const float tr1 = cc[t1] + cc[t2];
@@ -396,7 +396,12 @@ VAMD_DEV void radf4_wave(int ido, int l1, const float *cc, float *ch, const floa
         ch[t4] = ti1 - cc[t1 + t0];
         ch[t4 + t5] = ti1 + cc[t1 + t0];
       }
-    } else {
+    }
+  }
+  // the (k, i = 2m) butterflies, m >= 1 (the m = 0 slot of each k idles: k and m stay a shift and a mask)
+  WAVE_FOR(g, l1 << lh) {
+    const int k = g >> lh, m = g & ((1 << lh) - 1);
+    if (m != 0) {
       const int i = 2 * m;
       const int t1 = k * ido;
       const int t2 = t1 + i;
