@@ -39,7 +39,8 @@ struct FitTerm {
 // maps, the floor's static index tables) is NOT here: it lives one entry per lane in
 // registers (LaneInts / LaneDoubles) and is read with v_readlane.
 struct FloorScratch {
-  FitAcc acc[VAMD_MAXPOSTS];
+  FitAcc acc[VAMD_MAXPOSTS];  // 48 B each; later reused as [intervals][5] doubles (40 B each)
+  double pair_sums[16];
   int segx[VAMD_MAXPOSTS + 1], segy[VAMD_MAXPOSTS + 1];
   int nseg;
 };
@@ -152,6 +153,54 @@ VAMD_DEV int fit_line(const FitTerms &T, int first, int fits, int x0, int x1, in
   *y1 = 0;
   return 1;
 }
+
+#if VAMD_GPU
+// The two fit_line calls of a split (lib/floor1.c:648-651: left and right of the new post, both
+// unconstrained) as ONE pass over the wave: lanes 0-4 sum the five quantities of the left range,
+// lanes 8-12 those of the right range, each in interval order out of LDS (one 8-byte read and one
+// dependent fp64 add per interval instead of ten v_readlane and five adds), then every lane of a
+// group evaluates the closed form once.  Same operand order as fit_line above.
+//   term   LDS [intervals][5] doubles: xb, yb, x2b, xyb, bn of each interval (fit_term)
+//   sums   LDS [2][8] doubles scratch
+VAMD_DEV void fit_line_pair(const double *term, double *sums, int firstL, int fitsL, int x0L, int x1L, int firstR,
+                            int fitsR, int x0R, int x1R, int *ret0, int *ly0, int *ly1, int *ret1, int *hy0,
+                            int *hy1) {
+  const int grp = (LANE >> 3) & 1, q = LANE & 7;
+  const int first = grp ? firstR : firstL, fits = grp ? fitsR : fitsL;
+  const int most = fitsL > fitsR ? fitsL : fitsR;
+  double acc = 0.;
+  if (LANE < 16 && q < 5) {
+    const double *t = term + first * 5 + q;
+    for (int i = 0; i < most; i++)
+      if (i < fits) acc += t[i * 5];
+    sums[grp * 8 + q] = acc;
+  }
+  WAVE_SYNC();
+  const double xb = sums[grp * 8], yb = sums[grp * 8 + 1], x2b = sums[grp * 8 + 2], xyb = sums[grp * 8 + 3],
+               bn = sums[grp * 8 + 4];
+  const int x0 = grp ? x0R : x0L, x1 = grp ? x1R : x1L;
+  const double denom = (bn * x2b - xb * xb);
+  int r = 1, y0 = 0, y1 = 0;
+  if (denom > 0.) {
+    const double aa = (yb * x2b - xyb * xb) / denom;
+    const double bb = (bn * xyb - xb * yb) / denom;
+    y0 = (int)rint(aa + bb * x0);
+    y1 = (int)rint(aa + bb * x1);
+    if (y0 > 1023) y0 = 1023;
+    if (y1 > 1023) y1 = 1023;
+    if (y0 < 0) y0 = 0;
+    if (y1 < 0) y1 = 0;
+    r = 0;
+  }
+  *ret0 = __builtin_amdgcn_readlane(r, 0);
+  *ly0 = __builtin_amdgcn_readlane(y0, 0);
+  *ly1 = __builtin_amdgcn_readlane(y1, 0);
+  *ret1 = __builtin_amdgcn_readlane(r, 8);
+  *hy0 = __builtin_amdgcn_readlane(y0, 8);
+  *hy1 = __builtin_amdgcn_readlane(y1, 8);
+  WAVE_SYNC();  // sums[] is rewritten by the next split
+}
+#endif
 
 struct LineStep {  // Bresenham constants shared by inspect_error / render_line0
   int base, sgn, ady, adx;
@@ -313,17 +362,25 @@ VAMD_DEV int floor_fit_render_block(const FloorP &F, int n2, const float *mask, 
   }
   nz = wave_sum(nz);
   WAVE_SYNC();
+#if !VAMD_GPU
   FitTerms T;
+#endif
   {
     // lane i forms interval i's fit_line contribution
 #if VAMD_GPU
     FitAcc mine = sc->acc[LANE < posts - 1 ? LANE : 0];
     const FitTerm ft = fit_term(mine, F.twofitweight);
-    T.xb.set_mine(ft.xb);
-    T.yb.set_mine(ft.yb);
-    T.x2b.set_mine(ft.x2b);
-    T.xyb.set_mine(ft.xyb);
-    T.bn.set_mine(ft.bn);
+    // the terms go to LDS as rows for fit_line_pair, over the accumulators (dead from here on)
+    WAVE_SYNC();
+    if (LANE < posts - 1) {
+      double *row = (double *)sc->acc + LANE * 5;
+      row[0] = ft.xb;
+      row[1] = ft.yb;
+      row[2] = ft.x2b;
+      row[3] = ft.xyb;
+      row[4] = ft.bn;
+    }
+    WAVE_SYNC();
 #else
     for (int i = 0; i < posts - 1; i++) {
       const FitTerm ft = fit_term(sc->acc[i], F.twofitweight);
@@ -350,7 +407,13 @@ VAMD_DEV int floor_fit_render_block(const FloorP &F, int n2, const float *mask, 
   // walks the same decisions; the state is in lane registers.
   {
     int y0 = -200, y1 = -200;
+#if VAMD_GPU
+    int r0, r1, u0, u1;  // the whole-range fit rides in the left half of the pair routine
+    fit_line_pair((const double *)sc->acc, sc->pair_sums, 0, posts - 1, sorted_index.get(0), sorted_index.get(posts - 1),
+                  0, 0, 0, 0, &r0, &y0, &y1, &r1, &u0, &u1);
+#else
     fit_line(T, 0, posts - 1, sorted_index.get(0), sorted_index.get(posts - 1), &y0, &y1);
+#endif
     fitA.set(0, y0);
     fitB.set(0, y0);
     fitB.set(1, y1);
@@ -370,10 +433,17 @@ VAMD_DEV int floor_fit_render_block(const FloorP &F, int n2, const float *mask, 
       // (ly == -1 || hy == -1 => exit(1) in the reference: unreachable, fits are >= 0 or -200)
       if (inspect_error_wave(lx, hx, ly, hy, mask, cls, F)) {
         int ly0 = -200, ly1 = -200, hy0 = -200, hy1 = -200;
+#if VAMD_GPU
+        int ret0, ret1;
+        fit_line_pair((const double *)sc->acc, sc->pair_sums, lsortpos, sortpos - lsortpos, sorted_index.get(lsortpos),
+                      sorted_index.get(sortpos), sortpos, hsortpos - sortpos, sorted_index.get(sortpos),
+                      sorted_index.get(hsortpos), &ret0, &ly0, &ly1, &ret1, &hy0, &hy1);
+#else
         const int ret0 = fit_line(T, lsortpos, sortpos - lsortpos, sorted_index.get(lsortpos),
                                   sorted_index.get(sortpos), &ly0, &ly1);
         const int ret1 = fit_line(T, sortpos, hsortpos - sortpos, sorted_index.get(sortpos),
                                   sorted_index.get(hsortpos), &hy0, &hy1);
+#endif
         if (ret0) {
           ly0 = ly;
           ly1 = hy0;
