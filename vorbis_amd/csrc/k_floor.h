@@ -244,7 +244,11 @@ VAMD_DEV int inspect_error_wave(int x0, int x1, int y0, int y1, const float *mas
   mse = wave_sum(mse);
   if (F.maxover * F.maxover / (float)cnt > F.maxerr) return 0;
   if (F.maxunder * F.maxunder / (float)cnt > F.maxerr) return 0;
-  if ((float)(mse / cnt) > F.maxerr) return 1;  // (one true integer divide per call; mse may exceed 2^24)
+  // (float)(mse / cnt) > maxerr, without the integer divide: the quotient q is an integer, so for
+  // maxerr >= 0 the test is q >= floor(maxerr) + 1, i.e. mse >= (floor(maxerr) + 1) * cnt.  (q >= 2^24,
+  // where the float conversion would round, is far above any maxerr and true on both sides.)
+  if (F.maxerr >= 0.f && F.maxerr < 1048576.f) return mse >= ((int)F.maxerr + 1) * cnt;
+  if ((float)(mse / cnt) > F.maxerr) return 1;
   return 0;
 }
 
