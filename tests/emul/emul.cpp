@@ -100,9 +100,8 @@ int emul_analyze_block(void *h, const float *pcm, int lW, int W, int nW, int blo
       tonemask_block(P, &logfft[i * n2], &tone[i * n2], global, local[i], seed.data() + seed_pad_lo(P.eighth_octave_lines), ampstack.data(),
                      flr.data(), ring_amp.data(), ring_pos.data(), surv.data(), pc);
       offset_and_mix_wave(P, &noise[i * n2], &tone[i * n2], &logmdct[i * n2], &mdct_raw[i * n2], &mdct[i * n2],
-                          mask.data(), (unsigned char *)lmd.data(), F.twofitatten, pc);
-      memcpy(&logmask[i * n2], mask.data(), sizeof(float) * n2);
-      nonzero[i] = floor_fit_render_block(F, n2, mask.data(), (const unsigned char *)lmd.data(), &sc, &posts[i * VAMD_POSTS_STRIDE],
+                          &logmask[i * n2], (unsigned short *)lmd.data(), F.twofitatten, pc);
+      nonzero[i] = floor_fit_render_block(F, n2, (const unsigned short *)lmd.data(), &sc, &posts[i * VAMD_POSTS_STRIDE],
                                           &post_valid[i], &ilogmask[i * n2], pc);
     }
   }

@@ -12,8 +12,9 @@
 // error is an integer wave sum and the early-outs are an any().  fit_line's
 // fp64 sums run in the reference's term order on every lane.
 //
-// LDS: mask[n] (logmask), cls[n] bytes (the fit's "mdct + twofitatten >= mask" class of every bin --
-// the only thing the fit reads logmdct for), FloorScratch (interval accumulators + the
+// LDS: qc[n] 16-bit words -- everything the fit reads per bin: the mask quantised by vorbis_dBquant
+// (bits 0-9; the fit never looks at the float mask) and the "mdct + twofitatten >= mask" class
+// (bit 15; the only thing the fit reads logmdct for) --, FloorScratch (interval accumulators + the
 // rendered segment list).
 #pragma once
 #include "vamd_wave.h"
@@ -48,8 +49,8 @@ struct FloorScratch {
 // _vp_offset_and_mix with offset_select == 1 (the only select the VBR path uses)
 VAMD_DEV void offset_and_mix_wave(const PsyP &P, const float *__restrict__ noise, const float *__restrict__ tone,
                                   const float *__restrict__ logmdct_in, const float *__restrict__ mdct_io_src,
-                                  float *__restrict__ mdct_out, float *mask, unsigned char *cls, float twofitatten,
-                                  PhaseClock &pc) {
+                                  float *__restrict__ mdct_out, float *__restrict__ logmask_out /* HBM or null */,
+                                  unsigned short *qc, float twofitatten, PhaseClock &pc) {
   const int n = P.n;
   const float toneatt = P.tone_masteratt1;
   const float cx = P.m_val;
@@ -80,12 +81,18 @@ VAMD_DEV void offset_and_mix_wave(const PsyP &P, const float *__restrict__ noise
       }
       md[c] *= de;
     }
-    ((F4 *)mask)[q] = f4_make(mk);
-    // accumulate_fit / inspect_error split bins by this test (lib/floor1.c:427,536); one byte per
-    // bin keeps the block's LDS footprint at 5 bytes per bin instead of 8
-    uint32_t cw = 0;
-    for (int c = 0; c < 4; c++) cw |= (uint32_t)(lmv[c] + twofitatten >= mk[c] ? 1 : 0) << (8 * c);
-    ((uint32_t *)cls)[q] = cw;
+    if (logmask_out) ((F4 *)logmask_out)[q] = f4_make(mk);
+    // accumulate_fit / inspect_error read the mask only through vorbis_dBquant and split bins by the
+    // class test (lib/floor1.c:421-427,530-536): 2 bytes per bin instead of two floats
+    uint32_t w[2] = {0, 0};
+    for (int c = 0; c < 4; c++) {
+      const uint32_t v = (uint32_t)dBquant(mk[c]) | (lmv[c] + twofitatten >= mk[c] ? 0x8000u : 0u);
+      w[c >> 1] |= v << (16 * (c & 1));
+    }
+    I2 pk;
+    pk.x = (int)w[0];
+    pk.y = (int)w[1];
+    ((I2 *)qc)[q] = pk;
     ((F4 *)mdct_out)[q] = f4_make(md);
   }
   WAVE_SYNC();
@@ -223,17 +230,17 @@ VAMD_DEV int line_y(const LineStep &s, int y0, int k) {
 }
 
 // inspect_error, lib/floor1.c:516-565, wave-parallel over x in [x0, x1)
-VAMD_DEV int inspect_error_wave(int x0, int x1, int y0, int y1, const float *mask, const unsigned char *cls,
-                                const FloorP &F) {
+VAMD_DEV int inspect_error_wave(int x0, int x1, int y0, int y1, const unsigned short *qc, const FloorP &F) {
   const LineStep s = line_step(x0, x1, y0, y1);
   const int cnt = (x1 - x0) > 1 ? (x1 - x0) : 1;  // points visited: x0, then x0+1 .. x1-1
   int mse = 0, bad = 0;
   WAVE_FOR(k, cnt) {
     const int x = x0 + k;
     const int y = line_y(s, y0, k);
-    const int val = dBquant(mask[x]);
+    const int qv = qc[x];
+    const int val = qv & 0x7fff;
     mse += (y - val) * (y - val);
-    if (cls[x]) {  // mdct[x] + twofitatten >= mask[x]
+    if (qv & 0x8000) {  // mdct[x] + twofitatten >= mask[x]
       if (k == 0 || val) {  // the first point is checked even when val == 0 (lib/floor1.c:536-539)
         if ((float)y + F.maxover < (float)val) bad = 1;
         if ((float)y - F.maxunder > (float)val) bad = 1;
@@ -270,11 +277,11 @@ VAMD_DEV int render_point(int x0, int x1, int y0, int y1, int x) {
 }
 
 // floor1_fit + the curve half of floor1_encode for one channel-block.
-//   mask      LDS [n2]   logmask;  cls  LDS [n2] bytes, see offset_and_mix_wave
+//   qc        LDS [n2]   quantised mask + class bit, see offset_and_mix_wave
 //   posts_out HBM [VAMD_POSTS_STRIDE] floor1_fit's return (untouched by encode)
 //   ilogmask  HBM [n2]
 // Returns floor1_encode's nonzero flag (1 = non-trivial floor).
-VAMD_DEV int floor_fit_render_block(const FloorP &F, int n2, const float *mask, const unsigned char *cls,
+VAMD_DEV int floor_fit_render_block(const FloorP &F, int n2, const unsigned short *qc,
                                     FloorScratch *sc, int *__restrict__ posts_out, int *__restrict__ post_valid,
                                     int *__restrict__ ilogmask, PhaseClock &pc) {
   const int posts = F.posts, n = F.look_n;
@@ -305,22 +312,12 @@ VAMD_DEV int floor_fit_render_block(const FloorP &F, int n2, const float *mask, 
     int jprev = -1;
     FitAcc t;
     t.xa = t.ya = t.x2a = t.y2a = t.xya = t.an = t.xb = t.yb = t.x2b = t.y2b = t.xyb = t.bn = 0;
-    // the 16 bins' interval bytes and class bytes arrive in one 16-byte load each, the mask
-    // values in four 16-byte LDS reads
+    // the 16 bins' interval bytes arrive in one 16-byte load, their quantised-mask words in two
     const I4 jw = ((const I4 *)F.bin_interval)[span];
     const unsigned int jq4[4] = {(unsigned)jw.x, (unsigned)jw.y, (unsigned)jw.z, (unsigned)jw.w};
-    const I4 cw = ((const I4 *)cls)[span];
-    const unsigned int cq4[4] = {(unsigned)cw.x, (unsigned)cw.y, (unsigned)cw.z, (unsigned)cw.w};
-    float mk4[4][4];
-#if VAMD_GPU
-#pragma unroll
-#endif
-    for (int u = 0; u < 4; u++) {
-      const int qd = (span << 2) + u;
-      if ((qd << 2) < n) {
-        f4_get(((const F4 *)mask)[qd], mk4[u]);
-      }
-    }
+    const I4 qa = ((const I4 *)qc)[2 * span], qb = ((const I4 *)qc)[2 * span + 1];
+    const unsigned int qw[8] = {(unsigned)qa.x, (unsigned)qa.y, (unsigned)qa.z, (unsigned)qa.w,
+                                (unsigned)qb.x, (unsigned)qb.y, (unsigned)qb.z, (unsigned)qb.w};
 #if VAMD_GPU
 #pragma unroll
 #endif
@@ -337,7 +334,8 @@ VAMD_DEV int floor_fit_render_block(const FloorP &F, int n2, const float *mask, 
         const int jb = (int)((jq >> (8 * c)) & 0xff);
         const int j = (i < n && jb != 255) ? (jb & 0x7f) : 255;
         const bool shared = jb != 255 && (jb & 0x80);
-        const int q = j != 255 ? dBquant(mk4[u][c]) : 0;
+        const unsigned int qv = (qw[2 * u + (c >> 1)] >> (16 * (c & 1))) & 0xffffu;
+        const int q = j != 255 ? (int)(qv & 0x7fffu) : 0;
         if (j != jprev) {
           if (jprev >= 0) accumulate_flush(&sc->acc[jprev], t);
           jprev = j == 255 ? -1 : j;
@@ -345,7 +343,7 @@ VAMD_DEV int floor_fit_render_block(const FloorP &F, int n2, const float *mask, 
         if (q) {
           FitAcc b;
           b.xa = b.ya = b.x2a = b.y2a = b.xya = b.an = b.xb = b.yb = b.x2b = b.y2b = b.xyb = b.bn = 0;
-          const bool cls_a = (cq4[u] >> (8 * c)) & 1u;
+          const bool cls_a = (qv & 0x8000u) != 0;
           if (cls_a) {
             b.xa = i; b.ya = q; b.x2a = i * i; b.y2a = q * q; b.xya = i * q; b.an = 1;
           } else {
@@ -435,7 +433,7 @@ VAMD_DEV int floor_fit_render_block(const FloorP &F, int n2, const float *mask, 
       const int ly = post_Y(fitA, fitB, ln);
       const int hy = post_Y(fitA, fitB, hn);
       // (ly == -1 || hy == -1 => exit(1) in the reference: unreachable, fits are >= 0 or -200)
-      if (inspect_error_wave(lx, hx, ly, hy, mask, cls, F)) {
+      if (inspect_error_wave(lx, hx, ly, hy, qc, F)) {
         int ly0 = -200, ly1 = -200, hy0 = -200, hy1 = -200;
 #if VAMD_GPU
         int ret0, ret1;

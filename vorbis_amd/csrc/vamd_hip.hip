@@ -288,15 +288,13 @@ __global__ __launch_bounds__(64) void k_floor(PsyP P0, PsyP P1, FloorP F, DescP 
   const long blk = cb / ch;
   const PsyP &P = d_bt(d, blk) ? P1 : P0;
   const int n2 = P.n;
-  float *mask = (float *)vamd_smem;
-  unsigned char *cls = (unsigned char *)(mask + n2);  // [n2 rounded up to 16]
-  FloorScratch *sc = (FloorScratch *)(cls + ((n2 + 15) & ~15));
+  unsigned short *qc = (unsigned short *)vamd_smem;  // [n2 rounded up to 16]
+  FloorScratch *sc = (FloorScratch *)(qc + ((n2 + 15) & ~15));
   PhaseClock pc;
   pc.start(d.dbg ? d.dbg + 48 : nullptr);
-  offset_and_mix_wave(P, noise + cb * n2, tone + cb * n2, logmdct + cb * n2, mdct_raw + cb * n2, mdct + cb * n2, mask,
-                      cls, F.twofitatten, pc);
-  if (logmask_out) WAVE_FOR(i, n2) logmask_out[cb * n2 + i] = mask[i];
-  const int nzf = floor_fit_render_block(F, n2, mask, cls, sc, posts + cb * VAMD_POSTS_STRIDE, post_valid + cb,
+  offset_and_mix_wave(P, noise + cb * n2, tone + cb * n2, logmdct + cb * n2, mdct_raw + cb * n2, mdct + cb * n2,
+                      logmask_out ? logmask_out + cb * n2 : nullptr, qc, F.twofitatten, pc);
+  const int nzf = floor_fit_render_block(F, n2, qc, sc, posts + cb * VAMD_POSTS_STRIDE, post_valid + cb,
                                          ilogmask + cb * n2, pc);
   if (LANE == 0) nonzero[cb] = nzf;
   pc.flush();
@@ -847,7 +845,7 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level) {
     prof_mark(c), R->nst++;
   }
   if (level >= VAMD_LEVEL_FULL) {
-    hipLaunchKernelGGL(k_floor, dim3(gcb), dim3(64), (size_t)n2 * 4 + ((n2 + 15) & ~15) + sizeof(FloorScratch), s, P0, P1, c->B.floor[W],
+    hipLaunchKernelGGL(k_floor, dim3(gcb), dim3(64), (size_t)((n2 + 15) & ~15) * 2 + sizeof(FloorScratch), s, P0, P1, c->B.floor[W],
                        d, ch, p.noise, p.tone, p.logmdct, p.mdct_raw, p.mdct, R->io->logmask, p.posts, p.post_valid,
                        p.ilogmask, p.nonzero);
     prof_mark(c), R->nst++;
