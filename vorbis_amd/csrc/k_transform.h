@@ -354,7 +354,7 @@ VAMD_DEV void st_pair(float *p, int t, float a, float b) {  // p[t-1] = a, p[t] 
 // three: m = 0 does both k-only columns, m >= 1 the (k, i = 2m) butterfly.  ido is a power
 // of two (>= 4) for every pass but the first, so k and m are a shift and a mask.
 template <bool AL>
-VAMD_DEV void radf4_wave(int ido, int l1, const float *cc, float *ch, const float *__restrict__ wa1,
+VAMD_DEV void radf4_wave(int ido, int l1, const float *__restrict__ cc, float *__restrict__ ch, const float *__restrict__ wa1,
                          const float *__restrict__ wa2, const float *__restrict__ wa3) {
   const float hsqt2 = .70710678118654752f;
   const int t0 = l1 * ido;
@@ -430,7 +430,7 @@ VAMD_DEV void radf4_wave(int ido, int l1, const float *cc, float *ch, const floa
 
 // dradf2, lib/smallft.c:113-166, same flattening
 template <bool AL>
-VAMD_DEV void radf2_wave(int ido, int l1, const float *cc, float *ch, const float *__restrict__ wa1) {
+VAMD_DEV void radf2_wave(int ido, int l1, const float *__restrict__ cc, float *__restrict__ ch, const float *__restrict__ wa1) {
   const int t0 = l1 * ido;
   if (ido == 1) {
     WAVE_FOR(k, l1) {
