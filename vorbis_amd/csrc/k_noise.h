@@ -104,6 +104,7 @@ VAMD_DEV void running_sum_inplace(float *p, int n) {
 //    path -- a ds_write_b128 costs the same ~13 cycles whether 5 or 35 lanes carry data -- so
 //    sharing the instructions between blocks is what makes it cheaper.
 struct ScanSolo {
+  VAMD_MEM void before_terms() const {}  // the wave's own WAVE_SYNC after the previous evaluation suffices
   VAMD_MEM void operator()(float *S, int n) const {
     WAVE_SYNC();
     WAVE_FOR(a, 5) running_sum_inplace(S + a * (n + 4), n);
@@ -113,7 +114,10 @@ struct ScanSolo {
 #if VAMD_GPU
 struct ScanGroup {
   float *S_all;  // the workgroup's LDS: chain c lives at S_all + c*(n+4)
-  int nchains;   // 5 x waves
+  int nchains;   // 5 x blocks
+  // a block's arrays are shared by the waves that split its bins: nobody may overwrite them
+  // with new terms while a sibling is still evaluating lines from the previous sums
+  VAMD_MEM void before_terms() const { __syncthreads(); }
   VAMD_MEM void operator()(float *, int n) const {
     __syncthreads();
     if ((threadIdx.x >> 6) == 0) {
@@ -125,17 +129,21 @@ struct ScanGroup {
 #endif
 
 // bark_noise_hybridmp(n, bark, f, noise, offset, fixed).  f and noise are per-lane
-// register tiles: lane l owns the quads l, l+64, ... (LANE_QUADS), four bins each.
-template <class Scan>
+// register tiles: this wave owns the quads [q0, q1) of the block, lane l the quads q0+l,
+// q0+l+64, ... (SLICE_QUADS, QPS per lane), four bins each.  With one wave per block the slice is
+// the whole block; the persistent kernel gives a block to two waves so that the per-bin phases --
+// bound by each wave's dependent chains, not by issue slots -- take half as long.
+template <class Scan, int QPS>
 VAMD_DEV void bark_noise_wave(const PsyP &P, const float (*f)[4], float (*noise)[4], const float offset,
-                              const int fixed, float *S, const Scan &scan, PhaseClock &pc, int slot) {
-  const int n = P.n, nq = n >> 2;
+                              const int fixed, float *S, const Scan &scan, PhaseClock &pc, int slot, int q0, int q1) {
+  const int n = P.n;
   // each array starts 16 bytes further round the banks so that the five scanning lanes'
   // 16-byte accesses do not collide
   float *N = S, *X = S + (n + 4), *XX = S + 2 * (n + 4), *Y = S + 3 * (n + 4), *XY = S + 4 * (n + 4);
 
   // per-bin terms (lib/psy.c:571-597)
-  LANE_QUADS(kq, q, nq) {
+  scan.before_terms();
+  SLICE_QUADS(kq, q, q0, q1, QPS) {
     float tn[4], tx[4], txx[4], ty[4], txy[4];
 #if VAMD_GPU
 #pragma unroll
@@ -180,7 +188,7 @@ VAMD_DEV void bark_noise_wave(const PsyP &P, const float (*f)[4], float (*noise)
   last.B = 0.f;
   last.D = 1.f;
   if (P.bark_i2 > 0) last = bark_fit_from(P, S, P.bark_i2 - 1, P.bark[P.bark_i2 - 1]);
-  LANE_QUADS(kq, q, nq) {
+  SLICE_QUADS(kq, q, q0, q1, QPS) {
     const I4 bq = ((const I4 *)P.bark)[q];
     const int bk[4] = {bq.x, bq.y, bq.z, bq.w};
 #if VAMD_GPU
@@ -198,7 +206,7 @@ VAMD_DEV void bark_noise_wave(const PsyP &P, const float (*f)[4], float (*noise)
   if (fixed > 0) {
     // fixed-width window pass: keep the lower of the two curves (lib/psy.c:660-703)
     if (P.fix_i2 > 0) last = fixed_fit_at(P, S, P.fix_i2 - 1, fixed);
-    LANE_QUADS(kq, q, nq) {
+    SLICE_QUADS(kq, q, q0, q1, QPS) {
 #if VAMD_GPU
 #pragma unroll
 #endif
@@ -216,18 +224,17 @@ VAMD_DEV void bark_noise_wave(const PsyP &P, const float (*f)[4], float (*noise)
 }
 
 // _vp_noisemask on a block whose logmdct is already in a register tile
-template <class Scan>
+template <class Scan, int QPS>
 VAMD_DEV void noisemask_tile(const PsyP &P, const float (*lm)[4], float (*o)[4], float *S, const Scan &scan,
-                             PhaseClock &pc) {
-  const int nq = P.n >> 2;
-  float nz[VAMD_QPL][4], wk[VAMD_QPL][4];
-  bark_noise_wave(P, lm, nz, 140.f, -1, S, scan, pc, 0);
-  LANE_QUADS(kq, q, nq) {
+                             PhaseClock &pc, int q0, int q1) {
+  float nz[QPS][4], wk[QPS][4];
+  bark_noise_wave<Scan, QPS>(P, lm, nz, 140.f, -1, S, scan, pc, 0, q0, q1);
+  SLICE_QUADS(kq, q, q0, q1, QPS) {
     for (int c = 0; c < 4; c++) wk[kq][c] = lm[kq][c] - nz[kq][c];
   }
   pc.mark(3);
-  bark_noise_wave(P, wk, nz, 0.f, P.noisewindowfixed, S, scan, pc, 4);
-  LANE_QUADS(kq, q, nq) {
+  bark_noise_wave<Scan, QPS>(P, wk, nz, 0.f, P.noisewindowfixed, S, scan, pc, 4, q0, q1);
+  SLICE_QUADS(kq, q, q0, q1, QPS) {
 #if VAMD_GPU
 #pragma unroll
 #endif
@@ -251,7 +258,7 @@ VAMD_DEV void noisemask_block(const PsyP &P, const float *__restrict__ logmdct, 
   const int nq = P.n >> 2;
   float lm[VAMD_QPL][4], o[VAMD_QPL][4];
   LANE_QUADS(kq, q, nq) f4_get(((const F4 *)logmdct)[q], lm[kq]);
-  noisemask_tile(P, lm, o, S, ScanSolo(), pc);
+  noisemask_tile<ScanSolo, VAMD_QPL>(P, lm, o, S, ScanSolo(), pc, 0, nq);
   LANE_QUADS(kq, q, nq)((F4 *)out)[q] = f4_make(o[kq]);
 }
 

@@ -135,35 +135,42 @@ __global__ __launch_bounds__(64 * VAMD_XF_WAVES) void k_transform(XformP G, int 
   pc.flush();
 }
 
-// stage 2: _vp_noisemask.  Persistent workgroup of VAMD_NZ_WAVES waves per CU; every wave owns one
-// channel-block per round, and one wave runs the ordered running sums of the whole round
-// (ScanGroup, k_noise.h).
-#define VAMD_NZ_WAVES 7
-#define VAMD_NZ_WAVES_SHARED 6
-__global__ __launch_bounds__(64 * VAMD_NZ_WAVES) void k_noise(PsyP P0, PsyP P1, DescP d, int ch, long ncb,
-                                                             const float *__restrict__ logmdct,
-                                                             float *__restrict__ noise) {
-  const int nw = blockDim.x >> 6, wave = threadIdx.x >> 6;
+// stage 2: _vp_noisemask.  Persistent workgroup per CU holding VAMD_NZ_WAVES channel-blocks per round
+// (their running sums fill the LDS); each block's bins are shared by VAMD_NZ_SPLIT waves, and one
+// wave runs the ordered running sums of the whole round (ScanGroup, k_noise.h).
+#define VAMD_NZ_WAVES 7         // blocks per round when the kernel has the CU to itself
+#define VAMD_NZ_WAVES_SHARED 6  // ... when the tone kernels run beside it
+#define VAMD_NZ_SPLIT 2
+__global__ __launch_bounds__(64 * VAMD_NZ_WAVES * VAMD_NZ_SPLIT) void k_noise(PsyP P0, PsyP P1, DescP d, int ch,
+                                                                             long ncb,
+                                                                             const float *__restrict__ logmdct,
+                                                                             float *__restrict__ noise) {
+  const int wave = threadIdx.x >> 6;
+  const int nblk = (blockDim.x >> 6) / VAMD_NZ_SPLIT, slot = wave / VAMD_NZ_SPLIT, part = wave % VAMD_NZ_SPLIT;
   const int n2 = P0.n, nq = n2 >> 2;
+  // this wave's slice of the block's quads, a whole number of wave-widths
+  const int per = ((nq + VAMD_NZ_SPLIT * 64 - 1) / (VAMD_NZ_SPLIT * 64)) * 64;
+  const int q0 = part * per < nq ? part * per : nq, q1 = q0 + per < nq ? q0 + per : nq;
   float *S_all = (float *)vamd_smem;
-  float *S = S_all + wave * 5 * (n2 + 4);
+  float *S = S_all + slot * 5 * (n2 + 4);
   ScanGroup scan;
   scan.S_all = S_all;
-  scan.nchains = 5 * nw;
+  scan.nchains = 5 * nblk;
   PhaseClock pc;
   pc.start(d.dbg ? d.dbg + 16 : nullptr);
-  const long stride = (long)gridDim.x * nw;
+  const long stride = (long)gridDim.x * nblk;
   const long rounds = (ncb + stride - 1) / stride;  // identical for every wave: barriers inside
+  constexpr int QPS = (VAMD_QPL + VAMD_NZ_SPLIT - 1) / VAMD_NZ_SPLIT;
   for (long r = 0; r < rounds; r++) {
-    const long cb_raw = r * stride + (long)blockIdx.x * nw + wave;
+    const long cb_raw = r * stride + (long)blockIdx.x * nblk + slot;
     const bool live = cb_raw < ncb;
-    const long cb = live ? cb_raw : ncb - 1;  // idle waves shadow the last block (no store)
+    const long cb = live ? cb_raw : ncb - 1;  // idle slots shadow the last block (no store)
     const PsyP &P = d_bt(d, cb / ch) ? P1 : P0;
-    float lm[VAMD_QPL][4], o[VAMD_QPL][4];
-    LANE_QUADS(kq, q, nq) f4_get(((const F4 *)(logmdct + cb * n2))[q], lm[kq]);
-    noisemask_tile(P, lm, o, S, scan, pc);
+    float lm[QPS][4], o[QPS][4];
+    SLICE_QUADS(kq, q, q0, q1, QPS) f4_get(((const F4 *)(logmdct + cb * n2))[q], lm[kq]);
+    noisemask_tile<ScanGroup, QPS>(P, lm, o, S, scan, pc, q0, q1);
     if (live) {
-      LANE_QUADS(kq, q, nq)((F4 *)(noise + cb * n2))[q] = f4_make(o[kq]);
+      SLICE_QUADS(kq, q, q0, q1, QPS)((F4 *)(noise + cb * n2))[q] = f4_make(o[kq]);
     }
   }
   pc.flush();
@@ -822,7 +829,7 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level) {
       while (waves > 1 && (size_t)waves * 5 * (n2 + 4) * 4 > c->lds_per_block) waves--;
       const long groups = ((long)gcb + waves - 1) / waves;
       const unsigned grid = (unsigned)(groups < c->num_cus ? groups : c->num_cus);
-      hipLaunchKernelGGL(k_noise, dim3(grid), dim3(64 * waves), (size_t)waves * 5 * (n2 + 4) * 4, s, P0, P1, d, ch,
+      hipLaunchKernelGGL(k_noise, dim3(grid), dim3(64 * waves * VAMD_NZ_SPLIT), (size_t)waves * 5 * (n2 + 4) * 4, s, P0, P1, d, ch,
                          (long)gcb, p.logmdct, p.noise);
     }
     prof_mark(c), R->nst++;

@@ -64,12 +64,16 @@
 #if VAMD_GPU
 #define VAMD_QPL 4
 #define LANE_QUADS(kq, q, nq) _Pragma("unroll") for (int kq = 0, q = LANE; kq < VAMD_QPL; kq++, q += NLANES) if (q < (nq))
+// a slice [q0, q1) of the quads, QPS per lane: several waves can share one block's bins
+#define SLICE_QUADS(kq, q, q0, q1, QPS) \
+  _Pragma("unroll") for (int kq = 0, q = (q0) + LANE; kq < (QPS); kq++, q += NLANES) if (q < (q1))
 // the same for a whole n-sample block (2048 samples -> 8 quads per lane)
 #define VAMD_QPL2 8
 #define LANE_QUADS2(kq, q, nq) _Pragma("unroll") for (int kq = 0, q = LANE; kq < VAMD_QPL2; kq++, q += NLANES) if (q < (nq))
 #else
 #define VAMD_QPL 1024
 #define LANE_QUADS(kq, q, nq) for (int kq = 0, q = LANE; kq < VAMD_QPL && q < (nq); kq++, q += NLANES)
+#define SLICE_QUADS(kq, q, q0, q1, QPS) for (int kq = 0, q = (q0) + LANE; kq < (QPS) && q < (q1); kq++, q += NLANES)
 #define VAMD_QPL2 2048
 #define LANE_QUADS2(kq, q, nq) for (int kq = 0, q = LANE; kq < VAMD_QPL2 && q < (nq); kq++, q += NLANES)
 #endif
