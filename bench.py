@@ -122,6 +122,39 @@ def cpu_baseline(setup_name, seconds):
     }
 
 
+def neighbour_stages(an, pcm, outs, nb):
+    """Outside the timed region and outside the metric: throughput of the analysis with the residue
+    back-end's search enabled, and of the block-switching detector on a slice of the same samples."""
+    import vorbis_amd
+    res = dict(outs)
+    res.update(an.alloc_outputs(1, nb, ("res_class", "res_entries", "res_count")))
+    an.analyze(pcm, outs=res)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        an.analyze(pcm, outs=res)
+    torch.cuda.synchronize()
+    with_res = 3 * nb / (time.perf_counter() - t0)
+    entries = float(res["res_count"][:, 1].float().mean().item())
+    del res
+    ns = 256
+    streams = pcm[: ns * 64].reshape(ns, 64, pcm.shape[1], pcm.shape[2]).permute(0, 2, 1, 3).reshape(ns, pcm.shape[1], -1)
+    streams = streams.contiguous()                      # 256 streams of 64 blocks' samples
+    win, step = an.envelope_geometry()
+    steps = (streams.shape[2] - win) // step + 1
+    ret, st = an.envelope_search_batch(streams, steps)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        st.zero_()
+        an.envelope_search_batch(streams, steps, states=st, ret=ret)
+    torch.cuda.synchronize()
+    det = 3 * ns * steps / (time.perf_counter() - t0)
+    return {"analysis_with_residue_search": {"value": with_res, "unit": "stereo blocks/s", "mean_entries_per_block": entries},
+            "block_switching_detector": {"value": det, "unit": "stereo detector steps/s (one per 64 samples)",
+                                         "streams": ns, "steps_per_stream": int(steps)}}
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -249,6 +282,11 @@ def main():
             },
             "roofline": roof,
         }
+        if world == 1 and a.workload == "c4":
+            try:  # informational: the stages either side of the metric's path
+                line["neighbours"] = neighbour_stages(an, pcm, outs, nb)
+            except Exception as e:
+                line["neighbours"] = {"error": repr(e)}
         if world == 1 and not a.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(a.setup, a.cpu_seconds)
