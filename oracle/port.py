@@ -34,6 +34,10 @@ class PortEnvState(C.Structure):  # all-zero = start of stream
     _fields_ = [("stretch", C.c_int), ("f", _PortEnvFilter * 7 * 2)]
 
 
+class _MTaps(C.Structure):  # port_mtaps: per candidate packet of a bitrate-managed block
+    _fields_ = [(k, _i32p) for k in ("posts", "post_valid", "ilogmask", "iwork", "nonzero")]
+
+
 _lib = None
 
 
@@ -59,6 +63,8 @@ def lib():
                                      C.POINTER(_Taps)]
         L.port_time_dsp.restype = C.c_double
         L.port_time_dsp.argtypes = [C.c_void_p, _f32p, C.c_long, C.c_int]
+        L.port_tap_block_managed.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                             C.POINTER(_Taps), C.POINTER(_MTaps)]
         L.port_envelope_steps.argtypes = [C.c_void_p, C.POINTER(PortEnvState), _f32p, C.c_long, C.c_long, C.c_void_p]
         _lib = L
     return _lib
@@ -154,6 +160,31 @@ class PortEncoder:
         o["ampmax_out"] = float(o["ampmax_out"][0])
         o["res_class"] = rcls[:t.res_partvals].copy()
         o["res_entries"] = rent[:t.res_count].copy()
+        return o
+
+    def tap_block_managed(self, pcm, lW=1, W=1, nW=1, blocktype=1, ampmax_in=-9999.0):
+        """All 15 candidate packets' floors / residues of one block (same keys as RefEncoder.tap_block_managed)."""
+        ch = self.channels
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        n = self.blocksize(W)
+        n2 = n // 2
+        o = {"mdct": np.empty((ch, n2), np.float32), "logmask": np.empty((ch, n2), np.float32),
+             "ampmax_out": np.empty(1, np.float32)}
+        t = _Taps()
+        for k, v in o.items():
+            setattr(t, k, v.ctypes.data_as(_f32p))
+        mo = {"posts": np.zeros((15, ch, 65), np.int32), "post_valid": np.zeros((15, ch), np.int32),
+              "ilogmask": np.zeros((15, ch, n2), np.int32), "iwork": np.zeros((15, ch, n2), np.int32),
+              "nonzero": np.zeros((15, ch), np.int32)}
+        m = _MTaps()
+        for k, v in mo.items():
+            setattr(m, k, v.ctypes.data_as(_i32p))
+        r = self.L.port_tap_block_managed(self.h, _fp(pcm), lW, W, nW, blocktype, ampmax_in, C.byref(t), C.byref(m))
+        if r:
+            raise RuntimeError("port_tap_block_managed failed: %d" % r)
+        o["ampmax_out"] = float(o["ampmax_out"][0])
+        for k, v in mo.items():
+            o["m_" + k] = v
         return o
 
     def envelope_steps(self, pcm, nsteps, state=None):

@@ -45,6 +45,15 @@ typedef struct port_taps {
   long res_entries_cap, res_count;
 } port_taps;
 
+/* per candidate packet of a bitrate-managed block (lib/mapping0.c:507-573,596-646) */
+typedef struct port_mtaps {
+  int *posts;      /* [15][ch][VAMD_POSIT] */
+  int *post_valid; /* [15][ch] */
+  int *ilogmask;   /* [15][ch][n/2] */
+  int *iwork;      /* [15][ch][n/2] */
+  int *nonzero;    /* [15][ch] */
+} port_mtaps;
+
 static const float *tabf(const port_enc *e, uint32_t off) { return (const float *)(e->blob + off); }
 static const int32_t *tabi(const port_enc *e, uint32_t off) { return (const int32_t *)(e->blob + off); }
 
@@ -721,12 +730,12 @@ void port_tonemask(const port_enc *e, int psy, const float *logfft, float *logma
 }
 
 /* ---- _vp_offset_and_mix (offset_select 1), lib/psy.c:779-835 --------------------- */
-static void offset_and_mix(const port_enc *e, int psy, const float *noise, const float *tone, float *logmask,
-                           float *mdct, const float *logmdct) {
+static void offset_and_mix(const port_enc *e, int psy, const float *noise, const float *tone, int offset_select,
+                           float *logmask, float *mdct, const float *logmdct) {
   const vamd_psy_tab *p = &e->h.psy[psy];
   const int n = p->n;
-  const float *noff = tabf(e, p->off_noiseoffset) + n; /* noiseoffset[1] */
-  const float toneatt = p->tone_masteratt[1], cx = p->m_val;
+  const float *noff = tabf(e, p->off_noiseoffset) + (size_t)offset_select * n; /* noiseoffset[offset_select] */
+  const float toneatt = p->tone_masteratt[offset_select], cx = p->m_val;
   float de, coeffi;
   int i;
   for (i = 0; i < n; i++) {
@@ -735,14 +744,16 @@ static void offset_and_mix(const port_enc *e, int psy, const float *noise, const
     if (val > p->noisemaxsupp) val = p->noisemaxsupp;
     t = tone[i] + toneatt;
     logmask[i] = (val < t) ? t : val;
-    coeffi = -17.2;
-    val = val - logmdct[i];
-    if (val > coeffi) {
-      de = 1.0 - ((val - coeffi) * 0.005 * cx);
-      if (de < 0) de = 0.0001;
-    } else
-      de = 1.0 - ((val - coeffi) * 0.0003 * cx);
-    mdct[i] *= de;
+    if (offset_select == 1) { /* AoTuV M1 touches the spectrum for the middle curve only, lib/psy.c:807 */
+      coeffi = -17.2;
+      val = val - logmdct[i];
+      if (val > coeffi) {
+        de = 1.0 - ((val - coeffi) * 0.005 * cx);
+        if (de < 0) de = 0.0001;
+      } else
+        de = 1.0 - ((val - coeffi) * 0.0003 * cx);
+      mdct[i] *= de;
+    }
   }
 }
 
@@ -1078,11 +1089,11 @@ static float noise_norm(const vamd_psy_tab *p, int limit, float *r, float *q, fl
   return acc;
 }
 
-static void couple_quantize(const port_enc *e, int psy, int W, float **mdct, int **iwork, int *nonzero) {
+static void couple_quantize(const port_enc *e, int psy, int W, int blob, float **mdct, int **iwork, int *nonzero) {
   const vamd_psy_tab *p = &e->h.psy[psy];
   const vamd_mode_tab *m = &e->h.mode[W];
   const vamd_psy_global_tab *g = &e->h.psy_g;
-  const int ch = e->h.channels, blob = VAMD_PACKETBLOBS / 2;
+  const int ch = e->h.channels;
   const int n = p->n;
   const int partition = (p->normal_p ? p->normal_partition : 16);
   const int limit = g->coupling_pointlimit[p->blockflag][blob];
@@ -1307,8 +1318,35 @@ static int residue2(const port_enc *e, int W, int **in, const int *nonzero, port
 }
 
 /* ---- the block: mapping0_forward's VBR path, lib/mapping0.c:254-646 ------------------ */
+/* floor1_interpolate_fit, lib/floor1.c:731-750; returns whether a curve exists */
+static int interpolate_fit(const vamd_floor1_tab *f, const int *A, int haveA, const int *B, int haveB, int del,
+                           int *out) {
+  int i;
+  memset(out, 0, sizeof(int) * VAMD_POSIT);
+  if (!(haveA && haveB)) return 0;
+  for (i = 0; i < f->posts; i++) {
+    out[i] = ((65536 - del) * (A[i] & 0x7fff) + del * (B[i] & 0x7fff) + 32768) >> 16;
+    if (A[i] & 0x8000 && B[i] & 0x8000) out[i] |= 0x8000;
+  }
+  return 1;
+}
+
+static int tap_block(const port_enc *e, const float *pcm_in, int lW, int W, int nW, int blocktype, float ampmax_in,
+                     port_taps *t, port_mtaps *m);
+
 int port_tap_block(const port_enc *e, const float *pcm_in, int lW, int W, int nW, int blocktype, float ampmax_in,
                    port_taps *t) {
+  return tap_block(e, pcm_in, lW, W, nW, blocktype, ampmax_in, t, NULL);
+}
+
+/* the same block as a bitrate-managed encoder analyses it: all 15 candidate packets' floors and residues */
+int port_tap_block_managed(const port_enc *e, const float *pcm_in, int lW, int W, int nW, int blocktype,
+                           float ampmax_in, port_taps *t, port_mtaps *m) {
+  return tap_block(e, pcm_in, lW, W, nW, blocktype, ampmax_in, t, m);
+}
+
+static int tap_block(const port_enc *e, const float *pcm_in, int lW, int W, int nW, int blocktype, float ampmax_in,
+                     port_taps *t, port_mtaps *m) {
   const int ch = e->h.channels, n = e->h.blocksizes[W], n2 = n / 2;
   const int psy = blocktype + (W ? 2 : 0);
   const vamd_floor1_tab *fl = &e->h.mode[W].floor;
@@ -1318,6 +1356,7 @@ int port_tap_block(const port_enc *e, const float *pcm_in, int lW, int W, int nW
   float *noise = (float *)malloc(sizeof(float) * n2), *tone = (float *)malloc(sizeof(float) * n2);
   float global_ampmax = ampmax_in, local_ampmax[VAMD_MAX_CH];
   int nonzero[VAMD_MAX_CH], fit[VAMD_MAX_CH][VAMD_POSIT], have[VAMD_MAX_CH];
+  int mfit[VAMD_MAX_CH][VAMD_PACKETBLOBS][VAMD_POSIT], mhave[VAMD_MAX_CH][VAMD_PACKETBLOBS];
   float *gmp[VAMD_MAX_CH];
   int *iwp[VAMD_MAX_CH];
   int i, j;
@@ -1354,20 +1393,64 @@ int port_tap_block(const port_enc *e, const float *pcm_in, int lW, int W, int nW
     if (t->noise) memcpy(t->noise + (size_t)i * n2, noise, n2 * sizeof(float));
     port_tonemask(e, psy, logfft, tone, global_ampmax, local_ampmax[i]);
     if (t->tone) memcpy(t->tone + (size_t)i * n2, tone, n2 * sizeof(float));
-    offset_and_mix(e, psy, noise, tone, logmask, mdct, logmdct);
+    offset_and_mix(e, psy, noise, tone, 1, logmask, mdct, logmdct);
     if (t->logmask) memcpy(t->logmask + (size_t)i * n2, logmask, n2 * sizeof(float));
     if (t->mdct) memcpy(t->mdct + (size_t)i * n2, mdct, n2 * sizeof(float));
     memset(fit[i], 0, sizeof(fit[i]));
     have[i] = floor_fit(fl, logmdct, logmask, fit[i]);
     if (t->post_valid) t->post_valid[i] = have[i];
     if (t->posts) memcpy(t->posts + (size_t)i * VAMD_POSIT, fit[i], VAMD_POSIT * sizeof(int));
+    if (m) { /* the hi / lo fits and the interpolated curves, lib/mapping0.c:507-573 */
+      const int mid = VAMD_PACKETBLOBS / 2, last = VAMD_PACKETBLOBS - 1;
+      int k;
+      memset(mfit[i], 0, sizeof(mfit[i]));
+      memset(mhave[i], 0, sizeof(mhave[i]));
+      memcpy(mfit[i][mid], fit[i], sizeof(fit[i]));
+      mhave[i][mid] = have[i];
+      if (have[i]) {
+        offset_and_mix(e, psy, noise, tone, 2, logmask, mdct, logmdct);
+        mhave[i][last] = floor_fit(fl, logmdct, logmask, mfit[i][last]);
+        offset_and_mix(e, psy, noise, tone, 0, logmask, mdct, logmdct);
+        mhave[i][0] = floor_fit(fl, logmdct, logmask, mfit[i][0]);
+        for (k = 1; k < mid; k++)
+          mhave[i][k] = interpolate_fit(fl, mfit[i][0], mhave[i][0], mfit[i][mid], mhave[i][mid], k * 65536 / mid, mfit[i][k]);
+        for (k = mid + 1; k < last; k++)
+          mhave[i][k] = interpolate_fit(fl, mfit[i][mid], mhave[i][mid], mfit[i][last], mhave[i][last],
+                                        (k - mid) * 65536 / mid, mfit[i][k]);
+      }
+      for (k = 0; k < VAMD_PACKETBLOBS; k++) {
+        if (!mhave[i][k]) memset(mfit[i][k], 0, sizeof(mfit[i][k]));
+        if (m->post_valid) m->post_valid[k * ch + i] = mhave[i][k];
+        if (m->posts) memcpy(m->posts + ((size_t)k * ch + i) * VAMD_POSIT, mfit[i][k], VAMD_POSIT * sizeof(int));
+      }
+    }
   }
   if (t->ampmax_out) *t->ampmax_out = global_ampmax;
+  if (m) { /* lib/mapping0.c:596-646 for every candidate packet */
+    int k;
+    for (k = 0; k < VAMD_PACKETBLOBS; k++) {
+      for (i = 0; i < ch; i++) {
+        nonzero[i] = floor_curve(fl, mfit[i][k], mhave[i][k], n2, iwp[i]);
+        if (m->ilogmask) memcpy(m->ilogmask + ((size_t)k * ch + i) * n2, iwp[i], n2 * sizeof(int));
+      }
+      couple_quantize(e, psy, W, k, gmp, iwp, nonzero);
+      for (i = 0; i < ch; i++) {
+        if (m->iwork) memcpy(m->iwork + ((size_t)k * ch + i) * n2, iwp[i], n2 * sizeof(int));
+        if (m->nonzero) m->nonzero[k * ch + i] = nonzero[i];
+      }
+    }
+    free(pcm);
+    free(gm);
+    free(iw);
+    free(noise);
+    free(tone);
+    return 0;
+  }
   for (i = 0; i < ch; i++) {
     nonzero[i] = floor_curve(fl, fit[i], have[i], n2, iwp[i]);
     if (t->ilogmask) memcpy(t->ilogmask + (size_t)i * n2, iwp[i], n2 * sizeof(int));
   }
-  couple_quantize(e, psy, W, gmp, iwp, nonzero);
+  couple_quantize(e, psy, W, VAMD_PACKETBLOBS / 2, gmp, iwp, nonzero);
   for (i = 0; i < ch; i++) {
     if (t->iwork) memcpy(t->iwork + (size_t)i * n2, iwp[i], n2 * sizeof(int));
     if (t->nonzero) t->nonzero[i] = nonzero[i];

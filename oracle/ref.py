@@ -38,6 +38,15 @@ class _Taps(C.Structure):
     ]
 
 
+PACKETBLOBS = 15
+
+
+class _MTaps(C.Structure):  # ref_mtaps (ref_harness.c): per candidate packet of a bitrate-managed encode
+    _fields_ = [("posts", _i32p), ("post_valid", _i32p), ("ilogmask", _i32p), ("iwork", _i32p), ("nonzero", _i32p),
+                ("packets", _u8p), ("packets_cap", C.c_long), ("packet_bytes", C.c_long * PACKETBLOBS),
+                ("packets_match_real", C.c_int)]
+
+
 class _BlockRec(C.Structure):
     _fields_ = [
         ("lW", C.c_int), ("W", C.c_int), ("nW", C.c_int), ("blocktype", C.c_int),
@@ -100,6 +109,11 @@ def lib(hybrid=False):
         L.ref_envelope_get.restype = C.c_long
         L.ref_envelope_get.argtypes = [C.c_void_p, _f32p, C.c_long, C.POINTER(C.c_long), _i32p, C.c_long,
                                        C.POINTER(_EnvState)]
+        L.ref_open_managed.restype = C.c_void_p
+        L.ref_open_managed.argtypes = [C.c_int, C.c_long, C.c_long, C.c_long, C.c_long]
+        L.ref_is_managed.argtypes = [C.c_void_p]
+        L.ref_tap_block_managed.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                            C.POINTER(_Taps), C.POINTER(_MTaps)]
         _libs[path] = L
     return _libs[path]
 
@@ -115,12 +129,17 @@ def _ip(a):
 class RefEncoder:
     """One reference encoder state (vorbis_info + vorbis_dsp_state + a vorbis_block)."""
 
-    def __init__(self, channels=2, rate=44100, quality=0.4, hybrid=False):
+    def __init__(self, channels=2, rate=44100, quality=0.4, hybrid=False, managed=None):
+        """quality: libvorbisenc VBR quality; or managed=(max, nominal, min) bitrates for a
+        bitrate-managed encoder (vorbis_encode_init), whose blocks carry 15 candidate packets."""
         self.L = lib(hybrid)
-        self.h = self.L.ref_open(channels, rate, quality)
+        if managed is None:
+            self.h = self.L.ref_open(channels, rate, quality)
+        else:
+            self.h = self.L.ref_open_managed(channels, rate, *[int(v) for v in managed])
         if not self.h:
-            raise RuntimeError("vorbis_encode_init_vbr failed")
-        self.channels, self.rate, self.quality = channels, rate, quality
+            raise RuntimeError("vorbis_encode_init[_vbr] failed")
+        self.channels, self.rate, self.quality, self.managed = channels, rate, quality, managed
 
     def close(self):
         if self.h:
@@ -229,6 +248,42 @@ class RefEncoder:
         assert t.res_count <= rent.size
         o["res_class"] = rcls[:t.res_partvals].copy()
         o["res_entries"] = rent[:t.res_count].copy()
+        return o
+
+    def tap_block_managed(self, pcm, lW=1, W=1, nW=1, blocktype=BLOCKTYPE_LONG, ampmax_in=-9999.0):
+        """Managed-mode taps: the shared tensors of tap_block (mdct, logmask of select 1, ampmax) plus, per
+        candidate packet k = 0..14, posts / post_valid / ilogmask / iwork / nonzero and the packet bytes."""
+        ch = self.channels
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        n = self.blocksize(W)
+        assert pcm.shape == (ch, n), pcm.shape
+        n2 = n // 2
+        o = {"mdct_raw": np.empty((ch, n2), np.float32), "logfft": np.empty((ch, n2), np.float32),
+             "logmdct": np.empty((ch, n2), np.float32), "noise": np.empty((ch, n2), np.float32),
+             "tone": np.empty((ch, n2), np.float32), "logmask": np.empty((ch, n2), np.float32),
+             "mdct": np.empty((ch, n2), np.float32), "local_ampmax": np.empty(ch, np.float32),
+             "ampmax_out": np.empty(1, np.float32)}
+        t = _Taps()
+        for k, v in o.items():
+            setattr(t, k, _fp(v))
+        mo = {"posts": np.zeros((PACKETBLOBS, ch, 65), np.int32), "post_valid": np.zeros((PACKETBLOBS, ch), np.int32),
+              "ilogmask": np.zeros((PACKETBLOBS, ch, n2), np.int32), "iwork": np.zeros((PACKETBLOBS, ch, n2), np.int32),
+              "nonzero": np.zeros((PACKETBLOBS, ch), np.int32)}
+        m = _MTaps()
+        for k, v in mo.items():
+            setattr(m, k, _ip(v))
+        pk = np.zeros(1 << 20, np.uint8)
+        m.packets, m.packets_cap = pk.ctypes.data_as(_u8p), pk.size
+        ret = self.L.ref_tap_block_managed(self.h, _fp(pcm), lW, W, nW, blocktype, ampmax_in, C.byref(t), C.byref(m))
+        if ret:
+            raise RuntimeError("ref_tap_block_managed failed: %d" % ret)
+        o["ampmax_out"] = float(o["ampmax_out"][0])
+        for k, v in mo.items():
+            o["m_" + k] = v
+        sizes = [int(m.packet_bytes[k]) for k in range(PACKETBLOBS)]
+        offs = np.concatenate([[0], np.cumsum(sizes)])
+        o["m_packets"] = [bytes(pk[offs[k]:offs[k + 1]]) for k in range(PACKETBLOBS)]
+        o["packets_match_real"] = bool(m.packets_match_real)
         return o
 
     def encode_stream(self, pcm, max_blocks=1 << 16):

@@ -61,6 +61,26 @@ ref_enc *ref_open(int channels, long rate, float quality) {
   return e;
 }
 
+/* a bitrate-managed encoder (vorbis_encode_init: ABR/CBR): mapping0_forward then builds all
+ * PACKETBLOBS candidate packets per block (lib/mapping0.c:507-573,596-687) */
+ref_enc *ref_open_managed(int channels, long rate, long max_bitrate, long nominal_bitrate, long min_bitrate) {
+  ref_enc *e = (ref_enc *)calloc(1, sizeof(*e));
+  if (!e) return NULL;
+  vorbis_info_init(&e->vi);
+  if (vorbis_encode_init(&e->vi, channels, rate, max_bitrate, nominal_bitrate, min_bitrate)) {
+    vorbis_info_clear(&e->vi);
+    free(e);
+    return NULL;
+  }
+  vorbis_analysis_init(&e->vd, &e->vi);
+  vorbis_block_init(&e->vd, &e->vb);
+  e->channels = channels;
+  e->quality = -999.f;
+  return e;
+}
+
+int ref_is_managed(ref_enc *e) { return vorbis_bitrate_managed(&e->vb) ? 1 : 0; }
+
 void ref_close(ref_enc *e) {
   if (!e) return;
   vorbis_block_clear(&e->vb);
@@ -167,6 +187,19 @@ typedef struct ref_taps {
   long res_count;            /* out */
 } ref_taps;
 
+/* managed-mode taps: everything that exists once per candidate packet (blob) */
+typedef struct ref_mtaps {
+  int *posts;        /* [PACKETBLOBS][ch][65] floor_posts[i][k]; all-zero + post_valid 0 where NULL */
+  int *post_valid;   /* [PACKETBLOBS][ch] */
+  int *ilogmask;     /* [PACKETBLOBS][ch][n/2] */
+  int *iwork;        /* [PACKETBLOBS][ch][n/2] */
+  int *nonzero;      /* [PACKETBLOBS][ch] */
+  unsigned char *packets; /* the PACKETBLOBS candidate packets back to back */
+  long packets_cap;
+  long packet_bytes[PACKETBLOBS]; /* out */
+  int packets_match_real;         /* out */
+} ref_mtaps;
+
 /* lib/res0.c is compiled with -Dvorbis_book_encode=ref_tap_book_encode (oracle/Makefile): the
  * reference source is untouched, its calls to the bit-writer just pass through here first */
 #undef vorbis_book_encode
@@ -225,7 +258,7 @@ long ref_real_block(ref_enc *e, const float *pcm, int lW, int W, int nW, int blo
 
 /* mapping0_forward restated over the reference's extern functions, VBR branch only */
 static int tap_core(ref_enc *e, const float *pcm, int lW, int W, int nW, int blocktype,
-                    float ampmax_in, ref_taps *t, int with_residue) {
+                    float ampmax_in, ref_taps *t, int with_residue, ref_mtaps *m) {
   vorbis_block *vb = &e->vb;
   vorbis_info *vi = &e->vi;
   codec_setup_info *ci = (codec_setup_info *)vi->codec_setup;
@@ -241,10 +274,12 @@ static int tap_core(ref_enc *e, const float *pcm, int lW, int W, int nW, int blo
   float *gmdct[8];
   int *iwork[8];
   int *posts[8];
+  int *mposts[8][PACKETBLOBS];
   float *noise, *tone;
   oggpack_buffer *opb;
+  const int managed = vorbis_bitrate_managed(vb) ? 1 : 0;
 
-  if (vorbis_bitrate_managed(vb) || ch > 8) return OV_EIMPL;
+  if ((managed && !m) || (!managed && m) || ch > 8) return OV_EIMPL;
 
   load_block(e, pcm, lW, W, nW, blocktype, ampmax_in);
   for (i = 0; i < PACKETBLOBS; i++) oggpack_reset(vbi->packetblob[i]);
@@ -303,9 +338,86 @@ static int tap_core(ref_enc *e, const float *pcm, int lW, int W, int nW, int blo
       memset(t->posts + (size_t)i * 65, 0, 65 * sizeof(int));
       if (posts[i]) memcpy(t->posts + (size_t)i * 65, posts[i], np * sizeof(int));
     }
+    if (managed) { /* lib/mapping0.c:507-573 */
+      vorbis_look_floor1 *fl = (vorbis_look_floor1 *)b->flr[info->floorsubmap[submap]];
+      int kk;
+      for (kk = 0; kk < PACKETBLOBS; kk++) mposts[i][kk] = NULL;
+      mposts[i][PACKETBLOBS / 2] = posts[i];
+      if (posts[i]) {
+        _vp_offset_and_mix(psy_look, noise, tone, 2, logmask, mdct, logmdct);
+        mposts[i][PACKETBLOBS - 1] = floor1_fit(vb, fl, logmdct, logmask);
+        _vp_offset_and_mix(psy_look, noise, tone, 0, logmask, mdct, logmdct);
+        mposts[i][0] = floor1_fit(vb, fl, logmdct, logmask);
+        for (kk = 1; kk < PACKETBLOBS / 2; kk++)
+          mposts[i][kk] = floor1_interpolate_fit(vb, fl, mposts[i][0], mposts[i][PACKETBLOBS / 2],
+                                                 kk * 65536 / (PACKETBLOBS / 2));
+        for (kk = PACKETBLOBS / 2 + 1; kk < PACKETBLOBS - 1; kk++)
+          mposts[i][kk] = floor1_interpolate_fit(vb, fl, mposts[i][PACKETBLOBS / 2], mposts[i][PACKETBLOBS - 1],
+                                                 (kk - PACKETBLOBS / 2) * 65536 / (PACKETBLOBS / 2));
+      }
+      for (kk = 0; kk < PACKETBLOBS; kk++) {
+        if (m->post_valid) m->post_valid[kk * ch + i] = mposts[i][kk] ? 1 : 0;
+        if (m->posts) {
+          int *dst = m->posts + ((size_t)kk * ch + i) * 65;
+          memset(dst, 0, 65 * sizeof(int));
+          if (mposts[i][kk]) memcpy(dst, mposts[i][kk], fl->posts * sizeof(int));
+        }
+      }
+    }
   }
   vbi->ampmax = global_ampmax;
   if (t->ampmax_out) *t->ampmax_out = global_ampmax;
+
+  if (managed) { /* lib/mapping0.c:596-687, every candidate packet */
+    int **couple_bundle = (int **)alloca(sizeof(*couple_bundle) * ch);
+    int *zerobundle = (int *)alloca(sizeof(*zerobundle) * ch);
+    long used = 0;
+    int kk;
+    for (kk = 0; kk < PACKETBLOBS; kk++) {
+      opb = vbi->packetblob[kk];
+      oggpack_write(opb, 0, 1);
+      oggpack_write(opb, W, b->modebits);
+      if (W) {
+        oggpack_write(opb, lW, 1);
+        oggpack_write(opb, nW, 1);
+      }
+      for (i = 0; i < ch; i++) {
+        int submap = info->chmuxlist[i];
+        nonzero[i] = floor1_encode(opb, vb, (vorbis_look_floor1 *)b->flr[info->floorsubmap[submap]], mposts[i][kk],
+                                   iwork[i]);
+        if (m->ilogmask) memcpy(m->ilogmask + ((size_t)kk * ch + i) * n2, iwork[i], n2 * sizeof(int));
+      }
+      _vp_couple_quantize_normalize(kk, &ci->psy_g_param, psy_look, info, gmdct, iwork, nonzero,
+                                    ci->psy_g_param.sliding_lowpass[W][kk], ch);
+      for (i = 0; i < ch; i++) {
+        if (m->iwork) memcpy(m->iwork + ((size_t)kk * ch + i) * n2, iwork[i], n2 * sizeof(int));
+        if (m->nonzero) m->nonzero[kk * ch + i] = nonzero[i];
+      }
+      for (i = 0; i < info->submaps; i++) {
+        int ch_in_bundle = 0;
+        long **classifications;
+        int resnum = info->residuesubmap[i];
+        for (j = 0; j < ch; j++)
+          if (info->chmuxlist[j] == i) {
+            zerobundle[ch_in_bundle] = nonzero[j] ? 1 : 0;
+            couple_bundle[ch_in_bundle++] = iwork[j];
+          }
+        classifications = _residue_P[ci->residue_type[resnum]]->class(vb, b->residue[resnum], couple_bundle,
+                                                                     zerobundle, ch_in_bundle);
+        ch_in_bundle = 0;
+        for (j = 0; j < ch; j++)
+          if (info->chmuxlist[j] == i) couple_bundle[ch_in_bundle++] = iwork[j];
+        _residue_P[ci->residue_type[resnum]]->forward(opb, vb, b->residue[resnum], couple_bundle, zerobundle,
+                                                       ch_in_bundle, classifications, i);
+      }
+      m->packet_bytes[kk] = oggpack_bytes(opb);
+      if (m->packets && used + m->packet_bytes[kk] <= m->packets_cap)
+        memcpy(m->packets + used, oggpack_get_buffer(opb), m->packet_bytes[kk]);
+      used += m->packet_bytes[kk];
+    }
+    t->packet_bytes = 0;
+    return 0;
+  }
 
   oggpack_write(opb, 0, 1);
   oggpack_write(opb, W, b->modebits);
@@ -378,7 +490,7 @@ int ref_tap_block(ref_enc *e, const float *pcm, int lW, int W, int nW, int block
   int ret;
   if (realbytes < 0) { free(realpkt); return (int)realbytes; }
   t->ampmax_out = &tap_ampmax;
-  ret = tap_core(e, pcm, lW, W, nW, blocktype, ampmax_in, t, 1);
+  ret = tap_core(e, pcm, lW, W, nW, blocktype, ampmax_in, t, 1, NULL);
   t->ampmax_out = user_ampmax;
   if (user_ampmax) *user_ampmax = tap_ampmax;
   if (ret == 0) {
@@ -400,6 +512,44 @@ typedef struct ref_block_rec {
   long packet_offset;  /* offset of this block's packet in packets_out */
   long packet_bytes;
 } ref_block_rec;
+
+/* Managed-mode counterpart of ref_tap_block: runs the real vorbis_analysis(vb, NULL) first (the
+ * only legal call in managed mode, lib/analysis.c:50-53) and keeps its PACKETBLOBS candidate
+ * packets, then the tap restatement, and compares all of them byte for byte. */
+int ref_tap_block_managed(ref_enc *e, const float *pcm, int lW, int W, int nW, int blocktype, float ampmax_in,
+                          ref_taps *t, ref_mtaps *m) {
+  vorbis_block_internal *vbi = (vorbis_block_internal *)e->vb.internal;
+  unsigned char *real = (unsigned char *)malloc(1 << 20);
+  long realbytes[PACKETBLOBS], used = 0, at = 0;
+  float real_ampmax, tap_ampmax = 0.f, *user_ampmax = t->ampmax_out;
+  int ret, k, same = 1;
+  if (!ref_is_managed(e)) { free(real); return OV_EINVAL; }
+  load_block(e, pcm, lW, W, nW, blocktype, ampmax_in);
+  ret = vorbis_analysis(&e->vb, NULL);
+  if (ret) { free(real); return ret; }
+  real_ampmax = vbi->ampmax;
+  for (k = 0; k < PACKETBLOBS; k++) {
+    realbytes[k] = oggpack_bytes(vbi->packetblob[k]);
+    if (used + realbytes[k] > (1 << 20)) { free(real); return -1; }
+    memcpy(real + used, oggpack_get_buffer(vbi->packetblob[k]), realbytes[k]);
+    used += realbytes[k];
+  }
+  t->ampmax_out = &tap_ampmax;
+  ret = tap_core(e, pcm, lW, W, nW, blocktype, ampmax_in, t, 1, m);
+  t->ampmax_out = user_ampmax;
+  if (user_ampmax) *user_ampmax = tap_ampmax;
+  if (ret == 0) {
+    for (k = 0; k < PACKETBLOBS; k++) {
+      if (m->packet_bytes[k] != realbytes[k] ||
+          memcmp(oggpack_get_buffer(vbi->packetblob[k]), real + at, realbytes[k]) != 0)
+        same = 0;
+      at += realbytes[k];
+    }
+    m->packets_match_real = same && real_ampmax == tap_ampmax;
+  }
+  free(real);
+  return ret;
+}
 
 /* Feed planar PCM pcm[ch][frames] in 1024-frame chunks through
  * vorbis_analysis_buffer/_wrote/_blockout/vorbis_analysis exactly as
@@ -563,7 +713,7 @@ double ref_time_dsp(ref_enc *e, const float *pcm, long nblocks, int reps) {
     for (k = 0; k < nblocks; k++) {
       const float *blk = pcm + (size_t)k * e->channels * n;
       clock_gettime(CLOCK_MONOTONIC, &t0);
-      tap_core(e, blk, 1, 1, 1, BLOCKTYPE_LONG, -9999.f, &t, 0);
+      tap_core(e, blk, 1, 1, 1, BLOCKTYPE_LONG, -9999.f, &t, 0, NULL);
       clock_gettime(CLOCK_MONOTONIC, &t1);
       total += (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
     }
