@@ -276,31 +276,27 @@ VAMD_DEV int render_point(int x0, int x1, int y0, int y1, int x) {
   return dy < 0 ? y0 - off : y0 + off;
 }
 
-// floor1_fit + the curve half of floor1_encode for one channel-block.
-//   qc        LDS [n2]   quantised mask + class bit, see offset_and_mix_wave
-//   posts_out HBM [VAMD_POSTS_STRIDE] floor1_fit's return (untouched by encode)
-//   ilogmask  HBM [n2]
-// Returns floor1_encode's nonzero flag (1 = non-trivial floor).
-VAMD_DEV int floor_fit_render_block(const FloorP &F, int n2, const unsigned short *qc,
-                                    FloorScratch *sc, int *__restrict__ posts_out, int *__restrict__ post_valid,
-                                    int *__restrict__ ilogmask, PhaseClock &pc) {
+// floor1_fit for one channel-block (lib/floor1.c:576-729).
+//   qc    LDS [n2]   quantised mask + class bit, see offset_and_mix_wave
+//   outp  floor1_fit's return, one post per lane (bit 15 = unused flag); untouched when it returns 0
+// Returns 1, or 0 where the reference returns NULL (nothing above the fit's floor).
+VAMD_DEV int floor_fit_posts(const FloorP &F, const unsigned short *qc, FloorScratch *sc, LaneInts &outp,
+                             PhaseClock &pc) {
   const int posts = F.posts, n = F.look_n;
 
-  LaneInts postlist, sorted_index, forward_index, reverse_index, hineighbor, loneighbor;
+  LaneInts postlist, sorted_index, reverse_index, hineighbor, loneighbor;
   postlist.load(F.postlist, posts);
   sorted_index.load(F.sorted_index, posts);
-  forward_index.load(F.forward_index, posts);
   reverse_index.load(F.reverse_index, posts);
   hineighbor.load(F.hineighbor, posts);
   loneighbor.load(F.loneighbor, posts);
-  LaneInts fitA, fitB, lon, hin, memo, outp, post;
+  LaneInts fitA, fitB, lon, hin, memo;
   fitA.fill(-200);
   fitB.fill(-200);
   lon.fill(0);
   hin.fill(1);
   memo.fill(-1);
   outp.fill(0);
-  post.fill(0);
   WAVE_FOR(i, (posts - 1) * 12)((int *)sc->acc)[i] = 0;
   WAVE_SYNC();
   // accumulate_fit for all post intervals at once: every lane takes quads of bins, sums
@@ -396,14 +392,7 @@ VAMD_DEV int floor_fit_render_block(const FloorP &F, int n2, const unsigned shor
   }
   pc.mark(1);
 
-  if (!nz) {
-    // floor1_fit returns NULL; floor1_encode writes a zero curve (lib/floor1.c:948-952)
-    WAVE_FOR(i, VAMD_POSTS_STRIDE) if (posts_out) posts_out[i] = 0;
-    if (post_valid && LANE == 0) *post_valid = 0;
-    WAVE_FOR(i, n2) if (ilogmask) ilogmask[i] = 0;
-    WAVE_SYNC();
-    return 0;
-  }
+  if (!nz) return 0;  // floor1_fit returns NULL
 
   // ---- greedy progressive split, lib/floor1.c:610-698.  Wave-uniform: every lane
   // walks the same decisions; the state is in lane registers.
@@ -501,6 +490,34 @@ VAMD_DEV int floor_fit_render_block(const FloorP &F, int n2, const unsigned shor
       }
     }
   }
+  return 1;
+}
+
+// The curve half of floor1_encode for one set of posts (lib/floor1.c:766-831,923-952): quantise,
+// predict, settle the unused flags, render the integer curve.
+//   outp / valid  a floor1_fit result (floor_fit_posts) or an interpolation of two
+//   posts_out HBM [VAMD_POSTS_STRIDE] the posts as fitted (what the host hands floor1_encode)
+//   ilogmask  HBM [n2]
+// Returns floor1_encode's nonzero flag (1 = non-trivial floor).
+VAMD_DEV int floor_encode_render(const FloorP &F, int n2, const LaneInts &outp, int valid, FloorScratch *sc,
+                                 int *__restrict__ posts_out, int *__restrict__ post_valid,
+                                 int *__restrict__ ilogmask, PhaseClock &pc) {
+  const int posts = F.posts;
+  if (!valid) {
+    // no fit: floor1_encode writes a zero curve (lib/floor1.c:948-952)
+    WAVE_FOR(i, VAMD_POSTS_STRIDE) if (posts_out) posts_out[i] = 0;
+    if (post_valid && LANE == 0) *post_valid = 0;
+    WAVE_FOR(i, n2) if (ilogmask) ilogmask[i] = 0;
+    WAVE_SYNC();
+    return 0;
+  }
+  LaneInts postlist, forward_index, lo2, hi2, level, post;
+  postlist.load(F.postlist, posts);
+  forward_index.load(F.forward_index, posts);
+  lo2.load_shifted(F.loneighbor, 2, posts);
+  hi2.load_shifted(F.hineighbor, 2, posts);
+  level.load(F.level, posts);
+  post.fill(0);
 #if VAMD_GPU
   if (posts_out && LANE < VAMD_POSTS_STRIDE) posts_out[LANE] = LANE < posts ? outp.mine() : 0;
 #else
@@ -601,6 +618,29 @@ VAMD_DEV int floor_fit_render_block(const FloorP &F, int n2, const unsigned shor
   WAVE_SYNC();
   pc.mark(4);
   return 1;
+}
+
+// floor1_fit + the curve half of floor1_encode for one channel-block (the VBR path: one curve)
+VAMD_DEV int floor_fit_render_block(const FloorP &F, int n2, const unsigned short *qc, FloorScratch *sc,
+                                    int *__restrict__ posts_out, int *__restrict__ post_valid,
+                                    int *__restrict__ ilogmask, PhaseClock &pc) {
+  LaneInts outp;
+  const int valid = floor_fit_posts(F, qc, sc, outp, pc);
+  return floor_encode_render(F, n2, outp, valid, sc, posts_out, post_valid, ilogmask, pc);
+}
+
+// floor1_interpolate_fit, lib/floor1.c:731-750, one post per lane
+VAMD_DEV void floor_interpolate(const LaneInts &A, int haveA, const LaneInts &B, int haveB, int del, LaneInts &out,
+                                int *have) {
+  *have = haveA && haveB;
+  out.fill(0);
+  if (!*have) return;
+  WAVE_FOR(i, 64) {
+    const int a = A.at(i), b = B.at(i);
+    int v = ((65536 - del) * (a & 0x7fff) + del * (b & 0x7fff) + 32768) >> 16;
+    if ((a & 0x8000) && (b & 0x8000)) v |= 0x8000;
+    out.put(i, v);
+  }
 }
 
 }  // namespace vamd
