@@ -207,6 +207,38 @@ int vamd_envelope_search_batch(vamd_ctx *ctx, const float *pcm, long stream_stri
 int vamd_envelope_search(vamd_ctx *ctx, const float *const *pcm, long nsteps, vamd_envelope_state *state,
                          unsigned char *ret);
 
+/* ---- bitrate-managed blocks ----------------------------------------------
+ * With a bitrate manager (vorbis_encode_init; vorbis_bitrate_managed()) mapping0_forward prepares
+ * PACKETBLOBS = 15 candidate packets per block and lets vorbis_bitrate_addblock() pick one: two more
+ * floor fits on the lower / higher noise curves (offset_select 0 / 2), twelve interpolated floors
+ * (floor1_interpolate_fit), and for every candidate its own floor curve, couple/quantise with that
+ * candidate's coupling parameters, and residue (lib/mapping0.c:507-573,596-687).  The spectrum, the
+ * select-1 mask and ampmax are shared.  Outputs are laid out [block][candidate][channel][...]. */
+typedef struct vamd_managed_io {
+  int32_t  *posts;       /* out [nb][15][ch][VAMD_POSTS_STRIDE] floor_posts[i][k]                (required) */
+  int32_t  *post_valid;  /* out [nb][15][ch] 0 where floor_posts[i][k] is NULL                   (required) */
+  int32_t  *iwork;       /* out [nb][15][ch][n/2] quantised, coupled residue of candidate k      (required) */
+  int32_t  *nonzero;     /* out [nb][15][ch]                                                     (required) */
+  int32_t  *res_class;   /* out [nb][15][VAMD_RES_CLASS_STRIDE]   optional, all three or none */
+  uint16_t *res_entries; /* out [nb][15][vamd_residue_capacity(ctx, W)] */
+  int32_t  *res_count;   /* out [nb][15][2] */
+} vamd_managed_io;
+
+/* vamd_analyze_batch(level FULL) for bitrate-managed blocks: `io` carries pcm and the shared outputs
+ * (mdct, logmask, ampmax_out, the psy taps; its per-candidate fields posts/post_valid/ilogmask/iwork/
+ * nonzero/res_* are ignored), `m` the per-candidate ones.  Works on any setup blob: the fifteen
+ * candidates' parameters are part of every libvorbisenc setup. */
+int vamd_analyze_batch_managed(vamd_ctx *ctx, const vamd_batch_desc *desc, const vamd_batch_io *io,
+                               const vamd_managed_io *m);
+
+/* One managed block from host memory (the binding's call): mdct [ch][n/2] and ampmax_out are shared,
+ * posts [15][ch][VAMD_POSTS_STRIDE], post_valid / nonzero [15][ch], iwork [15][ch][n/2]; the res_*
+ * arrays ([15][...] as above) may be NULL. */
+int vamd_analyze_block_managed(vamd_ctx *ctx, const float *const *pcm, int lW, int W, int nW, int blocktype,
+                               float ampmax_in, float *mdct, float *ampmax_out, int32_t *posts,
+                               int32_t *post_valid, int32_t *iwork, int32_t *nonzero, int32_t *res_class,
+                               uint16_t *res_entries, int32_t *res_count);
+
 /* vamd_analyze_block() plus the residue back-end's decisions for the block (host pointers; any may be
  * NULL).  res_entries must hold vamd_residue_capacity(ctx, W) entries, res_class VAMD_RES_CLASS_STRIDE
  * ints, res_count 2 ints.  Fails with VAMD_EIMPL when res_* are asked for a mode that is not covered. */

@@ -20,9 +20,10 @@
  * tests/test_gpu_dropin.py checks that an encode through the hybrid library
  * emits byte-identical packets to the pure reference.
  *
- * Managed-bitrate setups (15 packet blobs) are outside the covered path: the
- * binding falls through to the reference's CPU forward for them (host code
- * choosing its own CPU implementation -- the GPU library itself has no CPU path).
+ * Bitrate-managed encoders get all PACKETBLOBS candidate packets the same way
+ * (vamd_analyze_block_managed); the bitrate manager that picks one is untouched host code.
+ * Only channel counts above VAMD_MAX_CH fall through to the reference's CPU forward (host
+ * code choosing its own CPU implementation -- the GPU library itself has no CPU path).
  */
 #include <stdio.h>
 #define mapping0_exportbundle mapping0_exportbundle_cpu
@@ -101,96 +102,127 @@ void vamd_release_key(const void *key) {
 /* for a build WITHOUT envelope_vamd.c: call from vorbis_dsp_clear() before b->ve is freed */
 void vamd_release_state(vorbis_dsp_state *state) { vamd_release_key(vamd_key(state)); }
 
+/* The bit-writing half for one candidate packet k, unchanged host code (lib/mapping0.c:596-687):
+ * packet header, floor1_encode's Huffman words from the posts the GPU fitted, residue.
+ *   posts / post_valid / iwork / nonzero  this candidate's [ch][...] rows
+ *   res_*   this candidate's residue decisions, or rescap == 0 for the host's own res*_class/forward */
+static int vamd_write_packet(vorbis_block *vb, int k, int *posts, const int *post_valid, int *iwork,
+                             const int *nonzero, int rescap, const int32_t *res_class, const uint16_t *res_entries,
+                             const int32_t *res_count, int *scratch) {
+  vorbis_dsp_state *vd = vb->vd;
+  vorbis_info *vi = vd->vi;
+  codec_setup_info *ci = vi->codec_setup;
+  private_state *b = vd->backend_state;
+  vorbis_block_internal *vbi = (vorbis_block_internal *)vb->internal;
+  const int n = vb->pcmend, ch = vi->channels, modenumber = vb->W;
+  vorbis_info_mapping0 *info = ci->map_param[modenumber];
+  oggpack_buffer *opb = vbi->packetblob[k];
+  int **couple_bundle = alloca(sizeof(*couple_bundle) * ch);
+  int *zerobundle = alloca(sizeof(*zerobundle) * ch);
+  int i, j;
+
+  oggpack_write(opb, 0, 1);
+  oggpack_write(opb, modenumber, b->modebits);
+  if (vb->W) {
+    oggpack_write(opb, vb->lW, 1);
+    oggpack_write(opb, vb->nW, 1);
+  }
+  for (i = 0; i < ch; i++) {
+    int submap = info->chmuxlist[i];
+    /* the integer curve floor1_encode renders as a side effect is identical to the one the GPU
+       already divided out, and is discarded */
+    floor1_encode(opb, vb, b->flr[info->floorsubmap[submap]], post_valid[i] ? posts + i * VAMD_POSTS_STRIDE : NULL,
+                  scratch);
+  }
+  if (rescap > 0) {
+    /* lib/mapping0.c:673-683 with the search done: the reference's _01forward writes the bits */
+    if (vamd_res2_forward(opb, vb, b->residue[info->residuesubmap[0]], res_class, res_count[0], res_entries,
+                          res_count[1]))
+      return OV_EFAULT;
+    return 0;
+  }
+  for (i = 0; i < info->submaps; i++) {
+    int ch_in_bundle = 0;
+    long **classifications;
+    int resnum = info->residuesubmap[i];
+    for (j = 0; j < ch; j++)
+      if (info->chmuxlist[j] == i) {
+        zerobundle[ch_in_bundle] = nonzero[j] ? 1 : 0; /* already carries the coupling fix-up */
+        couple_bundle[ch_in_bundle++] = iwork + j * (n / 2);
+      }
+    classifications = _residue_P[ci->residue_type[resnum]]->class(vb, b->residue[resnum], couple_bundle, zerobundle,
+                                                                 ch_in_bundle);
+    ch_in_bundle = 0;
+    for (j = 0; j < ch; j++)
+      if (info->chmuxlist[j] == i) couple_bundle[ch_in_bundle++] = iwork + j * (n / 2);
+    _residue_P[ci->residue_type[resnum]]->forward(opb, vb, b->residue[resnum], couple_bundle, zerobundle,
+                                                   ch_in_bundle, classifications, i);
+  }
+  return 0;
+}
+
 static int mapping0_forward_vamd(vorbis_block *vb) {
   vorbis_dsp_state *vd = vb->vd;
   vorbis_info *vi = vd->vi;
   codec_setup_info *ci = vi->codec_setup;
-  private_state *b = vb->vd->backend_state;
   vorbis_block_internal *vbi = (vorbis_block_internal *)vb->internal;
-  const int n = vb->pcmend, ch = vi->channels, k = PACKETBLOBS / 2;
-  const int modenumber = vb->W;
-  vorbis_info_mapping0 *info = ci->map_param[modenumber];
+  const int n = vb->pcmend, ch = vi->channels;
+  const int managed = vorbis_bitrate_managed(vb) ? 1 : 0, nk = managed ? PACKETBLOBS : 1;
+  vorbis_info_mapping0 *info = ci->map_param[vb->W];
   vamd_ctx *ctx;
   float *mdct;
   int *iwork, *posts, *post_valid, *nonzero, *scratch;
-  int32_t *res_class = NULL, res_count[2] = {0, 0};
+  int32_t *res_class = NULL, *res_count = NULL;
   uint16_t *res_entries = NULL;
   float ampmax_out;
-  int i, j, ret, rescap;
+  int k, ret, rescap;
 
-  if (vorbis_bitrate_managed(vb) || ch > VAMD_MAX_CH) return mapping0_forward(vb);
+  if (ch > VAMD_MAX_CH) return mapping0_forward(vb); /* not covered: the host's own CPU code */
   ctx = vamd_ctx_for(vd);
   if (!ctx) return OV_EFAULT; /* no silent fallback: a missing GPU is an error */
 
-  vb->mode = modenumber;
+  vb->mode = vb->W;
   mdct = _vorbis_block_alloc(vb, ch * (n / 2) * sizeof(*mdct));
-  iwork = _vorbis_block_alloc(vb, ch * (n / 2) * sizeof(*iwork));
   scratch = _vorbis_block_alloc(vb, (n / 2) * sizeof(*scratch));
-  posts = _vorbis_block_alloc(vb, ch * VAMD_POSTS_STRIDE * sizeof(*posts));
-  post_valid = _vorbis_block_alloc(vb, ch * sizeof(*post_valid));
-  nonzero = _vorbis_block_alloc(vb, ch * sizeof(*nonzero));
-
-  /* ---- the numeric section: window, MDCT, FFT, masking, floor fit, floor curve,
-     couple/quantise -- one call (lib/mapping0.c:254-576,613-646) */
-  /* where the mode's residue is covered (type 2 stereo / type 1 mono, one submap), its classification and lattice search
-     come back with the same call and the host only writes bits */
+  iwork = _vorbis_block_alloc(vb, nk * ch * (n / 2) * sizeof(*iwork));
+  posts = _vorbis_block_alloc(vb, nk * ch * VAMD_POSTS_STRIDE * sizeof(*posts));
+  post_valid = _vorbis_block_alloc(vb, nk * ch * sizeof(*post_valid));
+  nonzero = _vorbis_block_alloc(vb, nk * ch * sizeof(*nonzero));
+  /* where the mode's residue is covered (type 2 stereo / type 1 mono, one submap), its classification
+     and lattice search come back with the same call and the host only writes bits */
   rescap = info->submaps == 1 ? vamd_residue_capacity(ctx, vb->W) : 0;
   if (rescap > 0) {
-    res_class = _vorbis_block_alloc(vb, VAMD_RES_CLASS_STRIDE * sizeof(*res_class));
-    res_entries = _vorbis_block_alloc(vb, rescap * sizeof(*res_entries));
+    res_class = _vorbis_block_alloc(vb, nk * VAMD_RES_CLASS_STRIDE * sizeof(*res_class));
+    res_entries = _vorbis_block_alloc(vb, nk * rescap * sizeof(*res_entries));
+    res_count = _vorbis_block_alloc(vb, nk * 2 * sizeof(*res_count));
   }
-  ret = vamd_analyze_block_res(ctx, (const float *const *)vb->pcm, vb->lW, vb->W, vb->nW, vbi->blocktype, vbi->ampmax,
-                               mdct, NULL, posts, post_valid, iwork, nonzero, &ampmax_out, res_class, res_entries,
-                               rescap > 0 ? res_count : NULL);
+
+  /* ---- the numeric section: window, MDCT, FFT, masking, floor fit(s), floor curve(s),
+     couple/quantise, residue search -- one call (lib/mapping0.c:254-576,613-646; managed: +:507-573
+     and :613-646 for each of the PACKETBLOBS candidates) */
+  if (managed)
+    ret = vamd_analyze_block_managed(ctx, (const float *const *)vb->pcm, vb->lW, vb->W, vb->nW, vbi->blocktype,
+                                     vbi->ampmax, mdct, &ampmax_out, posts, post_valid, iwork, nonzero, res_class,
+                                     res_entries, res_count);
+  else
+    ret = vamd_analyze_block_res(ctx, (const float *const *)vb->pcm, vb->lW, vb->W, vb->nW, vbi->blocktype,
+                                 vbi->ampmax, mdct, NULL, posts, post_valid, iwork, nonzero, &ampmax_out, res_class,
+                                 res_entries, res_count);
   if (ret) {
     fprintf(stderr, "vorbis_amd: block analysis failed (%d): %s\n", ret, vamd_last_error(ctx));
     return ret;
   }
   vbi->ampmax = ampmax_out; /* lib/mapping0.c:576 */
 
-  /* ---- the bit-writing half, unchanged host code (lib/mapping0.c:596-687, VBR: blob 7 only) */
-  {
-    oggpack_buffer *opb = vbi->packetblob[k];
-    int **couple_bundle = alloca(sizeof(*couple_bundle) * ch);
-    int *zerobundle = alloca(sizeof(*zerobundle) * ch);
-
-    oggpack_write(opb, 0, 1);
-    oggpack_write(opb, modenumber, b->modebits);
-    if (vb->W) {
-      oggpack_write(opb, vb->lW, 1);
-      oggpack_write(opb, vb->nW, 1);
-    }
-    for (i = 0; i < ch; i++) {
-      int submap = info->chmuxlist[i];
-      /* floor1_encode writes the floor's Huffman words from the posts the GPU fitted; the
-         integer curve it renders as a side effect is identical to the one the GPU already
-         divided out, and is discarded */
-      floor1_encode(opb, vb, b->flr[info->floorsubmap[submap]],
-                    post_valid[i] ? posts + i * VAMD_POSTS_STRIDE : NULL, scratch);
-    }
-    if (rescap > 0) {
-      /* lib/mapping0.c:673-683 with the search done: the reference's _01forward writes the bits */
-      if (vamd_res2_forward(opb, vb, b->residue[info->residuesubmap[0]], res_class, res_count[0], res_entries,
-                            res_count[1]))
-        return OV_EFAULT;
-    } else
-    for (i = 0; i < info->submaps; i++) {
-      int ch_in_bundle = 0;
-      long **classifications;
-      int resnum = info->residuesubmap[i];
-      for (j = 0; j < ch; j++)
-        if (info->chmuxlist[j] == i) {
-          zerobundle[ch_in_bundle] = nonzero[j] ? 1 : 0; /* already carries the coupling fix-up */
-          couple_bundle[ch_in_bundle++] = iwork + j * (n / 2);
-        }
-      classifications = _residue_P[ci->residue_type[resnum]]->class(vb, b->residue[resnum], couple_bundle,
-                                                                   zerobundle, ch_in_bundle);
-      ch_in_bundle = 0;
-      for (j = 0; j < ch; j++)
-        if (info->chmuxlist[j] == i) couple_bundle[ch_in_bundle++] = iwork + j * (n / 2);
-      _residue_P[ci->residue_type[resnum]]->forward(opb, vb, b->residue[resnum], couple_bundle, zerobundle,
-                                                     ch_in_bundle, classifications, i);
-    }
+  /* ---- the bit-writing half: VBR writes candidate PACKETBLOBS/2 only, a managed encoder all of
+     them and lets vorbis_bitrate_addblock() choose (lib/mapping0.c:593-595) */
+  for (k = 0; k < nk; k++) {
+    ret = vamd_write_packet(vb, managed ? k : PACKETBLOBS / 2, posts + k * ch * VAMD_POSTS_STRIDE, post_valid + k * ch,
+                            iwork + k * ch * (n / 2), nonzero + k * ch, rescap,
+                            rescap > 0 ? res_class + k * VAMD_RES_CLASS_STRIDE : NULL,
+                            rescap > 0 ? res_entries + (long)k * rescap : NULL, rescap > 0 ? res_count + 2 * k : NULL,
+                            scratch);
+    if (ret) return ret;
   }
   return 0;
 }

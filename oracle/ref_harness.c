@@ -591,7 +591,15 @@ long ref_encode_stream(ref_enc *e, const float *pcm, long frames, ref_block_rec 
           pcm_used += (long)ch * n;
         }
       }
-      ret = vorbis_analysis(&vb, &op);
+      if (vorbis_bitrate_managed(&vb)) {
+        /* the general application loop, examples/encoder_example.c:211-217: the bitrate manager
+           picks one of the block's candidate packets */
+        ret = vorbis_analysis(&vb, NULL);
+        if (!ret) ret = vorbis_bitrate_addblock(&vb);
+        if (!ret && vorbis_bitrate_flushpacket(&e->vd, &op) != 1) ret = -1;
+      } else {
+        ret = vorbis_analysis(&vb, &op);
+      }
       if (ret) { vorbis_block_clear(&vb); return ret; }
       if (nblocks < max_blocks && recs) {
         ref_block_rec *r = recs + nblocks;

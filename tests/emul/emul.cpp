@@ -36,6 +36,13 @@ struct EmulTaps {  // arrays [ch][...], any may be null
   int *res_count;               // [2]
 };
 
+struct EmulMTaps {  // per candidate packet of a bitrate-managed block, [15][ch][...]
+  int *posts, *post_valid, *iwork, *nonzero;
+};
+
+static int analyze_core(void *h, const float *pcm, int lW, int W, int nW, int blocktype, float ampmax_in, EmulTaps *t,
+                        EmulMTaps *m);
+
 extern "C" {
 
 void *emul_open(const void *blob, size_t bytes) {
@@ -67,6 +74,16 @@ int emul_mdct_forward(void *h, int W, const float *in, float *out) {
 
 int emul_analyze_block(void *h, const float *pcm, int lW, int W, int nW, int blocktype, float ampmax_in,
                        EmulTaps *t) {
+  return analyze_core(h, pcm, lW, W, nW, blocktype, ampmax_in, t, nullptr);
+}
+int emul_analyze_block_managed(void *h, const float *pcm, int lW, int W, int nW, int blocktype, float ampmax_in,
+                               EmulTaps *t, EmulMTaps *m) {
+  return analyze_core(h, pcm, lW, W, nW, blocktype, ampmax_in, t, m);
+}
+}
+
+static int analyze_core(void *h, const float *pcm, int lW, int W, int nW, int blocktype, float ampmax_in, EmulTaps *t,
+                        EmulMTaps *m) {
   Emul *e = (Emul *)h;
   const Bound &B = e->B;
   const int ch = B.channels, n = B.bs[W], n2 = n / 2;
@@ -79,6 +96,7 @@ int emul_analyze_block(void *h, const float *pcm, int lW, int W, int nW, int blo
       logmask(ch * n2), mdct(ch * n2), lmd(n2), mask(n2);
   std::vector<int> posts(ch * VAMD_POSTS_STRIDE), post_valid(ch), ilogmask(ch * n2), iwork(ch * n2), nonzero(ch);
   std::vector<float> local(ch);
+  std::vector<int> m_ilog;
   float global = ampmax_in;
   PhaseClock pc;
   pc.start(nullptr);
@@ -101,6 +119,13 @@ int emul_analyze_block(void *h, const float *pcm, int lW, int W, int nW, int blo
                      flr.data(), ring_amp.data(), ring_pos.data(), surv.data(), pc);
       offset_and_mix_wave(P, &noise[i * n2], &tone[i * n2], &logmdct[i * n2], &mdct_raw[i * n2], &mdct[i * n2],
                           &logmask[i * n2], (unsigned short *)lmd.data(), F.twofitatten, pc);
+      if (m) {
+        m_ilog.resize((size_t)VAMD_PACKETBLOBS * ch * n2);
+        floor_managed_block(P, F, n2, &noise[i * n2], &tone[i * n2], &logmdct[i * n2], (unsigned short *)lmd.data(), &sc,
+                            m->posts + i * VAMD_POSTS_STRIDE, (long)ch * VAMD_POSTS_STRIDE, m->post_valid + i, ch,
+                            m_ilog.data() + (size_t)i * n2, (long)ch * n2, m->nonzero + i, ch, pc);
+        continue;
+      }
       nonzero[i] = floor_fit_render_block(F, n2, (const unsigned short *)lmd.data(), &sc, &posts[i * VAMD_POSTS_STRIDE],
                                           &post_valid[i], &ilogmask[i * n2], pc);
     }
@@ -115,6 +140,19 @@ int emul_analyze_block(void *h, const float *pcm, int lW, int W, int nW, int blo
       mp[i] = &mdct[i * n2];
       ip[i] = &ilogmask[i * n2];
       op[i] = &iwork[i * n2];
+    }
+    if (m) {  // every candidate packet with its own coupling parameters, over the same spectrum
+      for (int k = 0; k < VAMD_PACKETBLOBS; k++) {
+        for (int i = 0; i < ch; i++) {
+          ip[i] = m_ilog.data() + ((size_t)k * ch + i) * n2;
+          op[i] = m->iwork + ((size_t)k * ch + i) * n2;
+        }
+        couple_block(B.couple_all[W].c[k], P, n2, mp, ip, op, m->nonzero + k * ch, L, pc);
+      }
+      if (t->mdct) memcpy(t->mdct, mdct.data(), sizeof(float) * mdct.size());
+      if (t->logmask) memcpy(t->logmask, logmask.data(), sizeof(float) * logmask.size());
+      if (t->ampmax_out) *t->ampmax_out = global;
+      return 0;
     }
     couple_block(C, P, n2, mp, ip, op, nonzero.data(), L, pc);
   }
@@ -146,6 +184,8 @@ int emul_analyze_block(void *h, const float *pcm, int lW, int W, int nW, int blo
   if (t->ampmax_out) *t->ampmax_out = global;
   return 0;
 }
+
+extern "C" {
 // the block-switching detector, one stream: the same four stages the HIP library launches
 // (vamd_envelope_search_batch), run in order on the host.  pcm[ch][len].
 int emul_envelope_search(void *h, const float *pcm, long len, long nsteps, vamd_envelope_state *st,

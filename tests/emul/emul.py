@@ -35,6 +35,10 @@ def build(force=False):
     return LIB
 
 
+class _MTaps(C.Structure):
+    _fields_ = [(k, _i32p) for k in ("posts", "post_valid", "iwork", "nonzero")]
+
+
 class Emul:
     def __init__(self, blob):
         self.L = C.CDLL(build())
@@ -44,6 +48,8 @@ class Emul:
         self.L.emul_mdct_forward.argtypes = [C.c_void_p, C.c_int, _f32p, _f32p]
         self.L.emul_analyze_block.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                               C.POINTER(_Taps)]
+        self.L.emul_analyze_block_managed.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                                      C.POINTER(_Taps), C.POINTER(_MTaps)]
         self.L.emul_residue_capacity.argtypes = [C.c_void_p, C.c_int]
         self.L.emul_envelope_search.argtypes = [C.c_void_p, _f32p, C.c_long, C.c_long, C.c_void_p, C.c_void_p]
         blob = np.ascontiguousarray(blob, dtype=np.uint8)
@@ -86,6 +92,29 @@ class Emul:
         if cap > 0:
             o["res_class"] = rcls[:rcnt[0]].copy()
             o["res_entries"] = rent[:rcnt[1]].copy()
+        return o
+
+    def analyze_block_managed(self, pcm, lW=1, W=1, nW=1, blocktype=1, ampmax_in=-9999.0):
+        """All 15 candidate packets of a bitrate-managed block (keys as RefEncoder.tap_block_managed)."""
+        ch, n = self.channels, self.bs[W]
+        n2 = n // 2
+        pcm = np.ascontiguousarray(pcm, np.float32)
+        o = {"mdct": np.zeros((ch, n2), np.float32), "logmask": np.zeros((ch, n2), np.float32),
+             "ampmax_out": np.zeros(1, np.float32)}
+        t = _Taps()
+        for k, v in o.items():
+            setattr(t, k, v.ctypes.data_as(_f32p))
+        mo = {"posts": np.zeros((15, ch, POSTS_STRIDE), np.int32), "post_valid": np.zeros((15, ch), np.int32),
+              "iwork": np.zeros((15, ch, n2), np.int32), "nonzero": np.zeros((15, ch), np.int32)}
+        m = _MTaps()
+        for k, v in mo.items():
+            setattr(m, k, v.ctypes.data_as(_i32p))
+        r = self.L.emul_analyze_block_managed(self.h, pcm.ctypes.data_as(_f32p), lW, W, nW, blocktype, ampmax_in,
+                                              C.byref(t), C.byref(m))
+        assert r == 0
+        o["ampmax_out"] = float(o["ampmax_out"][0])
+        for k, v in mo.items():
+            o["m_" + k] = v
         return o
 
     def envelope_search(self, pcm, nsteps, state):

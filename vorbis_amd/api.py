@@ -17,7 +17,8 @@ EXPORTED_SYMBOLS = ["vamd_create", "vamd_destroy", "vamd_last_error", "vamd_set_
                     "vamd_channels", "vamd_blocksize", "vamd_posts", "vamd_mdct_forward_batch",
                     "vamd_analyze_batch", "vamd_analyze_stream", "vamd_analyze_block", "vamd_profile",
                     "vamd_stage_ms", "vamd_debug_cycles", "vamd_analyze_stream_mixed", "vamd_envelope_search_batch",
-                    "vamd_envelope_search", "vamd_envelope_geometry", "vamd_residue_capacity", "vamd_analyze_block_res"]
+                    "vamd_envelope_search", "vamd_envelope_geometry", "vamd_residue_capacity", "vamd_analyze_block_res", "vamd_analyze_batch_managed", "vamd_analyze_block_managed"]
+PACKETBLOBS = 15
 
 _vp = C.c_void_p
 
@@ -35,6 +36,10 @@ RES_CLASS_STRIDE = 64
 
 class _IO(C.Structure):
     _fields_ = [(k, _vp) for k in _IO_FIELDS]
+
+
+class _MIO(C.Structure):  # vamd_managed_io
+    _fields_ = [(k, _vp) for k in ("posts", "post_valid", "iwork", "nonzero", "res_class", "res_entries", "res_count")]
 
 
 class VamdError(RuntimeError):
@@ -83,6 +88,8 @@ def load_library():
     L.vamd_envelope_geometry.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.vamd_residue_capacity.argtypes = [_vp, C.c_int]
     L.vamd_analyze_block_res.argtypes = [_vp, C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_float] + [_vp] * 10
+    L.vamd_analyze_batch_managed.argtypes = [_vp, C.POINTER(_Desc), C.POINTER(_IO), C.POINTER(_MIO)]
+    L.vamd_analyze_block_managed.argtypes = [_vp, C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_float] + [_vp] * 9
     L.vamd_profile.argtypes = [_vp, C.c_int]
     L.vamd_stage_ms.argtypes = [_vp, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]
     _lib = L
@@ -336,6 +343,64 @@ class Analyzer:
                                                   _vp(o["iwork"].ctypes.data), _vp(o["nonzero"].ctypes.data),
                                                   C.byref(amp)))
         o["ampmax_out"] = amp.value
+        return o
+
+    # ---- bitrate-managed blocks: fifteen candidate packets each (vamd_analyze_*_managed) ------------
+    def analyze_managed(self, pcm, W=1, lW=1, nW=1, blocktype=BLOCKTYPE_LONG, ampmax_in=-9999.0, residue=False):
+        """vamd_analyze_batch_managed.  pcm: cuda float32 [nblocks, ch, n].  Returns a dict: shared `mdct`,
+        `logmask`, `ampmax_out`, and per candidate `m_posts` [nb,15,ch,32], `m_post_valid` / `m_nonzero`
+        [nb,15,ch], `m_iwork` [nb,15,ch,n/2] (+ `m_res_class`, `m_res_entries`, `m_res_count` with residue=True)."""
+        t = self.torch
+        n = self.blocksizes[W]
+        assert pcm.is_cuda and pcm.dtype == t.float32 and pcm.is_contiguous() and pcm.shape[1:] == (self.channels, n)
+        nb, ch, n2, dev = pcm.shape[0], self.channels, n // 2, pcm.device
+        outs = self.alloc_outputs(W, nb, ("mdct", "logmask", "ampmax_out"))
+        keep = []
+        d = self._desc(W, nb, lW, nW, blocktype, ampmax_in, keep)
+        io = self._io(pcm, outs)
+        mo = {"posts": t.empty((nb, PACKETBLOBS, ch, POSTS_STRIDE), dtype=t.int32, device=dev),
+              "post_valid": t.empty((nb, PACKETBLOBS, ch), dtype=t.int32, device=dev),
+              "iwork": t.empty((nb, PACKETBLOBS, ch, n2), dtype=t.int32, device=dev),
+              "nonzero": t.empty((nb, PACKETBLOBS, ch), dtype=t.int32, device=dev)}
+        if residue:
+            mo["res_class"] = t.zeros((nb, PACKETBLOBS, RES_CLASS_STRIDE), dtype=t.int32, device=dev)
+            mo["res_entries"] = t.zeros((nb, PACKETBLOBS, self.residue_capacity(W)), dtype=t.int16, device=dev)
+            mo["res_count"] = t.zeros((nb, PACKETBLOBS, 2), dtype=t.int32, device=dev)
+        m = _MIO()
+        for k, v in mo.items():
+            setattr(m, k, _vp(v.data_ptr()))
+        self._bind_stream()
+        self._check(self.L.vamd_analyze_batch_managed(self.h, C.byref(d), C.byref(io), C.byref(m)))
+        for k, v in mo.items():
+            outs["m_" + k] = v
+        return outs
+
+    def analyze_block_managed(self, pcm, lW=1, W=1, nW=1, blocktype=BLOCKTYPE_LONG, ampmax_in=-9999.0):
+        """vamd_analyze_block_managed: host numpy pcm[ch][n] in; shared mdct / ampmax_out and the fifteen
+        candidates' m_posts / m_post_valid / m_iwork / m_nonzero (+ residue decisions where covered) out."""
+        ch, n = self.channels, self.blocksizes[W]
+        n2 = n // 2
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        assert pcm.shape == (ch, n)
+        ptrs = (_vp * ch)(*[_vp(pcm[i].ctypes.data) for i in range(ch)])
+        o = dict(mdct=np.empty((ch, n2), np.float32), m_posts=np.empty((PACKETBLOBS, ch, POSTS_STRIDE), np.int32),
+                 m_post_valid=np.empty((PACKETBLOBS, ch), np.int32), m_iwork=np.empty((PACKETBLOBS, ch, n2), np.int32),
+                 m_nonzero=np.empty((PACKETBLOBS, ch), np.int32))
+        amp = C.c_float(0)
+        cap = self.residue_capacity(W)
+        rcls = np.zeros((PACKETBLOBS, RES_CLASS_STRIDE), np.int32)
+        rent = np.zeros((PACKETBLOBS, max(cap, 1)), np.uint16)
+        rcnt = np.zeros((PACKETBLOBS, 2), np.int32)
+        rp = [_vp(rcls.ctypes.data), _vp(rent.ctypes.data), _vp(rcnt.ctypes.data)] if cap > 0 else [None, None, None]
+        self._bind_stream()
+        self._check(self.L.vamd_analyze_block_managed(
+            self.h, ptrs, lW, W, nW, blocktype, ampmax_in, _vp(o["mdct"].ctypes.data), C.cast(C.byref(amp), _vp),
+            _vp(o["m_posts"].ctypes.data), _vp(o["m_post_valid"].ctypes.data), _vp(o["m_iwork"].ctypes.data),
+            _vp(o["m_nonzero"].ctypes.data), *rp))
+        o["ampmax_out"] = amp.value
+        if cap > 0:
+            o["m_res_class"] = [rcls[k, :rcnt[k, 0]].copy() for k in range(PACKETBLOBS)]
+            o["m_res_entries"] = [rent[k, :rcnt[k, 1]].copy() for k in range(PACKETBLOBS)]
         return o
 
     # ---- the block-switching detector (vamd_envelope_search*) ---------------------------------

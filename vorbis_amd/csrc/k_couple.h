@@ -149,6 +149,13 @@ VAMD_DEV float couple_bin(ChanBin &M, ChanBin &A, int &iM, int &iA, int b, int n
       iA = 0;
     }
   }
+  else if (b >= nstart) {
+    // past the sliding lowpass nothing is coupled, and the magnitude is renormalised from what the
+    // per-channel noise_normalize left in quant[]: out*out*floor for a final value, floor for a
+    // promoted candidate, 0 for a dropped one (lib/psy.c:985,998-1003) -- all three are iM*iM*floor.
+    // (Only bitrate-managed candidates 0..6 put the lowpass inside the block.)
+    M.qe = (float)(iM * iM) * M.fl2;
+  }
   M.fl2 = A.fl2 = M.fl2 + A.fl2;
   float cand = -1.f;
   if (!M.fg) {

@@ -99,6 +99,38 @@ VAMD_DEV void offset_and_mix_wave(const PsyP &P, const float *__restrict__ noise
   pc.mark(0);
 }
 
+// _vp_offset_and_mix's mask for offset_select 0 or 2 (the lo / hi curves of a bitrate-managed block,
+// lib/mapping0.c:507-545), reduced to what the fit reads: those selects leave the spectrum alone
+// (lib/psy.c:807) and nobody keeps their float mask.
+VAMD_DEV void mask_quantise_wave(const PsyP &P, int offset_select, const float *__restrict__ noise,
+                                 const float *__restrict__ tone, const float *__restrict__ logmdct_in,
+                                 unsigned short *qc, float twofitatten) {
+  const int n = P.n;
+  const float toneatt = offset_select ? P.tone_masteratt2 : P.tone_masteratt0;
+  const float *__restrict__ noff = offset_select ? P.noiseoffset2 : P.noiseoffset0;
+  WAVE_FOR(q, n >> 2) {
+    float nz[4], no[4], tn[4], lmv[4];
+    f4_get(((const F4 *)noise)[q], nz);
+    f4_get(((const F4 *)noff)[q], no);
+    f4_get(((const F4 *)tone)[q], tn);
+    f4_get(((const F4 *)logmdct_in)[q], lmv);
+    uint32_t w[2] = {0, 0};
+    for (int c = 0; c < 4; c++) {
+      float val = nz[c] + no[c];
+      if (val > P.noisemaxsupp) val = P.noisemaxsupp;
+      const float t = tn[c] + toneatt;
+      const float mk = (val < t) ? t : val;
+      const uint32_t v = (uint32_t)dBquant(mk) | (lmv[c] + twofitatten >= mk ? 0x8000u : 0u);
+      w[c >> 1] |= v << (16 * (c & 1));
+    }
+    I2 pk;
+    pk.x = (int)w[0];
+    pk.y = (int)w[1];
+    ((I2 *)qc)[q] = pk;
+  }
+  WAVE_SYNC();
+}
+
 // add a lane's private sums to an interval's accumulators and clear them
 VAMD_DEV void accumulate_flush(FitAcc *dst, FitAcc &t) {
   if (t.an) {
@@ -640,6 +672,59 @@ VAMD_DEV void floor_interpolate(const LaneInts &A, int haveA, const LaneInts &B,
     int v = ((65536 - del) * (a & 0x7fff) + del * (b & 0x7fff) + 32768) >> 16;
     if ((a & 0x8000) && (b & 0x8000)) v |= 0x8000;
     out.put(i, v);
+  }
+}
+
+// A bitrate-managed block's floors for one channel (lib/mapping0.c:499-573 + the floor half of
+// :613-646 for every candidate packet k): three fits (the middle one was just prepared in qc by
+// offset_and_mix_wave), twelve interpolations, fifteen encode/render passes.
+//   posts_out [15][VAMD_POSTS_STRIDE], post_valid [15], ilogmask [15][n2], nonzero [15], each with
+//   the given element stride between consecutive k
+VAMD_DEV void floor_managed_block(const PsyP &P, const FloorP &F, int n2, const float *__restrict__ noise,
+                                  const float *__restrict__ tone, const float *__restrict__ logmdct,
+                                  unsigned short *qc, FloorScratch *sc, int *__restrict__ posts_out, long posts_stride,
+                                  int *__restrict__ post_valid, long valid_stride, int *__restrict__ ilogmask,
+                                  long ilog_stride, int *__restrict__ nonzero, long nz_stride, PhaseClock &pc) {
+  const int mid = VAMD_PACKETBLOBS / 2, last = VAMD_PACKETBLOBS - 1;
+  LaneInts fmid, flo, fhi;
+  fmid.fill(0);
+  flo.fill(0);
+  fhi.fill(0);
+  const int hmid = floor_fit_posts(F, qc, sc, fmid, pc);
+  int hlo = 0, hhi = 0;
+  if (hmid) {
+    WAVE_SYNC();
+    mask_quantise_wave(P, 2, noise, tone, logmdct, qc, F.twofitatten);
+    hhi = floor_fit_posts(F, qc, sc, fhi, pc);
+    WAVE_SYNC();
+    mask_quantise_wave(P, 0, noise, tone, logmdct, qc, F.twofitatten);
+    hlo = floor_fit_posts(F, qc, sc, flo, pc);
+    WAVE_SYNC();
+  }
+  for (int k = 0; k < VAMD_PACKETBLOBS; k++) {
+    LaneInts cur;
+    int have;
+    if (k == mid) {
+      cur = fmid;
+      have = hmid;
+    } else if (!hmid) {  // the managed branch is skipped: every other curve stays NULL
+      cur.fill(0);
+      have = 0;
+    } else if (k == 0) {
+      cur = flo;
+      have = hlo;
+    } else if (k == last) {
+      cur = fhi;
+      have = hhi;
+    } else if (k < mid) {
+      floor_interpolate(flo, hlo, fmid, hmid, k * 65536 / mid, cur, &have);
+    } else {
+      floor_interpolate(fmid, hmid, fhi, hhi, (k - mid) * 65536 / mid, cur, &have);
+    }
+    const int nzf = floor_encode_render(F, n2, cur, have, sc, posts_out + k * posts_stride,
+                                        post_valid + k * valid_stride, ilogmask + k * ilog_stride, pc);
+    if (LANE == 0) nonzero[k * nz_stride] = nzf;
+    WAVE_SYNC();
   }
 }
 

@@ -21,6 +21,7 @@ struct Bound {
   PsyP psy[4];
   FloorP floor[2];
   CoupleP couple[2];
+  CoupleSet couple_all[2];
   EnvP env;
   ResP res[2];
   int res_stages[2], res_partvals[2];
@@ -53,10 +54,6 @@ inline int build_image(const void *blob_v, size_t bytes, std::vector<unsigned ch
   }
   if (h.channels < 1 || h.channels > VAMD_MAX_CH) {
     *err = "channel count not covered (1 or 2)";
-    return VAMD_EIMPL;
-  }
-  if (h.managed) {
-    *err = "bitrate-managed setups (15 packet blobs) are not covered";
     return VAMD_EIMPL;
   }
   for (int W = 0; W < 2; W++) {
@@ -285,6 +282,14 @@ inline void bind_params(const std::vector<unsigned char> &image, const std::vect
     C.prepoint = stereo_threshold(h.psy_g.coupling_prepointamp[blob_k], false);
     C.postpoint = stereo_threshold(h.psy_g.coupling_postpointamp[blob_k], (x.n / 2) > 1000);
     C.sliding_lowpass = h.psy_g.sliding_lowpass[W][blob_k];
+    for (int k = 0; k < VAMD_PACKETBLOBS; k++) {  // lib/psy.c:1027-1029,1056-1057 per blobno
+      CoupleP &K = B->couple_all[W].c[k];
+      K = C;
+      K.pointlimit = h.psy_g.coupling_pointlimit[W][k];
+      K.prepoint = stereo_threshold(h.psy_g.coupling_prepointamp[k], false);
+      K.postpoint = stereo_threshold(h.psy_g.coupling_postpointamp[k], (x.n / 2) > 1000);
+      K.sliding_lowpass = h.psy_g.sliding_lowpass[W][k];
+    }
   }
   {
     const vamd_envelope_tab &e = h.env;
@@ -350,6 +355,8 @@ inline void bind_params(const std::vector<unsigned char> &image, const std::vect
     P.ath_adjatt = t.ath_adjatt;
     P.ath_maxatt = t.ath_maxatt;
     P.tone_masteratt1 = t.tone_masteratt[1];
+    P.tone_masteratt0 = t.tone_masteratt[0];
+    P.tone_masteratt2 = t.tone_masteratt[2];
     P.tone_abs_limit = t.tone_abs_limit;
     P.noisemaxsupp = t.noisemaxsupp;
     P.noisewindowfixed = t.noisewindowfixed;
@@ -358,6 +365,8 @@ inline void bind_params(const std::vector<unsigned char> &image, const std::vect
     P.octave = (const int *)(base + t.off_octave);
     P.bark = (const int *)(base + t.off_bark);
     P.noiseoffset1 = (const float *)(base + t.off_noiseoffset) + t.n;
+    P.noiseoffset0 = (const float *)(base + t.off_noiseoffset);
+    P.noiseoffset2 = (const float *)(base + t.off_noiseoffset) + 2 * t.n;
     P.tonecurves = (const float *)(base + t.off_tonecurves);
     P.noisecompand = (const float *)(base + offsetof(vamd_setup_header, psy) + sizeof(vamd_psy_tab) * p +
                                      offsetof(vamd_psy_tab, noisecompand));

@@ -308,12 +308,17 @@ __global__ __launch_bounds__(64) void k_floor(PsyP P0, PsyP P1, FloorP F, DescP 
 }
 
 // stage 5: couple / quantise / normalise, one wave per block (all channels)
-__global__ __launch_bounds__(64) void k_couple(PsyP P0, PsyP P1, CoupleP C, DescP d, const float *__restrict__ mdct,
-                                               const int *__restrict__ ilogmask, int *__restrict__ iwork,
-                                               int *__restrict__ nonzero) {
-  const long blk = blockIdx.x;
-  const PsyP &P = d_bt(d, blk) ? P1 : P0;
+// A unit is one (block, candidate packet): VBR has one packet per block (blob_base = PACKETBLOBS/2,
+// nblobs = 1), a bitrate-managed block all fifteen, each with its own coupling parameters over the
+// same spectrum.  ilogmask / iwork / nonzero are indexed by unit, mdct by block.
+__global__ __launch_bounds__(64) void k_couple(PsyP P0, PsyP P1, CoupleSet CS, int blob_base, int nblobs, DescP d,
+                                               const float *__restrict__ mdct, const int *__restrict__ ilogmask,
+                                               int *__restrict__ iwork, int *__restrict__ nonzero) {
+  const long unit = blockIdx.x, mblk = unit / nblobs;
+  const CoupleP &C = CS.c[blob_base + (int)(unit - mblk * nblobs)];
+  const PsyP &P = d_bt(d, mblk) ? P1 : P0;
   const int n2 = P.n, ch = C.ch;
+  const long blk = unit;
   CoupleLds L;
   L.cand = (float *)vamd_smem;
   L.key = L.cand + n2;
@@ -323,7 +328,7 @@ __global__ __launch_bounds__(64) void k_couple(PsyP P0, PsyP P1, CoupleP C, Desc
   int *op[VAMD_MAX_CH];
   int nz[VAMD_MAX_CH];
   for (int c = 0; c < ch; c++) {
-    mp[c] = mdct + (blk * ch + c) * n2;
+    mp[c] = mdct + (mblk * ch + c) * n2;
     ip[c] = ilogmask + (blk * ch + c) * n2;
     op[c] = iwork + (blk * ch + c) * n2;
     nz[c] = nonzero[blk * ch + c];
@@ -335,6 +340,33 @@ __global__ __launch_bounds__(64) void k_couple(PsyP P0, PsyP P1, CoupleP C, Desc
   if (LANE == 0)
     for (int c = 0; c < ch; c++) nonzero[blk * ch + c] = nz[c];
   pc.flush();
+}
+
+// stage 4 of a bitrate-managed batch: the same offset_and_mix, then three fits, twelve interpolated
+// curves and fifteen rendered floors per channel (floor_managed_block, k_floor.h).  Outputs are laid
+// out [block][candidate packet][channel][...].
+__global__ __launch_bounds__(64) void k_floor_managed(PsyP P0, PsyP P1, FloorP F, DescP d, int ch,
+                                                      const float *__restrict__ noise, const float *__restrict__ tone,
+                                                      const float *__restrict__ logmdct,
+                                                      const float *__restrict__ mdct_raw, float *__restrict__ mdct,
+                                                      float *__restrict__ logmask_out, int *__restrict__ posts,
+                                                      int *__restrict__ post_valid, int *__restrict__ ilogmask,
+                                                      int *__restrict__ nonzero) {
+  const long cb = blockIdx.x;
+  const long blk = cb / ch;
+  const int c = (int)(cb - blk * ch);
+  const PsyP &P = d_bt(d, blk) ? P1 : P0;
+  const int n2 = P.n;
+  unsigned short *qc = (unsigned short *)vamd_smem;
+  FloorScratch *sc = (FloorScratch *)(qc + ((n2 + 15) & ~15));
+  PhaseClock pc;
+  pc.start(nullptr);
+  offset_and_mix_wave(P, noise + cb * n2, tone + cb * n2, logmdct + cb * n2, mdct_raw + cb * n2, mdct + cb * n2,
+                      logmask_out ? logmask_out + cb * n2 : nullptr, qc, F.twofitatten, pc);
+  const long u0 = blk * VAMD_PACKETBLOBS * ch + c;  // unit (blk, k = 0), channel c
+  floor_managed_block(P, F, n2, noise + cb * n2, tone + cb * n2, logmdct + cb * n2, qc, sc,
+                      posts + u0 * VAMD_POSTS_STRIDE, (long)ch * VAMD_POSTS_STRIDE, post_valid + u0, ch,
+                      ilogmask + u0 * n2, (long)ch * n2, nonzero + u0, ch, pc);
 }
 
 // stage 6 (optional): residue classification + lattice-VQ search, one wave per block (k_residue.h)
@@ -479,7 +511,7 @@ struct vamd_ctx {
   // workspace, grown on demand (vamd_reserve to pre-size)
   enum { WS_MDCT_RAW, WS_LOGMDCT, WS_LOGFFT, WS_NOISE, WS_TONE, WS_MDCT, WS_ILOGMASK, WS_IWORK, WS_POSTS, WS_POSTVALID,
          WS_NONZERO, WS_LOCAL, WS_AMPIN, WS_AMPGLOB, WS_PCM, WS_SEED, WS_SURV, WS_NSURV, WS_MISC,
-         WS_ENV_NEAR, WS_ENV_RAW, WS_ENV_AMP, WS_ENV_BITS, WS_ENV_STAGE, WS_COUNT };
+         WS_ENV_NEAR, WS_ENV_RAW, WS_ENV_AMP, WS_ENV_BITS, WS_ENV_STAGE, WS_M_ILOGMASK, WS_M_STAGE, WS_COUNT };
   DevBuf ws[2][WS_COUNT];  // per size class (a mixed stream keeps both batches in flight)
   // pinned staging for the per-block host API
   void *h_stage = nullptr;
@@ -808,7 +840,7 @@ static void launch_transform(vamd_ctx *c, BatchRun *R) {
 }
 
 // stages 2..5 (masking, floor, couple); R->d.ampmax_in / p.ampglob must be final
-static void launch_rest(vamd_ctx *c, BatchRun *R, int level) {
+static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_io *M = nullptr, int *m_ilogmask = nullptr) {
   if (R->nb == 0) return;
   const int W = R->W, ch = c->B.channels;
   const WsPlan &p = R->p;
@@ -851,7 +883,25 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level) {
     }
     prof_mark(c), R->nst++;
   }
-  if (level >= VAMD_LEVEL_FULL) {
+  if (level >= VAMD_LEVEL_FULL && M) {
+    // bitrate-managed: fifteen candidate packets per block
+    const size_t flds = (size_t)((n2 + 15) & ~15) * 2 + sizeof(FloorScratch);
+    hipLaunchKernelGGL(k_floor_managed, dim3(gcb), dim3(64), flds, s, P0, P1, c->B.floor[W], d, ch, p.noise, p.tone,
+                       p.logmdct, p.mdct_raw, p.mdct, R->io->logmask, M->posts, M->post_valid, m_ilogmask, M->nonzero);
+    prof_mark(c), R->nst++;
+    const bool norm0 = P0.normal_p && P0.normal_start < n2, norm1 = P1.normal_p && P1.normal_start < n2;
+    hipLaunchKernelGGL(k_couple, dim3(gb * VAMD_PACKETBLOBS), dim3(64), (norm0 || norm1) ? (size_t)n2 * 12 : 0, s, P0, P1,
+                       c->B.couple_all[W], 0, VAMD_PACKETBLOBS, d, p.mdct, m_ilogmask, M->iwork, M->nonzero);
+    prof_mark(c), R->nst++;
+    if (M->res_entries) {
+      const ResP &Rp = c->B.res[W];
+      const int stages = c->B.res_stages[W], partvals = c->B.res_partvals[W];
+      const size_t lds = ((size_t)ch * n2 + VAMD_RES_CLASS_STRIDE + 2 * (size_t)stages * partvals + 1) * 4;
+      hipLaunchKernelGGL(k_residue, dim3(gb * VAMD_PACKETBLOBS), dim3(64), lds, s, Rp, d, ch, n2, M->iwork, M->nonzero,
+                         M->res_class, M->res_entries, M->res_count);
+      prof_mark(c), R->nst++;
+    }
+  } else if (level >= VAMD_LEVEL_FULL) {
     hipLaunchKernelGGL(k_floor, dim3(gcb), dim3(64), (size_t)((n2 + 15) & ~15) * 2 + sizeof(FloorScratch), s, P0, P1, c->B.floor[W],
                        d, ch, p.noise, p.tone, p.logmdct, p.mdct_raw, p.mdct, R->io->logmask, p.posts, p.post_valid,
                        p.ilogmask, p.nonzero);
@@ -860,7 +910,7 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level) {
     // stage is register-only and the CU holds twice as many of its waves
     const bool norm0 = P0.normal_p && P0.normal_start < n2, norm1 = P1.normal_p && P1.normal_start < n2;
     const bool want_res = R->io && R->io->res_entries;
-    hipLaunchKernelGGL(k_couple, dim3(gb), dim3(64), (norm0 || norm1) ? (size_t)n2 * 12 : 0, s, P0, P1, c->B.couple[W], d, p.mdct, p.ilogmask,
+    hipLaunchKernelGGL(k_couple, dim3(gb), dim3(64), (norm0 || norm1) ? (size_t)n2 * 12 : 0, s, P0, P1, c->B.couple_all[W], VAMD_PACKETBLOBS / 2, 1, d, p.mdct, p.ilogmask,
                        p.iwork, p.nonzero);
     prof_mark(c), R->nst++;
     if (want_res) {
@@ -875,11 +925,19 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level) {
 }
 
 static int run_batch(vamd_ctx *c, const vamd_batch_desc *desc, const vamd_batch_io *io, int level, bool stream_mode,
-                     float *ampmax_state) {
+                     float *ampmax_state, const vamd_managed_io *M = nullptr) {
   BatchRun R;
   int r = prepare_run(c, desc, io, level, &R);
   if (r) return r;
   if (R.nb == 0) return VAMD_OK;
+  int *m_ilogmask = nullptr;
+  if (M) {  // the fifteen integer floor curves live in workspace only
+    void *v;
+    r = ws_get(c, R.W, vamd_ctx::WS_M_ILOGMASK,
+               (size_t)R.nb * VAMD_PACKETBLOBS * c->B.channels * (c->B.bs[R.W] / 2) * 4, &v);
+    if (r) return r;
+    m_ilogmask = (int *)v;
+  }
   const int ch = c->B.channels;
   hipStream_t s = c->stream;
   launch_transform(c, &R);
@@ -893,7 +951,7 @@ static int run_batch(vamd_ctx *c, const vamd_batch_desc *desc, const vamd_batch_
                        R.p.ampglob);
   }
   prof_mark(c), R.nst++;
-  launch_rest(c, &R, level);
+  launch_rest(c, &R, level, M, m_ilogmask);
   if (c->profile) c->ev_runs.push_back(R.nst);
   HIP_TRY(c, hipGetLastError());
   if (stream_mode) {
@@ -909,6 +967,102 @@ int vamd_analyze_batch(vamd_ctx *c, const vamd_batch_desc *desc, const vamd_batc
   if (r) return r;
   if (level < VAMD_LEVEL_TRANSFORM || level > VAMD_LEVEL_FULL) return fail(c, VAMD_EINVAL, "bad level");
   return run_batch(c, desc, io, level, false, nullptr);
+}
+
+int vamd_analyze_batch_managed(vamd_ctx *c, const vamd_batch_desc *desc, const vamd_batch_io *io,
+                               const vamd_managed_io *m) {
+  int r = check_desc(c, desc, io);
+  if (r) return r;
+  if (!m || !m->posts || !m->post_valid || !m->iwork || !m->nonzero)
+    return fail(c, VAMD_EINVAL, "managed outputs posts / post_valid / iwork / nonzero are required");
+  if (m->res_class || m->res_entries || m->res_count) {
+    if (!(m->res_class && m->res_entries && m->res_count))
+      return fail(c, VAMD_EINVAL, "res_class / res_entries / res_count go together");
+    if (!c->B.res[desc->W].covered)
+      return fail(c, VAMD_EIMPL, "this mode's residue back-end is not covered on the GPU (type 2 stereo, type 1 mono)");
+  }
+  vamd_batch_io shared = *io;  // per-candidate fields of the VBR io do not apply
+  shared.posts = shared.post_valid = shared.ilogmask = shared.iwork = shared.nonzero = nullptr;
+  shared.res_class = nullptr;
+  shared.res_entries = nullptr;
+  shared.res_count = nullptr;
+  return run_batch(c, desc, &shared, VAMD_LEVEL_FULL, false, nullptr, m);
+}
+
+int vamd_analyze_block_managed(vamd_ctx *c, const float *const *pcm, int lW, int W, int nW, int blocktype,
+                               float ampmax_in, float *mdct, float *ampmax_out, int32_t *posts,
+                               int32_t *post_valid, int32_t *iwork, int32_t *nonzero, int32_t *res_class,
+                               uint16_t *res_entries, int32_t *res_count) {
+  if (!c) return VAMD_EINVAL;
+  if (!pcm || (W != 0 && W != 1)) return fail(c, VAMD_EINVAL, "bad pcm / W");
+  const bool want_res = res_class || res_entries || res_count;
+  if (want_res && !c->B.res[W].covered)
+    return fail(c, VAMD_EIMPL, "this mode's residue back-end is not covered on the GPU (type 2 stereo, type 1 mono)");
+  const size_t rcap = want_res ? (size_t)c->B.res[W].cap : 0;
+  const size_t ch = c->B.channels, n = c->B.bs[W], n2 = n / 2, K = VAMD_PACKETBLOBS;
+  auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
+  const size_t o_pcm = 0, o_mdct = al(o_pcm + ch * n * 4), o_amp = al(o_mdct + ch * n2 * 4), o_posts = o_amp + 16,
+               o_valid = al(o_posts + K * ch * VAMD_POSTS_STRIDE * 4), o_nz = al(o_valid + K * ch * 4),
+               o_iwork = al(o_nz + K * ch * 4), o_rcls = al(o_iwork + K * ch * n2 * 4),
+               o_rcnt = al(o_rcls + (want_res ? K * VAMD_RES_CLASS_STRIDE * 4 : 0)),
+               o_rent = al(o_rcnt + (want_res ? K * 2 * 4 : 0)), total = al(o_rent + K * rcap * 2);
+  if (c->h_stage_bytes < total) {
+    if (c->h_stage) HIP_TRY(c, hipHostFree(c->h_stage));
+    c->h_stage = nullptr;
+    c->h_stage_bytes = 0;
+    HIP_TRY(c, hipHostMalloc(&c->h_stage, total, hipHostMallocDefault));
+    c->h_stage_bytes = total;
+  }
+  void *dv;
+  int r = ws_get(c, W, vamd_ctx::WS_M_STAGE, total, &dv);
+  if (r) return r;
+  unsigned char *hs = (unsigned char *)c->h_stage, *ds = (unsigned char *)dv;
+  for (size_t i = 0; i < ch; i++) {
+    if (!pcm[i]) return fail(c, VAMD_EINVAL, "null channel pointer");
+    memcpy(hs + o_pcm + i * n * 4, pcm[i], n * 4);
+  }
+  hipStream_t s = c->stream;
+  HIP_TRY(c, hipMemcpyAsync(ds + o_pcm, hs + o_pcm, ch * n * 4, hipMemcpyHostToDevice, s));
+  vamd_batch_desc d;
+  memset(&d, 0, sizeof(d));
+  d.W = W;
+  d.nblocks = 1;
+  d.uniform_lW = lW;
+  d.uniform_nW = nW;
+  d.uniform_blocktype = blocktype;
+  d.uniform_ampmax_in = ampmax_in;
+  vamd_batch_io io;
+  memset(&io, 0, sizeof(io));
+  io.pcm = (const float *)(ds + o_pcm);
+  io.mdct = (float *)(ds + o_mdct);
+  io.ampmax_out = (float *)(ds + o_amp);
+  vamd_managed_io m;
+  memset(&m, 0, sizeof(m));
+  m.posts = (int32_t *)(ds + o_posts);
+  m.post_valid = (int32_t *)(ds + o_valid);
+  m.nonzero = (int32_t *)(ds + o_nz);
+  m.iwork = (int32_t *)(ds + o_iwork);
+  if (want_res) {
+    m.res_class = (int32_t *)(ds + o_rcls);
+    m.res_count = (int32_t *)(ds + o_rcnt);
+    m.res_entries = (uint16_t *)(ds + o_rent);
+  }
+  r = vamd_analyze_batch_managed(c, &d, &io, &m);
+  if (r) return r;
+  HIP_TRY(c, hipMemcpyAsync(hs + o_mdct, ds + o_mdct, total - o_mdct, hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  if (mdct) memcpy(mdct, hs + o_mdct, ch * n2 * 4);
+  if (ampmax_out) memcpy(ampmax_out, hs + o_amp, 4);
+  if (posts) memcpy(posts, hs + o_posts, K * ch * VAMD_POSTS_STRIDE * 4);
+  if (post_valid) memcpy(post_valid, hs + o_valid, K * ch * 4);
+  if (nonzero) memcpy(nonzero, hs + o_nz, K * ch * 4);
+  if (iwork) memcpy(iwork, hs + o_iwork, K * ch * n2 * 4);
+  if (want_res) {
+    if (res_class) memcpy(res_class, hs + o_rcls, K * VAMD_RES_CLASS_STRIDE * 4);
+    if (res_count) memcpy(res_count, hs + o_rcnt, K * 2 * 4);
+    if (res_entries) memcpy(res_entries, hs + o_rent, K * rcap * 2);
+  }
+  return VAMD_OK;
 }
 
 int vamd_analyze_stream(vamd_ctx *c, const vamd_batch_desc *desc, const vamd_batch_io *io, float *ampmax_state) {

@@ -28,6 +28,7 @@ struct PsyP {
   float m_val;
   float ath_adjatt, ath_maxatt;
   float tone_masteratt1;     // tone_masteratt[1]: VBR uses offset_select 1 only
+  float tone_masteratt0, tone_masteratt2;  // the lo / hi curves of a bitrate-managed block
   float tone_abs_limit;
   float noisemaxsupp;
   int noisewindowfixed;
@@ -36,6 +37,7 @@ struct PsyP {
   const int *octave;         // [n]
   const int *bark;           // [n]
   const float *noiseoffset1; // [n]  noiseoffset[1]
+  const float *noiseoffset0, *noiseoffset2;
   const float *tonecurves;   // [17][8][58]
   const float *noisecompand; // [40] (inside the blob header copy in HBM)
   // derived at vamd_create() from the static tables (host, once):
@@ -92,6 +94,11 @@ struct CoupleP {
   int pointlimit;        // coupling_pointlimit[blockflag][PACKETBLOBS/2]
   float prepoint, postpoint;
   int sliding_lowpass;   // sliding_lowpass[W][PACKETBLOBS/2]
+};
+
+// the coupling parameters of every candidate packet (blob) of a size class; VBR uses [PACKETBLOBS/2]
+struct CoupleSet {
+  CoupleP c[VAMD_PACKETBLOBS];
 };
 
 // per-block descriptor source (arrays may be null -> uniform value)
