@@ -177,7 +177,7 @@ typedef struct vamd_setup_header {
   int32_t  channels;
   int32_t  rate;
   int32_t  blocksizes[2];
-  int32_t  managed;                /* bitrate-managed setup (15 packet blobs): not covered */
+  int32_t  managed;                /* the host runs a bitrate manager: blocks want all 15 candidate packets */
   int32_t  pad[3];
   vamd_xform_tab      xform[2];
   vamd_psy_tab        psy[4];
