@@ -88,22 +88,34 @@ static size_t transform_lds_bytes(const XformP &P, int waves) {
   return (tables + (size_t)waves * ((P.n + 4) + (P.n + P.n / 32))) * 4;
 }
 
-// mdct_forward only (BASELINE config 2): in[nframes][n] -> out[nframes][n/2]
-__global__ __launch_bounds__(64 * VAMD_XF_WAVES) void k_mdct_only(XformP G, int W, long nframes,
+// mdct_forward only (BASELINE config 2): in[nframes][n] -> out[nframes][n/2].  The one HBM-bound
+// kernel of the path.  The fold reads each input value exactly once, so it reads the frame straight
+// from HBM (no LDS copy of it): a wave then needs only the butterfly buffer (8.4 KB at n = 2048) and
+// sixteen waves fit on a CU beside the trig / bit-reverse tables.
+#define VAMD_MD_WAVES 16
+static size_t mdct_only_lds_bytes(const XformP &P, int waves) {
+  const size_t n2 = P.n / 2;
+  return ((size_t)(P.n + P.n / 4) + P.n / 4 + (size_t)waves * (n2 + VAMD_PW_SIZE(n2))) * 4;
+}
+__global__ __launch_bounds__(64 * VAMD_MD_WAVES) void k_mdct_only(XformP G, int W, long nframes,
                                                                  const float *__restrict__ in,
                                                                  float *__restrict__ out) {
-  const XformLds L = stage_transform_tables(G);
-  const XformP &P = L.P;
-  const int n2 = P.n >> 1, nw = blockDim.x >> 6;
+  const int n = G.n, n2 = n >> 1, nw = blockDim.x >> 6;
+  float *trig = (float *)vamd_smem;          // [n + n/4]
+  int *bitrev = (int *)(trig + n + n / 4);   // [n/4]
+  float *work = (float *)(bitrev + n / 4);
+  for (int i = threadIdx.x; i < n + n / 4; i += blockDim.x) trig[i] = G.trig[i];
+  for (int i = threadIdx.x; i < n / 4; i += blockDim.x) bitrev[i] = G.bitrev[i];
+  __syncthreads();
+  XformP P = G;
+  P.trig = trig;
+  P.bitrev = bitrev;
+  float *B = work + (size_t)(threadIdx.x >> 6) * (n2 + VAMD_PW_SIZE(n2));
   PhaseClock pc;
   pc.start(nullptr);
-  // (no register prefetch here: this kernel is HBM-bound and measured faster loading each
-  // frame straight into LDS -- 246 vs 195 M frames/s)
   for (long f = (long)blockIdx.x * nw + (threadIdx.x >> 6); f < nframes; f += (long)gridDim.x * nw) {
-    WAVE_FOR(q, P.n >> 2)((F4 *)L.A)[q] = ((const F4 *)(in + f * P.n))[q];
-    WAVE_SYNC();
-    mdct_forward_wave(P, L.A, L.B, L.B + n2, pc);
-    WAVE_FOR(q, n2 >> 2)((F4 *)(out + f * n2))[q] = ((const F4 *)(L.B + n2))[q];
+    mdct_forward_wave(P, in + f * n, B, B + n2, pc);
+    WAVE_FOR(q, n2 >> 2)((F4 *)(out + f * n2))[q] = ((const F4 *)(B + n2))[q];
     WAVE_SYNC();
   }
 }
@@ -765,10 +777,11 @@ int vamd_mdct_forward_batch(vamd_ctx *c, int W, const float *in, float *out, lon
   if (!in || !out) return fail(c, VAMD_EINVAL, "null frame buffer");
   if (nframes > 0x7fffffffL) return fail(c, VAMD_EINVAL, "too many frames for one launch");
   const XformP &P = c->B.xf[W];
-  const int waves = xf_waves(c, P);
+  int waves = VAMD_MD_WAVES;
+  while (waves > 1 && mdct_only_lds_bytes(P, waves) > c->lds_per_block) waves--;
   const long groups = (nframes + waves - 1) / waves;
   const unsigned grid = (unsigned)(groups < c->num_cus ? groups : c->num_cus);
-  hipLaunchKernelGGL(k_mdct_only, dim3(grid), dim3(64 * waves), transform_lds_bytes(P, waves), c->stream, P, W, nframes, in,
+  hipLaunchKernelGGL(k_mdct_only, dim3(grid), dim3(64 * waves), mdct_only_lds_bytes(P, waves), c->stream, P, W, nframes, in,
                      out);
   HIP_TRY(c, hipGetLastError());
   return VAMD_OK;
