@@ -48,7 +48,10 @@ long vamd_pack_setup(vorbis_dsp_state *vd, void *dst, long cap) {
   vi = vd->vi;
   ci = (codec_setup_info *)vi->codec_setup;
   b = (private_state *)vd->backend_state;
-  if (!ci || ci->psys != 4) return OV_EINVAL;
+  /* two block sizes: four psy looks and two modes; the single-size setups (8 / 11 kHz) have two looks
+     and one mode, and only ever produce W = 0 blocks (lib/block.c:572-573): their W = 1 slots are
+     filled with copies so the blob keeps one shape */
+  if (!ci || (ci->psys != 4 && ci->psys != 2) || ci->modes < 1) return OV_EINVAL;
   if (vi->channels < 1 || vi->channels > VAMD_MAX_CH) return OV_EIMPL;
 
   /* a sizing pass (dst == NULL) always runs before anything is written */
@@ -92,7 +95,7 @@ long vamd_pack_setup(vorbis_dsp_state *vd, void *dst, long cap) {
 
   for (p = 0; p < 4; p++) {
     vamd_psy_tab *t = &h.psy[p];
-    vorbis_look_psy *l = b->psy + p;
+    vorbis_look_psy *l = b->psy + (ci->psys == 4 ? p : (p & 1));
     vorbis_info_psy *pi = l->vi;
     int n = l->n;
     uint32_t off;
@@ -161,9 +164,9 @@ long vamd_pack_setup(vorbis_dsp_state *vd, void *dst, long cap) {
     vorbis_look_floor1 *fl;
     vorbis_info_floor1 *fi;
     int fidx;
-    if (W >= ci->modes) return OV_EIMPL;
-    if (ci->map_type[ci->mode_param[W]->mapping] != 0) return OV_EIMPL;
-    map = (vorbis_info_mapping0 *)ci->map_param[ci->mode_param[W]->mapping];
+    const int mode = W < ci->modes ? W : 0;
+    if (ci->map_type[ci->mode_param[mode]->mapping] != 0) return OV_EIMPL;
+    map = (vorbis_info_mapping0 *)ci->map_param[ci->mode_param[mode]->mapping];
     m->submaps = map->submaps;
     m->coupling_steps = map->coupling_steps;
     if (map->submaps != 1 || map->coupling_steps > 1) return OV_EIMPL;
@@ -251,7 +254,7 @@ long vamd_pack_setup(vorbis_dsp_state *vd, void *dst, long cap) {
       }
     }
     for (W = 0; W < 2; W++) {
-      vorbis_info_mapping0 *map = (vorbis_info_mapping0 *)ci->map_param[ci->mode_param[W]->mapping];
+      vorbis_info_mapping0 *map = (vorbis_info_mapping0 *)ci->map_param[ci->mode_param[W < ci->modes ? W : 0]->mapping];
       int resnum = map->residuesubmap[0], acc = 0, maxstage = 0;
       vorbis_info_residue0 *ri = (vorbis_info_residue0 *)ci->residue_param[resnum];
       vamd_residue_tab *t = &h.res[W];

@@ -1,0 +1,71 @@
+"""Every libvorbisenc sample-rate family (lib/modes/setup_8.h ... setup_X.h): block sizes 256/2048,
+512/1024, and the single-size 512/512 setups of 8 and 11 kHz (two psy looks, one mode, W = 0 only),
+mono and stereo.  The reference is the checker throughout (these need /root/reference or the prebuilt
+oracle/_ref library; the shipped setup blobs only cover 44.1 kHz)."""
+import numpy as np
+import pytest
+
+import vorbis_amd
+from oracle import port, ref
+from tests import checker
+
+pytestmark = pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built (needs /root/reference)")
+RATES = [(96000, 2, 0.5), (48000, 2, 0.5), (32000, 2, 0.4), (22050, 2, 0.4), (16000, 2, 0.3), (11025, 1, 0.4),
+         (11025, 2, 0.5), (8000, 1, 0.3), (8000, 2, 0.2)]
+
+
+def cases(e, seed):
+    rng = np.random.default_rng(seed)
+    bs = (e.blocksize(0), e.blocksize(1))
+    for W in ((1, 0) if bs[0] != bs[1] else (0,)):
+        for amp in (0.5, 0.01):
+            pcm = ((rng.random((e.channels, bs[W]), dtype=np.float32) - 0.5) * 2 * amp).astype(np.float32)
+            yield (pcm, W, W, W, 1 if W else 0), W
+
+
+def same_res(a, b):
+    return np.array_equal(a["res_class"], b["res_class"]) and np.array_equal(a["res_entries"], b["res_entries"])
+
+
+@pytest.mark.parametrize("rate,ch,q", RATES)
+def test_port_and_kernel_bodies(rate, ch, q):
+    from tests.emul.emul import Emul
+    e = ref.RefEncoder(ch, rate, q)
+    blob = e.pack_setup()
+    p, em = port.PortEncoder(blob), Emul(blob)
+    for args, W in cases(e, rate + ch):
+        a = e.tap_block(*args)
+        assert a["packet_matches_real"]
+        b, g = p.tap_block(*args), em.analyze_block(*args)
+        assert checker.compare_block(a, b, e.floor_posts(W), verbose=True) == 0 and same_res(a, b)
+        assert checker.compare_block(a, g, e.floor_posts(W), verbose=True) == 0 and same_res(a, g)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rate,ch,q", [(48000, 2, 0.5), (22050, 2, 0.4), (11025, 1, 0.4), (8000, 2, 0.2)])
+def test_gpu(rate, ch, q):
+    e = ref.RefEncoder(ch, rate, q)
+    an = vorbis_amd.Analyzer(e.pack_setup(), 0)
+    for args, W in cases(e, rate):
+        a = e.tap_block(*args)
+        g = an.analyze_block(*args)
+        assert checker.compare_block(a, g, e.floor_posts(W), keys=("mdct", "post_valid", "iwork", "nonzero"),
+                                     verbose=True) == 0
+        assert same_res(a, g)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not ref.hybrid_available(), reason="hybrid library not built")
+@pytest.mark.parametrize("rate,ch,q", [(22050, 2, 0.4), (8000, 1, 0.3)])
+def test_hybrid_encode(rate, ch, q):
+    rng = np.random.default_rng(rate)
+    frames = rate * 2
+    t = np.arange(frames)
+    x = (rng.random((ch, frames), dtype=np.float32) - 0.5) * 2 * np.where((t % (rate // 4)) < rate // 40, 0.5, 0.0005)
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    want = ref.RefEncoder(ch, rate, q).encode_stream(x)
+    got = ref.RefEncoder(ch, rate, q, hybrid=True).encode_stream(x)
+    assert len(want) == len(got) > 20
+    for k, (a, b) in enumerate(zip(want, got)):
+        assert (a["lW"], a["W"], a["nW"], a["blocktype"]) == (b["lW"], b["W"], b["nW"], b["blocktype"]), k
+        assert a["packet"] == b["packet"], "packet %d differs (W=%d)" % (k, a["W"])
