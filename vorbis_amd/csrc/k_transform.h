@@ -63,6 +63,36 @@ VAMD_DEV void window_store(const XformP &P, int W, int lW, int nW, const PcmTile
   }
 }
 
+// The same window for blocks the register tile does not hold (n > 2048): HBM -> LDS directly.
+VAMD_DEV void window_store_hbm(const XformP &P, int W, int lW, int nW, const float *__restrict__ pcm, float *A) {
+  const int n = P.n;
+  lW = W ? lW : 0;
+  nW = W ? nW : 0;
+  const int ln = lW ? P.bs1 : P.bs0;
+  const int rn = nW ? P.bs1 : P.bs0;
+  const float *winL = lW ? P.win_long : P.win_short;
+  const float *winR = nW ? P.win_long : P.win_short;
+  const int leftbegin = n / 4 - ln / 4, leftend = leftbegin + ln / 2;
+  const int rightbegin = n / 2 + n / 4 - rn / 4, rightend = rightbegin + rn / 2;
+  WAVE_FOR(q, n >> 2) {
+    const int i = q << 2;
+    float v[4];
+    f4_get(((const F4 *)pcm)[q], v);
+    if (i < leftbegin || i >= rightend) {
+      v[0] = v[1] = v[2] = v[3] = 0.f;
+    } else if (i < leftend) {
+      float w[4];
+      f4_get(*(const F4 *)(winL + (i - leftbegin)), w);
+      v[0] *= w[0]; v[1] *= w[1]; v[2] *= w[2]; v[3] *= w[3];
+    } else if (i >= rightbegin) {
+      float w[4];
+      f4_get(*(const F4 *)(winR + (rn / 2 - 4 - (i - rightbegin))), w);
+      v[0] *= w[3]; v[1] *= w[2]; v[2] *= w[1]; v[3] *= w[0];
+    }
+    ((F4 *)A)[q] = f4_make(v);
+  }
+}
+
 // cPI*_8 of lib/mdct.h:43-45
 #define VAMD_C1 .92387953251128675613F
 #define VAMD_C2 .70710678118654752441F

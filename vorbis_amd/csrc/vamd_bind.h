@@ -62,8 +62,8 @@ inline int build_image(const void *blob_v, size_t bytes, std::vector<unsigned ch
       *err = "block size must be a power of two in [64, 8192]";
       return VAMD_EINVAL;
     }
-    if (x.n > 8 * 64 * VAMD_QPL_GPU) {
-      *err = "block sizes above 2048 are not covered (per-lane register tiles hold 1024 bins)";
+    if (x.n > 4096) {
+      *err = "block sizes above 4096 are not covered";
       return VAMD_EIMPL;
     }
     if (x.fft_nf < 1 || x.fft_nf > 8) {

@@ -136,11 +136,18 @@ __global__ __launch_bounds__(64 * VAMD_XF_WAVES) void k_transform(XformP G, int 
   const long cstride = (long)gridDim.x * nw;
   long cb = (long)blockIdx.x * nw + (threadIdx.x >> 6);
   PcmTile tile;
-  if (cb < ncb) pcm_fetch(tile, pcm + cb * n, n);
+  const bool tiled = n <= 4 * 64 * VAMD_QPL2;  // the register tile holds blocks up to 2048 samples
+  if (tiled && cb < ncb) pcm_fetch(tile, pcm + cb * n, n);
   for (; cb < ncb; cb += cstride) {
     const long blk = cb / ch;
-    transform_window(P, W, d_lW(d, blk), d_nW(d, blk), tile, L.A, pc);
-    if (cb + cstride < ncb) pcm_fetch(tile, pcm + (cb + cstride) * n, n);  // next block, one ahead
+    if (tiled) {
+      transform_window(P, W, d_lW(d, blk), d_nW(d, blk), tile, L.A, pc);
+      if (cb + cstride < ncb) pcm_fetch(tile, pcm + (cb + cstride) * n, n);  // next block, one ahead
+    } else {
+      window_store_hbm(P, W, d_lW(d, blk), d_nW(d, blk), pcm + cb * n, L.A);  // larger blocks: straight from HBM
+      WAVE_SYNC();
+      pc.mark(0);
+    }
     const float amp = transform_block(P, L.A, L.B, mdct_raw + cb * n2, logmdct + cb * n2, logfft + cb * n2, pc);
     if (LANE == 0) local_ampmax[cb] = amp;
   }
@@ -154,14 +161,16 @@ __global__ __launch_bounds__(64 * VAMD_XF_WAVES) void k_transform(XformP G, int 
 #define VAMD_NZ_WAVES_SHARED 6  // ... when the tone kernels run beside it
 #define VAMD_NZ_SPLIT 2
 __global__ __launch_bounds__(64 * VAMD_NZ_WAVES * VAMD_NZ_SPLIT) void k_noise(PsyP P0, PsyP P1, DescP d, int ch,
-                                                                             long ncb,
+                                                                             long ncb, int split,
                                                                              const float *__restrict__ logmdct,
                                                                              float *__restrict__ noise) {
   const int wave = threadIdx.x >> 6;
-  const int nblk = (blockDim.x >> 6) / VAMD_NZ_SPLIT, slot = wave / VAMD_NZ_SPLIT, part = wave % VAMD_NZ_SPLIT;
+  // `split` waves share a block: VAMD_NZ_SPLIT, more for blocks whose slices would not fit the
+  // per-lane register tiles (n = 4096: four waves of 512 bins)
+  const int nblk = (blockDim.x >> 6) / split, slot = wave / split, part = wave % split;
   const int n2 = P0.n, nq = n2 >> 2;
   // this wave's slice of the block's quads, a whole number of wave-widths
-  const int per = ((nq + VAMD_NZ_SPLIT * 64 - 1) / (VAMD_NZ_SPLIT * 64)) * 64;
+  const int per = ((nq + split * 64 - 1) / (split * 64)) * 64;
   const int q0 = part * per < nq ? part * per : nq, q1 = q0 + per < nq ? q0 + per : nq;
   float *S_all = (float *)vamd_smem;
   float *S = S_all + slot * 5 * (n2 + 4);
@@ -872,10 +881,14 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_
       // alone, 7 blocks' running sums fill the LDS; beside the tone kernels 6 leave those room
       int waves = overlap ? VAMD_NZ_WAVES_SHARED : VAMD_NZ_WAVES;
       while (waves > 1 && (size_t)waves * 5 * (n2 + 4) * 4 > c->lds_per_block) waves--;
+      // a wave's slice is at most QPS * 256 = 512 bins
+      int split = VAMD_NZ_SPLIT;
+      while ((n2 + split * 512 - 1) / (split * 512) > 1) split *= 2;
+      while (waves > 1 && waves * split > VAMD_NZ_WAVES * VAMD_NZ_SPLIT) waves--;
       const long groups = ((long)gcb + waves - 1) / waves;
       const unsigned grid = (unsigned)(groups < c->num_cus ? groups : c->num_cus);
-      hipLaunchKernelGGL(k_noise, dim3(grid), dim3(64 * waves * VAMD_NZ_SPLIT), (size_t)waves * 5 * (n2 + 4) * 4, s, P0, P1, d, ch,
-                         (long)gcb, p.logmdct, p.noise);
+      hipLaunchKernelGGL(k_noise, dim3(grid), dim3(64 * waves * split), (size_t)waves * 5 * (n2 + 4) * 4, s, P0, P1, d, ch,
+                         (long)gcb, split, p.logmdct, p.noise);
     }
     prof_mark(c), R->nst++;
     if (overlap) s = c->side;
