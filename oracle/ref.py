@@ -112,6 +112,8 @@ def lib(hybrid=False):
         L.ref_open_managed.restype = C.c_void_p
         L.ref_open_managed.argtypes = [C.c_int, C.c_long, C.c_long, C.c_long, C.c_long]
         L.ref_is_managed.argtypes = [C.c_void_p]
+        L.ref_open_uncoupled.restype = C.c_void_p
+        L.ref_open_uncoupled.argtypes = [C.c_int, C.c_long, C.c_float]
         L.ref_tap_block_managed.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                             C.POINTER(_Taps), C.POINTER(_MTaps)]
         _libs[path] = L
@@ -129,11 +131,13 @@ def _ip(a):
 class RefEncoder:
     """One reference encoder state (vorbis_info + vorbis_dsp_state + a vorbis_block)."""
 
-    def __init__(self, channels=2, rate=44100, quality=0.4, hybrid=False, managed=None):
+    def __init__(self, channels=2, rate=44100, quality=0.4, hybrid=False, managed=None, coupled=True):
         """quality: libvorbisenc VBR quality; or managed=(max, nominal, min) bitrates for a
         bitrate-managed encoder (vorbis_encode_init), whose blocks carry 15 candidate packets."""
         self.L = lib(hybrid)
-        if managed is None:
+        if not coupled:
+            self.h = self.L.ref_open_uncoupled(channels, rate, quality)  # OV_ECTL_COUPLING_SET = 0
+        elif managed is None:
             self.h = self.L.ref_open(channels, rate, quality)
         else:
             self.h = self.L.ref_open_managed(channels, rate, *[int(v) for v in managed])

@@ -79,6 +79,26 @@ ref_enc *ref_open_managed(int channels, long rate, long max_bitrate, long nomina
   return e;
 }
 
+/* VBR with channel coupling switched off (vorbis_encode_ctl OV_ECTL_COUPLING_SET = 0): stereo as two
+ * independent channels, residue type 1 over both */
+ref_enc *ref_open_uncoupled(int channels, long rate, float quality) {
+  ref_enc *e = (ref_enc *)calloc(1, sizeof(*e));
+  int zero = 0;
+  if (!e) return NULL;
+  vorbis_info_init(&e->vi);
+  if (vorbis_encode_setup_vbr(&e->vi, channels, rate, quality) ||
+      vorbis_encode_ctl(&e->vi, OV_ECTL_COUPLING_SET, &zero) || vorbis_encode_setup_init(&e->vi)) {
+    vorbis_info_clear(&e->vi);
+    free(e);
+    return NULL;
+  }
+  vorbis_analysis_init(&e->vd, &e->vi);
+  vorbis_block_init(&e->vd, &e->vb);
+  e->channels = channels;
+  e->quality = quality;
+  return e;
+}
+
 int ref_is_managed(ref_enc *e) { return vorbis_bitrate_managed(&e->vb) ? 1 : 0; }
 
 void ref_close(ref_enc *e) {

@@ -72,3 +72,34 @@ def test_hybrid_encode(rate, ch, q):
     for k, (a, b) in enumerate(zip(want, got)):
         assert (a["lW"], a["W"], a["nW"], a["blocktype"]) == (b["lW"], b["W"], b["nW"], b["blocktype"]), k
         assert a["packet"] == b["packet"], "packet %d differs (W=%d)" % (k, a["W"])
+
+
+# ---- stereo with channel coupling switched off (vorbis_encode_ctl OV_ECTL_COUPLING_SET = 0):
+# coupling_steps == 0, residue type 1 over two channels (that residue stays on the host) ----------
+@pytest.mark.parametrize("q", [0.1, 0.4, 0.9])
+def test_uncoupled_stereo_port_and_kernel_bodies(q):
+    from tests.emul.emul import Emul
+    e = ref.RefEncoder(2, 44100, q, coupled=False)
+    blob = e.pack_setup()
+    p, em = port.PortEncoder(blob), Emul(blob)
+    for args, W in cases(e, int(q * 10)):
+        a = e.tap_block(*args)
+        assert a["packet_matches_real"]
+        assert checker.compare_block(a, p.tap_block(*args), e.floor_posts(W), verbose=True) == 0
+        g = em.analyze_block(*args)
+        assert checker.compare_block(a, g, e.floor_posts(W), verbose=True) == 0 and "res_class" not in g
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not ref.hybrid_available(), reason="hybrid library not built")
+def test_uncoupled_stereo_hybrid_encode():
+    rng = np.random.default_rng(4)
+    frames = 44100
+    t = np.arange(frames)
+    x = (rng.random((2, frames), dtype=np.float32) - 0.5) * 2 * np.where((t % 11025) < 1102, 0.5, 0.0005)
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    want = ref.RefEncoder(2, 44100, 0.4, coupled=False).encode_stream(x)
+    got = ref.RefEncoder(2, 44100, 0.4, coupled=False, hybrid=True).encode_stream(x)
+    assert len(want) == len(got) > 20
+    for k, (a, b) in enumerate(zip(want, got)):
+        assert a["packet"] == b["packet"], "packet %d differs (W=%d)" % (k, a["W"])
