@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define VAMD_SETUP_MAGIC   0x31544553444d4156ULL /* "VAMDSET1" little-endian */
-#define VAMD_SETUP_VERSION 4u
+#define VAMD_SETUP_VERSION 5u
 
 #define VAMD_PACKETBLOBS   15  /* lib/codec_internal.h:28 */
 #define VAMD_P_BANDS       17  /* lib/psy.h:28 */
@@ -36,6 +36,8 @@ extern "C" {
 #define VAMD_P_NOISECURVES 3   /* lib/psy.h:31 */
 #define VAMD_NOISE_COMPAND_LEVELS 40 /* lib/psy.h:33 */
 #define VAMD_POSIT         65  /* VIF_POSIT+2, lib/backends.h:57 */
+#define VAMD_FLOOR_PARTS   31  /* VIF_PARTS, lib/backends.h:59 */
+#define VAMD_FLOOR_CLASSES 16  /* VIF_CLASS, lib/backends.h:58 */
 #define VAMD_MAX_CH        2   /* channel counts the kernels cover this round */
 #define VAMD_VE_BANDS      7   /* lib/envelope.h:28 */
 #define VAMD_VE_NEARDC     15  /* lib/envelope.h:29 */
@@ -113,6 +115,14 @@ typedef struct vamd_floor1_tab {
   int32_t hineighbor[VAMD_POSIT];
   int32_t loneighbor[VAMD_POSIT];
   int32_t pad2[2];
+  /* the bit-writing half of floor1_encode (lib/floor1.c:833-921): vorbis_info_floor1's partition and
+   * class tables (lib/backends.h:60-72) */
+  int32_t partitions;
+  int32_t partitionclass[VAMD_FLOOR_PARTS];
+  int32_t class_dim[VAMD_FLOOR_CLASSES];
+  int32_t class_subs[VAMD_FLOOR_CLASSES];
+  int32_t class_book[VAMD_FLOOR_CLASSES];
+  int32_t class_subbook[VAMD_FLOOR_CLASSES][8];   /* book number, -1 = none */
 } vamd_floor1_tab;
 
 /* one per mode W: vorbis_info_mapping0 (lib/backends.h:130-141) with its floor */
@@ -167,7 +177,8 @@ typedef struct vamd_book_tab {
   int32_t  dim, entries;
   int32_t  minval, delta, quantvals;
   uint32_t off_lengths;  /* int8[entries] codeword lengths (<= 0: unused entry) */
-  int32_t  pad[2];
+  uint32_t off_codes;    /* uint32[entries] codebook.codelist: the codewords as written, LSb first */
+  int32_t  pad;
 } vamd_book_tab;
 
 typedef struct vamd_setup_header {
@@ -178,7 +189,9 @@ typedef struct vamd_setup_header {
   int32_t  rate;
   int32_t  blocksizes[2];
   int32_t  managed;                /* the host runs a bitrate manager: blocks want all 15 candidate packets */
-  int32_t  pad[3];
+  int32_t  modebits;               /* private_state.modebits: width of a packet's mode number */
+  int32_t  modes;                  /* ci->modes (1: both size classes share mode 0) */
+  int32_t  pad;
   vamd_xform_tab      xform[2];
   vamd_psy_tab        psy[4];
   vamd_psy_global_tab psy_g;

@@ -131,6 +131,13 @@ typedef struct vamd_batch_io {
   int32_t  *res_class;    /* out [nb][VAMD_RES_CLASS_STRIDE] class of each partition */
   uint16_t *res_entries;  /* out [nb][vamd_residue_capacity(ctx, W)] entry numbers, (stage, partition, vector) order */
   int32_t  *res_count;    /* out [nb][2] {partitions classified (0 = nothing to code), entries} */
+  /* packet assembly, level FULL only, both or none: the block's finished audio
+   * packet -- header bits, floor1_encode's writes, the residue's phrase words and codewords, packed
+   * LSb first exactly as oggpack_write would (lib/mapping0.c:598-606, lib/floor1.c:833-921,
+   * lib/res0.c:534-640).  Available when vamd_packet_capacity() > 0. */
+  uint8_t  *packets;      /* out [nb][packet_stride] bytes; the packet is the first (bits+7)/8 of a row */
+  int32_t  *packet_bits;  /* out [nb] oggpack_bits(); > 8*packet_stride: the row was too short, packet cut off */
+  int64_t   packet_stride;/* row length in bytes, a multiple of 4 (vamd_packet_capacity() always suffices) */
 } vamd_batch_io;
 
 #define VAMD_RES_CLASS_STRIDE 64 /* ints per block in res_class[] (>= (end-begin)/grouping) */
@@ -138,6 +145,11 @@ typedef struct vamd_batch_io {
 /* Entries one block of size class W can emit at most (the row length of res_entries), or 0 when the
  * mode's residue is not covered on the GPU (type 2 over a 2-channel bundle and type 1 over one channel are). */
 int vamd_residue_capacity(const vamd_ctx *ctx, int W);
+
+/* Bytes the longest possible packet of size class W takes (a multiple of 4; worst case over every
+ * field's longest codeword), or 0 when packets of this mode are not assembled on the GPU (they are
+ * wherever vamd_residue_capacity() > 0). */
+int vamd_packet_capacity(const vamd_ctx *ctx, int W);
 
 /* how far down mapping0_forward the batch runs */
 #define VAMD_LEVEL_TRANSFORM 1 /* window, MDCT, FFT, logfft/logmdct, local ampmax (lib/mapping0.c:254-360,384) */
@@ -222,6 +234,9 @@ typedef struct vamd_managed_io {
   int32_t  *res_class;   /* out [nb][15][VAMD_RES_CLASS_STRIDE]   optional, all three or none */
   uint16_t *res_entries; /* out [nb][15][vamd_residue_capacity(ctx, W)] */
   int32_t  *res_count;   /* out [nb][15][2] */
+  uint8_t  *packets;     /* out [nb][15][packet_stride]           optional, with packet_bits (as vamd_batch_io) */
+  int32_t  *packet_bits; /* out [nb][15] */
+  int64_t   packet_stride;
 } vamd_managed_io;
 
 /* vamd_analyze_batch(level FULL) for bitrate-managed blocks: `io` carries pcm and the shared outputs
@@ -246,6 +261,14 @@ int vamd_analyze_block_res(vamd_ctx *ctx, const float *const *pcm, int lW, int W
                            float ampmax_in, float *mdct, float *logmask, int32_t *posts, int32_t *post_valid,
                            int32_t *iwork, int32_t *nonzero, float *ampmax_out, int32_t *res_class,
                            uint16_t *res_entries, int32_t *res_count);
+
+/* One block from host memory all the way to its packet(s): what mapping0_forward leaves in
+ * vbi->packetblob[] (lib/mapping0.c:593-687).  managed == 0: one packet (candidate PACKETBLOBS/2, the
+ * VBR case); managed != 0: all 15 candidates of a bitrate-managed block.  packets [1 or 15][packet_stride]
+ * and packet_bits [1 or 15] are host memory; rows need vamd_packet_capacity(ctx, W) bytes.  Fails with
+ * VAMD_EIMPL where vamd_packet_capacity() is 0. */
+int vamd_encode_block(vamd_ctx *ctx, const float *const *pcm, int lW, int W, int nW, int blocktype, float ampmax_in,
+                      int managed, float *ampmax_out, uint8_t *packets, long packet_stride, int32_t *packet_bits);
 
 /* winlength / searchstep of the detector (128 / 64 in every libvorbis setup). */
 int vamd_envelope_geometry(const vamd_ctx *ctx, int *winlength, int *searchstep);

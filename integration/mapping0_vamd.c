@@ -8,11 +8,12 @@
  *   - it pulls the reference's own mapping0.c in by path (pack/unpack/free_info/
  *     inverse and the CPU forward stay exactly as they are; nothing is copied),
  *     renaming only the exported bundle;
- *   - it defines mapping0_forward_vamd(): the numeric section of mapping0_forward
- *     (lib/mapping0.c:254-576 and the floor render + couple/quantise of :613-646)
- *     is ONE call into libvorbis_amd.so; the bit-writing half (packet header,
- *     floor1_encode's Huffman writes, res*_class / res*_forward) is the
- *     reference's unchanged host code;
+ *   - it defines mapping0_forward_vamd(): all of mapping0_forward (lib/mapping0.c:254-687)
+ *     is ONE call into libvorbis_amd.so that returns the block's packet bytes
+ *     (vamd_encode_block), copied into vbi->packetblob[]; for the few modes whose residue
+ *     the GPU does not search, the numeric section (:254-576,613-646) is one call and the
+ *     bit-writing half (packet header, floor1_encode's Huffman writes, res*_class /
+ *     res*_forward) remains the reference's unchanged host code;
  *   - it exports a mapping0_exportbundle whose .forward is that function.
  *
  * Everything else in libvorbis / libvorbisenc links unchanged.  oracle/Makefile
@@ -20,8 +21,8 @@
  * tests/test_gpu_dropin.py checks that an encode through the hybrid library
  * emits byte-identical packets to the pure reference.
  *
- * Bitrate-managed encoders get all PACKETBLOBS candidate packets the same way
- * (vamd_analyze_block_managed); the bitrate manager that picks one is untouched host code.
+ * Bitrate-managed encoders get all PACKETBLOBS candidate packets the same way;
+ * the bitrate manager that picks one is untouched host code.
  * Only channel counts above VAMD_MAX_CH fall through to the reference's CPU forward (host
  * code choosing its own CPU implementation -- the GPU library itself has no CPU path).
  */
@@ -33,9 +34,6 @@
 #include "vorbis_amd.h"
 
 extern long vamd_pack_setup(vorbis_dsp_state *vd, void *dst, long cap);
-/* res0_vamd.c: res2_forward for classes / entries the GPU already chose */
-extern int vamd_res2_forward(oggpack_buffer *opb, vorbis_block *vb, vorbis_look_residue *vl, const int32_t *res_class,
-                             long partvals, const uint16_t *entries, long nentries);
 
 /* one GPU context per analysis state, created on first use (vorbis_analysis_init has
  * already built every lookup by then).  A real integration would hang the pointer off
@@ -102,13 +100,12 @@ void vamd_release_key(const void *key) {
 /* for a build WITHOUT envelope_vamd.c: call from vorbis_dsp_clear() before b->ve is freed */
 void vamd_release_state(vorbis_dsp_state *state) { vamd_release_key(vamd_key(state)); }
 
-/* The bit-writing half for one candidate packet k, unchanged host code (lib/mapping0.c:596-687):
- * packet header, floor1_encode's Huffman words from the posts the GPU fitted, residue.
- *   posts / post_valid / iwork / nonzero  this candidate's [ch][...] rows
- *   res_*   this candidate's residue decisions, or rescap == 0 for the host's own res*_class/forward */
+/* The bit-writing half for one candidate packet k where the GPU does not assemble packets (the mode's
+ * residue back-end is not covered there): unchanged host code, lib/mapping0.c:596-687 -- packet header,
+ * floor1_encode's Huffman words from the posts the GPU fitted, res*_class / res*_forward.
+ *   posts / post_valid / iwork / nonzero  this candidate's [ch][...] rows */
 static int vamd_write_packet(vorbis_block *vb, int k, int *posts, const int *post_valid, int *iwork,
-                             const int *nonzero, int rescap, const int32_t *res_class, const uint16_t *res_entries,
-                             const int32_t *res_count, int *scratch) {
+                             const int *nonzero, int *scratch) {
   vorbis_dsp_state *vd = vb->vd;
   vorbis_info *vi = vd->vi;
   codec_setup_info *ci = vi->codec_setup;
@@ -134,13 +131,6 @@ static int vamd_write_packet(vorbis_block *vb, int k, int *posts, const int *pos
     floor1_encode(opb, vb, b->flr[info->floorsubmap[submap]], post_valid[i] ? posts + i * VAMD_POSTS_STRIDE : NULL,
                   scratch);
   }
-  if (rescap > 0) {
-    /* lib/mapping0.c:673-683 with the search done: the reference's _01forward writes the bits */
-    if (vamd_res2_forward(opb, vb, b->residue[info->residuesubmap[0]], res_class, res_count[0], res_entries,
-                          res_count[1]))
-      return OV_EFAULT;
-    return 0;
-  }
   for (i = 0; i < info->submaps; i++) {
     int ch_in_bundle = 0;
     long **classifications;
@@ -164,64 +154,66 @@ static int vamd_write_packet(vorbis_block *vb, int k, int *posts, const int *pos
 static int mapping0_forward_vamd(vorbis_block *vb) {
   vorbis_dsp_state *vd = vb->vd;
   vorbis_info *vi = vd->vi;
-  codec_setup_info *ci = vi->codec_setup;
   vorbis_block_internal *vbi = (vorbis_block_internal *)vb->internal;
   const int n = vb->pcmend, ch = vi->channels;
   const int managed = vorbis_bitrate_managed(vb) ? 1 : 0, nk = managed ? PACKETBLOBS : 1;
-  vorbis_info_mapping0 *info = ci->map_param[vb->W];
   vamd_ctx *ctx;
   float *mdct;
   int *iwork, *posts, *post_valid, *nonzero, *scratch;
-  int32_t *res_class = NULL, *res_count = NULL;
-  uint16_t *res_entries = NULL;
   float ampmax_out;
-  int k, ret, rescap;
+  int k, ret, pkcap;
 
   if (ch > VAMD_MAX_CH) return mapping0_forward(vb); /* not covered: the host's own CPU code */
   ctx = vamd_ctx_for(vd);
   if (!ctx) return OV_EFAULT; /* no silent fallback: a missing GPU is an error */
 
   vb->mode = vb->W;
+
+  /* ---- the whole of mapping0_forward in one call (lib/mapping0.c:254-687): the block's finished
+     packet -- all PACKETBLOBS candidates for a bitrate-managed encoder, which lets
+     vorbis_bitrate_addblock() choose (lib/mapping0.c:593-595) -- comes back as bytes */
+  pkcap = vamd_packet_capacity(ctx, vb->W);
+  if (pkcap > 0) {
+    unsigned char *packets = _vorbis_block_alloc(vb, (long)nk * pkcap);
+    int32_t *bits = _vorbis_block_alloc(vb, nk * sizeof(*bits));
+    ret = vamd_encode_block(ctx, (const float *const *)vb->pcm, vb->lW, vb->W, vb->nW, vbi->blocktype, vbi->ampmax,
+                            managed, &ampmax_out, packets, pkcap, bits);
+    if (ret) {
+      fprintf(stderr, "vorbis_amd: block encode failed (%d): %s\n", ret, vamd_last_error(ctx));
+      return ret;
+    }
+    vbi->ampmax = ampmax_out; /* lib/mapping0.c:576 */
+    for (k = 0; k < nk; k++) {
+      if (bits[k] > 8 * pkcap) return OV_EFAULT; /* cannot happen: pkcap is the worst case */
+      oggpack_writecopy(vbi->packetblob[managed ? k : PACKETBLOBS / 2], packets + (long)k * pkcap, bits[k]);
+    }
+    return 0;
+  }
+
+  /* ---- modes whose residue the GPU does not search (e.g. coupling switched off): the numeric
+     section through couple/quantise is one call (lib/mapping0.c:254-576,613-646; managed: +:507-573
+     for each candidate), the bit-writing half stays the reference's host code */
   mdct = _vorbis_block_alloc(vb, ch * (n / 2) * sizeof(*mdct));
   scratch = _vorbis_block_alloc(vb, (n / 2) * sizeof(*scratch));
   iwork = _vorbis_block_alloc(vb, nk * ch * (n / 2) * sizeof(*iwork));
   posts = _vorbis_block_alloc(vb, nk * ch * VAMD_POSTS_STRIDE * sizeof(*posts));
   post_valid = _vorbis_block_alloc(vb, nk * ch * sizeof(*post_valid));
   nonzero = _vorbis_block_alloc(vb, nk * ch * sizeof(*nonzero));
-  /* where the mode's residue is covered (type 2 stereo / type 1 mono, one submap), its classification
-     and lattice search come back with the same call and the host only writes bits */
-  rescap = info->submaps == 1 ? vamd_residue_capacity(ctx, vb->W) : 0;
-  if (rescap > 0) {
-    res_class = _vorbis_block_alloc(vb, nk * VAMD_RES_CLASS_STRIDE * sizeof(*res_class));
-    res_entries = _vorbis_block_alloc(vb, nk * rescap * sizeof(*res_entries));
-    res_count = _vorbis_block_alloc(vb, nk * 2 * sizeof(*res_count));
-  }
-
-  /* ---- the numeric section: window, MDCT, FFT, masking, floor fit(s), floor curve(s),
-     couple/quantise, residue search -- one call (lib/mapping0.c:254-576,613-646; managed: +:507-573
-     and :613-646 for each of the PACKETBLOBS candidates) */
   if (managed)
     ret = vamd_analyze_block_managed(ctx, (const float *const *)vb->pcm, vb->lW, vb->W, vb->nW, vbi->blocktype,
-                                     vbi->ampmax, mdct, &ampmax_out, posts, post_valid, iwork, nonzero, res_class,
-                                     res_entries, res_count);
+                                     vbi->ampmax, mdct, &ampmax_out, posts, post_valid, iwork, nonzero, NULL, NULL,
+                                     NULL);
   else
-    ret = vamd_analyze_block_res(ctx, (const float *const *)vb->pcm, vb->lW, vb->W, vb->nW, vbi->blocktype,
-                                 vbi->ampmax, mdct, NULL, posts, post_valid, iwork, nonzero, &ampmax_out, res_class,
-                                 res_entries, res_count);
+    ret = vamd_analyze_block(ctx, (const float *const *)vb->pcm, vb->lW, vb->W, vb->nW, vbi->blocktype, vbi->ampmax,
+                             mdct, NULL, posts, post_valid, iwork, nonzero, &ampmax_out);
   if (ret) {
     fprintf(stderr, "vorbis_amd: block analysis failed (%d): %s\n", ret, vamd_last_error(ctx));
     return ret;
   }
   vbi->ampmax = ampmax_out; /* lib/mapping0.c:576 */
-
-  /* ---- the bit-writing half: VBR writes candidate PACKETBLOBS/2 only, a managed encoder all of
-     them and lets vorbis_bitrate_addblock() choose (lib/mapping0.c:593-595) */
   for (k = 0; k < nk; k++) {
     ret = vamd_write_packet(vb, managed ? k : PACKETBLOBS / 2, posts + k * ch * VAMD_POSTS_STRIDE, post_valid + k * ch,
-                            iwork + k * ch * (n / 2), nonzero + k * ch, rescap,
-                            rescap > 0 ? res_class + k * VAMD_RES_CLASS_STRIDE : NULL,
-                            rescap > 0 ? res_entries + (long)k * rescap : NULL, rescap > 0 ? res_count + 2 * k : NULL,
-                            scratch);
+                            iwork + k * ch * (n / 2), nonzero + k * ch, scratch);
     if (ret) return ret;
   }
   return 0;

@@ -198,7 +198,19 @@ long vamd_pack_setup(vorbis_dsp_state *vd, void *dst, long cap) {
       m->floor.hineighbor[i] = fl->hineighbor[i];
       m->floor.loneighbor[i] = fl->loneighbor[i];
     }
+    /* what the bit-writing half of floor1_encode walks (lib/floor1.c:833-921) */
+    if (fi->partitions > VAMD_FLOOR_PARTS) return OV_EIMPL;
+    m->floor.partitions = fi->partitions;
+    for (i = 0; i < fi->partitions; i++) m->floor.partitionclass[i] = fi->partitionclass[i];
+    for (i = 0; i < VAMD_FLOOR_CLASSES; i++) {
+      m->floor.class_dim[i] = fi->class_dim[i];
+      m->floor.class_subs[i] = fi->class_subs[i];
+      m->floor.class_book[i] = fi->class_book[i];
+      for (j = 0; j < 8; j++) m->floor.class_subbook[i][j] = fi->class_subbook[i][j];
+    }
   }
+  h.modebits = b->modebits;
+  h.modes = ci->modes;
 
   {
     /* the block-switching detector's lookup (lib/envelope.c:30-74) */
@@ -242,6 +254,8 @@ long vamd_pack_setup(vorbis_dsp_state *vd, void *dst, long cap) {
     for (i = 0; i < ci->books; i++) {
       const codebook *cb = ci->fullbooks + i;
       uint32_t off = place(&cur, (uint32_t)cb->entries);
+      uint32_t offc = place(&cur, (uint32_t)cb->entries * 4u);
+      if (!cb->codelist) return OV_EINVAL; /* (vorbis_book_init_encode builds it) */
       if (dst) {
         vamd_book_tab *t = books + i;
         t->dim = (int32_t)cb->dim;
@@ -250,6 +264,8 @@ long vamd_pack_setup(vorbis_dsp_state *vd, void *dst, long cap) {
         t->delta = cb->delta;
         t->quantvals = cb->quantvals;
         t->off_lengths = off;
+        t->off_codes = offc;
+        put(dst, offc, cb->codelist, (uint32_t)cb->entries * 4u);
         for (j = 0; j < cb->entries; j++) ((signed char *)dst)[off + j] = (signed char)cb->c->lengthlist[j];
       }
     }

@@ -77,6 +77,15 @@ fail:
   oggpack_writeclear(b);
 }
 
+/* libogg's oggpack_writecopy(): append `bits` bits of an LSb-first packed buffer (whole bytes,
+ * then the low bits of the last one) */
+void oggpack_writecopy(oggpack_buffer *b, void *source, long bits) {
+  const unsigned char *src = (const unsigned char *)source;
+  long i, bytes = bits / 8;
+  for (i = 0; i < bytes; i++) oggpack_write(b, src[i], 8);
+  if (bits & 7) oggpack_write(b, src[bytes], (int)(bits & 7));
+}
+
 void oggpack_readinit(oggpack_buffer *b, unsigned char *buf, int bytes) {
   memset(b, 0, sizeof(*b));
   b->buffer = b->ptr = buf;

@@ -40,6 +40,7 @@ void  oggpack_reset(oggpack_buffer *b);
 void  oggpack_writeclear(oggpack_buffer *b);
 void  oggpack_readinit(oggpack_buffer *b, unsigned char *buf, int bytes);
 void  oggpack_write(oggpack_buffer *b, unsigned long value, int bits);
+void  oggpack_writecopy(oggpack_buffer *b, void *source, long bits);
 long  oggpack_look(oggpack_buffer *b, int bits);
 void  oggpack_adv(oggpack_buffer *b, int bits);
 long  oggpack_read(oggpack_buffer *b, int bits);

@@ -16,6 +16,7 @@
 #include "k_couple.h"
 #include "k_envelope.h"
 #include "k_residue.h"
+#include "k_pack.h"
 
 using namespace vamd;
 
@@ -34,11 +35,35 @@ struct EmulTaps {  // arrays [ch][...], any may be null
   int *res_class;               // [VAMD_RES_CLASS_STRIDE]
   unsigned short *res_entries;  // [capacity of the mode]
   int *res_count;               // [2]
+  unsigned char *packet;        // [emul_packet_capacity] (needs the three res_* too)
+  int *packet_bits;
 };
 
 struct EmulMTaps {  // per candidate packet of a bitrate-managed block, [15][ch][...]
   int *posts, *post_valid, *iwork, *nonzero;
+  unsigned char *packets;  // [15][emul_packet_capacity] or null
+  int *packet_bits;        // [15]
 };
+
+// residue search + packet assembly of one packet, the way k_residue / k_pack run them
+static void residue_and_pack(const Bound &B, int W, int lW, int nW, const int *iwork, const int *nonzero, const int *posts,
+                             const int *post_valid, int *res_class, unsigned short *res_entries, int *res_count,
+                             unsigned char *packet, int *packet_bits) {
+  const int ch = B.channels, n2 = B.bs[W] / 2;
+  const ResP &Rp = B.res[W];
+  PhaseClock pc;
+  pc.start(nullptr);
+  std::vector<int> work(ch * n2), cls(VAMD_RES_CLASS_STRIDE), off(B.res_stages[W] * B.res_partvals[W] + 1),
+      info(B.res_stages[W] * B.res_partvals[W] + 1);
+  const int *ip[VAMD_MAX_CH];
+  for (int i = 0; i < ch; i++) ip[i] = iwork + i * n2;
+  residue2_block(Rp, ch, n2, ip, nonzero, work.data(), cls.data(), off.data(), info.data(), res_class, res_entries, res_count,
+                 pc);
+  if (!packet) return;
+  std::vector<int> ring(VAMD_PK_RING), outv(VAMD_POSTS_STRIDE);
+  pack_block(B.pack[W], B.floor[W], Rp, ch, W, lW, nW, posts, post_valid, res_class, res_entries, res_count, ring.data(),
+             outv.data(), cls.data(), off.data(), info.data(), (unsigned *)packet, B.pack[W].capacity / 4, packet_bits);
+}
 
 static int analyze_core(void *h, const float *pcm, int lW, int W, int nW, int blocktype, float ampmax_in, EmulTaps *t,
                         EmulMTaps *m);
@@ -57,6 +82,7 @@ void *emul_open(const void *blob, size_t bytes) {
 }
 void emul_close(void *h) { delete (Emul *)h; }
 int emul_residue_capacity(void *h, int W) { return ((Emul *)h)->B.res[W].covered ? ((Emul *)h)->B.res[W].cap : 0; }
+int emul_packet_capacity(void *h, int W) { return ((Emul *)h)->B.pack[W].capacity; }
 
 int emul_mdct_forward(void *h, int W, const float *in, float *out) {
   Emul *e = (Emul *)h;
@@ -148,6 +174,14 @@ static int analyze_core(void *h, const float *pcm, int lW, int W, int nW, int bl
           op[i] = m->iwork + ((size_t)k * ch + i) * n2;
         }
         couple_block(B.couple_all[W].c[k], P, n2, mp, ip, op, m->nonzero + k * ch, L, pc);
+        if (m->packets) {
+          if (!B.res[W].covered) return -130;
+          std::vector<int> rc(VAMD_RES_CLASS_STRIDE), cnt(2);
+          std::vector<unsigned short> re(B.res[W].cap);
+          residue_and_pack(B, W, lW, nW, m->iwork + (size_t)k * ch * n2, m->nonzero + k * ch,
+                           m->posts + (size_t)k * ch * VAMD_POSTS_STRIDE, m->post_valid + k * ch, rc.data(), re.data(),
+                           cnt.data(), m->packets + (size_t)k * B.pack[W].capacity, m->packet_bits + k);
+        }
       }
       if (t->mdct) memcpy(t->mdct, mdct.data(), sizeof(float) * mdct.size());
       if (t->logmask) memcpy(t->logmask, logmask.data(), sizeof(float) * logmask.size());
@@ -157,14 +191,9 @@ static int analyze_core(void *h, const float *pcm, int lW, int W, int nW, int bl
     couple_block(C, P, n2, mp, ip, op, nonzero.data(), L, pc);
   }
   if (t->res_entries && t->res_class && t->res_count) {
-    const ResP &Rp = B.res[W];
-    if (!Rp.covered) return -130;
-    std::vector<int> work(ch * n2), cls(VAMD_RES_CLASS_STRIDE), off(B.res_stages[W] * B.res_partvals[W] + 1),
-        info(B.res_stages[W] * B.res_partvals[W] + 1);
-    const int *ip[VAMD_MAX_CH];
-    for (int i = 0; i < ch; i++) ip[i] = &iwork[i * n2];
-    residue2_block(Rp, ch, n2, ip, nonzero.data(), work.data(), cls.data(), off.data(), info.data(), t->res_class, t->res_entries,
-                   t->res_count, pc);
+    if (!B.res[W].covered) return -130;
+    residue_and_pack(B, W, lW, nW, iwork.data(), nonzero.data(), posts.data(), post_valid.data(), t->res_class,
+                     t->res_entries, t->res_count, t->packet, t->packet_bits);
   }
 #define OUT(name, vec, type) \
   if (t->name) memcpy(t->name, vec.data(), sizeof(type) * vec.size())

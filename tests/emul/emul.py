@@ -18,7 +18,16 @@ class _Taps(C.Structure):
     _fields_ = [(k, _f32p) for k in ("mdct_raw", "logfft", "logmdct", "noise", "tone", "logmask", "mdct")] + \
                [(k, _i32p) for k in ("posts", "post_valid", "ilogmask", "iwork", "nonzero")] + \
                [("local_ampmax", _f32p), ("ampmax_out", _f32p)] + \
-               [("res_class", _i32p), ("res_entries", C.POINTER(C.c_ushort)), ("res_count", _i32p)]
+               [("res_class", _i32p), ("res_entries", C.POINTER(C.c_ushort)), ("res_count", _i32p)] + \
+               [("packet", C.c_void_p), ("packet_bits", _i32p)]
+
+
+def packet_bytes(row, bits):
+    """The packet as oggpack_get_buffer()/oggpack_bytes() would hand it over: (bits+7)/8 bytes, the
+    unused high bits of the last one zero."""
+    nbytes = (bits + 7) // 8
+    assert nbytes <= row.size, "packet longer than its row"
+    return row[:nbytes].tobytes()
 
 
 def build(force=False):
@@ -36,7 +45,8 @@ def build(force=False):
 
 
 class _MTaps(C.Structure):
-    _fields_ = [(k, _i32p) for k in ("posts", "post_valid", "iwork", "nonzero")]
+    _fields_ = [(k, _i32p) for k in ("posts", "post_valid", "iwork", "nonzero")] + \
+               [("packets", C.c_void_p), ("packet_bits", _i32p)]
 
 
 class Emul:
@@ -51,6 +61,7 @@ class Emul:
         self.L.emul_analyze_block_managed.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                                       C.POINTER(_Taps), C.POINTER(_MTaps)]
         self.L.emul_residue_capacity.argtypes = [C.c_void_p, C.c_int]
+        self.L.emul_packet_capacity.argtypes = [C.c_void_p, C.c_int]
         self.L.emul_envelope_search.argtypes = [C.c_void_p, _f32p, C.c_long, C.c_long, C.c_void_p, C.c_void_p]
         blob = np.ascontiguousarray(blob, dtype=np.uint8)
         self.h = self.L.emul_open(blob.ctypes.data_as(C.c_void_p), blob.size)
@@ -86,12 +97,17 @@ class Emul:
             rcls, rent, rcnt = np.zeros(64, np.int32), np.zeros(cap, np.uint16), np.zeros(2, np.int32)
             t.res_class, t.res_count = rcls.ctypes.data_as(_i32p), rcnt.ctypes.data_as(_i32p)
             t.res_entries = rent.ctypes.data_as(C.POINTER(C.c_ushort))
+            pk = np.full(self.L.emul_packet_capacity(self.h, W), 0xAA, np.uint8)
+            pbits = np.zeros(1, np.int32)
+            t.packet, t.packet_bits = pk.ctypes.data, pbits.ctypes.data_as(_i32p)
         r = self.L.emul_analyze_block(self.h, pcm.ctypes.data_as(_f32p), lW, W, nW, blocktype, ampmax_in, C.byref(t))
         assert r == 0
         o["ampmax_out"] = float(o["ampmax_out"][0])
         if cap > 0:
             o["res_class"] = rcls[:rcnt[0]].copy()
             o["res_entries"] = rent[:rcnt[1]].copy()
+            o["packet_bits"] = int(pbits[0])
+            o["packet"] = packet_bytes(pk, int(pbits[0]))
         return o
 
     def analyze_block_managed(self, pcm, lW=1, W=1, nW=1, blocktype=1, ampmax_in=-9999.0):
@@ -109,12 +125,18 @@ class Emul:
         m = _MTaps()
         for k, v in mo.items():
             setattr(m, k, v.ctypes.data_as(_i32p))
+        pcap = self.L.emul_packet_capacity(self.h, W)
+        if pcap > 0:
+            pk, pbits = np.full((15, pcap), 0xAA, np.uint8), np.zeros(15, np.int32)
+            m.packets, m.packet_bits = pk.ctypes.data, pbits.ctypes.data_as(_i32p)
         r = self.L.emul_analyze_block_managed(self.h, pcm.ctypes.data_as(_f32p), lW, W, nW, blocktype, ampmax_in,
                                               C.byref(t), C.byref(m))
         assert r == 0
         o["ampmax_out"] = float(o["ampmax_out"][0])
         for k, v in mo.items():
             o["m_" + k] = v
+        if pcap > 0:
+            o["m_packets"] = [packet_bytes(pk[k], int(pbits[k])) for k in range(15)]
         return o
 
     def envelope_search(self, pcm, nsteps, state):

@@ -1,14 +1,15 @@
 """GPU suite: the drop-in boundary end to end.
 
 oracle/_ref/libvorbis_hybrid.so is the reference's own libvorbis objects with lib/mapping0.c replaced
-by the binding integration/mapping0_vamd.c (numeric section -> libvorbis_amd.so, bit-writing half
-unchanged) and lib/envelope.c replaced by integration/envelope_vamd.c (the block-switching detector's
-steps -> libvorbis_amd.so, mark/cursor bookkeeping unchanged), so on the gated streams below the GPU
-also decides where the short blocks go; and lib/res0.c replaced by integration/res0_vamd.c (partition
-classes and lattice-VQ entries come from libvorbis_amd.so, the reference's _01forward writes their bits).  Driving the unmodified application loop (vorbis_analysis_buffer / _wrote / _blockout /
-vorbis_analysis, examples/encoder_example.c:179-236) through it must yield the very packets the
-pure CPU reference emits -- the strongest parity statement the domain offers: every float and integer
-the GPU produced went through the reference's Huffman/VQ back-end and came out as identical bytes.
+by the binding integration/mapping0_vamd.c (all of mapping0_forward -> one call into libvorbis_amd.so
+that returns the block's packet bytes; for modes whose residue the GPU does not search, the numeric
+section only and the reference's bit-writing half unchanged) and lib/envelope.c replaced by
+integration/envelope_vamd.c (the block-switching detector's steps -> libvorbis_amd.so, mark/cursor
+bookkeeping unchanged), so on the gated streams below the GPU also decides where the short blocks go.
+Driving the unmodified application loop (vorbis_analysis_buffer / _wrote / _blockout / vorbis_analysis,
+examples/encoder_example.c:179-236) through it must yield the very packets the pure CPU reference
+emits -- the strongest parity statement the domain offers: every bit of every packet was produced on
+the GPU and is identical to what the reference's own analysis, Huffman and VQ code writes.
 """
 import numpy as np
 import pytest
@@ -35,7 +36,7 @@ def _stream(ch, seconds, kind, seed):
 @pytest.mark.parametrize("ch,q,kind", [(2, 0.4, "s16"), (2, 0.9, "gated"), (2, 0.1, "gated"), (1, 0.5, "gated")])
 def test_hybrid_encode_emits_reference_packets(ch, q, kind):
     assert hasattr(ref.lib(hybrid=True), "_ve_envelope_search_cpu")  # the detector binding is linked in
-    assert hasattr(ref.lib(hybrid=True), "vamd_res2_forward")        # ... and the residue binding
+    assert hasattr(ref.lib(hybrid=True), "vamd_encode_block")        # ... and packets come from the GPU library
     pcm = _stream(ch, 1.0 if kind == "s16" else 2.0, kind, seed=12345)
     want = ref.RefEncoder(ch, 44100, q).encode_stream(pcm)
     got = ref.RefEncoder(ch, 44100, q, hybrid=True).encode_stream(pcm)

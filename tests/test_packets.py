@@ -1,0 +1,219 @@
+"""Packet assembly on the device: the bit-writing half of mapping0_forward (reference
+lib/mapping0.c:598-606 header bits, lib/floor1.c:833-921 floor1_encode's writes, lib/res0.c:534-640
+_01forward's phrase words and codewords, lib/codebook.c:146-151, oggpack_write); SURVEY.md 8f rank 4.
+
+What pins what:
+  * tests/golden/blocks_*.npz carry, for every fixture block, the packet bytes the reference's real
+    vorbis_analysis() emitted (tools/make_golden.py): the kernel bodies compiled for the host -- CPU
+    suite -- and the HIP library -- GPU suite, per block and batched -- must reproduce them byte for byte;
+  * against the reference compiled in place: every libvorbisenc quality, all four lW/nW flag
+    combinations, silence, bitrate-managed blocks (all fifteen candidate packets);
+  * the capacity bound (vamd_packet_capacity) must hold and a row that is too short must say so.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import vorbis_amd
+from oracle import ref
+from tests import checker, golden_io
+
+ROOT = checker.ROOT
+NAMES = list(checker.SETUPS)
+needs_ref = pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built (needs /root/reference)")
+
+
+def blob_of(name):
+    return np.fromfile(os.path.join(ROOT, "vorbis_amd", "data", "setup_%s.bin" % name), dtype=np.uint8)
+
+
+def block_args(b):
+    return (b["pcm"], b["lW"], b["W"], b["nW"], b["blocktype"], b["ampmax_in"])
+
+
+def random_blocks(e, seed):
+    """(pcm, lW, W, nW): loud / quiet / full-scale / silent / spiky long blocks with every flag pair, two short."""
+    rng = np.random.default_rng(seed)
+    for it, amp in enumerate((0.5, 0.01, 1.0, 0.0, 0.9, 1e-4, 0.7, 0.02)):
+        W = 0 if it >= 6 else 1
+        n = e.blocksize(W)
+        pcm = ((rng.random((e.channels, n), dtype=np.float32) - 0.5) * 2 * amp).astype(np.float32)
+        if it == 4:
+            pcm[:, ::7] *= -1.0
+        yield pcm, (it & 1 if W else 0), W, ((it >> 1) & 1 if W else 0)
+
+
+# ------------------------------------------------------------------------------------------
+# CPU suite
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", NAMES)
+def test_kernel_bodies_match_golden_packets(name):
+    from tests.emul.emul import Emul
+    blocks, _, _ = golden_io.load(name)
+    em = Emul(blob_of(name))
+    sizes = []
+    for b in blocks:
+        g = em.analyze_block(*block_args(b))
+        assert g["packet"] == b["packet"], (b["W"], b["blocktype"])
+        assert (g["packet_bits"] + 7) // 8 == len(b["packet"])
+        assert len(b["packet"]) <= em.L.emul_packet_capacity(em.h, b["W"])
+        sizes.append(len(b["packet"]))
+    assert min(sizes) == 1 and max(sizes) > 100   # silence (header + "no floor" flags only) and real packets
+
+
+@needs_ref
+@pytest.mark.parametrize("ch,quality", [(2, -0.1), (2, 0.1), (2, 0.4), (2, 0.7), (2, 0.9), (2, 1.0), (1, 0.0), (1, 0.5), (1, 1.0)])
+def test_kernel_bodies_match_reference(ch, quality):
+    from tests.emul.emul import Emul
+    e = ref.RefEncoder(ch, 44100, quality)
+    em = Emul(e.pack_setup())
+    seen = 0
+    for pcm, lW, W, nW in random_blocks(e, int(quality * 10) + ch):
+        cap = em.L.emul_packet_capacity(em.h, W)
+        if cap == 0:
+            assert ch == 2 and quality < 0 and W == 1   # 128 residue partitions: that packet stays on the host
+            continue
+        assert cap % 4 == 0
+        a = e.tap_block(pcm, lW, W, nW, 1 if W else 0)
+        assert a["packet_matches_real"]
+        g = em.analyze_block(pcm, lW, W, nW, 1 if W else 0)
+        assert g["packet"] == a["packet"], (W, lW, nW)
+        assert len(a["packet"]) <= cap
+        seen += 1
+    assert seen >= 2
+
+
+@needs_ref
+@pytest.mark.parametrize("ch,rates", [(2, (-1, 128000, -1)), (2, (-1, 64000, -1)), (2, (160000, 96000, 64000)), (1, (-1, 48000, -1))])
+def test_kernel_bodies_match_reference_managed(ch, rates):
+    from tests.emul.emul import Emul
+    e = ref.RefEncoder(ch, 44100, managed=rates)
+    em = Emul(e.pack_setup())
+    for pcm, lW, W, nW in random_blocks(e, rates[1]):
+        a = e.tap_block_managed(pcm, lW, W, nW, 1 if W else 0)
+        assert a["packets_match_real"]
+        g = em.analyze_block_managed(pcm, lW, W, nW, 1 if W else 0)
+        for k in range(15):
+            assert g["m_packets"][k] == a["m_packets"][k], (W, k)
+
+
+@needs_ref
+def test_uncovered_mode_reports_no_capacity():
+    """Coupling switched off: a type-1 residue over two channels, not searched on the GPU -> no device packets."""
+    from tests.emul.emul import Emul
+    em = Emul(ref.RefEncoder(2, 44100, 0.4, coupled=False).pack_setup())
+    assert em.L.emul_packet_capacity(em.h, 0) == 0 and em.L.emul_packet_capacity(em.h, 1) == 0
+
+
+# ------------------------------------------------------------------------------------------
+# GPU suite (through the C ABI)
+# ------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_gpu_encode_block_matches_golden(name):
+    blocks, _, _ = golden_io.load(name)
+    an = vorbis_amd.Analyzer(blob_of(name), 0)
+    for b in blocks:
+        pk, amp = an.encode_block(*block_args(b))
+        assert pk[0] == b["packet"], (b["W"], b["blocktype"])
+        assert np.float32(amp) == np.float32(b["ampmax_out"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_gpu_batch_matches_golden(name):
+    """The fixture blocks of one size class as a batch with per-block lW / nW / blocktype / ampmax arrays."""
+    import torch
+    blocks, _, _ = golden_io.load(name)
+    an = vorbis_amd.Analyzer(blob_of(name), 0)
+    for W in (0, 1):
+        bs = [b for b in blocks if b["W"] == W]
+        if not bs:
+            continue
+        pcm = torch.from_numpy(np.stack([b["pcm"] for b in bs])).cuda()
+        o = an.analyze(pcm, W=W, lW=[b["lW"] for b in bs], nW=[b["nW"] for b in bs],
+                       blocktype=[b["blocktype"] for b in bs], ampmax_in=[b["ampmax_in"] for b in bs],
+                       want=("packets", "packet_bits"))
+        torch.cuda.synchronize()
+        rows, bits = o["packets"].cpu().numpy(), o["packet_bits"].cpu().numpy()
+        for k, b in enumerate(bs):
+            assert vorbis_amd.packet_bytes(rows[k], bits[k]) == b["packet"], (W, k)
+
+
+@pytest.mark.gpu
+@needs_ref
+@pytest.mark.parametrize("ch,quality", [(2, 0.1), (2, 0.4), (2, 1.0), (1, 0.5)])
+def test_gpu_batch_matches_reference(ch, quality):
+    """Larger random batches (packets well past the kernel's LDS ring), residue outputs asked for or not."""
+    import torch
+    e = ref.RefEncoder(ch, 44100, quality)
+    an = vorbis_amd.Analyzer(e.pack_setup(), 0)
+    rng = np.random.default_rng(17)
+    for W, nb in ((1, 40), (0, 24)):
+        n = an.blocksizes[W]
+        amp = np.array([0.5, 0.01, 1.0, 0.0, 0.9])[np.arange(nb) % 5, None, None]
+        pcm = ((rng.random((nb, ch, n), dtype=np.float32) - 0.5) * 2 * amp).astype(np.float32)
+        want = ("packets", "packet_bits") + (("res_class", "res_entries", "res_count") if W else ())
+        o = an.analyze(torch.from_numpy(pcm).cuda(), W=W, lW=W, nW=0, blocktype=1 if W else 0, want=want)
+        torch.cuda.synchronize()
+        rows, bits = o["packets"].cpu().numpy(), o["packet_bits"].cpu().numpy()
+        for k in range(nb):
+            a = e.tap_block(pcm[k], W, W, 0, 1 if W else 0)
+            assert vorbis_amd.packet_bytes(rows[k], bits[k]) == a["packet"], (W, k)
+        assert not W or bits.max() > 8 * 256 * 4 or quality < 0.9   # (the ring holds 1 KB: long q10 packets wrap it)
+
+
+@pytest.mark.gpu
+@needs_ref
+@pytest.mark.parametrize("rates", [(-1, 128000, -1), (-1, 64000, -1)])
+def test_gpu_managed_packets(rates):
+    import torch
+    e = ref.RefEncoder(2, 44100, managed=rates)
+    an = vorbis_amd.Analyzer(e.pack_setup(), 0)
+    blocks = list(random_blocks(e, 5))
+    for pcm, lW, W, nW in blocks:     # per block, host memory (the binding's call)
+        a = e.tap_block_managed(pcm, lW, W, nW, 1 if W else 0)
+        pk, amp = an.encode_block(pcm, lW, W, nW, 1 if W else 0, managed=True)
+        assert pk == a["m_packets"], W
+    longs = [b for b in blocks if b[2] == 1]   # batched
+    o = an.analyze_managed(torch.from_numpy(np.stack([b[0] for b in longs])).cuda(), W=1, lW=[b[1] for b in longs],
+                           nW=[b[3] for b in longs], packets=True)
+    torch.cuda.synchronize()
+    rows, bits = o["m_packets"].cpu().numpy(), o["m_packet_bits"].cpu().numpy()
+    for k, (pcm, lW, W, nW) in enumerate(longs):
+        a = e.tap_block_managed(pcm, lW, W, nW, 1)
+        assert [vorbis_amd.packet_bytes(rows[k, j], bits[k, j]) for j in range(15)] == a["m_packets"], k
+
+
+@pytest.mark.gpu
+def test_gpu_short_rows_and_argument_errors():
+    import torch
+    an = vorbis_amd.Analyzer(blob_of("44k_stereo_q9"), 0)
+    cap = an.packet_capacity(1)
+    assert cap > 0 and cap % 4 == 0 and an.packet_capacity(0) > 0 and an.L.vamd_packet_capacity(None, 1) == 0
+    rng = np.random.default_rng(3)
+    pcm = torch.from_numpy(((rng.random((3, 2, 2048), dtype=np.float32) - 0.5) * 1.6).astype(np.float32)).cuda()
+    full = an.analyze(pcm, want=("packets", "packet_bits"))
+    # a row shorter than the packet: the true length is still reported, the row holds the packet's head,
+    # and nothing is written past the row
+    outs = {"packets": torch.full((3, 256), 0x5A, dtype=torch.uint8, device="cuda"),
+            "packet_bits": torch.zeros(3, dtype=torch.int32, device="cuda")}
+    short = an.analyze(pcm[:, :, :], outs={"packets": outs["packets"][:, :128].contiguous(), "packet_bits": outs["packet_bits"]})
+    torch.cuda.synchronize()
+    assert torch.equal(short["packet_bits"], full["packet_bits"]) and int(full["packet_bits"].min()) > 8 * 128
+    assert torch.equal(short["packets"], full["packets"][:, :128])
+    with pytest.raises(ValueError):
+        vorbis_amd.packet_bytes(short["packets"][0].cpu().numpy(), int(short["packet_bits"][0]))
+    # argument errors
+    with pytest.raises(vorbis_amd.VamdError) as ei:      # the two outputs go together
+        an.analyze(pcm, outs={"packet_bits": outs["packet_bits"]})
+    assert ei.value.code == -131
+    with pytest.raises(vorbis_amd.VamdError) as ei:      # level
+        an.analyze(pcm, level=vorbis_amd.LEVEL_PSY, outs=an.alloc_outputs(1, 3, ("packets", "packet_bits")))
+    assert ei.value.code == -131
+    bad = an.alloc_outputs(1, 3, ("packets", "packet_bits"))
+    bad["packets"] = torch.zeros((3, 130), dtype=torch.uint8, device="cuda")   # stride not a multiple of 4
+    with pytest.raises(vorbis_amd.VamdError) as ei:
+        an.analyze(pcm, outs=bad)
+    assert ei.value.code == -131

@@ -8,8 +8,8 @@ What pins what:
     tests/golden/blocks_*.npz carry both for every fixture block (tools/make_golden.py).
   * oracle/port (sequential restatement) and the kernel bodies compiled for the host must reproduce
     them exactly -- CPU suite; the HIP library must too, per block and batched -- GPU suite.
-  * end to end, tests/test_gpu_dropin.py: the hybrid libvorbis writes its residue bits from these
-    entries (integration/res0_vamd.c) and still emits byte-identical packets.
+  * end to end, tests/test_packets.py / tests/test_gpu_dropin.py: the packets assembled from these
+    entries are byte-identical to the reference's.
 """
 import ctypes as C
 import os

@@ -8,8 +8,8 @@ without a GPU, every compute call raises.
 """
 from .api import (Analyzer, VamdError, load_library, library_path, default_setup_blob, LEVEL_TRANSFORM,
                   LEVEL_PSY, LEVEL_FULL, POSTS_STRIDE, BLOCKTYPE_IMPULSE, BLOCKTYPE_PADDING,
-                  BLOCKTYPE_TRANSITION, BLOCKTYPE_LONG, EXPORTED_SYMBOLS, EnvelopeState, envelope_marks)
+                  BLOCKTYPE_TRANSITION, BLOCKTYPE_LONG, EXPORTED_SYMBOLS, EnvelopeState, envelope_marks, packet_bytes)
 
 __all__ = ["Analyzer", "VamdError", "load_library", "library_path", "default_setup_blob", "LEVEL_TRANSFORM",
            "LEVEL_PSY", "LEVEL_FULL", "POSTS_STRIDE", "BLOCKTYPE_IMPULSE", "BLOCKTYPE_PADDING",
-           "BLOCKTYPE_TRANSITION", "BLOCKTYPE_LONG", "EXPORTED_SYMBOLS", "EnvelopeState", "envelope_marks"]
+           "BLOCKTYPE_TRANSITION", "BLOCKTYPE_LONG", "EXPORTED_SYMBOLS", "EnvelopeState", "envelope_marks", "packet_bytes"]

@@ -17,7 +17,8 @@ EXPORTED_SYMBOLS = ["vamd_create", "vamd_destroy", "vamd_last_error", "vamd_set_
                     "vamd_channels", "vamd_blocksize", "vamd_posts", "vamd_mdct_forward_batch",
                     "vamd_analyze_batch", "vamd_analyze_stream", "vamd_analyze_block", "vamd_profile",
                     "vamd_stage_ms", "vamd_debug_cycles", "vamd_analyze_stream_mixed", "vamd_envelope_search_batch",
-                    "vamd_envelope_search", "vamd_envelope_geometry", "vamd_residue_capacity", "vamd_analyze_block_res", "vamd_analyze_batch_managed", "vamd_analyze_block_managed"]
+                    "vamd_envelope_search", "vamd_envelope_geometry", "vamd_residue_capacity", "vamd_analyze_block_res", "vamd_analyze_batch_managed", "vamd_analyze_block_managed",
+                    "vamd_packet_capacity", "vamd_encode_block"]
 PACKETBLOBS = 15
 
 _vp = C.c_void_p
@@ -35,11 +36,20 @@ RES_CLASS_STRIDE = 64
 
 
 class _IO(C.Structure):
-    _fields_ = [(k, _vp) for k in _IO_FIELDS]
+    _fields_ = [(k, _vp) for k in _IO_FIELDS] + [("packets", _vp), ("packet_bits", _vp), ("packet_stride", C.c_int64)]
 
 
 class _MIO(C.Structure):  # vamd_managed_io
-    _fields_ = [(k, _vp) for k in ("posts", "post_valid", "iwork", "nonzero", "res_class", "res_entries", "res_count")]
+    _fields_ = [(k, _vp) for k in ("posts", "post_valid", "iwork", "nonzero", "res_class", "res_entries", "res_count",
+                                   "packets", "packet_bits")] + [("packet_stride", C.c_int64)]
+
+
+def packet_bytes(row, bits):
+    """A packet as oggpack_get_buffer() / oggpack_bytes() hand it over: the first (bits+7)/8 bytes of its row."""
+    nbytes = (int(bits) + 7) // 8
+    if nbytes > len(row):
+        raise ValueError("packet (%d bits) was cut off at its row length %d" % (bits, len(row)))
+    return bytes(bytearray(row[:nbytes]))
 
 
 class VamdError(RuntimeError):
@@ -90,6 +100,9 @@ def load_library():
     L.vamd_analyze_block_res.argtypes = [_vp, C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_float] + [_vp] * 10
     L.vamd_analyze_batch_managed.argtypes = [_vp, C.POINTER(_Desc), C.POINTER(_IO), C.POINTER(_MIO)]
     L.vamd_analyze_block_managed.argtypes = [_vp, C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_float] + [_vp] * 9
+    L.vamd_packet_capacity.argtypes = [_vp, C.c_int]
+    L.vamd_encode_block.argtypes = [_vp, C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _vp, _vp,
+                                    C.c_long, _vp]
     L.vamd_profile.argtypes = [_vp, C.c_int]
     L.vamd_stage_ms.argtypes = [_vp, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]
     _lib = L
@@ -150,7 +163,7 @@ class Analyzer:
         s = self.torch.cuda.current_stream(self.device)
         self._check(self.L.vamd_set_stream(self.h, _vp(s.cuda_stream)))
 
-    STAGES = ("transform", "ampmax", "noisemask", "tonemask", "floor", "couple", "residue")
+    STAGES = ("transform", "ampmax", "noisemask", "tonemask", "floor", "couple", "residue", "pack")
 
     def profile(self, enable=True):
         self._bind_stream()
@@ -158,9 +171,9 @@ class Analyzer:
 
     def stage_ms(self):
         """(dict stage -> summed ms, number of batches) since the last call; synchronises."""
-        ms = (C.c_float * 7)()
+        ms = (C.c_float * 8)()
         runs = C.c_int(0)
-        self._check(self.L.vamd_stage_ms(self.h, ms, 7, C.byref(runs)))
+        self._check(self.L.vamd_stage_ms(self.h, ms, 8, C.byref(runs)))
         return dict(zip(self.STAGES, [float(x) for x in ms])), runs.value
 
     def debug_cycles(self, enable=True, read=False):
@@ -190,6 +203,8 @@ class Analyzer:
         d.W, d.nblocks = W, nb
 
         def arr(v, dtype, name, uni):
+            if isinstance(v, (list, tuple, np.ndarray)):   # per-block values from the host
+                v = t.as_tensor(np.asarray(v), dtype=dtype).to(self._dev())
             if t.is_tensor(v):
                 assert v.is_cuda and v.dtype == dtype and v.is_contiguous() and v.numel() == nb, name
                 keep.append(v)
@@ -228,6 +243,10 @@ class Analyzer:
                 o[k] = t.zeros((nb, self.residue_capacity(W)), dtype=t.int16, device=dev)  # uint16 payload
             elif k == "res_count":
                 o[k] = t.zeros((nb, 2), dtype=t.int32, device=dev)
+            elif k == "packets":
+                o[k] = t.zeros((nb, self.packet_capacity(W)), dtype=t.uint8, device=dev)
+            elif k == "packet_bits":
+                o[k] = t.zeros((nb,), dtype=t.int32, device=dev)
             else:
                 raise KeyError(k)
         return o
@@ -236,12 +255,18 @@ class Analyzer:
         """Row length of res_entries for size class W; 0 when the GPU does not cover this mode's residue."""
         return int(self.L.vamd_residue_capacity(self.h, W))
 
+    def packet_capacity(self, W):
+        """Bytes the longest possible packet of size class W takes; 0 when packets are not assembled on the GPU."""
+        return int(self.L.vamd_packet_capacity(self.h, W))
+
     def _io(self, pcm, outs):
         io = _IO()
         io.pcm = _vp(pcm.data_ptr())
         for k, v in outs.items():
             assert v.is_cuda and v.is_contiguous()
             setattr(io, k, _vp(v.data_ptr()))
+        if "packets" in outs:
+            io.packet_stride = outs["packets"].shape[-1]
         return io
 
     _DEFAULT_WANT = {LEVEL_TRANSFORM: ("mdct_raw", "logfft", "logmdct", "local_ampmax"),
@@ -346,7 +371,8 @@ class Analyzer:
         return o
 
     # ---- bitrate-managed blocks: fifteen candidate packets each (vamd_analyze_*_managed) ------------
-    def analyze_managed(self, pcm, W=1, lW=1, nW=1, blocktype=BLOCKTYPE_LONG, ampmax_in=-9999.0, residue=False):
+    def analyze_managed(self, pcm, W=1, lW=1, nW=1, blocktype=BLOCKTYPE_LONG, ampmax_in=-9999.0, residue=False,
+                        packets=False):
         """vamd_analyze_batch_managed.  pcm: cuda float32 [nblocks, ch, n].  Returns a dict: shared `mdct`,
         `logmask`, `ampmax_out`, and per candidate `m_posts` [nb,15,ch,32], `m_post_valid` / `m_nonzero`
         [nb,15,ch], `m_iwork` [nb,15,ch,n/2] (+ `m_res_class`, `m_res_entries`, `m_res_count` with residue=True)."""
@@ -366,9 +392,14 @@ class Analyzer:
             mo["res_class"] = t.zeros((nb, PACKETBLOBS, RES_CLASS_STRIDE), dtype=t.int32, device=dev)
             mo["res_entries"] = t.zeros((nb, PACKETBLOBS, self.residue_capacity(W)), dtype=t.int16, device=dev)
             mo["res_count"] = t.zeros((nb, PACKETBLOBS, 2), dtype=t.int32, device=dev)
+        if packets:  # (+ `m_packets` [nb,15,packet_capacity] uint8, `m_packet_bits` [nb,15])
+            mo["packets"] = t.zeros((nb, PACKETBLOBS, self.packet_capacity(W)), dtype=t.uint8, device=dev)
+            mo["packet_bits"] = t.zeros((nb, PACKETBLOBS), dtype=t.int32, device=dev)
         m = _MIO()
         for k, v in mo.items():
             setattr(m, k, _vp(v.data_ptr()))
+        if packets:
+            m.packet_stride = mo["packets"].shape[-1]
         self._bind_stream()
         self._check(self.L.vamd_analyze_batch_managed(self.h, C.byref(d), C.byref(io), C.byref(m)))
         for k, v in mo.items():
@@ -402,6 +433,21 @@ class Analyzer:
             o["m_res_class"] = [rcls[k, :rcnt[k, 0]].copy() for k in range(PACKETBLOBS)]
             o["m_res_entries"] = [rent[k, :rcnt[k, 1]].copy() for k in range(PACKETBLOBS)]
         return o
+
+    def encode_block(self, pcm, lW=1, W=1, nW=1, blocktype=BLOCKTYPE_LONG, ampmax_in=-9999.0, managed=False):
+        """vamd_encode_block: host numpy pcm[ch][n] in; (list of 1 or 15 packets as bytes, ampmax_out) out."""
+        ch, n = self.channels, self.blocksizes[W]
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        assert pcm.shape == (ch, n)
+        ptrs = (_vp * ch)(*[_vp(pcm[i].ctypes.data) for i in range(ch)])
+        nk, cap = (PACKETBLOBS if managed else 1), self.packet_capacity(W)
+        pk, bits = np.zeros((nk, max(cap, 4)), np.uint8), np.zeros(nk, np.int32)
+        amp = C.c_float(0)
+        self._bind_stream()
+        self._check(self.L.vamd_encode_block(self.h, ptrs, lW, W, nW, blocktype, C.c_float(ampmax_in), 1 if managed else 0,
+                                             C.cast(C.byref(amp), _vp), _vp(pk.ctypes.data), C.c_long(pk.shape[1]),
+                                             _vp(bits.ctypes.data)))
+        return [packet_bytes(pk[k], bits[k]) for k in range(nk)], amp.value
 
     # ---- the block-switching detector (vamd_envelope_search*) ---------------------------------
     def envelope_geometry(self):

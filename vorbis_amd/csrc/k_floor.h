@@ -525,6 +525,65 @@ VAMD_DEV int floor_fit_posts(const FloorP &F, const unsigned short *qc, FloorScr
   return 1;
 }
 
+// floor1_encode, value half: quantise by mult, predict, settle the "unused" flags
+// (lib/floor1.c:766-831).  A post keeps its flag iff it is itself trivial (flagged by the fit, or
+// equal to its prediction) and no non-trivial post names it as a neighbour; values by dependency
+// level (a post's neighbours always sit on lower levels).
+//   outp     the posts as fitted, one per lane
+//   post     <- quantised values, bit 15 = unused (then the value is the prediction)
+//   wrapped  <- (optional) out[]: what floor1_encode writes for each post -- posts 0/1 verbatim,
+//               the others' deviation from the prediction folded into [0, range) (:805-824)
+VAMD_DEV void floor_quantise_predict(const FloorP &F, const LaneInts &outp, const LaneInts &postlist, LaneInts &post,
+                                     LaneInts *wrapped) {
+  const int posts = F.posts;
+  LaneInts lo2, hi2, level;
+  lo2.load_shifted(F.loneighbor, 2, posts);
+  hi2.load_shifted(F.hineighbor, 2, posts);
+  level.load(F.level, posts);
+  post.fill(0);
+  WAVE_FOR(i, posts) {
+    const int o = outp.at(i);
+    int val = o & 0x7fff;
+    switch (F.mult) {
+      case 1: val >>= 2; break;
+      case 2: val >>= 3; break;
+      case 3: val /= 12; break;
+      case 4: val >>= 4; break;
+    }
+    post.put(i, val | (o & 0x8000));
+    if (wrapped) wrapped->put(i, i < 2 ? val | (o & 0x8000) : 0);
+  }
+  unsigned long long needed = 3ull;  // posts 0 and 1 are always used
+  for (int L = 1; L <= F.nlevels; L++) {
+    WAVE_FOR(i, posts) {
+      const int ln = lo2.at(i), hn = hi2.at(i);
+      const int x0 = postlist.gather(ln), x1 = postlist.gather(hn), y0 = post.gather(ln), y1 = post.gather(hn);
+      if (i >= 2 && level.at(i) == L) {
+        const int pi = post.at(i);
+        const int predicted = render_point(x0, x1, y0, y1, postlist.at(i));
+        if ((pi & 0x8000) || predicted == pi) {
+          post.put(i, predicted | 0x8000);
+        } else {
+          needed |= (1ull << i) | (1ull << ln) | (1ull << hn);
+          if (wrapped) {
+            const int room = F.quant_q - predicted < predicted ? F.quant_q - predicted : predicted;
+            int val = pi - predicted;
+            if (val < 0)
+              val = val < -room ? room - val - 1 : -1 - (val * 2);
+            else
+              val = val >= room ? val + room : val << 1;
+            wrapped->put(i, val);
+          }
+        }
+      }
+    }
+  }
+  needed = wave_or64(needed);
+  WAVE_FOR(i, posts) {
+    if ((needed >> i) & 1) post.put(i, post.at(i) & 0x7fff);
+  }
+}
+
 // The curve half of floor1_encode for one set of posts (lib/floor1.c:766-831,923-952): quantise,
 // predict, settle the unused flags, render the integer curve.
 //   outp / valid  a floor1_fit result (floor_fit_posts) or an interpolation of two
@@ -543,13 +602,9 @@ VAMD_DEV int floor_encode_render(const FloorP &F, int n2, const LaneInts &outp, 
     WAVE_SYNC();
     return 0;
   }
-  LaneInts postlist, forward_index, lo2, hi2, level, post;
+  LaneInts postlist, forward_index, post;
   postlist.load(F.postlist, posts);
   forward_index.load(F.forward_index, posts);
-  lo2.load_shifted(F.loneighbor, 2, posts);
-  hi2.load_shifted(F.hineighbor, 2, posts);
-  level.load(F.level, posts);
-  post.fill(0);
 #if VAMD_GPU
   if (posts_out && LANE < VAMD_POSTS_STRIDE) posts_out[LANE] = LANE < posts ? outp.mine() : 0;
 #else
@@ -557,42 +612,7 @@ VAMD_DEV int floor_encode_render(const FloorP &F, int n2, const LaneInts &outp, 
     if (posts_out) posts_out[i] = i < posts ? outp.get(i) : 0;
 #endif
   if (post_valid && LANE == 0) *post_valid = 1;
-
-  // ---- floor1_encode, value half: quantise by mult, predict, settle the
-  // "unused" flags (lib/floor1.c:766-831).  The Huffman writes stay on the host.
-  // A post keeps its flag iff it is itself trivial (flagged by the fit, or equal to its
-  // prediction) and no non-trivial post names it as a neighbour; values again by level.
-  WAVE_FOR(i, posts) {
-    const int o = outp.at(i);
-    int val = o & 0x7fff;
-    switch (F.mult) {
-      case 1: val >>= 2; break;
-      case 2: val >>= 3; break;
-      case 3: val /= 12; break;
-      case 4: val >>= 4; break;
-    }
-    post.put(i, val | (o & 0x8000));
-  }
-  unsigned long long needed = 3ull;  // posts 0 and 1 are always used
-  for (int L = 1; L <= F.nlevels; L++) {
-    WAVE_FOR(i, posts) {
-      const int ln = lo2.at(i), hn = hi2.at(i);
-      const int x0 = postlist.gather(ln), x1 = postlist.gather(hn), y0 = post.gather(ln), y1 = post.gather(hn);
-      if (i >= 2 && level.at(i) == L) {
-        const int pi = post.at(i);
-        const int predicted = render_point(x0, x1, y0, y1, postlist.at(i));
-        if ((pi & 0x8000) || predicted == pi) {
-          post.put(i, predicted | 0x8000);
-        } else {
-          needed |= (1ull << i) | (1ull << ln) | (1ull << hn);
-        }
-      }
-    }
-  }
-  needed = wave_or64(needed);
-  WAVE_FOR(i, posts) {
-    if ((needed >> i) & 1) post.put(i, post.at(i) & 0x7fff);
-  }
+  floor_quantise_predict(F, outp, postlist, post, nullptr);
 
   // ---- render the integer curve, lib/floor1.c:923-946: segment list of the
   // used posts in x order, then every bin evaluates its segment's line.

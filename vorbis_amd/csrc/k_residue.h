@@ -83,6 +83,34 @@ VAMD_DEV int residue_besterror(const ResP &R, const vamd_book_tab &bk, int *a) {
   return index;
 }
 
+// Emission offsets of a block's codebook entries, (stage, partition) order, from the partition
+// classes: off[s*partvals + i] = entries written before partition i's stage-s vectors,
+// off[stages*partvals] = the total (returned); `info` keeps each pair's book (-1 = the class skips
+// the stage) so that nothing downstream goes back to the class tables.  cls/off/info in LDS.
+VAMD_DEV int residue_offsets(const ResP &R, int partvals, const int *cls, int *off, int *info) {
+  const vamd_residue_tab &t = *R.tab;
+  const int spp = t.grouping, items = t.stages * partvals;
+  WAVE_FOR(it, items) {
+    const int s = it / partvals, i = it - s * partvals;
+    const int c = cls[i];
+    const int bn = ((t.secondstages[c] >> s) & 1) ? t.partbooks[c][s] : -1;
+    info[it] = bn;
+    off[it] = bn >= 0 ? spp / R.books[bn].dim : 0;
+  }
+  WAVE_SYNC();
+  int carry = 0;  // exclusive prefix sum over the <= 8 x 64 counts, a wave-width at a time
+  for (int base = 0; base < items; base += NLANES) {
+    const int it = base + LANE;
+    const int c = it < items ? off[it] : 0;
+    const int incl = wave_scan_sum(c);
+    if (it < items) off[it] = carry + incl - c;
+    carry += wave_last(incl);
+  }
+  if (LANE == 0) off[items] = carry;
+  WAVE_SYNC();
+  return carry;
+}
+
 //   iwork[c]   HBM [n2]   quantised (and coupled) residue of channel c
 //   work       LDS [ch*n2]; cls LDS [partvals]; off LDS [stages*partvals + 1]; info LDS [stages*partvals]
 //   class_out  HBM [VAMD_RES_CLASS_STRIDE]; entries_out HBM [R.cap]; count_out HBM [2] = {partvals, entries}
@@ -142,33 +170,11 @@ VAMD_DEV void residue2_block(const ResP &R, int ch, int n2, const int *const *iw
     class_out[i] = j;
   }
   WAVE_SYNC();
-  // emission offsets, (stage, partition) order; `info` keeps each pair's book so that the search
-  // below never goes back to the class tables
-  const int items = stages * partvals;
-  WAVE_FOR(it, items) {
-    const int s = it / partvals, i = it - s * partvals;
-    const int c = cls[i];
-    const int bn = ((t.secondstages[c] >> s) & 1) ? t.partbooks[c][s] : -1;
-    info[it] = bn;
-    off[it] = bn >= 0 ? spp / R.books[bn].dim : 0;
+  const int carry = residue_offsets(R, partvals, cls, off, info);
+  if (LANE == 0) {
+    count_out[0] = partvals;
+    count_out[1] = carry;
   }
-  WAVE_SYNC();
-  {  // exclusive prefix sum over the <= 8 x 64 counts, a wave-width at a time
-    int carry = 0;
-    for (int base = 0; base < items; base += NLANES) {
-      const int it = base + LANE;
-      const int c = it < items ? off[it] : 0;
-      const int incl = wave_scan_sum(c);
-      if (it < items) off[it] = carry + incl - c;
-      carry += wave_last(incl);
-    }
-    if (LANE == 0) {
-      off[items] = carry;
-      count_out[0] = partvals;
-      count_out[1] = carry;
-    }
-  }
-  WAVE_SYNC();
   pc.mark(0);
   // the search, stage by stage (_01forward's s loop outermost, :585).  A stage's vectors are
   // numbered densely (its slice of the emission order), so every lane has one to search.

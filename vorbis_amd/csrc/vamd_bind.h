@@ -4,6 +4,7 @@
 #pragma once
 #include <stddef.h>
 #include <string.h>
+#include <algorithm>
 #include <string>
 #include <vector>
 #include "vamd_derive.h"
@@ -24,6 +25,7 @@ struct Bound {
   CoupleSet couple_all[2];
   EnvP env;
   ResP res[2];
+  PackP pack[2];
   int res_stages[2], res_partvals[2];
   float ampmax_att_per_sec;
 };
@@ -143,13 +145,38 @@ inline int build_image(const void *blob_v, size_t bytes, std::vector<unsigned ch
   for (int i = 0; i < h.nbooks; i++) {
     vamd_book_tab bk;
     memcpy(&bk, blob + h.off_books + (size_t)i * sizeof(bk), sizeof(bk));
-    if (bk.dim < 1 || bk.entries < 0 || (uint64_t)bk.off_lengths + (uint64_t)bk.entries > h.total_bytes) {
+    if (bk.dim < 1 || bk.entries < 0 || (uint64_t)bk.off_lengths + (uint64_t)bk.entries > h.total_bytes ||
+        (bk.off_codes & 3) || (uint64_t)bk.off_codes + 4 * (uint64_t)bk.entries > h.total_bytes) {
       *err = "setup blob: codebook out of range";
+      return VAMD_EINVAL;
+    }
+  }
+  if (h.modebits < 0 || h.modebits > 8) {
+    *err = "setup blob: mode number width out of range";
+    return VAMD_EINVAL;
+  }
+  for (int W = 0; W < 2; W++) {
+    const vamd_floor1_tab &f = h.mode[W].floor;
+    int covered = 2;
+    bool ok = f.partitions >= 0 && f.partitions <= VAMD_FLOOR_PARTS;
+    for (int i = 0; ok && i < f.partitions; i++) {
+      const int c = f.partitionclass[i];
+      ok = c >= 0 && c < VAMD_FLOOR_CLASSES && f.class_dim[c] >= 1 && f.class_dim[c] <= 8 && f.class_subs[c] >= 0 &&
+           f.class_subs[c] <= 3 && f.class_book[c] < h.nbooks && (f.class_subs[c] == 0 || f.class_book[c] >= 0);
+      for (int k = 0; ok && k < 8; k++) ok = f.class_subbook[c][k] < h.nbooks;
+      if (ok) covered += f.class_dim[c];
+    }
+    if (!ok || covered != f.posts) {
+      *err = "setup blob: floor1 partition tables out of range";
       return VAMD_EINVAL;
     }
   }
   for (int W = 0; W < 2; W++) {
     const vamd_residue_tab &r = h.res[W];
+    if (r.groupbook < 0 || r.groupbook >= h.nbooks || r.groupbook_dim < 1) {
+      *err = "setup blob: residue phrase book out of range";
+      return VAMD_EINVAL;
+    }
     if (r.partitions < 1 || r.partitions > VAMD_RES_MAXCLASS || r.stages < 0 || r.stages > VAMD_RES_MAXSTAGE ||
         r.grouping < 1 || r.begin < 0 || r.end < r.begin) {
       *err = "setup blob: residue table out of range";
@@ -342,6 +369,47 @@ inline void bind_params(const std::vector<unsigned char> &image, const std::vect
     B->res_partvals[W] = (r.end - r.begin) / r.grouping;
     Rp.covered = ok ? 1 : 0;
     Rp.cap = ok ? worst * ((r.end - r.begin) / r.grouping) : 0;
+
+    // packet assembly: the longest packet this size class can produce, field by field
+    PackP &K = B->pack[W];
+    const vamd_floor1_tab &f = h.mode[W].floor;
+    K.ftab = (const vamd_floor1_tab *)(base + offsetof(vamd_setup_header, mode) + sizeof(vamd_mode_tab) * W +
+                                       offsetof(vamd_mode_tab, floor));
+    K.books = Rp.books;
+    K.base = base;
+    K.modebits = h.modebits;
+    K.qbits = 0;
+    for (unsigned v = f.quant_q > 0 ? (unsigned)(f.quant_q - 1) : 0; v; v >>= 1) K.qbits++;  // ov_ilog
+    auto longest = [&](int bn) {
+      int m = 0;
+      if (bn < 0) return 0;
+      const signed char *len = (const signed char *)(image.data() + hb[bn].off_lengths);
+      for (int e = 0; e < hb[bn].entries; e++)
+        if (len[e] > m) m = len[e];
+      return m;
+    };
+    long bits = 1 + K.modebits + 2;
+    long fl = 1 + 2 * K.qbits;
+    for (int i = 0; i < f.partitions; i++) {
+      const int c = f.partitionclass[i];
+      int sub = 0;
+      for (int k = 0; k < (1 << f.class_subs[c]); k++) sub = std::max(sub, longest(f.class_subbook[c][k]));
+      fl += (f.class_subs[c] ? longest(f.class_book[c]) : 0) + f.class_dim[c] * sub;
+    }
+    bits += fl * h.channels;
+    if (ok) {
+      const int partvals = (r.end - r.begin) / r.grouping;
+      long per_part = 0;
+      for (int c = 0; c < r.partitions; c++) {
+        long per = 0;
+        for (int s = 0; s < r.stages; s++)
+          if (((r.secondstages[c] >> s) & 1) && r.partbooks[c][s] >= 0)
+            per += (long)(r.grouping / hb[r.partbooks[c][s]].dim) * longest(r.partbooks[c][s]);
+        per_part = std::max(per_part, per);
+      }
+      bits += per_part * partvals + (long)((partvals + r.groupbook_dim - 1) / r.groupbook_dim) * longest(r.groupbook);
+    }
+    K.capacity = ok ? (int)(((bits + 31) / 32) * 4) : 0;
   }
   for (int p = 0; p < 4; p++) {
     const vamd_psy_tab &t = h.psy[p];

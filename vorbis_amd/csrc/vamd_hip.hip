@@ -28,6 +28,7 @@
 #include "k_couple.h"
 #include "k_envelope.h"
 #include "k_residue.h"
+#include "k_pack.h"
 
 using namespace vamd;
 
@@ -413,6 +414,24 @@ __global__ __launch_bounds__(64) void k_residue(ResP R, DescP d, int ch, int n2,
   pc.flush();
 }
 
+// stage 7 (optional): packet assembly, one wave per packet (k_pack.h).  unit = block * nblobs + candidate
+__global__ __launch_bounds__(64) void k_pack(PackP K, FloorP F, ResP R, DescP d, int ch, int W, int nblobs,
+                                             const int *__restrict__ posts, const int *__restrict__ post_valid,
+                                             const int *__restrict__ res_class,
+                                             const unsigned short *__restrict__ res_entries,
+                                             const int *__restrict__ res_count, unsigned *__restrict__ packets,
+                                             int stride_words, int *__restrict__ packet_bits) {
+  const long u = blockIdx.x, blk = u / nblobs;
+  int *ring = (int *)vamd_smem;                  // [VAMD_PK_RING]
+  int *outv = ring + VAMD_PK_RING;               // [VAMD_POSTS_STRIDE]
+  int *cls = outv + VAMD_POSTS_STRIDE;           // [VAMD_RES_CLASS_STRIDE]
+  int *off = cls + VAMD_RES_CLASS_STRIDE;        // [stages*partvals + 1], then info [stages*partvals]
+  int *info = off + (R.tab->stages * ((R.tab->end - R.tab->begin) / R.tab->grouping) + 1);
+  pack_block(K, F, R, ch, W, d_lW(d, blk), d_nW(d, blk), posts + u * ch * VAMD_POSTS_STRIDE, post_valid + u * ch,
+             res_class + u * VAMD_RES_CLASS_STRIDE, res_entries + u * (long)R.cap, res_count + u * 2, ring, outv, cls, off,
+             info, packets + u * (long)stride_words, stride_words, packet_bits + u);
+}
+
 // ---------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------
@@ -532,7 +551,8 @@ struct vamd_ctx {
   // workspace, grown on demand (vamd_reserve to pre-size)
   enum { WS_MDCT_RAW, WS_LOGMDCT, WS_LOGFFT, WS_NOISE, WS_TONE, WS_MDCT, WS_ILOGMASK, WS_IWORK, WS_POSTS, WS_POSTVALID,
          WS_NONZERO, WS_LOCAL, WS_AMPIN, WS_AMPGLOB, WS_PCM, WS_SEED, WS_SURV, WS_NSURV, WS_MISC,
-         WS_ENV_NEAR, WS_ENV_RAW, WS_ENV_AMP, WS_ENV_BITS, WS_ENV_STAGE, WS_M_ILOGMASK, WS_M_STAGE, WS_COUNT };
+         WS_ENV_NEAR, WS_ENV_RAW, WS_ENV_AMP, WS_ENV_BITS, WS_ENV_STAGE, WS_M_ILOGMASK, WS_M_STAGE,
+         WS_RES_CLASS, WS_RES_ENTRIES, WS_RES_COUNT, WS_COUNT };
   DevBuf ws[2][WS_COUNT];  // per size class (a mixed stream keeps both batches in flight)
   // pinned staging for the per-block host API
   void *h_stage = nullptr;
@@ -810,14 +830,44 @@ static int check_desc(vamd_ctx *c, const vamd_batch_desc *d, const vamd_batch_io
 }
 
 // ---- the launch sequence ---------------------------------------------------------
+// the residue search's outputs: the caller's buffers, or workspace when only the packets are wanted
+struct ResBufs {
+  int32_t *cls;
+  uint16_t *entries;
+  int32_t *count;
+};
 struct BatchRun {
   int W;
   long nb;
   WsPlan p;
   DescP d;
   const vamd_batch_io *io;
+  ResBufs rb;
   int nst;  // stages launched (for vamd_profile)
 };
+
+static int check_packets(vamd_ctx *c, int W, int level, const void *packets, const void *bits, int64_t stride) {
+  if (!(packets && bits)) return fail(c, VAMD_EINVAL, "packets / packet_bits go together");
+  if (level < VAMD_LEVEL_FULL) return fail(c, VAMD_EINVAL, "packet outputs need level FULL");
+  if (stride < 4 || (stride & 3) || stride > 0x7fffffffL) return fail(c, VAMD_EINVAL, "packet_stride must be a positive multiple of 4");
+  if ((W != 0 && W != 1) || c->B.pack[W].capacity == 0)
+    return fail(c, VAMD_EIMPL, "this mode's packets are not assembled on the GPU (its residue back-end is not covered)");
+  return VAMD_OK;
+}
+
+static int res_bufs(vamd_ctx *c, int W, long units, int32_t *cls, uint16_t *entries, int32_t *count, ResBufs *o) {
+  o->cls = cls, o->entries = entries, o->count = count;
+  if (entries) return VAMD_OK;
+  void *v;
+  int r;
+  if ((r = ws_get(c, W, vamd_ctx::WS_RES_CLASS, (size_t)units * VAMD_RES_CLASS_STRIDE * 4, &v))) return r;
+  o->cls = (int32_t *)v;
+  if ((r = ws_get(c, W, vamd_ctx::WS_RES_ENTRIES, (size_t)units * c->B.res[W].cap * 2, &v))) return r;
+  o->entries = (uint16_t *)v;
+  if ((r = ws_get(c, W, vamd_ctx::WS_RES_COUNT, (size_t)units * 8, &v))) return r;
+  o->count = (int32_t *)v;
+  return VAMD_OK;
+}
 
 static int prepare_run(vamd_ctx *c, const vamd_batch_desc *desc, const vamd_batch_io *io, int level, BatchRun *R) {
   memset(R, 0, sizeof(*R));
@@ -827,12 +877,19 @@ static int prepare_run(vamd_ctx *c, const vamd_batch_desc *desc, const vamd_batc
     if ((desc->W != 0 && desc->W != 1) || !c->B.res[desc->W].covered)
       return fail(c, VAMD_EIMPL, "this mode's residue back-end is not covered on the GPU (type 2 stereo, type 1 mono)");
   }
+  if (io && (io->packets || io->packet_bits)) {
+    int r = check_packets(c, desc->W, level, io->packets, io->packet_bits, io->packet_stride);
+    if (r) return r;
+  }
   R->W = desc->W;
   R->nb = desc->nblocks;
   R->io = io;
   if (R->nb == 0) return VAMD_OK;
   int r = plan(c, R->W, R->nb, io, level, &R->p);
   if (r) return r;
+  if (io && level >= VAMD_LEVEL_FULL && (io->res_entries || io->packets) &&
+      (r = res_bufs(c, R->W, R->nb, io->res_class, io->res_entries, io->res_count, &R->rb)))
+    return r;
   DescP &d = R->d;
   d.lW = desc->lW;
   d.nW = desc->nW;
@@ -862,8 +919,13 @@ static void launch_transform(vamd_ctx *c, BatchRun *R) {
 }
 
 // stages 2..5 (masking, floor, couple); R->d.ampmax_in / p.ampglob must be final
+static size_t pack_lds_bytes(int stages, int partvals) {
+  return ((size_t)VAMD_PK_RING + VAMD_POSTS_STRIDE + VAMD_RES_CLASS_STRIDE + 2 * (size_t)stages * partvals + 1) * 4;
+}
+
 static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_io *M = nullptr, int *m_ilogmask = nullptr) {
   if (R->nb == 0) return;
+  const ResBufs &rb = R->rb;
   const int W = R->W, ch = c->B.channels;
   const WsPlan &p = R->p;
   const DescP &d = R->d;
@@ -919,13 +981,19 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_
     hipLaunchKernelGGL(k_couple, dim3(gb * VAMD_PACKETBLOBS), dim3(64), (norm0 || norm1) ? (size_t)n2 * 12 : 0, s, P0, P1,
                        c->B.couple_all[W], 0, VAMD_PACKETBLOBS, d, p.mdct, m_ilogmask, M->iwork, M->nonzero);
     prof_mark(c), R->nst++;
-    if (M->res_entries) {
+    if (M->res_entries || M->packets) {
       const ResP &Rp = c->B.res[W];
       const int stages = c->B.res_stages[W], partvals = c->B.res_partvals[W];
       const size_t lds = ((size_t)ch * n2 + VAMD_RES_CLASS_STRIDE + 2 * (size_t)stages * partvals + 1) * 4;
       hipLaunchKernelGGL(k_residue, dim3(gb * VAMD_PACKETBLOBS), dim3(64), lds, s, Rp, d, ch, n2, M->iwork, M->nonzero,
-                         M->res_class, M->res_entries, M->res_count);
+                         rb.cls, rb.entries, rb.count);
       prof_mark(c), R->nst++;
+      if (M->packets) {
+        hipLaunchKernelGGL(k_pack, dim3(gb * VAMD_PACKETBLOBS), dim3(64), pack_lds_bytes(stages, partvals), s, c->B.pack[W],
+                           c->B.floor[W], Rp, d, ch, W, VAMD_PACKETBLOBS, M->posts, M->post_valid, rb.cls, rb.entries, rb.count,
+                           (unsigned *)M->packets, (int)(M->packet_stride / 4), M->packet_bits);
+        prof_mark(c), R->nst++;
+      }
     }
   } else if (level >= VAMD_LEVEL_FULL) {
     hipLaunchKernelGGL(k_floor, dim3(gcb), dim3(64), (size_t)((n2 + 15) & ~15) * 2 + sizeof(FloorScratch), s, P0, P1, c->B.floor[W],
@@ -935,7 +1003,7 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_
     // the LDS arrays serve noise normalisation's sort only (lib/psy.c:941-1010); without it the
     // stage is register-only and the CU holds twice as many of its waves
     const bool norm0 = P0.normal_p && P0.normal_start < n2, norm1 = P1.normal_p && P1.normal_start < n2;
-    const bool want_res = R->io && R->io->res_entries;
+    const bool want_res = R->io && (R->io->res_entries || R->io->packets);
     hipLaunchKernelGGL(k_couple, dim3(gb), dim3(64), (norm0 || norm1) ? (size_t)n2 * 12 : 0, s, P0, P1, c->B.couple_all[W], VAMD_PACKETBLOBS / 2, 1, d, p.mdct, p.ilogmask,
                        p.iwork, p.nonzero);
     prof_mark(c), R->nst++;
@@ -943,9 +1011,15 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_
       const ResP &Rp = c->B.res[W];
       const int stages = c->B.res_stages[W], partvals = c->B.res_partvals[W];
       const size_t lds = ((size_t)ch * n2 + VAMD_RES_CLASS_STRIDE + 2 * (size_t)stages * partvals + 1) * 4;
-      hipLaunchKernelGGL(k_residue, dim3(gb), dim3(64), lds, s, Rp, d, ch, n2, p.iwork, p.nonzero, R->io->res_class,
-                         R->io->res_entries, R->io->res_count);
+      hipLaunchKernelGGL(k_residue, dim3(gb), dim3(64), lds, s, Rp, d, ch, n2, p.iwork, p.nonzero, rb.cls, rb.entries,
+                         rb.count);
       prof_mark(c), R->nst++;
+      if (R->io->packets) {
+        hipLaunchKernelGGL(k_pack, dim3(gb), dim3(64), pack_lds_bytes(stages, partvals), s, c->B.pack[W], c->B.floor[W], Rp, d,
+                           ch, W, 1, p.posts, p.post_valid, rb.cls, rb.entries, rb.count, (unsigned *)R->io->packets,
+                           (int)(R->io->packet_stride / 4), R->io->packet_bits);
+        prof_mark(c), R->nst++;
+      }
     }
   }
 }
@@ -963,6 +1037,9 @@ static int run_batch(vamd_ctx *c, const vamd_batch_desc *desc, const vamd_batch_
                (size_t)R.nb * VAMD_PACKETBLOBS * c->B.channels * (c->B.bs[R.W] / 2) * 4, &v);
     if (r) return r;
     m_ilogmask = (int *)v;
+    if ((M->res_entries || M->packets) &&
+        (r = res_bufs(c, R.W, R.nb * VAMD_PACKETBLOBS, M->res_class, M->res_entries, M->res_count, &R.rb)))
+      return r;
   }
   const int ch = c->B.channels;
   hipStream_t s = c->stream;
@@ -1007,7 +1084,12 @@ int vamd_analyze_batch_managed(vamd_ctx *c, const vamd_batch_desc *desc, const v
     if (!c->B.res[desc->W].covered)
       return fail(c, VAMD_EIMPL, "this mode's residue back-end is not covered on the GPU (type 2 stereo, type 1 mono)");
   }
+  if ((m->packets || m->packet_bits) &&
+      (r = check_packets(c, desc->W, VAMD_LEVEL_FULL, m->packets, m->packet_bits, m->packet_stride)))
+    return r;
   vamd_batch_io shared = *io;  // per-candidate fields of the VBR io do not apply
+  shared.packets = nullptr;
+  shared.packet_bits = nullptr;
   shared.posts = shared.post_valid = shared.ilogmask = shared.iwork = shared.nonzero = nullptr;
   shared.res_class = nullptr;
   shared.res_entries = nullptr;
@@ -1217,6 +1299,86 @@ int vamd_analyze_block_res(vamd_ctx *c, const float *const *pcm, int lW, int W, 
     if (res_count) memcpy(res_count, cnt, 8);
     if (res_class) memcpy(res_class, hs + o_rcls, VAMD_RES_CLASS_STRIDE * 4);
     if (res_entries) memcpy(res_entries, hs + o_rent, (size_t)(cnt[1] < (int)rcap ? cnt[1] : (int)rcap) * 2);
+  }
+  return VAMD_OK;
+}
+
+int vamd_packet_capacity(const vamd_ctx *c, int W) {
+  if (!c || (W != 0 && W != 1)) return 0;
+  return c->B.pack[W].capacity;
+}
+
+int vamd_encode_block(vamd_ctx *c, const float *const *pcm, int lW, int W, int nW, int blocktype, float ampmax_in,
+                      int managed, float *ampmax_out, uint8_t *packets, long packet_stride, int32_t *packet_bits) {
+  if (!c) return VAMD_EINVAL;
+  if (!pcm || (W != 0 && W != 1)) return fail(c, VAMD_EINVAL, "bad pcm / W");
+  if (!packets || !packet_bits) return fail(c, VAMD_EINVAL, "null packets / packet_bits");
+  const size_t cap = (size_t)c->B.pack[W].capacity;
+  if (cap == 0)
+    return fail(c, VAMD_EIMPL, "this mode's packets are not assembled on the GPU (its residue back-end is not covered)");
+  if (packet_stride < 4) return fail(c, VAMD_EINVAL, "packet_stride too small");
+  const size_t ch = c->B.channels, n = c->B.bs[W], n2 = n / 2, K = managed ? VAMD_PACKETBLOBS : 1;
+  const size_t row = cap < (size_t)packet_stride ? cap : ((size_t)packet_stride & ~(size_t)3);  // device row length
+  auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
+  // one pinned + one device arena: [pcm | ampmax | bits | packets || the managed candidates' intermediates]
+  const size_t o_pcm = 0, o_amp = al(ch * n * 4), o_bits = o_amp + 16, o_pk = al(o_bits + K * 4), o_back = al(o_pk + K * row),
+               o_posts = o_back, o_valid = al(o_posts + K * ch * VAMD_POSTS_STRIDE * 4), o_nz = al(o_valid + K * ch * 4),
+               o_iwork = al(o_nz + K * ch * 4), total = managed ? al(o_iwork + K * ch * n2 * 4) : o_back;
+  if (c->h_stage_bytes < o_back) {
+    if (c->h_stage) HIP_TRY(c, hipHostFree(c->h_stage));
+    c->h_stage = nullptr;
+    c->h_stage_bytes = 0;
+    HIP_TRY(c, hipHostMalloc(&c->h_stage, o_back, hipHostMallocDefault));
+    c->h_stage_bytes = o_back;
+  }
+  void *dv;
+  int r = ws_get(c, W, managed ? vamd_ctx::WS_M_STAGE : vamd_ctx::WS_PCM, total, &dv);
+  if (r) return r;
+  unsigned char *hs = (unsigned char *)c->h_stage, *ds = (unsigned char *)dv;
+  for (size_t i = 0; i < ch; i++) {
+    if (!pcm[i]) return fail(c, VAMD_EINVAL, "null channel pointer");
+    memcpy(hs + o_pcm + i * n * 4, pcm[i], n * 4);
+  }
+  hipStream_t s = c->stream;
+  HIP_TRY(c, hipMemcpyAsync(ds + o_pcm, hs + o_pcm, ch * n * 4, hipMemcpyHostToDevice, s));
+  vamd_batch_desc d;
+  memset(&d, 0, sizeof(d));
+  d.W = W;
+  d.nblocks = 1;
+  d.uniform_lW = lW;
+  d.uniform_nW = nW;
+  d.uniform_blocktype = blocktype;
+  d.uniform_ampmax_in = ampmax_in;
+  vamd_batch_io io;
+  memset(&io, 0, sizeof(io));
+  io.pcm = (const float *)(ds + o_pcm);
+  io.ampmax_out = (float *)(ds + o_amp);
+  if (managed) {
+    vamd_managed_io m;
+    memset(&m, 0, sizeof(m));
+    m.posts = (int32_t *)(ds + o_posts);
+    m.post_valid = (int32_t *)(ds + o_valid);
+    m.nonzero = (int32_t *)(ds + o_nz);
+    m.iwork = (int32_t *)(ds + o_iwork);
+    m.packets = ds + o_pk;
+    m.packet_bits = (int32_t *)(ds + o_bits);
+    m.packet_stride = (int64_t)row;
+    r = vamd_analyze_batch_managed(c, &d, &io, &m);
+  } else {
+    io.packets = ds + o_pk;
+    io.packet_bits = (int32_t *)(ds + o_bits);
+    io.packet_stride = (int64_t)row;
+    r = vamd_analyze_batch(c, &d, &io, VAMD_LEVEL_FULL);
+  }
+  if (r) return r;
+  HIP_TRY(c, hipMemcpyAsync(hs + o_amp, ds + o_amp, o_back - o_amp, hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  if (ampmax_out) memcpy(ampmax_out, hs + o_amp, 4);
+  memcpy(packet_bits, hs + o_bits, K * 4);
+  for (size_t k = 0; k < K; k++) {
+    size_t bytes = ((size_t)(packet_bits[k] > 0 ? packet_bits[k] : 0) + 7) / 8;
+    if (bytes > row) bytes = row;  // (cut off: packet_bits says so)
+    memcpy(packets + k * (size_t)packet_stride, hs + o_pk + k * row, bytes);
   }
   return VAMD_OK;
 }

@@ -79,6 +79,16 @@ struct ResP {
   int covered;                // 1 when the GPU handles this mode's residue (type 2, 2 channels)
 };
 
+// packet assembly (k_pack.h): the floor's class tables and the codebooks' codewords, in the HBM image
+struct PackP {
+  const vamd_floor1_tab *ftab;
+  const vamd_book_tab *books;
+  const unsigned char *base;
+  int modebits;   // width of the mode number
+  int qbits;      // ilog(quant_q - 1): width of the two end posts
+  int capacity;   // bytes the largest packet of this size class can take (multiple of 4); 0 = not assembled here
+};
+
 struct FloorP {
   int posts, look_n, quant_q, mult;
   float maxover, maxunder, maxerr, twofitweight, twofitatten;
