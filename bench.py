@@ -124,7 +124,8 @@ def cpu_baseline(setup_name, seconds):
 
 def neighbour_stages(an, pcm, outs, nb):
     """Outside the timed region and outside the metric: throughput of the analysis with the residue
-    back-end's search enabled, and of the block-switching detector on a slice of the same samples."""
+    back-end's search enabled, of the whole block encode (PCM in, packets out), and of the block-switching
+    detector on a slice of the same samples."""
     import vorbis_amd
     res = dict(outs)
     res.update(an.alloc_outputs(1, nb, ("res_class", "res_entries", "res_count")))
@@ -137,6 +138,17 @@ def neighbour_stages(an, pcm, outs, nb):
     with_res = 3 * nb / (time.perf_counter() - t0)
     entries = float(res["res_count"][:, 1].float().mean().item())
     del res
+    # PCM in, finished packets out (residue search + packet assembly; intermediate tensors internal)
+    pk = an.alloc_outputs(1, nb, ("ampmax_out", "packets", "packet_bits"))
+    an.analyze(pcm, outs=pk)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        an.analyze(pcm, outs=pk)
+    torch.cuda.synchronize()
+    to_packets = 3 * nb / (time.perf_counter() - t0)
+    packet_bytes = float(pk["packet_bits"].float().mean().item()) / 8
+    del pk
     ns = 256
     streams = pcm[: ns * 64].reshape(ns, 64, pcm.shape[1], pcm.shape[2]).permute(0, 2, 1, 3).reshape(ns, pcm.shape[1], -1)
     streams = streams.contiguous()                      # 256 streams of 64 blocks' samples
@@ -151,6 +163,7 @@ def neighbour_stages(an, pcm, outs, nb):
     torch.cuda.synchronize()
     det = 3 * ns * steps / (time.perf_counter() - t0)
     return {"analysis_with_residue_search": {"value": with_res, "unit": "stereo blocks/s", "mean_entries_per_block": entries},
+            "pcm_to_packets": {"value": to_packets, "unit": "stereo blocks/s", "mean_packet_bytes": packet_bytes},
             "block_switching_detector": {"value": det, "unit": "stereo detector steps/s (one per 64 samples)",
                                          "streams": ns, "steps_per_stream": int(steps)}}
 
