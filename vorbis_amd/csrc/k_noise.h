@@ -12,12 +12,16 @@
 // of the window loops depend only on the static bark[] table and are
 // precomputed by vamd_create().
 //
-// LDS: S[5][n+4] running sums only; the noise curve and work vector stay in registers.
+// LDS: S[5][VAMD_NZ_STRIDE(n)] running sums only; the noise curve and work vector stay in registers.
 #pragma once
 #include "vamd_wave.h"
 #include "vamd_params.h"
 
 namespace vamd {
+
+// floats between a block's five running-sum arrays in LDS: n plus a stagger of 16, which puts the four
+// chains a 16-lane LDS phase of the four-lanes-per-chain scan touches on disjoint bank groups
+#define VAMD_NZ_STRIDE(n) ((n) + 16)
 
 struct LineFit {
   float A, B, D;
@@ -35,12 +39,12 @@ VAMD_DEV LineFit fit_from_sums(float tN, float tX, float tXX, float tY, float tX
 
 // window sums with a mirrored low edge (lo < 0 in the reference: lib/psy.c:613-617,666-670)
 VAMD_DEV LineFit fit_mirrored(const float *S, int n, int hi, int mlo /* = -lo */) {
-  const float *N = S, *X = S + (n + 4), *XX = S + 2 * (n + 4), *Y = S + 3 * (n + 4), *XY = S + 4 * (n + 4);
+  const float *N = S, *X = S + VAMD_NZ_STRIDE(n), *XX = S + 2 * VAMD_NZ_STRIDE(n), *Y = S + 3 * VAMD_NZ_STRIDE(n), *XY = S + 4 * VAMD_NZ_STRIDE(n);
   return fit_from_sums(N[hi] + N[mlo], X[hi] - X[mlo], XX[hi] + XX[mlo], Y[hi] + Y[mlo], XY[hi] - XY[mlo]);
 }
 // plain window differences (lib/psy.c:635-639,687-691)
 VAMD_DEV LineFit fit_plain(const float *S, int n, int hi, int lo) {
-  const float *N = S, *X = S + (n + 4), *XX = S + 2 * (n + 4), *Y = S + 3 * (n + 4), *XY = S + 4 * (n + 4);
+  const float *N = S, *X = S + VAMD_NZ_STRIDE(n), *XX = S + 2 * VAMD_NZ_STRIDE(n), *Y = S + 3 * VAMD_NZ_STRIDE(n), *XY = S + 4 * VAMD_NZ_STRIDE(n);
   return fit_from_sums(N[hi] - N[lo], X[hi] - X[lo], XX[hi] - XX[lo], Y[hi] - Y[lo], XY[hi] - XY[lo]);
 }
 
@@ -99,29 +103,88 @@ VAMD_DEV void running_sum_inplace(float *p, int n) {
 
 // Who runs the five running sums of a block.
 //  ScanSolo : the wave that owns the block (5 lanes busy) -- single-wave workgroups, tests.
-//  ScanGroup: the waves of a workgroup meet at a barrier and ONE wave walks the chains of
-//    every wave's block together (5 x waves lanes busy).  The scan is bound by the LDS store
-//    path -- a ds_write_b128 costs the same ~13 cycles whether 5 or 35 lanes carry data -- so
-//    sharing the instructions between blocks is what makes it cheaper.
+//  ScanGroup: the waves of a workgroup meet at a barrier and the first few of them walk the chains
+//    of every block of the round, eight chains per wave and eight lanes per chain (below).
 struct ScanSolo {
   VAMD_MEM void before_terms() const {}  // the wave's own WAVE_SYNC after the previous evaluation suffices
   VAMD_MEM void operator()(float *S, int n) const {
     WAVE_SYNC();
-    WAVE_FOR(a, 5) running_sum_inplace(S + a * (n + 4), n);
+    WAVE_FOR(a, 5) running_sum_inplace(S + a * VAMD_NZ_STRIDE(n), n);
     WAVE_SYNC();
   }
 };
 #if VAMD_GPU
+// The same running sums with L = 4 or 8 lanes per chain.  A wave's LDS instruction moves 64 lanes'
+// worth of bytes whether or not the lanes carry data, and a VALU instruction occupies the SIMD for
+// its four cycles whatever the lane mask, so a wave walks 64/L chains, 4L values of each per
+// load/store pair: lane j of a chain's L owns quad L*s+j of step s.  The order of the adds is kept
+// by handing the running total from lane to lane (DPP row_shr:1, fused into the next add): every
+// lane runs all L rounds into temporaries -- only lane r's round-r result is meaningful, and it is
+// exactly what lane r+1 receives for round r+1 -- so nothing on the dependent chain is predicated;
+// a select tree off the chain then keeps each lane's own round.  tools/micro/scan_quad.hip, cycles
+// per element of a chain: one lane per chain 18, L = 4: 12.2, L = 8: 10.4 -- elapsed time falls, but
+// the SIMD time per chain-element does not (more instructions serve fewer chains), so this pays
+// only where the other SIMDs would idle: small groups (<= 16 chains, one wave, L = 4), and the
+// stand-alone 7-block group (L = 8, one wave per SIMD).
+// Chains [first, first+count) of S_all, count <= 64/L; n a multiple of 8L.
+VAMD_DEV float dpp_from_lane_below(float v) {  // row_shr:1 -- lane i receives lane i-1's value
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));
+}
+template <int L>
+VAMD_DEV float dpp_from_last_lane(float v) {  // row_shl:(L-1) -- lane i receives lane i+L-1's value
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + (L - 1), 0xf, 0xf, true));
+}
+template <int L>
+VAMD_DEV void running_sum_lanes(float *S_all, int first, int count, int n) {
+  const int g = LANE / L, j = LANE % L;
+  const bool act = g < count;
+  F4 *q = (F4 *)(S_all + (first + (act ? g : 0)) * VAMD_NZ_STRIDE(n)) + j;
+  const int steps = n / (4 * L);  // even
+  float carry = 0.f;              // lane j == 0: the chain's total through the previous step
+  F4 a = q[0], b = q[L];
+  for (int s = 0; s < steps; s += 2) {
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      F4 &v = half ? b : a;
+      F4 t[L];
+      float cin = carry;
+#pragma unroll
+      for (int r = 0; r < L; r++) {
+        t[r].x = cin + v.x;
+        t[r].y = t[r].x + v.y;
+        t[r].z = t[r].y + v.z;
+        t[r].w = t[r].z + v.w;
+        cin = dpp_from_lane_below(t[r].w);
+      }
+      carry = dpp_from_last_lane<L>(t[L - 1].w);
+      F4 o = t[0];
+#pragma unroll
+      for (int r = 1; r < L; r++) {
+        const bool m = j == r;
+        o.x = m ? t[r].x : o.x;
+        o.y = m ? t[r].y : o.y;
+        o.z = m ? t[r].z : o.z;
+        o.w = m ? t[r].w : o.w;
+      }
+      if (act) q[L * (s + half)] = o;
+      if (s + half + 2 < steps) v = q[L * (s + half + 2)];
+    }
+  }
+}
+
 struct ScanGroup {
-  float *S_all;  // the workgroup's LDS: chain c lives at S_all + c*(n+4)
+  float *S_all;  // the workgroup's LDS: chain c lives at S_all + c*VAMD_NZ_STRIDE(n)
   int nchains;   // 5 x blocks
   // a block's arrays are shared by the waves that split its bins: nobody may overwrite them
   // with new terms while a sibling is still evaluating lines from the previous sums
   VAMD_MEM void before_terms() const { __syncthreads(); }
   VAMD_MEM void operator()(float *, int n) const {
     __syncthreads();
-    if ((threadIdx.x >> 6) == 0) {
-      WAVE_FOR(c, nchains) running_sum_inplace(S_all + c * (n + 4), n);
+    if (nchains <= 16) {  // one wave, four lanes per chain
+      if ((threadIdx.x >> 6) == 0) running_sum_lanes<4>(S_all, 0, nchains, n);
+    } else {              // eight lanes per chain, eight chains per wave
+      const int first = (threadIdx.x >> 6) * 8;
+      if (first < nchains) running_sum_lanes<8>(S_all, first, nchains - first < 8 ? nchains - first : 8, n);
     }
     __syncthreads();
   }
@@ -137,9 +200,7 @@ template <class Scan, int QPS>
 VAMD_DEV void bark_noise_wave(const PsyP &P, const float (*f)[4], float (*noise)[4], const float offset,
                               const int fixed, float *S, const Scan &scan, PhaseClock &pc, int slot, int q0, int q1) {
   const int n = P.n;
-  // each array starts 16 bytes further round the banks so that the five scanning lanes'
-  // 16-byte accesses do not collide
-  float *N = S, *X = S + (n + 4), *XX = S + 2 * (n + 4), *Y = S + 3 * (n + 4), *XY = S + 4 * (n + 4);
+  float *N = S, *X = S + VAMD_NZ_STRIDE(n), *XX = S + 2 * VAMD_NZ_STRIDE(n), *Y = S + 3 * VAMD_NZ_STRIDE(n), *XY = S + 4 * VAMD_NZ_STRIDE(n);
 
   // per-bin terms (lib/psy.c:571-597)
   scan.before_terms();
@@ -250,7 +311,7 @@ VAMD_DEV void noisemask_tile(const PsyP &P, const float (*lm)[4], float (*o)[4],
 }
 
 // _vp_noisemask(p, logmdct, logmask) for one block (single-wave form)
-//   logmdct  [n] input (HBM), out [n] (HBM); S = LDS [5][n+4]
+//   logmdct  [n] input (HBM), out [n] (HBM); S = LDS [5][VAMD_NZ_STRIDE(n)]
 // The noise curve and the work vector never change hands between lanes, so they live in
 // registers (VAMD_QPL quads per lane: block sizes up to 2048 on the GPU).
 VAMD_DEV void noisemask_block(const PsyP &P, const float *__restrict__ logmdct, float *__restrict__ out, float *S,

@@ -155,12 +155,13 @@ __global__ __launch_bounds__(64 * VAMD_XF_WAVES) void k_transform(XformP G, int 
   pc.flush();
 }
 
-// stage 2: _vp_noisemask.  Persistent workgroup per CU holding VAMD_NZ_WAVES channel-blocks per round
-// (their running sums fill the LDS); each block's bins are shared by VAMD_NZ_SPLIT waves, and one
-// wave runs the ordered running sums of the whole round (ScanGroup, k_noise.h).
+// stage 2: _vp_noisemask.  Persistent workgroups, a CU holding VAMD_NZ_WAVES channel-blocks per round
+// (their running sums fill the LDS); each block's bins are shared by VAMD_NZ_SPLIT waves, and the
+// group's first wave(s) run the ordered running sums of the whole group (ScanGroup, k_noise.h).
 #define VAMD_NZ_WAVES 7         // blocks per round when the kernel has the CU to itself
 #define VAMD_NZ_WAVES_SHARED 6  // ... when the tone kernels run beside it
 #define VAMD_NZ_SPLIT 2
+#define VAMD_NZ_GROUP 2         // blocks per workgroup beside the tone kernels (three workgroups per CU)
 __global__ __launch_bounds__(64 * VAMD_NZ_WAVES * VAMD_NZ_SPLIT) void k_noise(PsyP P0, PsyP P1, DescP d, int ch,
                                                                              long ncb, int split,
                                                                              const float *__restrict__ logmdct,
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(64 * VAMD_NZ_WAVES * VAMD_NZ_SPLIT) void k_noise(Ps
   const int per = ((nq + split * 64 - 1) / (split * 64)) * 64;
   const int q0 = part * per < nq ? part * per : nq, q1 = q0 + per < nq ? q0 + per : nq;
   float *S_all = (float *)vamd_smem;
-  float *S = S_all + slot * 5 * (n2 + 4);
+  float *S = S_all + slot * 5 * VAMD_NZ_STRIDE(n2);
   ScanGroup scan;
   scan.S_all = S_all;
   scan.nchains = 5 * nblk;
@@ -940,16 +941,20 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_
       (void)hipStreamWaitEvent(c->side, c->ev_fork, 0);
     }
     {
-      // alone, 7 blocks' running sums fill the LDS; beside the tone kernels 6 leave those room
+      // alone, 7 blocks' running sums fill a CU's LDS; beside the tone kernels 6 leave those room
       int waves = overlap ? VAMD_NZ_WAVES_SHARED : VAMD_NZ_WAVES;
-      while (waves > 1 && (size_t)waves * 5 * (n2 + 4) * 4 > c->lds_per_block) waves--;
+      while (waves > 1 && (size_t)waves * 5 * VAMD_NZ_STRIDE(n2) * 4 > c->lds_per_block) waves--;
       // a wave's slice is at most QPS * 256 = 512 bins
       int split = VAMD_NZ_SPLIT;
       while ((n2 + split * 512 - 1) / (split * 512) > 1) split *= 2;
       while (waves > 1 && waves * split > VAMD_NZ_WAVES * VAMD_NZ_SPLIT) waves--;
+      // beside the tone kernels the CU's six blocks run as three workgroups of two: each group's ordered
+      // sums are one wave's work (ten chains, four lanes each) and overlap the other groups' per-bin phases
+      int wgs = 1;
+      if (overlap && waves == VAMD_NZ_WAVES_SHARED) waves = VAMD_NZ_GROUP, wgs = VAMD_NZ_WAVES_SHARED / VAMD_NZ_GROUP;
       const long groups = ((long)gcb + waves - 1) / waves;
-      const unsigned grid = (unsigned)(groups < c->num_cus ? groups : c->num_cus);
-      hipLaunchKernelGGL(k_noise, dim3(grid), dim3(64 * waves * split), (size_t)waves * 5 * (n2 + 4) * 4, s, P0, P1, d, ch,
+      const unsigned grid = (unsigned)(groups < (long)c->num_cus * wgs ? groups : (long)c->num_cus * wgs);
+      hipLaunchKernelGGL(k_noise, dim3(grid), dim3(64 * waves * split), (size_t)waves * 5 * VAMD_NZ_STRIDE(n2) * 4, s, P0, P1, d, ch,
                          (long)gcb, split, p.logmdct, p.noise);
     }
     prof_mark(c), R->nst++;
