@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define VAMD_SETUP_MAGIC   0x31544553444d4156ULL /* "VAMDSET1" little-endian */
-#define VAMD_SETUP_VERSION 5u
+#define VAMD_SETUP_VERSION 6u
 
 #define VAMD_PACKETBLOBS   15  /* lib/codec_internal.h:28 */
 #define VAMD_P_BANDS       17  /* lib/psy.h:28 */
@@ -38,7 +38,9 @@ extern "C" {
 #define VAMD_POSIT         65  /* VIF_POSIT+2, lib/backends.h:57 */
 #define VAMD_FLOOR_PARTS   31  /* VIF_PARTS, lib/backends.h:59 */
 #define VAMD_FLOOR_CLASSES 16  /* VIF_CLASS, lib/backends.h:58 */
-#define VAMD_MAX_CH        2   /* channel counts the kernels cover this round */
+#define VAMD_MAX_CH        6   /* channel counts covered: 1, 2 and the 5.1 layout of libvorbisenc */
+#define VAMD_MAX_SUBMAPS   2   /* 5.1: the five full-range channels, and the LFE on its own floor and residue */
+#define VAMD_MAX_COUPLING  4   /* coupling steps (5.1: L-R, surround L-R, L-C, L-SL; lib/modes/residue_44p51.h:283) */
 #define VAMD_VE_BANDS      7   /* lib/envelope.h:28 */
 #define VAMD_VE_NEARDC     15  /* lib/envelope.h:29 */
 #define VAMD_VE_AMP        17  /* VE_PRE+VE_POST-1, lib/envelope.h:26 */
@@ -127,10 +129,11 @@ typedef struct vamd_floor1_tab {
 
 /* one per mode W: vorbis_info_mapping0 (lib/backends.h:130-141) with its floor */
 typedef struct vamd_mode_tab {
-  int32_t submaps;                 /* only 1 is covered this round */
-  int32_t coupling_steps;          /* 0 or 1 */
-  int32_t coupling_mag, coupling_ang;
-  vamd_floor1_tab floor;
+  int32_t submaps;                 /* 1 or 2 */
+  int32_t coupling_steps;          /* 0 .. VAMD_MAX_COUPLING, applied in order */
+  int32_t coupling_mag[VAMD_MAX_COUPLING], coupling_ang[VAMD_MAX_COUPLING];
+  int32_t chmuxlist[VAMD_MAX_CH];  /* submap of each channel */
+  vamd_floor1_tab floor[VAMD_MAX_SUBMAPS];   /* the floor of each submap (floorsubmap[]) */
 } vamd_mode_tab;
 
 /* the block-switching detector: envelope_lookup (lib/envelope.h:54-74, built by
@@ -197,7 +200,7 @@ typedef struct vamd_setup_header {
   vamd_psy_global_tab psy_g;
   vamd_mode_tab       mode[2];
   vamd_envelope_tab   env;
-  vamd_residue_tab    res[2];      /* per mode W */
+  vamd_residue_tab    res[2][VAMD_MAX_SUBMAPS];  /* per mode W and submap (residuesubmap[]) */
   int32_t             nbooks;      /* ci->books */
   uint32_t            off_books;   /* vamd_book_tab[nbooks] */
 } vamd_setup_header;

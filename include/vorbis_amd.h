@@ -128,9 +128,11 @@ typedef struct vamd_batch_io {
   /* residue back-end, level FULL only, all three or none: what res2_class
    * decides and, in the order res2_forward emits them, the codebook entries its lattice search
    * picks (lib/res0.c:479-532,783-809,534-640,322-410).  Available when vamd_residue_capacity() > 0. */
-  int32_t  *res_class;    /* out [nb][VAMD_RES_CLASS_STRIDE] class of each partition */
-  uint16_t *res_entries;  /* out [nb][vamd_residue_capacity(ctx, W)] entry numbers, (stage, partition, vector) order */
-  int32_t  *res_count;    /* out [nb][2] {partitions classified (0 = nothing to code), entries} */
+  int32_t  *res_class;    /* out [nb][S][VAMD_RES_CLASS_STRIDE] class of each partition (S = vamd_submaps(ctx, W);
+                             type 1 over several channels: index = partition * coded channels + channel) */
+  uint16_t *res_entries;  /* out [nb][vamd_residue_capacity(ctx, W)] entry numbers in emission order, (stage,
+                             partition, channel, vector); a second submap's start at vamd_residue_offset(ctx, W, 1) */
+  int32_t  *res_count;    /* out [nb][S][2] {classes (0 = nothing to code), entries} of each submap */
   /* packet assembly, level FULL only, both or none: the block's finished audio
    * packet -- header bits, floor1_encode's writes, the residue's phrase words and codewords, packed
    * LSb first exactly as oggpack_write would (lib/mapping0.c:598-606, lib/floor1.c:833-921,
@@ -140,11 +142,15 @@ typedef struct vamd_batch_io {
   int64_t   packet_stride;/* row length in bytes, a multiple of 4 (vamd_packet_capacity() always suffices) */
 } vamd_batch_io;
 
-#define VAMD_RES_CLASS_STRIDE 64 /* ints per block in res_class[] (>= (end-begin)/grouping) */
+#define VAMD_RES_CLASS_STRIDE 256 /* ints per block and submap in res_class[] (>= classified partitions) */
 
 /* Entries one block of size class W can emit at most (the row length of res_entries), or 0 when the
  * mode's residue is not covered on the GPU (type 2 over a 2-channel bundle and type 1 over one channel are). */
 int vamd_residue_capacity(const vamd_ctx *ctx, int W);
+/* Submaps of the mode (1; 2 for the 5.1 layout: the full-range channels, then the LFE), and where in a
+ * block's res_entries row submap `sm`'s entries start. */
+int vamd_submaps(const vamd_ctx *ctx, int W);
+int vamd_residue_offset(const vamd_ctx *ctx, int W, int submap);
 
 /* Bytes the longest possible packet of size class W takes (a multiple of 4; worst case over every
  * field's longest codeword), or 0 when packets of this mode are not assembled on the GPU (they are
@@ -231,9 +237,9 @@ typedef struct vamd_managed_io {
   int32_t  *post_valid;  /* out [nb][15][ch] 0 where floor_posts[i][k] is NULL                   (required) */
   int32_t  *iwork;       /* out [nb][15][ch][n/2] quantised, coupled residue of candidate k      (required) */
   int32_t  *nonzero;     /* out [nb][15][ch]                                                     (required) */
-  int32_t  *res_class;   /* out [nb][15][VAMD_RES_CLASS_STRIDE]   optional, all three or none */
+  int32_t  *res_class;   /* out [nb][15][S][VAMD_RES_CLASS_STRIDE]   optional, all three or none */
   uint16_t *res_entries; /* out [nb][15][vamd_residue_capacity(ctx, W)] */
-  int32_t  *res_count;   /* out [nb][15][2] */
+  int32_t  *res_count;   /* out [nb][15][S][2] */
   uint8_t  *packets;     /* out [nb][15][packet_stride]           optional, with packet_bits (as vamd_batch_io) */
   int32_t  *packet_bits; /* out [nb][15] */
   int64_t   packet_stride;
@@ -255,8 +261,8 @@ int vamd_analyze_block_managed(vamd_ctx *ctx, const float *const *pcm, int lW, i
                                uint16_t *res_entries, int32_t *res_count);
 
 /* vamd_analyze_block() plus the residue back-end's decisions for the block (host pointers; any may be
- * NULL).  res_entries must hold vamd_residue_capacity(ctx, W) entries, res_class VAMD_RES_CLASS_STRIDE
- * ints, res_count 2 ints.  Fails with VAMD_EIMPL when res_* are asked for a mode that is not covered. */
+ * NULL).  res_entries must hold vamd_residue_capacity(ctx, W) entries, res_class S * VAMD_RES_CLASS_STRIDE
+ * ints, res_count S * 2 ints (S = vamd_submaps(ctx, W)).  Fails with VAMD_EIMPL when res_* are asked for a mode that is not covered. */
 int vamd_analyze_block_res(vamd_ctx *ctx, const float *const *pcm, int lW, int W, int nW, int blocktype,
                            float ampmax_in, float *mdct, float *logmask, int32_t *posts, int32_t *post_valid,
                            int32_t *iwork, int32_t *nonzero, float *ampmax_out, int32_t *res_class,

@@ -161,52 +161,56 @@ long vamd_pack_setup(vorbis_dsp_state *vd, void *dst, long cap) {
     /* mode number == W in every libvorbisenc setup (lib/mapping0.c:248) */
     vamd_mode_tab *m = &h.mode[W];
     vorbis_info_mapping0 *map;
-    vorbis_look_floor1 *fl;
-    vorbis_info_floor1 *fi;
-    int fidx;
+    int sm;
     const int mode = W < ci->modes ? W : 0;
     if (ci->map_type[ci->mode_param[mode]->mapping] != 0) return OV_EIMPL;
     map = (vorbis_info_mapping0 *)ci->map_param[ci->mode_param[mode]->mapping];
     m->submaps = map->submaps;
     m->coupling_steps = map->coupling_steps;
-    if (map->submaps != 1 || map->coupling_steps > 1) return OV_EIMPL;
-    if (map->coupling_steps == 1) {
-      m->coupling_mag = map->coupling_mag[0];
-      m->coupling_ang = map->coupling_ang[0];
+    if (map->submaps < 1 || map->submaps > VAMD_MAX_SUBMAPS || map->coupling_steps > VAMD_MAX_COUPLING) return OV_EIMPL;
+    for (i = 0; i < map->coupling_steps; i++) {
+      m->coupling_mag[i] = map->coupling_mag[i];
+      m->coupling_ang[i] = map->coupling_ang[i];
     }
-    fidx = map->floorsubmap[0];
-    if (ci->floor_type[fidx] != 1) return OV_EIMPL; /* lib/mapping0.c:498 */
-    fl = (vorbis_look_floor1 *)b->flr[fidx];
-    fi = fl->vi;
-    m->floor.posts = fl->posts;
-    m->floor.look_n = fl->n;
-    m->floor.quant_q = fl->quant_q;
-    m->floor.mult = fi->mult;
-    m->floor.info_n = fi->n;
-    m->floor.maxover = fi->maxover;
-    m->floor.maxunder = fi->maxunder;
-    m->floor.maxerr = fi->maxerr;
-    m->floor.twofitweight = fi->twofitweight;
-    m->floor.twofitatten = fi->twofitatten;
-    for (i = 0; i < fl->posts && i < VAMD_POSIT; i++) {
-      m->floor.postlist[i] = fi->postlist[i];
-      m->floor.sorted_index[i] = fl->sorted_index[i];
-      m->floor.forward_index[i] = fl->forward_index[i];
-      m->floor.reverse_index[i] = fl->reverse_index[i];
-    }
-    for (i = 0; i < fl->posts - 2 && i < VIF_POSIT; i++) {
-      m->floor.hineighbor[i] = fl->hineighbor[i];
-      m->floor.loneighbor[i] = fl->loneighbor[i];
-    }
-    /* what the bit-writing half of floor1_encode walks (lib/floor1.c:833-921) */
-    if (fi->partitions > VAMD_FLOOR_PARTS) return OV_EIMPL;
-    m->floor.partitions = fi->partitions;
-    for (i = 0; i < fi->partitions; i++) m->floor.partitionclass[i] = fi->partitionclass[i];
-    for (i = 0; i < VAMD_FLOOR_CLASSES; i++) {
-      m->floor.class_dim[i] = fi->class_dim[i];
-      m->floor.class_subs[i] = fi->class_subs[i];
-      m->floor.class_book[i] = fi->class_book[i];
-      for (j = 0; j < 8; j++) m->floor.class_subbook[i][j] = fi->class_subbook[i][j];
+    for (i = 0; i < vi->channels; i++) m->chmuxlist[i] = map->submaps > 1 ? map->chmuxlist[i] : 0;
+    for (sm = 0; sm < map->submaps; sm++) {
+      vamd_floor1_tab *f = &m->floor[sm];
+      const int fidx = map->floorsubmap[sm];
+      vorbis_look_floor1 *fl;
+      vorbis_info_floor1 *fi;
+      if (ci->floor_type[fidx] != 1) return OV_EIMPL; /* lib/mapping0.c:498 */
+      fl = (vorbis_look_floor1 *)b->flr[fidx];
+      fi = fl->vi;
+      f->posts = fl->posts;
+      f->look_n = fl->n;
+      f->quant_q = fl->quant_q;
+      f->mult = fi->mult;
+      f->info_n = fi->n;
+      f->maxover = fi->maxover;
+      f->maxunder = fi->maxunder;
+      f->maxerr = fi->maxerr;
+      f->twofitweight = fi->twofitweight;
+      f->twofitatten = fi->twofitatten;
+      for (i = 0; i < fl->posts && i < VAMD_POSIT; i++) {
+        f->postlist[i] = fi->postlist[i];
+        f->sorted_index[i] = fl->sorted_index[i];
+        f->forward_index[i] = fl->forward_index[i];
+        f->reverse_index[i] = fl->reverse_index[i];
+      }
+      for (i = 0; i < fl->posts - 2 && i < VIF_POSIT; i++) {
+        f->hineighbor[i] = fl->hineighbor[i];
+        f->loneighbor[i] = fl->loneighbor[i];
+      }
+      /* what the bit-writing half of floor1_encode walks (lib/floor1.c:833-921) */
+      if (fi->partitions > VAMD_FLOOR_PARTS) return OV_EIMPL;
+      f->partitions = fi->partitions;
+      for (i = 0; i < fi->partitions; i++) f->partitionclass[i] = fi->partitionclass[i];
+      for (i = 0; i < VAMD_FLOOR_CLASSES; i++) {
+        f->class_dim[i] = fi->class_dim[i];
+        f->class_subs[i] = fi->class_subs[i];
+        f->class_book[i] = fi->class_book[i];
+        for (j = 0; j < 8; j++) f->class_subbook[i][j] = fi->class_subbook[i][j];
+      }
     }
   }
   h.modebits = b->modebits;
@@ -270,10 +274,12 @@ long vamd_pack_setup(vorbis_dsp_state *vd, void *dst, long cap) {
       }
     }
     for (W = 0; W < 2; W++) {
-      vorbis_info_mapping0 *map = (vorbis_info_mapping0 *)ci->map_param[ci->mode_param[W < ci->modes ? W : 0]->mapping];
-      int resnum = map->residuesubmap[0], acc = 0, maxstage = 0;
+     int sm;
+     vorbis_info_mapping0 *map = (vorbis_info_mapping0 *)ci->map_param[ci->mode_param[W < ci->modes ? W : 0]->mapping];
+     for (sm = 0; sm < map->submaps; sm++) {
+      int resnum = map->residuesubmap[sm], acc = 0, maxstage = 0;
       vorbis_info_residue0 *ri = (vorbis_info_residue0 *)ci->residue_param[resnum];
-      vamd_residue_tab *t = &h.res[W];
+      vamd_residue_tab *t = &h.res[W][sm];
       t->type = ci->residue_type[resnum];
       t->begin = (int32_t)ri->begin;
       t->end = (int32_t)ri->end;
@@ -295,6 +301,7 @@ long vamd_pack_setup(vorbis_dsp_state *vd, void *dst, long cap) {
           if (ri->secondstages[i] & (1 << j)) t->partbooks[i][j] = ri->booklist[acc++]; /* lib/res0.c:214-222 */
       }
       t->stages = maxstage;
+     }
     }
   }
 

@@ -63,6 +63,11 @@ port_enc *port_open(const void *blob, size_t bytes) {
   if (!blob || bytes < sizeof(h)) return NULL;
   memcpy(&h, blob, sizeof(h));
   if (h.magic != VAMD_SETUP_MAGIC || h.version != VAMD_SETUP_VERSION || h.total_bytes > bytes) return NULL;
+  /* this restatement covers the mono / stereo layouts (one submap, at most one coupling step); the 5.1
+     layout is pinned against oracle/_ref only */
+  if (h.channels > 2 || h.mode[0].submaps != 1 || h.mode[1].submaps != 1 || h.mode[0].coupling_steps > 1 ||
+      h.mode[1].coupling_steps > 1)
+    return NULL;
   e = (port_enc *)calloc(1, sizeof(*e));
   e->blob = (unsigned char *)malloc(h.total_bytes);
   memcpy(e->blob, blob, h.total_bytes);
@@ -78,7 +83,7 @@ void port_close(port_enc *e) {
 
 int port_channels(const port_enc *e) { return e->h.channels; }
 int port_blocksize(const port_enc *e, int W) { return e->h.blocksizes[W]; }
-int port_floor_posts(const port_enc *e, int W) { return e->h.mode[W].floor.posts; }
+int port_floor_posts(const port_enc *e, int W) { return e->h.mode[W].floor[0].posts; }
 
 /* ---- scalar helpers --------------------------------------------------------- */
 
@@ -1141,7 +1146,7 @@ static void couple_quantize(const port_enc *e, int psy, int W, int blob, float *
       track++;
     }
     if (m->coupling_steps == 1) {
-      const int Mi = m->coupling_mag, Ai = m->coupling_ang;
+      const int Mi = m->coupling_mag[0], Ai = m->coupling_ang[0];
       int *iM = &iwork[Mi][i], *iA = &iwork[Ai][i];
       float *reM = raw[Mi], *reA = raw[Ai], *qeM = quant[Mi], *qeA = quant[Ai];
       float *floorM = flo[Mi], *floorA = flo[Ai];
@@ -1189,9 +1194,9 @@ static void couple_quantize(const port_enc *e, int psy, int W, int blob, float *
       }
     }
   }
-  if (m->coupling_steps == 1 && (nonzero[m->coupling_mag] || nonzero[m->coupling_ang])) {
-    nonzero[m->coupling_mag] = 1;
-    nonzero[m->coupling_ang] = 1;
+  if (m->coupling_steps == 1 && (nonzero[m->coupling_mag[0]] || nonzero[m->coupling_ang[0]])) {
+    nonzero[m->coupling_mag[0]] = 1;
+    nonzero[m->coupling_ang[0]] = 1;
   }
 }
 
@@ -1250,7 +1255,7 @@ static int book_besterror(const port_enc *e, const vamd_book_tab *bk, int *a) { 
 /* Type 2 (any channel count, interleaved) and type 1 with a single channel (_01class :412-470,
  * res1_class/res1_forward :729-755).  Returns 0, or -1 when the mode is not covered. */
 static int residue2(const port_enc *e, int W, int **in, const int *nonzero, port_taps *t) {
-  const vamd_residue_tab *r = &e->h.res[W];
+  const vamd_residue_tab *r = &e->h.res[W][0];
   const vamd_book_tab *books = (const vamd_book_tab *)(e->blob + e->h.off_books);
   const int ch = e->h.channels, n2 = e->h.blocksizes[W] / 2;
   const int spp = r->grouping, nparts = r->partitions, n = r->end - r->begin, partvals = n / spp;
@@ -1349,7 +1354,7 @@ static int tap_block(const port_enc *e, const float *pcm_in, int lW, int W, int 
                      port_taps *t, port_mtaps *m) {
   const int ch = e->h.channels, n = e->h.blocksizes[W], n2 = n / 2;
   const int psy = blocktype + (W ? 2 : 0);
-  const vamd_floor1_tab *fl = &e->h.mode[W].floor;
+  const vamd_floor1_tab *fl = &e->h.mode[W].floor[0];
   float *pcm = (float *)malloc(sizeof(float) * ch * n);
   float *gm = (float *)malloc(sizeof(float) * ch * n2);
   int *iw = (int *)malloc(sizeof(int) * ch * n2);

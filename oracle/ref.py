@@ -238,7 +238,7 @@ class RefEncoder:
             setattr(t, k, _fp(v) if v.dtype == np.float32 else _ip(v))
         t.packet = pkt.ctypes.data_as(_u8p)
         t.packet_cap = pkt.size
-        rcls = np.zeros(256, np.int32)
+        rcls = np.zeros(1024, np.int32)
         rent = np.zeros(1 << 15, np.uint16)
         t.res_class, t.res_class_cap = _ip(rcls), rcls.size
         t.res_entries, t.res_entries_cap = rent.ctypes.data_as(C.POINTER(C.c_ushort)), rent.size
@@ -248,7 +248,8 @@ class RefEncoder:
         o["packet"] = bytes(pkt[:t.packet_bytes])
         o["packet_matches_real"] = bool(t.packet_matches_real)
         o["ampmax_out"] = float(o["ampmax_out"][0])
-        # residue back-end of submap 0: classes per partition, and every codebook entry in emission order
+        # residue back-end, submap after submap: classes per (partition, coded channel), and every codebook
+        # entry in emission order
         assert t.res_count <= rent.size
         o["res_class"] = rcls[:t.res_partvals].copy()
         o["res_entries"] = rent[:t.res_count].copy()

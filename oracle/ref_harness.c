@@ -199,7 +199,7 @@ typedef struct ref_taps {
   int packet_matches_real; /* out: 1 when the real vorbis_analysis() produced identical bytes+ampmax */
   /* residue back-end (submap 0): what res*_class decided and, in call order, every codebook entry
      res*_forward emitted through vorbis_book_encode() except the phrase-book words */
-  int *res_class;            /* [res_class_cap] partword[0][i] (channel 0 of the bundle) */
+  int *res_class;            /* [res_class_cap] the partition classes, submap after submap (see tap_core) */
   long res_class_cap;
   long res_partvals;         /* out: partitions classified (0 when the class function returned NULL) */
   unsigned short *res_entries;
@@ -471,27 +471,38 @@ static int tap_core(ref_enc *e, const float *pcm, int lW, int W, int nW, int blo
         }
       classifications = _residue_P[ci->residue_type[resnum]]->class(vb, b->residue[resnum], couple_bundle,
                                                                    zerobundle, ch_in_bundle);
-      if (i == 0) {
+      {
+        /* classes of every submap one after the other; a type-1 residue classifies each coded channel
+           (partition-major, channel-minor: the order _01forward walks them in) */
         vorbis_info_residue0 *ri = (vorbis_info_residue0 *)ci->residue_param[resnum];
         long pv = (ri->end - ri->begin) / ri->grouping, p;
-        t->res_partvals = classifications ? pv : 0;
-        if (classifications && t->res_class)
-          for (p = 0; p < pv && p < t->res_class_cap; p++) t->res_class[p] = (int)classifications[0][p];
+        int streams = 1, q;
+        if (ci->residue_type[resnum] != 2) {
+          streams = 0;
+          for (q = 0; q < ch_in_bundle; q++) streams += zerobundle[q] ? 1 : 0;
+        }
+        if (i == 0) {
+          t->res_partvals = 0;
+          res_tap.out = t->res_entries;
+          res_tap.cap = t->res_entries_cap;
+          res_tap.count = 0;
+        }
+        if (classifications)
+          for (p = 0; p < pv; p++)
+            for (q = 0; q < streams; q++) {
+              if (t->res_class && t->res_partvals < t->res_class_cap) t->res_class[t->res_partvals] = (int)classifications[q][p];
+              t->res_partvals++;
+            }
         res_tap.armed = 1;
         res_tap.skip = ci->fullbooks + ri->groupbook;
-        res_tap.out = t->res_entries;
-        res_tap.cap = t->res_entries_cap;
-        res_tap.count = 0;
       }
       ch_in_bundle = 0;
       for (j = 0; j < ch; j++)
         if (info->chmuxlist[j] == i) couple_bundle[ch_in_bundle++] = iwork[j];
       _residue_P[ci->residue_type[resnum]]->forward(opb, vb, b->residue[resnum], couple_bundle, zerobundle,
                                                      ch_in_bundle, classifications, i);
-      if (i == 0) {
-        res_tap.armed = 0;
-        t->res_count = res_tap.count;
-      }
+      res_tap.armed = 0;
+      t->res_count = res_tap.count;
     }
   }
   t->packet_bytes = oggpack_bytes(opb);

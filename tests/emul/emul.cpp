@@ -50,19 +50,41 @@ static void residue_and_pack(const Bound &B, int W, int lW, int nW, const int *i
                              const int *post_valid, int *res_class, unsigned short *res_entries, int *res_count,
                              unsigned char *packet, int *packet_bits) {
   const int ch = B.channels, n2 = B.bs[W] / 2;
-  const ResP &Rp = B.res[W];
+  const ChMap &cm = B.chmap[W];
   PhaseClock pc;
   pc.start(nullptr);
-  std::vector<int> work(ch * n2), cls(VAMD_RES_CLASS_STRIDE), off(B.res_stages[W] * B.res_partvals[W] + 1),
-      info(B.res_stages[W] * B.res_partvals[W] + 1);
-  const int *ip[VAMD_MAX_CH];
-  for (int i = 0; i < ch; i++) ip[i] = iwork + i * n2;
-  residue2_block(Rp, ch, n2, ip, nonzero, work.data(), cls.data(), off.data(), info.data(), res_class, res_entries, res_count,
-                 pc);
+  std::vector<int> lds(B.res_lds_ints[W] + 16);
+  for (int sm = 0; sm < cm.submaps; sm++) {
+    const ResP &Rp = B.res[W][sm];
+    int *work = lds.data(), *cls = work + Rp.bundle * n2, *off = cls + VAMD_RES_CLASS_STRIDE,
+        *info = off + (Rp.tab->stages * Rp.slots + 1);
+    const int *ip[VAMD_MAX_CH];
+    int nz[VAMD_MAX_CH], nb = 0;
+    for (int c = 0; c < ch; c++)
+      if (cm.sub[c] == sm) ip[nb] = iwork + c * n2, nz[nb] = nonzero[c], nb++;
+    residue_block(Rp, n2, ip, nz, work, cls, off, info, res_class + Rp.cls_base, res_entries + Rp.ent_base, res_count + 2 * sm,
+                  pc);
+  }
   if (!packet) return;
-  std::vector<int> ring(VAMD_PK_RING), outv(VAMD_POSTS_STRIDE);
-  pack_block(B.pack[W], B.floor[W], Rp, ch, W, lW, nW, posts, post_valid, res_class, res_entries, res_count, ring.data(),
-             outv.data(), cls.data(), off.data(), info.data(), (unsigned *)packet, B.pack[W].capacity / 4, packet_bits);
+  std::vector<int> ring(VAMD_PK_RING), outv(VAMD_POSTS_STRIDE), cls(VAMD_RES_CLASS_STRIDE), off(B.res_off_ints[W]),
+      info(B.res_off_ints[W]);
+  pack_block(B.pack[W], B.floor[W], B.res[W], cm, ch, W, lW, nW, posts, post_valid, res_class, res_entries, res_count,
+             ring.data(), outv.data(), cls.data(), off.data(), info.data(), (unsigned *)packet, B.pack[W].capacity / 4,
+             packet_bits);
+}
+
+// couple / quantise / normalise with whichever form the layout needs (as launch_couple picks the kernel)
+static void couple_any(const CoupleP &C, const PsyP &P, int n2, const float *const *mp, const int *const *ip, int *const *op,
+                       int *nonzero, PhaseClock &pc) {
+  std::vector<float> cand(n2), key(n2), sgn(n2);
+  CoupleLds L = {cand.data(), key.data(), sgn.data()};
+  if (C.ch > 2 || C.coupling_steps > 1) {
+    std::vector<int> pre((size_t)C.ch * n2), snap((size_t)(C.coupling_steps + 1) * n2);
+    CoupleGeneralLds G = {L, pre.data(), snap.data()};
+    couple_block_general(C, P, n2, mp, ip, op, nonzero, G, pc);
+  } else {
+    couple_block(C, P, n2, mp, ip, op, nonzero, L, pc);
+  }
 }
 
 static int analyze_core(void *h, const float *pcm, int lW, int W, int nW, int blocktype, float ampmax_in, EmulTaps *t,
@@ -81,7 +103,9 @@ void *emul_open(const void *blob, size_t bytes) {
   return e;
 }
 void emul_close(void *h) { delete (Emul *)h; }
-int emul_residue_capacity(void *h, int W) { return ((Emul *)h)->B.res[W].covered ? ((Emul *)h)->B.res[W].cap : 0; }
+int emul_residue_capacity(void *h, int W) { return ((Emul *)h)->B.res_cap[W]; }
+int emul_submaps(void *h, int W) { return ((Emul *)h)->B.chmap[W].submaps; }
+int emul_residue_offset(void *h, int W, int sm) { return ((Emul *)h)->B.res[W][sm].ent_base; }
 int emul_packet_capacity(void *h, int W) { return ((Emul *)h)->B.pack[W].capacity; }
 
 int emul_mdct_forward(void *h, int W, const float *in, float *out) {
@@ -115,7 +139,6 @@ static int analyze_core(void *h, const float *pcm, int lW, int W, int nW, int bl
   const int ch = B.channels, n = B.bs[W], n2 = n / 2;
   const XformP &X = B.xf[W];
   const PsyP &P = B.psy[blocktype + (W ? 2 : 0)];
-  const FloorP &F = B.floor[W];
   const CoupleP &C = B.couple[W];
   std::vector<float> A(n + 4), Bw(n + n / 32);
   std::vector<float> mdct_raw(ch * n2), logfft(ch * n2), logmdct(ch * n2), noise(ch * n2), tone(ch * n2),
@@ -140,6 +163,7 @@ static int analyze_core(void *h, const float *pcm, int lW, int W, int nW, int bl
     std::vector<unsigned short> surv(nlp);
     FloorScratch sc;
     for (int i = 0; i < ch; i++) {
+      const FloorP &F = B.floor[W][B.chmap[W].sub[i]];
       noisemask_block(P, &logmdct[i * n2], &noise[i * n2], S.data(), pc);
       tonemask_block(P, &logfft[i * n2], &tone[i * n2], global, local[i], seed.data() + seed_pad_lo(P.eighth_octave_lines), ampstack.data(),
                      flr.data(), ring_amp.data(), ring_pos.data(), surv.data(), pc);
@@ -157,8 +181,6 @@ static int analyze_core(void *h, const float *pcm, int lW, int W, int nW, int bl
     }
   }
   {
-    std::vector<float> cand(n2), key(n2), sgn(n2);
-    CoupleLds L = {cand.data(), key.data(), sgn.data()};
     const float *mp[VAMD_MAX_CH];
     const int *ip[VAMD_MAX_CH];
     int *op[VAMD_MAX_CH];
@@ -173,11 +195,11 @@ static int analyze_core(void *h, const float *pcm, int lW, int W, int nW, int bl
           ip[i] = m_ilog.data() + ((size_t)k * ch + i) * n2;
           op[i] = m->iwork + ((size_t)k * ch + i) * n2;
         }
-        couple_block(B.couple_all[W].c[k], P, n2, mp, ip, op, m->nonzero + k * ch, L, pc);
+        couple_any(B.couple_all[W].c[k], P, n2, mp, ip, op, m->nonzero + k * ch, pc);
         if (m->packets) {
-          if (!B.res[W].covered) return -130;
-          std::vector<int> rc(VAMD_RES_CLASS_STRIDE), cnt(2);
-          std::vector<unsigned short> re(B.res[W].cap);
+          if (!B.res_cap[W]) return -130;
+          std::vector<int> rc(VAMD_MAX_SUBMAPS * VAMD_RES_CLASS_STRIDE), cnt(2 * VAMD_MAX_SUBMAPS);
+          std::vector<unsigned short> re(B.res_cap[W]);
           residue_and_pack(B, W, lW, nW, m->iwork + (size_t)k * ch * n2, m->nonzero + k * ch,
                            m->posts + (size_t)k * ch * VAMD_POSTS_STRIDE, m->post_valid + k * ch, rc.data(), re.data(),
                            cnt.data(), m->packets + (size_t)k * B.pack[W].capacity, m->packet_bits + k);
@@ -188,10 +210,10 @@ static int analyze_core(void *h, const float *pcm, int lW, int W, int nW, int bl
       if (t->ampmax_out) *t->ampmax_out = global;
       return 0;
     }
-    couple_block(C, P, n2, mp, ip, op, nonzero.data(), L, pc);
+    couple_any(C, P, n2, mp, ip, op, nonzero.data(), pc);
   }
   if (t->res_entries && t->res_class && t->res_count) {
-    if (!B.res[W].covered) return -130;
+    if (!B.res_cap[W]) return -130;
     residue_and_pack(B, W, lW, nW, iwork.data(), nonzero.data(), posts.data(), post_valid.data(), t->res_class,
                      t->res_entries, t->res_count, t->packet, t->packet_bits);
   }

@@ -12,6 +12,7 @@ _f32p = C.POINTER(C.c_float)
 _i32p = C.POINTER(C.c_int)
 
 POSTS_STRIDE = 32
+RES_CLASS_STRIDE = 256
 
 
 class _Taps(C.Structure):
@@ -62,6 +63,8 @@ class Emul:
                                                       C.POINTER(_Taps), C.POINTER(_MTaps)]
         self.L.emul_residue_capacity.argtypes = [C.c_void_p, C.c_int]
         self.L.emul_packet_capacity.argtypes = [C.c_void_p, C.c_int]
+        self.L.emul_submaps.argtypes = [C.c_void_p, C.c_int]
+        self.L.emul_residue_offset.argtypes = [C.c_void_p, C.c_int, C.c_int]
         self.L.emul_envelope_search.argtypes = [C.c_void_p, _f32p, C.c_long, C.c_long, C.c_void_p, C.c_void_p]
         blob = np.ascontiguousarray(blob, dtype=np.uint8)
         self.h = self.L.emul_open(blob.ctypes.data_as(C.c_void_p), blob.size)
@@ -94,7 +97,8 @@ class Emul:
             setattr(t, k, v.ctypes.data_as(_f32p if v.dtype == np.float32 else _i32p))
         cap = self.L.emul_residue_capacity(self.h, W)
         if cap > 0:
-            rcls, rent, rcnt = np.zeros(64, np.int32), np.zeros(cap, np.uint16), np.zeros(2, np.int32)
+            S = self.L.emul_submaps(self.h, W)
+            rcls, rent, rcnt = np.zeros(S * RES_CLASS_STRIDE, np.int32), np.zeros(cap, np.uint16), np.zeros(2 * S, np.int32)
             t.res_class, t.res_count = rcls.ctypes.data_as(_i32p), rcnt.ctypes.data_as(_i32p)
             t.res_entries = rent.ctypes.data_as(C.POINTER(C.c_ushort))
             pk = np.full(self.L.emul_packet_capacity(self.h, W), 0xAA, np.uint8)
@@ -104,8 +108,10 @@ class Emul:
         assert r == 0
         o["ampmax_out"] = float(o["ampmax_out"][0])
         if cap > 0:
-            o["res_class"] = rcls[:rcnt[0]].copy()
-            o["res_entries"] = rent[:rcnt[1]].copy()
+            # all submaps' classes / entries one after the other (the order the reference emits them in)
+            offs = [self.L.emul_residue_offset(self.h, W, sm) for sm in range(S)]
+            o["res_class"] = np.concatenate([rcls[sm * RES_CLASS_STRIDE:sm * RES_CLASS_STRIDE + rcnt[2 * sm]] for sm in range(S)])
+            o["res_entries"] = np.concatenate([rent[offs[sm]:offs[sm] + rcnt[2 * sm + 1]] for sm in range(S)])
             o["packet_bits"] = int(pbits[0])
             o["packet"] = packet_bytes(pk, int(pbits[0]))
         return o

@@ -71,10 +71,7 @@ def test_kernel_bodies_match_reference(ch, quality):
     seen = 0
     for pcm, lW, W, nW in random_blocks(e, int(quality * 10) + ch):
         cap = em.L.emul_packet_capacity(em.h, W)
-        if cap == 0:
-            assert ch == 2 and quality < 0 and W == 1   # 128 residue partitions: that packet stays on the host
-            continue
-        assert cap % 4 == 0
+        assert cap > 0 and cap % 4 == 0
         a = e.tap_block(pcm, lW, W, nW, 1 if W else 0)
         assert a["packet_matches_real"]
         g = em.analyze_block(pcm, lW, W, nW, 1 if W else 0)
@@ -99,11 +96,13 @@ def test_kernel_bodies_match_reference_managed(ch, rates):
 
 
 @needs_ref
-def test_uncovered_mode_reports_no_capacity():
-    """Coupling switched off: a type-1 residue over two channels, not searched on the GPU -> no device packets."""
+def test_capacity_of_every_libvorbisenc_layout():
+    """Every layout libvorbisenc sets up at 44.1 kHz has its packets assembled on the device: uncoupled stereo
+    (a type-1 residue over two channels), the 4096-sample blocks of q < 0 (128 partitions), 5.1, mono."""
     from tests.emul.emul import Emul
-    em = Emul(ref.RefEncoder(2, 44100, 0.4, coupled=False).pack_setup())
-    assert em.L.emul_packet_capacity(em.h, 0) == 0 and em.L.emul_packet_capacity(em.h, 1) == 0
+    for ch, q, coupled in ((2, 0.4, False), (2, -0.1, True), (6, 0.4, True), (6, 0.9, True), (1, 0.3, True)):
+        em = Emul(ref.RefEncoder(ch, 44100, q, coupled=coupled).pack_setup())
+        assert em.L.emul_packet_capacity(em.h, 0) > 0 and em.L.emul_packet_capacity(em.h, 1) > 0, (ch, q, coupled)
 
 
 # ------------------------------------------------------------------------------------------

@@ -75,7 +75,7 @@ def test_hybrid_encode(rate, ch, q):
 
 
 # ---- stereo with channel coupling switched off (vorbis_encode_ctl OV_ECTL_COUPLING_SET = 0):
-# coupling_steps == 0, residue type 1 over two channels (that residue stays on the host) ----------
+# coupling_steps == 0, residue type 1 over two channels (each coded on its own) ----------
 @pytest.mark.parametrize("q", [0.1, 0.4, 0.9])
 def test_uncoupled_stereo_port_and_kernel_bodies(q):
     from tests.emul.emul import Emul
@@ -87,7 +87,9 @@ def test_uncoupled_stereo_port_and_kernel_bodies(q):
         assert a["packet_matches_real"]
         assert checker.compare_block(a, p.tap_block(*args), e.floor_posts(W), verbose=True) == 0
         g = em.analyze_block(*args)
-        assert checker.compare_block(a, g, e.floor_posts(W), verbose=True) == 0 and "res_class" not in g
+        assert checker.compare_block(a, g, e.floor_posts(W), verbose=True) == 0
+        assert np.array_equal(a["res_class"], g["res_class"]) and np.array_equal(a["res_entries"], g["res_entries"])
+        assert a["packet"] == g["packet"]
 
 
 @pytest.mark.gpu

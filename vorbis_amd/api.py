@@ -18,7 +18,7 @@ EXPORTED_SYMBOLS = ["vamd_create", "vamd_destroy", "vamd_last_error", "vamd_set_
                     "vamd_analyze_batch", "vamd_analyze_stream", "vamd_analyze_block", "vamd_profile",
                     "vamd_stage_ms", "vamd_debug_cycles", "vamd_analyze_stream_mixed", "vamd_envelope_search_batch",
                     "vamd_envelope_search", "vamd_envelope_geometry", "vamd_residue_capacity", "vamd_analyze_block_res", "vamd_analyze_batch_managed", "vamd_analyze_block_managed",
-                    "vamd_packet_capacity", "vamd_encode_block"]
+                    "vamd_packet_capacity", "vamd_encode_block", "vamd_submaps", "vamd_residue_offset"]
 PACKETBLOBS = 15
 
 _vp = C.c_void_p
@@ -32,7 +32,8 @@ class _Desc(C.Structure):
 
 _IO_FIELDS = ["pcm", "mdct_raw", "logfft", "logmdct", "noise", "tone", "logmask", "mdct", "posts", "post_valid",
               "ilogmask", "iwork", "nonzero", "local_ampmax", "ampmax_out", "res_class", "res_entries", "res_count"]
-RES_CLASS_STRIDE = 64
+RES_CLASS_STRIDE = 256
+MAX_CH = 6
 
 
 class _IO(C.Structure):
@@ -101,6 +102,8 @@ def load_library():
     L.vamd_analyze_batch_managed.argtypes = [_vp, C.POINTER(_Desc), C.POINTER(_IO), C.POINTER(_MIO)]
     L.vamd_analyze_block_managed.argtypes = [_vp, C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_float] + [_vp] * 9
     L.vamd_packet_capacity.argtypes = [_vp, C.c_int]
+    L.vamd_submaps.argtypes = [_vp, C.c_int]
+    L.vamd_residue_offset.argtypes = [_vp, C.c_int, C.c_int]
     L.vamd_encode_block.argtypes = [_vp, C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _vp, _vp,
                                     C.c_long, _vp]
     L.vamd_profile.argtypes = [_vp, C.c_int]
@@ -237,12 +240,12 @@ class Analyzer:
                 o[k] = t.empty((nb, ch), dtype=t.float32, device=dev)
             elif k == "ampmax_out":
                 o[k] = t.empty((nb,), dtype=t.float32, device=dev)
-            elif k == "res_class":
-                o[k] = t.zeros((nb, RES_CLASS_STRIDE), dtype=t.int32, device=dev)
+            elif k == "res_class":   # (modes with two submaps: one more axis, [nb, 2, ...], here and in res_count)
+                o[k] = t.zeros((nb,) + self._sub(W) + (RES_CLASS_STRIDE,), dtype=t.int32, device=dev)
             elif k == "res_entries":
                 o[k] = t.zeros((nb, self.residue_capacity(W)), dtype=t.int16, device=dev)  # uint16 payload
             elif k == "res_count":
-                o[k] = t.zeros((nb, 2), dtype=t.int32, device=dev)
+                o[k] = t.zeros((nb,) + self._sub(W) + (2,), dtype=t.int32, device=dev)
             elif k == "packets":
                 o[k] = t.zeros((nb, self.packet_capacity(W)), dtype=t.uint8, device=dev)
             elif k == "packet_bits":
@@ -250,6 +253,23 @@ class Analyzer:
             else:
                 raise KeyError(k)
         return o
+
+    def submaps(self, W):
+        return int(self.L.vamd_submaps(self.h, W))
+
+    def _sub(self, W):
+        S = self.submaps(W)
+        return (S,) if S > 1 else ()
+
+    def residue_lists(self, W, cls, ent, cnt):
+        """One block's residue rows -> (classes, entries) with the submaps one after the other, the order the
+        reference classifies / emits them in.  cls / ent / cnt: numpy rows of res_class / res_entries / res_count."""
+        S = self.submaps(W)
+        cls, cnt = np.asarray(cls).reshape(S, RES_CLASS_STRIDE), np.asarray(cnt).reshape(S, 2)
+        ent = np.asarray(ent).view(np.uint16)
+        offs = [int(self.L.vamd_residue_offset(self.h, W, sm)) for sm in range(S)]
+        return (np.concatenate([cls[sm, :cnt[sm, 0]] for sm in range(S)]),
+                np.concatenate([ent[offs[sm]:offs[sm] + cnt[sm, 1]] for sm in range(S)]))
 
     def residue_capacity(self, W):
         """Row length of res_entries for size class W; 0 when the GPU does not cover this mode's residue."""
@@ -354,13 +374,14 @@ class Analyzer:
         self._bind_stream()
         cap = self.residue_capacity(W)
         if cap > 0:  # the residue back-end's decisions ride along where the mode is covered
-            rcls, rent, rcnt = np.zeros(RES_CLASS_STRIDE, np.int32), np.zeros(cap, np.uint16), np.zeros(2, np.int32)
+            S = self.submaps(W)
+            rcls, rent, rcnt = np.zeros(S * RES_CLASS_STRIDE, np.int32), np.zeros(cap, np.uint16), np.zeros(2 * S, np.int32)
             self._check(self.L.vamd_analyze_block_res(
                 self.h, ptrs, lW, W, nW, blocktype, ampmax_in, _vp(o["mdct"].ctypes.data), _vp(o["logmask"].ctypes.data),
                 _vp(o["posts"].ctypes.data), _vp(o["post_valid"].ctypes.data), _vp(o["iwork"].ctypes.data),
                 _vp(o["nonzero"].ctypes.data), C.cast(C.byref(amp), _vp), _vp(rcls.ctypes.data), _vp(rent.ctypes.data),
                 _vp(rcnt.ctypes.data)))
-            o["res_class"], o["res_entries"] = rcls[:rcnt[0]].copy(), rent[:rcnt[1]].copy()
+            o["res_class"], o["res_entries"] = self.residue_lists(W, rcls, rent, rcnt)
         else:
             self._check(self.L.vamd_analyze_block(self.h, ptrs, lW, W, nW, blocktype, ampmax_in,
                                                   _vp(o["mdct"].ctypes.data), _vp(o["logmask"].ctypes.data),
@@ -389,9 +410,9 @@ class Analyzer:
               "iwork": t.empty((nb, PACKETBLOBS, ch, n2), dtype=t.int32, device=dev),
               "nonzero": t.empty((nb, PACKETBLOBS, ch), dtype=t.int32, device=dev)}
         if residue:
-            mo["res_class"] = t.zeros((nb, PACKETBLOBS, RES_CLASS_STRIDE), dtype=t.int32, device=dev)
+            mo["res_class"] = t.zeros((nb, PACKETBLOBS) + self._sub(W) + (RES_CLASS_STRIDE,), dtype=t.int32, device=dev)
             mo["res_entries"] = t.zeros((nb, PACKETBLOBS, self.residue_capacity(W)), dtype=t.int16, device=dev)
-            mo["res_count"] = t.zeros((nb, PACKETBLOBS, 2), dtype=t.int32, device=dev)
+            mo["res_count"] = t.zeros((nb, PACKETBLOBS) + self._sub(W) + (2,), dtype=t.int32, device=dev)
         if packets:  # (+ `m_packets` [nb,15,packet_capacity] uint8, `m_packet_bits` [nb,15])
             mo["packets"] = t.zeros((nb, PACKETBLOBS, self.packet_capacity(W)), dtype=t.uint8, device=dev)
             mo["packet_bits"] = t.zeros((nb, PACKETBLOBS), dtype=t.int32, device=dev)
@@ -419,9 +440,10 @@ class Analyzer:
                  m_nonzero=np.empty((PACKETBLOBS, ch), np.int32))
         amp = C.c_float(0)
         cap = self.residue_capacity(W)
-        rcls = np.zeros((PACKETBLOBS, RES_CLASS_STRIDE), np.int32)
+        S = self.submaps(W)
+        rcls = np.zeros((PACKETBLOBS, S * RES_CLASS_STRIDE), np.int32)
         rent = np.zeros((PACKETBLOBS, max(cap, 1)), np.uint16)
-        rcnt = np.zeros((PACKETBLOBS, 2), np.int32)
+        rcnt = np.zeros((PACKETBLOBS, 2 * S), np.int32)
         rp = [_vp(rcls.ctypes.data), _vp(rent.ctypes.data), _vp(rcnt.ctypes.data)] if cap > 0 else [None, None, None]
         self._bind_stream()
         self._check(self.L.vamd_analyze_block_managed(
@@ -430,8 +452,9 @@ class Analyzer:
             _vp(o["m_nonzero"].ctypes.data), *rp))
         o["ampmax_out"] = amp.value
         if cap > 0:
-            o["m_res_class"] = [rcls[k, :rcnt[k, 0]].copy() for k in range(PACKETBLOBS)]
-            o["m_res_entries"] = [rent[k, :rcnt[k, 1]].copy() for k in range(PACKETBLOBS)]
+            lists = [self.residue_lists(W, rcls[k], rent[k], rcnt[k]) for k in range(PACKETBLOBS)]
+            o["m_res_class"] = [l[0] for l in lists]
+            o["m_res_entries"] = [l[1] for l in lists]
         return o
 
     def encode_block(self, pcm, lW=1, W=1, nW=1, blocktype=BLOCKTYPE_LONG, ampmax_in=-9999.0, managed=False):
@@ -493,7 +516,7 @@ class Analyzer:
 class EnvelopeState(C.Structure):
     """vamd_envelope_state (include/vorbis_amd.h); all-zero = start of a stream."""
     _fields_ = [("steps", C.c_int64), ("stretch", C.c_int32), ("pad", C.c_int32),
-                ("near_hist", C.c_float * 30 * 2), ("amp_hist", C.c_float * 8 * 16 * 2)]
+                ("near_hist", C.c_float * 30 * MAX_CH), ("amp_hist", C.c_float * 8 * 16 * MAX_CH)]
 
 
 def envelope_marks(ret, first=0, marks=None):

@@ -172,6 +172,7 @@ VAMD_DEV float couple_bin(ChanBin &M, ChanBin &A, int &iM, int &iA, int b, int n
 // ilogmask[k]  HBM [n2]  integer floor curve (floor1_encode's output)
 // iwork[k]     HBM [n2]  out: quantised (and coupled) residue
 // nonzero      [ch] in: floor1_encode's return per channel; out: after the coupling fix-up
+// (one or two channels, at most one coupling step: every stereo and mono setup)
 VAMD_DEV void couple_block(const CoupleP &C, const PsyP &P, int n2, const float *const *mdct,
                            const int *const *ilogmask, int *const *iwork, int *nonzero, const CoupleLds &L,
                            PhaseClock &pc) {
@@ -182,13 +183,13 @@ VAMD_DEV void couple_block(const CoupleP &C, const PsyP &P, int n2, const float 
   const int nparts = (n2 + partition - 1) / partition;
   int nz[VAMD_MAX_CH];
   for (int k = 0; k < ch; k++) nz[k] = nonzero[k];
-  const bool coupled = C.coupling_steps == 1 && (nz[C.mag] || nz[C.ang]);
+  const bool coupled = C.coupling_steps == 1 && (nz[C.mag[0]] || nz[C.ang[0]]);
 
   if (!norm_active) {
     // Common case (noise normalisation inactive in this block size, e.g. q >= 0.4 at
     // 44.1 kHz): nothing is ordered, so each lane takes quads of bins straight through
     // quantise -> couple -> re-normalise with one 16-byte load per input tensor.
-    const int Mi = C.coupling_steps == 1 ? C.mag : 0, Ai = C.coupling_steps == 1 ? C.ang : (ch > 1 ? 1 : 0);
+    const int Mi = C.coupling_steps == 1 ? C.mag[0] : 0, Ai = C.coupling_steps == 1 ? C.ang[0] : (ch > 1 ? 1 : 0);
     WAVE_FOR(q, n2 >> 2) {
       float m0[4], m1[4];
       int l0[4], l1[4], o0[4], o1[4];
@@ -224,7 +225,7 @@ VAMD_DEV void couple_block(const CoupleP &C, const PsyP &P, int n2, const float 
       }
     }
     pc.mark(0);
-    if (coupled) nz[C.mag] = nz[C.ang] = 1;  // lib/psy.c:1204-1212
+    if (coupled) nz[C.mag[0]] = nz[C.ang[0]] = 1;  // lib/psy.c:1204-1212
     for (int k = 0; k < ch; k++) nonzero[k] = nz[k];
     pc.mark(1);
     return;
@@ -253,7 +254,7 @@ VAMD_DEV void couple_block(const CoupleP &C, const PsyP &P, int n2, const float 
   pc.mark(0);
   // ---- coupling (one step: magnitude Mi, angle Ai), lib/psy.c:1111-1201
   if (coupled) {
-    const int Mi = C.mag, Ai = C.ang;
+    const int Mi = C.mag[0], Ai = C.ang[0];
     WAVE_FOR(b, n2) {
       // rebuild the per-bin state the first pass had (cheaper than keeping it in LDS)
       ChanBin M = chan_bin(nz[Mi], nz[Mi] ? mdct[Mi][b] : 0.f, nz[Mi] ? ilogmask[Mi][b] : 0, b, nstart, C);
@@ -277,6 +278,122 @@ VAMD_DEV void couple_block(const CoupleP &C, const PsyP &P, int n2, const float 
   }
   for (int k = 0; k < ch; k++) nonzero[k] = nz[k];
   pc.mark(1);
+}
+
+// ---- any channel count, any number of coupling steps (the 5.1 layout: six channels, four steps, the
+// left channel the magnitude of three of them; lib/psy.c:1111-1201 "depth>1 coupling").
+// Per bin the steps are a fixed sequence of couple_bin() calls on the channels' running state; the only
+// thing one bin needs from its neighbours is the outcome of noise normalisation's sort for bins that
+// were candidates in an earlier step.  So every step is: per bin, REPLAY the prefill and the earlier
+// steps (taking candidates' outcomes from a snapshot of what the sort left), run this step, hand the
+// new candidates to the per-partition sort, snapshot.  Without noise normalisation in the block there
+// are no candidates and one replay of all steps does everything.
+//   pre   [ch][n2]   the channels' integers after the prefill (and its sort)
+//   snap  [steps][n2] the magnitude channel's integers after each step's sort
+struct CoupleGeneralLds {
+  CoupleLds L;
+  int *pre, *snap;
+};
+
+// state of every channel of bin b after the prefill and coupling steps [0, upto]; returns step upto's
+// noise-norm candidate energy for its magnitude channel (or -1)
+VAMD_DEV float couple_replay(const CoupleP &C, int ch, const int *nz0, int b, int n2, int nstart,
+                             const float *const *mdct, const int *const *ilogmask, const int *pre, const int *snap,
+                             int upto, ChanBin *st, int *io) {
+  int nzl[VAMD_MAX_CH];
+  for (int k = 0; k < ch; k++) {
+    nzl[k] = nz0[k];
+    st[k] = chan_bin(nz0[k], nz0[k] ? mdct[k][b] : 0.f, nz0[k] ? ilogmask[k][b] : 0, b, nstart, C);
+    io[k] = pre ? pre[k * n2 + b] : st[k].out;
+    // what noise_normalize leaves in quant[] past normal_start: out*out*floor, or floor / 0 for a promoted /
+    // dropped candidate -- all three are out*out*floor (lib/psy.c:985,998-1003)
+    if (nz0[k] && b >= nstart) st[k].qe = (float)(io[k] * io[k]) * st[k].fl2;
+  }
+  float cand = -1.f;
+  for (int t = 0; t <= upto; t++) {
+    const int Mi = C.mag[t], Ai = C.ang[t];
+    if (!(nzl[Mi] || nzl[Ai])) continue;  // lib/psy.c:1125
+    nzl[Mi] = nzl[Ai] = 1;
+    cand = couple_bin(st[Mi], st[Ai], io[Mi], io[Ai], b, nstart, C);
+    if (t < upto) {
+      if (cand >= 0.f) io[Mi] = snap[t * n2 + b];
+      if (b >= nstart && !st[Mi].fg) st[Mi].qe = (float)(io[Mi] * io[Mi]) * st[Mi].fl2;
+    }
+  }
+  return cand;
+}
+
+VAMD_DEV void couple_block_general(const CoupleP &C, const PsyP &P, int n2, const float *const *mdct,
+                                   const int *const *ilogmask, int *const *iwork, int *nonzero,
+                                   const CoupleGeneralLds &G, PhaseClock &pc) {
+  const int ch = C.ch, steps = C.coupling_steps;
+  const CoupleLds &L = G.L;
+  const int partition = P.normal_p ? P.normal_partition : 16;
+  const int nstart = P.normal_p ? P.normal_start : 0x7fffffff;
+  const bool norm_active = nstart < n2;
+  const int nparts = (n2 + partition - 1) / partition;
+  int nz[VAMD_MAX_CH];
+  for (int k = 0; k < ch; k++) nz[k] = nonzero[k];
+
+  if (!norm_active) {
+    WAVE_FOR(b, n2) {
+      ChanBin st[VAMD_MAX_CH];
+      int io[VAMD_MAX_CH];
+      couple_replay(C, ch, nz, b, n2, nstart, mdct, ilogmask, nullptr, nullptr, steps - 1, st, io);
+      for (int k = 0; k < ch; k++) iwork[k][b] = io[k];
+    }
+  } else {
+    // prefill: per channel, first quantisation and its sort
+    for (int k = 0; k < ch; k++) {
+      WAVE_FOR(b, n2) {
+        const ChanBin B = chan_bin(nz[k], nz[k] ? mdct[k][b] : 0.f, nz[k] ? ilogmask[k][b] : 0, b, nstart, C);
+        iwork[k][b] = B.out;
+        L.cand[b] = B.cand;
+        L.key[b] = B.qe;
+        L.sgn[b] = B.re;
+      }
+      WAVE_SYNC_GLOBAL();
+      if (nz[k]) {
+        WAVE_FOR(p, nparts) {
+          const int b0 = p * partition;
+          noise_norm_partition(P, L, b0, partition > n2 - b0 ? n2 - b0 : partition, iwork[k]);
+        }
+        WAVE_SYNC_GLOBAL();
+      }
+      WAVE_FOR(b, n2) G.pre[k * n2 + b] = iwork[k][b];
+      WAVE_SYNC();
+    }
+    pc.mark(0);
+    int nzl[VAMD_MAX_CH];
+    for (int k = 0; k < ch; k++) nzl[k] = nz[k];
+    for (int t = 0; t < steps; t++) {
+      const int Mi = C.mag[t], Ai = C.ang[t];
+      if (!(nzl[Mi] || nzl[Ai])) continue;
+      nzl[Mi] = nzl[Ai] = 1;
+      WAVE_FOR(b, n2) {
+        ChanBin st[VAMD_MAX_CH];
+        int io[VAMD_MAX_CH];
+        const float cand = couple_replay(C, ch, nz, b, n2, nstart, mdct, ilogmask, G.pre, G.snap, t, st, io);
+        iwork[Mi][b] = io[Mi];
+        iwork[Ai][b] = io[Ai];
+        L.cand[b] = cand;
+        L.key[b] = st[Mi].qe;
+        L.sgn[b] = st[Mi].re;
+      }
+      WAVE_SYNC_GLOBAL();
+      WAVE_FOR(p, nparts) {
+        const int b0 = p * partition;
+        noise_norm_partition(P, L, b0, partition > n2 - b0 ? n2 - b0 : partition, iwork[Mi]);
+      }
+      WAVE_SYNC_GLOBAL();
+      WAVE_FOR(b, n2) G.snap[t * n2 + b] = iwork[Mi][b];
+      WAVE_SYNC();
+    }
+  }
+  pc.mark(1);
+  for (int t = 0; t < steps; t++)  // lib/psy.c:1204-1212, in step order
+    if (nz[C.mag[t]] || nz[C.ang[t]]) nz[C.mag[t]] = nz[C.ang[t]] = 1;
+  for (int k = 0; k < ch; k++) nonzero[k] = nz[k];
 }
 
 }  // namespace vamd

@@ -81,13 +81,13 @@ VAMD_DEV int floor_subclass(const PackP &K, const vamd_floor1_tab &f, int cls, i
 }
 
 // One channel's floor1_encode writes.  outv LDS [VAMD_POSTS_STRIDE].
-VAMD_DEV void pack_floor(const PackP &K, const FloorP &F, const int *__restrict__ posts, int valid, int *outv,
+VAMD_DEV void pack_floor(const PackP &K, int sm, const FloorP &F, const int *__restrict__ posts, int valid, int *outv,
                          BitRing &r) {
   if (!valid) {  // "oggpack_write(opb,0,1)", lib/floor1.c:948-952
     ring_put(r, 0u, LANE == 0 ? 1 : 0);
     return;
   }
-  const vamd_floor1_tab &f = *K.ftab;
+  const vamd_floor1_tab &f = *K.ftab[sm];
   {
     LaneInts fitted, postlist, post, wrapped;
     fitted.load(posts, F.posts);
@@ -100,7 +100,7 @@ VAMD_DEV void pack_floor(const PackP &K, const FloorP &F, const int *__restrict_
   // the nontrivial-floor flag and the two end posts (:833-841)
   for (int t0 = 0; t0 < 3; t0 += NLANES) {
     const int t = t0 + LANE;
-    ring_put(r, t == 0 ? 1u : (unsigned)outv[t < 3 ? t - 1 : 0], t == 0 ? 1 : (t < 3 ? K.qbits : 0));
+    ring_put(r, t == 0 ? 1u : (unsigned)outv[t < 3 ? t - 1 : 0], t == 0 ? 1 : (t < 3 ? K.qbits[sm] : 0));
   }
   // partition by partition (:845-917): slot 0 of a partition is its cascade word, slots 1..8 its posts
   const int slots = f.partitions * 9;
@@ -131,49 +131,52 @@ VAMD_DEV void pack_floor(const PackP &K, const FloorP &F, const int *__restrict_
 }
 
 // The residue of one submap (lib/res0.c:534-640 with the search already done).
-//   res_class / res_entries / res_count: what residue2_block left (k_residue.h)
-//   cls LDS [partvals]; off LDS [stages*partvals + 1]; info LDS [stages*partvals]
+//   res_class / res_entries / res_count: what residue_block left for this submap (k_residue.h)
+//   cls LDS [slots]; off LDS [stages*slots + 1]; info LDS [stages*slots]
 VAMD_DEV void pack_residue(const PackP &K, const ResP &R, const int *__restrict__ res_class,
                            const unsigned short *__restrict__ res_entries, const int *__restrict__ res_count,
                            int *cls, int *off, int *info, BitRing &r) {
   const vamd_residue_tab &t = *R.tab;
-  const int partvals = res_count[0];
-  if (partvals <= 0) return;  // nothing to code: res*_forward writes nothing
-  WAVE_FOR(i, partvals) cls[i] = res_class[i];
+  const int slots = res_count[0];
+  if (slots <= 0) return;  // nothing to code: res*_forward writes nothing
+  const int partvals = R.partvals, ns = slots / partvals;  // streams: 1 (type 2) or the coded channels (type 1)
+  WAVE_FOR(i, slots) cls[i] = res_class[i];
   WAVE_SYNC();
-  residue_offsets(R, partvals, cls, off, info);
-  const int ppw = t.groupbook_dim, groups = (partvals + ppw - 1) / ppw;
+  residue_offsets(R, slots, cls, off, info);
+  const int ppw = t.groupbook_dim;
   for (int s = 0; s < t.stages; s++) {
-    const int *so = off + s * partvals;
+    const int *so = off + s * slots;
     const int base = so[0];
-    const int total = so[partvals] - base + (s == 0 ? groups : 0);  // stage 0 also carries the phrase words
+    // stage 0 also carries the phrase words: one per stream ahead of every group of ppw partitions
+    const int total = so[slots] - base + (s == 0 ? ns * ((partvals + ppw - 1) / ppw) : 0);
     for (int v0 = 0; v0 < total; v0 += NLANES) {
       const int v = v0 + LANE;
       unsigned code = 0;
       int len = 0;
       if (v < total) {
-        // fields are numbered in emission order; partition i's start at so[i]-base plus, in stage 0,
-        // one phrase word per group of ppw partitions begun before or at it
-        int lo = 0, hi = partvals - 1;
+        // fields are numbered in emission order; slot q = (partition i, stream j)'s start at so[q]-base
+        // plus, in stage 0, the phrase words of the groups begun before it (its own group's once j > 0)
+        int lo = 0, hi = slots - 1;
         while (lo < hi) {
           const int mid = (lo + hi + 1) >> 1;
-          const int at = so[mid] - base + (s == 0 ? (mid + ppw - 1) / ppw : 0);
+          const int mi = mid / ns, mj = mid - mi * ns;
+          const int at = so[mid] - base + (s == 0 ? ns * ((mi + (mj > 0) + ppw - 1) / ppw) : 0);
           if (at <= v) lo = mid; else hi = mid - 1;
         }
-        const int i = lo;
-        int k = v - (so[i] - base + (s == 0 ? (i + ppw - 1) / ppw : 0));
-        const bool leads = s == 0 && i % ppw == 0;
-        if (leads && k == 0) {  // the group's classes as one number, lib/res0.c:589-598
-          int val = cls[i];
-          for (int q = 1; q < ppw; q++) {
+        const int q = lo, i = q / ns, j = q - i * ns;
+        int k = v - (so[q] - base + (s == 0 ? ns * ((i + (j > 0) + ppw - 1) / ppw) : 0));
+        const bool leads = s == 0 && j == 0 && i % ppw == 0;
+        if (leads && k < ns) {  // stream k's classes of the group as one number, lib/res0.c:589-598
+          int val = cls[i * ns + k];
+          for (int p = 1; p < ppw; p++) {
             val *= t.partitions;
-            if (i + q < partvals) val += cls[i + q];
+            if (i + p < partvals) val += cls[(i + p) * ns + k];
           }
           book_word(K, t.groupbook, val, code, len);
         } else {
-          if (leads) k--;
-          const int e = so[i] + k;
-          book_word(K, info[s * partvals + i], e < R.cap ? (int)res_entries[e] : -1, code, len);
+          if (leads) k -= ns;
+          const int e = so[q] + k;
+          book_word(K, info[s * slots + q], e < R.cap ? (int)res_entries[e] : -1, code, len);
         }
       }
       ring_put(r, code, len);
@@ -181,12 +184,13 @@ VAMD_DEV void pack_residue(const PackP &K, const ResP &R, const int *__restrict_
   }
 }
 
-// One packet: header, the channels' floors, the residue.
+// One packet: header, the channels' floors, the submaps' residues.
 //   posts [ch][VAMD_POSTS_STRIDE], post_valid [ch]  as floor_encode_render left them
+//   res_class [submaps][VAMD_RES_CLASS_STRIDE], res_entries [row], res_count [submaps][2]: one block's rows
 //   packet HBM [out_words] words; bits_out <- oggpack_bits()
 //   LDS: ring [VAMD_PK_RING] zeroed here, outv [VAMD_POSTS_STRIDE], cls/off/info as pack_residue
-VAMD_DEV void pack_block(const PackP &K, const FloorP &F, const ResP &R, int ch, int W, int lW, int nW,
-                         const int *__restrict__ posts, const int *__restrict__ post_valid,
+VAMD_DEV void pack_block(const PackP &K, const FloorP *F /*[submaps]*/, const ResP *R /*[submaps]*/, const ChMap &cm, int ch,
+                         int W, int lW, int nW, const int *__restrict__ posts, const int *__restrict__ post_valid,
                          const int *__restrict__ res_class, const unsigned short *__restrict__ res_entries,
                          const int *__restrict__ res_count, int *ring, int *outv, int *cls, int *off, int *info,
                          unsigned *__restrict__ packet, int out_words, int *__restrict__ bits_out) {
@@ -208,8 +212,12 @@ VAMD_DEV void pack_block(const PackP &K, const FloorP &F, const ResP &R, int ch,
     }
     ring_put(r, hdr, LANE == 0 ? len : 0);
   }
-  for (int c = 0; c < ch; c++) pack_floor(K, F, posts + c * VAMD_POSTS_STRIDE, post_valid[c], outv, r);
-  pack_residue(K, R, res_class, res_entries, res_count, cls, off, info, r);
+  for (int c = 0; c < ch; c++) {
+    const int sm = cm.sub[c];
+    pack_floor(K, sm, F[sm], posts + c * VAMD_POSTS_STRIDE, post_valid[c], outv, r);
+  }
+  for (int sm = 0; sm < cm.submaps; sm++)
+    pack_residue(K, R[sm], res_class + R[sm].cls_base, res_entries + R[sm].ent_base, res_count + 2 * sm, cls, off, info, r);
   ring_flush(r, (r.bitpos + 31) >> 5);
   if (LANE == 0) *bits_out = (int)r.bitpos;
 }

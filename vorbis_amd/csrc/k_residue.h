@@ -1,12 +1,11 @@
 // k_residue.h -- the residue back-end's numeric half: partition classes and the lattice-VQ search
-// for type-2 residues (channels interleaved: res2_class / res2_forward) and single-channel type-1
-// residues (res1_class / res1_forward) (reference lib/res0.c: _2class :479-532, _01class :412-470,
-// res2_forward :783-809, _01forward :534-640, _encodepart :384-410, local_book_besterror :322-382);
-// SURVEY.md 8f rank 2.  What stays on the host is the serial
-// part: looking each chosen entry's codeword up and writing its bits (vorbis_book_encode), and
-// the phrase-book words.
+// for type-2 residues (a bundle's channels interleaved: res2_class / res2_forward) and type-1
+// residues (every coded channel on its own: res1_class / res1_forward) (reference lib/res0.c:
+// _2class :479-532, _01class :412-470, res1_forward :729-746, res2_forward :783-809, _01forward
+// :534-640, _encodepart :384-410, local_book_besterror :322-382); SURVEY.md 8f rank 2.  Looking the
+// chosen entries' codewords up and packing them, with the phrase-book words, is k_pack.h.
 //
-// One wave per block.  A partition's class needs only its own 2 x 16 values; a (partition,
+// One wave per block and submap.  A partition's class needs only its own 2 x 16 values; a (partition,
 // stage, vector) search touches only its own `dim` values of the running work vector and is
 // integer arithmetic, so within a stage all vectors of all partitions are searched at once and
 // the stages -- which refine the same values -- follow each other with a wave sync.  Entries are
@@ -83,8 +82,8 @@ VAMD_DEV int residue_besterror(const ResP &R, const vamd_book_tab &bk, int *a) {
   return index;
 }
 
-// Emission offsets of a block's codebook entries, (stage, partition) order, from the partition
-// classes: off[s*partvals + i] = entries written before partition i's stage-s vectors,
+// Emission offsets of a block's codebook entries, (stage, slot) order, from the slots' classes
+// (`partvals` = number of slots): off[s*partvals + i] = entries written before slot i's stage-s vectors,
 // off[stages*partvals] = the total (returned); `info` keeps each pair's book (-1 = the class skips
 // the stage) so that nothing downstream goes back to the class tables.  cls/off/info in LDS.
 VAMD_DEV int residue_offsets(const ResP &R, int partvals, const int *cls, int *off, int *info) {
@@ -111,32 +110,54 @@ VAMD_DEV int residue_offsets(const ResP &R, int partvals, const int *cls, int *o
   return carry;
 }
 
-//   iwork[c]   HBM [n2]   quantised (and coupled) residue of channel c
-//   work       LDS [ch*n2]; cls LDS [partvals]; off LDS [stages*partvals + 1]; info LDS [stages*partvals]
-//   class_out  HBM [VAMD_RES_CLASS_STRIDE]; entries_out HBM [R.cap]; count_out HBM [2] = {partvals, entries}
-VAMD_DEV void residue2_block(const ResP &R, int ch, int n2, const int *const *iwork, const int *nonzero, int *work,
-                             int *cls, int *off, int *info, int *__restrict__ class_out, unsigned short *__restrict__ entries_out,
-                             int *__restrict__ count_out, PhaseClock &pc) {
+// One submap's residue: classification and search.
+//   iwork[c]   HBM [n2]   quantised (and coupled) residue of the bundle's channel c; nonzero[c] its flag
+//   work       LDS [bundle*n2]; cls LDS [slots]; off LDS [stages*slots + 1]; info LDS [stages*slots]
+//   class_out  HBM [VAMD_RES_CLASS_STRIDE]; entries_out HBM [R.cap]; count_out HBM [2] = {classes, entries}
+// A type-2 residue codes the bundle's channels interleaved as ONE stream (res2_class / res2_forward);
+// type 1 codes every channel whose floor is not all zero as a stream of its own (res1_class /
+// res1_forward, lib/res0.c:729-762), and _01forward then walks (stage, partition, stream, vector): a
+// "slot" below is a (partition, stream) pair, numbered partition-major.
+VAMD_DEV void residue_block(const ResP &R, int n2, const int *const *iwork, const int *nonzero, int *work, int *cls, int *off,
+                            int *info, int *__restrict__ class_out, unsigned short *__restrict__ entries_out,
+                            int *__restrict__ count_out, PhaseClock &pc) {
   const vamd_residue_tab &t = *R.tab;
-  const int spp = t.grouping, nparts = t.partitions, partvals = (t.end - t.begin) / spp, stages = t.stages;
-  int used = 0;
-  for (int c = 0; c < ch; c++) used |= nonzero[c];
-  if (!used) {  // res2_class returns NULL and res2_forward writes nothing (:766-777,:799-808)
+  const int ch = R.bundle, spp = t.grouping, nparts = t.partitions, partvals = R.partvals, stages = t.stages;
+  int ns = 0;  // streams
+  if (t.type == 2) {
+    int used = 0;
+    for (int c = 0; c < ch; c++) used |= nonzero[c];
+    ns = used ? 1 : 0;
+  } else {
+    for (int c = 0; c < ch; c++) ns += nonzero[c] ? 1 : 0;
+  }
+  if (!ns) {  // res*_class returns NULL and res*_forward writes nothing (:740-744,:766-777,:799-808)
     if (LANE == 0) {
       count_out[0] = 0;
       count_out[1] = 0;
     }
     return;
   }
-  // the interleaved work vector of res2_forward (:791-797)
-  WAVE_FOR(j, n2)
-    for (int c = 0; c < ch; c++) work[j * ch + c] = iwork[c][j];
+  if (t.type == 2) {
+    // the interleaved work vector of res2_forward (:791-797)
+    WAVE_FOR(j, n2)
+      for (int c = 0; c < ch; c++) work[j * ch + c] = iwork[c][j];
+  } else {
+    int sidx = 0;  // coded channels, packed in order (:738-739)
+    for (int c = 0; c < ch; c++)
+      if (nonzero[c]) {
+        WAVE_FOR(j, n2) work[sidx * n2 + j] = iwork[c][j];
+        sidx++;
+      }
+  }
   WAVE_SYNC();
-  // _01class with one channel (:436-453): peak against classmetric1, scaled mean against classmetric2
+  const int slots = partvals * ns;
+  // _01class (:436-453): peak against classmetric1, scaled mean against classmetric2, stream by stream
   if (t.type == 1) {
     const float scale = (float)(100. / spp);
-    WAVE_FOR(i, partvals) {
-      const int *w = work + t.begin + i * spp;
+    WAVE_FOR(q, slots) {
+      const int i = q / ns, strm = q - i * ns;
+      const int *w = work + strm * n2 + t.begin + i * spp;
       int mx = 0, ent = 0;
       for (int k = 0; k < spp; k++) {
         const int a = w[k] < 0 ? -w[k] : w[k];
@@ -147,8 +168,8 @@ VAMD_DEV void residue2_block(const ResP &R, int ch, int n2, const int *const *iw
       int k = 0;
       for (; k < nparts - 1; k++)
         if (mx <= t.classmetric1[k] && (t.classmetric2[k] < 0 || ent < t.classmetric2[k])) break;
-      cls[i] = k;
-      class_out[i] = k;
+      cls[q] = k;
+      class_out[q] = k;
     }
   }
   // _2class (:501-518): channel 0 of the bundle against classmetric1, the rest against classmetric2
@@ -170,26 +191,27 @@ VAMD_DEV void residue2_block(const ResP &R, int ch, int n2, const int *const *iw
     class_out[i] = j;
   }
   WAVE_SYNC();
-  const int carry = residue_offsets(R, partvals, cls, off, info);
+  const int carry = residue_offsets(R, slots, cls, off, info);
   if (LANE == 0) {
-    count_out[0] = partvals;
+    count_out[0] = slots;
     count_out[1] = carry;
   }
   pc.mark(0);
   // the search, stage by stage (_01forward's s loop outermost, :585).  A stage's vectors are
   // numbered densely (its slice of the emission order), so every lane has one to search.
   for (int s = 0; s < stages; s++) {
-    const int *so = off + s * partvals;
-    const int base = so[0], total = so[partvals] - base;  // (off[] is stage-major: the next stage starts there)
+    const int *so = off + s * slots;
+    const int base = so[0], total = so[slots] - base;  // (off[] is stage-major: the next stage starts there)
     WAVE_FOR(v, total) {
-      int lo = 0, hi = partvals - 1;  // the partition whose vectors include v: last i with so[i] - base <= v
+      int lo = 0, hi = slots - 1;  // the slot whose vectors include v: last q with so[q] - base <= v
       while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
         if (so[mid] - base <= v) lo = mid; else hi = mid - 1;
       }
-      const int i = lo, k = v - (so[i] - base);
-      const vamd_book_tab &bk = R.books[info[s * partvals + i]];
-      const int entry = residue_besterror(R, bk, work + t.begin + i * spp + k * bk.dim);
+      const int q = lo, k = v - (so[q] - base);
+      const int i = q / ns, strm = q - i * ns;
+      const vamd_book_tab &bk = R.books[info[s * slots + q]];
+      const int entry = residue_besterror(R, bk, work + strm * n2 + t.begin + i * spp + k * bk.dim);
       if (base + v < R.cap) entries_out[base + v] = (unsigned short)entry;
     }
     WAVE_SYNC();

@@ -20,13 +20,16 @@ struct Bound {
   int bs[2];
   XformP xf[2];
   PsyP psy[4];
-  FloorP floor[2];
+  FloorP floor[2][VAMD_MAX_SUBMAPS];
+  ChMap chmap[2];
   CoupleP couple[2];
   CoupleSet couple_all[2];
   EnvP env;
-  ResP res[2];
+  ResP res[2][VAMD_MAX_SUBMAPS];
   PackP pack[2];
-  int res_stages[2], res_partvals[2];
+  int res_cap[2];         // entries per block over all submaps (row length of res_entries); 0 = not covered
+  int res_lds_ints[2];    // LDS ints k_residue needs for the largest submap of the mode
+  int res_off_ints[2];    // largest stages*slots + 1 over the mode's submaps (k_pack's offset arrays)
   float ampmax_att_per_sec;
 };
 
@@ -78,17 +81,30 @@ inline int build_image(const void *blob_v, size_t bytes, std::vector<unsigned ch
         return VAMD_EIMPL;
       }
     const vamd_mode_tab &m = h.mode[W];
-    if (m.submaps != 1 || m.coupling_steps < 0 || m.coupling_steps > 1) {
-      *err = "only single-submap mappings with at most one coupling step are covered";
+    if (m.submaps < 1 || m.submaps > VAMD_MAX_SUBMAPS || m.coupling_steps < 0 || m.coupling_steps > VAMD_MAX_COUPLING) {
+      *err = "mapping: submaps / coupling steps out of the covered range";
       return VAMD_EIMPL;
     }
-    if (m.floor.posts < 2 || m.floor.posts > VAMD_POSTS_STRIDE) {
-      *err = "floor1 post count out of range";
-      return VAMD_EIMPL;
-    }
-    if (m.floor.look_n > x.n / 2) {
-      *err = "floor1 range exceeds the block";
-      return VAMD_EINVAL;
+    for (int i = 0; i < m.coupling_steps; i++)
+      if (m.coupling_mag[i] < 0 || m.coupling_mag[i] >= h.channels || m.coupling_ang[i] < 0 ||
+          m.coupling_ang[i] >= h.channels || m.coupling_mag[i] == m.coupling_ang[i]) {
+        *err = "mapping: coupling channel out of range";
+        return VAMD_EINVAL;
+      }
+    for (int c = 0; c < h.channels; c++)
+      if (m.chmuxlist[c] < 0 || m.chmuxlist[c] >= m.submaps) {
+        *err = "mapping: channel multiplex out of range";
+        return VAMD_EINVAL;
+      }
+    for (int sm = 0; sm < m.submaps; sm++) {
+      if (m.floor[sm].posts < 2 || m.floor[sm].posts > VAMD_POSTS_STRIDE) {
+        *err = "floor1 post count out of range";
+        return VAMD_EIMPL;
+      }
+      if (m.floor[sm].look_n > x.n / 2) {
+        *err = "floor1 range exceeds the block";
+        return VAMD_EINVAL;
+      }
     }
   }
   for (int p = 0; p < 4; p++) {
@@ -155,8 +171,9 @@ inline int build_image(const void *blob_v, size_t bytes, std::vector<unsigned ch
     *err = "setup blob: mode number width out of range";
     return VAMD_EINVAL;
   }
-  for (int W = 0; W < 2; W++) {
-    const vamd_floor1_tab &f = h.mode[W].floor;
+  for (int W = 0; W < 2; W++)
+   for (int sm = 0; sm < h.mode[W].submaps; sm++) {
+    const vamd_floor1_tab &f = h.mode[W].floor[sm];
     int covered = 2;
     bool ok = f.partitions >= 0 && f.partitions <= VAMD_FLOOR_PARTS;
     for (int i = 0; ok && i < f.partitions; i++) {
@@ -171,8 +188,9 @@ inline int build_image(const void *blob_v, size_t bytes, std::vector<unsigned ch
       return VAMD_EINVAL;
     }
   }
-  for (int W = 0; W < 2; W++) {
-    const vamd_residue_tab &r = h.res[W];
+  for (int W = 0; W < 2; W++)
+   for (int sm = 0; sm < h.mode[W].submaps; sm++) {
+    const vamd_residue_tab &r = h.res[W][sm];
     if (r.groupbook < 0 || r.groupbook >= h.nbooks || r.groupbook_dim < 1) {
       *err = "setup blob: residue phrase book out of range";
       return VAMD_EINVAL;
@@ -227,20 +245,23 @@ inline int build_image(const void *blob_v, size_t bytes, std::vector<unsigned ch
     const unsigned char *b = (const unsigned char *)d.line_group.data();
     image->insert(image->end(), b, b + 2 * d.line_group.size());
   }
-  for (int W = 0; W < 2; W++) {
-    std::vector<unsigned char> bi = derive_bin_interval(h.mode[W].floor, h.blocksizes[W] / 2);
-    while (image->size() & 15) image->push_back(0);
-    derived_off->push_back((uint32_t)image->size());
-    image->insert(image->end(), bi.begin(), bi.end());
-  }
-  for (int W = 0; W < 2; W++) {  // slots 26, 27: post levels
-    int nl = 0;
-    std::vector<int32_t> lv = derive_post_levels(h.mode[W].floor, &nl);
-    while (image->size() & 15) image->push_back(0);
-    derived_off->push_back((uint32_t)image->size());
-    const unsigned char *a = (const unsigned char *)lv.data();
-    image->insert(image->end(), a, a + 4 * lv.size());
-  }
+  for (int W = 0; W < 2; W++)
+    for (int sm = 0; sm < VAMD_MAX_SUBMAPS; sm++) {  // slots 24 + 2W + sm: bin -> fit interval, per floor
+      const vamd_floor1_tab &f = h.mode[W].floor[sm < h.mode[W].submaps ? sm : 0];
+      std::vector<unsigned char> bi = derive_bin_interval(f, h.blocksizes[W] / 2);
+      while (image->size() & 15) image->push_back(0);
+      derived_off->push_back((uint32_t)image->size());
+      image->insert(image->end(), bi.begin(), bi.end());
+    }
+  for (int W = 0; W < 2; W++)
+    for (int sm = 0; sm < VAMD_MAX_SUBMAPS; sm++) {  // slots 28 + 2W + sm: post levels
+      int nl = 0;
+      std::vector<int32_t> lv = derive_post_levels(h.mode[W].floor[sm < h.mode[W].submaps ? sm : 0], &nl);
+      while (image->size() & 15) image->push_back(0);
+      derived_off->push_back((uint32_t)image->size());
+      const unsigned char *a = (const unsigned char *)lv.data();
+      image->insert(image->end(), a, a + 4 * lv.size());
+    }
   while (image->size() & 15) image->push_back(0);
   return VAMD_OK;
 }
@@ -272,27 +293,31 @@ inline void bind_params(const std::vector<unsigned char> &image, const std::vect
     X.fft_nf = x.fft_nf;
     for (int i = 0; i < 8; i++) X.fft_fac[i] = i < x.fft_nf ? x.fft_fac[i] : 0;
 
-    const vamd_floor1_tab &f = h.mode[W].floor;
-    FloorP &F = B->floor[W];
-    F.posts = f.posts;
-    F.look_n = f.look_n;
-    F.quant_q = f.quant_q;
-    F.mult = f.mult;
-    F.maxover = f.maxover;
-    F.maxunder = f.maxunder;
-    F.maxerr = f.maxerr;
-    F.twofitweight = f.twofitweight;
-    F.twofitatten = f.twofitatten;
-    const size_t fo = offsetof(vamd_setup_header, mode) + sizeof(vamd_mode_tab) * W + offsetof(vamd_mode_tab, floor);
-    F.postlist = (const int *)(base + fo + offsetof(vamd_floor1_tab, postlist));
-    F.sorted_index = (const int *)(base + fo + offsetof(vamd_floor1_tab, sorted_index));
-    F.forward_index = (const int *)(base + fo + offsetof(vamd_floor1_tab, forward_index));
-    F.reverse_index = (const int *)(base + fo + offsetof(vamd_floor1_tab, reverse_index));
-    F.hineighbor = (const int *)(base + fo + offsetof(vamd_floor1_tab, hineighbor));
-    F.loneighbor = (const int *)(base + fo + offsetof(vamd_floor1_tab, loneighbor));
-    F.bin_interval = base + derived_off[24 + W];  // slots 24, 25
-    F.level = (const int *)(base + derived_off[26 + W]);
-    {
+    B->chmap[W].submaps = h.mode[W].submaps;
+    for (int c = 0; c < VAMD_MAX_CH; c++) B->chmap[W].sub[c] = c < h.channels ? (unsigned char)h.mode[W].chmuxlist[c] : 0;
+    for (int sm = 0; sm < VAMD_MAX_SUBMAPS; sm++) {
+      const int src = sm < h.mode[W].submaps ? sm : 0;  // unused slots mirror submap 0
+      const vamd_floor1_tab &f = h.mode[W].floor[src];
+      FloorP &F = B->floor[W][sm];
+      F.posts = f.posts;
+      F.look_n = f.look_n;
+      F.quant_q = f.quant_q;
+      F.mult = f.mult;
+      F.maxover = f.maxover;
+      F.maxunder = f.maxunder;
+      F.maxerr = f.maxerr;
+      F.twofitweight = f.twofitweight;
+      F.twofitatten = f.twofitatten;
+      const size_t fo = offsetof(vamd_setup_header, mode) + sizeof(vamd_mode_tab) * W + offsetof(vamd_mode_tab, floor) +
+                        sizeof(vamd_floor1_tab) * src;
+      F.postlist = (const int *)(base + fo + offsetof(vamd_floor1_tab, postlist));
+      F.sorted_index = (const int *)(base + fo + offsetof(vamd_floor1_tab, sorted_index));
+      F.forward_index = (const int *)(base + fo + offsetof(vamd_floor1_tab, forward_index));
+      F.reverse_index = (const int *)(base + fo + offsetof(vamd_floor1_tab, reverse_index));
+      F.hineighbor = (const int *)(base + fo + offsetof(vamd_floor1_tab, hineighbor));
+      F.loneighbor = (const int *)(base + fo + offsetof(vamd_floor1_tab, loneighbor));
+      F.bin_interval = base + derived_off[24 + 2 * W + src];
+      F.level = (const int *)(base + derived_off[28 + 2 * W + src]);
       int nl = 0;
       derive_post_levels(f, &nl);
       F.nlevels = nl;
@@ -302,8 +327,10 @@ inline void bind_params(const std::vector<unsigned char> &image, const std::vect
     const int blob_k = VAMD_PACKETBLOBS / 2;
     C.ch = h.channels;
     C.coupling_steps = h.mode[W].coupling_steps;
-    C.mag = h.mode[W].coupling_mag;
-    C.ang = h.mode[W].coupling_ang;
+    for (int i = 0; i < VAMD_MAX_COUPLING; i++) {
+      C.mag[i] = (signed char)(i < C.coupling_steps ? h.mode[W].coupling_mag[i] : 0);
+      C.ang[i] = (signed char)(i < C.coupling_steps ? h.mode[W].coupling_ang[i] : 0);
+    }
     // lib/psy.c:1027-1029,1056-1057; blockflag of the psy looks of this W is W
     C.pointlimit = h.psy_g.coupling_pointlimit[W][blob_k];
     C.prepoint = stereo_threshold(h.psy_g.coupling_prepointamp[blob_k], false);
@@ -340,76 +367,94 @@ inline void bind_params(const std::vector<unsigned char> &image, const std::vect
       for (int j = 0; j < VAMD_VE_BANDWIN; j++) E.band_window[i][j] = e.band_window[i][j];
     }
   }
+  const vamd_book_tab *hb = (const vamd_book_tab *)(image.data() + h.off_books);
+  auto longest = [&](int bn) {  // longest codeword of a book
+    int m = 0;
+    if (bn < 0) return 0;
+    const signed char *len = (const signed char *)(image.data() + hb[bn].off_lengths);
+    for (int e = 0; e < hb[bn].entries; e++)
+      if (len[e] > m) m = len[e];
+    return m;
+  };
   for (int W = 0; W < 2; W++) {
-    const vamd_residue_tab &r = h.res[W];
-    ResP &Rp = B->res[W];
-    Rp.tab = (const vamd_residue_tab *)(base + offsetof(vamd_setup_header, res) + sizeof(vamd_residue_tab) * W);
-    Rp.books = (const vamd_book_tab *)(base + h.off_books);
-    Rp.base = base;
-    Rp.log2_grouping = 0;
-    while ((1 << Rp.log2_grouping) < r.grouping) Rp.log2_grouping++;
-    // the GPU covers the interleaved (type 2) residue of a 2-channel bundle and the type-1 residue of a
-    // single channel, with partitions a power of two long that hold <= 8-dimensional vectors
-    bool ok = ((r.type == 2 && h.channels == 2) || (r.type == 1 && h.channels == 1)) &&
-              (1 << Rp.log2_grouping) == r.grouping && r.end <= h.channels * (h.blocksizes[W] / 2) &&
-              (r.begin % h.channels) == 0 && (r.end - r.begin) / r.grouping <= VAMD_RES_CLASS_STRIDE;
-    int worst = 0;
-    const vamd_book_tab *hb = (const vamd_book_tab *)(image.data() + h.off_books);
-    for (int c = 0; c < r.partitions && ok; c++) {
-      int per = 0;
-      for (int s = 0; s < r.stages; s++)
-        if (((r.secondstages[c] >> s) & 1) && r.partbooks[c][s] >= 0) {
-          const vamd_book_tab &bk = hb[r.partbooks[c][s]];
-          if (bk.dim > 8 || bk.dim > r.grouping || bk.entries > 65535 || r.grouping % bk.dim) ok = false;
-          else per += r.grouping / bk.dim;
-        }
-      if (per > worst) worst = per;
-    }
-    B->res_stages[W] = r.stages;
-    B->res_partvals[W] = (r.end - r.begin) / r.grouping;
-    Rp.covered = ok ? 1 : 0;
-    Rp.cap = ok ? worst * ((r.end - r.begin) / r.grouping) : 0;
-
-    // packet assembly: the longest packet this size class can produce, field by field
+    const vamd_mode_tab &m = h.mode[W];
+    const int n2 = h.blocksizes[W] / 2;
     PackP &K = B->pack[W];
-    const vamd_floor1_tab &f = h.mode[W].floor;
-    K.ftab = (const vamd_floor1_tab *)(base + offsetof(vamd_setup_header, mode) + sizeof(vamd_mode_tab) * W +
-                                       offsetof(vamd_mode_tab, floor));
-    K.books = Rp.books;
+    K.books = (const vamd_book_tab *)(base + h.off_books);
     K.base = base;
     K.modebits = h.modebits;
-    K.qbits = 0;
-    for (unsigned v = f.quant_q > 0 ? (unsigned)(f.quant_q - 1) : 0; v; v >>= 1) K.qbits++;  // ov_ilog
-    auto longest = [&](int bn) {
-      int m = 0;
-      if (bn < 0) return 0;
-      const signed char *len = (const signed char *)(image.data() + hb[bn].off_lengths);
-      for (int e = 0; e < hb[bn].entries; e++)
-        if (len[e] > m) m = len[e];
-      return m;
-    };
-    long bits = 1 + K.modebits + 2;
-    long fl = 1 + 2 * K.qbits;
-    for (int i = 0; i < f.partitions; i++) {
-      const int c = f.partitionclass[i];
-      int sub = 0;
-      for (int k = 0; k < (1 << f.class_subs[c]); k++) sub = std::max(sub, longest(f.class_subbook[c][k]));
-      fl += (f.class_subs[c] ? longest(f.class_book[c]) : 0) + f.class_dim[c] * sub;
-    }
-    bits += fl * h.channels;
-    if (ok) {
+    long bits = 1 + K.modebits + 2;  // the longest packet this size class can produce, field by field
+    bool all_ok = true;
+    int ent_base = 0, lds = 0, offi = 0;
+    for (int sm = 0; sm < VAMD_MAX_SUBMAPS; sm++) {
+      const int src = sm < m.submaps ? sm : 0;
+      const vamd_residue_tab &r = h.res[W][src];
+      ResP &Rp = B->res[W][sm];
+      Rp.tab = (const vamd_residue_tab *)(base + offsetof(vamd_setup_header, res) +
+                                          sizeof(vamd_residue_tab) * (W * VAMD_MAX_SUBMAPS + src));
+      Rp.books = K.books;
+      Rp.base = base;
+      Rp.log2_grouping = 0;
+      while ((1 << Rp.log2_grouping) < r.grouping) Rp.log2_grouping++;
+      int bundle = 0;
+      for (int c = 0; c < h.channels; c++) bundle += m.chmuxlist[c] == src;
       const int partvals = (r.end - r.begin) / r.grouping;
-      long per_part = 0;
-      for (int c = 0; c < r.partitions; c++) {
-        long per = 0;
+      // covered: the interleaved (type 2) residue of a bundle and the per-channel type-1 residue, holding
+      // vectors of <= 8 dimensions that tile the partitions
+      const int streams = r.type == 2 ? 1 : bundle;
+      bool ok = sm < m.submaps && (r.type == 2 || r.type == 1) && bundle >= 1 &&
+                r.end <= (r.type == 2 ? bundle : 1) * n2 && (r.type != 2 || (r.begin % bundle) == 0) &&
+                partvals >= 1 && partvals * streams <= VAMD_RES_CLASS_STRIDE &&
+                (r.type != 2 || r.grouping % bundle == 0);
+      int worst = 0;
+      long worst_bits = 0;
+      for (int c = 0; c < r.partitions && ok; c++) {
+        int per = 0;
+        long perb = 0;
         for (int s = 0; s < r.stages; s++)
-          if (((r.secondstages[c] >> s) & 1) && r.partbooks[c][s] >= 0)
-            per += (long)(r.grouping / hb[r.partbooks[c][s]].dim) * longest(r.partbooks[c][s]);
-        per_part = std::max(per_part, per);
+          if (((r.secondstages[c] >> s) & 1) && r.partbooks[c][s] >= 0) {
+            const vamd_book_tab &bk = hb[r.partbooks[c][s]];
+            if (bk.dim > 8 || bk.dim > r.grouping || bk.entries > 65535 || r.grouping % bk.dim) ok = false;
+            else per += r.grouping / bk.dim, perb += (long)(r.grouping / bk.dim) * longest(r.partbooks[c][s]);
+          }
+        if (per > worst) worst = per;
+        if (perb > worst_bits) worst_bits = perb;
       }
-      bits += per_part * partvals + (long)((partvals + r.groupbook_dim - 1) / r.groupbook_dim) * longest(r.groupbook);
+      Rp.covered = ok ? 1 : 0;
+      Rp.bundle = bundle;
+      Rp.partvals = partvals;
+      Rp.slots = partvals * streams;
+      Rp.cap = ok ? worst * Rp.slots : 0;
+      Rp.cls_base = sm * VAMD_RES_CLASS_STRIDE;
+      Rp.ent_base = ent_base;
+      if (sm < m.submaps) {
+        all_ok = all_ok && ok;
+        ent_base += Rp.cap;
+        lds = std::max(lds, bundle * n2 + VAMD_RES_CLASS_STRIDE + 2 * r.stages * Rp.slots + 1);
+        offi = std::max(offi, r.stages * Rp.slots + 1);
+        bits += worst_bits * Rp.slots + (long)((partvals + r.groupbook_dim - 1) / r.groupbook_dim) * streams * longest(r.groupbook);
+      }
+      // the floor of this submap's channels
+      const vamd_floor1_tab &f = m.floor[src];
+      K.ftab[sm] = (const vamd_floor1_tab *)(base + offsetof(vamd_setup_header, mode) + sizeof(vamd_mode_tab) * W +
+                                             offsetof(vamd_mode_tab, floor) + sizeof(vamd_floor1_tab) * src);
+      K.qbits[sm] = 0;
+      for (unsigned v = f.quant_q > 0 ? (unsigned)(f.quant_q - 1) : 0; v; v >>= 1) K.qbits[sm]++;  // ov_ilog
+      long fl = 1 + 2 * K.qbits[sm];
+      for (int i = 0; i < f.partitions; i++) {
+        const int c = f.partitionclass[i];
+        int sub = 0;
+        for (int k = 0; k < (1 << f.class_subs[c]); k++) sub = std::max(sub, longest(f.class_subbook[c][k]));
+        fl += (f.class_subs[c] ? longest(f.class_book[c]) : 0) + f.class_dim[c] * sub;
+      }
+      if (sm < m.submaps) bits += fl * bundle;
     }
-    K.capacity = ok ? (int)(((bits + 31) / 32) * 4) : 0;
+    B->res_cap[W] = all_ok ? ent_base : 0;
+    B->res_lds_ints[W] = lds;
+    B->res_off_ints[W] = offi;
+    if (!all_ok)
+      for (int sm = 0; sm < VAMD_MAX_SUBMAPS; sm++) B->res[W][sm].covered = 0;
+    K.capacity = all_ok ? (int)(((bits + 31) / 32) * 4) : 0;
   }
   for (int p = 0; p < 4; p++) {
     const vamd_psy_tab &t = h.psy[p];

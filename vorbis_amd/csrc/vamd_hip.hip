@@ -308,7 +308,7 @@ __global__ __launch_bounds__(64) void k_tone_fold(PsyP P0, PsyP P1, DescP d, int
 }
 
 // stage 4: offset_and_mix + floor1_fit + floor curve
-__global__ __launch_bounds__(64) void k_floor(PsyP P0, PsyP P1, FloorP F, DescP d, int ch,
+__global__ __launch_bounds__(64) void k_floor(PsyP P0, PsyP P1, FloorP F0, FloorP F1, ChMap cm, DescP d, int ch,
                                               const float *__restrict__ noise, const float *__restrict__ tone,
                                               const float *__restrict__ logmdct, const float *__restrict__ mdct_raw,
                                               float *__restrict__ mdct, float *__restrict__ logmask_out,
@@ -317,6 +317,7 @@ __global__ __launch_bounds__(64) void k_floor(PsyP P0, PsyP P1, FloorP F, DescP 
   const long cb = blockIdx.x;
   const long blk = cb / ch;
   const PsyP &P = d_bt(d, blk) ? P1 : P0;
+  const FloorP &F = cm.sub[cb - blk * ch] ? F1 : F0;  // the floor of this channel's submap
   const int n2 = P.n;
   unsigned short *qc = (unsigned short *)vamd_smem;  // [n2 rounded up to 16]
   FloorScratch *sc = (FloorScratch *)(qc + ((n2 + 15) & ~15));
@@ -365,10 +366,43 @@ __global__ __launch_bounds__(64) void k_couple(PsyP P0, PsyP P1, CoupleSet CS, i
   pc.flush();
 }
 
+// the same stage for layouts beyond stereo (more than two channels or more than one coupling step:
+// couple_block_general, k_couple.h).  LDS: cand/key/sgn [n2] each, pre [ch][n2], snap [steps][n2].
+__global__ __launch_bounds__(64) void k_couple_general(PsyP P0, PsyP P1, CoupleSet CS, int blob_base, int nblobs, DescP d,
+                                                       const float *__restrict__ mdct, const int *__restrict__ ilogmask,
+                                                       int *__restrict__ iwork, int *__restrict__ nonzero) {
+  const long unit = blockIdx.x, mblk = unit / nblobs;
+  const CoupleP &C = CS.c[blob_base + (int)(unit - mblk * nblobs)];
+  const PsyP &P = d_bt(d, mblk) ? P1 : P0;
+  const int n2 = P.n, ch = C.ch;
+  CoupleGeneralLds G;
+  G.L.cand = (float *)vamd_smem;
+  G.L.key = G.L.cand + n2;
+  G.L.sgn = G.L.key + n2;
+  G.pre = (int *)(G.L.sgn + n2);
+  G.snap = G.pre + ch * n2;
+  const float *mp[VAMD_MAX_CH];
+  const int *ip[VAMD_MAX_CH];
+  int *op[VAMD_MAX_CH];
+  int nz[VAMD_MAX_CH];
+  for (int c = 0; c < ch; c++) {
+    mp[c] = mdct + (mblk * ch + c) * n2;
+    ip[c] = ilogmask + (unit * ch + c) * n2;
+    op[c] = iwork + (unit * ch + c) * n2;
+    nz[c] = nonzero[unit * ch + c];
+  }
+  WAVE_SYNC_GLOBAL();  // every lane has read nonzero[] before lane 0 rewrites it
+  PhaseClock pc;
+  pc.start(nullptr);
+  couple_block_general(C, P, n2, mp, ip, op, nz, G, pc);
+  if (LANE == 0)
+    for (int c = 0; c < ch; c++) nonzero[unit * ch + c] = nz[c];
+}
+
 // stage 4 of a bitrate-managed batch: the same offset_and_mix, then three fits, twelve interpolated
 // curves and fifteen rendered floors per channel (floor_managed_block, k_floor.h).  Outputs are laid
 // out [block][candidate packet][channel][...].
-__global__ __launch_bounds__(64) void k_floor_managed(PsyP P0, PsyP P1, FloorP F, DescP d, int ch,
+__global__ __launch_bounds__(64) void k_floor_managed(PsyP P0, PsyP P1, FloorP F0, FloorP F1, ChMap cm, DescP d, int ch,
                                                       const float *__restrict__ noise, const float *__restrict__ tone,
                                                       const float *__restrict__ logmdct,
                                                       const float *__restrict__ mdct_raw, float *__restrict__ mdct,
@@ -379,6 +413,7 @@ __global__ __launch_bounds__(64) void k_floor_managed(PsyP P0, PsyP P1, FloorP F
   const long blk = cb / ch;
   const int c = (int)(cb - blk * ch);
   const PsyP &P = d_bt(d, blk) ? P1 : P0;
+  const FloorP &F = cm.sub[c] ? F1 : F0;
   const int n2 = P.n;
   unsigned short *qc = (unsigned short *)vamd_smem;
   FloorScratch *sc = (FloorScratch *)(qc + ((n2 + 15) & ~15));
@@ -392,33 +427,38 @@ __global__ __launch_bounds__(64) void k_floor_managed(PsyP P0, PsyP P1, FloorP F
                       ilogmask + u0 * n2, (long)ch * n2, nonzero + u0, ch, pc);
 }
 
-// stage 6 (optional): residue classification + lattice-VQ search, one wave per block (k_residue.h)
-__global__ __launch_bounds__(64) void k_residue(ResP R, DescP d, int ch, int n2, const int *__restrict__ iwork,
-                                                const int *__restrict__ nonzero, int *__restrict__ res_class,
-                                                unsigned short *__restrict__ res_entries,
+// stage 6 (optional): residue classification + lattice-VQ search, one wave per unit and submap
+// (k_residue.h).  Output rows of a unit: res_class [submaps][VAMD_RES_CLASS_STRIDE], res_entries [ent_row],
+// res_count [submaps][2]; this launch fills submap `sm`'s part.
+__global__ __launch_bounds__(64) void k_residue(ResP R, ChMap cm, int sm, int ent_row, DescP d, int ch, int n2,
+                                                const int *__restrict__ iwork, const int *__restrict__ nonzero,
+                                                int *__restrict__ res_class, unsigned short *__restrict__ res_entries,
                                                 int *__restrict__ res_count) {
-  const long blk = blockIdx.x;
-  int *work = (int *)vamd_smem;       // [ch*n2]
-  int *cls = work + ch * n2;          // [VAMD_RES_CLASS_STRIDE]
-  int *off = cls + VAMD_RES_CLASS_STRIDE;  // [stages*partvals + 1], then info [stages*partvals]
-  int *info = off + (R.tab->stages * ((R.tab->end - R.tab->begin) / R.tab->grouping) + 1);
+  const long u = blockIdx.x;
+  int *work = (int *)vamd_smem;                 // [bundle*n2]
+  int *cls = work + R.bundle * n2;              // [VAMD_RES_CLASS_STRIDE]
+  int *off = cls + VAMD_RES_CLASS_STRIDE;       // [stages*slots + 1], then info [stages*slots]
+  int *info = off + (R.tab->stages * R.slots + 1);
   const int *ip[VAMD_MAX_CH];
   int nz[VAMD_MAX_CH];
-  for (int c = 0; c < ch; c++) {
-    ip[c] = iwork + (blk * ch + c) * n2;
-    nz[c] = nonzero[blk * ch + c];
-  }
+  int nb = 0;
+  for (int c = 0; c < ch; c++)
+    if (cm.sub[c] == sm) {
+      ip[nb] = iwork + (u * ch + c) * n2;
+      nz[nb] = nonzero[u * ch + c];
+      nb++;
+    }
   PhaseClock pc;
   pc.start(d.dbg ? d.dbg + 72 : nullptr);
-  residue2_block(R, ch, n2, ip, nz, work, cls, off, info, res_class + blk * VAMD_RES_CLASS_STRIDE,
-                 res_entries + blk * (long)R.cap, res_count + blk * 2, pc);
+  residue_block(R, n2, ip, nz, work, cls, off, info, res_class + u * (cm.submaps * VAMD_RES_CLASS_STRIDE) + R.cls_base,
+                res_entries + u * (long)ent_row + R.ent_base, res_count + (u * cm.submaps + sm) * 2, pc);
   pc.flush();
 }
 
 // stage 7 (optional): packet assembly, one wave per packet (k_pack.h).  unit = block * nblobs + candidate
-__global__ __launch_bounds__(64) void k_pack(PackP K, FloorP F, ResP R, DescP d, int ch, int W, int nblobs,
-                                             const int *__restrict__ posts, const int *__restrict__ post_valid,
-                                             const int *__restrict__ res_class,
+__global__ __launch_bounds__(64) void k_pack(PackP K, FloorP F0, FloorP F1, ResP R0, ResP R1, ChMap cm, int ent_row, int lds_ints,
+                                             DescP d, int ch, int W, int nblobs, const int *__restrict__ posts,
+                                             const int *__restrict__ post_valid, const int *__restrict__ res_class,
                                              const unsigned short *__restrict__ res_entries,
                                              const int *__restrict__ res_count, unsigned *__restrict__ packets,
                                              int stride_words, int *__restrict__ packet_bits) {
@@ -426,11 +466,14 @@ __global__ __launch_bounds__(64) void k_pack(PackP K, FloorP F, ResP R, DescP d,
   int *ring = (int *)vamd_smem;                  // [VAMD_PK_RING]
   int *outv = ring + VAMD_PK_RING;               // [VAMD_POSTS_STRIDE]
   int *cls = outv + VAMD_POSTS_STRIDE;           // [VAMD_RES_CLASS_STRIDE]
-  int *off = cls + VAMD_RES_CLASS_STRIDE;        // [stages*partvals + 1], then info [stages*partvals]
-  int *info = off + (R.tab->stages * ((R.tab->end - R.tab->begin) / R.tab->grouping) + 1);
-  pack_block(K, F, R, ch, W, d_lW(d, blk), d_nW(d, blk), posts + u * ch * VAMD_POSTS_STRIDE, post_valid + u * ch,
-             res_class + u * VAMD_RES_CLASS_STRIDE, res_entries + u * (long)R.cap, res_count + u * 2, ring, outv, cls, off,
-             info, packets + u * (long)stride_words, stride_words, packet_bits + u);
+  int *off = cls + VAMD_RES_CLASS_STRIDE;        // [stages*slots + 1], then info [stages*slots], sized for the larger submap
+  int *info = off + lds_ints;
+  const FloorP F[VAMD_MAX_SUBMAPS] = {F0, F1};
+  const ResP R[VAMD_MAX_SUBMAPS] = {R0, R1};
+  pack_block(K, F, R, cm, ch, W, d_lW(d, blk), d_nW(d, blk), posts + u * ch * VAMD_POSTS_STRIDE, post_valid + u * ch,
+             res_class + u * (cm.submaps * VAMD_RES_CLASS_STRIDE), res_entries + u * (long)ent_row,
+             res_count + u * cm.submaps * 2, ring, outv, cls, off, info, packets + u * (long)stride_words, stride_words,
+             packet_bits + u);
 }
 
 // ---------------------------------------------------------------------------
@@ -747,7 +790,7 @@ int vamd_debug_cycles(vamd_ctx *c, int enable, unsigned long long *out80) {
 
 int vamd_channels(const vamd_ctx *c) { return c ? c->B.channels : VAMD_EINVAL; }
 int vamd_blocksize(const vamd_ctx *c, int W) { return (c && (W == 0 || W == 1)) ? c->B.bs[W] : VAMD_EINVAL; }
-int vamd_posts(const vamd_ctx *c, int W) { return (c && (W == 0 || W == 1)) ? c->B.floor[W].posts : VAMD_EINVAL; }
+int vamd_posts(const vamd_ctx *c, int W) { return (c && (W == 0 || W == 1)) ? c->B.floor[W][0].posts : VAMD_EINVAL; }
 
 struct WsPlan {
   float *mdct_raw, *logmdct, *logfft, *noise, *tone, *mdct, *local, *ampin, *ampglob, *seed;
@@ -861,11 +904,11 @@ static int res_bufs(vamd_ctx *c, int W, long units, int32_t *cls, uint16_t *entr
   if (entries) return VAMD_OK;
   void *v;
   int r;
-  if ((r = ws_get(c, W, vamd_ctx::WS_RES_CLASS, (size_t)units * VAMD_RES_CLASS_STRIDE * 4, &v))) return r;
+  if ((r = ws_get(c, W, vamd_ctx::WS_RES_CLASS, (size_t)units * c->B.chmap[W].submaps * VAMD_RES_CLASS_STRIDE * 4, &v))) return r;
   o->cls = (int32_t *)v;
-  if ((r = ws_get(c, W, vamd_ctx::WS_RES_ENTRIES, (size_t)units * c->B.res[W].cap * 2, &v))) return r;
+  if ((r = ws_get(c, W, vamd_ctx::WS_RES_ENTRIES, (size_t)units * c->B.res_cap[W] * 2, &v))) return r;
   o->entries = (uint16_t *)v;
-  if ((r = ws_get(c, W, vamd_ctx::WS_RES_COUNT, (size_t)units * 8, &v))) return r;
+  if ((r = ws_get(c, W, vamd_ctx::WS_RES_COUNT, (size_t)units * c->B.chmap[W].submaps * 8, &v))) return r;
   o->count = (int32_t *)v;
   return VAMD_OK;
 }
@@ -875,7 +918,7 @@ static int prepare_run(vamd_ctx *c, const vamd_batch_desc *desc, const vamd_batc
   if (io && (io->res_class || io->res_entries || io->res_count)) {
     if (!(io->res_class && io->res_entries && io->res_count)) return fail(c, VAMD_EINVAL, "res_class / res_entries / res_count go together");
     if (level < VAMD_LEVEL_FULL) return fail(c, VAMD_EINVAL, "residue outputs need level FULL");
-    if ((desc->W != 0 && desc->W != 1) || !c->B.res[desc->W].covered)
+    if ((desc->W != 0 && desc->W != 1) || !c->B.res_cap[desc->W])
       return fail(c, VAMD_EIMPL, "this mode's residue back-end is not covered on the GPU (type 2 stereo, type 1 mono)");
   }
   if (io && (io->packets || io->packet_bits)) {
@@ -920,8 +963,42 @@ static void launch_transform(vamd_ctx *c, BatchRun *R) {
 }
 
 // stages 2..5 (masking, floor, couple); R->d.ampmax_in / p.ampglob must be final
-static size_t pack_lds_bytes(int stages, int partvals) {
-  return ((size_t)VAMD_PK_RING + VAMD_POSTS_STRIDE + VAMD_RES_CLASS_STRIDE + 2 * (size_t)stages * partvals + 1) * 4;
+// stage 6 for every submap of the mode, then (optionally) stage 7; a unit is a (block, candidate packet)
+static void launch_residue_pack(vamd_ctx *c, BatchRun *R, hipStream_t s, long units, int nblobs, const int *posts,
+                                const int *post_valid, const int *iwork, const int *nonzero, const ResBufs &rb,
+                                void *packets, int64_t packet_stride, int32_t *packet_bits) {
+  const int W = R->W, ch = c->B.channels, n2 = c->B.xf[W].n / 2;
+  const ChMap &cm = c->B.chmap[W];
+  for (int sm = 0; sm < cm.submaps; sm++)
+    hipLaunchKernelGGL(k_residue, dim3((unsigned)units), dim3(64), (size_t)c->B.res_lds_ints[W] * 4, s, c->B.res[W][sm], cm, sm,
+                       c->B.res_cap[W], R->d, ch, n2, iwork, nonzero, rb.cls, rb.entries, rb.count);
+  prof_mark(c), R->nst++;
+  if (packets) {
+    const size_t lds = ((size_t)VAMD_PK_RING + VAMD_POSTS_STRIDE + VAMD_RES_CLASS_STRIDE + 2 * (size_t)c->B.res_off_ints[W]) * 4;
+    hipLaunchKernelGGL(k_pack, dim3((unsigned)units), dim3(64), lds, s, c->B.pack[W], c->B.floor[W][0], c->B.floor[W][1],
+                       c->B.res[W][0], c->B.res[W][1], cm, c->B.res_cap[W], c->B.res_off_ints[W], R->d, ch, W, nblobs, posts,
+                       post_valid, rb.cls, rb.entries, rb.count, (unsigned *)packets, (int)(packet_stride / 4), packet_bits);
+    prof_mark(c), R->nst++;
+  }
+}
+
+// couple / quantise / normalise for `units` (block, candidate) pairs
+static void launch_couple(vamd_ctx *c, BatchRun *R, hipStream_t s, long units, int blob_base, int nblobs, const float *mdct,
+                          const int *ilogmask, int *iwork, int *nonzero) {
+  const int W = R->W, ch = c->B.channels;
+  const PsyP &P0 = c->B.psy[2 * W], &P1 = c->B.psy[2 * W + 1];
+  const int n2 = c->B.xf[W].n / 2;
+  if (ch > 2 || c->B.couple[W].coupling_steps > 1) {
+    const size_t lds = (size_t)n2 * 4 * (3 + ch + c->B.couple[W].coupling_steps);
+    hipLaunchKernelGGL(k_couple_general, dim3((unsigned)units), dim3(64), lds, s, P0, P1, c->B.couple_all[W], blob_base, nblobs,
+                       R->d, mdct, ilogmask, iwork, nonzero);
+    return;
+  }
+  // the LDS arrays serve noise normalisation's sort only (lib/psy.c:941-1010); without it the
+  // stage is register-only and the CU holds twice as many of its waves
+  const bool norm0 = P0.normal_p && P0.normal_start < n2, norm1 = P1.normal_p && P1.normal_start < n2;
+  hipLaunchKernelGGL(k_couple, dim3((unsigned)units), dim3(64), (norm0 || norm1) ? (size_t)n2 * 12 : 0, s, P0, P1,
+                     c->B.couple_all[W], blob_base, nblobs, R->d, mdct, ilogmask, iwork, nonzero);
 }
 
 static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_io *M = nullptr, int *m_ilogmask = nullptr) {
@@ -979,53 +1056,24 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_
   if (level >= VAMD_LEVEL_FULL && M) {
     // bitrate-managed: fifteen candidate packets per block
     const size_t flds = (size_t)((n2 + 15) & ~15) * 2 + sizeof(FloorScratch);
-    hipLaunchKernelGGL(k_floor_managed, dim3(gcb), dim3(64), flds, s, P0, P1, c->B.floor[W], d, ch, p.noise, p.tone,
+    hipLaunchKernelGGL(k_floor_managed, dim3(gcb), dim3(64), flds, s, P0, P1, c->B.floor[W][0], c->B.floor[W][1], c->B.chmap[W], d, ch, p.noise, p.tone,
                        p.logmdct, p.mdct_raw, p.mdct, R->io->logmask, M->posts, M->post_valid, m_ilogmask, M->nonzero);
     prof_mark(c), R->nst++;
-    const bool norm0 = P0.normal_p && P0.normal_start < n2, norm1 = P1.normal_p && P1.normal_start < n2;
-    hipLaunchKernelGGL(k_couple, dim3(gb * VAMD_PACKETBLOBS), dim3(64), (norm0 || norm1) ? (size_t)n2 * 12 : 0, s, P0, P1,
-                       c->B.couple_all[W], 0, VAMD_PACKETBLOBS, d, p.mdct, m_ilogmask, M->iwork, M->nonzero);
+    launch_couple(c, R, s, (long)gb * VAMD_PACKETBLOBS, 0, VAMD_PACKETBLOBS, p.mdct, m_ilogmask, M->iwork, M->nonzero);
     prof_mark(c), R->nst++;
-    if (M->res_entries || M->packets) {
-      const ResP &Rp = c->B.res[W];
-      const int stages = c->B.res_stages[W], partvals = c->B.res_partvals[W];
-      const size_t lds = ((size_t)ch * n2 + VAMD_RES_CLASS_STRIDE + 2 * (size_t)stages * partvals + 1) * 4;
-      hipLaunchKernelGGL(k_residue, dim3(gb * VAMD_PACKETBLOBS), dim3(64), lds, s, Rp, d, ch, n2, M->iwork, M->nonzero,
-                         rb.cls, rb.entries, rb.count);
-      prof_mark(c), R->nst++;
-      if (M->packets) {
-        hipLaunchKernelGGL(k_pack, dim3(gb * VAMD_PACKETBLOBS), dim3(64), pack_lds_bytes(stages, partvals), s, c->B.pack[W],
-                           c->B.floor[W], Rp, d, ch, W, VAMD_PACKETBLOBS, M->posts, M->post_valid, rb.cls, rb.entries, rb.count,
-                           (unsigned *)M->packets, (int)(M->packet_stride / 4), M->packet_bits);
-        prof_mark(c), R->nst++;
-      }
-    }
+    if (M->res_entries || M->packets)
+      launch_residue_pack(c, R, s, (long)gb * VAMD_PACKETBLOBS, VAMD_PACKETBLOBS, M->posts, M->post_valid, M->iwork, M->nonzero, rb,
+                          M->packets, M->packet_stride, M->packet_bits);
   } else if (level >= VAMD_LEVEL_FULL) {
-    hipLaunchKernelGGL(k_floor, dim3(gcb), dim3(64), (size_t)((n2 + 15) & ~15) * 2 + sizeof(FloorScratch), s, P0, P1, c->B.floor[W],
-                       d, ch, p.noise, p.tone, p.logmdct, p.mdct_raw, p.mdct, R->io->logmask, p.posts, p.post_valid,
-                       p.ilogmask, p.nonzero);
+    hipLaunchKernelGGL(k_floor, dim3(gcb), dim3(64), (size_t)((n2 + 15) & ~15) * 2 + sizeof(FloorScratch), s, P0, P1,
+                       c->B.floor[W][0], c->B.floor[W][1], c->B.chmap[W], d, ch, p.noise, p.tone, p.logmdct, p.mdct_raw, p.mdct,
+                       R->io->logmask, p.posts, p.post_valid, p.ilogmask, p.nonzero);
     prof_mark(c), R->nst++;
-    // the LDS arrays serve noise normalisation's sort only (lib/psy.c:941-1010); without it the
-    // stage is register-only and the CU holds twice as many of its waves
-    const bool norm0 = P0.normal_p && P0.normal_start < n2, norm1 = P1.normal_p && P1.normal_start < n2;
-    const bool want_res = R->io && (R->io->res_entries || R->io->packets);
-    hipLaunchKernelGGL(k_couple, dim3(gb), dim3(64), (norm0 || norm1) ? (size_t)n2 * 12 : 0, s, P0, P1, c->B.couple_all[W], VAMD_PACKETBLOBS / 2, 1, d, p.mdct, p.ilogmask,
-                       p.iwork, p.nonzero);
+    launch_couple(c, R, s, gb, VAMD_PACKETBLOBS / 2, 1, p.mdct, p.ilogmask, p.iwork, p.nonzero);
     prof_mark(c), R->nst++;
-    if (want_res) {
-      const ResP &Rp = c->B.res[W];
-      const int stages = c->B.res_stages[W], partvals = c->B.res_partvals[W];
-      const size_t lds = ((size_t)ch * n2 + VAMD_RES_CLASS_STRIDE + 2 * (size_t)stages * partvals + 1) * 4;
-      hipLaunchKernelGGL(k_residue, dim3(gb), dim3(64), lds, s, Rp, d, ch, n2, p.iwork, p.nonzero, rb.cls, rb.entries,
-                         rb.count);
-      prof_mark(c), R->nst++;
-      if (R->io->packets) {
-        hipLaunchKernelGGL(k_pack, dim3(gb), dim3(64), pack_lds_bytes(stages, partvals), s, c->B.pack[W], c->B.floor[W], Rp, d,
-                           ch, W, 1, p.posts, p.post_valid, rb.cls, rb.entries, rb.count, (unsigned *)R->io->packets,
-                           (int)(R->io->packet_stride / 4), R->io->packet_bits);
-        prof_mark(c), R->nst++;
-      }
-    }
+    if (R->io && (R->io->res_entries || R->io->packets))
+      launch_residue_pack(c, R, s, gb, 1, p.posts, p.post_valid, p.iwork, p.nonzero, rb, R->io->packets, R->io->packet_stride,
+                          R->io->packet_bits);
   }
 }
 
@@ -1086,7 +1134,7 @@ int vamd_analyze_batch_managed(vamd_ctx *c, const vamd_batch_desc *desc, const v
   if (m->res_class || m->res_entries || m->res_count) {
     if (!(m->res_class && m->res_entries && m->res_count))
       return fail(c, VAMD_EINVAL, "res_class / res_entries / res_count go together");
-    if (!c->B.res[desc->W].covered)
+    if (!c->B.res_cap[desc->W])
       return fail(c, VAMD_EIMPL, "this mode's residue back-end is not covered on the GPU (type 2 stereo, type 1 mono)");
   }
   if ((m->packets || m->packet_bits) &&
@@ -1109,16 +1157,17 @@ int vamd_analyze_block_managed(vamd_ctx *c, const float *const *pcm, int lW, int
   if (!c) return VAMD_EINVAL;
   if (!pcm || (W != 0 && W != 1)) return fail(c, VAMD_EINVAL, "bad pcm / W");
   const bool want_res = res_class || res_entries || res_count;
-  if (want_res && !c->B.res[W].covered)
+  if (want_res && !c->B.res_cap[W])
     return fail(c, VAMD_EIMPL, "this mode's residue back-end is not covered on the GPU (type 2 stereo, type 1 mono)");
-  const size_t rcap = want_res ? (size_t)c->B.res[W].cap : 0;
+  const size_t rcap = want_res ? (size_t)c->B.res_cap[W] : 0;
+  const size_t S = (size_t)c->B.chmap[W].submaps;
   const size_t ch = c->B.channels, n = c->B.bs[W], n2 = n / 2, K = VAMD_PACKETBLOBS;
   auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
   const size_t o_pcm = 0, o_mdct = al(o_pcm + ch * n * 4), o_amp = al(o_mdct + ch * n2 * 4), o_posts = o_amp + 16,
                o_valid = al(o_posts + K * ch * VAMD_POSTS_STRIDE * 4), o_nz = al(o_valid + K * ch * 4),
                o_iwork = al(o_nz + K * ch * 4), o_rcls = al(o_iwork + K * ch * n2 * 4),
-               o_rcnt = al(o_rcls + (want_res ? K * VAMD_RES_CLASS_STRIDE * 4 : 0)),
-               o_rent = al(o_rcnt + (want_res ? K * 2 * 4 : 0)), total = al(o_rent + K * rcap * 2);
+               o_rcnt = al(o_rcls + (want_res ? K * S * VAMD_RES_CLASS_STRIDE * 4 : 0)),
+               o_rent = al(o_rcnt + (want_res ? K * S * 2 * 4 : 0)), total = al(o_rent + K * rcap * 2);
   if (c->h_stage_bytes < total) {
     if (c->h_stage) HIP_TRY(c, hipHostFree(c->h_stage));
     c->h_stage = nullptr;
@@ -1171,8 +1220,8 @@ int vamd_analyze_block_managed(vamd_ctx *c, const float *const *pcm, int lW, int
   if (nonzero) memcpy(nonzero, hs + o_nz, K * ch * 4);
   if (iwork) memcpy(iwork, hs + o_iwork, K * ch * n2 * 4);
   if (want_res) {
-    if (res_class) memcpy(res_class, hs + o_rcls, K * VAMD_RES_CLASS_STRIDE * 4);
-    if (res_count) memcpy(res_count, hs + o_rcnt, K * 2 * 4);
+    if (res_class) memcpy(res_class, hs + o_rcls, K * S * VAMD_RES_CLASS_STRIDE * 4);
+    if (res_count) memcpy(res_count, hs + o_rcnt, K * S * 2 * 4);
     if (res_entries) memcpy(res_entries, hs + o_rent, K * rcap * 2);
   }
   return VAMD_OK;
@@ -1237,15 +1286,16 @@ int vamd_analyze_block_res(vamd_ctx *c, const float *const *pcm, int lW, int W, 
   if (!c) return VAMD_EINVAL;
   if (!pcm || (W != 0 && W != 1)) return fail(c, VAMD_EINVAL, "bad pcm / W");
   const bool want_res = res_class || res_entries || res_count;
-  if (want_res && !c->B.res[W].covered)
+  if (want_res && !c->B.res_cap[W])
     return fail(c, VAMD_EIMPL, "this mode's residue back-end is not covered on the GPU (type 2 stereo, type 1 mono)");
-  const size_t rcap = want_res ? (size_t)c->B.res[W].cap : 0;
+  const size_t rcap = want_res ? (size_t)c->B.res_cap[W] : 0;
+  const size_t S = (size_t)c->B.chmap[W].submaps;
   const int ch = c->B.channels, n = c->B.bs[W], n2 = n / 2;
   // one pinned + one device arena: [pcm | mdct | logmask | iwork | posts | post_valid | nonzero | ampmax]
   const size_t o_pcm = 0, o_mdct = o_pcm + (size_t)ch * n * 4, o_mask = o_mdct + (size_t)ch * n2 * 4,
                o_iwork = o_mask + (size_t)ch * n2 * 4, o_posts = o_iwork + (size_t)ch * n2 * 4,
                o_valid = o_posts + (size_t)ch * VAMD_POSTS_STRIDE * 4, o_nz = o_valid + (size_t)ch * 4,
-               o_amp = o_nz + (size_t)ch * 4, o_rcls = o_amp + 16, o_rcnt = o_rcls + VAMD_RES_CLASS_STRIDE * 4,
+               o_amp = ((o_nz + (size_t)ch * 4 + 15) & ~(size_t)15), o_rcls = o_amp + 16, o_rcnt = o_rcls + S * VAMD_RES_CLASS_STRIDE * 4,
                o_rent = o_rcnt + 16, total = o_rent + ((rcap * 2 + 15) & ~(size_t)15);
   if (c->h_stage_bytes < total) {
     if (c->h_stage) HIP_TRY(c, hipHostFree(c->h_stage));
@@ -1299,11 +1349,9 @@ int vamd_analyze_block_res(vamd_ctx *c, const float *const *pcm, int lW, int W, 
   if (nonzero) memcpy(nonzero, hs + o_nz, (size_t)ch * 4);
   if (ampmax_out) memcpy(ampmax_out, hs + o_amp, 4);
   if (want_res) {
-    int32_t cnt[2];
-    memcpy(cnt, hs + o_rcnt, 8);
-    if (res_count) memcpy(res_count, cnt, 8);
-    if (res_class) memcpy(res_class, hs + o_rcls, VAMD_RES_CLASS_STRIDE * 4);
-    if (res_entries) memcpy(res_entries, hs + o_rent, (size_t)(cnt[1] < (int)rcap ? cnt[1] : (int)rcap) * 2);
+    if (res_count) memcpy(res_count, hs + o_rcnt, S * 8);
+    if (res_class) memcpy(res_class, hs + o_rcls, S * VAMD_RES_CLASS_STRIDE * 4);
+    if (res_entries) memcpy(res_entries, hs + o_rent, rcap * 2);
   }
   return VAMD_OK;
 }
@@ -1390,7 +1438,14 @@ int vamd_encode_block(vamd_ctx *c, const float *const *pcm, int lW, int W, int n
 
 int vamd_residue_capacity(const vamd_ctx *c, int W) {
   if (!c || (W != 0 && W != 1)) return 0;
-  return c->B.res[W].covered ? c->B.res[W].cap : 0;
+  return c->B.res_cap[W];
+}
+
+int vamd_submaps(const vamd_ctx *c, int W) { return (c && (W == 0 || W == 1)) ? c->B.chmap[W].submaps : VAMD_EINVAL; }
+
+int vamd_residue_offset(const vamd_ctx *c, int W, int submap) {
+  if (!c || (W != 0 && W != 1) || submap < 0 || submap >= c->B.chmap[W].submaps) return VAMD_EINVAL;
+  return c->B.res[W][submap].ent_base;
 }
 
 int vamd_envelope_geometry(const vamd_ctx *c, int *winlength, int *searchstep) {

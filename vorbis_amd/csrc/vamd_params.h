@@ -76,17 +76,28 @@ struct ResP {
   const unsigned char *base;  // image base: books[].off_lengths are relative to it
   int log2_grouping;
   int cap;                    // entries a block can emit at most (sizes the output rows)
-  int covered;                // 1 when the GPU handles this mode's residue (type 2, 2 channels)
+  int covered;                // 1 when the GPU handles this residue
+  int bundle;                 // channels in this submap's bundle
+  int partvals;               // (end - begin) / grouping
+  int slots;                  // classified (partition, stream) pairs at most: partvals x streams
+  int cls_base, ent_base;     // where this submap's rows start inside a block's res_class / res_entries rows
 };
 
 // packet assembly (k_pack.h): the floor's class tables and the codebooks' codewords, in the HBM image
 struct PackP {
-  const vamd_floor1_tab *ftab;
+  const vamd_floor1_tab *ftab[VAMD_MAX_SUBMAPS];
   const vamd_book_tab *books;
   const unsigned char *base;
-  int modebits;   // width of the mode number
-  int qbits;      // ilog(quant_q - 1): width of the two end posts
+  int modebits;                    // width of the mode number
+  int qbits[VAMD_MAX_SUBMAPS];     // ilog(quant_q - 1): width of the two end posts
   int capacity;   // bytes the largest packet of this size class can take (multiple of 4); 0 = not assembled here
+};
+
+// which submap (floor, residue) each channel belongs to: vorbis_info_mapping0.chmuxlist
+struct ChMap {
+  int submaps;
+  unsigned char sub[VAMD_MAX_CH];
+  unsigned char pad[2];
 };
 
 struct FloorP {
@@ -100,7 +111,8 @@ struct FloorP {
 
 struct CoupleP {
   int ch;
-  int coupling_steps, mag, ang;
+  int coupling_steps;
+  signed char mag[VAMD_MAX_COUPLING], ang[VAMD_MAX_COUPLING];  // applied in order (lib/psy.c:1111-1201)
   int pointlimit;        // coupling_pointlimit[blockflag][PACKETBLOBS/2]
   float prepoint, postpoint;
   int sliding_lowpass;   // sliding_lowpass[W][PACKETBLOBS/2]
