@@ -56,9 +56,9 @@ class _BlockRec(C.Structure):
 
 
 class _EnvState(C.Structure):  # ref_env_state (ref_harness.c): envelope_filter_state x channels + ve->stretch
-    _fields_ = [("stretch", C.c_int), ("ampptr", C.c_int * 7 * 2), ("ampbuf", C.c_float * 17 * 7 * 2),
-                ("nearptr", C.c_int * 2), ("nearDC", C.c_float * 15 * 2), ("nearDC_acc", C.c_float * 2),
-                ("nearDC_partialacc", C.c_float * 2)]
+    _fields_ = [("stretch", C.c_int), ("ampptr", C.c_int * 7 * 6), ("ampbuf", C.c_float * 17 * 7 * 6),
+                ("nearptr", C.c_int * 6), ("nearDC", C.c_float * 15 * 6), ("nearDC_acc", C.c_float * 6),
+                ("nearDC_partialacc", C.c_float * 6)]
 
 
 def available():

@@ -673,13 +673,14 @@ long ref_envelope_feed(ref_enc *e, const float *pcm, long frames) {
   return b->ve->current / b->ve->searchstep;
 }
 
+#define REF_ENV_MAX_CH 6
 typedef struct ref_env_state {
   int stretch;
-  int ampptr[2][VE_BANDS];
-  float ampbuf[2][VE_BANDS][VE_AMP];
-  int nearptr[2];
-  float nearDC[2][VE_NEARDC];
-  float nearDC_acc[2], nearDC_partialacc[2];
+  int ampptr[REF_ENV_MAX_CH][VE_BANDS];
+  float ampbuf[REF_ENV_MAX_CH][VE_BANDS][VE_AMP];
+  int nearptr[REF_ENV_MAX_CH];
+  float nearDC[REF_ENV_MAX_CH][VE_NEARDC];
+  float nearDC_acc[REF_ENV_MAX_CH], nearDC_partialacc[REF_ENV_MAX_CH];
 } ref_env_state;
 
 /* Copy out what the detector saw and decided: the PCM ring as it stands (pcm_seen[ch][cap],
@@ -701,7 +702,7 @@ long ref_envelope_get(ref_enc *e, float *pcm_seen, long cap, long *pcm_len, int 
   if (st) {
     memset(st, 0, sizeof(*st));
     st->stretch = ve->stretch;
-    for (i = 0; i < e->channels && i < 2; i++) {
+    for (i = 0; i < e->channels && i < REF_ENV_MAX_CH; i++) {
       envelope_filter_state *f = ve->filter + i * VE_BANDS;
       st->nearptr[i] = f->nearptr;
       st->nearDC_acc[i] = f->nearDC_acc;

@@ -76,12 +76,13 @@ static void residue_and_pack(const Bound &B, int W, int lW, int nW, const int *i
 // couple / quantise / normalise with whichever form the layout needs (as launch_couple picks the kernel)
 static void couple_any(const CoupleP &C, const PsyP &P, int n2, const float *const *mp, const int *const *ip, int *const *op,
                        int *nonzero, PhaseClock &pc) {
-  std::vector<float> cand(n2), key(n2), sgn(n2);
-  CoupleLds L = {cand.data(), key.data(), sgn.data()};
+  std::vector<float> cand(n2), key(n2), sgn(n2), accp(256);
+  CoupleLds L = {cand.data(), key.data(), sgn.data(), accp.data()};
   if (C.ch > 2 || C.coupling_steps > 1) {
-    std::vector<int> pre((size_t)C.ch * n2), snap((size_t)(C.coupling_steps + 1) * n2);
-    CoupleGeneralLds G = {L, pre.data(), snap.data()};
-    couple_block_general(C, P, n2, mp, ip, op, nonzero, G, pc);
+    std::vector<float> st((size_t)4 * C.ch * n2);
+    CoupleState S = {st.data(), st.data() + (size_t)C.ch * n2, st.data() + (size_t)2 * C.ch * n2,
+                     (int *)(st.data() + (size_t)3 * C.ch * n2)};
+    couple_block_general(C, P, n2, mp, ip, op, nonzero, L, S, pc);
   } else {
     couple_block(C, P, n2, mp, ip, op, nonzero, L, pc);
   }

@@ -107,9 +107,40 @@ def test_kernel_bodies_match_reference_managed(rates):
         assert g["m_packets"] == a["m_packets"]
 
 
+@needs_ref
+def test_detector_kernel_bodies_match_reference():
+    """The block-switching detector ORs its triggers over all six channels (lib/envelope.c:234-239)."""
+    from tests.emul.emul import Emul
+    from tests.test_envelope import gated, check_state
+    from vorbis_amd import EnvelopeState, envelope_marks
+    x = gated(6, 40000, 66)
+    x[2] = np.roll(x[2], 2500)        # the centre channel's bursts fall between the others'
+    e = ref.RefEncoder(6, 44100, 0.3)
+    o = e.envelope_feed(x)
+    assert o["marks"].sum() > 10
+    st = EnvelopeState()
+    flags = Emul(blob()).envelope_search(o["pcm"], o["steps"], st)
+    assert np.array_equal(envelope_marks(flags)[:o["steps"] + 2], o["marks"])
+    check_state(st, o, 6)
+
+
 # ------------------------------------------------------------------------------------------
 # GPU suite (through the C ABI)
 # ------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@needs_ref
+def test_gpu_detector_matches_reference():
+    from tests.test_envelope import gated, check_state
+    from vorbis_amd import envelope_marks
+    x = gated(6, 60000, 67)
+    x[4] = np.roll(x[4], 1700)
+    o = ref.RefEncoder(6, 44100, 0.3).envelope_feed(x)
+    an = vorbis_amd.Analyzer(blob(), 0)
+    flags, st = an.envelope_search(o["pcm"], o["steps"])
+    assert np.array_equal(envelope_marks(flags)[:o["steps"] + 2], o["marks"]) and o["marks"].sum() > 10
+    check_state(st, o, 6)
+
+
 @pytest.mark.gpu
 def test_gpu_matches_golden():
     import torch

@@ -37,39 +37,42 @@ struct CoupleLds {
   float *cand;  // [n2]
   float *key;   // [n2] sort key q[] = |r| (or the coupled energy)
   float *sgn;   // [n2] r (sign source for unitnorm)
+  float *accp;  // [partitions] the partitions' energy budgets
 };
 
-// The ordered part of noise_normalize for one partition [b0, b0+jn): accumulate
-// candidates' ve in index order, sort them by key descending (stable: glibc's
-// qsort is a merge sort at these sizes), then promote to +-1 while the energy
-// budget lasts (lib/psy.c:993-1007).
-VAMD_DEV void noise_norm_partition(const PsyP &P, const CoupleLds &L, int b0, int jn, int *out) {
-  float acc = 0.f;
-  int count = 0;
-  for (int j = 0; j < jn; j++)
-    if (L.cand[b0 + j] >= 0.f) {
-      acc += L.cand[b0 + j];
-      count++;
-    }
-  // selection in sorted order without materialising the permutation: repeatedly
-  // take the largest remaining key, earliest index first among equals
-  for (int t = 0; t < count; t++) {
-    int best = -1;
-    float bk = 0.f;
-    for (int j = 0; j < jn; j++) {
-      const int b = b0 + j;
-      if (L.cand[b] >= 0.f && (best < 0 || L.key[b] > bk)) {
-        best = b;
-        bk = L.key[b];
+// The ordered part of noise_normalize (lib/psy.c:976-1007) for every partition of the block at once.
+// Per partition the reference accumulates the candidates' ve in index order, sorts them by key
+// descending (stable: glibc's qsort is a merge sort at these sizes) and promotes them to +-1 in that
+// order while the energy budget lasts: "if(acc>=thresh){out=unitnorm; acc-=1.f}else out=0".
+//  * the budget: one lane per partition adds its candidates in index order (fp32, as the reference);
+//  * the order: a candidate's place in the sorted list is the number of candidates with a larger key,
+//    plus those with an equal key and a smaller index -- counted by the candidate's own lane;
+//  * the walk: once a candidate fails the test the budget stops moving and every later one fails
+//    too, so the candidate at place r is promoted iff acc0 - r >= thresh; acc0 - r in one
+//    subtraction equals r subtractions of 1.f, all of which are exact (the operand is a float no
+//    larger than jn/4, the result is smaller and a multiple of the operand's ulp).
+//   accp  LDS [nparts] scratch
+VAMD_DEV void noise_norm_wave(const PsyP &P, const CoupleLds &L, float *accp, int n2, int partition, int nparts, int *out) {
+  WAVE_FOR(p, nparts) {
+    const int b0 = p * partition, jn = partition > n2 - b0 ? n2 - b0 : partition;
+    float acc = 0.f;
+    for (int j = 0; j < jn; j++)
+      if (L.cand[b0 + j] >= 0.f) acc += L.cand[b0 + j];
+    accp[p] = acc;
+  }
+  WAVE_SYNC();
+  WAVE_FOR(b, n2) {
+    if (L.cand[b] >= 0.f) {
+      const int p = b / partition, b0 = p * partition, jn = partition > n2 - b0 ? n2 - b0 : partition;
+      const float kb = L.key[b];
+      int rank = 0;
+      for (int j = 0; j < jn; j++) {
+        const int o = b0 + j;
+        if (L.cand[o] >= 0.f && (L.key[o] > kb || (L.key[o] == kb && o < b))) rank++;
       }
+      const float left = accp[p] - (float)rank;
+      out[b] = (double)left >= P.normal_thresh ? (int)unitnorm(L.sgn[b]) : 0;
     }
-    if ((double)acc >= P.normal_thresh) {
-      out[best] = (int)unitnorm(L.sgn[best]);
-      acc -= 1.f;
-    } else {
-      out[best] = 0;
-    }
-    L.cand[best] = -1.f;  // consumed
   }
 }
 
@@ -241,15 +244,9 @@ VAMD_DEV void couple_block(const CoupleP &C, const PsyP &P, int n2, const float 
       L.key[b] = B.qe;
       L.sgn[b] = B.re;
     }
-    if (nz[k]) {
-      WAVE_SYNC_GLOBAL();  // iwork[] changes hands between lanes through HBM
-      WAVE_FOR(p, nparts) {
-        const int b0 = p * partition;
-        const int jn = partition > n2 - b0 ? n2 - b0 : partition;
-        noise_norm_partition(P, L, b0, jn, iwork[k]);
-      }
-      WAVE_SYNC_GLOBAL();
-    }
+    WAVE_SYNC();
+    if (nz[k]) noise_norm_wave(P, L, L.accp, n2, partition, nparts, iwork[k]);
+    WAVE_SYNC_GLOBAL();  // iwork[] changes hands between lanes through HBM
   }
   pc.mark(0);
   // ---- coupling (one step: magnitude Mi, angle Ai), lib/psy.c:1111-1201
@@ -267,12 +264,8 @@ VAMD_DEV void couple_block(const CoupleP &C, const PsyP &P, int n2, const float 
       L.key[b] = M.qe;
       L.sgn[b] = M.re;
     }
-    WAVE_SYNC_GLOBAL();
-    WAVE_FOR(p, nparts) {
-      const int b0 = p * partition;
-      const int jn = partition > n2 - b0 ? n2 - b0 : partition;
-      noise_norm_partition(P, L, b0, jn, iwork[Mi]);
-    }
+    WAVE_SYNC();
+    noise_norm_wave(P, L, L.accp, n2, partition, nparts, iwork[Mi]);
     WAVE_SYNC_GLOBAL();
     nz[Mi] = nz[Ai] = 1;  // lib/psy.c:1204-1212
   }
@@ -282,113 +275,86 @@ VAMD_DEV void couple_block(const CoupleP &C, const PsyP &P, int n2, const float 
 
 // ---- any channel count, any number of coupling steps (the 5.1 layout: six channels, four steps, the
 // left channel the magnitude of three of them; lib/psy.c:1111-1201 "depth>1 coupling").
-// Per bin the steps are a fixed sequence of couple_bin() calls on the channels' running state; the only
-// thing one bin needs from its neighbours is the outcome of noise normalisation's sort for bins that
-// were candidates in an earlier step.  So every step is: per bin, REPLAY the prefill and the earlier
-// steps (taking candidates' outcomes from a snapshot of what the sort left), run this step, hand the
-// new candidates to the per-partition sort, snapshot.  Without noise normalisation in the block there
-// are no candidates and one replay of all steps does everything.
-//   pre   [ch][n2]   the channels' integers after the prefill (and its sort)
-//   snap  [steps][n2] the magnitude channel's integers after each step's sort
-struct CoupleGeneralLds {
-  CoupleLds L;
-  int *pre, *snap;
+// Per bin the steps are a fixed sequence of couple_bin() calls on the channels' running state (signed
+// energy, energy, squared floor, lossless flag, the integer quantised so far); between steps that
+// state rests in a per-unit workspace in HBM, one row per channel, so a step touches only its
+// magnitude and angle rows, addressed by the step's channel numbers.  The only thing a bin needs
+// from its neighbours is noise normalisation's outcome for the candidates of its partition
+// (noise_norm_wave); what the reference then leaves in quant[] past normal_start -- out*out*floor,
+// or floor / 0 for a promoted / dropped candidate, all three out*out*floor (lib/psy.c:985,998-1003) --
+// is applied when the channel is next read (`pend`).
+//   state  HBM [4][ch][n2]: re, qe, fl2 (floats) and fg (ints)
+struct CoupleState {
+  float *re, *qe, *fl2;
+  int *fg;
 };
 
-// state of every channel of bin b after the prefill and coupling steps [0, upto]; returns step upto's
-// noise-norm candidate energy for its magnitude channel (or -1)
-VAMD_DEV float couple_replay(const CoupleP &C, int ch, const int *nz0, int b, int n2, int nstart,
-                             const float *const *mdct, const int *const *ilogmask, const int *pre, const int *snap,
-                             int upto, ChanBin *st, int *io) {
-  int nzl[VAMD_MAX_CH];
-  for (int k = 0; k < ch; k++) {
-    nzl[k] = nz0[k];
-    st[k] = chan_bin(nz0[k], nz0[k] ? mdct[k][b] : 0.f, nz0[k] ? ilogmask[k][b] : 0, b, nstart, C);
-    io[k] = pre ? pre[k * n2 + b] : st[k].out;
-    // what noise_normalize leaves in quant[] past normal_start: out*out*floor, or floor / 0 for a promoted /
-    // dropped candidate -- all three are out*out*floor (lib/psy.c:985,998-1003)
-    if (nz0[k] && b >= nstart) st[k].qe = (float)(io[k] * io[k]) * st[k].fl2;
-  }
-  float cand = -1.f;
-  for (int t = 0; t <= upto; t++) {
-    const int Mi = C.mag[t], Ai = C.ang[t];
-    if (!(nzl[Mi] || nzl[Ai])) continue;  // lib/psy.c:1125
-    nzl[Mi] = nzl[Ai] = 1;
-    cand = couple_bin(st[Mi], st[Ai], io[Mi], io[Ai], b, nstart, C);
-    if (t < upto) {
-      if (cand >= 0.f) io[Mi] = snap[t * n2 + b];
-      if (b >= nstart && !st[Mi].fg) st[Mi].qe = (float)(io[Mi] * io[Mi]) * st[Mi].fl2;
-    }
-  }
-  return cand;
-}
-
 VAMD_DEV void couple_block_general(const CoupleP &C, const PsyP &P, int n2, const float *const *mdct,
-                                   const int *const *ilogmask, int *const *iwork, int *nonzero,
-                                   const CoupleGeneralLds &G, PhaseClock &pc) {
+                                   const int *const *ilogmask, int *const *iwork, int *nonzero, const CoupleLds &L,
+                                   const CoupleState &S, PhaseClock &pc) {
   const int ch = C.ch, steps = C.coupling_steps;
-  const CoupleLds &L = G.L;
   const int partition = P.normal_p ? P.normal_partition : 16;
   const int nstart = P.normal_p ? P.normal_start : 0x7fffffff;
   const bool norm_active = nstart < n2;
   const int nparts = (n2 + partition - 1) / partition;
-  int nz[VAMD_MAX_CH];
-  for (int k = 0; k < ch; k++) nz[k] = nonzero[k];
+  int nz[VAMD_MAX_CH], nzl[VAMD_MAX_CH], pend[VAMD_MAX_CH];
+  for (int k = 0; k < ch; k++) nz[k] = nzl[k] = nonzero[k];
 
-  if (!norm_active) {
+  // prefill: per channel, first quantisation (and its ordered part)
+  for (int k = 0; k < ch; k++) {
     WAVE_FOR(b, n2) {
-      ChanBin st[VAMD_MAX_CH];
-      int io[VAMD_MAX_CH];
-      couple_replay(C, ch, nz, b, n2, nstart, mdct, ilogmask, nullptr, nullptr, steps - 1, st, io);
-      for (int k = 0; k < ch; k++) iwork[k][b] = io[k];
-    }
-  } else {
-    // prefill: per channel, first quantisation and its sort
-    for (int k = 0; k < ch; k++) {
-      WAVE_FOR(b, n2) {
-        const ChanBin B = chan_bin(nz[k], nz[k] ? mdct[k][b] : 0.f, nz[k] ? ilogmask[k][b] : 0, b, nstart, C);
-        iwork[k][b] = B.out;
+      const ChanBin B = chan_bin(nz[k], nz[k] ? mdct[k][b] : 0.f, nz[k] ? ilogmask[k][b] : 0, b, nstart, C);
+      iwork[k][b] = B.out;
+      S.re[k * n2 + b] = B.re;
+      S.qe[k * n2 + b] = B.qe;
+      S.fl2[k * n2 + b] = B.fl2;
+      S.fg[k * n2 + b] = B.fg;
+      if (norm_active) {
         L.cand[b] = B.cand;
         L.key[b] = B.qe;
         L.sgn[b] = B.re;
       }
-      WAVE_SYNC_GLOBAL();
-      if (nz[k]) {
-        WAVE_FOR(p, nparts) {
-          const int b0 = p * partition;
-          noise_norm_partition(P, L, b0, partition > n2 - b0 ? n2 - b0 : partition, iwork[k]);
-        }
-        WAVE_SYNC_GLOBAL();
-      }
-      WAVE_FOR(b, n2) G.pre[k * n2 + b] = iwork[k][b];
-      WAVE_SYNC();
     }
-    pc.mark(0);
-    int nzl[VAMD_MAX_CH];
-    for (int k = 0; k < ch; k++) nzl[k] = nz[k];
-    for (int t = 0; t < steps; t++) {
-      const int Mi = C.mag[t], Ai = C.ang[t];
-      if (!(nzl[Mi] || nzl[Ai])) continue;
-      nzl[Mi] = nzl[Ai] = 1;
-      WAVE_FOR(b, n2) {
-        ChanBin st[VAMD_MAX_CH];
-        int io[VAMD_MAX_CH];
-        const float cand = couple_replay(C, ch, nz, b, n2, nstart, mdct, ilogmask, G.pre, G.snap, t, st, io);
-        iwork[Mi][b] = io[Mi];
-        iwork[Ai][b] = io[Ai];
+    if (norm_active) {
+      WAVE_SYNC();
+      if (nz[k]) noise_norm_wave(P, L, L.accp, n2, partition, nparts, iwork[k]);
+    }
+    WAVE_SYNC_GLOBAL();
+    pend[k] = nz[k] ? 1 : 0;  // quant[] = out*out*floor past normal_start, flags or not (flags == NULL)
+  }
+  pc.mark(0);
+  for (int t = 0; t < steps; t++) {
+    const int Mi = C.mag[t], Ai = C.ang[t];
+    if (!(nzl[Mi] || nzl[Ai])) continue;  // lib/psy.c:1125
+    nzl[Mi] = nzl[Ai] = 1;
+    const int pm = pend[Mi], pa = pend[Ai];
+    WAVE_FOR(b, n2) {
+      ChanBin M, A;
+      M.re = S.re[Mi * n2 + b], M.qe = S.qe[Mi * n2 + b], M.fl2 = S.fl2[Mi * n2 + b], M.fg = S.fg[Mi * n2 + b];
+      A.re = S.re[Ai * n2 + b], A.qe = S.qe[Ai * n2 + b], A.fl2 = S.fl2[Ai * n2 + b], A.fg = S.fg[Ai * n2 + b];
+      int iM = iwork[Mi][b], iA = iwork[Ai][b];
+      if (b >= nstart) {
+        if (pm == 1 || (pm == 2 && !M.fg)) M.qe = (float)(iM * iM) * M.fl2;
+        if (pa == 1 || (pa == 2 && !A.fg)) A.qe = (float)(iA * iA) * A.fl2;
+      }
+      const float cand = couple_bin(M, A, iM, iA, b, nstart, C);
+      S.re[Mi * n2 + b] = M.re, S.qe[Mi * n2 + b] = M.qe, S.fl2[Mi * n2 + b] = M.fl2, S.fg[Mi * n2 + b] = M.fg;
+      S.re[Ai * n2 + b] = A.re, S.qe[Ai * n2 + b] = A.qe, S.fl2[Ai * n2 + b] = A.fl2, S.fg[Ai * n2 + b] = A.fg;
+      iwork[Mi][b] = iM;
+      iwork[Ai][b] = iA;
+      if (norm_active) {
         L.cand[b] = cand;
-        L.key[b] = st[Mi].qe;
-        L.sgn[b] = st[Mi].re;
+        L.key[b] = M.qe;
+        L.sgn[b] = M.re;
       }
-      WAVE_SYNC_GLOBAL();
-      WAVE_FOR(p, nparts) {
-        const int b0 = p * partition;
-        noise_norm_partition(P, L, b0, partition > n2 - b0 ? n2 - b0 : partition, iwork[Mi]);
-      }
-      WAVE_SYNC_GLOBAL();
-      WAVE_FOR(b, n2) G.snap[t * n2 + b] = iwork[Mi][b];
-      WAVE_SYNC();
     }
+    if (norm_active) {
+      WAVE_SYNC();
+      noise_norm_wave(P, L, L.accp, n2, partition, nparts, iwork[Mi]);
+    }
+    WAVE_SYNC_GLOBAL();
+    pend[Mi] = 2;  // noise_normalize with flags: unflagged bins only
+    pend[Ai] = 0;
   }
   pc.mark(1);
   for (int t = 0; t < steps; t++)  // lib/psy.c:1204-1212, in step order

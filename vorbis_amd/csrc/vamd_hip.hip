@@ -347,6 +347,7 @@ __global__ __launch_bounds__(64) void k_couple(PsyP P0, PsyP P1, CoupleSet CS, i
   L.cand = (float *)vamd_smem;
   L.key = L.cand + n2;
   L.sgn = L.key + n2;
+  L.accp = L.sgn + n2;
   const float *mp[VAMD_MAX_CH];
   const int *ip[VAMD_MAX_CH];
   int *op[VAMD_MAX_CH];
@@ -367,20 +368,26 @@ __global__ __launch_bounds__(64) void k_couple(PsyP P0, PsyP P1, CoupleSet CS, i
 }
 
 // the same stage for layouts beyond stereo (more than two channels or more than one coupling step:
-// couple_block_general, k_couple.h).  LDS: cand/key/sgn [n2] each, pre [ch][n2], snap [steps][n2].
+// couple_block_general, k_couple.h).  LDS: cand/key/sgn [n2] each + the partitions' budgets; the channels'
+// running state lives in `state` [unit][4][ch][n2].
 __global__ __launch_bounds__(64) void k_couple_general(PsyP P0, PsyP P1, CoupleSet CS, int blob_base, int nblobs, DescP d,
                                                        const float *__restrict__ mdct, const int *__restrict__ ilogmask,
-                                                       int *__restrict__ iwork, int *__restrict__ nonzero) {
+                                                       int *__restrict__ iwork, int *__restrict__ nonzero,
+                                                       float *__restrict__ state) {
   const long unit = blockIdx.x, mblk = unit / nblobs;
   const CoupleP &C = CS.c[blob_base + (int)(unit - mblk * nblobs)];
   const PsyP &P = d_bt(d, mblk) ? P1 : P0;
   const int n2 = P.n, ch = C.ch;
-  CoupleGeneralLds G;
-  G.L.cand = (float *)vamd_smem;
-  G.L.key = G.L.cand + n2;
-  G.L.sgn = G.L.key + n2;
-  G.pre = (int *)(G.L.sgn + n2);
-  G.snap = G.pre + ch * n2;
+  CoupleLds L;
+  L.cand = (float *)vamd_smem;
+  L.key = L.cand + n2;
+  L.sgn = L.key + n2;
+  L.accp = L.sgn + n2;
+  CoupleState S;
+  S.re = state + unit * 4 * ch * n2;
+  S.qe = S.re + ch * n2;
+  S.fl2 = S.qe + ch * n2;
+  S.fg = (int *)(S.fl2 + ch * n2);
   const float *mp[VAMD_MAX_CH];
   const int *ip[VAMD_MAX_CH];
   int *op[VAMD_MAX_CH];
@@ -394,7 +401,7 @@ __global__ __launch_bounds__(64) void k_couple_general(PsyP P0, PsyP P1, CoupleS
   WAVE_SYNC_GLOBAL();  // every lane has read nonzero[] before lane 0 rewrites it
   PhaseClock pc;
   pc.start(nullptr);
-  couple_block_general(C, P, n2, mp, ip, op, nz, G, pc);
+  couple_block_general(C, P, n2, mp, ip, op, nz, L, S, pc);
   if (LANE == 0)
     for (int c = 0; c < ch; c++) nonzero[unit * ch + c] = nz[c];
 }
@@ -596,7 +603,7 @@ struct vamd_ctx {
   enum { WS_MDCT_RAW, WS_LOGMDCT, WS_LOGFFT, WS_NOISE, WS_TONE, WS_MDCT, WS_ILOGMASK, WS_IWORK, WS_POSTS, WS_POSTVALID,
          WS_NONZERO, WS_LOCAL, WS_AMPIN, WS_AMPGLOB, WS_PCM, WS_SEED, WS_SURV, WS_NSURV, WS_MISC,
          WS_ENV_NEAR, WS_ENV_RAW, WS_ENV_AMP, WS_ENV_BITS, WS_ENV_STAGE, WS_M_ILOGMASK, WS_M_STAGE,
-         WS_RES_CLASS, WS_RES_ENTRIES, WS_RES_COUNT, WS_COUNT };
+         WS_RES_CLASS, WS_RES_ENTRIES, WS_RES_COUNT, WS_COUPLE_STATE, WS_COUNT };
   DevBuf ws[2][WS_COUNT];  // per size class (a mixed stream keeps both batches in flight)
   // pinned staging for the per-block host API
   void *h_stage = nullptr;
@@ -887,6 +894,7 @@ struct BatchRun {
   DescP d;
   const vamd_batch_io *io;
   ResBufs rb;
+  float *couple_state;  // [units][4][ch][n2] or null (alloc_couple_state)
   int nst;  // stages launched (for vamd_profile)
 };
 
@@ -982,22 +990,35 @@ static void launch_residue_pack(vamd_ctx *c, BatchRun *R, hipStream_t s, long un
   }
 }
 
+// layouts beyond stereo keep the channels' running state of the coupling stage in HBM (k_couple.h)
+static bool needs_general_couple(const vamd_ctx *c, int W) {
+  return c->B.channels > 2 || c->B.couple[W].coupling_steps > 1;
+}
+static int alloc_couple_state(vamd_ctx *c, BatchRun *R, long units) {
+  R->couple_state = nullptr;
+  if (R->nb == 0 || !needs_general_couple(c, R->W)) return VAMD_OK;
+  void *v;
+  int r = ws_get(c, R->W, vamd_ctx::WS_COUPLE_STATE, (size_t)units * 4 * c->B.channels * (c->B.bs[R->W] / 2) * 4, &v);
+  if (r) return r;
+  R->couple_state = (float *)v;
+  return VAMD_OK;
+}
+
 // couple / quantise / normalise for `units` (block, candidate) pairs
 static void launch_couple(vamd_ctx *c, BatchRun *R, hipStream_t s, long units, int blob_base, int nblobs, const float *mdct,
                           const int *ilogmask, int *iwork, int *nonzero) {
   const int W = R->W, ch = c->B.channels;
   const PsyP &P0 = c->B.psy[2 * W], &P1 = c->B.psy[2 * W + 1];
   const int n2 = c->B.xf[W].n / 2;
-  if (ch > 2 || c->B.couple[W].coupling_steps > 1) {
-    const size_t lds = (size_t)n2 * 4 * (3 + ch + c->B.couple[W].coupling_steps);
-    hipLaunchKernelGGL(k_couple_general, dim3((unsigned)units), dim3(64), lds, s, P0, P1, c->B.couple_all[W], blob_base, nblobs,
-                       R->d, mdct, ilogmask, iwork, nonzero);
+  if (needs_general_couple(c, W)) {
+    hipLaunchKernelGGL(k_couple_general, dim3((unsigned)units), dim3(64), (size_t)n2 * 12 + 1024, s, P0, P1, c->B.couple_all[W],
+                       blob_base, nblobs, R->d, mdct, ilogmask, iwork, nonzero, R->couple_state);
     return;
   }
   // the LDS arrays serve noise normalisation's sort only (lib/psy.c:941-1010); without it the
   // stage is register-only and the CU holds twice as many of its waves
   const bool norm0 = P0.normal_p && P0.normal_start < n2, norm1 = P1.normal_p && P1.normal_start < n2;
-  hipLaunchKernelGGL(k_couple, dim3((unsigned)units), dim3(64), (norm0 || norm1) ? (size_t)n2 * 12 : 0, s, P0, P1,
+  hipLaunchKernelGGL(k_couple, dim3((unsigned)units), dim3(64), (norm0 || norm1) ? (size_t)n2 * 12 + 1024 : 0, s, P0, P1,
                      c->B.couple_all[W], blob_base, nblobs, R->d, mdct, ilogmask, iwork, nonzero);
 }
 
@@ -1094,6 +1115,7 @@ static int run_batch(vamd_ctx *c, const vamd_batch_desc *desc, const vamd_batch_
         (r = res_bufs(c, R.W, R.nb * VAMD_PACKETBLOBS, M->res_class, M->res_entries, M->res_count, &R.rb)))
       return r;
   }
+  if (level >= VAMD_LEVEL_FULL && (r = alloc_couple_state(c, &R, M ? R.nb * VAMD_PACKETBLOBS : R.nb))) return r;
   const int ch = c->B.channels;
   hipStream_t s = c->stream;
   launch_transform(c, &R);
@@ -1249,6 +1271,7 @@ int vamd_analyze_stream_mixed(vamd_ctx *c, const vamd_batch_desc *desc_short, co
   BatchRun R[2];
   if ((r = prepare_run(c, desc_short, io_short, VAMD_LEVEL_FULL, &R[0]))) return r;
   if ((r = prepare_run(c, desc_long, io_long, VAMD_LEVEL_FULL, &R[1]))) return r;
+  if ((r = alloc_couple_state(c, &R[0], R[0].nb)) || (r = alloc_couple_state(c, &R[1], R[1].nb))) return r;
   // scratch for the chained state; an empty size class still needs valid (unused) pointers
   void *misc = nullptr;
   if ((r = ws_get(c, 0, vamd_ctx::WS_MISC, 256, &misc))) return r;
