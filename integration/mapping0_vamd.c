@@ -190,7 +190,7 @@ static int mapping0_forward_vamd(vorbis_block *vb) {
     return 0;
   }
 
-  /* ---- modes whose residue the GPU does not search (e.g. coupling switched off): the numeric
+  /* ---- modes whose residue the GPU does not search (none that libvorbisenc sets up; hand-built ones): the numeric
      section through couple/quantise is one call (lib/mapping0.c:254-576,613-646; managed: +:507-573
      for each candidate), the bit-writing half stays the reference's host code */
   mdct = _vorbis_block_alloc(vb, ch * (n / 2) * sizeof(*mdct));
