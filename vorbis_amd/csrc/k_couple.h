@@ -52,23 +52,52 @@ struct CoupleLds {
 //    subtraction equals r subtractions of 1.f, all of which are exact (the operand is a float no
 //    larger than jn/4, the result is smaller and a multiple of the operand's ulp).
 //   accp  LDS [nparts] scratch
-VAMD_DEV void noise_norm_wave(const PsyP &P, const CoupleLds &L, float *accp, int n2, int partition, int nparts, int *out) {
-  WAVE_FOR(p, nparts) {
+//   L.cand  ve of a candidate, -1 otherwise;  L.key  the sort key q[] of a candidate, -1.f otherwise (read as
+//           integers: non-negative floats order like their bit patterns, and -1.f is below all of them)
+//   accp    LDS [nparts] scratch
+VAMD_DEV void noise_norm_wave(const PsyP &P, const CoupleLds &L, float *accp, int n2, int partition, int nparts, int nstart,
+                              int *out) {
+  const int p_first = nstart / partition;  // partitions before normal_start hold no candidates
+  const bool quads = (partition & 3) == 0;
+  WAVE_FOR(pp, nparts - p_first) {
+    const int p = pp + p_first;
     const int b0 = p * partition, jn = partition > n2 - b0 ? n2 - b0 : partition;
     float acc = 0.f;
-    for (int j = 0; j < jn; j++)
-      if (L.cand[b0 + j] >= 0.f) acc += L.cand[b0 + j];
+    if (quads && jn == partition) {
+      for (int j = 0; j < jn; j += 4) {
+        const F4 v = *(const F4 *)(L.cand + b0 + j);
+        acc += v.x >= 0.f ? v.x : 0.f;  // (adding +0 is exact: the sum is the candidates' alone, in index order)
+        acc += v.y >= 0.f ? v.y : 0.f;
+        acc += v.z >= 0.f ? v.z : 0.f;
+        acc += v.w >= 0.f ? v.w : 0.f;
+      }
+    } else {
+      for (int j = 0; j < jn; j++)
+        if (L.cand[b0 + j] >= 0.f) acc += L.cand[b0 + j];
+    }
     accp[p] = acc;
   }
   WAVE_SYNC();
-  WAVE_FOR(b, n2) {
+  const int *sk = (const int *)L.key;
+  const int lo = p_first * partition;
+  WAVE_FOR(bb, n2 - lo) {
+    const int b = bb + lo;
     if (L.cand[b] >= 0.f) {
       const int p = b / partition, b0 = p * partition, jn = partition > n2 - b0 ? n2 - b0 : partition;
-      const float kb = L.key[b];
+      const int kb = sk[b];
+      // place in the stable descending sort: keys above mine, and equal keys ahead of me (s >= k <=> s + 1 > k)
       int rank = 0;
-      for (int j = 0; j < jn; j++) {
-        const int o = b0 + j;
-        if (L.cand[o] >= 0.f && (L.key[o] > kb || (L.key[o] == kb && o < b))) rank++;
+      if (quads && jn == partition) {
+        for (int j = 0; j < jn; j += 4) {
+          const I4 v = *(const I4 *)(sk + b0 + j);
+          const int o = b0 + j;
+          rank += (v.x + (o < b ? 1 : 0)) > kb ? 1 : 0;
+          rank += (v.y + (o + 1 < b ? 1 : 0)) > kb ? 1 : 0;
+          rank += (v.z + (o + 2 < b ? 1 : 0)) > kb ? 1 : 0;
+          rank += (v.w + (o + 3 < b ? 1 : 0)) > kb ? 1 : 0;
+        }
+      } else {
+        for (int j = 0; j < jn; j++) rank += (sk[b0 + j] + (b0 + j < b ? 1 : 0)) > kb ? 1 : 0;
       }
       const float left = accp[p] - (float)rank;
       out[b] = (double)left >= P.normal_thresh ? (int)unitnorm(L.sgn[b]) : 0;
@@ -241,11 +270,11 @@ VAMD_DEV void couple_block(const CoupleP &C, const PsyP &P, int n2, const float 
       const ChanBin B = chan_bin(nz[k], nz[k] ? mdct[k][b] : 0.f, nz[k] ? ilogmask[k][b] : 0, b, nstart, C);
       iwork[k][b] = B.out;
       L.cand[b] = B.cand;
-      L.key[b] = B.qe;
+      L.key[b] = B.cand >= 0.f ? B.qe : -1.f;
       L.sgn[b] = B.re;
     }
     WAVE_SYNC();
-    if (nz[k]) noise_norm_wave(P, L, L.accp, n2, partition, nparts, iwork[k]);
+    if (nz[k]) noise_norm_wave(P, L, L.accp, n2, partition, nparts, nstart, iwork[k]);
     WAVE_SYNC_GLOBAL();  // iwork[] changes hands between lanes through HBM
   }
   pc.mark(0);
@@ -261,11 +290,11 @@ VAMD_DEV void couple_block(const CoupleP &C, const PsyP &P, int n2, const float 
       iwork[Mi][b] = iM;
       iwork[Ai][b] = iA;
       L.cand[b] = cand;
-      L.key[b] = M.qe;
+      L.key[b] = cand >= 0.f ? M.qe : -1.f;
       L.sgn[b] = M.re;
     }
     WAVE_SYNC();
-    noise_norm_wave(P, L, L.accp, n2, partition, nparts, iwork[Mi]);
+    noise_norm_wave(P, L, L.accp, n2, partition, nparts, nstart, iwork[Mi]);
     WAVE_SYNC_GLOBAL();
     nz[Mi] = nz[Ai] = 1;  // lib/psy.c:1204-1212
   }
@@ -311,13 +340,13 @@ VAMD_DEV void couple_block_general(const CoupleP &C, const PsyP &P, int n2, cons
       S.fg[k * n2 + b] = B.fg;
       if (norm_active) {
         L.cand[b] = B.cand;
-        L.key[b] = B.qe;
+        L.key[b] = B.cand >= 0.f ? B.qe : -1.f;
         L.sgn[b] = B.re;
       }
     }
     if (norm_active) {
       WAVE_SYNC();
-      if (nz[k]) noise_norm_wave(P, L, L.accp, n2, partition, nparts, iwork[k]);
+      if (nz[k]) noise_norm_wave(P, L, L.accp, n2, partition, nparts, nstart, iwork[k]);
     }
     WAVE_SYNC_GLOBAL();
     pend[k] = nz[k] ? 1 : 0;  // quant[] = out*out*floor past normal_start, flags or not (flags == NULL)
@@ -344,13 +373,13 @@ VAMD_DEV void couple_block_general(const CoupleP &C, const PsyP &P, int n2, cons
       iwork[Ai][b] = iA;
       if (norm_active) {
         L.cand[b] = cand;
-        L.key[b] = M.qe;
+        L.key[b] = cand >= 0.f ? M.qe : -1.f;
         L.sgn[b] = M.re;
       }
     }
     if (norm_active) {
       WAVE_SYNC();
-      noise_norm_wave(P, L, L.accp, n2, partition, nparts, iwork[Mi]);
+      noise_norm_wave(P, L, L.accp, n2, partition, nparts, nstart, iwork[Mi]);
     }
     WAVE_SYNC_GLOBAL();
     pend[Mi] = 2;  // noise_normalize with flags: unflagged bins only
