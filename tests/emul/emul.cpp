@@ -68,7 +68,7 @@ static void residue_and_pack(const Bound &B, int W, int lW, int nW, const int *i
   if (!packet) return;
   std::vector<int> ring(VAMD_PK_RING), outv(VAMD_POSTS_STRIDE), cls(VAMD_RES_CLASS_STRIDE), off(B.res_off_ints[W]),
       info(B.res_off_ints[W]);
-  pack_block(B.pack[W], B.floor[W], B.res[W], cm, ch, W, lW, nW, posts, post_valid, res_class, res_entries, res_count,
+  pack_block(B.pack[W], B.floor[W][0], B.floor[W][1], B.res[W][0], B.res[W][1], cm, ch, W, lW, nW, posts, post_valid, res_class, res_entries, res_count,
              ring.data(), outv.data(), cls.data(), off.data(), info.data(), (unsigned *)packet, B.pack[W].capacity / 4,
              packet_bits);
 }

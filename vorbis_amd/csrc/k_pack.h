@@ -87,7 +87,7 @@ VAMD_DEV void pack_floor(const PackP &K, int sm, const FloorP &F, const int *__r
     ring_put(r, 0u, LANE == 0 ? 1 : 0);
     return;
   }
-  const vamd_floor1_tab &f = *K.ftab[sm];
+  const vamd_floor1_tab &f = *(sm ? K.ftab[1] : K.ftab[0]);  // (no dynamic index into the by-value parameter struct)
   {
     LaneInts fitted, postlist, post, wrapped;
     fitted.load(posts, F.posts);
@@ -100,7 +100,7 @@ VAMD_DEV void pack_floor(const PackP &K, int sm, const FloorP &F, const int *__r
   // the nontrivial-floor flag and the two end posts (:833-841)
   for (int t0 = 0; t0 < 3; t0 += NLANES) {
     const int t = t0 + LANE;
-    ring_put(r, t == 0 ? 1u : (unsigned)outv[t < 3 ? t - 1 : 0], t == 0 ? 1 : (t < 3 ? K.qbits[sm] : 0));
+    ring_put(r, t == 0 ? 1u : (unsigned)outv[t < 3 ? t - 1 : 0], t == 0 ? 1 : (t < 3 ? (sm ? K.qbits[1] : K.qbits[0]) : 0));
   }
   // partition by partition (:845-917): slot 0 of a partition is its cascade word, slots 1..8 its posts
   const int slots = f.partitions * 9;
@@ -189,8 +189,8 @@ VAMD_DEV void pack_residue(const PackP &K, const ResP &R, const int *__restrict_
 //   res_class [submaps][VAMD_RES_CLASS_STRIDE], res_entries [row], res_count [submaps][2]: one block's rows
 //   packet HBM [out_words] words; bits_out <- oggpack_bits()
 //   LDS: ring [VAMD_PK_RING] zeroed here, outv [VAMD_POSTS_STRIDE], cls/off/info as pack_residue
-VAMD_DEV void pack_block(const PackP &K, const FloorP *F /*[submaps]*/, const ResP *R /*[submaps]*/, const ChMap &cm, int ch,
-                         int W, int lW, int nW, const int *__restrict__ posts, const int *__restrict__ post_valid,
+VAMD_DEV void pack_block(const PackP &K, const FloorP &F0, const FloorP &F1, const ResP &R0, const ResP &R1, const ChMap &cm,
+                         int ch, int W, int lW, int nW, const int *__restrict__ posts, const int *__restrict__ post_valid,
                          const int *__restrict__ res_class, const unsigned short *__restrict__ res_entries,
                          const int *__restrict__ res_count, int *ring, int *outv, int *cls, int *off, int *info,
                          unsigned *__restrict__ packet, int out_words, int *__restrict__ bits_out) {
@@ -214,10 +214,12 @@ VAMD_DEV void pack_block(const PackP &K, const FloorP *F /*[submaps]*/, const Re
   }
   for (int c = 0; c < ch; c++) {
     const int sm = cm.sub[c];
-    pack_floor(K, sm, F[sm], posts + c * VAMD_POSTS_STRIDE, post_valid[c], outv, r);
+    pack_floor(K, sm, sm ? F1 : F0, posts + c * VAMD_POSTS_STRIDE, post_valid[c], outv, r);
   }
-  for (int sm = 0; sm < cm.submaps; sm++)
-    pack_residue(K, R[sm], res_class + R[sm].cls_base, res_entries + R[sm].ent_base, res_count + 2 * sm, cls, off, info, r);
+  for (int sm = 0; sm < cm.submaps; sm++) {
+    const ResP &R = sm ? R1 : R0;
+    pack_residue(K, R, res_class + R.cls_base, res_entries + R.ent_base, res_count + 2 * sm, cls, off, info, r);
+  }
   ring_flush(r, (r.bitpos + 31) >> 5);
   if (LANE == 0) *bits_out = (int)r.bitpos;
 }

@@ -5,7 +5,7 @@
 // :534-640, _encodepart :384-410, local_book_besterror :322-382); SURVEY.md 8f rank 2.  Looking the
 // chosen entries' codewords up and packing them, with the phrase-book words, is k_pack.h.
 //
-// One wave per block and submap.  A partition's class needs only its own 2 x 16 values; a (partition,
+// One team (workgroup of up to four waves) per block and submap.  A partition's class needs only its own 2 x 16 values; a (partition,
 // stage, vector) search touches only its own `dim` values of the running work vector and is
 // integer arithmetic, so within a stage all vectors of all partitions are searched at once and
 // the stages -- which refine the same values -- follow each other with a wave sync.  Entries are
@@ -89,25 +89,27 @@ VAMD_DEV int residue_besterror(const ResP &R, const vamd_book_tab &bk, int *a) {
 VAMD_DEV int residue_offsets(const ResP &R, int partvals, const int *cls, int *off, int *info) {
   const vamd_residue_tab &t = *R.tab;
   const int spp = t.grouping, items = t.stages * partvals;
-  WAVE_FOR(it, items) {
+  TEAM_FOR(it, items) {
     const int s = it / partvals, i = it - s * partvals;
     const int c = cls[i];
     const int bn = ((t.secondstages[c] >> s) & 1) ? t.partbooks[c][s] : -1;
     info[it] = bn;
     off[it] = bn >= 0 ? spp / R.books[bn].dim : 0;
   }
-  WAVE_SYNC();
-  int carry = 0;  // exclusive prefix sum over the <= 8 x 64 counts, a wave-width at a time
-  for (int base = 0; base < items; base += NLANES) {
-    const int it = base + LANE;
-    const int c = it < items ? off[it] : 0;
-    const int incl = wave_scan_sum(c);
-    if (it < items) off[it] = carry + incl - c;
-    carry += wave_last(incl);
+  TEAM_SYNC();
+  if (TEAM_FIRST_WAVE) {
+    int carry = 0;  // exclusive prefix sum over the <= 8 x 256 counts, a wave-width at a time
+    for (int base = 0; base < items; base += NLANES) {
+      const int it = base + LANE;
+      const int c = it < items ? off[it] : 0;
+      const int incl = wave_scan_sum(c);
+      if (it < items) off[it] = carry + incl - c;
+      carry += wave_last(incl);
+    }
+    if (LANE == 0) off[items] = carry;
   }
-  if (LANE == 0) off[items] = carry;
-  WAVE_SYNC();
-  return carry;
+  TEAM_SYNC();
+  return off[items];
 }
 
 // One submap's residue: classification and search.
@@ -132,7 +134,7 @@ VAMD_DEV void residue_block(const ResP &R, int n2, const int *const *iwork, cons
     for (int c = 0; c < ch; c++) ns += nonzero[c] ? 1 : 0;
   }
   if (!ns) {  // res*_class returns NULL and res*_forward writes nothing (:740-744,:766-777,:799-808)
-    if (LANE == 0) {
+    if (TEAM_LEADER) {
       count_out[0] = 0;
       count_out[1] = 0;
     }
@@ -140,22 +142,22 @@ VAMD_DEV void residue_block(const ResP &R, int n2, const int *const *iwork, cons
   }
   if (t.type == 2) {
     // the interleaved work vector of res2_forward (:791-797)
-    WAVE_FOR(j, n2)
+    TEAM_FOR(j, n2)
       for (int c = 0; c < ch; c++) work[j * ch + c] = iwork[c][j];
   } else {
     int sidx = 0;  // coded channels, packed in order (:738-739)
     for (int c = 0; c < ch; c++)
       if (nonzero[c]) {
-        WAVE_FOR(j, n2) work[sidx * n2 + j] = iwork[c][j];
+        TEAM_FOR(j, n2) work[sidx * n2 + j] = iwork[c][j];
         sidx++;
       }
   }
-  WAVE_SYNC();
+  TEAM_SYNC();
   const int slots = partvals * ns;
   // _01class (:436-453): peak against classmetric1, scaled mean against classmetric2, stream by stream
   if (t.type == 1) {
     const float scale = (float)(100. / spp);
-    WAVE_FOR(q, slots) {
+    TEAM_FOR(q, slots) {
       const int i = q / ns, strm = q - i * ns;
       const int *w = work + strm * n2 + t.begin + i * spp;
       int mx = 0, ent = 0;
@@ -173,7 +175,7 @@ VAMD_DEV void residue_block(const ResP &R, int n2, const int *const *iwork, cons
     }
   }
   // _2class (:501-518): channel 0 of the bundle against classmetric1, the rest against classmetric2
-  if (t.type != 1) WAVE_FOR(i, partvals) {
+  if (t.type != 1) TEAM_FOR(i, partvals) {
     int magmax = 0, angmax = 0;
     const int *w = work + t.begin + i * spp;  // begin/ch bins in, interleaved
     for (int j = 0; j < spp; j += ch) {
@@ -190,9 +192,9 @@ VAMD_DEV void residue_block(const ResP &R, int n2, const int *const *iwork, cons
     cls[i] = j;
     class_out[i] = j;
   }
-  WAVE_SYNC();
+  TEAM_SYNC();
   const int carry = residue_offsets(R, slots, cls, off, info);
-  if (LANE == 0) {
+  if (TEAM_LEADER) {
     count_out[0] = slots;
     count_out[1] = carry;
   }
@@ -202,7 +204,7 @@ VAMD_DEV void residue_block(const ResP &R, int n2, const int *const *iwork, cons
   for (int s = 0; s < stages; s++) {
     const int *so = off + s * slots;
     const int base = so[0], total = so[slots] - base;  // (off[] is stage-major: the next stage starts there)
-    WAVE_FOR(v, total) {
+    TEAM_FOR(v, total) {
       int lo = 0, hi = slots - 1;  // the slot whose vectors include v: last q with so[q] - base <= v
       while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
@@ -214,7 +216,7 @@ VAMD_DEV void residue_block(const ResP &R, int n2, const int *const *iwork, cons
       const int entry = residue_besterror(R, bk, work + strm * n2 + t.begin + i * spp + k * bk.dim);
       if (base + v < R.cap) entries_out[base + v] = (unsigned short)entry;
     }
-    WAVE_SYNC();
+    TEAM_SYNC();
   }
   pc.mark(1);
 }

@@ -437,7 +437,8 @@ __global__ __launch_bounds__(64) void k_floor_managed(PsyP P0, PsyP P1, FloorP F
 // stage 6 (optional): residue classification + lattice-VQ search, one wave per unit and submap
 // (k_residue.h).  Output rows of a unit: res_class [submaps][VAMD_RES_CLASS_STRIDE], res_entries [ent_row],
 // res_count [submaps][2]; this launch fills submap `sm`'s part.
-__global__ __launch_bounds__(64) void k_residue(ResP R, ChMap cm, int sm, int ent_row, DescP d, int ch, int n2,
+#define VAMD_RES_WAVES 4  // waves per unit: they share one LDS copy of the work vector
+__global__ __launch_bounds__(64 * VAMD_RES_WAVES) void k_residue(ResP R, ChMap cm, int sm, int ent_row, DescP d, int ch, int n2,
                                                 const int *__restrict__ iwork, const int *__restrict__ nonzero,
                                                 int *__restrict__ res_class, unsigned short *__restrict__ res_entries,
                                                 int *__restrict__ res_count) {
@@ -475,9 +476,7 @@ __global__ __launch_bounds__(64) void k_pack(PackP K, FloorP F0, FloorP F1, ResP
   int *cls = outv + VAMD_POSTS_STRIDE;           // [VAMD_RES_CLASS_STRIDE]
   int *off = cls + VAMD_RES_CLASS_STRIDE;        // [stages*slots + 1], then info [stages*slots], sized for the larger submap
   int *info = off + lds_ints;
-  const FloorP F[VAMD_MAX_SUBMAPS] = {F0, F1};
-  const ResP R[VAMD_MAX_SUBMAPS] = {R0, R1};
-  pack_block(K, F, R, cm, ch, W, d_lW(d, blk), d_nW(d, blk), posts + u * ch * VAMD_POSTS_STRIDE, post_valid + u * ch,
+  pack_block(K, F0, F1, R0, R1, cm, ch, W, d_lW(d, blk), d_nW(d, blk), posts + u * ch * VAMD_POSTS_STRIDE, post_valid + u * ch,
              res_class + u * (cm.submaps * VAMD_RES_CLASS_STRIDE), res_entries + u * (long)ent_row,
              res_count + u * cm.submaps * 2, ring, outv, cls, off, info, packets + u * (long)stride_words, stride_words,
              packet_bits + u);
@@ -978,7 +977,7 @@ static void launch_residue_pack(vamd_ctx *c, BatchRun *R, hipStream_t s, long un
   const int W = R->W, ch = c->B.channels, n2 = c->B.xf[W].n / 2;
   const ChMap &cm = c->B.chmap[W];
   for (int sm = 0; sm < cm.submaps; sm++)
-    hipLaunchKernelGGL(k_residue, dim3((unsigned)units), dim3(64), (size_t)c->B.res_lds_ints[W] * 4, s, c->B.res[W][sm], cm, sm,
+    hipLaunchKernelGGL(k_residue, dim3((unsigned)units), dim3(64 * (c->B.res[W][sm].bundle * n2 > 4096 ? VAMD_RES_WAVES : 2)), (size_t)c->B.res_lds_ints[W] * 4, s, c->B.res[W][sm], cm, sm,
                        c->B.res_cap[W], R->d, ch, n2, iwork, nonzero, rb.cls, rb.entries, rb.count);
   prof_mark(c), R->nst++;
   if (packets) {

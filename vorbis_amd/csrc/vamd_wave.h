@@ -86,6 +86,21 @@
 #define WAVE_FOR(i, count) for (int i = LANE; i < (count); i += NLANES)
 #endif
 
+// A "team": all the waves of a workgroup working on one unit (k_residue: the search of a block's
+// vectors is wide enough for several waves, and sharing one LDS copy of the work vector between them
+// keeps more units resident per CU).  With a 64-thread workgroup a team is a wave.
+#if VAMD_GPU
+#define TEAM_FOR(i, count) for (int i = (int)threadIdx.x; i < (count); i += (int)blockDim.x)
+#define TEAM_SYNC() __syncthreads()
+#define TEAM_FIRST_WAVE (threadIdx.x < 64)
+#define TEAM_LEADER (threadIdx.x == 0)
+#else
+#define TEAM_FOR(i, count) for (int i = 0; i < (count); i++)
+#define TEAM_SYNC() ((void)0)
+#define TEAM_FIRST_WAVE 1
+#define TEAM_LEADER 1
+#endif
+
 namespace vamd {
 
 #if VAMD_GPU
