@@ -162,7 +162,26 @@ def neighbour_stages(an, pcm, outs, nb):
         an.envelope_search_batch(streams, steps, states=st, ret=ret)
     torch.cuda.synchronize()
     det = 3 * ns * steps / (time.perf_counter() - t0)
-    return {"analysis_with_residue_search": {"value": with_res, "unit": "stereo blocks/s", "mean_entries_per_block": entries},
+    # the 5.1 layout (six channels, two submaps, four coupling steps), PCM in, packets out
+    surround = None
+    try:
+        an6 = vorbis_amd.Analyzer(vorbis_amd.default_setup_blob("44k_51_q3"), an.device)
+        nb6 = max(1024, nb // 8)
+        pcm6 = torch.rand((nb6, 6, an6.blocksizes[1]), device=pcm.device) - 0.5
+        pk6 = an6.alloc_outputs(1, nb6, ("ampmax_out", "packets", "packet_bits"))
+        an6.analyze(pcm6, outs=pk6)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            an6.analyze(pcm6, outs=pk6)
+        torch.cuda.synchronize()
+        surround = {"value": 3 * nb6 / (time.perf_counter() - t0), "unit": "six-channel blocks/s (q 0.3 tables, PCM to packets)",
+                    "mean_packet_bytes": float(pk6["packet_bits"].float().mean().item()) / 8}
+        del pk6, pcm6
+        an6.close()
+    except Exception as e:  # informational only
+        surround = {"error": repr(e)}
+    return {"surround_5_1": surround, "analysis_with_residue_search": {"value": with_res, "unit": "stereo blocks/s", "mean_entries_per_block": entries},
             "pcm_to_packets": {"value": to_packets, "unit": "stereo blocks/s", "mean_packet_bytes": packet_bytes},
             "block_switching_detector": {"value": det, "unit": "stereo detector steps/s (one per 64 samples)",
                                          "streams": ns, "steps_per_stream": int(steps)}}
