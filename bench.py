@@ -71,6 +71,7 @@ def parse():
     ap.add_argument("--blocks", type=int, default=None, help="stereo blocks per GPU (default 131072; c2/c3: 65536)")
     ap.add_argument("--setup", default="44k_stereo_q4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-neighbours", action="store_true", help="skip the informational extra stages (profiling runs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -314,7 +315,7 @@ def main():
             },
             "roofline": roof,
         }
-        if world == 1 and a.workload == "c4":
+        if world == 1 and a.workload == "c4" and not a.no_neighbours:
             try:  # informational: the stages either side of the metric's path
                 line["neighbours"] = neighbour_stages(an, pcm, outs, nb)
             except Exception as e:

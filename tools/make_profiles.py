@@ -26,7 +26,7 @@ def table(path):
 bench = json.loads(open(os.path.join(SRC, "bench_under_rocprof.json")).read().strip().splitlines()[-1])
 kt = open(os.path.join(SRC, "kernel_trace_stats.txt")).read().splitlines()
 with open(os.path.join(ROOT, "profiles", TAG + "_kernel_trace_stats.txt"), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline\n")
+    f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-neighbours\n")
     f.write("# MI355X (gfx950).  %d stereo 2048-blocks per step (C4 full analysis), 6 launches of each stage\n"
             % bench["config"]["blocks_per_gpu"])
     f.write("# kernel = 1 warm-up + 5 timed steps.  Durations in microseconds (rocpd `top_kernels` view).\n")

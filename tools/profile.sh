@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/profile
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/kt_bench -o kt -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/kt_bench.log
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/kt_bench -o kt -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-neighbours > $O/bench_under_rocprof.json 2> $O/kt_bench.log
 python $R/tools/prof_summary.py kt $O/kt_bench/kt_results.db > $O/kernel_trace_stats.txt 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o f -- python $R/tools/prof_run.py 65536 1 > /dev/null 2> $O/pmc_fetch.log
 python $R/tools/prof_summary.py pmc $O/pmc_fetch/f_results.db > $O/pmc_fetch_size.txt 2>&1
