@@ -210,3 +210,24 @@ def test_hybrid_encode_emits_reference_packets(quality):
     assert [(b["lW"], b["W"], b["nW"], b["blocktype"]) for b in want] == [(b["lW"], b["W"], b["nW"], b["blocktype"]) for b in got]
     for k, (a, b) in enumerate(zip(want, got)):
         assert a["packet"] == b["packet"], "packet %d differs (W=%d)" % (k, a["W"])
+
+
+@pytest.mark.gpu
+@needs_ref
+def test_gpu_48k_surround_stream_api():
+    """48 kHz 5.1 through the stream entry point (ampmax chained across blocks) straight to packets."""
+    import torch
+    e = ref.RefEncoder(6, 48000, 0.5)
+    rng = np.random.default_rng(48)
+    x = ((rng.random((6, 48000), dtype=np.float32) - 0.5) * 0.8).astype(np.float32)
+    stream = e.encode_stream(x)
+    run = stream[4:12]                                   # consecutive blocks of the stream (steady noise: all long)
+    assert all(b["W"] == 1 and b["lW"] == 1 and b["nW"] == 1 for b in run)
+    an = vorbis_amd.Analyzer(e.pack_setup(), 0)
+    pcm = torch.from_numpy(np.stack([b["pcm"] for b in run])).cuda()
+    outs, state = an.analyze_stream(pcm, stream[3]["ampmax_out"], W=1, want=("ampmax_out", "packets", "packet_bits"))
+    torch.cuda.synchronize()
+    rows, bits = outs["packets"].cpu().numpy(), outs["packet_bits"].cpu().numpy()
+    for k, b in enumerate(run):
+        assert vorbis_amd.packet_bytes(rows[k], bits[k]) == b["packet"], k
+    assert np.float32(state) == np.float32(run[-1]["ampmax_out"])

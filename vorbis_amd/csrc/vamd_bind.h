@@ -394,8 +394,6 @@ inline void bind_params(const std::vector<unsigned char> &image, const std::vect
                                           sizeof(vamd_residue_tab) * (W * VAMD_MAX_SUBMAPS + src));
       Rp.books = K.books;
       Rp.base = base;
-      Rp.log2_grouping = 0;
-      while ((1 << Rp.log2_grouping) < r.grouping) Rp.log2_grouping++;
       int bundle = 0;
       for (int c = 0; c < h.channels; c++) bundle += m.chmuxlist[c] == src;
       const int partvals = (r.end - r.begin) / r.grouping;
@@ -427,6 +425,7 @@ inline void bind_params(const std::vector<unsigned char> &image, const std::vect
       Rp.cap = ok ? worst * Rp.slots : 0;
       Rp.cls_base = sm * VAMD_RES_CLASS_STRIDE;
       Rp.ent_base = ent_base;
+      Rp.lds_ints = bundle * n2 + VAMD_RES_CLASS_STRIDE + 2 * r.stages * Rp.slots + 1;
       if (sm < m.submaps) {
         all_ok = all_ok && ok;
         ent_base += Rp.cap;

@@ -977,7 +977,9 @@ static void launch_residue_pack(vamd_ctx *c, BatchRun *R, hipStream_t s, long un
   const int W = R->W, ch = c->B.channels, n2 = c->B.xf[W].n / 2;
   const ChMap &cm = c->B.chmap[W];
   for (int sm = 0; sm < cm.submaps; sm++)
-    hipLaunchKernelGGL(k_residue, dim3((unsigned)units), dim3(64 * (c->B.res[W][sm].bundle * n2 > 4096 ? VAMD_RES_WAVES : 2)), (size_t)c->B.res_lds_ints[W] * 4, s, c->B.res[W][sm], cm, sm,
+    // a stereo bundle's search keeps two waves busy, the five-channel bundle of the 5.1 layout four
+    hipLaunchKernelGGL(k_residue, dim3((unsigned)units), dim3(64 * (c->B.res[W][sm].bundle * n2 > 4096 ? VAMD_RES_WAVES : 2)),
+                       (size_t)c->B.res[W][sm].lds_ints * 4, s, c->B.res[W][sm], cm, sm,
                        c->B.res_cap[W], R->d, ch, n2, iwork, nonzero, rb.cls, rb.entries, rb.count);
   prof_mark(c), R->nst++;
   if (packets) {

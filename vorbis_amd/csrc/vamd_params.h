@@ -69,18 +69,18 @@ struct EnvP {
   float band_window[VAMD_VE_BANDS][VAMD_VE_BANDWIN];
 };
 
-// residue back-end of one mode (type 2): tables stay in the HBM image
+// residue back-end of one mode and submap: tables stay in the HBM image
 struct ResP {
   const vamd_residue_tab *tab;
   const vamd_book_tab *books;
   const unsigned char *base;  // image base: books[].off_lengths are relative to it
-  int log2_grouping;
   int cap;                    // entries a block can emit at most (sizes the output rows)
   int covered;                // 1 when the GPU handles this residue
   int bundle;                 // channels in this submap's bundle
   int partvals;               // (end - begin) / grouping
   int slots;                  // classified (partition, stream) pairs at most: partvals x streams
   int cls_base, ent_base;     // where this submap's rows start inside a block's res_class / res_entries rows
+  int lds_ints;               // LDS ints k_residue needs for this submap
 };
 
 // packet assembly (k_pack.h): the floor's class tables and the codebooks' codewords, in the HBM image
