@@ -63,11 +63,6 @@ port_enc *port_open(const void *blob, size_t bytes) {
   if (!blob || bytes < sizeof(h)) return NULL;
   memcpy(&h, blob, sizeof(h));
   if (h.magic != VAMD_SETUP_MAGIC || h.version != VAMD_SETUP_VERSION || h.total_bytes > bytes) return NULL;
-  /* this restatement covers the mono / stereo layouts (one submap, at most one coupling step); the 5.1
-     layout is pinned against oracle/_ref only */
-  if (h.channels > 2 || h.mode[0].submaps != 1 || h.mode[1].submaps != 1 || h.mode[0].coupling_steps > 1 ||
-      h.mode[1].coupling_steps > 1)
-    return NULL;
   e = (port_enc *)calloc(1, sizeof(*e));
   e->blob = (unsigned char *)malloc(h.total_bytes);
   memcpy(e->blob, blob, h.total_bytes);
@@ -1107,7 +1102,8 @@ static void couple_quantize(const port_enc *e, int psy, int W, int blob, float *
   float postpoint = stereo_thr[g->coupling_postpointamp[blob]];
   float raw[VAMD_MAX_CH][64], quant[VAMD_MAX_CH][64], flo[VAMD_MAX_CH][64];
   int flag[VAMD_MAX_CH][64], nz[VAMD_MAX_CH];
-  float acc[VAMD_MAX_CH + 1];
+  float acc[VAMD_MAX_CH + VAMD_MAX_COUPLING];
+  int step;
   int i, j, k;
   if (n > 1000) postpoint = stereo_thr_limited[g->coupling_postpointamp[blob]];
   if (partition > 64) return; /* scratch rows hold 64 bins; libvorbisenc never exceeds 32 */
@@ -1145,8 +1141,8 @@ static void couple_quantize(const port_enc *e, int psy, int W, int blob, float *
       }
       track++;
     }
-    if (m->coupling_steps == 1) {
-      const int Mi = m->coupling_mag[0], Ai = m->coupling_ang[0];
+    for (step = 0; step < m->coupling_steps; step++) { /* lib/psy.c:1111-1201 */
+      const int Mi = m->coupling_mag[step], Ai = m->coupling_ang[step];
       int *iM = &iwork[Mi][i], *iA = &iwork[Ai][i];
       float *reM = raw[Mi], *reA = raw[Ai], *qeM = quant[Mi], *qeA = quant[Ai];
       float *floorM = flo[Mi], *floorA = flo[Ai];
@@ -1194,10 +1190,11 @@ static void couple_quantize(const port_enc *e, int psy, int W, int blob, float *
       }
     }
   }
-  if (m->coupling_steps == 1 && (nonzero[m->coupling_mag[0]] || nonzero[m->coupling_ang[0]])) {
-    nonzero[m->coupling_mag[0]] = 1;
-    nonzero[m->coupling_ang[0]] = 1;
-  }
+  for (step = 0; step < m->coupling_steps; step++) /* lib/psy.c:1204-1212 */
+    if (nonzero[m->coupling_mag[step]] || nonzero[m->coupling_ang[step]]) {
+      nonzero[m->coupling_mag[step]] = 1;
+      nonzero[m->coupling_ang[step]] = 1;
+    }
 }
 
 /* ---- residue back-end, type 2 (lib/res0.c:322-382,479-532,534-640,766-809) ----------------
@@ -1252,39 +1249,43 @@ static int book_besterror(const port_enc *e, const vamd_book_tab *bk, int *a) { 
   return index;
 }
 
-/* Type 2 (any channel count, interleaved) and type 1 with a single channel (_01class :412-470,
- * res1_class/res1_forward :729-755).  Returns 0, or -1 when the mode is not covered. */
-static int residue2(const port_enc *e, int W, int **in, const int *nonzero, port_taps *t) {
-  const vamd_residue_tab *r = &e->h.res[W][0];
+/* One submap's residue (lib/mapping0.c:660-684 hands the back-end the submap's bundle of channels):
+ * type 2 classifies and codes the bundle interleaved as one vector (res2_class / res2_forward,
+ * :766-809); type 1 every channel with a non-trivial floor on its own (res1_class / res1_forward,
+ * :729-762, _01class :412-470) -- _01forward then walks stage, partition, channel (:585-636; the phrase
+ * words it interleaves are host / k_pack business and not restated).  Classes are appended to the taps
+ * partition-major, channel-minor; entries in emission order.  Returns 0, or -1 for residue type 0. */
+static int residue_submap(const port_enc *e, int W, int sm, int **in, const int *nonzero, int ch, port_taps *t) {
+  const vamd_residue_tab *r = &e->h.res[W][sm];
   const vamd_book_tab *books = (const vamd_book_tab *)(e->blob + e->h.off_books);
-  const int ch = e->h.channels, n2 = e->h.blocksizes[W] / 2;
+  const int n2 = e->h.blocksizes[W] / 2;
   const int spp = r->grouping, nparts = r->partitions, n = r->end - r->begin, partvals = n / spp;
-  int *work, *cls;
-  long i, j, k, l, s, used = 0;
-  t->res_partvals = 0;
-  t->res_count = 0;
-  if (!(r->type == 2 || (r->type == 1 && ch == 1))) return -1;
+  int *work, *cls, *src[VAMD_MAX_CH];
+  long i, j, k, l, s, q, used = 0, streams;
+  if (r->type != 1 && r->type != 2) return -1;
   for (i = 0; i < ch; i++)
-    if (nonzero[i]) used++;
+    if (nonzero[i]) src[used++] = in[i];
   if (!used) return 0; /* res*_class returns NULL, res*_forward writes nothing */
-  cls = (int *)malloc(sizeof(int) * (partvals + 1));
-  if (r->type == 1) { /* _01class with one channel, :436-453 */
+  streams = r->type == 2 ? 1 : used;
+  cls = (int *)malloc(sizeof(int) * (partvals * streams + 1));
+  if (r->type == 1) { /* _01class over the coded channels, :436-453 */
     const float scale = 100. / spp;
     for (i = 0; i < partvals; i++) {
       const int offset = (int)(i * spp + r->begin);
-      int max = 0, ent = 0;
-      for (k = 0; k < spp; k++) {
-        if (abs(in[0][offset + k]) > max) max = abs(in[0][offset + k]);
-        ent += abs(in[0][offset + k]);
+      for (q = 0; q < used; q++) {
+        int max = 0, ent = 0;
+        for (k = 0; k < spp; k++) {
+          if (abs(src[q][offset + k]) > max) max = abs(src[q][offset + k]);
+          ent += abs(src[q][offset + k]);
+        }
+        ent *= scale;
+        for (k = 0; k < nparts - 1; k++)
+          if (max <= r->classmetric1[k] && (r->classmetric2[k] < 0 || ent < r->classmetric2[k])) break;
+        cls[i * streams + q] = (int)k;
       }
-      ent *= scale;
-      for (k = 0; k < nparts - 1; k++)
-        if (max <= r->classmetric1[k] && (r->classmetric2[k] < 0 || ent < r->classmetric2[k])) break;
-      cls[i] = (int)k;
-      if (t->res_class && i < t->res_class_cap) t->res_class[i] = (int)k;
     }
   } else
-  for (i = 0, l = r->begin / ch; i < partvals; i++) { /* _2class, :501-518 */
+  for (i = 0, l = r->begin / ch; i < partvals; i++) { /* _2class, :501-518 (all channels of the bundle, coded or not) */
     int magmax = 0, angmax = 0;
     for (j = 0; j < spp; j += ch) {
       if (abs(in[0][l]) > magmax) magmax = abs(in[0][l]);
@@ -1295,30 +1296,57 @@ static int residue2(const port_enc *e, int W, int **in, const int *nonzero, port
     for (j = 0; j < nparts - 1; j++)
       if (magmax <= r->classmetric1[j] && angmax <= r->classmetric2[j]) break;
     cls[i] = (int)j;
-    if (t->res_class && i < t->res_class_cap) t->res_class[i] = (int)j;
   }
-  t->res_partvals = partvals;
-  work = (int *)malloc(sizeof(int) * ch * n2); /* res2_forward, :791-797 */
-  for (i = 0; i < ch; i++)
-    for (j = 0, k = i; j < n2; j++, k += ch) work[k] = in[i][j];
-  for (s = 0; s < r->stages; s++) /* _01forward with ch == 1, :585-636 (phrase words are host code) */
+  for (i = 0; i < partvals * streams; i++) {
+    if (t->res_class && t->res_partvals < t->res_class_cap) t->res_class[t->res_partvals] = cls[i];
+    t->res_partvals++;
+  }
+  work = (int *)malloc(sizeof(int) * ch * n2);
+  if (r->type == 2) { /* res2_forward's interleaved working vector, :791-797 */
+    for (i = 0; i < ch; i++)
+      for (j = 0, k = i; j < n2; j++, k += ch) work[k] = in[i][j];
+  } else {
+    for (q = 0; q < used; q++) memcpy(work + q * n2, src[q], sizeof(int) * n2);
+  }
+  for (s = 0; s < r->stages; s++) /* _01forward, :585-636 */
     for (i = 0; i < partvals; i++) {
       const long offset = i * spp + r->begin;
-      if (r->secondstages[cls[i]] & (1 << s)) {
-        const int bn = r->partbooks[cls[i]][s];
-        if (bn >= 0) {
-          const vamd_book_tab *bk = books + bn;
-          const int step = spp / bk->dim;
-          for (k = 0; k < step; k++) { /* _encodepart, :396-410 */
-            int entry = book_besterror(e, bk, work + offset + k * bk->dim);
-            if (t->res_entries && t->res_count < t->res_entries_cap) t->res_entries[t->res_count] = (unsigned short)entry;
-            t->res_count++;
+      for (q = 0; q < streams; q++) {
+        const int c = cls[i * streams + q];
+        if (r->secondstages[c] & (1 << s)) {
+          const int bn = r->partbooks[c][s];
+          if (bn >= 0) {
+            const vamd_book_tab *bk = books + bn;
+            const int step = spp / bk->dim;
+            for (k = 0; k < step; k++) { /* _encodepart, :396-410 */
+              int entry = book_besterror(e, bk, work + (r->type == 2 ? 0 : q * n2) + offset + k * bk->dim);
+              if (t->res_entries && t->res_count < t->res_entries_cap) t->res_entries[t->res_count] = (unsigned short)entry;
+              t->res_count++;
+            }
           }
         }
       }
     }
   free(work);
   free(cls);
+  return 0;
+}
+
+/* every submap in order, lib/mapping0.c:660-684 */
+static int residue_all(const port_enc *e, int W, int **iwork, const int *nonzero, port_taps *t) {
+  const vamd_mode_tab *m = &e->h.mode[W];
+  int sm, c;
+  t->res_partvals = 0;
+  t->res_count = 0;
+  for (sm = 0; sm < m->submaps; sm++) {
+    int *bundle[VAMD_MAX_CH], zb[VAMD_MAX_CH], nb = 0;
+    for (c = 0; c < e->h.channels; c++)
+      if (m->chmuxlist[c] == sm) {
+        zb[nb] = nonzero[c] ? 1 : 0;
+        bundle[nb++] = iwork[c];
+      }
+    if (residue_submap(e, W, sm, bundle, zb, nb, t)) return -1;
+  }
   return 0;
 }
 
@@ -1354,7 +1382,7 @@ static int tap_block(const port_enc *e, const float *pcm_in, int lW, int W, int 
                      port_taps *t, port_mtaps *m) {
   const int ch = e->h.channels, n = e->h.blocksizes[W], n2 = n / 2;
   const int psy = blocktype + (W ? 2 : 0);
-  const vamd_floor1_tab *fl = &e->h.mode[W].floor[0];
+  const vamd_floor1_tab *fl;
   float *pcm = (float *)malloc(sizeof(float) * ch * n);
   float *gm = (float *)malloc(sizeof(float) * ch * n2);
   int *iw = (int *)malloc(sizeof(int) * ch * n2);
@@ -1392,6 +1420,7 @@ static int tap_block(const port_enc *e, const float *pcm_in, int lW, int W, int 
   }
   for (i = 0; i < ch; i++) {
     float *mdct = gmp[i], *logfft = pcm + (size_t)i * n, *logmdct = logfft + n2, *logmask = logfft;
+    fl = &e->h.mode[W].floor[e->h.mode[W].chmuxlist[i]]; /* floorsubmap[chmuxlist[i]], lib/mapping0.c:497 */
     for (j = 0; j < n2; j++) logmdct[j] = to_dB(mdct[j]) + .345;
     if (t->logmdct) memcpy(t->logmdct + (size_t)i * n2, logmdct, n2 * sizeof(float));
     port_noisemask(e, psy, logmdct, noise);
@@ -1435,7 +1464,7 @@ static int tap_block(const port_enc *e, const float *pcm_in, int lW, int W, int 
     int k;
     for (k = 0; k < VAMD_PACKETBLOBS; k++) {
       for (i = 0; i < ch; i++) {
-        nonzero[i] = floor_curve(fl, mfit[i][k], mhave[i][k], n2, iwp[i]);
+        nonzero[i] = floor_curve(&e->h.mode[W].floor[e->h.mode[W].chmuxlist[i]], mfit[i][k], mhave[i][k], n2, iwp[i]);
         if (m->ilogmask) memcpy(m->ilogmask + ((size_t)k * ch + i) * n2, iwp[i], n2 * sizeof(int));
       }
       couple_quantize(e, psy, W, k, gmp, iwp, nonzero);
@@ -1452,7 +1481,7 @@ static int tap_block(const port_enc *e, const float *pcm_in, int lW, int W, int 
     return 0;
   }
   for (i = 0; i < ch; i++) {
-    nonzero[i] = floor_curve(fl, fit[i], have[i], n2, iwp[i]);
+    nonzero[i] = floor_curve(&e->h.mode[W].floor[e->h.mode[W].chmuxlist[i]], fit[i], have[i], n2, iwp[i]);
     if (t->ilogmask) memcpy(t->ilogmask + (size_t)i * n2, iwp[i], n2 * sizeof(int));
   }
   couple_quantize(e, psy, W, VAMD_PACKETBLOBS / 2, gmp, iwp, nonzero);
@@ -1460,7 +1489,7 @@ static int tap_block(const port_enc *e, const float *pcm_in, int lW, int W, int 
     if (t->iwork) memcpy(t->iwork + (size_t)i * n2, iwp[i], n2 * sizeof(int));
     if (t->nonzero) t->nonzero[i] = nonzero[i];
   }
-  residue2(e, W, iwp, nonzero, t);
+  residue_all(e, W, iwp, nonzero, t);
   free(pcm);
   free(gm);
   free(iw);

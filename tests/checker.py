@@ -15,7 +15,7 @@ SETUPS = {"44k_stereo_q4": (2, 44100, 0.4), "44k_stereo_q9": (2, 44100, 0.9), "4
           "44k_mono_q5": (1, 44100, 0.5)}
 
 # the 5.1 layout (two submaps, four coupling steps; q 0.3 keeps coupling and noise normalisation both live).
-# Kept apart from SETUPS: oracle/port restates the mono / stereo layouts only.
+# Kept apart from SETUPS (the fixture carries the decisions and the packet, not the float taps).
 SURROUND = {"44k_51_q3": (6, 44100, 0.3)}
 
 FLOAT_KEYS = ("mdct_raw", "logfft", "logmdct", "noise", "tone", "logmask", "mdct", "local_ampmax")

@@ -12,7 +12,7 @@ What pins what:
     normalisation on below 0.4), silence, an LFE-only block, bitrate-managed candidates;
   * end to end: a 5.1 stream through the hybrid libvorbis -- block switching, all of mapping0_forward and the
     packets from the GPU -- emits the reference's bytes.
-oracle/port restates the mono / stereo layouts only; the six-channel path is pinned by the reference itself.
+oracle/port (the sequential plain-C restatement) covers the layout too and is pinned the same way.
 """
 import os
 
@@ -20,7 +20,7 @@ import numpy as np
 import pytest
 
 import vorbis_amd
-from oracle import ref
+from oracle import port, ref
 from tests import checker, golden_io
 
 ROOT = checker.ROOT
@@ -66,10 +66,11 @@ def surround_blocks(e, seed):
 def test_kernel_bodies_match_golden():
     from tests.emul.emul import Emul
     blocks, posts, _ = golden_io.load(NAME)
-    em = Emul(blob())
+    em, p = Emul(blob()), port.PortEncoder(blob())
     assert em.channels == 6 and em.L.emul_submaps(em.h, 1) == 2
     kinds = set()
     for b in blocks:
+        same_decisions(b, p.tap_block(*block_args(b)), posts[b["W"]])
         g = em.analyze_block(*block_args(b))
         same_decisions(b, g, posts[b["W"]])
         assert np.array_equal(np.asarray(b["posts"])[:, :posts[b["W"]]], g["posts"][:, :posts[b["W"]]])
@@ -83,10 +84,13 @@ def test_kernel_bodies_match_golden():
 def test_kernel_bodies_match_reference(quality):
     from tests.emul.emul import Emul
     e = ref.RefEncoder(6, 44100, quality)
-    em = Emul(e.pack_setup())
+    em, p = Emul(e.pack_setup()), port.PortEncoder(e.pack_setup())
     for pcm, lW, W, nW in surround_blocks(e, int(quality * 10) + 60):
         a = e.tap_block(pcm, lW, W, nW, 1 if W else 0)
         assert a["packet_matches_real"]
+        o = p.tap_block(pcm, lW, W, nW, 1 if W else 0)
+        assert checker.compare_block(a, o, e.floor_posts(W), verbose=True) == 0
+        same_decisions(a, o, e.floor_posts(W))
         g = em.analyze_block(pcm, lW, W, nW, 1 if W else 0)
         assert checker.compare_block(a, g, e.floor_posts(W), verbose=True) == 0   # every float tap too
         same_decisions(a, g, e.floor_posts(W))
@@ -98,10 +102,12 @@ def test_kernel_bodies_match_reference(quality):
 def test_kernel_bodies_match_reference_managed(rates):
     from tests.emul.emul import Emul
     e = ref.RefEncoder(6, 44100, managed=rates)
-    em = Emul(e.pack_setup())
+    em, p = Emul(e.pack_setup()), port.PortEncoder(e.pack_setup())
     for pcm, lW, W, nW in list(surround_blocks(e, rates[1]))[:3] + list(surround_blocks(e, rates[1]))[6:7]:
         a = e.tap_block_managed(pcm, lW, W, nW, 1 if W else 0)
         assert a["packets_match_real"]
+        o = p.tap_block_managed(pcm, lW, W, nW, 1 if W else 0)
+        assert np.array_equal(a["m_iwork"], o["m_iwork"]) and np.array_equal(a["m_nonzero"], o["m_nonzero"])
         g = em.analyze_block_managed(pcm, lW, W, nW, 1 if W else 0)
         assert np.array_equal(a["m_iwork"], g["m_iwork"]) and np.array_equal(a["m_nonzero"], g["m_nonzero"])
         assert g["m_packets"] == a["m_packets"]
