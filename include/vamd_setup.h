@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define VAMD_SETUP_MAGIC   0x31544553444d4156ULL /* "VAMDSET1" little-endian */
-#define VAMD_SETUP_VERSION 6u
+#define VAMD_SETUP_VERSION 7u
 
 #define VAMD_PACKETBLOBS   15  /* lib/codec_internal.h:28 */
 #define VAMD_P_BANDS       17  /* lib/psy.h:28 */
@@ -38,7 +38,7 @@ extern "C" {
 #define VAMD_POSIT         65  /* VIF_POSIT+2, lib/backends.h:57 */
 #define VAMD_FLOOR_PARTS   31  /* VIF_PARTS, lib/backends.h:59 */
 #define VAMD_FLOOR_CLASSES 16  /* VIF_CLASS, lib/backends.h:58 */
-#define VAMD_MAX_CH        6   /* channel counts covered: 1, 2 and the 5.1 layout of libvorbisenc */
+#define VAMD_MAX_CH        8   /* channel counts covered: every layout Vorbis I assigns an order to (mono .. 7.1) */
 #define VAMD_MAX_SUBMAPS   2   /* 5.1: the five full-range channels, and the LFE on its own floor and residue */
 #define VAMD_MAX_COUPLING  4   /* coupling steps (5.1: L-R, surround L-R, L-C, L-SL; lib/modes/residue_44p51.h:283) */
 #define VAMD_VE_BANDS      7   /* lib/envelope.h:28 */

@@ -142,7 +142,7 @@ typedef struct vamd_batch_io {
   int64_t   packet_stride;/* row length in bytes, a multiple of 4 (vamd_packet_capacity() always suffices) */
 } vamd_batch_io;
 
-#define VAMD_RES_CLASS_STRIDE 256 /* ints per block and submap in res_class[] (>= classified partitions) */
+#define VAMD_RES_CLASS_STRIDE 512 /* ints per block and submap in res_class[] (>= classified partitions) */
 
 /* Entries one block of size class W can emit at most (the row length of res_entries), or 0 when the
  * mode's residue is not covered on the GPU (type 2 over a 2-channel bundle and type 1 over one channel are). */

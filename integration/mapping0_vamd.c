@@ -163,7 +163,7 @@ static int mapping0_forward_vamd(vorbis_block *vb) {
   float ampmax_out;
   int k, ret, pkcap;
 
-  if (ch > VAMD_MAX_CH) return mapping0_forward(vb); /* not covered: the host's own CPU code */
+  if (ch > VAMD_MAX_CH) return mapping0_forward(vb); /* more than 8 channels: the host's own CPU code */
   ctx = vamd_ctx_for(vd);
   if (!ctx) return OV_EFAULT; /* no silent fallback: a missing GPU is an error */
 

@@ -150,7 +150,7 @@ class PortEncoder:
         t = _Taps()
         for k, v in o.items():
             setattr(t, k, v.ctypes.data_as(_f32p if v.dtype == np.float32 else _i32p))
-        rcls = np.zeros(1024, np.int32)
+        rcls = np.zeros(2048, np.int32)
         rent = np.zeros(1 << 15, np.uint16)
         t.res_class, t.res_class_cap = rcls.ctypes.data_as(_i32p), rcls.size
         t.res_entries, t.res_entries_cap = rent.ctypes.data_as(C.POINTER(C.c_ushort)), rent.size

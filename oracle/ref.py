@@ -56,9 +56,9 @@ class _BlockRec(C.Structure):
 
 
 class _EnvState(C.Structure):  # ref_env_state (ref_harness.c): envelope_filter_state x channels + ve->stretch
-    _fields_ = [("stretch", C.c_int), ("ampptr", C.c_int * 7 * 6), ("ampbuf", C.c_float * 17 * 7 * 6),
-                ("nearptr", C.c_int * 6), ("nearDC", C.c_float * 15 * 6), ("nearDC_acc", C.c_float * 6),
-                ("nearDC_partialacc", C.c_float * 6)]
+    _fields_ = [("stretch", C.c_int), ("ampptr", C.c_int * 7 * 8), ("ampbuf", C.c_float * 17 * 7 * 8),
+                ("nearptr", C.c_int * 8), ("nearDC", C.c_float * 15 * 8), ("nearDC_acc", C.c_float * 8),
+                ("nearDC_partialacc", C.c_float * 8)]
 
 
 def available():
@@ -238,7 +238,7 @@ class RefEncoder:
             setattr(t, k, _fp(v) if v.dtype == np.float32 else _ip(v))
         t.packet = pkt.ctypes.data_as(_u8p)
         t.packet_cap = pkt.size
-        rcls = np.zeros(1024, np.int32)
+        rcls = np.zeros(2048, np.int32)
         rent = np.zeros(1 << 15, np.uint16)
         t.res_class, t.res_class_cap = _ip(rcls), rcls.size
         t.res_entries, t.res_entries_cap = rent.ctypes.data_as(C.POINTER(C.c_ushort)), rent.size

@@ -673,7 +673,7 @@ long ref_envelope_feed(ref_enc *e, const float *pcm, long frames) {
   return b->ve->current / b->ve->searchstep;
 }
 
-#define REF_ENV_MAX_CH 6
+#define REF_ENV_MAX_CH 8
 typedef struct ref_env_state {
   int stretch;
   int ampptr[REF_ENV_MAX_CH][VE_BANDS];

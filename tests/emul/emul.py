@@ -12,7 +12,7 @@ _f32p = C.POINTER(C.c_float)
 _i32p = C.POINTER(C.c_int)
 
 POSTS_STRIDE = 32
-RES_CLASS_STRIDE = 256
+RES_CLASS_STRIDE = 512
 
 
 class _Taps(C.Structure):

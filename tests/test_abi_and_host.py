@@ -45,7 +45,7 @@ def test_create_rejects_bad_blobs_without_touching_the_gpu():
     assert L.vamd_create(C.byref(h), ver.ctypes.data_as(C.c_void_p), ver.size, -1) == -134  # OV_EVERSION
     trunc = good[:1000].copy()
     assert L.vamd_create(C.byref(h), trunc.ctypes.data_as(C.c_void_p), trunc.size, -1) == -131
-    chs = good.copy(); chs[16:20] = np.frombuffer(np.int32(7).tobytes(), np.uint8)   # beyond the 5.1 layout
+    chs = good.copy(); chs[16:20] = np.frombuffer(np.int32(9).tobytes(), np.uint8)   # beyond VAMD_MAX_CH
     assert L.vamd_create(C.byref(h), chs.ctypes.data_as(C.c_void_p), chs.size, -1) == -130   # OV_EIMPL
     assert not h.value
 

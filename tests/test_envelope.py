@@ -50,8 +50,8 @@ def gated(ch, frames, seed, period=5000, on=700):
 def check_state(st, want, ch):
     """EnvelopeState (history form) against the reference's rings (already rolled oldest-first)."""
     assert st.stretch == want["stretch"]
-    amp = np.array(st.amp_hist, np.float32).reshape(6, 16, 8)[:ch]
-    near = np.array(st.near_hist, np.float32).reshape(6, 30)[:ch]
+    amp = np.array(st.amp_hist, np.float32).reshape(8, 16, 8)[:ch]
+    near = np.array(st.near_hist, np.float32).reshape(8, 30)[:ch]
     # reference keeps 17 amplitudes / 15 near-DC terms; the histories keep 16 / 30
     assert np.array_equal(bits(amp[:, :, :7].transpose(0, 2, 1)), bits(want["amp"][:, :, 1:]))
     assert np.array_equal(bits(near[:, 15:]), bits(want["near"]))
@@ -116,10 +116,10 @@ def test_envelope_state_layout_matches_header():
     """ctypes mirror == the C struct of include/vorbis_amd.h (sizes the device-side state arrays)."""
     hdr = open(os.path.join(ROOT, "include", "vorbis_amd.h")).read()
     assert "#define VAMD_VE_NEAR_HIST 30" in hdr and "#define VAMD_VE_AMP_HIST  16" in hdr
-    assert "#define VAMD_MAX_CH        6" in open(os.path.join(ROOT, "include", "vamd_setup.h")).read()
-    assert C.sizeof(EnvelopeState) == 8 + 4 + 4 + 6 * 30 * 4 + 6 * 16 * 8 * 4
+    assert "#define VAMD_MAX_CH        8" in open(os.path.join(ROOT, "include", "vamd_setup.h")).read()
+    assert C.sizeof(EnvelopeState) == 8 + 4 + 4 + 8 * 30 * 4 + 8 * 16 * 8 * 4
     assert EnvelopeState.steps.offset == 0 and EnvelopeState.stretch.offset == 8
-    assert EnvelopeState.near_hist.offset == 16 and EnvelopeState.amp_hist.offset == 16 + 720
+    assert EnvelopeState.near_hist.offset == 16 and EnvelopeState.amp_hist.offset == 16 + 960
 
 
 # ------------------------------------------------------------------------------------------

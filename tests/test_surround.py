@@ -237,3 +237,43 @@ def test_gpu_48k_surround_stream_api():
     for k, b in enumerate(run):
         assert vorbis_amd.packet_bytes(rows[k], bits[k]) == b["packet"], k
     assert np.float32(state) == np.float32(run[-1]["ampmax_out"])
+
+
+# ---- the other channel counts Vorbis I assigns an order to (3, 4, 5, 6.1, 7.1): libvorbisenc sets them up
+# uncoupled -- one submap, no coupling steps, a type-1 residue that codes every channel on its own ----------
+@needs_ref
+@pytest.mark.parametrize("ch", [3, 4, 5, 7, 8])
+def test_other_channel_counts_port_and_kernel_bodies(ch):
+    from tests.emul.emul import Emul
+    rng = np.random.default_rng(ch)
+    for q in (0.1, 0.6):
+        e = ref.RefEncoder(ch, 44100, q)
+        setup = e.pack_setup()
+        em, p = Emul(setup), port.PortEncoder(setup)
+        for W, amp in ((1, 0.5), (1, 0.0), (0, 0.3)):
+            pcm = ((rng.random((ch, e.blocksize(W)), dtype=np.float32) - 0.5) * 2 * amp).astype(np.float32)
+            if ch > 3:
+                pcm[ch - 1] = 0.0          # a silent channel: one stream fewer in the residue
+            a = e.tap_block(pcm, W, W, W, 1 if W else 0)
+            assert a["packet_matches_real"]
+            for g in (p.tap_block(pcm, W, W, W, 1 if W else 0), em.analyze_block(pcm, W, W, W, 1 if W else 0)):
+                assert checker.compare_block(a, g, e.floor_posts(W), verbose=True) == 0
+                same_decisions(a, g, e.floor_posts(W))
+            assert g["packet"] == a["packet"]
+
+
+@pytest.mark.gpu
+@needs_ref
+@pytest.mark.parametrize("ch", [3, 8])
+def test_gpu_other_channel_counts(ch):
+    rng = np.random.default_rng(10 + ch)
+    e = ref.RefEncoder(ch, 44100, 0.4)
+    an = vorbis_amd.Analyzer(e.pack_setup(), 0)
+    for W, amp in ((1, 0.5), (0, 0.3), (1, 0.0)):
+        pcm = ((rng.random((ch, e.blocksize(W)), dtype=np.float32) - 0.5) * 2 * amp).astype(np.float32)
+        pcm[ch - 1] *= 0.0
+        a = e.tap_block(pcm, W, W, W, 1 if W else 0)
+        g = an.analyze_block(pcm, W, W, W, 1 if W else 0)
+        same_decisions(a, g, e.floor_posts(W))
+        pk, _ = an.encode_block(pcm, W, W, W, 1 if W else 0)
+        assert pk[0] == a["packet"]

@@ -32,8 +32,8 @@ class _Desc(C.Structure):
 
 _IO_FIELDS = ["pcm", "mdct_raw", "logfft", "logmdct", "noise", "tone", "logmask", "mdct", "posts", "post_valid",
               "ilogmask", "iwork", "nonzero", "local_ampmax", "ampmax_out", "res_class", "res_entries", "res_count"]
-RES_CLASS_STRIDE = 256
-MAX_CH = 6
+RES_CLASS_STRIDE = 512
+MAX_CH = 8
 
 
 class _IO(C.Structure):

@@ -97,7 +97,6 @@ struct PackP {
 struct ChMap {
   int submaps;
   unsigned char sub[VAMD_MAX_CH];
-  unsigned char pad[2];
 };
 
 struct FloorP {
