@@ -77,4 +77,27 @@ for ch, rate, q, coupled in CONFIGS:
     an.close()
     print("%d ch %d Hz q %.1f coupled=%s done, %d blocks so far, %d mismatches, %.0f s" % (ch, rate, q, coupled, total, bad, time.time() - t0),
           flush=True)
+# bitrate-managed: all fifteen candidate packets of every block
+for ch, rates in ((2, (-1, 128000, -1)), (2, (-1, 64000, -1)), (6, (-1, 256000, -1)), (1, (64000, 48000, 32000))):
+    e = ref.RefEncoder(ch, 44100, managed=rates)
+    an = vorbis_amd.Analyzer(e.pack_setup(), 0)
+    rng = np.random.default_rng(ch * 7 + rates[1] // 1000)
+    for W in (1, 0):
+        n = e.blocksize(W)
+        nb = max(8, NB // 10) if W else max(8, NB // 30)
+        x = signals(rng, nb, ch, n)
+        lW = rng.integers(0, 2, nb).astype(np.int32) * W
+        nW = rng.integers(0, 2, nb).astype(np.int32) * W
+        o = an.analyze_managed(torch.from_numpy(x).cuda(), W=W, lW=lW, nW=nW, blocktype=1 if W else 0, packets=True)
+        torch.cuda.synchronize()
+        rows, bits = o["m_packets"].cpu().numpy(), o["m_packet_bits"].cpu().numpy()
+        for k in range(nb):
+            a = e.tap_block_managed(x[k], int(lW[k]), W, int(nW[k]), 1 if W else 0)
+            ok = a["packets_match_real"] and [vorbis_amd.packet_bytes(rows[k, j], bits[k, j]) for j in range(15)] == a["m_packets"]
+            total += 1
+            if not ok:
+                bad += 1
+                print("MISMATCH managed", ch, rates, "W", W, "block", k, "kind", k % 8)
+    an.close()
+    print("managed %d ch %s done, %d blocks so far, %d mismatches, %.0f s" % (ch, rates, total, bad, time.time() - t0), flush=True)
 print("SOAK", "FAILED" if bad else "OK", total, "blocks", bad, "mismatches")
