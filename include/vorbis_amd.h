@@ -4,10 +4,14 @@
  * Drop-in boundary: libvorbis reaches the analysis
  * through vorbis_analysis() (reference lib/analysis.c:29-63) ->
  * _mapping_P[0]->forward == mapping0_forward() (lib/mapping0.c:230-696).  The
- * entry points below replace the numeric section of mapping0_forward
- * (lib/mapping0.c:254-576 and the floor-render + couple/quantise half of
- * :613-646); the host keeps blockout, the Huffman/VQ bit-writing and bitrate
- * management.  INTEGRATION.md shows the patch a libvorbis maintainer applies.
+ * entry points below replace mapping0_forward -- the numeric section
+ * (lib/mapping0.c:254-576, :613-646), the residue back-end's classification and
+ * VQ search and the bit-writing of the packet (:596-687) -- and the step loop of
+ * the block-switching detector (lib/envelope.c:217-262); the host keeps blockout,
+ * bitrate management and Ogg framing.  INTEGRATION.md shows the patch a libvorbis
+ * maintainer applies.  Covered: 1 to 8 channels (mono, stereo, the 5.1 layout with
+ * its two submaps and four coupling steps, and libvorbisenc's uncoupled template
+ * for the rest), VBR and bitrate-managed encoders, block sizes up to 4096.
  *
  * Conventions follow libvorbis: plain C types, caller-allocated outputs, int
  * return codes with the OV_* values of include/vorbis/codec.h:221-235, no
