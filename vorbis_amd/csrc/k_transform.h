@@ -212,10 +212,14 @@ VAMD_DEV void bfly32(float *x) {
 // in + t*in_stride, w + t*w_stride, out_lds + t*out_stride): every loop then ranges over
 // (transform, item) so that small transforms -- the 128-point one of the block-switching
 // detector has only two 32-point groups -- still fill the wave.
-template <int LOGS = 0>
+// LOGN > 0 fixes the transform size at compile time (n = 2^LOGN): loop counts, strides and every index
+// expression derived from n then fold into constants and immediate offsets -- the stage is bound by
+// instruction issue, and a good part of its instructions is address arithmetic.  0 = take n from P.
+template <int LOGS = 0, int LOGN = 0>
 VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in0, float *w0, float *out0, PhaseClock &pc,
                                 int in_stride = 0, int w_stride = 0, int out_stride = 0) {
-  const int n = P.n, n2 = n >> 1, n4 = n >> 2, n8 = n >> 3;
+  const int n = LOGN ? (1 << LOGN) : P.n, n2 = n >> 1, n4 = n >> 2, n8 = n >> 3;
+  const int log2n = LOGN ? LOGN : P.log2n;
   const float *__restrict__ trig = P.trig;
 // item index -> (transform t, item g) for a loop of `1 << lcount` items per transform
 #define VAMD_MDCT_SPLIT(gg, lcount)                            \
@@ -232,7 +236,7 @@ VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in0, float *w0, fl
   // quarter is folded with which sign.  x0[0],x0[2] / x1[0],x1[2] of the reference
   // are the .x,.z / .y,.w lanes of two aligned quads of the input.
   WAVE_FOR(pp, n4 << LOGS) {
-    VAMD_MDCT_SPLIT(pp, P.log2n - 2)
+    VAMD_MDCT_SPLIT(pp, log2n - 2)
     const int p = g_;
     const F2 T = *(const F2 *)(trig + n2 - 2 * (p + 1));
     float r0, r1;
@@ -265,11 +269,11 @@ VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in0, float *w0, fl
   // x into 2^s sub-blocks of n2>>s points; butterfly q of a sub-block pairs
   // x[pts-2-2q] with x[pts/2-2-2q] and uses T[(4<<s)*q].  n2/4 = n/8 butterflies per
   // stage in total, all independent.
-  const int nstages = P.log2n - 6;  // first + (log2n-7) generic passes
+  const int nstages = log2n - 6;  // first + (log2n-7) generic passes
   for (int s = 0; s < nstages; s++) {
-    const int pts = n2 >> s, lper = P.log2n - 3 - s, tstride = 4 << s;  // per = pts/4 = 1 << lper
+    const int pts = n2 >> s, lper = log2n - 3 - s, tstride = 4 << s;  // per = pts/4 = 1 << lper
     WAVE_FOR(gg, n8 << LOGS) {
-      VAMD_MDCT_SPLIT(gg, P.log2n - 3)
+      VAMD_MDCT_SPLIT(gg, log2n - 3)
       const int g = g_;
       const int j = g >> lper, q = g & ((1 << lper) - 1);
       const int ia = pts * j + pts - 2 - 2 * q, ib = pts * j + (pts >> 1) - 2 - 2 * q;
@@ -289,7 +293,7 @@ VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in0, float *w0, fl
   pc.mark(2);
   // 32-point butterflies, one group per lane, in registers
   WAVE_FOR(gg, (n2 / 32) << LOGS) {
-    VAMD_MDCT_SPLIT(gg, P.log2n - 6)
+    VAMD_MDCT_SPLIT(gg, log2n - 6)
     const int g = g_;
     float v[32];
     F2 *pg = (F2 *)(w2 + 34 * g);  // == VAMD_PW(32 g)
@@ -319,7 +323,7 @@ VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in0, float *w0, fl
   // lower half w[0..n2).  Unit u produces w[2u], w[2u+1], w[n2-2u-2], w[n2-2u-1].
   const int *__restrict__ bit = P.bitrev;
   WAVE_FOR(uu, n8 << LOGS) {
-    VAMD_MDCT_SPLIT(uu, P.log2n - 3)
+    VAMD_MDCT_SPLIT(uu, log2n - 3)
     const int u = g_;
     const I2 bi = *(const I2 *)(bit + 2 * u);
     const F2 x0 = *(const F2 *)(w2 + VAMD_PW(bi.x));
@@ -344,7 +348,7 @@ VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in0, float *w0, fl
 
   // final rotate * scale, lib/mdct.c:552-561 -> out[n2]
   WAVE_FOR(ii, n4 << LOGS) {
-    VAMD_MDCT_SPLIT(ii, P.log2n - 2)
+    VAMD_MDCT_SPLIT(ii, log2n - 2)
     const int i = g_;
     const F2 T = *(const F2 *)(trig + n2 + 2 * i);
     const F2 ab = *(const F2 *)(w + 2 * i);
@@ -501,13 +505,20 @@ VAMD_DEV void radf2_wave(int ido, int l1, const float *__restrict__ cc, float *_
 // order and c<->ch ping-pong.  `c` holds the windowed block (plain layout, n+4
 // floats available), `ch` is scratch (n+4 floats).  Returns the buffer (offset layout:
 // element t at ret[t]) that holds the packed spectrum R0,R1,I1,...,R(n/2).
+// LOGN > 0: n = 2^LOGN, whose FFTPACK factorisation is radix 4 throughout with one radix-2 pass at the end
+// when LOGN is odd (drfti1 tries 4 first and moves a leftover 2 to the front of ifac[], which drftf1
+// walks backwards: lib/smallft.c:35-70,572-631); vamd_create() checks the blob's factors against that.
+template <int LOGN = 0>
 VAMD_DEV const float *drft_forward_wave(const XformP &P, float *c, float *ch) {
-  const int n = P.n, nf = P.fft_nf;
+  const int n = LOGN ? (1 << LOGN) : P.n, nf = LOGN ? (LOGN >> 1) + (LOGN & 1) : P.fft_nf;
   const float *__restrict__ wa = P.wa;
   float *bufc = c + 1, *bufh = ch + 1;  // offset layouts of the two buffers
   int na = 1, l2 = n, iw = n;
+#if VAMD_GPU
+#pragma unroll
+#endif
   for (int k1 = 0; k1 < nf; k1++) {
-    const int ip = P.fft_fac[nf - k1 - 1];
+    const int ip = LOGN ? (k1 < (LOGN >> 1) ? 4 : 2) : P.fft_fac[nf - k1 - 1];
     const int l1 = l2 / ip, ido = n / l2;
     iw -= (ip - 1) * ido;
     na = 1 - na;
@@ -548,12 +559,13 @@ VAMD_DEV void transform_window(const XformP &P, int W, int lW, int nW, const Pcm
   pc.mark(0);
 }
 
+template <int LOGN = 0>
 VAMD_DEV float transform_block(const XformP &P, float *A, float *B, float *__restrict__ mdct_out,
                                float *__restrict__ logmdct_out, float *__restrict__ logfft_out, PhaseClock &pc) {
-  const int n = P.n, n2 = n >> 1;
+  const int n = LOGN ? (1 << LOGN) : P.n, n2 = n >> 1;
 
   // MDCT: spectrum lands in B[n2..n) (LDS), then goes out with its dB twin
-  mdct_forward_wave(P, A, B, B + n2, pc);
+  mdct_forward_wave<0, LOGN>(P, A, B, B + n2, pc);
   WAVE_FOR(j, n2) {
     const float m = B[n2 + j];
     if (mdct_out) mdct_out[j] = m;
@@ -563,7 +575,7 @@ VAMD_DEV float transform_block(const XformP &P, float *A, float *B, float *__res
 
   pc.mark(5);
   // FFT of the same windowed block (A), ping-ponging with B
-  const float *spec = drft_forward_wave(P, A, B);
+  const float *spec = drft_forward_wave<LOGN>(P, A, B);
   pc.mark(6);
 
   // logfft + local ampmax, lib/mapping0.c:255-346

@@ -94,14 +94,25 @@ static size_t transform_lds_bytes(const XformP &P, int waves) {
 // from HBM (no LDS copy of it): a wave then needs only the butterfly buffer (8.4 KB at n = 2048) and
 // sixteen waves fit on a CU beside the trig / bit-reverse tables.
 #define VAMD_MD_WAVES 16
+// log2 n when the transform kernels have an instantiation for this size and the blob's FFT factors are the
+// ones that instantiation assumes (radix 4 throughout, one radix-2 pass last for an odd log2 n); else 0
+static int fixed_logn(const XformP &P) {
+  const int l = P.log2n;
+  if (l < 8 || l > 12 || (1 << l) != P.n || P.fft_nf != (l >> 1) + (l & 1)) return 0;
+  for (int k1 = 0; k1 < P.fft_nf; k1++)
+    if (P.fft_fac[P.fft_nf - k1 - 1] != (k1 < (l >> 1) ? 4 : 2)) return 0;
+  return l;
+}
+
 static size_t mdct_only_lds_bytes(const XformP &P, int waves) {
   const size_t n2 = P.n / 2;
   return ((size_t)(P.n + P.n / 4) + P.n / 4 + (size_t)waves * (n2 + VAMD_PW_SIZE(n2))) * 4;
 }
+template <int LOGN>
 __global__ __launch_bounds__(64 * VAMD_MD_WAVES) void k_mdct_only(XformP G, int W, long nframes,
                                                                  const float *__restrict__ in,
                                                                  float *__restrict__ out) {
-  const int n = G.n, n2 = n >> 1, nw = blockDim.x >> 6;
+  const int n = LOGN ? (1 << LOGN) : G.n, n2 = n >> 1, nw = blockDim.x >> 6;
   float *trig = (float *)vamd_smem;          // [n + n/4]
   int *bitrev = (int *)(trig + n + n / 4);   // [n/4]
   float *work = (float *)(bitrev + n / 4);
@@ -115,13 +126,15 @@ __global__ __launch_bounds__(64 * VAMD_MD_WAVES) void k_mdct_only(XformP G, int 
   PhaseClock pc;
   pc.start(nullptr);
   for (long f = (long)blockIdx.x * nw + (threadIdx.x >> 6); f < nframes; f += (long)gridDim.x * nw) {
-    mdct_forward_wave(P, in + f * n, B, B + n2, pc);
+    mdct_forward_wave<0, LOGN>(P, in + f * n, B, B + n2, pc);
     WAVE_FOR(q, n2 >> 2)((F4 *)(out + f * n2))[q] = ((const F4 *)(B + n2))[q];
     WAVE_SYNC();
   }
 }
 
-// stage 1: window + MDCT + FFT + logs, one wave per channel-block
+// stage 1: window + MDCT + FFT + logs, one wave per channel-block.  Instantiated per block size (LOGN =
+// log2 n; 0 = any size, read from the parameters).
+template <int LOGN>
 __global__ __launch_bounds__(64 * VAMD_XF_WAVES) void k_transform(XformP G, int W, DescP d, int ch, long ncb,
                                                                  const float *__restrict__ pcm,
                                                                  float *__restrict__ mdct_raw,
@@ -130,7 +143,7 @@ __global__ __launch_bounds__(64 * VAMD_XF_WAVES) void k_transform(XformP G, int 
                                                                  float *__restrict__ local_ampmax) {
   const XformLds L = stage_transform_tables(G);
   const XformP &P = L.P;
-  const int n = P.n, n2 = n >> 1, nw = blockDim.x >> 6;
+  const int n = LOGN ? (1 << LOGN) : P.n, n2 = n >> 1, nw = blockDim.x >> 6;
   PhaseClock pc;
   pc.start(d.dbg);
   // cb = channel-block index = block*ch + channel
@@ -149,7 +162,7 @@ __global__ __launch_bounds__(64 * VAMD_XF_WAVES) void k_transform(XformP G, int 
       WAVE_SYNC();
       pc.mark(0);
     }
-    const float amp = transform_block(P, L.A, L.B, mdct_raw + cb * n2, logmdct + cb * n2, logfft + cb * n2, pc);
+    const float amp = transform_block<LOGN>(P, L.A, L.B, mdct_raw + cb * n2, logmdct + cb * n2, logfft + cb * n2, pc);
     if (LANE == 0) local_ampmax[cb] = amp;
   }
   pc.flush();
@@ -689,10 +702,13 @@ int vamd_create(vamd_ctx **out, const void *setup_blob, size_t blob_bytes, int d
       c->lds_per_block = prop.sharedMemPerBlock;
       // opt in to the full LDS for the persistent transform kernels (a no-op where the
       // runtime does not require it)
-      (void)hipFuncSetAttribute((const void *)k_transform, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)c->lds_per_block);
-      (void)hipFuncSetAttribute((const void *)k_mdct_only, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)c->lds_per_block);
+#define VAMD_OPT_IN(LOGN)                                                                                      \
+  (void)hipFuncSetAttribute((const void *)k_transform<LOGN>, hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                            (int)c->lds_per_block);                                                            \
+  (void)hipFuncSetAttribute((const void *)k_mdct_only<LOGN>, hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                            (int)c->lds_per_block);
+      VAMD_OPT_IN(0) VAMD_OPT_IN(8) VAMD_OPT_IN(9) VAMD_OPT_IN(10) VAMD_OPT_IN(11) VAMD_OPT_IN(12)
+#undef VAMD_OPT_IN
       (void)hipFuncSetAttribute((const void *)k_noise, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)c->lds_per_block);
       (void)hipGetLastError();
@@ -860,8 +876,18 @@ int vamd_mdct_forward_batch(vamd_ctx *c, int W, const float *in, float *out, lon
   while (waves > 1 && mdct_only_lds_bytes(P, waves) > c->lds_per_block) waves--;
   const long groups = (nframes + waves - 1) / waves;
   const unsigned grid = (unsigned)(groups < c->num_cus ? groups : c->num_cus);
-  hipLaunchKernelGGL(k_mdct_only, dim3(grid), dim3(64 * waves), mdct_only_lds_bytes(P, waves), c->stream, P, W, nframes, in,
-                     out);
+#define VAMD_GO(LOGN)                                                                                                     \
+  hipLaunchKernelGGL(k_mdct_only<LOGN>, dim3(grid), dim3(64 * waves), mdct_only_lds_bytes(P, waves), c->stream, P, W, nframes, \
+                     in, out)
+  switch (fixed_logn(P)) {
+    case 8: VAMD_GO(8); break;
+    case 9: VAMD_GO(9); break;
+    case 10: VAMD_GO(10); break;
+    case 11: VAMD_GO(11); break;
+    case 12: VAMD_GO(12); break;
+    default: VAMD_GO(0);
+  }
+#undef VAMD_GO
   HIP_TRY(c, hipGetLastError());
   return VAMD_OK;
 }
@@ -964,8 +990,18 @@ static void launch_transform(vamd_ctx *c, BatchRun *R) {
   const long groups = ((long)gcb + waves - 1) / waves;
   const unsigned grid = (unsigned)(groups < c->num_cus ? groups : c->num_cus);
   prof_mark(c);
-  hipLaunchKernelGGL(k_transform, dim3(grid), dim3(64 * waves), transform_lds_bytes(X, waves), c->stream, X, R->W, R->d,
-                     ch, (long)gcb, R->io->pcm, R->p.mdct_raw, R->p.logmdct, R->p.logfft, R->p.local);
+#define VAMD_GO(LOGN)                                                                                                      \
+  hipLaunchKernelGGL(k_transform<LOGN>, dim3(grid), dim3(64 * waves), transform_lds_bytes(X, waves), c->stream, X, R->W, R->d, \
+                     ch, (long)gcb, R->io->pcm, R->p.mdct_raw, R->p.logmdct, R->p.logfft, R->p.local)
+  switch (fixed_logn(X)) {
+    case 8: VAMD_GO(8); break;
+    case 9: VAMD_GO(9); break;
+    case 10: VAMD_GO(10); break;
+    case 11: VAMD_GO(11); break;
+    case 12: VAMD_GO(12); break;
+    default: VAMD_GO(0);
+  }
+#undef VAMD_GO
   prof_mark(c), R->nst++;
 }
 
