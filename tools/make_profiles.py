@@ -19,6 +19,8 @@ def table(path):
             continue
         n, val, ctr = parts[-1], parts[-2], parts[-3]
         name = ln[:ln.index(ctr)].strip()
+        if name.startswith("void k_"):   # instantiated kernels: "void k_transform<11>(...)" -> k_transform
+            name = name[5:].split("<")[0]
         rows[name] = float(val)
     return lines, rows
 

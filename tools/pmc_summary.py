@@ -6,6 +6,8 @@ for f in sys.argv[1:]:
     d = collections.defaultdict(dict)
     waves = {}
     for k, c, v, n, g, wg in rows:
+        if k.startswith("void "):   # instantiated kernels print as "void k_transform<11>(...)"
+            k = k[5:]
         if not k.startswith("k_"):
             continue
         kk = k.split("(")[0]
