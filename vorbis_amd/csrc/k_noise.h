@@ -48,13 +48,11 @@ VAMD_DEV LineFit fit_plain(const float *S, int n, int hi, int lo) {
   return fit_from_sums(N[hi] - N[lo], X[hi] - X[lo], XX[hi] - XX[lo], Y[hi] - Y[lo], XY[hi] - XY[lo]);
 }
 
-VAMD_DEV LineFit bark_fit_from(const PsyP &P, const float *S, int i, int b /* = bark[i] */) {
-  const int n = P.n;
+VAMD_DEV LineFit bark_fit_from(const PsyP &P, int n, const float *S, int i, int b /* = bark[i] */) {
   const int lo = b >> 16, hi = b & 0xffff;
   return (i < P.bark_i1) ? fit_mirrored(S, n, hi, -lo) : fit_plain(S, n, hi, lo);
 }
-VAMD_DEV LineFit fixed_fit_at(const PsyP &P, const float *S, int i, int fixed) {
-  const int n = P.n;
+VAMD_DEV LineFit fixed_fit_at(const PsyP &P, int n, const float *S, int i, int fixed) {
   const int hi = i + fixed / 2, lo = hi - fixed;
   return (i < P.fix_i1) ? fit_mirrored(S, n, hi, -lo) : fit_plain(S, n, hi, lo);
 }
@@ -196,10 +194,12 @@ struct ScanGroup {
 // q0+l+64, ... (SLICE_QUADS, QPS per lane), four bins each.  With one wave per block the slice is
 // the whole block; the persistent kernel gives a block to two waves so that the per-bin phases --
 // bound by each wave's dependent chains, not by issue slots -- take half as long.
-template <class Scan, int QPS>
+// LOGN > 0: the bin count is the compile-time constant 2^LOGN (array strides and window-edge addresses
+// then fold into immediate offsets); 0 = P.n.
+template <class Scan, int QPS, int LOGN = 0>
 VAMD_DEV void bark_noise_wave(const PsyP &P, const float (*f)[4], float (*noise)[4], const float offset,
                               const int fixed, float *S, const Scan &scan, PhaseClock &pc, int slot, int q0, int q1) {
-  const int n = P.n;
+  const int n = LOGN ? (1 << LOGN) : P.n;
   float *N = S, *X = S + VAMD_NZ_STRIDE(n), *XX = S + 2 * VAMD_NZ_STRIDE(n), *Y = S + 3 * VAMD_NZ_STRIDE(n), *XY = S + 4 * VAMD_NZ_STRIDE(n);
 
   // per-bin terms (lib/psy.c:571-597)
@@ -248,7 +248,7 @@ VAMD_DEV void bark_noise_wave(const PsyP &P, const float (*f)[4], float (*noise)
   last.A = 0.f;
   last.B = 0.f;
   last.D = 1.f;
-  if (P.bark_i2 > 0) last = bark_fit_from(P, S, P.bark_i2 - 1, P.bark[P.bark_i2 - 1]);
+  if (P.bark_i2 > 0) last = bark_fit_from(P, n, S, P.bark_i2 - 1, P.bark[P.bark_i2 - 1]);
   SLICE_QUADS(kq, q, q0, q1, QPS) {
     const I4 bq = ((const I4 *)P.bark)[q];
     const int bk[4] = {bq.x, bq.y, bq.z, bq.w};
@@ -257,7 +257,7 @@ VAMD_DEV void bark_noise_wave(const PsyP &P, const float (*f)[4], float (*noise)
 #endif
     for (int c = 0; c < 4; c++) {
       const int i = (q << 2) + c;
-      const LineFit L = (i < P.bark_i2) ? bark_fit_from(P, S, i, bk[c]) : last;
+      const LineFit L = (i < P.bark_i2) ? bark_fit_from(P, n, S, i, bk[c]) : last;
       const float x = (float)i;
       float R = (L.A + x * L.B) / L.D;
       if (R < 0.f) R = 0.f;
@@ -266,14 +266,14 @@ VAMD_DEV void bark_noise_wave(const PsyP &P, const float (*f)[4], float (*noise)
   }
   if (fixed > 0) {
     // fixed-width window pass: keep the lower of the two curves (lib/psy.c:660-703)
-    if (P.fix_i2 > 0) last = fixed_fit_at(P, S, P.fix_i2 - 1, fixed);
+    if (P.fix_i2 > 0) last = fixed_fit_at(P, n, S, P.fix_i2 - 1, fixed);
     SLICE_QUADS(kq, q, q0, q1, QPS) {
 #if VAMD_GPU
 #pragma unroll
 #endif
       for (int c = 0; c < 4; c++) {
         const int i = (q << 2) + c;
-        const LineFit L = (i < P.fix_i2) ? fixed_fit_at(P, S, i, fixed) : last;
+        const LineFit L = (i < P.fix_i2) ? fixed_fit_at(P, n, S, i, fixed) : last;
         const float x = (float)i;
         const float R = (L.A + x * L.B) / L.D;
         if (R - offset < noise[kq][c]) noise[kq][c] = R - offset;
@@ -285,16 +285,16 @@ VAMD_DEV void bark_noise_wave(const PsyP &P, const float (*f)[4], float (*noise)
 }
 
 // _vp_noisemask on a block whose logmdct is already in a register tile
-template <class Scan, int QPS>
+template <class Scan, int QPS, int LOGN = 0>
 VAMD_DEV void noisemask_tile(const PsyP &P, const float (*lm)[4], float (*o)[4], float *S, const Scan &scan,
                              PhaseClock &pc, int q0, int q1) {
   float nz[QPS][4], wk[QPS][4];
-  bark_noise_wave<Scan, QPS>(P, lm, nz, 140.f, -1, S, scan, pc, 0, q0, q1);
+  bark_noise_wave<Scan, QPS, LOGN>(P, lm, nz, 140.f, -1, S, scan, pc, 0, q0, q1);
   SLICE_QUADS(kq, q, q0, q1, QPS) {
     for (int c = 0; c < 4; c++) wk[kq][c] = lm[kq][c] - nz[kq][c];
   }
   pc.mark(3);
-  bark_noise_wave<Scan, QPS>(P, wk, nz, 0.f, P.noisewindowfixed, S, scan, pc, 4, q0, q1);
+  bark_noise_wave<Scan, QPS, LOGN>(P, wk, nz, 0.f, P.noisewindowfixed, S, scan, pc, 4, q0, q1);
   SLICE_QUADS(kq, q, q0, q1, QPS) {
 #if VAMD_GPU
 #pragma unroll

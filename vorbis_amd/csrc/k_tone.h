@@ -40,8 +40,12 @@ namespace vamd {
 // also skips, is reset by the caller).  Per point that leaves add, add, ds_max_f32.
 VAMD_HOSTDEV int seed_pad_lo(int linesper) { return (VAMD_EHMER_OFFSET * linesper + (linesper >> 1) + 3) & ~3; }
 VAMD_HOSTDEV int seed_pad_hi(int linesper) { return ((VAMD_EHMER_MAX - VAMD_EHMER_OFFSET) * linesper + 3) & ~3; }
+// LP > 0 fixes linesper (eighth_octave_lines: 8 in every libvorbisenc setup) at compile time, which turns
+// the 56 scatter addresses into one base register plus immediate offsets.
+template <int LP = 0>
 VAMD_DEV void seed_curve_scatter(float *seed, const float *__restrict__ band_rows /*[8] rows of one band*/,
-                                 int stride, float amp, int oc, int linesper, float dBoffset) {
+                                 int stride, float amp, int oc, int linesper_rt, float dBoffset) {
+  const int linesper = LP ? LP : linesper_rt;
   int choice = (int)(((double)(amp + dBoffset) - 30.) * (double).1f);
   choice = choice < 0 ? 0 : choice;
   choice = choice > VAMD_P_LEVELS - 1 ? VAMD_P_LEVELS - 1 : choice;
@@ -156,6 +160,7 @@ VAMD_DEV int tone_chase_thread(const float *__restrict__ seeds, int linesper, in
 // scatter half: seed[] for one channel-block (LDS), lib/psy.c:417-452,762-771
 // logfft is read straight from HBM: each lane walks the few bins of its own run, neighbouring
 // lanes walk neighbouring runs, and a copy in LDS would only cost the block its co-residency
+template <int LP = 0>
 VAMD_DEV void tone_seed_block(const PsyP &P, const float *__restrict__ logfft, float global_ampmax,
                               float local_ampmax, float *seed, PhaseClock &pc) {
   const int n = P.n, nlines = P.total_octave_lines;
@@ -174,7 +179,7 @@ VAMD_DEV void tone_seed_block(const PsyP &P, const float *__restrict__ logfft, f
     for (int i = s + 1; i < e; i++)
       if (fft[i] > mx) mx = fft[i];
     if (mx + 6.f > f_from_bits((uint32_t)rec.w) + att)
-      seed_curve_scatter(seed, P.curves64 + rec.z * (VAMD_P_LEVELS * P.curve_stride), P.curve_stride, mx, rec.y,
+      seed_curve_scatter<LP>(seed, P.curves64 + rec.z * (VAMD_P_LEVELS * P.curve_stride), P.curve_stride, mx, rec.y,
                          P.eighth_octave_lines, dBoffset);
   }
   WAVE_SYNC();

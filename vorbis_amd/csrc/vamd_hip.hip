@@ -175,6 +175,8 @@ __global__ __launch_bounds__(64 * VAMD_XF_WAVES) void k_transform(XformP G, int 
 #define VAMD_NZ_WAVES_SHARED 6  // ... when the tone kernels run beside it
 #define VAMD_NZ_SPLIT 2
 #define VAMD_NZ_GROUP 2         // blocks per workgroup beside the tone kernels (three workgroups per CU)
+// LOGN2 > 0: the bin count n/2 = 2^LOGN2 is a compile-time constant (as for k_transform).
+template <int LOGN2>
 __global__ __launch_bounds__(64 * VAMD_NZ_WAVES * VAMD_NZ_SPLIT) void k_noise(PsyP P0, PsyP P1, DescP d, int ch,
                                                                              long ncb, int split,
                                                                              const float *__restrict__ logmdct,
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(64 * VAMD_NZ_WAVES * VAMD_NZ_SPLIT) void k_noise(Ps
   // `split` waves share a block: VAMD_NZ_SPLIT, more for blocks whose slices would not fit the
   // per-lane register tiles (n = 4096: four waves of 512 bins)
   const int nblk = (blockDim.x >> 6) / split, slot = wave / split, part = wave % split;
-  const int n2 = P0.n, nq = n2 >> 2;
+  const int n2 = LOGN2 ? (1 << LOGN2) : P0.n, nq = n2 >> 2;
   // this wave's slice of the block's quads, a whole number of wave-widths
   const int per = ((nq + split * 64 - 1) / (split * 64)) * 64;
   const int q0 = part * per < nq ? part * per : nq, q1 = q0 + per < nq ? q0 + per : nq;
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(64 * VAMD_NZ_WAVES * VAMD_NZ_SPLIT) void k_noise(Ps
     const PsyP &P = d_bt(d, cb / ch) ? P1 : P0;
     float lm[QPS][4], o[QPS][4];
     SLICE_QUADS(kq, q, q0, q1, QPS) f4_get(((const F4 *)(logmdct + cb * n2))[q], lm[kq]);
-    noisemask_tile<ScanGroup, QPS>(P, lm, o, S, scan, pc, q0, q1);
+    noisemask_tile<ScanGroup, QPS, LOGN2>(P, lm, o, S, scan, pc, q0, q1);
     if (live) {
       SLICE_QUADS(kq, q, q0, q1, QPS)((F4 *)(noise + cb * n2))[q] = f4_make(o[kq]);
     }
@@ -269,6 +271,7 @@ __global__ void k_ampmax_stream_mixed(int ch, long ntotal, const int *__restrict
 }
 
 // stage 3: _vp_tonemask, in three launches (k_tone.h).  nlp = octave lines padded to 16.
+template <int LP>
 __global__ __launch_bounds__(64) void k_tone_seed(PsyP P0, PsyP P1, DescP d, int ch, int nlp,
                                                   const float *__restrict__ logfft,
                                                   const float *__restrict__ local_ampmax,
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(64) void k_tone_seed(PsyP P0, PsyP P1, DescP d, int
   (void)n2;
   PhaseClock pc;
   pc.start(d.dbg ? d.dbg + 32 : nullptr);
-  tone_seed_block(P, logfft + cb * n2, ampmax_glob[blk], local_ampmax[cb], seed, pc);
+  tone_seed_block<LP>(P, logfft + cb * n2, ampmax_glob[blk], local_ampmax[cb], seed, pc);
   WAVE_FOR(i, nlp) seed_g[cb * nlp + i] = i < nl ? seed[i] : VAMD_NEGINF;
   pc.flush();
 }
@@ -709,8 +712,12 @@ int vamd_create(vamd_ctx **out, const void *setup_blob, size_t blob_bytes, int d
                             (int)c->lds_per_block);
       VAMD_OPT_IN(0) VAMD_OPT_IN(8) VAMD_OPT_IN(9) VAMD_OPT_IN(10) VAMD_OPT_IN(11) VAMD_OPT_IN(12)
 #undef VAMD_OPT_IN
-      (void)hipFuncSetAttribute((const void *)k_noise, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)c->lds_per_block);
+      (void)hipFuncSetAttribute((const void *)k_noise<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_per_block);
+      (void)hipFuncSetAttribute((const void *)k_noise<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_per_block);
+      (void)hipFuncSetAttribute((const void *)k_noise<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_per_block);
+      (void)hipFuncSetAttribute((const void *)k_noise<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_per_block);
+      (void)hipFuncSetAttribute((const void *)k_noise<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_per_block);
+      (void)hipFuncSetAttribute((const void *)k_noise<11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_per_block);
       (void)hipGetLastError();
       if (getenv("VAMD_VERBOSE"))
         fprintf(stderr, "vamd_create: %d CUs, %zu B LDS per workgroup\n", c->num_cus, c->lds_per_block);
@@ -1089,16 +1096,30 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_
       if (overlap && waves == VAMD_NZ_WAVES_SHARED) waves = VAMD_NZ_GROUP, wgs = VAMD_NZ_WAVES_SHARED / VAMD_NZ_GROUP;
       const long groups = ((long)gcb + waves - 1) / waves;
       const unsigned grid = (unsigned)(groups < (long)c->num_cus * wgs ? groups : (long)c->num_cus * wgs);
-      hipLaunchKernelGGL(k_noise, dim3(grid), dim3(64 * waves * split), (size_t)waves * 5 * VAMD_NZ_STRIDE(n2) * 4, s, P0, P1, d, ch,
-                         (long)gcb, split, p.logmdct, p.noise);
+#define VAMD_GO(L)                                                                                                          \
+  hipLaunchKernelGGL(k_noise<L>, dim3(grid), dim3(64 * waves * split), (size_t)waves * 5 * VAMD_NZ_STRIDE(n2) * 4, s, P0, P1, d, \
+                     ch, (long)gcb, split, p.logmdct, p.noise)
+      switch (n2) {
+        case 128: VAMD_GO(7); break;
+        case 256: VAMD_GO(8); break;
+        case 512: VAMD_GO(9); break;
+        case 1024: VAMD_GO(10); break;
+        case 2048: VAMD_GO(11); break;
+        default: VAMD_GO(0);
+      }
+#undef VAMD_GO
     }
     prof_mark(c), R->nst++;
     if (overlap) s = c->side;
     {
       const int nlp = (nl + 15) & ~15;
       const size_t seed_lds = (size_t)(seed_pad_lo(P0.eighth_octave_lines) + nlp + seed_pad_hi(P0.eighth_octave_lines)) * 4;
-      hipLaunchKernelGGL(k_tone_seed, dim3(gcb), dim3(64), seed_lds, s, P0, P1, d, ch, nlp, p.logfft, p.local,
-                         p.ampglob, p.seed);
+      if (P0.eighth_octave_lines == 8 && P1.eighth_octave_lines == 8)
+        hipLaunchKernelGGL(k_tone_seed<8>, dim3(gcb), dim3(64), seed_lds, s, P0, P1, d, ch, nlp, p.logfft, p.local, p.ampglob,
+                           p.seed);
+      else
+        hipLaunchKernelGGL(k_tone_seed<0>, dim3(gcb), dim3(64), seed_lds, s, P0, P1, d, ch, nlp, p.logfft, p.local, p.ampglob,
+                           p.seed);
       hipLaunchKernelGGL(k_tone_chase, dim3((gcb + 63) / 64), dim3(64), (size_t)VAMD_RING * 64 * 8, s,
                          P0.eighth_octave_lines, nl, nlp, (long)gcb, d, p.seed, p.surv, p.nsurv);
       hipLaunchKernelGGL(k_tone_fold, dim3(gcb), dim3(64), (size_t)(nlp + (P0.ngroups > P1.ngroups ? P0.ngroups : P1.ngroups)) * 4, s, P0, P1, d, ch, nlp, p.seed, p.surv,
