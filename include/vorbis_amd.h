@@ -188,6 +188,16 @@ int vamd_analyze_stream_mixed(vamd_ctx *ctx, const vamd_batch_desc *desc_short, 
                               const vamd_batch_desc *desc_long, const vamd_batch_io *io_long, const int32_t *order,
                               long nblocks_total, float *ampmax_state);
 
+/* The same for MANY streams in one call (an encoder farm's batch): the blocks of all streams are bucketed
+ * by size class as above; order[] lists them stream after stream, each stream's in its own stream order,
+ * and stream s owns order[stream_start[s] .. stream_start[s+1]) (device int64 [nstreams+1], stream_start[0]
+ * = 0, stream_start[nstreams] = nblocks_total).  ampmax_states (device float [nstreams]) holds every
+ * stream's vorbis_look_psy_global.ampmax on entry and is updated in place; the chains run one thread per
+ * stream.  Asynchronous on the context's stream like vamd_analyze_batch. */
+int vamd_analyze_streams_mixed(vamd_ctx *ctx, const vamd_batch_desc *desc_short, const vamd_batch_io *io_short,
+                               const vamd_batch_desc *desc_long, const vamd_batch_io *io_long, const int32_t *order,
+                               const int64_t *stream_start, long nstreams, long nblocks_total, float *ampmax_states);
+
 /* ---- per-block host API: the compatibility path behind vorbis_analysis() -----
  * Host pointers.  pcm[ch] -> n samples each (vb->pcm); outputs sized as above for
  * nblocks == 1.  Latency-bound by design (one launch sequence + two PCIe

@@ -216,3 +216,29 @@ def test_gpu_short_rows_and_argument_errors():
     with pytest.raises(vorbis_amd.VamdError) as ei:
         an.analyze(pcm, outs=bad)
     assert ei.value.code == -131
+
+
+@pytest.mark.gpu
+@needs_ref
+def test_gpu_many_streams_in_one_call():
+    """An encoder farm's batch: four real streams (block decisions taken by the reference's own blockout, short and
+    long blocks mixed, each with its own ampmax chain) analysed by ONE vamd_analyze_streams_mixed call, straight
+    to packets; every packet of every stream must be the reference's."""
+    rng = np.random.default_rng(2024)
+    e = ref.RefEncoder(2, 44100, 0.5)
+    an = vorbis_amd.Analyzer(e.pack_setup(), 0)
+    streams = []
+    for s in range(4):
+        frames = 30000 + 9000 * s
+        t = np.arange(frames)
+        gate = np.where((t % (7000 + 900 * s)) < 800, 0.5, 0.001 * (s + 1)).astype(np.float32)
+        x = ((rng.random((2, frames), dtype=np.float32) - 0.5) * 2 * gate).astype(np.float32)
+        streams.append(ref.RefEncoder(2, 44100, 0.5).encode_stream(x))
+    assert all(any(b["W"] == 0 for b in st) and any(b["W"] == 1 for b in st) for st in streams)
+    # every stream starts from a fresh psy_g_look.ampmax (-9999); its chain then runs through its own blocks
+    res, states = an.analyze_streams_mixed(streams, [-9999.0] * len(streams), want=("ampmax_out", "packets", "packet_bits"))
+    for s, (st, out) in enumerate(zip(streams, res)):
+        assert len(st) == len(out) > 10
+        for k, (b, o) in enumerate(zip(st, out)):
+            assert vorbis_amd.packet_bytes(o["packets"], o["packet_bits"]) == b["packet"], (s, k, b["W"])
+        assert np.float32(states[s]) == np.float32(st[-1]["ampmax_out"])

@@ -18,7 +18,7 @@ EXPORTED_SYMBOLS = ["vamd_create", "vamd_destroy", "vamd_last_error", "vamd_set_
                     "vamd_analyze_batch", "vamd_analyze_stream", "vamd_analyze_block", "vamd_profile",
                     "vamd_stage_ms", "vamd_debug_cycles", "vamd_analyze_stream_mixed", "vamd_envelope_search_batch",
                     "vamd_envelope_search", "vamd_envelope_geometry", "vamd_residue_capacity", "vamd_analyze_block_res", "vamd_analyze_batch_managed", "vamd_analyze_block_managed",
-                    "vamd_packet_capacity", "vamd_encode_block", "vamd_submaps", "vamd_residue_offset"]
+                    "vamd_packet_capacity", "vamd_encode_block", "vamd_submaps", "vamd_residue_offset", "vamd_analyze_streams_mixed"]
 PACKETBLOBS = 15
 
 _vp = C.c_void_p
@@ -94,6 +94,8 @@ def load_library():
     L.vamd_debug_cycles.argtypes = [_vp, C.c_int, _vp]
     L.vamd_analyze_stream_mixed.argtypes = [_vp, C.POINTER(_Desc), C.POINTER(_IO), C.POINTER(_Desc), C.POINTER(_IO), _vp,
                                             C.c_long, C.POINTER(C.c_float)]
+    L.vamd_analyze_streams_mixed.argtypes = [_vp, C.POINTER(_Desc), C.POINTER(_IO), C.POINTER(_Desc), C.POINTER(_IO), _vp, _vp,
+                                             C.c_long, C.c_long, _vp]
     L.vamd_envelope_search_batch.argtypes = [_vp, _vp, C.c_long, C.c_long, C.c_long, C.c_long, _vp, _vp]
     L.vamd_envelope_search.argtypes = [_vp, C.POINTER(_vp), C.c_long, _vp, _vp]
     L.vamd_envelope_geometry.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -358,6 +360,51 @@ class Analyzer:
             W, i = (o >> 30) & 1, o & 0x3fffffff
             res.append({k: v[i] for k, v in host[W].items()})
         return res, st.value
+
+    def analyze_streams_mixed(self, streams, ampmax_states, want=None):
+        """vamd_analyze_streams_mixed.  `streams`: list of stream-ordered block lists (dicts as for
+        analyze_stream_mixed); `ampmax_states`: one float per stream.  One call for all of them.
+        Returns (per stream: per-block list of output dicts, new states as numpy)."""
+        t = self.torch
+        want = self._DEFAULT_WANT[LEVEL_FULL] if want is None else want
+        idx = {0: [], 1: []}
+        order, start = [], [0]
+        for blocks in streams:
+            for b in blocks:
+                order.append((b["W"] << 30) | len(idx[b["W"]]))
+                idx[b["W"]].append(b)
+            start.append(len(order))
+        descs, ios, outs, keep = {}, {}, {}, []
+        for W in (0, 1):
+            sel = idx[W]
+            nb = len(sel)
+            n = self.blocksizes[W]
+            pcm = t.from_numpy(np.stack([b["pcm"] for b in sel]).astype(np.float32)).cuda() if nb else \
+                t.empty((0, self.channels, n), device=self._dev())
+            dv = lambda k: t.tensor([b[k] for b in sel], dtype=t.int32, device=self._dev()) if nb else 0  # noqa: E731
+            outs[W] = self.alloc_outputs(W, nb, want)
+            descs[W] = self._desc(W, nb, dv("lW"), dv("nW"), dv("blocktype"), 0.0, keep)
+            ios[W] = self._io(pcm, outs[W])
+            keep.append(pcm)
+        od = t.tensor(order, dtype=t.int32, device=self._dev())
+        sd = t.tensor(start, dtype=t.int64, device=self._dev())
+        st = t.tensor(list(ampmax_states), dtype=t.float32, device=self._dev())
+        self._bind_stream()
+        self._check(self.L.vamd_analyze_streams_mixed(self.h, C.byref(descs[0]), C.byref(ios[0]), C.byref(descs[1]),
+                                                      C.byref(ios[1]), _vp(od.data_ptr()), _vp(sd.data_ptr()), len(streams),
+                                                      len(order), _vp(st.data_ptr())))
+        t.cuda.synchronize()
+        host = {W: {k: v.cpu().numpy() for k, v in outs[W].items()} for W in (0, 1)}
+        res, k = [], 0
+        for blocks in streams:
+            cur = []
+            for _ in blocks:
+                o = order[k]
+                W, i = (o >> 30) & 1, o & 0x3fffffff
+                cur.append({kk: v[i] for kk, v in host[W].items()})
+                k += 1
+            res.append(cur)
+        return res, st.cpu().numpy()
 
     def analyze_block(self, pcm, lW=1, W=1, nW=1, blocktype=BLOCKTYPE_LONG, ampmax_in=-9999.0):
         """vamd_analyze_block: host numpy pcm[ch][n] in, host numpy results out (the per-block

@@ -270,6 +270,31 @@ __global__ void k_ampmax_stream_mixed(int ch, long ntotal, const int *__restrict
   *state_out = amp;
 }
 
+// many streams at once: thread s walks order[start[s] .. start[s+1]) with its own running state
+__global__ void k_ampmax_streams_mixed(int ch, long nstreams, const long long *__restrict__ start,
+                                       const int *__restrict__ order, float secs0, float secs1, float att,
+                                       float *__restrict__ states, const float *__restrict__ local0,
+                                       const float *__restrict__ local1, float *__restrict__ in0,
+                                       float *__restrict__ in1, float *__restrict__ glob0, float *__restrict__ glob1) {
+  const long sidx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (sidx >= nstreams) return;
+  float amp = states[sidx];
+  for (long long k = start[sidx]; k < start[sidx + 1]; k++) {
+    const int o = order[k], W = (o >> 30) & 1;
+    const long b = o & 0x3fffffff;
+    amp += (W ? secs1 : secs0) * att;
+    if (amp < -9999) amp = -9999;
+    (W ? in1 : in0)[b] = amp;
+    const float *loc = W ? local1 : local0;
+    for (int c = 0; c < ch; c++) {
+      const float l = loc[b * ch + c];
+      if (l > amp) amp = l;
+    }
+    (W ? glob1 : glob0)[b] = amp;
+  }
+  states[sidx] = amp;
+}
+
 // stage 3: _vp_tonemask, in three launches (k_tone.h).  nlp = octave lines padded to 16.
 template <int LP>
 __global__ __launch_bounds__(64) void k_tone_seed(PsyP P0, PsyP P1, DescP d, int ch, int nlp,
@@ -1314,11 +1339,12 @@ int vamd_analyze_stream(vamd_ctx *c, const vamd_batch_desc *desc, const vamd_bat
   return run_batch(c, desc, io, VAMD_LEVEL_FULL, true, ampmax_state);
 }
 
-int vamd_analyze_stream_mixed(vamd_ctx *c, const vamd_batch_desc *desc_short, const vamd_batch_io *io_short,
-                              const vamd_batch_desc *desc_long, const vamd_batch_io *io_long, const int32_t *order,
-                              long nblocks_total, float *ampmax_state) {
-  if (!c) return VAMD_EINVAL;
-  if (!desc_short || !desc_long || !ampmax_state) return fail(c, VAMD_EINVAL, "null argument");
+// the two-size-class stream run; nstreams == 0: one stream whose state is the host float *ampmax_state,
+// otherwise `stream_start` [nstreams+1] and `states` [nstreams] are device arrays
+static int run_streams_mixed(vamd_ctx *c, const vamd_batch_desc *desc_short, const vamd_batch_io *io_short,
+                             const vamd_batch_desc *desc_long, const vamd_batch_io *io_long, const int32_t *order,
+                             long nblocks_total, float *ampmax_state, const int64_t *stream_start, long nstreams,
+                             float *states) {
   if (desc_short->W != 0 || desc_long->W != 1) return fail(c, VAMD_EINVAL, "desc_short->W must be 0, desc_long->W 1");
   if (nblocks_total != desc_short->nblocks + desc_long->nblocks || (nblocks_total && !order))
     return fail(c, VAMD_EINVAL, "order[] must name every block of both batches exactly once");
@@ -1340,17 +1366,42 @@ int vamd_analyze_stream_mixed(vamd_ctx *c, const vamd_batch_desc *desc_short, co
   launch_transform(c, &R[0]);
   launch_transform(c, &R[1]);
   const float secs0 = (float)(c->B.bs[0] / 2) / (float)c->B.rate, secs1 = (float)(c->B.bs[1] / 2) / (float)c->B.rate;
-  hipLaunchKernelGGL(k_ampmax_stream_mixed, dim3(1), dim3(1), 0, s, c->B.channels, nblocks_total, (const int *)order, secs0,
-                     secs1, c->B.ampmax_att_per_sec, *ampmax_state, R[0].p.local, R[1].p.local, R[0].p.ampin,
-                     R[1].p.ampin, R[0].p.ampglob, R[1].p.ampglob, d_state);
+  if (nstreams)
+    hipLaunchKernelGGL(k_ampmax_streams_mixed, dim3((unsigned)((nstreams + 63) / 64)), dim3(64), 0, s, c->B.channels, nstreams,
+                       (const long long *)stream_start, (const int *)order, secs0, secs1, c->B.ampmax_att_per_sec, states,
+                       R[0].p.local, R[1].p.local, R[0].p.ampin, R[1].p.ampin, R[0].p.ampglob, R[1].p.ampglob);
+  else
+    hipLaunchKernelGGL(k_ampmax_stream_mixed, dim3(1), dim3(1), 0, s, c->B.channels, nblocks_total, (const int *)order, secs0,
+                       secs1, c->B.ampmax_att_per_sec, *ampmax_state, R[0].p.local, R[1].p.local, R[0].p.ampin,
+                       R[1].p.ampin, R[0].p.ampglob, R[1].p.ampglob, d_state);
   R[0].d.ampmax_in = R[0].p.ampin;
   R[1].d.ampmax_in = R[1].p.ampin;
   launch_rest(c, &R[0], VAMD_LEVEL_FULL);
   launch_rest(c, &R[1], VAMD_LEVEL_FULL);
   HIP_TRY(c, hipGetLastError());
-  HIP_TRY(c, hipMemcpyAsync(ampmax_state, d_state, sizeof(float), hipMemcpyDeviceToHost, s));
-  HIP_TRY(c, hipStreamSynchronize(s));
+  if (!nstreams) {
+    HIP_TRY(c, hipMemcpyAsync(ampmax_state, d_state, sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+  }
   return VAMD_OK;
+}
+
+int vamd_analyze_stream_mixed(vamd_ctx *c, const vamd_batch_desc *desc_short, const vamd_batch_io *io_short,
+                              const vamd_batch_desc *desc_long, const vamd_batch_io *io_long, const int32_t *order,
+                              long nblocks_total, float *ampmax_state) {
+  if (!c) return VAMD_EINVAL;
+  if (!desc_short || !desc_long || !ampmax_state) return fail(c, VAMD_EINVAL, "null argument");
+  return run_streams_mixed(c, desc_short, io_short, desc_long, io_long, order, nblocks_total, ampmax_state, nullptr, 0, nullptr);
+}
+
+int vamd_analyze_streams_mixed(vamd_ctx *c, const vamd_batch_desc *desc_short, const vamd_batch_io *io_short,
+                               const vamd_batch_desc *desc_long, const vamd_batch_io *io_long, const int32_t *order,
+                               const int64_t *stream_start, long nstreams, long nblocks_total, float *ampmax_states) {
+  if (!c) return VAMD_EINVAL;
+  if (!desc_short || !desc_long) return fail(c, VAMD_EINVAL, "null argument");
+  if (nstreams < 1 || !stream_start || !ampmax_states) return fail(c, VAMD_EINVAL, "stream_start / ampmax_states / nstreams");
+  return run_streams_mixed(c, desc_short, io_short, desc_long, io_long, order, nblocks_total, nullptr, stream_start, nstreams,
+                           ampmax_states);
 }
 
 int vamd_analyze_block(vamd_ctx *c, const float *const *pcm, int lW, int W, int nW, int blocktype, float ampmax_in,
