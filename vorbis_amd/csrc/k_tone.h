@@ -175,9 +175,19 @@ VAMD_DEV void tone_seed_block(const PsyP &P, const float *__restrict__ logfft, f
   WAVE_FOR(r, P.nruns) {
     const I4 rec = ((const I4 *)P.runs)[r];
     const int s = rec.x & 0xffff, e = rec.x >> 16;  // bins [s, e)
+    // the run's peak, four loads in flight at a time: one at a time, every compare would wait out a full
+    // memory round trip (runs reach ~10 bins at the top of the spectrum).  Indices past the run are clamped
+    // to its last bin, which a maximum does not mind.
     float mx = fft[s];
-    for (int i = s + 1; i < e; i++)
-      if (fft[i] > mx) mx = fft[i];
+    for (int i = s + 1; i < e; i += 4) {
+      const int last = e - 1;
+      const float a = fft[i], b = fft[i + 1 < last ? i + 1 : last], c = fft[i + 2 < last ? i + 2 : last],
+                  dd = fft[i + 3 < last ? i + 3 : last];
+      if (a > mx) mx = a;
+      if (b > mx) mx = b;
+      if (c > mx) mx = c;
+      if (dd > mx) mx = dd;
+    }
     if (mx + 6.f > f_from_bits((uint32_t)rec.w) + att)
       seed_curve_scatter<LP>(seed, P.curves64 + rec.z * (VAMD_P_LEVELS * P.curve_stride), P.curve_stride, mx, rec.y,
                          P.eighth_octave_lines, dBoffset);
