@@ -113,8 +113,16 @@ VAMD_DEV int tone_chase_thread(const float *__restrict__ seeds, int linesper, in
   float a1 = 0.f, a2 = 0.f;
   int p1 = 0, p2 = 0;
   const F4 *q = (const F4 *)seeds;
-  for (int b = 0; b < ((n + 15) >> 4); b++) {
-    const F4 v0 = q[4 * b], v1 = q[4 * b + 1], v2 = q[4 * b + 2], v3 = q[4 * b + 3];  // row is padded to 16
+  const int nblk = (n + 15) >> 4;
+  F4 w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3];  // row is padded to 16; the next 16 lines load while these are walked
+  for (int b = 0; b < nblk; b++) {
+    const F4 v0 = w0, v1 = w1, v2 = w2, v3 = w3;
+    if (b + 1 < nblk) {
+      w0 = q[4 * b + 4];
+      w1 = q[4 * b + 5];
+      w2 = q[4 * b + 6];
+      w3 = q[4 * b + 7];
+    }
     const float blk[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w,
                            v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
 #if VAMD_GPU
