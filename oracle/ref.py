@@ -77,6 +77,10 @@ def lib(hybrid=False):
     if path not in _libs:
         if not os.path.exists(path):
             raise RuntimeError("%s missing: run `make -C oracle` (needs /root/reference)" % path)
+        if hybrid:
+            # the hybrid links libvorbis_amd.so and through it the HIP runtime; the tests also use torch, which
+            # ships its own copy -- load torch's first so that the process ends up with one runtime
+            import torch  # noqa: F401
         L = C.CDLL(path)
         L.ref_open.restype = C.c_void_p
         L.ref_open.argtypes = [C.c_int, C.c_long, C.c_float]

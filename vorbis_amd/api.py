@@ -75,6 +75,11 @@ def load_library():
     if not os.path.exists(path):
         raise ImportError("vorbis_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; "
                           "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback." % path)
+    # The library and torch must share ONE HIP runtime (device pointers and streams cross between them): torch
+    # ships its own libamdhip64, so it is loaded first and the dlopen below binds to the copy already in the
+    # process.  Loaded the other way round, the system runtime and torch's both initialise and this library's
+    # sees no device.
+    import torch  # noqa: F401
     L = C.CDLL(path)
     L.vamd_create.argtypes = [C.POINTER(_vp), _vp, C.c_size_t, C.c_int]
     L.vamd_destroy.argtypes = [_vp]
