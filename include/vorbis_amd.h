@@ -149,7 +149,7 @@ typedef struct vamd_batch_io {
 #define VAMD_RES_CLASS_STRIDE 512 /* ints per block and submap in res_class[] (>= classified partitions) */
 
 /* Entries one block of size class W can emit at most (the row length of res_entries), or 0 when the
- * mode's residue is not covered on the GPU (type 2 over a 2-channel bundle and type 1 over one channel are). */
+ * mode's residue is not covered on the GPU (residue types 1 and 2 with vectors of <= 8 dimensions are). */
 int vamd_residue_capacity(const vamd_ctx *ctx, int W);
 /* Submaps of the mode (1; 2 for the 5.1 layout: the full-range channels, then the LFE), and where in a
  * block's res_entries row submap `sm`'s entries start. */

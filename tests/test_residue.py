@@ -84,8 +84,8 @@ def test_residue_tables_in_blob_are_consistent():
         em = Emul(blob_of(name))
         for W in (0, 1):
             cap = em.L.emul_residue_capacity(em.h, W)
-            assert cap > 0, (name, W)        # all four shipped setups are covered (type 2 stereo, type 1 mono)
-            assert cap <= 64 * 64
+            assert cap > 0, (name, W)        # all four shipped setups are covered
+            assert cap <= 512 * 64
 
 
 # ------------------------------------------------------------------------------------------

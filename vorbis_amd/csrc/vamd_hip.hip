@@ -984,7 +984,7 @@ static int prepare_run(vamd_ctx *c, const vamd_batch_desc *desc, const vamd_batc
     if (!(io->res_class && io->res_entries && io->res_count)) return fail(c, VAMD_EINVAL, "res_class / res_entries / res_count go together");
     if (level < VAMD_LEVEL_FULL) return fail(c, VAMD_EINVAL, "residue outputs need level FULL");
     if ((desc->W != 0 && desc->W != 1) || !c->B.res_cap[desc->W])
-      return fail(c, VAMD_EIMPL, "this mode's residue back-end is not covered on the GPU (type 2 stereo, type 1 mono)");
+      return fail(c, VAMD_EIMPL, "this mode's residue back-end is not covered on the GPU (residue types 1 and 2 are)");
   }
   if (io && (io->packets || io->packet_bits)) {
     int r = check_packets(c, desc->W, level, io->packets, io->packet_bits, io->packet_stride);
@@ -1240,7 +1240,7 @@ int vamd_analyze_batch_managed(vamd_ctx *c, const vamd_batch_desc *desc, const v
     if (!(m->res_class && m->res_entries && m->res_count))
       return fail(c, VAMD_EINVAL, "res_class / res_entries / res_count go together");
     if (!c->B.res_cap[desc->W])
-      return fail(c, VAMD_EIMPL, "this mode's residue back-end is not covered on the GPU (type 2 stereo, type 1 mono)");
+      return fail(c, VAMD_EIMPL, "this mode's residue back-end is not covered on the GPU (residue types 1 and 2 are)");
   }
   if ((m->packets || m->packet_bits) &&
       (r = check_packets(c, desc->W, VAMD_LEVEL_FULL, m->packets, m->packet_bits, m->packet_stride)))
@@ -1263,7 +1263,7 @@ int vamd_analyze_block_managed(vamd_ctx *c, const float *const *pcm, int lW, int
   if (!pcm || (W != 0 && W != 1)) return fail(c, VAMD_EINVAL, "bad pcm / W");
   const bool want_res = res_class || res_entries || res_count;
   if (want_res && !c->B.res_cap[W])
-    return fail(c, VAMD_EIMPL, "this mode's residue back-end is not covered on the GPU (type 2 stereo, type 1 mono)");
+    return fail(c, VAMD_EIMPL, "this mode's residue back-end is not covered on the GPU (residue types 1 and 2 are)");
   const size_t rcap = want_res ? (size_t)c->B.res_cap[W] : 0;
   const size_t S = (size_t)c->B.chmap[W].submaps;
   const size_t ch = c->B.channels, n = c->B.bs[W], n2 = n / 2, K = VAMD_PACKETBLOBS;
@@ -1419,7 +1419,7 @@ int vamd_analyze_block_res(vamd_ctx *c, const float *const *pcm, int lW, int W, 
   if (!pcm || (W != 0 && W != 1)) return fail(c, VAMD_EINVAL, "bad pcm / W");
   const bool want_res = res_class || res_entries || res_count;
   if (want_res && !c->B.res_cap[W])
-    return fail(c, VAMD_EIMPL, "this mode's residue back-end is not covered on the GPU (type 2 stereo, type 1 mono)");
+    return fail(c, VAMD_EIMPL, "this mode's residue back-end is not covered on the GPU (residue types 1 and 2 are)");
   const size_t rcap = want_res ? (size_t)c->B.res_cap[W] : 0;
   const size_t S = (size_t)c->B.chmap[W].submaps;
   const int ch = c->B.channels, n = c->B.bs[W], n2 = n / 2;
