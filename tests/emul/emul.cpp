@@ -20,6 +20,23 @@
 
 using namespace vamd;
 
+// the single-lane order of events of _vp_noisemask: all bins in one lane, the five running sums one after the other
+struct ScanSerial {
+  void before_terms() const {}
+  void scan(float *S, int n) const {
+    for (int a = 0; a < 5; a++) running_sum_inplace(S + a * VAMD_NZ_STRIDE(n), n);
+  }
+};
+#define VAMD_NZ_HOST_BINS 4096
+static void noisemask_block(const PsyP &P, const float *logmdct, float *out, float *S, PhaseClock &pc) {
+  static float lm[VAMD_NZ_HOST_BINS], o[VAMD_NZ_HOST_BINS];
+  static int bk[VAMD_NZ_HOST_BINS];
+  for (int i = 0; i < P.n; i++) lm[i] = logmdct[i];
+  noise_bark_fetch<VAMD_NZ_HOST_BINS, 0>(P, bk, 0);
+  noisemask_bins<ScanSerial, VAMD_NZ_HOST_BINS, 0>(P, lm, bk, o, S, P.noisecompand, ScanSerial(), pc, 0);
+  for (int i = 0; i < P.n; i++) out[i] = o[i];
+}
+
 struct Emul {
   std::vector<unsigned char> image;
   std::vector<uint32_t> doff;

@@ -1,15 +1,16 @@
 // k_noise.h -- _vp_noisemask (reference lib/psy.c:706-752) with its two
-// bark_noise_hybridmp passes (lib/psy.c:547-704); SURVEY.md 8a row a9.  One
-// wavefront per channel-block.
+// bark_noise_hybridmp passes (lib/psy.c:547-704); SURVEY.md 8a row a9.  A team
+// of up to four wavefronts per channel-block.
 //
 // What is parallel and what is not: the per-bin terms y, w, w*x, w*x*x, w*y,
-// w*x*y and the windowed line evaluation are independent per bin and are spread
-// over the 64 lanes.  The five running sums N, X, XX, Y, XY are fp32
-// accumulations *in index order* in the reference; windowed differences of them
-// feed a division, so any re-association moves the answer by up to 5e-3
-// (SURVEY.md Appendix A).  They are therefore accumulated serially, one lane
-// per array, out of LDS -- five lanes busy for n steps.  The regime boundaries
-// of the window loops depend only on the static bark[] table and are
+// w*x*y and the windowed line evaluation are independent per bin: lane l of
+// wave w takes the bins i0(w) + l + 64k, so that every LDS access of a wave is a
+// run of consecutive words (no bank conflicts).  The five running sums N, X,
+// XX, Y, XY are fp32 accumulations *in index order* in the reference; windowed
+// differences of them feed a division, so any re-association moves the answer
+// by up to 5e-3.  They are walked in order by the team's
+// first wave, eight lanes per chain (running_sum_rounds below).  The regime
+// boundaries of the window loops depend only on the static bark[] table and are
 // precomputed by vamd_create().
 //
 // LDS: S[5][VAMD_NZ_STRIDE(n)] running sums only; the noise curve and work vector stay in registers.
@@ -19,9 +20,15 @@
 
 namespace vamd {
 
-// floats between a block's five running-sum arrays in LDS: n plus a stagger of 16, which puts the four
-// chains a 16-lane LDS phase of the four-lanes-per-chain scan touches on disjoint bank groups
-#define VAMD_NZ_STRIDE(n) ((n) + 16)
+// The five running-sum arrays of a block in LDS.  Element e of an array lives at word nz_swz(e): bit 6 of
+// the index is folded into bit 2, which swaps neighbouring 16-byte quads in every other run of 64.  The
+// per-bin phases touch consecutive e from consecutive lanes and stay conflict-free under it (a wave's 32
+// lanes of an LDS cycle still cover 32 different banks); the ordered walk (running_sum_rounds), where each
+// lane of a chain's eight moves the 64 bytes of its own run, needs it: without the fold lanes j and j+4 of
+// a chain -- and every chain of the block -- would queue on the same four banks.  The arrays are n + 8
+// floats apart, which sets neighbouring chains half a bank row apart for the same reason.
+#define VAMD_NZ_STRIDE(n) ((n) + 8)
+VAMD_DEV int nz_swz(int e) { return e ^ ((e >> 4) & 4); }
 
 struct LineFit {
   float A, B, D;
@@ -37,94 +44,26 @@ VAMD_DEV LineFit fit_from_sums(float tN, float tX, float tXX, float tY, float tX
   return r;
 }
 
-// window sums with a mirrored low edge (lo < 0 in the reference: lib/psy.c:613-617,666-670)
-VAMD_DEV LineFit fit_mirrored(const float *S, int n, int hi, int mlo /* = -lo */) {
-  const float *N = S, *X = S + VAMD_NZ_STRIDE(n), *XX = S + 2 * VAMD_NZ_STRIDE(n), *Y = S + 3 * VAMD_NZ_STRIDE(n), *XY = S + 4 * VAMD_NZ_STRIDE(n);
-  return fit_from_sums(N[hi] + N[mlo], X[hi] - X[mlo], XX[hi] + XX[mlo], Y[hi] + Y[mlo], XY[hi] - XY[mlo]);
-}
-// plain window differences (lib/psy.c:635-639,687-691)
-VAMD_DEV LineFit fit_plain(const float *S, int n, int hi, int lo) {
-  const float *N = S, *X = S + VAMD_NZ_STRIDE(n), *XX = S + 2 * VAMD_NZ_STRIDE(n), *Y = S + 3 * VAMD_NZ_STRIDE(n), *XY = S + 4 * VAMD_NZ_STRIDE(n);
-  return fit_from_sums(N[hi] - N[lo], X[hi] - X[lo], XX[hi] - XX[lo], Y[hi] - Y[lo], XY[hi] - XY[lo]);
-}
-
-VAMD_DEV LineFit bark_fit_from(const PsyP &P, int n, const float *S, int i, int b /* = bark[i] */) {
-  const int lo = b >> 16, hi = b & 0xffff;
-  return (i < P.bark_i1) ? fit_mirrored(S, n, hi, -lo) : fit_plain(S, n, hi, lo);
-}
-VAMD_DEV LineFit fixed_fit_at(const PsyP &P, int n, const float *S, int i, int fixed) {
-  const int hi = i + fixed / 2, lo = hi - fixed;
-  return (i < P.fix_i1) ? fit_mirrored(S, n, hi, -lo) : fit_plain(S, n, hi, lo);
-}
-
 // In-place running sum p[i] = p[0] + ... + p[i], strictly left to right in fp32
-// (the reference's tN/tX/... accumulators, lib/psy.c:576-603).  One lane; n is a
-// multiple of 32 (block sizes are powers of two >= 64).  The next 16 values are
-// fetched from LDS while the current 16 are being added, so the dependent add
-// chain -- the irreducible part -- is the only thing on the critical path.
-#define VAMD_SCAN4(acc, v) \
-  acc += v.x; v.x = acc; acc += v.y; v.y = acc; acc += v.z; v.z = acc; acc += v.w; v.w = acc;
-
+// (the reference's tN/tX/... accumulators, lib/psy.c:576-603), one lane per array.
 VAMD_DEV void running_sum_inplace(float *p, int n) {
-  F4 *q = (F4 *)p;
   float acc = 0.f;
-  const int nblk = n >> 4;  // 16 values (4 quads) per block; nblk is even for n >= 32
-  // two register sets (a*, b*) alternate so that no value is ever copied: while one set
-  // is being summed the other set's loads are in flight and the previous stores drain
-  F4 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
-  F4 b0 = q[4], b1 = q[5], b2 = q[6], b3 = q[7];
-  for (int b = 0; b < nblk; b += 2) {
-    VAMD_SCAN4(acc, a0) VAMD_SCAN4(acc, a1) VAMD_SCAN4(acc, a2) VAMD_SCAN4(acc, a3)
-    q[4 * b] = a0;
-    q[4 * b + 1] = a1;
-    q[4 * b + 2] = a2;
-    q[4 * b + 3] = a3;
-    if (b + 2 < nblk) {
-      a0 = q[4 * b + 8];
-      a1 = q[4 * b + 9];
-      a2 = q[4 * b + 10];
-      a3 = q[4 * b + 11];
-    }
-    VAMD_SCAN4(acc, b0) VAMD_SCAN4(acc, b1) VAMD_SCAN4(acc, b2) VAMD_SCAN4(acc, b3)
-    q[4 * b + 4] = b0;
-    q[4 * b + 5] = b1;
-    q[4 * b + 6] = b2;
-    q[4 * b + 7] = b3;
-    if (b + 3 < nblk) {
-      b0 = q[4 * b + 12];
-      b1 = q[4 * b + 13];
-      b2 = q[4 * b + 14];
-      b3 = q[4 * b + 15];
-    }
+  for (int i = 0; i < n; i++) {
+    acc += p[nz_swz(i)];
+    p[nz_swz(i)] = acc;
   }
 }
 
-// Who runs the five running sums of a block.
-//  ScanSolo : the wave that owns the block (5 lanes busy) -- single-wave workgroups, tests.
-//  ScanGroup: the waves of a workgroup meet at a barrier and the first few of them walk the chains
-//    of every block of the round, eight chains per wave and eight lanes per chain (below).
-struct ScanSolo {
-  VAMD_MEM void before_terms() const {}  // the wave's own WAVE_SYNC after the previous evaluation suffices
-  VAMD_MEM void operator()(float *S, int n) const {
-    WAVE_SYNC();
-    WAVE_FOR(a, 5) running_sum_inplace(S + a * VAMD_NZ_STRIDE(n), n);
-    WAVE_SYNC();
-  }
-};
 #if VAMD_GPU
-// The same running sums with L = 4 or 8 lanes per chain.  A wave's LDS instruction moves 64 lanes'
-// worth of bytes whether or not the lanes carry data, and a VALU instruction occupies the SIMD for
-// its four cycles whatever the lane mask, so a wave walks 64/L chains, 4L values of each per
-// load/store pair: lane j of a chain's L owns quad L*s+j of step s.  The order of the adds is kept
-// by handing the running total from lane to lane (DPP row_shr:1, fused into the next add): every
-// lane runs all L rounds into temporaries -- only lane r's round-r result is meaningful, and it is
-// exactly what lane r+1 receives for round r+1 -- so nothing on the dependent chain is predicated;
-// a select tree off the chain then keeps each lane's own round.  tools/micro/scan_quad.hip, cycles
-// per element of a chain: one lane per chain 18, L = 4: 12.2, L = 8: 10.4 -- elapsed time falls, but
-// the SIMD time per chain-element does not (more instructions serve fewer chains), so this pays
-// only where the other SIMDs would idle: small groups (<= 16 chains, one wave, L = 4), and the
-// stand-alone 7-block group (L = 8, one wave per SIMD).
-// Chains [first, first+count) of S_all, count <= 64/L; n a multiple of 8L.
+// The running sums of up to eight chains by ONE wave (tools/micro/scan_e.hip).  A lone wave issues an
+// instruction every ~5 cycles and a dependent v_add_f32 every ~7.2, so what a walk costs is the number of
+// instructions it puts between two elements of a chain.  Here L = 8 lanes share a chain; per step each lane
+// loads E consecutive elements (its "run"), and the runs are summed in L rounds under an exec mask: in
+// round r only lane r of every chain executes, E back-to-back dependent adds starting from the total that
+// lane r-1 handed over (DPP row_shr:1).  A round is E adds + ~5 bookkeeping instructions, so with E = 16
+// the wave walks at 8.5 cycles per element of every chain it carries (E = 4, the hand-off after every
+// quad that round 1 shipped, measured 14; one lane per chain out of a chain-interleaved layout 20.6).
+// Chain c lives at S + c*stride; n is a multiple of 8*E.
 VAMD_DEV float dpp_from_lane_below(float v) {  // row_shr:1 -- lane i receives lane i-1's value
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));
 }
@@ -132,195 +71,202 @@ template <int L>
 VAMD_DEV float dpp_from_last_lane(float v) {  // row_shl:(L-1) -- lane i receives lane i+L-1's value
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + (L - 1), 0xf, 0xf, true));
 }
-template <int L>
-VAMD_DEV void running_sum_lanes(float *S_all, int first, int count, int n) {
+// L = 8 or 16 lanes per chain (64/L chains per wave; a chain must not straddle a row of 16 lanes: DPP)
+template <int L, int E>
+VAMD_DEV void running_sum_rounds(float *S, int stride, int nchains, int n) {
+  constexpr int Q = E / 4;
   const int g = LANE / L, j = LANE % L;
-  const bool act = g < count;
-  F4 *q = (F4 *)(S_all + (first + (act ? g : 0)) * VAMD_NZ_STRIDE(n)) + j;
-  const int steps = n / (4 * L);  // even
-  float carry = 0.f;              // lane j == 0: the chain's total through the previous step
-  F4 a = q[0], b = q[L];
-  for (int s = 0; s < steps; s += 2) {
+  const bool act = g < nchains;
+  // this lane's run of step s: elements [s*L*E + j*E, +E); its quad k sits at quad k ^ m of the run (nz_swz:
+  // bit 6 of the element index, constant per lane for E >= 8; E = 4: such blocks are too short to matter)
+  const int m = E >= 8 ? ((j * E) >> 6) & 1 : 0;
+  float *p = S + (act ? g : 0) * stride + j * E;
+  const int steps = n / (L * E);
+  float c0 = 0.f;  // lane j == 0: the chain's total through the previous step
+  for (int s = 0; s < steps; s++) {
+    float v[E];
 #pragma unroll
-    for (int half = 0; half < 2; half++) {
-      F4 &v = half ? b : a;
-      F4 t[L];
-      float cin = carry;
+    for (int k = 0; k < Q; k++) f4_get(*(const F4 *)(p + s * L * E + 4 * (k ^ m)), v + 4 * k);
+    float cin = c0;
 #pragma unroll
-      for (int r = 0; r < L; r++) {
-        t[r].x = cin + v.x;
-        t[r].y = t[r].x + v.y;
-        t[r].z = t[r].y + v.z;
-        t[r].w = t[r].z + v.w;
-        cin = dpp_from_lane_below(t[r].w);
+    for (int r = 0; r < L; r++) {
+      if (j == r) {
+        v[0] = cin + v[0];
+#pragma unroll
+        for (int k = 1; k < E; k++) v[k] = v[k - 1] + v[k];
       }
-      carry = dpp_from_last_lane<L>(t[L - 1].w);
-      F4 o = t[0];
+      cin = dpp_from_lane_below(v[E - 1]);  // lane r+1 now holds lane r's total (the others do not care)
+    }
+    c0 = dpp_from_last_lane<L>(v[E - 1]);
+    if (act) {
 #pragma unroll
-      for (int r = 1; r < L; r++) {
-        const bool m = j == r;
-        o.x = m ? t[r].x : o.x;
-        o.y = m ? t[r].y : o.y;
-        o.z = m ? t[r].z : o.z;
-        o.w = m ? t[r].w : o.w;
-      }
-      if (act) q[L * (s + half)] = o;
-      if (s + half + 2 < steps) v = q[L * (s + half + 2)];
+      for (int k = 0; k < Q; k++) *(F4 *)(p + s * L * E + 4 * (k ^ m)) = f4_make(v + 4 * k);
     }
   }
 }
 
-struct ScanGroup {
-  float *S_all;  // the workgroup's LDS: chain c lives at S_all + c*VAMD_NZ_STRIDE(n)
-  int nchains;   // 5 x blocks
-  // a block's arrays are shared by the waves that split its bins: nobody may overwrite them
-  // with new terms while a sibling is still evaluating lines from the previous sums
-  VAMD_MEM void before_terms() const { __syncthreads(); }
-  VAMD_MEM void operator()(float *, int n) const {
-    __syncthreads();
-    if (nchains <= 16) {  // one wave, four lanes per chain
-      if ((threadIdx.x >> 6) == 0) running_sum_lanes<4>(S_all, 0, nchains, n);
-    } else {              // eight lanes per chain, eight chains per wave
-      const int first = (threadIdx.x >> 6) * 8;
-      if (first < nchains) running_sum_lanes<8>(S_all, first, nchains - first < 8 ? nchains - first : 8, n);
+// workgroup barrier for data exchanged through LDS: the wave's own LDS traffic has landed, then s_barrier.
+// (__syncthreads() would also drain the HBM loads and stores in flight.)
+VAMD_DEV void team_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Who runs the five running sums of a block: the team's first wave, between two barriers.
+struct ScanTeam {
+  VAMD_MEM void before_terms() const { team_lds_barrier(); }  // nobody still evaluates lines from the previous sums
+  VAMD_MEM void scan(float *S, int n) const {
+    team_lds_barrier();
+    if (threadIdx.x < 64) {
+      // the walk is one dependent add after the other: every issue slot it loses to a neighbour's per-bin
+      // phase on the same SIMD lengthens it, so it goes first
+      __builtin_amdgcn_s_setprio(3);
+      if ((n & 127) == 0) running_sum_rounds<8, 16>(S, VAMD_NZ_STRIDE(n), 5, n);
+      else if ((n & 63) == 0) running_sum_rounds<8, 8>(S, VAMD_NZ_STRIDE(n), 5, n);
+      else if ((n & 31) == 0) running_sum_rounds<8, 4>(S, VAMD_NZ_STRIDE(n), 5, n);
+      else if (LANE < 5) running_sum_inplace(S + LANE * VAMD_NZ_STRIDE(n), n);
+      __builtin_amdgcn_s_setprio(0);
     }
-    __syncthreads();
+    team_lds_barrier();
   }
 };
+#define LANE_BINS(k, i, i0, KPL, n) _Pragma("unroll") for (int k = 0, i = (i0) + LANE; k < (KPL); k++, i += NLANES) if (i < (n))
+#else
+#define LANE_BINS(k, i, i0, KPL, n) for (int k = 0, i = (i0); k < (KPL) && i < (n); k++, i++)
 #endif
 
-// bark_noise_hybridmp(n, bark, f, noise, offset, fixed).  f and noise are per-lane
-// register tiles: this wave owns the quads [q0, q1) of the block, lane l the quads q0+l,
-// q0+l+64, ... (SLICE_QUADS, QPS per lane), four bins each.  With one wave per block the slice is
-// the whole block; the persistent kernel gives a block to two waves so that the per-bin phases --
-// bound by each wave's dependent chains, not by issue slots -- take half as long.
+// One window of running sums -> (A, B, D).  `hi` is the upper edge; `e2` the lower edge, or the mirrored
+// lower edge -lo when `mir` (lo < 0 in the reference: lib/psy.c:613-617,666-670 against :635-639,687-691);
+// both already as LDS word positions (nz_swz).
+// MIR = false: the caller knows that none of the wave's bins is in the mirrored regime.
+template <bool MIR>
+VAMD_DEV LineFit fit_window(const float *S, int n, int hi, int e2, bool mir) {
+  const float *N = S, *X = S + VAMD_NZ_STRIDE(n), *XX = S + 2 * VAMD_NZ_STRIDE(n), *Y = S + 3 * VAMD_NZ_STRIDE(n), *XY = S + 4 * VAMD_NZ_STRIDE(n);
+  const float n1 = N[hi], x1 = X[hi], xx1 = XX[hi], y1 = Y[hi], xy1 = XY[hi];
+  const float n2 = N[e2], x2 = X[e2], xx2 = XX[e2], y2 = Y[e2], xy2 = XY[e2];
+  if (MIR && mir) return fit_from_sums(n1 + n2, x1 - x2, xx1 + xx2, y1 + y2, xy1 - xy2);
+  return fit_from_sums(n1 - n2, x1 - x2, xx1 - xx2, y1 - y2, xy1 - xy2);
+}
+
+// bark_noise_hybridmp(n, bark, f, noise, offset, fixed).  f and noise are per-lane register
+// arrays: this lane owns the bins i0 + LANE + 64k, k < KPL (LANE_BINS).
+//   bk[k]   the window of bin min(i, bark_i2 - 1) -- the bins past the last fitted line extend it
+//           (lib/psy.c:649-656), which is what evaluating that line's window again yields -- as LDS word
+//           positions: upper edge | lower (or mirrored lower) edge << 16 (noise_bark_edges).  Prepared by
+//           the caller ahead of time: bark[] is a table in HBM and its latency should not sit between the
+//           running sums and their use.
 // LOGN > 0: the bin count is the compile-time constant 2^LOGN (array strides and window-edge addresses
 // then fold into immediate offsets); 0 = P.n.
-template <class Scan, int QPS, int LOGN = 0>
-VAMD_DEV void bark_noise_wave(const PsyP &P, const float (*f)[4], float (*noise)[4], const float offset,
-                              const int fixed, float *S, const Scan &scan, PhaseClock &pc, int slot, int q0, int q1) {
+template <class Scan, int KPL, int LOGN>
+VAMD_DEV void bark_noise_bins(const PsyP &P, const float *f, const int *bk, float *noise, const float offset,
+                              const int fixed, float *S, const Scan &scan, PhaseClock &pc, int slot, int i0) {
   const int n = LOGN ? (1 << LOGN) : P.n;
   float *N = S, *X = S + VAMD_NZ_STRIDE(n), *XX = S + 2 * VAMD_NZ_STRIDE(n), *Y = S + 3 * VAMD_NZ_STRIDE(n), *XY = S + 4 * VAMD_NZ_STRIDE(n);
 
   // per-bin terms (lib/psy.c:571-597)
   scan.before_terms();
-  SLICE_QUADS(kq, q, q0, q1, QPS) {
-    float tn[4], tx[4], txx[4], ty[4], txy[4];
-#if VAMD_GPU
-#pragma unroll
-#endif
-    for (int c = 0; c < 4; c++) {
-      const int i = (q << 2) + c;
-      float y = f[kq][c] + offset;
-      if (y < 1.f) y = 1.f;
-      if (i == 0) {
-        const float w = (float)((double)(y * y) * .5);
-        tn[c] = w;
-        tx[c] = w;  // sic: the reference adds w, not w*x, at bin 0 (lib/psy.c:577)
-        txx[c] = 0.f;
-        ty[c] = w * y;
-        txy[c] = 0.f;
-      } else {
-        const float x = (float)i;
-        const float w = y * y;
-        tn[c] = w;
-        tx[c] = w * x;
-        txx[c] = w * x * x;
-        ty[c] = w * y;
-        txy[c] = w * x * y;
-      }
-    }
-    ((F4 *)N)[q] = f4_make(tn);
-    ((F4 *)X)[q] = f4_make(tx);
-    ((F4 *)XX)[q] = f4_make(txx);
-    ((F4 *)Y)[q] = f4_make(ty);
-    ((F4 *)XY)[q] = f4_make(txy);
+  LANE_BINS(k, i, i0, KPL, n) {
+    float y = f[k] + offset;
+    if (y < 1.f) y = 1.f;
+    const float x = (float)i;
+    float w = y * y;
+    if (i == 0) w = (float)((double)w * .5);
+    const int e = nz_swz(i);
+    N[e] = w;
+    X[e] = i == 0 ? w : w * x;  // sic: the reference adds w, not w*x, at bin 0 (lib/psy.c:577)
+    XX[e] = w * x * x;
+    Y[e] = w * y;
+    XY[e] = w * x * y;
   }
   pc.mark(slot);
 
-  // the five running sums, in index order, one lane each (lib/psy.c:576-603)
-  scan(S, n);
+  // the five running sums, in index order (lib/psy.c:576-603)
+  scan.scan(S, n);
   pc.mark(slot + 1);
 
-  // line evaluation; three regimes split at the static indices i1 <= i2
-  // (lib/psy.c:606-656).  Beyond i2 the last fitted line is extended.
-  LineFit last;
-  last.A = 0.f;
-  last.B = 0.f;
-  last.D = 1.f;
-  if (P.bark_i2 > 0) last = bark_fit_from(P, n, S, P.bark_i2 - 1, P.bark[P.bark_i2 - 1]);
-  SLICE_QUADS(kq, q, q0, q1, QPS) {
-    const I4 bq = ((const I4 *)P.bark)[q];
-    const int bk[4] = {bq.x, bq.y, bq.z, bq.w};
-#if VAMD_GPU
-#pragma unroll
-#endif
-    for (int c = 0; c < 4; c++) {
-      const int i = (q << 2) + c;
-      const LineFit L = (i < P.bark_i2) ? bark_fit_from(P, n, S, i, bk[c]) : last;
+  // line evaluation; three regimes split at the static indices i1 <= i2 (lib/psy.c:606-656): mirrored
+  // lower edge, plain window, and beyond i2 the last fitted line extended.  Written without branches over
+  // the lane's bins so that all their LDS reads are in flight together.
+  {
+    const bool any_mir = i0 < P.bark_i1 || P.bark_i2 - 1 < P.bark_i1, none = P.bark_i2 <= 0;  // wave-uniform
+    LineFit L[KPL];
+    if (any_mir) {
+      LANE_BINS(k, i, i0, KPL, n) {
+        const bool mir = (i < P.bark_i2 ? i : P.bark_i2 - 1) < P.bark_i1;
+        L[k] = fit_window<true>(S, n, bk[k] & 0xffff, (int)((unsigned)bk[k] >> 16), mir);
+      }
+    } else {
+      LANE_BINS(k, i, i0, KPL, n) L[k] = fit_window<false>(S, n, bk[k] & 0xffff, (int)((unsigned)bk[k] >> 16), false);
+    }
+    LANE_BINS(k, i, i0, KPL, n) {
+      if (none) L[k].A = 0.f, L[k].B = 0.f, L[k].D = 1.f;
       const float x = (float)i;
-      float R = (L.A + x * L.B) / L.D;
+      float R = (L[k].A + x * L[k].B) / L[k].D;
       if (R < 0.f) R = 0.f;
-      noise[kq][c] = R - offset;
+      noise[k] = R - offset;
     }
   }
   if (fixed > 0) {
     // fixed-width window pass: keep the lower of the two curves (lib/psy.c:660-703)
-    if (P.fix_i2 > 0) last = fixed_fit_at(P, n, S, P.fix_i2 - 1, fixed);
-    SLICE_QUADS(kq, q, q0, q1, QPS) {
-#if VAMD_GPU
-#pragma unroll
-#endif
-      for (int c = 0; c < 4; c++) {
-        const int i = (q << 2) + c;
-        const LineFit L = (i < P.fix_i2) ? fixed_fit_at(P, n, S, i, fixed) : last;
-        const float x = (float)i;
-        const float R = (L.A + x * L.B) / L.D;
-        if (R - offset < noise[kq][c]) noise[kq][c] = R - offset;
-      }
+    const bool any_mir = i0 < P.fix_i1 || P.fix_i2 - 1 < P.fix_i1, none = P.fix_i2 <= 0;
+    LineFit L[KPL];
+    LANE_BINS(k, i, i0, KPL, n) {
+      const int ii = i < P.fix_i2 ? i : P.fix_i2 - 1;
+      const int hi = ii + fixed / 2, lo = hi - fixed;
+      const bool mir = any_mir && ii < P.fix_i1;
+      if (any_mir)
+        L[k] = fit_window<true>(S, n, none ? 0 : nz_swz(hi), none ? 0 : nz_swz(mir ? -lo : lo), mir);
+      else
+        L[k] = fit_window<false>(S, n, none ? 0 : nz_swz(hi), none ? 0 : nz_swz(lo), false);
+    }
+    LANE_BINS(k, i, i0, KPL, n) {
+      if (none) L[k].A = 0.f, L[k].B = 0.f, L[k].D = 1.f;
+      const float x = (float)i;
+      const float R = (L[k].A + x * L[k].B) / L[k].D;
+      if (R - offset < noise[k]) noise[k] = R - offset;
     }
   }
-  WAVE_SYNC();  // S is rewritten by the next pass
   pc.mark(slot + 2);
 }
 
-// _vp_noisemask on a block whose logmdct is already in a register tile
-template <class Scan, int QPS, int LOGN = 0>
-VAMD_DEV void noisemask_tile(const PsyP &P, const float (*lm)[4], float (*o)[4], float *S, const Scan &scan,
-                             PhaseClock &pc, int q0, int q1) {
-  float nz[QPS][4], wk[QPS][4];
-  bark_noise_wave<Scan, QPS, LOGN>(P, lm, nz, 140.f, -1, S, scan, pc, 0, q0, q1);
-  SLICE_QUADS(kq, q, q0, q1, QPS) {
-    for (int c = 0; c < 4; c++) wk[kq][c] = lm[kq][c] - nz[kq][c];
+// bark[] of this lane's bins for bark_noise_bins (see there): the raw table words, fetched early
+template <int KPL, int LOGN>
+VAMD_DEV void noise_bark_fetch(const PsyP &P, int *braw, int i0) {
+  const int n = LOGN ? (1 << LOGN) : P.n;
+  LANE_BINS(k, i, i0, KPL, n) {
+    const int ii = i < P.bark_i2 ? i : P.bark_i2 - 1;
+    braw[k] = P.bark[ii < 0 ? 0 : ii];
   }
-  pc.mark(3);
-  bark_noise_wave<Scan, QPS, LOGN>(P, wk, nz, 0.f, P.noisewindowfixed, S, scan, pc, 4, q0, q1);
-  SLICE_QUADS(kq, q, q0, q1, QPS) {
-#if VAMD_GPU
-#pragma unroll
-#endif
-    for (int c = 0; c < 4; c++) {
-      const float w = lm[kq][c] - wk[kq][c];
-      int dB = (int)((double)nz[kq][c] + .5);
-      if (dB >= VAMD_NOISE_COMPAND_LEVELS) dB = VAMD_NOISE_COMPAND_LEVELS - 1;
-      if (dB < 0) dB = 0;
-      o[kq][c] = w + P.noisecompand[dB];
-    }
+}
+// ... and turned into LDS word positions once the words have arrived
+template <int KPL, int LOGN>
+VAMD_DEV void noise_bark_edges(const PsyP &P, const int *braw, int *bk, int i0) {
+  const int n = LOGN ? (1 << LOGN) : P.n;
+  LANE_BINS(k, i, i0, KPL, n) {
+    const int ii = i < P.bark_i2 ? i : P.bark_i2 - 1;
+    const int lo = braw[k] >> 16, hi = braw[k] & 0xffff;
+    bk[k] = nz_swz(hi) | (nz_swz(ii < P.bark_i1 ? -lo : lo) << 16);
   }
-  pc.mark(7);
 }
 
-// _vp_noisemask(p, logmdct, logmask) for one block (single-wave form)
-//   logmdct  [n] input (HBM), out [n] (HBM); S = LDS [5][VAMD_NZ_STRIDE(n)]
-// The noise curve and the work vector never change hands between lanes, so they live in
-// registers (VAMD_QPL quads per lane: block sizes up to 2048 on the GPU).
-VAMD_DEV void noisemask_block(const PsyP &P, const float *__restrict__ logmdct, float *__restrict__ out, float *S,
-                              PhaseClock &pc) {
-  const int nq = P.n >> 2;
-  float lm[VAMD_QPL][4], o[VAMD_QPL][4];
-  LANE_QUADS(kq, q, nq) f4_get(((const F4 *)logmdct)[q], lm[kq]);
-  noisemask_tile<ScanSolo, VAMD_QPL>(P, lm, o, S, ScanSolo(), pc, 0, nq);
-  LANE_QUADS(kq, q, nq)((F4 *)out)[q] = f4_make(o[kq]);
+// _vp_noisemask on a block whose logmdct is already in the lanes' registers (lm[k] = bin i0 + LANE + 64k)
+//   compand  noisecompand[] (P.noisecompand, or the caller's copy of it in LDS)
+template <class Scan, int KPL, int LOGN>
+VAMD_DEV void noisemask_bins(const PsyP &P, const float *lm, const int *braw, float *o, float *S, const float *compand,
+                             const Scan &scan, PhaseClock &pc, int i0) {
+  const int n = LOGN ? (1 << LOGN) : P.n;
+  float nz[KPL], wk[KPL];
+  int bk[KPL];
+  noise_bark_edges<KPL, LOGN>(P, braw, bk, i0);  // (placed by the compiler where braw is first needed: after the first walk)
+  bark_noise_bins<Scan, KPL, LOGN>(P, lm, bk, nz, 140.f, -1, S, scan, pc, 0, i0);
+  LANE_BINS(k, i, i0, KPL, n) wk[k] = lm[k] - nz[k];
+  pc.mark(3);
+  bark_noise_bins<Scan, KPL, LOGN>(P, wk, bk, nz, 0.f, P.noisewindowfixed, S, scan, pc, 4, i0);
+  LANE_BINS(k, i, i0, KPL, n) {
+    const float w = lm[k] - wk[k];
+    int dB = (int)((double)nz[k] + .5);
+    if (dB >= VAMD_NOISE_COMPAND_LEVELS) dB = VAMD_NOISE_COMPAND_LEVELS - 1;
+    if (dB < 0) dB = 0;
+    o[k] = w + compand[dB];
+  }
+  pc.mark(7);
 }
 
 }  // namespace vamd

@@ -168,48 +168,45 @@ __global__ __launch_bounds__(64 * VAMD_XF_WAVES) void k_transform(XformP G, int 
   pc.flush();
 }
 
-// stage 2: _vp_noisemask.  Persistent workgroups, a CU holding VAMD_NZ_WAVES channel-blocks per round
-// (their running sums fill the LDS); each block's bins are shared by VAMD_NZ_SPLIT waves, and the
-// group's first wave(s) run the ordered running sums of the whole group (ScanGroup, k_noise.h).
-#define VAMD_NZ_WAVES 7         // blocks per round when the kernel has the CU to itself
-#define VAMD_NZ_WAVES_SHARED 6  // ... when the tone kernels run beside it
-#define VAMD_NZ_SPLIT 2
-#define VAMD_NZ_GROUP 2         // blocks per workgroup beside the tone kernels (three workgroups per CU)
-// LOGN2 > 0: the bin count n/2 = 2^LOGN2 is a compile-time constant (as for k_transform).
+// stage 2: _vp_noisemask.  One workgroup ("team") of up to four waves per channel-block: every wave takes a
+// quarter of the bins for the per-bin phases, the first wave walks the five ordered running sums
+// (ScanTeam, k_noise.h).  LDS per team: the five sums (20.3 KB at 1024 bins), so a CU holds seven teams;
+// what hides the ~17k cycles a block spends in its two ordered walks is the other six teams.
+// LOGN2 = log2 of the bin count n/2.
 template <int LOGN2>
-__global__ __launch_bounds__(64 * VAMD_NZ_WAVES * VAMD_NZ_SPLIT) void k_noise(PsyP P0, PsyP P1, DescP d, int ch,
-                                                                             long ncb, int split,
-                                                                             const float *__restrict__ logmdct,
-                                                                             float *__restrict__ noise) {
-  const int wave = threadIdx.x >> 6;
-  // `split` waves share a block: VAMD_NZ_SPLIT, more for blocks whose slices would not fit the
-  // per-lane register tiles (n = 4096: four waves of 512 bins)
-  const int nblk = (blockDim.x >> 6) / split, slot = wave / split, part = wave % split;
-  const int n2 = LOGN2 ? (1 << LOGN2) : P0.n, nq = n2 >> 2;
-  // this wave's slice of the block's quads, a whole number of wave-widths
-  const int per = ((nq + split * 64 - 1) / (split * 64)) * 64;
-  const int q0 = part * per < nq ? part * per : nq, q1 = q0 + per < nq ? q0 + per : nq;
-  float *S_all = (float *)vamd_smem;
-  float *S = S_all + slot * 5 * VAMD_NZ_STRIDE(n2);
-  ScanGroup scan;
-  scan.S_all = S_all;
-  scan.nchains = 5 * nblk;
+struct NoiseGeom {
+  static constexpr int n2 = 1 << LOGN2;
+  static constexpr int NW = n2 >= 256 ? 4 : (n2 >= 64 ? n2 / 64 : 1);  // waves per team
+  static constexpr int KPL = n2 / (64 * NW) > 0 ? n2 / (64 * NW) : 1;  // bins per lane
+};
+template <int LOGN2>
+__global__ __launch_bounds__(64 * NoiseGeom<LOGN2>::NW, NoiseGeom<LOGN2>::KPL <= 4 ? 7 : 4) void k_noise(PsyP P0, PsyP P1, DescP d, int ch, long ncb,
+                                                                     const float *__restrict__ logmdct,
+                                                                     float *__restrict__ noise) {
+  constexpr int n2 = NoiseGeom<LOGN2>::n2, KPL = NoiseGeom<LOGN2>::KPL;
+  float *S = (float *)vamd_smem;
+  float *compand = S + 5 * VAMD_NZ_STRIDE(n2);  // noisecompand[] beside the sums: the final lookup is data-dependent
+  const int i0 = (threadIdx.x >> 6) * 64 * KPL;  // this wave's first bin
   PhaseClock pc;
   pc.start(d.dbg ? d.dbg + 16 : nullptr);
-  const long stride = (long)gridDim.x * nblk;
-  const long rounds = (ncb + stride - 1) / stride;  // identical for every wave: barriers inside
-  constexpr int QPS = (VAMD_QPL + VAMD_NZ_SPLIT - 1) / VAMD_NZ_SPLIT;
-  for (long r = 0; r < rounds; r++) {
-    const long cb_raw = r * stride + (long)blockIdx.x * nblk + slot;
-    const bool live = cb_raw < ncb;
-    const long cb = live ? cb_raw : ncb - 1;  // idle slots shadow the last block (no store)
-    const PsyP &P = d_bt(d, cb / ch) ? P1 : P0;
-    float lm[QPS][4], o[QPS][4];
-    SLICE_QUADS(kq, q, q0, q1, QPS) f4_get(((const F4 *)(logmdct + cb * n2))[q], lm[kq]);
-    noisemask_tile<ScanGroup, QPS, LOGN2>(P, lm, o, S, scan, pc, q0, q1);
-    if (live) {
-      SLICE_QUADS(kq, q, q0, q1, QPS)((F4 *)(noise + cb * n2))[q] = f4_make(o[kq]);
-    }
+  if (threadIdx.x < 2 * VAMD_NOISE_COMPAND_LEVELS)  // both block types' tables
+    compand[threadIdx.x] = threadIdx.x < VAMD_NOISE_COMPAND_LEVELS ? P0.noisecompand[threadIdx.x]
+                                                                 : P1.noisecompand[threadIdx.x - VAMD_NOISE_COMPAND_LEVELS];
+  // persistent: the next block's spectrum is fetched while this one is worked on
+  float lm[KPL];
+  long cb = blockIdx.x;
+  if (cb < ncb) LANE_BINS(k, i, i0, KPL, n2) lm[k] = logmdct[cb * n2 + i];
+  for (; cb < ncb; cb += gridDim.x) {
+    const int bt = d_bt(d, (long)((unsigned)cb / (unsigned)ch));  // (cb < 2^31: check_desc)
+    const PsyP &P = bt ? P1 : P0;
+    float o[KPL], lm_next[KPL];
+    int braw[KPL];
+    const long nb = cb + gridDim.x < ncb ? cb + gridDim.x : cb;
+    noise_bark_fetch<KPL, LOGN2>(P, braw, i0);
+    LANE_BINS(k, i, i0, KPL, n2) lm_next[k] = logmdct[nb * n2 + i];
+    noisemask_bins<ScanTeam, KPL, LOGN2>(P, lm, braw, o, S, compand + (bt ? VAMD_NOISE_COMPAND_LEVELS : 0), ScanTeam(), pc, i0);
+    LANE_BINS(k, i, i0, KPL, n2) noise[cb * n2 + i] = o[k];
+    LANE_BINS(k, i, i0, KPL, n2) lm[k] = lm_next[k];
   }
   pc.flush();
 }
@@ -737,12 +734,6 @@ int vamd_create(vamd_ctx **out, const void *setup_blob, size_t blob_bytes, int d
                             (int)c->lds_per_block);
       VAMD_OPT_IN(0) VAMD_OPT_IN(8) VAMD_OPT_IN(9) VAMD_OPT_IN(10) VAMD_OPT_IN(11) VAMD_OPT_IN(12)
 #undef VAMD_OPT_IN
-      (void)hipFuncSetAttribute((const void *)k_noise<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_per_block);
-      (void)hipFuncSetAttribute((const void *)k_noise<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_per_block);
-      (void)hipFuncSetAttribute((const void *)k_noise<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_per_block);
-      (void)hipFuncSetAttribute((const void *)k_noise<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_per_block);
-      (void)hipFuncSetAttribute((const void *)k_noise<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_per_block);
-      (void)hipFuncSetAttribute((const void *)k_noise<11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_per_block);
       (void)hipGetLastError();
       if (getenv("VAMD_VERBOSE"))
         fprintf(stderr, "vamd_create: %d CUs, %zu B LDS per workgroup\n", c->num_cus, c->lds_per_block);
@@ -1108,29 +1099,24 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_
       (void)hipStreamWaitEvent(c->side, c->ev_fork, 0);
     }
     {
-      // alone, 7 blocks' running sums fill a CU's LDS; beside the tone kernels 6 leave those room
-      int waves = overlap ? VAMD_NZ_WAVES_SHARED : VAMD_NZ_WAVES;
-      while (waves > 1 && (size_t)waves * 5 * VAMD_NZ_STRIDE(n2) * 4 > c->lds_per_block) waves--;
-      // a wave's slice is at most QPS * 256 = 512 bins
-      int split = VAMD_NZ_SPLIT;
-      while ((n2 + split * 512 - 1) / (split * 512) > 1) split *= 2;
-      while (waves > 1 && waves * split > VAMD_NZ_WAVES * VAMD_NZ_SPLIT) waves--;
-      // beside the tone kernels the CU's six blocks run as three workgroups of two: each group's ordered
-      // sums are one wave's work (ten chains, four lanes each) and overlap the other groups' per-bin phases
-      int wgs = 1;
-      if (overlap && waves == VAMD_NZ_WAVES_SHARED) waves = VAMD_NZ_GROUP, wgs = VAMD_NZ_WAVES_SHARED / VAMD_NZ_GROUP;
-      const long groups = ((long)gcb + waves - 1) / waves;
-      const unsigned grid = (unsigned)(groups < (long)c->num_cus * wgs ? groups : (long)c->num_cus * wgs);
-#define VAMD_GO(L)                                                                                                          \
-  hipLaunchKernelGGL(k_noise<L>, dim3(grid), dim3(64 * waves * split), (size_t)waves * 5 * VAMD_NZ_STRIDE(n2) * 4, s, P0, P1, d, \
-                     ch, (long)gcb, split, p.logmdct, p.noise)
+      // persistent teams, as many per CU as its LDS and its 32 wave slots hold (7 at 1024 bins)
+      const size_t lds = ((size_t)5 * VAMD_NZ_STRIDE(n2) + 2 * VAMD_NOISE_COMPAND_LEVELS) * 4;
+      const int nw = n2 >= 256 ? 4 : (n2 >= 64 ? n2 / 64 : 1);
+      long per_cu = (long)(c->lds_per_block / lds);
+      if (per_cu > 32 / nw) per_cu = 32 / nw;
+      if (per_cu < 1) per_cu = 1;
+      const unsigned grid = (unsigned)((long)gcb < per_cu * c->num_cus ? (long)gcb : per_cu * c->num_cus);
+#define VAMD_GO(L)                                                                                                    \
+  hipLaunchKernelGGL(k_noise<L>, dim3(grid), dim3(64 * NoiseGeom<L>::NW), lds, s, P0, P1, d, ch, (long)gcb, p.logmdct, \
+                     p.noise)
       switch (n2) {
+        case 32: VAMD_GO(5); break;
+        case 64: VAMD_GO(6); break;
         case 128: VAMD_GO(7); break;
         case 256: VAMD_GO(8); break;
         case 512: VAMD_GO(9); break;
         case 1024: VAMD_GO(10); break;
-        case 2048: VAMD_GO(11); break;
-        default: VAMD_GO(0);
+        default: VAMD_GO(11); break;  // 2048 bins: the largest block size the context accepts
       }
 #undef VAMD_GO
     }
