@@ -30,6 +30,8 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+from vorbis_amd import sharding  # noqa: E402
+
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 
 # algorithmic HBM bytes per unit, fp32/int32, every tensor touched once, tables excluded
@@ -46,23 +48,46 @@ STAGE_BYTES = {
 }
 
 
+def source_hash():
+    """sha256 over the kernel sources and the ABI headers: what a PMC profile must have been taken from to
+    still describe the library this run loads."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in ("vorbis_amd/csrc", "include"):
+        for f in sorted(os.listdir(os.path.join(ROOT, d))):
+            if f.endswith((".h", ".hip")):
+                h.update(f.encode())
+                h.update(open(os.path.join(ROOT, d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+TRAFFIC_PROFILE = "profiles/r02_pmc_traffic.json"
+
+
 def measured_traffic(workload, units):
-    """HBM bytes per step from the committed PMC run (profiles/r01_pmc_traffic.json: rocprofv3
-    --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950 calibration).
-    Returns (total bytes per step, per-stage dict) or (None, {})."""
+    """HBM bytes per step from the committed PMC run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+    passes, FETCH_SIZE doubled per the gfx950 calibration; tools/profile.sh + tools/make_profiles.py).  The
+    profile carries the hash of the sources it was taken from; if the sources have changed since, the figure
+    is withheld (None, {}, reason) rather than reported stale.  Returns (bytes per step, per-kernel dict, note)."""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        t = json.load(open(os.path.join(ROOT, TRAFFIC_PROFILE)))
     except Exception:
-        return None, {}
+        return None, {}, "no committed PMC profile"
+    if t.get("source_hash") != source_hash():
+        return None, {}, "PMC profile %s was taken from other sources (%s, now %s): re-run tools/profile.sh" % (
+            TRAFFIC_PROFILE, t.get("source_hash"), source_hash())
+    note = "%s (source hash %s matches this build)" % (t["source"], t["source_hash"])
     if workload == "c2":
-        return t["mdct_only_B_per_frame"] * units, {}
+        return t["mdct_only_B_per_frame"] * units, {}, note
+    if workload == "c5":
+        return None, {}, "no PMC pass for the mixed-size workload"
     per = {k: (v["read_B_per_stereo_block"] + v["write_B_per_stereo_block"]) * units for k, v in t["per_kernel"].items()}
     if workload == "c3":
-        per = {k: v for k, v in per.items() if k in ("k_transform", "k_noise", "k_tone_seed", "k_tone_chase", "k_tone_fold")}
-    return sum(per.values()), per
+        per = {k: v for k, v in per.items() if k in ("k_transform", "k_noise", "k_tone_seed", "k_tone_chase", "k_tone_fold", "k_tone")}
+    return sum(per.values()), per, note
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -72,8 +97,12 @@ def parse():
     ap.add_argument("--setup", default="44k_stereo_q4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-neighbours", action="store_true", help="skip the informational extra stages (profiling runs)")
+    ap.add_argument("--no-parity-sample", action="store_true", help="skip the post-run oracle check of the timed batch")
+    ap.add_argument("--parity-blocks", type=int, default=256)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    return ap.parse_args()
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only for the CPU rehearsal of the rank logic)")
+    return ap.parse_args(argv)
 
 
 def cpu_baseline(setup_name, seconds):
@@ -84,7 +113,7 @@ def cpu_baseline(setup_name, seconds):
     from oracle import ref
     ch, rate, q = checker.SETUPS[setup_name]
     cores = os.cpu_count() or 1
-    nthreads = min(cores, 64)
+    nthreads = min(cores, 256)
     sample_blocks = 256
     rng = np.random.default_rng(99)
     pcm = (rng.random((sample_blocks, ch, 2048), dtype=np.float32) - 0.5).astype(np.float32)
@@ -97,6 +126,14 @@ def cpu_baseline(setup_name, seconds):
         blob = np.fromfile(os.path.join(ROOT, "vorbis_amd", "data", "setup_%s.bin" % setup_name), dtype=np.uint8)
         make = lambda: port.PortEncoder(blob)  # noqa: E731
     encs = [make() for _ in range(nthreads)]
+    # one thread on an otherwise idle host first: what a core does unshared (the threaded figure below divides
+    # the cores' caches, memory bandwidth and -- past the physical core count -- their SMT siblings)
+    t1 = time.time()
+    n1 = 0
+    while time.time() - t1 < min(2.0, seconds / 4):
+        encs[0].time_dsp(pcm, 1)
+        n1 += sample_blocks
+    single = n1 / (time.time() - t1)
     done = [0] * nthreads
     cpu_time = [0.0] * nthreads
     deadline = time.time() + seconds
@@ -114,8 +151,8 @@ def cpu_baseline(setup_name, seconds):
     wall = time.time() - t0
     total = sum(done)
     return {
-        "value": total / wall, "unit": "stereo blocks/s", "cores": nthreads, "kind": kind,
-        "per_core": total / max(sum(cpu_time), 1e-9),
+        "value": total / wall, "unit": "stereo blocks/s", "cores": nthreads, "nproc": cores, "kind": kind,
+        "per_core": total / max(sum(cpu_time), 1e-9), "single_thread_value": single,
         "sample": "%d threads x repeated passes over %d seeded white-noise stereo 2048-blocks for %.0f s wall "
                   "(%d blocks total); window+MDCT+FFT+psy+floor1 fit/encode+couple/quantise of "
                   "mapping0_forward (the part the GPU path computes; residue VQ/Huffman excluded)"
@@ -188,113 +225,150 @@ def neighbour_stages(an, pcm, outs, nb):
                                          "streams": ns, "steps_per_stream": int(steps)}}
 
 
-def main():
-    a = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        dist = None
-        torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+class GpuRunner:
+    """One rank's share of the workload on its GPU: owns the context, the resident inputs and outputs."""
 
+    def __init__(self, a, blob, dev, rank, world):
+        import vorbis_amd
+        self.a, self.dev, self.rank = a, dev, rank
+        self.vorbis_amd = vorbis_amd
+        self.an = an = vorbis_amd.Analyzer(blob, device=dev.index)
+        ch, n = an.channels, an.blocksizes[1]
+        nb = a.blocks or (131072 if a.workload == "c4" else 65536)
+        # weak scaling: `nb` units per rank; rank r owns [lo, hi) of the job's nb * world units
+        self.lo, self.hi = sharding.shard_range(nb * world, rank, world)
+        self.nb = nb = self.hi - self.lo
+        g = torch.Generator(device=dev)
+        g.manual_seed(1234 + rank)
+        if a.workload == "c2":
+            self.frames = torch.rand((nb, n), generator=g, device=dev, dtype=torch.float32) - 0.5
+            self.out = torch.empty((nb, n // 2), device=dev, dtype=torch.float32)
+            self.units, self.unit_name = nb, "2048-sample frames/s"
+            self.ev0, self.ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        else:
+            self.pcm = torch.rand((nb, ch, n), generator=g, device=dev, dtype=torch.float32) - 0.5
+            self.level = vorbis_amd.LEVEL_FULL if a.workload == "c4" else vorbis_amd.LEVEL_PSY
+            want = ("mdct", "logmask", "posts", "post_valid", "iwork", "nonzero", "ampmax_out") if a.workload == "c4" \
+                else ("mdct_raw", "noise", "tone")
+            self.outs = an.alloc_outputs(1, nb, want)
+            an.reserve(1, nb)
+            self.units, self.unit_name = nb, "stereo blocks/s"
+
+    def step(self):
+        if self.a.workload == "c2":
+            self.an.mdct_forward(1, self.frames, out=self.out)
+        else:
+            self.an.analyze(self.pcm, W=1, lW=1, nW=1, blocktype=1, ampmax_in=-9999.0, level=self.level, outs=self.outs)
+
+    def sync(self):
+        torch.cuda.synchronize()
+
+    def timed_begin(self):
+        if self.a.workload != "c2":
+            self.an.profile(True)
+        else:
+            self.ev0.record()
+
+    def timed_end(self):
+        if self.a.workload == "c2":
+            self.ev1.record()
+
+    def stage_ms(self, steps):
+        """per-kernel durations from HIP events recorded on the launch stream inside the timed region"""
+        if self.a.workload != "c2":
+            ms, runs = self.an.stage_ms()
+            self.an.profile(False)
+            return {k: v / max(runs, 1) for k, v in ms.items() if v > 0}
+        return {"mdct_forward": self.ev0.elapsed_time(self.ev1) / steps}
+
+    def parity_sample(self, count):
+        """After the timed region: `count` randomly indexed units of the very batch that was timed, every output
+        the run produced for them compared bit-for-bit with the CPU checker (oracle/_ref when its prebuilt library
+        is here, else the pinned C restatement).  Returns (units checked, mismatching units, checker kind)."""
+        from tests import checker
+        chk = checker.Checker(self.a.setup)
+        rng = np.random.default_rng(4242 + self.rank)
+        idx = np.sort(rng.choice(self.nb, size=min(count, self.nb), replace=False))
+        sel = torch.from_numpy(idx).to(self.dev)
+        bad = 0
+        if self.a.workload == "c2":
+            x, y = self.frames[sel].cpu().numpy(), self.out[sel].cpu().numpy()
+            for k in range(len(idx)):
+                bad += not np.array_equal(chk.mdct_forward(1, x[k]).view(np.uint32), y[k].view(np.uint32))
+            return len(idx), bad, chk.kind
+        pcm = self.pcm[sel].cpu().numpy()
+        got = {k: v[sel].cpu().numpy() for k, v in self.outs.items()}
+        nposts = self.an.posts[1]
+        for k in range(len(idx)):
+            ref = chk.tap_block(pcm[k])
+            bad += checker.compare_block(ref, {kk: v[k] for kk, v in got.items()}, nposts) != 0
+        return len(idx), bad, chk.kind
+
+    def workload_text(self):
+        nb = self.nb
+        return {"c4": "C4 full mapping0_forward analysis (window+MDCT+FFT+noise/tone mask+floor1 fit+"
+                      "couple/quantise), %d stereo 2048-blocks per GPU, 44.1 kHz q=0.4 tables, "
+                      "white noise, independent frames, inputs resident in HBM" % nb,
+                "c3": "C3 MDCT + _vp_noisemask/_vp_tonemask, %d stereo 2048-blocks per GPU" % nb,
+                "c2": "C2 batched mdct_forward only, %d x n=2048 frames per GPU" % nb}[self.a.workload]
+
+    def neighbours(self):
+        return neighbour_stages(self.an, self.pcm, self.outs, self.nb)
+
+
+def main(argv=None, make_runner=None):
+    """`make_runner(a, blob, dev, rank, world)` replaces the GPU runner; only the CPU rehearsal of the rank logic
+    (tests/test_abi_and_host.py, gloo, world size 2) passes one."""
+    a = parse(argv)
+    rank, world, dev = sharding.init_from_env(a.backend, use_cuda=make_runner is None)
     import vorbis_amd
-    # rank 0 owns the setup blob; everyone else receives it over RCCL
-    if rank == 0:
-        blob = torch.from_numpy(vorbis_amd.default_setup_blob(a.setup).copy()).to(dev)
-        size = torch.tensor([blob.numel()], dtype=torch.int64, device=dev)
-    else:
-        size = torch.zeros(1, dtype=torch.int64, device=dev)
-    if dist:
-        dist.broadcast(size, 0)
-        if rank != 0:
-            blob = torch.empty(int(size.item()), dtype=torch.uint8, device=dev)
-        dist.broadcast(blob, 0)
-    an = vorbis_amd.Analyzer(blob.cpu().numpy(), device=dev.index)
-    ch = an.channels
-    n = an.blocksizes[1]
-
-    nb = a.blocks or (131072 if a.workload == "c4" else 65536)
-    g = torch.Generator(device=dev)
-    g.manual_seed(1234 + rank)
-    if a.workload == "c2":
-        frames = torch.rand((nb, n), generator=g, device=dev, dtype=torch.float32) - 0.5
-        out = torch.empty((nb, n // 2), device=dev, dtype=torch.float32)
-
-        def step():
-            an.mdct_forward(1, frames, out=out)
-        units, unit_name = nb, "2048-sample frames/s"
-    else:
-        pcm = torch.rand((nb, ch, n), generator=g, device=dev, dtype=torch.float32) - 0.5
-        level = vorbis_amd.LEVEL_FULL if a.workload == "c4" else vorbis_amd.LEVEL_PSY
-        want = ("mdct", "logmask", "posts", "post_valid", "iwork", "nonzero", "ampmax_out") if a.workload == "c4" \
-            else ("mdct_raw", "noise", "tone")
-        outs = an.alloc_outputs(1, nb, want)
-        an.reserve(1, nb)
-
-        def step():
-            an.analyze(pcm, W=1, lW=1, nW=1, blocktype=1, ampmax_in=-9999.0, level=level, outs=outs)
-        units, unit_name = nb, "stereo blocks/s"
+    # rank 0 owns the setup blob; everyone else receives it over RCCL -- the job's only collective besides timing
+    blob = sharding.broadcast_blob(vorbis_amd.default_setup_blob(a.setup) if rank == 0 else None, dev)
+    R = (make_runner or GpuRunner)(a, blob, dev, rank, world)
 
     for _ in range(a.warmup):
-        step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    if a.workload != "c2":
-        an.profile(True)
-    else:
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
+        R.step()
+    R.sync()
+    sharding.barrier()
+    R.sync()
     t0 = time.perf_counter()
-    if a.workload == "c2":
-        ev0.record()
+    R.timed_begin()
     for _ in range(a.steps):
-        step()
-    if a.workload == "c2":
-        ev1.record()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        R.step()
+    R.timed_end()
+    R.sync()
+    sharding.barrier()
+    elapsed = sharding.max_over_ranks(time.perf_counter() - t0, dev)
 
-    # per-kernel durations from HIP events recorded on the launch stream inside the timed region
-    if a.workload != "c2":
-        ms, runs = an.stage_ms()
-        stage_ms = {k: v / max(runs, 1) for k, v in ms.items() if v > 0}
-        an.profile(False)
-    else:
-        stage_ms = {"mdct_forward": ev0.elapsed_time(ev1) / a.steps}
+    stage_ms = R.stage_ms(a.steps)
+    parity = None
+    if not a.no_parity_sample:
+        try:
+            n_chk, n_bad, kind = R.parity_sample(max(1, a.parity_blocks // world))
+            parity = {"blocks": sharding.sum_over_ranks(n_chk, dev), "mismatches": sharding.sum_over_ranks(n_bad, dev),
+                      "checker": kind, "compared": "every output tensor of the timed batch for randomly indexed units, bit-exact"}
+        except Exception as e:  # a missing checker must not lose the GPU number -- but it is said, not hidden
+            sharding.sum_over_ranks(0, dev), sharding.sum_over_ranks(0, dev)
+            parity = {"blocks": 0, "mismatches": None, "error": repr(e)}
 
+    rc = 0
     if rank == 0:
+        units = R.units
         value = world * units * a.steps / elapsed
         kernels_ms = sum(stage_ms.values())
         dom = max(stage_ms, key=stage_ms.get)
         alg = ALG_BYTES[a.workload] * units                      # bytes per step per GPU, algorithmic
         achieved = alg / (kernels_ms * 1e-3) / 1e9                # GB/s over the path's kernels
         dom_bytes = (STAGE_BYTES.get(dom, ALG_BYTES["c2"]) * units)
-        traffic, traffic_per = measured_traffic(a.workload, units)
+        traffic, traffic_per, traffic_note = measured_traffic(a.workload, units)
         stage_of = {"k_transform": "transform", "k_noise": "noisemask", "k_floor": "floor", "k_couple": "couple",
-                    "k_tone_seed": "tonemask", "k_tone_chase": "tonemask", "k_tone_fold": "tonemask"}
+                    "k_tone_seed": "tonemask", "k_tone_chase": "tonemask", "k_tone_fold": "tonemask", "k_tone": "tonemask"}
         dom_traffic = sum(v for k, v in traffic_per.items() if stage_of.get(k) == dom) or None
         roof = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, "
-                              "separate passes; bytes per step of this workload)" if traffic else None,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
             "definition": "algorithmic bytes of the whole path per step (%d B/unit x %d units) / summed "
-                          "HIP-event segments of the path's stages on the launch stream per step; the tone-masking "
-                          "kernels run on a side stream beside k_noise, so 'noisemask' is k_noise's launch "
-                          "duration with them co-resident and 'tonemask' is only their tail after k_noise ends"
+                          "HIP-event segments of the path's stages on the launch stream per step"
                           % (ALG_BYTES[a.workload], units),
             "kernels_ms_per_step": stage_ms,
             "dominant_kernel": {"name": dom, "ms": stage_ms[dom], "own_bytes_per_step": dom_bytes,
@@ -302,33 +376,36 @@ def main():
         }
         line = {
             "metric": "audio blocks/s (2048-sample MDCT+psy) @1/2/4/8 GPU; % HBM roofline",
-            "value": value, "unit": unit_name, "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "value": value, "unit": R.unit_name, "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": {"c4": "C4 full mapping0_forward analysis (window+MDCT+FFT+noise/tone mask+floor1 fit+"
-                                   "couple/quantise), %d stereo 2048-blocks per GPU, 44.1 kHz q=0.4 tables, "
-                                   "white noise, independent frames, inputs resident in HBM" % nb,
-                             "c3": "C3 MDCT + _vp_noisemask/_vp_tonemask, %d stereo 2048-blocks per GPU" % nb,
-                             "c2": "C2 batched mdct_forward only, %d x n=2048 frames per GPU" % nb}[a.workload],
-                "blocks_per_gpu": nb, "setup": a.setup, "parallelism": "blocks sharded x%d, no data-path collective" % world,
+                "workload": R.workload_text(),
+                "blocks_per_gpu": units, "setup": a.setup, "parallelism": "blocks sharded x%d, no data-path collective" % world,
             },
             "roofline": roof,
         }
-        if world == 1 and a.workload == "c4" and not a.no_neighbours:
+        if parity is not None:
+            line["parity_sample"] = parity
+            if parity.get("mismatches"):
+                rc = 3
+        if world == 1 and a.workload == "c4" and not a.no_neighbours and make_runner is None:
             try:  # informational: the stages either side of the metric's path
-                line["neighbours"] = neighbour_stages(an, pcm, outs, nb)
+                line["neighbours"] = R.neighbours()
             except Exception as e:
                 line["neighbours"] = {"error": repr(e)}
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and make_runner is None:
             try:
                 line["cpu_baseline"] = cpu_baseline(a.setup, a.cpu_seconds)
             except Exception as e:  # a missing checker must not lose the GPU number
                 line["cpu_baseline"] = {"value": None, "error": repr(e)}
         print(json.dumps(line))
-    if dist:
-        dist.destroy_process_group()
+        if rc:
+            print("bench: parity_sample found %d mismatching units -- the timed outputs differ from the oracle"
+                  % parity["mismatches"], file=sys.stderr)
+    sharding.finish()
+    return rc
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

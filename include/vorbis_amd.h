@@ -69,11 +69,13 @@ int vamd_set_stream(vamd_ctx *ctx, void *hip_stream);
 int vamd_reserve(vamd_ctx *ctx, int W, long max_blocks);
 
 /* Measurement hook (no libvorbis counterpart): when enabled, a HIP event is
- * recorded on the context's stream before each stage kernel and after the last.
- * vamd_stage_ms() synchronises the stream and returns, per stage, the summed
- * elapsed milliseconds of all batches issued since the last call (stage order:
- * 0 transform, 1 ampmax, 2 noisemask, 3 tonemask, 4 floor, 5 couple) and the
- * number of batches in *runs. */
+ * recorded on the context's stream before the first stage kernel of a batch and
+ * after every stage.  vamd_stage_ms() synchronises the stream and returns, per
+ * stage, the summed elapsed milliseconds of all batches issued since the last
+ * call -- eight stages: 0 transform, 1 ampmax, 2 noisemask, 3 tonemask, 4 floor,
+ * 5 couple, 6 residue search, 7 packet assembly (stages a batch did not run stay
+ * 0; with nstages < 8 the later ones are dropped) -- and the number of batches in
+ * *runs (a mixed-size call counts once; both size classes add to the same stage). */
 int vamd_profile(vamd_ctx *ctx, int enable);
 int vamd_stage_ms(vamd_ctx *ctx, float *ms, int nstages, int *runs);
 

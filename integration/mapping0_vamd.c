@@ -23,10 +23,9 @@
  *
  * Bitrate-managed encoders get all PACKETBLOBS candidate packets the same way;
  * the bitrate manager that picks one is untouched host code.
- * Only channel counts above VAMD_MAX_CH fall through to the reference's CPU forward (host
- * code choosing its own CPU implementation -- the GPU library itself has no CPU path).
+ * Channel counts above VAMD_MAX_CH are refused with OV_EIMPL (see mapping0_forward_vamd); errors
+ * travel as OV_* return codes like everywhere else in libvorbis -- nothing is printed.
  */
-#include <stdio.h>
 #define mapping0_exportbundle mapping0_exportbundle_cpu
 #include "mapping0.c" /* the reference's lib/mapping0.c, found through -I$(REF)/lib */
 #undef mapping0_exportbundle
@@ -41,59 +40,90 @@ extern long vamd_pack_setup(vorbis_dsp_state *vd, void *dst, long cap);
  * envelope_lookup (private_state.ve, lib/block.c:304): it is allocated by
  * vorbis_analysis_init and handed to _ve_envelope_clear() by vorbis_dsp_clear()
  * (lib/block.c:325-328), which is where envelope_vamd.c releases the entry -- so an entry
- * never outlives its stream even though no reference file is edited. */
-#define VAMD_MAX_STATES 64
-static struct {
-  const void *vd; /* key: private_state.ve */
+ * never outlives its stream even though no reference file is edited.
+ *
+ * libvorbis lets independent vorbis_dsp_states live on different threads, so the table is
+ * guarded by a mutex, grows on demand, and holds POINTERS to heap entries: an entry's
+ * address (its detector state is handed out by pointer) stays put while the table moves.
+ * One state is still used by one thread at a time, as libvorbis itself requires. */
+#include <pthread.h>
+typedef struct vamd_entry {
+  const void *key; /* private_state.ve */
   vamd_ctx *ctx;
   vamd_envelope_state env; /* the block-switching detector's running state (envelope_vamd.c) */
-} vamd_states[VAMD_MAX_STATES];
+} vamd_entry;
+static pthread_mutex_t vamd_lock = PTHREAD_MUTEX_INITIALIZER;
+static vamd_entry **vamd_table = NULL;
+static int vamd_count = 0, vamd_cap = 0;
 
 static const void *vamd_key(vorbis_dsp_state *vd) { return ((private_state *)vd->backend_state)->ve; }
 
-vamd_ctx *vamd_ctx_for(vorbis_dsp_state *state) {
-  const void *vd = vamd_key(state);
+/* the entry of `state`, created (context and all) on first use; NULL if the GPU side cannot be set up */
+static vamd_entry *vamd_entry_for(vorbis_dsp_state *state) {
+  const void *key = vamd_key(state);
+  vamd_entry *e = NULL;
   int i;
-  if (!vd) return NULL;
-  for (i = 0; i < VAMD_MAX_STATES; i++)
-    if (vamd_states[i].vd == vd) return vamd_states[i].ctx;
-  for (i = 0; i < VAMD_MAX_STATES; i++)
-    if (!vamd_states[i].vd) {
-      long need = vamd_pack_setup(state, NULL, 0);
-      void *blob;
-      vamd_ctx *ctx = NULL;
-      if (need < 0) return NULL;
-      blob = _ogg_malloc(need);
-      if (vamd_pack_setup(state, blob, need) != need || vamd_create(&ctx, blob, (size_t)need, -1) != VAMD_OK)
-        ctx = NULL;
-      _ogg_free(blob);
-      if (ctx) {
-        vamd_states[i].vd = vd;
-        vamd_states[i].ctx = ctx;
-        memset(&vamd_states[i].env, 0, sizeof(vamd_states[i].env)); /* fresh stream, lib/envelope.c:71 */
-      }
-      return ctx;
+  if (!key) return NULL;
+  pthread_mutex_lock(&vamd_lock);
+  for (i = 0; i < vamd_count; i++)
+    if (vamd_table[i]->key == key) {
+      e = vamd_table[i];
+      break;
     }
-  return NULL;
+  if (!e) {
+    /* (held across vamd_create: two threads opening encoders at once serialise here, once per stream) */
+    long need = vamd_pack_setup(state, NULL, 0);
+    if (need >= 0) {
+      void *blob = _ogg_malloc(need);
+      vamd_ctx *ctx = NULL;
+      if (blob && vamd_pack_setup(state, blob, need) == need && vamd_create(&ctx, blob, (size_t)need, -1) == VAMD_OK) {
+        if (vamd_count == vamd_cap) {
+          int ncap = vamd_cap ? 2 * vamd_cap : 16;
+          vamd_entry **nt = _ogg_realloc(vamd_table, ncap * sizeof(*nt));
+          if (nt) vamd_table = nt, vamd_cap = ncap;
+        }
+        if (vamd_count < vamd_cap && (e = _ogg_calloc(1, sizeof(*e)))) { /* env all-zero: a fresh stream, lib/envelope.c:71 */
+          e->key = key;
+          e->ctx = ctx;
+          vamd_table[vamd_count++] = e;
+        } else {
+          vamd_destroy(ctx);
+        }
+      }
+      if (blob) _ogg_free(blob);
+    }
+  }
+  pthread_mutex_unlock(&vamd_lock);
+  return e;
+}
+
+vamd_ctx *vamd_ctx_for(vorbis_dsp_state *state) {
+  vamd_entry *e = vamd_entry_for(state);
+  return e ? e->ctx : NULL;
 }
 
 vamd_envelope_state *vamd_envelope_state_for(vorbis_dsp_state *state) {
-  int i;
-  if (!vamd_ctx_for(state)) return NULL;
-  for (i = 0; i < VAMD_MAX_STATES; i++)
-    if (vamd_states[i].vd == vamd_key(state)) return &vamd_states[i].env;
-  return NULL;
+  vamd_entry *e = vamd_entry_for(state);
+  return e ? &e->env : NULL;
 }
 
 /* called by _ve_envelope_clear() (envelope_vamd.c) with the envelope_lookup being torn down */
 void vamd_release_key(const void *key) {
+  vamd_entry *e = NULL;
   int i;
-  for (i = 0; i < VAMD_MAX_STATES; i++)
-    if (key && vamd_states[i].vd == key) {
-      vamd_destroy(vamd_states[i].ctx);
-      vamd_states[i].vd = NULL;
-      vamd_states[i].ctx = NULL;
+  if (!key) return;
+  pthread_mutex_lock(&vamd_lock);
+  for (i = 0; i < vamd_count; i++)
+    if (vamd_table[i]->key == key) {
+      e = vamd_table[i];
+      vamd_table[i] = vamd_table[--vamd_count];
+      break;
     }
+  pthread_mutex_unlock(&vamd_lock);
+  if (e) {
+    vamd_destroy(e->ctx);
+    _ogg_free(e);
+  }
 }
 
 
@@ -163,7 +193,16 @@ static int mapping0_forward_vamd(vorbis_block *vb) {
   float ampmax_out;
   int k, ret, pkcap;
 
-  if (ch > VAMD_MAX_CH) return mapping0_forward(vb); /* more than 8 channels: the host's own CPU code */
+  /* more than VAMD_MAX_CH (8) channels -- no layout Vorbis I assigns a channel order to -- is outside the GPU
+     path.  That is an error here (OV_EIMPL out of vorbis_analysis()), not a quiet detour: a maintainer who wants
+     such streams on the host's own mapping0_forward says so at build time. */
+  if (ch > VAMD_MAX_CH) {
+#ifdef VAMD_HOST_FORWARD_ABOVE_MAX_CH
+    return mapping0_forward(vb);
+#else
+    return OV_EIMPL;
+#endif
+  }
   ctx = vamd_ctx_for(vd);
   if (!ctx) return OV_EFAULT; /* no silent fallback: a missing GPU is an error */
 
@@ -178,10 +217,7 @@ static int mapping0_forward_vamd(vorbis_block *vb) {
     int32_t *bits = _vorbis_block_alloc(vb, nk * sizeof(*bits));
     ret = vamd_encode_block(ctx, (const float *const *)vb->pcm, vb->lW, vb->W, vb->nW, vbi->blocktype, vbi->ampmax,
                             managed, &ampmax_out, packets, pkcap, bits);
-    if (ret) {
-      fprintf(stderr, "vorbis_amd: block encode failed (%d): %s\n", ret, vamd_last_error(ctx));
-      return ret;
-    }
+    if (ret) return ret; /* an OV_* code, out through vorbis_analysis(); the text stays with vamd_last_error(ctx) */
     vbi->ampmax = ampmax_out; /* lib/mapping0.c:576 */
     for (k = 0; k < nk; k++) {
       if (bits[k] > 8 * pkcap) return OV_EFAULT; /* cannot happen: pkcap is the worst case */
@@ -206,10 +242,7 @@ static int mapping0_forward_vamd(vorbis_block *vb) {
   else
     ret = vamd_analyze_block(ctx, (const float *const *)vb->pcm, vb->lW, vb->W, vb->nW, vbi->blocktype, vbi->ampmax,
                              mdct, NULL, posts, post_valid, iwork, nonzero, &ampmax_out);
-  if (ret) {
-    fprintf(stderr, "vorbis_amd: block analysis failed (%d): %s\n", ret, vamd_last_error(ctx));
-    return ret;
-  }
+  if (ret) return ret;
   vbi->ampmax = ampmax_out; /* lib/mapping0.c:576 */
   for (k = 0; k < nk; k++) {
     ret = vamd_write_packet(vb, managed ? k : PACKETBLOBS / 2, posts + k * ch * VAMD_POSTS_STRIDE, post_valid + k * ch,

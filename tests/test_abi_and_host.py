@@ -2,6 +2,7 @@
 declares; host-side validation of setup blobs; the product never falls back to a CPU path; the
 N>1 sharding/broadcast logic over gloo with world_size 2."""
 import ctypes as C
+import json
 import os
 import re
 import subprocess
@@ -50,6 +51,88 @@ def test_create_rejects_bad_blobs_without_touching_the_gpu():
     assert not h.value
 
 
+def _header_layout():
+    """Byte offsets inside vamd_setup_header, read off the C header with a tiny compiled probe (no hand-kept copy)."""
+    import tempfile
+    src = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "vamd_setup.h"
+int main(void) {
+  printf("total_bytes %zu\nxform0_off_trig %zu\nxform1_off_bitrev %zu\nxform1_log2n %zu\npsy2_off_octave %zu\npsy2_off_bark %zu\n"
+         "floor1_hineighbor %zu\nfloor1_postlist %zu\nres1_end %zu\n",
+         offsetof(vamd_setup_header, total_bytes), offsetof(vamd_setup_header, xform[0].off_mdct_trig),
+         offsetof(vamd_setup_header, xform[1].off_mdct_bitrev), offsetof(vamd_setup_header, xform[1].log2n),
+         offsetof(vamd_setup_header, psy[2].off_octave), offsetof(vamd_setup_header, psy[2].off_bark),
+         offsetof(vamd_setup_header, mode[1].floor[0].hineighbor), offsetof(vamd_setup_header, mode[1].floor[0].postlist),
+         offsetof(vamd_setup_header, res[1][0].end));
+  return 0;
+}'''
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "p.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I" + os.path.join(ROOT, "include"), os.path.join(d, "p.c"), "-o", os.path.join(d, "p")])
+        out = subprocess.check_output([os.path.join(d, "p")], text=True)
+    return {ln.split()[0]: int(ln.split()[1]) for ln in out.splitlines()}
+
+
+def test_create_rejects_truncated_stale_and_corrupt_tables():
+    """Every table a kernel walks or indexes through is bounds- and range-checked at vamd_create(): a truncated,
+    stale or bit-flipped blob comes back as OV_EINVAL instead of reading out of bounds on the device."""
+    L = C.CDLL(LIB)
+    L.vamd_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_size_t, C.c_int]
+    h = C.c_void_p()
+    good = np.fromfile(os.path.join(ROOT, "vorbis_amd", "data", "setup_44k_stereo_q4.bin"), dtype=np.uint8)
+    off = _header_layout()
+
+    def create(b):
+        return L.vamd_create(C.byref(h), b.ctypes.data_as(C.c_void_p), b.size, -1)
+
+    def put32(b, at, v):
+        b[at:at + 4] = np.frombuffer(np.int32(v).tobytes(), np.uint8)
+
+    def get32(b, at):
+        return int(np.frombuffer(b[at:at + 4].tobytes(), np.int32)[0])
+
+    # truncated behind the header: total_bytes still claims the full size
+    assert create(good[:good.size // 2].copy()) == -131
+    # total_bytes smaller than the header itself
+    b = good.copy(); put32(b, off["total_bytes"], 64)
+    assert create(b) == -131
+    # transform tables pointing past the end / log2n not matching n
+    b = good.copy(); put32(b, off["xform0_off_trig"], good.size - 16)
+    assert create(b) == -131
+    b = good.copy(); put32(b, off["xform1_log2n"], 10)
+    assert create(b) == -131
+    # a bit-reverse entry that would gather outside the MDCT work vector
+    b = good.copy(); put32(b, get32(good, off["xform1_off_bitrev"]) + 12, 5000)
+    assert create(b) == -131
+    # octave[] outside the seed vector, bark[] window beyond the block
+    b = good.copy(); put32(b, get32(good, off["psy2_off_octave"]) + 4 * 700, 1 << 20)
+    assert create(b) == -131
+    b = good.copy(); put32(b, get32(good, off["psy2_off_bark"]) + 4 * 100, (5 << 16) | 60000)
+    assert create(b) == -131
+    # floor: a neighbour index that is not an earlier post, a post beyond the fit range
+    b = good.copy(); put32(b, off["floor1_hineighbor"] + 4 * 3, 40)
+    assert create(b) == -131
+    b = good.copy(); put32(b, off["floor1_postlist"] + 4 * 5, 99999)
+    assert create(b) == -131
+    # residue range beyond the interleaved bundle
+    b = good.copy(); put32(b, off["res1_end"], 1 << 20)
+    assert create(b) == -131
+    # ... and random single-byte corruption never crashes the host-side validation
+    rng = np.random.default_rng(5)
+    for _ in range(300):
+        b = good.copy()
+        b[rng.integers(0, 6000)] ^= 1 << rng.integers(0, 8)      # somewhere in the header's tables
+        r = create(b)                                            # a flip in a value nothing indexes through may pass:
+        assert r in (0, -131, -130, -134, -129)                  # then it is a context (GPU box) or EFAULT (no GPU)
+        if r == 0:
+            L.vamd_destroy.argtypes = [C.c_void_p]
+            L.vamd_destroy(h)
+            h = C.c_void_p()
+    assert not h.value
+
+
 def test_no_cpu_fallback():
     """Without a GPU the product raises; it must never quietly compute on the host."""
     import torch
@@ -75,36 +158,90 @@ def test_derived_tables_match_reference_walks():
     Emul(blob)  # build_image + derive run inside emul_open; golden/oracle tests cover the values
 
 
-WORKER = r'''
+WORKER = r"""
 import os, sys
 sys.path.insert(0, %(root)r)
 import numpy as np, torch, torch.distributed as dist
-from tests.sharding import shard_range, broadcast_blob
-dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
-rank, world = dist.get_rank(), dist.get_world_size()
+from vorbis_amd import sharding
+rank, world, dev = sharding.init_from_env("gloo", use_cuda=False)
 blob = np.fromfile(os.path.join(%(root)r, "vorbis_amd", "data", "setup_44k_stereo_q4.bin"), dtype=np.uint8)
-got = broadcast_blob(blob if rank == 0 else None, torch.device("cpu"))
+got = sharding.broadcast_blob(blob if rank == 0 else None, dev)
 assert np.array_equal(got, blob)
 total = 1000003
-lo, hi = shard_range(total, rank, world)
-cnt = torch.tensor([hi - lo], dtype=torch.int64)
-dist.all_reduce(cnt)
-assert int(cnt.item()) == total
+lo, hi = sharding.shard_range(total, rank, world)
+assert sharding.sum_over_ranks(hi - lo, dev) == total
 edges = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
 dist.all_gather(edges, torch.tensor([lo, hi], dtype=torch.int64))
 for a, b in zip(edges[:-1], edges[1:]):
     assert int(a[1]) == int(b[0])
 assert int(edges[0][0]) == 0 and int(edges[-1][1]) == total
-dist.destroy_process_group()
+assert sharding.max_over_ranks(1.0 + rank, dev) == float(world)
+sharding.finish()
 print("rank", rank, "ok")
-'''
+"""
+
+
+def _torchrun(script, port, timeout=300):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                          env=env, capture_output=True, text=True, timeout=timeout)
 
 
 def test_two_rank_sharding_and_table_broadcast_gloo(tmp_path):
+    """vorbis_amd/sharding.py -- the module bench.py runs on -- over gloo with two ranks."""
     script = tmp_path / "worker.py"
     script.write_text(WORKER % {"root": ROOT})
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29617")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29617", str(script)],
-                       env=env, capture_output=True, text=True, timeout=300)
+    r = _torchrun(script, 29617)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+# bench.main()'s own distributed branch (process group from the environment, blob broadcast, barriers around the
+# timed region, max-over-ranks, the parity sample's sums, JSON assembly on rank 0) with only the GPU work replaced:
+# the stub runner lives HERE, bench.py has no dry-run path of its own.
+BENCH_WORKER = r"""
+import os, sys, time, hashlib
+sys.path.insert(0, @ROOT@)
+import numpy as np
+import bench
+
+class StubRunner:
+    def __init__(self, a, blob, dev, rank, world):
+        from vorbis_amd import sharding
+        ref = np.fromfile(os.path.join(@ROOT@, "vorbis_amd", "data", "setup_%s.bin" % a.setup), dtype=np.uint8)
+        assert np.array_equal(np.asarray(blob), ref), "rank %d received a different setup blob" % rank
+        nb = a.blocks or 131072
+        self.lo, self.hi = sharding.shard_range(nb * world, rank, world)
+        self.units, self.unit_name, self.rank, self.steps_run = self.hi - self.lo, "stereo blocks/s", rank, 0
+    def step(self):
+        time.sleep(0.01 * (1 + self.rank))   # rank 1 is the slow one: the reported time must be ITS time
+        self.steps_run += 1
+    def sync(self): pass
+    def timed_begin(self): self.t0 = self.steps_run
+    def timed_end(self): self.timed = self.steps_run - self.t0
+    def stage_ms(self, steps):
+        assert self.timed == steps
+        return {"transform": 1.0, "noisemask": 2.0}
+    def parity_sample(self, count): return count, 0, "stub"
+    def workload_text(self): return "rank-logic rehearsal (no GPU work)"
+
+rc = bench.main(["--gpus", "2", "--steps", "5", "--warmup", "1", "--backend", "gloo", "--blocks", "1000"], make_runner=StubRunner)
+sys.exit(rc)
+"""
+
+
+def test_bench_distributed_branch_runs_under_gloo(tmp_path):
+    script = tmp_path / "bench_worker.py"
+    script.write_text(BENCH_WORKER.replace("@ROOT@", repr(ROOT)))
+    r = _torchrun(script, 29619)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout          # rank 0 alone prints, one line
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 5 and line["scaling"] == "weak"
+    assert line["config"]["blocks_per_gpu"] == 1000
+    assert line["ms_per_step"] >= 19.0        # the slow rank sleeps 20 ms per step: max over ranks, not rank 0's 10 ms
+    assert abs(line["value"] - 2 * 1000 * 5 / (line["ms_per_step"] * 5e-3)) < 1e-6 * line["value"]
+    assert line["parity_sample"] == {"blocks": 256, "mismatches": 0, "checker": "stub",
+                                     "compared": line["parity_sample"]["compared"]}
+    assert "roofline" in line and line["roofline"]["kernels_ms_per_step"] == {"transform": 1.0, "noisemask": 2.0}

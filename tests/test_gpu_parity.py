@@ -238,3 +238,45 @@ def test_argument_errors(torch_mod):
     assert ei.value.code == -131  # OV_EINVAL
     with pytest.raises(vorbis_amd.VamdError):
         an.analyze(pcm, level=7, want=("mdct_raw",))
+
+
+def test_context_on_second_device_while_first_is_current():
+    """A vamd_ctx belongs to the device it was created on: every entry point switches to it and puts the caller's
+    device back (vamd_create used to move the caller; later calls ran on whatever was current)."""
+    import torch
+    import vorbis_amd
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    torch.cuda.set_device(0)
+    an = vorbis_amd.Analyzer(vorbis_amd.default_setup_blob("44k_stereo_q4"), device=1)
+    assert torch.cuda.current_device() == 0
+    rng = np.random.default_rng(3)
+    pcm = (rng.random((4, 2, 2048), dtype=np.float32) - 0.5).astype(np.float32)
+    outs = an.analyze(torch.from_numpy(pcm).to("cuda:1"))
+    torch.cuda.synchronize(1)
+    assert torch.cuda.current_device() == 0
+    assert all(v.device.index == 1 for v in outs.values())
+    chk = checker.Checker("44k_stereo_q4")
+    for b in range(4):
+        assert checker.compare_block(chk.tap_block(pcm[b]), {k: v[b].cpu().numpy() for k, v in outs.items()}, an.posts[1]) == 0
+    with pytest.raises(ValueError):
+        an.analyze(torch.from_numpy(pcm).to("cuda:0"))   # a tensor on the wrong device never reaches the kernels
+    an.close()
+
+
+def test_argument_checks_raise_value_errors():
+    import torch
+    import vorbis_amd
+    an = vorbis_amd.Analyzer(vorbis_amd.default_setup_blob("44k_stereo_q4"), 0)
+    good = torch.zeros((2, 2, 2048), device="cuda")
+    with pytest.raises(ValueError):
+        an.analyze(good.double())
+    with pytest.raises(ValueError):
+        an.analyze(good[:, :, ::2])
+    with pytest.raises(ValueError):
+        an.analyze(good.cpu())
+    with pytest.raises(ValueError):
+        an.analyze(good, outs={"mdct": torch.zeros((2, 2, 1024), dtype=torch.int32, device="cuda")})
+    with pytest.raises(ValueError):
+        an.analyze(good, lW=torch.zeros(3, dtype=torch.int32, device="cuda"))
+    an.close()

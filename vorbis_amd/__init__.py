@@ -2,7 +2,7 @@
 numeric path) behind a C ABI (include/vorbis_amd.h).
 
 This package is only plumbing: it loads libvorbis_amd.so (hand-written HIP for gfx950, built by
-`__graft_entry__.build()` / `make -C vorbis_amd/csrc`), hands it device pointers of torch tensors and
+`__graft_entry__.build()`: one hipcc command, see there), hands it device pointers of torch tensors and
 mirrors the C entry points one-to-one.  There is no CPU fallback: without the HIP library, or
 without a GPU, every compute call raises.
 """

@@ -169,6 +169,23 @@ class Analyzer:
     def _dev(self):
         return self.torch.device("cuda", self.device)
 
+    def _need(self, ok, what):
+        """Argument checks that survive `python -O`: raw pointers go to the kernels, so a wrong dtype, device or
+        stride must stop here."""
+        if not ok:
+            raise ValueError("vorbis_amd: " + what)
+
+    def _need_tensor(self, v, dtype, name, numel=None, shape=None):
+        t = self.torch
+        self._need(t.is_tensor(v), "%s must be a torch tensor" % name)
+        self._need(v.is_cuda and v.device.index == self.device, "%s must live on cuda:%d (it is on %s)" % (name, self.device, v.device))
+        self._need(dtype is None or v.dtype == dtype, "%s must be %s (it is %s)" % (name, dtype, v.dtype))
+        self._need(v.is_contiguous(), "%s must be contiguous" % name)
+        if numel is not None:
+            self._need(v.numel() == numel, "%s must hold %d elements (it holds %d)" % (name, numel, v.numel()))
+        if shape is not None:
+            self._need(tuple(v.shape) == tuple(shape), "%s must have shape %s (it has %s)" % (name, tuple(shape), tuple(v.shape)))
+
     def _bind_stream(self):
         s = self.torch.cuda.current_stream(self.device)
         self._check(self.L.vamd_set_stream(self.h, _vp(s.cuda_stream)))
@@ -199,10 +216,13 @@ class Analyzer:
     def mdct_forward(self, W, frames, out=None):
         t = self.torch
         n = self.blocksizes[W]
-        assert frames.is_cuda and frames.dtype == t.float32 and frames.is_contiguous() and frames.shape[-1] == n
+        self._need_tensor(frames, t.float32, "frames")
+        self._need(frames.dim() >= 1 and frames.shape[-1] == n, "frames must end in %d samples" % n)
         nf = frames.numel() // n
         if out is None:
             out = t.empty(frames.shape[:-1] + (n // 2,), dtype=t.float32, device=frames.device)
+        else:
+            self._need_tensor(out, t.float32, "out", numel=nf * (n // 2))
         self._bind_stream()
         self._check(self.L.vamd_mdct_forward_batch(self.h, W, _vp(frames.data_ptr()), _vp(out.data_ptr()), nf))
         return out
@@ -216,7 +236,7 @@ class Analyzer:
             if isinstance(v, (list, tuple, np.ndarray)):   # per-block values from the host
                 v = t.as_tensor(np.asarray(v), dtype=dtype).to(self._dev())
             if t.is_tensor(v):
-                assert v.is_cuda and v.dtype == dtype and v.is_contiguous() and v.numel() == nb, name
+                self._need_tensor(v, dtype, name, numel=nb)
                 keep.append(v)
                 setattr(d, name, _vp(v.data_ptr()))
             else:
@@ -286,11 +306,26 @@ class Analyzer:
         """Bytes the longest possible packet of size class W takes; 0 when packets are not assembled on the GPU."""
         return int(self.L.vamd_packet_capacity(self.h, W))
 
+    _OUT_DTYPES = None
+
+    def _out_dtype(self, k):
+        t = self.torch
+        if k in _FLOAT_OUT or k in ("local_ampmax", "ampmax_out"):
+            return t.float32
+        if k == "res_entries":
+            return t.int16
+        if k == "packets":
+            return t.uint8
+        return t.int32
+
     def _io(self, pcm, outs):
         io = _IO()
         io.pcm = _vp(pcm.data_ptr())
+        nb = pcm.shape[0]
         for k, v in outs.items():
-            assert v.is_cuda and v.is_contiguous()
+            self._need(hasattr(io, k), "unknown output %r" % (k,))
+            self._need_tensor(v, self._out_dtype(k), "outs[%r]" % k)
+            self._need(v.dim() >= 1 and v.shape[0] == nb, "outs[%r] must have one row per block (%d)" % (k, nb))
             setattr(io, k, _vp(v.data_ptr()))
         if "packets" in outs:
             io.packet_stride = outs["packets"].shape[-1]
@@ -305,8 +340,10 @@ class Analyzer:
         """vamd_analyze_batch.  pcm: cuda float32 [nblocks, ch, n].  Returns dict name -> tensor."""
         t = self.torch
         n = self.blocksizes[W]
-        assert pcm.is_cuda and pcm.dtype == t.float32 and pcm.is_contiguous()
-        assert pcm.dim() == 3 and pcm.shape[1] == self.channels and pcm.shape[2] == n, tuple(pcm.shape)
+        self._need(W in (0, 1), "W must be 0 or 1")
+        self._need_tensor(pcm, t.float32, "pcm")
+        self._need(pcm.dim() == 3 and pcm.shape[1] == self.channels and pcm.shape[2] == n,
+                   "pcm must be [blocks, %d, %d] (it is %s)" % (self.channels, n, tuple(pcm.shape)))
         nb = pcm.shape[0]
         if outs is None:
             outs = self.alloc_outputs(W, nb, self._DEFAULT_WANT[level] if want is None else want)
@@ -320,8 +357,10 @@ class Analyzer:
     def analyze_stream(self, pcm, ampmax_state, W=1, lW=1, nW=1, blocktype=BLOCKTYPE_LONG, want=None, outs=None):
         """vamd_analyze_stream.  Returns (outs, new ampmax_state)."""
         n = self.blocksizes[W]
+        self._need_tensor(pcm, self.torch.float32, "pcm")
+        self._need(pcm.dim() == 3 and tuple(pcm.shape[1:]) == (self.channels, n),
+                   "pcm must be [blocks, %d, %d] (it is %s)" % (self.channels, n, tuple(pcm.shape)))
         nb = pcm.shape[0]
-        assert pcm.is_cuda and pcm.is_contiguous() and pcm.shape[1:] == (self.channels, n)
         if outs is None:
             outs = self.alloc_outputs(W, nb, self._DEFAULT_WANT[LEVEL_FULL] if want is None else want)
         keep = []
@@ -347,7 +386,7 @@ class Analyzer:
             sel = idx[W]
             nb = len(sel)
             n = self.blocksizes[W]
-            pcm = t.from_numpy(np.stack([b["pcm"] for b in sel]).astype(np.float32)).cuda() if nb else \
+            pcm = t.from_numpy(np.stack([b["pcm"] for b in sel]).astype(np.float32)).to(self._dev()) if nb else \
                 t.empty((0, self.channels, n), device=self._dev())
             dv = lambda k: t.tensor([b[k] for b in sel], dtype=t.int32, device=self._dev()) if nb else 0  # noqa: E731
             outs[W] = self.alloc_outputs(W, nb, want)
@@ -384,7 +423,7 @@ class Analyzer:
             sel = idx[W]
             nb = len(sel)
             n = self.blocksizes[W]
-            pcm = t.from_numpy(np.stack([b["pcm"] for b in sel]).astype(np.float32)).cuda() if nb else \
+            pcm = t.from_numpy(np.stack([b["pcm"] for b in sel]).astype(np.float32)).to(self._dev()) if nb else \
                 t.empty((0, self.channels, n), device=self._dev())
             dv = lambda k: t.tensor([b[k] for b in sel], dtype=t.int32, device=self._dev()) if nb else 0  # noqa: E731
             outs[W] = self.alloc_outputs(W, nb, want)
@@ -417,7 +456,7 @@ class Analyzer:
         ch, n = self.channels, self.blocksizes[W]
         n2 = n // 2
         pcm = np.ascontiguousarray(pcm, dtype=np.float32)
-        assert pcm.shape == (ch, n)
+        self._need(pcm.shape == (ch, n), "pcm must be [%d][%d] (it is %s)" % (ch, n, pcm.shape))
         ptrs = (_vp * ch)(*[_vp(pcm[i].ctypes.data) for i in range(ch)])
         o = dict(mdct=np.empty((ch, n2), np.float32), logmask=np.empty((ch, n2), np.float32),
                  posts=np.empty((ch, POSTS_STRIDE), np.int32), post_valid=np.empty(ch, np.int32),
@@ -451,7 +490,8 @@ class Analyzer:
         [nb,15,ch], `m_iwork` [nb,15,ch,n/2] (+ `m_res_class`, `m_res_entries`, `m_res_count` with residue=True)."""
         t = self.torch
         n = self.blocksizes[W]
-        assert pcm.is_cuda and pcm.dtype == t.float32 and pcm.is_contiguous() and pcm.shape[1:] == (self.channels, n)
+        self._need_tensor(pcm, t.float32, "pcm")
+        self._need(pcm.dim() == 3 and tuple(pcm.shape[1:]) == (self.channels, n), "pcm must be [blocks, %d, %d]" % (self.channels, n))
         nb, ch, n2, dev = pcm.shape[0], self.channels, n // 2, pcm.device
         outs = self.alloc_outputs(W, nb, ("mdct", "logmask", "ampmax_out"))
         keep = []
@@ -485,7 +525,7 @@ class Analyzer:
         ch, n = self.channels, self.blocksizes[W]
         n2 = n // 2
         pcm = np.ascontiguousarray(pcm, dtype=np.float32)
-        assert pcm.shape == (ch, n)
+        self._need(pcm.shape == (ch, n), "pcm must be [%d][%d] (it is %s)" % (ch, n, pcm.shape))
         ptrs = (_vp * ch)(*[_vp(pcm[i].ctypes.data) for i in range(ch)])
         o = dict(mdct=np.empty((ch, n2), np.float32), m_posts=np.empty((PACKETBLOBS, ch, POSTS_STRIDE), np.int32),
                  m_post_valid=np.empty((PACKETBLOBS, ch), np.int32), m_iwork=np.empty((PACKETBLOBS, ch, n2), np.int32),
@@ -513,7 +553,7 @@ class Analyzer:
         """vamd_encode_block: host numpy pcm[ch][n] in; (list of 1 or 15 packets as bytes, ampmax_out) out."""
         ch, n = self.channels, self.blocksizes[W]
         pcm = np.ascontiguousarray(pcm, dtype=np.float32)
-        assert pcm.shape == (ch, n)
+        self._need(pcm.shape == (ch, n), "pcm must be [%d][%d] (it is %s)" % (ch, n, pcm.shape))
         ptrs = (_vp * ch)(*[_vp(pcm[i].ctypes.data) for i in range(ch)])
         nk, cap = (PACKETBLOBS if managed else 1), self.packet_capacity(W)
         pk, bits = np.zeros((nk, max(cap, 4)), np.uint8), np.zeros(nk, np.int32)
@@ -536,7 +576,8 @@ class Analyzer:
         ch = self.channels
         win, step = self.envelope_geometry()
         pcm = np.ascontiguousarray(pcm, dtype=np.float32)
-        assert pcm.ndim == 2 and pcm.shape[0] == ch and pcm.shape[1] >= (nsteps - 1) * step + win
+        self._need(pcm.ndim == 2 and pcm.shape[0] == ch and pcm.shape[1] >= (nsteps - 1) * step + win,
+                   "pcm must be [%d][>= %d samples]" % (ch, (nsteps - 1) * step + win))
         if state is None:
             state = EnvelopeState()
         ret = np.zeros(nsteps, np.uint8)
@@ -550,11 +591,12 @@ class Analyzer:
         [nstreams][sizeof(vamd_envelope_state)] (zeros = fresh streams), updated in place.
         Returns (ret cuda uint8 [nstreams][nsteps], states)."""
         t = self.torch
-        assert pcm.is_cuda and pcm.dtype == t.float32 and pcm.is_contiguous() and pcm.dim() == 3
+        self._need_tensor(pcm, t.float32, "pcm")
+        self._need(pcm.dim() == 3, "pcm must be [streams, channels, samples]")
         ns, ch, ln = pcm.shape
-        assert ch == self.channels
+        self._need(ch == self.channels, "pcm must have %d channels" % self.channels)
         win, step = self.envelope_geometry()
-        assert ln >= (nsteps - 1) * step + win
+        self._need(ln >= (nsteps - 1) * step + win, "streams too short for %d steps" % nsteps)
         if states is None:
             states = t.zeros((ns, C.sizeof(EnvelopeState)), dtype=t.uint8, device=pcm.device)
         if ret is None:

@@ -53,8 +53,8 @@ inline int build_image(const void *blob_v, size_t bytes, std::vector<unsigned ch
     *err = "setup blob: version mismatch";
     return VAMD_EVERSION;
   }
-  if (h.total_bytes > bytes) {
-    *err = "setup blob: total_bytes exceeds buffer";
+  if (h.total_bytes > bytes || h.total_bytes < sizeof(vamd_setup_header)) {
+    *err = "setup blob: total_bytes exceeds the buffer or is shorter than the header";
     return VAMD_EINVAL;
   }
   if (h.channels < 1 || h.channels > VAMD_MAX_CH) {
@@ -71,9 +71,41 @@ inline int build_image(const void *blob_v, size_t bytes, std::vector<unsigned ch
       *err = "block sizes above 4096 are not covered";
       return VAMD_EIMPL;
     }
+    if ((1 << x.log2n) != x.n) {
+      *err = "transform table: log2n does not match n";
+      return VAMD_EINVAL;
+    }
+    {
+      const uint64_t need[] = {(uint64_t)x.off_mdct_trig + 4ull * (x.n + x.n / 4), (uint64_t)x.off_mdct_bitrev + 4ull * (x.n / 4),
+                               (uint64_t)x.off_fft_wa + 8ull * x.n, (uint64_t)x.off_window + 4ull * (x.n / 2)};
+      for (uint64_t e : need)
+        if (e > h.total_bytes) {
+          *err = "setup blob: transform table offset out of range";
+          return VAMD_EINVAL;
+        }
+      if ((x.off_mdct_trig | x.off_mdct_bitrev | x.off_fft_wa | x.off_window) & 3) {
+        *err = "setup blob: transform table misaligned";
+        return VAMD_EINVAL;
+      }
+      // mdct_bitreverse gathers through this table (lib/mdct.c:346-394): entries index the n/2 work vector
+      const int32_t *br = (const int32_t *)(blob + x.off_mdct_bitrev);
+      for (int i = 0; i < x.n / 4; i++)
+        if (br[i] < 0 || br[i] > x.n / 2 - 2 || (br[i] & 1)) {
+          *err = "setup blob: MDCT bit-reverse entry out of range";
+          return VAMD_EINVAL;
+        }
+    }
     if (x.fft_nf < 1 || x.fft_nf > 8) {
       *err = "unsupported FFT factorisation";
       return VAMD_EIMPL;
+    }
+    {
+      long prod = 1;
+      for (int i = 0; i < x.fft_nf; i++) prod *= x.fft_fac[i];
+      if (prod != x.n) {
+        *err = "FFT factors do not multiply to the block size";
+        return VAMD_EINVAL;
+      }
     }
     for (int i = 0; i < x.fft_nf; i++)
       if (x.fft_fac[i] != 2 && x.fft_fac[i] != 4) {
@@ -101,8 +133,22 @@ inline int build_image(const void *blob_v, size_t bytes, std::vector<unsigned ch
         *err = "floor1 post count out of range";
         return VAMD_EIMPL;
       }
-      if (m.floor[sm].look_n > x.n / 2) {
+      if (m.floor[sm].look_n > x.n / 2 || m.floor[sm].look_n < 1) {
         *err = "floor1 range exceeds the block";
+        return VAMD_EINVAL;
+      }
+      // the fit walks these as indices (lib/floor1.c:576-729): posts inside the range, index maps inside the posts
+      const vamd_floor1_tab &f = m.floor[sm];
+      bool ok = f.mult >= 1 && f.mult <= 4 && f.quant_q >= 1 && f.quant_q <= 256;
+      for (int i = 0; ok && i < f.posts; i++)
+        ok = f.postlist[i] >= 0 && f.postlist[i] <= f.look_n && f.sorted_index[i] >= 0 && f.sorted_index[i] <= f.look_n &&
+             f.forward_index[i] >= 0 && f.forward_index[i] < f.posts && f.reverse_index[i] >= 0 && f.reverse_index[i] < f.posts;
+      for (int i = 0; ok && i + 1 < f.posts; i++) ok = f.sorted_index[i] < f.sorted_index[i + 1];
+      for (int i = 0; ok && i + 2 < f.posts; i++)  // neighbours of post i+2: earlier posts only (what makes the level order valid)
+        ok = f.hineighbor[i] >= 0 && f.hineighbor[i] < i + 2 && f.loneighbor[i] >= 0 && f.loneighbor[i] < i + 2 &&
+             f.postlist[f.loneighbor[i]] < f.postlist[f.hineighbor[i]];
+      if (!ok) {
+        *err = "setup blob: floor1 post / neighbour tables out of range";
         return VAMD_EINVAL;
       }
     }
@@ -128,6 +174,48 @@ inline int build_image(const void *blob_v, size_t bytes, std::vector<unsigned ch
     }
     if (t.total_octave_lines < 1 || t.total_octave_lines > 4096) {
       *err = "total_octave_lines out of range";
+      return VAMD_EINVAL;
+    }
+    if ((t.off_ath | t.off_octave | t.off_bark | t.off_noiseoffset | t.off_tonecurves) & 3) {
+      *err = "setup blob: psy table misaligned";
+      return VAMD_EINVAL;
+    }
+    if (t.eighth_octave_lines < 1 || t.eighth_octave_lines > 64 || t.shiftoc < 0 || t.shiftoc > 16) {
+      *err = "psy octave geometry out of range";
+      return VAMD_EINVAL;
+    }
+    // tables the kernels use as indices: octave[] is a non-decreasing line position inside the seed vector
+    // (seed_loop / max_seeds, lib/psy.c:417-545); bark[] packs window edges inside the block or its mirror
+    // (bark_noise_hybridmp, lib/psy.c:606-656)
+    {
+      const int32_t *oc = (const int32_t *)(blob + t.off_octave), *bk = (const int32_t *)(blob + t.off_bark);
+      for (int i = 0; i < t.n; i++) {
+        const long line = (long)oc[i] - t.firstoc;
+        if (line < 0 || line >= t.total_octave_lines || (i && oc[i] < oc[i - 1])) {
+          *err = "setup blob: octave[] entry outside the seed vector";
+          return VAMD_EINVAL;
+        }
+        const int lo = bk[i] >> 16, hi = bk[i] & 0xffff;
+        if (lo <= -32768 + 1 || lo > t.n || hi > 2 * t.n) {
+          *err = "setup blob: bark[] window edge out of range";
+          return VAMD_EINVAL;
+        }
+      }
+      const float *tc = (const float *)(blob + t.off_tonecurves);
+      for (int c = 0; c < VAMD_P_BANDS * VAMD_P_LEVELS; c++) {
+        const float p0 = tc[(size_t)c * (VAMD_EHMER_MAX + 2)], p1 = tc[(size_t)c * (VAMD_EHMER_MAX + 2) + 1];
+        if (!(p0 >= 0.f && p0 <= (float)VAMD_EHMER_MAX && p1 >= 0.f && p1 <= (float)VAMD_EHMER_MAX)) {
+          *err = "setup blob: tone curve fence posts out of range";
+          return VAMD_EINVAL;
+        }
+      }
+    }
+    if (t.normal_p && (t.normal_partition < 1 || t.normal_partition > t.n || t.normal_start < 0)) {
+      *err = "setup blob: noise normalisation partition out of range";
+      return VAMD_EINVAL;
+    }
+    if (t.noisewindowfixed > (1 << 20)) {  // (<= 0: the pass is off; wider than the block: every bin extends nothing)
+      *err = "setup blob: fixed noise window out of range";
       return VAMD_EINVAL;
     }
   }
@@ -199,6 +287,16 @@ inline int build_image(const void *blob_v, size_t bytes, std::vector<unsigned ch
         r.grouping < 1 || r.begin < 0 || r.end < r.begin) {
       *err = "setup blob: residue table out of range";
       return VAMD_EINVAL;
+    }
+    {
+      // the coded range lies inside the submap's bundle (type 2: the channels interleaved; types 0/1: one channel)
+      int bundle = 0;
+      for (int c = 0; c < h.channels; c++) bundle += h.mode[W].chmuxlist[c] == sm;
+      const long span = (long)(h.blocksizes[W] / 2) * (r.type == 2 ? (bundle > 0 ? bundle : 1) : 1);
+      if (r.end > span) {
+        *err = "setup blob: residue range exceeds its bundle";
+        return VAMD_EINVAL;
+      }
     }
     for (int c = 0; c < r.partitions; c++)
       for (int s = 0; s < VAMD_RES_MAXSTAGE; s++)

@@ -650,17 +650,23 @@ struct vamd_ctx {
   bool profile = false;
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
-  std::vector<int> ev_runs;  // number of stages of each recorded run
+  std::vector<int> ev_stage;  // per recorded event: the stage whose interval it closes (VAMD_ST_BEGIN = none)
+  int prof_runs = 0;          // batches recorded since the last vamd_stage_ms()
 };
 
-static void prof_mark(vamd_ctx *c) {
+// stage ids of vamd_stage_ms(); a mark closes the interval of the stage it names (VAMD_ST_BEGIN: opens one)
+enum { VAMD_ST_BEGIN = -1, VAMD_ST_TRANSFORM = 0, VAMD_ST_AMPMAX, VAMD_ST_NOISE, VAMD_ST_TONE, VAMD_ST_FLOOR, VAMD_ST_COUPLE,
+       VAMD_ST_RESIDUE, VAMD_ST_PACK, VAMD_ST_COUNT };
+static void prof_mark(vamd_ctx *c, int stage) {
   if (!c->profile) return;
   if (c->ev_used == c->ev_pool.size()) {
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess) return;
     c->ev_pool.push_back(e);
   }
-  (void)hipEventRecord(c->ev_pool[c->ev_used++], c->stream);
+  (void)hipEventRecord(c->ev_pool[c->ev_used], c->stream);
+  if (c->ev_stage.size() <= c->ev_used) c->ev_stage.resize(c->ev_used + 1);
+  c->ev_stage[c->ev_used++] = stage;
 }
 
 // waves per persistent transform workgroup: as many as fit beside the staged tables
@@ -686,6 +692,22 @@ static int fail(vamd_ctx *c, int code, const char *what, hipError_t e = hipSucce
     hipError_t e__ = (expr);                                          \
     if (e__ != hipSuccess) return fail((c), VAMD_EFAULT, #expr, e__); \
   } while (0)
+
+
+// A context is bound to ONE device (vamd_create).  Every public entry point runs with that device current --
+// workspace allocations, pinned staging, launches and the side stream all belong to it -- and puts the caller's
+// device back on the way out, so a context on GPU 1 works while the caller (or torch) sits on GPU 0.
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceGuard(const vamd_ctx *c) {
+    if (!c) return;
+    if (hipGetDevice(&prev) == hipSuccess && prev != c->device) switched = hipSetDevice(c->device) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
 
 static int ws_get(vamd_ctx *c, int W, int which, size_t bytes, void **out) {
   DevBuf &b = c->ws[W][which];
@@ -717,6 +739,8 @@ int vamd_create(vamd_ctx **out, const void *setup_blob, size_t blob_bytes, int d
     return r;
   }
   hipError_t e = hipSuccess;
+  int caller_device = -1;
+  (void)hipGetDevice(&caller_device);  // put back before returning: creating a context must not move the caller
   if (device >= 0) e = hipSetDevice(device);
   if (e == hipSuccess) e = hipGetDevice(&c->device);
   if (e == hipSuccess) {
@@ -751,16 +775,19 @@ int vamd_create(vamd_ctx **out, const void *setup_blob, size_t blob_bytes, int d
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->side) (void)hipStreamDestroy(c->side);
+    if (caller_device >= 0) (void)hipSetDevice(caller_device);
     delete c;
     return VAMD_EFAULT;
   }
   c->image_bytes = image.size();
   bind_params(image, doff, derived, c->d_image, &c->B);
+  if (caller_device >= 0 && caller_device != c->device) (void)hipSetDevice(caller_device);
   *out = c;
   return VAMD_OK;
 }
 
 void vamd_destroy(vamd_ctx *c) {
+  DeviceGuard dev_guard(c);
   if (!c) return;
   for (int W = 0; W < 2; W++)
     for (int i = 0; i < vamd_ctx::WS_COUNT; i++)
@@ -787,32 +814,30 @@ int vamd_profile(vamd_ctx *c, int enable) {
   if (!c) return VAMD_EINVAL;
   c->profile = enable != 0;
   c->ev_used = 0;
-  c->ev_runs.clear();
+  c->prof_runs = 0;
   return VAMD_OK;
 }
 
 int vamd_stage_ms(vamd_ctx *c, float *ms, int nstages, int *runs) {
+  DeviceGuard dev_guard(c);
   if (!c || !ms || nstages < 1) return VAMD_EINVAL;
   for (int i = 0; i < nstages; i++) ms[i] = 0.f;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  size_t at = 0;
-  int nr = 0;
-  for (int st : c->ev_runs) {
-    for (int i = 0; i < st && i < nstages; i++) {
-      float t = 0.f;
-      HIP_TRY(c, hipEventElapsedTime(&t, c->ev_pool[at + i], c->ev_pool[at + i + 1]));
-      ms[i] += t;
-    }
-    at += st + 1;
-    nr++;
+  for (size_t i = 1; i < c->ev_used; i++) {
+    const int st = c->ev_stage[i];
+    if (st < 0 || st >= nstages) continue;
+    float t = 0.f;
+    HIP_TRY(c, hipEventElapsedTime(&t, c->ev_pool[i - 1], c->ev_pool[i]));
+    ms[st] += t;
   }
-  if (runs) *runs = nr;
+  if (runs) *runs = c->prof_runs;
   c->ev_used = 0;
-  c->ev_runs.clear();
+  c->prof_runs = 0;
   return VAMD_OK;
 }
 
 int vamd_debug_cycles(vamd_ctx *c, int enable, unsigned long long *out80) {
+  DeviceGuard dev_guard(c);
   if (!c) return VAMD_EINVAL;
   if (out80 && c->d_dbg) {
     std::vector<unsigned long long> all(64 * 80);
@@ -884,12 +909,14 @@ static int plan(vamd_ctx *c, int W, long nb, const vamd_batch_io *io, int level,
 }
 
 int vamd_reserve(vamd_ctx *c, int W, long max_blocks) {
+  DeviceGuard dev_guard(c);
   if (!c || (W != 0 && W != 1) || max_blocks < 1) return VAMD_EINVAL;
   WsPlan p;
   return plan(c, W, max_blocks, nullptr, VAMD_LEVEL_FULL, &p);
 }
 
 int vamd_mdct_forward_batch(vamd_ctx *c, int W, const float *in, float *out, long nframes) {
+  DeviceGuard dev_guard(c);
   if (!c || (W != 0 && W != 1) || nframes < 0) return VAMD_EINVAL;
   if (nframes == 0) return VAMD_OK;
   if (!in || !out) return fail(c, VAMD_EINVAL, "null frame buffer");
@@ -943,7 +970,6 @@ struct BatchRun {
   const vamd_batch_io *io;
   ResBufs rb;
   float *couple_state;  // [units][4][ch][n2] or null (alloc_couple_state)
-  int nst;  // stages launched (for vamd_profile)
 };
 
 static int check_packets(vamd_ctx *c, int W, int level, const void *packets, const void *bits, int64_t stride) {
@@ -1012,7 +1038,7 @@ static void launch_transform(vamd_ctx *c, BatchRun *R) {
   const int waves = xf_waves(c, X);
   const long groups = ((long)gcb + waves - 1) / waves;
   const unsigned grid = (unsigned)(groups < c->num_cus ? groups : c->num_cus);
-  prof_mark(c);
+  prof_mark(c, VAMD_ST_BEGIN);
 #define VAMD_GO(LOGN)                                                                                                      \
   hipLaunchKernelGGL(k_transform<LOGN>, dim3(grid), dim3(64 * waves), transform_lds_bytes(X, waves), c->stream, X, R->W, R->d, \
                      ch, (long)gcb, R->io->pcm, R->p.mdct_raw, R->p.logmdct, R->p.logfft, R->p.local)
@@ -1025,7 +1051,7 @@ static void launch_transform(vamd_ctx *c, BatchRun *R) {
     default: VAMD_GO(0);
   }
 #undef VAMD_GO
-  prof_mark(c), R->nst++;
+  prof_mark(c, VAMD_ST_TRANSFORM);
 }
 
 // stages 2..5 (masking, floor, couple); R->d.ampmax_in / p.ampglob must be final
@@ -1040,13 +1066,13 @@ static void launch_residue_pack(vamd_ctx *c, BatchRun *R, hipStream_t s, long un
     hipLaunchKernelGGL(k_residue, dim3((unsigned)units), dim3(64 * (c->B.res[W][sm].bundle * n2 > 4096 ? VAMD_RES_WAVES : 2)),
                        (size_t)c->B.res[W][sm].lds_ints * 4, s, c->B.res[W][sm], cm, sm,
                        c->B.res_cap[W], R->d, ch, n2, iwork, nonzero, rb.cls, rb.entries, rb.count);
-  prof_mark(c), R->nst++;
+  prof_mark(c, VAMD_ST_RESIDUE);
   if (packets) {
     const size_t lds = ((size_t)VAMD_PK_RING + VAMD_POSTS_STRIDE + VAMD_RES_CLASS_STRIDE + 2 * (size_t)c->B.res_off_ints[W]) * 4;
     hipLaunchKernelGGL(k_pack, dim3((unsigned)units), dim3(64), lds, s, c->B.pack[W], c->B.floor[W][0], c->B.floor[W][1],
                        c->B.res[W][0], c->B.res[W][1], cm, c->B.res_cap[W], c->B.res_off_ints[W], R->d, ch, W, nblobs, posts,
                        post_valid, rb.cls, rb.entries, rb.count, (unsigned *)packets, (int)(packet_stride / 4), packet_bits);
-    prof_mark(c), R->nst++;
+    prof_mark(c, VAMD_ST_PACK);
   }
 }
 
@@ -1120,7 +1146,7 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_
       }
 #undef VAMD_GO
     }
-    prof_mark(c), R->nst++;
+    prof_mark(c, VAMD_ST_NOISE);
     if (overlap) s = c->side;
     {
       const int nlp = (nl + 15) & ~15;
@@ -1141,16 +1167,16 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_
       s = c->stream;
       (void)hipStreamWaitEvent(s, c->ev_join, 0);
     }
-    prof_mark(c), R->nst++;
+    prof_mark(c, VAMD_ST_TONE);
   }
   if (level >= VAMD_LEVEL_FULL && M) {
     // bitrate-managed: fifteen candidate packets per block
     const size_t flds = (size_t)((n2 + 15) & ~15) * 2 + sizeof(FloorScratch);
     hipLaunchKernelGGL(k_floor_managed, dim3(gcb), dim3(64), flds, s, P0, P1, c->B.floor[W][0], c->B.floor[W][1], c->B.chmap[W], d, ch, p.noise, p.tone,
                        p.logmdct, p.mdct_raw, p.mdct, R->io->logmask, M->posts, M->post_valid, m_ilogmask, M->nonzero);
-    prof_mark(c), R->nst++;
+    prof_mark(c, VAMD_ST_FLOOR);
     launch_couple(c, R, s, (long)gb * VAMD_PACKETBLOBS, 0, VAMD_PACKETBLOBS, p.mdct, m_ilogmask, M->iwork, M->nonzero);
-    prof_mark(c), R->nst++;
+    prof_mark(c, VAMD_ST_COUPLE);
     if (M->res_entries || M->packets)
       launch_residue_pack(c, R, s, (long)gb * VAMD_PACKETBLOBS, VAMD_PACKETBLOBS, M->posts, M->post_valid, M->iwork, M->nonzero, rb,
                           M->packets, M->packet_stride, M->packet_bits);
@@ -1158,9 +1184,9 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_
     hipLaunchKernelGGL(k_floor, dim3(gcb), dim3(64), (size_t)((n2 + 15) & ~15) * 2 + sizeof(FloorScratch), s, P0, P1,
                        c->B.floor[W][0], c->B.floor[W][1], c->B.chmap[W], d, ch, p.noise, p.tone, p.logmdct, p.mdct_raw, p.mdct,
                        R->io->logmask, p.posts, p.post_valid, p.ilogmask, p.nonzero);
-    prof_mark(c), R->nst++;
+    prof_mark(c, VAMD_ST_FLOOR);
     launch_couple(c, R, s, gb, VAMD_PACKETBLOBS / 2, 1, p.mdct, p.ilogmask, p.iwork, p.nonzero);
-    prof_mark(c), R->nst++;
+    prof_mark(c, VAMD_ST_COUPLE);
     if (R->io && (R->io->res_entries || R->io->packets))
       launch_residue_pack(c, R, s, gb, 1, p.posts, p.post_valid, p.iwork, p.nonzero, rb, R->io->packets, R->io->packet_stride,
                           R->io->packet_bits);
@@ -1197,9 +1223,9 @@ static int run_batch(vamd_ctx *c, const vamd_batch_desc *desc, const vamd_batch_
     hipLaunchKernelGGL(k_ampmax, dim3((unsigned)((R.nb + 255) / 256)), dim3(256), 0, s, R.d, ch, R.nb, R.p.local,
                        R.p.ampglob);
   }
-  prof_mark(c), R.nst++;
+  prof_mark(c, VAMD_ST_AMPMAX);
   launch_rest(c, &R, level, M, m_ilogmask);
-  if (c->profile) c->ev_runs.push_back(R.nst);
+  if (c->profile) c->prof_runs++;
   HIP_TRY(c, hipGetLastError());
   if (stream_mode) {
     // new state = ampmax_out of the last block
@@ -1210,6 +1236,7 @@ static int run_batch(vamd_ctx *c, const vamd_batch_desc *desc, const vamd_batch_
 }
 
 int vamd_analyze_batch(vamd_ctx *c, const vamd_batch_desc *desc, const vamd_batch_io *io, int level) {
+  DeviceGuard dev_guard(c);
   int r = check_desc(c, desc, io);
   if (r) return r;
   if (level < VAMD_LEVEL_TRANSFORM || level > VAMD_LEVEL_FULL) return fail(c, VAMD_EINVAL, "bad level");
@@ -1218,6 +1245,7 @@ int vamd_analyze_batch(vamd_ctx *c, const vamd_batch_desc *desc, const vamd_batc
 
 int vamd_analyze_batch_managed(vamd_ctx *c, const vamd_batch_desc *desc, const vamd_batch_io *io,
                                const vamd_managed_io *m) {
+  DeviceGuard dev_guard(c);
   int r = check_desc(c, desc, io);
   if (r) return r;
   if (!m || !m->posts || !m->post_valid || !m->iwork || !m->nonzero)
@@ -1245,6 +1273,7 @@ int vamd_analyze_block_managed(vamd_ctx *c, const float *const *pcm, int lW, int
                                float ampmax_in, float *mdct, float *ampmax_out, int32_t *posts,
                                int32_t *post_valid, int32_t *iwork, int32_t *nonzero, int32_t *res_class,
                                uint16_t *res_entries, int32_t *res_count) {
+  DeviceGuard dev_guard(c);
   if (!c) return VAMD_EINVAL;
   if (!pcm || (W != 0 && W != 1)) return fail(c, VAMD_EINVAL, "bad pcm / W");
   const bool want_res = res_class || res_entries || res_count;
@@ -1319,6 +1348,7 @@ int vamd_analyze_block_managed(vamd_ctx *c, const float *const *pcm, int lW, int
 }
 
 int vamd_analyze_stream(vamd_ctx *c, const vamd_batch_desc *desc, const vamd_batch_io *io, float *ampmax_state) {
+  DeviceGuard dev_guard(c);
   int r = check_desc(c, desc, io);
   if (r) return r;
   if (!ampmax_state) return fail(c, VAMD_EINVAL, "null ampmax_state");
@@ -1360,10 +1390,12 @@ static int run_streams_mixed(vamd_ctx *c, const vamd_batch_desc *desc_short, con
     hipLaunchKernelGGL(k_ampmax_stream_mixed, dim3(1), dim3(1), 0, s, c->B.channels, nblocks_total, (const int *)order, secs0,
                        secs1, c->B.ampmax_att_per_sec, *ampmax_state, R[0].p.local, R[1].p.local, R[0].p.ampin,
                        R[1].p.ampin, R[0].p.ampglob, R[1].p.ampglob, d_state);
+  prof_mark(c, VAMD_ST_AMPMAX);
   R[0].d.ampmax_in = R[0].p.ampin;
   R[1].d.ampmax_in = R[1].p.ampin;
   launch_rest(c, &R[0], VAMD_LEVEL_FULL);
   launch_rest(c, &R[1], VAMD_LEVEL_FULL);
+  if (c->profile) c->prof_runs++;
   HIP_TRY(c, hipGetLastError());
   if (!nstreams) {
     HIP_TRY(c, hipMemcpyAsync(ampmax_state, d_state, sizeof(float), hipMemcpyDeviceToHost, s));
@@ -1375,6 +1407,7 @@ static int run_streams_mixed(vamd_ctx *c, const vamd_batch_desc *desc_short, con
 int vamd_analyze_stream_mixed(vamd_ctx *c, const vamd_batch_desc *desc_short, const vamd_batch_io *io_short,
                               const vamd_batch_desc *desc_long, const vamd_batch_io *io_long, const int32_t *order,
                               long nblocks_total, float *ampmax_state) {
+  DeviceGuard dev_guard(c);
   if (!c) return VAMD_EINVAL;
   if (!desc_short || !desc_long || !ampmax_state) return fail(c, VAMD_EINVAL, "null argument");
   return run_streams_mixed(c, desc_short, io_short, desc_long, io_long, order, nblocks_total, ampmax_state, nullptr, 0, nullptr);
@@ -1383,6 +1416,7 @@ int vamd_analyze_stream_mixed(vamd_ctx *c, const vamd_batch_desc *desc_short, co
 int vamd_analyze_streams_mixed(vamd_ctx *c, const vamd_batch_desc *desc_short, const vamd_batch_io *io_short,
                                const vamd_batch_desc *desc_long, const vamd_batch_io *io_long, const int32_t *order,
                                const int64_t *stream_start, long nstreams, long nblocks_total, float *ampmax_states) {
+  DeviceGuard dev_guard(c);
   if (!c) return VAMD_EINVAL;
   if (!desc_short || !desc_long) return fail(c, VAMD_EINVAL, "null argument");
   if (nstreams < 1 || !stream_start || !ampmax_states) return fail(c, VAMD_EINVAL, "stream_start / ampmax_states / nstreams");
@@ -1393,6 +1427,7 @@ int vamd_analyze_streams_mixed(vamd_ctx *c, const vamd_batch_desc *desc_short, c
 int vamd_analyze_block(vamd_ctx *c, const float *const *pcm, int lW, int W, int nW, int blocktype, float ampmax_in,
                        float *mdct, float *logmask, int32_t *posts, int32_t *post_valid, int32_t *iwork,
                        int32_t *nonzero, float *ampmax_out) {
+  DeviceGuard dev_guard(c);
   return vamd_analyze_block_res(c, pcm, lW, W, nW, blocktype, ampmax_in, mdct, logmask, posts, post_valid, iwork,
                                 nonzero, ampmax_out, nullptr, nullptr, nullptr);
 }
@@ -1401,6 +1436,7 @@ int vamd_analyze_block_res(vamd_ctx *c, const float *const *pcm, int lW, int W, 
                            float ampmax_in, float *mdct, float *logmask, int32_t *posts, int32_t *post_valid,
                            int32_t *iwork, int32_t *nonzero, float *ampmax_out, int32_t *res_class,
                            uint16_t *res_entries, int32_t *res_count) {
+  DeviceGuard dev_guard(c);
   if (!c) return VAMD_EINVAL;
   if (!pcm || (W != 0 && W != 1)) return fail(c, VAMD_EINVAL, "bad pcm / W");
   const bool want_res = res_class || res_entries || res_count;
@@ -1481,6 +1517,7 @@ int vamd_packet_capacity(const vamd_ctx *c, int W) {
 
 int vamd_encode_block(vamd_ctx *c, const float *const *pcm, int lW, int W, int nW, int blocktype, float ampmax_in,
                       int managed, float *ampmax_out, uint8_t *packets, long packet_stride, int32_t *packet_bits) {
+  DeviceGuard dev_guard(c);
   if (!c) return VAMD_EINVAL;
   if (!pcm || (W != 0 && W != 1)) return fail(c, VAMD_EINVAL, "bad pcm / W");
   if (!packets || !packet_bits) return fail(c, VAMD_EINVAL, "null packets / packet_bits");
@@ -1575,6 +1612,7 @@ int vamd_envelope_geometry(const vamd_ctx *c, int *winlength, int *searchstep) {
 
 int vamd_envelope_search_batch(vamd_ctx *c, const float *pcm, long stream_stride, long channel_stride, long nstreams,
                                long nsteps, vamd_envelope_state *states, unsigned char *ret) {
+  DeviceGuard dev_guard(c);
   if (!c) return VAMD_EINVAL;
   if (nstreams < 0 || nsteps < 0) return fail(c, VAMD_EINVAL, "negative stream / step count");
   if (nstreams == 0 || nsteps == 0) return VAMD_OK;
@@ -1619,6 +1657,7 @@ int vamd_envelope_search_batch(vamd_ctx *c, const float *pcm, long stream_stride
 
 int vamd_envelope_search(vamd_ctx *c, const float *const *pcm, long nsteps, vamd_envelope_state *state,
                          unsigned char *ret) {
+  DeviceGuard dev_guard(c);
   if (!c) return VAMD_EINVAL;
   if (nsteps < 0) return fail(c, VAMD_EINVAL, "negative step count");
   if (nsteps == 0) return VAMD_OK;

@@ -1,0 +1,88 @@
+"""vorbis_amd/sharding.py -- the multi-GPU plumbing of the batch path: one process per GPU,
+contiguous block ranges per rank, ONE collective at start-up (the setup blob from rank 0), none on the data
+path, and the max-over-ranks reduction of a timing.  `bench.py` runs on this module; the world-size-2 CPU test
+(tests/test_abi_and_host.py) drives the very same functions over gloo.
+
+torch.distributed backend "nccl" is RCCL on ROCm (xGMI between the GPUs of a node); "gloo" serves the CPU tests.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend="nccl", use_cuda=True):
+    """Join the process group described by RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run).
+    Returns (rank, world, device).  A single process needs no group: (0, 1, device)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if use_cuda:
+        dev = torch.device("cuda", local_rank if world > 1 else 0)
+        torch.cuda.set_device(dev)
+    else:
+        dev = torch.device("cpu")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, dev
+
+
+def active():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def shard_range(total_blocks, rank, world):
+    """Contiguous [lo, hi) of `total_blocks` for `rank`; sizes differ by at most one."""
+    base, rem = divmod(total_blocks, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def broadcast_blob(blob_or_none, device):
+    """Rank 0 passes the setup blob (numpy uint8); every rank returns an identical numpy copy.  Two broadcasts:
+    the length, then the bytes (~220 KB: latency-bound, link bandwidth irrelevant)."""
+    if not active():
+        return np.ascontiguousarray(blob_or_none)
+    rank = dist.get_rank()
+    if rank == 0:
+        t = torch.from_numpy(np.ascontiguousarray(blob_or_none).copy()).to(device)
+        size = torch.tensor([t.numel()], dtype=torch.int64, device=device)
+    else:
+        size = torch.zeros(1, dtype=torch.int64, device=device)
+    dist.broadcast(size, 0)
+    if rank != 0:
+        t = torch.empty(int(size.item()), dtype=torch.uint8, device=device)
+    dist.broadcast(t, 0)
+    return t.cpu().numpy()
+
+
+def barrier():
+    if active():
+        dist.barrier()
+
+
+def max_over_ranks(value, device):
+    """The slowest rank's figure (every rank gets it)."""
+    if not active():
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value, device):
+    if not active():
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())
+
+
+def finish():
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
