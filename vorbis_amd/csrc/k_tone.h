@@ -44,24 +44,42 @@ VAMD_HOSTDEV int seed_pad_hi(int linesper) { return ((VAMD_EHMER_MAX - VAMD_EHME
 // the 56 scatter addresses into one base register plus immediate offsets.
 template <int LP = 0>
 VAMD_DEV void seed_curve_scatter(float *seed, const float *__restrict__ band_rows /*[8] rows of one band*/,
-                                 int stride, float amp, int oc, int linesper_rt, float dBoffset) {
+                                 int stride, float amp, int oc, int linesper_rt, float dBoffset, bool active) {
   const int linesper = LP ? LP : linesper_rt;
   int choice = (int)(((double)(amp + dBoffset) - 30.) * (double).1f);
   choice = choice < 0 ? 0 : choice;
   choice = choice > VAMD_P_LEVELS - 1 ? VAMD_P_LEVELS - 1 : choice;
   const F4 *__restrict__ row = (const F4 *)(band_rows + choice * stride);
-  float c[VAMD_EHMER_MAX];
-#if VAMD_GPU
-#pragma unroll
-#endif
-  for (int k = 0; k < VAMD_EHMER_MAX / 4; k++) f4_get(row[k], c + 4 * k);
   float *p = seed + (oc - VAMD_EHMER_OFFSET * linesper - (linesper >> 1));
-  // straight-line on purpose: skipping the points no lane of the wave reaches (a curve
-  // spans ~20 of the 56) was measured slower -- the branches cost more than the atomics
+  // The rows are finite only between their fence posts -- 8 to 50 of the 56 points, 12 to 25 for most of the
+  // spectrum -- and what a point costs is an LDS float atomic plus its share of the row's trip from L1 whether
+  // the value is -inf or not.  So the points go in seven groups of eight, and a group that holds no finite
+  // point for any lane of the wave is skipped (one wave-uniform branch per group: per-POINT skipping was
+  // measured slower than no skipping at all).  Inside a group everything stays straight-line with immediate
+  // offsets.  The posts live in the row's padding: curves64 rows are 64 floats, [56] = first, [57] = last+1.
+  int p0 = VAMD_EHMER_MAX, p1 = 0;
+  if (active) {
+    const F2 posts = *(const F2 *)((const float *)row + VAMD_EHMER_MAX);
+    p0 = (int)posts.x;
+    p1 = (int)posts.y;
+  }
+#if VAMD_GPU
+  const unsigned long long live = __ballot(active);
+  (void)live;
+#pragma unroll
+#endif
+  for (int g = 0; g < VAMD_EHMER_MAX / 8; g++) {
+    if (!wave_any(active && p0 < 8 * g + 8 && p1 > 8 * g)) continue;
+    if (active) {
+      float c[8];
+      f4_get(row[2 * g], c);
+      f4_get(row[2 * g + 1], c + 4);
 #if VAMD_GPU
 #pragma unroll
 #endif
-  for (int i = 0; i < VAMD_EHMER_MAX; i++) lds_atomic_max(p + i * linesper, amp + c[i]);
+      for (int i = 0; i < 8; i++) lds_atomic_max(p + (8 * g + i) * linesper, amp + c[i]);
+    }
+  }
 }
 
 // seed_chase part 2, lib/psy.c:489-503: entry k paints [start_k, end_k) where
@@ -196,9 +214,8 @@ VAMD_DEV void tone_seed_block(const PsyP &P, const float *__restrict__ logfft, f
       if (c > mx) mx = c;
       if (dd > mx) mx = dd;
     }
-    if (mx + 6.f > f_from_bits((uint32_t)rec.w) + att)
-      seed_curve_scatter<LP>(seed, P.curves64 + rec.z * (VAMD_P_LEVELS * P.curve_stride), P.curve_stride, mx, rec.y,
-                         P.eighth_octave_lines, dBoffset);
+    seed_curve_scatter<LP>(seed, P.curves64 + rec.z * (VAMD_P_LEVELS * P.curve_stride), P.curve_stride, mx, rec.y,
+                           P.eighth_octave_lines, dBoffset, mx + 6.f > f_from_bits((uint32_t)rec.w) + att);
   }
   WAVE_SYNC();
   if (LANE == 0) seed[0] = VAMD_NEGINF;  // seedptr > 0, lib/psy.c:406

@@ -109,6 +109,9 @@ inline PsyDerived derive_psy(const vamd_psy_tab &t, const unsigned char *blob) {
       const int i0 = (int)row[0], i1 = (int)row[1];
       for (int k = 0; k < VAMD_EHMER_MAX; k++)
         if (k >= i0 && k < i1) d.curves64[(size_t)bc * 64 + k] = row[2 + k];
+      // the fence posts ride in the row's padding: the scatter skips the point groups no lane needs
+      d.curves64[(size_t)bc * 64 + VAMD_EHMER_MAX] = (float)i0;
+      d.curves64[(size_t)bc * 64 + VAMD_EHMER_MAX + 1] = (float)i1;
     }
   }
 

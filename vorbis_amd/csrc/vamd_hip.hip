@@ -311,17 +311,21 @@ __global__ __launch_bounds__(64) void k_tone_seed(PsyP P0, PsyP P1, DescP d, int
   pc.flush();
 }
 
-// one THREAD per channel-block: the ordered stack walk of seed_chase
+// one THREAD per channel-block: the ordered stack walk of seed_chase, VAMD_CHASE_LANES walks per wave.  (Measured
+// round 2: half-filled waves -- twice as many waves for the SIMDs to interleave -- are slower, 1.01 against 0.82 ms per
+// 131 072 stereo blocks; a walk whose stack is a register bit mask fed through coalesced LDS tiles executes three
+// times the instructions once 64 divergent walks share them, 2.96 ms.  tools/pmc_quick.sh has the counters.)
+#define VAMD_CHASE_LANES 64
 __global__ __launch_bounds__(64) void k_tone_chase(int linesper, int nl, int nlp, long ncb, DescP d,
                                                    const float *__restrict__ seed_g,
                                                    unsigned short *__restrict__ surv, int *__restrict__ nsurv) {
   float *ring_amp = (float *)vamd_smem;
-  int *ring_pos = (int *)(ring_amp + VAMD_RING * 64);
-  const long cb = (long)blockIdx.x * 64 + threadIdx.x;
+  int *ring_pos = (int *)(ring_amp + VAMD_RING * VAMD_CHASE_LANES);
+  const long cb = (long)blockIdx.x * VAMD_CHASE_LANES + threadIdx.x;
   PhaseClock pc;
   pc.start(d.dbg ? d.dbg + 32 : nullptr);
   if (cb < ncb)
-    nsurv[cb] = tone_chase_thread(seed_g + cb * nlp, linesper, nl, ring_amp, ring_pos, 64, threadIdx.x, surv + cb * nlp);
+    nsurv[cb] = tone_chase_thread(seed_g + cb * nlp, linesper, nl, ring_amp, ring_pos, VAMD_CHASE_LANES, threadIdx.x, surv + cb * nlp);
   pc.mark(2);
   pc.flush();
 }
@@ -1157,7 +1161,8 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_
       else
         hipLaunchKernelGGL(k_tone_seed<0>, dim3(gcb), dim3(64), seed_lds, s, P0, P1, d, ch, nlp, p.logfft, p.local, p.ampglob,
                            p.seed);
-      hipLaunchKernelGGL(k_tone_chase, dim3((gcb + 63) / 64), dim3(64), (size_t)VAMD_RING * 64 * 8, s,
+      hipLaunchKernelGGL(k_tone_chase, dim3((gcb + VAMD_CHASE_LANES - 1) / VAMD_CHASE_LANES), dim3(VAMD_CHASE_LANES),
+                         (size_t)VAMD_RING * VAMD_CHASE_LANES * 8, s,
                          P0.eighth_octave_lines, nl, nlp, (long)gcb, d, p.seed, p.surv, p.nsurv);
       hipLaunchKernelGGL(k_tone_fold, dim3(gcb), dim3(64), (size_t)(nlp + (P0.ngroups > P1.ngroups ? P0.ngroups : P1.ngroups)) * 4, s, P0, P1, d, ch, nlp, p.seed, p.surv,
                          p.nsurv, p.local, p.tone);
