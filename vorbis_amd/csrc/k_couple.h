@@ -205,13 +205,16 @@ VAMD_DEV float couple_bin(ChanBin &M, ChanBin &A, int &iM, int &iA, int b, int n
 // iwork[k]     HBM [n2]  out: quantised (and coupled) residue
 // nonzero      [ch] in: floor1_encode's return per channel; out: after the coupling fix-up
 // (one or two channels, at most one coupling step: every stereo and mono setup)
+// NORM = false: the caller knows noise normalisation is inactive for this size class (the launch picks the
+// instantiation): the ordered general path below is then not even compiled in, which halves the registers.
+template <bool NORM = true>
 VAMD_DEV void couple_block(const CoupleP &C, const PsyP &P, int n2, const float *const *mdct,
                            const int *const *ilogmask, int *const *iwork, int *nonzero, const CoupleLds &L,
                            PhaseClock &pc) {
   const int ch = C.ch;
   const int partition = P.normal_p ? P.normal_partition : 16;
   const int nstart = P.normal_p ? P.normal_start : 0x7fffffff;  // first bin subject to noise norm
-  const bool norm_active = nstart < n2;
+  const bool norm_active = NORM && nstart < n2;
   const int nparts = (n2 + partition - 1) / partition;
   int nz[VAMD_MAX_CH];
   for (int k = 0; k < ch; k++) nz[k] = nonzero[k];
@@ -222,7 +225,13 @@ VAMD_DEV void couple_block(const CoupleP &C, const PsyP &P, int n2, const float 
     // 44.1 kHz): nothing is ordered, so each lane takes quads of bins straight through
     // quantise -> couple -> re-normalise with one 16-byte load per input tensor.
     const int Mi = C.coupling_steps == 1 ? C.mag[0] : 0, Ai = C.coupling_steps == 1 ? C.ang[0] : (ch > 1 ? 1 : 0);
-    WAVE_FOR(q, n2 >> 2) {
+    // (two quads in flight, not WAVE_FOR's four: at four the kernel needs 110 VGPRs and the SIMD holds four waves;
+    // the stage is a chain of fp64 square roots and correctly rounded divisions, which more waves hide better
+    // than more unrolling)
+#if VAMD_GPU
+#pragma unroll 2
+#endif
+    for (int q = LANE; q < (n2 >> 2); q += NLANES) {
       float m0[4], m1[4];
       int l0[4], l1[4], o0[4], o1[4];
       f4_get(((const F4 *)mdct[Mi])[q], m0);
@@ -262,6 +271,7 @@ VAMD_DEV void couple_block(const CoupleP &C, const PsyP &P, int n2, const float 
     pc.mark(1);
     return;
   }
+  if (!NORM) return;
 
   // ---- general path: noise normalisation's ordered sort may touch any partition.
   // per channel: floor lookup, lossless flags, energies, first quantisation

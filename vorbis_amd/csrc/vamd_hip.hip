@@ -377,6 +377,7 @@ __global__ __launch_bounds__(64) void k_floor(PsyP P0, PsyP P1, FloorP F0, Floor
 // A unit is one (block, candidate packet): VBR has one packet per block (blob_base = PACKETBLOBS/2,
 // nblobs = 1), a bitrate-managed block all fifteen, each with its own coupling parameters over the
 // same spectrum.  ilogmask / iwork / nonzero are indexed by unit, mdct by block.
+template <bool NORM>
 __global__ __launch_bounds__(64) void k_couple(PsyP P0, PsyP P1, CoupleSet CS, int blob_base, int nblobs, DescP d,
                                                const float *__restrict__ mdct, const int *__restrict__ ilogmask,
                                                int *__restrict__ iwork, int *__restrict__ nonzero) {
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(64) void k_couple(PsyP P0, PsyP P1, CoupleSet CS, i
   WAVE_SYNC_GLOBAL();  // every lane has read nonzero[] before lane 0 rewrites it
   PhaseClock pc;
   pc.start(d.dbg ? d.dbg + 64 : nullptr);
-  couple_block(C, P, n2, mp, ip, op, nz, L, pc);
+  couple_block<NORM>(C, P, n2, mp, ip, op, nz, L, pc);
   if (LANE == 0)
     for (int c = 0; c < ch; c++) nonzero[blk * ch + c] = nz[c];
   pc.flush();
@@ -1108,8 +1109,12 @@ static void launch_couple(vamd_ctx *c, BatchRun *R, hipStream_t s, long units, i
   // the LDS arrays serve noise normalisation's sort only (lib/psy.c:941-1010); without it the
   // stage is register-only and the CU holds twice as many of its waves
   const bool norm0 = P0.normal_p && P0.normal_start < n2, norm1 = P1.normal_p && P1.normal_start < n2;
-  hipLaunchKernelGGL(k_couple, dim3((unsigned)units), dim3(64), (norm0 || norm1) ? (size_t)n2 * 12 + 1024 : 0, s, P0, P1,
-                     c->B.couple_all[W], blob_base, nblobs, R->d, mdct, ilogmask, iwork, nonzero);
+  if (norm0 || norm1)
+    hipLaunchKernelGGL(k_couple<true>, dim3((unsigned)units), dim3(64), (size_t)n2 * 12 + 1024, s, P0, P1, c->B.couple_all[W], blob_base,
+                       nblobs, R->d, mdct, ilogmask, iwork, nonzero);
+  else
+    hipLaunchKernelGGL(k_couple<false>, dim3((unsigned)units), dim3(64), 0, s, P0, P1, c->B.couple_all[W], blob_base, nblobs, R->d,
+                       mdct, ilogmask, iwork, nonzero);
 }
 
 static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_io *M = nullptr, int *m_ilogmask = nullptr) {
