@@ -33,7 +33,7 @@ static void noisemask_block(const PsyP &P, const float *logmdct, float *out, flo
   static int bk[VAMD_NZ_HOST_BINS];
   for (int i = 0; i < P.n; i++) lm[i] = logmdct[i];
   noise_bark_fetch<VAMD_NZ_HOST_BINS, 0>(P, bk, 0);
-  noisemask_bins<ScanSerial, VAMD_NZ_HOST_BINS, 0>(P, lm, bk, o, S, P.noisecompand, ScanSerial(), pc, 0);
+  noisemask_bins<ScanSerial, VAMD_NZ_HOST_BINS, 0>(P, lm, bk, o, S, [&](int dB) { return P.noisecompand[dB]; }, ScanSerial(), pc, 0);
   for (int i = 0; i < P.n; i++) out[i] = o[i];
 }
 

@@ -25,9 +25,10 @@ namespace vamd {
 // per-bin phases touch consecutive e from consecutive lanes and stay conflict-free under it (a wave's 32
 // lanes of an LDS cycle still cover 32 different banks); the ordered walk (running_sum_rounds), where each
 // lane of a chain's eight moves the 64 bytes of its own run, needs it: without the fold lanes j and j+4 of
-// a chain -- and every chain of the block -- would queue on the same four banks.  The arrays are n + 8
-// floats apart, which sets neighbouring chains half a bank row apart for the same reason.
-#define VAMD_NZ_STRIDE(n) ((n) + 8)
+// a chain would queue on the same four banks.  The arrays are exactly n floats apart: at 1024 bins a block's
+// five arrays are 20 480 bytes and EIGHT blocks fill a CU's 160 KB to the byte -- one more block in flight is
+// worth more than the few LDS cycles the walk's 16-byte accesses lose to the chains sharing their banks.
+#define VAMD_NZ_STRIDE(n) (n)
 VAMD_DEV int nz_swz(int e) { return e ^ ((e >> 4) & 4); }
 
 struct LineFit {
@@ -247,9 +248,11 @@ VAMD_DEV void noise_bark_edges(const PsyP &P, const int *braw, int *bk, int i0) 
 }
 
 // _vp_noisemask on a block whose logmdct is already in the lanes' registers (lm[k] = bin i0 + LANE + 64k)
-//   compand  noisecompand[] (P.noisecompand, or the caller's copy of it in LDS)
-template <class Scan, int KPL, int LOGN>
-VAMD_DEV void noisemask_bins(const PsyP &P, const float *lm, const int *braw, float *o, float *S, const float *compand,
+//   compand  noisecompand[] as a callable (level) -> value: the table itself in the test build; on the GPU a
+//            cross-lane read of the copy the wave keeps one entry per lane (the index is data-dependent, the
+//            team's LDS is full to the byte, and a trip to L1 at the very end of a block is exposed latency)
+template <class Scan, int KPL, int LOGN, class Compand>
+VAMD_DEV void noisemask_bins(const PsyP &P, const float *lm, const int *braw, float *o, float *S, const Compand &compand,
                              const Scan &scan, PhaseClock &pc, int i0) {
   const int n = LOGN ? (1 << LOGN) : P.n;
   float nz[KPL], wk[KPL];
@@ -264,7 +267,7 @@ VAMD_DEV void noisemask_bins(const PsyP &P, const float *lm, const int *braw, fl
     int dB = (int)((double)nz[k] + .5);
     if (dB >= VAMD_NOISE_COMPAND_LEVELS) dB = VAMD_NOISE_COMPAND_LEVELS - 1;
     if (dB < 0) dB = 0;
-    o[k] = w + compand[dB];
+    o[k] = w + compand(dB);
   }
   pc.mark(7);
 }

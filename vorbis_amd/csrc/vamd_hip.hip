@@ -180,31 +180,35 @@ struct NoiseGeom {
   static constexpr int KPL = n2 / (64 * NW) > 0 ? n2 / (64 * NW) : 1;  // bins per lane
 };
 template <int LOGN2>
-__global__ __launch_bounds__(64 * NoiseGeom<LOGN2>::NW, NoiseGeom<LOGN2>::KPL <= 4 ? 7 : 4) void k_noise(PsyP P0, PsyP P1, DescP d, int ch, long ncb,
+__global__ __launch_bounds__(64 * NoiseGeom<LOGN2>::NW, NoiseGeom<LOGN2>::KPL <= 4 ? 8 : 4) void k_noise(PsyP P0, PsyP P1, DescP d, int ch, long ncb,
                                                                      const float *__restrict__ logmdct,
                                                                      float *__restrict__ noise) {
   constexpr int n2 = NoiseGeom<LOGN2>::n2, KPL = NoiseGeom<LOGN2>::KPL;
-  float *S = (float *)vamd_smem;
-  float *compand = S + 5 * VAMD_NZ_STRIDE(n2);  // noisecompand[] beside the sums: the final lookup is data-dependent
+  float *S = (float *)vamd_smem;  // the five running sums and nothing else: see VAMD_NZ_STRIDE
   const int i0 = (threadIdx.x >> 6) * 64 * KPL;  // this wave's first bin
   PhaseClock pc;
   pc.start(d.dbg ? d.dbg + 16 : nullptr);
-  if (threadIdx.x < 2 * VAMD_NOISE_COMPAND_LEVELS)  // both block types' tables
-    compand[threadIdx.x] = threadIdx.x < VAMD_NOISE_COMPAND_LEVELS ? P0.noisecompand[threadIdx.x]
-                                                                 : P1.noisecompand[threadIdx.x - VAMD_NOISE_COMPAND_LEVELS];
   // persistent: the next block's spectrum is fetched while this one is worked on
   float lm[KPL];
+  int braw[KPL], bt_have = -1;
+  float compand_lane = 0.f;  // noisecompand[LANE]
   long cb = blockIdx.x;
   if (cb < ncb) LANE_BINS(k, i, i0, KPL, n2) lm[k] = logmdct[cb * n2 + i];
   for (; cb < ncb; cb += gridDim.x) {
     const int bt = d_bt(d, (long)((unsigned)cb / (unsigned)ch));  // (cb < 2^31: check_desc)
     const PsyP &P = bt ? P1 : P0;
     float o[KPL], lm_next[KPL];
-    int braw[KPL];
     const long nb = cb + gridDim.x < ncb ? cb + gridDim.x : cb;
-    noise_bark_fetch<KPL, LOGN2>(P, braw, i0);
+    if (bt != bt_have) {  // the window edges of this lane's bins and noisecompand[]: properties of the block type, kept across blocks
+      noise_bark_fetch<KPL, LOGN2>(P, braw, i0);
+      compand_lane = LANE < VAMD_NOISE_COMPAND_LEVELS ? P.noisecompand[LANE] : 0.f;
+      bt_have = bt;
+    }
     LANE_BINS(k, i, i0, KPL, n2) lm_next[k] = logmdct[nb * n2 + i];
-    noisemask_bins<ScanTeam, KPL, LOGN2>(P, lm, braw, o, S, compand + (bt ? VAMD_NOISE_COMPAND_LEVELS : 0), ScanTeam(), pc, i0);
+    noisemask_bins<ScanTeam, KPL, LOGN2>(
+        P, lm, braw, o, S,
+        [&](int dB) { return __int_as_float(__builtin_amdgcn_ds_bpermute(dB << 2, __float_as_int(compand_lane))); }, ScanTeam(), pc,
+        i0);
     LANE_BINS(k, i, i0, KPL, n2) noise[cb * n2 + i] = o[k];
     LANE_BINS(k, i, i0, KPL, n2) lm[k] = lm_next[k];
   }
@@ -1134,8 +1138,8 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_
       (void)hipStreamWaitEvent(c->side, c->ev_fork, 0);
     }
     {
-      // persistent teams, as many per CU as its LDS and its 32 wave slots hold (7 at 1024 bins)
-      const size_t lds = ((size_t)5 * VAMD_NZ_STRIDE(n2) + 2 * VAMD_NOISE_COMPAND_LEVELS) * 4;
+      // persistent teams, as many per CU as its LDS and its 32 wave slots hold (8 at 1024 bins: both exactly full)
+      const size_t lds = (size_t)5 * VAMD_NZ_STRIDE(n2) * 4;
       const int nw = n2 >= 256 ? 4 : (n2 >= 64 ? n2 / 64 : 1);
       long per_cu = (long)(c->lds_per_block / lds);
       if (per_cu > 32 / nw) per_cu = 32 / nw;
