@@ -28,6 +28,7 @@ struct ScanSerial {
   }
 };
 #define VAMD_NZ_HOST_BINS 4096
+#define VAMD_HOST_QUADS 2048  // a whole block's quads in the one lane of this build (blocks up to 8192 samples)
 static void noisemask_block(const PsyP &P, const float *logmdct, float *out, float *S, PhaseClock &pc) {
   static float lm[VAMD_NZ_HOST_BINS], o[VAMD_NZ_HOST_BINS];
   static int bk[VAMD_NZ_HOST_BINS];
@@ -132,9 +133,10 @@ int emul_mdct_forward(void *h, int W, const float *in, float *out) {
   std::vector<float> A(P.n + 4), Bw(P.n + P.n / 32);
   PhaseClock pc;
   pc.start(nullptr);
-  static PcmTile tile;
-  pcm_fetch(tile, in, P.n);
-  window_store(P, W, 1, 1, tile, A.data(), false);
+  static PcmTile<VAMD_HOST_QUADS> tile;
+  const WaveTeam tm;
+  pcm_fetch(tile, in, P.n, tm);
+  window_store(P, W, 1, 1, tile, A.data(), false, tm);
   mdct_forward_wave(P, A.data(), Bw.data(), Bw.data() + P.n / 2, pc);
   memcpy(out, Bw.data() + P.n / 2, sizeof(float) * (P.n / 2));
   return 0;
@@ -168,9 +170,10 @@ static int analyze_core(void *h, const float *pcm, int lW, int W, int nW, int bl
   PhaseClock pc;
   pc.start(nullptr);
   for (int i = 0; i < ch; i++) {
-    static PcmTile tile;
-    pcm_fetch(tile, pcm + (size_t)i * n, n);
-    transform_window(X, W, lW, nW, tile, A.data(), pc);
+    static PcmTile<VAMD_HOST_QUADS> tile;
+    const WaveTeam tm;
+    pcm_fetch(tile, pcm + (size_t)i * n, n, tm);
+    transform_window(X, W, lW, nW, tile, A.data(), pc, tm);
     local[i] = transform_block(X, A.data(), Bw.data(), &mdct_raw[i * n2], &logmdct[i * n2], &logfft[i * n2], pc);
     if (local[i] > global) global = local[i];
   }

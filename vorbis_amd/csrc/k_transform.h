@@ -11,28 +11,65 @@
 //
 // LDS: A[n+4] (PCM -> windowed -> FFT buffer "c"), B[n + n/32] (MDCT work "w" with its
 // padded butterfly half, then FFT buffer "ch"; n/32 >= 4 covers the offset layout).
+//
+// Who runs a block: a TEAM.  Every phase below is a loop over independent items (butterflies, pairs,
+// quads) followed by a team-wide sync; the items are dealt round the team's threads.  The kernels run one
+// wave per transform (WaveTeam) -- measured round 2: four waves per block (BlockTeam) bring nothing, 2.9
+// against 2.3 ms, because the stage is bound by the CU's LDS pipe (92 % busy, half of it bank conflicts) and
+// not by any wave's latency -- and the test build runs everything in a single lane.
 #pragma once
 #include "vamd_wave.h"
 #include "vamd_params.h"
 
 namespace vamd {
 
-// A block of PCM held in registers (lane l owns quads l, l+64, ...): fetched from HBM one
-// block ahead of its use so that the load latency hides behind the previous block's
-// transforms (persistent kernels), then windowed on its way into LDS.
-struct PcmTile {
-  float v[VAMD_QPL2][4];
+struct WaveTeam {  // the 64 lanes of one wavefront (one lane in the test build)
+  VAMD_MEM int tid() const { return LANE; }
+  VAMD_MEM int size() const { return NLANES; }
+  VAMD_MEM void sync() const { WAVE_SYNC(); }
 };
+#if VAMD_GPU
+// TW waves of a workgroup.  The sync is the WORKGROUP's barrier: every team of a workgroup walks the same
+// phases with the same trip counts (a team without a block shadows one), so they may as well meet.
+template <int TW>
+struct BlockTeam {
+  VAMD_MEM int tid() const { return (int)(threadIdx.x & (64 * TW - 1)); }
+  VAMD_MEM int size() const { return 64 * TW; }
+  VAMD_MEM void sync() const { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+};
+#endif
+#if VAMD_GPU
+// (unrolled x4 so that the independent LDS reads of four items are in flight together)
+#define TEAM_EACH(i, count, tm) _Pragma("unroll 4") for (int i = (tm).tid(); i < (count); i += (tm).size())
+#else
+#define TEAM_EACH(i, count, tm) for (int i = (tm).tid(); i < (count); i += (tm).size())
+#endif
 
-VAMD_DEV void pcm_fetch(PcmTile &t, const float *__restrict__ pcm, int n) {
-  LANE_QUADS2(kq, q, n >> 2) f4_get(((const F4 *)pcm)[q], t.v[kq]);
+// A block of PCM held in registers (thread t of the team owns quads t, t+T, ...): fetched from HBM one
+// block ahead of its use so that the load latency hides behind the previous block's
+// transforms (persistent kernels), then windowed on its way into LDS.  QPT = quads per thread.
+template <int QPT>
+struct PcmTile {
+  float v[QPT][4];
+};
+#if VAMD_GPU
+#define TEAM_QUADS(kq, q, nq, QPT, tm) _Pragma("unroll") for (int kq = 0, q = (tm).tid(); kq < (QPT); kq++, q += (tm).size()) if (q < (nq))
+#else
+#define TEAM_QUADS(kq, q, nq, QPT, tm) for (int kq = 0, q = (tm).tid(); kq < (QPT) && q < (nq); kq++, q += (tm).size())
+#endif
+
+template <int QPT, class Team>
+VAMD_DEV void pcm_fetch(PcmTile<QPT> &t, const float *__restrict__ pcm, int n, const Team &tm) {
+  TEAM_QUADS(kq, q, n >> 2, QPT, tm) f4_get(((const F4 *)pcm)[q], t.v[kq]);
 }
 
 // _vorbis_apply_window, lib/window.c:2102-2135, applied while the tile is written to LDS.
-VAMD_DEV void window_store(const XformP &P, int W, int lW, int nW, const PcmTile &t, float *A, bool apply_window) {
+template <int QPT, class Team>
+VAMD_DEV void window_store(const XformP &P, int W, int lW, int nW, const PcmTile<QPT> &t, float *A, bool apply_window,
+                           const Team &tm) {
   const int n = P.n;
   if (!apply_window) {
-    LANE_QUADS2(kq, q, n >> 2)((F4 *)A)[q] = f4_make(t.v[kq]);
+    TEAM_QUADS(kq, q, n >> 2, QPT, tm)((F4 *)A)[q] = f4_make(t.v[kq]);
     return;
   }
   lW = W ? lW : 0;
@@ -45,7 +82,7 @@ VAMD_DEV void window_store(const XformP &P, int W, int lW, int nW, const PcmTile
   const int rightbegin = n / 2 + n / 4 - rn / 4, rightend = rightbegin + rn / 2;
   // every boundary is a multiple of 4 (block sizes are powers of two >= 64), so a
   // 16-byte quad never straddles two regions
-  LANE_QUADS2(kq, q, n >> 2) {
+  TEAM_QUADS(kq, q, n >> 2, QPT, tm) {
     const int i = q << 2;
     float v[4] = {t.v[kq][0], t.v[kq][1], t.v[kq][2], t.v[kq][3]};
     if (i < leftbegin || i >= rightend) {
@@ -63,138 +100,78 @@ VAMD_DEV void window_store(const XformP &P, int W, int lW, int nW, const PcmTile
   }
 }
 
-// The same window for blocks the register tile does not hold (n > 2048): HBM -> LDS directly.
-VAMD_DEV void window_store_hbm(const XformP &P, int W, int lW, int nW, const float *__restrict__ pcm, float *A) {
-  const int n = P.n;
-  lW = W ? lW : 0;
-  nW = W ? nW : 0;
-  const int ln = lW ? P.bs1 : P.bs0;
-  const int rn = nW ? P.bs1 : P.bs0;
-  const float *winL = lW ? P.win_long : P.win_short;
-  const float *winR = nW ? P.win_long : P.win_short;
-  const int leftbegin = n / 4 - ln / 4, leftend = leftbegin + ln / 2;
-  const int rightbegin = n / 2 + n / 4 - rn / 4, rightend = rightbegin + rn / 2;
-  WAVE_FOR(q, n >> 2) {
-    const int i = q << 2;
-    float v[4];
-    f4_get(((const F4 *)pcm)[q], v);
-    if (i < leftbegin || i >= rightend) {
-      v[0] = v[1] = v[2] = v[3] = 0.f;
-    } else if (i < leftend) {
-      float w[4];
-      f4_get(*(const F4 *)(winL + (i - leftbegin)), w);
-      v[0] *= w[0]; v[1] *= w[1]; v[2] *= w[2]; v[3] *= w[3];
-    } else if (i >= rightbegin) {
-      float w[4];
-      f4_get(*(const F4 *)(winR + (rn / 2 - 4 - (i - rightbegin))), w);
-      v[0] *= w[3]; v[1] *= w[2]; v[2] *= w[1]; v[3] *= w[0];
-    }
-    ((F4 *)A)[q] = f4_make(v);
-  }
-}
-
 // cPI*_8 of lib/mdct.h:43-45
 #define VAMD_C1 .92387953251128675613F
 #define VAMD_C2 .70710678118654752441F
 #define VAMD_C3 .38268343236508977175F
 
-// mdct_butterfly_8, lib/mdct.c:93-114 (in registers)
-VAMD_DEV void bfly8(float *x) {
-  float r0 = x[6] + x[2], r1 = x[6] - x[2], r2 = x[4] + x[0], r3 = x[4] - x[0];
-  x[6] = r0 + r2;
-  x[4] = r0 - r2;
-  r0 = x[5] - x[1];
-  r2 = x[7] - x[3];
-  x[0] = r1 + r0;
-  x[2] = r1 - r0;
-  r0 = x[5] + x[1];
-  r1 = x[7] + x[3];
-  x[3] = r2 + r3;
-  x[1] = r2 - r3;
-  x[7] = r1 + r0;
-  x[5] = r1 - r0;
+// The last three butterfly levels of mdct_butterflies (lib/mdct.c:93-213: the 32-, 16- and 8-point
+// networks the reference finishes each group of 32 with), stated as what they are:
+//   level 32: eight pair-operations per group, each on the pairs (x[2a], x[2a+1]) and (x[16+2a], x[17+2a]);
+//   level 16: four per 16-point half, on (x[2b], x[2b+1]) and (x[8+2b], x[9+2b]);
+//   level  8: per 8 points a two-layer add/subtract network.
+// In each pair-operation the upper pair takes the sums, the lower pair a rotation of the differences by a
+// multiple of pi/8 -- the reference spells each of the eight (four) out with its own constants and signs, and
+// the expression trees are kept: which differences, which products, and whether a sum is multiplied or
+// products are summed.  (Negating an operand or swapping the operands of an add changes no bit.)
+// x = the padded vector (VAMD_PW); g = group of 32.
+struct PairOp {
+  F2 lo, hi;
+};
+VAMD_DEV PairOp bfly_level32(int a, F2 lo, F2 hi) {
+  PairOp r;
+  r.hi.x = hi.x + lo.x;
+  r.hi.y = hi.y + lo.y;
+  // differences as the reference takes them: upper minus lower for a >= 3 (the y of a == 3 the other way),
+  // lower minus upper for a <= 2
+  const float dx = a >= 3 ? hi.x - lo.x : lo.x - hi.x;
+  const float dy = (a >= 4) ? hi.y - lo.y : lo.y - hi.y;
+  switch (a) {
+    case 7: r.lo.x = dx; r.lo.y = dy; break;
+    case 6: r.lo.x = dx * VAMD_C1 - dy * VAMD_C3; r.lo.y = dx * VAMD_C3 + dy * VAMD_C1; break;
+    case 5: r.lo.x = (dx - dy) * VAMD_C2; r.lo.y = (dx + dy) * VAMD_C2; break;
+    case 4: r.lo.x = dx * VAMD_C3 - dy * VAMD_C1; r.lo.y = dy * VAMD_C3 + dx * VAMD_C1; break;
+    case 3: r.lo.x = dy; r.lo.y = dx; break;
+    case 2: r.lo.x = dy * VAMD_C1 + dx * VAMD_C3; r.lo.y = dy * VAMD_C3 - dx * VAMD_C1; break;
+    case 1: r.lo.x = (dy + dx) * VAMD_C2; r.lo.y = (dy - dx) * VAMD_C2; break;
+    default: r.lo.x = dy * VAMD_C3 + dx * VAMD_C1; r.lo.y = dy * VAMD_C1 - dx * VAMD_C3; break;
+  }
+  return r;
 }
-
-// mdct_butterfly_16, lib/mdct.c:117-149
-VAMD_DEV void bfly16(float *x) {
-  float r0 = x[1] - x[9], r1 = x[0] - x[8];
-  x[8] += x[0];
-  x[9] += x[1];
-  x[0] = (r0 + r1) * VAMD_C2;
-  x[1] = (r0 - r1) * VAMD_C2;
-  r0 = x[3] - x[11];
-  r1 = x[10] - x[2];
-  x[10] += x[2];
-  x[11] += x[3];
-  x[2] = r0;
-  x[3] = r1;
-  r0 = x[12] - x[4];
-  r1 = x[13] - x[5];
-  x[12] += x[4];
-  x[13] += x[5];
-  x[4] = (r0 - r1) * VAMD_C2;
-  x[5] = (r0 + r1) * VAMD_C2;
-  r0 = x[14] - x[6];
-  r1 = x[15] - x[7];
-  x[14] += x[6];
-  x[15] += x[7];
-  x[6] = r0;
-  x[7] = r1;
-  bfly8(x);
-  bfly8(x + 8);
+VAMD_DEV PairOp bfly_level16(int b, F2 lo, F2 hi) {
+  PairOp r;
+  r.hi.x = hi.x + lo.x;
+  r.hi.y = hi.y + lo.y;
+  if (b == 0) {
+    const float d0 = lo.y - hi.y, d1 = lo.x - hi.x;
+    r.lo.x = (d0 + d1) * VAMD_C2;
+    r.lo.y = (d0 - d1) * VAMD_C2;
+  } else if (b == 1) {
+    r.lo.x = lo.y - hi.y;
+    r.lo.y = hi.x - lo.x;
+  } else if (b == 2) {
+    const float d0 = hi.x - lo.x, d1 = hi.y - lo.y;
+    r.lo.x = (d0 - d1) * VAMD_C2;
+    r.lo.y = (d0 + d1) * VAMD_C2;
+  } else {
+    r.lo.x = hi.x - lo.x;
+    r.lo.y = hi.y - lo.y;
+  }
+  return r;
 }
-
-// mdct_butterfly_32, lib/mdct.c:152-213
-VAMD_DEV void bfly32(float *x) {
-  float r0 = x[30] - x[14], r1 = x[31] - x[15];
-  x[30] += x[14];
-  x[31] += x[15];
-  x[14] = r0;
-  x[15] = r1;
-  r0 = x[28] - x[12];
-  r1 = x[29] - x[13];
-  x[28] += x[12];
-  x[29] += x[13];
-  x[12] = r0 * VAMD_C1 - r1 * VAMD_C3;
-  x[13] = r0 * VAMD_C3 + r1 * VAMD_C1;
-  r0 = x[26] - x[10];
-  r1 = x[27] - x[11];
-  x[26] += x[10];
-  x[27] += x[11];
-  x[10] = (r0 - r1) * VAMD_C2;
-  x[11] = (r0 + r1) * VAMD_C2;
-  r0 = x[24] - x[8];
-  r1 = x[25] - x[9];
-  x[24] += x[8];
-  x[25] += x[9];
-  x[8] = r0 * VAMD_C3 - r1 * VAMD_C1;
-  x[9] = r1 * VAMD_C3 + r0 * VAMD_C1;
-  r0 = x[22] - x[6];
-  r1 = x[7] - x[23];
-  x[22] += x[6];
-  x[23] += x[7];
-  x[6] = r1;
-  x[7] = r0;
-  r0 = x[4] - x[20];
-  r1 = x[5] - x[21];
-  x[20] += x[4];
-  x[21] += x[5];
-  x[4] = r1 * VAMD_C1 + r0 * VAMD_C3;
-  x[5] = r1 * VAMD_C3 - r0 * VAMD_C1;
-  r0 = x[2] - x[18];
-  r1 = x[3] - x[19];
-  x[18] += x[2];
-  x[19] += x[3];
-  x[2] = (r1 + r0) * VAMD_C2;
-  x[3] = (r1 - r0) * VAMD_C2;
-  r0 = x[0] - x[16];
-  r1 = x[1] - x[17];
-  x[16] += x[0];
-  x[17] += x[1];
-  x[0] = r1 * VAMD_C3 + r0 * VAMD_C1;
-  x[1] = r1 * VAMD_C1 - r0 * VAMD_C3;
-  bfly16(x);
-  bfly16(x + 16);
+// eight points e[0..7] in place: first the four sums and four differences of the points four apart, then one
+// more add/subtract between them
+VAMD_DEV void bfly_level8(float *e) {
+  const float s0 = e[6] + e[2], t0 = e[6] - e[2], s1 = e[4] + e[0], t1 = e[4] - e[0];
+  const float t2 = e[5] - e[1], t3 = e[7] - e[3], s2 = e[5] + e[1], s3 = e[7] + e[3];
+  e[6] = s0 + s1;
+  e[4] = s0 - s1;
+  e[0] = t0 + t2;
+  e[2] = t0 - t2;
+  e[3] = t3 + t1;
+  e[1] = t3 - t1;
+  e[7] = s3 + s2;
+  e[5] = s3 - s2;
 }
 
 // The butterfly work vector lives in LDS with two floats of padding after every 32:
@@ -215,9 +192,9 @@ VAMD_DEV void bfly32(float *x) {
 // LOGN > 0 fixes the transform size at compile time (n = 2^LOGN): loop counts, strides and every index
 // expression derived from n then fold into constants and immediate offsets -- the stage is bound by
 // instruction issue, and a good part of its instructions is address arithmetic.  0 = take n from P.
-template <int LOGS = 0, int LOGN = 0>
+template <int LOGS = 0, int LOGN = 0, class Team = WaveTeam>
 VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in0, float *w0, float *out0, PhaseClock &pc,
-                                int in_stride = 0, int w_stride = 0, int out_stride = 0) {
+                                int in_stride = 0, int w_stride = 0, int out_stride = 0, const Team &tm = Team()) {
   const int n = LOGN ? (1 << LOGN) : P.n, n2 = n >> 1, n4 = n >> 2, n8 = n >> 3;
   const int log2n = LOGN ? LOGN : P.log2n;
   const float *__restrict__ trig = P.trig;
@@ -235,7 +212,7 @@ VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in0, float *w0, fl
   // Pair p writes w2[2p], w2[2p+1]; the three loops differ in which input
   // quarter is folded with which sign.  x0[0],x0[2] / x1[0],x1[2] of the reference
   // are the .x,.z / .y,.w lanes of two aligned quads of the input.
-  WAVE_FOR(pp, n4 << LOGS) {
+  TEAM_EACH(pp, n4 << LOGS, tm) {
     VAMD_MDCT_SPLIT(pp, log2n - 2)
     const int p = g_;
     const F2 T = *(const F2 *)(trig + n2 - 2 * (p + 1));
@@ -261,7 +238,7 @@ VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in0, float *w0, fl
     o.y = r1 * T.x - r0 * T.y;
     *(F2 *)(w2 + VAMD_PW(2 * p)) = o;
   }
-  WAVE_SYNC();
+  tm.sync();
   pc.mark(1);
 
   // mdct_butterflies, lib/mdct.c:316-336, on x = w2, points = n2.
@@ -272,13 +249,13 @@ VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in0, float *w0, fl
   const int nstages = log2n - 6;  // first + (log2n-7) generic passes
   for (int s = 0; s < nstages; s++) {
     const int pts = n2 >> s, lper = log2n - 3 - s, tstride = 4 << s;  // per = pts/4 = 1 << lper
-    WAVE_FOR(gg, n8 << LOGS) {
+    TEAM_EACH(gg, n8 << LOGS, tm) {
       VAMD_MDCT_SPLIT(gg, log2n - 3)
       const int g = g_;
       const int j = g >> lper, q = g & ((1 << lper) - 1);
       const int ia = pts * j + pts - 2 - 2 * q, ib = pts * j + (pts >> 1) - 2 - 2 * q;
       F2 *pa = (F2 *)(w2 + VAMD_PW(ia)), *pb = (F2 *)(w2 + VAMD_PW(ib));
-      const F2 T = *(const F2 *)(trig + tstride * q);
+      const F2 T = *(const F2 *)(trig + tstride * q);  // (packing these per stage, stride 1, was measured: no gain)
       F2 a = *pa, b = *pb;
       const float r0 = a.x - b.x, r1 = a.y - b.y;
       a.x += b.x;
@@ -288,41 +265,65 @@ VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in0, float *w0, fl
       *pa = a;
       *pb = b;
     }
-    WAVE_SYNC();
+    tm.sync();
   }
   pc.mark(2);
-  // 32-point butterflies, one group per lane, in registers
-  WAVE_FOR(gg, (n2 / 32) << LOGS) {
+  // the 32-, 16- and 8-point levels (see bfly_level32 above): one thread finishes a group of 32 in registers --
+  // one trip through LDS for all three levels (the stage is bound by the LDS pipe, not by idle lanes).  Group g
+  // starts at w2 + 34 g (== VAMD_PW(32 g)); inside a group the padded layout is plain.
+  TEAM_EACH(gg, (n2 / 32) << LOGS, tm) {
     VAMD_MDCT_SPLIT(gg, log2n - 6)
-    const int g = g_;
-    float v[32];
-    F2 *pg = (F2 *)(w2 + 34 * g);  // == VAMD_PW(32 g)
+    F2 *pg = (F2 *)(w2 + 34 * g_);
+    F2 e[16];
 #if VAMD_GPU
 #pragma unroll
 #endif
-    for (int k = 0; k < 16; k++) {
-      const F2 t = pg[k];
-      v[2 * k] = t.x;
-      v[2 * k + 1] = t.y;
+    for (int k = 0; k < 16; k++) e[k] = pg[k];
+#if VAMD_GPU
+#pragma unroll
+#endif
+    for (int a = 0; a < 8; a++) {
+      const PairOp r = bfly_level32(a, e[a], e[8 + a]);
+      e[a] = r.lo;
+      e[8 + a] = r.hi;
     }
-    bfly32(v);
 #if VAMD_GPU
 #pragma unroll
 #endif
-    for (int k = 0; k < 16; k++) {
-      F2 t;
-      t.x = v[2 * k];
-      t.y = v[2 * k + 1];
-      pg[k] = t;
+    for (int h = 0; h < 2; h++) {
+#if VAMD_GPU
+#pragma unroll
+#endif
+      for (int b2 = 0; b2 < 4; b2++) {
+        const PairOp r = bfly_level16(b2, e[8 * h + b2], e[8 * h + 4 + b2]);
+        e[8 * h + b2] = r.lo;
+        e[8 * h + 4 + b2] = r.hi;
+      }
+    }
+#if VAMD_GPU
+#pragma unroll
+#endif
+    for (int o = 0; o < 4; o++) {
+      float v[8] = {e[4 * o].x, e[4 * o].y, e[4 * o + 1].x, e[4 * o + 1].y, e[4 * o + 2].x, e[4 * o + 2].y, e[4 * o + 3].x, e[4 * o + 3].y};
+      bfly_level8(v);
+#if VAMD_GPU
+#pragma unroll
+#endif
+      for (int k = 0; k < 4; k++) {
+        F2 t;
+        t.x = v[2 * k];
+        t.y = v[2 * k + 1];
+        pg[4 * o + k] = t;
+      }
     }
   }
-  WAVE_SYNC();
+  tm.sync();
   pc.mark(3);
 
   // mdct_bitreverse, lib/mdct.c:346-394: reads x = w2 (upper half), writes the
   // lower half w[0..n2).  Unit u produces w[2u], w[2u+1], w[n2-2u-2], w[n2-2u-1].
   const int *__restrict__ bit = P.bitrev;
-  WAVE_FOR(uu, n8 << LOGS) {
+  TEAM_EACH(uu, n8 << LOGS, tm) {
     VAMD_MDCT_SPLIT(uu, log2n - 3)
     const int u = g_;
     const I2 bi = *(const I2 *)(bit + 2 * u);
@@ -343,11 +344,11 @@ VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in0, float *w0, fl
     *(F2 *)(w + 2 * u) = lo;
     *(F2 *)(w + n2 - 2 * u - 2) = hi;
   }
-  WAVE_SYNC();
+  tm.sync();
   pc.mark(4);
 
   // final rotate * scale, lib/mdct.c:552-561 -> out[n2]
-  WAVE_FOR(ii, n4 << LOGS) {
+  TEAM_EACH(ii, n4 << LOGS, tm) {
     VAMD_MDCT_SPLIT(ii, log2n - 2)
     const int i = g_;
     const F2 T = *(const F2 *)(trig + n2 + 2 * i);
@@ -355,7 +356,7 @@ VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in0, float *w0, fl
     out_lds[i] = (ab.x * T.x + ab.y * T.y) * P.mdct_scale;
     out_lds[n2 - 1 - i] = (ab.x * T.y - ab.y * T.x) * P.mdct_scale;
   }
-  WAVE_SYNC();
+  tm.sync();
 }
 #undef VAMD_MDCT_SPLIT
 
@@ -387,14 +388,14 @@ VAMD_DEV void st_pair(float *p, int t, float a, float b) {  // p[t-1] = a, p[t] 
 // i = ido column).  Here one flat loop over g = (k, m) with m in [0, ido/2) covers all
 // three: m = 0 does both k-only columns, m >= 1 the (k, i = 2m) butterfly.  ido is a power
 // of two (>= 4) for every pass but the first, so k and m are a shift and a mask.
-template <bool AL>
+template <bool AL, class Team>
 VAMD_DEV void radf4_wave(int ido, int l1, const float *__restrict__ cc, float *__restrict__ ch, const float *__restrict__ wa1,
-                         const float *__restrict__ wa2, const float *__restrict__ wa3) {
+                         const float *__restrict__ wa2, const float *__restrict__ wa3, const Team &tm) {
   const float hsqt2 = .70710678118654752f;
   const int t0 = l1 * ido;
   if (ido == 1) {
     // first pass: four contiguous outputs per k -> one 16-byte store (offset layout: index 4k at +1)
-    WAVE_FOR(k, l1) {
+    TEAM_EACH(k, l1, tm) {
       const float c1 = cc[t0 + k], c2 = cc[3 * t0 + k], c3 = cc[k], c4 = cc[2 * t0 + k];
       const float tr1 = c1 + c2, tr2 = c3 + c4;
       float *o = ch + 4 * k;
@@ -407,7 +408,7 @@ VAMD_DEV void radf4_wave(int ido, int l1, const float *__restrict__ cc, float *_
   }
   const int lh = 31 - __builtin_clz((unsigned)(ido >> 1));  // log2(ido/2)
   // the two k-only columns (i = 0 and i = ido), one lane per k
-  WAVE_FOR(k, l1) {
+  TEAM_EACH(k, l1, tm) {
     {
       {
         const int t1 = t0 + k * ido, t2 = 3 * t0 + k * ido, t3 = k * ido, t4 = 2 * t0 + k * ido;
@@ -433,7 +434,7 @@ VAMD_DEV void radf4_wave(int ido, int l1, const float *__restrict__ cc, float *_
     }
   }
   // the (k, i = 2m) butterflies, m >= 1 (the m = 0 slot of each k idles: k and m stay a shift and a mask)
-  WAVE_FOR(g, l1 << lh) {
+  TEAM_EACH(g, l1 << lh, tm) {
     const int k = g >> lh, m = g & ((1 << lh) - 1);
     if (m != 0) {
       const int i = 2 * m;
@@ -463,18 +464,19 @@ VAMD_DEV void radf4_wave(int ido, int l1, const float *__restrict__ cc, float *_
 }
 
 // dradf2, lib/smallft.c:113-166, same flattening
-template <bool AL>
-VAMD_DEV void radf2_wave(int ido, int l1, const float *__restrict__ cc, float *__restrict__ ch, const float *__restrict__ wa1) {
+template <bool AL, class Team>
+VAMD_DEV void radf2_wave(int ido, int l1, const float *__restrict__ cc, float *__restrict__ ch, const float *__restrict__ wa1,
+                         const Team &tm) {
   const int t0 = l1 * ido;
   if (ido == 1) {
-    WAVE_FOR(k, l1) {
+    TEAM_EACH(k, l1, tm) {
       ch[2 * k] = cc[k] + cc[t0 + k];
       ch[2 * k + 1] = cc[k] - cc[t0 + k];
     }
     return;
   }
   const int lh = 31 - __builtin_clz((unsigned)(ido >> 1));
-  WAVE_FOR(g, l1 << lh) {
+  TEAM_EACH(g, l1 << lh, tm) {
     const int k = g >> lh, m = g & ((1 << lh) - 1);
     if (m == 0) {
       {
@@ -508,8 +510,8 @@ VAMD_DEV void radf2_wave(int ido, int l1, const float *__restrict__ cc, float *_
 // LOGN > 0: n = 2^LOGN, whose FFTPACK factorisation is radix 4 throughout with one radix-2 pass at the end
 // when LOGN is odd (drfti1 tries 4 first and moves a leftover 2 to the front of ifac[], which drftf1
 // walks backwards: lib/smallft.c:35-70,572-631); vamd_create() checks the blob's factors against that.
-template <int LOGN = 0>
-VAMD_DEV const float *drft_forward_wave(const XformP &P, float *c, float *ch) {
+template <int LOGN = 0, class Team = WaveTeam>
+VAMD_DEV const float *drft_forward_wave(const XformP &P, float *c, float *ch, const Team &tm = Team()) {
   const int n = LOGN ? (1 << LOGN) : P.n, nf = LOGN ? (LOGN >> 1) + (LOGN & 1) : P.fft_nf;
   const float *__restrict__ wa = P.wa;
   float *bufc = c + 1, *bufh = ch + 1;  // offset layouts of the two buffers
@@ -527,17 +529,17 @@ VAMD_DEV const float *drft_forward_wave(const XformP &P, float *c, float *ch) {
       // the first pass reads the plain (un-offset) block; ld_pair<false> covers the case
       // where it has pairs to read (ido > 2)
       if (ip == 4)
-        radf4_wave<false>(ido, l1, c, dst, wa + iw - 1, wa + iw + ido - 1, wa + iw + 2 * ido - 1);
+        radf4_wave<false>(ido, l1, c, dst, wa + iw - 1, wa + iw + ido - 1, wa + iw + 2 * ido - 1, tm);
       else
-        radf2_wave<false>(ido, l1, c, dst, wa + iw - 1);
+        radf2_wave<false>(ido, l1, c, dst, wa + iw - 1, tm);
     } else {
       const float *src = na ? bufh : bufc;
       if (ip == 4)
-        radf4_wave<true>(ido, l1, src, dst, wa + iw - 1, wa + iw + ido - 1, wa + iw + 2 * ido - 1);
+        radf4_wave<true>(ido, l1, src, dst, wa + iw - 1, wa + iw + ido - 1, wa + iw + 2 * ido - 1, tm);
       else
-        radf2_wave<true>(ido, l1, src, dst, wa + iw - 1);
+        radf2_wave<true>(ido, l1, src, dst, wa + iw - 1, tm);
     }
-    WAVE_SYNC();
+    tm.sync();
     l2 = l1;
   }
   // the reference copies ch back into c when the last pass landed in ch; the caller
@@ -546,57 +548,68 @@ VAMD_DEV const float *drft_forward_wave(const XformP &P, float *c, float *ch) {
 }
 
 // The whole stage for one channel-block.
-//   pcm      HBM [n]           un-windowed block (vb->pcm[i])
-//   A, B     LDS [n] each
+//   A, B     LDS [n + 4], [n + n/32]
 //   outputs  HBM, each may be null
-// Returns the channel's local_ampmax (all lanes).
-// `tile` holds the un-windowed block (pcm_fetch); it is consumed before anything else, so the
-// caller may refill it for the next block as soon as this returns from its first phase.
-VAMD_DEV void transform_window(const XformP &P, int W, int lW, int nW, const PcmTile &tile, float *A,
-                               PhaseClock &pc) {
-  window_store(P, W, lW, nW, tile, A, true);
-  WAVE_SYNC();
+// `tile` holds the un-windowed block (pcm_fetch); it is consumed by transform_window, so the caller may refill
+// it for the next block as soon as that returns.
+template <int QPT, class Team>
+VAMD_DEV void transform_window(const XformP &P, int W, int lW, int nW, const PcmTile<QPT> &tile, float *A, PhaseClock &pc,
+                               const Team &tm) {
+  window_store(P, W, lW, nW, tile, A, true, tm);
+  tm.sync();
   pc.mark(0);
 }
 
-template <int LOGN = 0>
+// Returns the local_ampmax contribution of THIS WAVE (every lane holds it): the caller combines the team's waves.
+template <int LOGN = 0, class Team = WaveTeam>
 VAMD_DEV float transform_block(const XformP &P, float *A, float *B, float *__restrict__ mdct_out,
-                               float *__restrict__ logmdct_out, float *__restrict__ logfft_out, PhaseClock &pc) {
+                               float *__restrict__ logmdct_out, float *__restrict__ logfft_out, PhaseClock &pc,
+                               const Team &tm = Team()) {
   const int n = LOGN ? (1 << LOGN) : P.n, n2 = n >> 1;
 
-  // MDCT: spectrum lands in B[n2..n) (LDS), then goes out with its dB twin
-  mdct_forward_wave<0, LOGN>(P, A, B, B + n2, pc);
-  WAVE_FOR(j, n2) {
-    const float m = B[n2 + j];
-    if (mdct_out) mdct_out[j] = m;
-    if (logmdct_out) logmdct_out[j] = todB_345(m);  // lib/mapping0.c:384-385
+  // MDCT: spectrum lands in B[n2..n) (LDS), then goes out with its dB twin, 16 bytes per thread and tensor
+  mdct_forward_wave<0, LOGN, Team>(P, A, B, B + n2, pc, 0, 0, 0, tm);
+  TEAM_EACH(q, n2 >> 2, tm) {
+    float m[4], l[4];
+    f4_get(((const F4 *)(B + n2))[q], m);
+    for (int c = 0; c < 4; c++) l[c] = todB_345(m[c]);  // lib/mapping0.c:384-385
+    if (mdct_out) ((F4 *)mdct_out)[q] = f4_make(m);
+    if (logmdct_out) ((F4 *)logmdct_out)[q] = f4_make(l);
   }
-  WAVE_SYNC();
+  tm.sync();
 
   pc.mark(5);
   // FFT of the same windowed block (A), ping-ponging with B
-  const float *spec = drft_forward_wave<LOGN>(P, A, B);
+  const float *spec = drft_forward_wave<LOGN, Team>(P, A, B, tm);
   pc.mark(6);
 
-  // logfft + local ampmax, lib/mapping0.c:255-346
+  // logfft + local ampmax, lib/mapping0.c:255-346; four bins per thread
   const float scale = 4.f / n;
   const float scale_dB = todB_345(scale);
   float amp = -1e30f;
-  WAVE_FOR(k, n2) {
-    float v;
-    if (k == 0) {
-      v = (float)((double)(scale_dB + todB(spec[0])) + .345);
-    } else {
-      const F2 z = *(const F2 *)(spec + 2 * k - 1);  // (Re_k, Im_k), aligned in the offset layout
-      const float temp = z.x * z.x + z.y * z.y;
-      v = (float)((double)(scale_dB + .5f * todB(temp)) + .345);
+  TEAM_EACH(q, n2 >> 2, tm) {
+    // bins 4q .. 4q+3: (Re_k, Im_k) = (spec[2k-1], spec[2k]); spec - 1 is the buffer's 16-byte aligned start, so the
+    // four pairs are two aligned quads
+    float z[8], v[4];
+    f4_get(((const F4 *)(spec - 1))[2 * q], z);
+    f4_get(((const F4 *)(spec - 1))[2 * q + 1], z + 4);
+#if VAMD_GPU
+#pragma unroll
+#endif
+    for (int c = 0; c < 4; c++) {
+      if (4 * q + c == 0) {
+        v[c] = (float)((double)(scale_dB + todB(z[1])) + .345);  // bin 0: spec[0] alone
+      } else {
+        const float temp = z[2 * c] * z[2 * c] + z[2 * c + 1] * z[2 * c + 1];
+        v[c] = (float)((double)(scale_dB + .5f * todB(temp)) + .345);
+      }
+      amp = fmaxf(amp, v[c]);
     }
-    if (logfft_out) logfft_out[k] = v;
-    amp = fmaxf(amp, v);
+    if (logfft_out) ((F4 *)logfft_out)[q] = f4_make(v);
   }
   amp = wave_max(amp);
-  if (amp > 0.f) amp = 0.f;
-  WAVE_SYNC();
+  if (amp > 0.f) amp = 0.f;  // lib/mapping0.c:346 (the clamp commutes with the maximum over the team's waves)
+  tm.sync();
   pc.mark(7);
   return amp;
 }

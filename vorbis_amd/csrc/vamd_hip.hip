@@ -149,19 +149,14 @@ __global__ __launch_bounds__(64 * VAMD_XF_WAVES) void k_transform(XformP G, int 
   // cb = channel-block index = block*ch + channel
   const long cstride = (long)gridDim.x * nw;
   long cb = (long)blockIdx.x * nw + (threadIdx.x >> 6);
-  PcmTile tile;
-  const bool tiled = n <= 4 * 64 * VAMD_QPL2;  // the register tile holds blocks up to 2048 samples
-  if (tiled && cb < ncb) pcm_fetch(tile, pcm + cb * n, n);
+  constexpr int QPT = LOGN ? ((1 << LOGN) / 4 + 63) / 64 : 4096 / 4 / 64;  // quads of a block per lane
+  const WaveTeam tm;
+  PcmTile<QPT> tile;
+  if (cb < ncb) pcm_fetch(tile, pcm + cb * n, n, tm);
   for (; cb < ncb; cb += cstride) {
-    const long blk = cb / ch;
-    if (tiled) {
-      transform_window(P, W, d_lW(d, blk), d_nW(d, blk), tile, L.A, pc);
-      if (cb + cstride < ncb) pcm_fetch(tile, pcm + (cb + cstride) * n, n);  // next block, one ahead
-    } else {
-      window_store_hbm(P, W, d_lW(d, blk), d_nW(d, blk), pcm + cb * n, L.A);  // larger blocks: straight from HBM
-      WAVE_SYNC();
-      pc.mark(0);
-    }
+    const long blk = (long)((unsigned)cb / (unsigned)ch);
+    transform_window(P, W, d_lW(d, blk), d_nW(d, blk), tile, L.A, pc, tm);
+    if (cb + cstride < ncb) pcm_fetch(tile, pcm + (cb + cstride) * n, n, tm);  // next block, one ahead
     const float amp = transform_block<LOGN>(P, L.A, L.B, mdct_raw + cb * n2, logmdct + cb * n2, logfft + cb * n2, pc);
     if (LANE == 0) local_ampmax[cb] = amp;
   }
