@@ -200,6 +200,7 @@ int vamd_analyze_streams_mixed(vamd_ctx *ctx, const vamd_batch_desc *desc_short,
                                const vamd_batch_desc *desc_long, const vamd_batch_io *io_long, const int32_t *order,
                                const int64_t *stream_start, long nstreams, long nblocks_total, float *ampmax_states);
 
+
 /* ---- per-block host API: the compatibility path behind vorbis_analysis() -----
  * Host pointers.  pcm[ch] -> n samples each (vb->pcm); outputs sized as above for
  * nblocks == 1.  Latency-bound by design (one launch sequence + two PCIe
@@ -294,6 +295,43 @@ int vamd_encode_block(vamd_ctx *ctx, const float *const *pcm, int lW, int W, int
 
 /* winlength / searchstep of the detector (128 / 64 in every libvorbis setup). */
 int vamd_envelope_geometry(const vamd_ctx *ctx, int *winlength, int *searchstep);
+
+/* ---- device-resident stream control (reference lib/block.c:534-693 vorbis_analysis_blockout's decisions,
+ * lib/envelope.c:262-353 cursor walk and _ve_envelope_mark): whole streams in, block lists out, no host round
+ * trip per block.
+ *
+ * vamd_plan_streams: `nstreams` streams of `nsamples` samples per channel, device-resident -- stream s, channel c
+ * at pcm + s*stream_stride + c*channel_stride -- each laid out as the encoder's own PCM buffer would be had
+ * nothing been shifted out of it: what vorbis_analysis_buffer()/vorbis_analysis_wrote() accumulate, the
+ * start-of-stream pre-extrapolation included (lib/block.c:398-458: host code in the reference, the caller's
+ * here), so the first block is centred at blocksizes[1]/2.  Runs the block-switching detector over every
+ * stream (as vamd_envelope_search_batch; `states` [nstreams], device, all-zero = fresh streams, updated),
+ * then one thread per stream replays blockout's size / window / blocktype decisions and the plan's device
+ * arrays are filled.  A plan covers the blocks the reference hands out while the given data suffices
+ * (eofflag == 0); a caller closing a stream appends the reference's end-of-stream tail (lib/block.c:486-532)
+ * to the buffer first.  Synchronises the context's stream once (the block counts come back to size the
+ * outputs).  The plan's arrays belong to the context and stay valid until the next vamd_plan_streams on it.
+ *
+ * vamd_gather_blocks: the planned blocks of size class W copied out of the streams into a batch
+ * pcm_blocks[nblocks[W]][ch][blocksize[W]] (device), the layout vamd_analyze_streams_mixed takes -- whose
+ * descriptor arrays, order[] and stream_start[] are the plan's. */
+typedef struct vamd_stream_plan {
+  int64_t nstreams;
+  int64_t nblocks[2];            /* blocks of each size class over all streams */
+  const int32_t *lW[2], *nW[2], *blocktype[2];   /* device, per size class [nblocks[W]] */
+  const int64_t *src[2];         /* device [nblocks[W]]: offset of the block's first sample from `pcm` (channel 0) */
+  const int32_t *order;          /* device [nblocks[0] + nblocks[1]]: W << 30 | index, stream after stream */
+  const int64_t *stream_start;   /* device [nstreams + 1] into order[] */
+} vamd_stream_plan;
+
+int vamd_plan_streams(vamd_ctx *ctx, const float *pcm, long stream_stride, long channel_stride, long nstreams,
+                      long nsamples, vamd_envelope_state *states, vamd_stream_plan *plan);
+int vamd_gather_blocks(vamd_ctx *ctx, const vamd_stream_plan *plan, int W, const float *pcm, long channel_stride,
+                       float *pcm_blocks);
+/* A plan's lists copied to host arrays (any may be NULL): per size class W lW / nW / blocktype / src [nblocks[W]],
+ * order [nblocks[0] + nblocks[1]], stream_start [nstreams + 1].  Synchronises. */
+int vamd_plan_fetch(vamd_ctx *ctx, const vamd_stream_plan *plan, int32_t *const lW[2], int32_t *const nW[2],
+                    int32_t *const blocktype[2], int64_t *const src[2], int32_t *order, int64_t *stream_start);
 
 #ifdef __cplusplus
 }

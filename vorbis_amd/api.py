@@ -18,10 +18,16 @@ EXPORTED_SYMBOLS = ["vamd_create", "vamd_destroy", "vamd_last_error", "vamd_set_
                     "vamd_analyze_batch", "vamd_analyze_stream", "vamd_analyze_block", "vamd_profile",
                     "vamd_stage_ms", "vamd_debug_cycles", "vamd_analyze_stream_mixed", "vamd_envelope_search_batch",
                     "vamd_envelope_search", "vamd_envelope_geometry", "vamd_residue_capacity", "vamd_analyze_block_res", "vamd_analyze_batch_managed", "vamd_analyze_block_managed",
-                    "vamd_packet_capacity", "vamd_encode_block", "vamd_submaps", "vamd_residue_offset", "vamd_analyze_streams_mixed"]
+                    "vamd_packet_capacity", "vamd_encode_block", "vamd_submaps", "vamd_residue_offset", "vamd_analyze_streams_mixed",
+                    "vamd_plan_streams", "vamd_gather_blocks", "vamd_plan_fetch"]
 PACKETBLOBS = 15
 
 _vp = C.c_void_p
+
+
+class _Plan(C.Structure):
+    _fields_ = [("nstreams", C.c_int64), ("nblocks", C.c_int64 * 2), ("lW", _vp * 2), ("nW", _vp * 2), ("blocktype", _vp * 2),
+                ("src", _vp * 2), ("order", _vp), ("stream_start", _vp)]
 
 
 class _Desc(C.Structure):
@@ -108,6 +114,9 @@ def load_library():
     L.vamd_analyze_block_res.argtypes = [_vp, C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_float] + [_vp] * 10
     L.vamd_analyze_batch_managed.argtypes = [_vp, C.POINTER(_Desc), C.POINTER(_IO), C.POINTER(_MIO)]
     L.vamd_analyze_block_managed.argtypes = [_vp, C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_float] + [_vp] * 9
+    L.vamd_plan_streams.argtypes = [_vp, _vp, C.c_long, C.c_long, C.c_long, C.c_long, _vp, C.POINTER(_Plan)]
+    L.vamd_gather_blocks.argtypes = [_vp, C.POINTER(_Plan), C.c_int, _vp, C.c_long, _vp]
+    L.vamd_plan_fetch.argtypes = [_vp, C.POINTER(_Plan), _vp * 2, _vp * 2, _vp * 2, _vp * 2, _vp, _vp]
     L.vamd_packet_capacity.argtypes = [_vp, C.c_int]
     L.vamd_submaps.argtypes = [_vp, C.c_int]
     L.vamd_residue_offset.argtypes = [_vp, C.c_int, C.c_int]
@@ -449,6 +458,73 @@ class Analyzer:
                 k += 1
             res.append(cur)
         return res, st.cpu().numpy()
+
+    # ---- device-resident stream control: whole streams in, block lists out (vamd_plan_streams) ----
+    def plan_streams(self, streams, states=None):
+        """streams: cuda float32 [nstreams, ch, nsamples], each laid out as the encoder's own PCM buffer (first block
+        centred at blocksizes[1]/2).  Returns (plan, states): the plan struct (its device arrays belong to the
+        context and stay valid until the next plan_streams) and the detector states tensor."""
+        t = self.torch
+        self._need_tensor(streams, t.float32, "streams")
+        self._need(streams.dim() == 3 and streams.shape[1] == self.channels, "streams must be [nstreams, %d, nsamples]" % self.channels)
+        ns, ch, ln = streams.shape
+        if states is None:
+            states = t.zeros((ns, C.sizeof(EnvelopeState)), dtype=t.uint8, device=self._dev())
+        plan = _Plan()
+        self._bind_stream()
+        self._check(self.L.vamd_plan_streams(self.h, _vp(streams.data_ptr()), ch * ln, ln, ns, ln, _vp(states.data_ptr()),
+                                             C.byref(plan)))
+        return plan, states
+
+    def plan_lists(self, plan):
+        """A plan on the host: dict with per size class lW / nW / blocktype / src arrays, order and stream_start."""
+        out = {}
+        arrs = {}
+        for name, dt in (("lW", np.int32), ("nW", np.int32), ("blocktype", np.int32), ("src", np.int64)):
+            arrs[name] = [np.zeros(max(1, plan.nblocks[W]), dt) for W in (0, 1)]
+        order = np.zeros(max(1, plan.nblocks[0] + plan.nblocks[1]), np.int32)
+        start = np.zeros(plan.nstreams + 1, np.int64)
+        pair = lambda k: (_vp * 2)(_vp(arrs[k][0].ctypes.data), _vp(arrs[k][1].ctypes.data))  # noqa: E731
+        self._check(self.L.vamd_plan_fetch(self.h, C.byref(plan), pair("lW"), pair("nW"), pair("blocktype"), pair("src"),
+                                           _vp(order.ctypes.data), _vp(start.ctypes.data)))
+        for k, v in arrs.items():
+            out[k] = [v[W][:plan.nblocks[W]] for W in (0, 1)]
+        out["order"] = order[:plan.nblocks[0] + plan.nblocks[1]]
+        out["stream_start"] = start
+        return out
+
+    def gather_blocks(self, plan, W, streams, out=None):
+        """The planned blocks of size class W copied out of `streams` into [nblocks[W], ch, blocksize[W]]."""
+        t = self.torch
+        n = self.blocksizes[W]
+        if out is None:
+            out = t.empty((plan.nblocks[W], self.channels, n), dtype=t.float32, device=self._dev())
+        else:
+            self._need_tensor(out, t.float32, "out", numel=plan.nblocks[W] * self.channels * n)
+        self._bind_stream()
+        self._check(self.L.vamd_gather_blocks(self.h, C.byref(plan), W, _vp(streams.data_ptr()), streams.shape[2], _vp(out.data_ptr())))
+        return out
+
+    def analyze_plan(self, plan, pcm_blocks, outs, ampmax_states):
+        """vamd_analyze_streams_mixed over a plan: pcm_blocks / outs = per size class (index 0 short, 1 long) the gathered
+        batch and its output dict; ampmax_states: cuda float32 [nstreams], updated in place."""
+        t = self.torch
+        descs, ios = [], []
+        for W in (0, 1):
+            d = _Desc()
+            d.W, d.nblocks = W, plan.nblocks[W]
+            d.lW, d.nW, d.blocktype, d.ampmax_in = plan.lW[W], plan.nW[W], plan.blocktype[W], None
+            descs.append(d)
+            if plan.nblocks[W]:
+                self._need_tensor(pcm_blocks[W], t.float32, "pcm_blocks[%d]" % W, numel=plan.nblocks[W] * self.channels * self.blocksizes[W])
+                ios.append(self._io(pcm_blocks[W].reshape(plan.nblocks[W], self.channels, self.blocksizes[W]), outs[W]))
+            else:
+                ios.append(_IO())
+        self._need_tensor(ampmax_states, t.float32, "ampmax_states", numel=plan.nstreams)
+        self._bind_stream()
+        self._check(self.L.vamd_analyze_streams_mixed(self.h, C.byref(descs[0]), C.byref(ios[0]), C.byref(descs[1]), C.byref(ios[1]),
+                                                      plan.order, plan.stream_start, plan.nstreams, plan.nblocks[0] + plan.nblocks[1],
+                                                      _vp(ampmax_states.data_ptr())))
 
     def analyze_block(self, pcm, lW=1, W=1, nW=1, blocktype=BLOCKTYPE_LONG, ampmax_in=-9999.0):
         """vamd_analyze_block: host numpy pcm[ch][n] in, host numpy results out (the per-block

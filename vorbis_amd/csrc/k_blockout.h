@@ -1,0 +1,109 @@
+// k_blockout.h -- the block-size decisions of vorbis_analysis_blockout() (reference lib/block.c:534-693) and
+// the integer half of _ve_envelope_search() / _ve_envelope_mark() (lib/envelope.c:241-353), device-resident:
+// one THREAD per stream walks its whole mark sequence and emits the stream's block list, so that a set of
+// streams goes from PCM to analysed blocks without a host round trip per block.
+//
+// The reference keeps a sliding PCM buffer and shifts every position by the block advance after each block
+// (lib/block.c:649-685, _ve_envelope_shift); here every position is an ABSOLUTE sample index into the stream's
+// buffer as the encoder would hold it had nothing been shifted out (what vorbis_analysis_buffer/_wrote
+// accumulate, including the start-of-stream pre-extrapolation of lib/block.c:398-458, which is host code in
+// the reference and stays the caller's).  Shifting subtracts the same amount from both sides of every
+// comparison, so the decisions are the same.  The one asymmetry -- ve->curmark stops being shifted once it
+// is negative, lib/envelope.c:372 -- only ever makes an already out-of-range mark stay out of range.
+//
+// What a plan covers: the blocks the reference would hand out while the data given suffices, i.e. with
+// v->eofflag == 0 throughout.  The end-of-stream padding and its forced short blocks (lib/block.c:486-532,
+// :558-563) depend on the LPC extrapolation of the tail, host code again: a caller that closes a stream
+// appends that tail to the buffer and plans over it.
+#pragma once
+#include "vamd_wave.h"
+
+namespace vamd {
+
+#define VAMD_VE_WIN 4   // lib/envelope.h:23
+#define VAMD_VE_POST 2  // lib/envelope.h:24
+
+struct BlockoutP {
+  int bs[2];        // blocksizes
+  int searchstep;   // 64
+  long nsamples;    // samples per channel in each stream's buffer
+  long nsteps;      // detector steps available per stream (flags[s][0 .. nsteps))
+  int maxblocks;    // capacity of a stream's row in `blocks`
+};
+
+// one planned block: W | lW << 1 | nW << 2 | blocktype << 3 in `kind`, and where its window starts
+struct PlannedBlock {
+  int kind;
+  int begin;  // first sample of the block's window in the stream's buffer (centerW - blocksize/2)
+};
+
+// ve->mark[p] once every step that can touch it has run (lib/envelope.c:241-258): step j clears mark[j+2],
+// then a pre-echo flag (1) marks j and j+1, a post-echo flag (2) marks j and j-1.  The clear of p happens at
+// step p-2, before any of its setters (steps p-1, p, p+1), so the final value is the OR of those.
+VAMD_DEV int mark_at(const unsigned char *__restrict__ flags, long nsteps, long p) {
+  int m = 0;
+  if (p < 0) return 0;
+  if (p >= 1 && p - 1 < nsteps) m |= flags[p - 1] & 1;
+  if (p < nsteps) m |= flags[p] & 3;
+  if (p + 1 < nsteps) m |= flags[p + 1] & 2;
+  return m != 0;
+}
+
+// The walk for one stream.  Returns the number of blocks planned (<= maxblocks) and counts per size class.
+VAMD_DEV int plan_stream(const BlockoutP &B, const unsigned char *__restrict__ flags, PlannedBlock *__restrict__ out,
+                         int *count_short, int *count_long) {
+  const long step = B.searchstep;
+  // vorbis_analysis_init / _ve_envelope_init: lib/block.c:211-213, lib/envelope.c:41
+  int W = 0, lW = 0;
+  long centerW = B.bs[1] / 2, cursor = B.bs[1] / 2, curmark = 0;
+  // what _ve_envelope_search has marked: steps [0, last), last = pcm_current/searchstep - VE_WIN (:223-224)
+  long last = B.nsamples / step - VAMD_VE_WIN;
+  if (last > B.nsteps) last = B.nsteps;
+  const long current = last * step;
+  int n = 0, n0 = 0, n1 = 0;
+  while (n < B.maxblocks) {
+    // ---- _ve_envelope_search's cursor walk, lib/envelope.c:262-325
+    const long testW = centerW + B.bs[W] / 4 + B.bs[1] / 2 + B.bs[0] / 4;
+    int bp = -1;
+    for (long j = cursor; j < current - step; j += step) {
+      if (j >= testW) {
+        bp = 1;
+        break;
+      }
+      cursor = j;
+      if (mark_at(flags, last, j / step) && j > centerW) {
+        curmark = j;
+        bp = j >= testW ? 1 : 0;
+        break;
+      }
+    }
+    if (bp < 0) break;  // "not enough data currently to search for a full long block", lib/block.c:558-560
+    const int nW = B.bs[0] == B.bs[1] ? 0 : bp;
+    const long centerNext = centerW + B.bs[W] / 4 + B.bs[nW] / 4;
+    if (B.nsamples < centerNext + B.bs[nW] / 2) break;  // lib/block.c:574-583
+    // ---- the block, lib/block.c:589-611
+    int blocktype;
+    if (W) {
+      blocktype = (!lW || !nW) ? 0 /* BLOCKTYPE_TRANSITION */ : 1 /* BLOCKTYPE_LONG */;
+    } else {
+      // _ve_envelope_mark, lib/envelope.c:329-353 (W == 0: both neighbours count as short)
+      const long beginW = centerW - B.bs[0] / 4 - B.bs[0] / 4, endW = centerW + B.bs[0] / 4 + B.bs[0] / 4;
+      int hit = curmark >= beginW && curmark < endW;
+      for (long i = beginW / step; !hit && i < endW / step; i++) hit = mark_at(flags, last, i);
+      blocktype = hit ? 0 /* BLOCKTYPE_IMPULSE */ : 1 /* BLOCKTYPE_PADDING */;
+    }
+    out[n].kind = W | (lW << 1) | (nW << 2) | (blocktype << 3);
+    out[n].begin = (int)(centerW - B.bs[W] / 2);
+    n++;
+    if (W) n1++; else n0++;
+    // ---- advance, lib/block.c:649-685 (positions stay absolute: nothing to shift)
+    lW = W;
+    W = nW;
+    centerW = centerNext;
+  }
+  *count_short = n0;
+  *count_long = n1;
+  return n;
+}
+
+}  // namespace vamd

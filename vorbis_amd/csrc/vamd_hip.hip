@@ -29,6 +29,7 @@
 #include "k_envelope.h"
 #include "k_residue.h"
 #include "k_pack.h"
+#include "k_blockout.h"
 
 using namespace vamd;
 
@@ -621,6 +622,54 @@ __global__ __launch_bounds__(64) void k_env_walk(int ch, long nstreams, long nst
   }
 }
 
+// ---- device-resident stream control (k_blockout.h) ----------------------------------------------------
+__global__ void k_plan_streams(BlockoutP B, long nstreams, const unsigned char *__restrict__ flags,
+                               PlannedBlock *__restrict__ blocks, int *__restrict__ counts) {
+  const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nstreams) return;
+  int n0 = 0, n1 = 0;
+  plan_stream(B, flags + s * B.nsteps, blocks + s * B.maxblocks, &n0, &n1);
+  counts[2 * s] = n0;
+  counts[2 * s + 1] = n1;
+}
+
+// base[2s + W] = index of stream s's first block inside size class W's batch; start[s] = into order[]
+struct PlanOut {
+  int *lW[2], *nW[2], *bt[2];
+  long long *src[2];
+  int *order;
+};
+__global__ void k_plan_emit(BlockoutP B, long nstreams, long stream_stride, const PlannedBlock *__restrict__ blocks,
+                            const int *__restrict__ counts, const long long *__restrict__ base,
+                            const long long *__restrict__ start, PlanOut O) {
+  const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nstreams) return;
+  const int n = counts[2 * s] + counts[2 * s + 1];
+  long long at[2] = {base[2 * s], base[2 * s + 1]};
+  for (int k = 0; k < n; k++) {
+    const PlannedBlock b = blocks[s * B.maxblocks + k];
+    const int W = b.kind & 1;
+    const long long i = at[W]++;
+    O.lW[W][i] = (b.kind >> 1) & 1;
+    O.nW[W][i] = (b.kind >> 2) & 1;
+    O.bt[W][i] = (b.kind >> 3) & 1;
+    O.src[W][i] = (long long)s * stream_stride + b.begin;
+    O.order[start[s] + k] = (W << 30) | (int)i;
+  }
+}
+
+// out[b][c][0 .. n) = pcm[src[b] + c*channel_stride ..): one 16-byte piece per thread
+__global__ void k_gather_blocks(int ch, int n, long nb, const long long *__restrict__ src, long channel_stride,
+                                const float *__restrict__ pcm, float *__restrict__ out) {
+  const long nq = n >> 2, total = nb * ch * nq;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const long b = t / (ch * nq), r = t - b * ch * nq;
+    const int c = (int)(r / nq);
+    const long q = r - c * nq;
+    ((F4 *)out)[t] = ((const F4 *)(pcm + src[b] + (long)c * channel_stride))[q];
+  }
+}
+
 struct DevBuf {
   void *p = nullptr;
   size_t bytes = 0;
@@ -644,7 +693,8 @@ struct vamd_ctx {
   enum { WS_MDCT_RAW, WS_LOGMDCT, WS_LOGFFT, WS_NOISE, WS_TONE, WS_MDCT, WS_ILOGMASK, WS_IWORK, WS_POSTS, WS_POSTVALID,
          WS_NONZERO, WS_LOCAL, WS_AMPIN, WS_AMPGLOB, WS_PCM, WS_SEED, WS_SURV, WS_NSURV, WS_MISC,
          WS_ENV_NEAR, WS_ENV_RAW, WS_ENV_AMP, WS_ENV_BITS, WS_ENV_STAGE, WS_M_ILOGMASK, WS_M_STAGE,
-         WS_RES_CLASS, WS_RES_ENTRIES, WS_RES_COUNT, WS_COUPLE_STATE, WS_COUNT };
+         WS_RES_CLASS, WS_RES_ENTRIES, WS_RES_COUNT, WS_COUPLE_STATE,
+         WS_PLAN_FLAGS, WS_PLAN_BLOCKS, WS_PLAN_COUNTS, WS_PLAN_BASE, WS_PLAN_DESC, WS_PLAN_ORDER, WS_COUNT };
   DevBuf ws[2][WS_COUNT];  // per size class (a mixed stream keeps both batches in flight)
   // pinned staging for the per-block host API
   void *h_stage = nullptr;
@@ -1701,6 +1751,127 @@ int vamd_envelope_search(vamd_ctx *c, const float *const *pcm, long nsteps, vamd
   HIP_TRY(c, hipStreamSynchronize(s));
   memcpy(state, hs + o_state, sizeof(*state));
   memcpy(ret, hs + o_ret, (size_t)nsteps);
+  return VAMD_OK;
+}
+
+int vamd_plan_streams(vamd_ctx *c, const float *pcm, long stream_stride, long channel_stride, long nstreams, long nsamples,
+                      vamd_envelope_state *states, vamd_stream_plan *plan) {
+  DeviceGuard dev_guard(c);
+  if (!c) return VAMD_EINVAL;
+  if (!plan) return fail(c, VAMD_EINVAL, "null plan");
+  memset(plan, 0, sizeof(*plan));
+  if (nstreams < 0 || nsamples < 0) return fail(c, VAMD_EINVAL, "negative stream / sample count");
+  if (nstreams == 0) return VAMD_OK;
+  if (!pcm || !states) return fail(c, VAMD_EINVAL, "null pcm / states");
+  if ((stream_stride | channel_stride) & 3) return fail(c, VAMD_EINVAL, "stream / channel strides must be multiples of 4 samples");
+  if (nstreams > 0x3fffffffL || nsamples > 0x3fffffffL) return fail(c, VAMD_EINVAL, "too many streams / samples for one plan");
+  const EnvP &E = c->B.env;
+  BlockoutP B;
+  B.bs[0] = c->B.bs[0];
+  B.bs[1] = c->B.bs[1];
+  B.searchstep = E.searchstep;
+  B.nsamples = nsamples;
+  B.nsteps = nsamples / E.searchstep - VAMD_VE_WIN;  // the steps _ve_envelope_search takes with this much data (lib/envelope.c:223-224)
+  if (B.nsteps < 0) B.nsteps = 0;
+  B.maxblocks = (int)(nsamples / (B.bs[0] / 2)) + 2;  // a block advances the stream by at least blocksizes[0]/2
+  plan->nstreams = nstreams;
+  void *v_flags, *v_blocks, *v_counts, *v_base;
+  int r;
+  if ((r = ws_get(c, 0, vamd_ctx::WS_PLAN_FLAGS, (size_t)nstreams * (B.nsteps ? B.nsteps : 1), &v_flags))) return r;
+  if ((r = ws_get(c, 0, vamd_ctx::WS_PLAN_BLOCKS, (size_t)nstreams * B.maxblocks * sizeof(PlannedBlock), &v_blocks))) return r;
+  if ((r = ws_get(c, 0, vamd_ctx::WS_PLAN_COUNTS, (size_t)nstreams * 2 * sizeof(int), &v_counts))) return r;
+  if ((r = ws_get(c, 0, vamd_ctx::WS_PLAN_BASE, (size_t)(3 * nstreams + 1) * sizeof(long long), &v_base))) return r;
+  if (B.nsteps && (r = vamd_envelope_search_batch(c, pcm, stream_stride, channel_stride, nstreams, B.nsteps, states, (unsigned char *)v_flags)))
+    return r;
+  hipStream_t s = c->stream;
+  hipLaunchKernelGGL(k_plan_streams, dim3((unsigned)((nstreams + 63) / 64)), dim3(64), 0, s, B, nstreams,
+                     (const unsigned char *)v_flags, (PlannedBlock *)v_blocks, (int *)v_counts);
+  std::vector<int> counts((size_t)nstreams * 2);
+  HIP_TRY(c, hipMemcpyAsync(counts.data(), v_counts, counts.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  std::vector<long long> base((size_t)3 * nstreams + 1);  // [2s + W] then start[nstreams + 1]
+  long long tot[2] = {0, 0}, all = 0;
+  for (long i = 0; i < nstreams; i++) {
+    base[2 * i] = tot[0];
+    base[2 * i + 1] = tot[1];
+    base[2 * nstreams + i] = all;
+    tot[0] += counts[2 * i];
+    tot[1] += counts[2 * i + 1];
+    all += counts[2 * i] + counts[2 * i + 1];
+  }
+  base[3 * nstreams] = all;
+  if (tot[0] > 0x3fffffffLL || tot[1] > 0x3fffffffLL) return fail(c, VAMD_EINVAL, "plan too large: order[] holds 30-bit indices");
+  HIP_TRY(c, hipMemcpyAsync(v_base, base.data(), base.size() * sizeof(long long), hipMemcpyHostToDevice, s));
+  // descriptor arrays: per class lW, nW, blocktype (int32) and src (int64); then order
+  void *v_desc, *v_order;
+  const size_t per[2] = {(size_t)tot[0], (size_t)tot[1]};
+  const size_t desc_bytes = (per[0] + per[1]) * (3 * sizeof(int) + sizeof(long long)) + 64;
+  if ((r = ws_get(c, 0, vamd_ctx::WS_PLAN_DESC, desc_bytes, &v_desc))) return r;
+  if ((r = ws_get(c, 0, vamd_ctx::WS_PLAN_ORDER, (size_t)(all ? all : 1) * sizeof(int), &v_order))) return r;
+  PlanOut O;
+  long long *p64 = (long long *)v_desc;  // the 8-byte arrays first (alignment)
+  O.src[0] = p64;
+  O.src[1] = p64 + per[0];
+  int *p32 = (int *)(p64 + per[0] + per[1]);
+  for (int W = 0; W < 2; W++) {
+    O.lW[W] = p32, p32 += per[W];
+    O.nW[W] = p32, p32 += per[W];
+    O.bt[W] = p32, p32 += per[W];
+  }
+  O.order = (int *)v_order;
+  hipLaunchKernelGGL(k_plan_emit, dim3((unsigned)((nstreams + 63) / 64)), dim3(64), 0, s, B, nstreams, stream_stride,
+                     (const PlannedBlock *)v_blocks, (const int *)v_counts, (const long long *)v_base,
+                     (const long long *)v_base + 2 * nstreams, O);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipStreamSynchronize(s));  // `base` (host) must outlive its upload
+  for (int W = 0; W < 2; W++) {
+    plan->nblocks[W] = tot[W];
+    plan->lW[W] = O.lW[W];
+    plan->nW[W] = O.nW[W];
+    plan->blocktype[W] = O.bt[W];
+    plan->src[W] = (const int64_t *)O.src[W];
+  }
+  plan->order = O.order;
+  plan->stream_start = (const int64_t *)((const long long *)v_base + 2 * nstreams);
+  return VAMD_OK;
+}
+
+int vamd_gather_blocks(vamd_ctx *c, const vamd_stream_plan *plan, int W, const float *pcm, long channel_stride,
+                       float *pcm_blocks) {
+  DeviceGuard dev_guard(c);
+  if (!c) return VAMD_EINVAL;
+  if (!plan || (W != 0 && W != 1)) return fail(c, VAMD_EINVAL, "null plan / bad size class");
+  const long nb = plan->nblocks[W];
+  if (nb == 0) return VAMD_OK;
+  if (!pcm || !pcm_blocks) return fail(c, VAMD_EINVAL, "null pcm / pcm_blocks");
+  if (channel_stride & 3) return fail(c, VAMD_EINVAL, "channel stride must be a multiple of 4 samples");
+  const int ch = c->B.channels, n = c->B.bs[W];
+  const long total = nb * ch * (n / 4);
+  const long blocks = (total + 255) / 256;
+  const long cap = (long)c->num_cus * 16;
+  hipLaunchKernelGGL(k_gather_blocks, dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(256), 0, c->stream, ch, n, nb,
+                     (const long long *)plan->src[W], channel_stride, pcm, pcm_blocks);
+  HIP_TRY(c, hipGetLastError());
+  return VAMD_OK;
+}
+
+int vamd_plan_fetch(vamd_ctx *c, const vamd_stream_plan *plan, int32_t *const lW[2], int32_t *const nW[2],
+                    int32_t *const blocktype[2], int64_t *const src[2], int32_t *order, int64_t *stream_start) {
+  DeviceGuard dev_guard(c);
+  if (!c) return VAMD_EINVAL;
+  if (!plan) return fail(c, VAMD_EINVAL, "null plan");
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (int W = 0; W < 2; W++) {
+    const size_t n = (size_t)plan->nblocks[W];
+    if (!n) continue;
+    if (lW && lW[W]) HIP_TRY(c, hipMemcpy(lW[W], plan->lW[W], n * 4, hipMemcpyDeviceToHost));
+    if (nW && nW[W]) HIP_TRY(c, hipMemcpy(nW[W], plan->nW[W], n * 4, hipMemcpyDeviceToHost));
+    if (blocktype && blocktype[W]) HIP_TRY(c, hipMemcpy(blocktype[W], plan->blocktype[W], n * 4, hipMemcpyDeviceToHost));
+    if (src && src[W]) HIP_TRY(c, hipMemcpy(src[W], plan->src[W], n * 8, hipMemcpyDeviceToHost));
+  }
+  const size_t all = (size_t)(plan->nblocks[0] + plan->nblocks[1]);
+  if (order && all) HIP_TRY(c, hipMemcpy(order, plan->order, all * 4, hipMemcpyDeviceToHost));
+  if (stream_start && plan->nstreams) HIP_TRY(c, hipMemcpy(stream_start, plan->stream_start, (size_t)(plan->nstreams + 1) * 8, hipMemcpyDeviceToHost));
   return VAMD_OK;
 }
 
