@@ -37,6 +37,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 ach
 # algorithmic HBM bytes per unit, fp32/int32, every tensor touched once, tables excluded
 # (restated in DESIGN.md 5)
 ALG_BYTES = {
+    "c5": None,    # mixed sizes: 5248 B per short (256-sample) and 41216 B per long stereo block, see StreamRunner
     "c2": 12288,   # per channel-frame: 8192 in + 4096 out
     "c3": 40960,   # per stereo block: 16384 in + mdct 8192 + noise 8192 + tone 8192
     "c4": 41216,   # per stereo block: 16384 in + mdct 8192 + logmask 8192 + iwork 8192 + 256 posts/flags
@@ -92,9 +93,11 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=("c2", "c3", "c4"), default="c4")
+    ap.add_argument("--workload", choices=("c2", "c3", "c4", "c5"), default="c4")
     ap.add_argument("--blocks", type=int, default=None, help="stereo blocks per GPU (default 131072; c2/c3: 65536)")
-    ap.add_argument("--setup", default="44k_stereo_q4")
+    ap.add_argument("--setup", default=None, help="setup blob name (default 44k_stereo_q4; c5: 44k_stereo_q9)")
+    ap.add_argument("--streams", type=int, default=1024, help="c5: streams per GPU")
+    ap.add_argument("--stream-samples", type=int, default=131072, help="c5: samples per channel and stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-neighbours", action="store_true", help="skip the informational extra stages (profiling runs)")
     ap.add_argument("--no-parity-sample", action="store_true", help="skip the post-run oracle check of the timed batch")
@@ -102,7 +105,10 @@ def parse(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only for the CPU rehearsal of the rank logic)")
-    return ap.parse_args(argv)
+    a = ap.parse_args(argv)
+    if a.setup is None:
+        a.setup = "44k_stereo_q9" if a.workload == "c5" else "44k_stereo_q4"
+    return a
 
 
 def cpu_baseline(setup_name, seconds):
@@ -316,6 +322,95 @@ class GpuRunner:
         return neighbour_stages(self.an, self.pcm, self.outs, self.nb)
 
 
+class StreamRunner:
+    """BASELINE config 5: many gated-noise streams resident in HBM; a step plans them on the device (block-switching
+    detector + the blockout decisions, vamd_plan_streams), gathers the planned blocks of both sizes and analyses them
+    with each stream's ampmax chain (vamd_analyze_streams_mixed).  Units = blocks of either size."""
+
+    def __init__(self, a, blob, dev, rank, world):
+        import vorbis_amd
+        self.a, self.dev, self.rank = a, dev, rank
+        self.an = an = vorbis_amd.Analyzer(blob, device=dev.index)
+        ch = an.channels
+        ns, ln = a.streams, a.stream_samples & ~3
+        g = torch.Generator(device=dev)
+        g.manual_seed(4321 + rank)
+        # noise gated by bursts at stream-dependent periods: bursts trigger short blocks, the quiet stretches run long
+        t = torch.arange(ln, device=dev)
+        period = (6000 + 977 * torch.arange(ns, device=dev) % 9000).view(ns, 1)
+        gate = torch.where((t.view(1, ln) % period) < 600, 0.5, 0.0005).view(ns, 1, ln)
+        self.streams = ((torch.rand((ns, ch, ln), generator=g, device=dev) - 0.5) * 2 * gate).contiguous()
+        self.want = ("mdct", "logmask", "posts", "post_valid", "iwork", "nonzero", "ampmax_out")
+        self.unit_name = "stereo blocks/s (256- and 2048-sample)"
+        self._run(alloc=True)
+        self.units = int(self.plan.nblocks[0] + self.plan.nblocks[1])
+
+    def _run(self, alloc=False):
+        an = self.an
+        self.plan, _ = an.plan_streams(self.streams)
+        if alloc:
+            self.blocks = [torch.empty((self.plan.nblocks[W], an.channels, an.blocksizes[W]), device=self.dev) for W in (0, 1)]
+            self.outs = [an.alloc_outputs(W, self.plan.nblocks[W], self.want) for W in (0, 1)]
+            for W in (0, 1):
+                an.reserve(W, max(1, self.plan.nblocks[W]))
+            self.amp = torch.empty(self.streams.shape[0], device=self.dev)
+        for W in (0, 1):
+            an.gather_blocks(self.plan, W, self.streams, out=self.blocks[W])
+        self.amp.fill_(-9999.0)
+        an.analyze_plan(self.plan, self.blocks, self.outs, self.amp)
+
+    def step(self):
+        self._run()
+
+    def sync(self):
+        torch.cuda.synchronize()
+
+    def timed_begin(self):
+        self.an.profile(True)
+
+    def timed_end(self):
+        pass
+
+    def stage_ms(self, steps):
+        ms, runs = self.an.stage_ms()
+        self.an.profile(False)
+        return {k: v / max(runs, 1) for k, v in ms.items() if v > 0}
+
+    def alg_bytes(self):
+        return 5248 * int(self.plan.nblocks[0]) + 41216 * int(self.plan.nblocks[1])
+
+    def parity_sample(self, count):
+        """Randomly chosen planned blocks: window flags, block type and every output against the CPU checker fed the
+        gathered block and the chain's incoming ampmax (decay of the previous block's, from the timed outputs)."""
+        from tests import checker
+        chk = checker.Checker(self.a.setup)
+        L = self.an.plan_lists(self.plan)
+        rng = np.random.default_rng(99 + self.rank)
+        order, start = L["order"], L["stream_start"]
+        pick = np.sort(rng.choice(len(order), size=min(count, len(order)), replace=False))
+        bad = 0
+        amp_out = [self.outs[W]["ampmax_out"].cpu().numpy() for W in (0, 1)]
+        for k in pick:
+            s = int(np.searchsorted(start, k, side="right") - 1)
+            W, i = (int(order[k]) >> 30) & 1, int(order[k]) & 0x3fffffff
+            prev = -9999.0
+            if k > start[s]:
+                pW, pi = (int(order[k - 1]) >> 30) & 1, int(order[k - 1]) & 0x3fffffff
+                prev = float(amp_out[pW][pi])
+            amp_in = chk.enc.ampmax_decay(prev, W)
+            pcm = self.blocks[W][i].cpu().numpy()
+            ref = chk.tap_block(pcm, int(L["lW"][W][i]), W, int(L["nW"][W][i]), int(L["blocktype"][W][i]), amp_in)
+            got = {kk: v[i].cpu().numpy() for kk, v in self.outs[W].items()}
+            bad += checker.compare_block(ref, got, self.an.posts[W]) != 0
+        return len(pick), bad, chk.kind
+
+    def workload_text(self):
+        return ("C5 mixed short/long-block streams: %d gated-noise stereo streams x %d samples per GPU, 44.1 kHz q=0.9 tables; per step: "
+                "block-switching detector + blockout decisions on the device (vamd_plan_streams), gather, full analysis of the "
+                "%d short and %d long blocks with per-stream ampmax chains" % (self.streams.shape[0], self.streams.shape[2],
+                                                                               self.plan.nblocks[0], self.plan.nblocks[1]))
+
+
 def main(argv=None, make_runner=None):
     """`make_runner(a, blob, dev, rank, world)` replaces the GPU runner; only the CPU rehearsal of the rank logic
     (tests/test_abi_and_host.py, gloo, world size 2) passes one."""
@@ -324,7 +419,7 @@ def main(argv=None, make_runner=None):
     import vorbis_amd
     # rank 0 owns the setup blob; everyone else receives it over RCCL -- the job's only collective besides timing
     blob = sharding.broadcast_blob(vorbis_amd.default_setup_blob(a.setup) if rank == 0 else None, dev)
-    R = (make_runner or GpuRunner)(a, blob, dev, rank, world)
+    R = (make_runner or (StreamRunner if a.workload == "c5" else GpuRunner))(a, blob, dev, rank, world)
 
     for _ in range(a.warmup):
         R.step()
@@ -357,7 +452,7 @@ def main(argv=None, make_runner=None):
         value = world * units * a.steps / elapsed
         kernels_ms = sum(stage_ms.values())
         dom = max(stage_ms, key=stage_ms.get)
-        alg = ALG_BYTES[a.workload] * units                      # bytes per step per GPU, algorithmic
+        alg = R.alg_bytes() if a.workload == "c5" else ALG_BYTES[a.workload] * units   # bytes per step per GPU, algorithmic
         achieved = alg / (kernels_ms * 1e-3) / 1e9                # GB/s over the path's kernels
         dom_bytes = (STAGE_BYTES.get(dom, ALG_BYTES["c2"]) * units)
         traffic, traffic_per, traffic_note = measured_traffic(a.workload, units)
@@ -367,9 +462,8 @@ def main(argv=None, make_runner=None):
         roof = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
-            "definition": "algorithmic bytes of the whole path per step (%d B/unit x %d units) / summed "
-                          "HIP-event segments of the path's stages on the launch stream per step"
-                          % (ALG_BYTES[a.workload], units),
+            "definition": "algorithmic bytes of the whole path per step (%d B over %d units) / summed "
+                          "HIP-event segments of the path's stages on the launch stream per step" % (alg, units),
             "kernels_ms_per_step": stage_ms,
             "dominant_kernel": {"name": dom, "ms": stage_ms[dom], "own_bytes_per_step": dom_bytes,
                                 "own_GBps": dom_bytes / (stage_ms[dom] * 1e-3) / 1e9, "traffic": dom_traffic},
