@@ -6,7 +6,9 @@ summaries under profiles/:  rNN_kernel_trace_stats.txt, rNN_pmc_hbm_traffic.txt,
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "profile")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
+sys.path.insert(0, ROOT)
+import bench as bench_mod  # noqa: E402  (source_hash: the profile is stamped with the sources it was taken from)
 NB_PMC = 65536  # tools/prof_run.py 65536 1
 
 
@@ -32,9 +34,9 @@ with open(os.path.join(ROOT, "profiles", TAG + "_kernel_trace_stats.txt"), "w") 
     f.write("# MI355X (gfx950).  %d stereo 2048-blocks per step (C4 full analysis), 6 launches of each stage\n"
             % bench["config"]["blocks_per_gpu"])
     f.write("# kernel = 1 warm-up + 5 timed steps.  Durations in microseconds (rocpd `top_kernels` view).\n")
-    f.write("# k_tone_seed / k_tone_chase / k_tone_fold run on the library's side stream CONCURRENTLY with k_noise\n")
-    f.write("# (fork after the transform, join before the floor fit), so their durations overlap k_noise's and the\n")
-    f.write("# column does not add up to the step time.\n")
+    f.write("# k_tone_seed / k_tone_chase / k_tone_fold are issued on the library's side stream beside k_noise (fork after the\n")
+    f.write("# transform, join before the floor fit); k_noise is persistent and fills the CUs, so they mostly run after it.\n")
+    f.write("# source hash %s\n" % bench_mod.source_hash())
     f.write("# bench.py's own line from the same run: %.2f M stereo blocks/s, %.2f ms/step; its HIP-event figure for\n"
             % (bench["value"] / 1e6, bench["ms_per_step"]))
     f.write("# the dominant kernel (k_noise): %.3f ms per launch.\n" % bench["roofline"]["dominant_kernel"]["ms"])
@@ -60,6 +62,7 @@ for k in fetch:
         per[k] = {"read_B_per_stereo_block": 2 * fetch[k] * 1024 / NB_PMC,
                   "write_B_per_stereo_block": write[k] * 1024 / NB_PMC}
 out = {
+    "source_hash": bench_mod.source_hash(),
     "source": "profiles/%s_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, "
               "65536 stereo blocks; FETCH_SIZE x2 per calibration)" % TAG,
     "workload": "c4",
@@ -69,3 +72,13 @@ out = {
 }
 json.dump(out, open(os.path.join(ROOT, "profiles", TAG + "_pmc_traffic.json"), "w"), indent=1)
 print("total B/stereo block %.0f, mdct-only B/frame %.0f" % (out["total_B_per_stereo_block"], out["mdct_only_B_per_frame"]))
+c5 = os.path.join(SRC, "kernel_trace_stats_c5.txt")
+if os.path.exists(c5):
+    b5 = json.loads(open(os.path.join(SRC, "bench_c5_under_rocprof.json")).read().strip().splitlines()[-1])
+    with open(os.path.join(ROOT, "profiles", TAG + "_c5_kernel_trace_stats.txt"), "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --workload c5 --steps 3 --warmup 1 --no-cpu-baseline\n")
+        f.write("# %s\n" % b5["config"]["workload"])
+        f.write("# bench.py's own line from the same run: %.2f M blocks/s, %.2f ms/step, parity sample %s\n"
+                % (b5["value"] / 1e6, b5["ms_per_step"], b5.get("parity_sample")))
+        f.write("# source hash %s\n" % bench_mod.source_hash())
+        f.write(open(c5).read())

@@ -49,16 +49,23 @@ VAMD_DEV int mark_at(const unsigned char *__restrict__ flags, long nsteps, long 
   return m != 0;
 }
 
+VAMD_DEV long blockout_steps(const BlockoutP &B) {
+  long last = B.nsamples / B.searchstep - VAMD_VE_WIN;
+  if (last > B.nsteps) last = B.nsteps;
+  return last < 0 ? 0 : last;
+}
+
 // The walk for one stream.  Returns the number of blocks planned (<= maxblocks) and counts per size class.
-VAMD_DEV int plan_stream(const BlockoutP &B, const unsigned char *__restrict__ flags, PlannedBlock *__restrict__ out,
+//   marks  ve->mark[] of the steps [0, last) as bytes (mark_at applied by the caller's lanes; entries at and beyond
+//          `last` are 0: steps not taken yet)
+VAMD_DEV int plan_stream(const BlockoutP &B, const unsigned char *marks, PlannedBlock *__restrict__ out,
                          int *count_short, int *count_long) {
   const long step = B.searchstep;
   // vorbis_analysis_init / _ve_envelope_init: lib/block.c:211-213, lib/envelope.c:41
   int W = 0, lW = 0;
   long centerW = B.bs[1] / 2, cursor = B.bs[1] / 2, curmark = 0;
   // what _ve_envelope_search has marked: steps [0, last), last = pcm_current/searchstep - VE_WIN (:223-224)
-  long last = B.nsamples / step - VAMD_VE_WIN;
-  if (last > B.nsteps) last = B.nsteps;
+  const long last = blockout_steps(B);
   const long current = last * step;
   int n = 0, n0 = 0, n1 = 0;
   while (n < B.maxblocks) {
@@ -71,7 +78,7 @@ VAMD_DEV int plan_stream(const BlockoutP &B, const unsigned char *__restrict__ f
         break;
       }
       cursor = j;
-      if (mark_at(flags, last, j / step) && j > centerW) {
+      if (marks[j / step] && j > centerW) {
         curmark = j;
         bp = j >= testW ? 1 : 0;
         break;
@@ -89,7 +96,7 @@ VAMD_DEV int plan_stream(const BlockoutP &B, const unsigned char *__restrict__ f
       // _ve_envelope_mark, lib/envelope.c:329-353 (W == 0: both neighbours count as short)
       const long beginW = centerW - B.bs[0] / 4 - B.bs[0] / 4, endW = centerW + B.bs[0] / 4 + B.bs[0] / 4;
       int hit = curmark >= beginW && curmark < endW;
-      for (long i = beginW / step; !hit && i < endW / step; i++) hit = mark_at(flags, last, i);
+      for (long i = beginW / step; !hit && i < endW / step; i++) hit = i >= 0 && i < last && marks[i];
       blocktype = hit ? 0 /* BLOCKTYPE_IMPULSE */ : 1 /* BLOCKTYPE_PADDING */;
     }
     out[n].kind = W | (lW << 1) | (nW << 2) | (blocktype << 3);

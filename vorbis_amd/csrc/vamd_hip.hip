@@ -623,14 +623,23 @@ __global__ __launch_bounds__(64) void k_env_walk(int ch, long nstreams, long nst
 }
 
 // ---- device-resident stream control (k_blockout.h) ----------------------------------------------------
-__global__ void k_plan_streams(BlockoutP B, long nstreams, const unsigned char *__restrict__ flags,
-                               PlannedBlock *__restrict__ blocks, int *__restrict__ counts) {
-  const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= nstreams) return;
-  int n0 = 0, n1 = 0;
-  plan_stream(B, flags + s * B.nsteps, blocks + s * B.maxblocks, &n0, &n1);
-  counts[2 * s] = n0;
-  counts[2 * s + 1] = n1;
+// one wave per stream: the lanes turn the stream's flags into its mark bytes in LDS (coalesced reads, ve->mark[] as
+// mark_at defines it), then one lane does the walk out of LDS -- a dependent chain of a few thousand steps that would
+// otherwise pay a trip to HBM at each of them
+__global__ __launch_bounds__(64) void k_plan_streams(BlockoutP B, long nstreams, const unsigned char *__restrict__ flags,
+                                                     PlannedBlock *__restrict__ blocks, int *__restrict__ counts) {
+  unsigned char *marks = (unsigned char *)vamd_smem;  // [nsteps + 4]
+  const long s = blockIdx.x;
+  const long last = blockout_steps(B);
+  const unsigned char *f = flags + s * B.nsteps;
+  for (long p = threadIdx.x; p < B.nsteps + 4; p += 64) marks[p] = p < last ? (unsigned char)mark_at(f, last, p) : 0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int n0 = 0, n1 = 0;
+    plan_stream(B, marks, blocks + s * B.maxblocks, &n0, &n1);
+    counts[2 * s] = n0;
+    counts[2 * s + 1] = n1;
+  }
 }
 
 // base[2s + W] = index of stream s's first block inside size class W's batch; start[s] = into order[]
@@ -1784,7 +1793,8 @@ int vamd_plan_streams(vamd_ctx *c, const float *pcm, long stream_stride, long ch
   if (B.nsteps && (r = vamd_envelope_search_batch(c, pcm, stream_stride, channel_stride, nstreams, B.nsteps, states, (unsigned char *)v_flags)))
     return r;
   hipStream_t s = c->stream;
-  hipLaunchKernelGGL(k_plan_streams, dim3((unsigned)((nstreams + 63) / 64)), dim3(64), 0, s, B, nstreams,
+  if ((size_t)B.nsteps + 4 > c->lds_per_block) return fail(c, VAMD_EINVAL, "streams too long for one plan (their marks must fit a workgroup's LDS)");
+  hipLaunchKernelGGL(k_plan_streams, dim3((unsigned)nstreams), dim3(64), (size_t)((B.nsteps + 4 + 15) & ~15L), s, B, nstreams,
                      (const unsigned char *)v_flags, (PlannedBlock *)v_blocks, (int *)v_counts);
   std::vector<int> counts((size_t)nstreams * 2);
   HIP_TRY(c, hipMemcpyAsync(counts.data(), v_counts, counts.size() * sizeof(int), hipMemcpyDeviceToHost, s));
