@@ -15,6 +15,7 @@
 #include "k_floor.h"
 #include "k_couple.h"
 #include "k_envelope.h"
+#include "k_blockout.h"
 #include "k_residue.h"
 #include "k_pack.h"
 
@@ -303,5 +304,28 @@ int emul_envelope_search(void *h, const float *pcm, long len, long nsteps, vamd_
     for (int i = 0; i < VAMD_VE_AMP_HIST * 8; i++) st->amp_hist[c][i >> 3][i & 7] = at[i];
   }
   return 0;
+}
+}
+
+extern "C" {
+// blockout's decisions for one stream from its detector flags: what k_plan_streams does per stream (mark bytes via
+// mark_at, then plan_stream).  kind[], begin[] hold maxblocks entries; returns the number of blocks planned.
+int emul_plan_stream(void *h, const unsigned char *flags, long nsteps, long nsamples, int maxblocks, int *kind, int *begin) {
+  Emul *e = (Emul *)h;
+  BlockoutP B;
+  B.bs[0] = e->B.bs[0];
+  B.bs[1] = e->B.bs[1];
+  B.searchstep = e->B.env.searchstep;
+  B.nsamples = nsamples;
+  B.nsteps = nsteps;
+  B.maxblocks = maxblocks;
+  const long last = blockout_steps(B);
+  std::vector<unsigned char> marks((size_t)nsteps + 4, 0);
+  for (long p = 0; p < nsteps + 4; p++) marks[p] = p < last ? (unsigned char)mark_at(flags, last, p) : 0;
+  std::vector<PlannedBlock> out((size_t)maxblocks);
+  int n0, n1;
+  const int n = plan_stream(B, marks.data(), out.data(), &n0, &n1);
+  for (int k = 0; k < n; k++) kind[k] = out[k].kind, begin[k] = out[k].begin;
+  return n;
 }
 }

@@ -66,6 +66,7 @@ class Emul:
         self.L.emul_submaps.argtypes = [C.c_void_p, C.c_int]
         self.L.emul_residue_offset.argtypes = [C.c_void_p, C.c_int, C.c_int]
         self.L.emul_envelope_search.argtypes = [C.c_void_p, _f32p, C.c_long, C.c_long, C.c_void_p, C.c_void_p]
+        self.L.emul_plan_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_void_p, C.c_void_p]
         blob = np.ascontiguousarray(blob, dtype=np.uint8)
         self.h = self.L.emul_open(blob.ctypes.data_as(C.c_void_p), blob.size)
         if not self.h:
@@ -153,3 +154,13 @@ class Emul:
                                         ret.ctypes.data_as(C.c_void_p))
         assert r == 0
         return ret
+
+    def plan_stream(self, flags, nsamples, maxblocks=4096):
+        """blockout's decisions for one stream from its detector flags (k_blockout.h compiled for the host).
+        Returns (kind[n], begin[n]): kind = W | lW << 1 | nW << 2 | blocktype << 3."""
+        flags = np.ascontiguousarray(flags, np.uint8)
+        kind = np.zeros(maxblocks, np.int32)
+        begin = np.zeros(maxblocks, np.int32)
+        n = self.L.emul_plan_stream(self.h, flags.ctypes.data_as(C.c_void_p), C.c_long(len(flags)), C.c_long(nsamples),
+                                    maxblocks, kind.ctypes.data_as(C.c_void_p), begin.ctypes.data_as(C.c_void_p))
+        return kind[:n], begin[:n]

@@ -112,6 +112,35 @@ def test_port_and_bodies_match_reference_streams(name, seed):
     check_state(st, o, ch)
 
 
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("name,seed", [("44k_stereo_q4", 5), ("44k_stereo_q9", 6), ("44k_mono_q5", 7)])
+def test_blockout_walk_matches_reference(name, seed):
+    """k_blockout.h (the walk k_plan_streams runs per stream) compiled for the host: from the detector's flags over the
+    encoder's PCM buffer to the block list -- sizes, window flags, block types, positions -- of the reference's own
+    vorbis_analysis_blockout() on the same stream (lib/block.c:534-693)."""
+    from tests.emul.emul import Emul
+    ch, rate, q = checker.SETUPS[name]
+    frames = 60000
+    x = gated(ch, frames, seed)
+    e = ref.RefEncoder(ch, rate, q)
+    for k in range(0, frames, 1024):   # the application's feed size: the start-of-stream extrapolation sees this much
+        o = e.envelope_feed(x[:, k:k + 1024])
+    blocks = ref.RefEncoder(ch, rate, q).encode_stream(x)
+    em = Emul(blob_of(name))
+    nsamples = o["pcm"].shape[1]
+    nsteps = nsamples // 64 - 4
+    flags = em.envelope_search(o["pcm"], nsteps, EnvelopeState())
+    kind, begin = em.plan_stream(flags, nsamples)
+    assert 10 < len(kind) <= len(blocks) and len(blocks) - len(kind) <= 12
+    assert len(set(int(k) & 1 for k in kind)) == 2, "the stream should switch block sizes"
+    for k in range(len(kind)):
+        b = blocks[k]
+        assert (int(kind[k]) & 1, (int(kind[k]) >> 1) & 1, (int(kind[k]) >> 2) & 1, (int(kind[k]) >> 3) & 1) == \
+            (b["W"], b["lW"], b["nW"], b["blocktype"]), k
+        n = b["pcm"].shape[1]
+        assert np.array_equal(o["pcm"][:, begin[k]:begin[k] + n], b["pcm"]), k
+
+
 def test_envelope_state_layout_matches_header():
     """ctypes mirror == the C struct of include/vorbis_amd.h (sizes the device-side state arrays)."""
     hdr = open(os.path.join(ROOT, "include", "vorbis_amd.h")).read()
