@@ -131,7 +131,7 @@ int emul_packet_capacity(void *h, int W) { return ((Emul *)h)->B.pack[W].capacit
 int emul_mdct_forward(void *h, int W, const float *in, float *out) {
   Emul *e = (Emul *)h;
   const XformP &P = e->B.xf[W];
-  std::vector<float> A(P.n + 4), Bw(P.n + P.n / 32);
+  std::vector<float> A(VAMD_XF_A_FLOATS(P.n)), Bw(VAMD_XF_B_FLOATS(P.n));
   PhaseClock pc;
   pc.start(nullptr);
   static PcmTile<VAMD_HOST_QUADS> tile;
@@ -161,7 +161,7 @@ static int analyze_core(void *h, const float *pcm, int lW, int W, int nW, int bl
   const XformP &X = B.xf[W];
   const PsyP &P = B.psy[blocktype + (W ? 2 : 0)];
   const CoupleP &C = B.couple[W];
-  std::vector<float> A(n + 4), Bw(n + n / 32);
+  std::vector<float> A(VAMD_XF_A_FLOATS(n)), Bw(VAMD_XF_B_FLOATS(n));
   std::vector<float> mdct_raw(ch * n2), logfft(ch * n2), logmdct(ch * n2), noise(ch * n2), tone(ch * n2),
       logmask(ch * n2), mdct(ch * n2), lmd(n2), mask(n2);
   std::vector<int> posts(ch * VAMD_POSTS_STRIDE), post_valid(ch), ilogmask(ch * n2), iwork(ch * n2), nonzero(ch);
@@ -175,7 +175,13 @@ static int analyze_core(void *h, const float *pcm, int lW, int W, int nW, int bl
     const WaveTeam tm;
     pcm_fetch(tile, pcm + (size_t)i * n, n, tm);
     transform_window(X, W, lW, nW, tile, A.data(), pc, tm);
-    local[i] = transform_block(X, A.data(), Bw.data(), &mdct_raw[i * n2], &logmdct[i * n2], &logfft[i * n2], pc);
+    // the size-specialised instantiations the launcher picks, and the general one for everything else
+    switch (fixed_logn(X)) {
+#define EMUL_XF(L) case L: local[i] = transform_block<L>(X, A.data(), Bw.data(), &mdct_raw[i * n2], &logmdct[i * n2], &logfft[i * n2], pc); break;
+      EMUL_XF(8) EMUL_XF(9) EMUL_XF(10) EMUL_XF(11) EMUL_XF(12)
+#undef EMUL_XF
+      default: local[i] = transform_block(X, A.data(), Bw.data(), &mdct_raw[i * n2], &logmdct[i * n2], &logfft[i * n2], pc);
+    }
     if (local[i] > global) global = local[i];
   }
   {

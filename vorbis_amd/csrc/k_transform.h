@@ -9,8 +9,9 @@
 // *schedule* differs: each stage's independent butterflies are spread across
 // the 64 lanes with the work vectors in LDS.
 //
-// LDS: A[n+4] (PCM -> windowed -> FFT buffer "c"), B[n + n/32] (MDCT work "w" with its
-// padded butterfly half, then FFT buffer "ch"; n/32 >= 4 covers the offset layout).
+// LDS: A[VAMD_XF_A_FLOATS(n)] (PCM -> windowed -> FFT buffer "c"), B[VAMD_XF_B_FLOATS(n)] (MDCT work "w" with its
+// padded butterfly half, then FFT buffer "ch"); the FFT's early passes leave their output in padded layouts
+// (VAMD_F2_POS / VAMD_F3_POS below), which is what the sizes allow for.
 //
 // Who runs a block: a TEAM.  Every phase below is a loop over independent items (butterflies, pairs,
 // quads) followed by a team-wide sync; the items are dealt round the team's threads.  The kernels run one
@@ -22,6 +23,9 @@
 #include "vamd_params.h"
 
 namespace vamd {
+
+#define VAMD_XF_A_FLOATS(n) (((n) + ((n) >> 5) + 4 + 3) & ~3)
+#define VAMD_XF_B_FLOATS(n) (((n) + ((n) >> 4) + 4 + 3) & ~3)
 
 struct WaveTeam {  // the 64 lanes of one wavefront (one lane in the test build)
   VAMD_MEM int tid() const { return LANE; }
@@ -388,11 +392,15 @@ VAMD_DEV void st_pair(float *p, int t, float a, float b) {  // p[t-1] = a, p[t] 
 // i = ido column).  Here one flat loop over g = (k, m) with m in [0, ido/2) covers all
 // three: m = 0 does both k-only columns, m >= 1 the (k, i = 2m) butterfly.  ido is a power
 // of two (>= 4) for every pass but the first, so k and m are a shift and a mask.
-template <bool AL, class Team>
+// SRC3: cc is in the VAMD_F3_POS layout (the pass with ido = 64 that follows fft_pass3_wave): a k-block of 64
+// starts 66 floats after the previous one; the four input quarters stay a constant distance apart.
+template <bool AL, bool SRC3 = false, class Team>
 VAMD_DEV void radf4_wave(int ido, int l1, const float *__restrict__ cc, float *__restrict__ ch, const float *__restrict__ wa1,
                          const float *__restrict__ wa2, const float *__restrict__ wa3, const Team &tm) {
   const float hsqt2 = .70710678118654752f;
   const int t0 = l1 * ido;
+  const int ks = SRC3 ? ido + 2 : ido;              // source stride between k-blocks
+  const int q0 = SRC3 ? t0 + (t0 >> 5) : t0;        // ... and between input quarters
   if (ido == 1) {
     // first pass: four contiguous outputs per k -> one 16-byte store (offset layout: index 4k at +1)
     TEAM_EACH(k, l1, tm) {
@@ -411,10 +419,10 @@ VAMD_DEV void radf4_wave(int ido, int l1, const float *__restrict__ cc, float *_
   TEAM_EACH(k, l1, tm) {
     {
       {
-        const int t1 = t0 + k * ido, t2 = 3 * t0 + k * ido, t3 = k * ido, t4 = 2 * t0 + k * ido;
+        const int t1 = q0 + k * ks, t2 = 3 * q0 + k * ks, t3 = k * ks, t4 = 2 * q0 + k * ks;
         const float tr1 = cc[t1] + cc[t2];
         const float tr2 = cc[t3] + cc[t4];
-        int t5 = t3 << 2;
+        int t5 = (k * ido) << 2;
         ch[t5] = tr1 + tr2;
         ch[(ido << 2) + t5 - 1] = tr2 - tr1;
         t5 += ido << 1;
@@ -422,14 +430,14 @@ VAMD_DEV void radf4_wave(int ido, int l1, const float *__restrict__ cc, float *_
         ch[t5] = cc[t2] - cc[t1];
       }
       {
-        const int t1 = t0 + ido - 1 + k * ido, t2 = t1 + (t0 << 1);
-        const int t4 = ido + k * (ido << 2), t5 = ido << 1, t6 = ido + k * ido;
+        const int t1 = q0 + ido - 1 + k * ks, t2 = t1 + (q0 << 1);
+        const int t4 = ido + k * (ido << 2), t5 = ido << 1, t6 = ido + k * ks;
         const float ti1 = -hsqt2 * (cc[t1] + cc[t2]);
         const float tr1 = hsqt2 * (cc[t1] - cc[t2]);
         ch[t4 - 1] = tr1 + cc[t6 - 1];
         ch[t4 + t5 - 1] = cc[t6 - 1] - tr1;
-        ch[t4] = ti1 - cc[t1 + t0];
-        ch[t4 + t5] = ti1 + cc[t1 + t0];
+        ch[t4] = ti1 - cc[t1 + q0];
+        ch[t4 + t5] = ti1 + cc[t1 + q0];
       }
     }
   }
@@ -439,13 +447,13 @@ VAMD_DEV void radf4_wave(int ido, int l1, const float *__restrict__ cc, float *_
     if (m != 0) {
       const int i = 2 * m;
       const int t1 = k * ido;
-      const int t2 = t1 + i;
+      const int t2 = k * ks + i;
       const int t4 = (t1 << 2) + i;
       const int t6 = ido << 1;
       const int t5 = t6 + (t1 << 2) - i;
       const F2 w1 = *(const F2 *)(wa1 + i - 2), w2 = *(const F2 *)(wa2 + i - 2), w3 = *(const F2 *)(wa3 + i - 2);
-      const F2 c0 = ld_pair<AL>(cc, t2), c1 = ld_pair<AL>(cc, t2 + t0), c2 = ld_pair<AL>(cc, t2 + 2 * t0),
-               c3 = ld_pair<AL>(cc, t2 + 3 * t0);
+      const F2 c0 = ld_pair<AL>(cc, t2), c1 = ld_pair<AL>(cc, t2 + q0), c2 = ld_pair<AL>(cc, t2 + 2 * q0),
+               c3 = ld_pair<AL>(cc, t2 + 3 * q0);
       const float cr2 = w1.x * c1.x + w1.y * c1.y;
       const float ci2 = w1.x * c1.y - w1.y * c1.x;
       const float cr3 = w2.x * c2.x + w2.y * c2.y;
@@ -462,6 +470,159 @@ VAMD_DEV void radf4_wave(int ido, int l1, const float *__restrict__ cc, float *_
     }
   }
 }
+
+// ---- the first three passes (ido = 1, 4, 16) when n >= 256 --------------------------------------------------
+// As radf4_wave runs them, the passes with a small ido scatter their output: a thread's stores land 4*ido floats from
+// its neighbour's, i.e. on the same few LDS banks (16-way conflicts at ido = 4, 32-way for the two k-only columns at
+// ido = 16) -- half of the stage's LDS time (SQ_LDS_BANK_CONFLICT).  Two changes, same butterflies:
+//  * passes 1 and 2 run in ONE trip: the sixteen values in[k + (n/16) m] that the ido = 4 butterfly group k consumes
+//    come from four ido = 1 butterflies that need nothing else, so a thread loads the sixteen, does both passes in
+//    registers and stores sixteen consecutive outputs.  The ido = 4 twiddles are the same for every thread.
+//  * the outputs go out in padded layouts: after pass 2 two floats of padding per 32 (VAMD_F2_POS, the butterfly
+//    vector's layout) so that threads 16 floats apart store to distinct banks; after pass 3 two per 64
+//    (VAMD_F3_POS), with pass 3 dealing sixteen DIFFERENT k to neighbouring lanes (their stores are then 66 floats
+//    apart: distinct banks; and their loads 16 or 18 apart: distinct too).  The ido = 64 pass reads that layout
+//    (radf4_wave<.., SRC3>) with lanes along i, where a plain layout is conflict-free, and writes plainly.
+#define VAMD_F2_POS(t) ((t) + (((t) >> 5) << 1))
+#define VAMD_F3_POS(t) ((t) + (((t) >> 6) << 1))
+
+// passes 1 + 2: c plain [n] -> dst (offset layout, VAMD_F2_POS).  w = the ido = 4 pass's three twiddle pairs.
+template <int LOGN, class Team>
+VAMD_DEV void fft_pass12_wave(const float *__restrict__ c, float *__restrict__ dst, const float *__restrict__ wa1,
+                              const float *__restrict__ wa2, const float *__restrict__ wa3, const Team &tm) {
+  constexpr int n = 1 << LOGN, u = n / 16;
+  const float hsqt2 = .70710678118654752f;
+  const F2 w1 = *(const F2 *)wa1, w2 = *(const F2 *)wa2, w3 = *(const F2 *)wa3;
+  TEAM_EACH(k, u, tm) {
+    float x[16];
+#if VAMD_GPU
+#pragma unroll
+#endif
+    for (int m = 0; m < 16; m++) x[m] = c[k + u * m];
+    // dradf4 with ido = 1 (lib/smallft.c:176-193), butterfly k + u*t: its cc[t0+k], cc[3t0+k], cc[k], cc[2t0+k]
+    // are x[t+4], x[t+12], x[t], x[t+8]; y[t][0..3] = its four outputs = the ido = 4 pass's cc[4k + i + (n/4) t]
+    float y[4][4];
+#if VAMD_GPU
+#pragma unroll
+#endif
+    for (int t = 0; t < 4; t++) {
+      const float c1 = x[t + 4], c2 = x[t + 12], c3 = x[t], c4 = x[t + 8];
+      const float tr1 = c1 + c2, tr2 = c3 + c4;
+      y[t][0] = tr1 + tr2;
+      y[t][1] = c3 - c4;
+      y[t][2] = c2 - c1;
+      y[t][3] = tr2 - tr1;
+    }
+    float o[16];
+    {  // ido = 4, the i = 0 column (lib/smallft.c:176-193): cc[t1], cc[t2], cc[t3], cc[t4] = y[1][0], y[3][0], y[0][0], y[2][0]
+      const float tr1 = y[1][0] + y[3][0];
+      const float tr2 = y[0][0] + y[2][0];
+      o[0] = tr1 + tr2;
+      o[15] = tr2 - tr1;
+      o[7] = y[0][0] - y[2][0];
+      o[8] = y[3][0] - y[1][0];
+    }
+    {  // the i = ido column (:246-268): cc[t1], cc[t2], cc[t6-1], cc[t1+t0] = y[1][3], y[3][3], y[0][3], y[2][3]
+      const float ti1 = -hsqt2 * (y[1][3] + y[3][3]);
+      const float tr1 = hsqt2 * (y[1][3] - y[3][3]);
+      o[3] = tr1 + y[0][3];
+      o[11] = y[0][3] - tr1;
+      o[4] = ti1 - y[2][3];
+      o[12] = ti1 + y[2][3];
+    }
+    {  // the i = 2 butterfly (:197-243) on the pairs (y[t][1], y[t][2])
+      const float cr2 = w1.x * y[1][1] + w1.y * y[1][2];
+      const float ci2 = w1.x * y[1][2] - w1.y * y[1][1];
+      const float cr3 = w2.x * y[2][1] + w2.y * y[2][2];
+      const float ci3 = w2.x * y[2][2] - w2.y * y[2][1];
+      const float cr4 = w3.x * y[3][1] + w3.y * y[3][2];
+      const float ci4 = w3.x * y[3][2] - w3.y * y[3][1];
+      const float tr1 = cr2 + cr4, tr4 = cr4 - cr2, ti1 = ci2 + ci4, ti4 = ci2 - ci4;
+      const float ti2 = y[0][2] + ci3, ti3 = y[0][2] - ci3;
+      const float tr2 = y[0][1] + cr3, tr3 = y[0][1] - cr3;
+      o[1] = tr1 + tr2;
+      o[2] = ti1 + ti2;
+      o[5] = tr3 - ti4;
+      o[6] = tr4 - ti3;
+      o[9] = ti4 + tr3;
+      o[10] = tr4 + ti3;
+      o[13] = tr2 - tr1;
+      o[14] = ti1 - ti2;
+    }
+    float *d = dst + VAMD_F2_POS(16 * k);  // the sixteen share a group of 32: one pad for all
+    d[0] = o[0];
+#if VAMD_GPU
+#pragma unroll
+#endif
+    for (int m = 1; m < 8; m++) st_pair(d, 2 * m, o[2 * m - 1], o[2 * m]);
+    d[15] = o[15];
+  }
+}
+
+// pass 3 (ido = 16, l1 = n/64): src offset layout in VAMD_F2_POS, dst offset layout in VAMD_F3_POS.
+template <int LOGN, class Team>
+VAMD_DEV void fft_pass3_wave(const float *__restrict__ cc, float *__restrict__ ch, const float *__restrict__ wa1,
+                             const float *__restrict__ wa2, const float *__restrict__ wa3, const Team &tm) {
+  constexpr int n = 1 << LOGN, ido = 16, l1 = n / 64, t0 = n / 4;
+  constexpr int LL1 = LOGN - 6;
+  constexpr int q0 = t0 + (t0 >> 4);  // VAMD_F2_POS of a quarter's start (t0 is a multiple of 32)
+  const float hsqt2 = .70710678118654752f;
+  // the two k-only columns
+  TEAM_EACH(k, l1, tm) {
+    const float *s = cc + VAMD_F2_POS(16 * k);
+    float *d = ch + 66 * k;
+    {
+      const float a1 = s[q0], a2 = s[3 * q0], a3 = s[0], a4 = s[2 * q0];
+      const float tr1 = a1 + a2;
+      const float tr2 = a3 + a4;
+      d[0] = tr1 + tr2;
+      d[63] = tr2 - tr1;
+      d[31] = a3 - a4;
+      d[32] = a2 - a1;
+    }
+    {
+      const float b1 = s[q0 + 15], b2 = s[3 * q0 + 15], b6 = s[15], b3 = s[2 * q0 + 15];
+      const float ti1 = -hsqt2 * (b1 + b2);
+      const float tr1 = hsqt2 * (b1 - b2);
+      d[15] = tr1 + b6;
+      d[47] = b6 - tr1;
+      d[16] = ti1 - b3;
+      d[48] = ti1 + b3;
+    }
+  }
+  // the (k, i = 2m) butterflies, m = 1..7: sixteen k side by side in the wave, then m
+  TEAM_EACH(g, l1 * 8, tm) {
+    int k, m;
+    if (LL1 >= 4) {
+      k = (g & 15) | (((g >> 6) & ((1 << (LL1 - 4)) - 1)) << 4);
+      m = ((g >> 4) & 3) | ((g >> (6 + (LL1 >= 4 ? LL1 - 4 : 0))) << 2);
+    } else {
+      k = g & (l1 - 1);
+      m = g >> LL1;
+    }
+    if (m != 0) {
+      const int i = 2 * m;
+      const float *s = cc + VAMD_F2_POS(16 * k) + i;
+      float *d = ch + 66 * k;
+      const F2 w1 = *(const F2 *)(wa1 + i - 2), w2 = *(const F2 *)(wa2 + i - 2), w3 = *(const F2 *)(wa3 + i - 2);
+      const F2 c0 = ld_pair<true>(s, 0), c1 = ld_pair<true>(s, q0), c2 = ld_pair<true>(s, 2 * q0), c3 = ld_pair<true>(s, 3 * q0);
+      const float cr2 = w1.x * c1.x + w1.y * c1.y;
+      const float ci2 = w1.x * c1.y - w1.y * c1.x;
+      const float cr3 = w2.x * c2.x + w2.y * c2.y;
+      const float ci3 = w2.x * c2.y - w2.y * c2.x;
+      const float cr4 = w3.x * c3.x + w3.y * c3.y;
+      const float ci4 = w3.x * c3.y - w3.y * c3.x;
+      const float tr1 = cr2 + cr4, tr4 = cr4 - cr2, ti1 = ci2 + ci4, ti4 = ci2 - ci4;
+      const float ti2 = c0.y + ci3, ti3 = c0.y - ci3;
+      const float tr2 = c0.x + cr3, tr3 = c0.x - cr3;
+      st_pair(d, i, tr1 + tr2, ti1 + ti2);
+      st_pair(d, 32 - i, tr3 - ti4, tr4 - ti3);
+      st_pair(d, 32 + i, ti4 + tr3, tr4 + ti3);
+      st_pair(d, 64 - i, tr2 - tr1, ti1 - ti2);
+    }
+  }
+}
+
 
 // dradf2, lib/smallft.c:113-166, same flattening
 template <bool AL, class Team>
@@ -515,11 +676,23 @@ VAMD_DEV const float *drft_forward_wave(const XformP &P, float *c, float *ch, co
   const int n = LOGN ? (1 << LOGN) : P.n, nf = LOGN ? (LOGN >> 1) + (LOGN & 1) : P.fft_nf;
   const float *__restrict__ wa = P.wa;
   float *bufc = c + 1, *bufh = ch + 1;  // offset layouts of the two buffers
-  int na = 1, l2 = n, iw = n;
+  int na = 1, l2 = n, iw = n, kfirst = 0;
+  if (LOGN >= 8) {
+    // ido = 1 and 4 in one trip (c -> ch), ido = 16 (ch -> c); twiddles as drftf1 would hand them to dradf4:
+    // iw = n - 3 after the first pass, n - 15 for the second, n - 63 for the third
+    fft_pass12_wave<LOGN ? LOGN : 8>(c, bufh, wa + n - 16, wa + n - 12, wa + n - 8, tm);
+    tm.sync();
+    fft_pass3_wave<LOGN ? LOGN : 8>(bufh, bufc, wa + n - 64, wa + n - 48, wa + n - 32, tm);
+    tm.sync();
+    na = 1;  // the data is in c: the next pass writes ch
+    l2 = n >> 6;
+    iw = n - 63;
+    kfirst = 3;
+  }
 #if VAMD_GPU
 #pragma unroll
 #endif
-  for (int k1 = 0; k1 < nf; k1++) {
+  for (int k1 = kfirst; k1 < nf; k1++) {
     const int ip = LOGN ? (k1 < (LOGN >> 1) ? 4 : 2) : P.fft_fac[nf - k1 - 1];
     const int l1 = l2 / ip, ido = n / l2;
     iw -= (ip - 1) * ido;
@@ -529,13 +702,15 @@ VAMD_DEV const float *drft_forward_wave(const XformP &P, float *c, float *ch, co
       // the first pass reads the plain (un-offset) block; ld_pair<false> covers the case
       // where it has pairs to read (ido > 2)
       if (ip == 4)
-        radf4_wave<false>(ido, l1, c, dst, wa + iw - 1, wa + iw + ido - 1, wa + iw + 2 * ido - 1, tm);
+        radf4_wave<false, false>(ido, l1, c, dst, wa + iw - 1, wa + iw + ido - 1, wa + iw + 2 * ido - 1, tm);
       else
         radf2_wave<false>(ido, l1, c, dst, wa + iw - 1, tm);
     } else {
       const float *src = na ? bufh : bufc;
-      if (ip == 4)
-        radf4_wave<true>(ido, l1, src, dst, wa + iw - 1, wa + iw + ido - 1, wa + iw + 2 * ido - 1, tm);
+      if (ip == 4 && LOGN >= 8 && k1 == 3)
+        radf4_wave<true, true>(ido, l1, src, dst, wa + iw - 1, wa + iw + ido - 1, wa + iw + 2 * ido - 1, tm);
+      else if (ip == 4)
+        radf4_wave<true, false>(ido, l1, src, dst, wa + iw - 1, wa + iw + ido - 1, wa + iw + 2 * ido - 1, tm);
       else
         radf2_wave<true>(ido, l1, src, dst, wa + iw - 1, tm);
     }
@@ -548,7 +723,7 @@ VAMD_DEV const float *drft_forward_wave(const XformP &P, float *c, float *ch, co
 }
 
 // The whole stage for one channel-block.
-//   A, B     LDS [n + 4], [n + n/32]
+//   A, B     LDS [VAMD_XF_A_FLOATS(n)], [VAMD_XF_B_FLOATS(n)]
 //   outputs  HBM, each may be null
 // `tile` holds the un-windowed block (pcm_fetch); it is consumed by transform_window, so the caller may refill
 // it for the next block as soon as that returns.
@@ -612,6 +787,16 @@ VAMD_DEV float transform_block(const XformP &P, float *A, float *B, float *__res
   tm.sync();
   pc.mark(7);
   return amp;
+}
+
+// log2 n when the size-specialised transforms apply -- a power of two in [256, 4096] whose FFT factors are the ones
+// they assume (radix 4 throughout, one radix-2 pass last for an odd log2 n) -- else 0 (the general code).
+inline int fixed_logn(const XformP &P) {
+  const int l = P.log2n;
+  if (l < 8 || l > 12 || (1 << l) != P.n || P.fft_nf != (l >> 1) + (l & 1)) return 0;
+  for (int k1 = 0; k1 < P.fft_nf; k1++)
+    if (P.fft_fac[P.fft_nf - k1 - 1] != (k1 < (l >> 1) ? 4 : 2)) return 0;
+  return l;
 }
 
 }  // namespace vamd

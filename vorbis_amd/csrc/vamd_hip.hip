@@ -79,15 +79,15 @@ __device__ __forceinline__ XformLds stage_transform_tables(const XformP &G) {
   L.P.win_short = winS;
   L.P.bitrev = bitrev;
   const int wave = threadIdx.x >> 6;
-  const int per_wave = (n + 4) + (n + n / 32);
+  const int per_wave = VAMD_XF_A_FLOATS(n) + VAMD_XF_B_FLOATS(n);
   L.A = work + wave * per_wave;
-  L.B = L.A + n + 4;
+  L.B = L.A + VAMD_XF_A_FLOATS(n);
   return L;
 }
 
 static size_t transform_lds_bytes(const XformP &P, int waves) {
   const size_t tables = (size_t)(P.n + P.n / 4) + P.n + P.bs1 / 2 + P.bs0 / 2 + P.n / 4;
-  return (tables + (size_t)waves * ((P.n + 4) + (P.n + P.n / 32))) * 4;
+  return (tables + (size_t)waves * (VAMD_XF_A_FLOATS(P.n) + VAMD_XF_B_FLOATS(P.n))) * 4;
 }
 
 // mdct_forward only (BASELINE config 2): in[nframes][n] -> out[nframes][n/2].  The one HBM-bound
@@ -97,14 +97,6 @@ static size_t transform_lds_bytes(const XformP &P, int waves) {
 #define VAMD_MD_WAVES 16
 // log2 n when the transform kernels have an instantiation for this size and the blob's FFT factors are the
 // ones that instantiation assumes (radix 4 throughout, one radix-2 pass last for an odd log2 n); else 0
-static int fixed_logn(const XformP &P) {
-  const int l = P.log2n;
-  if (l < 8 || l > 12 || (1 << l) != P.n || P.fft_nf != (l >> 1) + (l & 1)) return 0;
-  for (int k1 = 0; k1 < P.fft_nf; k1++)
-    if (P.fft_fac[P.fft_nf - k1 - 1] != (k1 < (l >> 1) ? 4 : 2)) return 0;
-  return l;
-}
-
 static size_t mdct_only_lds_bytes(const XformP &P, int waves) {
   const size_t n2 = P.n / 2;
   return ((size_t)(P.n + P.n / 4) + P.n / 4 + (size_t)waves * (n2 + VAMD_PW_SIZE(n2))) * 4;
