@@ -176,8 +176,12 @@ static int analyze_core(void *h, const float *pcm, int lW, int W, int nW, int bl
     pcm_fetch(tile, pcm + (size_t)i * n, n, tm);
     transform_window(X, W, lW, nW, tile, A.data(), pc, tm);
     // the size-specialised instantiations the launcher picks, and the general one for everything else
+    std::vector<float> tpack(VAMD_TPACK_FLOATS(n) > 0 ? VAMD_TPACK_FLOATS(n) : 1);
+    mdct_tpack_fill(tpack.data(), X.trig, n, 0, 1);
+    XformP XP = X;
+    XP.tpack = tpack.data();
     switch (fixed_logn(X)) {
-#define EMUL_XF(L) case L: local[i] = transform_block<L>(X, A.data(), Bw.data(), &mdct_raw[i * n2], &logmdct[i * n2], &logfft[i * n2], pc); break;
+#define EMUL_XF(L) case L: local[i] = transform_block<L>(XP, A.data(), Bw.data(), &mdct_raw[i * n2], &logmdct[i * n2], &logfft[i * n2], pc); break;
       EMUL_XF(8) EMUL_XF(9) EMUL_XF(10) EMUL_XF(11) EMUL_XF(12)
 #undef EMUL_XF
       default: local[i] = transform_block(X, A.data(), Bw.data(), &mdct_raw[i * n2], &logmdct[i * n2], &logfft[i * n2], pc);

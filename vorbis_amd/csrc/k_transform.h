@@ -186,6 +186,22 @@ VAMD_DEV void bfly_level8(float *e) {
 #define VAMD_PW(p) ((p) + (((p) >> 5) << 1))
 #define VAMD_PW_SIZE(n2) ((n2) + ((n2) >> 4))
 
+// The trig pairs of the generic butterfly stages s = 1 .. log2n-7 (stage s reads trig[(4 << s) q], q < n/8 >> s),
+// stage after stage: n/8 - 16 pairs, stage s starting at pair n/8 - (n/8 >> (s-1)).  Thread `first` of `step`.
+#define VAMD_TPACK_FLOATS(n) ((n) / 4 - 32)
+VAMD_DEV void mdct_tpack_fill(float *tpack, const float *__restrict__ trig, int n, int first, int step) {
+  for (int i = first; i < n / 8 - 16; i += step) {
+    int s = 1, q = i, cnt = n / 16;
+    while (q >= cnt) {
+      q -= cnt;
+      cnt >>= 1;
+      s++;
+    }
+    tpack[2 * i] = trig[(4 << s) * q];
+    tpack[2 * i + 1] = trig[(4 << s) * q + 1];
+  }
+}
+
 // mdct_forward, lib/mdct.c:492-562.  `in` = A (windowed block, LDS, n floats);
 // w = work buffer: w[0..n2) plain + padded butterfly vector at w + n2
 // (VAMD_PW_SIZE(n2) floats).  The n/2 spectrum is written to out_lds[0..n2).
@@ -196,7 +212,11 @@ VAMD_DEV void bfly_level8(float *e) {
 // LOGN > 0 fixes the transform size at compile time (n = 2^LOGN): loop counts, strides and every index
 // expression derived from n then fold into constants and immediate offsets -- the stage is bound by
 // instruction issue, and a good part of its instructions is address arithmetic.  0 = take n from P.
-template <int LOGS = 0, int LOGN = 0, class Team = WaveTeam>
+// PACKED: P.tpack holds the generic butterfly stages' trig pairs one stage after the other, each at stride 1
+// (mdct_tpack_fill) -- read out of the plain table at its stride of 4 << s floats, the 32 lanes of a load share
+// one or two LDS banks from the third stage on (16-way conflicts: a tenth of the stage's LDS time) -- and the
+// bit-reverse indices are computed, not fetched (P.bitrev_std).
+template <int LOGS = 0, int LOGN = 0, class Team = WaveTeam, bool PACKED = false>
 VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in0, float *w0, float *out0, PhaseClock &pc,
                                 int in_stride = 0, int w_stride = 0, int out_stride = 0, const Team &tm = Team()) {
   const int n = LOGN ? (1 << LOGN) : P.n, n2 = n >> 1, n4 = n >> 2, n8 = n >> 3;
@@ -259,7 +279,7 @@ VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in0, float *w0, fl
       const int j = g >> lper, q = g & ((1 << lper) - 1);
       const int ia = pts * j + pts - 2 - 2 * q, ib = pts * j + (pts >> 1) - 2 - 2 * q;
       F2 *pa = (F2 *)(w2 + VAMD_PW(ia)), *pb = (F2 *)(w2 + VAMD_PW(ib));
-      const F2 T = *(const F2 *)(trig + tstride * q);  // (packing these per stage, stride 1, was measured: no gain)
+      const F2 T = PACKED && s > 0 ? *(const F2 *)(P.tpack + (n4 - (n4 >> (s - 1))) + 2 * q) : *(const F2 *)(trig + tstride * q);
       F2 a = *pa, b = *pb;
       const float r0 = a.x - b.x, r1 = a.y - b.y;
       a.x += b.x;
@@ -330,7 +350,13 @@ VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in0, float *w0, fl
   TEAM_EACH(uu, n8 << LOGS, tm) {
     VAMD_MDCT_SPLIT(uu, log2n - 3)
     const int u = g_;
-    const I2 bi = *(const I2 *)(bit + 2 * u);
+    I2 bi;
+    if (PACKED) {  // lib/mdct.c:77-88
+      bi.y = (int)(brev32((unsigned)u) >> (32 - (log2n - 1)));
+      bi.x = ((~bi.y) & ((1 << (log2n - 1)) - 1)) - 1;
+    } else {
+      bi = *(const I2 *)(bit + 2 * u);
+    }
     const F2 x0 = *(const F2 *)(w2 + VAMD_PW(bi.x));
     const F2 x1 = *(const F2 *)(w2 + VAMD_PW(bi.y));
     const F2 T = *(const F2 *)(trig + n + 2 * u);
@@ -735,15 +761,15 @@ VAMD_DEV void transform_window(const XformP &P, int W, int lW, int nW, const Pcm
   pc.mark(0);
 }
 
-// Returns the local_ampmax contribution of THIS WAVE (every lane holds it): the caller combines the team's waves.
+// MDCT (spectrum and its dB twin out to HBM) and the FFT of the same windowed block.  Returns the buffer holding the
+// packed FFT output (offset layout), which is A + 1 or B + 1 depending on the number of passes: when it is B's, A
+// is free again and the caller may already put the next block into it.
 template <int LOGN = 0, class Team = WaveTeam>
-VAMD_DEV float transform_block(const XformP &P, float *A, float *B, float *__restrict__ mdct_out,
-                               float *__restrict__ logmdct_out, float *__restrict__ logfft_out, PhaseClock &pc,
-                               const Team &tm = Team()) {
+VAMD_DEV const float *transform_spectra(const XformP &P, float *A, float *B, float *__restrict__ mdct_out,
+                                        float *__restrict__ logmdct_out, PhaseClock &pc, const Team &tm = Team()) {
   const int n = LOGN ? (1 << LOGN) : P.n, n2 = n >> 1;
-
   // MDCT: spectrum lands in B[n2..n) (LDS), then goes out with its dB twin, 16 bytes per thread and tensor
-  mdct_forward_wave<0, LOGN, Team>(P, A, B, B + n2, pc, 0, 0, 0, tm);
+  mdct_forward_wave<0, LOGN, Team, LOGN != 0>(P, A, B, B + n2, pc, 0, 0, 0, tm);
   TEAM_EACH(q, n2 >> 2, tm) {
     float m[4], l[4];
     f4_get(((const F4 *)(B + n2))[q], m);
@@ -752,30 +778,31 @@ VAMD_DEV float transform_block(const XformP &P, float *A, float *B, float *__res
     if (logmdct_out) ((F4 *)logmdct_out)[q] = f4_make(l);
   }
   tm.sync();
-
   pc.mark(5);
   // FFT of the same windowed block (A), ping-ponging with B
   const float *spec = drft_forward_wave<LOGN, Team>(P, A, B, tm);
   pc.mark(6);
+  return spec;
+}
 
-  // logfft + local ampmax, lib/mapping0.c:255-346; four bins per thread
+// logfft + local ampmax, lib/mapping0.c:255-346; four bins per thread.  Returns the local_ampmax contribution of
+// THIS WAVE (every lane holds it): the caller combines the team's waves.
+template <int LOGN = 0, class Team = WaveTeam>
+VAMD_DEV float transform_logfft(const XformP &P, const float *spec, float *__restrict__ logfft_out, PhaseClock &pc,
+                                const Team &tm = Team()) {
+  const int n = LOGN ? (1 << LOGN) : P.n, n2 = n >> 1;
   const float scale = 4.f / n;
   const float scale_dB = todB_345(scale);
   float amp = -1e30f;
   TEAM_EACH(q, n2 >> 2, tm) {
-    // bins 4q .. 4q+3: (Re_k, Im_k) = (spec[2k-1], spec[2k]); spec - 1 is the buffer's 16-byte aligned start, so the
-    // four pairs are two aligned quads
-    float z[8], v[4];
-    f4_get(((const F4 *)(spec - 1))[2 * q], z);
-    f4_get(((const F4 *)(spec - 1))[2 * q + 1], z + 4);
-#if VAMD_GPU
-#pragma unroll
-#endif
+    float v[4];
     for (int c = 0; c < 4; c++) {
-      if (4 * q + c == 0) {
-        v[c] = (float)((double)(scale_dB + todB(z[1])) + .345);  // bin 0: spec[0] alone
+      const int k = 4 * q + c;
+      if (k == 0) {
+        v[c] = (float)((double)(scale_dB + todB(spec[0])) + .345);
       } else {
-        const float temp = z[2 * c] * z[2 * c] + z[2 * c + 1] * z[2 * c + 1];
+        const F2 z = *(const F2 *)(spec + 2 * k - 1);  // (Re_k, Im_k), aligned in the offset layout
+        const float temp = z.x * z.x + z.y * z.y;
         v[c] = (float)((double)(scale_dB + .5f * todB(temp)) + .345);
       }
       amp = fmaxf(amp, v[c]);
@@ -783,17 +810,24 @@ VAMD_DEV float transform_block(const XformP &P, float *A, float *B, float *__res
     if (logfft_out) ((F4 *)logfft_out)[q] = f4_make(v);
   }
   amp = wave_max(amp);
-  if (amp > 0.f) amp = 0.f;  // lib/mapping0.c:346 (the clamp commutes with the maximum over the team's waves)
   tm.sync();
   pc.mark(7);
   return amp;
+}
+
+template <int LOGN = 0, class Team = WaveTeam>
+VAMD_DEV float transform_block(const XformP &P, float *A, float *B, float *__restrict__ mdct_out,
+                               float *__restrict__ logmdct_out, float *__restrict__ logfft_out, PhaseClock &pc,
+                               const Team &tm = Team()) {
+  const float *spec = transform_spectra<LOGN, Team>(P, A, B, mdct_out, logmdct_out, pc, tm);
+  return transform_logfft<LOGN, Team>(P, spec, logfft_out, pc, tm);
 }
 
 // log2 n when the size-specialised transforms apply -- a power of two in [256, 4096] whose FFT factors are the ones
 // they assume (radix 4 throughout, one radix-2 pass last for an odd log2 n) -- else 0 (the general code).
 inline int fixed_logn(const XformP &P) {
   const int l = P.log2n;
-  if (l < 8 || l > 12 || (1 << l) != P.n || P.fft_nf != (l >> 1) + (l & 1)) return 0;
+  if (l < 8 || l > 12 || (1 << l) != P.n || P.fft_nf != (l >> 1) + (l & 1) || !P.bitrev_std) return 0;
   for (int k1 = 0; k1 < P.fft_nf; k1++)
     if (P.fft_fac[P.fft_nf - k1 - 1] != (k1 < (l >> 1) ? 4 : 2)) return 0;
   return l;

@@ -390,6 +390,18 @@ inline void bind_params(const std::vector<unsigned char> &image, const std::vect
     X.bs1 = h.blocksizes[1];
     X.fft_nf = x.fft_nf;
     for (int i = 0; i < 8; i++) X.fft_fac[i] = i < x.fft_nf ? x.fft_fac[i] : 0;
+    X.tpack = nullptr;
+    {  // is the bit-reverse table the one mdct_init builds (lib/mdct.c:77-88)?  Then kernels need not fetch it.
+      const int32_t *br = (const int32_t *)(image.data() + x.off_mdct_bitrev);
+      const int lb = x.log2n - 1, mask = (1 << lb) - 1;
+      X.bitrev_std = x.log2n >= 4 && x.log2n <= 16 && (1 << x.log2n) == x.n;
+      for (int i = 0; X.bitrev_std && i < x.n / 8; i++) {
+        int acc = 0;
+        for (int j = 0; j < lb; j++)
+          if ((i >> (lb - 1 - j)) & 1) acc |= 1 << j;
+        if (br[2 * i] != ((~acc) & mask) - 1 || br[2 * i + 1] != acc) X.bitrev_std = 0;
+      }
+    }
 
     B->chmap[W].submaps = h.mode[W].submaps;
     for (int c = 0; c < VAMD_MAX_CH; c++) B->chmap[W].sub[c] = c < h.channels ? (unsigned char)h.mode[W].chmuxlist[c] : 0;
@@ -452,6 +464,8 @@ inline void bind_params(const std::vector<unsigned char> &image, const std::vect
     E.mdct.mdct_scale = e.mdct_scale;
     E.mdct.trig = (const float *)(base + e.off_mdct_trig);
     E.mdct.bitrev = (const int *)(base + e.off_mdct_bitrev);
+    E.mdct.bitrev_std = 0;
+    E.mdct.tpack = nullptr;
     E.win = (const float *)(base + e.off_window);
     E.searchstep = e.searchstep;
     E.minenergy = e.minenergy;

@@ -57,19 +57,25 @@ struct XformLds {
   float *A, *B;   // this wave's work buffers
 };
 
+template <int LOGN>
 __device__ __forceinline__ XformLds stage_transform_tables(const XformP &G) {
   const int n = G.n;
   float *trig = (float *)vamd_smem;          // [n + n/4]
   float *wa = trig + n + n / 4;              // [n]   (the twiddles the passes touch: wa[0 .. n-1))
   float *winL = wa + n;                      // [bs1/2]
   float *winS = winL + G.bs1 / 2;            // [bs0/2]
-  int *bitrev = (int *)(winS + G.bs0 / 2);   // [n/4]
+  // [n/4]: the bit-reverse table, or (size-specialised kernels, which compute those indices) the butterfly
+  // stages' repacked trig pairs
+  int *bitrev = (int *)(winS + G.bs0 / 2);
   float *work = (float *)(bitrev + n / 4);
   for (int i = threadIdx.x; i < n + n / 4; i += blockDim.x) trig[i] = G.trig[i];
   for (int i = threadIdx.x; i < n; i += blockDim.x) wa[i] = G.wa[i];
   for (int i = threadIdx.x; i < G.bs1 / 2; i += blockDim.x) winL[i] = G.win_long[i];
   for (int i = threadIdx.x; i < G.bs0 / 2; i += blockDim.x) winS[i] = G.win_short[i];
-  for (int i = threadIdx.x; i < n / 4; i += blockDim.x) bitrev[i] = G.bitrev[i];
+  if (LOGN)
+    mdct_tpack_fill((float *)bitrev, G.trig, n, threadIdx.x, blockDim.x);
+  else
+    for (int i = threadIdx.x; i < n / 4; i += blockDim.x) bitrev[i] = G.bitrev[i];
   __syncthreads();
   XformLds L;
   L.P = G;
@@ -77,7 +83,8 @@ __device__ __forceinline__ XformLds stage_transform_tables(const XformP &G) {
   L.P.wa = wa;
   L.P.win_long = winL;
   L.P.win_short = winS;
-  L.P.bitrev = bitrev;
+  L.P.bitrev = LOGN ? nullptr : bitrev;
+  L.P.tpack = LOGN ? (const float *)bitrev : nullptr;
   const int wave = threadIdx.x >> 6;
   const int per_wave = VAMD_XF_A_FLOATS(n) + VAMD_XF_B_FLOATS(n);
   L.A = work + wave * per_wave;
@@ -110,16 +117,20 @@ __global__ __launch_bounds__(64 * VAMD_MD_WAVES) void k_mdct_only(XformP G, int 
   int *bitrev = (int *)(trig + n + n / 4);   // [n/4]
   float *work = (float *)(bitrev + n / 4);
   for (int i = threadIdx.x; i < n + n / 4; i += blockDim.x) trig[i] = G.trig[i];
-  for (int i = threadIdx.x; i < n / 4; i += blockDim.x) bitrev[i] = G.bitrev[i];
+  if (LOGN)  // the slot holds the butterfly stages' repacked trig instead (mdct_forward_wave<.., PACKED>)
+    mdct_tpack_fill((float *)bitrev, G.trig, n, threadIdx.x, blockDim.x);
+  else
+    for (int i = threadIdx.x; i < n / 4; i += blockDim.x) bitrev[i] = G.bitrev[i];
   __syncthreads();
   XformP P = G;
   P.trig = trig;
-  P.bitrev = bitrev;
+  P.bitrev = LOGN ? nullptr : bitrev;
+  P.tpack = LOGN ? (const float *)bitrev : nullptr;
   float *B = work + (size_t)(threadIdx.x >> 6) * (n2 + VAMD_PW_SIZE(n2));
   PhaseClock pc;
   pc.start(nullptr);
   for (long f = (long)blockIdx.x * nw + (threadIdx.x >> 6); f < nframes; f += (long)gridDim.x * nw) {
-    mdct_forward_wave<0, LOGN>(P, in + f * n, B, B + n2, pc);
+    mdct_forward_wave<0, LOGN, WaveTeam, LOGN != 0>(P, in + f * n, B, B + n2, pc);
     WAVE_FOR(q, n2 >> 2)((F4 *)(out + f * n2))[q] = ((const F4 *)(B + n2))[q];
     WAVE_SYNC();
   }
@@ -134,7 +145,7 @@ __global__ __launch_bounds__(64 * VAMD_XF_WAVES) void k_transform(XformP G, int 
                                                                  float *__restrict__ logmdct,
                                                                  float *__restrict__ logfft,
                                                                  float *__restrict__ local_ampmax) {
-  const XformLds L = stage_transform_tables(G);
+  const XformLds L = stage_transform_tables<LOGN>(G);
   const XformP &P = L.P;
   const int n = LOGN ? (1 << LOGN) : P.n, n2 = n >> 1, nw = blockDim.x >> 6;
   PhaseClock pc;

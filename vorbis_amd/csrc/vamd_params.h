@@ -19,6 +19,8 @@ struct XformP {
   int bs0, bs1;          // blocksizes
   int fft_nf;
   int fft_fac[8];
+  int bitrev_std;        // bitrev[] is lib/mdct.c:77-88's table for this n (vamd_create checks): kernels may compute it
+  const float *tpack;    // the butterfly stages' trig pairs repacked per stage (mdct_tpack_fill), or null
 };
 
 // one vorbis_look_psy (+ the vorbis_info_psy scalars)

@@ -57,6 +57,16 @@
 #define WAVE_SYNC_GLOBAL() ((void)0)
 #endif
 
+VAMD_DEV unsigned brev32(unsigned x) {  // bit 0 <-> bit 31
+#if VAMD_GPU
+  return __builtin_bitreverse32(x);
+#else
+  unsigned r = 0;
+  for (int b = 0; b < 32; b++) r |= ((x >> b) & 1u) << (31 - b);
+  return r;
+#endif
+}
+
 // Register tiles: a lane may keep "its" quads of a block in registers across phases.
 // Lane l owns quads l, l+64, ... (four consecutive bins each); VAMD_QPL bounds how
 // many (block sizes up to 2048 -> 1024 bins -> 4 quads per lane on the GPU; the
