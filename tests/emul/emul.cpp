@@ -199,11 +199,11 @@ static int analyze_core(void *h, const float *pcm, int lW, int W, int nW, int bl
       noisemask_block(P, &logmdct[i * n2], &noise[i * n2], S.data(), pc);
       tonemask_block(P, &logfft[i * n2], &tone[i * n2], global, local[i], seed.data() + seed_pad_lo(P.eighth_octave_lines), ampstack.data(),
                      flr.data(), ring_amp.data(), ring_pos.data(), surv.data(), pc);
-      offset_and_mix_wave(P, &noise[i * n2], &tone[i * n2], &logmdct[i * n2], &mdct_raw[i * n2], &mdct[i * n2],
+      offset_and_mix_wave(P, &noise[i * n2], &tone[i * n2], &mdct_raw[i * n2], &mdct[i * n2],
                           &logmask[i * n2], (unsigned short *)lmd.data(), F.twofitatten, pc);
       if (m) {
         m_ilog.resize((size_t)VAMD_PACKETBLOBS * ch * n2);
-        floor_managed_block(P, F, n2, &noise[i * n2], &tone[i * n2], &logmdct[i * n2], (unsigned short *)lmd.data(), &sc,
+        floor_managed_block(P, F, n2, &noise[i * n2], &tone[i * n2], &mdct_raw[i * n2], (unsigned short *)lmd.data(), &sc,
                             m->posts + i * VAMD_POSTS_STRIDE, (long)ch * VAMD_POSTS_STRIDE, m->post_valid + i, ch,
                             m_ilog.data() + (size_t)i * n2, (long)ch * n2, m->nonzero + i, ch, pc);
         continue;

@@ -48,8 +48,7 @@ struct FloorScratch {
 
 // _vp_offset_and_mix with offset_select == 1 (the only select the VBR path uses)
 VAMD_DEV void offset_and_mix_wave(const PsyP &P, const float *__restrict__ noise, const float *__restrict__ tone,
-                                  const float *__restrict__ logmdct_in, const float *__restrict__ mdct_io_src,
-                                  float *__restrict__ mdct_out, float *__restrict__ logmask_out /* HBM or null */,
+                                  const float *__restrict__ mdct_io_src, float *__restrict__ mdct_out, float *__restrict__ logmask_out /* HBM or null */,
                                   unsigned short *qc, float twofitatten, PhaseClock &pc) {
   const int n = P.n;
   const float toneatt = P.tone_masteratt1;
@@ -60,8 +59,10 @@ VAMD_DEV void offset_and_mix_wave(const PsyP &P, const float *__restrict__ noise
     f4_get(((const F4 *)noise)[q], nz);
     f4_get(((const F4 *)P.noiseoffset1)[q], no);
     f4_get(((const F4 *)tone)[q], tn);
-    f4_get(((const F4 *)logmdct_in)[q], lmv);
     f4_get(((const F4 *)mdct_io_src)[q], md);
+    // logmdct (lib/mapping0.c:384-385) is a function of the spectrum that is read here anyway: recomputed, not
+    // fetched -- the transform stage need not write it, nor this one read it (16 KB per stereo block)
+    for (int c = 0; c < 4; c++) lmv[c] = todB_345(md[c]);
 #if VAMD_GPU
 #pragma unroll
 #endif
@@ -103,7 +104,7 @@ VAMD_DEV void offset_and_mix_wave(const PsyP &P, const float *__restrict__ noise
 // lib/mapping0.c:507-545), reduced to what the fit reads: those selects leave the spectrum alone
 // (lib/psy.c:807) and nobody keeps their float mask.
 VAMD_DEV void mask_quantise_wave(const PsyP &P, int offset_select, const float *__restrict__ noise,
-                                 const float *__restrict__ tone, const float *__restrict__ logmdct_in,
+                                 const float *__restrict__ tone, const float *__restrict__ mdct_raw_in,
                                  unsigned short *qc, float twofitatten) {
   const int n = P.n;
   const float toneatt = offset_select ? P.tone_masteratt2 : P.tone_masteratt0;
@@ -113,7 +114,8 @@ VAMD_DEV void mask_quantise_wave(const PsyP &P, int offset_select, const float *
     f4_get(((const F4 *)noise)[q], nz);
     f4_get(((const F4 *)noff)[q], no);
     f4_get(((const F4 *)tone)[q], tn);
-    f4_get(((const F4 *)logmdct_in)[q], lmv);
+    f4_get(((const F4 *)mdct_raw_in)[q], lmv);
+    for (int c = 0; c < 4; c++) lmv[c] = todB_345(lmv[c]);  // logmdct, lib/mapping0.c:384-385
     uint32_t w[2] = {0, 0};
     for (int c = 0; c < 4; c++) {
       float val = nz[c] + no[c];
@@ -701,7 +703,7 @@ VAMD_DEV void floor_interpolate(const LaneInts &A, int haveA, const LaneInts &B,
 //   posts_out [15][VAMD_POSTS_STRIDE], post_valid [15], ilogmask [15][n2], nonzero [15], each with
 //   the given element stride between consecutive k
 VAMD_DEV void floor_managed_block(const PsyP &P, const FloorP &F, int n2, const float *__restrict__ noise,
-                                  const float *__restrict__ tone, const float *__restrict__ logmdct,
+                                  const float *__restrict__ tone, const float *__restrict__ mdct_raw,
                                   unsigned short *qc, FloorScratch *sc, int *__restrict__ posts_out, long posts_stride,
                                   int *__restrict__ post_valid, long valid_stride, int *__restrict__ ilogmask,
                                   long ilog_stride, int *__restrict__ nonzero, long nz_stride, PhaseClock &pc) {
@@ -714,10 +716,10 @@ VAMD_DEV void floor_managed_block(const PsyP &P, const FloorP &F, int n2, const 
   int hlo = 0, hhi = 0;
   if (hmid) {
     WAVE_SYNC();
-    mask_quantise_wave(P, 2, noise, tone, logmdct, qc, F.twofitatten);
+    mask_quantise_wave(P, 2, noise, tone, mdct_raw, qc, F.twofitatten);
     hhi = floor_fit_posts(F, qc, sc, fhi, pc);
     WAVE_SYNC();
-    mask_quantise_wave(P, 0, noise, tone, logmdct, qc, F.twofitatten);
+    mask_quantise_wave(P, 0, noise, tone, mdct_raw, qc, F.twofitatten);
     hlo = floor_fit_posts(F, qc, sc, flo, pc);
     WAVE_SYNC();
   }

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(64 * VAMD_XF_WAVES) void k_transform(XformP G, int 
     const long blk = (long)((unsigned)cb / (unsigned)ch);
     transform_window(P, W, d_lW(d, blk), d_nW(d, blk), tile, L.A, pc, tm);
     if (cb + cstride < ncb) pcm_fetch(tile, pcm + (cb + cstride) * n, n, tm);  // next block, one ahead
-    const float amp = transform_block<LOGN>(P, L.A, L.B, mdct_raw + cb * n2, logmdct + cb * n2, logfft + cb * n2, pc);
+    const float amp = transform_block<LOGN>(P, L.A, L.B, mdct_raw + cb * n2, logmdct ? logmdct + cb * n2 : nullptr, logfft + cb * n2, pc);
     if (LANE == 0) local_ampmax[cb] = amp;
   }
   pc.flush();
@@ -180,7 +180,7 @@ struct NoiseGeom {
 };
 template <int LOGN2>
 __global__ __launch_bounds__(64 * NoiseGeom<LOGN2>::NW, NoiseGeom<LOGN2>::KPL <= 4 ? 8 : 4) void k_noise(PsyP P0, PsyP P1, DescP d, int ch, long ncb,
-                                                                     const float *__restrict__ logmdct,
+                                                                     const float *__restrict__ mdct_raw,
                                                                      float *__restrict__ noise) {
   constexpr int n2 = NoiseGeom<LOGN2>::n2, KPL = NoiseGeom<LOGN2>::KPL;
   float *S = (float *)vamd_smem;  // the five running sums and nothing else: see VAMD_NZ_STRIDE
@@ -192,7 +192,8 @@ __global__ __launch_bounds__(64 * NoiseGeom<LOGN2>::NW, NoiseGeom<LOGN2>::KPL <=
   int braw[KPL], bt_have = -1;
   float compand_lane = 0.f;  // noisecompand[LANE]
   long cb = blockIdx.x;
-  if (cb < ncb) LANE_BINS(k, i, i0, KPL, n2) lm[k] = logmdct[cb * n2 + i];
+  // (the spectrum in dB, lib/mapping0.c:384-385, is formed here from the spectrum itself: nobody writes it to HBM)
+  if (cb < ncb) LANE_BINS(k, i, i0, KPL, n2) lm[k] = mdct_raw[cb * n2 + i];
   for (; cb < ncb; cb += gridDim.x) {
     const int bt = d_bt(d, (long)((unsigned)cb / (unsigned)ch));  // (cb < 2^31: check_desc)
     const PsyP &P = bt ? P1 : P0;
@@ -203,7 +204,8 @@ __global__ __launch_bounds__(64 * NoiseGeom<LOGN2>::NW, NoiseGeom<LOGN2>::KPL <=
       compand_lane = LANE < VAMD_NOISE_COMPAND_LEVELS ? P.noisecompand[LANE] : 0.f;
       bt_have = bt;
     }
-    LANE_BINS(k, i, i0, KPL, n2) lm_next[k] = logmdct[nb * n2 + i];
+    LANE_BINS(k, i, i0, KPL, n2) lm_next[k] = mdct_raw[nb * n2 + i];
+    LANE_BINS(k, i, i0, KPL, n2) lm[k] = todB_345(lm[k]);
     noisemask_bins<ScanTeam, KPL, LOGN2>(
         P, lm, braw, o, S,
         [&](int dB) { return __int_as_float(__builtin_amdgcn_ds_bpermute(dB << 2, __float_as_int(compand_lane))); }, ScanTeam(), pc,
@@ -355,7 +357,7 @@ __global__ __launch_bounds__(64) void k_tone_fold(PsyP P0, PsyP P1, DescP d, int
 // stage 4: offset_and_mix + floor1_fit + floor curve
 __global__ __launch_bounds__(64) void k_floor(PsyP P0, PsyP P1, FloorP F0, FloorP F1, ChMap cm, DescP d, int ch,
                                               const float *__restrict__ noise, const float *__restrict__ tone,
-                                              const float *__restrict__ logmdct, const float *__restrict__ mdct_raw,
+                                              const float *__restrict__ mdct_raw,
                                               float *__restrict__ mdct, float *__restrict__ logmask_out,
                                               int *__restrict__ posts, int *__restrict__ post_valid,
                                               int *__restrict__ ilogmask, int *__restrict__ nonzero) {
@@ -368,7 +370,7 @@ __global__ __launch_bounds__(64) void k_floor(PsyP P0, PsyP P1, FloorP F0, Floor
   FloorScratch *sc = (FloorScratch *)(qc + ((n2 + 15) & ~15));
   PhaseClock pc;
   pc.start(d.dbg ? d.dbg + 48 : nullptr);
-  offset_and_mix_wave(P, noise + cb * n2, tone + cb * n2, logmdct + cb * n2, mdct_raw + cb * n2, mdct + cb * n2,
+  offset_and_mix_wave(P, noise + cb * n2, tone + cb * n2, mdct_raw + cb * n2, mdct + cb * n2,
                       logmask_out ? logmask_out + cb * n2 : nullptr, qc, F.twofitatten, pc);
   const int nzf = floor_fit_render_block(F, n2, qc, sc, posts + cb * VAMD_POSTS_STRIDE, post_valid + cb,
                                          ilogmask + cb * n2, pc);
@@ -457,7 +459,6 @@ __global__ __launch_bounds__(64) void k_couple_general(PsyP P0, PsyP P1, CoupleS
 // out [block][candidate packet][channel][...].
 __global__ __launch_bounds__(64) void k_floor_managed(PsyP P0, PsyP P1, FloorP F0, FloorP F1, ChMap cm, DescP d, int ch,
                                                       const float *__restrict__ noise, const float *__restrict__ tone,
-                                                      const float *__restrict__ logmdct,
                                                       const float *__restrict__ mdct_raw, float *__restrict__ mdct,
                                                       float *__restrict__ logmask_out, int *__restrict__ posts,
                                                       int *__restrict__ post_valid, int *__restrict__ ilogmask,
@@ -472,10 +473,10 @@ __global__ __launch_bounds__(64) void k_floor_managed(PsyP P0, PsyP P1, FloorP F
   FloorScratch *sc = (FloorScratch *)(qc + ((n2 + 15) & ~15));
   PhaseClock pc;
   pc.start(nullptr);
-  offset_and_mix_wave(P, noise + cb * n2, tone + cb * n2, logmdct + cb * n2, mdct_raw + cb * n2, mdct + cb * n2,
+  offset_and_mix_wave(P, noise + cb * n2, tone + cb * n2, mdct_raw + cb * n2, mdct + cb * n2,
                       logmask_out ? logmask_out + cb * n2 : nullptr, qc, F.twofitatten, pc);
   const long u0 = blk * VAMD_PACKETBLOBS * ch + c;  // unit (blk, k = 0), channel c
-  floor_managed_block(P, F, n2, noise + cb * n2, tone + cb * n2, logmdct + cb * n2, qc, sc,
+  floor_managed_block(P, F, n2, noise + cb * n2, tone + cb * n2, mdct_raw + cb * n2, qc, sc,
                       posts + u0 * VAMD_POSTS_STRIDE, (long)ch * VAMD_POSTS_STRIDE, post_valid + u0, ch,
                       ilogmask + u0 * n2, (long)ch * n2, nonzero + u0, ch, pc);
 }
@@ -949,7 +950,7 @@ static int plan(vamd_ctx *c, int W, long nb, const vamd_batch_io *io, int level,
     p->field = (decltype(p->field))v;                   \
   }
   PICK(mdct_raw, io ? io->mdct_raw : nullptr, WS_MDCT_RAW, per);
-  PICK(logmdct, io ? io->logmdct : nullptr, WS_LOGMDCT, per);
+  p->logmdct = io ? io->logmdct : nullptr;  // a tap only: the later stages form it from mdct_raw
   PICK(logfft, io ? io->logfft : nullptr, WS_LOGFFT, per);
   PICK(local, io ? io->local_ampmax : nullptr, WS_LOCAL, (size_t)nb * ch * 4);
   PICK(ampglob, io ? io->ampmax_out : nullptr, WS_AMPGLOB, (size_t)nb * 4);
@@ -1203,7 +1204,7 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_
       if (per_cu < 1) per_cu = 1;
       const unsigned grid = (unsigned)((long)gcb < per_cu * c->num_cus ? (long)gcb : per_cu * c->num_cus);
 #define VAMD_GO(L)                                                                                                    \
-  hipLaunchKernelGGL(k_noise<L>, dim3(grid), dim3(64 * NoiseGeom<L>::NW), lds, s, P0, P1, d, ch, (long)gcb, p.logmdct, \
+  hipLaunchKernelGGL(k_noise<L>, dim3(grid), dim3(64 * NoiseGeom<L>::NW), lds, s, P0, P1, d, ch, (long)gcb, p.mdct_raw, \
                      p.noise)
       switch (n2) {
         case 32: VAMD_GO(5); break;
@@ -1244,7 +1245,7 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_
     // bitrate-managed: fifteen candidate packets per block
     const size_t flds = (size_t)((n2 + 15) & ~15) * 2 + sizeof(FloorScratch);
     hipLaunchKernelGGL(k_floor_managed, dim3(gcb), dim3(64), flds, s, P0, P1, c->B.floor[W][0], c->B.floor[W][1], c->B.chmap[W], d, ch, p.noise, p.tone,
-                       p.logmdct, p.mdct_raw, p.mdct, R->io->logmask, M->posts, M->post_valid, m_ilogmask, M->nonzero);
+                       p.mdct_raw, p.mdct, R->io->logmask, M->posts, M->post_valid, m_ilogmask, M->nonzero);
     prof_mark(c, VAMD_ST_FLOOR);
     launch_couple(c, R, s, (long)gb * VAMD_PACKETBLOBS, 0, VAMD_PACKETBLOBS, p.mdct, m_ilogmask, M->iwork, M->nonzero);
     prof_mark(c, VAMD_ST_COUPLE);
@@ -1253,7 +1254,7 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_
                           M->packets, M->packet_stride, M->packet_bits);
   } else if (level >= VAMD_LEVEL_FULL) {
     hipLaunchKernelGGL(k_floor, dim3(gcb), dim3(64), (size_t)((n2 + 15) & ~15) * 2 + sizeof(FloorScratch), s, P0, P1,
-                       c->B.floor[W][0], c->B.floor[W][1], c->B.chmap[W], d, ch, p.noise, p.tone, p.logmdct, p.mdct_raw, p.mdct,
+                       c->B.floor[W][0], c->B.floor[W][1], c->B.chmap[W], d, ch, p.noise, p.tone, p.mdct_raw, p.mdct,
                        R->io->logmask, p.posts, p.post_valid, p.ilogmask, p.nonzero);
     prof_mark(c, VAMD_ST_FLOOR);
     launch_couple(c, R, s, gb, VAMD_PACKETBLOBS / 2, 1, p.mdct, p.ilogmask, p.iwork, p.nonzero);
