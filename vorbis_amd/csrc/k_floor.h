@@ -619,20 +619,67 @@ VAMD_DEV int floor_encode_render(const FloorP &F, int n2, const LaneInts &outp, 
   // ---- render the integer curve, lib/floor1.c:923-946: segment list of the
   // used posts in x order, then every bin evaluates its segment's line.
 #if VAMD_GPU
+  // lane j looks at the j-th post in x order; used posts are compacted by rank.  Which segment a bin falls into
+  // then needs no search: bin_interval[x] (static) is the last post at or before x in x order, and the used posts
+  // among those up to it are a population count of the ballot.
+  unsigned long long um;
   {
-    // lane j looks at the j-th post in x order; used posts are compacted by rank
     const int j = LANE;
     const int cur = forward_index.at(j);
     const int src = j < posts ? cur : 0;
     const int pv = post.gather(src), px = postlist.gather(src);  // (gathers need every lane active)
     const bool used = j < posts && (j == 0 || (pv & 0x8000) == 0);
-    const unsigned long long um = __ballot(used);
+    um = __ballot(used);
     if (used) {
       const int r = __builtin_popcountll(um & ((1ull << j) - 1ull));
       sc->segx[r] = j == 0 ? 0 : px;
       sc->segy[r] = (pv & 0x7fff) * F.mult;
     }
-    if (LANE == 0) sc->nseg = __builtin_popcountll(um) - 1;
+  }
+  WAVE_SYNC();
+  // one row per segment: where it starts and its Bresenham constants (render_line0, lib/floor1.c:923-946);
+  // the last used post gets a flat row (the curve is held beyond it, :941-943).  The rows overlay the fit's
+  // accumulators, which are dead by now.
+  struct SegRow {
+    int x0, y0, base, sgn;
+    int ady, adx;
+    float rcp;
+    int pad;
+  };
+  SegRow *rows = (SegRow *)sc->acc;
+  {
+    const int ns = __builtin_popcountll(um) - 1;
+    if (LANE <= ns) {
+      SegRow r;
+      r.x0 = sc->segx[LANE];
+      r.y0 = sc->segy[LANE];
+      r.base = 0, r.sgn = 1, r.ady = 0, r.adx = 1, r.rcp = 1.f, r.pad = 0;
+      if (LANE < ns) {
+        const LineStep st = line_step(r.x0, sc->segx[LANE + 1], r.y0, sc->segy[LANE + 1]);
+        r.base = st.base, r.sgn = st.sgn, r.ady = st.ady, r.adx = st.adx, r.rcp = st.rcp;
+      }
+      rows[LANE] = r;
+    }
+  }
+  WAVE_SYNC();
+  pc.mark(3);
+  if (ilogmask) {
+    WAVE_FOR(q, n2 >> 2) {
+      const unsigned int jq = ((const unsigned int *)F.bin_interval)[q];
+      int v[4];
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const int jb = (int)((jq >> (8 * c)) & 0xff);
+        const int j = jb == 255 ? 63 : (jb & 0x7f);
+        const int sgm = __builtin_popcountll(um & ((2ull << j) - 1ull)) - 1;
+        const SegRow r = rows[sgm];
+        const int k = 4 * q + c - r.x0;
+        v[c] = r.y0 + k * r.base + r.sgn * div_small(k * r.ady, r.adx, r.rcp);
+      }
+      I4 o;
+      o.x = v[0], o.y = v[1], o.z = v[2], o.w = v[3];
+      ((I4 *)ilogmask)[q] = o;
+    }
   }
 #else
   {
@@ -651,7 +698,6 @@ VAMD_DEV int floor_encode_render(const FloorP &F, int n2, const LaneInts &outp, 
     }
     sc->nseg = ns;
   }
-#endif
   WAVE_SYNC();
   pc.mark(3);
   if (ilogmask) {
@@ -669,6 +715,7 @@ VAMD_DEV int floor_encode_render(const FloorP &F, int n2, const LaneInts &outp, 
       ilogmask[x] = v;
     }
   }
+#endif
   WAVE_SYNC();
   pc.mark(4);
   return 1;
