@@ -355,7 +355,9 @@ __global__ __launch_bounds__(64) void k_tone_fold(PsyP P0, PsyP P1, DescP d, int
 }
 
 // stage 4: offset_and_mix + floor1_fit + floor curve
-__global__ __launch_bounds__(64) void k_floor(PsyP P0, PsyP P1, FloorP F0, FloorP F1, ChMap cm, DescP d, int ch,
+// (eight waves per SIMD, i.e. 64 registers: measured against the 73 the compiler would take and six or seven waves --
+// the stage is latency-bound, its time follows the blocks in flight: tools/floor_occ.sh -- 2.14 against 2.24 ms)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_floor(PsyP P0, PsyP P1, FloorP F0, FloorP F1, ChMap cm, DescP d, int ch,
                                               const float *__restrict__ noise, const float *__restrict__ tone,
                                               const float *__restrict__ mdct_raw,
                                               float *__restrict__ mdct, float *__restrict__ logmask_out,
@@ -1253,7 +1255,8 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_
       launch_residue_pack(c, R, s, (long)gb * VAMD_PACKETBLOBS, VAMD_PACKETBLOBS, M->posts, M->post_valid, M->iwork, M->nonzero, rb,
                           M->packets, M->packet_stride, M->packet_bits);
   } else if (level >= VAMD_LEVEL_FULL) {
-    hipLaunchKernelGGL(k_floor, dim3(gcb), dim3(64), (size_t)((n2 + 15) & ~15) * 2 + sizeof(FloorScratch), s, P0, P1,
+    static const size_t floor_pad = getenv("VAMD_FLOOR_LDS_PAD") ? (size_t)atoi(getenv("VAMD_FLOOR_LDS_PAD")) : 0;  // (experiment: occupancy)
+    hipLaunchKernelGGL(k_floor, dim3(gcb), dim3(64), (size_t)((n2 + 15) & ~15) * 2 + sizeof(FloorScratch) + floor_pad, s, P0, P1,
                        c->B.floor[W][0], c->B.floor[W][1], c->B.chmap[W], d, ch, p.noise, p.tone, p.mdct_raw, p.mdct,
                        R->io->logmask, p.posts, p.post_valid, p.ilogmask, p.nonzero);
     prof_mark(c, VAMD_ST_FLOOR);
