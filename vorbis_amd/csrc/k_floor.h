@@ -252,7 +252,7 @@ VAMD_DEV LineStep line_step(int x0, int x1, int y0, int y1) {
   const int dy = y1 - y0;
   s.adx = x1 - x0;
   int ady = dy < 0 ? -dy : dy;
-  s.rcp = div_rcp(s.adx);
+  s.rcp = div_rcp_fast(s.adx);  // (quotients here are line heights and offsets: < 2^11)
   const int ab = div_small(ady, s.adx, s.rcp);  // |dy| / adx; C's dy/adx truncates toward zero
   s.base = dy < 0 ? -ab : ab;
   s.sgn = dy < 0 ? -1 : 1;  // sy - base
@@ -276,15 +276,19 @@ VAMD_DEV int inspect_error_wave(int x0, int x1, int y0, int y1, const unsigned s
     mse += (y - val) * (y - val);
     if (qv & 0x8000) {  // mdct[x] + twofitatten >= mask[x]
       if (k == 0 || val) {  // the first point is checked even when val == 0 (lib/floor1.c:536-539)
-        if ((float)y + F.maxover < (float)val) bad = 1;
-        if ((float)y - F.maxunder > (float)val) bad = 1;
+        if (F.int_tests) {  // the same two tests in integers (floor_derive_tests)
+          if (val - y >= F.over_i || y - val >= F.under_i) bad = 1;
+        } else {
+          if ((float)y + F.maxover < (float)val) bad = 1;
+          if ((float)y - F.maxunder > (float)val) bad = 1;
+        }
       }
     }
   }
   if (wave_any(bad)) return 1;
+  // maxover^2 / cnt > maxerr, maxunder^2 / cnt > maxerr (:556-557), as thresholds on cnt (floor_derive_tests)
+  if (cnt <= F.cnt_over || cnt <= F.cnt_under) return 0;
   mse = wave_sum(mse);
-  if (F.maxover * F.maxover / (float)cnt > F.maxerr) return 0;
-  if (F.maxunder * F.maxunder / (float)cnt > F.maxerr) return 0;
   // (float)(mse / cnt) > maxerr, without the integer divide: the quotient q is an integer, so for
   // maxerr >= 0 the test is q >= floor(maxerr) + 1, i.e. mse >= (floor(maxerr) + 1) * cnt.  (q >= 2^24,
   // where the float conversion would round, is far above any maxerr and true on both sides.)
@@ -306,7 +310,7 @@ VAMD_DEV int render_point(int x0, int x1, int y0, int y1, int x) {
   y1 &= 0x7fff;
   const int dy = y1 - y0, adx = x1 - x0;
   const int ady = dy < 0 ? -dy : dy;
-  const int off = div_small(ady * (x - x0), adx, div_rcp(adx));
+  const int off = div_small(ady * (x - x0), adx, div_rcp_fast(adx));
   return dy < 0 ? y0 - off : y0 + off;
 }
 

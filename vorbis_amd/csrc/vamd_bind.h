@@ -2,6 +2,7 @@
 // tables (vamd_derive.h) and bind the kernel parameter structs to a base
 // address (the HBM copy for the product, the host copy for tests/emul).
 #pragma once
+#include <math.h>
 #include <stddef.h>
 #include <string.h>
 #include <algorithm>
@@ -364,6 +365,24 @@ inline int build_image(const void *blob_v, size_t bytes, std::vector<unsigned ch
   return VAMD_OK;
 }
 
+// inspect_error's comparisons whose operands do not depend on the audio (lib/floor1.c:536-563), settled here with
+// the reference's own float expressions:
+//  * "maxover*maxover/n > maxerr" for a point count n: the quotient falls as n grows, so the test is n <= cnt_over;
+//  * "y + maxover < val" / "y - maxunder > val" with y, val integers in [0, 1023]: when maxover is a multiple of
+//    2^-13 below 1024 the float sum is exact and the test is the integer val - y >= floor(maxover) + 1 (likewise
+//    y - val >= floor(maxunder) + 1); otherwise the kernels keep the float form (int_tests = 0).
+inline void floor_derive_tests(FloorP *F) {
+  F->cnt_over = F->cnt_under = 0;
+  for (int n = 1; n <= 65536; n++) {
+    if (F->maxover * F->maxover / (float)n > F->maxerr) F->cnt_over = n;
+    if (F->maxunder * F->maxunder / (float)n > F->maxerr) F->cnt_under = n;
+  }
+  auto nice = [](float v) { return fabsf(v) < 1024.f && v * 8192.f == floorf(v * 8192.f); };
+  F->int_tests = nice(F->maxover) && nice(F->maxunder);
+  F->over_i = F->int_tests ? (int)floorf(F->maxover) + 1 : 0;
+  F->under_i = F->int_tests ? (int)floorf(F->maxunder) + 1 : 0;
+}
+
 // Bind parameter structs to `base` (address of the image in the memory space
 // the kernels will read: device pointer for HIP, host pointer for tests/emul).
 inline void bind_params(const std::vector<unsigned char> &image, const std::vector<uint32_t> &derived_off,
@@ -418,6 +437,7 @@ inline void bind_params(const std::vector<unsigned char> &image, const std::vect
       F.maxerr = f.maxerr;
       F.twofitweight = f.twofitweight;
       F.twofitatten = f.twofitatten;
+      floor_derive_tests(&F);
       const size_t fo = offsetof(vamd_setup_header, mode) + sizeof(vamd_mode_tab) * W + offsetof(vamd_mode_tab, floor) +
                         sizeof(vamd_floor1_tab) * src;
       F.postlist = (const int *)(base + fo + offsetof(vamd_floor1_tab, postlist));

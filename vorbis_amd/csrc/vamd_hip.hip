@@ -357,7 +357,7 @@ __global__ __launch_bounds__(64) void k_tone_fold(PsyP P0, PsyP P1, DescP d, int
 // stage 4: offset_and_mix + floor1_fit + floor curve
 // (eight waves per SIMD, i.e. 64 registers: measured against the 73 the compiler would take and six or seven waves --
 // the stage is latency-bound, its time follows the blocks in flight: tools/floor_occ.sh -- 2.14 against 2.24 ms)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_floor(PsyP P0, PsyP P1, FloorP F0, FloorP F1, ChMap cm, DescP d, int ch,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_floor(const Bound *__restrict__ Bd, int W, DescP d, int ch,
                                               const float *__restrict__ noise, const float *__restrict__ tone,
                                               const float *__restrict__ mdct_raw,
                                               float *__restrict__ mdct, float *__restrict__ logmask_out,
@@ -365,8 +365,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                                               int *__restrict__ ilogmask, int *__restrict__ nonzero) {
   const long cb = blockIdx.x;
   const long blk = cb / ch;
-  const PsyP &P = d_bt(d, blk) ? P1 : P0;
-  const FloorP &F = cm.sub[cb - blk * ch] ? F1 : F0;  // the floor of this channel's submap
+  // (the parameter structs stay in HBM and are read field by field through the scalar cache: four of them by value
+  // are more SGPRs than the stage has)
+  const PsyP &P = Bd->psy[2 * W + (d_bt(d, blk) ? 1 : 0)];
+  const FloorP &F = Bd->floor[W][Bd->chmap[W].sub[cb - blk * ch]];  // the floor of this channel's submap
   const int n2 = P.n;
   unsigned short *qc = (unsigned short *)vamd_smem;  // [n2 rounded up to 16]
   FloorScratch *sc = (FloorScratch *)(qc + ((n2 + 15) & ~15));
@@ -702,6 +704,7 @@ struct vamd_ctx {
   bool overlap = true;
   Bound B;                 // parameter structs bound to the HBM image
   unsigned char *d_image = nullptr;
+  Bound *d_bound = nullptr;  // c->B in HBM: kernels that would otherwise carry several parameter structs in SGPRs read it
   size_t image_bytes = 0;
   std::string err;
   // workspace, grown on demand (vamd_reserve to pre-size)
@@ -841,6 +844,7 @@ int vamd_create(vamd_ctx **out, const void *setup_blob, size_t blob_bytes, int d
   if (e != hipSuccess) {
     fprintf(stderr, "vamd_create: HIP failure: %s\n", hipGetErrorString(e));
     if (c->d_image) (void)hipFree(c->d_image);
+  if (c->d_bound) (void)hipFree(c->d_bound);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->side) (void)hipStreamDestroy(c->side);
@@ -850,6 +854,18 @@ int vamd_create(vamd_ctx **out, const void *setup_blob, size_t blob_bytes, int d
   }
   c->image_bytes = image.size();
   bind_params(image, doff, derived, c->d_image, &c->B);
+  if (hipMalloc((void **)&c->d_bound, sizeof(Bound)) != hipSuccess ||
+      hipMemcpy(c->d_bound, &c->B, sizeof(Bound), hipMemcpyHostToDevice) != hipSuccess) {
+    fprintf(stderr, "vamd_create: HIP failure uploading the parameter block\n");
+    if (c->d_bound) (void)hipFree(c->d_bound);
+    (void)hipFree(c->d_image);
+    (void)hipEventDestroy(c->ev_fork);
+    (void)hipEventDestroy(c->ev_join);
+    (void)hipStreamDestroy(c->side);
+    if (caller_device >= 0) (void)hipSetDevice(caller_device);
+    delete c;
+    return VAMD_EFAULT;
+  }
   if (caller_device >= 0 && caller_device != c->device) (void)hipSetDevice(caller_device);
   *out = c;
   return VAMD_OK;
@@ -868,6 +884,7 @@ void vamd_destroy(vamd_ctx *c) {
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->side) (void)hipStreamDestroy(c->side);
   if (c->d_image) (void)hipFree(c->d_image);
+  if (c->d_bound) (void)hipFree(c->d_bound);
   delete c;
 }
 
@@ -1256,8 +1273,8 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_
                           M->packets, M->packet_stride, M->packet_bits);
   } else if (level >= VAMD_LEVEL_FULL) {
     static const size_t floor_pad = getenv("VAMD_FLOOR_LDS_PAD") ? (size_t)atoi(getenv("VAMD_FLOOR_LDS_PAD")) : 0;  // (experiment: occupancy)
-    hipLaunchKernelGGL(k_floor, dim3(gcb), dim3(64), (size_t)((n2 + 15) & ~15) * 2 + sizeof(FloorScratch) + floor_pad, s, P0, P1,
-                       c->B.floor[W][0], c->B.floor[W][1], c->B.chmap[W], d, ch, p.noise, p.tone, p.mdct_raw, p.mdct,
+    hipLaunchKernelGGL(k_floor, dim3(gcb), dim3(64), (size_t)((n2 + 15) & ~15) * 2 + sizeof(FloorScratch) + floor_pad, s,
+                       (const Bound *)c->d_bound, W, d, ch, p.noise, p.tone, p.mdct_raw, p.mdct,
                        R->io->logmask, p.posts, p.post_valid, p.ilogmask, p.nonzero);
     prof_mark(c, VAMD_ST_FLOOR);
     launch_couple(c, R, s, gb, VAMD_PACKETBLOBS / 2, 1, p.mdct, p.ilogmask, p.iwork, p.nonzero);

@@ -108,6 +108,10 @@ struct FloorP {
   const unsigned char *bin_interval;  // [n2] derived: accumulate_fit interval of each bin (255 = none)
   const int *level;                   // [64] derived: dependency level of each post
   int nlevels;
+  // inspect_error's tests (lib/floor1.c:516-565) with the float work done once, at vamd_create (floor_derive_tests):
+  int cnt_over, cnt_under;  // maxover^2 / n > maxerr holds exactly for the point counts n <= cnt_over (same for under)
+  int int_tests;            // maxover / maxunder are multiples of 2^-13 below 1024: "y + maxover < val" is exact in
+  int over_i, under_i;      //   integers: val - y >= over_i, resp. y - val >= under_i
 };
 
 struct CoupleP {

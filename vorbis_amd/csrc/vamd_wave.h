@@ -334,6 +334,15 @@ struct LaneDoubles {
 // Exact floor(num/den) for 0 <= num < 2^24, 0 < den < 2^12 without the integer-divide
 // expansion: one fp32 multiply by a precomputed reciprocal, then a +-1 fix-up.
 VAMD_DEV float div_rcp(int den) { return 1.0f / (float)den; }
+// For quotients below 2^12 (num < 2^24): the hardware's one-instruction reciprocal (1 ulp) leaves the product within
+// a thousandth of the true quotient, far inside div_small's +-1 fix-up; the result is the exact floor either way.
+VAMD_DEV float div_rcp_fast(int den) {
+#if VAMD_GPU
+  return __builtin_amdgcn_rcpf((float)den);
+#else
+  return 1.0f / (float)den;
+#endif
+}
 VAMD_DEV int div_small(int num, int den, float rcp) {
   int q = (int)((float)num * rcp);
   const int r = num - q * den;
