@@ -92,18 +92,24 @@ VAMD_DEV void seed_curve_scatter(float *seed, const float *__restrict__ band_row
 VAMD_DEV void seed_chase_paint(float *seeds, const float *__restrict__ src, int linesper, int n, int stack,
                                const unsigned short *__restrict__ posstack) {
   int carry = 0;
+  // Software pipeline over the chunks of 64 survivors: the list entries are fetched two chunks ahead and the
+  // amplitudes they point at one chunk ahead, so that a chunk finds both in registers (one after the other they are
+  // two dependent trips to memory per chunk, in a stage that spends three quarters of its time waiting).
+  auto at = [&](int k) { return k < stack ? (int)posstack[k] : 0; };
+  int pos1 = at(LANE), npos1 = at(LANE + 1);                    // chunk 0
+  int pos2 = at(LANE + NLANES), npos2 = at(LANE + NLANES + 1);  // chunk 1
+  float a1 = src[pos1], an1 = src[npos1];
   for (int base = 0; base < stack; base += NLANES) {
     const int k = base + LANE;
+    const int pos = pos1, npos = npos1;
+    const float a = a1, an = an1;
+    pos1 = pos2, npos1 = npos2;
+    a1 = src[pos1], an1 = src[npos1];
+    pos2 = at(k + 2 * NLANES), npos2 = at(k + 2 * NLANES + 1);
     int endpos = 0;
-    float a = 0.f;
     if (k < stack) {
-      const int pos = posstack[k];
-      a = src[pos];
       endpos = pos + linesper + 1;
-      if (k < stack - 1) {
-        const int npos = posstack[k + 1];
-        if (src[npos] > a) endpos = npos;
-      }
+      if (k < stack - 1 && an > a) endpos = npos;
       if (endpos > n) endpos = n;
     }
     const int incl = wave_scan_max(endpos);
