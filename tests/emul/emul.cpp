@@ -93,7 +93,7 @@ static void residue_and_pack(const Bound &B, int W, int lW, int nW, const int *i
 }
 
 // couple / quantise / normalise with whichever form the layout needs (as launch_couple picks the kernel)
-static void couple_any(const CoupleP &C, const PsyP &P, int n2, const float *const *mp, const int *const *ip, int *const *op,
+static void couple_any(const CoupleP &C, const PsyP &P, int n2, const float *const *mp, const ilog_t *const *ip, int *const *op,
                        int *nonzero, PhaseClock &pc) {
   std::vector<float> cand(n2), key(n2), sgn(n2), accp(256);
   CoupleLds L = {cand.data(), key.data(), sgn.data(), accp.data()};
@@ -164,9 +164,10 @@ static int analyze_core(void *h, const float *pcm, int lW, int W, int nW, int bl
   std::vector<float> A(VAMD_XF_A_FLOATS(n)), Bw(VAMD_XF_B_FLOATS(n));
   std::vector<float> mdct_raw(ch * n2), logfft(ch * n2), logmdct(ch * n2), noise(ch * n2), tone(ch * n2),
       logmask(ch * n2), mdct(ch * n2), lmd(n2), mask(n2);
-  std::vector<int> posts(ch * VAMD_POSTS_STRIDE), post_valid(ch), ilogmask(ch * n2), iwork(ch * n2), nonzero(ch);
+  std::vector<int> posts(ch * VAMD_POSTS_STRIDE), post_valid(ch), iwork(ch * n2), nonzero(ch);
+  std::vector<ilog_t> ilogmask(ch * n2);
   std::vector<float> local(ch);
-  std::vector<int> m_ilog;
+  std::vector<ilog_t> m_ilog;
   float global = ampmax_in;
   PhaseClock pc;
   pc.start(nullptr);
@@ -214,7 +215,7 @@ static int analyze_core(void *h, const float *pcm, int lW, int W, int nW, int bl
   }
   {
     const float *mp[VAMD_MAX_CH];
-    const int *ip[VAMD_MAX_CH];
+    const ilog_t *ip[VAMD_MAX_CH];
     int *op[VAMD_MAX_CH];
     for (int i = 0; i < ch; i++) {
       mp[i] = &mdct[i * n2];
@@ -260,7 +261,8 @@ static int analyze_core(void *h, const float *pcm, int lW, int W, int nW, int bl
   OUT(mdct, mdct, float);
   OUT(posts, posts, int);
   OUT(post_valid, post_valid, int);
-  OUT(ilogmask, ilogmask, int);
+  if (t->ilogmask)
+    for (size_t k = 0; k < ilogmask.size(); k++) t->ilogmask[k] = ilogmask[k];
   OUT(iwork, iwork, int);
   OUT(nonzero, nonzero, int);
   OUT(local_ampmax, local, float);

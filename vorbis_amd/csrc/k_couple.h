@@ -209,7 +209,7 @@ VAMD_DEV float couple_bin(ChanBin &M, ChanBin &A, int &iM, int &iA, int b, int n
 // instantiation): the ordered general path below is then not even compiled in, which halves the registers.
 template <bool NORM = true>
 VAMD_DEV void couple_block(const CoupleP &C, const PsyP &P, int n2, const float *const *mdct,
-                           const int *const *ilogmask, int *const *iwork, int *nonzero, const CoupleLds &L,
+                           const ilog_t *const *ilogmask, int *const *iwork, int *nonzero, const CoupleLds &L,
                            PhaseClock &pc) {
   const int ch = C.ch;
   const int partition = P.normal_p ? P.normal_partition : 16;
@@ -235,12 +235,12 @@ VAMD_DEV void couple_block(const CoupleP &C, const PsyP &P, int n2, const float 
       float m0[4], m1[4];
       int l0[4], l1[4], o0[4], o1[4];
       f4_get(((const F4 *)mdct[Mi])[q], m0);
-      const I4 t0 = ((const I4 *)ilogmask[Mi])[q];
-      l0[0] = t0.x; l0[1] = t0.y; l0[2] = t0.z; l0[3] = t0.w;
+      const I2 t0 = ((const I2 *)ilogmask[Mi])[q];
+      l0[0] = t0.x & 0xffff; l0[1] = (int)((unsigned)t0.x >> 16); l0[2] = t0.y & 0xffff; l0[3] = (int)((unsigned)t0.y >> 16);
       if (ch > 1) {
         f4_get(((const F4 *)mdct[Ai])[q], m1);
-        const I4 t1 = ((const I4 *)ilogmask[Ai])[q];
-        l1[0] = t1.x; l1[1] = t1.y; l1[2] = t1.z; l1[3] = t1.w;
+        const I2 t1 = ((const I2 *)ilogmask[Ai])[q];
+        l1[0] = t1.x & 0xffff; l1[1] = (int)((unsigned)t1.x >> 16); l1[2] = t1.y & 0xffff; l1[3] = (int)((unsigned)t1.y >> 16);
       }
 #if VAMD_GPU
 #pragma unroll
@@ -329,7 +329,7 @@ struct CoupleState {
 };
 
 VAMD_DEV void couple_block_general(const CoupleP &C, const PsyP &P, int n2, const float *const *mdct,
-                                   const int *const *ilogmask, int *const *iwork, int *nonzero, const CoupleLds &L,
+                                   const ilog_t *const *ilogmask, int *const *iwork, int *nonzero, const CoupleLds &L,
                                    const CoupleState &S, PhaseClock &pc) {
   const int ch = C.ch, steps = C.coupling_steps;
   const int partition = P.normal_p ? P.normal_partition : 16;

@@ -598,7 +598,7 @@ VAMD_DEV void floor_quantise_predict(const FloorP &F, const LaneInts &outp, cons
 // Returns floor1_encode's nonzero flag (1 = non-trivial floor).
 VAMD_DEV int floor_encode_render(const FloorP &F, int n2, const LaneInts &outp, int valid, FloorScratch *sc,
                                  int *__restrict__ posts_out, int *__restrict__ post_valid,
-                                 int *__restrict__ ilogmask, PhaseClock &pc) {
+                                 ilog_t *__restrict__ ilogmask, PhaseClock &pc) {
   const int posts = F.posts;
   if (!valid) {
     // no fit: floor1_encode writes a zero curve (lib/floor1.c:948-952)
@@ -680,9 +680,9 @@ VAMD_DEV int floor_encode_render(const FloorP &F, int n2, const LaneInts &outp, 
         const int k = 4 * q + c - r.x0;
         v[c] = r.y0 + k * r.base + r.sgn * div_small(k * r.ady, r.adx, r.rcp);
       }
-      I4 o;
-      o.x = v[0], o.y = v[1], o.z = v[2], o.w = v[3];
-      ((I4 *)ilogmask)[q] = o;
+      I2 o;
+      o.x = v[0] | (v[1] << 16), o.y = v[2] | (v[3] << 16);
+      ((I2 *)ilogmask)[q] = o;
     }
   }
 #else
@@ -716,7 +716,7 @@ VAMD_DEV int floor_encode_render(const FloorP &F, int n2, const LaneInts &outp, 
         const LineStep st = line_step(sc->segx[s], sc->segx[s + 1], sc->segy[s], sc->segy[s + 1]);
         v = line_y(st, sc->segy[s], x - sc->segx[s]);
       }
-      ilogmask[x] = v;
+      ilogmask[x] = (ilog_t)v;
     }
   }
 #endif
@@ -728,7 +728,7 @@ VAMD_DEV int floor_encode_render(const FloorP &F, int n2, const LaneInts &outp, 
 // floor1_fit + the curve half of floor1_encode for one channel-block (the VBR path: one curve)
 VAMD_DEV int floor_fit_render_block(const FloorP &F, int n2, const unsigned short *qc, FloorScratch *sc,
                                     int *__restrict__ posts_out, int *__restrict__ post_valid,
-                                    int *__restrict__ ilogmask, PhaseClock &pc) {
+                                    ilog_t *__restrict__ ilogmask, PhaseClock &pc) {
   LaneInts outp;
   const int valid = floor_fit_posts(F, qc, sc, outp, pc);
   return floor_encode_render(F, n2, outp, valid, sc, posts_out, post_valid, ilogmask, pc);
@@ -756,7 +756,7 @@ VAMD_DEV void floor_interpolate(const LaneInts &A, int haveA, const LaneInts &B,
 VAMD_DEV void floor_managed_block(const PsyP &P, const FloorP &F, int n2, const float *__restrict__ noise,
                                   const float *__restrict__ tone, const float *__restrict__ mdct_raw,
                                   unsigned short *qc, FloorScratch *sc, int *__restrict__ posts_out, long posts_stride,
-                                  int *__restrict__ post_valid, long valid_stride, int *__restrict__ ilogmask,
+                                  int *__restrict__ post_valid, long valid_stride, ilog_t *__restrict__ ilogmask,
                                   long ilog_stride, int *__restrict__ nonzero, long nz_stride, PhaseClock &pc) {
   const int mid = VAMD_PACKETBLOBS / 2, last = VAMD_PACKETBLOBS - 1;
   LaneInts fmid, flo, fhi;

@@ -362,7 +362,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                                               const float *__restrict__ mdct_raw,
                                               float *__restrict__ mdct, float *__restrict__ logmask_out,
                                               int *__restrict__ posts, int *__restrict__ post_valid,
-                                              int *__restrict__ ilogmask, int *__restrict__ nonzero) {
+                                              ilog_t *__restrict__ ilogmask, int *__restrict__ nonzero) {
   const long cb = blockIdx.x;
   const long blk = cb / ch;
   // (the parameter structs stay in HBM and are read field by field through the scalar cache: four of them by value
@@ -382,13 +382,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   pc.flush();
 }
 
+// the int32 `ilogmask` tap of the C ABI from the 16-bit curve the stages exchange
+__global__ void k_widen_ilog(long n, const ilog_t *__restrict__ in, int *__restrict__ out) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = in[i];
+}
+
 // stage 5: couple / quantise / normalise, one wave per block (all channels)
 // A unit is one (block, candidate packet): VBR has one packet per block (blob_base = PACKETBLOBS/2,
 // nblobs = 1), a bitrate-managed block all fifteen, each with its own coupling parameters over the
 // same spectrum.  ilogmask / iwork / nonzero are indexed by unit, mdct by block.
 template <bool NORM>
 __global__ __launch_bounds__(64) void k_couple(PsyP P0, PsyP P1, CoupleSet CS, int blob_base, int nblobs, DescP d,
-                                               const float *__restrict__ mdct, const int *__restrict__ ilogmask,
+                                               const float *__restrict__ mdct, const ilog_t *__restrict__ ilogmask,
                                                int *__restrict__ iwork, int *__restrict__ nonzero) {
   const long unit = blockIdx.x, mblk = unit / nblobs;
   const CoupleP &C = CS.c[blob_base + (int)(unit - mblk * nblobs)];
@@ -401,7 +406,7 @@ __global__ __launch_bounds__(64) void k_couple(PsyP P0, PsyP P1, CoupleSet CS, i
   L.sgn = L.key + n2;
   L.accp = L.sgn + n2;
   const float *mp[VAMD_MAX_CH];
-  const int *ip[VAMD_MAX_CH];
+  const ilog_t *ip[VAMD_MAX_CH];
   int *op[VAMD_MAX_CH];
   int nz[VAMD_MAX_CH];
   for (int c = 0; c < ch; c++) {
@@ -423,7 +428,7 @@ __global__ __launch_bounds__(64) void k_couple(PsyP P0, PsyP P1, CoupleSet CS, i
 // couple_block_general, k_couple.h).  LDS: cand/key/sgn [n2] each + the partitions' budgets; the channels'
 // running state lives in `state` [unit][4][ch][n2].
 __global__ __launch_bounds__(64) void k_couple_general(PsyP P0, PsyP P1, CoupleSet CS, int blob_base, int nblobs, DescP d,
-                                                       const float *__restrict__ mdct, const int *__restrict__ ilogmask,
+                                                       const float *__restrict__ mdct, const ilog_t *__restrict__ ilogmask,
                                                        int *__restrict__ iwork, int *__restrict__ nonzero,
                                                        float *__restrict__ state) {
   const long unit = blockIdx.x, mblk = unit / nblobs;
@@ -441,7 +446,7 @@ __global__ __launch_bounds__(64) void k_couple_general(PsyP P0, PsyP P1, CoupleS
   S.fl2 = S.qe + ch * n2;
   S.fg = (int *)(S.fl2 + ch * n2);
   const float *mp[VAMD_MAX_CH];
-  const int *ip[VAMD_MAX_CH];
+  const ilog_t *ip[VAMD_MAX_CH];
   int *op[VAMD_MAX_CH];
   int nz[VAMD_MAX_CH];
   for (int c = 0; c < ch; c++) {
@@ -465,7 +470,7 @@ __global__ __launch_bounds__(64) void k_floor_managed(PsyP P0, PsyP P1, FloorP F
                                                       const float *__restrict__ noise, const float *__restrict__ tone,
                                                       const float *__restrict__ mdct_raw, float *__restrict__ mdct,
                                                       float *__restrict__ logmask_out, int *__restrict__ posts,
-                                                      int *__restrict__ post_valid, int *__restrict__ ilogmask,
+                                                      int *__restrict__ post_valid, ilog_t *__restrict__ ilogmask,
                                                       int *__restrict__ nonzero) {
   const long cb = blockIdx.x;
   const long blk = cb / ch;
@@ -952,7 +957,8 @@ struct WsPlan {
   float *mdct_raw, *logmdct, *logfft, *noise, *tone, *mdct, *local, *ampin, *ampglob, *seed;
   unsigned short *surv;
   int32_t *nsurv;
-  int32_t *ilogmask, *iwork, *posts, *post_valid, *nonzero;
+  ilog_t *ilogmask;  // 16-bit, workspace only (the int32 tap is widened from it: k_widen_ilog)
+  int32_t *iwork, *posts, *post_valid, *nonzero;
 };
 
 // Resolve every inter-stage tensor: the caller's buffer when given, otherwise workspace.
@@ -984,7 +990,7 @@ static int plan(vamd_ctx *c, int W, long nb, const vamd_batch_io *io, int level,
   }
   if (level >= VAMD_LEVEL_FULL) {
     PICK(mdct, io ? io->mdct : nullptr, WS_MDCT, per);
-    PICK(ilogmask, io ? io->ilogmask : nullptr, WS_ILOGMASK, per);
+    PICK(ilogmask, (ilog_t *)nullptr, WS_ILOGMASK, per / 2);
     PICK(iwork, io ? io->iwork : nullptr, WS_IWORK, per);
     PICK(posts, io ? io->posts : nullptr, WS_POSTS, (size_t)nb * ch * VAMD_POSTS_STRIDE * 4);
     PICK(post_valid, io ? io->post_valid : nullptr, WS_POSTVALID, (size_t)nb * ch * 4);
@@ -1178,7 +1184,7 @@ static int alloc_couple_state(vamd_ctx *c, BatchRun *R, long units) {
 
 // couple / quantise / normalise for `units` (block, candidate) pairs
 static void launch_couple(vamd_ctx *c, BatchRun *R, hipStream_t s, long units, int blob_base, int nblobs, const float *mdct,
-                          const int *ilogmask, int *iwork, int *nonzero) {
+                          const ilog_t *ilogmask, int *iwork, int *nonzero) {
   const int W = R->W, ch = c->B.channels;
   const PsyP &P0 = c->B.psy[2 * W], &P1 = c->B.psy[2 * W + 1];
   const int n2 = c->B.xf[W].n / 2;
@@ -1198,7 +1204,7 @@ static void launch_couple(vamd_ctx *c, BatchRun *R, hipStream_t s, long units, i
                        mdct, ilogmask, iwork, nonzero);
 }
 
-static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_io *M = nullptr, int *m_ilogmask = nullptr) {
+static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_io *M = nullptr, ilog_t *m_ilogmask = nullptr) {
   if (R->nb == 0) return;
   const ResBufs &rb = R->rb;
   const int W = R->W, ch = c->B.channels;
@@ -1276,6 +1282,8 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_
     hipLaunchKernelGGL(k_floor, dim3(gcb), dim3(64), (size_t)((n2 + 15) & ~15) * 2 + sizeof(FloorScratch) + floor_pad, s,
                        (const Bound *)c->d_bound, W, d, ch, p.noise, p.tone, p.mdct_raw, p.mdct,
                        R->io->logmask, p.posts, p.post_valid, p.ilogmask, p.nonzero);
+    if (R->io->ilogmask)  // (a tap: tests and callers with their own quantiser)
+      hipLaunchKernelGGL(k_widen_ilog, dim3(1024), dim3(256), 0, s, (long)gcb * n2, (const ilog_t *)p.ilogmask, R->io->ilogmask);
     prof_mark(c, VAMD_ST_FLOOR);
     launch_couple(c, R, s, gb, VAMD_PACKETBLOBS / 2, 1, p.mdct, p.ilogmask, p.iwork, p.nonzero);
     prof_mark(c, VAMD_ST_COUPLE);
@@ -1291,13 +1299,13 @@ static int run_batch(vamd_ctx *c, const vamd_batch_desc *desc, const vamd_batch_
   int r = prepare_run(c, desc, io, level, &R);
   if (r) return r;
   if (R.nb == 0) return VAMD_OK;
-  int *m_ilogmask = nullptr;
+  ilog_t *m_ilogmask = nullptr;
   if (M) {  // the fifteen integer floor curves live in workspace only
     void *v;
     r = ws_get(c, R.W, vamd_ctx::WS_M_ILOGMASK,
-               (size_t)R.nb * VAMD_PACKETBLOBS * c->B.channels * (c->B.bs[R.W] / 2) * 4, &v);
+               (size_t)R.nb * VAMD_PACKETBLOBS * c->B.channels * (c->B.bs[R.W] / 2) * sizeof(ilog_t), &v);
     if (r) return r;
-    m_ilogmask = (int *)v;
+    m_ilogmask = (ilog_t *)v;
     if ((M->res_entries || M->packets) &&
         (r = res_bufs(c, R.W, R.nb * VAMD_PACKETBLOBS, M->res_class, M->res_entries, M->res_count, &R.rb)))
       return r;

@@ -6,6 +6,11 @@
 
 namespace vamd {
 
+// The integer floor curve between the floor and the coupling stage (floor1_encode's render, lib/floor1.c:923-952):
+// values are a post's quantised height times mult, below 1024, so they travel as 16 bits (half the stream of the
+// one stage that is bound by HBM bandwidth).  The int32 `ilogmask` tap of the C ABI is widened from it on request.
+typedef unsigned short ilog_t;
+
 // window + MDCT + FFT tables for one size class W
 struct XformP {
   int n;                 // block size
