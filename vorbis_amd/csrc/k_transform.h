@@ -271,21 +271,54 @@ VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in0, float *w0, fl
   // x[pts-2-2q] with x[pts/2-2-2q] and uses T[(4<<s)*q].  n2/4 = n/8 butterflies per
   // stage in total, all independent.
   const int nstages = log2n - 6;  // first + (log2n-7) generic passes
-  for (int s = 0; s < nstages; s++) {
-    const int pts = n2 >> s, lper = log2n - 3 - s, tstride = 4 << s;  // per = pts/4 = 1 << lper
+  // one butterfly: the upper pair takes the sum, the lower the difference rotated by T (lib/mdct.c:222-257)
+  auto bfly = [](F2 &a, F2 &b, const F2 T) {
+    const float r0 = a.x - b.x, r1 = a.y - b.y;
+    a.x += b.x;
+    a.y += b.y;
+    b.x = r1 * T.y + r0 * T.x;
+    b.y = r1 * T.x - r0 * T.y;
+  };
+  auto stage_trig = [&](int s, int q) {
+    return PACKED && s > 0 ? *(const F2 *)(P.tpack + (n4 - (n4 >> (s - 1))) + 2 * q) : *(const F2 *)(trig + (4 << s) * q);
+  };
+  int s = 0;
+  // Two stages per trip through LDS where there are two to take: the butterflies (A, B) and (C, D) of stage s -- A, C
+  // in the upper half of a sub-block, a quarter apart, B, D below them -- feed exactly the butterflies (A, C) and
+  // (B, D) of stage s+1, whose sub-blocks are those halves.  Same operations on the same operands; half the loads
+  // and stores (the stage is bound by the LDS pipe, stores above all).
+  for (; s + 1 < nstages; s += 2) {
+    const int pts = n2 >> s, lq = log2n - 4 - s;  // units per sub-block: pts/8 = 1 << lq
+    TEAM_EACH(gg, (n8 >> 1) << LOGS, tm) {
+      VAMD_MDCT_SPLIT(gg, log2n - 4)
+      const int g = g_;
+      const int j = g >> lq, q = g & ((1 << lq) - 1);
+      const int base = pts * j - 2 - 2 * q;
+      F2 *pA = (F2 *)(w2 + VAMD_PW(base + pts)), *pB = (F2 *)(w2 + VAMD_PW(base + (pts >> 1)));
+      F2 *pC = (F2 *)(w2 + VAMD_PW(base + 3 * (pts >> 2))), *pD = (F2 *)(w2 + VAMD_PW(base + (pts >> 2)));
+      const F2 Tab = stage_trig(s, q), Tcd = stage_trig(s, q + (pts >> 3)), T1 = stage_trig(s + 1, q);
+      F2 A = *pA, B = *pB, C = *pC, D = *pD;
+      bfly(A, B, Tab);
+      bfly(C, D, Tcd);
+      bfly(A, C, T1);
+      bfly(B, D, T1);
+      *pA = A;
+      *pB = B;
+      *pC = C;
+      *pD = D;
+    }
+    tm.sync();
+  }
+  for (; s < nstages; s++) {
+    const int pts = n2 >> s, lper = log2n - 3 - s;  // per = pts/4 = 1 << lper
     TEAM_EACH(gg, n8 << LOGS, tm) {
       VAMD_MDCT_SPLIT(gg, log2n - 3)
       const int g = g_;
       const int j = g >> lper, q = g & ((1 << lper) - 1);
       const int ia = pts * j + pts - 2 - 2 * q, ib = pts * j + (pts >> 1) - 2 - 2 * q;
       F2 *pa = (F2 *)(w2 + VAMD_PW(ia)), *pb = (F2 *)(w2 + VAMD_PW(ib));
-      const F2 T = PACKED && s > 0 ? *(const F2 *)(P.tpack + (n4 - (n4 >> (s - 1))) + 2 * q) : *(const F2 *)(trig + tstride * q);
       F2 a = *pa, b = *pb;
-      const float r0 = a.x - b.x, r1 = a.y - b.y;
-      a.x += b.x;
-      a.y += b.y;
-      b.x = r1 * T.y + r0 * T.x;
-      b.y = r1 * T.x - r0 * T.y;
+      bfly(a, b, stage_trig(s, q));
       *pa = a;
       *pb = b;
     }
