@@ -287,6 +287,44 @@ VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in0, float *w0, fl
   // in the upper half of a sub-block, a quarter apart, B, D below them -- feed exactly the butterflies (A, C) and
   // (B, D) of stage s+1, whose sub-blocks are those halves.  Same operations on the same operands; half the loads
   // and stores (the stage is bound by the LDS pipe, stores above all).
+  // ... and three where there are three: eight pairs E1..E8 an eighth of a sub-block apart (E8 on top) close under
+  // the butterflies (E8,E4) (E7,E3) (E6,E2) (E5,E1) of stage s, (E8,E6) (E7,E5) (E4,E2) (E3,E1) of stage s+1 and
+  // (E8,E7) (E6,E5) (E4,E3) (E2,E1) of stage s+2.
+  for (; s + 2 < nstages && (nstages - s) != 4; s += 3) {
+    const int pts = n2 >> s, lq = log2n - 5 - s;  // units per sub-block: pts/16 = 1 << lq
+    const int e8 = pts >> 3;
+    TEAM_EACH(gg, (n8 >> 2) << LOGS, tm) {
+      VAMD_MDCT_SPLIT(gg, log2n - 5)
+      const int g = g_;
+      const int j = g >> lq, q = g & ((1 << lq) - 1);
+      const int base = pts * j - 2 - 2 * q;
+      F2 E[8];
+#if VAMD_GPU
+#pragma unroll
+#endif
+      for (int k = 0; k < 8; k++) E[k] = *(const F2 *)(w2 + VAMD_PW(base + (k + 1) * e8));
+      const int h = pts >> 4;  // q advances by a sixteenth of the sub-block from one eighth to the next
+      bfly(E[7], E[3], stage_trig(s, q));
+      bfly(E[6], E[2], stage_trig(s, q + h));
+      bfly(E[5], E[1], stage_trig(s, q + 2 * h));
+      bfly(E[4], E[0], stage_trig(s, q + 3 * h));
+      const F2 T1a = stage_trig(s + 1, q), T1b = stage_trig(s + 1, q + h);
+      bfly(E[7], E[5], T1a);
+      bfly(E[6], E[4], T1b);
+      bfly(E[3], E[1], T1a);
+      bfly(E[2], E[0], T1b);
+      const F2 T2 = stage_trig(s + 2, q);
+      bfly(E[7], E[6], T2);
+      bfly(E[5], E[4], T2);
+      bfly(E[3], E[2], T2);
+      bfly(E[1], E[0], T2);
+#if VAMD_GPU
+#pragma unroll
+#endif
+      for (int k = 0; k < 8; k++) *(F2 *)(w2 + VAMD_PW(base + (k + 1) * e8)) = E[k];
+    }
+    tm.sync();
+  }
   for (; s + 1 < nstages; s += 2) {
     const int pts = n2 >> s, lq = log2n - 4 - s;  // units per sub-block: pts/8 = 1 << lq
     TEAM_EACH(gg, (n8 >> 1) << LOGS, tm) {
