@@ -761,6 +761,99 @@ VAMD_DEV void radf2_wave(int ido, int l1, const float *__restrict__ cc, float *_
   }
 }
 
+// The last radix-4 pass (l1 = 2, ido = n/8) and the radix-2 pass that ends an odd log2 n (ido = n/2) in ONE trip:
+// the radix-2 butterfly at index i takes the pair at i of the radix-4 pass's first output block and the pair at i of
+// its second, and the radix-4 butterflies (k = 0, i) and (k = 1, i) produce exactly the pairs at i, 2ido-i, 2ido+i
+// and 4ido-i of those two blocks -- so a thread runs both, then the four radix-2 butterflies on what it holds.
+// Unit 0 takes the two k-only columns of both blocks (values at 0, ido-1, ido, ... 4ido-1) and the radix-2 work
+// they feed (its i = 0 column and the butterflies at ido, 2ido, 3ido).  src, dst: offset layout, plain.
+template <int LOGN, class Team>
+VAMD_DEV void fft_tail42_wave(const float *__restrict__ cc, float *__restrict__ ch, const float *__restrict__ wa,
+                              const Team &tm) {
+  constexpr int n = 1 << LOGN, ido = n / 8, t0 = n / 4, n2 = n / 2;
+  const float hsqt2 = .70710678118654752f;
+  const float *__restrict__ wa1 = wa + n2, *__restrict__ wa2 = wa1 + ido, *__restrict__ wa3 = wa2 + ido;  // iw = n/2 + 1
+  // dradf2's butterfly at i (lib/smallft.c:139-163) on the pairs c5 (first block) and c3 (second block)
+  auto radf2_bfly = [&](int i, const F2 c5, const F2 c3) {
+    const F2 w1 = *(const F2 *)(wa + i - 2);  // iw = 1
+    const float tr2 = w1.x * c3.x + w1.y * c3.y;
+    const float ti2 = w1.x * c3.y - w1.y * c3.x;
+    st_pair(ch, i, c5.x + tr2, c5.y + ti2);
+    st_pair(ch, n - i, c5.x - tr2, ti2 - c5.y);
+  };
+  TEAM_EACH(g, ido / 2, tm) {
+    if (g == 0) {
+      float V[2][8];  // block k's values at 0, ido-1, ido, 2ido-1, 2ido, 3ido-1, 3ido, 4ido-1
+#if VAMD_GPU
+#pragma unroll
+#endif
+      for (int k = 0; k < 2; k++) {
+        {
+          const int t1 = t0 + k * ido, t2 = 3 * t0 + k * ido, t3 = k * ido, t4 = 2 * t0 + k * ido;
+          const float tr1 = cc[t1] + cc[t2];
+          const float tr2 = cc[t3] + cc[t4];
+          V[k][0] = tr1 + tr2;
+          V[k][7] = tr2 - tr1;
+          V[k][3] = cc[t3] - cc[t4];
+          V[k][4] = cc[t2] - cc[t1];
+        }
+        {
+          const int t1 = t0 + ido - 1 + k * ido, t2 = t1 + (t0 << 1), t6 = ido + k * ido;
+          const float ti1 = -hsqt2 * (cc[t1] + cc[t2]);
+          const float tr1 = hsqt2 * (cc[t1] - cc[t2]);
+          V[k][1] = tr1 + cc[t6 - 1];
+          V[k][5] = cc[t6 - 1] - tr1;
+          V[k][2] = ti1 - cc[t1 + t0];
+          V[k][6] = ti1 + cc[t1 + t0];
+        }
+      }
+      // dradf2's i = 0 column (lib/smallft.c:121-136): cc[0], cc[t0] and the two values at ido-1 of its own pass
+      ch[0] = V[0][0] + V[1][0];
+      ch[n - 1] = V[0][0] - V[1][0];
+      ch[n2] = -V[1][7];
+      ch[n2 - 1] = V[0][7];
+#if VAMD_GPU
+#pragma unroll
+#endif
+      for (int j = 1; j < 4; j++) {
+        F2 c5, c3;
+        c5.x = V[0][2 * j - 1], c5.y = V[0][2 * j];
+        c3.x = V[1][2 * j - 1], c3.y = V[1][2 * j];
+        radf2_bfly(j * ido, c5, c3);
+      }
+    } else {
+      const int i = 2 * g;
+      const F2 w1 = *(const F2 *)(wa1 + i - 2), w2 = *(const F2 *)(wa2 + i - 2), w3 = *(const F2 *)(wa3 + i - 2);
+      F2 Pk[2][4];  // block k's pairs at i, 2ido-i, 2ido+i, 4ido-i
+#if VAMD_GPU
+#pragma unroll
+#endif
+      for (int k = 0; k < 2; k++) {
+        const int t2 = k * ido + i;
+        const F2 c0 = ld_pair<true>(cc, t2), c1 = ld_pair<true>(cc, t2 + t0), c2 = ld_pair<true>(cc, t2 + 2 * t0),
+                 c3 = ld_pair<true>(cc, t2 + 3 * t0);
+        const float cr2 = w1.x * c1.x + w1.y * c1.y;
+        const float ci2 = w1.x * c1.y - w1.y * c1.x;
+        const float cr3 = w2.x * c2.x + w2.y * c2.y;
+        const float ci3 = w2.x * c2.y - w2.y * c2.x;
+        const float cr4 = w3.x * c3.x + w3.y * c3.y;
+        const float ci4 = w3.x * c3.y - w3.y * c3.x;
+        const float tr1 = cr2 + cr4, tr4 = cr4 - cr2, ti1 = ci2 + ci4, ti4 = ci2 - ci4;
+        const float ti2 = c0.y + ci3, ti3 = c0.y - ci3;
+        const float tr2 = c0.x + cr3, tr3 = c0.x - cr3;
+        Pk[k][0].x = tr1 + tr2, Pk[k][0].y = ti1 + ti2;
+        Pk[k][1].x = tr3 - ti4, Pk[k][1].y = tr4 - ti3;
+        Pk[k][2].x = ti4 + tr3, Pk[k][2].y = tr4 + ti3;
+        Pk[k][3].x = tr2 - tr1, Pk[k][3].y = ti1 - ti2;
+      }
+      radf2_bfly(i, Pk[0][0], Pk[1][0]);
+      radf2_bfly(2 * ido - i, Pk[0][1], Pk[1][1]);
+      radf2_bfly(2 * ido + i, Pk[0][2], Pk[1][2]);
+      radf2_bfly(4 * ido - i, Pk[0][3], Pk[1][3]);
+    }
+  }
+}
+
 // drftf1, lib/smallft.c:572-631: unnormalised real FFT with the reference's pass
 // order and c<->ch ping-pong.  `c` holds the windowed block (plain layout, n+4
 // floats available), `ch` is scratch (n+4 floats).  Returns the buffer (offset layout:
@@ -786,10 +879,12 @@ VAMD_DEV const float *drft_forward_wave(const XformP &P, float *c, float *ch, co
     iw = n - 63;
     kfirst = 3;
   }
+  constexpr bool TAIL42 = LOGN >= 11 && (LOGN & 1);  // (at log2 n = 9 the last radix-4 pass reads the padded layout)
+  const int nloop = TAIL42 ? nf - 2 : nf;
 #if VAMD_GPU
 #pragma unroll
 #endif
-  for (int k1 = kfirst; k1 < nf; k1++) {
+  for (int k1 = kfirst; k1 < nloop; k1++) {
     const int ip = LOGN ? (k1 < (LOGN >> 1) ? 4 : 2) : P.fft_fac[nf - k1 - 1];
     const int l1 = l2 / ip, ido = n / l2;
     iw -= (ip - 1) * ido;
@@ -813,6 +908,11 @@ VAMD_DEV const float *drft_forward_wave(const XformP &P, float *c, float *ch, co
     }
     tm.sync();
     l2 = l1;
+  }
+  if (TAIL42) {
+    na = 1 - na;
+    fft_tail42_wave<TAIL42 ? LOGN : 11>(na ? bufh : bufc, na ? bufc : bufh, wa, tm);
+    tm.sync();
   }
   // the reference copies ch back into c when the last pass landed in ch; the caller
   // just reads whichever buffer holds the result
