@@ -156,11 +156,22 @@ __global__ __launch_bounds__(64 * VAMD_XF_WAVES) void k_transform(XformP G, int 
   constexpr int QPT = LOGN ? ((1 << LOGN) / 4 + 63) / 64 : 4096 / 4 / 64;  // quads of a block per lane
   const WaveTeam tm;
   PcmTile<QPT> tile;
-  if (cb < ncb) pcm_fetch(tile, pcm + cb * n, n, tm);
-  for (; cb < ncb; cb += cstride) {
+  // A block's samples AND its window flags are fetched one block ahead: a load issued at the top of the loop -- even a
+  // conditional one that is not taken -- makes the wait there a wait for everything outstanding, the stores of the
+  // previous block's spectra included.
+  int lW = 0, nW = 0;
+  if (cb < ncb) {
     const long blk = (long)((unsigned)cb / (unsigned)ch);
-    transform_window(P, W, d_lW(d, blk), d_nW(d, blk), tile, L.A, pc, tm);
-    if (cb + cstride < ncb) pcm_fetch(tile, pcm + (cb + cstride) * n, n, tm);  // next block, one ahead
+    lW = d_lW(d, blk), nW = d_nW(d, blk);
+    pcm_fetch(tile, pcm + cb * n, n, tm);
+  }
+  for (; cb < ncb; cb += cstride) {
+    transform_window(P, W, lW, nW, tile, L.A, pc, tm);
+    if (cb + cstride < ncb) {  // next block, one ahead
+      const long blk = (long)((unsigned)(cb + cstride) / (unsigned)ch);
+      lW = d_lW(d, blk), nW = d_nW(d, blk);
+      pcm_fetch(tile, pcm + (cb + cstride) * n, n, tm);
+    }
     const float amp = transform_block<LOGN>(P, L.A, L.B, mdct_raw + cb * n2, logmdct ? logmdct + cb * n2 : nullptr, logfft + cb * n2, pc);
     if (LANE == 0) local_ampmax[cb] = amp;
   }
