@@ -204,7 +204,8 @@ VAMD_DEV void mdct_tpack_fill(float *tpack, const float *__restrict__ trig, int 
 
 // mdct_forward, lib/mdct.c:492-562.  `in` = A (windowed block, LDS, n floats);
 // w = work buffer: w[0..n2) plain + padded butterfly vector at w + n2
-// (VAMD_PW_SIZE(n2) floats).  The n/2 spectrum is written to out_lds[0..n2).
+// (VAMD_PW_SIZE(n2) floats).  The n/2 spectrum is written to out_lds[0..n2), which may be w itself (the plain half is
+// not used otherwise) but must not overlap the padded half.
 // LOGS > 0 runs 2^LOGS independent transforms of the same size side by side (transform t at
 // in + t*in_stride, w + t*w_stride, out_lds + t*out_stride): every loop then ranges over
 // (transform, item) so that small transforms -- the 128-point one of the block-switching
@@ -442,22 +443,22 @@ VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in0, float *w0, fl
     lo.y = r1 + r3;
     hi.x = r0 - r2;
     hi.y = r3 - r1;
-    *(F2 *)(w + 2 * u) = lo;
-    *(F2 *)(w + n2 - 2 * u - 2) = hi;
+    // lo, hi are w[2u], w[2u+1] and w[n2-2u-2], w[n2-2u-1] of the reference's work vector: exactly the pairs that
+    // items i = u and i = n4-1-u of the final rotate * scale (lib/mdct.c:552-561) consume, so they never go to
+    // LDS.  (out_lds must not overlap the butterfly vector w2, which other threads are still gathering from: the
+    // callers hand over w itself, or a buffer of their own.)
+    {
+      const F2 Tl = *(const F2 *)(trig + n2 + 2 * u);
+      out_lds[u] = (lo.x * Tl.x + lo.y * Tl.y) * P.mdct_scale;
+      out_lds[n2 - 1 - u] = (lo.x * Tl.y - lo.y * Tl.x) * P.mdct_scale;
+      const int i2 = n4 - 1 - u;
+      const F2 Th = *(const F2 *)(trig + n2 + 2 * i2);
+      out_lds[i2] = (hi.x * Th.x + hi.y * Th.y) * P.mdct_scale;
+      out_lds[n2 - 1 - i2] = (hi.x * Th.y - hi.y * Th.x) * P.mdct_scale;
+    }
   }
   tm.sync();
   pc.mark(4);
-
-  // final rotate * scale, lib/mdct.c:552-561 -> out[n2]
-  TEAM_EACH(ii, n4 << LOGS, tm) {
-    VAMD_MDCT_SPLIT(ii, log2n - 2)
-    const int i = g_;
-    const F2 T = *(const F2 *)(trig + n2 + 2 * i);
-    const F2 ab = *(const F2 *)(w + 2 * i);
-    out_lds[i] = (ab.x * T.x + ab.y * T.y) * P.mdct_scale;
-    out_lds[n2 - 1 - i] = (ab.x * T.y - ab.y * T.x) * P.mdct_scale;
-  }
-  tm.sync();
 }
 #undef VAMD_MDCT_SPLIT
 
@@ -939,11 +940,11 @@ template <int LOGN = 0, class Team = WaveTeam>
 VAMD_DEV const float *transform_spectra(const XformP &P, float *A, float *B, float *__restrict__ mdct_out,
                                         float *__restrict__ logmdct_out, PhaseClock &pc, const Team &tm = Team()) {
   const int n = LOGN ? (1 << LOGN) : P.n, n2 = n >> 1;
-  // MDCT: spectrum lands in B[n2..n) (LDS), then goes out with its dB twin, 16 bytes per thread and tensor
-  mdct_forward_wave<0, LOGN, Team, LOGN != 0>(P, A, B, B + n2, pc, 0, 0, 0, tm);
+  // MDCT: spectrum lands in B[0..n2) (LDS), then goes out with its dB twin, 16 bytes per thread and tensor
+  mdct_forward_wave<0, LOGN, Team, LOGN != 0>(P, A, B, B, pc, 0, 0, 0, tm);
   TEAM_EACH(q, n2 >> 2, tm) {
     float m[4], l[4];
-    f4_get(((const F4 *)(B + n2))[q], m);
+    f4_get(((const F4 *)B)[q], m);
     for (int c = 0; c < 4; c++) l[c] = todB_345(m[c]);  // lib/mapping0.c:384-385
     if (mdct_out) ((F4 *)mdct_out)[q] = f4_make(m);
     if (logmdct_out) ((F4 *)logmdct_out)[q] = f4_make(l);
