@@ -140,29 +140,36 @@ def cpu_baseline(setup_name, seconds):
         encs[0].time_dsp(pcm, 1)
         n1 += sample_blocks
     single = n1 / (time.time() - t1)
-    done = [0] * nthreads
-    cpu_time = [0.0] * nthreads
-    deadline = time.time() + seconds
+    # all hardware threads, and one thread per physical core (SMT siblings and memory bandwidth make the first the
+    # slower one on some hosts): the better of the two is the figure reported
+    legs = []
+    for nt in sorted({nthreads, max(1, nthreads // 2)}):
+        done = [0] * nt
+        cpu_time = [0.0] * nt
+        deadline = time.time() + seconds / 2
 
-    def work(i):
-        e = encs[i]
-        while time.time() < deadline:
-            cpu_time[i] += e.time_dsp(pcm, 1)
-            done[i] += sample_blocks
+        def work(i, done=done, cpu_time=cpu_time, deadline=deadline):
+            e = encs[i]
+            while time.time() < deadline:
+                cpu_time[i] += e.time_dsp(pcm, 1)
+                done[i] += sample_blocks
 
-    t0 = time.time()
-    th = [threading.Thread(target=work, args=(i,)) for i in range(nthreads)]
-    [t.start() for t in th]
-    [t.join() for t in th]
-    wall = time.time() - t0
-    total = sum(done)
+        t0 = time.time()
+        th = [threading.Thread(target=work, args=(i,)) for i in range(nt)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        wall = time.time() - t0
+        legs.append({"threads": nt, "value": sum(done) / wall, "blocks": sum(done), "wall": wall,
+                     "per_core": sum(done) / max(sum(cpu_time), 1e-9)})
+    best = max(legs, key=lambda g: g["value"])
     return {
-        "value": total / wall, "unit": "stereo blocks/s", "cores": nthreads, "nproc": cores, "kind": kind,
-        "per_core": total / max(sum(cpu_time), 1e-9), "single_thread_value": single,
+        "value": best["value"], "unit": "stereo blocks/s", "cores": best["threads"], "nproc": cores, "kind": kind,
+        "per_core": best["per_core"], "single_thread_value": single,
+        "legs": [{"threads": g["threads"], "value": g["value"]} for g in legs],
         "sample": "%d threads x repeated passes over %d seeded white-noise stereo 2048-blocks for %.0f s wall "
                   "(%d blocks total); window+MDCT+FFT+psy+floor1 fit/encode+couple/quantise of "
                   "mapping0_forward (the part the GPU path computes; residue VQ/Huffman excluded)"
-                  % (nthreads, sample_blocks, wall, total),
+                  % (best["threads"], sample_blocks, best["wall"], best["blocks"]),
     }
 
 
