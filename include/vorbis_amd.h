@@ -333,6 +333,31 @@ int vamd_gather_blocks(vamd_ctx *ctx, const vamd_stream_plan *plan, int W, const
 int vamd_plan_fetch(vamd_ctx *ctx, const vamd_stream_plan *plan, int32_t *const lW[2], int32_t *const nW[2],
                     int32_t *const blocktype[2], int64_t *const src[2], int32_t *order, int64_t *stream_start);
 
+/* ---- the host shim for encoders that submit ONE block at a time from many threads.
+ * libvorbis' unit of work is one block of one stream (mapping0_forward, reference lib/mapping0.c:233-687); a
+ * batcher owns one context and coalesces concurrent vamd_batcher_encode_block() calls -- same contract as
+ * vamd_encode_block() for a VBR encoder, callable from any number of threads, one stream per thread as libvorbis
+ * itself requires -- into batched launches: the caller that finds no batch under way leads one, waits until every
+ * attached stream has a block pending, `max_batch` blocks have gathered or `max_wait_us` have passed, and runs the
+ * pending blocks of one size class as a single vamd_analyze_batch() with packet output.  No thread of its own.
+ * vamd_batcher_attach / _detach announce a stream (a vorbis_dsp_state) so that a leader knows how many blocks to
+ * expect; without them it waits out `max_wait_us`.  Errors: OV_*-valued as everywhere; the text of the last one with
+ * vamd_batcher_last_error().  vamd_batcher_context() is the owned context (capacities, geometry; NOT for concurrent
+ * launches).  Reference-side use: integration/mapping0_vamd.c with VAMD_BATCH set in the environment. */
+typedef struct vamd_batcher vamd_batcher;
+int vamd_batcher_create(vamd_batcher **out, const void *setup_blob, size_t blob_bytes, int device, int max_batch,
+                        int max_wait_us);
+void vamd_batcher_destroy(vamd_batcher *b);
+void vamd_batcher_attach(vamd_batcher *b);
+void vamd_batcher_detach(vamd_batcher *b);
+int vamd_batcher_encode_block(vamd_batcher *b, const float *const *pcm, int lW, int W, int nW, int blocktype,
+                              float ampmax_in, float *ampmax_out, uint8_t *packet, long packet_cap,
+                              int32_t *packet_bits);
+const char *vamd_batcher_last_error(const vamd_batcher *b);
+/* batches run, blocks carried, seconds spent inside the batched GPU calls (any pointer may be NULL) */
+void vamd_batcher_stats(vamd_batcher *b, long *batches, long *blocks, double *run_seconds);
+vamd_ctx *vamd_batcher_context(vamd_batcher *b);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,6 +28,7 @@
 extern vamd_ctx *vamd_ctx_for(vorbis_dsp_state *vd);
 extern vamd_envelope_state *vamd_envelope_state_for(vorbis_dsp_state *vd);
 extern void vamd_release_key(const void *key);
+extern int vamd_batching(void);
 
 /* vorbis_dsp_clear() tears the detector down here (lib/block.c:325-328): the GPU context that
  * was created for this analysis state goes with it */
@@ -37,6 +38,10 @@ void _ve_envelope_clear(envelope_lookup *e) {
 }
 
 long _ve_envelope_search(vorbis_dsp_state *v) {
+  /* batch mode (VAMD_BATCH, mapping0_vamd.c): the shared context belongs to the batcher's leader, and a detector
+     round trip per blockout call is exactly what batching is there to avoid -- the reference's own detector runs */
+  if (vamd_batching()) return _ve_envelope_search_cpu(v);
+  {
   vorbis_info *vi = v->vi;
   codec_setup_info *ci = vi->codec_setup;
   envelope_lookup *ve = ((private_state *)(v->backend_state))->ve;
@@ -96,4 +101,5 @@ long _ve_envelope_search(vorbis_dsp_state *v) {
     }
   }
   return -1;
+  }
 }

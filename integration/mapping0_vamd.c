@@ -23,6 +23,10 @@
  *
  * Bitrate-managed encoders get all PACKETBLOBS candidate packets the same way;
  * the bitrate manager that picks one is untouched host code.
+ * With VAMD_BATCH=<n> in the environment the VBR blocks of ALL encoder states that share a setup go through one
+ * vamd_batcher (include/vorbis_amd.h): many application threads, each driving its own vorbis_dsp_state as libvorbis
+ * allows, get their blocks analysed in shared GPU batches of up to n (VAMD_BATCH_WAIT_US, default 2000, bounds how
+ * long a batch waits for stragglers).  The block-switching detector then stays on the host (envelope_vamd.c).
  * Channel counts above VAMD_MAX_CH are refused with OV_EIMPL (see mapping0_forward_vamd); errors
  * travel as OV_* return codes like everywhere else in libvorbis -- nothing is printed.
  */
@@ -47,18 +51,60 @@ extern long vamd_pack_setup(vorbis_dsp_state *vd, void *dst, long cap);
  * address (its detector state is handed out by pointer) stays put while the table moves.
  * One state is still used by one thread at a time, as libvorbis itself requires. */
 #include <pthread.h>
+#include <stdlib.h>
+typedef struct vamd_shared { /* one batcher per distinct setup (VAMD_BATCH mode) */
+  void *blob;
+  long bytes;
+  vamd_batcher *batcher;
+  int users;
+} vamd_shared;
 typedef struct vamd_entry {
   const void *key; /* private_state.ve */
-  vamd_ctx *ctx;
+  vamd_ctx *ctx;   /* this state's own context (always in per-state mode; in batch mode only for what is not batched) */
+  vamd_shared *shared; /* batch mode: the batcher this state submits to */
   vamd_envelope_state env; /* the block-switching detector's running state (envelope_vamd.c) */
 } vamd_entry;
 static pthread_mutex_t vamd_lock = PTHREAD_MUTEX_INITIALIZER;
 static vamd_entry **vamd_table = NULL;
 static int vamd_count = 0, vamd_cap = 0;
+static vamd_shared *vamd_shares[16];
+static int vamd_nshares = 0;
 
 static const void *vamd_key(vorbis_dsp_state *vd) { return ((private_state *)vd->backend_state)->ve; }
 
-/* the entry of `state`, created (context and all) on first use; NULL if the GPU side cannot be set up */
+/* VAMD_BATCH=<max blocks per batch> switches the process to batch mode (read once) */
+int vamd_batching(void) {
+  static int mode = -1;
+  if (mode < 0) {
+    const char *v = getenv("VAMD_BATCH");
+    mode = v ? atoi(v) : 0;
+    if (mode < 0) mode = 0;
+  }
+  return mode;
+}
+
+/* the batcher for this setup blob, created on first use (vamd_lock held); takes ownership of `blob` when it keeps it */
+static vamd_shared *vamd_share_for(void *blob, long bytes, int *kept) {
+  int i;
+  *kept = 0;
+  for (i = 0; i < vamd_nshares; i++)
+    if (vamd_shares[i]->bytes == bytes && !memcmp(vamd_shares[i]->blob, blob, bytes)) return vamd_shares[i];
+  if (vamd_nshares < (int)(sizeof(vamd_shares) / sizeof(vamd_shares[0]))) {
+    vamd_shared *sh = _ogg_calloc(1, sizeof(*sh));
+    const char *w = getenv("VAMD_BATCH_WAIT_US");
+    if (sh && vamd_batcher_create(&sh->batcher, blob, (size_t)bytes, -1, vamd_batching(), w ? atoi(w) : 2000) == VAMD_OK) {
+      sh->blob = blob;
+      sh->bytes = bytes;
+      *kept = 1;
+      vamd_shares[vamd_nshares++] = sh;
+      return sh;
+    }
+    if (sh) _ogg_free(sh);
+  }
+  return NULL;
+}
+
+/* the entry of `state`, created (context or batcher and all) on first use; NULL if the GPU side cannot be set up */
 static vamd_entry *vamd_entry_for(vorbis_dsp_state *state) {
   const void *key = vamd_key(state);
   vamd_entry *e = NULL;
@@ -76,7 +122,15 @@ static vamd_entry *vamd_entry_for(vorbis_dsp_state *state) {
     if (need >= 0) {
       void *blob = _ogg_malloc(need);
       vamd_ctx *ctx = NULL;
-      if (blob && vamd_pack_setup(state, blob, need) == need && vamd_create(&ctx, blob, (size_t)need, -1) == VAMD_OK) {
+      vamd_shared *sh = NULL;
+      int kept = 0, ok = 0;
+      if (blob && vamd_pack_setup(state, blob, need) == need) {
+        if (vamd_batching())
+          ok = (sh = vamd_share_for(blob, need, &kept)) != NULL;
+        else
+          ok = vamd_create(&ctx, blob, (size_t)need, -1) == VAMD_OK;
+      }
+      if (ok) {
         if (vamd_count == vamd_cap) {
           int ncap = vamd_cap ? 2 * vamd_cap : 16;
           vamd_entry **nt = _ogg_realloc(vamd_table, ncap * sizeof(*nt));
@@ -85,21 +139,34 @@ static vamd_entry *vamd_entry_for(vorbis_dsp_state *state) {
         if (vamd_count < vamd_cap && (e = _ogg_calloc(1, sizeof(*e)))) { /* env all-zero: a fresh stream, lib/envelope.c:71 */
           e->key = key;
           e->ctx = ctx;
+          e->shared = sh;
+          if (sh) {
+            sh->users++;
+            vamd_batcher_attach(sh->batcher);
+          }
           vamd_table[vamd_count++] = e;
-        } else {
+        } else if (ctx) {
           vamd_destroy(ctx);
         }
       }
-      if (blob) _ogg_free(blob);
+      if (blob && !kept) _ogg_free(blob);
     }
   }
   pthread_mutex_unlock(&vamd_lock);
   return e;
 }
 
+/* this state's OWN context: what every per-state call uses; in batch mode it is made only when something that is
+ * not batched asks for it (a bitrate-managed encoder's fifteen candidates) */
 vamd_ctx *vamd_ctx_for(vorbis_dsp_state *state) {
   vamd_entry *e = vamd_entry_for(state);
-  return e ? e->ctx : NULL;
+  if (!e) return NULL;
+  if (!e->ctx && e->shared) {
+    pthread_mutex_lock(&vamd_lock);
+    if (!e->ctx && vamd_create(&e->ctx, e->shared->blob, (size_t)e->shared->bytes, -1) != VAMD_OK) e->ctx = NULL;
+    pthread_mutex_unlock(&vamd_lock);
+  }
+  return e->ctx;
 }
 
 vamd_envelope_state *vamd_envelope_state_for(vorbis_dsp_state *state) {
@@ -110,6 +177,7 @@ vamd_envelope_state *vamd_envelope_state_for(vorbis_dsp_state *state) {
 /* called by _ve_envelope_clear() (envelope_vamd.c) with the envelope_lookup being torn down */
 void vamd_release_key(const void *key) {
   vamd_entry *e = NULL;
+  vamd_shared *dead = NULL;
   int i;
   if (!key) return;
   pthread_mutex_lock(&vamd_lock);
@@ -119,13 +187,43 @@ void vamd_release_key(const void *key) {
       vamd_table[i] = vamd_table[--vamd_count];
       break;
     }
+  if (e && e->shared) {
+    vamd_batcher_detach(e->shared->batcher);
+    if (--e->shared->users == 0) { /* the last stream of this setup takes the batcher with it */
+      dead = e->shared;
+      for (i = 0; i < vamd_nshares; i++)
+        if (vamd_shares[i] == dead) vamd_shares[i] = vamd_shares[--vamd_nshares];
+    }
+  }
   pthread_mutex_unlock(&vamd_lock);
+  if (dead) {
+    vamd_batcher_destroy(dead->batcher);
+    _ogg_free(dead->blob);
+    _ogg_free(dead);
+  }
   if (e) {
-    vamd_destroy(e->ctx);
+    if (e->ctx) vamd_destroy(e->ctx);
     _ogg_free(e);
   }
 }
 
+
+/* batches run and blocks carried so far, over all batchers (diagnostics) */
+void vamd_batch_stats(long *batches, long *blocks, double *run_seconds) {
+  int i;
+  *batches = *blocks = 0;
+  *run_seconds = 0.;
+  pthread_mutex_lock(&vamd_lock);
+  for (i = 0; i < vamd_nshares; i++) {
+    long a = 0, b = 0;
+    double t = 0.;
+    vamd_batcher_stats(vamd_shares[i]->batcher, &a, &b, &t);
+    *batches += a;
+    *blocks += b;
+    *run_seconds += t;
+  }
+  pthread_mutex_unlock(&vamd_lock);
+}
 
 /* for a build WITHOUT envelope_vamd.c: call from vorbis_dsp_clear() before b->ve is freed */
 void vamd_release_state(vorbis_dsp_state *state) { vamd_release_key(vamd_key(state)); }
@@ -203,10 +301,28 @@ static int mapping0_forward_vamd(vorbis_block *vb) {
     return OV_EIMPL;
 #endif
   }
+  vb->mode = vb->W;
+
+  /* ---- batch mode (VAMD_BATCH): the block joins whatever the other encoder threads have pending and comes back
+     as its packet, exactly as from vamd_encode_block below */
+  if (vamd_batching() && !managed) {
+    vamd_entry *e = vamd_entry_for(vd);
+    if (!e || !e->shared) return OV_EFAULT;
+    pkcap = vamd_packet_capacity(vamd_batcher_context(e->shared->batcher), vb->W);
+    if (pkcap > 0) {
+      unsigned char *packet = _vorbis_block_alloc(vb, pkcap);
+      int32_t bits = 0;
+      ret = vamd_batcher_encode_block(e->shared->batcher, (const float *const *)vb->pcm, vb->lW, vb->W, vb->nW,
+                                      vbi->blocktype, vbi->ampmax, &ampmax_out, packet, pkcap, &bits);
+      if (ret) return ret;
+      vbi->ampmax = ampmax_out; /* lib/mapping0.c:576 */
+      oggpack_writecopy(vbi->packetblob[PACKETBLOBS / 2], packet, bits);
+      return 0;
+    }
+  }
+
   ctx = vamd_ctx_for(vd);
   if (!ctx) return OV_EFAULT; /* no silent fallback: a missing GPU is an error */
-
-  vb->mode = vb->W;
 
   /* ---- the whole of mapping0_forward in one call (lib/mapping0.c:254-687): the block's finished
      packet -- all PACKETBLOBS candidates for a bitrate-managed encoder, which lets

@@ -19,7 +19,7 @@ LIB = os.path.join(ROOT, "vorbis_amd", "libvorbis_amd.so")
 
 def declared_symbols():
     src = open(os.path.join(ROOT, "include", "vorbis_amd.h")).read()
-    return sorted(set(re.findall(r"^(?:int|void|const char \*)\s*(vamd_[a-z_]+)\s*\(", src, re.M)))
+    return sorted(set(re.findall(r"^(?:int|void|long|const char \*|vamd_ctx \*)\s*(vamd_[a-z0-9_]+)\s*\(", src, re.M)))
 
 
 def test_header_symbols_are_exported():

@@ -49,3 +49,51 @@ def test_hybrid_encode_emits_reference_packets(ch, q, kind):
         assert a["packet"] == b["packet"], "packet %d differs (W=%d)" % (k, a["W"])
     if kind == "gated":
         assert sum(1 for b in want if b["W"] == 0) > 10
+
+
+_BATCH_WORKER = r'''
+import sys, threading, time, json
+sys.path.insert(0, @ROOT@)
+import numpy as np
+from oracle import ref
+from tests.test_gpu_dropin import _stream
+N, q = int(sys.argv[1]), float(sys.argv[2])
+streams = [_stream(2, 1.5, "gated" if k % 2 else "s16", seed=100 + k) for k in range(N)]
+want = [ref.RefEncoder(2, 44100, q).encode_stream(x) for x in streams]
+got = [None] * N
+encs = [ref.RefEncoder(2, 44100, q, hybrid=True) for _ in range(N)]
+def work(k):
+    got[k] = encs[k].encode_stream(streams[k])     # one long C call: the GIL is released, the threads run together
+th = [threading.Thread(target=work, args=(k,)) for k in range(N)]
+t0 = time.time()
+[t.start() for t in th]
+[t.join() for t in th]
+wall = time.time() - t0
+bad = 0
+for k in range(N):
+    if len(want[k]) != len(got[k]):
+        bad += 1
+        continue
+    for a, b in zip(want[k], got[k]):
+        if a["packet"] != b["packet"] or np.float32(a["ampmax_out"]) != np.float32(b["ampmax_out"]):
+            bad += 1
+import ctypes as C
+L = ref.lib(hybrid=True)
+print(json.dumps({"streams": N, "blocks": sum(len(w) for w in want), "bad": bad, "wall": wall,
+                  "short_blocks": sum(1 for w in want for b in w if b["W"] == 0)}))
+'''
+
+
+def test_batch_mode_many_encoder_threads_emit_reference_packets():
+    """VAMD_BATCH: sixteen application threads, each driving its own vorbis_dsp_state through the unmodified
+    application loop of the hybrid libvorbis, have their blocks coalesced by the vamd_batcher (one context, batched
+    launches); every packet of every stream equals the pure CPU reference's."""
+    import json, os, subprocess, sys
+    from tests import checker
+    env = dict(os.environ, VAMD_BATCH="64", VAMD_BATCH_WAIT_US="3000")
+    out = subprocess.run([sys.executable, "-c", _BATCH_WORKER.replace("@ROOT@", repr(checker.ROOT)), "16", "0.4"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert r["streams"] == 16 and r["blocks"] > 16 * 60 and r["short_blocks"] > 50
+    assert r["bad"] == 0, r

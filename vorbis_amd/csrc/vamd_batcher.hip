@@ -1,0 +1,290 @@
+// vamd_batcher.hip -- the host shim for encoders that call vorbis_analysis() one block at a time from MANY
+// threads (the other half of device-resident stream control: vamd_plan_streams serves callers that
+// can hand over whole streams, this serves callers that cannot).
+//
+// libvorbis' own unit of work is one block of one stream (mapping0_forward, reference lib/mapping0.c:233-687); on
+// the GPU one block is a handful of wavefronts walking serial phases (~0.4 ms), a batch of a thousand costs little
+// more.  A batcher owns ONE context and turns concurrent vamd_batcher_encode_block() calls -- same contract as
+// vamd_encode_block(), from any number of threads, one stream per thread as libvorbis requires -- into batched
+// launches: whoever finds no batch under way becomes its leader, waits until every attached stream has a block
+// pending (or `max_batch` have, or `max_wait_us` passed), takes the pending blocks of one size class, runs them as
+// ONE vamd_analyze_batch() with packet output, hands the packets back, wakes THEIR owners (each request has its
+// own condition variable: a finished batch must not wake hundreds of sleepers to find out it was not for them)
+// and appoints the owner of the oldest pending block to lead the next batch.  No thread of its own; blocks of a
+// stream stay in order because a stream has at most one pending.
+//
+// Built on the public C ABI only (the context is used by one thread at a time: the leader, under `busy`).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <string>
+#include <vector>
+#include "vorbis_amd.h"
+
+namespace {
+
+struct Request {
+  const float *const *pcm;
+  int lW, W, nW, blocktype;
+  float ampmax_in;
+  float *ampmax_out;
+  uint8_t *packet;
+  long packet_cap;
+  int32_t *packet_bits;
+  int status = 0;
+  bool done = false;
+  bool lead = false;  // appointed to lead the next batch
+  std::condition_variable cv;  // its owner sleeps here: a finished batch wakes its own blocks' owners, nobody else
+};
+
+}  // namespace
+
+struct vamd_batcher {
+  vamd_ctx *ctx = nullptr;
+  int device = 0, ch = 0;
+  int bs[2] = {0, 0};
+  long pkcap[2] = {0, 0};
+  int max_batch = 0, max_wait_us = 0;
+  hipStream_t stream = nullptr;
+  std::mutex m;
+  std::condition_variable cv_lead;  // the collecting leader sleeps here
+  bool collecting = false;
+  std::vector<Request *> pending[2];
+  bool busy = false;      // a leader is collecting or running a batch
+  int attached = 0;       // streams that announced themselves (vamd_batcher_attach)
+  void *h_stage = nullptr, *d_stage = nullptr;
+  size_t stage_bytes = 0;
+  long nbatches = 0, nblocks = 0;
+  double run_seconds = 0.;  // spent inside the batched GPU calls (staging copies included)
+  std::string err;
+};
+
+static size_t al16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+// one batch of blocks of size class W; called by the leader with `busy` set and the mutex NOT held
+static int run_batch(vamd_batcher *b, int W, Request *const *reqs, size_t nb) {
+  const size_t ch = (size_t)b->ch, n = (size_t)b->bs[W], row = (size_t)b->pkcap[W];
+  // arena: [pcm | lW | nW | blocktype | ampmax_in || ampmax_out | bits | packets]
+  const size_t o_pcm = 0, o_lW = al16(nb * ch * n * 4), o_nW = al16(o_lW + nb * 4), o_bt = al16(o_nW + nb * 4),
+               o_ain = al16(o_bt + nb * 4), o_out = al16(o_ain + nb * 4), o_aout = o_out, o_bits = al16(o_aout + nb * 4),
+               o_pk = al16(o_bits + nb * 4), total = al16(o_pk + nb * row);
+  hipError_t e = hipSetDevice(b->device);
+  if (e == hipSuccess && b->stage_bytes < total) {
+    if (b->h_stage) (void)hipHostFree(b->h_stage);
+    if (b->d_stage) (void)hipFree(b->d_stage);
+    b->h_stage = b->d_stage = nullptr;
+    b->stage_bytes = 0;
+    const size_t want = total + total / 2;
+    e = hipHostMalloc(&b->h_stage, want, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc(&b->d_stage, want);
+    if (e == hipSuccess) b->stage_bytes = want;
+  }
+  if (e != hipSuccess) {
+    b->err = std::string("batcher staging: ") + hipGetErrorString(e);
+    return VAMD_EFAULT;
+  }
+  unsigned char *hs = (unsigned char *)b->h_stage, *ds = (unsigned char *)b->d_stage;
+  for (size_t k = 0; k < nb; k++) {
+    const Request &r = *reqs[k];
+    for (size_t c = 0; c < ch; c++) memcpy(hs + o_pcm + (k * ch + c) * n * 4, r.pcm[c], n * 4);
+    ((int32_t *)(hs + o_lW))[k] = r.lW;
+    ((int32_t *)(hs + o_nW))[k] = r.nW;
+    ((int32_t *)(hs + o_bt))[k] = r.blocktype;
+    ((float *)(hs + o_ain))[k] = r.ampmax_in;
+  }
+  e = hipMemcpyAsync(ds, hs, o_out, hipMemcpyHostToDevice, b->stream);
+  if (e != hipSuccess) {
+    b->err = std::string("batcher upload: ") + hipGetErrorString(e);
+    return VAMD_EFAULT;
+  }
+  vamd_batch_desc d;
+  memset(&d, 0, sizeof(d));
+  d.W = W;
+  d.nblocks = (long)nb;
+  d.lW = (const int32_t *)(ds + o_lW);
+  d.nW = (const int32_t *)(ds + o_nW);
+  d.blocktype = (const int32_t *)(ds + o_bt);
+  d.ampmax_in = (const float *)(ds + o_ain);
+  vamd_batch_io io;
+  memset(&io, 0, sizeof(io));
+  io.pcm = (const float *)(ds + o_pcm);
+  io.ampmax_out = (float *)(ds + o_aout);
+  io.packets = ds + o_pk;
+  io.packet_bits = (int32_t *)(ds + o_bits);
+  io.packet_stride = (int64_t)row;
+  int r = vamd_analyze_batch(b->ctx, &d, &io, VAMD_LEVEL_FULL);
+  if (r) {
+    b->err = std::string("batcher analyze: ") + vamd_last_error(b->ctx);
+    return r;
+  }
+  e = hipMemcpyAsync(hs + o_out, ds + o_out, total - o_out, hipMemcpyDeviceToHost, b->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+  if (e != hipSuccess) {
+    b->err = std::string("batcher download: ") + hipGetErrorString(e);
+    return VAMD_EFAULT;
+  }
+  for (size_t k = 0; k < nb; k++) {
+    Request &q = *reqs[k];
+    const int32_t bits = ((const int32_t *)(hs + o_bits))[k];
+    const size_t bytes = ((size_t)bits + 7) / 8;
+    if (bits < 0 || bytes > row || bytes > (size_t)q.packet_cap) {
+      q.status = VAMD_EINVAL;  // the caller's buffer is shorter than vamd_packet_capacity()
+      continue;
+    }
+    memcpy(q.packet, hs + o_pk + k * row, bytes);
+    *q.packet_bits = bits;
+    if (q.ampmax_out) *q.ampmax_out = ((const float *)(hs + o_aout))[k];
+    q.status = VAMD_OK;
+  }
+  return VAMD_OK;
+}
+
+extern "C" {
+
+int vamd_batcher_create(vamd_batcher **out, const void *setup_blob, size_t blob_bytes, int device, int max_batch,
+                        int max_wait_us) {
+  if (!out) return VAMD_EINVAL;
+  *out = nullptr;
+  if (max_batch < 1 || max_wait_us < 0) return VAMD_EINVAL;
+  vamd_batcher *b = new vamd_batcher;
+  int r = vamd_create(&b->ctx, setup_blob, blob_bytes, device);
+  if (r) {
+    delete b;
+    return r;
+  }
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  b->device = device >= 0 ? device : cur;
+  b->ch = vamd_channels(b->ctx);
+  for (int W = 0; W < 2; W++) {
+    b->bs[W] = vamd_blocksize(b->ctx, W);
+    b->pkcap[W] = vamd_packet_capacity(b->ctx, W);
+  }
+  b->max_batch = max_batch;
+  b->max_wait_us = max_wait_us;
+  hipError_t e = hipSetDevice(b->device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+  if (e == hipSuccess && vamd_set_stream(b->ctx, b->stream) != VAMD_OK) e = hipErrorUnknown;
+  if (cur != b->device) (void)hipSetDevice(cur);
+  if (e != hipSuccess || b->pkcap[0] <= 0 || b->pkcap[1] <= 0) {
+    // (a mode whose packets the GPU does not assemble has nothing to batch here)
+    if (b->stream) (void)hipStreamDestroy(b->stream);
+    vamd_destroy(b->ctx);
+    delete b;
+    return e != hipSuccess ? VAMD_EFAULT : VAMD_EIMPL;
+  }
+  *out = b;
+  return VAMD_OK;
+}
+
+void vamd_batcher_destroy(vamd_batcher *b) {
+  if (!b) return;
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  (void)hipSetDevice(b->device);
+  if (b->h_stage) (void)hipHostFree(b->h_stage);
+  if (b->d_stage) (void)hipFree(b->d_stage);
+  vamd_destroy(b->ctx);
+  if (b->stream) (void)hipStreamDestroy(b->stream);
+  (void)hipSetDevice(cur);
+  delete b;
+}
+
+void vamd_batcher_attach(vamd_batcher *b) {
+  if (!b) return;
+  std::lock_guard<std::mutex> g(b->m);
+  b->attached++;
+}
+
+void vamd_batcher_detach(vamd_batcher *b) {
+  if (!b) return;
+  {
+    std::lock_guard<std::mutex> g(b->m);
+    if (b->attached > 0) b->attached--;
+  }
+  b->cv_lead.notify_one();  // a leader waiting for this stream's block need not wait any longer
+}
+
+int vamd_batcher_encode_block(vamd_batcher *b, const float *const *pcm, int lW, int W, int nW, int blocktype,
+                              float ampmax_in, float *ampmax_out, uint8_t *packet, long packet_cap,
+                              int32_t *packet_bits) {
+  if (!b || !pcm || !packet || !packet_bits || (W != 0 && W != 1)) return VAMD_EINVAL;
+  for (int c = 0; c < b->ch; c++)
+    if (!pcm[c]) return VAMD_EINVAL;
+  Request rq;
+  rq.pcm = pcm, rq.lW = lW, rq.W = W, rq.nW = nW, rq.blocktype = blocktype, rq.ampmax_in = ampmax_in;
+  rq.ampmax_out = ampmax_out, rq.packet = packet, rq.packet_cap = packet_cap, rq.packet_bits = packet_bits;
+  std::unique_lock<std::mutex> lk(b->m);
+  b->pending[W].push_back(&rq);
+  if (b->collecting) b->cv_lead.notify_one();  // the collecting leader counts it
+  if (b->busy) {
+    // someone leads: sleep until our block comes back, or until we are appointed to lead the next batch
+    while (!rq.done && !rq.lead) rq.cv.wait(lk);
+  } else {
+    b->busy = true;
+    rq.lead = true;
+  }
+  while (!rq.done) {
+    // ---- we lead (busy is set, and ours): gather, run one batch, hand the results back
+    b->collecting = true;
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(b->max_wait_us);
+    for (;;) {
+      const size_t have = b->pending[0].size() + b->pending[1].size();
+      if (have >= (size_t)b->max_batch || (b->attached > 0 && have >= (size_t)b->attached)) break;
+      if (b->cv_lead.wait_until(lk, deadline) == std::cv_status::timeout) break;
+    }
+    b->collecting = false;
+    // the size class with more blocks waiting goes first (ours, if it is a tie)
+    const int Wb = b->pending[W].size() >= b->pending[1 - W].size() ? W : 1 - W;
+    std::vector<Request *> take;
+    {
+      std::vector<Request *> &q = b->pending[Wb];
+      const size_t nb = q.size() < (size_t)b->max_batch ? q.size() : (size_t)b->max_batch;
+      take.assign(q.begin(), q.begin() + (long)nb);
+      q.erase(q.begin(), q.begin() + (long)nb);
+    }
+    lk.unlock();
+    const auto t0 = std::chrono::steady_clock::now();
+    const int r = run_batch(b, Wb, take.data(), take.size());
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    lk.lock();
+    b->run_seconds += dt;
+    b->nbatches++;
+    b->nblocks += (long)take.size();
+    for (Request *t : take) {
+      if (r) t->status = r;
+      t->done = true;
+      if (t != &rq) t->cv.notify_one();
+    }
+  }
+  // ---- our block is back: pass the lead to the owner of the oldest pending block, if there is one
+  if (rq.lead) {
+    Request *next = nullptr;
+    for (int w = 0; w < 2 && !next; w++)
+      if (!b->pending[w].empty()) next = b->pending[w].front();
+    if (next) {
+      next->lead = true;
+      next->cv.notify_one();
+    } else {
+      b->busy = false;
+    }
+  }
+  return rq.status;
+}
+
+const char *vamd_batcher_last_error(const vamd_batcher *b) { return b ? b->err.c_str() : "null batcher"; }
+
+void vamd_batcher_stats(vamd_batcher *b, long *batches, long *blocks, double *run_seconds) {
+  if (!b) return;
+  std::lock_guard<std::mutex> g(b->m);
+  if (batches) *batches = b->nbatches;
+  if (blocks) *blocks = b->nblocks;
+  if (run_seconds) *run_seconds = b->run_seconds;
+}
+
+vamd_ctx *vamd_batcher_context(vamd_batcher *b) { return b ? b->ctx : nullptr; }
+
+}  // extern "C"
