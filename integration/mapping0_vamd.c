@@ -25,7 +25,7 @@
  * the bitrate manager that picks one is untouched host code.
  * With VAMD_BATCH=<n> in the environment the VBR blocks of ALL encoder states that share a setup go through one
  * vamd_batcher (include/vorbis_amd.h): many application threads, each driving its own vorbis_dsp_state as libvorbis
- * allows, get their blocks analysed in shared GPU batches of up to n (VAMD_BATCH_WAIT_US, default 2000, bounds how
+ * allows, get their blocks analysed in shared GPU batches of up to n (VAMD_BATCH_WAIT_US, default 200, bounds how
  * long a batch waits for stragglers).  The block-switching detector then stays on the host (envelope_vamd.c).
  * Channel counts above VAMD_MAX_CH are refused with OV_EIMPL (see mapping0_forward_vamd); errors
  * travel as OV_* return codes like everywhere else in libvorbis -- nothing is printed.
@@ -92,7 +92,7 @@ static vamd_shared *vamd_share_for(void *blob, long bytes, int *kept) {
   if (vamd_nshares < (int)(sizeof(vamd_shares) / sizeof(vamd_shares[0]))) {
     vamd_shared *sh = _ogg_calloc(1, sizeof(*sh));
     const char *w = getenv("VAMD_BATCH_WAIT_US");
-    if (sh && vamd_batcher_create(&sh->batcher, blob, (size_t)bytes, -1, vamd_batching(), w ? atoi(w) : 2000) == VAMD_OK) {
+    if (sh && vamd_batcher_create(&sh->batcher, blob, (size_t)bytes, -1, vamd_batching(), w ? atoi(w) : 200) == VAMD_OK) {
       sh->blob = blob;
       sh->bytes = bytes;
       *kept = 1;

@@ -16,10 +16,13 @@ nb = [0] * N
 def work(k):
     nb[k] = len(encs[k].encode_stream(x))
 th = [threading.Thread(target=work, args=(k,)) for k in range(N)]
+c0 = os.times()
 t0 = time.time()
 [t.start() for t in th]
 [t.join() for t in th]
 wall = time.time() - t0
+c1 = os.times()
+print("host CPU: %.3f ms user + %.3f ms system per block" % (1e3 * (c1.user - c0.user) / max(sum(nb), 1), 1e3 * (c1.system - c0.system) / max(sum(nb), 1)))
 if hyb and os.environ.get("VAMD_BATCH"):
     import ctypes as C
     a, b, t = C.c_long(0), C.c_long(0), C.c_double(0)

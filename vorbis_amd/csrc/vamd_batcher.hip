@@ -13,9 +13,14 @@
 // and appoints the owner of the oldest pending block to lead the next batch.  No thread of its own; blocks of a
 // stream stay in order because a stream has at most one pending.
 //
-// Built on the public C ABI only (the context is used by one thread at a time: the leader, under `busy`).
+// A batcher has a few LANES (contexts with their own stream and staging; VAMD_BATCH_LANES, default 2): one leader
+// gathers at a time, but while its batch is on the GPU the next leader already gathers and launches on another lane --
+// a batch of a few dozen blocks is latency on the GPU, not load, and the gaps between batches were most of the time.
+//
+// Built on the public C ABI only (a context is used by one thread at a time: the leader that holds its lane).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <chrono>
 #include <condition_variable>
@@ -42,21 +47,27 @@ struct Request {
 
 }  // namespace
 
-struct vamd_batcher {
+// one context with its stream and staging arenas: a batch runs on one lane
+struct Lane {
   vamd_ctx *ctx = nullptr;
+  hipStream_t stream = nullptr;
+  void *h_stage = nullptr, *d_stage = nullptr;
+  size_t stage_bytes = 0;
+  bool in_use = false;
+};
+
+struct vamd_batcher {
+  std::vector<Lane> lanes;  // VAMD_BATCH_LANES (default 2): while one batch is on the GPU the next is gathered and launched
   int device = 0, ch = 0;
   int bs[2] = {0, 0};
   long pkcap[2] = {0, 0};
   int max_batch = 0, max_wait_us = 0;
-  hipStream_t stream = nullptr;
   std::mutex m;
   std::condition_variable cv_lead;  // the collecting leader sleeps here
-  bool collecting = false;
+  bool collecting = false;          // a leader is gathering (at most one at a time; the others are running theirs)
+  int leaders = 0;                  // leaders at work, gathering or running: <= lanes.size()
   std::vector<Request *> pending[2];
-  bool busy = false;      // a leader is collecting or running a batch
   int attached = 0;       // streams that announced themselves (vamd_batcher_attach)
-  void *h_stage = nullptr, *d_stage = nullptr;
-  size_t stage_bytes = 0;
   long nbatches = 0, nblocks = 0;
   double run_seconds = 0.;  // spent inside the batched GPU calls (staging copies included)
   std::string err;
@@ -64,29 +75,29 @@ struct vamd_batcher {
 
 static size_t al16(size_t x) { return (x + 15) & ~(size_t)15; }
 
-// one batch of blocks of size class W; called by the leader with `busy` set and the mutex NOT held
-static int run_batch(vamd_batcher *b, int W, Request *const *reqs, size_t nb) {
+// one batch of blocks of size class W on lane L; called by a leader with the mutex NOT held
+static int run_batch(vamd_batcher *b, Lane &L, int W, Request *const *reqs, size_t nb, std::string *err) {
   const size_t ch = (size_t)b->ch, n = (size_t)b->bs[W], row = (size_t)b->pkcap[W];
   // arena: [pcm | lW | nW | blocktype | ampmax_in || ampmax_out | bits | packets]
   const size_t o_pcm = 0, o_lW = al16(nb * ch * n * 4), o_nW = al16(o_lW + nb * 4), o_bt = al16(o_nW + nb * 4),
                o_ain = al16(o_bt + nb * 4), o_out = al16(o_ain + nb * 4), o_aout = o_out, o_bits = al16(o_aout + nb * 4),
                o_pk = al16(o_bits + nb * 4), total = al16(o_pk + nb * row);
   hipError_t e = hipSetDevice(b->device);
-  if (e == hipSuccess && b->stage_bytes < total) {
-    if (b->h_stage) (void)hipHostFree(b->h_stage);
-    if (b->d_stage) (void)hipFree(b->d_stage);
-    b->h_stage = b->d_stage = nullptr;
-    b->stage_bytes = 0;
+  if (e == hipSuccess && L.stage_bytes < total) {
+    if (L.h_stage) (void)hipHostFree(L.h_stage);
+    if (L.d_stage) (void)hipFree(L.d_stage);
+    L.h_stage = L.d_stage = nullptr;
+    L.stage_bytes = 0;
     const size_t want = total + total / 2;
-    e = hipHostMalloc(&b->h_stage, want, hipHostMallocDefault);
-    if (e == hipSuccess) e = hipMalloc(&b->d_stage, want);
-    if (e == hipSuccess) b->stage_bytes = want;
+    e = hipHostMalloc(&L.h_stage, want, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc(&L.d_stage, want);
+    if (e == hipSuccess) L.stage_bytes = want;
   }
   if (e != hipSuccess) {
-    b->err = std::string("batcher staging: ") + hipGetErrorString(e);
+    *err = std::string("batcher staging: ") + hipGetErrorString(e);
     return VAMD_EFAULT;
   }
-  unsigned char *hs = (unsigned char *)b->h_stage, *ds = (unsigned char *)b->d_stage;
+  unsigned char *hs = (unsigned char *)L.h_stage, *ds = (unsigned char *)L.d_stage;
   for (size_t k = 0; k < nb; k++) {
     const Request &r = *reqs[k];
     for (size_t c = 0; c < ch; c++) memcpy(hs + o_pcm + (k * ch + c) * n * 4, r.pcm[c], n * 4);
@@ -95,9 +106,9 @@ static int run_batch(vamd_batcher *b, int W, Request *const *reqs, size_t nb) {
     ((int32_t *)(hs + o_bt))[k] = r.blocktype;
     ((float *)(hs + o_ain))[k] = r.ampmax_in;
   }
-  e = hipMemcpyAsync(ds, hs, o_out, hipMemcpyHostToDevice, b->stream);
+  e = hipMemcpyAsync(ds, hs, o_out, hipMemcpyHostToDevice, L.stream);
   if (e != hipSuccess) {
-    b->err = std::string("batcher upload: ") + hipGetErrorString(e);
+    *err = std::string("batcher upload: ") + hipGetErrorString(e);
     return VAMD_EFAULT;
   }
   vamd_batch_desc d;
@@ -115,15 +126,15 @@ static int run_batch(vamd_batcher *b, int W, Request *const *reqs, size_t nb) {
   io.packets = ds + o_pk;
   io.packet_bits = (int32_t *)(ds + o_bits);
   io.packet_stride = (int64_t)row;
-  int r = vamd_analyze_batch(b->ctx, &d, &io, VAMD_LEVEL_FULL);
+  int r = vamd_analyze_batch(L.ctx, &d, &io, VAMD_LEVEL_FULL);
   if (r) {
-    b->err = std::string("batcher analyze: ") + vamd_last_error(b->ctx);
+    *err = std::string("batcher analyze: ") + vamd_last_error(L.ctx);
     return r;
   }
-  e = hipMemcpyAsync(hs + o_out, ds + o_out, total - o_out, hipMemcpyDeviceToHost, b->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+  e = hipMemcpyAsync(hs + o_out, ds + o_out, total - o_out, hipMemcpyDeviceToHost, L.stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(L.stream);
   if (e != hipSuccess) {
-    b->err = std::string("batcher download: ") + hipGetErrorString(e);
+    *err = std::string("batcher download: ") + hipGetErrorString(e);
     return VAMD_EFAULT;
   }
   for (size_t k = 0; k < nb; k++) {
@@ -144,38 +155,61 @@ static int run_batch(vamd_batcher *b, int W, Request *const *reqs, size_t nb) {
 
 extern "C" {
 
+static void free_lanes(vamd_batcher *b) {
+  for (Lane &L : b->lanes) {
+    if (L.h_stage) (void)hipHostFree(L.h_stage);
+    if (L.d_stage) (void)hipFree(L.d_stage);
+    if (L.ctx) vamd_destroy(L.ctx);
+    if (L.stream) (void)hipStreamDestroy(L.stream);
+  }
+  b->lanes.clear();
+}
+
 int vamd_batcher_create(vamd_batcher **out, const void *setup_blob, size_t blob_bytes, int device, int max_batch,
                         int max_wait_us) {
   if (!out) return VAMD_EINVAL;
   *out = nullptr;
   if (max_batch < 1 || max_wait_us < 0) return VAMD_EINVAL;
+  int nlanes = getenv("VAMD_BATCH_LANES") ? atoi(getenv("VAMD_BATCH_LANES")) : 2;
+  if (nlanes < 1) nlanes = 1;
+  if (nlanes > 8) nlanes = 8;
   vamd_batcher *b = new vamd_batcher;
-  int r = vamd_create(&b->ctx, setup_blob, blob_bytes, device);
-  if (r) {
-    delete b;
-    return r;
-  }
   int cur = 0;
   (void)hipGetDevice(&cur);
   b->device = device >= 0 ? device : cur;
-  b->ch = vamd_channels(b->ctx);
-  for (int W = 0; W < 2; W++) {
-    b->bs[W] = vamd_blocksize(b->ctx, W);
-    b->pkcap[W] = vamd_packet_capacity(b->ctx, W);
+  b->lanes.resize((size_t)nlanes);
+  int r = VAMD_OK;
+  for (Lane &L : b->lanes) {
+    r = vamd_create(&L.ctx, setup_blob, blob_bytes, device);
+    if (r) break;
+    hipError_t e = hipSetDevice(b->device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking);
+    if (e == hipSuccess && vamd_set_stream(L.ctx, L.stream) != VAMD_OK) e = hipErrorUnknown;
+    if (e != hipSuccess) {
+      r = VAMD_EFAULT;
+      break;
+    }
+  }
+  if (!r) {
+    vamd_ctx *c0 = b->lanes[0].ctx;
+    b->ch = vamd_channels(c0);
+    for (int W = 0; W < 2; W++) {
+      b->bs[W] = vamd_blocksize(c0, W);
+      b->pkcap[W] = vamd_packet_capacity(c0, W);
+    }
+    // (a mode whose packets the GPU does not assemble has nothing to batch here)
+    if (b->pkcap[0] <= 0 || b->pkcap[1] <= 0) r = VAMD_EIMPL;
   }
   b->max_batch = max_batch;
   b->max_wait_us = max_wait_us;
-  hipError_t e = hipSetDevice(b->device);
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
-  if (e == hipSuccess && vamd_set_stream(b->ctx, b->stream) != VAMD_OK) e = hipErrorUnknown;
-  if (cur != b->device) (void)hipSetDevice(cur);
-  if (e != hipSuccess || b->pkcap[0] <= 0 || b->pkcap[1] <= 0) {
-    // (a mode whose packets the GPU does not assemble has nothing to batch here)
-    if (b->stream) (void)hipStreamDestroy(b->stream);
-    vamd_destroy(b->ctx);
+  if (r) {
+    (void)hipSetDevice(b->device);
+    free_lanes(b);
+    (void)hipSetDevice(cur);
     delete b;
-    return e != hipSuccess ? VAMD_EFAULT : VAMD_EIMPL;
+    return r;
   }
+  if (cur != b->device) (void)hipSetDevice(cur);
   *out = b;
   return VAMD_OK;
 }
@@ -185,10 +219,7 @@ void vamd_batcher_destroy(vamd_batcher *b) {
   int cur = 0;
   (void)hipGetDevice(&cur);
   (void)hipSetDevice(b->device);
-  if (b->h_stage) (void)hipHostFree(b->h_stage);
-  if (b->d_stage) (void)hipFree(b->d_stage);
-  vamd_destroy(b->ctx);
-  if (b->stream) (void)hipStreamDestroy(b->stream);
+  free_lanes(b);
   (void)hipSetDevice(cur);
   delete b;
 }
@@ -219,16 +250,17 @@ int vamd_batcher_encode_block(vamd_batcher *b, const float *const *pcm, int lW, 
   rq.ampmax_out = ampmax_out, rq.packet = packet, rq.packet_cap = packet_cap, rq.packet_bits = packet_bits;
   std::unique_lock<std::mutex> lk(b->m);
   b->pending[W].push_back(&rq);
-  if (b->collecting) b->cv_lead.notify_one();  // the collecting leader counts it
-  if (b->busy) {
-    // someone leads: sleep until our block comes back, or until we are appointed to lead the next batch
-    while (!rq.done && !rq.lead) rq.cv.wait(lk);
-  } else {
-    b->busy = true;
+  if (b->collecting) {
+    b->cv_lead.notify_one();  // the gathering leader counts it
+  } else if (b->leaders < (int)b->lanes.size()) {
+    b->leaders++;  // nobody is gathering and a lane is free: we lead
     rq.lead = true;
   }
-  while (!rq.done) {
-    // ---- we lead (busy is set, and ours): gather, run one batch, hand the results back
+  for (;;) {
+    // sleep until our block comes back, or until we are appointed to lead a batch
+    while (!rq.done && !rq.lead) rq.cv.wait(lk);
+    if (rq.done) break;
+    // ---- we lead: gather (one leader at a time), then run the batch on a free lane, then hand the results back
     b->collecting = true;
     const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(b->max_wait_us);
     for (;;) {
@@ -236,7 +268,6 @@ int vamd_batcher_encode_block(vamd_batcher *b, const float *const *pcm, int lW, 
       if (have >= (size_t)b->max_batch || (b->attached > 0 && have >= (size_t)b->attached)) break;
       if (b->cv_lead.wait_until(lk, deadline) == std::cv_status::timeout) break;
     }
-    b->collecting = false;
     // the size class with more blocks waiting goes first (ours, if it is a tie)
     const int Wb = b->pending[W].size() >= b->pending[1 - W].size() ? W : 1 - W;
     std::vector<Request *> take;
@@ -246,11 +277,45 @@ int vamd_batcher_encode_block(vamd_batcher *b, const float *const *pcm, int lW, 
       take.assign(q.begin(), q.begin() + (long)nb);
       q.erase(q.begin(), q.begin() + (long)nb);
     }
+    Lane *lane = nullptr;
+    for (Lane &L : b->lanes)
+      if (!L.in_use) {
+        lane = &L;
+        break;
+      }
+    b->collecting = false;
+    if (take.empty() || !lane) {
+      // nothing left to run (an appointed leader that woke up late finds everything, its own block included, in
+      // another leader's batch): step down and wait for the block like everybody else
+      for (Request *t : take) t->status = VAMD_EFAULT, t->done = true, t->cv.notify_one();  // (no lane: cannot happen)
+      rq.lead = false;
+      b->leaders--;
+      continue;
+    }
+    lane->in_use = true;  // (there is one: leaders <= lanes, and every other leader holds at most one)
+    // what is still pending (the other size class, latecomers) gets its own leader at once if a lane is free
+    if (b->leaders < (int)b->lanes.size()) {
+      Request *next = nullptr;
+      for (int w = 0; w < 2 && !next; w++)
+        for (Request *t : b->pending[w])
+          if (!t->lead) {
+            next = t;
+            break;
+          }
+      if (next) {
+        b->leaders++;
+        next->lead = true;
+        next->cv.notify_one();
+      }
+    }
     lk.unlock();
+    std::string err;
     const auto t0 = std::chrono::steady_clock::now();
-    const int r = run_batch(b, Wb, take.data(), take.size());
+    const int r = run_batch(b, *lane, Wb, take.data(), take.size(), &err);
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     lk.lock();
+    lane->in_use = false;
+    if (r) b->err = err;
     b->run_seconds += dt;
     b->nbatches++;
     b->nblocks += (long)take.size();
@@ -260,16 +325,21 @@ int vamd_batcher_encode_block(vamd_batcher *b, const float *const *pcm, int lW, 
       if (t != &rq) t->cv.notify_one();
     }
   }
-  // ---- our block is back: pass the lead to the owner of the oldest pending block, if there is one
+  // ---- our block is back: pass the lead to the owner of the oldest pending block that has none, if any
   if (rq.lead) {
     Request *next = nullptr;
-    for (int w = 0; w < 2 && !next; w++)
-      if (!b->pending[w].empty()) next = b->pending[w].front();
+    if (!b->collecting)
+      for (int w = 0; w < 2 && !next; w++)
+        for (Request *t : b->pending[w])
+          if (!t->lead) {
+            next = t;
+            break;
+          }
     if (next) {
       next->lead = true;
       next->cv.notify_one();
     } else {
-      b->busy = false;
+      b->leaders--;
     }
   }
   return rq.status;
@@ -285,6 +355,6 @@ void vamd_batcher_stats(vamd_batcher *b, long *batches, long *blocks, double *ru
   if (run_seconds) *run_seconds = b->run_seconds;
 }
 
-vamd_ctx *vamd_batcher_context(vamd_batcher *b) { return b ? b->ctx : nullptr; }
+vamd_ctx *vamd_batcher_context(vamd_batcher *b) { return b && !b->lanes.empty() ? b->lanes[0].ctx : nullptr; }
 
 }  // extern "C"
