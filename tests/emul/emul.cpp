@@ -341,3 +341,21 @@ int emul_plan_stream(void *h, const unsigned char *flags, long nsteps, long nsam
   return n;
 }
 }
+
+extern "C" {
+// seed_chase part 1 two ways over the same seed lines: the serial walk (tone_chase_thread) and the chunked one
+// (chase_chunks_host); returns 1 if the survivor lists agree, and through *accepted whether the chunks verified.
+int emul_chase_compare(const float *seeds, int linesper, int n, int *accepted, int *nsurv_out, int *rounds) {
+  std::vector<float> ring_amp(VAMD_RING);
+  std::vector<int> ring_pos(VAMD_RING);
+  std::vector<unsigned short> a(n + 16), b(n + 16);
+  const int na = tone_chase_thread(seeds, linesper, n, ring_amp.data(), ring_pos.data(), 1, 0, a.data());
+  const int nb = chase_chunks_host(seeds, linesper, n, b.data(), accepted, rounds);
+  *nsurv_out = na;
+  if (!*accepted) return 1;  // (the kernel would take the serial walk)
+  if (na != nb) return 0;
+  for (int k = 0; k < na; k++)
+    if (a[k] != b[k]) return 0;
+  return 1;
+}
+}

@@ -67,6 +67,7 @@ class Emul:
         self.L.emul_residue_offset.argtypes = [C.c_void_p, C.c_int, C.c_int]
         self.L.emul_envelope_search.argtypes = [C.c_void_p, _f32p, C.c_long, C.c_long, C.c_void_p, C.c_void_p]
         self.L.emul_plan_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_void_p, C.c_void_p]
+        self.L.emul_chase_compare.argtypes = [_f32p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         blob = np.ascontiguousarray(blob, dtype=np.uint8)
         self.h = self.L.emul_open(blob.ctypes.data_as(C.c_void_p), blob.size)
         if not self.h:
@@ -164,3 +165,13 @@ class Emul:
         n = self.L.emul_plan_stream(self.h, flags.ctypes.data_as(C.c_void_p), C.c_long(len(flags)), C.c_long(nsamples),
                                     maxblocks, kind.ctypes.data_as(C.c_void_p), begin.ctypes.data_as(C.c_void_p))
         return kind[:n], begin[:n]
+
+    def chase_compare(self, seeds, linesper):
+        """seed_chase's stack walk serially and in 64 verified chunks (k_tone.h chase_chunk) over the same seed
+        lines: (lists agree, chunks accepted, survivors, repair rounds)."""
+        n = len(seeds)
+        buf = np.full((n + 31) & ~15, -9999.0, np.float32)
+        buf[:n] = seeds
+        acc, ns, rd = C.c_int(0), C.c_int(0), C.c_int(0)
+        same = self.L.emul_chase_compare(buf.ctypes.data_as(_f32p), linesper, n, C.byref(acc), C.byref(ns), C.byref(rd))
+        return bool(same), bool(acc.value), ns.value, rd.value

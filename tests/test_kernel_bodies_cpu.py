@@ -47,3 +47,45 @@ def test_bodies_match_oracle_random(name):
         a = chk.tap_block(pcm, ampmax_in=-9999.0 if it % 2 else -40.0)
         g = em.analyze_block(pcm, ampmax_in=-9999.0 if it % 2 else -40.0)
         assert checker.compare_block(a, g, em.L and 29, verbose=True) == 0
+
+
+def test_chunked_chase_equals_serial_walk():
+    """k_tone_chase_wave's algorithm on the host: the stack walk of seed_chase (lib/psy.c:454-487) cut into 64 chunks
+    with cold starts, entry/exit state verification and repair rounds gives the serial walk's survivor list on every
+    kind of seed vector; ordinary vectors verify at once, stretches of equal values take a few rounds, and a block with a
+    very long one is handed to the serial walk (which the kernel then runs) -- never a different list."""
+    from tests.emul.emul import Emul
+    em = Emul(np.fromfile(os.path.join(checker.ROOT, "vorbis_amd", "data", "setup_44k_stereo_q4.bin"), dtype=np.uint8))
+    rng = np.random.default_rng(2024)
+    for trial in range(500):
+        n = int(rng.choice([784, 784, 784, 400, 97, 1024, 33, 64, 65]))
+        kind = trial % 10
+        x = (rng.random(n) * 60 - 30).astype(np.float32)                  # white
+        if kind == 1:
+            x = np.round(x / 6) * 6                                         # heavy ties
+        elif kind == 2:
+            x = np.cumsum(rng.standard_normal(n)).astype(np.float32)        # slow drifts
+        elif kind == 3:
+            x[rng.random(n) < 0.7] = -9999.0                                # mostly empty lines
+        elif kind == 4:
+            x = np.sort(x)                                                  # rising
+        elif kind == 5:
+            x = np.sort(x)[::-1].copy()                                     # falling
+        elif kind == 6:
+            x[:] = 3.0                                                      # flat throughout
+        elif kind == 7:
+            x = (np.sin(np.arange(n) * rng.random() * 3) * 20).astype(np.float32)
+        elif kind == 8:
+            x[n // 2:] = -9999.0                                            # nothing reached the upper half
+        elif kind == 9:
+            x[3 * n // 4:] = -9999.0
+        for L in (8, 8, 4, 16):
+            same, accepted, ns, rounds = em.chase_compare(x.astype(np.float32), L)
+            assert same, (trial, kind, n, L)
+            assert ns > 0
+            if kind in (0, 1, 2, 4, 5, 7):
+                assert accepted and rounds == 0, (trial, kind, n, L, rounds)
+            if kind == 9:
+                assert accepted, (trial, n, L, rounds)
+            if kind == 6 and n >= 784:
+                assert not accepted and rounds < 0     # routed to the serial walk before any chunk is walked

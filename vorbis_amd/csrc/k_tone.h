@@ -189,6 +189,170 @@ VAMD_DEV int tone_chase_thread(const float *__restrict__ seeds, int linesper, in
   return stack;
 }
 
+// ---- seed_chase part 1 for ONE block spread over a wave (small batches, the per-block entry points) -------------
+// One lane per block is the right shape for a batch of thousands; for a handful of blocks it leaves a single lane
+// walking ~800 lines while the caller waits (most of a block's latency on the GPU).  The walk can be cut into
+// chunks because it forgets: an entry can be popped, or looked at, only while the current line is within
+// `linesper` of it, so what steps >= t do depends on the past only through WHICH of the lines t-linesper+1 .. t-1
+// are still on the stack (their amplitudes are the seed values; anything older fails the position tests, and the
+// stack holds two entries or more from line 2 on).  So chunk c is walked from a cold start `warm` lines early, and the
+// result is accepted iff every chunk's state on entry -- that alive mask -- equals its predecessor's state on exit
+// (chunk 0, and any chunk whose warm-up reaches back to line 0, start from the true state: induction does the rest).
+// A chunk whose entry state differs from its predecessor's exit is walked again, this time started exactly in that
+// exit state (a few rounds; runs of equal values -- stretches no curve reached -- carry a phase from their beginning
+// and need them); a block still inconsistent after VAMD_CHASE_ROUNDS takes the serial walk, so the outcome is the
+// reference's in every case (tests/test_kernel_bodies_cpu.py counts rounds and fallbacks).
+// A chunk also walks linesper-1 lines past its end: that is where its own last lines can still be popped.
+struct ChaseChunk {
+  uint32_t popped;   // bit k: line s+k was popped
+  uint32_t sig_in;   // alive mask of the window before line s, as the cold start left it
+  uint32_t sig_out;  // alive mask of the window before line e (valid when e < n)
+  int exact;         // the walk started at line 0: its state is the true one
+};
+//   warm >= 0: cold start `warm` lines before s.  warm < 0: start AT s from the state `enter` (an alive mask of the
+//   window before s, e.g. the predecessor's sig_out): the stack is rebuilt as one entry far out of reach -- standing
+//   for everything older, which can neither be popped nor pass a position test -- plus the window's alive lines.
+VAMD_DEV ChaseChunk chase_chunk(const float *seeds, int linesper, int n, int s, int e, int warm, uint32_t enter,
+                                float *ring_amp, int *ring_pos, int rstride, int rlane) {
+  ChaseChunk out;
+  out.popped = out.sig_in = out.sig_out = 0;
+  const int ws = warm < 0 ? s : (s - warm > 0 ? s - warm : 0);
+  out.exact = ws == 0;
+  const int stop = e + linesper - 1 < n ? e + linesper - 1 : n;
+  int stack = 0;
+  float a1 = 0.f, a2 = 0.f;
+  int p1 = 0, p2 = 0;
+  if (warm < 0 && s > 0) {
+    auto push = [&](float a, int pos) {
+      const int slot = stack & (VAMD_RING - 1);
+      ring_amp[slot * rstride + rlane] = a;
+      ring_pos[slot * rstride + rlane] = pos;
+      stack++;
+      a2 = a1;
+      p2 = p1;
+      a1 = a;
+      p1 = pos;
+    };
+    push(0.f, -(1 << 24));
+    const int lo = s - linesper + 1;
+    for (int k = 0; k < linesper - 1; k++)
+      if (lo + k >= 0 && ((enter >> k) & 1u)) push(seeds[lo + k], lo + k);
+  }
+  // alive mask of lines t-linesper+1 .. t-1 (bit = line - (t-linesper+1)): the stack's top entries, newest first
+  auto window = [&](int t) {
+    uint32_t m = 0;
+    const int lo = t - linesper + 1;
+    for (int k = stack - 1; k >= 0 && k >= stack - linesper; k--) {
+      const int pos = k == stack - 1 ? p1 : (k == stack - 2 ? p2 : ring_pos[(k & (VAMD_RING - 1)) * rstride + rlane]);
+      if (pos < lo) break;
+      m |= 1u << (pos - lo);
+    }
+    return m;
+  };
+  for (int i = ws; i < stop; i++) {
+    if (i == s) out.sig_in = window(s);
+    if (i == e) out.sig_out = window(e);
+    const float sv = seeds[i];
+    if (stack >= 2) {
+      while (!(sv < a1) && i < p1 + linesper && a1 <= a2 && i < p2 + linesper) {
+        if (p1 >= s && p1 < e) out.popped |= 1u << (p1 - s);
+        stack--;
+        a1 = a2;
+        p1 = p2;
+        if (stack < 2) break;
+        const int slot = (stack - 2) & (VAMD_RING - 1);
+        a2 = ring_amp[slot * rstride + rlane];
+        p2 = ring_pos[slot * rstride + rlane];
+      }
+    }
+    const int slot = stack & (VAMD_RING - 1);
+    ring_amp[slot * rstride + rlane] = sv;
+    ring_pos[slot * rstride + rlane] = i;
+    stack++;
+    a2 = a1;
+    p2 = p1;
+    a1 = sv;
+    p1 = i;
+  }
+  return out;
+}
+
+#define VAMD_CHASE_CHUNKS 64  // chunks per block = lanes of the wave
+// what the chunks of one block add up to: accepted (every chunk entered in its predecessor's exit state)?
+// Host form, chunk after chunk (the GPU kernel runs chase_chunk one per lane and combines with wave operations).
+// Repair rounds before a block is handed to the serial walk.  A run of equal values (a stretch no curve reached)
+// carries a phase from its beginning, so the true state crosses it one chunk per round: worth it up to about two dozen
+// chunks (a round is ~20 lines per lane, the serial walk ~800 for one); a block with a longer run goes serial at once
+// (chase_flat_chunk / VAMD_CHASE_FLAT_MAX).
+#define VAMD_CHASE_ROUNDS 26
+#define VAMD_CHASE_FLAT_MAX 24
+// does chunk [s, e) merely continue a run of equal values (every line equals line s-1)?
+VAMD_DEV int chase_flat_chunk(const float *seeds, int s, int e) {
+  if (s == 0 || s >= e) return 0;
+  const float v = seeds[s - 1];
+  int flat = 1;
+  for (int i = s; i < e; i++) flat &= seeds[i] == v;
+  return flat;
+}
+#if !VAMD_GPU
+VAMD_DEV int chase_chunks_host(const float *seeds, int linesper, int n, unsigned short *surv, int *accepted, int *rounds) {
+  const int cs = (n + VAMD_CHASE_CHUNKS - 1) / VAMD_CHASE_CHUNKS;
+  float ring_amp[VAMD_RING];
+  int ring_pos[VAMD_RING];
+  ChaseChunk r[VAMD_CHASE_CHUNKS];
+  uint32_t used[VAMD_CHASE_CHUNKS];
+  int nc = 0;
+  for (int c = 0; c < VAMD_CHASE_CHUNKS && c * cs < n; c++, nc++) {
+    const int s0 = c * cs, e0 = s0 + cs < n ? s0 + cs : n;
+    r[c] = chase_chunk(seeds, linesper, n, s0, e0, 4 * linesper, 0, ring_amp, ring_pos, 1, 0);
+    used[c] = r[c].sig_in;
+  }
+  int ok = 0, rd = 0;
+  {  // a long run of equal values: straight to the serial walk
+    int run = 0, longest = 0;
+    for (int c = 0; c < nc; c++) {
+      const int s0 = c * cs, e0 = s0 + cs < n ? s0 + cs : n;
+      run = chase_flat_chunk(seeds, s0, e0) ? run + 1 : 0;
+      if (run > longest) longest = run;
+    }
+    if (longest > VAMD_CHASE_FLAT_MAX) {
+      *accepted = 0;
+      *rounds = -1;
+      return 0;
+    }
+  }
+  for (; rd <= VAMD_CHASE_ROUNDS; rd++) {
+    // (all chunks of a round look at the previous round's exits, as the lanes of a wave do)
+    uint32_t prev[VAMD_CHASE_CHUNKS];
+    for (int c = 0; c < nc; c++) prev[c] = c ? r[c - 1].sig_out : 0;
+    int need_any = 0;
+    for (int c = 0; c < nc; c++) {
+      if (r[c].exact || used[c] == prev[c]) continue;
+      need_any = 1;
+      if (rd == VAMD_CHASE_ROUNDS) break;
+      const int s0 = c * cs, e0 = s0 + cs < n ? s0 + cs : n;
+      const ChaseChunk t = chase_chunk(seeds, linesper, n, s0, e0, -1, prev[c], ring_amp, ring_pos, 1, 0);
+      used[c] = prev[c];
+      r[c].popped = t.popped;
+      r[c].sig_out = t.sig_out;
+    }
+    if (!need_any) {
+      ok = 1;
+      break;
+    }
+  }
+  int ns = 0;
+  for (int c = 0; c < nc; c++) {
+    const int s0 = c * cs, e0 = s0 + cs < n ? s0 + cs : n;
+    for (int k = 0; k < e0 - s0; k++)
+      if (!((r[c].popped >> k) & 1u)) surv[ns++] = (unsigned short)(s0 + k);
+  }
+  *accepted = ok;
+  *rounds = rd;
+  return ns;
+}
+#endif
+
 // scatter half: seed[] for one channel-block (LDS), lib/psy.c:417-452,762-771
 // logfft is read straight from HBM: each lane walks the few bins of its own run, neighbouring
 // lanes walk neighbouring runs, and a copy in LDS would only cost the block its co-residency

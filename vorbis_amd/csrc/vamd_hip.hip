@@ -346,6 +346,59 @@ __global__ __launch_bounds__(64) void k_tone_chase(int linesper, int nl, int nlp
   pc.flush();
 }
 
+// the same for a small batch: one WAVE per channel-block, the walk cut into one chunk per lane (chase_chunk, k_tone.h)
+// LDS: the block's seed lines [nlp], then the rings [VAMD_RING][64] x 2
+__global__ __launch_bounds__(64) void k_tone_chase_wave(int linesper, int nl, int nlp, DescP d,
+                                                        const float *__restrict__ seed_g,
+                                                        unsigned short *__restrict__ surv, int *__restrict__ nsurv) {
+  float *seed = (float *)vamd_smem;
+  float *ring_amp = seed + nlp;
+  int *ring_pos = (int *)(ring_amp + VAMD_RING * 64);
+  const long cb = blockIdx.x;
+  WAVE_FOR(q, nlp >> 2)((F4 *)seed)[q] = ((const F4 *)(seed_g + cb * nlp))[q];
+  WAVE_SYNC();
+  const int cs = (nl + 63) / 64;
+  const int s0 = LANE * cs < nl ? LANE * cs : nl, e0 = s0 + cs < nl ? s0 + cs : nl;
+  unsigned short *out = surv + cb * nlp;
+  bool accepted = false;
+  ChaseChunk r;
+  r.popped = r.sig_in = r.sig_out = 0;
+  r.exact = 1;
+  // a long run of equal values (a stretch no curve reached) would take a repair round per chunk: serial at once
+  unsigned long long fm = __ballot(s0 < nl && chase_flat_chunk(seed, s0, e0));
+  int longest = 0;
+  for (; fm && longest <= VAMD_CHASE_FLAT_MAX; longest++) fm &= fm << 1;
+  if (longest <= VAMD_CHASE_FLAT_MAX) {
+    if (s0 < nl) r = chase_chunk(seed, linesper, nl, s0, e0, 4 * linesper, 0, ring_amp, ring_pos, 64, LANE);
+    uint32_t used = r.sig_in;
+    for (int rd = 0; rd <= VAMD_CHASE_ROUNDS; rd++) {
+      const uint32_t prev_out = (uint32_t)wave_shift_up1((int)r.sig_out, 0);
+      const bool need = s0 < nl && !r.exact && used != prev_out;
+      if (!__any(need)) {
+        accepted = true;
+        break;
+      }
+      if (rd == VAMD_CHASE_ROUNDS) break;
+      if (need) {  // walked again, started exactly in the predecessor's exit state
+        const ChaseChunk t = chase_chunk(seed, linesper, nl, s0, e0, -1, prev_out, ring_amp, ring_pos, 64, LANE);
+        used = prev_out;
+        r.popped = t.popped;
+        r.sig_out = t.sig_out;
+      }
+    }
+  }
+  if (accepted) {
+    const uint32_t alive = ~r.popped & (e0 - s0 >= 32 ? ~0u : ((1u << (e0 - s0)) - 1u));
+    const int cnt = __builtin_popcount(alive);
+    const int incl = wave_scan_sum(cnt);
+    int at = incl - cnt;
+    for (uint32_t m = alive; m; m &= m - 1) out[at++] = (unsigned short)(s0 + __builtin_ctz(m));
+    if (LANE == 63) nsurv[cb] = incl;
+  } else if (LANE == 0) {
+    nsurv[cb] = tone_chase_thread(seed, linesper, nl, ring_amp, ring_pos, 64, 0, out);
+  }
+}
+
 __global__ __launch_bounds__(64) void k_tone_fold(PsyP P0, PsyP P1, DescP d, int ch, int nlp,
                                                   const float *__restrict__ seed_g,
                                                   const unsigned short *__restrict__ surv,
@@ -1264,9 +1317,16 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_
       else
         hipLaunchKernelGGL(k_tone_seed<0>, dim3(gcb), dim3(64), seed_lds, s, P0, P1, d, ch, nlp, p.logfft, p.local, p.ampglob,
                            p.seed);
-      hipLaunchKernelGGL(k_tone_chase, dim3((gcb + VAMD_CHASE_LANES - 1) / VAMD_CHASE_LANES), dim3(VAMD_CHASE_LANES),
-                         (size_t)VAMD_RING * VAMD_CHASE_LANES * 8, s,
-                         P0.eighth_octave_lines, nl, nlp, (long)gcb, d, p.seed, p.surv, p.nsurv);
+      // a lane per block for batches, a wave per block (the walk in 64 chunks) where that would leave the GPU to a
+      // handful of lanes walking ~800 lines each: the per-block entry points, the batcher's small batches
+      static const long wave_max_cb = getenv("VAMD_CHASE_WAVE_MAX") ? atol(getenv("VAMD_CHASE_WAVE_MAX")) : 32768;
+      if ((long)gcb <= wave_max_cb && P0.eighth_octave_lines <= 16 && nl <= 2048)
+        hipLaunchKernelGGL(k_tone_chase_wave, dim3(gcb), dim3(64), (size_t)nlp * 4 + (size_t)VAMD_RING * 64 * 8, s,
+                           P0.eighth_octave_lines, nl, nlp, d, p.seed, p.surv, p.nsurv);
+      else
+        hipLaunchKernelGGL(k_tone_chase, dim3((gcb + VAMD_CHASE_LANES - 1) / VAMD_CHASE_LANES), dim3(VAMD_CHASE_LANES),
+                           (size_t)VAMD_RING * VAMD_CHASE_LANES * 8, s,
+                           P0.eighth_octave_lines, nl, nlp, (long)gcb, d, p.seed, p.surv, p.nsurv);
       hipLaunchKernelGGL(k_tone_fold, dim3(gcb), dim3(64), (size_t)(nlp + (P0.ngroups > P1.ngroups ? P0.ngroups : P1.ngroups)) * 4, s, P0, P1, d, ch, nlp, p.seed, p.surv,
                          p.nsurv, p.local, p.tone);
     }
