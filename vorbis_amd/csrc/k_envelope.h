@@ -109,31 +109,44 @@ VAMD_DEV float env_band_amp(const EnvP &E, const float *__restrict__ raw /*[32] 
 // bit 2h = pre-echo (ret |= 1|4), bit 2h+1 = post-echo (ret |= 2), OR-ed over channels and bands.
 //   amp[c]  points at this step's [VAMD_VE_BANDS+1] amplitudes of channel c; earlier steps sit
 //           `amp_stride` floats lower each
+// one (channel, band): `a` points at the step's band amplitude, earlier steps amp_stride floats apart.  The twelve
+// history values are fetched before any is used (one trip to memory, not twelve).
+VAMD_DEV uint32_t env_trigger_bits_one(const EnvP &E, const float *__restrict__ a, long amp_stride, int b) {
+  uint32_t bits = 0;
+  const float acc = a[0], prev = a[-amp_stride];
+  float hist[VAMD_VE_MAXSTRETCH];
+#if VAMD_GPU
+#pragma unroll
+#endif
+  for (int i = 0; i < VAMD_VE_MAXSTRETCH; i++) hist[i] = a[-(2 + i) * amp_stride];
+  const float postmax = acc > prev ? acc : prev;
+  const float postmin = acc < prev ? acc : prev;
+  float premax = -99999.f, premin = 99999.f;
+#if VAMD_GPU
+#pragma unroll
+#endif
+  for (int i = 0; i < VAMD_VE_MAXSTRETCH; i++) {
+    const float v = hist[i];
+    premax = premax > v ? premax : v;
+    premin = premin < v ? premin : v;
+    const int w = i + 1;  // window length reached: the `stretch` of h = w (and of h = 0,1 when w == 2)
+    if (w < VAMD_VE_MINSTRETCH) continue;
+    const float valmin = postmin - premin, valmax = postmax - premax;
+    for (int h = (w == VAMD_VE_MINSTRETCH ? 0 : w); h <= w; h++) {
+      float penalty = E.stretch_penalty - (float)(h - VAMD_VE_MINSTRETCH);
+      if (penalty < 0.f) penalty = 0.f;
+      if (penalty > E.stretch_penalty) penalty = E.stretch_penalty;
+      if (valmax > E.preecho_thresh[b] + penalty) bits |= 1u << (2 * h);
+      if (valmin < E.postecho_thresh[b] - penalty) bits |= 2u << (2 * h);
+    }
+  }
+  return bits;
+}
+
 VAMD_DEV uint32_t env_trigger_bits(const EnvP &E, const float *const *amp, int ch, long amp_stride) {
   uint32_t bits = 0;
   for (int c = 0; c < ch; c++)
-    for (int b = 0; b < VAMD_VE_BANDS; b++) {
-      const float *a = amp[c] + b;
-      const float acc = a[0], prev = a[-amp_stride];
-      const float postmax = acc > prev ? acc : prev;
-      const float postmin = acc < prev ? acc : prev;
-      float premax = -99999.f, premin = 99999.f;
-      for (int i = 0; i < VAMD_VE_MAXSTRETCH; i++) {
-        const float v = a[-(2 + i) * amp_stride];
-        premax = premax > v ? premax : v;
-        premin = premin < v ? premin : v;
-        const int w = i + 1;  // window length reached: the `stretch` of h = w (and of h = 0,1 when w == 2)
-        if (w < VAMD_VE_MINSTRETCH) continue;
-        const float valmin = postmin - premin, valmax = postmax - premax;
-        for (int h = (w == VAMD_VE_MINSTRETCH ? 0 : w); h <= w; h++) {
-          float penalty = E.stretch_penalty - (float)(h - VAMD_VE_MINSTRETCH);
-          if (penalty < 0.f) penalty = 0.f;
-          if (penalty > E.stretch_penalty) penalty = E.stretch_penalty;
-          if (valmax > E.preecho_thresh[b] + penalty) bits |= 1u << (2 * h);
-          if (valmin < E.postecho_thresh[b] - penalty) bits |= 2u << (2 * h);
-        }
-      }
-    }
+    for (int b = 0; b < VAMD_VE_BANDS; b++) bits |= env_trigger_bits_one(E, amp[c] + b, amp_stride, b);
   return bits;
 }
 

@@ -278,6 +278,10 @@ VAMD_DEV ChaseChunk chase_chunk(const float *seeds, int linesper, int n, int s, 
 }
 
 #define VAMD_CHASE_CHUNKS 64  // chunks per block = lanes of the wave
+#ifndef VAMD_CHASE_WARM
+#define VAMD_CHASE_WARM 2    // cold start this many windows (linesper) before a chunk: one needs a repair round every time,
+                             // two in one block out of thirty, three or four never (measured on the host; 16 + 20 lines walked)
+#endif
 // what the chunks of one block add up to: accepted (every chunk entered in its predecessor's exit state)?
 // Host form, chunk after chunk (the GPU kernel runs chase_chunk one per lane and combines with wave operations).
 // Repair rounds before a block is handed to the serial walk.  A run of equal values (a stretch no curve reached)
@@ -304,7 +308,7 @@ VAMD_DEV int chase_chunks_host(const float *seeds, int linesper, int n, unsigned
   int nc = 0;
   for (int c = 0; c < VAMD_CHASE_CHUNKS && c * cs < n; c++, nc++) {
     const int s0 = c * cs, e0 = s0 + cs < n ? s0 + cs : n;
-    r[c] = chase_chunk(seeds, linesper, n, s0, e0, 4 * linesper, 0, ring_amp, ring_pos, 1, 0);
+    r[c] = chase_chunk(seeds, linesper, n, s0, e0, VAMD_CHASE_WARM * linesper, 0, ring_amp, ring_pos, 1, 0);
     used[c] = r[c].sig_in;
   }
   int ok = 0, rd = 0;
