@@ -693,6 +693,18 @@ __global__ void k_env_bits(EnvP E, int ch, long nstreams, long nsteps, const flo
   if (live && sub == 0) bits[t] = my;
 }
 
+// ... and a thread per (stream, step) for big batches, where threads are plentiful and sixteen of them fetching the
+// same histories only multiply the loads (0.86 against 0.70 ms for 2 M steps)
+__global__ void k_env_bits_batch(EnvP E, int ch, long nstreams, long nsteps, const float *__restrict__ amp,
+                                 uint32_t *__restrict__ bits) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nstreams * nsteps) return;
+  const long s = t / nsteps, j = t - s * nsteps;
+  const float *a[VAMD_MAX_CH];
+  for (int c = 0; c < ch; c++) a[c] = amp + ((s * ch + c) * (VAMD_VE_AMP_HIST + nsteps) + VAMD_VE_AMP_HIST + j) * 8;
+  bits[t] = env_trigger_bits(E, a, ch, 8);
+}
+
 // the stretch recurrence, one wave per stream; then the state's histories roll forward
 __global__ __launch_bounds__(64) void k_env_walk(int ch, long nstreams, long nsteps, const uint32_t *__restrict__ bits,
                                                  const float *__restrict__ near, const float *__restrict__ amp,
@@ -1831,8 +1843,12 @@ int vamd_envelope_search_batch(vamd_ctx *c, const float *pcm, long stream_stride
     hipLaunchKernelGGL(k_env_amp, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, E, nsc, nsteps, states, ch,
                        near, raw, amp);
   }
-  hipLaunchKernelGGL(k_env_bits, dim3((unsigned)((nstreams * nsteps * 16 + 255) / 256)), dim3(256), 0, s, E, ch, nstreams, nsteps,
-                     amp, bits);
+  if (nstreams * nsteps <= 65536)
+    hipLaunchKernelGGL(k_env_bits, dim3((unsigned)((nstreams * nsteps * 16 + 255) / 256)), dim3(256), 0, s, E, ch, nstreams, nsteps,
+                       amp, bits);
+  else
+    hipLaunchKernelGGL(k_env_bits_batch, dim3((unsigned)((nstreams * nsteps + 255) / 256)), dim3(256), 0, s, E, ch, nstreams,
+                       nsteps, amp, bits);
   hipLaunchKernelGGL(k_env_walk, dim3((unsigned)nstreams), dim3(64), 0, s, ch, nstreams, nsteps, bits, near, amp,
                      states, ret);
   HIP_TRY(c, hipGetLastError());
