@@ -23,6 +23,8 @@ def signals(rng, nb, ch, n):
     for k in range(nb):
         kind = k % 8
         amp = 10.0 ** rng.uniform(-4.5, 0)
+        if k % 64 == 63:
+            amp *= 8.0    # over full scale now and then: a spectral maximum above 0 dB is clamped (lib/mapping0.c:345)
         if kind == 0:
             x[k] = (rng.random((ch, n)) - 0.5) * 2 * amp
         elif kind == 1:   # a few sines, channels correlated

@@ -83,6 +83,8 @@ def test_random_blocks_vs_oracle(torch_mod, name):
         pcm[5::7, 1] = pcm[5::7, 0] * 0.5     # correlated channels
         pcm[3::11, 1] = 0                       # one silent channel: zero floor + coupling fix-up
     pcm[17] = 0                                 # digital silence
+    pcm[23::24] *= 12.0                         # far over full scale: local ampmax above 0 dB, clamped (lib/mapping0.c:345)
+    pcm[23::24] += (6.0 * np.sin(np.arange(2048) * 0.07)).astype(np.float32)[None, None, :]
     amp_in = np.where(np.arange(nb) % 3 == 0, -9999.0, -35.0).astype(np.float32)
     outs = an.analyze(torch.from_numpy(pcm).cuda(), W=1, ampmax_in=torch.from_numpy(amp_in).cuda(), want=ALL)
     torch.cuda.synchronize()

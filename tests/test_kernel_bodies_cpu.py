@@ -41,9 +41,11 @@ def test_bodies_match_oracle_random(name):
     em = Emul(blob_of(name))
     ch = checker.SETUPS[name][0]
     rng = np.random.default_rng(77)
-    for it in range(8):
-        amp = [0.5, 0.003, 1.0, 0.1][it % 4]
+    for it in range(10):
+        amp = [0.5, 0.003, 1.0, 0.1, 6.0][it % 5]
         pcm = ((rng.random((ch, 2048), dtype=np.float32) - 0.5) * 2 * amp).astype(np.float32)
+        if it % 5 == 4:   # a tone above full scale: the block's spectral maximum is over 0 dB and is clamped (lib/mapping0.c:345)
+            pcm += (amp * np.sin(np.arange(2048) * 0.05)).astype(np.float32)[None, :]
         a = chk.tap_block(pcm, ampmax_in=-9999.0 if it % 2 else -40.0)
         g = em.analyze_block(pcm, ampmax_in=-9999.0 if it % 2 else -40.0)
         assert checker.compare_block(a, g, em.L and 29, verbose=True) == 0

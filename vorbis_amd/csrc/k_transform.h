@@ -982,6 +982,7 @@ VAMD_DEV float transform_logfft(const XformP &P, const float *spec, float *__res
     if (logfft_out) ((F4 *)logfft_out)[q] = f4_make(v);
   }
   amp = wave_max(amp);
+  if (amp > 0.f) amp = 0.f;  // lib/mapping0.c:345 (the clamp commutes with the maximum over the team's waves)
   tm.sync();
   pc.mark(7);
   return amp;
