@@ -134,6 +134,15 @@ VAMD_DEV void seed_chase_paint(float *seeds, const float *__restrict__ src, int 
 VAMD_DEV int tone_chase_thread(const float *__restrict__ seeds, int linesper, int n, float *ring_amp, int *ring_pos,
                                int rstride, int rlane, unsigned short *__restrict__ surv) {
   int stack = 0, hmax = 0;  // hmax = highest stack index ever written
+  // survivors leave in index order, 0, 1, 2, ...: four at a time as one 8-byte store (a lane per block means every
+  // lane stores into a cache line of its own, and 2-byte stores tripled the stage's write traffic)
+  unsigned long long wbuf = 0;
+  int nw = 0;
+  auto emit = [&](int pos) {
+    wbuf = (wbuf >> 16) | ((unsigned long long)(unsigned)pos << 48);
+    nw++;
+    if ((nw & 3) == 0) *(unsigned long long *)(surv + nw - 4) = wbuf;
+  };
   float a1 = 0.f, a2 = 0.f;
   int p1 = 0, p2 = 0;
   const F4 *q = (const F4 *)seeds;
@@ -171,7 +180,7 @@ VAMD_DEV int tone_chase_thread(const float *__restrict__ seeds, int linesper, in
         if (stack == hmax) {
           // first write of this index: the entry one ring-length below is final, emit it
           // before its slot is reused (re-pushes of an index already seen emit nothing)
-          if (stack >= VAMD_RING) surv[stack - VAMD_RING] = (unsigned short)ring_pos[slot * rstride + rlane];
+          if (stack >= VAMD_RING) emit(ring_pos[slot * rstride + rlane]);
           hmax++;
         }
         ring_amp[slot * rstride + rlane] = s;
@@ -184,8 +193,8 @@ VAMD_DEV int tone_chase_thread(const float *__restrict__ seeds, int linesper, in
       }
     }
   }
-  for (int k = hmax > VAMD_RING ? hmax - VAMD_RING : 0; k < stack; k++)
-    surv[k] = (unsigned short)ring_pos[(k & (VAMD_RING - 1)) * rstride + rlane];
+  for (int k = hmax > VAMD_RING ? hmax - VAMD_RING : 0; k < stack; k++) emit(ring_pos[(k & (VAMD_RING - 1)) * rstride + rlane]);
+  for (int k = nw & ~3; k < nw; k++) surv[k] = (unsigned short)(wbuf >> (16 * (4 - (nw & 3) + (k & 3))));  // the last one to three
   return stack;
 }
 
