@@ -24,9 +24,9 @@ namespace vamd {
 
 #define VAMD_MAXPOSTS 32
 
-struct FitAcc {  // lsfit_acc, lib/floor1.c:32-49 (x0/x1 come from sorted_index)
-  int xa, ya, x2a, y2a, xya, an;
-  int xb, yb, x2b, y2b, xyb, bn;
+struct FitAcc {  // lsfit_acc, lib/floor1.c:32-49 (x0/x1 come from sorted_index; y2a/y2b, which the reference
+  int xa, ya, x2a, xya, an;  // sums and never reads, are not kept)
+  int xb, yb, x2b, xyb, bn;
 };
 
 // fit_line's per-interval contribution (lib/floor1.c:463-472): depends only on the
@@ -40,7 +40,7 @@ struct FitTerm {
 // maps, the floor's static index tables) is NOT here: it lives one entry per lane in
 // registers (LaneInts / LaneDoubles) and is read with v_readlane.
 struct FloorScratch {
-  FitAcc acc[VAMD_MAXPOSTS];  // 48 B each; later reused as [intervals][5] doubles (40 B each)
+  FitAcc acc[VAMD_MAXPOSTS];  // 40 B each; later reused as [intervals][5] doubles (40 B each)
   double pair_sums[16];
   int segx[VAMD_MAXPOSTS + 1], segy[VAMD_MAXPOSTS + 1];
   int nseg;
@@ -133,17 +133,59 @@ VAMD_DEV void mask_quantise_wave(const PsyP &P, int offset_select, const float *
   WAVE_SYNC();
 }
 
-// add a lane's private sums to an interval's accumulators and clear them
-VAMD_DEV void accumulate_flush(FitAcc *dst, FitAcc &t) {
+// One record of the fit work list (derive_fit_segments): the lane sums its chunk's share of one interval and adds
+// it to that interval's accumulators.  Returns the class-a count (accumulate_fit's return value, summed by the
+// caller).  The sums are taken relative to the chunk's first bin and packed several to a register -- for a bin at
+// offset c (0..15) holding q (0..1023, 0 = skipped by the reference):
+//   [q != 0] * (1 | c << 8 | c*c << 16)   -> count (<= 16), sum c (<= 120), sum c*c (<= 1240)
+//   q * (1 | c << 14)                     -> sum q (<= 16368 < 2^14), sum c*q (<= 122760 < 2^17)
+// once for all bins and once for class a (mdct + twofitatten >= mask, bit 15); class b is the difference.  With
+// i = base + c:  sum i = base*n + sum c,  sum i*i = base*base*n + 2*base*sum c + sum c*c,  sum i*q = base*sum q +
+// sum c*q -- integer identities, so the totals are the reference's (lib/floor1.c:416-436).
+VAMD_DEV int accumulate_segment(const unsigned int *rec, const unsigned short *qc, FitAcc *acc) {
+  const I4 h = ((const I4 *)rec)[0], m0 = ((const I4 *)rec)[1], m1 = ((const I4 *)rec)[2];
+  const int chunk = h.x;
+  const I4 qa = ((const I4 *)qc)[2 * chunk], qb = ((const I4 *)qc)[2 * chunk + 1];
+  const unsigned int w[8] = {(unsigned)(qa.x & m0.x), (unsigned)(qa.y & m0.y), (unsigned)(qa.z & m0.z),
+                             (unsigned)(qa.w & m0.w), (unsigned)(qb.x & m1.x), (unsigned)(qb.y & m1.y),
+                             (unsigned)(qb.z & m1.z), (unsigned)(qb.w & m1.w)};
+  unsigned int cnt_all = 0, qs_all = 0, cnt_a = 0, qs_a = 0;
+#if VAMD_GPU
+#pragma unroll
+#endif
+  for (int c = 0; c < 16; c++) {
+    const unsigned int hw = (w[c >> 1] >> (16 * (c & 1))) & 0xffffu;
+    const unsigned int q = hw & 0x7fffu, a01 = hw >> 15;
+    const unsigned int v01 = (q + 1023u) >> 10;  // q <= 1023: 1 where q != 0
+    const unsigned int kc = 1u | ((unsigned)c << 8) | ((unsigned)(c * c) << 16), lc = 1u | ((unsigned)c << 14);
+    cnt_all += v01 * kc;
+    qs_all += q * lc;
+    cnt_a += (v01 & a01) * kc;
+    qs_a += (q * a01) * lc;
+  }
+  const int base = chunk << 4, j = h.y;
+  FitAcc t;
+  {
+    const int n = (int)(cnt_a & 0xff), sc = (int)((cnt_a >> 8) & 0xff), sc2 = (int)(cnt_a >> 16);
+    const int sq = (int)(qs_a & 0x3fff), scq = (int)(qs_a >> 14);
+    t.an = n; t.xa = base * n + sc; t.x2a = base * base * n + 2 * base * sc + sc2; t.ya = sq; t.xya = base * sq + scq;
+  }
+  {
+    const int n = (int)(cnt_all & 0xff), sc = (int)((cnt_all >> 8) & 0xff), sc2 = (int)(cnt_all >> 16);
+    const int sq = (int)(qs_all & 0x3fff), scq = (int)(qs_all >> 14);
+    t.bn = n - t.an; t.xb = base * n + sc - t.xa; t.x2b = base * base * n + 2 * base * sc + sc2 - t.x2a;
+    t.yb = sq - t.ya; t.xyb = base * sq + scq - t.xya;
+  }
+  FitAcc *dst = acc + j;
   if (t.an) {
     lds_atomic_add(&dst->xa, t.xa); lds_atomic_add(&dst->ya, t.ya); lds_atomic_add(&dst->x2a, t.x2a);
-    lds_atomic_add(&dst->y2a, t.y2a); lds_atomic_add(&dst->xya, t.xya); lds_atomic_add(&dst->an, t.an);
+    lds_atomic_add(&dst->xya, t.xya); lds_atomic_add(&dst->an, t.an);
   }
   if (t.bn) {
     lds_atomic_add(&dst->xb, t.xb); lds_atomic_add(&dst->yb, t.yb); lds_atomic_add(&dst->x2b, t.x2b);
-    lds_atomic_add(&dst->y2b, t.y2b); lds_atomic_add(&dst->xyb, t.xyb); lds_atomic_add(&dst->bn, t.bn);
+    lds_atomic_add(&dst->xyb, t.xyb); lds_atomic_add(&dst->bn, t.bn);
   }
-  t.xa = t.ya = t.x2a = t.y2a = t.xya = t.an = t.xb = t.yb = t.x2b = t.y2b = t.xyb = t.bn = 0;
+  return t.an;
 }
 
 // fit_line, lib/floor1.c:456-514.  a[0..fits) are consecutive intervals whose
@@ -335,67 +377,12 @@ VAMD_DEV int floor_fit_posts(const FloorP &F, const unsigned short *qc, FloorScr
   hin.fill(1);
   memo.fill(-1);
   outp.fill(0);
-  WAVE_FOR(i, (posts - 1) * 12)((int *)sc->acc)[i] = 0;
+  WAVE_FOR(i, (posts - 1) * 10)((int *)sc->acc)[i] = 0;
   WAVE_SYNC();
-  // accumulate_fit for all post intervals at once: every lane takes quads of bins, sums
-  // them privately and adds the six integer sums of each class to the owning interval
-  // (integer adds commute, so the totals equal the reference's sequential sums)
+  // accumulate_fit for all post intervals at once, a lane per record of the floor's work list (integer adds
+  // commute, so the totals equal the reference's sequential sums)
   int nz = 0;
-  // each lane owns 16 consecutive bins (4 quads), so it rarely crosses an interval
-  WAVE_FOR(span, (n + 15) >> 4) {
-    int jprev = -1;
-    FitAcc t;
-    t.xa = t.ya = t.x2a = t.y2a = t.xya = t.an = t.xb = t.yb = t.x2b = t.y2b = t.xyb = t.bn = 0;
-    // the 16 bins' interval bytes arrive in one 16-byte load, their quantised-mask words in two
-    const I4 jw = ((const I4 *)F.bin_interval)[span];
-    const unsigned int jq4[4] = {(unsigned)jw.x, (unsigned)jw.y, (unsigned)jw.z, (unsigned)jw.w};
-    const I4 qa = ((const I4 *)qc)[2 * span], qb = ((const I4 *)qc)[2 * span + 1];
-    const unsigned int qw[8] = {(unsigned)qa.x, (unsigned)qa.y, (unsigned)qa.z, (unsigned)qa.w,
-                                (unsigned)qb.x, (unsigned)qb.y, (unsigned)qb.z, (unsigned)qb.w};
-#if VAMD_GPU
-#pragma unroll
-#endif
-    for (int u = 0; u < 4; u++) {
-      const int qd = (span << 2) + u;
-      if ((qd << 2) >= n) break;
-      const int i0 = qd << 2;
-      const unsigned int jq = jq4[u];
-#if VAMD_GPU
-#pragma unroll
-#endif
-      for (int c = 0; c < 4; c++) {
-        const int i = i0 + c;
-        const int jb = (int)((jq >> (8 * c)) & 0xff);
-        const int j = (i < n && jb != 255) ? (jb & 0x7f) : 255;
-        const bool shared = jb != 255 && (jb & 0x80);
-        const unsigned int qv = (qw[2 * u + (c >> 1)] >> (16 * (c & 1))) & 0xffffu;
-        const int q = j != 255 ? (int)(qv & 0x7fffu) : 0;
-        if (j != jprev) {
-          if (jprev >= 0) accumulate_flush(&sc->acc[jprev], t);
-          jprev = j == 255 ? -1 : j;
-        }
-        if (q) {
-          FitAcc b;
-          b.xa = b.ya = b.x2a = b.y2a = b.xya = b.an = b.xb = b.yb = b.x2b = b.y2b = b.xyb = b.bn = 0;
-          const bool cls_a = (qv & 0x8000u) != 0;
-          if (cls_a) {
-            b.xa = i; b.ya = q; b.x2a = i * i; b.y2a = q * q; b.xya = i * q; b.an = 1;
-          } else {
-            b.xb = i; b.yb = q; b.x2b = i * i; b.y2b = q * q; b.xyb = i * q; b.bn = 1;
-          }
-          t.xa += b.xa; t.ya += b.ya; t.x2a += b.x2a; t.y2a += b.y2a; t.xya += b.xya; t.an += b.an;
-          t.xb += b.xb; t.yb += b.yb; t.x2b += b.x2b; t.y2b += b.y2b; t.xyb += b.xyb; t.bn += b.bn;
-          nz += b.an;
-          // a bin exactly on an interior post closes the previous interval too
-          if (shared) {
-            accumulate_flush(&sc->acc[j - 1], b);
-            nz += b.an;
-          }
-        }
-      }
-    }
-    if (jprev >= 0) accumulate_flush(&sc->acc[jprev], t);
-  }
+  WAVE_FOR(sg, F.fit_nseg) nz += accumulate_segment(F.fit_segs + VAMD_FITSEG_WORDS * sg, qc, sc->acc);
   nz = wave_sum(nz);
   WAVE_SYNC();
 #if !VAMD_GPU

@@ -361,6 +361,16 @@ inline int build_image(const void *blob_v, size_t bytes, std::vector<unsigned ch
       const unsigned char *a = (const unsigned char *)lv.data();
       image->insert(image->end(), a, a + 4 * lv.size());
     }
+  for (int W = 0; W < 2; W++)
+    for (int sm = 0; sm < VAMD_MAX_SUBMAPS; sm++) {  // slots 32 + 2W + sm: accumulate_fit work list
+      int ns = 0;
+      std::vector<uint32_t> sg =
+          derive_fit_segments(h.mode[W].floor[sm < h.mode[W].submaps ? sm : 0], h.blocksizes[W] / 2, &ns);
+      while (image->size() & 15) image->push_back(0);
+      derived_off->push_back((uint32_t)image->size());
+      const unsigned char *a = (const unsigned char *)sg.data();
+      image->insert(image->end(), a, a + 4 * sg.size());
+    }
   while (image->size() & 15) image->push_back(0);
   return VAMD_OK;
 }
@@ -451,6 +461,8 @@ inline void bind_params(const std::vector<unsigned char> &image, const std::vect
       int nl = 0;
       derive_post_levels(f, &nl);
       F.nlevels = nl;
+      F.fit_segs = (const unsigned int *)(base + derived_off[32 + 2 * W + src]);
+      derive_fit_segments(f, h.blocksizes[W] / 2, &F.fit_nseg);
     }
 
     CoupleP &C = B->couple[W];

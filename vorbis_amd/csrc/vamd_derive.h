@@ -8,6 +8,7 @@
 #include <string.h>
 #include <vector>
 #include "vamd_setup.h"
+#include "vamd_params.h"
 
 namespace vamd {
 
@@ -154,6 +155,30 @@ inline std::vector<unsigned char> derive_bin_interval(const vamd_floor1_tab &f, 
     int x0 = f.sorted_index[j], x1 = f.sorted_index[j + 1];
     if (x1 >= f.look_n) x1 = f.look_n - 1;
     for (int i = x0; i <= x1 && i < n2; i++) t[i] = (unsigned char)(j | ((j > 0 && i == x0) ? 0x80 : 0));
+  }
+  return t;
+}
+
+// The same ranges as a work list for a wave: interval j's bins cut at the 16-bin chunks of the quantised mask
+// (one 32-byte LDS read), so that a lane sums one chunk's share of ONE interval and adds it to that interval once.
+// A bin on an interior post sits in two records, as it sits in two of the reference's calls.  Record = 12 words:
+// [0] chunk, [1] interval, [2..3] 0, [4..11] keep-masks for the chunk's eight words (two 16-bit bins each).
+inline std::vector<uint32_t> derive_fit_segments(const vamd_floor1_tab &f, int n2, int *nseg) {
+  std::vector<uint32_t> t;
+  *nseg = 0;
+  for (int j = 0; j + 1 < f.posts; j++) {
+    int x0 = f.sorted_index[j], x1 = f.sorted_index[j + 1];
+    if (x1 >= f.look_n) x1 = f.look_n - 1;
+    if (x1 >= n2) x1 = n2 - 1;
+    for (int c = x0 >> 4; x0 <= x1 && c <= (x1 >> 4); c++) {
+      uint32_t r[VAMD_FITSEG_WORDS] = {(uint32_t)c, (uint32_t)j};
+      for (int b = 0; b < 16; b++) {
+        const int i = 16 * c + b;
+        if (i >= x0 && i <= x1) r[4 + (b >> 1)] |= 0xffffu << (16 * (b & 1));
+      }
+      t.insert(t.end(), r, r + VAMD_FITSEG_WORDS);
+      (*nseg)++;
+    }
   }
   return t;
 }

@@ -106,6 +106,8 @@ struct ChMap {
   unsigned char sub[VAMD_MAX_CH];
 };
 
+#define VAMD_FITSEG_WORDS 12  // one record of FloorP::fit_segs
+
 struct FloorP {
   int posts, look_n, quant_q, mult;
   float maxover, maxunder, maxerr, twofitweight, twofitatten;
@@ -113,6 +115,8 @@ struct FloorP {
   const unsigned char *bin_interval;  // [n2] derived: accumulate_fit interval of each bin (255 = none)
   const int *level;                   // [64] derived: dependency level of each post
   int nlevels;
+  const unsigned int *fit_segs;       // [fit_nseg][12] derived: accumulate_fit work list (derive_fit_segments)
+  int fit_nseg;
   // inspect_error's tests (lib/floor1.c:516-565) with the float work done once, at vamd_create (floor_derive_tests):
   int cnt_over, cnt_under;  // maxover^2 / n > maxerr holds exactly for the point counts n <= cnt_over (same for under)
   int int_tests;            // maxover / maxunder are multiples of 2^-13 below 1024: "y + maxover < val" is exact in
