@@ -343,6 +343,24 @@ int emul_plan_stream(void *h, const unsigned char *flags, long nsteps, long nsam
 }
 
 extern "C" {
+// div_magic() (the kernels' one-multiply floor division) against C's "/" over the domain the floor's line walks
+// use it on: every divisor den <= VAMD_DIV_MAGIC_MAX, every |dy| <= 1023, the steps k next to the ends and strided
+// through the middle.  Returns the number of disagreements.
+long emul_div_magic_check(void) {
+  const std::vector<uint32_t> m = derive_div_magic();
+  long bad = 0;
+  for (int den = 1; den <= VAMD_DIV_MAGIC_MAX; den++)
+    for (int ady = 0; ady <= 1023; ady++) {
+      const int ks[] = {0, 1, den / 3, den / 2, den - 2, den - 1};
+      for (int k : ks)
+        if (k >= 0 && k < den && div_magic(k * ady, m[den]) != (k * ady) / den) bad++;
+      if ((ady & 63) == 63 || ady == 1)
+        for (int k = 0; k < den; k += 7)
+          if (div_magic(k * ady, m[den]) != (k * ady) / den) bad++;
+    }
+  return bad;
+}
+
 // seed_chase part 1 two ways over the same seed lines: the serial walk (tone_chase_thread) and the chunked one
 // (chase_chunks_host); returns 1 if the survivor lists agree, and through *accepted whether the chunks verified.
 int emul_chase_compare(const float *seeds, int linesper, int n, int *accepted, int *nsurv_out, int *rounds) {

@@ -166,6 +166,11 @@ class Emul:
                                     maxblocks, kind.ctypes.data_as(C.c_void_p), begin.ctypes.data_as(C.c_void_p))
         return kind[:n], begin[:n]
 
+    def div_magic_mismatches(self):
+        """div_magic() against integer division over the floor line walks' domain (emul_div_magic_check)."""
+        self.L.emul_div_magic_check.restype = C.c_long
+        return int(self.L.emul_div_magic_check())
+
     def chase_compare(self, seeds, linesper):
         """seed_chase's stack walk serially and in 64 verified chunks (k_tone.h chase_chunk) over the same seed
         lines: (lists agree, chunks accepted, survivors, repair rounds)."""

@@ -51,6 +51,12 @@ def test_bodies_match_oracle_random(name):
         assert checker.compare_block(a, g, em.L and 29, verbose=True) == 0
 
 
+def test_div_magic_is_exact_on_the_floor_lines_domain():
+    """k_floor's line walks divide by x1 - x0 with one multiply (vamd_wave.h div_magic, table derive_div_magic)."""
+    em = Emul(np.fromfile(os.path.join(checker.ROOT, "vorbis_amd", "data", "setup_44k_stereo_q4.bin"), dtype=np.uint8))
+    assert em.div_magic_mismatches() == 0
+
+
 def test_chunked_chase_equals_serial_walk():
     """k_tone_chase_wave's algorithm on the host: the stack walk of seed_chase (lib/psy.c:454-487) cut into 64 chunks
     with cold starts, entry/exit state verification and repair rounds gives the serial walk's survivor list on every

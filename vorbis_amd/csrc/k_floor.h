@@ -285,45 +285,60 @@ VAMD_DEV void fit_line_pair(const double *term, double *sums, int firstL, int fi
 }
 #endif
 
-struct LineStep {  // Bresenham constants shared by inspect_error / render_line0
-  int base, sgn, ady, adx;
-  float rcp;  // 1/adx for div_small()
+// The line walk of inspect_error / render_line0 (lib/floor1.c:516-527,923-946) in closed form.  The reference steps
+// y by base = dy / adx and by one more whenever the running remainder of ady' = |dy| - |base| * adx overflows adx:
+// after k steps y = y0 + k * base + sgn * floor(k * ady' / adx) = y0 + sgn * floor(k * |dy| / adx), since
+// k * |base| is whole and |dy| = |base| * adx + ady'.
+struct LineStep {
+  int ady, sgn;        // |dy|, sign of dy
+  unsigned int magic;  // div_magic()'s multiplier for adx
 };
-VAMD_DEV LineStep line_step(int x0, int x1, int y0, int y1) {
+VAMD_DEV LineStep line_step(int x0, int x1, int y0, int y1, const unsigned int *magic) {
   LineStep s;
   const int dy = y1 - y0;
-  s.adx = x1 - x0;
-  int ady = dy < 0 ? -dy : dy;
-  s.rcp = div_rcp_fast(s.adx);  // (quotients here are line heights and offsets: < 2^11)
-  const int ab = div_small(ady, s.adx, s.rcp);  // |dy| / adx; C's dy/adx truncates toward zero
-  s.base = dy < 0 ? -ab : ab;
-  s.sgn = dy < 0 ? -1 : 1;  // sy - base
-  s.ady = ady - ab * s.adx;
+  s.ady = dy < 0 ? -dy : dy;
+  s.sgn = dy < 0 ? -1 : 1;
+  s.magic = magic[x1 - x0];
   return s;
 }
-VAMD_DEV int line_y(const LineStep &s, int y0, int k) {
-  return y0 + k * s.base + s.sgn * div_small(k * s.ady, s.adx, s.rcp);
-}
+VAMD_DEV int line_y(const LineStep &s, int y0, int k) { return y0 + s.sgn * div_magic(mad24(k, s.ady, 0), s.magic); }
 
 // inspect_error, lib/floor1.c:516-565, wave-parallel over x in [x0, x1)
 VAMD_DEV int inspect_error_wave(int x0, int x1, int y0, int y1, const unsigned short *qc, const FloorP &F) {
-  const LineStep s = line_step(x0, x1, y0, y1);
+  const LineStep s = line_step(x0, x1, y0, y1, F.div_magic);
   const int cnt = (x1 - x0) > 1 ? (x1 - x0) : 1;  // points visited: x0, then x0+1 .. x1-1
-  int mse = 0, bad = 0;
-  WAVE_FOR(k, cnt) {
-    const int x = x0 + k;
-    const int y = line_y(s, y0, k);
-    const int qv = qc[x];
-    const int val = qv & 0x7fff;
-    mse += (y - val) * (y - val);
-    if (qv & 0x8000) {  // mdct[x] + twofitatten >= mask[x]
-      if (k == 0 || val) {  // the first point is checked even when val == 0 (lib/floor1.c:536-539)
-        if (F.int_tests) {  // the same two tests in integers (floor_derive_tests)
-          if (val - y >= F.over_i || y - val >= F.under_i) bad = 1;
-        } else {
-          if ((float)y + F.maxover < (float)val) bad = 1;
-          if ((float)y - F.maxunder > (float)val) bad = 1;
-        }
+  int mse = 0;
+  bool bad = false;
+  if (F.int_tests) {
+    // The two tests in integers (floor_derive_tests), as one range check on d = val - y: the point is bad when d is
+    // outside (-under_i, over_i).  They apply to a point of class a (bit 15 of qc: mdct + twofitatten >= mask) that
+    // is non-zero, and to the first point even when it is zero (lib/floor1.c:536-539): "qc > 0x8000", with bit 0
+    // forced for the first point.
+    const int bias = F.under_i - 1;
+    const unsigned int span = (unsigned int)(F.over_i + F.under_i - 1);
+    unsigned int first = LANE == 0 ? 1u : 0u;
+    int nsgn = -s.sgn;
+#if VAMD_GPU
+    asm volatile("" : "+s"(nsgn));  // (kept opaque: a known +-1 turns the multiply-add into negate + select)
+#endif
+    for (int k = LANE; k < cnt; k += NLANES) {
+      const int q = div_magic(mad24(k, s.ady, 0), s.magic);
+      const unsigned int qv = qc[x0 + k];
+      const int d = mad24(q, nsgn, (int)(qv & 0x7fffu) - y0);  // val - y
+      mse = mad24(d, d, mse);
+      bad = bad || (((qv | first) > 0x8000u) && ((unsigned int)(d + bias) >= span));
+      first = 0;
+    }
+  } else {
+    WAVE_FOR(k, cnt) {
+      const int x = x0 + k;
+      const int y = line_y(s, y0, k);
+      const int qv = qc[x];
+      const int val = qv & 0x7fff;
+      mse += (y - val) * (y - val);
+      if ((qv & 0x8000) && (k == 0 || val)) {
+        if ((float)y + F.maxover < (float)val) bad = true;
+        if ((float)y - F.maxunder > (float)val) bad = true;
       }
     }
   }
@@ -347,12 +362,12 @@ VAMD_DEV int post_Y(const LaneInts &A, const LaneInts &B, int pos) {
 }
 
 // render_point, lib/floor1.c:257-271
-VAMD_DEV int render_point(int x0, int x1, int y0, int y1, int x) {
+VAMD_DEV int render_point(int x0, int x1, int y0, int y1, int x, const unsigned int *magic) {
   y0 &= 0x7fff;
   y1 &= 0x7fff;
   const int dy = y1 - y0, adx = x1 - x0;
   const int ady = dy < 0 ? -dy : dy;
-  const int off = div_small(ady * (x - x0), adx, div_rcp_fast(adx));
+  const int off = div_magic(mad24(ady, x - x0, 0), magic[adx]);
   return dy < 0 ? y0 - off : y0 + off;
 }
 
@@ -508,7 +523,7 @@ VAMD_DEV int floor_fit_posts(const FloorP &F, const unsigned short *qc, FloorScr
       const int ln = lo2.at(i), hn = hi2.at(i);
       const int x0 = postlist.gather(ln), x1 = postlist.gather(hn), y0 = outp.gather(ln), y1 = outp.gather(hn);
       if (i >= 2 && level.at(i) == L) {
-        const int predicted = render_point(x0, x1, y0, y1, postlist.at(i));
+        const int predicted = render_point(x0, x1, y0, y1, postlist.at(i), F.div_magic);
         const int a = fitA.at(i), b = fitB.at(i);
         const int vx = a < 0 ? b : (b < 0 ? a : (a + b) >> 1);
         outp.put(i, (vx >= 0 && predicted != vx) ? vx : (predicted | 0x8000));
@@ -553,7 +568,7 @@ VAMD_DEV void floor_quantise_predict(const FloorP &F, const LaneInts &outp, cons
       const int x0 = postlist.gather(ln), x1 = postlist.gather(hn), y0 = post.gather(ln), y1 = post.gather(hn);
       if (i >= 2 && level.at(i) == L) {
         const int pi = post.at(i);
-        const int predicted = render_point(x0, x1, y0, y1, postlist.at(i));
+        const int predicted = render_point(x0, x1, y0, y1, postlist.at(i), F.div_magic);
         if ((pi & 0x8000) || predicted == pi) {
           post.put(i, predicted | 0x8000);
         } else {
@@ -632,10 +647,9 @@ VAMD_DEV int floor_encode_render(const FloorP &F, int n2, const LaneInts &outp, 
   // the last used post gets a flat row (the curve is held beyond it, :941-943).  The rows overlay the fit's
   // accumulators, which are dead by now.
   struct SegRow {
-    int x0, y0, base, sgn;
-    int ady, adx;
-    float rcp;
-    int pad;
+    int x0, y0, ady, sgn;
+    unsigned int magic;
+    int pad[3];
   };
   SegRow *rows = (SegRow *)sc->acc;
   {
@@ -644,10 +658,10 @@ VAMD_DEV int floor_encode_render(const FloorP &F, int n2, const LaneInts &outp, 
       SegRow r;
       r.x0 = sc->segx[LANE];
       r.y0 = sc->segy[LANE];
-      r.base = 0, r.sgn = 1, r.ady = 0, r.adx = 1, r.rcp = 1.f, r.pad = 0;
+      r.ady = 0, r.sgn = 1, r.magic = 0, r.pad[0] = r.pad[1] = r.pad[2] = 0;
       if (LANE < ns) {
-        const LineStep st = line_step(r.x0, sc->segx[LANE + 1], r.y0, sc->segy[LANE + 1]);
-        r.base = st.base, r.sgn = st.sgn, r.ady = st.ady, r.adx = st.adx, r.rcp = st.rcp;
+        const LineStep st = line_step(r.x0, sc->segx[LANE + 1], r.y0, sc->segy[LANE + 1], F.div_magic);
+        r.ady = st.ady, r.sgn = st.sgn, r.magic = st.magic;
       }
       rows[LANE] = r;
     }
@@ -665,7 +679,7 @@ VAMD_DEV int floor_encode_render(const FloorP &F, int n2, const LaneInts &outp, 
         const int sgm = __builtin_popcountll(um & ((2ull << j) - 1ull)) - 1;
         const SegRow r = rows[sgm];
         const int k = 4 * q + c - r.x0;
-        v[c] = r.y0 + k * r.base + r.sgn * div_small(k * r.ady, r.adx, r.rcp);
+        v[c] = mad24(div_magic(mad24(k, r.ady, 0), r.magic), r.sgn, r.y0);
       }
       I2 o;
       o.x = v[0] | (v[1] << 16), o.y = v[2] | (v[3] << 16);
@@ -700,7 +714,7 @@ VAMD_DEV int floor_encode_render(const FloorP &F, int n2, const LaneInts &outp, 
       } else {
         int s = 0;
         while (x >= sc->segx[s + 1]) s++;
-        const LineStep st = line_step(sc->segx[s], sc->segx[s + 1], sc->segy[s], sc->segy[s + 1]);
+        const LineStep st = line_step(sc->segx[s], sc->segx[s + 1], sc->segy[s], sc->segy[s + 1], F.div_magic);
         v = line_y(st, sc->segy[s], x - sc->segx[s]);
       }
       ilogmask[x] = (ilog_t)v;

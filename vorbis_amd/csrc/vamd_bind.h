@@ -371,6 +371,13 @@ inline int build_image(const void *blob_v, size_t bytes, std::vector<unsigned ch
       const unsigned char *a = (const unsigned char *)sg.data();
       image->insert(image->end(), a, a + 4 * sg.size());
     }
+  {  // slot 36: div_magic's multipliers
+    std::vector<uint32_t> mg = derive_div_magic();
+    while (image->size() & 15) image->push_back(0);
+    derived_off->push_back((uint32_t)image->size());
+    const unsigned char *a = (const unsigned char *)mg.data();
+    image->insert(image->end(), a, a + 4 * mg.size());
+  }
   while (image->size() & 15) image->push_back(0);
   return VAMD_OK;
 }
@@ -388,7 +395,7 @@ inline void floor_derive_tests(FloorP *F) {
     if (F->maxunder * F->maxunder / (float)n > F->maxerr) F->cnt_under = n;
   }
   auto nice = [](float v) { return fabsf(v) < 1024.f && v * 8192.f == floorf(v * 8192.f); };
-  F->int_tests = nice(F->maxover) && nice(F->maxunder);
+  F->int_tests = nice(F->maxover) && nice(F->maxunder) && F->maxover >= 0.f && F->maxunder >= 0.f;
   F->over_i = F->int_tests ? (int)floorf(F->maxover) + 1 : 0;
   F->under_i = F->int_tests ? (int)floorf(F->maxunder) + 1 : 0;
 }
@@ -463,6 +470,7 @@ inline void bind_params(const std::vector<unsigned char> &image, const std::vect
       F.nlevels = nl;
       F.fit_segs = (const unsigned int *)(base + derived_off[32 + 2 * W + src]);
       derive_fit_segments(f, h.blocksizes[W] / 2, &F.fit_nseg);
+      F.div_magic = (const unsigned int *)(base + derived_off[36]);
     }
 
     CoupleP &C = B->couple[W];

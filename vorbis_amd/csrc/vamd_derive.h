@@ -183,6 +183,13 @@ inline std::vector<uint32_t> derive_fit_segments(const vamd_floor1_tab &f, int n
   return t;
 }
 
+// div_magic()'s multipliers: ceil(2^32 / den) for den = 2 .. VAMD_DIV_MAGIC_MAX ([0] and [1] only ever meet num == 0)
+inline std::vector<uint32_t> derive_div_magic() {
+  std::vector<uint32_t> t(VAMD_DIV_MAGIC_MAX + 1, 0xffffffffu);
+  for (uint64_t d = 2; d <= VAMD_DIV_MAGIC_MAX; d++) t[d] = (uint32_t)(((1ull << 32) + d - 1) / d);
+  return t;
+}
+
 // floor1_fit / floor1_encode settle the posts in list order, each from its two neighbours
 // (lib/floor1.c:708-724,790-831).  The neighbours are fixed by the look, so posts can be
 // settled level by level: level[i] = 1 + max(level[lo], level[hi]), posts 0 and 1 at level 0.

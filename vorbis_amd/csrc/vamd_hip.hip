@@ -438,6 +438,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   FloorScratch *sc = (FloorScratch *)(qc + ((n2 + 15) & ~15));
   PhaseClock pc;
   pc.start(d.dbg ? d.dbg + 48 : nullptr);
+#ifdef VAMD_STOP_AFTER
+  pc.stoppable = true;
+#endif
   offset_and_mix_wave(P, noise + cb * n2, tone + cb * n2, mdct_raw + cb * n2, mdct + cb * n2,
                       logmask_out ? logmask_out + cb * n2 : nullptr, qc, F.twofitatten, pc);
   const int nzf = floor_fit_render_block(F, n2, qc, sc, posts + cb * VAMD_POSTS_STRIDE, post_valid + cb,

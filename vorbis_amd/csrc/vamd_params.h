@@ -107,6 +107,7 @@ struct ChMap {
 };
 
 #define VAMD_FITSEG_WORDS 12  // one record of FloorP::fit_segs
+#define VAMD_DIV_MAGIC_MAX 2048  // the longest line of a floor: half the largest block (blocksizes <= 4096)
 
 struct FloorP {
   int posts, look_n, quant_q, mult;
@@ -117,6 +118,7 @@ struct FloorP {
   int nlevels;
   const unsigned int *fit_segs;       // [fit_nseg][12] derived: accumulate_fit work list (derive_fit_segments)
   int fit_nseg;
+  const unsigned int *div_magic;      // [VAMD_DIV_MAGIC_MAX + 1] derived: div_magic()'s multiplier per divisor
   // inspect_error's tests (lib/floor1.c:516-565) with the float work done once, at vamd_create (floor_derive_tests):
   int cnt_over, cnt_under;  // maxover^2 / n > maxerr holds exactly for the point counts n <= cnt_over (same for under)
   int int_tests;            // maxover / maxunder are multiples of 2^-13 below 1024: "y + maxover < val" is exact in

@@ -224,6 +224,7 @@ struct PhaseClock {
   unsigned long long *slots;
   long long t;
   unsigned int acc[8];
+  bool stoppable = false;
   VAMD_DEV void start(unsigned long long *s) {
     slots = s;
 #pragma unroll
@@ -231,6 +232,9 @@ struct PhaseClock {
     if (slots) t = clock64();
   }
   VAMD_DEV void mark(int k) {
+#ifdef VAMD_STOP_AFTER  // scratch builds for counting a stage's instructions phase by phase (tools/floor_phases_pmc.sh)
+    if (stoppable && k == VAMD_STOP_AFTER) __builtin_amdgcn_endpgm();
+#endif
     if (slots) {
       const long long now = clock64();
       acc[k & 7] += (unsigned int)(now - t);
@@ -341,6 +345,26 @@ VAMD_DEV float div_rcp_fast(int den) {
   return __builtin_amdgcn_rcpf((float)den);
 #else
   return 1.0f / (float)den;
+#endif
+}
+// products of operands that fit 24 signed bits (bin indices, line heights, their small quotients): one full-rate
+// instruction on the GPU, the plain product on the host
+VAMD_DEV int mad24(int a, int b, int c) {
+#if VAMD_GPU
+  return __mul24(a, b) + c;
+#else
+  return a * b + c;
+#endif
+}
+// floor(num / den) in one multiply for the line walks of floor 1, where den = x1 - x0 <= 2048 and
+// num = k * |dy| with k < den and |dy| <= 1023: magic = ceil(2^32 / den) (derive_div_magic, den >= 2) makes
+// (num * magic) >> 32 exact while num * (magic * den - 2^32) < 2^32, i.e. for num * (den - 1) < 2^32 -- here
+// num * den < 2047 * 1023 * 2048 < 2^32.  den == 1 only ever divides num == 0 (k < den).
+VAMD_DEV int div_magic(int num, unsigned int magic) {
+#if VAMD_GPU
+  return (int)__umulhi((unsigned int)num, magic);
+#else
+  return (int)(((unsigned long long)(unsigned int)num * magic) >> 32);
 #endif
 }
 VAMD_DEV int div_small(int num, int den, float rcp) {
