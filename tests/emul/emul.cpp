@@ -361,6 +361,41 @@ long emul_div_magic_check(void) {
   return bad;
 }
 
+// quant_energy() (two fused multiply-adds around a float square root) against the fp64 expression of the reference
+// (quant_energy_f64), on the values where they could part: the boundaries (k + 1/2)^2 and their float neighbours,
+// the squares, and a sweep of random floats.  Returns the number of disagreements.
+long emul_quant_energy_check(void) {
+  long bad = 0;
+  auto probe = [&](float ve) {
+    if (!(ve >= 0.f)) return;
+    if (quant_energy(ve, 1.f) != quant_energy_f64(ve, 1.f)) bad++;
+    if (quant_energy(ve, -1.f) != quant_energy_f64(ve, -1.f)) bad++;
+    if (ve < 1.7e13f) {  // the GPU's square root may be one ulp off: a candidate one beside the answer must do too
+      const int k = quant_energy_f64(ve, 1.f);
+      if (quant_energy_from(ve, 1.f, (float)(k + 1)) != k) bad++;
+      if (k > 0 && quant_energy_from(ve, 1.f, (float)(k - 1)) != k) bad++;
+    }
+  };
+  auto around = [&](double x) {
+    float f = (float)x;
+    for (int s = 0; s < 4; s++) f = nextafterf(f, 0.f);
+    for (int s = 0; s < 9; s++, f = nextafterf(f, INFINITY)) probe(f);
+  };
+  for (long k = 0; k < 6000000; k += (k < 70000 ? 1 : 997)) {
+    around(((double)k + .5) * ((double)k + .5));
+    around((double)k * (double)k);
+  }
+  uint32_t x = 12345u;
+  for (int i = 0; i < 4000000; i++) {
+    x = x * 1664525u + 1013904223u;
+    uint32_t bits = (x >> 1) % 0x5f000000u;  // non-negative floats up to ~9e18
+    float f;
+    memcpy(&f, &bits, 4);
+    probe(f);
+  }
+  return bad;
+}
+
 // seed_chase part 1 two ways over the same seed lines: the serial walk (tone_chase_thread) and the chunked one
 // (chase_chunks_host); returns 1 if the survivor lists agree, and through *accepted whether the chunks verified.
 int emul_chase_compare(const float *seeds, int linesper, int n, int *accepted, int *nsurv_out, int *rounds) {

@@ -171,6 +171,11 @@ class Emul:
         self.L.emul_div_magic_check.restype = C.c_long
         return int(self.L.emul_div_magic_check())
 
+    def quant_energy_mismatches(self):
+        """quant_energy() against the reference's fp64 expression (emul_quant_energy_check)."""
+        self.L.emul_quant_energy_check.restype = C.c_long
+        return int(self.L.emul_quant_energy_check())
+
     def chase_compare(self, seeds, linesper):
         """seed_chase's stack walk serially and in 64 verified chunks (k_tone.h chase_chunk) over the same seed
         lines: (lists agree, chunks accepted, survivors, repair rounds)."""

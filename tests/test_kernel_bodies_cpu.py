@@ -57,6 +57,12 @@ def test_div_magic_is_exact_on_the_floor_lines_domain():
     assert em.div_magic_mismatches() == 0
 
 
+def test_quant_energy_equals_the_fp64_expression():
+    """k_couple's +-rint(sqrt(ve)) without fp64 (k_couple.h quant_energy) against lib/psy.c:958-962 as written."""
+    em = Emul(np.fromfile(os.path.join(checker.ROOT, "vorbis_amd", "data", "setup_44k_stereo_q4.bin"), dtype=np.uint8))
+    assert em.quant_energy_mismatches() == 0
+
+
 def test_chunked_chase_equals_serial_walk():
     """k_tone_chase_wave's algorithm on the host: the stack walk of seed_chase (lib/psy.c:454-487) cut into 64 chunks
     with cold starts, entry/exit state verification and repair rounds gives the serial walk's survivor list on every

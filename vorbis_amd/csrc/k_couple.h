@@ -26,10 +26,34 @@ static const uint32_t g_floor1_db_bits[256] = {VAMD_FLOOR1_DB_TABLE_BITS};
 #endif
 VAMD_DEV float floor1_fromdB(int i) { return f_from_bits(g_floor1_db_bits[i & 255]); }
 
-// +-rint(sqrt(ve)) as the reference writes it (lib/psy.c:958-962): sqrt and rint in fp64
-VAMD_DEV int quant_energy(float ve, float r) {
+// +-rint(sqrt(ve)) as the reference writes it (lib/psy.c:958-962: sqrt and rint in fp64).  The answer is the integer
+// k with (k - 1/2)^2 <= ve <= (k + 1/2)^2, the even one where ve sits on a boundary; fp64 is only how the reference
+// gets there.  For k < 2^22 a single-precision square root lands within one of k, k +- 1/2 are exact floats, and
+// fma(h, h, -ve) has the sign of h*h - ve exactly (one rounding, and zero only for an exact zero), so two fused
+// multiply-adds settle the candidate; beyond that the fp64 route is kept.
+VAMD_DEV int quant_energy_f64(float ve, float r) {
   const double m = rint(sqrt((double)ve));
   return r < 0 ? (int)(-m) : (int)m;
+}
+// (kf: a whole number within one of the answer, below 2^22)
+VAMD_DEV int quant_energy_from(float ve, float r, float kf) {
+  const float hi = kf + 0.5f, lo = kf - 0.5f;
+  const float th = __builtin_fmaf(hi, hi, -ve), tl = __builtin_fmaf(lo, lo, -ve);
+  int k = (int)kf;
+  const bool odd = (k & 1) != 0;
+  if (th < 0.f || (th == 0.f && odd))
+    k++;
+  else if (k > 0 && (tl > 0.f || (tl == 0.f && odd)))
+    k--;
+  return r < 0 ? -k : k;
+}
+VAMD_DEV int quant_energy(float ve, float r) {
+  if (!(ve < 1.7e13f)) return quant_energy_f64(ve, r);  // k >= 2^22, or not a number
+#if VAMD_GPU
+  return quant_energy_from(ve, r, __builtin_rintf(__builtin_amdgcn_sqrtf(ve)));  // v_sqrt_f32: within one ulp
+#else
+  return quant_energy_from(ve, r, rintf(sqrtf(ve)));
+#endif
 }
 
 struct CoupleLds {
@@ -151,7 +175,9 @@ VAMD_DEV float couple_bin(ChanBin &M, ChanBin &A, int &iM, int &iA, int b, int n
   if (b < C.sliding_lowpass) {
     if (M.fg || A.fg) {
       // lossless: square-polar coupling of the already quantised integers
-      M.re = (float)(fabs((double)M.re) + fabs((double)A.re));
+      // (float)(fabs((double)M.re) + fabs((double)A.re)): the sum of two floats rounded through fp64 is the fp32 sum
+      // (53 >= 2 * 24 + 2, as for the quotient in chan_bin)
+      M.re = fabsf(M.re) + fabsf(A.re);
       M.qe = M.qe + A.qe;
       M.fg = A.fg = 1;
       const int a = iM, bb = iA;
@@ -172,7 +198,7 @@ VAMD_DEV float couple_bin(ChanBin &M, ChanBin &A, int &iM, int &iA, int b, int n
         M.re += A.re;
         M.qe = (float)fabs((double)M.re);
       } else {
-        const float e = (float)(fabs((double)M.re) + fabs((double)A.re));
+        const float e = fabsf(M.re) + fabsf(A.re);  // (as above)
         M.qe = e;
         M.re = (M.re + A.re < 0) ? -e : e;
       }
