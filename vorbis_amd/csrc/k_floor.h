@@ -305,7 +305,10 @@ VAMD_DEV int line_y(const LineStep &s, int y0, int k) { return y0 + s.sgn * div_
 
 // inspect_error, lib/floor1.c:516-565, wave-parallel over x in [x0, x1)
 VAMD_DEV int inspect_error_wave(int x0, int x1, int y0, int y1, const unsigned short *qc, const FloorP &F) {
-  const LineStep s = line_step(x0, x1, y0, y1, F.div_magic);
+  LineStep s;  // (line_step with wave-uniform operands)
+  s.ady = y1 < y0 ? y0 - y1 : y1 - y0;
+  s.sgn = y1 < y0 ? -1 : 1;
+  s.magic = load_uniform_u32(F.div_magic, x1 - x0);
   const int cnt = (x1 - x0) > 1 ? (x1 - x0) : 1;  // points visited: x0, then x0+1 .. x1-1
   int mse = 0;
   bool bad = false;
@@ -362,14 +365,32 @@ VAMD_DEV int post_Y(const LaneInts &A, const LaneInts &B, int pos) {
 }
 
 // render_point, lib/floor1.c:257-271
-VAMD_DEV int render_point(int x0, int x1, int y0, int y1, int x, const unsigned int *magic) {
+//   k = x - x0, magic = div_magic()'s multiplier for x1 - x0: fixed per post by the look (PostSteps below)
+VAMD_DEV int render_point(int y0, int y1, int k, unsigned int magic) {
   y0 &= 0x7fff;
   y1 &= 0x7fff;
-  const int dy = y1 - y0, adx = x1 - x0;
+  const int dy = y1 - y0;
   const int ady = dy < 0 ? -dy : dy;
-  const int off = div_magic(mad24(ady, x - x0, 0), magic[adx]);
+  const int off = div_magic(mad24(ady, k, 0), magic);
   return dy < 0 ? y0 - off : y0 + off;
 }
+
+// What render_point needs of a post's place between its two neighbours, one post per lane (posts 0 and 1 have no
+// neighbours: zeros)
+struct PostSteps {
+  LaneInts k, magic;
+  VAMD_MEM void load(const FloorP &F, const LaneInts &postlist, const LaneInts &lo2, const LaneInts &hi2) {
+    k.fill(0);
+    magic.fill(0);
+    WAVE_FOR(i, F.posts) {
+      const int x0 = postlist.gather(lo2.at(i)), x1 = postlist.gather(hi2.at(i));
+      if (i >= 2) {
+        k.put(i, postlist.at(i) - x0);
+        magic.put(i, (int)F.div_magic[x1 - x0]);
+      }
+    }
+  }
+};
 
 // floor1_fit for one channel-block (lib/floor1.c:576-729).
 //   qc    LDS [n2]   quantised mask + class bit, see offset_and_mix_wave
@@ -512,20 +533,22 @@ VAMD_DEV int floor_fit_posts(const FloorP &F, const unsigned short *qc, FloorScr
   lo2.load_shifted(F.loneighbor, 2, posts);
   hi2.load_shifted(F.hineighbor, 2, posts);
   level.load(F.level, posts);
+  PostSteps ps;
+  ps.load(F, postlist, lo2, hi2);
+  LaneInts fitted;  // the post's own fit (the mean of its two sides), settled before the levels
+  fitted.fill(0);
   WAVE_FOR(i, posts) {
-    if (i < 2) {
-      const int a = fitA.at(i), b = fitB.at(i);
-      outp.put(i, a < 0 ? b : (b < 0 ? a : (a + b) >> 1));
-    }
+    const int a = fitA.at(i), b = fitB.at(i);
+    const int vx = a < 0 ? b : (b < 0 ? a : (a + b) >> 1);
+    fitted.put(i, vx);
+    if (i < 2) outp.put(i, vx);
   }
   for (int L = 1; L <= F.nlevels; L++) {
     WAVE_FOR(i, posts) {
-      const int ln = lo2.at(i), hn = hi2.at(i);
-      const int x0 = postlist.gather(ln), x1 = postlist.gather(hn), y0 = outp.gather(ln), y1 = outp.gather(hn);
+      const int y0 = outp.gather(lo2.at(i)), y1 = outp.gather(hi2.at(i));
       if (i >= 2 && level.at(i) == L) {
-        const int predicted = render_point(x0, x1, y0, y1, postlist.at(i), F.div_magic);
-        const int a = fitA.at(i), b = fitB.at(i);
-        const int vx = a < 0 ? b : (b < 0 ? a : (a + b) >> 1);
+        const int predicted = render_point(y0, y1, ps.k.at(i), (unsigned int)ps.magic.at(i));
+        const int vx = fitted.at(i);
         outp.put(i, (vx >= 0 && predicted != vx) ? vx : (predicted | 0x8000));
       }
     }
@@ -561,14 +584,16 @@ VAMD_DEV void floor_quantise_predict(const FloorP &F, const LaneInts &outp, cons
     post.put(i, val | (o & 0x8000));
     if (wrapped) wrapped->put(i, i < 2 ? val | (o & 0x8000) : 0);
   }
+  PostSteps ps;
+  ps.load(F, postlist, lo2, hi2);
   unsigned long long needed = 3ull;  // posts 0 and 1 are always used
   for (int L = 1; L <= F.nlevels; L++) {
     WAVE_FOR(i, posts) {
       const int ln = lo2.at(i), hn = hi2.at(i);
-      const int x0 = postlist.gather(ln), x1 = postlist.gather(hn), y0 = post.gather(ln), y1 = post.gather(hn);
+      const int y0 = post.gather(ln), y1 = post.gather(hn);
       if (i >= 2 && level.at(i) == L) {
         const int pi = post.at(i);
-        const int predicted = render_point(x0, x1, y0, y1, postlist.at(i), F.div_magic);
+        const int predicted = render_point(y0, y1, ps.k.at(i), (unsigned int)ps.magic.at(i));
         if ((pi & 0x8000) || predicted == pi) {
           post.put(i, predicted | 0x8000);
         } else {

@@ -367,6 +367,16 @@ VAMD_DEV int div_magic(int num, unsigned int magic) {
   return (int)(((unsigned long long)(unsigned int)num * magic) >> 32);
 #endif
 }
+// p[i] for a wave-uniform i out of a table in HBM: through the scalar cache (the compiler cannot tell that a pointer it
+// read from a parameter struct points at constant memory, and would send all 64 lanes to fetch the same word)
+VAMD_DEV unsigned int load_uniform_u32(const unsigned int *p, int i) {
+#if VAMD_GPU
+  typedef const unsigned int __attribute__((address_space(4))) *cptr;
+  return ((cptr)p)[__builtin_amdgcn_readfirstlane(i)];
+#else
+  return p[i];
+#endif
+}
 VAMD_DEV int div_small(int num, int den, float rcp) {
   int q = (int)((float)num * rcp);
   const int r = num - q * den;
