@@ -650,27 +650,11 @@ VAMD_DEV int floor_encode_render(const FloorP &F, int n2, const LaneInts &outp, 
   // ---- render the integer curve, lib/floor1.c:923-946: segment list of the
   // used posts in x order, then every bin evaluates its segment's line.
 #if VAMD_GPU
-  // lane j looks at the j-th post in x order; used posts are compacted by rank.  Which segment a bin falls into
-  // then needs no search: bin_interval[x] (static) is the last post at or before x in x order, and the used posts
-  // among those up to it are a population count of the ballot.
-  unsigned long long um;
-  {
-    const int j = LANE;
-    const int cur = forward_index.at(j);
-    const int src = j < posts ? cur : 0;
-    const int pv = post.gather(src), px = postlist.gather(src);  // (gathers need every lane active)
-    const bool used = j < posts && (j == 0 || (pv & 0x8000) == 0);
-    um = __ballot(used);
-    if (used) {
-      const int r = __builtin_popcountll(um & ((1ull << j) - 1ull));
-      sc->segx[r] = j == 0 ? 0 : px;
-      sc->segy[r] = (pv & 0x7fff) * F.mult;
-    }
-  }
-  WAVE_SYNC();
-  // one row per segment: where it starts and its Bresenham constants (render_line0, lib/floor1.c:923-946);
-  // the last used post gets a flat row (the curve is held beyond it, :941-943).  The rows overlay the fit's
-  // accumulators, which are dead by now.
+  // Lane j looks at the j-th post in x order.  The curve over [x_j, x_j+1) is the line from the last USED post at or
+  // before j to the first used one after it (render_line0, lib/floor1.c:923-946; held flat past the last used post,
+  // :941-943): both are bit scans of the ballot of used posts, their x / y come over from those lanes, and lane j
+  // leaves the line's constants in row j.  A bin then needs no search at all: bin_interval[x] (static) IS its j.
+  // The rows overlay the fit's accumulators, which are dead by now.
   struct SegRow {
     int x0, y0, ady, sgn;
     unsigned int magic;
@@ -678,17 +662,28 @@ VAMD_DEV int floor_encode_render(const FloorP &F, int n2, const LaneInts &outp, 
   };
   SegRow *rows = (SegRow *)sc->acc;
   {
-    const int ns = __builtin_popcountll(um) - 1;
-    if (LANE <= ns) {
+    const int j = LANE;
+    const int cur = forward_index.at(j);
+    const int src = j < posts ? cur : 0;
+    const int pv = post.gather(src), px = postlist.gather(src);  // (gathers need every lane active)
+    const bool used = j < posts && (j == 0 || (pv & 0x8000) == 0);
+    const unsigned long long um = __ballot(used);
+    const int myx = j == 0 ? 0 : px, myy = (pv & 0x7fff) * F.mult;
+    const unsigned long long upto = j >= 63 ? ~0ull : ((2ull << j) - 1ull);
+    const int sidx = 63 - __builtin_clzll(um & upto);  // (bit 0 is always set)
+    const unsigned long long above = um & ~upto;
+    const int eidx = above ? __builtin_ctzll(above) : sidx;
+    const int xs = __shfl(myx, sidx, 64), ys = __shfl(myy, sidx, 64);
+    const int xe = __shfl(myx, eidx, 64), ye = __shfl(myy, eidx, 64);
+    if (j < posts) {
       SegRow r;
-      r.x0 = sc->segx[LANE];
-      r.y0 = sc->segy[LANE];
+      r.x0 = xs, r.y0 = ys;
       r.ady = 0, r.sgn = 1, r.magic = 0, r.pad[0] = r.pad[1] = r.pad[2] = 0;
-      if (LANE < ns) {
-        const LineStep st = line_step(r.x0, sc->segx[LANE + 1], r.y0, sc->segy[LANE + 1], F.div_magic);
+      if (above) {
+        const LineStep st = line_step(xs, xe, ys, ye, F.div_magic);
         r.ady = st.ady, r.sgn = st.sgn, r.magic = st.magic;
       }
-      rows[LANE] = r;
+      rows[j] = r;
     }
   }
   WAVE_SYNC();
@@ -700,9 +695,7 @@ VAMD_DEV int floor_encode_render(const FloorP &F, int n2, const LaneInts &outp, 
 #pragma unroll
       for (int c = 0; c < 4; c++) {
         const int jb = (int)((jq >> (8 * c)) & 0xff);
-        const int j = jb == 255 ? 63 : (jb & 0x7f);
-        const int sgm = __builtin_popcountll(um & ((2ull << j) - 1ull)) - 1;
-        const SegRow r = rows[sgm];
+        const SegRow r = rows[jb == 255 ? posts - 1 : (jb & 0x7f)];
         const int k = 4 * q + c - r.x0;
         v[c] = mad24(div_magic(mad24(k, r.ady, 0), r.magic), r.sgn, r.y0);
       }
