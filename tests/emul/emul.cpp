@@ -343,6 +343,38 @@ int emul_plan_stream(void *h, const unsigned char *flags, long nsteps, long nsam
 }
 
 extern "C" {
+// accumulate_fit's work list (derive_fit_segments, bound as FloorP::fit_segs) against the loops of the reference
+// (lib/floor1.c:601-608 calling :393-454): bin i is summed into interval j exactly when sorted_index[j] <= i <=
+// min(sorted_index[j+1], n-1).  Returns the number of (bin, interval) pairs on which the two disagree, over every
+// floor of both size classes of the setup.
+long emul_fit_segments_check(void *h) {
+  Emul *e = (Emul *)h;
+  long bad = 0;
+  for (int W = 0; W < 2; W++)
+    for (int sm = 0; sm < VAMD_MAX_SUBMAPS; sm++) {
+      const FloorP &F = e->B.floor[W][sm];
+      const int n2 = e->B.psy[2 * W].n;
+      std::vector<int> got((size_t)n2 * 64, 0), want((size_t)n2 * 64, 0);
+      for (int j = 0; j + 1 < F.posts; j++) {
+        int x1 = F.sorted_index[j + 1];
+        if (x1 >= F.look_n) x1 = F.look_n - 1;
+        for (int i = F.sorted_index[j]; i <= x1; i++)
+          if (i < n2) want[(size_t)i * 64 + j]++;
+      }
+      for (int sg = 0; sg < F.fit_nseg; sg++) {
+        const unsigned int *r = F.fit_segs + VAMD_FITSEG_WORDS * sg;
+        const int chunk = (int)r[0], j = (int)r[1];
+        for (int b = 0; b < 16; b++) {
+          const unsigned int m = (r[4 + (b >> 1)] >> (16 * (b & 1))) & 0xffffu;
+          if (m != 0 && m != 0xffffu) bad++;
+          if (m && 16 * chunk + b < n2 && j < 64) got[(size_t)(16 * chunk + b) * 64 + j]++;
+        }
+      }
+      for (size_t k = 0; k < got.size(); k++) bad += got[k] != want[k];
+    }
+  return bad;
+}
+
 // div_magic() (the kernels' one-multiply floor division) against C's "/" over the domain the floor's line walks
 // use it on: every divisor den <= VAMD_DIV_MAGIC_MAX, every |dy| <= 1023, the steps k next to the ends and strided
 // through the middle.  Returns the number of disagreements.

@@ -166,6 +166,12 @@ class Emul:
                                     maxblocks, kind.ctypes.data_as(C.c_void_p), begin.ctypes.data_as(C.c_void_p))
         return kind[:n], begin[:n]
 
+    def fit_segments_mismatches(self):
+        """accumulate_fit's static work list against the reference's loops (emul_fit_segments_check)."""
+        self.L.emul_fit_segments_check.restype = C.c_long
+        self.L.emul_fit_segments_check.argtypes = [C.c_void_p]
+        return int(self.L.emul_fit_segments_check(self.h))
+
     def div_magic_mismatches(self):
         """div_magic() against integer division over the floor line walks' domain (emul_div_magic_check)."""
         self.L.emul_div_magic_check.restype = C.c_long

@@ -51,6 +51,14 @@ def test_bodies_match_oracle_random(name):
         assert checker.compare_block(a, g, em.L and 29, verbose=True) == 0
 
 
+@pytest.mark.parametrize("name", ["44k_stereo_q4", "44k_51_q3", "44k_mono_q5", "44k_stereo_q9"])
+def test_fit_work_list_covers_the_reference_ranges(name):
+    """k_floor's accumulate_fit reads a static list of (chunk, interval) records (vamd_derive.h derive_fit_segments):
+    every bin must be summed into exactly the intervals lib/floor1.c:601-608 sums it into, the shared posts twice."""
+    em = Emul(np.fromfile(os.path.join(checker.ROOT, "vorbis_amd", "data", "setup_%s.bin" % name), dtype=np.uint8))
+    assert em.fit_segments_mismatches() == 0
+
+
 def test_div_magic_is_exact_on_the_floor_lines_domain():
     """k_floor's line walks divide by x1 - x0 with one multiply (vamd_wave.h div_magic, table derive_div_magic)."""
     em = Emul(np.fromfile(os.path.join(checker.ROOT, "vorbis_amd", "data", "setup_44k_stereo_q4.bin"), dtype=np.uint8))
