@@ -32,9 +32,10 @@ struct ScanSerial {
 #define VAMD_HOST_QUADS 2048  // a whole block's quads in the one lane of this build (blocks up to 8192 samples)
 static void noisemask_block(const PsyP &P, const float *logmdct, float *out, float *S, PhaseClock &pc) {
   static float lm[VAMD_NZ_HOST_BINS], o[VAMD_NZ_HOST_BINS];
-  static int bk[VAMD_NZ_HOST_BINS];
+  static int braw[VAMD_NZ_HOST_BINS], bk[VAMD_NZ_HOST_BINS];
   for (int i = 0; i < P.n; i++) lm[i] = logmdct[i];
-  noise_bark_fetch<VAMD_NZ_HOST_BINS, 0>(P, bk, 0);
+  noise_bark_fetch<VAMD_NZ_HOST_BINS, 0>(P, braw, 0);
+  noise_bark_edges<VAMD_NZ_HOST_BINS, 0>(P, braw, bk, 0);
   noisemask_bins<ScanSerial, VAMD_NZ_HOST_BINS, 0>(P, lm, bk, o, S, [&](int dB) { return P.noisecompand[dB]; }, ScanSerial(), pc, 0);
   for (int i = 0; i < P.n; i++) out[i] = o[i];
 }

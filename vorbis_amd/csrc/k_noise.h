@@ -151,8 +151,8 @@ VAMD_DEV LineFit fit_window(const float *S, int n, int hi, int e2, bool mir) {
 //   bk[k]   the window of bin min(i, bark_i2 - 1) -- the bins past the last fitted line extend it
 //           (lib/psy.c:649-656), which is what evaluating that line's window again yields -- as LDS word
 //           positions: upper edge | lower (or mirrored lower) edge << 16 (noise_bark_edges).  Prepared by
-//           the caller ahead of time: bark[] is a table in HBM and its latency should not sit between the
-//           running sums and their use.
+//           the caller once per block type (noise_bark_fetch + noise_bark_edges): a property of the lane's bins,
+//           not of the block.
 // LOGN > 0: the bin count is the compile-time constant 2^LOGN (array strides and window-edge addresses
 // then fold into immediate offsets); 0 = P.n.
 template <class Scan, int KPL, int LOGN>
@@ -252,12 +252,10 @@ VAMD_DEV void noise_bark_edges(const PsyP &P, const int *braw, int *bk, int i0) 
 //            cross-lane read of the copy the wave keeps one entry per lane (the index is data-dependent, the
 //            team's LDS is full to the byte, and a trip to L1 at the very end of a block is exposed latency)
 template <class Scan, int KPL, int LOGN, class Compand>
-VAMD_DEV void noisemask_bins(const PsyP &P, const float *lm, const int *braw, float *o, float *S, const Compand &compand,
+VAMD_DEV void noisemask_bins(const PsyP &P, const float *lm, const int *bk, float *o, float *S, const Compand &compand,
                              const Scan &scan, PhaseClock &pc, int i0) {
   const int n = LOGN ? (1 << LOGN) : P.n;
   float nz[KPL], wk[KPL];
-  int bk[KPL];
-  noise_bark_edges<KPL, LOGN>(P, braw, bk, i0);  // (placed by the compiler where braw is first needed: after the first walk)
   bark_noise_bins<Scan, KPL, LOGN>(P, lm, bk, nz, 140.f, -1, S, scan, pc, 0, i0);
   LANE_BINS(k, i, i0, KPL, n) wk[k] = lm[k] - nz[k];
   pc.mark(3);

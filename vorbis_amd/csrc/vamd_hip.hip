@@ -200,7 +200,7 @@ __global__ __launch_bounds__(64 * NoiseGeom<LOGN2>::NW, NoiseGeom<LOGN2>::KPL <=
   pc.start(d.dbg ? d.dbg + 16 : nullptr);
   // persistent: the next block's spectrum is fetched while this one is worked on
   float lm[KPL];
-  int braw[KPL], bt_have = -1;
+  int braw[KPL], bk[KPL], bt_have = -1;
   float compand_lane = 0.f;  // noisecompand[LANE]
   long cb = blockIdx.x;
   // (the spectrum in dB, lib/mapping0.c:384-385, is formed here from the spectrum itself: nobody writes it to HBM)
@@ -212,13 +212,14 @@ __global__ __launch_bounds__(64 * NoiseGeom<LOGN2>::NW, NoiseGeom<LOGN2>::KPL <=
     const long nb = cb + gridDim.x < ncb ? cb + gridDim.x : cb;
     if (bt != bt_have) {  // the window edges of this lane's bins and noisecompand[]: properties of the block type, kept across blocks
       noise_bark_fetch<KPL, LOGN2>(P, braw, i0);
+      noise_bark_edges<KPL, LOGN2>(P, braw, bk, i0);
       compand_lane = LANE < VAMD_NOISE_COMPAND_LEVELS ? P.noisecompand[LANE] : 0.f;
       bt_have = bt;
     }
     LANE_BINS(k, i, i0, KPL, n2) lm_next[k] = mdct_raw[nb * n2 + i];
     LANE_BINS(k, i, i0, KPL, n2) lm[k] = todB_345(lm[k]);
     noisemask_bins<ScanTeam, KPL, LOGN2>(
-        P, lm, braw, o, S,
+        P, lm, bk, o, S,
         [&](int dB) { return __int_as_float(__builtin_amdgcn_ds_bpermute(dB << 2, __float_as_int(compand_lane))); }, ScanTeam(), pc,
         i0);
     LANE_BINS(k, i, i0, KPL, n2) noise[cb * n2 + i] = o[k];
