@@ -146,7 +146,32 @@ typedef struct vamd_batch_io {
   uint8_t  *packets;      /* out [nb][packet_stride] bytes; the packet is the first (bits+7)/8 of a row */
   int32_t  *packet_bits;  /* out [nb] oggpack_bits(); > 8*packet_stride: the row was too short, packet cut off */
   int64_t   packet_stride;/* row length in bytes, a multiple of 4 (vamd_packet_capacity() always suffices) */
+  uint8_t  *status;       /* out [nb][ch] 1 where the channel-block was outside the input domain (below), else 0 */
 } vamd_batch_io;
+
+/* ---- Input domain ---------------------------------------------------------------------------------
+ * libvorbis does not validate PCM: whatever floats arrive go through mapping0_forward.  Inside the
+ * domain below this library reproduces the reference bit for bit (denormals, signed zeros and samples
+ * thousands of times over full scale included).  Outside it the reference's own result is not defined by
+ * C -- its float -> int conversions of the quantised residue overflow (x86 yields INT_MIN, other targets
+ * saturate), and a NaN sample reaches those conversions too -- so there is nothing to be identical to,
+ * and the library REPORTS such input instead of inventing an answer:
+ *
+ *   domain: every sample finite, and the block's spectral peak (the reference's logfft scale, 0 dB = a
+ *           full-scale sine, lib/mapping0.c:255-343, taken before the 0 dB clamp of :345) at most +150 dB,
+ *           i.e. samples up to ~3e7 x full scale.  One NaN or +-Inf anywhere in a block's window puts the
+ *           peak above +330 dB, so the test costs one compare per channel-block.
+ *
+ *   - the host-pointer calls (vamd_analyze_block*, vamd_encode_block, vamd_envelope_search,
+ *     vamd_batcher_encode_block) return VAMD_EINVAL (= OV_EINVAL) for a block / detector call outside the
+ *     domain; through the binding, vorbis_analysis() returns OV_EINVAL for that block and for every later
+ *     block of the stream;
+ *   - the device-pointer calls are asynchronous: they fill `status` (when given) and count;
+ *     vamd_input_status() synchronises the context's stream, returns VAMD_EINVAL if anything issued since the
+ *     previous call was outside the domain (how many channel-blocks / detector steps: the two optional
+ *     outputs) and resets the counts.  Outputs of such blocks are deterministic but unspecified; every
+ *     other block of the batch is unaffected. */
+int vamd_input_status(vamd_ctx *ctx, long *bad_channel_blocks, long *bad_detector_steps);
 
 #define VAMD_RES_CLASS_STRIDE 512 /* ints per block and submap in res_class[] (>= classified partitions) */
 

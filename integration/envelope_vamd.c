@@ -29,6 +29,7 @@ extern vamd_ctx *vamd_ctx_for(vorbis_dsp_state *vd);
 extern vamd_envelope_state *vamd_envelope_state_for(vorbis_dsp_state *vd);
 extern void vamd_release_key(const void *key);
 extern int vamd_batching(void);
+extern void vamd_poison(vorbis_dsp_state *vd);
 
 /* vorbis_dsp_clear() tears the detector down here (lib/block.c:325-328): the GPU context that
  * was created for this analysis state goes with it */
@@ -65,6 +66,13 @@ long _ve_envelope_search(vorbis_dsp_state *v) {
     int i, err = -1;
     for (i = 0; i < ve->ch; i++) chan[i] = v->pcm[i] + step * first;
     if (ctx && st) err = vamd_envelope_search(ctx, chan, nsteps, st, flags);
+    if (err == VAMD_EINVAL) {
+      /* a sample outside the input domain (NaN / Inf; vorbis_amd.h): no marks from these steps, and the stream is
+         flagged so that the next vorbis_analysis() returns OV_EINVAL (mapping0_vamd.c: vamd_poison) */
+      memset(flags, 0, nsteps);
+      vamd_poison(v);
+      err = 0;
+    }
     if (err) {
       /* this entry point has no error return (1 / 0 / -1 all mean something); like the
          reference's own exit(1) sites, refuse to continue rather than silently diverge */

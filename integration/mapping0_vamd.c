@@ -63,6 +63,7 @@ typedef struct vamd_entry {
   vamd_ctx *ctx;   /* this state's own context (always in per-state mode; in batch mode only for what is not batched) */
   vamd_shared *shared; /* batch mode: the batcher this state submits to */
   vamd_envelope_state env; /* the block-switching detector's running state (envelope_vamd.c) */
+  int poisoned;            /* the stream held a sample outside the input domain (vorbis_amd.h): every later block is OV_EINVAL */
 } vamd_entry;
 static pthread_mutex_t vamd_lock = PTHREAD_MUTEX_INITIALIZER;
 static vamd_entry **vamd_table = NULL;
@@ -172,6 +173,19 @@ vamd_ctx *vamd_ctx_for(vorbis_dsp_state *state) {
 vamd_envelope_state *vamd_envelope_state_for(vorbis_dsp_state *state) {
   vamd_entry *e = vamd_entry_for(state);
   return e ? &e->env : NULL;
+}
+
+/* Input outside the domain (a NaN / Inf sample, include/vorbis_amd.h "Input domain"): the reference's own output for
+ * such a stream is not defined by C, so the encode ends here -- vorbis_analysis() returns OV_EINVAL for the block that
+ * held the sample and for every block after it.  The detector has no error return (envelope_vamd.c), so it records
+ * the fact here and lets the next vorbis_analysis() report it. */
+void vamd_poison(vorbis_dsp_state *state) {
+  vamd_entry *e = vamd_entry_for(state);
+  if (e) e->poisoned = 1;
+}
+static int vamd_poisoned(vorbis_dsp_state *state) {
+  vamd_entry *e = vamd_entry_for(state);
+  return e ? e->poisoned : 0;
 }
 
 /* called by _ve_envelope_clear() (envelope_vamd.c) with the envelope_lookup being torn down */
@@ -302,6 +316,7 @@ static int mapping0_forward_vamd(vorbis_block *vb) {
 #endif
   }
   vb->mode = vb->W;
+  if (vamd_poisoned(vd)) return OV_EINVAL;
 
   /* ---- batch mode (VAMD_BATCH): the block joins whatever the other encoder threads have pending and comes back
      as its packet, exactly as from vamd_encode_block below */
@@ -314,6 +329,7 @@ static int mapping0_forward_vamd(vorbis_block *vb) {
       int32_t bits = 0;
       ret = vamd_batcher_encode_block(e->shared->batcher, (const float *const *)vb->pcm, vb->lW, vb->W, vb->nW,
                                       vbi->blocktype, vbi->ampmax, &ampmax_out, packet, pkcap, &bits);
+      if (ret == VAMD_EINVAL) vamd_poison(vd);
       if (ret) return ret;
       vbi->ampmax = ampmax_out; /* lib/mapping0.c:576 */
       oggpack_writecopy(vbi->packetblob[PACKETBLOBS / 2], packet, bits);
@@ -333,6 +349,7 @@ static int mapping0_forward_vamd(vorbis_block *vb) {
     int32_t *bits = _vorbis_block_alloc(vb, nk * sizeof(*bits));
     ret = vamd_encode_block(ctx, (const float *const *)vb->pcm, vb->lW, vb->W, vb->nW, vbi->blocktype, vbi->ampmax,
                             managed, &ampmax_out, packets, pkcap, bits);
+    if (ret == VAMD_EINVAL) vamd_poison(vd);
     if (ret) return ret; /* an OV_* code, out through vorbis_analysis(); the text stays with vamd_last_error(ctx) */
     vbi->ampmax = ampmax_out; /* lib/mapping0.c:576 */
     for (k = 0; k < nk; k++) {
@@ -358,6 +375,7 @@ static int mapping0_forward_vamd(vorbis_block *vb) {
   else
     ret = vamd_analyze_block(ctx, (const float *const *)vb->pcm, vb->lW, vb->W, vb->nW, vbi->blocktype, vbi->ampmax,
                              mdct, NULL, posts, post_valid, iwork, nonzero, &ampmax_out);
+  if (ret == VAMD_EINVAL) vamd_poison(vd);
   if (ret) return ret;
   vbi->ampmax = ampmax_out; /* lib/mapping0.c:576 */
   for (k = 0; k < nk; k++) {

@@ -120,6 +120,9 @@ def lib(hybrid=False):
         L.ref_open_uncoupled.argtypes = [C.c_int, C.c_long, C.c_float]
         L.ref_tap_block_managed.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                             C.POINTER(_Taps), C.POINTER(_MTaps)]
+        L.ref_matrix_case.restype = C.c_long
+        L.ref_matrix_case.argtypes = [C.c_int, C.c_long, C.c_float, _f32p, C.c_int, _u8p, C.c_long,
+                                      C.POINTER(C.c_long), C.c_long, _f32p, C.POINTER(C.c_long)]
         _libs[path] = L
     return _libs[path]
 
@@ -359,3 +362,22 @@ class RefEncoder:
     def time_dsp(self, blocks, reps=1):
         blocks = np.ascontiguousarray(blocks, dtype=np.float32)
         return float(self.L.ref_time_dsp(self.h, _fp(blocks), blocks.shape[0], reps))
+
+
+def matrix_case(ch, rate, q, data, hybrid=False):
+    """One cell of the reference's own test grid (test/test.c:30-75) through ref_matrix_case (ref_harness.c):
+    encode `data` (the same samples in every channel) as test/write_read.c does, decode the packets with the
+    reference's vorbis_synthesis.  Returns (packets incl. the three headers, decoded channel 0)."""
+    L = lib(hybrid)
+    data = np.ascontiguousarray(data, dtype=np.float32)
+    cap, maxp = 1 << 20, 256
+    pk = np.zeros(cap, np.uint8)
+    sizes = (C.c_long * maxp)()
+    dec = np.full(len(data), 3.141, np.float32)   # set_data_in(data_in, .., 3.141), test/test.c:55
+    total = C.c_long(0)
+    n = L.ref_matrix_case(ch, rate, C.c_float(q), _fp(data), len(data), pk.ctypes.data_as(_u8p), cap, sizes, maxp,
+                          _fp(dec), C.byref(total))
+    if n < 0:
+        raise RuntimeError("ref_matrix_case(%d, %d, %g) failed: %d" % (ch, rate, q, n))
+    offs = np.concatenate([[0], np.cumsum([sizes[k] for k in range(n)])])
+    return [bytes(pk[offs[k]:offs[k + 1]]) for k in range(n)], dec, int(total.value)

@@ -759,3 +759,103 @@ double ref_time_dsp(ref_enc *e, const float *pcm, long nblocks, int reps) {
     }
   return total;
 }
+
+/* ---- the reference's own test grid (test/test.c:30-75) ----------------------------------
+ * One cell: write_vorbis_data_or_die()'s encode sequence (test/write_read.c:30-126: the whole
+ * signal handed over in ONE vorbis_analysis_buffer/_wrote pair, the same samples in every channel,
+ * vorbis_analysis(vb, NULL) + vorbis_bitrate_addblock + vorbis_bitrate_flushpacket) and
+ * read_vorbis_data_or_die()'s decode (:130-300: three header packets into vorbis_synthesis_headerin,
+ * then vorbis_synthesis / _blockin / _pcmout, channel 0 kept), with the packets handed from one to the
+ * other directly instead of through libogg pages (libogg is not part of the reference tree and adds no
+ * arithmetic).  Linked into libvorbis_hybrid.so the same function runs the encode on the GPU back-end.
+ *   packets_out / sizes  every packet in order, the three headers first
+ *   decoded              channel 0 of the decoder's output, at most `count` samples
+ * Returns the number of packets (headers included), or < 0. */
+long ref_matrix_case(int ch, long rate, float q, const float *data, int count, unsigned char *packets_out,
+                     long cap, long *sizes, long max_packets, float *decoded, long *decoded_total) {
+  vorbis_info vi, vi2;
+  vorbis_comment vc, vc2;
+  vorbis_dsp_state vd, vd2;
+  vorbis_block vb, vb2;
+  ogg_packet hdr[3], op;
+  ogg_packet *ops = NULL;
+  long np = 0, used = 0, k, ret = 0, read_total = 0;
+  int i;
+
+  vorbis_info_init(&vi);
+  if (vorbis_encode_init_vbr(&vi, ch, rate, q)) {
+    vorbis_info_clear(&vi);
+    return -1;
+  }
+  vorbis_comment_init(&vc);
+  vorbis_comment_add_tag(&vc, "ENCODER", "test/util.c");
+  vorbis_analysis_init(&vd, &vi);
+  vorbis_block_init(&vd, &vb);
+  ops = (ogg_packet *)calloc(max_packets, sizeof(*ops));
+  vorbis_analysis_headerout(&vd, &vc, &hdr[0], &hdr[1], &hdr[2]);
+#define KEEP(P)                                                   \
+  do {                                                            \
+    if (np >= max_packets || used + (P).bytes > cap) {            \
+      ret = -2;                                                   \
+      goto done_encode;                                           \
+    }                                                             \
+    memcpy(packets_out + used, (P).packet, (P).bytes);            \
+    ops[np] = (P);                                                \
+    ops[np].packet = packets_out + used;                          \
+    sizes[np++] = (P).bytes;                                      \
+    used += (P).bytes;                                            \
+  } while (0)
+  for (i = 0; i < 3; i++) KEEP(hdr[i]);
+  {
+    float **buffer = vorbis_analysis_buffer(&vd, count);
+    for (i = 0; i < ch; i++) memcpy(buffer[i], data, count * sizeof(float));
+    vorbis_analysis_wrote(&vd, count);
+    vorbis_analysis_wrote(&vd, 0);
+  }
+  while (vorbis_analysis_blockout(&vd, &vb) == 1) {
+    if (vorbis_analysis(&vb, NULL) || vorbis_bitrate_addblock(&vb)) {
+      ret = -3;
+      goto done_encode;
+    }
+    while (vorbis_bitrate_flushpacket(&vd, &op)) KEEP(op);
+  }
+#undef KEEP
+done_encode:
+  vorbis_block_clear(&vb);
+  vorbis_dsp_clear(&vd);
+  vorbis_comment_clear(&vc);
+  vorbis_info_clear(&vi);
+  if (ret) {
+    free(ops);
+    return ret;
+  }
+
+  vorbis_info_init(&vi2);
+  vorbis_comment_init(&vc2);
+  for (k = 0; k < 3; k++)
+    if (vorbis_synthesis_headerin(&vi2, &vc2, &ops[k]) < 0) ret = -4;
+  if (!ret && vi2.rate != rate) ret = -5;
+  if (!ret && vorbis_synthesis_init(&vd2, &vi2)) ret = -6;
+  if (!ret) {
+    vorbis_block_init(&vd2, &vb2);
+    for (k = 3; k < np; k++) {
+      float **pcm;
+      int samples;
+      if (vorbis_synthesis(&vb2, &ops[k]) == 0) vorbis_synthesis_blockin(&vd2, &vb2);
+      while ((samples = vorbis_synthesis_pcmout(&vd2, &pcm)) > 0 && read_total < count) {
+        int bout = samples < count ? samples : count;
+        bout = read_total + bout > count ? count - read_total : bout;
+        memcpy(decoded + read_total, pcm[0], bout * sizeof(float));
+        vorbis_synthesis_read(&vd2, bout);
+        read_total += bout;
+      }
+    }
+    vorbis_block_clear(&vb2);
+    vorbis_dsp_clear(&vd2);
+  }
+  vorbis_comment_clear(&vc2);
+  vorbis_info_clear(&vi2);
+  free(ops);
+  *decoded_total = read_total;
+  return ret ? ret : np;
+}

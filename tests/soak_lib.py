@@ -1,6 +1,8 @@
 """tests/soak_lib.py -- random-signal soak of the GPU batch path against the reference's real vorbis_analysis():
-many random blocks of eight signal kinds (noise over 90 dB of level, sines, impulses, clipping, DC ramps, silent
-channels, s16 decaying harmonics, anti-phase pairs) with random window flags, block types and incoming ampmax,
+many random blocks of twelve signal kinds (noise over 90 dB of level, sines, impulses, clipping, DC ramps, silent
+channels, s16 decaying harmonics, anti-phase pairs; and the edges of the input domain: denormal-level noise, signed
+zeros around single denormals, noise 40-120 dB over full scale, impulses 100 dB over full scale on a denormal floor)
+with random window flags, block types and incoming ampmax,
 twelve configurations (1-8 channels, 22-96 kHz, q -0.1 .. 0.9, coupled and not), both block sizes; every packet and
 ampmax compared with oracle/_ref.  Then bitrate-managed blocks: all fifteen candidate packets each.
 Test infrastructure: driven by tests/test_gpu_soak.py (-m gpu) and tools/soak.py."""
@@ -21,7 +23,7 @@ def signals(rng, nb, ch, n):
     x = np.zeros((nb, ch, n), np.float32)
     t = np.arange(n, dtype=np.float64)
     for k in range(nb):
-        kind = k % 8
+        kind = k % NKINDS
         amp = 10.0 ** rng.uniform(-4.5, 0)
         if k % 64 == 63:
             amp *= 8.0    # over full scale now and then: a spectral maximum above 0 dB is clamped (lib/mapping0.c:345)
@@ -44,11 +46,27 @@ def signals(rng, nb, ch, n):
             f0 = rng.uniform(0.001, 0.02)
             s = sum(np.sin(2 * np.pi * f0 * h * t) / h for h in range(1, 12)) * np.exp(-t / rng.uniform(200, 4000))
             x[k] = np.round(amp * 0.5 * s[None, :] * rng.uniform(0.5, 1.0, (ch, 1)) * 32767) / 32768
-        else:             # anti-phase stereo pairs
+        elif kind == 7:   # anti-phase stereo pairs
             b = (rng.random(n) - 0.5) * 2 * amp
             for c in range(ch):
                 x[k, c] = b * (-1 if c & 1 else 1) * rng.uniform(0.8, 1.0)
+        # ---- the edges of the input domain (include/vorbis_amd.h): finite, so the reference's result is defined
+        # and must be met bit for bit.  x86 computes with denormals (no FTZ/DAZ); so must every GPU instruction.
+        elif kind == 8:   # denormal-level noise: every sample, and most of the spectrum, below FLT_MIN
+            x[k] = ((rng.random((ch, n)) - 0.5) * 2 * 10.0 ** rng.uniform(-44.5, -37.5)).astype(np.float32)
+        elif kind == 9:   # signed zeros with single denormals / tiny normals in them
+            x[k] = np.where(rng.random((ch, n)) < 0.5, np.float32(-0.0), np.float32(0.0))
+            for _ in range(int(rng.integers(0, 4))):
+                x[k, rng.integers(0, ch), rng.integers(0, n)] = np.float32(rng.choice([1e-45, -1e-45, 3e-39, -1.2e-38, 1e-30]))
+        elif kind == 10:  # far over full scale, inside the domain (spectral peak below +150 dB)
+            x[k] = ((rng.random((ch, n)) - 0.5) * 2 * 10.0 ** rng.uniform(2, 6)).astype(np.float32)
+        else:             # an impulse 100 dB over full scale on a denormal floor
+            x[k] = ((rng.random((ch, n)) - 0.5) * 1e-39).astype(np.float32)
+            x[k, :, rng.integers(0, n)] = np.float32(rng.choice([-1e5, 1e5]))
     return x
+
+
+NKINDS = 12
 
 
 
@@ -71,6 +89,9 @@ def run(NB=300, managed=True, log=print):
             o = an.analyze(torch.from_numpy(x).cuda(), W=W, lW=lW, nW=nW, blocktype=bt, ampmax_in=amp_in,
                            want=("ampmax_out", "packets", "packet_bits"))
             torch.cuda.synchronize()
+            if an.input_status() != (0, 0):   # every soak signal is inside the input domain
+                bad += 1
+                log("FLAGGED", (ch, rate, q, coupled), "W", W, ": blocks reported outside the input domain")
             rows, bits, amps = o["packets"].cpu().numpy(), o["packet_bits"].cpu().numpy(), o["ampmax_out"].cpu().numpy()
             for k in range(nb):
                 a = e.tap_block(x[k], int(lW[k]), W, int(nW[k]), int(bt[k]), float(amp_in[k]))
@@ -79,7 +100,7 @@ def run(NB=300, managed=True, log=print):
                 total += 1
                 if not ok:
                     bad += 1
-                    log("MISMATCH", (ch, rate, q, coupled), "W", W, "block", k, "kind", k % 8)
+                    log("MISMATCH", (ch, rate, q, coupled), "W", W, "block", k, "kind", k % NKINDS)
         an.close()
         log("%d ch %d Hz q %.1f coupled=%s done, %d blocks so far, %d mismatches, %.0f s" % (ch, rate, q, coupled, total, bad, time.time() - t0))
     if not managed:
@@ -104,7 +125,114 @@ def run(NB=300, managed=True, log=print):
                 total += 1
                 if not ok:
                     bad += 1
-                    log("MISMATCH managed", ch, rates, "W", W, "block", k, "kind", k % 8)
+                    log("MISMATCH managed", ch, rates, "W", W, "block", k, "kind", k % NKINDS)
         an.close()
         log("managed %d ch %s done, %d blocks so far, %d mismatches, %.0f s" % (ch, rates, total, bad, time.time() - t0))
     return total, bad
+
+
+# ---- outside the input domain -------------------------------------------------------------------------------------
+HOSTILE = ("nan", "+inf", "-inf", "1e30", "fltmax", "nan_everywhere", "nan_in_zeroed_window")
+
+
+def hostile_batch(rng, nb, ch, n, W):
+    """nb blocks of ordinary noise; every third one gets a hostile sample in ONE channel.  Returns
+    (pcm, lW, nW, expected status [nb][ch])."""
+    x = ((rng.random((nb, ch, n)) - 0.5) * 2 * 0.3).astype(np.float32)
+    lW = np.ones(nb, np.int32) * W
+    nW = np.ones(nb, np.int32) * W
+    want = np.zeros((nb, ch), np.uint8)
+    for k in range(0, nb, 3):
+        kind = HOSTILE[(k // 3) % len(HOSTILE)]
+        c = int(rng.integers(0, ch))
+        pos = int(rng.integers(n // 4 + 8, 3 * n // 4 - 8))   # inside every window shape's non-zero part
+        flagged = 1
+        if kind == "nan":
+            x[k, c, pos] = np.nan
+        elif kind == "+inf":
+            x[k, c, pos] = np.inf
+        elif kind == "-inf":
+            x[k, c, pos] = -np.inf
+        elif kind == "1e30":
+            x[k, c, pos] = 1e30
+        elif kind == "fltmax":
+            x[k, c, pos] = -3.4028235e38
+        elif kind == "nan_everywhere":
+            x[k, c, :] = np.nan
+        else:
+            # a long block after a short one: _vorbis_apply_window ZEROES [0, n/4 - bs0/4) instead of multiplying
+            # (lib/window.c:2117-2118), so a NaN there never enters the arithmetic -- the block is inside the
+            # domain, its result is the reference's, and it must NOT be flagged
+            if W:
+                lW[k] = 0
+                x[k, c, 3] = np.nan
+                flagged = 0
+            else:
+                x[k, c, pos] = np.nan
+        want[k, c] = flagged
+    return x, lW, nW, want
+
+
+def run_hostile(nb=48, log=print):
+    """Blocks outside the input domain are reported (status, vamd_input_status), never crash or hang, and leave
+    every other block of their batch bit-exact.  Returns (checks made, failures)."""
+    from vorbis_amd import VamdError
+    checks = bad = 0
+    for ch, rate, q in ((2, 44100, 0.4), (2, 44100, 0.1), (6, 44100, 0.3), (1, 22050, 0.5)):
+        e = ref.RefEncoder(ch, rate, q)
+        an = vorbis_amd.Analyzer(e.pack_setup(), 0)
+        rng = np.random.default_rng(ch * 1000 + int(q * 10))
+        for W in (1, 0):
+            n = e.blocksize(W)
+            x, lW, nW, want = hostile_batch(rng, nb, ch, n, W)
+            o = an.analyze(torch.from_numpy(x).cuda(), W=W, lW=lW, nW=nW, blocktype=1 if W else 0,
+                           want=("ampmax_out", "packets", "packet_bits", "status"))
+            torch.cuda.synchronize()
+            st = o["status"].cpu().numpy()
+            rows, bits, amps = o["packets"].cpu().numpy(), o["packet_bits"].cpu().numpy(), o["ampmax_out"].cpu().numpy()
+            checks += 1
+            if not np.array_equal(st, want):
+                bad += 1
+                log("HOSTILE status differs", (ch, rate, q), "W", W, np.argwhere(st != want)[:8].tolist())
+            counted = an.input_status()
+            checks += 1
+            if counted != (int(want.sum()), 0) or an.input_status() != (0, 0):
+                bad += 1
+                log("HOSTILE count differs", (ch, rate, q), "W", W, counted, int(want.sum()))
+            for k in range(nb):
+                if want[k].any():
+                    continue   # (deterministic but unspecified)
+                a = e.tap_block(x[k], int(lW[k]), W, int(nW[k]), 1 if W else 0, -9999.0)
+                checks += 1
+                if not (vorbis_amd.packet_bytes(rows[k], bits[k]) == a["packet"] and
+                        np.float32(amps[k]) == np.float32(a["ampmax_out"])):
+                    bad += 1
+                    log("HOSTILE clean block differs", (ch, rate, q), "W", W, "block", k)
+            # the host-pointer entry point says so itself
+            for k in (0, 1, 3):
+                checks += 1
+                try:
+                    an.analyze_block(x[k], int(lW[k]), W, int(nW[k]), 1 if W else 0, -9999.0)
+                    ok = not want[k].any()
+                except VamdError as err:
+                    ok = bool(want[k].any()) and err.code == vorbis_amd.VAMD_EINVAL
+                if not ok:
+                    bad += 1
+                    log("HOSTILE analyze_block verdict wrong", (ch, rate, q), "W", W, "block", k)
+        # the detector: clean steps are the reference's, a NaN is an error, and the state survives for the next stream
+        steps = 40
+        stream = ((rng.random((ch, 64 * (steps + 2))) - 0.5) * 0.2).astype(np.float32)
+        checks += 1
+        try:
+            poisoned = stream.copy()
+            poisoned[ch - 1, 777] = np.nan
+            an.envelope_search(poisoned, steps)
+            bad += 1
+            log("HOSTILE detector accepted a NaN", (ch, rate, q))
+        except VamdError as err:
+            if err.code != vorbis_amd.VAMD_EINVAL:
+                bad += 1
+                log("HOSTILE detector: wrong error", err)
+        an.close()
+        log("hostile %d ch %d Hz q %.1f done, %d checks, %d failures" % (ch, rate, q, checks, bad))
+    return checks, bad

@@ -1,0 +1,67 @@
+"""GPU suite: the input domain (include/vorbis_amd.h, "Input domain").
+
+Inside the domain -- every finite sample up to ~3e7 x full scale, denormals and signed zeros included -- results are
+the reference's bit for bit: those signal kinds are part of every soak run (tests/soak_lib.py kinds 8-11,
+tests/test_gpu_soak.py).  Outside it (NaN, +-Inf, 1e30 ...) the reference's own result is not defined by C; this
+suite checks that the library REPORTS such blocks through every door -- the per-block status tensor, the context's
+counter, VAMD_EINVAL from the host-pointer calls, OV_EINVAL out of vorbis_analysis() in the drop-in -- that it neither
+crashes nor hangs, and that every other block of the same batch / the next stream is untouched."""
+import numpy as np
+import pytest
+
+from oracle import ref
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built (needs /root/reference at build time)")]
+
+
+def test_blocks_outside_the_domain_are_reported_and_isolated():
+    from tests import soak_lib
+    lines = []
+    checks, bad = soak_lib.run_hostile(48, log=lambda *a: lines.append(" ".join(str(x) for x in a)))
+    assert checks > 500
+    assert bad == 0, "\n".join(lines[-20:])
+
+
+def test_mdct_only_path_propagates_like_ieee():
+    """vamd_mdct_forward_batch is plain float arithmetic with no integer conversion: non-finite samples propagate as
+    IEEE says, as they do in lib/mdct.c.  Clean frames of the same batch stay bit-exact; in a poisoned frame the
+    positions of non-finite outputs agree with the reference (NaN payloads and signs are not compared: x86 makes
+    0xffc00000 where gfx950 makes 0x7fc00000)."""
+    import torch
+    import vorbis_amd
+    e = ref.RefEncoder(2, 44100, 0.4)
+    an = vorbis_amd.Analyzer(e.pack_setup(), 0)
+    rng = np.random.default_rng(5)
+    x = (rng.random((64, 2048), dtype=np.float32) - 0.5)
+    x[3, 100] = np.nan
+    x[10, 1500] = np.inf
+    x[17] *= np.float32(1e-41)        # a frame of denormals
+    x[18, ::2] = -0.0
+    x[19] *= np.float32(3e30)         # finite in, partly Inf out? (products overflow nowhere: the MDCT only adds and scales)
+    got = an.mdct_forward(1, torch.from_numpy(x).cuda()).cpu().numpy()
+    for k in range(64):
+        want = e.mdct_forward(1, x[k])
+        fin = np.isfinite(want)
+        assert np.array_equal(fin, np.isfinite(got[k])), k
+        assert np.array_equal(np.isnan(want), np.isnan(got[k])), k
+        assert np.array_equal(want[fin].view(np.uint32), got[k][fin].view(np.uint32)), k
+        inf = np.isinf(want)
+        assert np.array_equal(want[inf], got[k][inf]), k
+    an.close()
+
+
+@pytest.mark.skipif(not ref.hybrid_available(), reason="oracle/_ref/libvorbis_hybrid.so not built")
+def test_dropin_returns_ov_einval_and_the_next_stream_is_clean():
+    """Through the hybrid libvorbis: a stream with a NaN in it makes vorbis_analysis() return OV_EINVAL (-131) -- the
+    encode ends, as for any libvorbis error -- and an encoder opened afterwards emits the reference's packets."""
+    rng = np.random.default_rng(9)
+    pcm = (rng.random((2, 44100), dtype=np.float32) - 0.5)
+    poisoned = pcm.copy()
+    poisoned[1, 30000] = np.nan
+    with pytest.raises(RuntimeError, match="-131"):
+        ref.RefEncoder(2, 44100, 0.4, hybrid=True).encode_stream(poisoned)
+    want = ref.RefEncoder(2, 44100, 0.4).encode_stream(pcm)
+    got = ref.RefEncoder(2, 44100, 0.4, hybrid=True).encode_stream(pcm)
+    assert len(want) == len(got) > 20
+    assert all(a["packet"] == b["packet"] for a, b in zip(want, got))

@@ -21,7 +21,8 @@ EXPORTED_SYMBOLS = ["vamd_create", "vamd_destroy", "vamd_last_error", "vamd_set_
                     "vamd_packet_capacity", "vamd_encode_block", "vamd_submaps", "vamd_residue_offset", "vamd_analyze_streams_mixed",
                     "vamd_plan_streams", "vamd_gather_blocks", "vamd_plan_fetch",
                     "vamd_batcher_create", "vamd_batcher_destroy", "vamd_batcher_attach", "vamd_batcher_detach",
-                    "vamd_batcher_encode_block", "vamd_batcher_last_error", "vamd_batcher_stats", "vamd_batcher_context"]
+                    "vamd_batcher_encode_block", "vamd_batcher_last_error", "vamd_batcher_stats", "vamd_batcher_context",
+                    "vamd_input_status"]
 PACKETBLOBS = 15
 
 _vp = C.c_void_p
@@ -45,7 +46,8 @@ MAX_CH = 8
 
 
 class _IO(C.Structure):
-    _fields_ = [(k, _vp) for k in _IO_FIELDS] + [("packets", _vp), ("packet_bits", _vp), ("packet_stride", C.c_int64)]
+    _fields_ = [(k, _vp) for k in _IO_FIELDS] + [("packets", _vp), ("packet_bits", _vp), ("packet_stride", C.c_int64),
+                                                 ("status", _vp)]
 
 
 class _MIO(C.Structure):  # vamd_managed_io
@@ -95,6 +97,7 @@ def load_library():
     L.vamd_last_error.argtypes = [_vp]
     L.vamd_last_error.restype = C.c_char_p
     L.vamd_set_stream.argtypes = [_vp, _vp]
+    L.vamd_input_status.argtypes = [_vp, C.POINTER(C.c_long), C.POINTER(C.c_long)]
     L.vamd_reserve.argtypes = [_vp, C.c_int, C.c_long]
     L.vamd_channels.argtypes = [_vp]
     L.vamd_blocksize.argtypes = [_vp, C.c_int]
@@ -223,6 +226,16 @@ class Analyzer:
     def reserve(self, W, max_blocks):
         self._check(self.L.vamd_reserve(self.h, W, max_blocks))
 
+    def input_status(self):
+        """vamd_input_status(): synchronise, then (channel-blocks, detector steps) issued since the last call that
+        were outside the input domain (a NaN / Inf sample, or one beyond ~3e7 x full scale); resets the counts.
+        (0, 0) means every result since then is the reference's, bit for bit."""
+        a, b = C.c_long(0), C.c_long(0)
+        r = self.L.vamd_input_status(self.h, C.byref(a), C.byref(b))
+        if r not in (VAMD_OK, VAMD_EINVAL):
+            self._check(r)
+        return int(a.value), int(b.value)
+
     # mdct_forward(lookup, in, out) batched -- BASELINE config 2
     def mdct_forward(self, W, frames, out=None):
         t = self.torch
@@ -288,6 +301,8 @@ class Analyzer:
                 o[k] = t.zeros((nb, self.packet_capacity(W)), dtype=t.uint8, device=dev)
             elif k == "packet_bits":
                 o[k] = t.zeros((nb,), dtype=t.int32, device=dev)
+            elif k == "status":      # 1 = the channel-block was outside the input domain (vorbis_amd.h)
+                o[k] = t.zeros((nb, ch), dtype=t.uint8, device=dev)
             else:
                 raise KeyError(k)
         return o
@@ -325,7 +340,7 @@ class Analyzer:
             return t.float32
         if k == "res_entries":
             return t.int16
-        if k == "packets":
+        if k in ("packets", "status"):
             return t.uint8
         return t.int32
 
@@ -499,6 +514,11 @@ class Analyzer:
         """The planned blocks of size class W copied out of `streams` into [nblocks[W], ch, blocksize[W]]."""
         t = self.torch
         n = self.blocksizes[W]
+        # the layout the plan was made for: float32, on this device, contiguous [nstreams, ch, nsamples], 16-byte rows
+        self._need_tensor(streams, t.float32, "streams")
+        self._need(streams.dim() == 3 and streams.shape[1] == self.channels and streams.shape[0] == plan.nstreams,
+                   "streams must be the [%d, %d, nsamples] tensor the plan was made from" % (plan.nstreams, self.channels))
+        self._need(streams.shape[2] % 4 == 0, "nsamples must be a multiple of 4 (16-byte lanes)")
         if out is None:
             out = t.empty((plan.nblocks[W], self.channels, n), dtype=t.float32, device=self._dev())
         else:

@@ -46,7 +46,7 @@ namespace vamd {
 template <int LOGS>
 VAMD_DEV void env_spectrum_wave(const EnvP &E, const float *__restrict__ pcm, int count, float *A, float *Wk,
                                 float *spec, float *__restrict__ near_out, float *__restrict__ raw_out,
-                                PhaseClock &pc) {
+                                PhaseClock &pc, unsigned int *bad = nullptr) {
   const int n = E.mdct.n, n2 = n >> 1, ln = E.mdct.log2n;
   WAVE_FOR(k, n << LOGS) {
     const int t = k >> ln, i = k & (n - 1);
@@ -59,14 +59,18 @@ VAMD_DEV void env_spectrum_wave(const EnvP &E, const float *__restrict__ pcm, in
     const float v0 = spec[t * n2], v1 = spec[t * n2 + 1], v2 = spec[t * n2 + 2];
     near_out[t] = (float)((double)(v0 * v0) + (.7 * (double)v1) * (double)v1 + (.2 * (double)v2) * (double)v2);
   }
+  float top = -1e30f;  // the input-domain test (VAMD_ENV_LIMIT_DB, vamd_params.h): dB values are finite whatever the samples were
   WAVE_FOR(k, (n >> 2) << LOGS) {
     const int t = k >> (ln - 2), kk = k & ((n >> 2) - 1);
     if (t < count) {
       const F2 z = *(const F2 *)(spec + t * n2 + 2 * kk);
       const float val = z.x * z.x + z.y * z.y;
-      raw_out[t * (n >> 2) + kk] = todB(val) * .5f;
+      const float dB = todB(val) * .5f;
+      raw_out[t * (n >> 2) + kk] = dB;
+      top = dB > top ? dB : top;
     }
   }
+  if (bad && wave_any(top > VAMD_ENV_LIMIT_DB) && LANE == 0) lds_or_global_count(bad);
   WAVE_SYNC();
 }
 

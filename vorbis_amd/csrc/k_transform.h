@@ -961,7 +961,7 @@ VAMD_DEV const float *transform_spectra(const XformP &P, float *A, float *B, flo
 // THIS WAVE (every lane holds it): the caller combines the team's waves.
 template <int LOGN = 0, class Team = WaveTeam>
 VAMD_DEV float transform_logfft(const XformP &P, const float *spec, float *__restrict__ logfft_out, PhaseClock &pc,
-                                const Team &tm = Team()) {
+                                const Team &tm = Team(), float *raw_max = nullptr) {
   const int n = LOGN ? (1 << LOGN) : P.n, n2 = n >> 1;
   const float scale = 4.f / n;
   const float scale_dB = todB_345(scale);
@@ -981,7 +981,11 @@ VAMD_DEV float transform_logfft(const XformP &P, const float *spec, float *__res
     }
     if (logfft_out) ((F4 *)logfft_out)[q] = f4_make(v);
   }
+  // (every v[c] is finite whatever the samples were -- todB() converts the BITS of its argument, so a NaN or Inf
+  // spectrum value becomes a large finite dB figure -- hence fmaxf here and in wave_max is the reference's
+  // `if(temp>local_ampmax[i])` compare, lib/mapping0.c:343, on every input)
   amp = wave_max(amp);
+  if (raw_max) *raw_max = amp;  // before the clamp: the input-domain test (VAMD_INPUT_LIMIT_DB)
   if (amp > 0.f) amp = 0.f;  // lib/mapping0.c:345 (the clamp commutes with the maximum over the team's waves)
   tm.sync();
   pc.mark(7);
@@ -991,9 +995,9 @@ VAMD_DEV float transform_logfft(const XformP &P, const float *spec, float *__res
 template <int LOGN = 0, class Team = WaveTeam>
 VAMD_DEV float transform_block(const XformP &P, float *A, float *B, float *__restrict__ mdct_out,
                                float *__restrict__ logmdct_out, float *__restrict__ logfft_out, PhaseClock &pc,
-                               const Team &tm = Team()) {
+                               const Team &tm = Team(), float *raw_max = nullptr) {
   const float *spec = transform_spectra<LOGN, Team>(P, A, B, mdct_out, logmdct_out, pc, tm);
-  return transform_logfft<LOGN, Team>(P, spec, logfft_out, pc, tm);
+  return transform_logfft<LOGN, Team>(P, spec, logfft_out, pc, tm, raw_max);
 }
 
 // log2 n when the size-specialised transforms apply -- a power of two in [256, 4096] whose FFT factors are the ones

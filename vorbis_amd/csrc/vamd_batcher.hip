@@ -64,7 +64,8 @@ struct vamd_batcher {
   int max_batch = 0, max_wait_us = 0;
   std::mutex m;
   std::condition_variable cv_lead;  // the collecting leader sleeps here
-  bool collecting = false;          // a leader is gathering (at most one at a time; the others are running theirs)
+  int gatherers = 0;                // leaders gathering right now (a re-leading or appointed leader can start while another still waits)
+  long in_flight = 0;               // blocks taken into batches that are on the GPU: their streams cannot submit meanwhile
   int leaders = 0;                  // leaders at work, gathering or running: <= lanes.size()
   std::vector<Request *> pending[2];
   int attached = 0;       // streams that announced themselves (vamd_batcher_attach)
@@ -78,10 +79,18 @@ static size_t al16(size_t x) { return (x + 15) & ~(size_t)15; }
 // one batch of blocks of size class W on lane L; called by a leader with the mutex NOT held
 static int run_batch(vamd_batcher *b, Lane &L, int W, Request *const *reqs, size_t nb, std::string *err) {
   const size_t ch = (size_t)b->ch, n = (size_t)b->bs[W], row = (size_t)b->pkcap[W];
-  // arena: [pcm | lW | nW | blocktype | ampmax_in || ampmax_out | bits | packets]
+  // arena: [pcm | lW | nW | blocktype | ampmax_in || ampmax_out | bits | input status | packets]
   const size_t o_pcm = 0, o_lW = al16(nb * ch * n * 4), o_nW = al16(o_lW + nb * 4), o_bt = al16(o_nW + nb * 4),
                o_ain = al16(o_bt + nb * 4), o_out = al16(o_ain + nb * 4), o_aout = o_out, o_bits = al16(o_aout + nb * 4),
-               o_pk = al16(o_bits + nb * 4), total = al16(o_pk + nb * row);
+               o_st = al16(o_bits + nb * 4), o_pk = al16(o_st + nb * ch), total = al16(o_pk + nb * row);
+  // the leader is an application thread inside vorbis_analysis(): its current device is put back on every way out
+  struct DeviceRestore {
+    int prev = -1;
+    DeviceRestore() { (void)hipGetDevice(&prev); }
+    ~DeviceRestore() {
+      if (prev >= 0) (void)hipSetDevice(prev);
+    }
+  } device_restore;
   hipError_t e = hipSetDevice(b->device);
   if (e == hipSuccess && L.stage_bytes < total) {
     if (L.h_stage) (void)hipHostFree(L.h_stage);
@@ -126,6 +135,7 @@ static int run_batch(vamd_batcher *b, Lane &L, int W, Request *const *reqs, size
   io.packets = ds + o_pk;
   io.packet_bits = (int32_t *)(ds + o_bits);
   io.packet_stride = (int64_t)row;
+  io.status = ds + o_st;
   int r = vamd_analyze_batch(L.ctx, &d, &io, VAMD_LEVEL_FULL);
   if (r) {
     *err = std::string("batcher analyze: ") + vamd_last_error(L.ctx);
@@ -139,6 +149,12 @@ static int run_batch(vamd_batcher *b, Lane &L, int W, Request *const *reqs, size
   }
   for (size_t k = 0; k < nb; k++) {
     Request &q = *reqs[k];
+    bool outside = false;  // this block's input was outside the domain (include/vorbis_amd.h): its own error, nobody else's
+    for (size_t c = 0; c < ch; c++) outside |= hs[o_st + k * ch + c] != 0;
+    if (outside) {
+      q.status = VAMD_EINVAL;
+      continue;
+    }
     const int32_t bits = ((const int32_t *)(hs + o_bits))[k];
     const size_t bytes = ((size_t)bits + 7) / 8;
     if (bits < 0 || bytes > row || bytes > (size_t)q.packet_cap) {
@@ -250,8 +266,8 @@ int vamd_batcher_encode_block(vamd_batcher *b, const float *const *pcm, int lW, 
   rq.ampmax_out = ampmax_out, rq.packet = packet, rq.packet_cap = packet_cap, rq.packet_bits = packet_bits;
   std::unique_lock<std::mutex> lk(b->m);
   b->pending[W].push_back(&rq);
-  if (b->collecting) {
-    b->cv_lead.notify_one();  // the gathering leader counts it
+  if (b->gatherers) {
+    b->cv_lead.notify_all();  // the gathering leaders count it
   } else if (b->leaders < (int)b->lanes.size()) {
     b->leaders++;  // nobody is gathering and a lane is free: we lead
     rq.lead = true;
@@ -261,11 +277,13 @@ int vamd_batcher_encode_block(vamd_batcher *b, const float *const *pcm, int lW, 
     while (!rq.done && !rq.lead) rq.cv.wait(lk);
     if (rq.done) break;
     // ---- we lead: gather (one leader at a time), then run the batch on a free lane, then hand the results back
-    b->collecting = true;
+    b->gatherers++;
     const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(b->max_wait_us);
     for (;;) {
+      // everybody who can still submit has: the attached streams less those whose block is in a running batch
       const size_t have = b->pending[0].size() + b->pending[1].size();
-      if (have >= (size_t)b->max_batch || (b->attached > 0 && have >= (size_t)b->attached)) break;
+      const long free_streams = (long)b->attached - b->in_flight;
+      if (have >= (size_t)b->max_batch || (b->attached > 0 && have > 0 && (long)have >= free_streams)) break;
       if (b->cv_lead.wait_until(lk, deadline) == std::cv_status::timeout) break;
     }
     // the size class with more blocks waiting goes first (ours, if it is a tie)
@@ -283,7 +301,7 @@ int vamd_batcher_encode_block(vamd_batcher *b, const float *const *pcm, int lW, 
         lane = &L;
         break;
       }
-    b->collecting = false;
+    b->gatherers--;
     if (take.empty() || !lane) {
       // nothing left to run (an appointed leader that woke up late finds everything, its own block included, in
       // another leader's batch): step down and wait for the block like everybody else
@@ -293,6 +311,8 @@ int vamd_batcher_encode_block(vamd_batcher *b, const float *const *pcm, int lW, 
       continue;
     }
     lane->in_use = true;  // (there is one: leaders <= lanes, and every other leader holds at most one)
+    b->in_flight += (long)take.size();
+    if (b->gatherers) b->cv_lead.notify_all();  // fewer streams are left to wait for
     // what is still pending (the other size class, latecomers) gets its own leader at once if a lane is free
     if (b->leaders < (int)b->lanes.size()) {
       Request *next = nullptr;
@@ -315,6 +335,7 @@ int vamd_batcher_encode_block(vamd_batcher *b, const float *const *pcm, int lW, 
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     lk.lock();
     lane->in_use = false;
+    b->in_flight -= (long)take.size();
     if (r) b->err = err;
     b->run_seconds += dt;
     b->nbatches++;
@@ -328,7 +349,7 @@ int vamd_batcher_encode_block(vamd_batcher *b, const float *const *pcm, int lW, 
   // ---- our block is back: pass the lead to the owner of the oldest pending block that has none, if any
   if (rq.lead) {
     Request *next = nullptr;
-    if (!b->collecting)
+    if (!b->gatherers)
       for (int w = 0; w < 2 && !next; w++)
         for (Request *t : b->pending[w])
           if (!t->lead) {

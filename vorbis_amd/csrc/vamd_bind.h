@@ -185,6 +185,12 @@ inline int build_image(const void *blob_v, size_t bytes, std::vector<unsigned ch
       *err = "psy octave geometry out of range";
       return VAMD_EINVAL;
     }
+    // seed_chase's ring of VAMD_RING stack entries and its "an entry a ring-length below the top is final" rule hold
+    // for linesper <= VAMD_RING (k_tone.h); libvorbisenc sets 8 everywhere
+    if (t.eighth_octave_lines > 16) {
+      *err = "eighth_octave_lines above 16 is outside the covered path (seed_chase's ring holds 16 entries)";
+      return VAMD_EIMPL;
+    }
     // tables the kernels use as indices: octave[] is a non-decreasing line position inside the seed vector
     // (seed_loop / max_seeds, lib/psy.c:417-545); bark[] packs window edges inside the block or its mirror
     // (bark_noise_hybridmp, lib/psy.c:606-656)

@@ -172,8 +172,14 @@ __global__ __launch_bounds__(64 * VAMD_XF_WAVES) void k_transform(XformP G, int 
       lW = d_lW(d, blk), nW = d_nW(d, blk);
       pcm_fetch(tile, pcm + (cb + cstride) * n, n, tm);
     }
-    const float amp = transform_block<LOGN>(P, L.A, L.B, mdct_raw + cb * n2, logmdct ? logmdct + cb * n2 : nullptr, logfft + cb * n2, pc);
-    if (LANE == 0) local_ampmax[cb] = amp;
+    float raw;
+    const float amp = transform_block<LOGN>(P, L.A, L.B, mdct_raw + cb * n2, logmdct ? logmdct + cb * n2 : nullptr, logfft + cb * n2, pc, tm, &raw);
+    if (LANE == 0) {
+      local_ampmax[cb] = amp;
+      const bool bad = raw > VAMD_INPUT_LIMIT_DB;  // outside the input domain: a non-finite or absurdly large sample
+      d.status[cb] = bad;
+      if (bad) atomicAdd(d.bad, 1u);
+    }
   }
   pc.flush();
 }
@@ -639,7 +645,7 @@ __global__ void k_env_prolog(int ch, long nstreams, long nsteps, const vamd_enve
 __global__ __launch_bounds__(64 * VAMD_ENV_WAVES) void k_env_spectrum(EnvP E, int ch, long nstreams, long nsteps,
                                                                       const float *__restrict__ pcm, long stream_stride,
                                                                       long channel_stride, float *__restrict__ near,
-                                                                      float *__restrict__ raw) {
+                                                                      float *__restrict__ raw, unsigned int *bad) {
   const int n = E.mdct.n, n2 = n >> 1, wave = threadIdx.x >> 6;
   const int per_step = n + n2 + VAMD_PW_SIZE(n2) + n2;
   float *A = (float *)vamd_smem + (size_t)wave * per_step * VAMD_ENV_STEPS;
@@ -654,7 +660,7 @@ __global__ __launch_bounds__(64 * VAMD_ENV_WAVES) void k_env_spectrum(EnvP E, in
     const int count = nsteps - j < VAMD_ENV_STEPS ? (int)(nsteps - j) : VAMD_ENV_STEPS;
     env_spectrum_wave<VAMD_ENV_LOGS>(E, pcm + s * stream_stride + c * channel_stride + j * E.searchstep, count, A, Wk,
                                      spec, near + sc * (VAMD_VE_NEAR_HIST + nsteps) + VAMD_VE_NEAR_HIST + j,
-                                     raw + (sc * nsteps + j) * VAMD_VE_SPREAD, pc);
+                                     raw + (sc * nsteps + j) * VAMD_VE_SPREAD, pc, bad);
   }
 }
 
@@ -803,6 +809,7 @@ struct vamd_ctx {
   Bound B;                 // parameter structs bound to the HBM image
   unsigned char *d_image = nullptr;
   Bound *d_bound = nullptr;  // c->B in HBM: kernels that would otherwise carry several parameter structs in SGPRs read it
+  unsigned int *d_bad = nullptr;  // [0] channel-blocks, [1] detector steps outside the input domain since vamd_input_status() (behind d_bound)
   size_t image_bytes = 0;
   std::string err;
   // workspace, grown on demand (vamd_reserve to pre-size)
@@ -810,7 +817,7 @@ struct vamd_ctx {
          WS_NONZERO, WS_LOCAL, WS_AMPIN, WS_AMPGLOB, WS_PCM, WS_SEED, WS_SURV, WS_NSURV, WS_MISC,
          WS_ENV_NEAR, WS_ENV_RAW, WS_ENV_AMP, WS_ENV_BITS, WS_ENV_STAGE, WS_M_ILOGMASK, WS_M_STAGE,
          WS_RES_CLASS, WS_RES_ENTRIES, WS_RES_COUNT, WS_COUPLE_STATE,
-         WS_PLAN_FLAGS, WS_PLAN_BLOCKS, WS_PLAN_COUNTS, WS_PLAN_BASE, WS_PLAN_DESC, WS_PLAN_ORDER, WS_COUNT };
+         WS_PLAN_FLAGS, WS_PLAN_BLOCKS, WS_PLAN_COUNTS, WS_PLAN_BASE, WS_PLAN_DESC, WS_PLAN_ORDER, WS_STATUS, WS_COUNT };
   DevBuf ws[2][WS_COUNT];  // per size class (a mixed stream keeps both batches in flight)
   // pinned staging for the per-block host API
   void *h_stage = nullptr;
@@ -952,7 +959,9 @@ int vamd_create(vamd_ctx **out, const void *setup_blob, size_t blob_bytes, int d
   }
   c->image_bytes = image.size();
   bind_params(image, doff, derived, c->d_image, &c->B);
-  if (hipMalloc((void **)&c->d_bound, sizeof(Bound)) != hipSuccess ||
+  const size_t bound_bytes = (sizeof(Bound) + 15) & ~(size_t)15;
+  if (hipMalloc((void **)&c->d_bound, bound_bytes + 16) != hipSuccess ||
+      hipMemset(c->d_bound, 0, bound_bytes + 16) != hipSuccess ||
       hipMemcpy(c->d_bound, &c->B, sizeof(Bound), hipMemcpyHostToDevice) != hipSuccess) {
     fprintf(stderr, "vamd_create: HIP failure uploading the parameter block\n");
     if (c->d_bound) (void)hipFree(c->d_bound);
@@ -964,6 +973,7 @@ int vamd_create(vamd_ctx **out, const void *setup_blob, size_t blob_bytes, int d
     delete c;
     return VAMD_EFAULT;
   }
+  c->d_bad = (unsigned int *)((unsigned char *)c->d_bound + bound_bytes);
   if (caller_device >= 0 && caller_device != c->device) (void)hipSetDevice(caller_device);
   *out = c;
   return VAMD_OK;
@@ -991,6 +1001,20 @@ const char *vamd_last_error(const vamd_ctx *c) { return c ? c->err.c_str() : "nu
 int vamd_set_stream(vamd_ctx *c, void *s) {
   if (!c) return VAMD_EINVAL;
   c->stream = (hipStream_t)s;
+  return VAMD_OK;
+}
+
+// Did any block (or detector step) issued on this context since the last call fall outside the input domain?
+int vamd_input_status(vamd_ctx *c, long *bad_channel_blocks, long *bad_detector_steps) {
+  DeviceGuard dev_guard(c);
+  if (!c) return VAMD_EINVAL;
+  unsigned int h[2] = {0, 0};
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemcpy(h, c->d_bad, sizeof(h), hipMemcpyDeviceToHost));
+  if (h[0] | h[1]) HIP_TRY(c, hipMemset(c->d_bad, 0, sizeof(h)));
+  if (bad_channel_blocks) *bad_channel_blocks = (long)h[0];
+  if (bad_detector_steps) *bad_detector_steps = (long)h[1];
+  if (h[0] | h[1]) return fail(c, VAMD_EINVAL, "input outside the domain: a non-finite sample, or one beyond ~3e7 x full scale");
   return VAMD_OK;
 }
 
@@ -1052,6 +1076,7 @@ struct WsPlan {
   int32_t *nsurv;
   ilog_t *ilogmask;  // 16-bit, workspace only (the int32 tap is widened from it: k_widen_ilog)
   int32_t *iwork, *posts, *post_valid, *nonzero;
+  unsigned char *status;
 };
 
 // Resolve every inter-stage tensor: the caller's buffer when given, otherwise workspace.
@@ -1073,6 +1098,7 @@ static int plan(vamd_ctx *c, int W, long nb, const vamd_batch_io *io, int level,
   PICK(local, io ? io->local_ampmax : nullptr, WS_LOCAL, (size_t)nb * ch * 4);
   PICK(ampglob, io ? io->ampmax_out : nullptr, WS_AMPGLOB, (size_t)nb * 4);
   PICK(ampin, (float *)nullptr, WS_AMPIN, (size_t)nb * 4);
+  PICK(status, io ? io->status : nullptr, WS_STATUS, (size_t)nb * ch);
   if (level >= VAMD_LEVEL_PSY) {
     PICK(noise, io ? io->noise : nullptr, WS_NOISE, per);
     PICK(tone, io ? io->tone : nullptr, WS_TONE, per);
@@ -1211,6 +1237,8 @@ static int prepare_run(vamd_ctx *c, const vamd_batch_desc *desc, const vamd_batc
   d.u_blocktype = desc->uniform_blocktype;
   d.u_ampmax_in = desc->uniform_ampmax_in;
   d.dbg = c->d_dbg;
+  d.status = R->p.status;
+  d.bad = c->d_bad;
   return VAMD_OK;
 }
 
@@ -1518,6 +1546,7 @@ int vamd_analyze_block_managed(vamd_ctx *c, const float *const *pcm, int lW, int
   io.pcm = (const float *)(ds + o_pcm);
   io.mdct = (float *)(ds + o_mdct);
   io.ampmax_out = (float *)(ds + o_amp);
+  io.status = ds + o_amp + 4;
   vamd_managed_io m;
   memset(&m, 0, sizeof(m));
   m.posts = (int32_t *)(ds + o_posts);
@@ -1533,6 +1562,8 @@ int vamd_analyze_block_managed(vamd_ctx *c, const float *const *pcm, int lW, int
   if (r) return r;
   HIP_TRY(c, hipMemcpyAsync(hs + o_mdct, ds + o_mdct, total - o_mdct, hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
+  for (size_t i = 0; i < ch; i++)
+    if (hs[o_amp + 4 + i]) return fail(c, VAMD_EINVAL, "input outside the domain: a non-finite sample, or one beyond ~3e7 x full scale");
   if (mdct) memcpy(mdct, hs + o_mdct, ch * n2 * 4);
   if (ampmax_out) memcpy(ampmax_out, hs + o_amp, 4);
   if (posts) memcpy(posts, hs + o_posts, K * ch * VAMD_POSTS_STRIDE * 4);
@@ -1686,6 +1717,7 @@ int vamd_analyze_block_res(vamd_ctx *c, const float *const *pcm, int lW, int W, 
   io.post_valid = (int32_t *)(ds + o_valid);
   io.nonzero = (int32_t *)(ds + o_nz);
   io.ampmax_out = (float *)(ds + o_amp);
+  io.status = ds + o_amp + 4;  // ch <= 8 bytes behind the float, inside its 16-byte slot
   if (want_res) {
     io.res_class = (int32_t *)(ds + o_rcls);
     io.res_count = (int32_t *)(ds + o_rcnt);
@@ -1695,6 +1727,8 @@ int vamd_analyze_block_res(vamd_ctx *c, const float *const *pcm, int lW, int W, 
   if (r) return r;
   HIP_TRY(c, hipMemcpyAsync(hs + o_mdct, ds + o_mdct, total - o_mdct, hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
+  for (int i = 0; i < ch; i++)
+    if (hs[o_amp + 4 + i]) return fail(c, VAMD_EINVAL, "input outside the domain: a non-finite sample, or one beyond ~3e7 x full scale");
   if (mdct) memcpy(mdct, hs + o_mdct, (size_t)ch * n2 * 4);
   if (logmask) memcpy(logmask, hs + o_mask, (size_t)ch * n2 * 4);
   if (iwork) memcpy(iwork, hs + o_iwork, (size_t)ch * n2 * 4);
@@ -1761,6 +1795,7 @@ int vamd_encode_block(vamd_ctx *c, const float *const *pcm, int lW, int W, int n
   memset(&io, 0, sizeof(io));
   io.pcm = (const float *)(ds + o_pcm);
   io.ampmax_out = (float *)(ds + o_amp);
+  io.status = ds + o_amp + 4;  // ch <= 8 bytes behind the float, inside its 16-byte slot
   if (managed) {
     vamd_managed_io m;
     memset(&m, 0, sizeof(m));
@@ -1781,6 +1816,8 @@ int vamd_encode_block(vamd_ctx *c, const float *const *pcm, int lW, int W, int n
   if (r) return r;
   HIP_TRY(c, hipMemcpyAsync(hs + o_amp, ds + o_amp, o_back - o_amp, hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
+  for (size_t i = 0; i < ch; i++)
+    if (hs[o_amp + 4 + i]) return fail(c, VAMD_EINVAL, "input outside the domain: a non-finite sample, or one beyond ~3e7 x full scale");
   if (ampmax_out) memcpy(ampmax_out, hs + o_amp, 4);
   memcpy(packet_bits, hs + o_bits, K * 4);
   for (size_t k = 0; k < K; k++) {
@@ -1810,8 +1847,9 @@ int vamd_envelope_geometry(const vamd_ctx *c, int *winlength, int *searchstep) {
   return VAMD_OK;
 }
 
-int vamd_envelope_search_batch(vamd_ctx *c, const float *pcm, long stream_stride, long channel_stride, long nstreams,
-                               long nsteps, vamd_envelope_state *states, unsigned char *ret) {
+// `bad`: the word (device) that counts detector steps outside the input domain
+static int envelope_search_batch(vamd_ctx *c, const float *pcm, long stream_stride, long channel_stride, long nstreams,
+                                 long nsteps, vamd_envelope_state *states, unsigned char *ret, unsigned int *bad) {
   DeviceGuard dev_guard(c);
   if (!c) return VAMD_EINVAL;
   if (nstreams < 0 || nsteps < 0) return fail(c, VAMD_EINVAL, "negative stream / step count");
@@ -1840,7 +1878,7 @@ int vamd_envelope_search_batch(vamd_ctx *c, const float *pcm, long stream_stride
     const long cap = (long)c->num_cus * 8;
     const size_t lds = (size_t)VAMD_ENV_WAVES * VAMD_ENV_STEPS * (n + n2 + VAMD_PW_SIZE(n2) + n2) * 4;
     hipLaunchKernelGGL(k_env_spectrum, dim3((unsigned)(groups < cap ? groups : cap)), dim3(64 * VAMD_ENV_WAVES), lds, s, E,
-                       ch, nstreams, nsteps, pcm, stream_stride, channel_stride, near, raw);
+                       ch, nstreams, nsteps, pcm, stream_stride, channel_stride, near, raw, bad);
   }
   {
     const long t = nsc * nsteps * 8;
@@ -1859,6 +1897,11 @@ int vamd_envelope_search_batch(vamd_ctx *c, const float *pcm, long stream_stride
   return VAMD_OK;
 }
 
+int vamd_envelope_search_batch(vamd_ctx *c, const float *pcm, long stream_stride, long channel_stride, long nstreams,
+                               long nsteps, vamd_envelope_state *states, unsigned char *ret) {
+  return envelope_search_batch(c, pcm, stream_stride, channel_stride, nstreams, nsteps, states, ret, c ? c->d_bad + 1 : nullptr);
+}
+
 int vamd_envelope_search(vamd_ctx *c, const float *const *pcm, long nsteps, vamd_envelope_state *state,
                          unsigned char *ret) {
   DeviceGuard dev_guard(c);
@@ -1868,8 +1911,9 @@ int vamd_envelope_search(vamd_ctx *c, const float *const *pcm, long nsteps, vamd
   if (!pcm || !state || !ret) return fail(c, VAMD_EINVAL, "null pcm / state / ret");
   const int ch = c->B.channels, n = c->B.env.mdct.n, step = c->B.env.searchstep;
   const long len = (nsteps - 1) * step + n;  // samples per channel the steps read
+  // [pcm | state | bad (one word, zero on the way up) | ret]
   const size_t o_pcm = 0, o_state = ((size_t)ch * len * 4 + 15) & ~(size_t)15,
-               o_ret = o_state + ((sizeof(vamd_envelope_state) + 15) & ~(size_t)15),
+               o_bad = o_state + ((sizeof(vamd_envelope_state) + 15) & ~(size_t)15), o_ret = o_bad + 16,
                total = o_ret + (((size_t)nsteps + 15) & ~(size_t)15);
   if (c->h_stage_bytes < total) {
     if (c->h_stage) HIP_TRY(c, hipHostFree(c->h_stage));
@@ -1887,13 +1931,16 @@ int vamd_envelope_search(vamd_ctx *c, const float *const *pcm, long nsteps, vamd
     memcpy(hs + o_pcm + (size_t)i * len * 4, pcm[i], (size_t)len * 4);
   }
   memcpy(hs + o_state, state, sizeof(*state));
+  memset(hs + o_bad, 0, 16);
   hipStream_t s = c->stream;
   HIP_TRY(c, hipMemcpyAsync(ds, hs, o_ret, hipMemcpyHostToDevice, s));
-  r = vamd_envelope_search_batch(c, (const float *)(ds + o_pcm), (long)ch * len, len, 1, nsteps,
-                                 (vamd_envelope_state *)(ds + o_state), ds + o_ret);
+  r = envelope_search_batch(c, (const float *)(ds + o_pcm), (long)ch * len, len, 1, nsteps,
+                            (vamd_envelope_state *)(ds + o_state), ds + o_ret, (unsigned int *)(ds + o_bad));
   if (r) return r;
   HIP_TRY(c, hipMemcpyAsync(hs + o_state, ds + o_state, total - o_state, hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
+  if (*(const unsigned int *)(hs + o_bad))  // (the state is left as it was: the stream is over for this caller)
+    return fail(c, VAMD_EINVAL, "input outside the domain: a non-finite sample (include/vorbis_amd.h, Input domain)");
   memcpy(state, hs + o_state, sizeof(*state));
   memcpy(ret, hs + o_ret, (size_t)nsteps);
   return VAMD_OK;
@@ -1929,12 +1976,21 @@ int vamd_plan_streams(vamd_ctx *c, const float *pcm, long stream_stride, long ch
   if (B.nsteps && (r = vamd_envelope_search_batch(c, pcm, stream_stride, channel_stride, nstreams, B.nsteps, states, (unsigned char *)v_flags)))
     return r;
   hipStream_t s = c->stream;
-  if ((size_t)B.nsteps + 4 > c->lds_per_block) return fail(c, VAMD_EINVAL, "streams too long for one plan (their marks must fit a workgroup's LDS)");
-  hipLaunchKernelGGL(k_plan_streams, dim3((unsigned)nstreams), dim3(64), (size_t)((B.nsteps + 4 + 15) & ~15L), s, B, nstreams,
+  const size_t plan_lds = (size_t)((B.nsteps + 4 + 15) & ~15L);
+  if (plan_lds > c->lds_per_block) return fail(c, VAMD_EINVAL, "streams too long for one plan (their marks must fit a workgroup's LDS)");
+  // (above the default 64 KB of dynamic LDS the launch needs the opt-in, and a launch that fails leaves counts[] --
+  // which sizes everything below -- uninitialised: hence the checks straight after it)
+  HIP_TRY(c, hipFuncSetAttribute((const void *)k_plan_streams, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_per_block));
+  HIP_TRY(c, hipMemsetAsync(v_counts, 0, (size_t)nstreams * 2 * sizeof(int), s));
+  hipLaunchKernelGGL(k_plan_streams, dim3((unsigned)nstreams), dim3(64), plan_lds, s, B, nstreams,
                      (const unsigned char *)v_flags, (PlannedBlock *)v_blocks, (int *)v_counts);
+  HIP_TRY(c, hipGetLastError());
   std::vector<int> counts((size_t)nstreams * 2);
   HIP_TRY(c, hipMemcpyAsync(counts.data(), v_counts, counts.size() * sizeof(int), hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
+  for (long i = 0; i < nstreams; i++)
+    if (counts[2 * i] < 0 || counts[2 * i + 1] < 0 || (long)counts[2 * i] + counts[2 * i + 1] > B.maxblocks)
+      return fail(c, VAMD_EFAULT, "stream plan: a block count outside its bound (the planning kernel did not run to completion)");
   std::vector<long long> base((size_t)3 * nstreams + 1);  // [2s + W] then start[nstreams + 1]
   long long tot[2] = {0, 0}, all = 0;
   for (long i = 0; i < nstreams; i++) {
@@ -1991,6 +2047,7 @@ int vamd_gather_blocks(vamd_ctx *c, const vamd_stream_plan *plan, int W, const f
   if (nb == 0) return VAMD_OK;
   if (!pcm || !pcm_blocks) return fail(c, VAMD_EINVAL, "null pcm / pcm_blocks");
   if (channel_stride & 3) return fail(c, VAMD_EINVAL, "channel stride must be a multiple of 4 samples");
+  if (((uintptr_t)pcm | (uintptr_t)pcm_blocks) & 15) return fail(c, VAMD_EINVAL, "pcm / pcm_blocks must be 16-byte aligned");
   const int ch = c->B.channels, n = c->B.bs[W];
   const long total = nb * ch * (n / 4);
   const long blocks = (total + 255) / 256;

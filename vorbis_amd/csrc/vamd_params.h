@@ -146,6 +146,20 @@ struct DescP {
   int u_lW, u_nW, u_blocktype;
   float u_ampmax_in;
   unsigned long long *dbg;  // phase stopwatch slots (null = off), 16 per stage kernel
+  // input-domain report (include/vorbis_amd.h, "Input domain"): status[channel-block] = 1 where the block's spectral
+  // peak, before the 0 dB clamp of lib/mapping0.c:345, is above VAMD_INPUT_LIMIT_DB -- a non-finite sample or one
+  // past ~3e7 x full scale; bad[0] counts such channel-blocks since vamd_input_status() last looked
+  unsigned char *status;
+  unsigned int *bad;
 };
+
+// Above this spectral peak (dB re a full-scale sine; the reference's logfft scale, lib/mapping0.c:255-343) the reference's
+// own arithmetic leaves the domain C defines: float -> int conversions of the quantised residue overflow from ~+190 dB, and
+// any NaN or Inf sample puts every FFT bin's todB() above +330 dB (todB reads the float's BITS, lib/scales.h:43-51, so the
+// dB value of a NaN is a large finite number -- which is also why no NaN ever reaches the maximum below).
+#define VAMD_INPUT_LIMIT_DB 150.f
+// the same test in the block-switching detector, on its unscaled 128-point spectra (todB(re^2+im^2)*.5): a finite
+// sample inside the limit above stays below ~+195 dB there, a NaN or Inf lands above +380
+#define VAMD_ENV_LIMIT_DB 300.f
 
 }  // namespace vamd

@@ -183,6 +183,7 @@ VAMD_DEV void lds_atomic_min(float *p, float v) {
 }
 VAMD_DEV void lds_atomic_add(int *p, int v) { atomicAdd(p, v); }
 VAMD_DEV void lds_atomic_or(int *p, int v) { atomicOr(p, v); }
+VAMD_DEV void lds_or_global_count(unsigned int *p) { atomicAdd(p, 1u); }  // an event counter in HBM (rare: error reports)
 #else
 VAMD_DEV float wave_max(float v) { return v; }
 VAMD_DEV int wave_sum(int v) { return v; }
@@ -199,6 +200,7 @@ VAMD_DEV void lds_atomic_max(float *p, float v) { if (*p < v) *p = v; }
 VAMD_DEV void lds_atomic_min(float *p, float v) { if (v < *p) *p = v; }
 VAMD_DEV void lds_atomic_add(int *p, int v) { *p += v; }
 VAMD_DEV void lds_atomic_or(int *p, int v) { *p |= v; }
+VAMD_DEV void lds_or_global_count(unsigned int *p) { *p += 1u; }
 #endif
 
 struct alignas(16) F4 {
