@@ -151,16 +151,19 @@ typedef struct vamd_batch_io {
 
 /* ---- Input domain ---------------------------------------------------------------------------------
  * libvorbis does not validate PCM: whatever floats arrive go through mapping0_forward.  Inside the
- * domain below this library reproduces the reference bit for bit (denormals, signed zeros and samples
- * thousands of times over full scale included).  Outside it the reference's own result is not defined by
- * C -- its float -> int conversions of the quantised residue overflow (x86 yields INT_MIN, other targets
- * saturate), and a NaN sample reaches those conversions too -- so there is nothing to be identical to,
- * and the library REPORTS such input instead of inventing an answer:
+ * domain below this library reproduces the reference bit for bit -- denormals, signed zeros and signals
+ * hundreds of times over full scale included (tests/soak_lib.py kinds 8-11).  Outside it the reference's
+ * own result is not defined by C: its residue search and noise normalisation square quantised values in
+ * `int` (lib/res0.c:361-364, lib/psy.c:985: signed overflow from values of 16 384 / 46 341 up), its
+ * float -> int conversions overflow further out, and a NaN sample reaches those conversions too.  There
+ * is then nothing to be identical to, and the library REPORTS such input instead of inventing an answer:
  *
  *   domain: every sample finite, and the block's spectral peak (the reference's logfft scale, 0 dB = a
- *           full-scale sine, lib/mapping0.c:255-343, taken before the 0 dB clamp of :345) at most +150 dB,
- *           i.e. samples up to ~3e7 x full scale.  One NaN or +-Inf anywhere in a block's window puts the
- *           peak above +330 dB, so the test costs one compare per channel-block.
+ *           full-scale sine, lib/mapping0.c:255-343, taken before the 0 dB clamp of :345) at most +60 dB,
+ *           i.e. a signal up to 1000 x full scale (vorbis_amd/csrc/vamd_params.h derives the margin).  One
+ *           NaN or +-Inf anywhere in a block's windowed span puts the peak above +330 dB, so the test costs
+ *           one compare per channel-block.  (A sample the window zeroes -- lib/window.c:2117-2118 -- never
+ *           enters the arithmetic, in the reference or here.)
  *
  *   - the host-pointer calls (vamd_analyze_block*, vamd_encode_block, vamd_envelope_search,
  *     vamd_batcher_encode_block) return VAMD_EINVAL (= OV_EINVAL) for a block / detector call outside the
@@ -170,7 +173,9 @@ typedef struct vamd_batch_io {
  *     vamd_input_status() synchronises the context's stream, returns VAMD_EINVAL if anything issued since the
  *     previous call was outside the domain (how many channel-blocks / detector steps: the two optional
  *     outputs) and resets the counts.  Outputs of such blocks are deterministic but unspecified; every
- *     other block of the batch is unaffected. */
+ *     other block of the batch is unaffected.
+ *   (The detector's test catches non-finite samples only; a finite stream is cut into the reference's
+ *   blocks whatever its level, and the blocks' own test applies.) */
 int vamd_input_status(vamd_ctx *ctx, long *bad_channel_blocks, long *bad_detector_steps);
 
 #define VAMD_RES_CLASS_STRIDE 512 /* ints per block and submap in res_class[] (>= classified partitions) */

@@ -1,6 +1,6 @@
 """GPU suite: the input domain (include/vorbis_amd.h, "Input domain").
 
-Inside the domain -- every finite sample up to ~3e7 x full scale, denormals and signed zeros included -- results are
+Inside the domain -- finite samples, spectral peak up to +60 dB over full scale, denormals and signed zeros included -- results are
 the reference's bit for bit: those signal kinds are part of every soak run (tests/soak_lib.py kinds 8-11,
 tests/test_gpu_soak.py).  Outside it (NaN, +-Inf, 1e30 ...) the reference's own result is not defined by C; this
 suite checks that the library REPORTS such blocks through every door -- the per-block status tensor, the context's
@@ -19,7 +19,7 @@ def test_blocks_outside_the_domain_are_reported_and_isolated():
     from tests import soak_lib
     lines = []
     checks, bad = soak_lib.run_hostile(48, log=lambda *a: lines.append(" ".join(str(x) for x in a)))
-    assert checks > 500
+    assert checks > 250
     assert bad == 0, "\n".join(lines[-20:])
 
 

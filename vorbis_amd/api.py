@@ -228,7 +228,7 @@ class Analyzer:
 
     def input_status(self):
         """vamd_input_status(): synchronise, then (channel-blocks, detector steps) issued since the last call that
-        were outside the input domain (a NaN / Inf sample, or one beyond ~3e7 x full scale); resets the counts.
+        were outside the input domain (a NaN / Inf sample, or a signal ~1000 x over full scale); resets the counts.
         (0, 0) means every result since then is the reference's, bit for bit."""
         a, b = C.c_long(0), C.c_long(0)
         r = self.L.vamd_input_status(self.h, C.byref(a), C.byref(b))

@@ -167,6 +167,13 @@ VAMD_DEV ChanBin chan_bin(int nzk, float m, int ilog, int b, int nstart, const C
   return r;
 }
 
+// out[j]*out[j] as the reference's x86-64 build computes it (lib/psy.c:985: an int product, converted to float
+// afterwards): past |out| = 46340 -- spectra 93 dB over full scale -- the product wraps modulo 2^32, the "energy" can
+// come out negative and the bin then counts as a noise-normalisation candidate.  Signed overflow is undefined in C,
+// so the wrap is spelt out in unsigned arithmetic here (a compiler may otherwise assume the square is non-negative);
+// the soak holds such blocks (tests/soak_lib.py kind 10).
+VAMD_DEV float int_square_as_float(int v) { return (float)(int)((unsigned int)v * (unsigned int)v); }
+
 // one bin of the coupling step (lib/psy.c:1129-1196) followed by the magnitude's
 // re-normalisation (noise_normalize with flags); M/A are updated in place, iM/iA
 // are the integers quantised so far.  Returns the magnitude's noise-norm
@@ -212,7 +219,7 @@ VAMD_DEV float couple_bin(ChanBin &M, ChanBin &A, int &iM, int &iA, int b, int n
     // per-channel noise_normalize left in quant[]: out*out*floor for a final value, floor for a
     // promoted candidate, 0 for a dropped one (lib/psy.c:985,998-1003) -- all three are iM*iM*floor.
     // (Only bitrate-managed candidates 0..6 put the lowpass inside the block.)
-    M.qe = (float)(iM * iM) * M.fl2;
+    M.qe = int_square_as_float(iM) * M.fl2;
   }
   M.fl2 = A.fl2 = M.fl2 + A.fl2;
   float cand = -1.f;
@@ -399,8 +406,8 @@ VAMD_DEV void couple_block_general(const CoupleP &C, const PsyP &P, int n2, cons
       A.re = S.re[Ai * n2 + b], A.qe = S.qe[Ai * n2 + b], A.fl2 = S.fl2[Ai * n2 + b], A.fg = S.fg[Ai * n2 + b];
       int iM = iwork[Mi][b], iA = iwork[Ai][b];
       if (b >= nstart) {
-        if (pm == 1 || (pm == 2 && !M.fg)) M.qe = (float)(iM * iM) * M.fl2;
-        if (pa == 1 || (pa == 2 && !A.fg)) A.qe = (float)(iA * iA) * A.fl2;
+        if (pm == 1 || (pm == 2 && !M.fg)) M.qe = int_square_as_float(iM) * M.fl2;
+        if (pa == 1 || (pa == 2 && !A.fg)) A.qe = int_square_as_float(iA) * A.fl2;
       }
       const float cand = couple_bin(M, A, iM, iA, b, nstart, C);
       S.re[Mi * n2 + b] = M.re, S.qe[Mi * n2 + b] = M.qe, S.fl2[Mi * n2 + b] = M.fl2, S.fg[Mi * n2 + b] = M.fg;

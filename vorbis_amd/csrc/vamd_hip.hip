@@ -1014,7 +1014,7 @@ int vamd_input_status(vamd_ctx *c, long *bad_channel_blocks, long *bad_detector_
   if (h[0] | h[1]) HIP_TRY(c, hipMemset(c->d_bad, 0, sizeof(h)));
   if (bad_channel_blocks) *bad_channel_blocks = (long)h[0];
   if (bad_detector_steps) *bad_detector_steps = (long)h[1];
-  if (h[0] | h[1]) return fail(c, VAMD_EINVAL, "input outside the domain: a non-finite sample, or one beyond ~3e7 x full scale");
+  if (h[0] | h[1]) return fail(c, VAMD_EINVAL, "input outside the domain: a non-finite sample, or a signal ~1000 x over full scale");
   return VAMD_OK;
 }
 
@@ -1563,7 +1563,7 @@ int vamd_analyze_block_managed(vamd_ctx *c, const float *const *pcm, int lW, int
   HIP_TRY(c, hipMemcpyAsync(hs + o_mdct, ds + o_mdct, total - o_mdct, hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
   for (size_t i = 0; i < ch; i++)
-    if (hs[o_amp + 4 + i]) return fail(c, VAMD_EINVAL, "input outside the domain: a non-finite sample, or one beyond ~3e7 x full scale");
+    if (hs[o_amp + 4 + i]) return fail(c, VAMD_EINVAL, "input outside the domain: a non-finite sample, or a signal ~1000 x over full scale");
   if (mdct) memcpy(mdct, hs + o_mdct, ch * n2 * 4);
   if (ampmax_out) memcpy(ampmax_out, hs + o_amp, 4);
   if (posts) memcpy(posts, hs + o_posts, K * ch * VAMD_POSTS_STRIDE * 4);
@@ -1728,7 +1728,7 @@ int vamd_analyze_block_res(vamd_ctx *c, const float *const *pcm, int lW, int W, 
   HIP_TRY(c, hipMemcpyAsync(hs + o_mdct, ds + o_mdct, total - o_mdct, hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
   for (int i = 0; i < ch; i++)
-    if (hs[o_amp + 4 + i]) return fail(c, VAMD_EINVAL, "input outside the domain: a non-finite sample, or one beyond ~3e7 x full scale");
+    if (hs[o_amp + 4 + i]) return fail(c, VAMD_EINVAL, "input outside the domain: a non-finite sample, or a signal ~1000 x over full scale");
   if (mdct) memcpy(mdct, hs + o_mdct, (size_t)ch * n2 * 4);
   if (logmask) memcpy(logmask, hs + o_mask, (size_t)ch * n2 * 4);
   if (iwork) memcpy(iwork, hs + o_iwork, (size_t)ch * n2 * 4);
@@ -1817,7 +1817,7 @@ int vamd_encode_block(vamd_ctx *c, const float *const *pcm, int lW, int W, int n
   HIP_TRY(c, hipMemcpyAsync(hs + o_amp, ds + o_amp, o_back - o_amp, hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
   for (size_t i = 0; i < ch; i++)
-    if (hs[o_amp + 4 + i]) return fail(c, VAMD_EINVAL, "input outside the domain: a non-finite sample, or one beyond ~3e7 x full scale");
+    if (hs[o_amp + 4 + i]) return fail(c, VAMD_EINVAL, "input outside the domain: a non-finite sample, or a signal ~1000 x over full scale");
   if (ampmax_out) memcpy(ampmax_out, hs + o_amp, 4);
   memcpy(packet_bits, hs + o_bits, K * 4);
   for (size_t k = 0; k < K; k++) {

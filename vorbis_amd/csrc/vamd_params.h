@@ -147,19 +147,24 @@ struct DescP {
   float u_ampmax_in;
   unsigned long long *dbg;  // phase stopwatch slots (null = off), 16 per stage kernel
   // input-domain report (include/vorbis_amd.h, "Input domain"): status[channel-block] = 1 where the block's spectral
-  // peak, before the 0 dB clamp of lib/mapping0.c:345, is above VAMD_INPUT_LIMIT_DB -- a non-finite sample or one
-  // past ~3e7 x full scale; bad[0] counts such channel-blocks since vamd_input_status() last looked
+  // peak, before the 0 dB clamp of lib/mapping0.c:345, is above VAMD_INPUT_LIMIT_DB -- a non-finite sample or a signal
+  // ~1000 x over full scale; bad[0] counts such channel-blocks since vamd_input_status() last looked
   unsigned char *status;
   unsigned int *bad;
 };
 
-// Above this spectral peak (dB re a full-scale sine; the reference's logfft scale, lib/mapping0.c:255-343) the reference's
-// own arithmetic leaves the domain C defines: float -> int conversions of the quantised residue overflow from ~+190 dB, and
-// any NaN or Inf sample puts every FFT bin's todB() above +330 dB (todB reads the float's BITS, lib/scales.h:43-51, so the
-// dB value of a NaN is a large finite number -- which is also why no NaN ever reaches the maximum below).
-#define VAMD_INPUT_LIMIT_DB 150.f
-// the same test in the block-switching detector, on its unscaled 128-point spectra (todB(re^2+im^2)*.5): a finite
-// sample inside the limit above stays below ~+195 dB there, a NaN or Inf lands above +380
+// The input domain (include/vorbis_amd.h).  Above this spectral peak (dB re a full-scale sine: the reference's logfft
+// scale, lib/mapping0.c:255-343) the reference's own INTEGER arithmetic leaves what C defines: its residue search sums
+// eight squared differences in an int (lib/res0.c:361-364: overflow from |value| ~ 16 384), noise_normalize squares
+// a quantised value in an int (lib/psy.c:985: from 46 341), and the float -> int conversions of the quantised
+// residue overflow from ~ +190 dB.  A quantised value is at most |mdct| / floor with floor <= 1, |mdct| stays
+// within ~1.6 x the FFT peak, and coupling can grow it by 2 * sqrt(2)^3 (three steps for the 5.1 left channel):
+// at +60 dB that is ~ 9 000, safely below the first of those limits.  Any NaN or Inf sample puts every FFT bin's
+// todB() above +330 dB (todB reads the float's BITS, lib/scales.h:43-51, so the dB value of a NaN is a large
+// finite number -- which is also why no NaN ever reaches the maximum in transform_logfft).
+#define VAMD_INPUT_LIMIT_DB 60.f
+// the same test in the block-switching detector, on its unscaled 128-point spectra (todB(re^2+im^2)*.5): finite
+// samples inside the limit above stay below ~ +150 dB there, a NaN or Inf lands above +380
 #define VAMD_ENV_LIMIT_DB 300.f
 
 }  // namespace vamd
