@@ -19,6 +19,7 @@
 #pragma once
 #include "vamd_wave.h"
 #include "vamd_params.h"
+#include "k_tone.h"
 
 namespace vamd {
 
@@ -46,56 +47,91 @@ struct FloorScratch {
   int nseg;
 };
 
-// _vp_offset_and_mix with offset_select == 1 (the only select the VBR path uses)
+// _vp_offset_and_mix with offset_select == 1 (the only select the VBR path uses), for one quad of bins:
+//   nz / tn / md  noise curve, tone curve, spectrum (md is scaled in place: AoTuV M1);  mk  the mask out
+// Returns what the fit reads of the four bins: 16 bits each (see offset_and_mix_wave).
+VAMD_DEV I2 offset_and_mix_quad(const PsyP &P, int q, const float *nz, const float *tn, float *md, float *mk, float twofitatten) {
+  const float toneatt = P.tone_masteratt1;
+  const float cx = P.m_val;
+  const float coeffi = -17.2f;  // float coeffi = -17.2 (lib/psy.c:808)
+  float no[4], lmv[4];
+  f4_get(((const F4 *)P.noiseoffset1)[q], no);
+  // logmdct (lib/mapping0.c:384-385) is a function of the spectrum that is read here anyway: recomputed, not
+  // fetched -- the transform stage need not write it, nor this one read it (16 KB per stereo block)
+  for (int c = 0; c < 4; c++) lmv[c] = todB_345(md[c]);
+#if VAMD_GPU
+#pragma unroll
+#endif
+  for (int c = 0; c < 4; c++) {
+    float val = nz[c] + no[c];
+    if (val > P.noisemaxsupp) val = P.noisemaxsupp;
+    const float t = tn[c] + toneatt;
+    mk[c] = (val < t) ? t : val;  // max(val, tone+toneatt), lib/psy.c:795 with os.h:78 max()
+    // AoTuV M1, lib/psy.c:807-832: double-promoted by the 1.0 / 0.005 / 0.0003 literals
+    val = val - lmv[c];
+    float de;
+    if (val > coeffi) {
+      de = (float)(1.0 - ((double)(val - coeffi) * 0.005 * (double)cx));
+      if (de < 0) de = 0.0001f;
+    } else {
+      de = (float)(1.0 - ((double)(val - coeffi) * 0.0003 * (double)cx));
+    }
+    md[c] *= de;
+  }
+  // accumulate_fit / inspect_error read the mask only through vorbis_dBquant and split bins by the
+  // class test (lib/floor1.c:421-427,530-536): 2 bytes per bin instead of two floats
+  uint32_t w[2] = {0, 0};
+  for (int c = 0; c < 4; c++) {
+    const uint32_t v = (uint32_t)dBquant(mk[c]) | (lmv[c] + twofitatten >= mk[c] ? 0x8000u : 0u);
+    w[c >> 1] |= v << (16 * (c & 1));
+  }
+  I2 pk;
+  pk.x = (int)w[0];
+  pk.y = (int)w[1];
+  return pk;
+}
+
 VAMD_DEV void offset_and_mix_wave(const PsyP &P, const float *__restrict__ noise, const float *__restrict__ tone,
                                   const float *__restrict__ mdct_io_src, float *__restrict__ mdct_out, float *__restrict__ logmask_out /* HBM or null */,
                                   unsigned short *qc, float twofitatten, PhaseClock &pc) {
   const int n = P.n;
-  const float toneatt = P.tone_masteratt1;
-  const float cx = P.m_val;
-  const float coeffi = -17.2f;  // float coeffi = -17.2 (lib/psy.c:808)
   WAVE_FOR(q, n >> 2) {
-    float nz[4], no[4], tn[4], lmv[4], md[4], mk[4];
+    float nz[4], tn[4], md[4], mk[4];
     f4_get(((const F4 *)noise)[q], nz);
-    f4_get(((const F4 *)P.noiseoffset1)[q], no);
     f4_get(((const F4 *)tone)[q], tn);
     f4_get(((const F4 *)mdct_io_src)[q], md);
-    // logmdct (lib/mapping0.c:384-385) is a function of the spectrum that is read here anyway: recomputed, not
-    // fetched -- the transform stage need not write it, nor this one read it (16 KB per stereo block)
-    for (int c = 0; c < 4; c++) lmv[c] = todB_345(md[c]);
-#if VAMD_GPU
-#pragma unroll
-#endif
-    for (int c = 0; c < 4; c++) {
-      float val = nz[c] + no[c];
-      if (val > P.noisemaxsupp) val = P.noisemaxsupp;
-      const float t = tn[c] + toneatt;
-      mk[c] = (val < t) ? t : val;  // max(val, tone+toneatt), lib/psy.c:795 with os.h:78 max()
-      // AoTuV M1, lib/psy.c:807-832: double-promoted by the 1.0 / 0.005 / 0.0003 literals
-      val = val - lmv[c];
-      float de;
-      if (val > coeffi) {
-        de = (float)(1.0 - ((double)(val - coeffi) * 0.005 * (double)cx));
-        if (de < 0) de = 0.0001f;
-      } else {
-        de = (float)(1.0 - ((double)(val - coeffi) * 0.0003 * (double)cx));
-      }
-      md[c] *= de;
-    }
+    const I2 pk = offset_and_mix_quad(P, q, nz, tn, md, mk, twofitatten);
     if (logmask_out) ((F4 *)logmask_out)[q] = f4_make(mk);
-    // accumulate_fit / inspect_error read the mask only through vorbis_dBquant and split bins by the
-    // class test (lib/floor1.c:421-427,530-536): 2 bytes per bin instead of two floats
-    uint32_t w[2] = {0, 0};
-    for (int c = 0; c < 4; c++) {
-      const uint32_t v = (uint32_t)dBquant(mk[c]) | (lmv[c] + twofitatten >= mk[c] ? 0x8000u : 0u);
-      w[c >> 1] |= v << (16 * (c & 1));
-    }
-    I2 pk;
-    pk.x = (int)w[0];
-    pk.y = (int)w[1];
     ((I2 *)qc)[q] = pk;
     ((F4 *)mdct_out)[q] = f4_make(md);
   }
+  WAVE_SYNC();
+  pc.mark(0);
+}
+
+// The same with the tone curve formed on the spot (k_tone.h: tone_fold_prepare has left the painted seed lines and the
+// groups' minima in LDS): a lane folds its quad and mixes it, the curve never exists in memory unless `tone_out` asks
+// for the tap.  The fit's 16-bit state takes the place of the seed lines in LDS, so it waits in registers (two per quad)
+// until every lane is through with them.  Blocks of up to 4 * 64 * VAMD_QPL bins.
+VAMD_DEV void fold_and_mix_wave(const PsyP &P, float att, const float *seed, const float *gmin,
+                                const float *__restrict__ noise, float *__restrict__ tone_out /* HBM or null */,
+                                const float *__restrict__ mdct_io_src, float *__restrict__ mdct_out,
+                                float *__restrict__ logmask_out /* HBM or null */, unsigned short *qc,
+                                float twofitatten, PhaseClock &pc) {
+  const int n = P.n;
+  I2 keep[VAMD_QPL];
+  LANE_QUADS(kq, q, n >> 2) {
+    float nz[4], tn[4], md[4], mk[4];
+    f4_get(((const F4 *)noise)[q], nz);
+    f4_get(((const F4 *)mdct_io_src)[q], md);
+    tone_fold_quad(P, att, seed, gmin, q, tn);
+    if (tone_out) ((F4 *)tone_out)[q] = f4_make(tn);
+    keep[kq] = offset_and_mix_quad(P, q, nz, tn, md, mk, twofitatten);
+    if (logmask_out) ((F4 *)logmask_out)[q] = f4_make(mk);
+    ((F4 *)mdct_out)[q] = f4_make(md);
+  }
+  WAVE_SYNC();  // nobody reads seed lines any more
+  LANE_QUADS(kq, q, n >> 2)((I2 *)qc)[q] = keep[kq];
   WAVE_SYNC();
   pc.mark(0);
 }

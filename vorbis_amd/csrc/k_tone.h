@@ -416,12 +416,12 @@ VAMD_DEV void tone_seed_block(const PsyP &P, const float *__restrict__ logfft, f
 
 // paint + fold half: seed[] (LDS, unpainted on entry), its unpainted HBM copy, the survivor
 // list -> tone curve
-VAMD_DEV void tone_fold_block(const PsyP &P, float local_ampmax, float *seed, const float *__restrict__ seed_src,
-                              const unsigned short *__restrict__ surv, int nsurv, float *gmin /* LDS [ngroups] */,
-                              float *__restrict__ out, PhaseClock &pc) {
-  const int n = P.n, nlines = P.total_octave_lines;
-  float att = local_ampmax + P.ath_adjatt;
-  if (att < P.ath_maxatt) att = P.ath_maxatt;
+// ... in two steps, so that a caller can take the curve quad by quad (k_floor mixes it without a trip through memory):
+// tone_fold_prepare leaves the painted lines and the groups' minima in LDS, tone_fold_quad forms four bins from them.
+VAMD_DEV void tone_fold_prepare(const PsyP &P, float *seed, const float *__restrict__ seed_src,
+                                const unsigned short *__restrict__ surv, int nsurv, float *gmin /* LDS [ngroups] */,
+                                PhaseClock &pc) {
+  const int nlines = P.total_octave_lines;
   seed_chase_paint(seed, seed_src, P.eighth_octave_lines, nlines, nsurv, surv);
   WAVE_SYNC();
   pc.mark(3);
@@ -440,31 +440,46 @@ VAMD_DEV void tone_fold_block(const PsyP &P, float local_ampmax, float *seed, co
     if (g != 0xffff && s > VAMD_NEGINF) lds_atomic_min(gmin + g, s);
   }
   WAVE_SYNC();
-  WAVE_FOR(q, n >> 2) {
-    const I4 bf = ((const I4 *)P.bin_fold)[q];
-    const int bfs[4] = {bf.x, bf.y, bf.z, bf.w};
-    float av[4], o[4];
-    f4_get(((const F4 *)P.ath)[q], av);
+}
+VAMD_DEV float tone_ath_att(const PsyP &P, float local_ampmax) {
+  float att = local_ampmax + P.ath_adjatt;
+  return att < P.ath_maxatt ? P.ath_maxatt : att;
+}
+VAMD_DEV void tone_fold_quad(const PsyP &P, float att, const float *seed, const float *gmin, int q, float *o) {
+  const int nlines = P.total_octave_lines;
+  const I4 bf = ((const I4 *)P.bin_fold)[q];
+  const int bfs[4] = {bf.x, bf.y, bf.z, bf.w};
+  float av[4];
+  f4_get(((const F4 *)P.ath)[q], av);
 #if VAMD_GPU
 #pragma unroll
 #endif
-    for (int c = 0; c < 4; c++) {
-      const int i = (q << 2) + c;
-      float minV;
-      if (i >= P.tail_linpos) {
-        minV = seed[nlines - 1];
-      } else {
-        minV = seed[bfs[c] & 0xffff];
-        if (minV > P.tone_abs_limit) minV = P.tone_abs_limit;
-        const float rest = gmin[bfs[c] >> 16];
-        if (rest < f_from_bits(0x7f800000u)) {
-          if (minV == VAMD_NEGINF || rest < minV) minV = rest;
-        }
+  for (int c = 0; c < 4; c++) {
+    const int i = (q << 2) + c;
+    float minV;
+    if (i >= P.tail_linpos) {
+      minV = seed[nlines - 1];
+    } else {
+      minV = seed[bfs[c] & 0xffff];
+      if (minV > P.tone_abs_limit) minV = P.tone_abs_limit;
+      const float rest = gmin[bfs[c] >> 16];
+      if (rest < f_from_bits(0x7f800000u)) {
+        if (minV == VAMD_NEGINF || rest < minV) minV = rest;
       }
-      float v = av[c] + att;
-      if (v < minV) v = minV;
-      o[c] = v;
     }
+    float v = av[c] + att;
+    if (v < minV) v = minV;
+    o[c] = v;
+  }
+}
+VAMD_DEV void tone_fold_block(const PsyP &P, float local_ampmax, float *seed, const float *__restrict__ seed_src,
+                              const unsigned short *__restrict__ surv, int nsurv, float *gmin /* LDS [ngroups] */,
+                              float *__restrict__ out, PhaseClock &pc) {
+  const float att = tone_ath_att(P, local_ampmax);
+  tone_fold_prepare(P, seed, seed_src, surv, nsurv, gmin, pc);
+  WAVE_FOR(q, P.n >> 2) {
+    float o[4];
+    tone_fold_quad(P, att, seed, gmin, q, o);
     ((F4 *)out)[q] = f4_make(o);
   }
   WAVE_SYNC();

@@ -428,8 +428,14 @@ __global__ __launch_bounds__(64) void k_tone_fold(PsyP P0, PsyP P1, DescP d, int
 // stage 4: offset_and_mix + floor1_fit + floor curve
 // (eight waves per SIMD, i.e. 64 registers: measured against the 73 the compiler would take and six or seven waves --
 // the stage is latency-bound, its time follows the blocks in flight: tools/floor_occ.sh -- 2.14 against 2.24 ms)
+// With `seed_g` the stage begins with the tone chain's last step (tone_fold_block: paint the chase's survivors,
+// max_seeds' fold) for its own channel-block: the tone curve then goes out and comes straight back through L2 inside
+// one wave instead of through a launch boundary, and the fold's waits sit among thirty-one other waves' floor fits.
+// The fold's LDS (seed lines + group minima, 3.7 KB) is the fit's own, used before it.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_floor(const Bound *__restrict__ Bd, int W, DescP d, int ch,
-                                              const float *__restrict__ noise, const float *__restrict__ tone,
+                                              const float *__restrict__ noise, float *__restrict__ tone,
+                                              const float *__restrict__ seed_g, const unsigned short *__restrict__ surv,
+                                              const int *__restrict__ nsurv, const float *__restrict__ local_ampmax, int nlp,
                                               const float *__restrict__ mdct_raw,
                                               float *__restrict__ mdct, float *__restrict__ logmask_out,
                                               int *__restrict__ posts, int *__restrict__ post_valid,
@@ -448,8 +454,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 #ifdef VAMD_STOP_AFTER
   pc.stoppable = true;
 #endif
-  offset_and_mix_wave(P, noise + cb * n2, tone + cb * n2, mdct_raw + cb * n2, mdct + cb * n2,
-                      logmask_out ? logmask_out + cb * n2 : nullptr, qc, F.twofitatten, pc);
+  if (seed_g) {
+    float *seed = (float *)vamd_smem;  // [nlp], then the group minima
+    WAVE_FOR(q, nlp >> 2)((F4 *)seed)[q] = ((const F4 *)(seed_g + cb * nlp))[q];
+    WAVE_SYNC();
+    PhaseClock none;
+    none.start(nullptr);
+    tone_fold_prepare(P, seed, seed_g + cb * nlp, surv + cb * nlp, nsurv[cb], seed + nlp, none);
+    fold_and_mix_wave(P, tone_ath_att(P, local_ampmax[cb]), seed, seed + nlp, noise + cb * n2, tone ? tone + cb * n2 : nullptr,
+                      mdct_raw + cb * n2, mdct + cb * n2, logmask_out ? logmask_out + cb * n2 : nullptr, qc, F.twofitatten, pc);
+  } else {
+    offset_and_mix_wave(P, noise + cb * n2, tone + cb * n2, mdct_raw + cb * n2, mdct + cb * n2,
+                        logmask_out ? logmask_out + cb * n2 : nullptr, qc, F.twofitatten, pc);
+  }
   const int nzf = floor_fit_render_block(F, n2, qc, sc, posts + cb * VAMD_POSTS_STRIDE, post_valid + cb,
                                          ilogmask + cb * n2, pc);
   if (LANE == 0) nonzero[cb] = nzf;
@@ -1336,6 +1353,11 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_
   const unsigned gcb = (unsigned)(R->nb * ch), gb = (unsigned)R->nb;
   hipStream_t s = c->stream;
   const bool overlap = c->overlap;
+  // the VBR path's floor stage takes the tone chain's last step with it (k_floor)
+  static const bool fold_env = getenv("VAMD_FOLD_SEPARATE") == nullptr;
+  const int nlp_all = (nl + 15) & ~15;
+  const size_t fold_lds = (size_t)(nlp_all + (P0.ngroups > P1.ngroups ? P0.ngroups : P1.ngroups)) * 4;
+  const bool fold_in_floor = fold_env && level >= VAMD_LEVEL_FULL && !M && n2 <= 64 * 4 * VAMD_QPL;
   if (level >= VAMD_LEVEL_PSY) {
     if (overlap) {  // fork: the tone chain needs only what is already queued on `stream`
       (void)hipEventRecord(c->ev_fork, c->stream);
@@ -1384,8 +1406,9 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_
         hipLaunchKernelGGL(k_tone_chase, dim3((gcb + VAMD_CHASE_LANES - 1) / VAMD_CHASE_LANES), dim3(VAMD_CHASE_LANES),
                            (size_t)VAMD_RING * VAMD_CHASE_LANES * 8, s,
                            P0.eighth_octave_lines, nl, nlp, (long)gcb, d, p.seed, p.surv, p.nsurv);
-      hipLaunchKernelGGL(k_tone_fold, dim3(gcb), dim3(64), (size_t)(nlp + (P0.ngroups > P1.ngroups ? P0.ngroups : P1.ngroups)) * 4, s, P0, P1, d, ch, nlp, p.seed, p.surv,
-                         p.nsurv, p.local, p.tone);
+      if (!fold_in_floor)
+        hipLaunchKernelGGL(k_tone_fold, dim3(gcb), dim3(64), (size_t)(nlp + (P0.ngroups > P1.ngroups ? P0.ngroups : P1.ngroups)) * 4, s, P0, P1, d, ch, nlp, p.seed, p.surv,
+                           p.nsurv, p.local, p.tone);
     }
     if (overlap) {  // join
       (void)hipEventRecord(c->ev_join, c->side);
@@ -1407,8 +1430,11 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_
                           M->packets, M->packet_stride, M->packet_bits);
   } else if (level >= VAMD_LEVEL_FULL) {
     static const size_t floor_pad = getenv("VAMD_FLOOR_LDS_PAD") ? (size_t)atoi(getenv("VAMD_FLOOR_LDS_PAD")) : 0;  // (experiment: occupancy)
-    hipLaunchKernelGGL(k_floor, dim3(gcb), dim3(64), (size_t)((n2 + 15) & ~15) * 2 + sizeof(FloorScratch) + floor_pad, s,
-                       (const Bound *)c->d_bound, W, d, ch, p.noise, p.tone, p.mdct_raw, p.mdct,
+    size_t floor_lds = (size_t)((n2 + 15) & ~15) * 2 + sizeof(FloorScratch) + floor_pad;
+    if (fold_in_floor && fold_lds > floor_lds) floor_lds = fold_lds;
+    hipLaunchKernelGGL(k_floor, dim3(gcb), dim3(64), floor_lds, s,
+                       (const Bound *)c->d_bound, W, d, ch, p.noise, fold_in_floor ? R->io->tone : p.tone, fold_in_floor ? p.seed : nullptr, p.surv, p.nsurv, p.local,
+                       nlp_all, p.mdct_raw, p.mdct,
                        R->io->logmask, p.posts, p.post_valid, p.ilogmask, p.nonzero);
     if (R->io->ilogmask)  // (a tap: tests and callers with their own quantiser)
       hipLaunchKernelGGL(k_widen_ilog, dim3(1024), dim3(256), 0, s, (long)gcb * n2, (const ilog_t *)p.ilogmask, R->io->ilogmask);
