@@ -141,26 +141,48 @@ __global__ void k_rate(int iters, unsigned long long *out, float *sink) {
     out[2 * (threadIdx.x >> 6)] = t1 - t0;
     out[2 * (threadIdx.x >> 6) + 1] = w1 - w0;
   }
+  if (threadIdx.x == 0) {  // where this workgroup ran: HW_ID (cu/sh/se) and the XCC id
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    out[40 + (blockIdx.x & 7)] = ((unsigned long long)(xcc & 0xf) << 32) | ((hw >> 8) & 0xff);
+  }
+  // (only the registers the instruction under test uses stay alive: with all 80 of them a 1024-thread workgroup
+  // would be alone on its CU and the "whole chip" rows would measure four waves per SIMD, not eight)
   float s = (float)sg;
+  constexpr bool PK = OP == OP_PKMUL || OP == OP_PKADD || OP == OP_PKFMA;
+  constexpr bool F64 = OP == OP_ADD64 || OP == OP_MUL64 || OP == OP_FMA64 || OP == OP_SQRT64 || OP == OP_RCP64 || OP == OP_DEP_FMA64;
 #pragma unroll
-  for (int i = 0; i < 16; i++) s += r[i] + p[i].x + p[i].y + (float)d[i];
+  for (int i = 0; i < 16; i++) s += PK ? p[i].x + p[i].y : (F64 ? (float)d[i] : r[i]);
   if (s == 12345.678f) sink[threadIdx.x] = s;
 }
 
+// one CU: the stream is masked down to CU 0 of the first shader engine, so that two 1024-thread workgroups (w = 8)
+// land on the same CU as one does
+static hipStream_t one_cu_stream() {
+  static hipStream_t s = nullptr;
+  if (!s) {
+    uint32_t mask[8] = {1u, 0, 0, 0, 0, 0, 0, 0};
+    if (hipExtStreamCreateWithCUMask(&s, 8, mask) != hipSuccess) s = nullptr;
+  }
+  return s;
+}
 template <int OP>
 void run(unsigned long long *dbuf, float *sink, int grid) {
   const int iters = 2000;
+  hipStream_t st = one_cu_stream();
   printf("%-30s", names[OP]);
   for (int w : {1, 2, 4, 8}) {
     unsigned long long h[64];
-    for (int rep = 0; rep < 2; rep++) hipLaunchKernelGGL((k_rate<OP>), dim3(grid), dim3(256 * w > 1024 ? 1024 : 256 * w), 0, 0, iters, dbuf, sink);
-    // (8 waves per SIMD needs two 1024-thread workgroups on the CU: use w <= 4 rows for the single-CU reading)
-    hipDeviceSynchronize();
+    const int wgs = w > 4 ? 2 : 1, threads = 256 * (w > 4 ? 4 : w);
+    if (w > 4 && !st) continue;
+    for (int rep = 0; rep < 2; rep++) hipLaunchKernelGGL((k_rate<OP>), dim3(wgs), dim3(threads), 0, st, iters, dbuf, sink);
+    hipStreamSynchronize(st);
     hipMemcpy(h, dbuf, sizeof(h), hipMemcpyDeviceToHost);
-    const int weff = w > 4 ? 4 : w;
     const double cyc = (double)h[0], wall = (double)h[1];
-    // instructions issued per SIMD = iters * 16 * weff
-    if (w <= 4) printf("  w=%d: %6.2f cyc/inst/SIMD (clk %.0f MHz)", weff, cyc / (iters * 16.0 * weff), cyc / wall * 100.0);
+    // instructions issued per SIMD = iters * 16 * w  (w = 8: both workgroups run side by side; each times itself)
+    const bool same_cu = wgs == 1 || h[40] == h[41];
+    printf("  w=%d: %5.2f (clk %.0f)%s", w, cyc / (iters * 16.0 * w), cyc / wall * 100.0, same_cu ? "" : " [two CUs!]");
   }
   printf("\n");
 }
@@ -193,7 +215,7 @@ int main() {
   float *sink;
   hipMalloc(&d, 4096);
   hipMalloc(&sink, 1 << 20);
-  printf("one workgroup on one CU, w waves per SIMD; cycles = s_memtime ticks\n");
+  printf("one CU (CU-masked stream), w waves per SIMD: s_memtime ticks per instruction per SIMD (tick rate in MHz against the 100 MHz wall clock)\n");
   run<OP_ADD>(d, sink, 1);
   run<OP_MUL>(d, sink, 1);
   run<OP_FMA>(d, sink, 1);

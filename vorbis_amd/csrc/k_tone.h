@@ -420,11 +420,11 @@ VAMD_DEV void tone_seed_block(const PsyP &P, const float *__restrict__ logfft, f
 // tone_fold_prepare leaves the painted lines and the groups' minima in LDS, tone_fold_quad forms four bins from them.
 VAMD_DEV void tone_fold_prepare(const PsyP &P, float *seed, const float *__restrict__ seed_src,
                                 const unsigned short *__restrict__ surv, int nsurv, float *gmin /* LDS [ngroups] */,
-                                PhaseClock &pc) {
+                                PhaseClock &pc, int slot = 3) {
   const int nlines = P.total_octave_lines;
   seed_chase_paint(seed, seed_src, P.eighth_octave_lines, nlines, nsurv, surv);
   WAVE_SYNC();
-  pc.mark(3);
+  pc.mark(slot);
 
   // max_seeds' fold, lib/psy.c:522-543.  Each outer-loop iteration ("group") of the
   // reference starts from seed[p0] (capped at tone_abs_limit) and then keeps the lowest
@@ -440,6 +440,7 @@ VAMD_DEV void tone_fold_prepare(const PsyP &P, float *seed, const float *__restr
     if (g != 0xffff && s > VAMD_NEGINF) lds_atomic_min(gmin + g, s);
   }
   WAVE_SYNC();
+  pc.mark(slot + 1);
 }
 VAMD_DEV float tone_ath_att(const PsyP &P, float local_ampmax) {
   float att = local_ampmax + P.ath_adjatt;

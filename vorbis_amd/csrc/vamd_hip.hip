@@ -458,9 +458,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     float *seed = (float *)vamd_smem;  // [nlp], then the group minima
     WAVE_FOR(q, nlp >> 2)((F4 *)seed)[q] = ((const F4 *)(seed_g + cb * nlp))[q];
     WAVE_SYNC();
-    PhaseClock none;
-    none.start(nullptr);
-    tone_fold_prepare(P, seed, seed_g + cb * nlp, surv + cb * nlp, nsurv[cb], seed + nlp, none);
+    tone_fold_prepare(P, seed, seed_g + cb * nlp, surv + cb * nlp, nsurv[cb], seed + nlp, pc, 5);
     fold_and_mix_wave(P, tone_ath_att(P, local_ampmax[cb]), seed, seed + nlp, noise + cb * n2, tone ? tone + cb * n2 : nullptr,
                       mdct_raw + cb * n2, mdct + cb * n2, logmask_out ? logmask_out + cb * n2 : nullptr, qc, F.twofitatten, pc);
   } else {
