@@ -42,11 +42,23 @@ ALG_BYTES = {
     "c3": 40960,   # per stereo block: 16384 in + mdct 8192 + noise 8192 + tone 8192
     "c4": 41216,   # per stereo block: 16384 in + mdct 8192 + logmask 8192 + iwork 8192 + 256 posts/flags
 }
-# what each stage kernel of the unfused pipeline itself must move per stereo block
-STAGE_BYTES = {
-    "transform": 16384 + 3 * 8192 + 8, "ampmax": 12, "noisemask": 2 * 8192, "tonemask": 2 * 8192 + 12,
-    "floor": 4 * 8192 + 3 * 8192 + 256 + 16, "couple": 3 * 8192 + 16,
-}
+
+
+def stage_bytes(stage, n, ch=2):
+    """What a stage of the pipeline as launched must itself move per block of n samples and ch channels (every tensor it
+    reads or writes once; tables excluded): the 'own bytes' of dominant_kernel.  Scales with the block size, so a
+    mixed-size workload adds its size classes up (StreamRunner.stage_bytes_total)."""
+    n2 = n // 2
+    nlp = {256: 592, 2048: 784}.get(n, n2)       # octave lines of the 44.1 kHz psy setups, padded to 16 (SURVEY 8)
+    per_ch = {
+        "transform": 4 * n + 2 * 4 * n2 + 5,                      # pcm in; spectrum + logfft out; local ampmax, status
+        "ampmax": 6,
+        "noisemask": 4 * n2 + 4 * n2,                             # spectrum in, noise curve out
+        "tonemask": 4 * n2 + 4 * nlp + 4 * nlp + 2 * nlp + 12,    # seed: logfft in, seed lines out; chase: lines in, survivors out
+        "floor": 4 * n2 + 4 * n2 + 4 * nlp + 2 * nlp + 4 * n2 + 4 * n2 + 2 * n2 + 136,  # noise, spectrum, lines, survivors in; mixed spectrum, mask, 16-bit curve, posts out
+        "couple": 4 * n2 + 2 * n2 + 4 * n2 + 4,                   # mixed spectrum + curve in, residue out
+    }
+    return per_ch.get(stage, 12288) * ch
 
 
 def source_hash():
@@ -286,6 +298,11 @@ class GpuRunner:
         if self.a.workload == "c2":
             self.ev1.record()
 
+    def stage_bytes_total(self, stage):
+        if self.a.workload == "c2":
+            return ALG_BYTES["c2"] * self.units
+        return stage_bytes(stage, self.an.blocksizes[1], self.an.channels) * self.units
+
     def stage_ms(self, steps):
         """per-kernel durations from HIP events recorded on the launch stream inside the timed region"""
         if self.a.workload != "c2":
@@ -386,6 +403,10 @@ class StreamRunner:
     def alg_bytes(self):
         return 5248 * int(self.plan.nblocks[0]) + 41216 * int(self.plan.nblocks[1])
 
+    def stage_bytes_total(self, stage):
+        an = self.an
+        return sum(stage_bytes(stage, an.blocksizes[W], an.channels) * int(self.plan.nblocks[W]) for W in (0, 1))
+
     def parity_sample(self, count):
         """Randomly chosen planned blocks: window flags, block type and every output against the CPU checker fed the
         gathered block and the chain's incoming ampmax (decay of the previous block's, from the timed outputs)."""
@@ -461,7 +482,7 @@ def main(argv=None, make_runner=None):
         dom = max(stage_ms, key=stage_ms.get)
         alg = R.alg_bytes() if a.workload == "c5" else ALG_BYTES[a.workload] * units   # bytes per step per GPU, algorithmic
         achieved = alg / (kernels_ms * 1e-3) / 1e9                # GB/s over the path's kernels
-        dom_bytes = (STAGE_BYTES.get(dom, ALG_BYTES["c2"]) * units)
+        dom_bytes = R.stage_bytes_total(dom)
         traffic, traffic_per, traffic_note = measured_traffic(a.workload, units)
         stage_of = {"k_transform": "transform", "k_noise": "noisemask", "k_floor": "floor", "k_couple": "couple",
                     "k_tone_seed": "tonemask", "k_tone_chase": "tonemask", "k_tone_fold": "tonemask", "k_tone": "tonemask"}

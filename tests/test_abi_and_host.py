@@ -223,6 +223,7 @@ class StubRunner:
         assert self.timed == steps
         return {"transform": 1.0, "noisemask": 2.0}
     def parity_sample(self, count): return count, 0, "stub"
+    def stage_bytes_total(self, stage): return bench.stage_bytes(stage, 2048) * self.units
     def workload_text(self): return "rank-logic rehearsal (no GPU work)"
 
 rc = bench.main(["--gpus", "2", "--steps", "5", "--warmup", "1", "--backend", "gloo", "--blocks", "1000"], make_runner=StubRunner)

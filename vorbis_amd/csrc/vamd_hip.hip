@@ -1362,11 +1362,22 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_
       (void)hipStreamWaitEvent(c->side, c->ev_fork, 0);
     }
     {
-      // persistent teams, as many per CU as its LDS and its 32 wave slots hold (8 at 1024 bins: both exactly full)
+      // persistent teams.  A CU's LDS and 32 wave slots hold 8 of them at 1024 bins (both exactly full) -- but then the
+      // tone chain on the side stream finds no room until they retire and runs behind them.  Six teams (three quarters of
+      // the wave slots) keep the vector units as busy -- the stage is issue-bound -- and leave eight slots and 40 KB in
+      // which the tone kernels, which wait on LDS atomics and memory, run BESIDE them: per 131 072 stereo blocks
+      // noise + tone tail 2.24 + 1.16 ms with eight teams, 2.42 + 0.82 with seven, 2.62 + 0.50 with six, 2.89 + 0.29
+      // with five, 3.30 + 0.01 with four.
       const size_t lds = (size_t)5 * VAMD_NZ_STRIDE(n2) * 4;
       const int nw = n2 >= 256 ? 4 : (n2 >= 64 ? n2 / 64 : 1);
       long per_cu = (long)(c->lds_per_block / lds);
       if (per_cu > 32 / nw) per_cu = 32 / nw;
+      static const int noise_cap = getenv("VAMD_NOISE_TEAMS") ? atoi(getenv("VAMD_NOISE_TEAMS")) : 0;  // (measurement aid)
+      if (noise_cap > 0) {
+        if (per_cu > noise_cap) per_cu = noise_cap;
+      } else if (overlap && per_cu > 24 / nw) {
+        per_cu = 24 / nw > 0 ? 24 / nw : 1;
+      }
       if (per_cu < 1) per_cu = 1;
       const unsigned grid = (unsigned)((long)gcb < per_cu * c->num_cus ? (long)gcb : per_cu * c->num_cus);
 #define VAMD_GO(L)                                                                                                    \
