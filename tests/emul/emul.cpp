@@ -429,6 +429,65 @@ long emul_quant_energy_check(void) {
   return bad;
 }
 
+// what the chunks of one block add up to, chunk after chunk (k_tone_chase_wave runs chase_chunk one per lane and
+// combines the chunks with wave operations)
+static int chase_chunks_host(const float *seeds, int linesper, int n, unsigned short *surv, int *accepted, int *rounds) {
+  const int cs = (n + VAMD_CHASE_CHUNKS - 1) / VAMD_CHASE_CHUNKS;
+  float ring_amp[VAMD_RING];
+  int ring_pos[VAMD_RING];
+  ChaseChunk r[VAMD_CHASE_CHUNKS];
+  uint32_t used[VAMD_CHASE_CHUNKS];
+  int nc = 0;
+  for (int c = 0; c < VAMD_CHASE_CHUNKS && c * cs < n; c++, nc++) {
+    const int s0 = c * cs, e0 = s0 + cs < n ? s0 + cs : n;
+    r[c] = chase_chunk(seeds, linesper, n, s0, e0, VAMD_CHASE_WARM * linesper, 0, ring_amp, ring_pos, 1, 0);
+    used[c] = r[c].sig_in;
+  }
+  int ok = 0, rd = 0;
+  {  // a long run of equal values: straight to the serial walk
+    int run = 0, longest = 0;
+    for (int c = 0; c < nc; c++) {
+      const int s0 = c * cs, e0 = s0 + cs < n ? s0 + cs : n;
+      run = chase_flat_chunk(seeds, s0, e0) ? run + 1 : 0;
+      if (run > longest) longest = run;
+    }
+    if (longest > VAMD_CHASE_FLAT_MAX) {
+      *accepted = 0;
+      *rounds = -1;
+      return 0;
+    }
+  }
+  for (; rd <= VAMD_CHASE_ROUNDS; rd++) {
+    // (all chunks of a round look at the previous round's exits, as the lanes of a wave do)
+    uint32_t prev[VAMD_CHASE_CHUNKS];
+    for (int c = 0; c < nc; c++) prev[c] = c ? r[c - 1].sig_out : 0;
+    int need_any = 0;
+    for (int c = 0; c < nc; c++) {
+      if (r[c].exact || used[c] == prev[c]) continue;
+      need_any = 1;
+      if (rd == VAMD_CHASE_ROUNDS) break;
+      const int s0 = c * cs, e0 = s0 + cs < n ? s0 + cs : n;
+      const ChaseChunk t = chase_chunk(seeds, linesper, n, s0, e0, -1, prev[c], ring_amp, ring_pos, 1, 0);
+      used[c] = prev[c];
+      r[c].popped = t.popped;
+      r[c].sig_out = t.sig_out;
+    }
+    if (!need_any) {
+      ok = 1;
+      break;
+    }
+  }
+  int ns = 0;
+  for (int c = 0; c < nc; c++) {
+    const int s0 = c * cs, e0 = s0 + cs < n ? s0 + cs : n;
+    for (int k = 0; k < e0 - s0; k++)
+      if (!((r[c].popped >> k) & 1u)) surv[ns++] = (unsigned short)(s0 + k);
+  }
+  *accepted = ok;
+  *rounds = rd;
+  return ns;
+}
+
 // seed_chase part 1 two ways over the same seed lines: the serial walk (tone_chase_thread) and the chunked one
 // (chase_chunks_host); returns 1 if the survivor lists agree, and through *accepted whether the chunks verified.
 int emul_chase_compare(const float *seeds, int linesper, int n, int *accepted, int *nsurv_out, int *rounds) {

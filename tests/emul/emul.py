@@ -32,14 +32,15 @@ def packet_bytes(row, bits):
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, "emul.cpp")] + [os.path.join(_ROOT, "vorbis_amd", "csrc", f)
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".cpp", ".h"))] + \
+           [os.path.join(_ROOT, "vorbis_amd", "csrc", f)
                                                  for f in os.listdir(os.path.join(_ROOT, "vorbis_amd", "csrc"))
                                                  if f.endswith(".h")] + \
            [os.path.join(_ROOT, "include", f) for f in os.listdir(os.path.join(_ROOT, "include"))]
     if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(s) for s in srcs):
         return LIB
     cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wno-unknown-pragmas",
-           "-I" + os.path.join(_ROOT, "include"), "-I" + os.path.join(_ROOT, "vorbis_amd", "csrc"),
+           "-I" + os.path.join(_ROOT, "include"), "-I" + os.path.join(_ROOT, "vorbis_amd", "csrc"), "-I" + _HERE,
            "-shared", "-o", LIB, os.path.join(_HERE, "emul.cpp")]
     subprocess.check_call(cmd)
     return LIB

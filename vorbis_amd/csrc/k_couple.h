@@ -19,11 +19,7 @@
 
 namespace vamd {
 
-#if VAMD_GPU
-__constant__ uint32_t g_floor1_db_bits[256] = {VAMD_FLOOR1_DB_TABLE_BITS};
-#else
-static const uint32_t g_floor1_db_bits[256] = {VAMD_FLOOR1_DB_TABLE_BITS};
-#endif
+VAMD_CONST_TABLE uint32_t g_floor1_db_bits[256] = {VAMD_FLOOR1_DB_TABLE_BITS};
 VAMD_DEV float floor1_fromdB(int i) { return f_from_bits(g_floor1_db_bits[i & 255]); }
 
 // +-rint(sqrt(ve)) as the reference writes it (lib/psy.c:958-962: sqrt and rint in fp64).  The answer is the integer
@@ -49,11 +45,7 @@ VAMD_DEV int quant_energy_from(float ve, float r, float kf) {
 }
 VAMD_DEV int quant_energy(float ve, float r) {
   if (!(ve < 1.7e13f)) return quant_energy_f64(ve, r);  // k >= 2^22, or not a number
-#if VAMD_GPU
-  return quant_energy_from(ve, r, __builtin_rintf(__builtin_amdgcn_sqrtf(ve)));  // v_sqrt_f32: within one ulp
-#else
-  return quant_energy_from(ve, r, rintf(sqrtf(ve)));
-#endif
+  return quant_energy_from(ve, r, rintf(approx_sqrtf(ve)));  // (v_sqrt_f32: within one ulp)
 }
 
 struct CoupleLds {
@@ -261,9 +253,7 @@ VAMD_DEV void couple_block(const CoupleP &C, const PsyP &P, int n2, const float 
     // (two quads in flight, not WAVE_FOR's four: at four the kernel needs 110 VGPRs and the SIMD holds four waves;
     // the stage is a chain of fp64 square roots and correctly rounded divisions, which more waves hide better
     // than more unrolling)
-#if VAMD_GPU
 #pragma unroll 2
-#endif
     for (int q = LANE; q < (n2 >> 2); q += NLANES) {
       float m0[4], m1[4];
       int l0[4], l1[4], o0[4], o1[4];
@@ -275,9 +265,7 @@ VAMD_DEV void couple_block(const CoupleP &C, const PsyP &P, int n2, const float 
         const I2 t1 = ((const I2 *)ilogmask[Ai])[q];
         l1[0] = t1.x & 0xffff; l1[1] = (int)((unsigned)t1.x >> 16); l1[2] = t1.y & 0xffff; l1[3] = (int)((unsigned)t1.y >> 16);
       }
-#if VAMD_GPU
 #pragma unroll
-#endif
       for (int c = 0; c < 4; c++) {
         const int b = (q << 2) + c;
         ChanBin M = chan_bin(nz[Mi], m0[c], l0[c], b, nstart, C);

@@ -119,16 +119,12 @@ VAMD_DEV uint32_t env_trigger_bits_one(const EnvP &E, const float *__restrict__ 
   uint32_t bits = 0;
   const float acc = a[0], prev = a[-amp_stride];
   float hist[VAMD_VE_MAXSTRETCH];
-#if VAMD_GPU
 #pragma unroll
-#endif
   for (int i = 0; i < VAMD_VE_MAXSTRETCH; i++) hist[i] = a[-(2 + i) * amp_stride];
   const float postmax = acc > prev ? acc : prev;
   const float postmin = acc < prev ? acc : prev;
   float premax = -99999.f, premin = 99999.f;
-#if VAMD_GPU
 #pragma unroll
-#endif
   for (int i = 0; i < VAMD_VE_MAXSTRETCH; i++) {
     const float v = hist[i];
     premax = premax > v ? premax : v;

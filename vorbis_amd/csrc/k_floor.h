@@ -39,12 +39,10 @@ struct FitTerm {
 
 // LDS scratch.  Everything the ordered sections chase serially (fit values, neighbour
 // maps, the floor's static index tables) is NOT here: it lives one entry per lane in
-// registers (LaneInts / LaneDoubles) and is read with v_readlane.
+// registers (LaneInts) and is read with v_readlane.
 struct FloorScratch {
   FitAcc acc[VAMD_MAXPOSTS];  // 40 B each; later reused as [intervals][5] doubles (40 B each)
   double pair_sums[16];
-  int segx[VAMD_MAXPOSTS + 1], segy[VAMD_MAXPOSTS + 1];
-  int nseg;
 };
 
 // _vp_offset_and_mix with offset_select == 1 (the only select the VBR path uses), for one quad of bins:
@@ -59,9 +57,7 @@ VAMD_DEV I2 offset_and_mix_quad(const PsyP &P, int q, const float *nz, const flo
   // logmdct (lib/mapping0.c:384-385) is a function of the spectrum that is read here anyway: recomputed, not
   // fetched -- the transform stage need not write it, nor this one read it (16 KB per stereo block)
   for (int c = 0; c < 4; c++) lmv[c] = todB_345(md[c]);
-#if VAMD_GPU
 #pragma unroll
-#endif
   for (int c = 0; c < 4; c++) {
     float val = nz[c] + no[c];
     if (val > P.noisemaxsupp) val = P.noisemaxsupp;
@@ -186,9 +182,7 @@ VAMD_DEV int accumulate_segment(const unsigned int *rec, const unsigned short *q
                              (unsigned)(qa.w & m0.w), (unsigned)(qb.x & m1.x), (unsigned)(qb.y & m1.y),
                              (unsigned)(qb.z & m1.z), (unsigned)(qb.w & m1.w)};
   unsigned int cnt_all = 0, qs_all = 0, cnt_a = 0, qs_a = 0;
-#if VAMD_GPU
 #pragma unroll
-#endif
   for (int c = 0; c < 16; c++) {
     const unsigned int hw = (w[c >> 1] >> (16 * (c & 1))) & 0xffffu;
     const unsigned int q = hw & 0x7fffu, a01 = hw >> 15;
@@ -237,89 +231,6 @@ VAMD_DEV FitTerm fit_term(const FitAcc &a, float twofitweight) {
   return t;  // (the reference also sums y2b, which nothing reads)
 }
 
-struct FitTerms {  // FitTerm of interval i lives in lane i
-  LaneDoubles xb, yb, x2b, xyb, bn;
-};
-
-VAMD_DEV int fit_line(const FitTerms &T, int first, int fits, int x0, int x1, int *y0, int *y1) {
-  double xb = 0, yb = 0, x2b = 0, xyb = 0, bn = 0;
-  for (int i = first; i < first + fits; i++) {
-    xb += T.xb.get(i);
-    yb += T.yb.get(i);
-    x2b += T.x2b.get(i);
-    xyb += T.xyb.get(i);
-    bn += T.bn.get(i);
-  }
-  if (*y0 >= 0) {
-    xb += x0; yb += *y0; x2b += x0 * x0; xyb += *y0 * x0; bn++;
-  }
-  if (*y1 >= 0) {
-    xb += x1; yb += *y1; x2b += x1 * x1; xyb += *y1 * x1; bn++;
-  }
-  const double denom = (bn * x2b - xb * xb);
-  if (denom > 0.) {
-    const double aa = (yb * x2b - xyb * xb) / denom;
-    const double bb = (bn * xyb - xb * yb) / denom;
-    *y0 = (int)rint(aa + bb * x0);
-    *y1 = (int)rint(aa + bb * x1);
-    if (*y0 > 1023) *y0 = 1023;
-    if (*y1 > 1023) *y1 = 1023;
-    if (*y0 < 0) *y0 = 0;
-    if (*y1 < 0) *y1 = 0;
-    return 0;
-  }
-  *y0 = 0;
-  *y1 = 0;
-  return 1;
-}
-
-#if VAMD_GPU
-// The two fit_line calls of a split (lib/floor1.c:648-651: left and right of the new post, both
-// unconstrained) as ONE pass over the wave: lanes 0-4 sum the five quantities of the left range,
-// lanes 8-12 those of the right range, each in interval order out of LDS (one 8-byte read and one
-// dependent fp64 add per interval instead of ten v_readlane and five adds), then every lane of a
-// group evaluates the closed form once.  Same operand order as fit_line above.
-//   term   LDS [intervals][5] doubles: xb, yb, x2b, xyb, bn of each interval (fit_term)
-//   sums   LDS [2][8] doubles scratch
-VAMD_DEV void fit_line_pair(const double *term, double *sums, int firstL, int fitsL, int x0L, int x1L, int firstR,
-                            int fitsR, int x0R, int x1R, int *ret0, int *ly0, int *ly1, int *ret1, int *hy0,
-                            int *hy1) {
-  const int grp = (LANE >> 3) & 1, q = LANE & 7;
-  const int first = grp ? firstR : firstL, fits = grp ? fitsR : fitsL;
-  const int most = fitsL > fitsR ? fitsL : fitsR;
-  double acc = 0.;
-  if (LANE < 16 && q < 5) {
-    const double *t = term + first * 5 + q;
-    for (int i = 0; i < most; i++)
-      if (i < fits) acc += t[i * 5];
-    sums[grp * 8 + q] = acc;
-  }
-  WAVE_SYNC();
-  const double xb = sums[grp * 8], yb = sums[grp * 8 + 1], x2b = sums[grp * 8 + 2], xyb = sums[grp * 8 + 3],
-               bn = sums[grp * 8 + 4];
-  const int x0 = grp ? x0R : x0L, x1 = grp ? x1R : x1L;
-  const double denom = (bn * x2b - xb * xb);
-  int r = 1, y0 = 0, y1 = 0;
-  if (denom > 0.) {
-    const double aa = (yb * x2b - xyb * xb) / denom;
-    const double bb = (bn * xyb - xb * yb) / denom;
-    y0 = (int)rint(aa + bb * x0);
-    y1 = (int)rint(aa + bb * x1);
-    if (y0 > 1023) y0 = 1023;
-    if (y1 > 1023) y1 = 1023;
-    if (y0 < 0) y0 = 0;
-    if (y1 < 0) y1 = 0;
-    r = 0;
-  }
-  *ret0 = __builtin_amdgcn_readlane(r, 0);
-  *ly0 = __builtin_amdgcn_readlane(y0, 0);
-  *ly1 = __builtin_amdgcn_readlane(y1, 0);
-  *ret1 = __builtin_amdgcn_readlane(r, 8);
-  *hy0 = __builtin_amdgcn_readlane(y0, 8);
-  *hy1 = __builtin_amdgcn_readlane(y1, 8);
-  WAVE_SYNC();  // sums[] is rewritten by the next split
-}
-#endif
 
 // The line walk of inspect_error / render_line0 (lib/floor1.c:516-527,923-946) in closed form.  The reference steps
 // y by base = dy / adx and by one more whenever the running remainder of ady' = |dy| - |base| * adx overflows adx:
@@ -357,9 +268,7 @@ VAMD_DEV int inspect_error_wave(int x0, int x1, int y0, int y1, const unsigned s
     const unsigned int span = (unsigned int)(F.over_i + F.under_i - 1);
     unsigned int first = LANE == 0 ? 1u : 0u;
     int nsgn = -s.sgn;
-#if VAMD_GPU
-    asm volatile("" : "+s"(nsgn));  // (kept opaque: a known +-1 turns the multiply-add into negate + select)
-#endif
+    keep_opaque(nsgn);  // (a known +-1 would turn the multiply-add into negate + select)
     for (int k = LANE; k < cnt; k += NLANES) {
       const int q = div_magic(mad24(k, s.ady, 0), s.magic);
       const unsigned int qv = qc[x0 + k];
@@ -428,6 +337,117 @@ struct PostSteps {
   }
 };
 
+// ---- the two wave-parallel pieces of the fit and of the curve.  (The one-lane test build, which has no lanes to
+// deal the work to, takes serial forms of the same two functions from tests/emul/k_floor_host.h.)
+#if VAMD_GPU
+// The two fit_line calls of a split (lib/floor1.c:648-651: left and right of the new post, both
+// unconstrained) as ONE pass over the wave: lanes 0-4 sum the five quantities of the left range,
+// lanes 8-12 those of the right range, each in interval order out of LDS (one 8-byte read and one
+// dependent fp64 add per interval instead of ten v_readlane and five adds), then every lane of a
+// group evaluates the closed form once.  Same operand order as fit_line above.
+//   term   LDS [intervals][5] doubles: xb, yb, x2b, xyb, bn of each interval (fit_term)
+//   sums   LDS [2][8] doubles scratch
+VAMD_DEV void fit_line_pair(const double *term, double *sums, int firstL, int fitsL, int x0L, int x1L, int firstR,
+                            int fitsR, int x0R, int x1R, int *ret0, int *ly0, int *ly1, int *ret1, int *hy0,
+                            int *hy1) {
+  const int grp = (LANE >> 3) & 1, q = LANE & 7;
+  const int first = grp ? firstR : firstL, fits = grp ? fitsR : fitsL;
+  const int most = fitsL > fitsR ? fitsL : fitsR;
+  double acc = 0.;
+  if (LANE < 16 && q < 5) {
+    const double *t = term + first * 5 + q;
+    for (int i = 0; i < most; i++)
+      if (i < fits) acc += t[i * 5];
+    sums[grp * 8 + q] = acc;
+  }
+  WAVE_SYNC();
+  const double xb = sums[grp * 8], yb = sums[grp * 8 + 1], x2b = sums[grp * 8 + 2], xyb = sums[grp * 8 + 3],
+               bn = sums[grp * 8 + 4];
+  const int x0 = grp ? x0R : x0L, x1 = grp ? x1R : x1L;
+  const double denom = (bn * x2b - xb * xb);
+  int r = 1, y0 = 0, y1 = 0;
+  if (denom > 0.) {
+    const double aa = (yb * x2b - xyb * xb) / denom;
+    const double bb = (bn * xyb - xb * yb) / denom;
+    y0 = (int)rint(aa + bb * x0);
+    y1 = (int)rint(aa + bb * x1);
+    if (y0 > 1023) y0 = 1023;
+    if (y1 > 1023) y1 = 1023;
+    if (y0 < 0) y0 = 0;
+    if (y1 < 0) y1 = 0;
+    r = 0;
+  }
+  *ret0 = __builtin_amdgcn_readlane(r, 0);
+  *ly0 = __builtin_amdgcn_readlane(y0, 0);
+  *ly1 = __builtin_amdgcn_readlane(y1, 0);
+  *ret1 = __builtin_amdgcn_readlane(r, 8);
+  *hy0 = __builtin_amdgcn_readlane(y0, 8);
+  *hy1 = __builtin_amdgcn_readlane(y1, 8);
+  WAVE_SYNC();  // sums[] is rewritten by the next split
+}
+
+// The integer curve of floor1_encode / render_line0 (lib/floor1.c:923-946), from the quantised posts.
+VAMD_DEV void floor_render_curve(const FloorP &F, int posts, int n2, const LaneInts &forward_index, const LaneInts &post,
+                                 const LaneInts &postlist, FloorScratch *sc, ilog_t *__restrict__ ilogmask, PhaseClock &pc) {
+  // Lane j looks at the j-th post in x order.  The curve over [x_j, x_j+1) is the line from the last USED post at or
+  // before j to the first used one after it (render_line0, lib/floor1.c:923-946; held flat past the last used post,
+  // :941-943): both are bit scans of the ballot of used posts, their x / y come over from those lanes, and lane j
+  // leaves the line's constants in row j.  A bin then needs no search at all: bin_interval[x] (static) IS its j.
+  // The rows overlay the fit's accumulators, which are dead by now.
+  struct SegRow {
+    int x0, y0, ady, sgn;
+    unsigned int magic;
+    int pad[3];
+  };
+  SegRow *rows = (SegRow *)sc->acc;
+  {
+    const int j = LANE;
+    const int cur = forward_index.at(j);
+    const int src = j < posts ? cur : 0;
+    const int pv = post.gather(src), px = postlist.gather(src);  // (gathers need every lane active)
+    const bool used = j < posts && (j == 0 || (pv & 0x8000) == 0);
+    const unsigned long long um = __ballot(used);
+    const int myx = j == 0 ? 0 : px, myy = (pv & 0x7fff) * F.mult;
+    const unsigned long long upto = j >= 63 ? ~0ull : ((2ull << j) - 1ull);
+    const int sidx = 63 - __builtin_clzll(um & upto);  // (bit 0 is always set)
+    const unsigned long long above = um & ~upto;
+    const int eidx = above ? __builtin_ctzll(above) : sidx;
+    const int xs = __shfl(myx, sidx, 64), ys = __shfl(myy, sidx, 64);
+    const int xe = __shfl(myx, eidx, 64), ye = __shfl(myy, eidx, 64);
+    if (j < posts) {
+      SegRow r;
+      r.x0 = xs, r.y0 = ys;
+      r.ady = 0, r.sgn = 1, r.magic = 0, r.pad[0] = r.pad[1] = r.pad[2] = 0;
+      if (above) {
+        const LineStep st = line_step(xs, xe, ys, ye, F.div_magic);
+        r.ady = st.ady, r.sgn = st.sgn, r.magic = st.magic;
+      }
+      rows[j] = r;
+    }
+  }
+  WAVE_SYNC();
+  pc.mark(3);
+  if (ilogmask) {
+    WAVE_FOR(q, n2 >> 2) {
+      const unsigned int jq = ((const unsigned int *)F.bin_interval)[q];
+      int v[4];
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const int jb = (int)((jq >> (8 * c)) & 0xff);
+        const SegRow r = rows[jb == 255 ? posts - 1 : (jb & 0x7f)];
+        const int k = 4 * q + c - r.x0;
+        v[c] = mad24(div_magic(mad24(k, r.ady, 0), r.magic), r.sgn, r.y0);
+      }
+      I2 o;
+      o.x = v[0] | (v[1] << 16), o.y = v[2] | (v[3] << 16);
+      ((I2 *)ilogmask)[q] = o;
+    }
+  }
+}
+#else
+#include "k_floor_host.h"
+#endif
+
 // floor1_fit for one channel-block (lib/floor1.c:576-729).
 //   qc    LDS [n2]   quantised mask + class bit, see offset_and_mix_wave
 //   outp  floor1_fit's return, one post per lane (bit 15 = unused flag); untouched when it returns 0
@@ -457,36 +477,18 @@ VAMD_DEV int floor_fit_posts(const FloorP &F, const unsigned short *qc, FloorScr
   WAVE_FOR(sg, F.fit_nseg) nz += accumulate_segment(F.fit_segs + VAMD_FITSEG_WORDS * sg, qc, sc->acc);
   nz = wave_sum(nz);
   WAVE_SYNC();
-#if !VAMD_GPU
-  FitTerms T;
-#endif
-  {
-    // lane i forms interval i's fit_line contribution
-#if VAMD_GPU
-    FitAcc mine = sc->acc[LANE < posts - 1 ? LANE : 0];
-    const FitTerm ft = fit_term(mine, F.twofitweight);
-    // the terms go to LDS as rows for fit_line_pair, over the accumulators (dead from here on)
-    WAVE_SYNC();
-    if (LANE < posts - 1) {
-      double *row = (double *)sc->acc + LANE * 5;
-      row[0] = ft.xb;
-      row[1] = ft.yb;
-      row[2] = ft.x2b;
-      row[3] = ft.xyb;
-      row[4] = ft.bn;
-    }
-    WAVE_SYNC();
-#else
-    for (int i = 0; i < posts - 1; i++) {
-      const FitTerm ft = fit_term(sc->acc[i], F.twofitweight);
-      T.xb.a[i] = ft.xb;
-      T.yb.a[i] = ft.yb;
-      T.x2b.a[i] = ft.x2b;
-      T.xyb.a[i] = ft.xyb;
-      T.bn.a[i] = ft.bn;
-    }
-#endif
+  // lane i forms interval i's fit_line contribution; the terms go to LDS as rows for fit_line_pair, each over its own
+  // interval's accumulators (40 bytes either way), which are dead from here on
+  WAVE_FOR(i, posts - 1) {
+    const FitTerm ft = fit_term(sc->acc[i], F.twofitweight);
+    double *row = (double *)sc->acc + i * 5;
+    row[0] = ft.xb;
+    row[1] = ft.yb;
+    row[2] = ft.x2b;
+    row[3] = ft.xyb;
+    row[4] = ft.bn;
   }
+  WAVE_SYNC();
   pc.mark(1);
 
   if (!nz) return 0;  // floor1_fit returns NULL
@@ -495,13 +497,9 @@ VAMD_DEV int floor_fit_posts(const FloorP &F, const unsigned short *qc, FloorScr
   // walks the same decisions; the state is in lane registers.
   {
     int y0 = -200, y1 = -200;
-#if VAMD_GPU
     int r0, r1, u0, u1;  // the whole-range fit rides in the left half of the pair routine
     fit_line_pair((const double *)sc->acc, sc->pair_sums, 0, posts - 1, sorted_index.get(0), sorted_index.get(posts - 1),
                   0, 0, 0, 0, &r0, &y0, &y1, &r1, &u0, &u1);
-#else
-    fit_line(T, 0, posts - 1, sorted_index.get(0), sorted_index.get(posts - 1), &y0, &y1);
-#endif
     fitA.set(0, y0);
     fitB.set(0, y0);
     fitB.set(1, y1);
@@ -521,17 +519,10 @@ VAMD_DEV int floor_fit_posts(const FloorP &F, const unsigned short *qc, FloorScr
       // (ly == -1 || hy == -1 => exit(1) in the reference: unreachable, fits are >= 0 or -200)
       if (inspect_error_wave(lx, hx, ly, hy, qc, F)) {
         int ly0 = -200, ly1 = -200, hy0 = -200, hy1 = -200;
-#if VAMD_GPU
         int ret0, ret1;
         fit_line_pair((const double *)sc->acc, sc->pair_sums, lsortpos, sortpos - lsortpos, sorted_index.get(lsortpos),
                       sorted_index.get(sortpos), sortpos, hsortpos - sortpos, sorted_index.get(sortpos),
                       sorted_index.get(hsortpos), &ret0, &ly0, &ly1, &ret1, &hy0, &hy1);
-#else
-        const int ret0 = fit_line(T, lsortpos, sortpos - lsortpos, sorted_index.get(lsortpos),
-                                  sorted_index.get(sortpos), &ly0, &ly1);
-        const int ret1 = fit_line(T, sortpos, hsortpos - sortpos, sorted_index.get(sortpos),
-                                  sorted_index.get(hsortpos), &hy0, &hy1);
-#endif
         if (ret0) {
           ly0 = ly;
           ly1 = hy0;
@@ -674,107 +665,12 @@ VAMD_DEV int floor_encode_render(const FloorP &F, int n2, const LaneInts &outp, 
   LaneInts postlist, forward_index, post;
   postlist.load(F.postlist, posts);
   forward_index.load(F.forward_index, posts);
-#if VAMD_GPU
-  if (posts_out && LANE < VAMD_POSTS_STRIDE) posts_out[LANE] = LANE < posts ? outp.mine() : 0;
-#else
-  for (int i = 0; i < VAMD_POSTS_STRIDE; i++)
-    if (posts_out) posts_out[i] = i < posts ? outp.get(i) : 0;
-#endif
+  WAVE_FOR(i, VAMD_POSTS_STRIDE) if (posts_out) posts_out[i] = i < posts ? outp.at(i) : 0;
   if (post_valid && LANE == 0) *post_valid = 1;
   floor_quantise_predict(F, outp, postlist, post, nullptr);
 
-  // ---- render the integer curve, lib/floor1.c:923-946: segment list of the
-  // used posts in x order, then every bin evaluates its segment's line.
-#if VAMD_GPU
-  // Lane j looks at the j-th post in x order.  The curve over [x_j, x_j+1) is the line from the last USED post at or
-  // before j to the first used one after it (render_line0, lib/floor1.c:923-946; held flat past the last used post,
-  // :941-943): both are bit scans of the ballot of used posts, their x / y come over from those lanes, and lane j
-  // leaves the line's constants in row j.  A bin then needs no search at all: bin_interval[x] (static) IS its j.
-  // The rows overlay the fit's accumulators, which are dead by now.
-  struct SegRow {
-    int x0, y0, ady, sgn;
-    unsigned int magic;
-    int pad[3];
-  };
-  SegRow *rows = (SegRow *)sc->acc;
-  {
-    const int j = LANE;
-    const int cur = forward_index.at(j);
-    const int src = j < posts ? cur : 0;
-    const int pv = post.gather(src), px = postlist.gather(src);  // (gathers need every lane active)
-    const bool used = j < posts && (j == 0 || (pv & 0x8000) == 0);
-    const unsigned long long um = __ballot(used);
-    const int myx = j == 0 ? 0 : px, myy = (pv & 0x7fff) * F.mult;
-    const unsigned long long upto = j >= 63 ? ~0ull : ((2ull << j) - 1ull);
-    const int sidx = 63 - __builtin_clzll(um & upto);  // (bit 0 is always set)
-    const unsigned long long above = um & ~upto;
-    const int eidx = above ? __builtin_ctzll(above) : sidx;
-    const int xs = __shfl(myx, sidx, 64), ys = __shfl(myy, sidx, 64);
-    const int xe = __shfl(myx, eidx, 64), ye = __shfl(myy, eidx, 64);
-    if (j < posts) {
-      SegRow r;
-      r.x0 = xs, r.y0 = ys;
-      r.ady = 0, r.sgn = 1, r.magic = 0, r.pad[0] = r.pad[1] = r.pad[2] = 0;
-      if (above) {
-        const LineStep st = line_step(xs, xe, ys, ye, F.div_magic);
-        r.ady = st.ady, r.sgn = st.sgn, r.magic = st.magic;
-      }
-      rows[j] = r;
-    }
-  }
-  WAVE_SYNC();
-  pc.mark(3);
-  if (ilogmask) {
-    WAVE_FOR(q, n2 >> 2) {
-      const unsigned int jq = ((const unsigned int *)F.bin_interval)[q];
-      int v[4];
-#pragma unroll
-      for (int c = 0; c < 4; c++) {
-        const int jb = (int)((jq >> (8 * c)) & 0xff);
-        const SegRow r = rows[jb == 255 ? posts - 1 : (jb & 0x7f)];
-        const int k = 4 * q + c - r.x0;
-        v[c] = mad24(div_magic(mad24(k, r.ady, 0), r.magic), r.sgn, r.y0);
-      }
-      I2 o;
-      o.x = v[0] | (v[1] << 16), o.y = v[2] | (v[3] << 16);
-      ((I2 *)ilogmask)[q] = o;
-    }
-  }
-#else
-  {
-    int ns = 0;
-    sc->segx[0] = 0;
-    sc->segy[0] = post.get(0) * F.mult;
-    for (int j = 1; j < posts; j++) {
-      const int cur = forward_index.get(j);
-      const int pc_ = post.get(cur);
-      const int hy = pc_ & 0x7fff;
-      if (hy == pc_) {
-        ns++;
-        sc->segx[ns] = postlist.get(cur);
-        sc->segy[ns] = hy * F.mult;
-      }
-    }
-    sc->nseg = ns;
-  }
-  WAVE_SYNC();
-  pc.mark(3);
-  if (ilogmask) {
-    const int ns = sc->nseg;
-    WAVE_FOR(x, n2) {
-      int v;
-      if (x >= sc->segx[ns]) {
-        v = sc->segy[ns];
-      } else {
-        int s = 0;
-        while (x >= sc->segx[s + 1]) s++;
-        const LineStep st = line_step(sc->segx[s], sc->segx[s + 1], sc->segy[s], sc->segy[s + 1], F.div_magic);
-        v = line_y(st, sc->segy[s], x - sc->segx[s]);
-      }
-      ilogmask[x] = (ilog_t)v;
-    }
-  }
-#endif
+  // ---- render the integer curve, lib/floor1.c:923-946
+  floor_render_curve(F, posts, n2, forward_index, post, postlist, sc, ilogmask, pc);
   WAVE_SYNC();
   pc.mark(4);
   return 1;

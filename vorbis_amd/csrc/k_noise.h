@@ -128,9 +128,6 @@ struct ScanTeam {
     team_lds_barrier();
   }
 };
-#define LANE_BINS(k, i, i0, KPL, n) _Pragma("unroll") for (int k = 0, i = (i0) + LANE; k < (KPL); k++, i += NLANES) if (i < (n))
-#else
-#define LANE_BINS(k, i, i0, KPL, n) for (int k = 0, i = (i0); k < (KPL) && i < (n); k++, i++)
 #endif
 
 // One window of running sums -> (A, B, D).  `hi` is the upper edge; `e2` the lower edge, or the mirrored

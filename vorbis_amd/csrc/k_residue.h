@@ -25,13 +25,9 @@ VAMD_DEV int residue_besterror(const ResP &R, const vamd_book_tab &bk, int *a) {
   int index = 0;
   int p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int av[8];
-#if VAMD_GPU
 #pragma unroll
-#endif
   for (int i = 0; i < 8; i++) av[i] = i < dim ? a[i] : 0;
-#if VAMD_GPU
 #pragma unroll
-#endif
   for (int o = 7; o >= 0; o--) {
     if (o >= dim) continue;
     // C's (a - minval + (del>>1)) / del truncates toward zero; del == 1 needs no division
@@ -74,9 +70,7 @@ VAMD_DEV int residue_besterror(const ResP &R, const vamd_book_tab &bk, int *a) {
       }
     }
   }
-#if VAMD_GPU
 #pragma unroll
-#endif
   for (int i = 0; i < 8; i++)
     if (i < dim) a[i] = av[i] - p[i];
   return index;

@@ -63,20 +63,14 @@ VAMD_DEV void seed_curve_scatter(float *seed, const float *__restrict__ band_row
     p0 = (int)posts.x;
     p1 = (int)posts.y;
   }
-#if VAMD_GPU
-  const unsigned long long live = __ballot(active);
-  (void)live;
 #pragma unroll
-#endif
   for (int g = 0; g < VAMD_EHMER_MAX / 8; g++) {
     if (!wave_any(active && p0 < 8 * g + 8 && p1 > 8 * g)) continue;
     if (active) {
       float c[8];
       f4_get(row[2 * g], c);
       f4_get(row[2 * g + 1], c + 4);
-#if VAMD_GPU
 #pragma unroll
-#endif
       for (int i = 0; i < 8; i++) lds_atomic_max(p + (8 * g + i) * linesper, amp + c[i]);
     }
   }
@@ -163,9 +157,7 @@ VAMD_DEV int tone_chase_thread(const float *__restrict__ seeds, int linesper, in
     }
     const float blk[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w,
                            v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
-#if VAMD_GPU
 #pragma unroll
-#endif
     for (int j = 0; j < 16; j++) {
       const int i = (b << 4) + j;
       if (i < n) {
@@ -299,8 +291,9 @@ VAMD_DEV ChaseChunk chase_chunk(const float *seeds, int linesper, int n, int s, 
 #define VAMD_CHASE_WARM 2    // cold start this many windows (linesper) before a chunk: one needs a repair round every time,
                              // two in one block out of thirty, three or four never (measured on the host; 16 + 20 lines walked)
 #endif
-// what the chunks of one block add up to: accepted (every chunk entered in its predecessor's exit state)?
-// Host form, chunk after chunk (the GPU kernel runs chase_chunk one per lane and combines with wave operations).
+// What the chunks of one block add up to: accepted iff every chunk entered in its predecessor's exit state
+// (k_tone_chase_wave runs chase_chunk one per lane and combines with wave operations; tests/emul/emul.cpp walks the same
+// chunks one after the other and compares with the serial walk).
 // Repair rounds before a block is handed to the serial walk.  A run of equal values (a stretch no curve reached)
 // carries a phase from its beginning, so the true state crosses it one chunk per round: worth it up to about two dozen
 // chunks (a round is ~20 lines per lane, the serial walk ~800 for one); a block with a longer run goes serial at once
@@ -315,64 +308,6 @@ VAMD_DEV int chase_flat_chunk(const float *seeds, int s, int e) {
   for (int i = s; i < e; i++) flat &= seeds[i] == v;
   return flat;
 }
-#if !VAMD_GPU
-VAMD_DEV int chase_chunks_host(const float *seeds, int linesper, int n, unsigned short *surv, int *accepted, int *rounds) {
-  const int cs = (n + VAMD_CHASE_CHUNKS - 1) / VAMD_CHASE_CHUNKS;
-  float ring_amp[VAMD_RING];
-  int ring_pos[VAMD_RING];
-  ChaseChunk r[VAMD_CHASE_CHUNKS];
-  uint32_t used[VAMD_CHASE_CHUNKS];
-  int nc = 0;
-  for (int c = 0; c < VAMD_CHASE_CHUNKS && c * cs < n; c++, nc++) {
-    const int s0 = c * cs, e0 = s0 + cs < n ? s0 + cs : n;
-    r[c] = chase_chunk(seeds, linesper, n, s0, e0, VAMD_CHASE_WARM * linesper, 0, ring_amp, ring_pos, 1, 0);
-    used[c] = r[c].sig_in;
-  }
-  int ok = 0, rd = 0;
-  {  // a long run of equal values: straight to the serial walk
-    int run = 0, longest = 0;
-    for (int c = 0; c < nc; c++) {
-      const int s0 = c * cs, e0 = s0 + cs < n ? s0 + cs : n;
-      run = chase_flat_chunk(seeds, s0, e0) ? run + 1 : 0;
-      if (run > longest) longest = run;
-    }
-    if (longest > VAMD_CHASE_FLAT_MAX) {
-      *accepted = 0;
-      *rounds = -1;
-      return 0;
-    }
-  }
-  for (; rd <= VAMD_CHASE_ROUNDS; rd++) {
-    // (all chunks of a round look at the previous round's exits, as the lanes of a wave do)
-    uint32_t prev[VAMD_CHASE_CHUNKS];
-    for (int c = 0; c < nc; c++) prev[c] = c ? r[c - 1].sig_out : 0;
-    int need_any = 0;
-    for (int c = 0; c < nc; c++) {
-      if (r[c].exact || used[c] == prev[c]) continue;
-      need_any = 1;
-      if (rd == VAMD_CHASE_ROUNDS) break;
-      const int s0 = c * cs, e0 = s0 + cs < n ? s0 + cs : n;
-      const ChaseChunk t = chase_chunk(seeds, linesper, n, s0, e0, -1, prev[c], ring_amp, ring_pos, 1, 0);
-      used[c] = prev[c];
-      r[c].popped = t.popped;
-      r[c].sig_out = t.sig_out;
-    }
-    if (!need_any) {
-      ok = 1;
-      break;
-    }
-  }
-  int ns = 0;
-  for (int c = 0; c < nc; c++) {
-    const int s0 = c * cs, e0 = s0 + cs < n ? s0 + cs : n;
-    for (int k = 0; k < e0 - s0; k++)
-      if (!((r[c].popped >> k) & 1u)) surv[ns++] = (unsigned short)(s0 + k);
-  }
-  *accepted = ok;
-  *rounds = rd;
-  return ns;
-}
-#endif
 
 // scatter half: seed[] for one channel-block (LDS), lib/psy.c:417-452,762-771
 // logfft is read straight from HBM: each lane walks the few bins of its own run, neighbouring
@@ -452,9 +387,7 @@ VAMD_DEV void tone_fold_quad(const PsyP &P, float att, const float *seed, const 
   const int bfs[4] = {bf.x, bf.y, bf.z, bf.w};
   float av[4];
   f4_get(((const F4 *)P.ath)[q], av);
-#if VAMD_GPU
 #pragma unroll
-#endif
   for (int c = 0; c < 4; c++) {
     const int i = (q << 2) + c;
     float minV;

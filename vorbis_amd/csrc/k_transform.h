@@ -15,7 +15,7 @@
 //
 // Who runs a block: a TEAM.  Every phase below is a loop over independent items (butterflies, pairs,
 // quads) followed by a team-wide sync; the items are dealt round the team's threads.  The kernels run one
-// wave per transform (WaveTeam) -- measured round 2: four waves per block (BlockTeam) bring nothing, 2.9
+// wave per transform (WaveTeam) -- measured round 2: four waves per block (a workgroup-wide team) bring nothing, 2.9
 // against 2.3 ms, because the stage is bound by the CU's LDS pipe (92 % busy, half of it bank conflicts) and
 // not by any wave's latency -- and the test build runs everything in a single lane.
 #pragma once
@@ -32,22 +32,6 @@ struct WaveTeam {  // the 64 lanes of one wavefront (one lane in the test build)
   VAMD_MEM int size() const { return NLANES; }
   VAMD_MEM void sync() const { WAVE_SYNC(); }
 };
-#if VAMD_GPU
-// TW waves of a workgroup.  The sync is the WORKGROUP's barrier: every team of a workgroup walks the same
-// phases with the same trip counts (a team without a block shadows one), so they may as well meet.
-template <int TW>
-struct BlockTeam {
-  VAMD_MEM int tid() const { return (int)(threadIdx.x & (64 * TW - 1)); }
-  VAMD_MEM int size() const { return 64 * TW; }
-  VAMD_MEM void sync() const { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-};
-#endif
-#if VAMD_GPU
-// (unrolled x4 so that the independent LDS reads of four items are in flight together)
-#define TEAM_EACH(i, count, tm) _Pragma("unroll 4") for (int i = (tm).tid(); i < (count); i += (tm).size())
-#else
-#define TEAM_EACH(i, count, tm) for (int i = (tm).tid(); i < (count); i += (tm).size())
-#endif
 
 // A block of PCM held in registers (thread t of the team owns quads t, t+T, ...): fetched from HBM one
 // block ahead of its use so that the load latency hides behind the previous block's
@@ -56,11 +40,6 @@ template <int QPT>
 struct PcmTile {
   float v[QPT][4];
 };
-#if VAMD_GPU
-#define TEAM_QUADS(kq, q, nq, QPT, tm) _Pragma("unroll") for (int kq = 0, q = (tm).tid(); kq < (QPT); kq++, q += (tm).size()) if (q < (nq))
-#else
-#define TEAM_QUADS(kq, q, nq, QPT, tm) for (int kq = 0, q = (tm).tid(); kq < (QPT) && q < (nq); kq++, q += (tm).size())
-#endif
 
 template <int QPT, class Team>
 VAMD_DEV void pcm_fetch(PcmTile<QPT> &t, const float *__restrict__ pcm, int n, const Team &tm) {
@@ -300,9 +279,7 @@ VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in0, float *w0, fl
       const int j = g >> lq, q = g & ((1 << lq) - 1);
       const int base = pts * j - 2 - 2 * q;
       F2 E[8];
-#if VAMD_GPU
 #pragma unroll
-#endif
       for (int k = 0; k < 8; k++) E[k] = *(const F2 *)(w2 + VAMD_PW(base + (k + 1) * e8));
       const int h = pts >> 4;  // q advances by a sixteenth of the sub-block from one eighth to the next
       bfly(E[7], E[3], stage_trig(s, q));
@@ -319,9 +296,7 @@ VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in0, float *w0, fl
       bfly(E[5], E[4], T2);
       bfly(E[3], E[2], T2);
       bfly(E[1], E[0], T2);
-#if VAMD_GPU
 #pragma unroll
-#endif
       for (int k = 0; k < 8; k++) *(F2 *)(w2 + VAMD_PW(base + (k + 1) * e8)) = E[k];
     }
     tm.sync();
@@ -371,40 +346,28 @@ VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in0, float *w0, fl
     VAMD_MDCT_SPLIT(gg, log2n - 6)
     F2 *pg = (F2 *)(w2 + 34 * g_);
     F2 e[16];
-#if VAMD_GPU
 #pragma unroll
-#endif
     for (int k = 0; k < 16; k++) e[k] = pg[k];
-#if VAMD_GPU
 #pragma unroll
-#endif
     for (int a = 0; a < 8; a++) {
       const PairOp r = bfly_level32(a, e[a], e[8 + a]);
       e[a] = r.lo;
       e[8 + a] = r.hi;
     }
-#if VAMD_GPU
 #pragma unroll
-#endif
     for (int h = 0; h < 2; h++) {
-#if VAMD_GPU
 #pragma unroll
-#endif
       for (int b2 = 0; b2 < 4; b2++) {
         const PairOp r = bfly_level16(b2, e[8 * h + b2], e[8 * h + 4 + b2]);
         e[8 * h + b2] = r.lo;
         e[8 * h + 4 + b2] = r.hi;
       }
     }
-#if VAMD_GPU
 #pragma unroll
-#endif
     for (int o = 0; o < 4; o++) {
       float v[8] = {e[4 * o].x, e[4 * o].y, e[4 * o + 1].x, e[4 * o + 1].y, e[4 * o + 2].x, e[4 * o + 2].y, e[4 * o + 3].x, e[4 * o + 3].y};
       bfly_level8(v);
-#if VAMD_GPU
 #pragma unroll
-#endif
       for (int k = 0; k < 4; k++) {
         F2 t;
         t.x = v[2 * k];
@@ -593,16 +556,12 @@ VAMD_DEV void fft_pass12_wave(const float *__restrict__ c, float *__restrict__ d
   const F2 w1 = *(const F2 *)wa1, w2 = *(const F2 *)wa2, w3 = *(const F2 *)wa3;
   TEAM_EACH(k, u, tm) {
     float x[16];
-#if VAMD_GPU
 #pragma unroll
-#endif
     for (int m = 0; m < 16; m++) x[m] = c[k + u * m];
     // dradf4 with ido = 1 (lib/smallft.c:176-193), butterfly k + u*t: its cc[t0+k], cc[3t0+k], cc[k], cc[2t0+k]
     // are x[t+4], x[t+12], x[t], x[t+8]; y[t][0..3] = its four outputs = the ido = 4 pass's cc[4k + i + (n/4) t]
     float y[4][4];
-#if VAMD_GPU
 #pragma unroll
-#endif
     for (int t = 0; t < 4; t++) {
       const float c1 = x[t + 4], c2 = x[t + 12], c3 = x[t], c4 = x[t + 8];
       const float tr1 = c1 + c2, tr2 = c3 + c4;
@@ -649,9 +608,7 @@ VAMD_DEV void fft_pass12_wave(const float *__restrict__ c, float *__restrict__ d
     }
     float *d = dst + VAMD_F2_POS(16 * k);  // the sixteen share a group of 32: one pad for all
     d[0] = o[0];
-#if VAMD_GPU
 #pragma unroll
-#endif
     for (int m = 1; m < 8; m++) st_pair(d, 2 * m, o[2 * m - 1], o[2 * m]);
     d[15] = o[15];
   }
@@ -785,9 +742,7 @@ VAMD_DEV void fft_tail42_wave(const float *__restrict__ cc, float *__restrict__ 
   TEAM_EACH(g, ido / 2, tm) {
     if (g == 0) {
       float V[2][8];  // block k's values at 0, ido-1, ido, 2ido-1, 2ido, 3ido-1, 3ido, 4ido-1
-#if VAMD_GPU
 #pragma unroll
-#endif
       for (int k = 0; k < 2; k++) {
         {
           const int t1 = t0 + k * ido, t2 = 3 * t0 + k * ido, t3 = k * ido, t4 = 2 * t0 + k * ido;
@@ -813,9 +768,7 @@ VAMD_DEV void fft_tail42_wave(const float *__restrict__ cc, float *__restrict__ 
       ch[n - 1] = V[0][0] - V[1][0];
       ch[n2] = -V[1][7];
       ch[n2 - 1] = V[0][7];
-#if VAMD_GPU
 #pragma unroll
-#endif
       for (int j = 1; j < 4; j++) {
         F2 c5, c3;
         c5.x = V[0][2 * j - 1], c5.y = V[0][2 * j];
@@ -826,9 +779,7 @@ VAMD_DEV void fft_tail42_wave(const float *__restrict__ cc, float *__restrict__ 
       const int i = 2 * g;
       const F2 w1 = *(const F2 *)(wa1 + i - 2), w2 = *(const F2 *)(wa2 + i - 2), w3 = *(const F2 *)(wa3 + i - 2);
       F2 Pk[2][4];  // block k's pairs at i, 2ido-i, 2ido+i, 4ido-i
-#if VAMD_GPU
 #pragma unroll
-#endif
       for (int k = 0; k < 2; k++) {
         const int t2 = k * ido + i;
         const F2 c0 = ld_pair<true>(cc, t2), c1 = ld_pair<true>(cc, t2 + t0), c2 = ld_pair<true>(cc, t2 + 2 * t0),
@@ -882,9 +833,7 @@ VAMD_DEV const float *drft_forward_wave(const XformP &P, float *c, float *ch, co
   }
   constexpr bool TAIL42 = LOGN >= 11 && (LOGN & 1);  // (at log2 n = 9 the last radix-4 pass reads the padded layout)
   const int nloop = TAIL42 ? nf - 2 : nf;
-#if VAMD_GPU
 #pragma unroll
-#endif
   for (int k1 = kfirst; k1 < nloop; k1++) {
     const int ip = LOGN ? (k1 < (LOGN >> 1) ? 4 : 2) : P.fft_fac[nf - k1 - 1];
     const int l1 = l2 / ip, ido = n / l2;

@@ -3,33 +3,27 @@
 // One 64-lane wavefront owns one channel-block (or one stereo block).  A kernel
 // body is a sequence of *phases*; inside a phase the lanes stride over
 // independent work items (WAVE_FOR), and WAVE_SYNC() separates phases that
-// communicate through LDS.  Written this way the same body compiles two ways:
+// communicate through LDS.
 //
-//   * hipcc / gfx950: LANE = threadIdx.x of a 64-thread workgroup, WAVE_SYNC =
-//     workgroup barrier (a single wave, so it is only an LDS fence + s_barrier),
-//     reductions are DPP/ds_swizzle-lowered __shfl_xor trees.
-//   * a plain host C++ compiler (tests/emul): LANE = 0, NLANES = 1 -- the phases
-//     run as ordinary serial loops.  This is a *test build only*: it lets the
-//     arithmetic of every kernel be checked bit-for-bit against the reference on
-//     a machine without a GPU.  It is never part of the product library.
+// This header defines that vocabulary for gfx950 -- the ONLY implementation the product contains: LANE =
+// threadIdx.x & 63, WAVE_SYNC = a compiler fence (the LDS unit executes a wave's DS instructions in order),
+// reductions and scans on the VALU's DPP path, small per-block arrays held one entry per lane and read with
+// v_readlane.  The test suite also compiles the kernel bodies with the host compiler as ONE lane (tests/emul), to
+// check their arithmetic against the oracle on a machine without a GPU; the vocabulary for that build lives with
+// the tests (tests/emul/vamd_wave_host.h, found only through the test build's include path) -- it is not a
+// fallback and is never part of the library.
 #pragma once
 #include <stdint.h>
 #include <string.h>
 
-#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIPCC__)
 #define VAMD_GPU 1
-#elif defined(__HIPCC__)
-#define VAMD_GPU 1
-#else
-#define VAMD_GPU 0
-#endif
-
-#if VAMD_GPU
 #include <hip/hip_runtime.h>
 #define VAMD_DEV __device__ __forceinline__
 #define VAMD_HOSTDEV __host__ __device__ __forceinline__
 #define VAMD_MEM __device__ __forceinline__
 #define VAMD_DEV_NOINLINE __device__ __noinline__
+#define VAMD_CONST_TABLE __constant__
 #define LANE ((int)(threadIdx.x & 63))  // a workgroup may hold several independent waves
 #define NLANES 64
 // Phase boundary for data exchanged through LDS.  The workgroup IS one wavefront, and
@@ -45,33 +39,10 @@
   } while (0)
 // Phase boundary for data exchanged through HBM between lanes of the wave.
 #define WAVE_SYNC_GLOBAL() __syncthreads()
-#else
-#include <math.h>
-#define VAMD_DEV static inline
-#define VAMD_HOSTDEV static inline
-#define VAMD_MEM inline
-#define VAMD_DEV_NOINLINE static
-#define LANE 0
-#define NLANES 1
-#define WAVE_SYNC() ((void)0)
-#define WAVE_SYNC_GLOBAL() ((void)0)
-#endif
-
-VAMD_DEV unsigned brev32(unsigned x) {  // bit 0 <-> bit 31
-#if VAMD_GPU
-  return __builtin_bitreverse32(x);
-#else
-  unsigned r = 0;
-  for (int b = 0; b < 32; b++) r |= ((x >> b) & 1u) << (31 - b);
-  return r;
-#endif
-}
 
 // Register tiles: a lane may keep "its" quads of a block in registers across phases.
 // Lane l owns quads l, l+64, ... (four consecutive bins each); VAMD_QPL bounds how
-// many (block sizes up to 2048 -> 1024 bins -> 4 quads per lane on the GPU; the
-// one-lane test build owns them all).
-#if VAMD_GPU
+// many (block sizes up to 2048 -> 1024 bins -> 4 quads per lane).
 #define VAMD_QPL 4
 #define LANE_QUADS(kq, q, nq) _Pragma("unroll") for (int kq = 0, q = LANE; kq < VAMD_QPL; kq++, q += NLANES) if (q < (nq))
 // a slice [q0, q1) of the quads, QPS per lane: several waves can share one block's bins
@@ -80,40 +51,27 @@ VAMD_DEV unsigned brev32(unsigned x) {  // bit 0 <-> bit 31
 // the same for a whole n-sample block (2048 samples -> 8 quads per lane)
 #define VAMD_QPL2 8
 #define LANE_QUADS2(kq, q, nq) _Pragma("unroll") for (int kq = 0, q = LANE; kq < VAMD_QPL2; kq++, q += NLANES) if (q < (nq))
-#else
-#define VAMD_QPL 1024
-#define LANE_QUADS(kq, q, nq) for (int kq = 0, q = LANE; kq < VAMD_QPL && q < (nq); kq++, q += NLANES)
-#define SLICE_QUADS(kq, q, q0, q1, QPS) for (int kq = 0, q = (q0) + LANE; kq < (QPS) && q < (q1); kq++, q += NLANES)
-#define VAMD_QPL2 2048
-#define LANE_QUADS2(kq, q, nq) for (int kq = 0, q = LANE; kq < VAMD_QPL2 && q < (nq); kq++, q += NLANES)
-#endif
-
-// lanes stride over [0, count).  On the GPU the loop is unrolled x4 so that the
-// independent HBM/L2 loads of four iterations are in flight together.
-#if VAMD_GPU
+// lanes stride over [0, count), unrolled x4 so that the independent HBM/L2 loads of four iterations are in
+// flight together
 #define WAVE_FOR(i, count) _Pragma("unroll 4") for (int i = LANE; i < (count); i += NLANES)
-#else
-#define WAVE_FOR(i, count) for (int i = LANE; i < (count); i += NLANES)
-#endif
-
+// a lane's bins i0 + LANE + 64 k, k < KPL (k_noise)
+#define LANE_BINS(k, i, i0, KPL, n) _Pragma("unroll") for (int k = 0, i = (i0) + LANE; k < (KPL); k++, i += NLANES) if (i < (n))
 // A "team": all the waves of a workgroup working on one unit (k_residue: the search of a block's
 // vectors is wide enough for several waves, and sharing one LDS copy of the work vector between them
 // keeps more units resident per CU).  With a 64-thread workgroup a team is a wave.
-#if VAMD_GPU
 #define TEAM_FOR(i, count) for (int i = (int)threadIdx.x; i < (count); i += (int)blockDim.x)
 #define TEAM_SYNC() __syncthreads()
 #define TEAM_FIRST_WAVE (threadIdx.x < 64)
 #define TEAM_LEADER (threadIdx.x == 0)
-#else
-#define TEAM_FOR(i, count) for (int i = 0; i < (count); i++)
-#define TEAM_SYNC() ((void)0)
-#define TEAM_FIRST_WAVE 1
-#define TEAM_LEADER 1
-#endif
+// items / register quads dealt over a team policy object (k_transform.h: WaveTeam); the item loop is
+// unrolled x4 so that the independent LDS reads of four items are in flight together
+#define TEAM_EACH(i, count, tm) _Pragma("unroll 4") for (int i = (tm).tid(); i < (count); i += (tm).size())
+#define TEAM_QUADS(kq, q, nq, QPT, tm) _Pragma("unroll") for (int kq = 0, q = (tm).tid(); kq < (QPT); kq++, q += (tm).size()) if (q < (nq))
 
 namespace vamd {
 
-#if VAMD_GPU
+VAMD_DEV unsigned brev32(unsigned x) { return __builtin_bitreverse32(x); }  // bit 0 <-> bit 31
+
 // Full-wave reductions and scans on the VALU's DPP path.  (The __shfl family compiles to
 // ds_bpermute_b32, which occupies the CU's LDS pipe like any other LDS instruction; the ordered
 // phases call these dozens of times per block.)  Every lane must be active; results of the
@@ -184,42 +142,10 @@ VAMD_DEV void lds_atomic_min(float *p, float v) {
 VAMD_DEV void lds_atomic_add(int *p, int v) { atomicAdd(p, v); }
 VAMD_DEV void lds_atomic_or(int *p, int v) { atomicOr(p, v); }
 VAMD_DEV void lds_or_global_count(unsigned int *p) { atomicAdd(p, 1u); }  // an event counter in HBM (rare: error reports)
-#else
-VAMD_DEV float wave_max(float v) { return v; }
-VAMD_DEV int wave_sum(int v) { return v; }
-VAMD_DEV int wave_any(int pred) { return pred != 0; }
-VAMD_DEV unsigned long long wave_or64(unsigned long long v) { return v; }
-VAMD_DEV int wave_scan_max(int v) { return v; }
-VAMD_DEV int wave_scan_sum(int v) { return v; }
-VAMD_DEV int wave_shift_up1(int v, int fill) { (void)v; return fill; }
-VAMD_DEV int wave_last(int v) { return v; }
-VAMD_DEV int wave_first(int v) { return v; }
-VAMD_DEV float f_from_bits(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
-VAMD_DEV uint32_t f_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
-VAMD_DEV void lds_atomic_max(float *p, float v) { if (*p < v) *p = v; }
-VAMD_DEV void lds_atomic_min(float *p, float v) { if (v < *p) *p = v; }
-VAMD_DEV void lds_atomic_add(int *p, int v) { *p += v; }
-VAMD_DEV void lds_atomic_or(int *p, int v) { *p |= v; }
-VAMD_DEV void lds_or_global_count(unsigned int *p) { *p += 1u; }
-#endif
-
-struct alignas(16) F4 {
-  float x, y, z, w;
-};
-struct alignas(16) I4 {
-  int x, y, z, w;
-};
-struct alignas(8) F2 {
-  float x, y;
-};
-struct alignas(8) I2 {
-  int x, y;
-};
 
 // Optional in-kernel stopwatch (measurement aid, off unless vamd_debug_cycles() armed it):
 // lane 0 of every wave adds the shader-clock ticks spent since the previous mark to a slot.
 struct PhaseClock {
-#if VAMD_GPU
   // ticks are summed in registers and flushed once per wave into one of 64 replicated
   // slot sets (spread by workgroup id), so the stopwatch itself costs a handful of
   // atomics per wave instead of one contended atomic per phase
@@ -251,18 +177,12 @@ struct PhaseClock {
         if (acc[k]) atomicAdd(dst + k, (unsigned long long)acc[k]);
     }
   }
-#else
-  VAMD_DEV void start(unsigned long long *) {}
-  VAMD_DEV void mark(int) {}
-  VAMD_DEV void flush() {}
-#endif
 };
 
 // A small array (<= 64 entries) kept one entry per lane in a VGPR.  Reads with a
 // wave-uniform index are a single v_readlane (no LDS round trip), which is what the
 // ordered, wave-uniform sections (floor split loop, post settling) are bound by.
 struct LaneInts {
-#if VAMD_GPU
   int v;
   VAMD_MEM int get(int i) const { return __builtin_amdgcn_readlane(v, i); }
   VAMD_MEM void set(int i, int x) { v = (LANE == i) ? x : v; }
@@ -294,91 +214,56 @@ struct LaneInts {
     const int last = stop ? __builtin_ctzll(stop) : count;  // first entry that ends the run
     if (LANE >= from && LANE < last) v = newv;
   }
-#else
-  int a[64];
-  VAMD_MEM int get(int i) const { return a[i]; }
-  VAMD_MEM void set(int i, int x) { a[i] = x; }
-  VAMD_MEM void fill(int x) { for (int i = 0; i < 64; i++) a[i] = x; }
-  VAMD_MEM void load(const int *p, int count) { for (int i = 0; i < 64; i++) a[i] = i < count ? p[i] : 0; }
-  VAMD_MEM int at(int i) const { return a[i]; }
-  VAMD_MEM void put(int i, int x) { a[i] = x; }
-  VAMD_MEM int gather(int idx) const { return a[idx]; }
-  VAMD_MEM void load_shifted(const int *p, int shift, int count) {
-    for (int i = 0; i < 64; i++) a[i] = (i >= shift && i < count) ? p[i - shift] : 0;
-  }
-  VAMD_MEM void replace_run_down(int from, int oldv, int newv) {
-    for (int j = from - 1; j >= 0; j--) {
-      if (a[j] != oldv) break;
-      a[j] = newv;
-    }
-  }
-  VAMD_MEM void replace_run_up(int from, int count, int oldv, int newv) {
-    for (int j = from; j < count; j++) {
-      if (a[j] != oldv) break;
-      a[j] = newv;
-    }
-  }
-#endif
 };
 
-struct LaneDoubles {
-#if VAMD_GPU
-  double v;
-  VAMD_MEM double get(int i) const {
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), i);
-    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), i);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-  }
-  VAMD_MEM void set_mine(double x) { v = x; }
+
+
+// For quotients below 2^12 (num < 2^24): the hardware's one-instruction reciprocal (1 ulp) leaves the product within
+// a thousandth of the true quotient, far inside div_small's +-1 fix-up; the result is the exact floor either way.
+VAMD_DEV float div_rcp_fast(int den) { return __builtin_amdgcn_rcpf((float)den); }
+// products of operands that fit 24 signed bits (bin indices, line heights, their small quotients): one full-rate
+// instruction
+VAMD_DEV int mad24(int a, int b, int c) { return __mul24(a, b) + c; }
+// floor(num / den) in one multiply for the line walks of floor 1, where den = x1 - x0 <= 2048 and
+// num = k * |dy| with k < den and |dy| <= 1023: magic = ceil(2^32 / den) (derive_div_magic, den >= 2) makes
+// (num * magic) >> 32 exact while num * (magic * den - 2^32) < 2^32, i.e. for num * (den - 1) < 2^32 -- here
+// num * den < 2047 * 1023 * 2048 < 2^32.  den == 1 only ever divides num == 0 (k < den).
+VAMD_DEV int div_magic(int num, unsigned int magic) { return (int)__umulhi((unsigned int)num, magic); }
+// p[i] for a wave-uniform i out of a table in HBM: through the scalar cache (the compiler cannot tell that a pointer it
+// read from a parameter struct points at constant memory, and would send all 64 lanes to fetch the same word)
+VAMD_DEV unsigned int load_uniform_u32(const unsigned int *p, int i) {
+  typedef const unsigned int __attribute__((address_space(4))) *cptr;
+  return ((cptr)p)[__builtin_amdgcn_readfirstlane(i)];
+}
+// v_sqrt_f32: within one ulp of the root (k_couple's quant_energy settles the candidate exactly)
+VAMD_DEV float approx_sqrtf(float x) { return __builtin_amdgcn_sqrtf(x); }
+// keeps a wave-uniform value opaque to the optimiser (k_floor: a known +-1 would turn a multiply-add into negate + select)
+VAMD_DEV void keep_opaque(int &v) { asm volatile("" : "+s"(v)); }
+
+}  // namespace vamd
 #else
-  double a[64];
-  VAMD_MEM double get(int i) const { return a[i]; }
+#define VAMD_GPU 0
+#include "vamd_wave_host.h"  // the one-lane test vocabulary: tests/emul only, see the note at the top
 #endif
+
+namespace vamd {
+
+struct alignas(16) F4 {
+  float x, y, z, w;
+};
+struct alignas(16) I4 {
+  int x, y, z, w;
+};
+struct alignas(8) F2 {
+  float x, y;
+};
+struct alignas(8) I2 {
+  int x, y;
 };
 
 // Exact floor(num/den) for 0 <= num < 2^24, 0 < den < 2^12 without the integer-divide
 // expansion: one fp32 multiply by a precomputed reciprocal, then a +-1 fix-up.
 VAMD_DEV float div_rcp(int den) { return 1.0f / (float)den; }
-// For quotients below 2^12 (num < 2^24): the hardware's one-instruction reciprocal (1 ulp) leaves the product within
-// a thousandth of the true quotient, far inside div_small's +-1 fix-up; the result is the exact floor either way.
-VAMD_DEV float div_rcp_fast(int den) {
-#if VAMD_GPU
-  return __builtin_amdgcn_rcpf((float)den);
-#else
-  return 1.0f / (float)den;
-#endif
-}
-// products of operands that fit 24 signed bits (bin indices, line heights, their small quotients): one full-rate
-// instruction on the GPU, the plain product on the host
-VAMD_DEV int mad24(int a, int b, int c) {
-#if VAMD_GPU
-  return __mul24(a, b) + c;
-#else
-  return a * b + c;
-#endif
-}
-// floor(num / den) in one multiply for the line walks of floor 1, where den = x1 - x0 <= 2048 and
-// num = k * |dy| with k < den and |dy| <= 1023: magic = ceil(2^32 / den) (derive_div_magic, den >= 2) makes
-// (num * magic) >> 32 exact while num * (magic * den - 2^32) < 2^32, i.e. for num * (den - 1) < 2^32 -- here
-// num * den < 2047 * 1023 * 2048 < 2^32.  den == 1 only ever divides num == 0 (k < den).
-VAMD_DEV int div_magic(int num, unsigned int magic) {
-#if VAMD_GPU
-  return (int)__umulhi((unsigned int)num, magic);
-#else
-  return (int)(((unsigned long long)(unsigned int)num * magic) >> 32);
-#endif
-}
-// p[i] for a wave-uniform i out of a table in HBM: through the scalar cache (the compiler cannot tell that a pointer it
-// read from a parameter struct points at constant memory, and would send all 64 lanes to fetch the same word)
-VAMD_DEV unsigned int load_uniform_u32(const unsigned int *p, int i) {
-#if VAMD_GPU
-  typedef const unsigned int __attribute__((address_space(4))) *cptr;
-  return ((cptr)p)[__builtin_amdgcn_readfirstlane(i)];
-#else
-  return p[i];
-#endif
-}
 VAMD_DEV int div_small(int num, int den, float rcp) {
   int q = (int)((float)num * rcp);
   const int r = num - q * den;
