@@ -74,26 +74,31 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-TRAFFIC_PROFILE = "profiles/r02_pmc_traffic.json"
+TRAFFIC_PROFILE = "profiles/r03_pmc_traffic.json"
+TRAFFIC_PROFILE_C5 = "profiles/r03_c5_pmc_traffic.json"
 
 
-def measured_traffic(workload, units):
+def measured_traffic(workload, units, alg_bytes=None):
     """HBM bytes per step from the committed PMC run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
     passes, FETCH_SIZE doubled per the gfx950 calibration; tools/profile.sh + tools/make_profiles.py).  The
     profile carries the hash of the sources it was taken from; if the sources have changed since, the figure
     is withheld (None, {}, reason) rather than reported stale.  Returns (bytes per step, per-kernel dict, note)."""
+    prof = TRAFFIC_PROFILE_C5 if workload == "c5" else TRAFFIC_PROFILE
     try:
-        t = json.load(open(os.path.join(ROOT, TRAFFIC_PROFILE)))
+        t = json.load(open(os.path.join(ROOT, prof)))
     except Exception:
         return None, {}, "no committed PMC profile"
     if t.get("source_hash") != source_hash():
         return None, {}, "PMC profile %s was taken from other sources (%s, now %s): re-run tools/profile.sh" % (
-            TRAFFIC_PROFILE, t.get("source_hash"), source_hash())
+            prof, t.get("source_hash"), source_hash())
     note = "%s (source hash %s matches this build)" % (t["source"], t["source_hash"])
     if workload == "c2":
         return t["mdct_only_B_per_frame"] * units, {}, note
     if workload == "c5":
-        return None, {}, "no PMC pass for the mixed-size workload"
+        # one step of this very workload was counted; a run with other stream counts scales by its algorithmic bytes
+        scale = (alg_bytes / t["alg_bytes_per_step"]) if alg_bytes else 1.0
+        per5 = {k: (v["read_B_per_step"] + v["write_B_per_step"]) * scale for k, v in t["per_kernel"].items()}
+        return sum(per5.values()), per5, note
     per = {k: (v["read_B_per_stereo_block"] + v["write_B_per_stereo_block"]) * units for k, v in t["per_kernel"].items()}
     if workload == "c3":
         per = {k: v for k, v in per.items() if k in ("k_transform", "k_noise", "k_tone_seed", "k_tone_chase", "k_tone_fold", "k_tone")}
@@ -483,10 +488,10 @@ def main(argv=None, make_runner=None):
         alg = R.alg_bytes() if a.workload == "c5" else ALG_BYTES[a.workload] * units   # bytes per step per GPU, algorithmic
         achieved = alg / (kernels_ms * 1e-3) / 1e9                # GB/s over the path's kernels
         dom_bytes = R.stage_bytes_total(dom)
-        traffic, traffic_per, traffic_note = measured_traffic(a.workload, units)
+        traffic, traffic_per, traffic_note = measured_traffic(a.workload, units, alg)
         stage_of = {"k_transform": "transform", "k_noise": "noisemask", "k_floor": "floor", "k_couple": "couple",
                     "k_tone_seed": "tonemask", "k_tone_chase": "tonemask", "k_tone_fold": "tonemask", "k_tone": "tonemask"}
-        dom_traffic = sum(v for k, v in traffic_per.items() if stage_of.get(k) == dom) or None
+        dom_traffic = sum(v for k, v in traffic_per.items() if stage_of.get(k.split("<")[0]) == dom) or None
         roof = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,

@@ -6,10 +6,10 @@ summaries under profiles/:  rNN_kernel_trace_stats.txt, rNN_pmc_hbm_traffic.txt,
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "profile")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
 sys.path.insert(0, ROOT)
 import bench as bench_mod  # noqa: E402  (source_hash: the profile is stamped with the sources it was taken from)
-NB_PMC = 65536  # tools/prof_run.py 65536 1
+NB_PMC = int(sys.argv[2]) if len(sys.argv) > 2 else 131072  # tools/prof_run.py <NB> 1
 
 
 def table(path):
@@ -34,23 +34,25 @@ with open(os.path.join(ROOT, "profiles", TAG + "_kernel_trace_stats.txt"), "w") 
     f.write("# MI355X (gfx950).  %d stereo 2048-blocks per step (C4 full analysis), 6 launches of each stage\n"
             % bench["config"]["blocks_per_gpu"])
     f.write("# kernel = 1 warm-up + 5 timed steps.  Durations in microseconds (rocpd `top_kernels` view).\n")
-    f.write("# k_tone_seed / k_tone_chase / k_tone_fold are issued on the library's side stream beside k_noise (fork after the\n")
-    f.write("# transform, join before the floor fit); k_noise is persistent and fills the CUs, so they mostly run after it.\n")
+    f.write("# k_tone_seed / k_tone_chase are issued on the library's side stream beside k_noise (fork after the transform, join\n")
+    f.write("# before the floor fit); k_noise is persistent and leaves a quarter of every CU's wave slots to them; the tone chain's\n")
+    f.write("# last step (paint + fold) is part of k_floor.\n")
     f.write("# source hash %s\n" % bench_mod.source_hash())
     f.write("# bench.py's own line from the same run: %.2f M stereo blocks/s, %.2f ms/step; its HIP-event figure for\n"
             % (bench["value"] / 1e6, bench["ms_per_step"]))
-    f.write("# the dominant kernel (k_noise): %.3f ms per launch.\n" % bench["roofline"]["dominant_kernel"]["ms"])
+    f.write("# the dominant kernel (%s): %.3f ms per launch.\n" % (bench["roofline"]["dominant_kernel"]["name"], bench["roofline"]["dominant_kernel"]["ms"]))
     f.write(kt[0].replace("total_ns", "total_us").replace("avg_ns", "avg_us") + "\n")
     f.write("\n".join(kt[1:]) + "\n")
 
-fl, fetch = table(os.path.join(SRC, "pmc_fetch_size.txt"))
-wl, write = table(os.path.join(SRC, "pmc_write_size.txt"))
+fl, fetch = table(os.path.join(SRC, "pmc_FETCH_SIZE.txt"))
+wl, write = table(os.path.join(SRC, "pmc_WRITE_SIZE.txt"))
 cal = [k for k in fetch if k.startswith("void at::native::vectorized_elementwise_kernel")][0]
 fcal, wcal = fetch[cal] / (1 << 20), write[cal] / (1 << 20)
 with open(os.path.join(ROOT, "profiles", TAG + "_pmc_hbm_traffic.txt"), "w") as f:
     f.write("# rocprofv3 --pmc FETCH_SIZE   (its own pass)   and   rocprofv3 --pmc WRITE_SIZE   (its own pass)\n")
-    f.write("#   -- python tools/prof_run.py 65536 1      (one full-analysis step over 65536 stereo blocks, one\n")
-    f.write("#      mdct-only call over 131072 frames, one 1 GiB torch copy as the calibration kernel)\n")
+    f.write("#   -- python tools/prof_run.py %d 1      (one full-analysis step over %d stereo blocks, one\n" % (NB_PMC, NB_PMC))
+    f.write("#      mdct-only call over %d frames, one 1 GiB torch copy as the calibration kernel)\n" % (2 * NB_PMC))
+    f.write("# source hash %s\n" % bench_mod.source_hash())
     f.write("# Units: KiB per dispatch.  Calibration (vectorized_elementwise_kernel = b.copy_(a), exactly 1 GiB read\n")
     f.write("# and 1 GiB written): FETCH_SIZE reads %.3f of the true bytes (the gfx950 half-count of\n" % fcal)
     f.write("# MI355X_MICROARCH.md \"HBM\"), WRITE_SIZE reads %.3f.  Corrected HBM bytes therefore\n" % wcal)
@@ -64,7 +66,7 @@ for k in fetch:
 out = {
     "source_hash": bench_mod.source_hash(),
     "source": "profiles/%s_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, "
-              "65536 stereo blocks; FETCH_SIZE x2 per calibration)" % TAG,
+              "%d stereo blocks; FETCH_SIZE x2 per calibration)" % (TAG, NB_PMC),
     "workload": "c4",
     "per_kernel": per,
     "total_B_per_stereo_block": sum(v["read_B_per_stereo_block"] + v["write_B_per_stereo_block"] for v in per.values()),
@@ -82,3 +84,49 @@ if os.path.exists(c5):
                 % (b5["value"] / 1e6, b5["ms_per_step"], b5.get("parity_sample")))
         f.write("# source hash %s\n" % bench_mod.source_hash())
         f.write(open(c5).read())
+
+# ---- C5: counter passes over one step of the mixed-size workload
+c5f = os.path.join(SRC, "pmc_c5_FETCH_SIZE.txt")
+if os.path.exists(c5f):
+    fl5, fetch5 = table(c5f)
+    wl5, write5 = table(os.path.join(SRC, "pmc_c5_WRITE_SIZE.txt"))
+    step = json.loads(open(os.path.join(SRC, "c5_step.json")).read().strip().splitlines()[-1])
+    calk = [k for k in fetch5 if k.startswith("void at::native::vectorized_elementwise_kernel")]
+    with open(os.path.join(ROOT, "profiles", TAG + "_c5_pmc_hbm_traffic.txt"), "w") as f:
+        f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python tools/prof_run_c5.py 1\n")
+        f.write("# one step of bench.py --workload c5 after its warm-up: %d short + %d long stereo blocks planned on the device\n"
+                % (step["short_blocks"], step["long_blocks"]))
+        f.write("# Units: KiB per dispatch (average over the warm-up and the step: identical work).  Corrected HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE.\n")
+        f.write("# source hash %s\n\n## FETCH_SIZE\n" % bench_mod.source_hash() + "\n".join(fl5) + "\n\n## WRITE_SIZE\n" + "\n".join(wl5) + "\n")
+    per5 = {}
+    with open(c5f) as fh:
+        pass
+    # per kernel name as printed (instantiations kept apart: k_transform<8> and k_transform<11> are different kernels here)
+    def table_full(path):
+        rows = {}
+        for ln in open(path).read().splitlines()[1:]:
+            parts = ln.split()
+            if len(parts) < 4:
+                continue
+            val, ctr = parts[-2], parts[-3]
+            name = ln[:ln.index(ctr)].strip()
+            if name.startswith("void "):
+                name = name[5:]
+            rows[name] = float(val)
+        return rows
+    F5, W5 = table_full(c5f), table_full(os.path.join(SRC, "pmc_c5_WRITE_SIZE.txt"))
+    for k in F5:
+        if k.startswith("k_"):
+            per5[k] = {"read_B_per_step": 2 * F5[k] * 1024, "write_B_per_step": W5.get(k, 0.0) * 1024}
+    out5 = {"source_hash": bench_mod.source_hash(), "workload": "c5", "short_blocks": step["short_blocks"], "long_blocks": step["long_blocks"],
+            "alg_bytes_per_step": step["alg_bytes"],
+            "source": "profiles/%s_c5_pmc_hbm_traffic.txt (one step of bench.py --workload c5; FETCH_SIZE x2 per calibration)" % TAG,
+            "per_kernel": per5, "total_B_per_step": sum(v["read_B_per_step"] + v["write_B_per_step"] for v in per5.values())}
+    json.dump(out5, open(os.path.join(ROOT, "profiles", TAG + "_c5_pmc_traffic.json"), "w"), indent=1)
+    print("c5: total B per step %.0f = %.2f x algorithmic" % (out5["total_B_per_step"], out5["total_B_per_step"] / step["alg_bytes"]))
+for name in ("pmc_sq_counters.txt", "pmc_sq_counters_c5.txt"):
+    srcp = os.path.join(SRC, name)
+    if os.path.exists(srcp):
+        with open(os.path.join(ROOT, "profiles", TAG + "_" + name), "w") as f:
+            f.write("# per-wave SQ counters (rocprofv3 --pmc, one set per pass; tools/profile.sh), source hash %s\n" % bench_mod.source_hash())
+            f.write(open(srcp).read())

@@ -3,7 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import vorbis_amd
-nb = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+nb = int(sys.argv[1]) if len(sys.argv) > 1 else 131072
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 an = vorbis_amd.Analyzer(vorbis_amd.default_setup_blob("44k_stereo_q4"), 0)
 pcm = torch.rand((nb, 2, 2048), device="cuda") - 0.5

@@ -65,13 +65,10 @@ VAMD_DEV I2 offset_and_mix_quad(const PsyP &P, int q, const float *nz, const flo
     mk[c] = (val < t) ? t : val;  // max(val, tone+toneatt), lib/psy.c:795 with os.h:78 max()
     // AoTuV M1, lib/psy.c:807-832: double-promoted by the 1.0 / 0.005 / 0.0003 literals
     val = val - lmv[c];
-    float de;
-    if (val > coeffi) {
-      de = (float)(1.0 - ((double)(val - coeffi) * 0.005 * (double)cx));
-      if (de < 0) de = 0.0001f;
-    } else {
-      de = (float)(1.0 - ((double)(val - coeffi) * 0.0003 * (double)cx));
-    }
+    // (the two arms differ in one literal: the literal is selected, not the arm -- a wave's lanes take both)
+    const bool above = val > coeffi;
+    float de = (float)(1.0 - ((double)(val - coeffi) * (above ? 0.005 : 0.0003) * (double)cx));
+    if (above && de < 0) de = 0.0001f;
     md[c] *= de;
   }
   // accumulate_fit / inspect_error read the mask only through vorbis_dBquant and split bins by the
