@@ -108,8 +108,8 @@ def measured_traffic(workload, units, alg_bytes=None):
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=("c2", "c3", "c4", "c5"), default="c4")
     ap.add_argument("--blocks", type=int, default=None, help="stereo blocks per GPU (default 131072; c2/c3: 65536)")
     ap.add_argument("--setup", default=None, help="setup blob name (default 44k_stereo_q4; c5: 44k_stereo_q9)")

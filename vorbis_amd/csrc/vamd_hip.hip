@@ -204,7 +204,8 @@ __global__ __launch_bounds__(64 * NoiseGeom<LOGN2>::NW, NoiseGeom<LOGN2>::KPL <=
   const int i0 = (threadIdx.x >> 6) * 64 * KPL;  // this wave's first bin
   PhaseClock pc;
   pc.start(d.dbg ? d.dbg + 16 : nullptr);
-  // persistent: the next block's spectrum is fetched while this one is worked on
+  // persistent.  The next block's spectrum is fetched at the end of this one, not a block ahead: four registers held across
+  // a whole block cost more (the stage sits on the 64-register line) than the fetch does beside five other teams
   float lm[KPL];
   int braw[KPL], bk[KPL], bt_have = -1;
   float compand_lane = 0.f;  // noisecompand[LANE]
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(64 * NoiseGeom<LOGN2>::NW, NoiseGeom<LOGN2>::KPL <=
   for (; cb < ncb; cb += gridDim.x) {
     const int bt = d_bt(d, (long)((unsigned)cb / (unsigned)ch));  // (cb < 2^31: check_desc)
     const PsyP &P = bt ? P1 : P0;
-    float o[KPL], lm_next[KPL];
+    float o[KPL];
     const long nb = cb + gridDim.x < ncb ? cb + gridDim.x : cb;
     if (bt != bt_have) {  // the window edges of this lane's bins and noisecompand[]: properties of the block type, kept across blocks
       noise_bark_fetch<KPL, LOGN2>(P, braw, i0);
@@ -222,14 +223,13 @@ __global__ __launch_bounds__(64 * NoiseGeom<LOGN2>::NW, NoiseGeom<LOGN2>::KPL <=
       compand_lane = LANE < VAMD_NOISE_COMPAND_LEVELS ? P.noisecompand[LANE] : 0.f;
       bt_have = bt;
     }
-    LANE_BINS(k, i, i0, KPL, n2) lm_next[k] = mdct_raw[nb * n2 + i];
     LANE_BINS(k, i, i0, KPL, n2) lm[k] = todB_345(lm[k]);
     noisemask_bins<ScanTeam, KPL, LOGN2>(
         P, lm, bk, o, S,
         [&](int dB) { return __int_as_float(__builtin_amdgcn_ds_bpermute(dB << 2, __float_as_int(compand_lane))); }, ScanTeam(), pc,
         i0);
     LANE_BINS(k, i, i0, KPL, n2) noise[cb * n2 + i] = o[k];
-    LANE_BINS(k, i, i0, KPL, n2) lm[k] = lm_next[k];
+    LANE_BINS(k, i, i0, KPL, n2) lm[k] = mdct_raw[nb * n2 + i];
   }
   pc.flush();
 }
