@@ -13,10 +13,10 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 #define REP16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
 
-enum { OP_ADD, OP_MUL, OP_FMA, OP_PKMUL, OP_PKADD, OP_PKFMA, OP_ADD64, OP_MUL64, OP_FMA64, OP_RCP, OP_SQRT64,
+enum { OP_ADD, OP_ADD_E64, OP_FMAC, OP_MUL, OP_FMA, OP_PKMUL, OP_PKADD, OP_PKFMA, OP_ADD64, OP_MUL64, OP_FMA64, OP_RCP, OP_SQRT64,
        OP_RCP64, OP_CND, OP_MULLO, OP_ADDDPP, OP_MOVDPP, OP_READLANE, OP_CVT, OP_DEP_ADD, OP_DEP_ADDDPP, OP_DEP_MOVDPP_ADD,
        OP_DEP_FMA64, OP_MAX3, OP_COUNT };
-static const char *names[] = {"v_add_f32", "v_mul_f32", "v_fma_f32", "v_pk_mul_f32", "v_pk_add_f32", "v_pk_fma_f32",
+static const char *names[] = {"v_add_f32", "v_add_f32_e64 (8-byte encoding)", "v_fmac_f32_e32 (4-byte fma)", "v_mul_f32", "v_fma_f32", "v_pk_mul_f32", "v_pk_add_f32", "v_pk_fma_f32",
                               "v_add_f64", "v_mul_f64", "v_fma_f64", "v_rcp_f32", "v_sqrt_f64", "v_rcp_f64", "v_cndmask_b32",
                               "v_mul_lo_u32", "v_add_f32 dpp row_shr:1", "v_mov_b32 dpp row_shr:1", "v_readlane_b32",
                               "v_cvt_f32_i32", "DEPENDENT v_add_f32", "DEPENDENT v_add_f32 dpp", "DEPENDENT v_mov dpp + v_add",
@@ -43,6 +43,14 @@ __global__ void k_rate(int iters, unsigned long long *out, float *sink) {
   for (int it = 0; it < iters; it++) {
     if (OP == OP_ADD) {
 #define X(i) asm volatile("v_add_f32 %0, %0, %1" : "+v"(r[i]) : "v"(c));
+      REP16(X)
+#undef X
+    } else if (OP == OP_ADD_E64) {
+#define X(i) asm volatile("v_add_f32_e64 %0, %0, %1" : "+v"(r[i]) : "v"(c));
+      REP16(X)
+#undef X
+    } else if (OP == OP_FMAC) {
+#define X(i) asm volatile("v_fmac_f32_e32 %0, %1, %1" : "+v"(r[i]) : "v"(c));
       REP16(X)
 #undef X
     } else if (OP == OP_MUL) {
@@ -217,6 +225,8 @@ int main() {
   hipMalloc(&sink, 1 << 20);
   printf("one CU (CU-masked stream), w waves per SIMD: s_memtime ticks per instruction per SIMD (tick rate in MHz against the 100 MHz wall clock)\n");
   run<OP_ADD>(d, sink, 1);
+  run<OP_ADD_E64>(d, sink, 1);
+  run<OP_FMAC>(d, sink, 1);
   run<OP_MUL>(d, sink, 1);
   run<OP_FMA>(d, sink, 1);
   run<OP_PKMUL>(d, sink, 1);
@@ -242,6 +252,8 @@ int main() {
   printf("whole chip, 512 workgroups x 16 waves, wall clock by events\n");
   run_chip<OP_DEP_ADD>(d, sink, 1);
   run_chip<OP_ADD>(d, sink, 1);
+  run_chip<OP_ADD_E64>(d, sink, 1);
+  run_chip<OP_FMAC>(d, sink, 2);
   run_chip<OP_FMA>(d, sink, 2);
   run_chip<OP_PKFMA>(d, sink, 4);
   run_chip<OP_PKMUL>(d, sink, 2);
