@@ -10,14 +10,15 @@ def kernel_stats(db):
     print("%-46s %6s %14s %12s %7s" % ("kernel", "calls", "total_ns", "avg_ns", "pct"))
     for n, c, t, a, p in rows:
         print("%-46s %6d %14.0f %12.0f %6.2f%%" % (n.split("(")[0][:46], c, t, a, p))
-    try:
-        r = con.execute("select kernel_name, max(vgpr_count), max(sgpr_count), max(lds_block_size), max(workgroup_size), max(grid_size) "
-                        "from kernels group by kernel_name").fetchall()
-        print("\n%-46s %6s %6s %9s %6s %10s" % ("kernel", "vgpr", "sgpr", "lds_B", "wg", "grid"))
-        for n, v, s, l, w, g in r:
-            if n.startswith("k_"):
-                print("%-46s %6s %6s %9s %6s %10s" % (n.split("(")[0][:46], v, s, l, w, g))
-    except Exception as e:  # column names differ between rocprofv3 builds
+    try:  # the `kernels` view of rocpd: one row per dispatch with its code-object resources
+        r = con.execute("select name, max(vgpr_count), max(accum_vgpr_count), max(sgpr_count), max(lds_size), max(scratch_size), "
+                        "max(workgroup_x), max(grid_x) from kernels group by name").fetchall()
+        print("\n%-46s %6s %6s %6s %9s %8s %6s %10s" % ("kernel", "vgpr", "agpr", "sgpr", "lds_B", "scratch", "wg", "grid"))
+        for n, v, a, sg, l, sc, w, g in r:
+            nm = n[5:] if n.startswith("void ") else n
+            if nm.startswith("k_"):
+                print("%-46s %6s %6s %6s %9s %8s %6s %10s" % (nm.split("(")[0][:46], v, a, sg, l, sc, w, g))
+    except Exception as e:  # view / column names differ between rocprofv3 builds
         print("(kernel resource table unavailable: %s)" % e)
 
 
