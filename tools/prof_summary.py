@@ -13,7 +13,9 @@ def kernel_stats(db):
     try:  # the `kernels` view of rocpd: one row per dispatch with its code-object resources
         r = con.execute("select name, max(vgpr_count), max(accum_vgpr_count), max(sgpr_count), max(lds_size), max(scratch_size), "
                         "max(workgroup_x), max(grid_x) from kernels group by name").fetchall()
-        print("\n%-46s %6s %6s %6s %9s %8s %6s %10s" % ("kernel", "vgpr", "agpr", "sgpr", "lds_B", "scratch", "wg", "grid"))
+        print("\n# code-object resources as rocpd's `kernels` view reports them (vgpr: half the allocated registers per lane --")
+        print("# k_floor's 64 show as 32, k_transform's 232 as 116; tools/kernel_resources.py prints the compiler's own figures)")
+        print("%-46s %6s %6s %6s %9s %8s %6s %10s" % ("kernel", "vgpr/2", "agpr", "sgpr", "lds_B", "scratch", "wg", "grid"))
         for n, v, a, sg, l, sc, w, g in r:
             nm = n[5:] if n.startswith("void ") else n
             if nm.startswith("k_"):
