@@ -65,3 +65,53 @@ def test_dropin_returns_ov_einval_and_the_next_stream_is_clean():
     got = ref.RefEncoder(2, 44100, 0.4, hybrid=True).encode_stream(pcm)
     assert len(want) == len(got) > 20
     assert all(a["packet"] == b["packet"] for a, b in zip(want, got))
+
+
+def test_stream_plan_path_reports_too():
+    """The device-resident stream path (vamd_plan_streams -> gather -> vamd_analyze_streams_mixed, BASELINE config 5):
+    a NaN in one of four streams is counted by the detector and by the blocks that hold it, per-block `status` names
+    them, and the other three streams' blocks come out exactly as they do without the poisoned neighbour."""
+    import torch
+    import vorbis_amd
+    an = vorbis_amd.Analyzer(vorbis_amd.default_setup_blob("44k_stereo_q9"), 0)
+    rng = np.random.default_rng(31)
+    ns, ln = 4, 65536
+    t = np.arange(ln)
+    gate = np.where((t % 9000) < 700, 0.5, 0.0005).astype(np.float32)
+    clean = ((rng.random((ns, 2, ln), dtype=np.float32) - 0.5) * 2 * gate).astype(np.float32)
+    poisoned = clean.copy()
+    poisoned[2, 1, 30000] = np.nan
+    want = ("mdct", "iwork", "posts", "ampmax_out", "status")
+
+    def run(x):
+        streams = torch.from_numpy(x).cuda()
+        plan, _ = an.plan_streams(streams)
+        blocks = [an.gather_blocks(plan, W, streams) for W in (0, 1)]
+        outs = [an.alloc_outputs(W, plan.nblocks[W], want) for W in (0, 1)]
+        amp = torch.full((ns,), -9999.0, device="cuda")
+        an.analyze_plan(plan, blocks, outs, amp)
+        torch.cuda.synchronize()
+        return an.plan_lists(plan), [{k: v.cpu().numpy() for k, v in o.items()} for o in outs], an.input_status()
+
+    L0, o0, st0 = run(clean)
+    assert st0 == (0, 0)
+    L1, o1, st1 = run(poisoned)
+    assert st1[0] >= 1 and st1[1] >= 1, st1            # blocks and detector steps outside the domain
+    flagged = sum(int(o1[W]["status"].sum()) for W in (0, 1))
+    assert flagged == st1[0]
+    # the flagged blocks all belong to stream 2, channel 1, and hold sample 30000
+    n_per = 2 * ln
+    for W in (0, 1):
+        bad = np.argwhere(o1[W]["status"] != 0)
+        for i, c in bad:
+            assert int(L1["src"][W][i]) // n_per == 2 and c == 1
+    # streams 0, 1, 3: the same block lists and the same results as without the neighbour
+    for s in (0, 1, 3):
+        a, b = slice(int(L0["stream_start"][s]), int(L0["stream_start"][s + 1])), slice(int(L1["stream_start"][s]), int(L1["stream_start"][s + 1]))
+        assert a.stop - a.start == b.stop - b.start > 10
+        for oa, ob in zip(L0["order"][a], L1["order"][b]):
+            Wa, ia, Wb, ib = (int(oa) >> 30) & 1, int(oa) & 0x3fffffff, (int(ob) >> 30) & 1, int(ob) & 0x3fffffff
+            assert Wa == Wb
+            for k in ("mdct", "iwork", "posts", "ampmax_out"):
+                assert np.array_equal(np.asarray(o0[Wa][k][ia]).view(np.uint32), np.asarray(o1[Wb][k][ib]).view(np.uint32)), (s, k)
+    an.close()
