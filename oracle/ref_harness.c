@@ -791,7 +791,14 @@ long ref_matrix_case(int ch, long rate, float q, const float *data, int count, u
   vorbis_comment_add_tag(&vc, "ENCODER", "test/util.c");
   vorbis_analysis_init(&vd, &vi);
   vorbis_block_init(&vd, &vb);
-  ops = (ogg_packet *)calloc(max_packets, sizeof(*ops));
+  ops = (ogg_packet *)calloc(max_packets > 0 ? max_packets : 1, sizeof(*ops));
+  if (!ops) {
+    vorbis_block_clear(&vb);
+    vorbis_dsp_clear(&vd);
+    vorbis_comment_clear(&vc);
+    vorbis_info_clear(&vi);
+    return -7;
+  }
   vorbis_analysis_headerout(&vd, &vc, &hdr[0], &hdr[1], &hdr[2]);
 #define KEEP(P)                                                   \
   do {                                                            \
