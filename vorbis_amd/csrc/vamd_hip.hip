@@ -863,7 +863,8 @@ static void prof_mark(vamd_ctx *c, int stage) {
 
 // waves per persistent transform workgroup: as many as fit beside the staged tables
 static int xf_waves(const vamd_ctx *c, const XformP &P) {
-  int w = VAMD_XF_WAVES;
+  static const int cap = getenv("VAMD_XF_WAVES_CAP") ? atoi(getenv("VAMD_XF_WAVES_CAP")) : VAMD_XF_WAVES;  // (measurement aid)
+  int w = cap > 0 && cap < VAMD_XF_WAVES ? cap : VAMD_XF_WAVES;
   while (w > 1 && transform_lds_bytes(P, w) > c->lds_per_block) w--;
   return w;
 }
