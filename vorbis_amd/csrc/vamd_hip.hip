@@ -480,8 +480,9 @@ __global__ void k_widen_ilog(long n, const ilog_t *__restrict__ in, int *__restr
 // A unit is one (block, candidate packet): VBR has one packet per block (blob_base = PACKETBLOBS/2,
 // nblobs = 1), a bitrate-managed block all fifteen, each with its own coupling parameters over the
 // same spectrum.  ilogmask / iwork / nonzero are indexed by unit, mdct by block.
+// NORM = false may be launched with several waves per unit (small batches: couple_block deals its quads over the team)
 template <bool NORM>
-__global__ __launch_bounds__(64) void k_couple(PsyP P0, PsyP P1, CoupleSet CS, int blob_base, int nblobs, DescP d,
+__global__ __launch_bounds__(256) void k_couple(PsyP P0, PsyP P1, CoupleSet CS, int blob_base, int nblobs, DescP d,
                                                const float *__restrict__ mdct, const ilog_t *__restrict__ ilogmask,
                                                int *__restrict__ iwork, int *__restrict__ nonzero) {
   const long unit = blockIdx.x, mblk = unit / nblobs;
@@ -508,7 +509,7 @@ __global__ __launch_bounds__(64) void k_couple(PsyP P0, PsyP P1, CoupleSet CS, i
   PhaseClock pc;
   pc.start(d.dbg ? d.dbg + 64 : nullptr);
   couple_block<NORM>(C, P, n2, mp, ip, op, nz, L, pc);
-  if (LANE == 0)
+  if (TEAM_LEADER)
     for (int c = 0; c < ch; c++) nonzero[blk * ch + c] = nz[c];
   pc.flush();
 }
@@ -1336,9 +1337,9 @@ static void launch_couple(vamd_ctx *c, BatchRun *R, hipStream_t s, long units, i
   if (norm0 || norm1)
     hipLaunchKernelGGL(k_couple<true>, dim3((unsigned)units), dim3(64), (size_t)n2 * 12 + 1024, s, P0, P1, c->B.couple_all[W], blob_base,
                        nblobs, R->d, mdct, ilogmask, iwork, nonzero);
-  else
-    hipLaunchKernelGGL(k_couple<false>, dim3((unsigned)units), dim3(64), 0, s, P0, P1, c->B.couple_all[W], blob_base, nblobs, R->d,
-                       mdct, ilogmask, iwork, nonzero);
+  else  // (a handful of blocks: four waves each)
+    hipLaunchKernelGGL(k_couple<false>, dim3((unsigned)units), dim3(units <= 2048 && n2 >= 512 ? 256 : 64), 0, s, P0, P1, c->B.couple_all[W],
+                       blob_base, nblobs, R->d, mdct, ilogmask, iwork, nonzero);
 }
 
 static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_io *M = nullptr, ilog_t *m_ilogmask = nullptr) {
@@ -1351,7 +1352,9 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_
   const int n2 = c->B.xf[W].n / 2, nl = P0.total_octave_lines;
   const unsigned gcb = (unsigned)(R->nb * ch), gb = (unsigned)R->nb;
   hipStream_t s = c->stream;
-  const bool overlap = c->overlap;
+  // (a handful of blocks: the fork / join through events costs more than running the tone chain beside the noise mask
+  // saves -- one stereo block 192 us with it, 181 without)
+  const bool overlap = c->overlap && gcb > 64;
   // the VBR path's floor stage takes the tone chain's last step with it (k_floor)
   static const bool fold_env = getenv("VAMD_FOLD_SEPARATE") == nullptr;
   const int nlp_all = (nl + 15) & ~15;
