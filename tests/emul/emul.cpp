@@ -104,7 +104,8 @@ static void couple_any(const CoupleP &C, const PsyP &P, int n2, const float *con
                      (int *)(st.data() + (size_t)3 * C.ch * n2)};
     couple_block_general(C, P, n2, mp, ip, op, nonzero, L, S, pc);
   } else {
-    couple_block(C, P, n2, mp, ip, op, nonzero, L, pc);
+    couple_block(C, P, n2, mp, ip, op, nonzero, L, pc,
+                 getenv("VAMD_EMUL_COUPLE_BAND_LOG2") ? ldexpf(1.f, atoi(getenv("VAMD_EMUL_COUPLE_BAND_LOG2"))) : VAMD_COUPLE_BAND);
   }
 }
 
@@ -426,6 +427,89 @@ long emul_quant_energy_check(void) {
     memcpy(&f, &bits, 4);
     probe(f);
   }
+  return bad;
+}
+
+// k_couple's division-free forms (chan_bin_sure, couple_bin_sure) against the exact ones, aimed at the decision steps:
+// |m| / f at the coupling point, at the half-integers and at their float neighbours, the coupled ratio at the squares
+// of the half-integers; every estimate moved down, left alone, moved up, and by the hash.  A bin the fast form calls
+// sure must equal the exact form in every field the stage reads.  Returns the disagreements; *unsure_ppm <- how often
+// a random bin is sent to the exact path (parts per million).
+long emul_couple_estimate_check(long *unsure_ppm) {
+  long bad = 0;
+  CoupleP C;
+  memset(&C, 0, sizeof C);
+  C.ch = 2, C.coupling_steps = 1, C.mag[0] = 0, C.ang[0] = 1;
+  C.pointlimit = 100, C.prepoint = 0.35f, C.postpoint = 1.49f, C.sliding_lowpass = 1 << 30;  // (values are arbitrary floats)
+  const float band = VAMD_COUPLE_BAND;
+  auto same_bin = [&](const ChanBin &a, const ChanBin &b) {
+    return a.fg == b.fg && a.out == b.out && !memcmp(&a.qe, &b.qe, 4) && !memcmp(&a.fl2, &b.fl2, 4) && a.re == b.re;
+  };
+  auto probe = [&](float m, int ilog, int b) {
+    const ChanBin e = chan_bin(1, m, ilog, b, 0x7fffffff, C);
+    bool unsure = false;
+    const ChanBin s = chan_bin_sure(1, m, ilog, b, C, band, unsure);
+    if (!unsure && !same_bin(e, s)) bad++;
+    return unsure;
+  };
+  auto around = [&](double x, int ilog, int b) {
+    float f = (float)x;
+    for (int s = 0; s < 6; s++) f = nextafterf(f, 0.f);
+    for (int s = 0; s < 13; s++, f = nextafterf(f, INFINITY)) probe(f, ilog, b), probe(-f, ilog, b);
+  };
+  auto probe_pair = [&](float qeM, float fl2M, float qeA, float fl2A, int fgM, int fgA, float sM, float sA, int b) {
+    ChanBin M, A;
+    M.re = sM * qeM, M.qe = qeM, M.fl2 = fl2M, M.fg = fgM, M.out = 3, M.cand = -1.f;
+    A.re = sA * qeA, A.qe = qeA, A.fl2 = fl2A, A.fg = fgA, A.out = -2, A.cand = -1.f;
+    ChanBin M2 = M, A2 = A;
+    int iM = M.out, iA = A.out, jM = iM, jA = iA;
+    couple_bin(M, A, iM, iA, b, 0x7fffffff, C);
+    bool unsure = false;
+    couple_bin_sure(M2, A2, jM, jA, b, C, band, unsure);
+    if (!unsure && (iM != jM || iA != jA)) bad++;
+    return unsure;
+  };
+  for (int mode = -1; mode <= 2; mode++) {
+    g_estimate_nudge = mode;
+    for (int ilog = 0; ilog < 256; ilog += (mode == 2 ? 1 : 5)) {
+      const double f = floor1_fromdB(ilog);
+      for (int b = 0; b < 200; b += 150) {
+        around(f * C.prepoint, ilog, b);
+        around(f * C.postpoint, ilog, b);
+        for (long k = 0; k < 300000; k += (k < 3000 ? 1 : 4001)) around(f * ((double)k + .5), ilog, b);
+      }
+    }
+    uint32_t x = 777u + mode;
+    for (int i = 0; i < 300000; i++) {  // the coupled ratio at the steps: qe = (k + 1/2)^2 * (fl2M + fl2A), and neighbours
+      x = x * 1664525u + 1013904223u;
+      const float fa = floor1_fromdB((x >> 8) & 255), fb = floor1_fromdB((x >> 16) & 255);
+      const float fl2M = fa * fa, fl2A = fb * fb, sum = fl2M + fl2A;
+      const long k = (x >> 24) < 200 ? (x >> 3) % 40 : (x >> 3) % 70000;
+      float q = (float)(((double)k + .5) * ((double)k + .5) * (double)sum);
+      for (int s = 0; s < 4; s++) q = nextafterf(q, 0.f);
+      for (int s = 0; s < 9; s++, q = nextafterf(q, INFINITY)) {
+        // lossy below the point limit (M.re += A.re, qe = |re|): give A a zero so that qe is q itself
+        probe_pair(q, fl2M, 0.f, fl2A, 0, 0, (x & 1) ? 1.f : -1.f, 1.f, 10);
+        // lossy above it: qe = |M.re| + |A.re|
+        probe_pair(q * .5f, fl2M, q * .5f, fl2A, 0, 0, (x & 1) ? 1.f : -1.f, (x & 2) ? 1.f : -1.f, 150);
+        probe_pair(q, fl2M, q * .25f, fl2A, (x >> 2) & 1, 1, 1.f, -1.f, 150);  // lossless: integers only
+      }
+    }
+  }
+  g_estimate_nudge = 2;
+  long unsure = 0, total = 0;
+  uint32_t x = 4242u;
+  for (int i = 0; i < 2000000; i++) {
+    x = x * 1664525u + 1013904223u;
+    const int ilog = (x >> 8) & 255;
+    // |m| / f log-uniform over 2^-6 .. 2^10
+    uint32_t y = x * 2654435761u;
+    y ^= y >> 13;
+    const float rho = ldexpf(1.f + (float)(y & 0x7fffffu) / 8388608.f, (int)((x >> 3) & 15) - 6);
+    unsure += probe(rho * floor1_fromdB(ilog), ilog, (x & 1) ? 10 : 150) ? 1 : 0;
+    total++;
+  }
+  if (unsure_ppm) *unsure_ppm = unsure * 1000000 / total;
   return bad;
 }
 

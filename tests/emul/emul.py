@@ -178,6 +178,13 @@ class Emul:
         self.L.emul_div_magic_check.restype = C.c_long
         return int(self.L.emul_div_magic_check())
 
+    def couple_estimate_mismatches(self):
+        """chan_bin_sure / couple_bin_sure against the exact forms (emul_couple_estimate_check): (mismatches, unsure ppm)."""
+        self.L.emul_couple_estimate_check.restype = C.c_long
+        ppm = C.c_long(0)
+        bad = int(self.L.emul_couple_estimate_check(C.byref(ppm)))
+        return bad, int(ppm.value)
+
     def quant_energy_mismatches(self):
         """quant_energy() against the reference's fp64 expression (emul_quant_energy_check)."""
         self.L.emul_quant_energy_check.restype = C.c_long

@@ -96,6 +96,39 @@ def test_random_blocks_vs_oracle(torch_mod, name):
     assert bad == 0, "checker=%s" % chk.kind
 
 
+@pytest.mark.parametrize("name", ["44k_stereo_q4", "44k_stereo_q9", "44k_mono_q5"])
+def test_couple_estimate_band_does_not_show(torch_mod, name, monkeypatch):
+    """k_couple decides a bin from an estimate of |m| / floor wherever that provably equals the reference's divisions
+    and sends the rest through them (k_couple.h chan_bin_sure).  VAMD_COUPLE_BAND_LOG2 (read at vamd_create) widens
+    the margin: at 1 every quad takes the exact path, at -6 about every other wave does, the default (-21) almost
+    none -- and the residue must be the same in all three (the default is also what every other parity test runs)."""
+    torch = torch_mod
+    rng = np.random.default_rng(99)
+    nb = 256
+    ch = 1 if "mono" in name else 2
+    amp = (10.0 ** rng.uniform(-3, 0.5, (nb, 1, 1))).astype(np.float32)
+    pcm = ((rng.random((nb, ch, 2048), dtype=np.float32) - 0.5) * 2 * amp).astype(np.float32)
+    t = np.arange(2048, dtype=np.float32)
+    for k in range(0, nb, 2):  # every other block: two tones far above the noise (large quantised values)
+        pcm[k] += (0.4 * np.sin(t * (0.02 + 0.003 * k)) + 0.2 * np.sin(t * (0.31 + 0.001 * k))).astype(np.float32)[None, :]
+    P = torch.from_numpy(pcm).cuda()
+    res = []
+    for log2 in (None, "1", "-6"):
+        if log2 is None:
+            monkeypatch.delenv("VAMD_COUPLE_BAND_LOG2", raising=False)
+        else:
+            monkeypatch.setenv("VAMD_COUPLE_BAND_LOG2", log2)
+        an = analyzer(name)
+        outs = an.analyze(P, W=1, want=("iwork", "nonzero"))
+        torch.cuda.synchronize()
+        res.append({k: v.cpu().numpy() for k, v in outs.items()})
+        an.close()
+    assert np.abs(res[0]["iwork"]).max() > 20  # (the batch reaches magnitudes where steps are hit often)
+    for r in res[1:]:
+        assert np.array_equal(r["iwork"], res[0]["iwork"])
+        assert np.array_equal(r["nonzero"], res[0]["nonzero"])
+
+
 def test_mdct_forward_batch(torch_mod):
     torch = torch_mod
     chk = checker.Checker("44k_stereo_q4")

@@ -71,6 +71,16 @@ def test_quant_energy_equals_the_fp64_expression():
     assert em.quant_energy_mismatches() == 0
 
 
+def test_couple_estimates_decide_like_the_divisions():
+    """k_couple's estimate-then-verify forms (k_couple.h chan_bin_sure / couple_bin_sure): wherever they call a bin sure
+    it equals the exact form, with the hardware's estimates anywhere inside their one-ulp promise; and the exact path
+    is the rare one."""
+    em = Emul(np.fromfile(os.path.join(checker.ROOT, "vorbis_amd", "data", "setup_44k_stereo_q4.bin"), dtype=np.uint8))
+    bad, ppm = em.couple_estimate_mismatches()
+    assert bad == 0
+    assert ppm < 400, ppm  # (|m| / f log-uniform up to 1024: the share grows with the magnitude)
+
+
 def test_chunked_chase_equals_serial_walk():
     """k_tone_chase_wave's algorithm on the host: the stack walk of seed_chase (lib/psy.c:454-487) cut into 64 chunks
     with cold starts, entry/exit state verification and repair rounds gives the serial walk's survivor list on every

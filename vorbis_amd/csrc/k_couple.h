@@ -159,6 +159,45 @@ VAMD_DEV ChanBin chan_bin(int nzk, float m, int ilog, int b, int nstart, const C
   return r;
 }
 
+// ---- the same bin without the divisions, where that is provably the same.  What the stage wants of |m| / f is a
+// flag (the quotient against the coupling point) and an integer (the rounded root of the energy ratio): both are
+// step functions of rho = |m| / f, and away from their steps a 2-instruction estimate of rho decides them.
+//   reference: flag from RN32(|m| / f) = rho * (1 + d'), |d'| <= 2^-24;  k = rint(sqrt_f64(RN32(RN32(m*m) / RN32(f*f))))
+//              = rint(rho * (1 + d)), |d| <= (3 * 2^-24) / 2 + O(2^-47) (three fp32 roundings under a square root)
+//   here:      rr = RN32(|m| * rcp(f)), v_rcp_f32 within one ulp: rr = rho * (1 + e), |e| <= 2^-23 + 2^-24 + O(2^-47)
+// so rr is within 2.25 * 2^-23 * rho of either, and wherever rr is further than `band` * rr (2^-21 = 4 * 2^-23)
+// from the point and from every half-integer, the flag and rint(rr) ARE the reference's.  (Overflowing or vanishing
+// intermediates: an infinite or huge rr is never sure; a vanishing one gives k = 0 on both sides.)  A lane that is not sure says so,
+// and the wave then takes the whole quad through the exact forms above (one wave's quads in a hundred or so at |k| ~ 10).
+// (`band` is a kernel argument so that a test can widen it until the exact path runs for most quads or for all.)
+VAMD_DEV float approx_ratio_root(float num, float den) { return approx_sqrtf(num * approx_rcpf(den)); }
+VAMD_DEV bool off_the_steps(float v, float kf, float band) { return fabsf(v - kf) < 0.5f - v * band; }  // (false for NaN)
+// (written without branches: the or-ed conditions as integers, both coupling arms computed and one selected)
+VAMD_DEV ChanBin chan_bin_sure(int nzk, float m, int ilog, int b, const CoupleP &C, float band, bool &unsure) {
+  ChanBin r;
+  r.out = 0;
+  r.cand = -1.f;
+  if (nzk) {
+    const float f = floor1_fromdB(ilog);
+    const float point = b >= C.pointlimit ? C.postpoint : C.prepoint;
+    const float rr = fabsf(m) * approx_rcpf(f);
+    r.fg = rr < point ? 0 : 1;
+    const float kf = rintf(rr);
+    const int at_point = !(fabsf(rr - point) > point * band), at_step = !off_the_steps(rr, kf, band);
+    unsure = (int)unsure | at_point | at_step;
+    r.re = m * fabsf(m);  // m*m, negated for m < 0 (a zero's sign differs for m = -0: nothing below tells them apart)
+    r.qe = fabsf(r.re);
+    r.fl2 = f * f;
+    r.out = (int)copysignf(kf, m);  // "r < 0 ? -k : k": k != 0 only where m*m is not zero either
+  } else {
+    r.fl2 = 1e-10f;
+    r.re = 0.f;
+    r.qe = 0.f;
+    r.fg = 0;
+  }
+  return r;
+}
+
 // out[j]*out[j] as the reference's x86-64 build computes it (lib/psy.c:985: an int product, converted to float
 // afterwards): past |out| = 46340 -- spectra 93 dB over full scale -- the product wraps modulo 2^32, the "energy" can
 // come out negative and the bin then counts as a noise-normalisation candidate.  Signed overflow is undefined in C,
@@ -170,7 +209,7 @@ VAMD_DEV float int_square_as_float(int v) { return (float)(int)((unsigned int)v 
 // re-normalisation (noise_normalize with flags); M/A are updated in place, iM/iA
 // are the integers quantised so far.  Returns the magnitude's noise-norm
 // candidate energy or -1.
-VAMD_DEV float couple_bin(ChanBin &M, ChanBin &A, int &iM, int &iA, int b, int nstart, const CoupleP &C) {
+VAMD_DEV void couple_bin_mix(ChanBin &M, ChanBin &A, int &iM, int &iA, int b, int nstart, const CoupleP &C) {
   if (b < C.sliding_lowpass) {
     if (M.fg || A.fg) {
       // lossless: square-polar coupling of the already quantised integers
@@ -214,6 +253,9 @@ VAMD_DEV float couple_bin(ChanBin &M, ChanBin &A, int &iM, int &iA, int b, int n
     M.qe = int_square_as_float(iM) * M.fl2;
   }
   M.fl2 = A.fl2 = M.fl2 + A.fl2;
+}
+VAMD_DEV float couple_bin(ChanBin &M, ChanBin &A, int &iM, int &iA, int b, int nstart, const CoupleP &C) {
+  couple_bin_mix(M, A, iM, iA, b, nstart, C);
   float cand = -1.f;
   if (!M.fg) {
     const float ve = M.qe / M.fl2;
@@ -225,6 +267,109 @@ VAMD_DEV float couple_bin(ChanBin &M, ChanBin &A, int &iM, int &iA, int b, int n
   return cand;
 }
 
+// couple_bin where no bin is a noise-normalisation candidate, the re-quantisation by estimate (see chan_bin_sure:
+// s = sqrt(qe * rcp(fl2)) is within (2^-23 + 2^-24) / 2 + 2^-23 of the root of the true ratio, the reference's fp64
+// root of the rounded quotient within 2^-25 of it)
+VAMD_DEV void couple_bin_sure(ChanBin &M, ChanBin &A, int &iM, int &iA, int b, const CoupleP &C, float band, bool &unsure) {
+  const float fl2 = M.fl2 + A.fl2;
+  M.fl2 = A.fl2 = fl2;
+  float re = M.re, qe = M.qe;
+  int fg = M.fg;
+  if (b < C.sliding_lowpass) {
+    // lossless arm (lib/psy.c:1141-1166): the integers only -- a flagged magnitude is not re-quantised, so nothing
+    // reads its energies again
+    const int a = iM, bb = iA;
+    const int aA = a < 0 ? -a : a, aB = bb < 0 ? -bb : bb, d1 = a - bb, d2 = bb - a;
+    const bool gt = aA > aB;
+    int lA = (gt ? a : bb) > 0 ? d1 : d2;
+    int lM = gt ? a : bb;
+    const bool flip = lA >= (gt ? aA : aB) * 2;
+    lA = flip ? -lA : lA;
+    lM = flip ? -lM : lM;
+    // lossy arm (:1167-1190)
+    const float sum = M.re + A.re, e = fabsf(M.re) + fabsf(A.re);
+    const bool below = b < C.pointlimit;
+    re = below ? sum : (sum < 0 ? -e : e);
+    qe = below ? fabsf(sum) : e;
+    fg = M.fg | A.fg;
+    iM = fg ? lM : iM;
+    iA = fg ? lA : 0;
+  }
+  const float s = approx_ratio_root(qe, fl2);
+  const float kf = rintf(s);
+  const int at_step = !off_the_steps(s, kf, band);
+  unsure = (int)unsure | (at_step & (fg ^ 1));
+  iM = fg ? iM : (int)copysignf(kf, re);  // (k != 0 only where re is not a zero)
+  M.re = re, M.qe = qe, M.fg = fg;
+}
+
+// The stage where nothing is ordered (noise normalisation inactive in this block size, e.g. q >= 0.4 at 44.1 kHz):
+// each lane takes quads of bins straight through quantise -> couple -> re-normalise with one 16-byte load per input
+// tensor, by estimate first (chan_bin_sure) and exactly where some lane of the wave is not sure.
+//   ALL   compile-time promise that both channels exist, have a floor and are coupled (the flags are then not read)
+template <bool ALL>
+VAMD_DEV void couple_quads(const CoupleP &C, int n2, const float *__restrict__ mdctM, const float *__restrict__ mdctA,
+                           const ilog_t *__restrict__ ilogM, const ilog_t *__restrict__ ilogA, int *__restrict__ iworkM,
+                           int *__restrict__ iworkA, int nzM_in, int nzA_in, bool two_in, bool coupled_in, int nstart,
+                           float band) {
+  const int nzM = ALL ? 1 : nzM_in, nzA = ALL ? 1 : nzA_in;
+  const bool two = ALL ? true : two_in, coupled = ALL ? true : coupled_in;
+  // (two quads in flight, not WAVE_FOR's four: at four the kernel needs 110 VGPRs and the SIMD holds four waves)
+#pragma unroll 1
+  // (the quads are dealt over the whole TEAM: for a handful of blocks the launch gives a block four waves, which
+  // brings a lone block's 18 us down to 6)
+  TEAM_FOR(q, n2 >> 2) {
+    float m0[4], m1[4];
+    int l0[4], l1[4], o0[4], o1[4];
+    f4_get(((const F4 *)mdctM)[q], m0);
+    const I2 t0 = ((const I2 *)ilogM)[q];
+    l0[0] = t0.x & 0xffff; l0[1] = (int)((unsigned)t0.x >> 16); l0[2] = t0.y & 0xffff; l0[3] = (int)((unsigned)t0.y >> 16);
+    if (two) {
+      f4_get(((const F4 *)mdctA)[q], m1);
+      const I2 t1 = ((const I2 *)ilogA)[q];
+      l1[0] = t1.x & 0xffff; l1[1] = (int)((unsigned)t1.x >> 16); l1[2] = t1.y & 0xffff; l1[3] = (int)((unsigned)t1.y >> 16);
+    }
+    bool unsure = false;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const int b = (q << 2) + c;
+      ChanBin M = chan_bin_sure(nzM, m0[c], l0[c], b, C, band, unsure);
+      int iM = M.out, iA = 0;
+      if (two) {
+        ChanBin A = chan_bin_sure(nzA, m1[c], l1[c], b, C, band, unsure);
+        iA = A.out;
+        if (coupled) couple_bin_sure(M, A, iM, iA, b, C, band, unsure);
+      }
+      o0[c] = iM;
+      o1[c] = iA;
+    }
+    I4 w0, w1;
+    w0.x = o0[0]; w0.y = o0[1]; w0.z = o0[2]; w0.w = o0[3];
+    ((I4 *)iworkM)[q] = w0;
+    if (two) {
+      w1.x = o1[0]; w1.y = o1[1]; w1.z = o1[2]; w1.w = o1[3];
+      ((I4 *)iworkA)[q] = w1;
+    }
+    if (wave_any(unsure)) {
+      // some bin of the wave's 64 quads sits on a step: the reference's own arithmetic, a bin at a time from the
+      // tensors again and over what was just written -- the rare path holds no registers of the usual one that way
+#pragma unroll 1
+      for (int c = 0; c < 4; c++) {
+        const int b = (q << 2) + c;
+        ChanBin M = chan_bin(nzM, mdctM[b], ilogM[b], b, nstart, C);
+        int iM = M.out, iA = 0;
+        if (two) {
+          ChanBin A = chan_bin(nzA, mdctA[b], ilogA[b], b, nstart, C);
+          iA = A.out;
+          if (coupled) couple_bin(M, A, iM, iA, b, nstart, C);
+          iworkA[b] = iA;
+        }
+        iworkM[b] = iM;
+      }
+    }
+  }
+}
+
 // mdct[k]      HBM [n2]  post-M1 spectrum of channel k
 // ilogmask[k]  HBM [n2]  integer floor curve (floor1_encode's output)
 // iwork[k]     HBM [n2]  out: quantised (and coupled) residue
@@ -233,9 +378,10 @@ VAMD_DEV float couple_bin(ChanBin &M, ChanBin &A, int &iM, int &iA, int b, int n
 // NORM = false: the caller knows noise normalisation is inactive for this size class (the launch picks the
 // instantiation): the ordered general path below is then not even compiled in, which halves the registers.
 template <bool NORM = true>
-VAMD_DEV void couple_block(const CoupleP &C, const PsyP &P, int n2, const float *const *mdct,
+VAMD_DEV void couple_block(const CoupleP &C_set, const PsyP &P, int n2, const float *const *mdct,
                            const ilog_t *const *ilogmask, int *const *iwork, int *nonzero, const CoupleLds &L,
-                           PhaseClock &pc) {
+                           PhaseClock &pc, float band = VAMD_COUPLE_BAND) {
+  const CoupleP C = C_set;  // (by value: the fields in scalar registers, not behind the set's run-time index)
   const int ch = C.ch;
   const int partition = P.normal_p ? P.normal_partition : 16;
   const int nstart = P.normal_p ? P.normal_start : 0x7fffffff;  // first bin subject to noise norm
@@ -246,48 +392,16 @@ VAMD_DEV void couple_block(const CoupleP &C, const PsyP &P, int n2, const float 
   const bool coupled = C.coupling_steps == 1 && (nz[C.mag[0]] || nz[C.ang[0]]);
 
   if (!norm_active) {
-    // Common case (noise normalisation inactive in this block size, e.g. q >= 0.4 at
-    // 44.1 kHz): nothing is ordered, so each lane takes quads of bins straight through
-    // quantise -> couple -> re-normalise with one 16-byte load per input tensor.
+    // Common case: nothing is ordered (couple_quads above)
     const int Mi = C.coupling_steps == 1 ? C.mag[0] : 0, Ai = C.coupling_steps == 1 ? C.ang[0] : (ch > 1 ? 1 : 0);
-    // (two quads in flight, not WAVE_FOR's four: at four the kernel needs 110 VGPRs and the SIMD holds four waves;
-    // the stage is a chain of fp64 square roots and correctly rounded divisions, which more waves hide better
-    // than more unrolling)
-#pragma unroll 2
-    // (the quads are dealt over the whole TEAM: for a handful of blocks the launch gives a block four waves, which
-    // brings a lone block's 18 us down to 6)
-    TEAM_FOR(q, n2 >> 2) {
-      float m0[4], m1[4];
-      int l0[4], l1[4], o0[4], o1[4];
-      f4_get(((const F4 *)mdct[Mi])[q], m0);
-      const I2 t0 = ((const I2 *)ilogmask[Mi])[q];
-      l0[0] = t0.x & 0xffff; l0[1] = (int)((unsigned)t0.x >> 16); l0[2] = t0.y & 0xffff; l0[3] = (int)((unsigned)t0.y >> 16);
-      if (ch > 1) {
-        f4_get(((const F4 *)mdct[Ai])[q], m1);
-        const I2 t1 = ((const I2 *)ilogmask[Ai])[q];
-        l1[0] = t1.x & 0xffff; l1[1] = (int)((unsigned)t1.x >> 16); l1[2] = t1.y & 0xffff; l1[3] = (int)((unsigned)t1.y >> 16);
-      }
-#pragma unroll
-      for (int c = 0; c < 4; c++) {
-        const int b = (q << 2) + c;
-        ChanBin M = chan_bin(nz[Mi], m0[c], l0[c], b, nstart, C);
-        int iM = M.out, iA = 0;
-        if (ch > 1) {
-          ChanBin A = chan_bin(nz[Ai], m1[c], l1[c], b, nstart, C);
-          iA = A.out;
-          if (coupled) couple_bin(M, A, iM, iA, b, nstart, C);
-        }
-        o0[c] = iM;
-        o1[c] = iA;
-      }
-      I4 w0, w1;
-      w0.x = o0[0]; w0.y = o0[1]; w0.z = o0[2]; w0.w = o0[3];
-      ((I4 *)iwork[Mi])[q] = w0;
-      if (ch > 1) {
-        w1.x = o1[0]; w1.y = o1[1]; w1.z = o1[2]; w1.w = o1[3];
-        ((I4 *)iwork[Ai])[q] = w1;
-      }
-    }
+    // (the usual block -- two channels, both with a floor, coupled -- gets a loop compiled for exactly that: the
+    // wave-uniform tests on nonzero[] and on the channel count otherwise stand between every two bins)
+    if (ch > 1 && coupled && nz[Mi] && nz[Ai])
+      couple_quads<true>(C, n2, mdct[Mi], mdct[Ai], ilogmask[Mi], ilogmask[Ai], iwork[Mi], iwork[Ai], 1, 1, true, true,
+                         nstart, band);
+    else
+      couple_quads<false>(C, n2, mdct[Mi], mdct[Ai], ilogmask[Mi], ilogmask[Ai], iwork[Mi], iwork[Ai], nz[Mi], nz[Ai],
+                          ch > 1, coupled, nstart, band);
     pc.mark(0);
     if (coupled) nz[C.mag[0]] = nz[C.ang[0]] = 1;  // lib/psy.c:1204-1212
     for (int k = 0; k < ch; k++) nonzero[k] = nz[k];

@@ -484,7 +484,7 @@ __global__ void k_widen_ilog(long n, const ilog_t *__restrict__ in, int *__restr
 template <bool NORM>
 __global__ __launch_bounds__(256) void k_couple(PsyP P0, PsyP P1, CoupleSet CS, int blob_base, int nblobs, DescP d,
                                                const float *__restrict__ mdct, const ilog_t *__restrict__ ilogmask,
-                                               int *__restrict__ iwork, int *__restrict__ nonzero) {
+                                               int *__restrict__ iwork, int *__restrict__ nonzero, float band) {
   const long unit = blockIdx.x, mblk = unit / nblobs;
   const CoupleP &C = CS.c[blob_base + (int)(unit - mblk * nblobs)];
   const PsyP &P = d_bt(d, mblk) ? P1 : P0;
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(256) void k_couple(PsyP P0, PsyP P1, CoupleSet CS, 
   WAVE_SYNC_GLOBAL();  // every lane has read nonzero[] before lane 0 rewrites it
   PhaseClock pc;
   pc.start(d.dbg ? d.dbg + 64 : nullptr);
-  couple_block<NORM>(C, P, n2, mp, ip, op, nz, L, pc);
+  couple_block<NORM>(C, P, n2, mp, ip, op, nz, L, pc, band);
   if (TEAM_LEADER)
     for (int c = 0; c < ch; c++) nonzero[blk * ch + c] = nz[c];
   pc.flush();
@@ -822,6 +822,7 @@ struct vamd_ctx {
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool overlap = true;
+  float couple_band = VAMD_COUPLE_BAND;  // k_couple.h, chan_bin_sure
   Bound B;                 // parameter structs bound to the HBM image
   unsigned char *d_image = nullptr;
   Bound *d_bound = nullptr;  // c->B in HBM: kernels that would otherwise carry several parameter structs in SGPRs read it
@@ -961,6 +962,8 @@ int vamd_create(vamd_ctx **out, const void *setup_blob, size_t blob_bytes, int d
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
   c->overlap = getenv("VAMD_NO_OVERLAP") == nullptr;
+  // (test aid: k_couple's estimate-then-verify margin as a power of two; 1 sends every quad through the exact path)
+  c->couple_band = getenv("VAMD_COUPLE_BAND_LOG2") ? ldexpf(1.f, atoi(getenv("VAMD_COUPLE_BAND_LOG2"))) : VAMD_COUPLE_BAND;
   if (e == hipSuccess) e = hipMalloc((void **)&c->d_image, image.size());
   if (e == hipSuccess) e = hipMemcpy(c->d_image, image.data(), image.size(), hipMemcpyHostToDevice);
   if (e != hipSuccess) {
@@ -1336,10 +1339,10 @@ static void launch_couple(vamd_ctx *c, BatchRun *R, hipStream_t s, long units, i
   const bool norm0 = P0.normal_p && P0.normal_start < n2, norm1 = P1.normal_p && P1.normal_start < n2;
   if (norm0 || norm1)
     hipLaunchKernelGGL(k_couple<true>, dim3((unsigned)units), dim3(64), (size_t)n2 * 12 + 1024, s, P0, P1, c->B.couple_all[W], blob_base,
-                       nblobs, R->d, mdct, ilogmask, iwork, nonzero);
+                       nblobs, R->d, mdct, ilogmask, iwork, nonzero, c->couple_band);
   else  // (a handful of blocks: four waves each)
     hipLaunchKernelGGL(k_couple<false>, dim3((unsigned)units), dim3(units <= 2048 && n2 >= 512 ? 256 : 64), 0, s, P0, P1, c->B.couple_all[W],
-                       blob_base, nblobs, R->d, mdct, ilogmask, iwork, nonzero);
+                       blob_base, nblobs, R->d, mdct, ilogmask, iwork, nonzero, c->couple_band);
 }
 
 static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_io *M = nullptr, ilog_t *m_ilogmask = nullptr) {

@@ -125,6 +125,12 @@ struct FloorP {
   int over_i, under_i;      //   integers: val - y >= over_i, resp. y - val >= under_i
 };
 
+// k_couple's estimate-then-verify margin (k_couple.h, chan_bin_sure): relative distance from a decision step inside
+// which a bin is sent through the reference's own divisions.  The estimate and the reference's own roundings are
+// together within 2.25 * 2^-23 of each other (derivation there); the steps are a whole number apart, so the share of
+// bins sent to the exact path grows with the band AND with the bin's magnitude -- hence no wider than this.
+#define VAMD_COUPLE_BAND 0x1p-21f
+
 struct CoupleP {
   int ch;
   int coupling_steps;

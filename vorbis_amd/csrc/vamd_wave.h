@@ -237,6 +237,8 @@ VAMD_DEV unsigned int load_uniform_u32(const unsigned int *p, int i) {
 }
 // v_sqrt_f32: within one ulp of the root (k_couple's quant_energy settles the candidate exactly)
 VAMD_DEV float approx_sqrtf(float x) { return __builtin_amdgcn_sqrtf(x); }
+// v_rcp_f32: within one ulp of the reciprocal
+VAMD_DEV float approx_rcpf(float x) { return __builtin_amdgcn_rcpf(x); }
 // keeps a wave-uniform value opaque to the optimiser (k_floor: a known +-1 would turn a multiply-add into negate + select)
 VAMD_DEV void keep_opaque(int &v) { asm volatile("" : "+s"(v)); }
 
