@@ -61,6 +61,47 @@ __device__ __forceinline__ void mfma_walk(float *S, int stride, int n) {
   if ((lane & 15) == 0) dst0[4 * (groups - 1)] = accA[0];
   if (lane == 0) dst1[4 * (groups - 1)] = accA[1];
 }
+// The same walk one element per instruction: v_mfma_f32_4x4x1_16b_f32 (two passes) computes, per block of four lanes,
+// D[i][j] = C[i][j] + A[i] * B[j]; with A = 1 in every lane and B = the lane's own next element, all four registers of
+// a lane advance the lane's own chain by one element -- a lane per chain, sixty-four chains, EVERY running total (no
+// fill-in), and still no vector issue slot.  Four accumulators rotate so that a quad's totals leave with four b32
+// stores while the chain moves on (a b128 store would want the four totals in consecutive registers: they are the
+// first registers of four different tuples).
+template <bool STORE>
+__device__ __forceinline__ void mfma_walk41(float *S, int stride, int n) {
+  const int lane = threadIdx.x & 63;
+  float *p = S + (lane < NCH ? lane : 0) * stride;
+  const bool st = STORE;
+  constexpr int U = 4;  // quads fetched ahead
+  const int quads = n >> 2;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  F4 v[U], vn[U];
+#pragma unroll
+  for (int u = 0; u < U; u++) v[u] = *(const F4 *)(p + 4 * u);
+  for (int q0 = 0; q0 < quads; q0 += U) {
+    if (q0 + U < quads) {
+#pragma unroll
+      for (int u = 0; u < U; u++) vn[u] = *(const F4 *)(p + 4 * (q0 + U + u));
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const f32x4 a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(1.0f, v[u].x, acc, 0, 0, 0);
+      const f32x4 a2 = __builtin_amdgcn_mfma_f32_4x4x1f32(1.0f, v[u].y, a1, 0, 0, 0);
+      const f32x4 a3 = __builtin_amdgcn_mfma_f32_4x4x1f32(1.0f, v[u].z, a2, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_4x4x1f32(1.0f, v[u].w, a3, 0, 0, 0);
+      if (st) {
+        float *d = p + 4 * (q0 + u);
+        __builtin_nontemporal_store(a1[0], d);  // (kept as four b32 stores: see above)
+        __builtin_nontemporal_store(a2[0], d + 1);
+        __builtin_nontemporal_store(a3[0], d + 2);
+        __builtin_nontemporal_store(acc[0], d + 3);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) v[u] = vn[u];
+  }
+  if (!STORE && lane < NCH) p[n - 1] = acc[0];
+}
 // fill-in: one lane per quad
 __device__ __forceinline__ void fill_in(float *S, int stride, int n) {
   const int groups = n >> 2;
@@ -99,6 +140,8 @@ __global__ void k(int mode, int n, int stride, const float *in, float *out, unsi
     if (mode == 0) serial_walk(sm, stride, n);
     if ((mode == 1 || mode == 2) && threadIdx.x < 64) mfma_walk<true>(sm, stride, n);
     if (mode == 3 && threadIdx.x < 64) mfma_walk<false>(sm, stride, n);
+    if (mode == 4 && threadIdx.x < NCH) mfma_walk41<true>(sm, stride, n);   // (the matrix instruction ignores EXEC;
+    if (mode == 5 && threadIdx.x < NCH) mfma_walk41<false>(sm, stride, n);  // the loads and stores need only these lanes)
     __syncthreads();
     if (mode == 2) fill_in(sm, stride, n);
     __syncthreads();
@@ -128,8 +171,9 @@ int main() {
     float acc = 0.f;
     for (int i = 0; i < n; i++) { acc += h[c * stride + i]; ref[c * stride + i] = acc; }
   }
-  const char *names[4] = {"serial lane-per-chain", "mfma walk (totals only)", "mfma walk + fill-in", "mfma chain, no stores"};
-  for (int mode = 0; mode < 4; mode++)
+  const char *names[6] = {"serial lane-per-chain", "mfma walk (totals only)", "mfma walk + fill-in", "mfma chain, no stores",
+                          "4x4x1 walk, every total", "4x4x1 chain, no stores"};
+  for (int mode = 0; mode < 6; mode++)
     for (int grid : {1, 256 * 8}) {
       hipLaunchKernelGGL(k, dim3(grid), dim3(256), NCH * stride * 4, 0, mode, n, stride, d_in, d_out, d_t, reps);
       hipDeviceSynchronize();
@@ -143,7 +187,7 @@ int main() {
       for (int c = 0; c < NCH; c++)
         for (int i = 0; i < n; i++) {
           if (mode == 1 && (i & 3) != 3) continue;
-          if (mode == 3 && i != n - 1) continue;
+          if ((mode == 3 || mode == 5) && i != n - 1) continue;
           bad += memcmp(&ref[c * stride + i], &got[c * stride + i], 4) != 0;
         }
       printf("%-26s grid %5d: %8.0f ticks per walk = %5.2f per element; mismatches vs host serial sum: %ld\n", names[mode], grid,

@@ -80,18 +80,38 @@ VAMD_DEV void seed_curve_scatter(float *seed, const float *__restrict__ band_row
 // end_k = next.pos if the next entry is louder else pos_k + linesper + 1 (clipped
 // to n) and start_k = max(end_0 .. end_{k-1}) because the reference's write
 // pointer only moves forward.  Spans are disjoint, so all lanes paint at once.
-//   seeds     LDS, painted in place;  src  the unpainted seed values (HBM copy): an entry's
-//             amplitude is src[its line], read there because painting may already have covered it
-//   posstack  the survivor list (HBM)
-VAMD_DEV void seed_chase_paint(float *seeds, const float *__restrict__ src, int linesper, int n, int stack,
-                               const unsigned short *__restrict__ posstack) {
+//   seeds     LDS, painted in place
+//   src       where an entry's amplitude (the unpainted value of its line) is read.  On the GPU that is `seeds` itself:
+//             chunk c+1's amplitudes are fetched before chunk c paints, and what chunks <= c-1 painted ends at most
+//             linesper lines past their last entry -- short of chunk c+1's first entry, which is 65 or more entries and
+//             therefore lines further on (linesper <= 16).  The one-lane test build, whose chunks are single entries,
+//             hands over a copy of the unpainted lines instead.
+//   posstack  the survivor list (HBM);  head  its first two chunks as fetched ahead by surv_head_load (optional)
+struct SurvHead {
+  int p1, np1, p2, np2;  // entries LANE, LANE + 1, LANE + NLANES, LANE + NLANES + 1, whatever the list's length
+};
+// (a block's list row is nlines entries long whatever the count, so reading past the count stays in the row: callers
+// keep two chunks + 1 entries readable)
+VAMD_DEV SurvHead surv_head_load(const unsigned short *__restrict__ posstack) {
+  SurvHead h;
+  h.p1 = posstack[LANE], h.np1 = posstack[LANE + 1];
+  h.p2 = posstack[LANE + NLANES], h.np2 = posstack[LANE + NLANES + 1];
+  return h;
+}
+VAMD_DEV void seed_chase_paint(float *seeds, const float *src, int linesper, int n, int stack,
+                               const unsigned short *__restrict__ posstack, const SurvHead *head = nullptr) {
   int carry = 0;
   // Software pipeline over the chunks of 64 survivors: the list entries are fetched two chunks ahead and the
-  // amplitudes they point at one chunk ahead, so that a chunk finds both in registers (one after the other they are
-  // two dependent trips to memory per chunk, in a stage that spends three quarters of its time waiting).
+  // amplitudes they point at one chunk ahead, so that a chunk finds both in registers.
   auto at = [&](int k) { return k < stack ? (int)posstack[k] : 0; };
-  int pos1 = at(LANE), npos1 = at(LANE + 1);                    // chunk 0
-  int pos2 = at(LANE + NLANES), npos2 = at(LANE + NLANES + 1);  // chunk 1
+  int pos1, npos1, pos2, npos2;
+  if (head) {
+    pos1 = LANE < stack ? head->p1 : 0, npos1 = LANE + 1 < stack ? head->np1 : 0;
+    pos2 = LANE + NLANES < stack ? head->p2 : 0, npos2 = LANE + NLANES + 1 < stack ? head->np2 : 0;
+  } else {
+    pos1 = at(LANE), npos1 = at(LANE + 1);                    // chunk 0
+    pos2 = at(LANE + NLANES), npos2 = at(LANE + NLANES + 1);  // chunk 1
+  }
   float a1 = src[pos1], an1 = src[npos1];
   for (int base = 0; base < stack; base += NLANES) {
     const int k = base + LANE;
@@ -109,6 +129,8 @@ VAMD_DEV void seed_chase_paint(float *seeds, const float *__restrict__ src, int 
     const int incl = wave_scan_max(endpos);
     int start = wave_shift_up1(incl, 0);
     if (start < carry) start = carry;
+    // (a wave's LDS accesses keep their order: the next chunk's amplitudes, asked for above, are read before this
+    // chunk's paint lands)
     if (k < stack)
       for (int p = start; p < endpos; p++) seeds[p] = a;
     const int last = wave_last(incl);
@@ -353,11 +375,11 @@ VAMD_DEV void tone_seed_block(const PsyP &P, const float *__restrict__ logfft, f
 // list -> tone curve
 // ... in two steps, so that a caller can take the curve quad by quad (k_floor mixes it without a trip through memory):
 // tone_fold_prepare leaves the painted lines and the groups' minima in LDS, tone_fold_quad forms four bins from them.
-VAMD_DEV void tone_fold_prepare(const PsyP &P, float *seed, const float *__restrict__ seed_src,
+VAMD_DEV void tone_fold_prepare(const PsyP &P, float *seed, const float *seed_src,
                                 const unsigned short *__restrict__ surv, int nsurv, float *gmin /* LDS [ngroups] */,
-                                PhaseClock &pc, int slot = 3) {
+                                PhaseClock &pc, int slot = 3, const SurvHead *head = nullptr) {
   const int nlines = P.total_octave_lines;
-  seed_chase_paint(seed, seed_src, P.eighth_octave_lines, nlines, nsurv, surv);
+  seed_chase_paint(seed, seed_src, P.eighth_octave_lines, nlines, nsurv, surv, head);
   WAVE_SYNC();
   pc.mark(slot);
 
@@ -406,7 +428,7 @@ VAMD_DEV void tone_fold_quad(const PsyP &P, float att, const float *seed, const 
     o[c] = v;
   }
 }
-VAMD_DEV void tone_fold_block(const PsyP &P, float local_ampmax, float *seed, const float *__restrict__ seed_src,
+VAMD_DEV void tone_fold_block(const PsyP &P, float local_ampmax, float *seed, const float *seed_src,
                               const unsigned short *__restrict__ surv, int nsurv, float *gmin /* LDS [ngroups] */,
                               float *__restrict__ out, PhaseClock &pc) {
   const float att = tone_ath_att(P, local_ampmax);

@@ -421,7 +421,7 @@ __global__ __launch_bounds__(64) void k_tone_fold(PsyP P0, PsyP P1, DescP d, int
   pc.start(d.dbg ? d.dbg + 32 : nullptr);
   WAVE_FOR(q, nlp >> 2)((F4 *)seed)[q] = ((const F4 *)(seed_g + cb * nlp))[q];
   WAVE_SYNC();
-  tone_fold_block(P, local_ampmax[cb], seed, seed_g + cb * nlp, surv + cb * nlp, nsurv[cb], gmin, tone + cb * n2, pc);
+  tone_fold_block(P, local_ampmax[cb], seed, seed, surv + cb * nlp, nsurv[cb], gmin, tone + cb * n2, pc);
   pc.flush();
 }
 
@@ -456,9 +456,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 #endif
   if (seed_g) {
     float *seed = (float *)vamd_smem;  // [nlp], then the group minima
+    // (one trip to memory for both: the head of the survivor list is asked for before the lines, and the survivors'
+    // amplitudes then come out of the lines' LDS copy)
+    const bool ahead = nlp >= 2 * 64 + 2;  // (the row holds the entries surv_head_load reads)
+    SurvHead head;
+    if (ahead) head = surv_head_load(surv + cb * nlp);
     WAVE_FOR(q, nlp >> 2)((F4 *)seed)[q] = ((const F4 *)(seed_g + cb * nlp))[q];
     WAVE_SYNC();
-    tone_fold_prepare(P, seed, seed_g + cb * nlp, surv + cb * nlp, nsurv[cb], seed + nlp, pc, 5);
+    tone_fold_prepare(P, seed, seed, surv + cb * nlp, nsurv[cb], seed + nlp, pc, 5, ahead ? &head : nullptr);
     fold_and_mix_wave(P, tone_ath_att(P, local_ampmax[cb]), seed, seed + nlp, noise + cb * n2, tone ? tone + cb * n2 : nullptr,
                       mdct_raw + cb * n2, mdct + cb * n2, logmask_out ? logmask_out + cb * n2 : nullptr, qc, F.twofitatten, pc);
   } else {
