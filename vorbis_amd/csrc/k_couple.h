@@ -322,12 +322,12 @@ VAMD_DEV void couple_quads(const CoupleP &C, int n2, const float *__restrict__ m
     float m0[4], m1[4];
     int l0[4], l1[4], o0[4], o1[4];
     f4_get(((const F4 *)mdctM)[q], m0);
-    const I2 t0 = ((const I2 *)ilogM)[q];
-    l0[0] = t0.x & 0xffff; l0[1] = (int)((unsigned)t0.x >> 16); l0[2] = t0.y & 0xffff; l0[3] = (int)((unsigned)t0.y >> 16);
+    const unsigned int t0 = ((const unsigned int *)ilogM)[q];  // (ilog_t: a byte per bin)
+    l0[0] = t0 & 0xff; l0[1] = (t0 >> 8) & 0xff; l0[2] = (t0 >> 16) & 0xff; l0[3] = t0 >> 24;
     if (two) {
       f4_get(((const F4 *)mdctA)[q], m1);
-      const I2 t1 = ((const I2 *)ilogA)[q];
-      l1[0] = t1.x & 0xffff; l1[1] = (int)((unsigned)t1.x >> 16); l1[2] = t1.y & 0xffff; l1[3] = (int)((unsigned)t1.y >> 16);
+      const unsigned int t1 = ((const unsigned int *)ilogA)[q];
+      l1[0] = t1 & 0xff; l1[1] = (t1 >> 8) & 0xff; l1[2] = (t1 >> 16) & 0xff; l1[3] = t1 >> 24;
     }
     bool unsure = false;
 #pragma unroll

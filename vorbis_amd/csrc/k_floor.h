@@ -435,9 +435,7 @@ VAMD_DEV void floor_render_curve(const FloorP &F, int posts, int n2, const LaneI
         const int k = 4 * q + c - r.x0;
         v[c] = mad24(div_magic(mad24(k, r.ady, 0), r.magic), r.sgn, r.y0);
       }
-      I2 o;
-      o.x = v[0] | (v[1] << 16), o.y = v[2] | (v[3] << 16);
-      ((I2 *)ilogmask)[q] = o;
+      ((unsigned int *)ilogmask)[q] = (unsigned)v[0] | ((unsigned)v[1] << 8) | ((unsigned)v[2] << 16) | ((unsigned)v[3] << 24);  // (ilog_t)
     }
   }
 }

@@ -1099,7 +1099,7 @@ struct WsPlan {
   float *mdct_raw, *logmdct, *logfft, *noise, *tone, *mdct, *local, *ampin, *ampglob, *seed;
   unsigned short *surv;
   int32_t *nsurv;
-  ilog_t *ilogmask;  // 16-bit, workspace only (the int32 tap is widened from it: k_widen_ilog)
+  ilog_t *ilogmask;  // a byte per bin, workspace only (the int32 tap is widened from it: k_widen_ilog)
   int32_t *iwork, *posts, *post_valid, *nonzero;
   unsigned char *status;
 };
@@ -1134,7 +1134,7 @@ static int plan(vamd_ctx *c, int W, long nb, const vamd_batch_io *io, int level,
   }
   if (level >= VAMD_LEVEL_FULL) {
     PICK(mdct, io ? io->mdct : nullptr, WS_MDCT, per);
-    PICK(ilogmask, (ilog_t *)nullptr, WS_ILOGMASK, per / 2);
+    PICK(ilogmask, (ilog_t *)nullptr, WS_ILOGMASK, per / 4 * sizeof(ilog_t));
     PICK(iwork, io ? io->iwork : nullptr, WS_IWORK, per);
     PICK(posts, io ? io->posts : nullptr, WS_POSTS, (size_t)nb * ch * VAMD_POSTS_STRIDE * 4);
     PICK(post_valid, io ? io->post_valid : nullptr, WS_POSTVALID, (size_t)nb * ch * 4);

@@ -7,9 +7,12 @@
 namespace vamd {
 
 // The integer floor curve between the floor and the coupling stage (floor1_encode's render, lib/floor1.c:923-952):
-// values are a post's quantised height times mult, below 1024, so they travel as 16 bits (half the stream of the
-// one stage that is bound by HBM bandwidth).  The int32 `ilogmask` tap of the C ABI is widened from it on request.
-typedef unsigned short ilog_t;
+// values are a post's quantised height times mult -- the fit's 0..1023 scale cut to 256 / mult steps (lib/floor1.c:
+// 772-781), i.e. at most 255 whatever mult is -- and the lines between two of them, so they travel as bytes: the
+// coupling stage, which moves its data at what HBM gives, reads a quarter of what an int curve would cost it, and
+// the table look-up it feeds (floor1_fromdB) has 256 entries.  The int32 `ilogmask` tap of the C ABI is widened from
+// it on request.
+typedef unsigned char ilog_t;
 
 // window + MDCT + FFT tables for one size class W
 struct XformP {
