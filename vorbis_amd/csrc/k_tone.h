@@ -332,36 +332,21 @@ VAMD_DEV int chase_flat_chunk(const float *seeds, int s, int e) {
 }
 
 // scatter half: seed[] for one channel-block (LDS), lib/psy.c:417-452,762-771
-// logfft is read straight from HBM: each lane walks the few bins of its own run, neighbouring
-// lanes walk neighbouring runs, and a copy in LDS would only cost the block its co-residency
+//   peaks  HBM [nruns]: the maximum of logfft over each run of bins that share an octave line (run_peak, formed by
+//          the transform stage while the block's logfft was in LDS): a float per run is all this stage needs of it
 template <int LP = 0>
-VAMD_DEV void tone_seed_block(const PsyP &P, const float *__restrict__ logfft, float global_ampmax,
+VAMD_DEV void tone_seed_block(const PsyP &P, const float *__restrict__ peaks, float global_ampmax,
                               float local_ampmax, float *seed, PhaseClock &pc) {
-  const int n = P.n, nlines = P.total_octave_lines;
+  const int nlines = P.total_octave_lines;
   float att = local_ampmax + P.ath_adjatt;
   if (att < P.ath_maxatt) att = P.ath_maxatt;
-  const float *__restrict__ fft = logfft;
-  (void)n;
   WAVE_FOR(i, nlines) seed[i] = VAMD_NEGINF;  // (the padding either side is write-only)
   WAVE_SYNC();
   pc.mark(0);
   const float dBoffset = P.max_curve_dB - global_ampmax;
   WAVE_FOR(r, P.nruns) {
     const I4 rec = ((const I4 *)P.runs)[r];
-    const int s = rec.x & 0xffff, e = rec.x >> 16;  // bins [s, e)
-    // the run's peak, four loads in flight at a time: one at a time, every compare would wait out a full
-    // memory round trip (runs reach ~10 bins at the top of the spectrum).  Indices past the run are clamped
-    // to its last bin, which a maximum does not mind.
-    float mx = fft[s];
-    for (int i = s + 1; i < e; i += 4) {
-      const int last = e - 1;
-      const float a = fft[i], b = fft[i + 1 < last ? i + 1 : last], c = fft[i + 2 < last ? i + 2 : last],
-                  dd = fft[i + 3 < last ? i + 3 : last];
-      if (a > mx) mx = a;
-      if (b > mx) mx = b;
-      if (c > mx) mx = c;
-      if (dd > mx) mx = dd;
-    }
+    const float mx = peaks[r];
     seed_curve_scatter<LP>(seed, P.curves64 + rec.z * (VAMD_P_LEVELS * P.curve_stride), P.curve_stride, mx, rec.y,
                            P.eighth_octave_lines, dBoffset, mx + 6.f > f_from_bits((uint32_t)rec.w) + att);
   }
@@ -450,7 +435,8 @@ VAMD_DEV void tone_fold_block(const PsyP &P, float local_ampmax, float *seed, co
 VAMD_DEV void tonemask_block(const PsyP &P, const float *__restrict__ logfft, float *__restrict__ out,
                              float global_ampmax, float local_ampmax, float *seed, float *seed_copy,
                              float *fft, float *ring_amp, int *ring_pos, unsigned short *surv, PhaseClock &pc) {
-  tone_seed_block(P, logfft, global_ampmax, local_ampmax, seed, pc);
+  for (int r = 0; r < P.nruns; r++) fft[r] = run_peak(logfft, P.run_start[r], P.run_start[r + 1]);  // (what k_transform hands over)
+  tone_seed_block(P, fft, global_ampmax, local_ampmax, seed, pc);
   const int nsurv = tone_chase_thread(seed, P.eighth_octave_lines, P.total_octave_lines, ring_amp, ring_pos, 1, 0, surv);
   for (int i = 0; i < P.total_octave_lines; i++) seed_copy[i] = seed[i];  // (single-lane test build only)
   tone_fold_block(P, local_ampmax, seed, seed_copy, surv, nsurv, fft /* reused as gmin */, out, pc);

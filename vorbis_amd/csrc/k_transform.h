@@ -906,15 +906,41 @@ VAMD_DEV const float *transform_spectra(const XformP &P, float *A, float *B, flo
   return spec;
 }
 
+// quads of an n/2-bin spectrum per thread of a one-wave team (the generic size: up to 4096 samples)
+#define VAMD_XF_QPS(LOGN) ((LOGN) ? (((1 << (LOGN)) / 8 + 63) / 64) : 4096 / 8 / 64)
+// the run ids transform_logfft wants, for this thread's quads (fetched once by a persistent kernel)
+template <int LOGN, class Team>
+VAMD_DEV void xf_run_ids(const XformP &P, const unsigned short *__restrict__ run_of_bin, I2 *rid, const Team &tm) {
+  const int n2 = (LOGN ? (1 << LOGN) : P.n) >> 1;
+  if (!LOGN) return;  // (the generic size reads the table as it goes)
+  TEAM_QUADS(kq, q, n2 >> 2, VAMD_XF_QPS(LOGN), tm) rid[kq] = ((const I2 *)run_of_bin)[q];
+}
+
 // logfft + local ampmax, lib/mapping0.c:255-346; four bins per thread.  Returns the local_ampmax contribution of
 // THIS WAVE (every lane holds it): the caller combines the team's waves.
+//   peaks_out  (optional) HBM [nruns]: the maximum of logfft over each run of bins that share an octave line -- all the
+//              tone stage reads of logfft (seed_loop's inner maximum, lib/psy.c:429-440; run_peak states it serially).
+//              run_of_bin [n/2] = the run of each bin (PsyP::run_of_bin); rid[kq] = the same for the four bins of this
+//              thread's quad number kq, 16 bits each, where the size is fixed at compile time (the persistent kernel
+//              fetches them once, they are the same for every block: xf_run_ids); peaks_lds = nruns floats of LDS that
+//              `spec` does not overlap.  Every bin's value is folded into its run's slot with an LDS float maximum as it is
+//              formed: no pass of its own, nothing that waits -- this stage has two waves per SIMD to hide a wait behind.
+//              (The order of a maximum matters for nothing here: the values are finite, and a tie between +0 and -0
+//              feeds additions only.)
 template <int LOGN = 0, class Team = WaveTeam>
 VAMD_DEV float transform_logfft(const XformP &P, const float *spec, float *__restrict__ logfft_out, PhaseClock &pc,
-                                const Team &tm = Team(), float *raw_max = nullptr) {
+                                const Team &tm = Team(), float *raw_max = nullptr, float *peaks_lds = nullptr,
+                                const I2 *rid = nullptr, const unsigned short *__restrict__ run_of_bin = nullptr,
+                                int nruns = 0, float *__restrict__ peaks_out = nullptr) {
   const int n = LOGN ? (1 << LOGN) : P.n, n2 = n >> 1;
   const float scale = 4.f / n;
   const float scale_dB = todB_345(scale);
   float amp = -1e30f;
+  if (peaks_out) {
+    TEAM_EACH(r, nruns, tm) peaks_lds[r] = f_from_bits(0xff800000u);  // -inf: every run has a bin, and every bin a finite value
+    tm.sync();
+  }
+  int kq = 0;  // (the size-specialised kernels unroll this loop entirely: rid[kq] is a register)
   TEAM_EACH(q, n2 >> 2, tm) {
     float v[4];
     for (int c = 0; c < 4; c++) {
@@ -929,6 +955,18 @@ VAMD_DEV float transform_logfft(const XformP &P, const float *spec, float *__res
       amp = fmaxf(amp, v[c]);
     }
     if (logfft_out) ((F4 *)logfft_out)[q] = f4_make(v);
+    if (peaks_out) {
+      const I2 r = LOGN ? rid[kq] : ((const I2 *)run_of_bin)[q];
+      lds_atomic_max(peaks_lds + (r.x & 0xffff), v[0]);
+      lds_atomic_max(peaks_lds + (int)((unsigned)r.x >> 16), v[1]);
+      lds_atomic_max(peaks_lds + (r.y & 0xffff), v[2]);
+      lds_atomic_max(peaks_lds + (int)((unsigned)r.y >> 16), v[3]);
+    }
+    kq++;
+  }
+  if (peaks_out) {
+    tm.sync();
+    TEAM_EACH(r, nruns, tm) peaks_out[r] = peaks_lds[r];
   }
   // (every v[c] is finite whatever the samples were -- todB() converts the BITS of its argument, so a NaN or Inf
   // spectrum value becomes a large finite dB figure -- hence fmaxf here and in wave_max is the reference's
@@ -944,9 +982,13 @@ VAMD_DEV float transform_logfft(const XformP &P, const float *spec, float *__res
 template <int LOGN = 0, class Team = WaveTeam>
 VAMD_DEV float transform_block(const XformP &P, float *A, float *B, float *__restrict__ mdct_out,
                                float *__restrict__ logmdct_out, float *__restrict__ logfft_out, PhaseClock &pc,
-                               const Team &tm = Team(), float *raw_max = nullptr) {
+                               const Team &tm = Team(), float *raw_max = nullptr, const I2 *rid = nullptr,
+                               const unsigned short *__restrict__ run_of_bin = nullptr, int nruns = 0,
+                               float *__restrict__ peaks_out = nullptr) {
   const float *spec = transform_spectra<LOGN, Team>(P, A, B, mdct_out, logmdct_out, pc, tm);
-  return transform_logfft<LOGN, Team>(P, spec, logfft_out, pc, tm, raw_max);
+  // (the spectrum sits in one of the two buffers: the other one is free by now)
+  float *lds_free = (spec >= A && spec < A + VAMD_XF_A_FLOATS(P.n)) ? B : A;
+  return transform_logfft<LOGN, Team>(P, spec, logfft_out, pc, tm, raw_max, lds_free, rid, run_of_bin, nruns, peaks_out);
 }
 
 // log2 n when the size-specialised transforms apply -- a power of two in [256, 4096] whose FFT factors are the ones

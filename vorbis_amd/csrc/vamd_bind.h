@@ -328,6 +328,14 @@ inline int build_image(const void *blob_v, size_t bytes, std::vector<unsigned ch
     image->insert(image->end(), b, b + 4 * d.seed_span.size());
     derived->push_back(d);
   }
+  // the transform stage hands the tone stage logfft's peak per run of bins (k_transform.h, run_peak) before it knows a
+  // block's type: the runs follow from the size and the rate alone (octave[], lib/psy.c:327-329), so the two looks of a
+  // size class share them -- checked, not assumed
+  for (int W = 0; W < 2; W++)
+    if ((*derived)[2 * W].run_start != (*derived)[2 * W + 1].run_start) {
+      *err = "the two psy looks of a block size disagree on octave[] (outside the covered path)";
+      return VAMD_EIMPL;
+    }
   for (int p = 0; p < 4; p++) {  // slots 8..15: per psy RunRec[] and the re-strided tone curves
     const PsyDerived &d = (*derived)[p];
     while (image->size() & 255) image->push_back(0);
@@ -383,6 +391,16 @@ inline int build_image(const void *blob_v, size_t bytes, std::vector<unsigned ch
     derived_off->push_back((uint32_t)image->size());
     const unsigned char *a = (const unsigned char *)mg.data();
     image->insert(image->end(), a, a + 4 * mg.size());
+  }
+  for (int W = 0; W < 2; W++) {  // slots 37 + W: bin -> run of bins of one octave line (run_start's inverse), per size class
+    const std::vector<int32_t> &rs = (*derived)[2 * W].run_start;
+    std::vector<uint16_t> rob((size_t)((h.blocksizes[W] / 2 + 7) & ~7), 0);
+    for (size_t r = 0; r + 1 < rs.size(); r++)
+      for (int i = rs[r]; i < rs[r + 1]; i++) rob[(size_t)i] = (uint16_t)r;
+    while (image->size() & 15) image->push_back(0);
+    derived_off->push_back((uint32_t)image->size());
+    const unsigned char *a = (const unsigned char *)rob.data();
+    image->insert(image->end(), a, a + 2 * rob.size());
   }
   while (image->size() & 15) image->push_back(0);
   return VAMD_OK;
@@ -647,6 +665,7 @@ inline void bind_params(const std::vector<unsigned char> &image, const std::vect
     P.fix_i2 = d.fix_i2;
     P.run_start = (const int *)(base + derived_off[2 * p]);
     P.nruns = (int)d.run_start.size() - 1;
+    P.run_of_bin = (const unsigned short *)(base + derived_off[37 + (p >> 1)]);
     P.seed_span = (const int *)(base + derived_off[2 * p + 1]);
     P.runs = (const int *)(base + derived_off[8 + 2 * p]);
     P.curves64 = (const float *)(base + derived_off[8 + 2 * p + 1]);

@@ -144,7 +144,9 @@ __global__ __launch_bounds__(64 * VAMD_XF_WAVES) void k_transform(XformP G, int 
                                                                  float *__restrict__ mdct_raw,
                                                                  float *__restrict__ logmdct,
                                                                  float *__restrict__ logfft,
-                                                                 float *__restrict__ local_ampmax) {
+                                                                 float *__restrict__ local_ampmax,
+                                                                 const unsigned short *__restrict__ run_of_bin, int nruns,
+                                                                 int nrp, float *__restrict__ peaks) {
   const XformLds L = stage_transform_tables<LOGN>(G);
   const XformP &P = L.P;
   const int n = LOGN ? (1 << LOGN) : P.n, n2 = n >> 1, nw = blockDim.x >> 6;
@@ -160,6 +162,8 @@ __global__ __launch_bounds__(64 * VAMD_XF_WAVES) void k_transform(XformP G, int 
   // conditional one that is not taken -- makes the wait there a wait for everything outstanding, the stores of the
   // previous block's spectra included.
   int lW = 0, nW = 0;
+  I2 rid[VAMD_XF_QPS(LOGN)];  // which run of bins each of this lane's bins belongs to: the same for every block
+  if (peaks) xf_run_ids<LOGN>(P, run_of_bin, rid, tm);
   if (cb < ncb) {
     const long blk = (long)((unsigned)cb / (unsigned)ch);
     lW = d_lW(d, blk), nW = d_nW(d, blk);
@@ -173,7 +177,11 @@ __global__ __launch_bounds__(64 * VAMD_XF_WAVES) void k_transform(XformP G, int 
       pcm_fetch(tile, pcm + (cb + cstride) * n, n, tm);
     }
     float raw;
-    const float amp = transform_block<LOGN>(P, L.A, L.B, mdct_raw + cb * n2, logmdct ? logmdct + cb * n2 : nullptr, logfft + cb * n2, pc, tm, &raw);
+    // (logfft goes out as what the tone stage reads of it -- its peak over each run of bins of one octave line, nrp
+    // floats per channel-block -- and in full only where a caller taps it)
+    const float amp = transform_block<LOGN>(P, L.A, L.B, mdct_raw + cb * n2, logmdct ? logmdct + cb * n2 : nullptr,
+                                            logfft ? logfft + cb * n2 : nullptr, pc, tm, &raw, rid, run_of_bin, nruns,
+                                            peaks ? peaks + cb * nrp : nullptr);
     if (LANE == 0) {
       local_ampmax[cb] = amp;
       const bool bad = raw > VAMD_INPUT_LIMIT_DB;  // outside the input domain: a non-finite or absurdly large sample
@@ -317,8 +325,8 @@ __global__ void k_ampmax_streams_mixed(int ch, long nstreams, const long long *_
 
 // stage 3: _vp_tonemask, in three launches (k_tone.h).  nlp = octave lines padded to 16.
 template <int LP>
-__global__ __launch_bounds__(64) void k_tone_seed(PsyP P0, PsyP P1, DescP d, int ch, int nlp,
-                                                  const float *__restrict__ logfft,
+__global__ __launch_bounds__(64) void k_tone_seed(PsyP P0, PsyP P1, DescP d, int ch, int nlp, int nrp,
+                                                  const float *__restrict__ peaks,
                                                   const float *__restrict__ local_ampmax,
                                                   const float *__restrict__ ampmax_glob, float *__restrict__ seed_g) {
   const long cb = blockIdx.x;
@@ -329,7 +337,7 @@ __global__ __launch_bounds__(64) void k_tone_seed(PsyP P0, PsyP P1, DescP d, int
   (void)n2;
   PhaseClock pc;
   pc.start(d.dbg ? d.dbg + 32 : nullptr);
-  tone_seed_block<LP>(P, logfft + cb * n2, ampmax_glob[blk], local_ampmax[cb], seed, pc);
+  tone_seed_block<LP>(P, peaks + cb * nrp, ampmax_glob[blk], local_ampmax[cb], seed, pc);
   WAVE_FOR(i, nlp) seed_g[cb * nlp + i] = i < nl ? seed[i] : VAMD_NEGINF;
   pc.flush();
 }
@@ -1097,12 +1105,16 @@ int vamd_posts(const vamd_ctx *c, int W) { return (c && (W == 0 || W == 1)) ? c-
 
 struct WsPlan {
   float *mdct_raw, *logmdct, *logfft, *noise, *tone, *mdct, *local, *ampin, *ampglob, *seed;
+  float *peaks;  // [channel-blocks][run_peaks_stride]: logfft's peak per run of bins, or null below the psy level
   unsigned short *surv;
   int32_t *nsurv;
   ilog_t *ilogmask;  // a byte per bin, workspace only (the int32 tap is widened from it: k_widen_ilog)
   int32_t *iwork, *posts, *post_valid, *nonzero;
   unsigned char *status;
 };
+
+// floats per channel-block of the run-peak hand-over (k_transform -> k_tone_seed), rows 16-byte aligned
+static int run_peaks_stride(const PsyP &P) { return (P.nruns + 3) & ~3; }
 
 // Resolve every inter-stage tensor: the caller's buffer when given, otherwise workspace.
 static int plan(vamd_ctx *c, int W, long nb, const vamd_batch_io *io, int level, WsPlan *p) {
@@ -1119,7 +1131,11 @@ static int plan(vamd_ctx *c, int W, long nb, const vamd_batch_io *io, int level,
   }
   PICK(mdct_raw, io ? io->mdct_raw : nullptr, WS_MDCT_RAW, per);
   p->logmdct = io ? io->logmdct : nullptr;  // a tap only: the later stages form it from mdct_raw
-  PICK(logfft, io ? io->logfft : nullptr, WS_LOGFFT, per);
+  p->logfft = io ? io->logfft : nullptr;  // a tap only: the tone stage reads the run peaks
+  p->peaks = nullptr;
+  if (level >= VAMD_LEVEL_PSY) {
+    PICK(peaks, (float *)nullptr, WS_LOGFFT, (size_t)nb * ch * run_peaks_stride(c->B.psy[2 * W]) * 4);
+  }
   PICK(local, io ? io->local_ampmax : nullptr, WS_LOCAL, (size_t)nb * ch * 4);
   PICK(ampglob, io ? io->ampmax_out : nullptr, WS_AMPGLOB, (size_t)nb * 4);
   PICK(ampin, (float *)nullptr, WS_AMPIN, (size_t)nb * 4);
@@ -1276,10 +1292,12 @@ static void launch_transform(vamd_ctx *c, BatchRun *R) {
   const int waves = xf_waves(c, X);
   const long groups = ((long)gcb + waves - 1) / waves;
   const unsigned grid = (unsigned)(groups < c->num_cus ? groups : c->num_cus);
+  const PsyP &PS = c->B.psy[2 * R->W];  // (the runs are the size class's: vamd_bind checks both block types share them)
   prof_mark(c, VAMD_ST_BEGIN);
 #define VAMD_GO(LOGN)                                                                                                      \
   hipLaunchKernelGGL(k_transform<LOGN>, dim3(grid), dim3(64 * waves), transform_lds_bytes(X, waves), c->stream, X, R->W, R->d, \
-                     ch, (long)gcb, R->io->pcm, R->p.mdct_raw, R->p.logmdct, R->p.logfft, R->p.local)
+                     ch, (long)gcb, R->io->pcm, R->p.mdct_raw, R->p.logmdct, R->p.logfft, R->p.local, PS.run_of_bin, PS.nruns,    \
+                     run_peaks_stride(PS), R->p.peaks)
   switch (fixed_logn(X)) {
     case 8: VAMD_GO(8); break;
     case 9: VAMD_GO(9); break;
@@ -1412,11 +1430,11 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_
       const int nlp = (nl + 15) & ~15;
       const size_t seed_lds = (size_t)(seed_pad_lo(P0.eighth_octave_lines) + nlp + seed_pad_hi(P0.eighth_octave_lines)) * 4;
       if (P0.eighth_octave_lines == 8 && P1.eighth_octave_lines == 8)
-        hipLaunchKernelGGL(k_tone_seed<8>, dim3(gcb), dim3(64), seed_lds, s, P0, P1, d, ch, nlp, p.logfft, p.local, p.ampglob,
-                           p.seed);
+        hipLaunchKernelGGL(k_tone_seed<8>, dim3(gcb), dim3(64), seed_lds, s, P0, P1, d, ch, nlp, run_peaks_stride(P0), p.peaks, p.local,
+                           p.ampglob, p.seed);
       else
-        hipLaunchKernelGGL(k_tone_seed<0>, dim3(gcb), dim3(64), seed_lds, s, P0, P1, d, ch, nlp, p.logfft, p.local, p.ampglob,
-                           p.seed);
+        hipLaunchKernelGGL(k_tone_seed<0>, dim3(gcb), dim3(64), seed_lds, s, P0, P1, d, ch, nlp, run_peaks_stride(P0), p.peaks, p.local,
+                           p.ampglob, p.seed);
       // a lane per block for batches, a wave per block (the walk in 64 chunks) where that would leave the GPU to a
       // handful of lanes walking ~800 lines each: the per-block entry points, the batcher's small batches
       static const long wave_max_cb = getenv("VAMD_CHASE_WAVE_MAX") ? atol(getenv("VAMD_CHASE_WAVE_MAX")) : 32768;

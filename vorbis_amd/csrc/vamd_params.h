@@ -55,6 +55,7 @@ struct PsyP {
   int fix_i1, fix_i2;        // same for the fixed-window pass (lib/psy.c:660-703)
   const int *run_start;      // [nruns+1] starts of runs of equal octave[] (lib/psy.c:429-435)
   int nruns;
+  const unsigned short *run_of_bin;  // [n] the run a bin belongs to (the size class's: both block types share the runs)
   const int *runs;           // [nruns][4] RunRec (vamd_derive.h)
   const float *curves64;     // [17][8] tone-curve rows of 56 points, `curve_stride` floats apart
   int curve_stride;          // 64 in HBM (256-byte rows); 60 for an LDS copy (rows staggered over the banks)

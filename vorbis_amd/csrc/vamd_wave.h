@@ -300,4 +300,14 @@ VAMD_DEV int dBquant(float x) {
   return i;
 }
 
+// The peak of logfft over one run of bins [s, e) that share an octave line (seed_loop's inner maximum,
+// lib/psy.c:429-440), as the reference compares: `if (f[i] > max) max = f[i]`.  Formed by the transform stage while
+// the block's logfft is still in LDS, and handed to the tone stage a float per run instead of a float per bin.
+VAMD_DEV float run_peak(const float *fft, int s, int e) {
+  float mx = fft[s];
+  for (int i = s + 1; i < e; i++)
+    if (fft[i] > mx) mx = fft[i];
+  return mx;
+}
+
 }  // namespace vamd
