@@ -1438,13 +1438,12 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_
       // a lane per block for batches, a wave per block (the walk in 64 chunks) where that would leave the GPU to a
       // handful of lanes walking ~800 lines each: the per-block entry points, the batcher's small batches
       static const long wave_max_cb = getenv("VAMD_CHASE_WAVE_MAX") ? atol(getenv("VAMD_CHASE_WAVE_MAX")) : 32768;
-      static const size_t chase_pad = getenv("VAMD_CHASE_LDS_PAD") ? (size_t)atoi(getenv("VAMD_CHASE_LDS_PAD")) : 0;  // (experiment: occupancy)
       if ((long)gcb <= wave_max_cb && P0.eighth_octave_lines <= 16 && nl <= 2048)
         hipLaunchKernelGGL(k_tone_chase_wave, dim3(gcb), dim3(64), (size_t)nlp * 4 + (size_t)VAMD_RING * 64 * 8, s,
                            P0.eighth_octave_lines, nl, nlp, d, p.seed, p.surv, p.nsurv);
       else
         hipLaunchKernelGGL(k_tone_chase, dim3((gcb + VAMD_CHASE_LANES - 1) / VAMD_CHASE_LANES), dim3(VAMD_CHASE_LANES),
-                           (size_t)VAMD_RING * VAMD_CHASE_LANES * 8 + chase_pad, s,
+                           (size_t)VAMD_RING * VAMD_CHASE_LANES * 8, s,
                            P0.eighth_octave_lines, nl, nlp, (long)gcb, d, p.seed, p.surv, p.nsurv);
       if (!fold_in_floor)
         hipLaunchKernelGGL(k_tone_fold, dim3(gcb), dim3(64), (size_t)(nlp + (P0.ngroups > P1.ngroups ? P0.ngroups : P1.ngroups)) * 4, s, P0, P1, d, ch, nlp, p.seed, p.surv,
