@@ -50,13 +50,14 @@ def stage_bytes(stage, n, ch=2):
     mixed-size workload adds its size classes up (StreamRunner.stage_bytes_total)."""
     n2 = n // 2
     nlp = {256: 592, 2048: 784}.get(n, n2)       # octave lines of the 44.1 kHz psy setups, padded to 16 (SURVEY 8)
+    nrp = {256: 100, 2048: 316}.get(n, n2 // 3)  # runs of bins sharing an octave line: logfft travels as one peak per run
     per_ch = {
-        "transform": 4 * n + 2 * 4 * n2 + 5,                      # pcm in; spectrum + logfft out; local ampmax, status
+        "transform": 4 * n + 4 * n2 + 4 * nrp + 5,                # pcm in; spectrum + run peaks out; local ampmax, status
         "ampmax": 6,
         "noisemask": 4 * n2 + 4 * n2,                             # spectrum in, noise curve out
-        "tonemask": 4 * n2 + 4 * nlp + 4 * nlp + 2 * nlp + 12,    # seed: logfft in, seed lines out; chase: lines in, survivors out
-        "floor": 4 * n2 + 4 * n2 + 4 * nlp + 2 * nlp + 4 * n2 + 4 * n2 + 2 * n2 + 136,  # noise, spectrum, lines, survivors in; mixed spectrum, mask, 16-bit curve, posts out
-        "couple": 4 * n2 + 2 * n2 + 4 * n2 + 4,                   # mixed spectrum + curve in, residue out
+        "tonemask": 4 * nrp + 8 + 4 * nlp + 4 * nlp + 2 * nlp + 4,  # seed: run peaks in, seed lines out; chase: lines in, survivors out
+        "floor": 4 * n2 + 4 * n2 + 4 * nlp + 2 * nlp + 4 * n2 + 4 * n2 + n2 + 136,  # noise, spectrum, lines, survivors in; mixed spectrum, mask, byte curve, posts out
+        "couple": 4 * n2 + n2 + 4 * n2 + 4,                       # mixed spectrum + byte curve in, residue out
     }
     return per_ch.get(stage, 12288) * ch
 
@@ -122,21 +123,53 @@ def parse(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only for the CPU rehearsal of the rank logic)")
+    ap.add_argument("--runner", default=None,
+                    help="test aid: 'module:Class' of a runner that replaces the GPU runner (the CPU rehearsal of the rank logic "
+                         "names a stub that does no analysis; the line then carries \"runner\" and is not a measurement)")
     a = ap.parse_args(argv)
     if a.setup is None:
         a.setup = "44k_stereo_q9" if a.workload == "c5" else "44k_stereo_q4"
     return a
 
 
+def host_cpus():
+    """What this process may use: (hardware threads the OS shows, threads in the affinity mask, CPUs the cgroup's
+    quota allows or None).  A container is often held to a CPU-time quota far below the threads it sees -- round 3's
+    "771 blocks/s per core at 128 threads against 7 769 on one" was 128 threads time-slicing a 16-CPU quota."""
+    seen = os.cpu_count() or 1
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except Exception:
+        aff = seen
+    quota = None
+    try:  # cgroup v2
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:  # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    return seen, aff, quota
+
+
 def cpu_baseline(setup_name, seconds):
-    """Reference libvorbis (oracle/_ref, unmodified sources) -- or the C port if the prebuilt
-    reference is absent -- timed on this box's host cores, one encoder state per thread, on a
-    bounded sample of the same white-noise workload.  Reported, not a target."""
+    """Reference libvorbis (oracle/_ref, unmodified sources) -- or the C port if the prebuilt reference is absent --
+    timed on this box's host cores on a bounded sample of the same white-noise workload: one thread alone, then two
+    legs over all the CPUs this process may use -- threads in this process (one encoder state each) and one PROCESS
+    per CPU (tools/cpu_ref_worker.py; the reference's per-block arena, lib/block.c:102-146, mallocs and frees several
+    KB per block, and separate address spaces take allocator locks out of the picture).  The better leg is the figure
+    reported, with its scaling efficiency against the single thread.  Reported, not a target."""
+    import subprocess
     from tests import checker
     from oracle import ref
     ch, rate, q = checker.SETUPS[setup_name]
-    cores = os.cpu_count() or 1
-    nthreads = min(cores, 256)
+    seen, aff, quota = host_cpus()
+    usable = max(1, min(aff, int(quota + 0.5) if quota else aff))
     sample_blocks = 256
     rng = np.random.default_rng(99)
     pcm = (rng.random((sample_blocks, ch, 2048), dtype=np.float32) - 0.5).astype(np.float32)
@@ -148,45 +181,61 @@ def cpu_baseline(setup_name, seconds):
         kind = "port"
         blob = np.fromfile(os.path.join(ROOT, "vorbis_amd", "data", "setup_%s.bin" % setup_name), dtype=np.uint8)
         make = lambda: port.PortEncoder(blob)  # noqa: E731
+    nthreads = min(usable, 256)
     encs = [make() for _ in range(nthreads)]
-    # one thread on an otherwise idle host first: what a core does unshared (the threaded figure below divides
-    # the cores' caches, memory bandwidth and -- past the physical core count -- their SMT siblings)
+    # one thread on an otherwise idle host first: what a core does unshared
     t1 = time.time()
     n1 = 0
-    while time.time() - t1 < min(2.0, seconds / 4):
+    while time.time() - t1 < min(2.0, seconds / 5):
         encs[0].time_dsp(pcm, 1)
         n1 += sample_blocks
     single = n1 / (time.time() - t1)
-    # all hardware threads, and one thread per physical core (SMT siblings and memory bandwidth make the first the
-    # slower one on some hosts): the better of the two is the figure reported
+    leg_s = (seconds - min(2.0, seconds / 5)) / 2
     legs = []
-    for nt in sorted({nthreads, max(1, nthreads // 2)}):
-        done = [0] * nt
-        cpu_time = [0.0] * nt
-        deadline = time.time() + seconds / 2
+    # leg 1: threads of this process (ctypes releases the GIL inside the library)
+    done = [0] * nthreads
+    deadline = time.time() + leg_s
 
-        def work(i, done=done, cpu_time=cpu_time, deadline=deadline):
-            e = encs[i]
-            while time.time() < deadline:
-                cpu_time[i] += e.time_dsp(pcm, 1)
-                done[i] += sample_blocks
+    def work(i):
+        e = encs[i]
+        while time.time() < deadline:
+            e.time_dsp(pcm, 1)
+            done[i] += sample_blocks
 
-        t0 = time.time()
-        th = [threading.Thread(target=work, args=(i,)) for i in range(nt)]
-        [t.start() for t in th]
-        [t.join() for t in th]
-        wall = time.time() - t0
-        legs.append({"threads": nt, "value": sum(done) / wall, "blocks": sum(done), "wall": wall,
-                     "per_core": sum(done) / max(sum(cpu_time), 1e-9)})
+    t0 = time.time()
+    c0 = time.process_time()
+    th = [threading.Thread(target=work, args=(i,)) for i in range(nthreads)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    wall = time.time() - t0
+    legs.append({"kind": "threads", "workers": nthreads, "value": sum(done) / wall, "blocks": sum(done), "wall": wall,
+                 "cpu_seconds": time.process_time() - c0})
+    # leg 2: one process per usable CPU
+    try:
+        start = time.time() + 2.5   # every worker is up (numpy + ctypes only) and waiting by then
+        procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "cpu_ref_worker.py"), setup_name, repr(start),
+                                   repr(leg_s)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+                 for _ in range(usable)]
+        outs = [p.communicate(timeout=leg_s + 60)[0].split() for p in procs]
+        blocks = sum(int(o[0]) for o in outs if len(o) == 3)
+        walls = [float(o[1]) for o in outs if len(o) == 3]
+        cpus = sum(float(o[2]) for o in outs if len(o) == 3)
+        if walls:
+            legs.append({"kind": "processes", "workers": len(walls), "value": blocks / max(walls), "blocks": blocks,
+                         "wall": max(walls), "cpu_seconds": cpus})
+    except Exception as e:  # the thread leg stands on its own
+        legs.append({"kind": "processes", "workers": 0, "value": 0.0, "blocks": 0, "wall": 0.0, "cpu_seconds": 0.0, "error": repr(e)})
     best = max(legs, key=lambda g: g["value"])
     return {
-        "value": best["value"], "unit": "stereo blocks/s", "cores": best["threads"], "nproc": cores, "kind": kind,
-        "per_core": best["per_core"], "single_thread_value": single,
-        "legs": [{"threads": g["threads"], "value": g["value"]} for g in legs],
-        "sample": "%d threads x repeated passes over %d seeded white-noise stereo 2048-blocks for %.0f s wall "
-                  "(%d blocks total); window+MDCT+FFT+psy+floor1 fit/encode+couple/quantise of "
-                  "mapping0_forward (the part the GPU path computes; residue VQ/Huffman excluded)"
-                  % (best["threads"], sample_blocks, best["wall"], best["blocks"]),
+        "value": best["value"], "unit": "stereo blocks/s", "cores": best["workers"], "kind": kind, "leg": best["kind"],
+        "single_thread_value": single, "scaling_efficiency": best["value"] / (single * best["workers"]),
+        "per_cpu_second": best["blocks"] / max(best["cpu_seconds"], 1e-9),
+        "host": {"hardware_threads": seen, "affinity": aff, "cgroup_cpu_quota": quota, "usable_cpus": usable},
+        "legs": [{"kind": g["kind"], "workers": g["workers"], "value": g["value"],
+                  "cpus_busy": g["cpu_seconds"] / max(g["wall"], 1e-9)} for g in legs],
+        "sample": "%d %s x repeated passes over seeded white-noise stereo 2048-blocks for %.0f s wall (%d blocks total); "
+                  "window+MDCT+FFT+psy+floor1 fit/encode+couple/quantise of mapping0_forward (the part the GPU path "
+                  "computes; residue VQ/Huffman excluded)" % (best["workers"], best["kind"], best["wall"], best["blocks"]),
     }
 
 
@@ -444,11 +493,39 @@ class StreamRunner:
                                                                                self.plan.nblocks[0], self.plan.nblocks[1]))
 
 
+def spawn_ranks(a, argv):
+    """`python bench.py --gpus N` with no process group in the environment: launch the N ranks ourselves, exactly as
+    the driver does (torch.distributed.run, one process per GPU, rendezvous on 127.0.0.1), and hand back their exit
+    code.  Rank 0 of the children prints the line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:  # a free port for the rendezvous
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    return subprocess.call(cmd, env=env)
+
+
 def main(argv=None, make_runner=None):
     """`make_runner(a, blob, dev, rank, world)` replaces the GPU runner; only the CPU rehearsal of the rank logic
-    (tests/test_abi_and_host.py, gloo, world size 2) passes one."""
+    (tests/test_abi_and_host.py, gloo, world size 2) passes one (or names one with --runner)."""
+    argv = list(sys.argv[1:] if argv is None else argv)
     a = parse(argv)
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and a.gpus > 1:
+        return spawn_ranks(a, argv)           # --gpus N means N ranks: launch them
+    if int(env_world or 1) != a.gpus:
+        print("bench: --gpus %d but WORLD_SIZE=%s: launch with --nproc-per-node %d (or leave WORLD_SIZE unset and "
+              "bench.py starts the ranks itself)" % (a.gpus, env_world, a.gpus), file=sys.stderr)
+        return 2
+    if a.runner and make_runner is None:
+        import importlib
+        mod, _, cls = a.runner.partition(":")
+        make_runner = getattr(importlib.import_module(mod), cls)
     rank, world, dev = sharding.init_from_env(a.backend, use_cuda=make_runner is None)
+    ranks_seen = sharding.sum_over_ranks(1, dev)   # an all-reduce of 1 over the group the job really has
     import vorbis_amd
     # rank 0 owns the setup blob; everyone else receives it over RCCL -- the job's only collective besides timing
     blob = sharding.broadcast_blob(vorbis_amd.default_setup_blob(a.setup) if rank == 0 else None, dev)
@@ -503,7 +580,8 @@ def main(argv=None, make_runner=None):
         }
         line = {
             "metric": "audio blocks/s (2048-sample MDCT+psy) @1/2/4/8 GPU; % HBM roofline",
-            "value": value, "unit": R.unit_name, "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "value": value, "unit": R.unit_name, "n_gpus": world, "world": world, "rccl_ranks_seen": ranks_seen,
+            "backend": (a.backend if world > 1 else None), "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
@@ -512,6 +590,8 @@ def main(argv=None, make_runner=None):
             },
             "roofline": roof,
         }
+        if a.runner:
+            line["runner"] = a.runner            # not the GPU runner: a rehearsal, not a measurement
         if parity is not None:
             line["parity_sample"] = parity
             if parity.get("mismatches"):

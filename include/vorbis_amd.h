@@ -85,6 +85,12 @@ int vamd_stage_ms(vamd_ctx *ctx, float *ms, int nstages, int *runs);
  * the slots accumulated so far are copied out first. */
 int vamd_debug_cycles(vamd_ctx *ctx, int enable, unsigned long long *out80);
 
+/* Calibration aid for counter passes (no libvorbis counterpart): copy `bytes` (a multiple of 16) from `src` to `dst`
+ * (device pointers) with the library's own kernel k_calib_copy, 16 bytes per lane -- exactly `bytes` read and
+ * `bytes` written under a name a profile can find, so that FETCH_SIZE / WRITE_SIZE are scaled by a measured factor
+ * (tools/prof_run.py, tools/make_profiles.py) instead of an assumed one. */
+int vamd_calib_copy(vamd_ctx *ctx, void *dst, const void *src, size_t bytes);
+
 int vamd_channels(const vamd_ctx *ctx);
 int vamd_blocksize(const vamd_ctx *ctx, int W);
 int vamd_posts(const vamd_ctx *ctx, int W);

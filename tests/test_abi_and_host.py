@@ -200,32 +200,10 @@ def test_two_rank_sharding_and_table_broadcast_gloo(tmp_path):
 # timed region, max-over-ranks, the parity sample's sums, JSON assembly on rank 0) with only the GPU work replaced:
 # the stub runner lives HERE, bench.py has no dry-run path of its own.
 BENCH_WORKER = r"""
-import os, sys, time, hashlib
+import sys
 sys.path.insert(0, @ROOT@)
-import numpy as np
 import bench
-
-class StubRunner:
-    def __init__(self, a, blob, dev, rank, world):
-        from vorbis_amd import sharding
-        ref = np.fromfile(os.path.join(@ROOT@, "vorbis_amd", "data", "setup_%s.bin" % a.setup), dtype=np.uint8)
-        assert np.array_equal(np.asarray(blob), ref), "rank %d received a different setup blob" % rank
-        nb = a.blocks or 131072
-        self.lo, self.hi = sharding.shard_range(nb * world, rank, world)
-        self.units, self.unit_name, self.rank, self.steps_run = self.hi - self.lo, "stereo blocks/s", rank, 0
-    def step(self):
-        time.sleep(0.01 * (1 + self.rank))   # rank 1 is the slow one: the reported time must be ITS time
-        self.steps_run += 1
-    def sync(self): pass
-    def timed_begin(self): self.t0 = self.steps_run
-    def timed_end(self): self.timed = self.steps_run - self.t0
-    def stage_ms(self, steps):
-        assert self.timed == steps
-        return {"transform": 1.0, "noisemask": 2.0}
-    def parity_sample(self, count): return count, 0, "stub"
-    def stage_bytes_total(self, stage): return bench.stage_bytes(stage, 2048) * self.units
-    def workload_text(self): return "rank-logic rehearsal (no GPU work)"
-
+from tests.stub_runner import StubRunner
 rc = bench.main(["--gpus", "2", "--steps", "5", "--warmup", "1", "--backend", "gloo", "--blocks", "1000"], make_runner=StubRunner)
 sys.exit(rc)
 """
@@ -246,3 +224,35 @@ def test_bench_distributed_branch_runs_under_gloo(tmp_path):
     assert line["parity_sample"] == {"blocks": 256, "mismatches": 0, "checker": "stub",
                                      "compared": line["parity_sample"]["compared"]}
     assert "roofline" in line and line["roofline"]["kernels_ms_per_step"] == {"transform": 1.0, "noisemask": 2.0}
+
+
+def _check_rehearsal_line(stdout):
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout          # rank 0 alone prints, one line
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["world"] == 2 and line["rccl_ranks_seen"] == 2 and line["backend"] == "gloo"
+    assert line["config"]["blocks_per_gpu"] == 1000
+    assert line["ms_per_step"] >= 19.0
+    return line
+
+
+def test_bench_gpus_flag_launches_the_ranks_itself():
+    """`python bench.py --gpus 2` as a plain command, no launcher and no WORLD_SIZE around it: bench.py starts the two
+    ranks itself (the flag used to be parsed and ignored).  gloo and a stub runner, since this box has no
+    GPU; everything else -- the spawn, the rendezvous, the broadcast, the reductions, the line -- is the shipped code."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "5",
+                        "--warmup", "1", "--blocks", "1000", "--runner", "tests.stub_runner:StubRunner"],
+                       env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = _check_rehearsal_line(r.stdout)
+    assert line["runner"] == "tests.stub_runner:StubRunner"     # a rehearsal says that it is one
+
+
+def test_bench_gpus_flag_must_agree_with_the_launcher():
+    """--gpus 4 inside a world of 2 is a contradiction, not a run: exit code 2, no line."""
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29655")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--backend", "gloo",
+                        "--runner", "tests.stub_runner:StubRunner"], env=env, capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert r.returncode == 2 and "WORLD_SIZE" in r.stderr and not r.stdout.strip()

@@ -6,7 +6,7 @@ summaries under profiles/:  rNN_kernel_trace_stats.txt, rNN_pmc_hbm_traffic.txt,
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "profile")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
 sys.path.insert(0, ROOT)
 import bench as bench_mod  # noqa: E402  (source_hash: the profile is stamped with the sources it was taken from)
 NB_PMC = int(sys.argv[2]) if len(sys.argv) > 2 else 131072  # tools/prof_run.py <NB> 1
@@ -41,36 +41,43 @@ with open(os.path.join(ROOT, "profiles", TAG + "_kernel_trace_stats.txt"), "w") 
     f.write("# bench.py's own line from the same run: %.2f M stereo blocks/s, %.2f ms/step; its HIP-event figure for\n"
             % (bench["value"] / 1e6, bench["ms_per_step"]))
     f.write("# the dominant kernel (%s): %.3f ms per launch.\n" % (bench["roofline"]["dominant_kernel"]["name"], bench["roofline"]["dominant_kernel"]["ms"]))
-    f.write(kt[0].replace("total_ns", "total_us").replace("avg_ns", "avg_us") + "\n")
+    f.write(kt[0] + "\n")
     f.write("\n".join(kt[1:]) + "\n")
 
 fl, fetch = table(os.path.join(SRC, "pmc_FETCH_SIZE.txt"))
 wl, write = table(os.path.join(SRC, "pmc_WRITE_SIZE.txt"))
-cal = [k for k in fetch if k.startswith("void at::native::vectorized_elementwise_kernel")][0]
-fcal, wcal = fetch[cal] / (1 << 20), write[cal] / (1 << 20)
+# calibration on the library's own named kernel: k_calib_copy moves exactly 1 GiB in and 1 GiB out (tools/prof_run.py), so
+# true bytes / counted KiB are the factors -- derived here, not assumed (round 3 picked the first torch elementwise kernel,
+# which was the random fill of the input, and got the right factors by accident)
+CAL_BYTES = float(1 << 30)
+fcal, wcal = fetch["k_calib_copy"] * 1024 / CAL_BYTES, write["k_calib_copy"] * 1024 / CAL_BYTES   # counted / true
+FSCALE, WSCALE = 1.0 / fcal, 1.0 / wcal                                                            # true bytes per counted byte
+assert 1.8 < FSCALE < 2.2 and 0.9 < WSCALE < 1.1, "calibration copy reads FETCH x%.3f WRITE x%.3f: not the gfx950 pattern" % (FSCALE, WSCALE)
 with open(os.path.join(ROOT, "profiles", TAG + "_pmc_hbm_traffic.txt"), "w") as f:
     f.write("# rocprofv3 --pmc FETCH_SIZE   (its own pass)   and   rocprofv3 --pmc WRITE_SIZE   (its own pass)\n")
     f.write("#   -- python tools/prof_run.py %d 1      (one full-analysis step over %d stereo blocks, one\n" % (NB_PMC, NB_PMC))
-    f.write("#      mdct-only call over %d frames, one 1 GiB torch copy as the calibration kernel)\n" % (2 * NB_PMC))
+    f.write("#      mdct-only call over %d frames, one 1 GiB copy by the library's k_calib_copy as the calibration kernel)\n" % (2 * NB_PMC))
     f.write("# source hash %s\n" % bench_mod.source_hash())
-    f.write("# Units: KiB per dispatch.  Calibration (vectorized_elementwise_kernel = b.copy_(a), exactly 1 GiB read\n")
-    f.write("# and 1 GiB written): FETCH_SIZE reads %.3f of the true bytes (the gfx950 half-count of\n" % fcal)
-    f.write("# MI355X_MICROARCH.md \"HBM\"), WRITE_SIZE reads %.3f.  Corrected HBM bytes therefore\n" % wcal)
-    f.write("# = 2 x FETCH_SIZE + 1 x WRITE_SIZE.\n\n## FETCH_SIZE\n" + "\n".join(fl) + "\n\n## WRITE_SIZE\n" + "\n".join(wl) + "\n")
+    f.write("# Units: KiB per dispatch.  Calibration (k_calib_copy: exactly 1 GiB read and 1 GiB written, 16 bytes per lane):\n")
+    f.write("# FETCH_SIZE counts %.4f of the true bytes read (the gfx950 half-count of MI355X_MICROARCH.md \"HBM\"),\n" % fcal)
+    f.write("# WRITE_SIZE counts %.4f of the true bytes written.  Corrected HBM bytes = %.4f x FETCH_SIZE + %.4f x WRITE_SIZE\n" % (wcal, FSCALE, WSCALE))
+    f.write("# (the factors of THIS run's calibration rows, applied below and in %s_pmc_traffic.json).\n\n## FETCH_SIZE\n" % TAG + "\n".join(fl) + "\n\n## WRITE_SIZE\n" + "\n".join(wl) + "\n")
 
 per = {}
 for k in fetch:
-    if k.startswith("k_") and k not in ("k_mdct_only", "k_ampmax"):
-        per[k] = {"read_B_per_stereo_block": 2 * fetch[k] * 1024 / NB_PMC,
-                  "write_B_per_stereo_block": write[k] * 1024 / NB_PMC}
+    if k.startswith("k_") and k not in ("k_mdct_only", "k_ampmax", "k_calib_copy"):
+        per[k] = {"read_B_per_stereo_block": FSCALE * fetch[k] * 1024 / NB_PMC,
+                  "write_B_per_stereo_block": WSCALE * write[k] * 1024 / NB_PMC}
 out = {
     "source_hash": bench_mod.source_hash(),
     "source": "profiles/%s_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, "
-              "%d stereo blocks; FETCH_SIZE x2 per calibration)" % (TAG, NB_PMC),
+              "%d stereo blocks; FETCH_SIZE x%.4f, WRITE_SIZE x%.4f per the run's own k_calib_copy rows)" % (TAG, NB_PMC, FSCALE, WSCALE),
+    "calibration": {"kernel": "k_calib_copy", "true_bytes_each_way": int(CAL_BYTES), "fetch_counted_fraction": fcal,
+                    "write_counted_fraction": wcal},
     "workload": "c4",
     "per_kernel": per,
     "total_B_per_stereo_block": sum(v["read_B_per_stereo_block"] + v["write_B_per_stereo_block"] for v in per.values()),
-    "mdct_only_B_per_frame": (2 * fetch["k_mdct_only"] + write["k_mdct_only"]) * 1024 / (2 * NB_PMC),
+    "mdct_only_B_per_frame": (FSCALE * fetch["k_mdct_only"] + WSCALE * write["k_mdct_only"]) * 1024 / (2 * NB_PMC),
 }
 json.dump(out, open(os.path.join(ROOT, "profiles", TAG + "_pmc_traffic.json"), "w"), indent=1)
 print("total B/stereo block %.0f, mdct-only B/frame %.0f" % (out["total_B_per_stereo_block"], out["mdct_only_B_per_frame"]))
@@ -82,8 +89,8 @@ if os.path.exists(c5):
         f.write("# %s\n" % b5["config"]["workload"])
         f.write("# bench.py's own line from the same run: %.2f M blocks/s, %.2f ms/step, parity sample %s\n"
                 % (b5["value"] / 1e6, b5["ms_per_step"], b5.get("parity_sample")))
-        f.write("# source hash %s\n" % bench_mod.source_hash())
-        f.write(open(c5).read())
+        f.write("# source hash %s.  Durations in microseconds (rocpd `top_kernels` view).\n" % bench_mod.source_hash())
+        f.write(open(c5).read().replace("total_ns", "total_us").replace("avg_ns", "avg_us"))
 
 # ---- C5: counter passes over one step of the mixed-size workload
 c5f = os.path.join(SRC, "pmc_c5_FETCH_SIZE.txt")
@@ -91,12 +98,14 @@ if os.path.exists(c5f):
     fl5, fetch5 = table(c5f)
     wl5, write5 = table(os.path.join(SRC, "pmc_c5_WRITE_SIZE.txt"))
     step = json.loads(open(os.path.join(SRC, "c5_step.json")).read().strip().splitlines()[-1])
-    calk = [k for k in fetch5 if k.startswith("void at::native::vectorized_elementwise_kernel")]
+    f5cal, w5cal = fetch5["k_calib_copy"] * 1024 / CAL_BYTES, write5["k_calib_copy"] * 1024 / CAL_BYTES
+    F5S, W5S = 1.0 / f5cal, 1.0 / w5cal
     with open(os.path.join(ROOT, "profiles", TAG + "_c5_pmc_hbm_traffic.txt"), "w") as f:
         f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python tools/prof_run_c5.py 1\n")
         f.write("# one step of bench.py --workload c5 after its warm-up: %d short + %d long stereo blocks planned on the device\n"
                 % (step["short_blocks"], step["long_blocks"]))
-        f.write("# Units: KiB per dispatch (average over the warm-up and the step: identical work).  Corrected HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE.\n")
+        f.write("# Units: KiB per dispatch (average over the warm-up and the step: identical work).  Corrected HBM bytes = %.4f x FETCH_SIZE + %.4f x WRITE_SIZE\n" % (F5S, W5S))
+        f.write("# (this run's k_calib_copy rows: 1 GiB each way counted as %.4f / %.4f of itself).\n" % (f5cal, w5cal))
         f.write("# source hash %s\n\n## FETCH_SIZE\n" % bench_mod.source_hash() + "\n".join(fl5) + "\n\n## WRITE_SIZE\n" + "\n".join(wl5) + "\n")
     per5 = {}
     with open(c5f) as fh:
@@ -116,11 +125,11 @@ if os.path.exists(c5f):
         return rows
     F5, W5 = table_full(c5f), table_full(os.path.join(SRC, "pmc_c5_WRITE_SIZE.txt"))
     for k in F5:
-        if k.startswith("k_"):
-            per5[k] = {"read_B_per_step": 2 * F5[k] * 1024, "write_B_per_step": W5.get(k, 0.0) * 1024}
+        if k.startswith("k_") and not k.startswith("k_calib_copy"):
+            per5[k] = {"read_B_per_step": F5S * F5[k] * 1024, "write_B_per_step": W5S * W5.get(k, 0.0) * 1024}
     out5 = {"source_hash": bench_mod.source_hash(), "workload": "c5", "short_blocks": step["short_blocks"], "long_blocks": step["long_blocks"],
             "alg_bytes_per_step": step["alg_bytes"],
-            "source": "profiles/%s_c5_pmc_hbm_traffic.txt (one step of bench.py --workload c5; FETCH_SIZE x2 per calibration)" % TAG,
+            "source": "profiles/%s_c5_pmc_hbm_traffic.txt (one step of bench.py --workload c5; FETCH_SIZE / WRITE_SIZE scaled by the run's own k_calib_copy rows)" % TAG,
             "per_kernel": per5, "total_B_per_step": sum(v["read_B_per_step"] + v["write_B_per_step"] for v in per5.values())}
     json.dump(out5, open(os.path.join(ROOT, "profiles", TAG + "_c5_pmc_traffic.json"), "w"), indent=1)
     print("c5: total B per step %.0f = %.2f x algorithmic" % (out5["total_B_per_step"], out5["total_B_per_step"] / step["alg_bytes"]))

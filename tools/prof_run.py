@@ -15,9 +15,10 @@ x = pcm.reshape(nb * 2, 2048)
 y = torch.empty((nb * 2, 1024), device="cuda")
 for _ in range(steps):
     an.mdct_forward(1, x, out=y)
-# calibration: a device-to-device copy of exactly 1 GiB read + 1 GiB written (float4 elementwise kernel)
+# calibration: exactly 1 GiB read + 1 GiB written by the library's own named kernel (k_calib_copy, 16 bytes per lane);
+# tools/make_profiles.py derives the FETCH_SIZE / WRITE_SIZE factors from ITS rows
 a = torch.empty(256 * 1024 * 1024, dtype=torch.float32, device="cuda").normal_()
 b = torch.empty_like(a)
 for _ in range(steps):
-    b.copy_(a)
+    an.calib_copy(b, a)
 torch.cuda.synchronize()

@@ -7,7 +7,7 @@ import sys
 def kernel_stats(db):
     con = sqlite3.connect(db)
     rows = con.execute("select name, total_calls, total_duration, average, percentage from top_kernels").fetchall()
-    print("%-46s %6s %14s %12s %7s" % ("kernel", "calls", "total_ns", "avg_ns", "pct"))
+    print("%-46s %6s %14s %12s %7s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
     for n, c, t, a, p in rows:
         print("%-46s %6d %14.0f %12.0f %6.2f%%" % (n.split("(")[0][:46], c, t, a, p))
     try:  # the `kernels` view of rocpd: one row per dispatch with its code-object resources

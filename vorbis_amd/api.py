@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = ["vamd_create", "vamd_destroy", "vamd_last_error", "vamd_set_
                     "vamd_plan_streams", "vamd_gather_blocks", "vamd_plan_fetch",
                     "vamd_batcher_create", "vamd_batcher_destroy", "vamd_batcher_attach", "vamd_batcher_detach",
                     "vamd_batcher_encode_block", "vamd_batcher_last_error", "vamd_batcher_stats", "vamd_batcher_context",
-                    "vamd_input_status"]
+                    "vamd_input_status", "vamd_calib_copy"]
 PACKETBLOBS = 15
 
 _vp = C.c_void_p
@@ -108,6 +108,7 @@ def load_library():
     L.vamd_analyze_block.argtypes = [_vp, C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _vp, _vp,
                                      _vp, _vp, _vp, _vp, C.POINTER(C.c_float)]
     L.vamd_debug_cycles.argtypes = [_vp, C.c_int, _vp]
+    L.vamd_calib_copy.argtypes = [_vp, _vp, _vp, C.c_size_t]
     L.vamd_analyze_stream_mixed.argtypes = [_vp, C.POINTER(_Desc), C.POINTER(_IO), C.POINTER(_Desc), C.POINTER(_IO), _vp,
                                             C.c_long, C.POINTER(C.c_float)]
     L.vamd_analyze_streams_mixed.argtypes = [_vp, C.POINTER(_Desc), C.POINTER(_IO), C.POINTER(_Desc), C.POINTER(_IO), _vp, _vp,
@@ -222,6 +223,12 @@ class Analyzer:
         out = np.zeros(80, dtype=np.uint64)
         self._check(self.L.vamd_debug_cycles(self.h, 1 if enable else 0, _vp(out.ctypes.data) if read else None))
         return out.reshape(5, 16)
+
+    def calib_copy(self, dst, src):
+        """vamd_calib_copy(): src -> dst (device tensors of equal byte size) with the library's named copy kernel."""
+        nbytes = src.numel() * src.element_size()
+        assert dst.numel() * dst.element_size() == nbytes
+        self._check(self.L.vamd_calib_copy(self.h, _vp(dst.data_ptr()), _vp(src.data_ptr()), nbytes))
 
     def reserve(self, W, max_blocks):
         self._check(self.L.vamd_reserve(self.h, W, max_blocks))

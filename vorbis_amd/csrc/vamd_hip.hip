@@ -138,8 +138,11 @@ __global__ __launch_bounds__(64 * VAMD_MD_WAVES) void k_mdct_only(XformP G, int 
 
 // stage 1: window + MDCT + FFT + logs, one wave per channel-block.  Instantiated per block size (LOGN =
 // log2 n; 0 = any size, read from the parameters).
+#ifndef VAMD_XF_VGPRS
+#define VAMD_XF_VGPRS 256
+#endif
 template <int LOGN>
-__global__ __launch_bounds__(64 * VAMD_XF_WAVES) void k_transform(XformP G, int W, DescP d, int ch, long ncb,
+__global__ __launch_bounds__(64 * VAMD_XF_WAVES) __attribute__((amdgpu_num_vgpr(VAMD_XF_VGPRS))) void k_transform(XformP G, int W, DescP d, int ch, long ncb,
                                                                  const float *__restrict__ pcm,
                                                                  float *__restrict__ mdct_raw,
                                                                  float *__restrict__ logmdct,
@@ -820,6 +823,11 @@ __global__ void k_gather_blocks(int ch, int n, long nb, const long long *__restr
   }
 }
 
+// calibration copy for counter passes (vamd_calib_copy): exactly 16 bytes in and 16 bytes out per lane-trip
+__global__ __launch_bounds__(256) void k_calib_copy(const F4 *__restrict__ src, F4 *__restrict__ dst, long n16) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
 struct DevBuf {
   void *p = nullptr;
   size_t bytes = 0;
@@ -1074,6 +1082,16 @@ int vamd_stage_ms(vamd_ctx *c, float *ms, int nstages, int *runs) {
   if (runs) *runs = c->prof_runs;
   c->ev_used = 0;
   c->prof_runs = 0;
+  return VAMD_OK;
+}
+
+int vamd_calib_copy(vamd_ctx *c, void *dst, const void *src, size_t bytes) {
+  DeviceGuard dev_guard(c);
+  if (!c) return VAMD_EINVAL;
+  if (!dst || !src || (bytes & 15) || (((uintptr_t)dst | (uintptr_t)src) & 15)) return fail(c, VAMD_EINVAL, "calibration copy: 16-byte aligned buffers and size");
+  if (bytes == 0) return VAMD_OK;
+  hipLaunchKernelGGL(k_calib_copy, dim3((unsigned)(c->num_cus * 16)), dim3(256), 0, c->stream, (const F4 *)src, (F4 *)dst, (long)(bytes / 16));
+  HIP_TRY(c, hipGetLastError());
   return VAMD_OK;
 }
 
