@@ -392,6 +392,9 @@ int vamd_batcher_encode_block(vamd_batcher *b, const float *const *pcm, int lW, 
 const char *vamd_batcher_last_error(const vamd_batcher *b);
 /* batches run, blocks carried, seconds spent inside the batched GPU calls (any pointer may be NULL) */
 void vamd_batcher_stats(vamd_batcher *b, long *batches, long *blocks, double *run_seconds);
+/* where the batches' time went, as text (diagnostics): gather / staging / GPU / hand-out / wake-up per batch, why gathers
+ * ended, batch-size histogram.  Returns the length written. */
+long vamd_batcher_report(vamd_batcher *b, char *buf, long cap);
 vamd_ctx *vamd_batcher_context(vamd_batcher *b);
 
 #ifdef __cplusplus

@@ -239,6 +239,15 @@ void vamd_batch_stats(long *batches, long *blocks, double *run_seconds) {
   pthread_mutex_unlock(&vamd_lock);
 }
 
+/* the first batcher's own account of where its batches' time went (diagnostics) */
+long vamd_batch_trace(char *buf, long cap) {
+  long n = 0;
+  pthread_mutex_lock(&vamd_lock);
+  if (vamd_nshares) n = vamd_batcher_report(vamd_shares[0]->batcher, buf, cap);
+  pthread_mutex_unlock(&vamd_lock);
+  return n;
+}
+
 /* for a build WITHOUT envelope_vamd.c: call from vorbis_dsp_clear() before b->ve is freed */
 void vamd_release_state(vorbis_dsp_state *state) { vamd_release_key(vamd_key(state)); }
 

@@ -653,6 +653,77 @@ long ref_encode_stream(ref_enc *e, const float *pcm, long frames, ref_block_rec 
   return nblocks;
 }
 
+/* ---- many encoder threads, timed in C (profiles/rNN_batcher.txt) -----------------------
+ * `nthreads` application threads, each with its own encoder state, each pushing the same `frames`-sample planar
+ * signal through the unmodified application loop above (nothing recorded), `passes` times over (a fresh state per
+ * pass).  The states of the first pass are opened before the clock starts; the clock runs from the moment every
+ * thread stands at the start line until the last one is through.  Linked into libvorbis_hybrid.so the same function
+ * times the GPU back-end (VAMD_BATCH in the environment: the batcher).  Python drives it with ONE call, so no
+ * interpreter lock, allocation or copy of Python's sits inside the timed region (round 3's figures were taken around
+ * ref_encode_stream() calls from Python threads, whose per-block post-processing serialises on the interpreter lock).
+ * Returns wall seconds (< 0: an encode failed); *blocks_out = blocks encoded, cpu_out[2] = user, system seconds. */
+#include <pthread.h>
+#include <sys/resource.h>
+typedef struct ref_tt_arg {
+  int ch, passes;
+  long rate, frames, blocks;
+  float q;
+  const float *pcm;
+  ref_enc *first;
+  pthread_barrier_t *line;
+  int failed;
+} ref_tt_arg;
+static void *ref_tt_run(void *v) {
+  ref_tt_arg *a = (ref_tt_arg *)v;
+  int p;
+  pthread_barrier_wait(a->line);
+  for (p = 0; p < a->passes; p++) {
+    ref_enc *e = p == 0 ? a->first : ref_open(a->ch, a->rate, a->q);
+    long nb = e ? ref_encode_stream(e, a->pcm, a->frames, NULL, 0, NULL, 0, NULL, 0) : -1;
+    if (e) ref_close(e);
+    if (nb < 0) { a->failed = 1; break; }
+    a->blocks += nb;
+  }
+  return NULL;
+}
+double ref_time_threads(int nthreads, int ch, long rate, float q, const float *pcm, long frames, int passes,
+                        long *blocks_out, double *cpu_out) {
+  pthread_t *th = (pthread_t *)calloc(nthreads, sizeof(*th));
+  ref_tt_arg *args = (ref_tt_arg *)calloc(nthreads, sizeof(*args));
+  pthread_barrier_t line;
+  struct timespec t0, t1;
+  struct rusage r0, r1;
+  pthread_attr_t attr;
+  int i, bad = 0;
+  long blocks = 0;
+  pthread_barrier_init(&line, NULL, nthreads + 1);
+  pthread_attr_init(&attr);
+  pthread_attr_setstacksize(&attr, 1 << 20); /* mapping0_forward's alloca()s are a few hundred KB at most */
+  for (i = 0; i < nthreads; i++) {
+    args[i].ch = ch, args[i].rate = rate, args[i].q = q, args[i].pcm = pcm, args[i].frames = frames;
+    args[i].passes = passes, args[i].line = &line;
+    args[i].first = ref_open(ch, rate, q);
+    pthread_create(&th[i], &attr, ref_tt_run, &args[i]);
+  }
+  getrusage(RUSAGE_SELF, &r0);
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  pthread_barrier_wait(&line);
+  for (i = 0; i < nthreads; i++) pthread_join(th[i], NULL);
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  getrusage(RUSAGE_SELF, &r1);
+  for (i = 0; i < nthreads; i++) blocks += args[i].blocks, bad |= args[i].failed;
+  if (blocks_out) *blocks_out = blocks;
+  if (cpu_out) {
+    cpu_out[0] = (r1.ru_utime.tv_sec - r0.ru_utime.tv_sec) + 1e-6 * (r1.ru_utime.tv_usec - r0.ru_utime.tv_usec);
+    cpu_out[1] = (r1.ru_stime.tv_sec - r0.ru_stime.tv_sec) + 1e-6 * (r1.ru_stime.tv_usec - r0.ru_stime.tv_usec);
+  }
+  pthread_barrier_destroy(&line);
+  pthread_attr_destroy(&attr);
+  free(th);
+  free(args);
+  return bad ? -1. : (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+}
+
 /* ---- the block-switching detector ------------------------------
  * ref_envelope_feed(): append `frames` samples per channel exactly as an application does
  * (vorbis_analysis_buffer + vorbis_analysis_wrote, which also runs the start-of-stream

@@ -21,7 +21,7 @@ EXPORTED_SYMBOLS = ["vamd_create", "vamd_destroy", "vamd_last_error", "vamd_set_
                     "vamd_packet_capacity", "vamd_encode_block", "vamd_submaps", "vamd_residue_offset", "vamd_analyze_streams_mixed",
                     "vamd_plan_streams", "vamd_gather_blocks", "vamd_plan_fetch",
                     "vamd_batcher_create", "vamd_batcher_destroy", "vamd_batcher_attach", "vamd_batcher_detach",
-                    "vamd_batcher_encode_block", "vamd_batcher_last_error", "vamd_batcher_stats", "vamd_batcher_context",
+                    "vamd_batcher_encode_block", "vamd_batcher_last_error", "vamd_batcher_stats", "vamd_batcher_context", "vamd_batcher_report",
                     "vamd_input_status", "vamd_calib_copy"]
 PACKETBLOBS = 15
 

@@ -20,6 +20,7 @@
 // Built on the public C ABI only (a context is used by one thread at a time: the leader that holds its lane).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <chrono>
@@ -71,13 +72,21 @@ struct vamd_batcher {
   int attached = 0;       // streams that announced themselves (vamd_batcher_attach)
   long nbatches = 0, nblocks = 0;
   double run_seconds = 0.;  // spent inside the batched GPU calls (staging copies included)
+  // where a batch's time goes (vamd_batcher_report): seconds summed over batches
+  double t_gather = 0., t_stage = 0., t_gpu = 0., t_unpack = 0., t_wake = 0.;
+  long end_full = 0, end_all = 0, end_timeout = 0;  // why gathers ended: max_batch reached / every free stream in / max_wait_us passed
+  long size_hist[12] = {0};                          // batches of 1, 2-3, 4-7, ... blocks
   std::string err;
 };
 
 static size_t al16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 // one batch of blocks of size class W on lane L; called by a leader with the mutex NOT held
-static int run_batch(vamd_batcher *b, Lane &L, int W, Request *const *reqs, size_t nb, std::string *err) {
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// phase[0..2]: seconds spent staging the inputs, on the GPU (upload, kernels, download, sync), handing the packets out
+static int run_batch(vamd_batcher *b, Lane &L, int W, Request *const *reqs, size_t nb, std::string *err, double *phase) {
+  const double t_in = now_s();
   const size_t ch = (size_t)b->ch, n = (size_t)b->bs[W], row = (size_t)b->pkcap[W];
   // arena: [pcm | lW | nW | blocktype | ampmax_in || ampmax_out | bits | input status | packets]
   const size_t o_pcm = 0, o_lW = al16(nb * ch * n * 4), o_nW = al16(o_lW + nb * 4), o_bt = al16(o_nW + nb * 4),
@@ -115,6 +124,7 @@ static int run_batch(vamd_batcher *b, Lane &L, int W, Request *const *reqs, size
     ((int32_t *)(hs + o_bt))[k] = r.blocktype;
     ((float *)(hs + o_ain))[k] = r.ampmax_in;
   }
+  const double t_staged = now_s();
   e = hipMemcpyAsync(ds, hs, o_out, hipMemcpyHostToDevice, L.stream);
   if (e != hipSuccess) {
     *err = std::string("batcher upload: ") + hipGetErrorString(e);
@@ -147,6 +157,7 @@ static int run_batch(vamd_batcher *b, Lane &L, int W, Request *const *reqs, size
     *err = std::string("batcher download: ") + hipGetErrorString(e);
     return VAMD_EFAULT;
   }
+  const double t_back = now_s();
   for (size_t k = 0; k < nb; k++) {
     Request &q = *reqs[k];
     bool outside = false;  // this block's input was outside the domain (include/vorbis_amd.h): its own error, nobody else's
@@ -166,6 +177,7 @@ static int run_batch(vamd_batcher *b, Lane &L, int W, Request *const *reqs, size
     if (q.ampmax_out) *q.ampmax_out = ((const float *)(hs + o_aout))[k];
     q.status = VAMD_OK;
   }
+  phase[0] = t_staged - t_in, phase[1] = t_back - t_staged, phase[2] = now_s() - t_back;
   return VAMD_OK;
 }
 
@@ -278,14 +290,26 @@ int vamd_batcher_encode_block(vamd_batcher *b, const float *const *pcm, int lW, 
     if (rq.done) break;
     // ---- we lead: gather (one leader at a time), then run the batch on a free lane, then hand the results back
     b->gatherers++;
+    const double t_g0 = now_s();
     const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(b->max_wait_us);
     for (;;) {
       // everybody who can still submit has: the attached streams less those whose block is in a running batch
       const size_t have = b->pending[0].size() + b->pending[1].size();
       const long free_streams = (long)b->attached - b->in_flight;
-      if (have >= (size_t)b->max_batch || (b->attached > 0 && have > 0 && (long)have >= free_streams)) break;
-      if (b->cv_lead.wait_until(lk, deadline) == std::cv_status::timeout) break;
+      if (have >= (size_t)b->max_batch) {
+        b->end_full++;
+        break;
+      }
+      if (b->attached > 0 && have > 0 && (long)have >= free_streams) {
+        b->end_all++;
+        break;
+      }
+      if (b->cv_lead.wait_until(lk, deadline) == std::cv_status::timeout) {
+        b->end_timeout++;
+        break;
+      }
     }
+    b->t_gather += now_s() - t_g0;
     // the size class with more blocks waiting goes first (ours, if it is a tie)
     const int Wb = b->pending[W].size() >= b->pending[1 - W].size() ? W : 1 - W;
     std::vector<Request *> take;
@@ -331,9 +355,17 @@ int vamd_batcher_encode_block(vamd_batcher *b, const float *const *pcm, int lW, 
     lk.unlock();
     std::string err;
     const auto t0 = std::chrono::steady_clock::now();
-    const int r = run_batch(b, *lane, Wb, take.data(), take.size(), &err);
+    double phase[3] = {0., 0., 0.};
+    const int r = run_batch(b, *lane, Wb, take.data(), take.size(), &err, phase);
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     lk.lock();
+    const double t_w0 = now_s();
+    b->t_stage += phase[0], b->t_gpu += phase[1], b->t_unpack += phase[2];
+    {
+      int h = 0;
+      for (size_t v = take.size(); v > 1 && h < 11; v >>= 1) h++;
+      b->size_hist[h]++;
+    }
     lane->in_use = false;
     b->in_flight -= (long)take.size();
     if (r) b->err = err;
@@ -345,6 +377,7 @@ int vamd_batcher_encode_block(vamd_batcher *b, const float *const *pcm, int lW, 
       t->done = true;
       if (t != &rq) t->cv.notify_one();
     }
+    b->t_wake += now_s() - t_w0;
   }
   // ---- our block is back: pass the lead to the owner of the oldest pending block that has none, if any
   if (rq.lead) {
@@ -374,6 +407,19 @@ void vamd_batcher_stats(vamd_batcher *b, long *batches, long *blocks, double *ru
   if (batches) *batches = b->nbatches;
   if (blocks) *blocks = b->nblocks;
   if (run_seconds) *run_seconds = b->run_seconds;
+}
+
+long vamd_batcher_report(vamd_batcher *b, char *buf, long cap) {
+  if (!b || !buf || cap < 1) return 0;
+  std::lock_guard<std::mutex> g(b->m);
+  const double nbt = b->nbatches > 0 ? (double)b->nbatches : 1.;
+  int n = snprintf(buf, (size_t)cap,
+                   "batches %ld (%ld lanes), blocks %ld; a batch on average: gathered for %.0f us (ended: %ld full, %ld every free stream in, %ld "
+                   "timed out), staged in %.0f us, on the GPU %.0f us, packets handed out in %.0f us, owners woken in %.0f us\nbatch sizes 1 / 2-3 / 4-7 / ... :",
+                   b->nbatches, (long)b->lanes.size(), b->nblocks, 1e6 * b->t_gather / nbt, b->end_full, b->end_all, b->end_timeout,
+                   1e6 * b->t_stage / nbt, 1e6 * b->t_gpu / nbt, 1e6 * b->t_unpack / nbt, 1e6 * b->t_wake / nbt);
+  for (int h = 0; h < 12 && n > 0 && n < cap; h++) n += snprintf(buf + n, (size_t)(cap - n), " %ld", b->size_hist[h]);
+  return n;
 }
 
 vamd_ctx *vamd_batcher_context(vamd_batcher *b) { return b && !b->lanes.empty() ? b->lanes[0].ctx : nullptr; }
