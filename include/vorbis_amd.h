@@ -371,15 +371,17 @@ int vamd_plan_fetch(vamd_ctx *ctx, const vamd_stream_plan *plan, int32_t *const 
 
 /* ---- the host shim for encoders that submit ONE block at a time from many threads.
  * libvorbis' unit of work is one block of one stream (mapping0_forward, reference lib/mapping0.c:233-687); a
- * batcher owns one context and coalesces concurrent vamd_batcher_encode_block() calls -- same contract as
- * vamd_encode_block() for a VBR encoder, callable from any number of threads, one stream per thread as libvorbis
- * itself requires -- into batched launches: the caller that finds no batch under way leads one, waits until every
- * attached stream has a block pending, `max_batch` blocks have gathered or `max_wait_us` have passed, and runs the
- * pending blocks of one size class as a single vamd_analyze_batch() with packet output.  No thread of its own.
- * vamd_batcher_attach / _detach announce a stream (a vorbis_dsp_state) so that a leader knows how many blocks to
- * expect; without them it waits out `max_wait_us`.  Errors: OV_*-valued as everywhere; the text of the last one with
- * vamd_batcher_last_error().  vamd_batcher_context() is the owned context (capacities, geometry; NOT for concurrent
- * launches).  Reference-side use: integration/mapping0_vamd.c with VAMD_BATCH set in the environment. */
+ * batcher coalesces concurrent vamd_batcher_encode_block() calls -- same contract as vamd_encode_block() for a VBR
+ * encoder, callable from any number of threads, one stream per thread as libvorbis itself requires -- into batched
+ * launches.  It owns a few LANES (VAMD_BATCH_LANES in the environment, default 4): a context, a HIP stream, staging
+ * arenas and one library thread each.  A caller queues its block and sleeps; a lane that is idle takes everything pending
+ * of one size class (at most `max_batch` blocks) at once, runs it as a single vamd_analyze_batch() with packet output
+ * and wakes exactly the owners of those blocks; blocks that arrive while every lane is busy gather for the next one.
+ * There is no timer (`max_wait_us` is accepted and unused since round 4: waiting for stragglers cost more than it
+ * gathered).  vamd_batcher_attach / _detach announce a stream (a vorbis_dsp_state); they are bookkeeping only.
+ * Errors: OV_*-valued as everywhere; the text of the last one with vamd_batcher_last_error().  vamd_batcher_context()
+ * is the first lane's context (capacities, geometry; NOT for launches).  Reference-side use:
+ * integration/mapping0_vamd.c with VAMD_BATCH set in the environment. */
 typedef struct vamd_batcher vamd_batcher;
 int vamd_batcher_create(vamd_batcher **out, const void *setup_blob, size_t blob_bytes, int device, int max_batch,
                         int max_wait_us);

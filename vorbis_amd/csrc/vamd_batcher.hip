@@ -3,31 +3,46 @@
 // can hand over whole streams, this serves callers that cannot).
 //
 // libvorbis' own unit of work is one block of one stream (mapping0_forward, reference lib/mapping0.c:233-687); on
-// the GPU one block is a handful of wavefronts walking serial phases (~0.4 ms), a batch of a thousand costs little
-// more.  A batcher owns ONE context and turns concurrent vamd_batcher_encode_block() calls -- same contract as
-// vamd_encode_block(), from any number of threads, one stream per thread as libvorbis requires -- into batched
-// launches: whoever finds no batch under way becomes its leader, waits until every attached stream has a block
-// pending (or `max_batch` have, or `max_wait_us` passed), takes the pending blocks of one size class, runs them as
-// ONE vamd_analyze_batch() with packet output, hands the packets back, wakes THEIR owners (each request has its
-// own condition variable: a finished batch must not wake hundreds of sleepers to find out it was not for them)
-// and appoints the owner of the oldest pending block to lead the next batch.  No thread of its own; blocks of a
-// stream stay in order because a stream has at most one pending.
+// the GPU one block is a handful of wavefronts walking serial phases (~0.2 ms), a batch of a hundred costs little
+// more.  A batcher turns concurrent vamd_batcher_encode_block() calls -- same contract as vamd_encode_block(), from
+// any number of threads, one stream per thread as libvorbis requires -- into batched launches.
 //
-// A batcher has a few LANES (contexts with their own stream and staging; VAMD_BATCH_LANES, default 2): one leader
-// gathers at a time, but while its batch is on the GPU the next leader already gathers and launches on another lane --
-// a batch of a few dozen blocks is latency on the GPU, not load, and the gaps between batches were most of the time.
+// Round 4 shape (round 2-3's had the callers elect a leader who waited out a timer for stragglers; measured in C with
+// 256 threads on a 16-CPU host it spent 0.56 ms of KERNEL time per block in futex traffic -- every submission woke the
+// gathering leader, every finished batch handed its owners the one mutex to queue on -- and nine gathers in ten ended
+// on the 200 us timer):
+//   * LANES (VAMD_BATCH_LANES, default 8): a context, a HIP stream, pinned + device staging arenas and ONE library
+//     thread each.  A lane sleeps while nothing is pending; woken, it takes EVERYTHING pending of one size class (up
+//     to max_batch), runs it as one vamd_analyze_batch() with packet output, hands the packets back and looks again.
+//     No timer: blocks gather by themselves while the lanes are busy (a batch is ~0.25 ms of latency on the GPU, not
+//     load), and when a lane is idle a block leaves at once.  The first VAMD_BATCH_EAGER (4) lanes start on whatever
+//     is pending; the others join only when VAMD_BATCH_JOIN (32) blocks wait -- eight lanes each carrying one or two
+//     blocks cost more in launches and queue switches than they overlap (the runtime maps streams onto four hardware
+//     queues unless GPU_MAX_HW_QUEUES says otherwise; 16 threads: 26 k blocks/s on eight lanes against 44 k on four),
+//     eight lanes carrying sixteen blocks each are what 256 threads need (175 k against 120-130 k).
+//   * no lock on the way in or out: a caller pushes its request onto a lock-free list (one compare-and-swap), wakes a
+//     lane only if one sleeps and may start, and sleeps on a futex word of ITS OWN request; a lane takes the whole list
+//     with one exchange, and sets the word and wakes exactly that caller when the packet is back.  (A mutex here, held
+//     for a dozen instructions, was where 256 threads on 16 CPUs spent 0.1 ms of kernel time per block: its holder
+//     gets descheduled and everybody else queues in the kernel.)
+// Blocks of a stream stay in order because a stream has at most one pending.
 //
-// Built on the public C ABI only (a context is used by one thread at a time: the leader that holds its lane).
+// Built on the public C ABI only (a context is used by one thread: its lane's).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 #include "vorbis_amd.h"
 
 namespace {
@@ -41,49 +56,86 @@ struct Request {
   long packet_cap;
   int32_t *packet_bits;
   int status = 0;
-  bool done = false;
-  bool lead = false;  // appointed to lead the next batch
-  std::condition_variable cv;  // its owner sleeps here: a finished batch wakes its own blocks' owners, nobody else
+  Request *next = nullptr;   // the pending list is intrusive
+  std::atomic<int> done{0};  // the futex word its owner sleeps on: 0 pending, 1 back (status and outputs are final)
 };
+
+// the owner's sleep and the lane's wake-up: one word per request, no shared lock on the way back
+inline void futex_wait_done(std::atomic<int> *w) {
+  while (w->load(std::memory_order_acquire) == 0)
+    (void)syscall(SYS_futex, (int *)w, FUTEX_WAIT_PRIVATE, 0, nullptr, nullptr, 0);
+}
+inline void futex_post_done(std::atomic<int> *w) {
+  w->store(1, std::memory_order_release);
+  (void)syscall(SYS_futex, (int *)w, FUTEX_WAKE_PRIVATE, 1, nullptr, nullptr, 0);
+}
 
 }  // namespace
 
-// one context with its stream and staging arenas: a batch runs on one lane
+// one context with its stream, staging arenas and thread: a batch runs on one lane
 struct Lane {
   vamd_ctx *ctx = nullptr;
   hipStream_t stream = nullptr;
   void *h_stage = nullptr, *d_stage = nullptr;
   size_t stage_bytes = 0;
-  bool in_use = false;
+  hipEvent_t done = nullptr;  // created with hipEventBlockingSync: a lane waiting for a large batch sleeps on the interrupt
+  std::thread worker;
 };
 
 struct vamd_batcher {
-  std::vector<Lane> lanes;  // VAMD_BATCH_LANES (default 2): while one batch is on the GPU the next is gathered and launched
+  std::vector<Lane> lanes;  // VAMD_BATCH_LANES (default 8)
   int device = 0, ch = 0;
   int bs[2] = {0, 0};
   long pkcap[2] = {0, 0};
   int max_batch = 0, max_wait_us = 0;
+  long spin_below = 16;  // VAMD_BATCH_SPIN_BELOW: batches smaller than this are waited for by polling
+  int eager = 4, join_at = 32;
+  // the way in: lock-free
+  std::atomic<Request *> head[2] = {{nullptr}, {nullptr}};  // pending requests per size class, newest first
+  std::atomic<int> npending[2] = {{0}, {0}};
+  // lanes come in two kinds: the first `eager` start on anything pending, the rest only on `join_at` blocks or more;
+  // each kind sleeps on its own futex word so that a caller wakes a lane that may actually start
+  std::atomic<int> sleepers[2] = {{0}, {0}};
+  std::atomic<int> work[2] = {{0}, {0}};
+  std::atomic<bool> stop{false};
+  std::atomic<int> attached{0};    // streams that announced themselves (vamd_batcher_attach)
+  // lanes' own bookkeeping (never taken by a caller)
   std::mutex m;
-  std::condition_variable cv_lead;  // the collecting leader sleeps here
-  int gatherers = 0;                // leaders gathering right now (a re-leading or appointed leader can start while another still waits)
-  long in_flight = 0;               // blocks taken into batches that are on the GPU: their streams cannot submit meanwhile
-  int leaders = 0;                  // leaders at work, gathering or running: <= lanes.size()
-  std::vector<Request *> pending[2];
-  int attached = 0;       // streams that announced themselves (vamd_batcher_attach)
   long nbatches = 0, nblocks = 0;
   double run_seconds = 0.;  // spent inside the batched GPU calls (staging copies included)
   // where a batch's time goes (vamd_batcher_report): seconds summed over batches
-  double t_gather = 0., t_stage = 0., t_gpu = 0., t_unpack = 0., t_wake = 0.;
-  long end_full = 0, end_all = 0, end_timeout = 0;  // why gathers ended: max_batch reached / every free stream in / max_wait_us passed
-  long size_hist[12] = {0};                          // batches of 1, 2-3, 4-7, ... blocks
+  double t_stage = 0., t_gpu = 0., t_unpack = 0., t_wake = 0.;
+  long size_hist[12] = {0};  // batches of 1, 2-3, 4-7, ... blocks
   std::string err;
 };
 
+// may a lane of kind k (0: one of the first `eager`, 1: the others) start a batch now?  (pending: both size classes)
+static bool may_start(const vamd_batcher *b, int k, int pending) { return pending >= (k ? b->join_at : 1); }
+static void push_request(vamd_batcher *b, int W, Request *r) {
+  r->next = b->head[W].load(std::memory_order_relaxed);
+  while (!b->head[W].compare_exchange_weak(r->next, r, std::memory_order_release, std::memory_order_relaxed)) {
+  }
+  b->npending[W].fetch_add(1, std::memory_order_seq_cst);
+}
+static void wake_lanes(vamd_batcher *b, int k, int n) {
+  b->work[k].fetch_add(1, std::memory_order_seq_cst);
+  (void)syscall(SYS_futex, (int *)&b->work[k], FUTEX_WAKE_PRIVATE, n, nullptr, nullptr, 0);
+}
+// after a push (or with blocks left over): wake one lane of each kind that sleeps and may start
+static void wake_for(vamd_batcher *b) {
+  const int pending = b->npending[0].load(std::memory_order_seq_cst) + b->npending[1].load(std::memory_order_seq_cst);
+  for (int k = 0; k < 2; k++)
+    if (b->sleepers[k].load(std::memory_order_seq_cst) > 0 && may_start(b, k, pending)) {
+      wake_lanes(b, k, 1);
+      break;  // (one lane takes everything of a size class: no point in waking two for one push)
+    }
+}
+
 static size_t al16(size_t x) { return (x + 15) & ~(size_t)15; }
 
-// one batch of blocks of size class W on lane L; called by a leader with the mutex NOT held
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+// one batch of blocks of size class W on lane L (its own thread, the mutex NOT held)
 // phase[0..2]: seconds spent staging the inputs, on the GPU (upload, kernels, download, sync), handing the packets out
 static int run_batch(vamd_batcher *b, Lane &L, int W, Request *const *reqs, size_t nb, std::string *err, double *phase) {
   const double t_in = now_s();
@@ -92,16 +144,8 @@ static int run_batch(vamd_batcher *b, Lane &L, int W, Request *const *reqs, size
   const size_t o_pcm = 0, o_lW = al16(nb * ch * n * 4), o_nW = al16(o_lW + nb * 4), o_bt = al16(o_nW + nb * 4),
                o_ain = al16(o_bt + nb * 4), o_out = al16(o_ain + nb * 4), o_aout = o_out, o_bits = al16(o_aout + nb * 4),
                o_st = al16(o_bits + nb * 4), o_pk = al16(o_st + nb * ch), total = al16(o_pk + nb * row);
-  // the leader is an application thread inside vorbis_analysis(): its current device is put back on every way out
-  struct DeviceRestore {
-    int prev = -1;
-    DeviceRestore() { (void)hipGetDevice(&prev); }
-    ~DeviceRestore() {
-      if (prev >= 0) (void)hipSetDevice(prev);
-    }
-  } device_restore;
-  hipError_t e = hipSetDevice(b->device);
-  if (e == hipSuccess && L.stage_bytes < total) {
+  hipError_t e = hipSuccess;  // (the lane's thread made b->device current when it started)
+  if (L.stage_bytes < total) {
     if (L.h_stage) (void)hipHostFree(L.h_stage);
     if (L.d_stage) (void)hipFree(L.d_stage);
     L.h_stage = L.d_stage = nullptr;
@@ -152,7 +196,18 @@ static int run_batch(vamd_batcher *b, Lane &L, int W, Request *const *reqs, size
     return r;
   }
   e = hipMemcpyAsync(hs + o_out, ds + o_out, total - o_out, hipMemcpyDeviceToHost, L.stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(L.stream);
+  // Waiting: hipStreamSynchronize() polls -- the right thing for a handful of blocks whose owners wait on this very
+  // latency with CPUs to spare, the wrong thing under many threads: four lanes polling are four CPUs the encoders do
+  // not get (measured on a 16-CPU host at 256 threads: 0.11 ms of kernel time per block).  A batch of `spin_below`
+  // blocks or more sleeps on the event's interrupt instead; its wake-up latency is shared by all of them.
+  if (e == hipSuccess) {
+    if ((long)nb < b->spin_below) {
+      e = hipStreamSynchronize(L.stream);
+    } else {
+      e = hipEventRecord(L.done, L.stream);
+      if (e == hipSuccess) e = hipEventSynchronize(L.done);
+    }
+  }
   if (e != hipSuccess) {
     *err = std::string("batcher download: ") + hipGetErrorString(e);
     return VAMD_EFAULT;
@@ -181,13 +236,80 @@ static int run_batch(vamd_batcher *b, Lane &L, int W, Request *const *reqs, size
   return VAMD_OK;
 }
 
+// a lane's life: sleep until it may start, take all of one size class, run it, hand it back, look again
+static void lane_main(vamd_batcher *b, Lane *lane) {
+  (void)hipSetDevice(b->device);
+  const int kind = (int)(lane - b->lanes.data()) < b->eager ? 0 : 1;
+  std::vector<Request *> take;
+  for (;;) {
+    if (b->stop.load()) break;
+    const int seen = b->work[kind].load(std::memory_order_seq_cst);
+    int n0 = b->npending[0].load(), n1 = b->npending[1].load();
+    if (!may_start(b, kind, n0 + n1)) {
+      // announce the sleep, look once more (a caller pushes first and reads `sleepers` second), then sleep
+      b->sleepers[kind].fetch_add(1, std::memory_order_seq_cst);
+      n0 = b->npending[0].load(), n1 = b->npending[1].load();
+      if (!b->stop.load() && !may_start(b, kind, n0 + n1))
+        (void)syscall(SYS_futex, (int *)&b->work[kind], FUTEX_WAIT_PRIVATE, seen, nullptr, nullptr, 0);
+      b->sleepers[kind].fetch_sub(1, std::memory_order_seq_cst);
+      continue;
+    }
+    // the size class with more blocks waiting goes first; the whole list in one exchange
+    const int W = n1 >= n0 ? 1 : 0;
+    Request *list = b->head[W].exchange(nullptr, std::memory_order_acquire);
+    take.clear();
+    for (Request *r = list; r;) {
+      Request *nx = r->next;  // (pushing a surplus request back rewrites its link)
+      if (take.size() < (size_t)b->max_batch) take.push_back(r);
+      else push_request(b, W, r), b->npending[W].fetch_sub(1);  // (it was counted when it first came)
+      r = nx;
+    }
+    if (take.empty()) continue;  // another lane was quicker
+    b->npending[W].fetch_sub((int)take.size());
+    wake_for(b);  // what is left (the other size class, a surplus) is another lane's, if one sleeps and may start
+    std::string err;
+    double phase[3] = {0., 0., 0.};
+    const double t0 = now_s();
+    const int r = run_batch(b, *lane, W, take.data(), take.size(), &err, phase);
+    const double t1 = now_s();
+    for (Request *t : take) {  // (a request is its owner's stack object: not to be touched once its word is posted)
+      if (r) t->status = r;
+      futex_post_done(&t->done);
+    }
+    const double t2 = now_s();
+    std::lock_guard<std::mutex> g(b->m);
+    if (r) b->err = err;
+    b->run_seconds += t1 - t0;
+    b->nbatches++;
+    b->nblocks += (long)take.size();
+    b->t_stage += phase[0], b->t_gpu += phase[1], b->t_unpack += phase[2], b->t_wake += t2 - t1;
+    int h = 0;
+    for (size_t v = take.size(); v > 1 && h < 11; v >>= 1) h++;
+    b->size_hist[h]++;
+  }
+}
+
 extern "C" {
 
 static void free_lanes(vamd_batcher *b) {
+  b->stop.store(true);
+  wake_lanes(b, 0, 1 << 20);
+  wake_lanes(b, 1, 1 << 20);
+  for (Lane &L : b->lanes)
+    if (L.worker.joinable()) L.worker.join();
+  // whoever still waits (a destroy under the callers' feet) is released with an error
+  for (int W = 0; W < 2; W++)
+    for (Request *t = b->head[W].exchange(nullptr); t;) {
+      Request *nx = t->next;
+      t->status = VAMD_EFAULT;
+      futex_post_done(&t->done);
+      t = nx;
+    }
   for (Lane &L : b->lanes) {
     if (L.h_stage) (void)hipHostFree(L.h_stage);
     if (L.d_stage) (void)hipFree(L.d_stage);
     if (L.ctx) vamd_destroy(L.ctx);
+    if (L.done) (void)hipEventDestroy(L.done);
     if (L.stream) (void)hipStreamDestroy(L.stream);
   }
   b->lanes.clear();
@@ -198,9 +320,9 @@ int vamd_batcher_create(vamd_batcher **out, const void *setup_blob, size_t blob_
   if (!out) return VAMD_EINVAL;
   *out = nullptr;
   if (max_batch < 1 || max_wait_us < 0) return VAMD_EINVAL;
-  int nlanes = getenv("VAMD_BATCH_LANES") ? atoi(getenv("VAMD_BATCH_LANES")) : 2;
+  int nlanes = getenv("VAMD_BATCH_LANES") ? atoi(getenv("VAMD_BATCH_LANES")) : 8;
   if (nlanes < 1) nlanes = 1;
-  if (nlanes > 8) nlanes = 8;
+  if (nlanes > 16) nlanes = 16;
   vamd_batcher *b = new vamd_batcher;
   int cur = 0;
   (void)hipGetDevice(&cur);
@@ -212,6 +334,7 @@ int vamd_batcher_create(vamd_batcher **out, const void *setup_blob, size_t blob_
     if (r) break;
     hipError_t e = hipSetDevice(b->device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&L.done, hipEventBlockingSync | hipEventDisableTiming);
     if (e == hipSuccess && vamd_set_stream(L.ctx, L.stream) != VAMD_OK) e = hipErrorUnknown;
     if (e != hipSuccess) {
       r = VAMD_EFAULT;
@@ -230,6 +353,10 @@ int vamd_batcher_create(vamd_batcher **out, const void *setup_blob, size_t blob_
   }
   b->max_batch = max_batch;
   b->max_wait_us = max_wait_us;
+  if (getenv("VAMD_BATCH_SPIN_BELOW")) b->spin_below = atol(getenv("VAMD_BATCH_SPIN_BELOW"));
+  if (getenv("VAMD_BATCH_EAGER")) b->eager = atoi(getenv("VAMD_BATCH_EAGER"));
+  if (getenv("VAMD_BATCH_JOIN")) b->join_at = atoi(getenv("VAMD_BATCH_JOIN"));
+  if (b->eager < 1) b->eager = 1;
   if (r) {
     (void)hipSetDevice(b->device);
     free_lanes(b);
@@ -238,6 +365,7 @@ int vamd_batcher_create(vamd_batcher **out, const void *setup_blob, size_t blob_
     return r;
   }
   if (cur != b->device) (void)hipSetDevice(cur);
+  for (Lane &L : b->lanes) L.worker = std::thread(lane_main, b, &L);
   *out = b;
   return VAMD_OK;
 }
@@ -253,18 +381,11 @@ void vamd_batcher_destroy(vamd_batcher *b) {
 }
 
 void vamd_batcher_attach(vamd_batcher *b) {
-  if (!b) return;
-  std::lock_guard<std::mutex> g(b->m);
-  b->attached++;
+  if (b) b->attached.fetch_add(1);
 }
 
 void vamd_batcher_detach(vamd_batcher *b) {
-  if (!b) return;
-  {
-    std::lock_guard<std::mutex> g(b->m);
-    if (b->attached > 0) b->attached--;
-  }
-  b->cv_lead.notify_one();  // a leader waiting for this stream's block need not wait any longer
+  if (b && b->attached.load() > 0) b->attached.fetch_sub(1);
 }
 
 int vamd_batcher_encode_block(vamd_batcher *b, const float *const *pcm, int lW, int W, int nW, int blocktype,
@@ -273,129 +394,13 @@ int vamd_batcher_encode_block(vamd_batcher *b, const float *const *pcm, int lW, 
   if (!b || !pcm || !packet || !packet_bits || (W != 0 && W != 1)) return VAMD_EINVAL;
   for (int c = 0; c < b->ch; c++)
     if (!pcm[c]) return VAMD_EINVAL;
+  if (b->stop.load()) return VAMD_EFAULT;
   Request rq;
   rq.pcm = pcm, rq.lW = lW, rq.W = W, rq.nW = nW, rq.blocktype = blocktype, rq.ampmax_in = ampmax_in;
   rq.ampmax_out = ampmax_out, rq.packet = packet, rq.packet_cap = packet_cap, rq.packet_bits = packet_bits;
-  std::unique_lock<std::mutex> lk(b->m);
-  b->pending[W].push_back(&rq);
-  if (b->gatherers) {
-    b->cv_lead.notify_all();  // the gathering leaders count it
-  } else if (b->leaders < (int)b->lanes.size()) {
-    b->leaders++;  // nobody is gathering and a lane is free: we lead
-    rq.lead = true;
-  }
-  for (;;) {
-    // sleep until our block comes back, or until we are appointed to lead a batch
-    while (!rq.done && !rq.lead) rq.cv.wait(lk);
-    if (rq.done) break;
-    // ---- we lead: gather (one leader at a time), then run the batch on a free lane, then hand the results back
-    b->gatherers++;
-    const double t_g0 = now_s();
-    const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(b->max_wait_us);
-    for (;;) {
-      // everybody who can still submit has: the attached streams less those whose block is in a running batch
-      const size_t have = b->pending[0].size() + b->pending[1].size();
-      const long free_streams = (long)b->attached - b->in_flight;
-      if (have >= (size_t)b->max_batch) {
-        b->end_full++;
-        break;
-      }
-      if (b->attached > 0 && have > 0 && (long)have >= free_streams) {
-        b->end_all++;
-        break;
-      }
-      if (b->cv_lead.wait_until(lk, deadline) == std::cv_status::timeout) {
-        b->end_timeout++;
-        break;
-      }
-    }
-    b->t_gather += now_s() - t_g0;
-    // the size class with more blocks waiting goes first (ours, if it is a tie)
-    const int Wb = b->pending[W].size() >= b->pending[1 - W].size() ? W : 1 - W;
-    std::vector<Request *> take;
-    {
-      std::vector<Request *> &q = b->pending[Wb];
-      const size_t nb = q.size() < (size_t)b->max_batch ? q.size() : (size_t)b->max_batch;
-      take.assign(q.begin(), q.begin() + (long)nb);
-      q.erase(q.begin(), q.begin() + (long)nb);
-    }
-    Lane *lane = nullptr;
-    for (Lane &L : b->lanes)
-      if (!L.in_use) {
-        lane = &L;
-        break;
-      }
-    b->gatherers--;
-    if (take.empty() || !lane) {
-      // nothing left to run (an appointed leader that woke up late finds everything, its own block included, in
-      // another leader's batch): step down and wait for the block like everybody else
-      for (Request *t : take) t->status = VAMD_EFAULT, t->done = true, t->cv.notify_one();  // (no lane: cannot happen)
-      rq.lead = false;
-      b->leaders--;
-      continue;
-    }
-    lane->in_use = true;  // (there is one: leaders <= lanes, and every other leader holds at most one)
-    b->in_flight += (long)take.size();
-    if (b->gatherers) b->cv_lead.notify_all();  // fewer streams are left to wait for
-    // what is still pending (the other size class, latecomers) gets its own leader at once if a lane is free
-    if (b->leaders < (int)b->lanes.size()) {
-      Request *next = nullptr;
-      for (int w = 0; w < 2 && !next; w++)
-        for (Request *t : b->pending[w])
-          if (!t->lead) {
-            next = t;
-            break;
-          }
-      if (next) {
-        b->leaders++;
-        next->lead = true;
-        next->cv.notify_one();
-      }
-    }
-    lk.unlock();
-    std::string err;
-    const auto t0 = std::chrono::steady_clock::now();
-    double phase[3] = {0., 0., 0.};
-    const int r = run_batch(b, *lane, Wb, take.data(), take.size(), &err, phase);
-    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    lk.lock();
-    const double t_w0 = now_s();
-    b->t_stage += phase[0], b->t_gpu += phase[1], b->t_unpack += phase[2];
-    {
-      int h = 0;
-      for (size_t v = take.size(); v > 1 && h < 11; v >>= 1) h++;
-      b->size_hist[h]++;
-    }
-    lane->in_use = false;
-    b->in_flight -= (long)take.size();
-    if (r) b->err = err;
-    b->run_seconds += dt;
-    b->nbatches++;
-    b->nblocks += (long)take.size();
-    for (Request *t : take) {
-      if (r) t->status = r;
-      t->done = true;
-      if (t != &rq) t->cv.notify_one();
-    }
-    b->t_wake += now_s() - t_w0;
-  }
-  // ---- our block is back: pass the lead to the owner of the oldest pending block that has none, if any
-  if (rq.lead) {
-    Request *next = nullptr;
-    if (!b->gatherers)
-      for (int w = 0; w < 2 && !next; w++)
-        for (Request *t : b->pending[w])
-          if (!t->lead) {
-            next = t;
-            break;
-          }
-    if (next) {
-      next->lead = true;
-      next->cv.notify_one();
-    } else {
-      b->leaders--;
-    }
-  }
+  push_request(b, W, &rq);
+  wake_for(b);  // a sleeping lane that may start takes it at once; busy lanes find it when they look again
+  futex_wait_done(&rq.done);
   return rq.status;
 }
 
@@ -414,10 +419,10 @@ long vamd_batcher_report(vamd_batcher *b, char *buf, long cap) {
   std::lock_guard<std::mutex> g(b->m);
   const double nbt = b->nbatches > 0 ? (double)b->nbatches : 1.;
   int n = snprintf(buf, (size_t)cap,
-                   "batches %ld (%ld lanes), blocks %ld; a batch on average: gathered for %.0f us (ended: %ld full, %ld every free stream in, %ld "
-                   "timed out), staged in %.0f us, on the GPU %.0f us, packets handed out in %.0f us, owners woken in %.0f us\nbatch sizes 1 / 2-3 / 4-7 / ... :",
-                   b->nbatches, (long)b->lanes.size(), b->nblocks, 1e6 * b->t_gather / nbt, b->end_full, b->end_all, b->end_timeout,
-                   1e6 * b->t_stage / nbt, 1e6 * b->t_gpu / nbt, 1e6 * b->t_unpack / nbt, 1e6 * b->t_wake / nbt);
+                   "batches %ld on %ld lanes, blocks %ld; a batch on average: staged in %.0f us, on the GPU %.0f us (upload, kernels, download, "
+                   "sync), packets handed out in %.0f us, owners woken in %.0f us\nbatch sizes 1 / 2-3 / 4-7 / ... :",
+                   b->nbatches, (long)b->lanes.size(), b->nblocks, 1e6 * b->t_stage / nbt, 1e6 * b->t_gpu / nbt, 1e6 * b->t_unpack / nbt,
+                   1e6 * b->t_wake / nbt);
   for (int h = 0; h < 12 && n > 0 && n < cap; h++) n += snprintf(buf + n, (size_t)(cap - n), " %ld", b->size_hist[h]);
   return n;
 }
