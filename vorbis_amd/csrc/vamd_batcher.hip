@@ -169,7 +169,17 @@ static int run_batch(vamd_batcher *b, Lane &L, int W, Request *const *reqs, size
     ((float *)(hs + o_ain))[k] = r.ampmax_in;
   }
   const double t_staged = now_s();
-  e = hipMemcpyAsync(ds, hs, o_out, hipMemcpyHostToDevice, L.stream);
+  // the kernels read samples and descriptors out of, and write packets into, the pinned arena itself (mapped into the
+  // device's address space): no copy commands either side of the launches, and only the bytes a packet really has
+  // cross the link.  VAMD_STAGE_COPIES=1 brings the two copies back (measurement aid).
+  static const bool staged_copies = getenv("VAMD_STAGE_COPIES") != nullptr;
+  if (!staged_copies) {
+    void *mapped = nullptr;
+    e = hipHostGetDevicePointer(&mapped, hs, 0);
+    ds = (unsigned char *)mapped;
+  } else {
+    e = hipMemcpyAsync(ds, hs, o_out, hipMemcpyHostToDevice, L.stream);
+  }
   if (e != hipSuccess) {
     *err = std::string("batcher upload: ") + hipGetErrorString(e);
     return VAMD_EFAULT;
@@ -195,7 +205,7 @@ static int run_batch(vamd_batcher *b, Lane &L, int W, Request *const *reqs, size
     *err = std::string("batcher analyze: ") + vamd_last_error(L.ctx);
     return r;
   }
-  e = hipMemcpyAsync(hs + o_out, ds + o_out, total - o_out, hipMemcpyDeviceToHost, L.stream);
+  if (staged_copies) e = hipMemcpyAsync(hs + o_out, ds + o_out, total - o_out, hipMemcpyDeviceToHost, L.stream);
   // Waiting: hipStreamSynchronize() polls -- the right thing for a handful of blocks whose owners wait on this very
   // latency with CPUs to spare, the wrong thing under many threads: four lanes polling are four CPUs the encoders do
   // not get (measured on a 16-CPU host at 256 threads: 0.11 ms of kernel time per block).  A batch of `spin_below`

@@ -331,16 +331,31 @@ template <int LP>
 __global__ __launch_bounds__(64) void k_tone_seed(PsyP P0, PsyP P1, DescP d, int ch, int nlp, int nrp,
                                                   const float *__restrict__ peaks,
                                                   const float *__restrict__ local_ampmax,
-                                                  const float *__restrict__ ampmax_glob, float *__restrict__ seed_g) {
+                                                  const float *__restrict__ ampmax_glob, float *__restrict__ ampmax_make,
+                                                  float *__restrict__ seed_g) {
   const long cb = blockIdx.x;
   const long blk = cb / ch;
   const PsyP &P = d_bt(d, blk) ? P1 : P0;
+  // the block's ampmax (lib/mapping0.c:346,576): read where a stream's chain has already formed it; otherwise formed here
+  // -- max of the incoming value and the channels' spectral peaks, what k_ampmax would have launched for -- and written
+  // once per block by its first channel's wave
+  float g_amp;
+  if (ampmax_make) {
+    g_amp = d_amp(d, blk);
+    for (int c = 0; c < ch; c++) {
+      const float l = local_ampmax[blk * ch + c];
+      if (l > g_amp) g_amp = l;
+    }
+    if (LANE == 0 && cb == blk * ch) ampmax_make[blk] = g_amp;
+  } else {
+    g_amp = ampmax_glob[blk];
+  }
   const int n2 = P.n, nl = P.total_octave_lines;
   float *seed = (float *)vamd_smem + seed_pad_lo(P.eighth_octave_lines);  // padded either side, see seed_curve_scatter
   (void)n2;
   PhaseClock pc;
   pc.start(d.dbg ? d.dbg + 32 : nullptr);
-  tone_seed_block<LP>(P, peaks + cb * nrp, ampmax_glob[blk], local_ampmax[cb], seed, pc);
+  tone_seed_block<LP>(P, peaks + cb * nrp, g_amp, local_ampmax[cb], seed, pc);
   WAVE_FOR(i, nlp) seed_g[cb * nlp + i] = i < nl ? seed[i] : VAMD_NEGINF;
   pc.flush();
 }
@@ -1240,6 +1255,7 @@ struct BatchRun {
   const vamd_batch_io *io;
   ResBufs rb;
   float *couple_state;  // [units][4][ch][n2] or null (alloc_couple_state)
+  bool make_ampmax;     // the block ampmax is formed by k_tone_seed (independent blocks at the psy level or above: no k_ampmax launch)
 };
 
 static int check_packets(vamd_ctx *c, int W, int level, const void *packets, const void *bits, int64_t stride) {
@@ -1449,10 +1465,10 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_
       const size_t seed_lds = (size_t)(seed_pad_lo(P0.eighth_octave_lines) + nlp + seed_pad_hi(P0.eighth_octave_lines)) * 4;
       if (P0.eighth_octave_lines == 8 && P1.eighth_octave_lines == 8)
         hipLaunchKernelGGL(k_tone_seed<8>, dim3(gcb), dim3(64), seed_lds, s, P0, P1, d, ch, nlp, run_peaks_stride(P0), p.peaks, p.local,
-                           p.ampglob, p.seed);
+                           p.ampglob, R->make_ampmax ? p.ampglob : nullptr, p.seed);
       else
         hipLaunchKernelGGL(k_tone_seed<0>, dim3(gcb), dim3(64), seed_lds, s, P0, P1, d, ch, nlp, run_peaks_stride(P0), p.peaks, p.local,
-                           p.ampglob, p.seed);
+                           p.ampglob, R->make_ampmax ? p.ampglob : nullptr, p.seed);
       // a lane per block for batches, a wave per block (the walk in 64 chunks) where that would leave the GPU to a
       // handful of lanes walking ~800 lines each: the per-block entry points, the batcher's small batches
       static const long wave_max_cb = getenv("VAMD_CHASE_WAVE_MAX") ? atol(getenv("VAMD_CHASE_WAVE_MAX")) : 32768;
@@ -1530,6 +1546,8 @@ static int run_batch(vamd_ctx *c, const vamd_batch_desc *desc, const vamd_batch_
     hipLaunchKernelGGL(k_ampmax_stream, dim3(1), dim3(1), 0, s, ch, R.nb, secs, c->B.ampmax_att_per_sec, *ampmax_state,
                        R.p.local, R.p.ampin, R.p.ampglob);
     R.d.ampmax_in = R.p.ampin;
+  } else if (level >= VAMD_LEVEL_PSY) {
+    R.make_ampmax = true;  // (one launch less: 4 us of a single block's 180)
   } else {
     hipLaunchKernelGGL(k_ampmax, dim3((unsigned)((R.nb + 255) / 256)), dim3(256), 0, s, R.d, ch, R.nb, R.p.local,
                        R.p.ampglob);
@@ -1865,7 +1883,19 @@ int vamd_encode_block(vamd_ctx *c, const float *const *pcm, int lW, int W, int n
     memcpy(hs + o_pcm + i * n * 4, pcm[i], n * 4);
   }
   hipStream_t s = c->stream;
-  HIP_TRY(c, hipMemcpyAsync(ds + o_pcm, hs + o_pcm, ch * n * 4, hipMemcpyHostToDevice, s));
+  // The kernels read the samples out of, and write the packet into, the pinned arena itself (it is mapped into the
+  // device's address space): 16 KB in and a few hundred bytes out per block cross the link inside the first and the
+  // last kernel instead of as two copy commands either side of them.  VAMD_STAGE_COPIES=1 brings the copies back
+  // (measurement aid).
+  static const bool staged_copies = getenv("VAMD_STAGE_COPIES") != nullptr;
+  unsigned char *io_base = ds;
+  if (!staged_copies) {
+    void *mapped = nullptr;
+    HIP_TRY(c, hipHostGetDevicePointer(&mapped, hs, 0));
+    io_base = (unsigned char *)mapped;
+  } else {
+    HIP_TRY(c, hipMemcpyAsync(ds + o_pcm, hs + o_pcm, ch * n * 4, hipMemcpyHostToDevice, s));
+  }
   vamd_batch_desc d;
   memset(&d, 0, sizeof(d));
   d.W = W;
@@ -1876,9 +1906,9 @@ int vamd_encode_block(vamd_ctx *c, const float *const *pcm, int lW, int W, int n
   d.uniform_ampmax_in = ampmax_in;
   vamd_batch_io io;
   memset(&io, 0, sizeof(io));
-  io.pcm = (const float *)(ds + o_pcm);
-  io.ampmax_out = (float *)(ds + o_amp);
-  io.status = ds + o_amp + 4;  // ch <= 8 bytes behind the float, inside its 16-byte slot
+  io.pcm = (const float *)(io_base + o_pcm);
+  io.ampmax_out = (float *)(io_base + o_amp);
+  io.status = io_base + o_amp + 4;  // ch <= 8 bytes behind the float, inside its 16-byte slot
   if (managed) {
     vamd_managed_io m;
     memset(&m, 0, sizeof(m));
@@ -1886,18 +1916,18 @@ int vamd_encode_block(vamd_ctx *c, const float *const *pcm, int lW, int W, int n
     m.post_valid = (int32_t *)(ds + o_valid);
     m.nonzero = (int32_t *)(ds + o_nz);
     m.iwork = (int32_t *)(ds + o_iwork);
-    m.packets = ds + o_pk;
-    m.packet_bits = (int32_t *)(ds + o_bits);
+    m.packets = io_base + o_pk;
+    m.packet_bits = (int32_t *)(io_base + o_bits);
     m.packet_stride = (int64_t)row;
     r = vamd_analyze_batch_managed(c, &d, &io, &m);
   } else {
-    io.packets = ds + o_pk;
-    io.packet_bits = (int32_t *)(ds + o_bits);
+    io.packets = io_base + o_pk;
+    io.packet_bits = (int32_t *)(io_base + o_bits);
     io.packet_stride = (int64_t)row;
     r = vamd_analyze_batch(c, &d, &io, VAMD_LEVEL_FULL);
   }
   if (r) return r;
-  HIP_TRY(c, hipMemcpyAsync(hs + o_amp, ds + o_amp, o_back - o_amp, hipMemcpyDeviceToHost, s));
+  if (staged_copies) HIP_TRY(c, hipMemcpyAsync(hs + o_amp, ds + o_amp, o_back - o_amp, hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
   for (size_t i = 0; i < ch; i++)
     if (hs[o_amp + 4 + i]) return fail(c, VAMD_EINVAL, "input outside the domain: a non-finite sample, or a signal ~1000 x over full scale");
