@@ -75,8 +75,55 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-TRAFFIC_PROFILE = "profiles/r03_pmc_traffic.json"
-TRAFFIC_PROFILE_C5 = "profiles/r03_c5_pmc_traffic.json"
+TRAFFIC_PROFILE = "profiles/r04_pmc_traffic.json"
+TRAFFIC_PROFILE_C5 = "profiles/r04_c5_pmc_traffic.json"
+VALU_PROFILE = "profiles/r04_pmc_valu.json"
+
+
+def measured_valu(workload, units, stage_ms):
+    """The other roofline: the path is bound by vector-instruction issue, not by HBM.  From the committed counter
+    pass (SQ_INSTS_VALU per kernel and its dynamic mix, hash-guarded like the traffic profile) and the price list of
+    tools/micro/chip_rate.hip: vector instructions per unit x SIMD cycles per instruction / (1024 SIMDs x clock) = the time the
+    instructions alone need on this chip, per stage and for the step, against the HIP-event time of the same stage."""
+    if workload not in ("c3", "c4"):
+        return None
+    try:
+        t = json.load(open(os.path.join(ROOT, VALU_PROFILE)))
+    except Exception:
+        return {"value": None, "note": "no committed VALU profile"}
+    if t.get("source_hash") != source_hash():
+        return {"value": None, "note": "VALU profile %s was taken from other sources (%s, now %s): re-run tools/profile.sh"
+                                       % (VALU_PROFILE, t.get("source_hash"), source_hash())}
+    stage_of = {"k_transform": "transform", "k_noise": "noisemask", "k_floor": "floor", "k_couple": "couple",
+                "k_tone_seed": "tonemask", "k_tone_chase": "tonemask", "k_tone_fold": "tonemask"}
+    rate = t["simds"] * t["clock_ghz"] * 1e9          # SIMD cycles per second, whole chip
+    per_stage, insts = {}, 0.0
+    for k, v in t["per_kernel"].items():
+        st = stage_of.get(k.split("<")[0])
+        if st is None or (workload == "c3" and st in ("floor", "couple")):
+            continue
+        d = per_stage.setdefault(st, {"valu_insts_per_unit": 0.0, "issue_ms": 0.0})
+        d["valu_insts_per_unit"] += v["valu_per_stereo_block"]
+        d["issue_ms"] += v["valu_per_stereo_block"] * units * v["cycles_per_inst_model"] / rate * 1e3
+        insts += v["valu_per_stereo_block"]
+    # the tone chain runs beside the noise mask: the pair is one segment of the step as far as issue slots go
+    for st, d in per_stage.items():
+        ms = stage_ms.get(st)
+        if st == "noisemask":
+            pair = d["issue_ms"] + per_stage.get("tonemask", {}).get("issue_ms", 0.0)
+            both = stage_ms.get("noisemask", 0.0) + stage_ms.get("tonemask", 0.0)
+            d["stage_ms"], d["frac_valu"] = both, (pair / both if both else None)
+            d["note"] = "with the tone chain, which runs beside it: %.3f ms of issue time in %.3f ms" % (pair, both)
+        elif st == "tonemask":
+            d["stage_ms"], d["frac_valu"] = ms, None
+        else:
+            d["stage_ms"], d["frac_valu"] = ms, (d["issue_ms"] / ms if ms else None)
+    total = sum(d["issue_ms"] for d in per_stage.values())
+    return {"valu_insts_per_unit": insts, "cycles_per_inst": total * 1e-3 * rate / max(insts * units, 1.0), "simds": t["simds"],
+            "clock_ghz": t["clock_ghz"], "issue_ms_per_step": total, "frac_valu": total / max(sum(stage_ms.values()), 1e-9),
+            "per_stage": per_stage, "source": t["source"],
+            "definition": "vector instructions per unit (SQ_INSTS_VALU) x modelled SIMD cycles per instruction (the kernel's dynamic "
+                          "mix priced with the measured whole-chip cost of each class) / (SIMDs x clock), against the summed stage events"}
 
 
 def measured_traffic(workload, units, alg_bytes=None):
@@ -577,6 +624,7 @@ def main(argv=None, make_runner=None):
             "kernels_ms_per_step": stage_ms,
             "dominant_kernel": {"name": dom, "ms": stage_ms[dom], "own_bytes_per_step": dom_bytes,
                                 "own_GBps": dom_bytes / (stage_ms[dom] * 1e-3) / 1e9, "traffic": dom_traffic},
+            "valu": measured_valu(a.workload, units, stage_ms),
         }
         line = {
             "metric": "audio blocks/s (2048-sample MDCT+psy) @1/2/4/8 GPU; % HBM roofline",

@@ -139,3 +139,43 @@ for name in ("pmc_sq_counters.txt", "pmc_sq_counters_c5.txt"):
         with open(os.path.join(ROOT, "profiles", TAG + "_" + name), "w") as f:
             f.write("# per-wave SQ counters (rocprofv3 --pmc, one set per pass; tools/profile.sh), source hash %s\n" % bench_mod.source_hash())
             f.write(open(srcp).read())
+
+# ---- roofline.valu: vector instructions per stereo block and what they cost to issue (VERDICT r03 "missing" 3) -------------------------
+# Per kernel: SQ_INSTS_VALU per wave x waves / blocks, and a cost per instruction from the run's own dynamic mix priced with
+# tools/micro/chip_rate.hip's list (profiles/rNN_micro_chip_rate.txt): whole chip, eight waves per SIMD, SIMD cycles per wave64 instruction.
+PRICE = {"ADD_F32": 2.66, "MUL_F32": 2.66, "FMA_F32": 4.30, "TRANS_F32": 8.70, "ADD_F64": 4.68, "MUL_F64": 4.71, "FMA_F64": 4.77,
+         "TRANS_F64": 16.5, "CVT": 4.76, "INT32": 3.80, "INT64": 4.68, "OTHER": 4.20}
+# (INT32: adds / and / xor / arithmetic shifts 2.85, everything else 4.67 -- the counter does not tell them apart: the mean.  OTHER: what no
+#  class counter claims -- moves 2.65, compares, selects, DPP, readlane, bit-field and three-operand forms 4.6-4.7.)
+mixf = os.path.join(SRC, "pmc_valu_mix.txt")
+if os.path.exists(mixf):
+    import ast
+    import re
+    rows = {}
+    for ln in open(mixf):
+        m = re.match(r"(k_[A-Za-z0-9_<>]+) waves (\d+) (\{.*\})", ln.strip())
+        if m:
+            d = rows.setdefault(m.group(1), {"waves": int(m.group(2))})
+            d.update(ast.literal_eval(m.group(3)))
+    perk = {}
+    for k, d in rows.items():
+        if k.startswith(("k_mdct_only", "k_ampmax", "k_calib_copy")) or "SQ_INSTS_VALU" not in d:
+            continue
+        n = d["SQ_INSTS_VALU"]
+        cls = {c: d.get("SQ_INSTS_VALU_" + c, 0.0) for c in PRICE if c != "OTHER"}
+        other = max(0.0, n - sum(cls.values()))
+        cyc = (sum(PRICE[c] * v for c, v in cls.items()) + PRICE["OTHER"] * other) / max(n, 1.0)
+        perk[k] = {"valu_per_wave": n, "waves": d["waves"], "valu_per_stereo_block": n * d["waves"] / NB_PMC,
+                   "mean_lanes_live": d.get("SQ_THREAD_CYCLES_VALU", 0.0) / max(n, 1.0),
+                   "mix_per_wave": dict(cls, OTHER=other), "cycles_per_inst_model": cyc}
+    outv = {"source_hash": bench_mod.source_hash(), "workload": "c4", "blocks": NB_PMC,
+            "source": "profiles/%s_pmc_valu_mix.txt (rocprofv3 --pmc, five passes over one step; tools/pmc_valu_mix.sh), priced with "
+                      "profiles/%s_micro_chip_rate.txt" % (TAG, TAG),
+            "price_cycles_per_wave64_inst": PRICE, "simds": 1024, "clock_ghz": 2.25, "per_kernel": perk,
+            "valu_per_stereo_block": sum(v["valu_per_stereo_block"] for v in perk.values())}
+    json.dump(outv, open(os.path.join(ROOT, "profiles", TAG + "_pmc_valu.json"), "w"), indent=1)
+    with open(os.path.join(ROOT, "profiles", TAG + "_pmc_valu_mix.txt"), "w") as f:
+        f.write("# dynamic vector-instruction mix per kernel, one full-analysis step over %d stereo blocks (tools/pmc_valu_mix.sh), source hash %s\n"
+                % (NB_PMC, bench_mod.source_hash()))
+        f.write(open(mixf).read())
+    print("valu: %.0f vector instructions per stereo block" % outv["valu_per_stereo_block"])

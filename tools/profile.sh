@@ -33,5 +33,6 @@ for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_INSTS_VM
   echo "== rocprofv3 --pmc $set -- python tools/prof_run_c5.py 1" >> $O/pmc_sq_counters_c5.txt
   python $R/tools/pmc_summary.py /tmp/p/x_results.db >> $O/pmc_sq_counters_c5.txt
 done
+bash $R/tools/pmc_valu_mix.sh $NB > $O/pmc_valu_mix.txt 2>&1   # the dynamic instruction mix behind roofline.valu
 rm -rf $O/kt_bench $O/kt_c5 $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_c5_FETCH_SIZE $O/pmc_c5_WRITE_SIZE
 ls -la $O
