@@ -35,6 +35,10 @@ extern "C" {
 #define VAMD_EIMPL    (-130) /* OV_EIMPL: setup/feature outside the covered path */
 #define VAMD_EINVAL   (-131) /* OV_EINVAL: bad argument */
 #define VAMD_EVERSION (-134) /* OV_EVERSION: setup blob version mismatch */
+/* NOT a libvorbis code: the input (not the call) was outside the domain the reference's own arithmetic is defined on ("Input
+ * domain" below).  Kept apart from VAMD_EINVAL so that a binding can tell a poisoned stream -- which it reports as OV_EINVAL
+ * out of vorbis_analysis() -- from a programming error in its own arguments, which it should not swallow. */
+#define VAMD_EDOMAIN  (-140)
 
 /* lib/codec_internal.h:23-26 */
 #define VAMD_BLOCKTYPE_IMPULSE    0
@@ -154,6 +158,12 @@ typedef struct vamd_batch_io {
   int64_t   packet_stride;/* row length in bytes, a multiple of 4 (vamd_packet_capacity() always suffices) */
   uint8_t  *status;       /* out [nb][ch] 1 where the channel-block was outside the input domain (below), else 0 */
 } vamd_batch_io;
+/* vamd_batch_desc / vamd_batch_io / vamd_managed_io MUST be zero-initialised by the caller (memset, = {0}) before the
+ * fields it uses are set: members are appended at the END between releases (`status` came in with ABI 6), and a member
+ * the caller does not know about is then a null pointer, which every entry point reads as "not wanted".  A caller built
+ * against another header than the library it loads finds out with vamd_abi_version() != VAMD_ABI_VERSION. */
+#define VAMD_ABI_VERSION 7
+int vamd_abi_version(void);
 
 /* ---- Input domain ---------------------------------------------------------------------------------
  * libvorbis does not validate PCM: whatever floats arrive go through mapping0_forward.  Inside the
@@ -172,11 +182,14 @@ typedef struct vamd_batch_io {
  *           enters the arithmetic, in the reference or here.)
  *
  *   - the host-pointer calls (vamd_analyze_block*, vamd_encode_block, vamd_envelope_search,
- *     vamd_batcher_encode_block) return VAMD_EINVAL (= OV_EINVAL) for a block / detector call outside the
- *     domain; through the binding, vorbis_analysis() returns OV_EINVAL for that block and for every later
- *     block of the stream;
+ *     vamd_batcher_encode_block) return VAMD_EDOMAIN for a block / detector call outside the domain (their
+ *     argument errors stay VAMD_EINVAL); through the binding, vorbis_analysis() returns OV_EINVAL for that
+ *     block and for every later block of the stream.  THIS IS A DELIBERATE DEVIATION FROM UPSTREAM, and it is
+ *     sticky: libvorbis itself encodes such input (into whatever its overflowing integers yield on the build's
+ *     target) and carries on; a stream that holds, say, un-normalised int16-scale floats (+90 dB) ends here
+ *     with an error instead.  README.md and INTEGRATION.md say so up front;
  *   - the device-pointer calls are asynchronous: they fill `status` (when given) and count;
- *     vamd_input_status() synchronises the context's stream, returns VAMD_EINVAL if anything issued since the
+ *     vamd_input_status() synchronises the context's stream, returns VAMD_EDOMAIN if anything issued since the
  *     previous call was outside the domain (how many channel-blocks / detector steps: the two optional
  *     outputs) and resets the counts.  Outputs of such blocks are deterministic but unspecified; every
  *     other block of the batch is unaffected.

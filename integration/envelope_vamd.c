@@ -66,9 +66,10 @@ long _ve_envelope_search(vorbis_dsp_state *v) {
     int i, err = -1;
     for (i = 0; i < ve->ch; i++) chan[i] = v->pcm[i] + step * first;
     if (ctx && st) err = vamd_envelope_search(ctx, chan, nsteps, st, flags);
-    if (err == VAMD_EINVAL) {
+    if (err == VAMD_EDOMAIN) {
       /* a sample outside the input domain (NaN / Inf; vorbis_amd.h): no marks from these steps, and the stream is
-         flagged so that the next vorbis_analysis() returns OV_EINVAL (mapping0_vamd.c: vamd_poison) */
+         flagged so that the next vorbis_analysis() returns OV_EINVAL (mapping0_vamd.c: vamd_poison).  An argument
+         error (VAMD_EINVAL) is NOT this case: it falls through to the hard stop below, as before */
       memset(flags, 0, nsteps);
       vamd_poison(v);
       err = 0;

@@ -338,7 +338,10 @@ static int mapping0_forward_vamd(vorbis_block *vb) {
       int32_t bits = 0;
       ret = vamd_batcher_encode_block(e->shared->batcher, (const float *const *)vb->pcm, vb->lW, vb->W, vb->nW,
                                       vbi->blocktype, vbi->ampmax, &ampmax_out, packet, pkcap, &bits);
-      if (ret == VAMD_EINVAL) vamd_poison(vd);
+      if (ret == VAMD_EDOMAIN) {
+        vamd_poison(vd);
+        ret = OV_EINVAL; /* what vorbis_analysis() reports for it */
+      }
       if (ret) return ret;
       vbi->ampmax = ampmax_out; /* lib/mapping0.c:576 */
       oggpack_writecopy(vbi->packetblob[PACKETBLOBS / 2], packet, bits);
@@ -358,7 +361,10 @@ static int mapping0_forward_vamd(vorbis_block *vb) {
     int32_t *bits = _vorbis_block_alloc(vb, nk * sizeof(*bits));
     ret = vamd_encode_block(ctx, (const float *const *)vb->pcm, vb->lW, vb->W, vb->nW, vbi->blocktype, vbi->ampmax,
                             managed, &ampmax_out, packets, pkcap, bits);
-    if (ret == VAMD_EINVAL) vamd_poison(vd);
+    if (ret == VAMD_EDOMAIN) {
+      vamd_poison(vd);
+      ret = OV_EINVAL; /* what vorbis_analysis() reports for it */
+    }
     if (ret) return ret; /* an OV_* code, out through vorbis_analysis(); the text stays with vamd_last_error(ctx) */
     vbi->ampmax = ampmax_out; /* lib/mapping0.c:576 */
     for (k = 0; k < nk; k++) {
@@ -384,7 +390,10 @@ static int mapping0_forward_vamd(vorbis_block *vb) {
   else
     ret = vamd_analyze_block(ctx, (const float *const *)vb->pcm, vb->lW, vb->W, vb->nW, vbi->blocktype, vbi->ampmax,
                              mdct, NULL, posts, post_valid, iwork, nonzero, &ampmax_out);
-  if (ret == VAMD_EINVAL) vamd_poison(vd);
+  if (ret == VAMD_EDOMAIN) {
+    vamd_poison(vd);
+    ret = OV_EINVAL; /* what vorbis_analysis() reports for it */
+  }
   if (ret) return ret;
   vbi->ampmax = ampmax_out; /* lib/mapping0.c:576 */
   for (k = 0; k < nk; k++) {

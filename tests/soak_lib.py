@@ -218,7 +218,7 @@ def run_hostile(nb=48, log=print):
                     an.analyze_block(x[k], int(lW[k]), W, int(nW[k]), 1 if W else 0, -9999.0)
                     ok = not want[k].any()
                 except VamdError as err:
-                    ok = bool(want[k].any()) and err.code == vorbis_amd.VAMD_EINVAL
+                    ok = bool(want[k].any()) and err.code == vorbis_amd.VAMD_EDOMAIN
                 if not ok:
                     bad += 1
                     log("HOSTILE analyze_block verdict wrong", (ch, rate, q), "W", W, "block", k)
@@ -234,7 +234,7 @@ def run_hostile(nb=48, log=print):
             bad += 1
             log("HOSTILE detector accepted a NaN", (ch, rate, q))
         except VamdError as err:
-            if err.code != vorbis_amd.VAMD_EINVAL:
+            if err.code != vorbis_amd.VAMD_EDOMAIN:
                 bad += 1
                 log("HOSTILE detector: wrong error", err)
         an.close()

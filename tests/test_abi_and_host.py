@@ -256,3 +256,16 @@ def test_bench_gpus_flag_must_agree_with_the_launcher():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--backend", "gloo",
                         "--runner", "tests.stub_runner:StubRunner"], env=env, capture_output=True, text=True, timeout=120, cwd=ROOT)
     assert r.returncode == 2 and "WORLD_SIZE" in r.stderr and not r.stdout.strip()
+
+
+def test_abi_version_matches_the_header():
+    """vamd_abi_version() is the VAMD_ABI_VERSION of the header the library was built from (a caller built against another
+    header finds out before it hands over a struct the library reads further than the caller wrote)."""
+    import re
+    import vorbis_amd
+    L = vorbis_amd.load_library()
+    hdr = open(os.path.join(ROOT, "include", "vorbis_amd.h")).read()
+    want = int(re.search(r"#define VAMD_ABI_VERSION (\d+)", hdr).group(1))
+    L.vamd_abi_version.restype = C.c_int
+    assert L.vamd_abi_version() == want
+    assert "VAMD_EDOMAIN" in hdr and vorbis_amd.VAMD_EDOMAIN == int(re.search(r"#define VAMD_EDOMAIN\s+\((-\d+)\)", hdr).group(1))

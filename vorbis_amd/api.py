@@ -7,7 +7,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
-VAMD_OK, VAMD_EFAULT, VAMD_EIMPL, VAMD_EINVAL, VAMD_EVERSION = 0, -129, -130, -131, -134
+VAMD_OK, VAMD_EFAULT, VAMD_EIMPL, VAMD_EINVAL, VAMD_EVERSION, VAMD_EDOMAIN = 0, -129, -130, -131, -134, -140
 LEVEL_TRANSFORM, LEVEL_PSY, LEVEL_FULL = 1, 2, 3
 POSTS_STRIDE = 32
 BLOCKTYPE_IMPULSE, BLOCKTYPE_PADDING, BLOCKTYPE_TRANSITION, BLOCKTYPE_LONG = 0, 1, 0, 1
@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = ["vamd_create", "vamd_destroy", "vamd_last_error", "vamd_set_
                     "vamd_plan_streams", "vamd_gather_blocks", "vamd_plan_fetch",
                     "vamd_batcher_create", "vamd_batcher_destroy", "vamd_batcher_attach", "vamd_batcher_detach",
                     "vamd_batcher_encode_block", "vamd_batcher_last_error", "vamd_batcher_stats", "vamd_batcher_context", "vamd_batcher_report",
-                    "vamd_input_status", "vamd_calib_copy"]
+                    "vamd_input_status", "vamd_calib_copy", "vamd_abi_version"]
 PACKETBLOBS = 15
 
 _vp = C.c_void_p
@@ -239,7 +239,7 @@ class Analyzer:
         (0, 0) means every result since then is the reference's, bit for bit."""
         a, b = C.c_long(0), C.c_long(0)
         r = self.L.vamd_input_status(self.h, C.byref(a), C.byref(b))
-        if r not in (VAMD_OK, VAMD_EINVAL):
+        if r not in (VAMD_OK, VAMD_EDOMAIN):
             self._check(r)
         return int(a.value), int(b.value)
 

@@ -475,13 +475,13 @@ VAMD_DEV int floor_fit_posts(const FloorP &F, const unsigned short *qc, FloorScr
   // lane i forms interval i's fit_line contribution; the terms go to LDS as rows for fit_line_pair, each over its own
   // interval's accumulators (40 bytes either way), which are dead from here on
   WAVE_FOR(i, posts - 1) {
-    const FitTerm ft = fit_term(sc->acc[i], F.twofitweight);
-    double *row = (double *)sc->acc + i * 5;
-    row[0] = ft.xb;
-    row[1] = ft.yb;
-    row[2] = ft.x2b;
-    row[3] = ft.xyb;
-    row[4] = ft.bn;
+    // (the row overlays the very accumulators it is formed from, ints then doubles through one address: the ints are
+    // copied out and a compiler fence stands between their last read and the first double store)
+    const FitAcc mine = sc->acc[i];
+    const FitTerm ft = fit_term(mine, F.twofitweight);
+    WAVE_SYNC();
+    double row[5] = {ft.xb, ft.yb, ft.x2b, ft.xyb, ft.bn};
+    memcpy((char *)sc->acc + (size_t)i * sizeof(row), row, sizeof(row));
   }
   WAVE_SYNC();
   pc.mark(1);

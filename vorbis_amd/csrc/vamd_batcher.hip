@@ -228,7 +228,7 @@ static int run_batch(vamd_batcher *b, Lane &L, int W, Request *const *reqs, size
     bool outside = false;  // this block's input was outside the domain (include/vorbis_amd.h): its own error, nobody else's
     for (size_t c = 0; c < ch; c++) outside |= hs[o_st + k * ch + c] != 0;
     if (outside) {
-      q.status = VAMD_EINVAL;
+      q.status = VAMD_EDOMAIN;
       continue;
     }
     const int32_t bits = ((const int32_t *)(hs + o_bits))[k];

@@ -1052,6 +1052,8 @@ void vamd_destroy(vamd_ctx *c) {
   delete c;
 }
 
+int vamd_abi_version(void) { return VAMD_ABI_VERSION; }
+
 const char *vamd_last_error(const vamd_ctx *c) { return c ? c->err.c_str() : "null context"; }
 
 int vamd_set_stream(vamd_ctx *c, void *s) {
@@ -1070,7 +1072,7 @@ int vamd_input_status(vamd_ctx *c, long *bad_channel_blocks, long *bad_detector_
   if (h[0] | h[1]) HIP_TRY(c, hipMemset(c->d_bad, 0, sizeof(h)));
   if (bad_channel_blocks) *bad_channel_blocks = (long)h[0];
   if (bad_detector_steps) *bad_detector_steps = (long)h[1];
-  if (h[0] | h[1]) return fail(c, VAMD_EINVAL, "input outside the domain: a non-finite sample, or a signal ~1000 x over full scale");
+  if (h[0] | h[1]) return fail(c, VAMD_EDOMAIN, "input outside the domain: a non-finite sample, or a signal ~1000 x over full scale");
   return VAMD_OK;
 }
 
@@ -1664,7 +1666,7 @@ int vamd_analyze_block_managed(vamd_ctx *c, const float *const *pcm, int lW, int
   HIP_TRY(c, hipMemcpyAsync(hs + o_mdct, ds + o_mdct, total - o_mdct, hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
   for (size_t i = 0; i < ch; i++)
-    if (hs[o_amp + 4 + i]) return fail(c, VAMD_EINVAL, "input outside the domain: a non-finite sample, or a signal ~1000 x over full scale");
+    if (hs[o_amp + 4 + i]) return fail(c, VAMD_EDOMAIN, "input outside the domain: a non-finite sample, or a signal ~1000 x over full scale");
   if (mdct) memcpy(mdct, hs + o_mdct, ch * n2 * 4);
   if (ampmax_out) memcpy(ampmax_out, hs + o_amp, 4);
   if (posts) memcpy(posts, hs + o_posts, K * ch * VAMD_POSTS_STRIDE * 4);
@@ -1829,7 +1831,7 @@ int vamd_analyze_block_res(vamd_ctx *c, const float *const *pcm, int lW, int W, 
   HIP_TRY(c, hipMemcpyAsync(hs + o_mdct, ds + o_mdct, total - o_mdct, hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
   for (int i = 0; i < ch; i++)
-    if (hs[o_amp + 4 + i]) return fail(c, VAMD_EINVAL, "input outside the domain: a non-finite sample, or a signal ~1000 x over full scale");
+    if (hs[o_amp + 4 + i]) return fail(c, VAMD_EDOMAIN, "input outside the domain: a non-finite sample, or a signal ~1000 x over full scale");
   if (mdct) memcpy(mdct, hs + o_mdct, (size_t)ch * n2 * 4);
   if (logmask) memcpy(logmask, hs + o_mask, (size_t)ch * n2 * 4);
   if (iwork) memcpy(iwork, hs + o_iwork, (size_t)ch * n2 * 4);
@@ -1930,7 +1932,7 @@ int vamd_encode_block(vamd_ctx *c, const float *const *pcm, int lW, int W, int n
   if (staged_copies) HIP_TRY(c, hipMemcpyAsync(hs + o_amp, ds + o_amp, o_back - o_amp, hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
   for (size_t i = 0; i < ch; i++)
-    if (hs[o_amp + 4 + i]) return fail(c, VAMD_EINVAL, "input outside the domain: a non-finite sample, or a signal ~1000 x over full scale");
+    if (hs[o_amp + 4 + i]) return fail(c, VAMD_EDOMAIN, "input outside the domain: a non-finite sample, or a signal ~1000 x over full scale");
   if (ampmax_out) memcpy(ampmax_out, hs + o_amp, 4);
   memcpy(packet_bits, hs + o_bits, K * 4);
   for (size_t k = 0; k < K; k++) {
@@ -2053,7 +2055,7 @@ int vamd_envelope_search(vamd_ctx *c, const float *const *pcm, long nsteps, vamd
   HIP_TRY(c, hipMemcpyAsync(hs + o_state, ds + o_state, total - o_state, hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
   if (*(const unsigned int *)(hs + o_bad))  // (the state is left as it was: the stream is over for this caller)
-    return fail(c, VAMD_EINVAL, "input outside the domain: a non-finite sample (include/vorbis_amd.h, Input domain)");
+    return fail(c, VAMD_EDOMAIN, "input outside the domain: a non-finite sample (include/vorbis_amd.h, Input domain)");
   memcpy(state, hs + o_state, sizeof(*state));
   memcpy(ret, hs + o_ret, (size_t)nsteps);
   return VAMD_OK;
