@@ -157,6 +157,12 @@ typedef struct vamd_batch_io {
   int32_t  *packet_bits;  /* out [nb] oggpack_bits(); > 8*packet_stride: the row was too short, packet cut off */
   int64_t   packet_stride;/* row length in bytes, a multiple of 4 (vamd_packet_capacity() always suffices) */
   uint8_t  *status;       /* out [nb][ch] 1 where the channel-block was outside the input domain (below), else 0 */
+  /* blocks read in place (ABI 7).  With pcm_src non-NULL the batch is NOT a packed [nb][ch][n] array: block b, channel c
+   * starts at pcm + pcm_src[b] + c * pcm_channel_stride (floats; both multiples of 4, pcm 16-byte aligned) -- e.g. a
+   * vamd_stream_plan's src[W] over the stream buffers themselves, which spares vamd_gather_blocks and its copy of every
+   * sample.  Blocks may overlap (consecutive blocks of a stream share half their samples). */
+  const int64_t *pcm_src;       /* in  device [nb], or NULL: packed */
+  int64_t   pcm_channel_stride; /* in  floats between a block's channels (only with pcm_src) */
 } vamd_batch_io;
 /* vamd_batch_desc / vamd_batch_io / vamd_managed_io MUST be zero-initialised by the caller (memset, = {0}) before the
  * fields it uses are set: members are appended at the END between releases (`status` came in with ABI 6), and a member

@@ -97,3 +97,20 @@ def test_batch_mode_many_encoder_threads_emit_reference_packets():
     r = json.loads(out.stdout.strip().splitlines()[-1])
     assert r["streams"] == 16 and r["blocks"] > 16 * 60 and r["short_blocks"] > 50
     assert r["bad"] == 0, r
+
+
+@pytest.mark.parametrize("threads,max_batch,lanes", [(96, 256, 8), (48, 8, 2)])
+def test_batch_mode_under_load(threads, max_batch, lanes):
+    """The round-4 batcher (a library thread per lane, lock-free submission, a futex word per request) with more streams than a
+    lane takes at once: 96 threads on eight lanes (the second kind of lane joins), and 48 threads against batches capped at
+    eight blocks on two lanes (a lane takes a surplus and pushes it back).  Mixed block sizes; every packet of every stream and
+    every ampmax equal the CPU reference's."""
+    import json, os, subprocess, sys
+    from tests import checker
+    env = dict(os.environ, VAMD_BATCH=str(max_batch), VAMD_BATCH_LANES=str(lanes))
+    out = subprocess.run([sys.executable, "-c", _BATCH_WORKER.replace("@ROOT@", repr(checker.ROOT)), str(threads), "0.4"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert r["streams"] == threads and r["blocks"] > threads * 60 and r["short_blocks"] > 50
+    assert r["bad"] == 0, r

@@ -96,6 +96,33 @@ def test_random_blocks_vs_oracle(torch_mod, name):
     assert bad == 0, "checker=%s" % chk.kind
 
 
+@pytest.mark.parametrize("nb", [1, 2, 31, 32, 33, 63, 65, 129])
+def test_batch_sizes_around_the_launch_thresholds(torch_mod, nb):
+    """The launch sequence changes shape with the batch: up to 32 blocks (64 channel-blocks) the tone chain stays on the
+    caller's stream and the chase runs a wave per block, above that it forks onto the side stream; persistent kernels get
+    fewer workgroups than CUs; the block ampmax is formed inside the tone seed (no launch of its own).  Every size lands
+    on the same bytes, ampmax_out included, for both ways an incoming ampmax can arrive (array / uniform)."""
+    torch = torch_mod
+    name = "44k_stereo_q4"
+    chk = checker.Checker(name)
+    an = analyzer(name)
+    rng = np.random.default_rng(4000 + nb)
+    pcm = ((rng.random((nb, 2, 2048), dtype=np.float32) - 0.5) * 2 * (10.0 ** rng.uniform(-3, 0, (nb, 1, 1)))).astype(np.float32)
+    amp_in = np.where(np.arange(nb) % 2 == 0, -9999.0, -20.0).astype(np.float32)
+    outs = an.analyze(torch.from_numpy(pcm).cuda(), W=1, ampmax_in=torch.from_numpy(amp_in).cuda(), want=ALL)
+    uni = an.analyze(torch.from_numpy(pcm).cuda(), W=1, ampmax_in=-20.0, want=("ampmax_out", "iwork"))
+    torch.cuda.synchronize()
+    outs = {k: v.cpu().numpy() for k, v in outs.items()}
+    bad = 0
+    for b in range(nb):
+        ref = chk.tap_block(pcm[b], ampmax_in=float(amp_in[b]))
+        bad += checker.compare_block(ref, {k: v[b] for k, v in outs.items()}, an.posts[1], verbose=bad < 3)
+        if amp_in[b] == -20.0:
+            assert np.float32(uni["ampmax_out"][b].item()) == np.float32(ref["ampmax_out"])
+            assert np.array_equal(uni["iwork"][b].cpu().numpy(), ref["iwork"])
+    assert bad == 0, "checker=%s" % chk.kind
+
+
 @pytest.mark.parametrize("name", ["44k_stereo_q4", "44k_stereo_q9", "44k_mono_q5"])
 def test_couple_estimate_band_does_not_show(torch_mod, name, monkeypatch):
     """k_couple decides a bin from an estimate of |m| / floor wherever that provably equals the reference's divisions

@@ -85,4 +85,14 @@ def test_plan_matches_reference_blockout(setup, q):
             W, i = (int(o) >> 30) & 1, int(o) & 0x3fffffff
             assert np.float32(host[W]["ampmax_out"][i]) == np.float32(blocks[k]["ampmax_out"]), (s, k)
         assert np.float32(states[s].item()) == np.float32(blocks[hi - lo - 1]["ampmax_out"])
+    # the same plan analysed IN PLACE -- the blocks read out of the stream buffers through the plan's offsets
+    # (vamd_batch_io::pcm_src), no gathered copy -- gives the gathered run's tensors bit for bit, chain states included
+    outs2 = [an.alloc_outputs(W, plan.nblocks[W], want) for W in (0, 1)]
+    states2 = torch.full((len(raws),), -9999.0, device="cuda")
+    an.analyze_plan(plan, None, outs2, states2, streams=streams)
+    torch.cuda.synchronize()
+    for W in (0, 1):
+        for k in want:
+            assert torch.equal(outs[W][k], outs2[W][k]), (W, k)
+    assert torch.equal(states, states2)
     an.close()

@@ -47,7 +47,7 @@ MAX_CH = 8
 
 class _IO(C.Structure):
     _fields_ = [(k, _vp) for k in _IO_FIELDS] + [("packets", _vp), ("packet_bits", _vp), ("packet_stride", C.c_int64),
-                                                 ("status", _vp)]
+                                                 ("status", _vp), ("pcm_src", _vp), ("pcm_channel_stride", C.c_int64)]
 
 
 class _MIO(C.Structure):  # vamd_managed_io
@@ -351,10 +351,10 @@ class Analyzer:
             return t.uint8
         return t.int32
 
-    def _io(self, pcm, outs):
+    def _io(self, pcm, outs, nb=None):
         io = _IO()
         io.pcm = _vp(pcm.data_ptr())
-        nb = pcm.shape[0]
+        nb = pcm.shape[0] if nb is None else nb
         for k, v in outs.items():
             self._need(hasattr(io, k), "unknown output %r" % (k,))
             self._need_tensor(v, self._out_dtype(k), "outs[%r]" % k)
@@ -534,21 +534,31 @@ class Analyzer:
         self._check(self.L.vamd_gather_blocks(self.h, C.byref(plan), W, _vp(streams.data_ptr()), streams.shape[2], _vp(out.data_ptr())))
         return out
 
-    def analyze_plan(self, plan, pcm_blocks, outs, ampmax_states):
-        """vamd_analyze_streams_mixed over a plan: pcm_blocks / outs = per size class (index 0 short, 1 long) the gathered
-        batch and its output dict; ampmax_states: cuda float32 [nstreams], updated in place."""
+    def analyze_plan(self, plan, pcm_blocks, outs, ampmax_states, streams=None):
+        """vamd_analyze_streams_mixed over a plan: outs = per size class (index 0 short, 1 long) the output dict;
+        ampmax_states: cuda float32 [nstreams], updated in place.  The blocks' samples: either pcm_blocks = per size class
+        the gathered batch (gather_blocks), or -- pcm_blocks None -- `streams`, the very [nstreams, ch, nsamples] tensor the
+        plan was made from, read in place through the plan's offsets (vamd_batch_io::pcm_src: no gathered copy)."""
         t = self.torch
         descs, ios = [], []
+        if pcm_blocks is None:
+            self._need_tensor(streams, t.float32, "streams")
+            self._need(streams.dim() == 3 and streams.shape[1] == self.channels and streams.shape[0] == plan.nstreams and
+                       streams.shape[2] % 4 == 0, "streams must be the [%d, %d, nsamples] tensor the plan was made from" % (plan.nstreams, self.channels))
         for W in (0, 1):
             d = _Desc()
             d.W, d.nblocks = W, plan.nblocks[W]
             d.lW, d.nW, d.blocktype, d.ampmax_in = plan.lW[W], plan.nW[W], plan.blocktype[W], None
             descs.append(d)
-            if plan.nblocks[W]:
+            if not plan.nblocks[W]:
+                ios.append(_IO())
+            elif pcm_blocks is None:
+                io = self._io(streams, outs[W], nb=plan.nblocks[W])
+                io.pcm_src, io.pcm_channel_stride = plan.src[W], streams.shape[2]
+                ios.append(io)
+            else:
                 self._need_tensor(pcm_blocks[W], t.float32, "pcm_blocks[%d]" % W, numel=plan.nblocks[W] * self.channels * self.blocksizes[W])
                 ios.append(self._io(pcm_blocks[W].reshape(plan.nblocks[W], self.channels, self.blocksizes[W]), outs[W]))
-            else:
-                ios.append(_IO())
         self._need_tensor(ampmax_states, t.float32, "ampmax_states", numel=plan.nstreams)
         self._bind_stream()
         self._check(self.L.vamd_analyze_streams_mixed(self.h, C.byref(descs[0]), C.byref(ios[0]), C.byref(descs[1]), C.byref(ios[1]),

@@ -167,17 +167,21 @@ __global__ __launch_bounds__(64 * VAMD_XF_WAVES) __attribute__((amdgpu_num_vgpr(
   int lW = 0, nW = 0;
   I2 rid[VAMD_XF_QPS(LOGN)];  // which run of bins each of this lane's bins belongs to: the same for every block
   if (peaks) xf_run_ids<LOGN>(P, run_of_bin, rid, tm);
+  // where a channel-block's samples start: packed [block][channel][n], or in place (a stream plan's offsets)
+  auto samples = [&](long cbi, long blk) -> const float * {
+    return d.src ? pcm + d.src[blk] + (cbi - blk * ch) * d.cstride : pcm + cbi * n;
+  };
   if (cb < ncb) {
     const long blk = (long)((unsigned)cb / (unsigned)ch);
     lW = d_lW(d, blk), nW = d_nW(d, blk);
-    pcm_fetch(tile, pcm + cb * n, n, tm);
+    pcm_fetch(tile, samples(cb, blk), n, tm);
   }
   for (; cb < ncb; cb += cstride) {
     transform_window(P, W, lW, nW, tile, L.A, pc, tm);
     if (cb + cstride < ncb) {  // next block, one ahead
       const long blk = (long)((unsigned)(cb + cstride) / (unsigned)ch);
       lW = d_lW(d, blk), nW = d_nW(d, blk);
-      pcm_fetch(tile, pcm + (cb + cstride) * n, n, tm);
+      pcm_fetch(tile, samples(cb + cstride, blk), n, tm);
     }
     float raw;
     // (logfft goes out as what the tone stage reads of it -- its peak over each run of bins of one octave line, nrp
@@ -1316,6 +1320,13 @@ static int prepare_run(vamd_ctx *c, const vamd_batch_desc *desc, const vamd_batc
   d.dbg = c->d_dbg;
   d.status = R->p.status;
   d.bad = c->d_bad;
+  d.src = nullptr;
+  d.cstride = 0;
+  if (io && io->pcm_src) {
+    if ((io->pcm_channel_stride & 3) || ((uintptr_t)io->pcm & 15)) return fail(c, VAMD_EINVAL, "pcm_src: pcm 16-byte aligned, pcm_channel_stride a multiple of 4");
+    d.src = (const long long *)io->pcm_src;
+    d.cstride = (long)io->pcm_channel_stride;
+  }
   return VAMD_OK;
 }
 
@@ -1716,6 +1727,16 @@ static int run_streams_mixed(vamd_ctx *c, const vamd_batch_desc *desc_short, con
   launch_transform(c, &R[0]);
   launch_transform(c, &R[1]);
   const float secs0 = (float)(c->B.bs[0] / 2) / (float)c->B.rate, secs1 = (float)(c->B.bs[1] / 2) / (float)c->B.rate;
+  // The chains' walk (a thread per stream, ~0.3 ms for a thousand streams of 130 blocks: latency, not load) feeds the tone
+  // seeds and nothing else of the masking stage, so where the tone chain runs on the side stream the walk goes there
+  // too, ahead of it, and the noise masks start at once on the main stream.
+  const bool chain_on_side = nstreams && c->overlap && (R[0].nb == 0 || R[0].nb * c->B.channels > 64) &&
+                             (R[1].nb == 0 || R[1].nb * c->B.channels > 64);
+  if (chain_on_side) {
+    (void)hipEventRecord(c->ev_fork, c->stream);
+    (void)hipStreamWaitEvent(c->side, c->ev_fork, 0);
+    s = c->side;
+  }
   if (nstreams)
     hipLaunchKernelGGL(k_ampmax_streams_mixed, dim3((unsigned)((nstreams + 63) / 64)), dim3(64), 0, s, c->B.channels, nstreams,
                        (const long long *)stream_start, (const int *)order, secs0, secs1, c->B.ampmax_att_per_sec, states,
@@ -1724,11 +1745,16 @@ static int run_streams_mixed(vamd_ctx *c, const vamd_batch_desc *desc_short, con
     hipLaunchKernelGGL(k_ampmax_stream_mixed, dim3(1), dim3(1), 0, s, c->B.channels, nblocks_total, (const int *)order, secs0,
                        secs1, c->B.ampmax_att_per_sec, *ampmax_state, R[0].p.local, R[1].p.local, R[0].p.ampin,
                        R[1].p.ampin, R[0].p.ampglob, R[1].p.ampglob, d_state);
+  s = c->stream;
   prof_mark(c, VAMD_ST_AMPMAX);
   R[0].d.ampmax_in = R[0].p.ampin;
   R[1].d.ampmax_in = R[1].p.ampin;
   launch_rest(c, &R[0], VAMD_LEVEL_FULL);
   launch_rest(c, &R[1], VAMD_LEVEL_FULL);
+  if (chain_on_side && R[0].nb == 0 && R[1].nb == 0) {  // (cannot happen -- nblocks_total > 0 -- but nothing may be left unjoined)
+    (void)hipEventRecord(c->ev_join, c->side);
+    (void)hipStreamWaitEvent(c->stream, c->ev_join, 0);
+  }
   if (c->profile) c->prof_runs++;
   HIP_TRY(c, hipGetLastError());
   if (!nstreams) {

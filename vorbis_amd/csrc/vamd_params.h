@@ -161,6 +161,9 @@ struct DescP {
   // ~1000 x over full scale; bad[0] counts such channel-blocks since vamd_input_status() last looked
   unsigned char *status;
   unsigned int *bad;
+  // blocks read in place (vamd_batch_io::pcm_src): block b, channel c at pcm + src[b] + c * cstride; null = packed
+  const long long *src;
+  long cstride;
 };
 
 // The input domain (include/vorbis_amd.h).  Above this spectral peak (dB re a full-scale sine: the reference's logfft
