@@ -196,9 +196,43 @@ VAMD_DEV void mdct_tpack_fill(float *tpack, const float *__restrict__ trig, int 
 // (mdct_tpack_fill) -- read out of the plain table at its stride of 4 << s floats, the 32 lanes of a load share
 // one or two LDS banks from the third stage on (16-way conflicts: a tenth of the stage's LDS time) -- and the
 // bit-reverse indices are computed, not fetched (P.bitrev_std).
-template <int LOGS = 0, int LOGN = 0, class Team = WaveTeam, bool PACKED = false>
+// The fold's operands of one lane for a block read straight out of HBM (k_mdct_only): x0.z, x0.x, x1.y, x1.w of the
+// reference's quads (lib/mdct.c:506-544) for each of the lane's trips over the n/4 pairs.  fold_fetch only issues the
+// loads: all of a frame's thirty-two words are in flight before the first is used.  (Measured round 4 and not kept:
+// holding the NEXT frame's operands across the butterflies -- 162 registers, twelve waves per CU instead of sixteen:
+// 312 against 328 M frames/s at 65 536 frames, 355 against 360 at 262 144; whole quads instead of the two words a pair
+// needs of each: no change.  The kernel sits at 4.0-4.4 TB/s, 65-70 % of what a copy reaches.)
+template <int LOGN>
+struct FoldOps {
+  static constexpr int NT = LOGN >= 8 ? (1 << LOGN) / 4 / 64 : 1;
+  float xa[NT], xb[NT], ya[NT], yb[NT];
+};
+template <int LOGN>
+VAMD_DEV void fold_fetch(FoldOps<LOGN> &o, const float *in) {
+  constexpr int n = 1 << LOGN, n2 = n >> 1, n4 = n >> 2, n8 = n >> 3;
+#pragma unroll
+  for (int k = 0; k < FoldOps<LOGN>::NT; k++) {
+    const int p = LANE + 64 * k;
+    const float *q0, *q1;
+    if (2 * (64 * k) < n8) {
+      q0 = in + n2 + n4 - 4 * (p + 1), q1 = in + n2 + n4 + 4 * p;
+    } else if (2 * (64 * k) < n2 - n8) {
+      q0 = in + n2 + n4 - 4 * (p + 1), q1 = in + 4 * (p - n8 / 2);
+    } else {
+      q0 = in + n - 4 * (p - (n2 - n8) / 2 + 1), q1 = in + 4 * (p - n8 / 2);
+    }
+    o.xa[k] = q0[2], o.xb[k] = q0[0], o.ya[k] = q1[1], o.yb[k] = q1[3];
+  }
+}
+
+// FOLD_AHEAD: the block is read straight out of HBM (k_mdct_only) -- every fold operand of the lane is fetched before the
+// first is used.  Written as one loop the fold waits for its four words eight times over (n = 2048: a frame spent 10 of
+// its 13 us there, and the kernel sat at the bytes its sixteen waves per CU keep in flight: 3.8 TB/s); the three regimes
+// change at multiples of a wave's stride for n >= 512, so which quarters a trip folds is known when it is compiled.
+template <int LOGS = 0, int LOGN = 0, class Team = WaveTeam, bool PACKED = false, bool FOLD_AHEAD = false>
 VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in0, float *w0, float *out0, PhaseClock &pc,
-                                int in_stride = 0, int w_stride = 0, int out_stride = 0, const Team &tm = Team()) {
+                                int in_stride = 0, int w_stride = 0, int out_stride = 0, const Team &tm = Team(),
+                                FoldOps<LOGN> *ahead = nullptr, const float *in_next = nullptr) {
   const int n = LOGN ? (1 << LOGN) : P.n, n2 = n >> 1, n4 = n >> 2, n8 = n >> 3;
   const int log2n = LOGN ? LOGN : P.log2n;
   const float *__restrict__ trig = P.trig;
@@ -216,6 +250,35 @@ VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in0, float *w0, fl
   // Pair p writes w2[2p], w2[2p+1]; the three loops differ in which input
   // quarter is folded with which sign.  x0[0],x0[2] / x1[0],x1[2] of the reference
   // are the .x,.z / .y,.w lanes of two aligned quads of the input.
+  if constexpr (FOLD_AHEAD && LOGN >= 9 && LOGN <= 11 && LOGS == 0) {  // (n = 4096: 64 operands per lane would spill)
+    // every operand of the lane first, then the arithmetic (`ahead`: a caller that fetched them earlier; `in_next`: the
+    // block whose operands it wants requested as soon as these are consumed)
+    constexpr int NT = FoldOps<LOGN>::NT;
+    float *w2 = w0 + n2;
+    FoldOps<LOGN> mine;
+    if (!ahead) {
+      fold_fetch<LOGN>(mine, in0);
+      ahead = &mine;
+    }
+#pragma unroll
+    for (int k = 0; k < NT; k++) {
+      const int p = LANE + 64 * k;
+      const F2 T = *(const F2 *)(trig + n2 - 2 * (p + 1));
+      float r0, r1;
+      if (2 * (64 * k) < n8) {
+        r0 = ahead->xa[k] + ahead->ya[k], r1 = ahead->xb[k] + ahead->yb[k];
+      } else if (2 * (64 * k) < n2 - n8) {
+        r0 = ahead->xa[k] - ahead->ya[k], r1 = ahead->xb[k] - ahead->yb[k];
+      } else {
+        r0 = -ahead->xa[k] - ahead->ya[k], r1 = -ahead->xb[k] - ahead->yb[k];
+      }
+      F2 o;
+      o.x = r1 * T.y + r0 * T.x;
+      o.y = r1 * T.x - r0 * T.y;
+      *(F2 *)(w2 + VAMD_PW(2 * p)) = o;
+    }
+    if (in_next) fold_fetch<LOGN>(*ahead, in_next);
+  } else
   TEAM_EACH(pp, n4 << LOGS, tm) {
     VAMD_MDCT_SPLIT(pp, log2n - 2)
     const int p = g_;

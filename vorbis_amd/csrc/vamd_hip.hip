@@ -130,7 +130,7 @@ __global__ __launch_bounds__(64 * VAMD_MD_WAVES) void k_mdct_only(XformP G, int 
   PhaseClock pc;
   pc.start(nullptr);
   for (long f = (long)blockIdx.x * nw + (threadIdx.x >> 6); f < nframes; f += (long)gridDim.x * nw) {
-    mdct_forward_wave<0, LOGN, WaveTeam, LOGN != 0>(P, in + f * n, B, B, pc);
+    mdct_forward_wave<0, LOGN, WaveTeam, LOGN != 0, true>(P, in + f * n, B, B, pc);
     WAVE_FOR(q, n2 >> 2)((F4 *)(out + f * n2))[q] = ((const F4 *)B)[q];
     WAVE_SYNC();
   }
