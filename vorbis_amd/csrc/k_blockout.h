@@ -1,7 +1,7 @@
 // k_blockout.h -- the block-size decisions of vorbis_analysis_blockout() (reference lib/block.c:534-693) and
 // the integer half of _ve_envelope_search() / _ve_envelope_mark() (lib/envelope.c:241-353), device-resident:
-// one THREAD per stream walks its whole mark sequence and emits the stream's block list, so that a set of
-// streams goes from PCM to analysed blocks without a host round trip per block.
+// one WAVE per stream walks its whole mark sequence (sixty-four marks per look) and emits the stream's block list, so
+// that a set of streams goes from PCM to analysed blocks without a host round trip per block.
 //
 // The reference keeps a sliding PCM buffer and shifts every position by the block advance after each block
 // (lib/block.c:649-685, _ve_envelope_shift); here every position is an ABSOLUTE sample index into the stream's
@@ -72,6 +72,34 @@ VAMD_DEV int plan_stream(const BlockoutP &B, const unsigned char *marks, Planned
     // ---- _ve_envelope_search's cursor walk, lib/envelope.c:262-325
     const long testW = centerW + B.bs[W] / 4 + B.bs[1] / 2 + B.bs[0] / 4;
     int bp = -1;
+#if VAMD_GPU
+    // The same walk sixty-four steps at a time (every lane of the wave runs plan_stream; all its values are
+    // wave-uniform): lane l looks at j = base + l * step.  The walk stops at the first j that is past the horizon
+    // (j >= testW: long block, cursor stays on the last j visited before it) or marked beyond the block's centre (short
+    // block, cursor and curmark on it); a j at or past current - step is not visited at all, and a walk that runs out
+    // of them leaves the cursor on the last one it did visit.
+    for (long base = cursor;; base += 64 * step) {
+      const long j = base + (long)LANE * step;
+      const bool visited = j < current - step;  // (the visited lanes are a prefix of the wave)
+      const bool past = visited && j >= testW;
+      const bool marked = visited && !past && marks[j / step] && j > centerW;
+      const unsigned long long stop = __ballot(past || marked);
+      if (stop) {
+        const int l = __builtin_ctzll(stop);
+        if ((__ballot(past) >> l) & 1) {
+          bp = 1;
+          if (l > 0) cursor = base + (long)(l - 1) * step;  // (else: where the previous trip, or the caller, left it)
+        } else {
+          bp = 0;
+          cursor = curmark = base + (long)l * step;
+        }
+        break;
+      }
+      const int nvis = __builtin_popcountll(__ballot(visited));
+      if (nvis > 0) cursor = base + (long)(nvis - 1) * step;
+      if (nvis < 64) break;  // ran out of steps: bp stays -1
+    }
+#else
     for (long j = cursor; j < current - step; j += step) {
       if (j >= testW) {
         bp = 1;
@@ -84,6 +112,7 @@ VAMD_DEV int plan_stream(const BlockoutP &B, const unsigned char *marks, Planned
         break;
       }
     }
+#endif
     if (bp < 0) break;  // "not enough data currently to search for a full long block", lib/block.c:558-560
     const int nW = B.bs[0] == B.bs[1] ? 0 : bp;
     const long centerNext = centerW + B.bs[W] / 4 + B.bs[nW] / 4;
@@ -96,11 +125,20 @@ VAMD_DEV int plan_stream(const BlockoutP &B, const unsigned char *marks, Planned
       // _ve_envelope_mark, lib/envelope.c:329-353 (W == 0: both neighbours count as short)
       const long beginW = centerW - B.bs[0] / 4 - B.bs[0] / 4, endW = centerW + B.bs[0] / 4 + B.bs[0] / 4;
       int hit = curmark >= beginW && curmark < endW;
+#if VAMD_GPU
+      for (long i0 = beginW / step; !hit && i0 < endW / step; i0 += 64) {  // (a short block's span is a handful of steps: one trip)
+        const long i = i0 + LANE;
+        hit = __ballot(i < endW / step && i >= 0 && i < last && marks[i]) != 0;
+      }
+#else
       for (long i = beginW / step; !hit && i < endW / step; i++) hit = i >= 0 && i < last && marks[i];
+#endif
       blocktype = hit ? 0 /* BLOCKTYPE_IMPULSE */ : 1 /* BLOCKTYPE_PADDING */;
     }
-    out[n].kind = W | (lW << 1) | (nW << 2) | (blocktype << 3);
-    out[n].begin = (int)(centerW - B.bs[W] / 2);
+    if (LANE == 0) {
+      out[n].kind = W | (lW << 1) | (nW << 2) | (blocktype << 3);
+      out[n].begin = (int)(centerW - B.bs[W] / 2);
+    }
     n++;
     if (W) n1++; else n0++;
     // ---- advance, lib/block.c:649-685 (positions stay absolute: nothing to shift)

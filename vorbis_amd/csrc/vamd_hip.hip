@@ -797,9 +797,9 @@ __global__ __launch_bounds__(64) void k_plan_streams(BlockoutP B, long nstreams,
   const unsigned char *f = flags + s * B.nsteps;
   for (long p = threadIdx.x; p < B.nsteps + 4; p += 64) marks[p] = p < last ? (unsigned char)mark_at(f, last, p) : 0;
   __syncthreads();
+  int n0 = 0, n1 = 0;
+  plan_stream(B, marks, blocks + s * B.maxblocks, &n0, &n1);  // (the whole wave: it looks at 64 marks at a time)
   if (threadIdx.x == 0) {
-    int n0 = 0, n1 = 0;
-    plan_stream(B, marks, blocks + s * B.maxblocks, &n0, &n1);
     counts[2 * s] = n0;
     counts[2 * s + 1] = n1;
   }
@@ -811,22 +811,35 @@ struct PlanOut {
   long long *src[2];
   int *order;
 };
-__global__ void k_plan_emit(BlockoutP B, long nstreams, long stream_stride, const PlannedBlock *__restrict__ blocks,
-                            const int *__restrict__ counts, const long long *__restrict__ base,
-                            const long long *__restrict__ start, PlanOut O) {
-  const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
+// a wave per stream: lane l takes the stream's blocks l, l + 64, ...; a block's place in its size class's batch is the
+// class's base plus the blocks of that class ahead of it in the stream -- a count over the lower lanes' ballot bits
+// (a thread per stream walking its ~140 blocks took 0.16 ms for a thousand streams: sixteen waves on the whole chip)
+__global__ __launch_bounds__(64) void k_plan_emit(BlockoutP B, long nstreams, long stream_stride, const PlannedBlock *__restrict__ blocks,
+                                                  const int *__restrict__ counts, const long long *__restrict__ base,
+                                                  const long long *__restrict__ start, PlanOut O) {
+  const long s = blockIdx.x;
   if (s >= nstreams) return;
   const int n = counts[2 * s] + counts[2 * s + 1];
   long long at[2] = {base[2 * s], base[2 * s + 1]};
-  for (int k = 0; k < n; k++) {
-    const PlannedBlock b = blocks[s * B.maxblocks + k];
+  const unsigned long long below = (1ull << LANE) - 1ull;
+  for (int k0 = 0; k0 < n; k0 += 64) {
+    const int k = k0 + LANE;
+    const bool live = k < n;
+    PlannedBlock b;
+    b.kind = 0, b.begin = 0;
+    if (live) b = blocks[s * B.maxblocks + k];
     const int W = b.kind & 1;
-    const long long i = at[W]++;
-    O.lW[W][i] = (b.kind >> 1) & 1;
-    O.nW[W][i] = (b.kind >> 2) & 1;
-    O.bt[W][i] = (b.kind >> 3) & 1;
-    O.src[W][i] = (long long)s * stream_stride + b.begin;
-    O.order[start[s] + k] = (W << 30) | (int)i;
+    const unsigned long long is_long = __ballot(live && W), is_short = __ballot(live && !W);
+    if (live) {
+      const long long i = at[W] + __builtin_popcountll((W ? is_long : is_short) & below);
+      O.lW[W][i] = (b.kind >> 1) & 1;
+      O.nW[W][i] = (b.kind >> 2) & 1;
+      O.bt[W][i] = (b.kind >> 3) & 1;
+      O.src[W][i] = (long long)s * stream_stride + b.begin;
+      O.order[start[s] + k] = (W << 30) | (int)i;
+    }
+    at[0] += __builtin_popcountll(is_short);
+    at[1] += __builtin_popcountll(is_long);
   }
 }
 
@@ -879,6 +892,8 @@ struct vamd_ctx {
   // pinned staging for the per-block host API
   void *h_stage = nullptr;
   size_t h_stage_bytes = 0;
+  void *h_plan = nullptr;  // pinned: a stream plan's per-stream bases on their way up (vamd_plan_streams)
+  size_t h_plan_bytes = 0;
   // optional per-stage timing (vamd_profile): one event before each stage + one after the last
   unsigned long long *d_dbg = nullptr;  // 80 phase-stopwatch slots when armed
   bool profile = false;
@@ -1046,6 +1061,7 @@ void vamd_destroy(vamd_ctx *c) {
     for (int i = 0; i < vamd_ctx::WS_COUNT; i++)
       if (c->ws[W][i].p) (void)hipFree(c->ws[W][i].p);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
+  if (c->h_plan) (void)hipHostFree(c->h_plan);
   if (c->d_dbg) (void)hipFree(c->d_dbg);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -2132,7 +2148,16 @@ int vamd_plan_streams(vamd_ctx *c, const float *pcm, long stream_stride, long ch
   for (long i = 0; i < nstreams; i++)
     if (counts[2 * i] < 0 || counts[2 * i + 1] < 0 || (long)counts[2 * i] + counts[2 * i + 1] > B.maxblocks)
       return fail(c, VAMD_EFAULT, "stream plan: a block count outside its bound (the planning kernel did not run to completion)");
-  std::vector<long long> base((size_t)3 * nstreams + 1);  // [2s + W] then start[nstreams + 1]
+  // [2s + W] then start[nstreams + 1]; pinned and the context's own, so that its upload needs no wait: the next plan on this
+  // context cannot write it before its own count read-back, which is queued behind the upload, has come home
+  if (c->h_plan_bytes < ((size_t)3 * nstreams + 1) * sizeof(long long)) {
+    if (c->h_plan) HIP_TRY(c, hipHostFree(c->h_plan));
+    c->h_plan = nullptr;
+    c->h_plan_bytes = 0;
+    HIP_TRY(c, hipHostMalloc(&c->h_plan, ((size_t)3 * nstreams + 1) * sizeof(long long), hipHostMallocDefault));
+    c->h_plan_bytes = ((size_t)3 * nstreams + 1) * sizeof(long long);
+  }
+  long long *base = (long long *)c->h_plan;
   long long tot[2] = {0, 0}, all = 0;
   for (long i = 0; i < nstreams; i++) {
     base[2 * i] = tot[0];
@@ -2144,7 +2169,7 @@ int vamd_plan_streams(vamd_ctx *c, const float *pcm, long stream_stride, long ch
   }
   base[3 * nstreams] = all;
   if (tot[0] > 0x3fffffffLL || tot[1] > 0x3fffffffLL) return fail(c, VAMD_EINVAL, "plan too large: order[] holds 30-bit indices");
-  HIP_TRY(c, hipMemcpyAsync(v_base, base.data(), base.size() * sizeof(long long), hipMemcpyHostToDevice, s));
+  HIP_TRY(c, hipMemcpyAsync(v_base, base, ((size_t)3 * nstreams + 1) * sizeof(long long), hipMemcpyHostToDevice, s));
   // descriptor arrays: per class lW, nW, blocktype (int32) and src (int64); then order
   void *v_desc, *v_order;
   const size_t per[2] = {(size_t)tot[0], (size_t)tot[1]};
@@ -2162,11 +2187,10 @@ int vamd_plan_streams(vamd_ctx *c, const float *pcm, long stream_stride, long ch
     O.bt[W] = p32, p32 += per[W];
   }
   O.order = (int *)v_order;
-  hipLaunchKernelGGL(k_plan_emit, dim3((unsigned)((nstreams + 63) / 64)), dim3(64), 0, s, B, nstreams, stream_stride,
+  hipLaunchKernelGGL(k_plan_emit, dim3((unsigned)nstreams), dim3(64), 0, s, B, nstreams, stream_stride,
                      (const PlannedBlock *)v_blocks, (const int *)v_counts, (const long long *)v_base,
                      (const long long *)v_base + 2 * nstreams, O);
   HIP_TRY(c, hipGetLastError());
-  HIP_TRY(c, hipStreamSynchronize(s));  // `base` (host) must outlive its upload
   for (int W = 0; W < 2; W++) {
     plan->nblocks[W] = tot[W];
     plan->lW[W] = O.lW[W];
