@@ -224,6 +224,38 @@ def test_gpu_batch_of_streams():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name,ragged", [("44k_stereo_q4", 0), ("44k_mono_q5", 7), ("44k_stereo_q9", 37)])
+def test_gpu_big_batch_takes_the_tiled_kernels(name, ragged):
+    """Above 65 536 step-streams the band amplitudes and the trigger bits come from LDS-tiled kernels (k_env_amp_tiled: 32
+    steps of a channel per workgroup; k_env_bits_tiled: 64 steps of a stream per wave); below it, from the thread-per-item
+    forms.  The same streams, gated so that both flags fire, once as one big batch and once stream by stream, with step
+    counts that leave ragged last tiles, and in two calls with the state carried: identical flags and identical states."""
+    import torch
+    an = vorbis_amd.Analyzer(blob_of(name), 0)
+    ch = an.channels
+    ns, steps = 96, 700 + ragged
+    ln = (steps - 1) * 64 + 128
+    rng = np.random.default_rng(5150 + ragged)
+    t = np.arange(ln)
+    gate = np.where(((t[None, :] + 997 * np.arange(ns)[:, None]) % (5000 + 13 * np.arange(ns)[:, None])) < 500, 0.6, 0.001)
+    pcm = ((rng.random((ns, ch, ln), dtype=np.float32) - 0.5) * gate[:, None, :]).astype(np.float32)
+    dev = torch.from_numpy(pcm).cuda()
+    assert ns * steps > 65536
+    big, st_big = an.envelope_search_batch(dev, steps)
+    big = big.cpu().numpy()
+    assert (big & 1).any() and (big & 2).any()
+    for k in range(0, ns, 7):
+        one, st_one = an.envelope_search_batch(dev[k:k + 1].contiguous(), steps)      # 700 step-streams: the small kernels
+        assert np.array_equal(one.cpu().numpy()[0], big[k]), k
+        assert torch.equal(st_one[0], st_big[k]), k
+    first = 333
+    r1, st = an.envelope_search_batch(dev[:, :, :(first - 1) * 64 + 128].contiguous(), first)
+    r2, st = an.envelope_search_batch(dev[:, :, first * 64:].contiguous(), steps - first, states=st)
+    assert np.array_equal(np.concatenate([r1.cpu().numpy(), r2.cpu().numpy()], axis=1), big)
+    assert torch.equal(st, st_big)
+
+
+@pytest.mark.gpu
 def test_gpu_envelope_argument_errors():
     an = vorbis_amd.Analyzer(blob_of("44k_stereo_q4"), 0)
     assert an.envelope_geometry() == (128, 64)

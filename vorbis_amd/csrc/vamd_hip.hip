@@ -731,6 +731,38 @@ __global__ void k_env_amp(EnvP E, long nsc /* streams x channels */, long nsteps
   amp[(sc * (VAMD_VE_AMP_HIST + nsteps) + VAMD_VE_AMP_HIST + j) * 8 + b] = env_band_amp(E, raw + it * VAMD_VE_SPREAD, decay, b);
 }
 
+// The same for big batches, a tile of VAMD_ENV_TJ steps of one (stream, channel) per workgroup: the tile's near-DC terms
+// (with the 29 before it that the replay reaches back to) and its raw dB pairs are staged in LDS once, the decay of a
+// step is replayed once (a lane per step) instead of once per band, and the band lanes read both out of LDS.  (The
+// thread-per-band form above has every step's eight lanes fetch the same 44 terms and replay the same 44 adds, and
+// its 32 raw values come seven overlapping times out of L2: 0.71 ms for 4 M channel-steps, twice its issue time.)
+#define VAMD_ENV_TJ 32
+#define VAMD_ENV_BACK (2 * VAMD_VE_NEARDC - 1)
+__global__ __launch_bounds__(8 * VAMD_ENV_TJ) void k_env_amp_tiled(EnvP E, long nsc, long nsteps,
+                                                                   const vamd_envelope_state *__restrict__ st, int ch,
+                                                                   const float *__restrict__ near, const float *__restrict__ raw,
+                                                                   float *__restrict__ amp) {
+  __shared__ float s_near[VAMD_ENV_TJ + VAMD_ENV_BACK + 3];
+  __shared__ float s_decay[VAMD_ENV_TJ];
+  __shared__ __attribute__((aligned(16))) float s_raw[VAMD_ENV_TJ * VAMD_VE_SPREAD];
+  const long tiles = (nsteps + VAMD_ENV_TJ - 1) / VAMD_ENV_TJ;
+  const long sc = blockIdx.x / tiles, j0 = (blockIdx.x - sc * tiles) * VAMD_ENV_TJ;
+  const int cnt = nsteps - j0 < VAMD_ENV_TJ ? (int)(nsteps - j0) : VAMD_ENV_TJ;
+  const float *nearp = near + sc * (VAMD_VE_NEAR_HIST + nsteps) + VAMD_VE_NEAR_HIST + j0;  // this tile's first term
+  for (int i = threadIdx.x; i < cnt + VAMD_ENV_BACK; i += blockDim.x) s_near[i] = nearp[i - VAMD_ENV_BACK];
+  {
+    const F4 *src = (const F4 *)(raw + (sc * nsteps + j0) * VAMD_VE_SPREAD);
+    for (int i = threadIdx.x; i < cnt * (VAMD_VE_SPREAD / 4); i += blockDim.x) ((F4 *)s_raw)[i] = src[i];
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < cnt) s_decay[threadIdx.x] = env_decay(s_near + VAMD_ENV_BACK + threadIdx.x, (long)st[sc / ch].steps + j0 + threadIdx.x);
+  __syncthreads();
+  const int jj = threadIdx.x >> 3, b = threadIdx.x & 7;
+  if (jj >= cnt) return;
+  float *out = amp + (sc * (VAMD_VE_AMP_HIST + nsteps) + VAMD_VE_AMP_HIST + j0 + jj) * 8 + b;
+  *out = b >= VAMD_VE_BANDS ? 0.f : env_band_amp(E, s_raw + jj * VAMD_VE_SPREAD, s_decay[jj], b);
+}
+
 // sixteen lanes per (stream, step): the (channel, band) pairs are dealt round them and their trigger bits OR-ed
 // together (a thread per step walked 14 pairs x 12 dependent loads: 47 us for the sixteen steps of one blockout call)
 __global__ void k_env_bits(EnvP E, int ch, long nstreams, long nsteps, const float *__restrict__ amp,
@@ -764,6 +796,39 @@ __global__ void k_env_bits_batch(EnvP E, int ch, long nstreams, long nsteps, con
   const float *a[VAMD_MAX_CH];
   for (int c = 0; c < ch; c++) a[c] = amp + ((s * ch + c) * (VAMD_VE_AMP_HIST + nsteps) + VAMD_VE_AMP_HIST + j) * 8;
   bits[t] = env_trigger_bits(E, a, ch, 8);
+}
+
+// ... and with the amplitudes staged: a wave takes 64 consecutive steps of one stream, copies the 64 + 13 rows of every
+// channel they and their histories cover into LDS once (rows padded to nine floats: lanes a step apart read a row apart),
+// and every lane forms its step's bits out of them.  (A thread per step fetched its 14 (channel, band) histories -- 196
+// words, 13 of every 14 of them its neighbour's too -- out of L2: 0.67 ms for 2 M steps, five times its issue time.)
+#define VAMD_ENV_BROWS (64 + VAMD_VE_MAXSTRETCH + 1)
+__global__ __launch_bounds__(256) void k_env_bits_tiled(EnvP E, int ch, long nstreams, long nsteps, const float *__restrict__ amp,
+                                                        uint32_t *__restrict__ bits) {
+  float *tile = (float *)vamd_smem + (size_t)(threadIdx.x >> 6) * ch * VAMD_ENV_BROWS * 9;  // [ch][BROWS][9]
+  const long tiles = (nsteps + 63) / 64;
+  const long item = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (item >= nstreams * tiles) return;  // (waves are independent: no workgroup barrier below)
+  const long s = item / tiles, j0 = (item - s * tiles) * 64;
+  const int cnt = nsteps - j0 < 64 ? (int)(nsteps - j0) : 64;
+  const int back = VAMD_VE_MAXSTRETCH + 1;  // rows a step reaches back to: 13 <= VAMD_VE_AMP_HIST
+  for (int c = 0; c < ch; c++) {
+    const F4 *src = (const F4 *)(amp + ((s * ch + c) * (VAMD_VE_AMP_HIST + nsteps) + VAMD_VE_AMP_HIST + j0 - back) * 8);
+    float *dst = tile + (size_t)c * VAMD_ENV_BROWS * 9;
+    for (int i = LANE; i < (cnt + back) * 2; i += 64) {
+      const F4 v = src[i];
+      float *d = dst + (i >> 1) * 9 + (i & 1) * 4;
+      d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
+    }
+  }
+  WAVE_SYNC();
+  if (LANE < cnt) {
+    uint32_t my = 0;
+    for (int c = 0; c < ch; c++)
+      for (int b = 0; b < VAMD_VE_BANDS; b++)
+        my |= env_trigger_bits_one(E, tile + (size_t)c * VAMD_ENV_BROWS * 9 + (back + LANE) * 9 + b, 9, b);
+    bits[s * nsteps + j0 + LANE] = my;
+  }
 }
 
 // the stretch recurrence, one wave per stream; then the state's histories roll forward
@@ -2037,7 +2102,13 @@ static int envelope_search_batch(vamd_ctx *c, const float *pcm, long stream_stri
     hipLaunchKernelGGL(k_env_spectrum, dim3((unsigned)(groups < cap ? groups : cap)), dim3(64 * VAMD_ENV_WAVES), lds, s, E,
                        ch, nstreams, nsteps, pcm, stream_stride, channel_stride, near, raw, bad);
   }
-  {
+  static const bool env_untiled = getenv("VAMD_ENV_UNTILED") != nullptr;  // (measurement aid: the thread-per-item forms)
+  const bool big = nstreams * nsteps > 65536 && !env_untiled;
+  if (big) {
+    const long tiles = (nsteps + VAMD_ENV_TJ - 1) / VAMD_ENV_TJ;
+    hipLaunchKernelGGL(k_env_amp_tiled, dim3((unsigned)(nsc * tiles)), dim3(8 * VAMD_ENV_TJ), 0, s, E, nsc, nsteps, states, ch,
+                       near, raw, amp);
+  } else {
     const long t = nsc * nsteps * 8;
     hipLaunchKernelGGL(k_env_amp, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, E, nsc, nsteps, states, ch,
                        near, raw, amp);
@@ -2045,7 +2116,11 @@ static int envelope_search_batch(vamd_ctx *c, const float *pcm, long stream_stri
   if (nstreams * nsteps <= 65536)
     hipLaunchKernelGGL(k_env_bits, dim3((unsigned)((nstreams * nsteps * 16 + 255) / 256)), dim3(256), 0, s, E, ch, nstreams, nsteps,
                        amp, bits);
-  else
+  else if (!env_untiled) {
+    const long items = nstreams * ((nsteps + 63) / 64);
+    hipLaunchKernelGGL(k_env_bits_tiled, dim3((unsigned)((items + 3) / 4)), dim3(256), (size_t)4 * ch * VAMD_ENV_BROWS * 9 * 4, s, E, ch,
+                       nstreams, nsteps, amp, bits);
+  } else
     hipLaunchKernelGGL(k_env_bits_batch, dim3((unsigned)((nstreams * nsteps + 255) / 256)), dim3(256), 0, s, E, ch, nstreams,
                        nsteps, amp, bits);
   hipLaunchKernelGGL(k_env_walk, dim3((unsigned)nstreams), dim3(64), 0, s, ch, nstreams, nsteps, bits, near, amp,
