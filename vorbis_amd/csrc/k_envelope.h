@@ -47,13 +47,16 @@ template <int LOGS>
 VAMD_DEV void env_spectrum_wave(const EnvP &E, const float *__restrict__ pcm, int count, float *A, float *Wk,
                                 float *spec, float *__restrict__ near_out, float *__restrict__ raw_out,
                                 PhaseClock &pc, unsigned int *bad = nullptr) {
-  const int n = E.mdct.n, n2 = n >> 1, ln = E.mdct.log2n;
+  // (the detector's transform is 128 points whatever the setup -- vamd_bind refuses anything else -- so its size is a
+  // compile-time constant here as the block transforms' are in k_transform: loop counts, strides and index arithmetic
+  // fold away; the stage is bound by vector issue)
+  constexpr int ln = 7, n = 1 << ln, n2 = n >> 1;
   WAVE_FOR(k, n << LOGS) {
     const int t = k >> ln, i = k & (n - 1);
     A[k] = t < count ? pcm[t * E.searchstep + i] * E.win[i] : 0.f;
   }
   WAVE_SYNC();
-  mdct_forward_wave<LOGS>(E.mdct, A, Wk, spec, pc, n, n2 + VAMD_PW_SIZE(n2), n2);
+  mdct_forward_wave<LOGS, ln>(E.mdct, A, Wk, spec, pc, n, n2 + VAMD_PW_SIZE(n2), n2);
   WAVE_FOR(t, count) {
     // float temp=vec[0]*vec[0]+.7*vec[1]*vec[1]+.2*vec[2]*vec[2];  the literals make it fp64
     const float v0 = spec[t * n2], v1 = spec[t * n2 + 1], v2 = spec[t * n2 + 2];
