@@ -43,14 +43,36 @@ namespace vamd {
 //   count  steps actually wanted (<= 2^LOGS; the rest of the slots compute on zeros, unstored)
 //   A LDS [n] per step, Wk LDS [n/2 + VAMD_PW_SIZE(n/2)] per step, spec LDS [n/2] per step
 //   near_out [count] the near-DC terms `temp`;  raw_out [count][n/4]  todB(re^2+im^2)*.5f before limiting
+// a lane's samples of 2^LOGS consecutive steps (lane l holds k = l + 64 m: step k >> 7, sample k & 127), fetched by the
+// caller one item ahead of the transform that consumes them (k_env_spectrum); steps past `count` read as zeros
+template <int LOGS>
+struct EnvSamples {
+  float v[(128 << LOGS) / 64];
+};
+template <int LOGS>
+VAMD_DEV void env_fetch(EnvSamples<LOGS> &x, const float *__restrict__ pcm, int count, int searchstep) {
+#pragma unroll
+  for (int m = 0; m < (128 << LOGS) / 64; m++) {
+    const int k = LANE + 64 * m, t = k >> 7, i = k & 127;
+    x.v[m] = t < count ? pcm[t * searchstep + i] : 0.f;
+  }
+}
+
 template <int LOGS>
 VAMD_DEV void env_spectrum_wave(const EnvP &E, const float *__restrict__ pcm, int count, float *A, float *Wk,
                                 float *spec, float *__restrict__ near_out, float *__restrict__ raw_out,
-                                PhaseClock &pc, unsigned int *bad = nullptr) {
+                                PhaseClock &pc, unsigned int *bad = nullptr, const EnvSamples<LOGS> *pre = nullptr) {
   // (the detector's transform is 128 points whatever the setup -- vamd_bind refuses anything else -- so its size is a
   // compile-time constant here as the block transforms' are in k_transform: loop counts, strides and index arithmetic
   // fold away; the stage is bound by vector issue)
   constexpr int ln = 7, n = 1 << ln, n2 = n >> 1;
+#if VAMD_GPU
+  if (pre) {  // the samples are already in registers; a lane's window values are two (i = LANE, LANE + 64)
+    const float w0 = E.win[LANE], w1 = E.win[LANE + 64];
+#pragma unroll
+    for (int m = 0; m < (n << LOGS) / 64; m++) A[LANE + 64 * m] = pre->v[m] * (m & 1 ? w1 : w0);
+  } else
+#endif
   WAVE_FOR(k, n << LOGS) {
     const int t = k >> ln, i = k & (n - 1);
     A[k] = t < count ? pcm[t * E.searchstep + i] * E.win[i] : 0.f;

@@ -693,7 +693,7 @@ __global__ void k_env_prolog(int ch, long nstreams, long nsteps, const vamd_enve
 #define VAMD_ENV_LOGS 2
 #define VAMD_ENV_STEPS (1 << VAMD_ENV_LOGS)
 #define VAMD_ENV_WAVES 4
-__global__ __launch_bounds__(64 * VAMD_ENV_WAVES) void k_env_spectrum(EnvP E, int ch, long nstreams, long nsteps,
+__global__ __launch_bounds__(64 * VAMD_ENV_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_env_spectrum(EnvP E, int ch, long nstreams, long nsteps,
                                                                       const float *__restrict__ pcm, long stream_stride,
                                                                       long channel_stride, float *__restrict__ near,
                                                                       float *__restrict__ raw, unsigned int *bad) {
@@ -704,14 +704,37 @@ __global__ __launch_bounds__(64 * VAMD_ENV_WAVES) void k_env_spectrum(EnvP E, in
   PhaseClock pc;
   pc.start(nullptr);
   const long groups = (nsteps + VAMD_ENV_STEPS - 1) / VAMD_ENV_STEPS, items = nstreams * ch * groups;
-  for (long it = (long)blockIdx.x * VAMD_ENV_WAVES + wave; it < items; it += (long)gridDim.x * VAMD_ENV_WAVES) {
-    const long sc = it / groups, j = (it - sc * groups) * VAMD_ENV_STEPS;
+  // an item's samples are requested while the previous item is in its transform (a wave lives for ~130 items and has
+  // three neighbours on its SIMD: the trip to memory at the head of every item was a fifth of its time)
+  auto where = [&](long it, long &sc, long &j, int &count) -> const float * {
+    sc = it / groups;
+    j = (it - sc * groups) * VAMD_ENV_STEPS;
     const long s = sc / ch;
     const int c = (int)(sc - s * ch);
-    const int count = nsteps - j < VAMD_ENV_STEPS ? (int)(nsteps - j) : VAMD_ENV_STEPS;
-    env_spectrum_wave<VAMD_ENV_LOGS>(E, pcm + s * stream_stride + c * channel_stride + j * E.searchstep, count, A, Wk,
-                                     spec, near + sc * (VAMD_VE_NEAR_HIST + nsteps) + VAMD_VE_NEAR_HIST + j,
-                                     raw + (sc * nsteps + j) * VAMD_VE_SPREAD, pc, bad);
+    count = nsteps - j < VAMD_ENV_STEPS ? (int)(nsteps - j) : VAMD_ENV_STEPS;
+    return pcm + s * stream_stride + c * channel_stride + j * E.searchstep;
+  };
+  const long stride = (long)gridDim.x * VAMD_ENV_WAVES;
+  long it = (long)blockIdx.x * VAMD_ENV_WAVES + wave;
+  EnvSamples<VAMD_ENV_LOGS> cur, nxt;
+  long sc, j;
+  int count;
+  const float *src = nullptr;
+  if (it < items) {
+    src = where(it, sc, j, count);
+    env_fetch<VAMD_ENV_LOGS>(cur, src, count, E.searchstep);
+  }
+  for (; it < items; it += stride) {
+    long sc2 = 0, j2 = 0;
+    int count2 = 0;
+    const float *src2 = nullptr;
+    if (it + stride < items) {
+      src2 = where(it + stride, sc2, j2, count2);
+      env_fetch<VAMD_ENV_LOGS>(nxt, src2, count2, E.searchstep);
+    }
+    env_spectrum_wave<VAMD_ENV_LOGS>(E, src, count, A, Wk, spec, near + sc * (VAMD_VE_NEAR_HIST + nsteps) + VAMD_VE_NEAR_HIST + j,
+                                     raw + (sc * nsteps + j) * VAMD_VE_SPREAD, pc, bad, &cur);
+    cur = nxt, sc = sc2, j = j2, count = count2, src = src2;
   }
 }
 
