@@ -1556,8 +1556,13 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_
       static const int noise_cap = getenv("VAMD_NOISE_TEAMS") ? atoi(getenv("VAMD_NOISE_TEAMS")) : 0;  // (measurement aid)
       if (noise_cap > 0) {
         if (per_cu > noise_cap) per_cu = noise_cap;
-      } else if (overlap && per_cu > 24 / nw) {
-        per_cu = 24 / nw > 0 ? 24 / nw : 1;
+      } else if (overlap) {
+        // ... and where the tone chain carries its own last step (the fold as a launch of its own: the masks-only level,
+        // bitrate-managed blocks) it needs half the CU to finish beside the noise mask: four teams.  65 536 stereo blocks
+        // at the masks-only level: noise + visible tone tail 1.17 + 0.80 ms with seven teams, 1.25 + 0.64 with six,
+        // 1.38 + 0.60 with five, 1.63 + 0.08 with four.
+        const long cap = (fold_in_floor ? 24 : 16) / nw;
+        if (per_cu > cap) per_cu = cap > 0 ? cap : 1;
       }
       if (per_cu < 1) per_cu = 1;
       const unsigned grid = (unsigned)((long)gcb < per_cu * c->num_cus ? (long)gcb : per_cu * c->num_cus);
