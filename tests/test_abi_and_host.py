@@ -269,3 +269,26 @@ def test_abi_version_matches_the_header():
     L.vamd_abi_version.restype = C.c_int
     assert L.vamd_abi_version() == want
     assert "VAMD_EDOMAIN" in hdr and vorbis_amd.VAMD_EDOMAIN == int(re.search(r"#define VAMD_EDOMAIN\s+\((-\d+)\)", hdr).group(1))
+
+
+def test_bench_rooflines_read_the_committed_profiles():
+    """bench.py's traffic and vector-issue figures come from the committed counter passes and are withheld when the sources
+    have changed since (source hash).  At a commit whose profiles were regenerated they must load, scale with the unit count
+    and stay inside what they describe; a stale profile must say so instead of reporting a number."""
+    import bench
+    stage_ms = {"transform": 1.47, "noisemask": 2.49, "tonemask": 0.46, "floor": 1.93, "couple": 0.47}
+    v = bench.measured_valu("c4", 131072, stage_ms)
+    traffic, per, note = bench.measured_traffic("c4", 131072)
+    prof = json.load(open(os.path.join(ROOT, bench.VALU_PROFILE)))
+    if prof["source_hash"] != bench.source_hash():       # (between a kernel edit and the next profiling run)
+        assert v["value"] is None and "re-run" in v["note"] and traffic is None
+        return
+    assert 20000 < v["valu_insts_per_unit"] < 32000 and 2.6 < v["cycles_per_inst"] < 4.8
+    assert abs(v["issue_ms_per_step"] - sum(d["issue_ms"] for d in v["per_stage"].values())) < 1e-9
+    assert 0.3 < v["frac_valu"] < 1.2 and 0.5 < v["per_stage"]["floor"]["frac_valu"] < 1.3
+    half = bench.measured_valu("c4", 65536, {k: x / 2 for k, x in stage_ms.items()})
+    assert abs(half["issue_ms_per_step"] * 2 - v["issue_ms_per_step"]) < 1e-9
+    assert 100e3 * 131072 < traffic < 200e3 * 131072 and set(per) >= {"k_floor", "k_noise", "k_transform", "k_couple"}
+    assert bench.measured_valu("c2", 65536, {"mdct_forward": 0.2}) is None
+    seen, aff, quota = bench.host_cpus()
+    assert seen >= 1 and 1 <= aff <= seen and (quota is None or quota > 0)
