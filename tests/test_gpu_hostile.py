@@ -4,7 +4,7 @@ Inside the domain -- finite samples, spectral peak up to +60 dB over full scale,
 the reference's bit for bit: those signal kinds are part of every soak run (tests/soak_lib.py kinds 8-11,
 tests/test_gpu_soak.py).  Outside it (NaN, +-Inf, 1e30 ...) the reference's own result is not defined by C; this
 suite checks that the library REPORTS such blocks through every door -- the per-block status tensor, the context's
-counter, VAMD_EINVAL from the host-pointer calls, OV_EINVAL out of vorbis_analysis() in the drop-in -- that it neither
+counter, VAMD_EDOMAIN from the host-pointer calls, OV_EINVAL out of vorbis_analysis() in the drop-in -- that it neither
 crashes nor hangs, and that every other block of the same batch / the next stream is untouched."""
 import numpy as np
 import pytest
