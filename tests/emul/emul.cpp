@@ -192,7 +192,7 @@ static int analyze_core(void *h, const float *pcm, int lW, int W, int nW, int bl
     if (local[i] > global) global = local[i];
   }
   {
-    const int nlp = (P.total_octave_lines + 15) & ~15;
+    const int nlp = VAMD_LINES_PAD(P.total_octave_lines);
     std::vector<float> S(5 * VAMD_NZ_STRIDE(n2)), nz(n2), wk(n2), seed(seed_pad_lo(P.eighth_octave_lines) + nlp + seed_pad_hi(P.eighth_octave_lines), -9999.f), ampstack(nlp), flr(n2), ring_amp(VAMD_RING);
     std::vector<int> ring_pos(VAMD_RING);
     std::vector<unsigned short> surv(nlp);

@@ -29,6 +29,8 @@
 namespace vamd {
 
 #define VAMD_NEGINF (-9999.f)
+// a block's row of seed lines / survivors in HBM: whole 128-byte lines (tone_chase_thread)
+#define VAMD_LINES_PAD(nl) (((nl) + 31) & ~31)
 
 // seed_curve, lib/psy.c:390-415.  The reference walks i = posts[0] .. post1-1 with
 // seedptr advancing by linesper and stops once seedptr >= n; point i therefore
@@ -144,7 +146,7 @@ VAMD_DEV void seed_chase_paint(float *seeds, const float *src, int linesper, int
 // 16-slot ring per lane; an entry pushed out of the ring is final and its line
 // index is appended to the survivor list.  Ring layout [slot][lane] keeps the 64
 // lanes on distinct LDS banks.
-//   seeds   this block's seed[] (HBM, read 16 lines at a time)
+//   seeds   this block's seed[] (HBM, read 32 lines -- a cache line -- at a time)
 //   surv    out: surviving line indices, ascending (uint16), returns their count
 #define VAMD_RING 16
 VAMD_DEV int tone_chase_thread(const float *__restrict__ seeds, int linesper, int n, float *ring_amp, int *ring_pos,
@@ -166,22 +168,25 @@ VAMD_DEV int tone_chase_thread(const float *__restrict__ seeds, int linesper, in
   };
   float a1 = 0.f, a2 = 0.f;
   int p1 = 0, p2 = 0;
+  // A lane reads its row a whole 128-byte line at a time (rows are padded to VAMD_LINES_PAD and start on a line): with 64
+  // bytes per trip every line was asked for twice, a few hundred cycles apart, by one lane of 65 536 whose lines fill the
+  // L2s exactly -- half of them had left by the second request (11.6 KB fetched per stereo block for 6.2 KB of lines).
   const F4 *q = (const F4 *)seeds;
-  const int nblk = (n + 15) >> 4;
-  F4 w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3];  // row is padded to 16; the next 16 lines load while these are walked
-  for (int b = 0; b < nblk; b++) {
-    const F4 v0 = w0, v1 = w1, v2 = w2, v3 = w3;
-    if (b + 1 < nblk) {
-      w0 = q[4 * b + 4];
-      w1 = q[4 * b + 5];
-      w2 = q[4 * b + 6];
-      w3 = q[4 * b + 7];
-    }
-    const float blk[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w,
-                           v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+  const int nblk = (n + 31) >> 5;
+  F4 w[8];
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-      const int i = (b << 4) + j;
+  for (int k = 0; k < 8; k++) w[k] = q[k];  // the next 32 lines load while these are walked
+  for (int b = 0; b < nblk; b++) {
+    float blk[32];
+#pragma unroll
+    for (int k = 0; k < 8; k++) blk[4 * k] = w[k].x, blk[4 * k + 1] = w[k].y, blk[4 * k + 2] = w[k].z, blk[4 * k + 3] = w[k].w;
+    if (b + 1 < nblk) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) w[k] = q[8 * b + 8 + k];
+    }
+#pragma unroll
+    for (int j = 0; j < 32; j++) {
+      const int i = (b << 5) + j;
       if (i < n) {
         const float s = blk[j];
         if (stack >= 2) {

@@ -330,7 +330,7 @@ __global__ void k_ampmax_streams_mixed(int ch, long nstreams, const long long *_
   states[sidx] = amp;
 }
 
-// stage 3: _vp_tonemask, in three launches (k_tone.h).  nlp = octave lines padded to 16.
+// stage 3: _vp_tonemask, in three launches (k_tone.h).  nlp = octave lines padded to 32 (VAMD_LINES_PAD).
 template <int LP>
 __global__ __launch_bounds__(64) void k_tone_seed(PsyP P0, PsyP P1, DescP d, int ch, int nlp, int nrp,
                                                   const float *__restrict__ peaks,
@@ -1286,7 +1286,7 @@ static int plan(vamd_ctx *c, int W, long nb, const vamd_batch_io *io, int level,
   if (level >= VAMD_LEVEL_PSY) {
     PICK(noise, io ? io->noise : nullptr, WS_NOISE, per);
     PICK(tone, io ? io->tone : nullptr, WS_TONE, per);
-    const size_t nlp = ((size_t)c->B.psy[2 * W].total_octave_lines + 15) & ~(size_t)15;
+    const size_t nlp = (size_t)VAMD_LINES_PAD(c->B.psy[2 * W].total_octave_lines);
     PICK(seed, (float *)nullptr, WS_SEED, (size_t)nb * ch * nlp * 4);
     PICK(surv, (unsigned short *)nullptr, WS_SURV, (size_t)nb * ch * nlp * 2);
     PICK(nsurv, (int32_t *)nullptr, WS_NSURV, (size_t)nb * ch * 4);
@@ -1534,7 +1534,7 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_
   const bool overlap = c->overlap && gcb > 64;
   // the VBR path's floor stage takes the tone chain's last step with it (k_floor)
   static const bool fold_env = getenv("VAMD_FOLD_SEPARATE") == nullptr;
-  const int nlp_all = (nl + 15) & ~15;
+  const int nlp_all = VAMD_LINES_PAD(nl);
   const size_t fold_lds = (size_t)(nlp_all + (P0.ngroups > P1.ngroups ? P0.ngroups : P1.ngroups)) * 4;
   const bool fold_in_floor = fold_env && level >= VAMD_LEVEL_FULL && !M && n2 <= 64 * 4 * VAMD_QPL;
   if (level >= VAMD_LEVEL_PSY) {
@@ -1583,7 +1583,7 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_
     prof_mark(c, VAMD_ST_NOISE);
     if (overlap) s = c->side;
     {
-      const int nlp = (nl + 15) & ~15;
+      const int nlp = VAMD_LINES_PAD(nl);
       const size_t seed_lds = (size_t)(seed_pad_lo(P0.eighth_octave_lines) + nlp + seed_pad_hi(P0.eighth_octave_lines)) * 4;
       if (P0.eighth_octave_lines == 8 && P1.eighth_octave_lines == 8)
         hipLaunchKernelGGL(k_tone_seed<8>, dim3(gcb), dim3(64), seed_lds, s, P0, P1, d, ch, nlp, run_peaks_stride(P0), p.peaks, p.local,
