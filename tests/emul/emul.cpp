@@ -87,10 +87,10 @@ static void residue_and_pack(const Bound &B, int W, int lW, int nW, const int *i
   }
   if (!packet) return;
   std::vector<int> ring(VAMD_PK_RING), outv(VAMD_POSTS_STRIDE), cls(VAMD_RES_CLASS_STRIDE), off(B.res_off_ints[W]),
-      info(B.res_off_ints[W]);
-  pack_block(B.pack[W], B.floor[W][0], B.floor[W][1], B.res[W][0], B.res[W][1], cm, ch, W, lW, nW, posts, post_valid, res_class, res_entries, res_count,
-             ring.data(), outv.data(), cls.data(), off.data(), info.data(), (unsigned *)packet, B.pack[W].capacity / 4,
-             packet_bits);
+      info(B.res_off_ints[W]), tabs(VAMD_PK_FTAB_INTS + 3 * B.pack[W].nbooks);
+  pack_block(B.pack[W], B.floor[W][0], B.floor[W][1], B.res[W][0], B.res[W][1], cm, ch, W, lW, nW, posts, nullptr, post_valid, res_class, res_entries, nullptr, res_count,
+             ring.data(), outv.data(), cls.data(), off.data(), info.data(), tabs.data(), (unsigned *)packet, B.pack[W].capacity / 4,
+             packet_bits, pc);
 }
 
 // couple / quantise / normalise with whichever form the layout needs (as launch_couple picks the kernel)
@@ -524,7 +524,9 @@ static int chase_chunks_host(const float *seeds, int linesper, int n, unsigned s
   int nc = 0;
   for (int c = 0; c < VAMD_CHASE_CHUNKS && c * cs < n; c++, nc++) {
     const int s0 = c * cs, e0 = s0 + cs < n ? s0 + cs : n;
-    r[c] = chase_chunk(seeds, linesper, n, s0, e0, VAMD_CHASE_WARM * linesper, 0, ring_amp, ring_pos, 1, 0);
+    // (eight lines per window, every libvorbisenc setup: the register form k_tone_seed_chase runs)
+    r[c] = linesper == 8 ? chase_chunk_regs<8>(seeds, n, s0, e0, cs, VAMD_CHASE_WARM * linesper, 0)
+                         : chase_chunk(seeds, linesper, n, s0, e0, VAMD_CHASE_WARM * linesper, 0, ring_amp, ring_pos, 1, 0);
     used[c] = r[c].sig_in;
   }
   int ok = 0, rd = 0;
@@ -551,7 +553,8 @@ static int chase_chunks_host(const float *seeds, int linesper, int n, unsigned s
       need_any = 1;
       if (rd == VAMD_CHASE_ROUNDS) break;
       const int s0 = c * cs, e0 = s0 + cs < n ? s0 + cs : n;
-      const ChaseChunk t = chase_chunk(seeds, linesper, n, s0, e0, -1, prev[c], ring_amp, ring_pos, 1, 0);
+      const ChaseChunk t = linesper == 8 ? chase_chunk_regs<8>(seeds, n, s0, e0, cs, -1, prev[c])
+                                         : chase_chunk(seeds, linesper, n, s0, e0, -1, prev[c], ring_amp, ring_pos, 1, 0);
       used[c] = prev[c];
       r[c].popped = t.popped;
       r[c].sig_out = t.sig_out;

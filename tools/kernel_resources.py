@@ -10,7 +10,7 @@ extra = sys.argv[2:]   # further compiler flags, e.g. -DVAMD_NOISE_NO_PREFETCH
 cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
        "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "vorbis_amd", "csrc"),
        "-Rpass-analysis=kernel-resource-usage"] + extra + ["-c", os.path.join(ROOT, "vorbis_amd", "csrc", "vamd_hip.hip"), "-o", "/tmp/vamd_res.o"]
-err = subprocess.run(cmd, capture_output=True, text=True).stderr
+err = subprocess.run(cmd, capture_output=True, text=True, stdin=subprocess.DEVNULL, timeout=900).stderr
 cur, rows = None, []
 for line in err.splitlines():
     m = re.search(r"remark:\s+(Function Name|TotalSGPRs|VGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|SGPRs Spill|VGPRs Spill): (\S+)", line)
@@ -22,7 +22,9 @@ for line in err.splitlines():
         rows.append(cur)
     elif cur is not None:
         cur[k] = v
-names = subprocess.run(["c++filt"] + [r["name"] for r in rows], capture_output=True, text=True).stdout.splitlines()
+if not rows:  # the compile failed (c++filt without arguments would wait on stdin)
+    sys.exit("no kernels reported:\n" + "\n".join(l for l in err.splitlines() if "error" in l)[:4000])
+names = subprocess.run(["c++filt"] + [r["name"] for r in rows], capture_output=True, text=True, stdin=subprocess.DEVNULL).stdout.splitlines()
 print("%-44s %5s %5s %7s %7s %7s %4s" % ("kernel", "VGPR", "SGPR", "vspill", "sspill", "scratch", "occ"))
 for r, nm in zip(rows, names):
     nm = re.sub(r"\(.*$", "", nm).replace("void ", "")

@@ -645,9 +645,10 @@ VAMD_DEV void floor_quantise_predict(const FloorP &F, const LaneInts &outp, cons
 //   posts_out HBM [VAMD_POSTS_STRIDE] the posts as fitted (what the host hands floor1_encode)
 //   ilogmask  HBM [n2]
 // Returns floor1_encode's nonzero flag (1 = non-trivial floor).
+//   wrapped_out HBM [posts] or null: floor1_encode's out[] (what the packet stage writes for each post), for k_pack
 VAMD_DEV int floor_encode_render(const FloorP &F, int n2, const LaneInts &outp, int valid, FloorScratch *sc,
                                  int *__restrict__ posts_out, int *__restrict__ post_valid,
-                                 ilog_t *__restrict__ ilogmask, PhaseClock &pc) {
+                                 ilog_t *__restrict__ ilogmask, PhaseClock &pc, int *__restrict__ wrapped_out = nullptr) {
   const int posts = F.posts;
   if (!valid) {
     // no fit: floor1_encode writes a zero curve (lib/floor1.c:948-952)
@@ -662,7 +663,14 @@ VAMD_DEV int floor_encode_render(const FloorP &F, int n2, const LaneInts &outp, 
   forward_index.load(F.forward_index, posts);
   WAVE_FOR(i, VAMD_POSTS_STRIDE) if (posts_out) posts_out[i] = i < posts ? outp.at(i) : 0;
   if (post_valid && LANE == 0) *post_valid = 1;
-  floor_quantise_predict(F, outp, postlist, post, nullptr);
+  if (wrapped_out) {
+    LaneInts wrapped;
+    wrapped.fill(0);
+    floor_quantise_predict(F, outp, postlist, post, &wrapped);
+    WAVE_FOR(i, posts) wrapped_out[i] = wrapped.at(i);
+  } else {
+    floor_quantise_predict(F, outp, postlist, post, nullptr);
+  }
 
   // ---- render the integer curve, lib/floor1.c:923-946
   floor_render_curve(F, posts, n2, forward_index, post, postlist, sc, ilogmask, pc);
@@ -674,10 +682,10 @@ VAMD_DEV int floor_encode_render(const FloorP &F, int n2, const LaneInts &outp, 
 // floor1_fit + the curve half of floor1_encode for one channel-block (the VBR path: one curve)
 VAMD_DEV int floor_fit_render_block(const FloorP &F, int n2, const unsigned short *qc, FloorScratch *sc,
                                     int *__restrict__ posts_out, int *__restrict__ post_valid,
-                                    ilog_t *__restrict__ ilogmask, PhaseClock &pc) {
+                                    ilog_t *__restrict__ ilogmask, PhaseClock &pc, int *__restrict__ wrapped_out = nullptr) {
   LaneInts outp;
   const int valid = floor_fit_posts(F, qc, sc, outp, pc);
-  return floor_encode_render(F, n2, outp, valid, sc, posts_out, post_valid, ilogmask, pc);
+  return floor_encode_render(F, n2, outp, valid, sc, posts_out, post_valid, ilogmask, pc, wrapped_out);
 }
 
 // floor1_interpolate_fit, lib/floor1.c:731-750, one post per lane

@@ -110,13 +110,15 @@ VAMD_DEV int residue_offsets(const ResP &R, int partvals, const int *cls, int *o
 //   iwork[c]   HBM [n2]   quantised (and coupled) residue of the bundle's channel c; nonzero[c] its flag
 //   work       LDS [bundle*n2]; cls LDS [slots]; off LDS [stages*slots + 1]; info LDS [stages*slots]
 //   class_out  HBM [VAMD_RES_CLASS_STRIDE]; entries_out HBM [R.cap]; count_out HBM [2] = {classes, entries}
+//   books_out  HBM [R.cap] or null: the book each entry belongs to, for the packet stage (k_pack.h: its fields then
+//              need no search for the (stage, slot) pair they come from)
 // A type-2 residue codes the bundle's channels interleaved as ONE stream (res2_class / res2_forward);
 // type 1 codes every channel whose floor is not all zero as a stream of its own (res1_class /
 // res1_forward, lib/res0.c:729-762), and _01forward then walks (stage, partition, stream, vector): a
 // "slot" below is a (partition, stream) pair, numbered partition-major.
 VAMD_DEV void residue_block(const ResP &R, int n2, const int *const *iwork, const int *nonzero, int *work, int *cls, int *off,
                             int *info, int *__restrict__ class_out, unsigned short *__restrict__ entries_out,
-                            int *__restrict__ count_out, PhaseClock &pc) {
+                            int *__restrict__ count_out, PhaseClock &pc, unsigned char *__restrict__ books_out = nullptr) {
   const vamd_residue_tab &t = *R.tab;
   const int ch = R.bundle, spp = t.grouping, nparts = t.partitions, partvals = R.partvals, stages = t.stages;
   int ns = 0;  // streams
@@ -208,7 +210,10 @@ VAMD_DEV void residue_block(const ResP &R, int n2, const int *const *iwork, cons
       const int i = q / ns, strm = q - i * ns;
       const vamd_book_tab &bk = R.books[info[s * slots + q]];
       const int entry = residue_besterror(R, bk, work + strm * n2 + t.begin + i * spp + k * bk.dim);
-      if (base + v < R.cap) entries_out[base + v] = (unsigned short)entry;
+      if (base + v < R.cap) {
+        entries_out[base + v] = (unsigned short)entry;
+        if (books_out) books_out[base + v] = (unsigned char)info[s * slots + q];  // (< 256 books: vamd_bind.h)
+      }
     }
     TEAM_SYNC();
   }

@@ -313,6 +313,63 @@ VAMD_DEV ChaseChunk chase_chunk(const float *seeds, int linesper, int n, int s, 
   return out;
 }
 
+// The same walk with its state in registers.  What a step can pop or look at are the lines within linesper of it, so the
+// stack as far as the walk can tell is a bit mask of which of the last LP-1 lines are still on it and their values,
+// newest first; older entries fail both position tests (lib/psy.c:470-474) whatever they hold, and chase_chunk's cold
+// start knows none either.  A push and a pop are LP-2 register moves: no ring in LDS, no trip to it per pop (a lone
+// wave waited some 20 us of a block's 25 there), and the alive masks chase_chunk gathers by walking its stack are the
+// state itself.  Masks here are newest-first (bit k = line t-1-k), the reverse of chase_chunk's: they are only ever
+// compared with, or handed to, this function's own.
+//   cs    the length every chunk of the block was cut to (the lanes of a wave step together: warm + cs + LP-1 steps,
+//         those before line 0 or past the chunk's last look doing nothing)
+template <int LP>
+VAMD_DEV ChaseChunk chase_chunk_regs(const float *seeds, int n, int s, int e, int cs, int warm, uint32_t enter) {
+  constexpr int WN = LP - 1;
+  constexpr uint32_t WMASK = (1u << WN) - 1u;
+  ChaseChunk out;
+  out.popped = out.sig_in = out.sig_out = 0;
+  const int ws = warm < 0 ? s : s - warm;
+  out.exact = ws <= 0;
+  const int stop = e + LP - 1 < n ? e + LP - 1 : n;
+  const int steps = (warm < 0 ? 0 : warm) + cs + LP - 1;
+  uint32_t m = 0;
+  float st[WN];
+#pragma unroll
+  for (int j = 0; j < WN; j++) st[j] = 0.f;
+  if (warm < 0 && s > 0) {
+    m = enter & WMASK;
+    uint32_t mm = m;
+#pragma unroll
+    for (int j = 0; j < WN; j++)
+      if (mm) {
+        st[j] = seeds[s - 1 - __builtin_ctz(mm)];
+        mm &= mm - 1;
+      }
+  }
+  float nxt = ws >= 0 && ws < n ? seeds[ws] : 0.f;  // a step's line is asked for a step ahead
+  for (int t = 0; t < steps; t++) {
+    const int i = ws + t;
+    const float sv = nxt;
+    nxt = i + 1 >= 0 && i + 1 < n ? seeds[i + 1] : 0.f;
+    if (i == s) out.sig_in = m;
+    if (i == e && i < stop) out.sig_out = m;
+    if (i >= 0 && i < stop) {
+      while ((m & (m - 1)) != 0 && !(sv < st[0]) && st[0] <= st[1]) {
+        const int p1 = i - 1 - __builtin_ctz(m);
+        if (p1 >= s && p1 < e) out.popped |= 1u << (p1 - s);
+        m &= m - 1;
+#pragma unroll
+        for (int j = 0; j + 1 < WN; j++) st[j] = st[j + 1];
+      }
+      m = ((m << 1) | 1u) & WMASK;
+#pragma unroll
+      for (int j = WN - 1; j > 0; j--) st[j] = st[j - 1];
+      st[0] = sv;
+    }
+  }
+  return out;
+}
+
 #define VAMD_CHASE_CHUNKS 64  // chunks per block = lanes of the wave
 #ifndef VAMD_CHASE_WARM
 #define VAMD_CHASE_WARM 2    // cold start this many windows (linesper) before a chunk: one needs a repair round every time,

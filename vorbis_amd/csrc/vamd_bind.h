@@ -557,6 +557,7 @@ inline void bind_params(const std::vector<unsigned char> &image, const std::vect
     const int n2 = h.blocksizes[W] / 2;
     PackP &K = B->pack[W];
     K.books = (const vamd_book_tab *)(base + h.off_books);
+    K.nbooks = h.nbooks;
     K.base = base;
     K.modebits = h.modebits;
     long bits = 1 + K.modebits + 2;  // the longest packet this size class can produce, field by field

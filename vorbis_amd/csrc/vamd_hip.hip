@@ -364,6 +364,88 @@ __global__ __launch_bounds__(64) void k_tone_seed(PsyP P0, PsyP P1, DescP d, int
   pc.flush();
 }
 
+// seed + chase in one launch for a small batch: one WAVE per channel-block scatters the curves into the lines in LDS
+// and walks them there, cut into one chunk per lane with the walk's state in registers (chase_chunk_regs, k_tone.h) --
+// the lines go out for the fold but do not come back in, and the chain is a launch shorter (a lone block: k_tone_seed
+// 9 us + k_tone_chase_wave 25 us -> this kernel's 14).  Every libvorbisenc setup has eight lines per window; others
+// take the two kernels.  LDS: the padded seed lines, then a 16-slot ring for the serial walk's fallback.
+template <int LP>
+__global__ __launch_bounds__(64) void k_tone_seed_chase(PsyP P0, PsyP P1, DescP d, int ch, int nlp, int nrp,
+                                                        const float *__restrict__ peaks,
+                                                        const float *__restrict__ local_ampmax,
+                                                        const float *__restrict__ ampmax_glob, float *__restrict__ ampmax_make,
+                                                        float *__restrict__ seed_g, unsigned short *__restrict__ surv,
+                                                        int *__restrict__ nsurv) {
+  const long cb = blockIdx.x;
+  const long blk = cb / ch;
+  const PsyP &P = d_bt(d, blk) ? P1 : P0;
+  float g_amp;  // (the block's ampmax: as k_tone_seed)
+  if (ampmax_make) {
+    g_amp = d_amp(d, blk);
+    for (int c = 0; c < ch; c++) {
+      const float l = local_ampmax[blk * ch + c];
+      if (l > g_amp) g_amp = l;
+    }
+    if (LANE == 0 && cb == blk * ch) ampmax_make[blk] = g_amp;
+  } else {
+    g_amp = ampmax_glob[blk];
+  }
+  const int nl = P.total_octave_lines;
+  float *seed = (float *)vamd_smem + seed_pad_lo(LP);
+  float *ring_amp = seed + nlp + seed_pad_hi(LP);
+  int *ring_pos = (int *)(ring_amp + VAMD_RING);
+  PhaseClock pc;
+  pc.start(d.dbg ? d.dbg + 32 : nullptr);
+  tone_seed_block<LP>(P, peaks + cb * nrp, g_amp, local_ampmax[cb], seed, pc);
+  WAVE_FOR(i, nlp) {
+    if (i >= nl) seed[i] = VAMD_NEGINF;  // (the row's padding, as it goes out: the serial walk reads whole lines of it)
+    seed_g[cb * nlp + i] = seed[i];
+  }
+  WAVE_SYNC();
+  const int cs = (nl + 63) / 64;
+  const int s0 = LANE * cs < nl ? LANE * cs : nl, e0 = s0 + cs < nl ? s0 + cs : nl;
+  unsigned short *out = surv + cb * nlp;
+  bool accepted = false;
+  ChaseChunk r;
+  r.popped = r.sig_in = r.sig_out = 0;
+  r.exact = 1;
+  // a long run of equal values (a stretch no curve reached) would take a repair round per chunk: serial at once
+  unsigned long long fm = __ballot(s0 < nl && chase_flat_chunk(seed, s0, e0));
+  int longest = 0;
+  for (; fm && longest <= VAMD_CHASE_FLAT_MAX; longest++) fm &= fm << 1;
+  if (longest <= VAMD_CHASE_FLAT_MAX) {
+    r = chase_chunk_regs<LP>(seed, nl, s0, e0, cs, VAMD_CHASE_WARM * LP, 0);  // (a lane past the last line walks nothing)
+    uint32_t used = r.sig_in;
+    for (int rd = 0; rd <= VAMD_CHASE_ROUNDS; rd++) {
+      const uint32_t prev_out = (uint32_t)wave_shift_up1((int)r.sig_out, 0);
+      const bool need = s0 < nl && !r.exact && used != prev_out;
+      if (!__any(need)) {
+        accepted = true;
+        break;
+      }
+      if (rd == VAMD_CHASE_ROUNDS) break;
+      if (need) {  // walked again, started exactly in the predecessor's exit state
+        const ChaseChunk t = chase_chunk_regs<LP>(seed, nl, s0, e0, cs, -1, prev_out);
+        used = prev_out;
+        r.popped = t.popped;
+        r.sig_out = t.sig_out;
+      }
+    }
+  }
+  if (accepted) {
+    const uint32_t alive = ~r.popped & (e0 - s0 >= 32 ? ~0u : ((1u << (e0 - s0)) - 1u));
+    const int cnt = __builtin_popcount(alive);
+    const int incl = wave_scan_sum(cnt);
+    int at = incl - cnt;
+    for (uint32_t m = alive; m; m &= m - 1) out[at++] = (unsigned short)(s0 + __builtin_ctz(m));
+    if (LANE == 63) nsurv[cb] = incl;
+  } else if (LANE == 0) {
+    nsurv[cb] = tone_chase_thread(seed, LP, nl, ring_amp, ring_pos, 1, 0, out);
+  }
+  pc.mark(2);
+  pc.flush();
+}
+
 // one THREAD per channel-block: the ordered stack walk of seed_chase, VAMD_CHASE_LANES walks per wave.  (Measured
 // round 2: half-filled waves -- twice as many waves for the SIMDs to interleave -- are slower, 1.01 against 0.82 ms per
 // 131 072 stereo blocks; a walk whose stack is a register bit mask fed through coalesced LDS tiles executes three
@@ -469,7 +551,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                                               const float *__restrict__ mdct_raw,
                                               float *__restrict__ mdct, float *__restrict__ logmask_out,
                                               int *__restrict__ posts, int *__restrict__ post_valid,
-                                              ilog_t *__restrict__ ilogmask, int *__restrict__ nonzero) {
+                                              ilog_t *__restrict__ ilogmask, int *__restrict__ nonzero,
+                                              int *__restrict__ wrapped /* [cb][VAMD_POSTS_STRIDE] for k_pack, or null */) {
   const long cb = blockIdx.x;
   const long blk = cb / ch;
   // (the parameter structs stay in HBM and are read field by field through the scalar cache: four of them by value
@@ -501,7 +584,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                         logmask_out ? logmask_out + cb * n2 : nullptr, qc, F.twofitatten, pc);
   }
   const int nzf = floor_fit_render_block(F, n2, qc, sc, posts + cb * VAMD_POSTS_STRIDE, post_valid + cb,
-                                         ilogmask + cb * n2, pc);
+                                         ilogmask + cb * n2, pc, wrapped ? wrapped + cb * VAMD_POSTS_STRIDE : nullptr);
   if (LANE == 0) nonzero[cb] = nzf;
   pc.flush();
 }
@@ -622,7 +705,7 @@ __global__ __launch_bounds__(64) void k_floor_managed(PsyP P0, PsyP P1, FloorP F
 __global__ __launch_bounds__(64 * VAMD_RES_WAVES) void k_residue(ResP R, ChMap cm, int sm, int ent_row, DescP d, int ch, int n2,
                                                 const int *__restrict__ iwork, const int *__restrict__ nonzero,
                                                 int *__restrict__ res_class, unsigned short *__restrict__ res_entries,
-                                                int *__restrict__ res_count) {
+                                                int *__restrict__ res_count, unsigned char *__restrict__ res_books) {
   const long u = blockIdx.x;
   int *work = (int *)vamd_smem;                 // [bundle*n2]
   int *cls = work + R.bundle * n2;              // [VAMD_RES_CLASS_STRIDE]
@@ -640,15 +723,18 @@ __global__ __launch_bounds__(64 * VAMD_RES_WAVES) void k_residue(ResP R, ChMap c
   PhaseClock pc;
   pc.start(d.dbg ? d.dbg + 72 : nullptr);
   residue_block(R, n2, ip, nz, work, cls, off, info, res_class + u * (cm.submaps * VAMD_RES_CLASS_STRIDE) + R.cls_base,
-                res_entries + u * (long)ent_row + R.ent_base, res_count + (u * cm.submaps + sm) * 2, pc);
+                res_entries + u * (long)ent_row + R.ent_base, res_count + (u * cm.submaps + sm) * 2, pc,
+                res_books ? res_books + u * (long)ent_row + R.ent_base : nullptr);
   pc.flush();
 }
 
 // stage 7 (optional): packet assembly, one wave per packet (k_pack.h).  unit = block * nblobs + candidate
 __global__ __launch_bounds__(64) void k_pack(PackP K, FloorP F0, FloorP F1, ResP R0, ResP R1, ChMap cm, int ent_row, int lds_ints,
                                              DescP d, int ch, int W, int nblobs, const int *__restrict__ posts,
+                                             const int *__restrict__ wrapped /* k_floor's, or null */,
                                              const int *__restrict__ post_valid, const int *__restrict__ res_class,
                                              const unsigned short *__restrict__ res_entries,
+                                             const unsigned char *__restrict__ res_books,
                                              const int *__restrict__ res_count, unsigned *__restrict__ packets,
                                              int stride_words, int *__restrict__ packet_bits) {
   const long u = blockIdx.x, blk = u / nblobs;
@@ -657,10 +743,15 @@ __global__ __launch_bounds__(64) void k_pack(PackP K, FloorP F0, FloorP F1, ResP
   int *cls = outv + VAMD_POSTS_STRIDE;           // [VAMD_RES_CLASS_STRIDE]
   int *off = cls + VAMD_RES_CLASS_STRIDE;        // [stages*slots + 1], then info [stages*slots], sized for the larger submap
   int *info = off + lds_ints;
-  pack_block(K, F0, F1, R0, R1, cm, ch, W, d_lW(d, blk), d_nW(d, blk), posts + u * ch * VAMD_POSTS_STRIDE, post_valid + u * ch,
+  int *tabs = info + lds_ints;                   // [VAMD_PK_FTAB_INTS + 3 * nbooks], PackTabs
+  PhaseClock pc;  // (marks 2..7 of the residue stage's slot set: k_residue uses 0 and 1)
+  pc.start(d.dbg ? d.dbg + 72 : nullptr);
+  pack_block(K, F0, F1, R0, R1, cm, ch, W, d_lW(d, blk), d_nW(d, blk), posts + u * ch * VAMD_POSTS_STRIDE,
+             wrapped ? wrapped + u * ch * VAMD_POSTS_STRIDE : nullptr, post_valid + u * ch,
              res_class + u * (cm.submaps * VAMD_RES_CLASS_STRIDE), res_entries + u * (long)ent_row,
-             res_count + u * cm.submaps * 2, ring, outv, cls, off, info, packets + u * (long)stride_words, stride_words,
-             packet_bits + u);
+             res_books ? res_books + u * (long)ent_row : nullptr, res_count + u * cm.submaps * 2, ring, outv, cls, off, info, tabs, packets + u * (long)stride_words, stride_words,
+             packet_bits + u, pc);
+  pc.flush();
 }
 
 // ---------------------------------------------------------------------------
@@ -975,7 +1066,7 @@ struct vamd_ctx {
          WS_NONZERO, WS_LOCAL, WS_AMPIN, WS_AMPGLOB, WS_PCM, WS_SEED, WS_SURV, WS_NSURV, WS_MISC,
          WS_ENV_NEAR, WS_ENV_RAW, WS_ENV_AMP, WS_ENV_BITS, WS_ENV_STAGE, WS_M_ILOGMASK, WS_M_STAGE,
          WS_RES_CLASS, WS_RES_ENTRIES, WS_RES_COUNT, WS_COUPLE_STATE,
-         WS_PLAN_FLAGS, WS_PLAN_BLOCKS, WS_PLAN_COUNTS, WS_PLAN_BASE, WS_PLAN_DESC, WS_PLAN_ORDER, WS_STATUS, WS_COUNT };
+         WS_PLAN_FLAGS, WS_PLAN_BLOCKS, WS_PLAN_COUNTS, WS_PLAN_BASE, WS_PLAN_DESC, WS_PLAN_ORDER, WS_STATUS, WS_WRAPPED, WS_RES_BOOKS, WS_COUNT };
   DevBuf ws[2][WS_COUNT];  // per size class (a mixed stream keeps both batches in flight)
   // pinned staging for the per-block host API
   void *h_stage = nullptr;
@@ -1253,6 +1344,7 @@ struct WsPlan {
   int32_t *nsurv;
   ilog_t *ilogmask;  // a byte per bin, workspace only (the int32 tap is widened from it: k_widen_ilog)
   int32_t *iwork, *posts, *post_valid, *nonzero;
+  int32_t *wrapped;  // [channel-blocks][VAMD_POSTS_STRIDE] floor1_encode's out[], k_floor -> k_pack; null unless packets are assembled
   unsigned char *status;
 };
 
@@ -1263,6 +1355,7 @@ static int run_peaks_stride(const PsyP &P) { return (P.nruns + 3) & ~3; }
 static int plan(vamd_ctx *c, int W, long nb, const vamd_batch_io *io, int level, WsPlan *p) {
   const size_t ch = c->B.channels, n2 = c->B.bs[W] / 2;
   const size_t per = (size_t)nb * ch * n2 * 4;
+  p->wrapped = nullptr;
   void *v;
 #define PICK(field, user, slot, bytes)                  \
   if (user) {                                           \
@@ -1298,6 +1391,7 @@ static int plan(vamd_ctx *c, int W, long nb, const vamd_batch_io *io, int level,
     PICK(posts, io ? io->posts : nullptr, WS_POSTS, (size_t)nb * ch * VAMD_POSTS_STRIDE * 4);
     PICK(post_valid, io ? io->post_valid : nullptr, WS_POSTVALID, (size_t)nb * ch * 4);
     PICK(nonzero, io ? io->nonzero : nullptr, WS_NONZERO, (size_t)nb * ch * 4);
+    if (io && io->packets) PICK(wrapped, (int32_t *)nullptr, WS_WRAPPED, (size_t)nb * ch * VAMD_POSTS_STRIDE * 4);
   }
 #undef PICK
   return VAMD_OK;
@@ -1356,6 +1450,7 @@ struct ResBufs {
   int32_t *cls;
   uint16_t *entries;
   int32_t *count;
+  uint8_t *books;  // [units][res_cap] the book of every entry, k_residue -> k_pack (workspace only)
 };
 struct BatchRun {
   int W;
@@ -1379,9 +1474,11 @@ static int check_packets(vamd_ctx *c, int W, int level, const void *packets, con
 
 static int res_bufs(vamd_ctx *c, int W, long units, int32_t *cls, uint16_t *entries, int32_t *count, ResBufs *o) {
   o->cls = cls, o->entries = entries, o->count = count;
-  if (entries) return VAMD_OK;
   void *v;
   int r;
+  if ((r = ws_get(c, W, vamd_ctx::WS_RES_BOOKS, (size_t)units * c->B.res_cap[W], &v))) return r;
+  o->books = (uint8_t *)v;
+  if (entries) return VAMD_OK;
   if ((r = ws_get(c, W, vamd_ctx::WS_RES_CLASS, (size_t)units * c->B.chmap[W].submaps * VAMD_RES_CLASS_STRIDE * 4, &v))) return r;
   o->cls = (int32_t *)v;
   if ((r = ws_get(c, W, vamd_ctx::WS_RES_ENTRIES, (size_t)units * c->B.res_cap[W] * 2, &v))) return r;
@@ -1464,7 +1561,7 @@ static void launch_transform(vamd_ctx *c, BatchRun *R) {
 // stages 2..5 (masking, floor, couple); R->d.ampmax_in / p.ampglob must be final
 // stage 6 for every submap of the mode, then (optionally) stage 7; a unit is a (block, candidate packet)
 static void launch_residue_pack(vamd_ctx *c, BatchRun *R, hipStream_t s, long units, int nblobs, const int *posts,
-                                const int *post_valid, const int *iwork, const int *nonzero, const ResBufs &rb,
+                                const int *wrapped /* k_floor's out[] per post, or null */, const int *post_valid, const int *iwork, const int *nonzero, const ResBufs &rb,
                                 void *packets, int64_t packet_stride, int32_t *packet_bits) {
   const int W = R->W, ch = c->B.channels, n2 = c->B.xf[W].n / 2;
   const ChMap &cm = c->B.chmap[W];
@@ -1472,13 +1569,14 @@ static void launch_residue_pack(vamd_ctx *c, BatchRun *R, hipStream_t s, long un
     // a stereo bundle's search keeps two waves busy, the five-channel bundle of the 5.1 layout four
     hipLaunchKernelGGL(k_residue, dim3((unsigned)units), dim3(64 * (c->B.res[W][sm].bundle * n2 > 4096 ? VAMD_RES_WAVES : 2)),
                        (size_t)c->B.res[W][sm].lds_ints * 4, s, c->B.res[W][sm], cm, sm,
-                       c->B.res_cap[W], R->d, ch, n2, iwork, nonzero, rb.cls, rb.entries, rb.count);
+                       c->B.res_cap[W], R->d, ch, n2, iwork, nonzero, rb.cls, rb.entries, rb.count, packets ? rb.books : nullptr);
   prof_mark(c, VAMD_ST_RESIDUE);
   if (packets) {
-    const size_t lds = ((size_t)VAMD_PK_RING + VAMD_POSTS_STRIDE + VAMD_RES_CLASS_STRIDE + 2 * (size_t)c->B.res_off_ints[W]) * 4;
+    const size_t lds = ((size_t)VAMD_PK_RING + VAMD_POSTS_STRIDE + VAMD_RES_CLASS_STRIDE + 2 * (size_t)c->B.res_off_ints[W] +
+                        VAMD_PK_FTAB_INTS + 3 * (size_t)c->B.pack[W].nbooks) * 4;
     hipLaunchKernelGGL(k_pack, dim3((unsigned)units), dim3(64), lds, s, c->B.pack[W], c->B.floor[W][0], c->B.floor[W][1],
                        c->B.res[W][0], c->B.res[W][1], cm, c->B.res_cap[W], c->B.res_off_ints[W], R->d, ch, W, nblobs, posts,
-                       post_valid, rb.cls, rb.entries, rb.count, (unsigned *)packets, (int)(packet_stride / 4), packet_bits);
+                       wrapped, post_valid, rb.cls, rb.entries, rb.books, rb.count, (unsigned *)packets, (int)(packet_stride / 4), packet_bits);
     prof_mark(c, VAMD_ST_PACK);
   }
 }
@@ -1585,22 +1683,30 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_
     {
       const int nlp = VAMD_LINES_PAD(nl);
       const size_t seed_lds = (size_t)(seed_pad_lo(P0.eighth_octave_lines) + nlp + seed_pad_hi(P0.eighth_octave_lines)) * 4;
-      if (P0.eighth_octave_lines == 8 && P1.eighth_octave_lines == 8)
-        hipLaunchKernelGGL(k_tone_seed<8>, dim3(gcb), dim3(64), seed_lds, s, P0, P1, d, ch, nlp, run_peaks_stride(P0), p.peaks, p.local,
-                           p.ampglob, R->make_ampmax ? p.ampglob : nullptr, p.seed);
-      else
-        hipLaunchKernelGGL(k_tone_seed<0>, dim3(gcb), dim3(64), seed_lds, s, P0, P1, d, ch, nlp, run_peaks_stride(P0), p.peaks, p.local,
-                           p.ampglob, R->make_ampmax ? p.ampglob : nullptr, p.seed);
       // a lane per block for batches, a wave per block (the walk in 64 chunks) where that would leave the GPU to a
       // handful of lanes walking ~800 lines each: the per-block entry points, the batcher's small batches
       static const long wave_max_cb = getenv("VAMD_CHASE_WAVE_MAX") ? atol(getenv("VAMD_CHASE_WAVE_MAX")) : 32768;
-      if ((long)gcb <= wave_max_cb && P0.eighth_octave_lines <= 16 && nl <= 2048)
-        hipLaunchKernelGGL(k_tone_chase_wave, dim3(gcb), dim3(64), (size_t)nlp * 4 + (size_t)VAMD_RING * 64 * 8, s,
-                           P0.eighth_octave_lines, nl, nlp, d, p.seed, p.surv, p.nsurv);
-      else
-        hipLaunchKernelGGL(k_tone_chase, dim3((gcb + VAMD_CHASE_LANES - 1) / VAMD_CHASE_LANES), dim3(VAMD_CHASE_LANES),
-                           (size_t)VAMD_RING * VAMD_CHASE_LANES * 8, s,
-                           P0.eighth_octave_lines, nl, nlp, (long)gcb, d, p.seed, p.surv, p.nsurv);
+      const bool by_wave = (long)gcb <= wave_max_cb && P0.eighth_octave_lines <= 16 && nl <= 2048;
+      const bool lp8 = P0.eighth_octave_lines == 8 && P1.eighth_octave_lines == 8;
+      if (by_wave && lp8) {  // ... and seed + chase in one launch (k_tone_seed_chase)
+        hipLaunchKernelGGL(k_tone_seed_chase<8>, dim3(gcb), dim3(64), seed_lds + (size_t)VAMD_RING * 8, s, P0, P1, d, ch, nlp,
+                           run_peaks_stride(P0), p.peaks, p.local, p.ampglob, R->make_ampmax ? p.ampglob : nullptr, p.seed, p.surv,
+                           p.nsurv);
+      } else {
+        if (lp8)
+          hipLaunchKernelGGL(k_tone_seed<8>, dim3(gcb), dim3(64), seed_lds, s, P0, P1, d, ch, nlp, run_peaks_stride(P0), p.peaks, p.local,
+                             p.ampglob, R->make_ampmax ? p.ampglob : nullptr, p.seed);
+        else
+          hipLaunchKernelGGL(k_tone_seed<0>, dim3(gcb), dim3(64), seed_lds, s, P0, P1, d, ch, nlp, run_peaks_stride(P0), p.peaks, p.local,
+                             p.ampglob, R->make_ampmax ? p.ampglob : nullptr, p.seed);
+        if (by_wave)
+          hipLaunchKernelGGL(k_tone_chase_wave, dim3(gcb), dim3(64), (size_t)nlp * 4 + (size_t)VAMD_RING * 64 * 8, s,
+                             P0.eighth_octave_lines, nl, nlp, d, p.seed, p.surv, p.nsurv);
+        else
+          hipLaunchKernelGGL(k_tone_chase, dim3((gcb + VAMD_CHASE_LANES - 1) / VAMD_CHASE_LANES), dim3(VAMD_CHASE_LANES),
+                             (size_t)VAMD_RING * VAMD_CHASE_LANES * 8, s,
+                             P0.eighth_octave_lines, nl, nlp, (long)gcb, d, p.seed, p.surv, p.nsurv);
+      }
       if (!fold_in_floor)
         hipLaunchKernelGGL(k_tone_fold, dim3(gcb), dim3(64), (size_t)(nlp + (P0.ngroups > P1.ngroups ? P0.ngroups : P1.ngroups)) * 4, s, P0, P1, d, ch, nlp, p.seed, p.surv,
                            p.nsurv, p.local, p.tone);
@@ -1621,7 +1727,7 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_
     launch_couple(c, R, s, (long)gb * VAMD_PACKETBLOBS, 0, VAMD_PACKETBLOBS, p.mdct, m_ilogmask, M->iwork, M->nonzero);
     prof_mark(c, VAMD_ST_COUPLE);
     if (M->res_entries || M->packets)
-      launch_residue_pack(c, R, s, (long)gb * VAMD_PACKETBLOBS, VAMD_PACKETBLOBS, M->posts, M->post_valid, M->iwork, M->nonzero, rb,
+      launch_residue_pack(c, R, s, (long)gb * VAMD_PACKETBLOBS, VAMD_PACKETBLOBS, M->posts, nullptr, M->post_valid, M->iwork, M->nonzero, rb,
                           M->packets, M->packet_stride, M->packet_bits);
   } else if (level >= VAMD_LEVEL_FULL) {
     static const size_t floor_pad = getenv("VAMD_FLOOR_LDS_PAD") ? (size_t)atoi(getenv("VAMD_FLOOR_LDS_PAD")) : 0;  // (experiment: occupancy)
@@ -1630,14 +1736,14 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_
     hipLaunchKernelGGL(k_floor, dim3(gcb), dim3(64), floor_lds, s,
                        (const Bound *)c->d_bound, W, d, ch, p.noise, fold_in_floor ? R->io->tone : p.tone, fold_in_floor ? p.seed : nullptr, p.surv, p.nsurv, p.local,
                        nlp_all, p.mdct_raw, p.mdct,
-                       R->io->logmask, p.posts, p.post_valid, p.ilogmask, p.nonzero);
+                       R->io->logmask, p.posts, p.post_valid, p.ilogmask, p.nonzero, p.wrapped);
     if (R->io->ilogmask)  // (a tap: tests and callers with their own quantiser)
       hipLaunchKernelGGL(k_widen_ilog, dim3(1024), dim3(256), 0, s, (long)gcb * n2, (const ilog_t *)p.ilogmask, R->io->ilogmask);
     prof_mark(c, VAMD_ST_FLOOR);
     launch_couple(c, R, s, gb, VAMD_PACKETBLOBS / 2, 1, p.mdct, p.ilogmask, p.iwork, p.nonzero);
     prof_mark(c, VAMD_ST_COUPLE);
     if (R->io && (R->io->res_entries || R->io->packets))
-      launch_residue_pack(c, R, s, gb, 1, p.posts, p.post_valid, p.iwork, p.nonzero, rb, R->io->packets, R->io->packet_stride,
+      launch_residue_pack(c, R, s, gb, 1, p.posts, p.wrapped, p.post_valid, p.iwork, p.nonzero, rb, R->io->packets, R->io->packet_stride,
                           R->io->packet_bits);
   }
 }

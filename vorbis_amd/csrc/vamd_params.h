@@ -98,6 +98,7 @@ struct ResP {
 struct PackP {
   const vamd_floor1_tab *ftab[VAMD_MAX_SUBMAPS];
   const vamd_book_tab *books;
+  int nbooks;
   const unsigned char *base;
   int modebits;                    // width of the mode number
   int qbits[VAMD_MAX_SUBMAPS];     // ilog(quant_q - 1): width of the two end posts
