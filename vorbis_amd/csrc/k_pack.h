@@ -234,7 +234,7 @@ VAMD_DEV void pack_residue(const PackP &K, const PackTabs &T, const ResP &R, con
   const int partvals = R.partvals, ns = slots / partvals;  // streams: 1 (type 2) or the coded channels (type 1)
   WAVE_FOR(i, slots) cls[i] = res_class[i];
   WAVE_SYNC();
-  residue_offsets(R, slots, cls, off, info);
+  residue_offsets<true>(R, slots, cls, off, info);  // (one wave: k_pack's only one, k_pack_pair's first)
   pc.mark(3);
   const int ppw = t.groupbook_dim;
   {

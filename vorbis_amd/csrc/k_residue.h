@@ -80,18 +80,26 @@ VAMD_DEV int residue_besterror(const ResP &R, const vamd_book_tab &bk, int *a) {
 // (`partvals` = number of slots): off[s*partvals + i] = entries written before slot i's stage-s vectors,
 // off[stages*partvals] = the total (returned); `info` keeps each pair's book (-1 = the class skips
 // the stage) so that nothing downstream goes back to the class tables.  cls/off/info in LDS.
+//   WAVE_ONLY: the caller is one wave of a larger workgroup (k_pack_pair): its lanes alone, no workgroup barrier
+template <bool WAVE_ONLY = false>
 VAMD_DEV int residue_offsets(const ResP &R, int partvals, const int *cls, int *off, int *info) {
   const vamd_residue_tab &t = *R.tab;
   const int spp = t.grouping, items = t.stages * partvals;
-  TEAM_FOR(it, items) {
+  auto item = [&](int it) {
     const int s = it / partvals, i = it - s * partvals;
     const int c = cls[i];
     const int bn = ((t.secondstages[c] >> s) & 1) ? t.partbooks[c][s] : -1;
     info[it] = bn;
     off[it] = bn >= 0 ? spp / R.books[bn].dim : 0;
+  };
+  if constexpr (WAVE_ONLY) {
+    WAVE_FOR(it, items) item(it);
+    WAVE_SYNC();
+  } else {
+    TEAM_FOR(it, items) item(it);
+    TEAM_SYNC();
   }
-  TEAM_SYNC();
-  if (TEAM_FIRST_WAVE) {
+  if (WAVE_ONLY || TEAM_FIRST_WAVE) {
     int carry = 0;  // exclusive prefix sum over the <= 8 x 256 counts, a wave-width at a time
     for (int base = 0; base < items; base += NLANES) {
       const int it = base + LANE;
@@ -102,7 +110,11 @@ VAMD_DEV int residue_offsets(const ResP &R, int partvals, const int *cls, int *o
     }
     if (LANE == 0) off[items] = carry;
   }
-  TEAM_SYNC();
+  if constexpr (WAVE_ONLY) {
+    WAVE_SYNC();
+  } else {
+    TEAM_SYNC();
+  }
   return off[items];
 }
 

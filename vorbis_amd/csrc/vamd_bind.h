@@ -561,6 +561,7 @@ inline void bind_params(const std::vector<unsigned char> &image, const std::vect
     K.base = base;
     K.modebits = h.modebits;
     long bits = 1 + K.modebits + 2;  // the longest packet this size class can produce, field by field
+    long head = bits;                // ... and the longest header + floors part of one
     bool all_ok = true;
     int ent_base = 0, lds = 0, offi = 0;
     for (int sm = 0; sm < VAMD_MAX_SUBMAPS; sm++) {
@@ -623,14 +624,17 @@ inline void bind_params(const std::vector<unsigned char> &image, const std::vect
         for (int k = 0; k < (1 << f.class_subs[c]); k++) sub = std::max(sub, longest(f.class_subbook[c][k]));
         fl += (f.class_subs[c] ? longest(f.class_book[c]) : 0) + f.class_dim[c] * sub;
       }
-      if (sm < m.submaps) bits += fl * bundle;
+      if (sm < m.submaps) bits += fl * bundle, head += fl * bundle;
     }
     B->res_cap[W] = all_ok ? ent_base : 0;
     B->res_lds_ints[W] = lds;
     B->res_off_ints[W] = offi;
     if (!all_ok)
       for (int sm = 0; sm < VAMD_MAX_SUBMAPS; sm++) B->res[W][sm].covered = 0;
-    K.capacity = all_ok ? (int)(((bits + 31) / 32) * 4) : 0;
+    // (k_pack_pair assembles the residue part a whole number of words past the longest possible head before it moves it
+    // down to the real one: two words of slack)
+    K.head_words = (int)((head + 31) / 32) + 1;
+    K.capacity = all_ok ? (int)(((bits + 31) / 32) * 4) + 8 : 0;
   }
   for (int p = 0; p < 4; p++) {
     const vamd_psy_tab &t = h.psy[p];

@@ -754,6 +754,109 @@ __global__ __launch_bounds__(64) void k_pack(PackP K, FloorP F0, FloorP F1, ResP
   pc.flush();
 }
 
+// The same for a handful of packets, TWO waves each: the header + floors part and the residue part of a packet are
+// looked up and packed at the same time -- wave 1 writes the former where it belongs; wave 0 assembles the latter
+// K.head_words into the row, past the longest head there can be, and when both are done the two waves move it down to
+// where the head really ended (a shift by a whole number of words and `sh` bits, low words first: a destination never
+// lies above its source).  A lone wave's packet is two strings of dependent lookups one after the other (k_pack: 10 +
+// 11 us of a block's latency); here they overlap.  LDS: two rings, then as k_pack.
+__global__ __launch_bounds__(128) void k_pack_pair(PackP K, FloorP F0, FloorP F1, ResP R0, ResP R1, ChMap cm, int ent_row, int lds_ints,
+                                                   DescP d, int ch, int W, int nblobs, const int *__restrict__ posts,
+                                                   const int *__restrict__ wrapped, const int *__restrict__ post_valid,
+                                                   const int *__restrict__ res_class,
+                                                   const unsigned short *__restrict__ res_entries,
+                                                   const unsigned char *__restrict__ res_books,
+                                                   const int *__restrict__ res_count, unsigned *__restrict__ packets,
+                                                   int stride_words, int *__restrict__ packet_bits) {
+  const long u = blockIdx.x, blk = u / nblobs;
+  const int wave = threadIdx.x >> 6;
+  int *ring = (int *)vamd_smem + wave * VAMD_PK_RING;  // [2][VAMD_PK_RING]
+  int *outv = (int *)vamd_smem + 2 * VAMD_PK_RING;     // [VAMD_POSTS_STRIDE]   (wave 1)
+  int *cls = outv + VAMD_POSTS_STRIDE;                 // [VAMD_RES_CLASS_STRIDE], off, info (wave 0)
+  int *off = cls + VAMD_RES_CLASS_STRIDE;
+  int *info = off + lds_ints;
+  int *tabs = info + lds_ints;
+  int *share = tabs + VAMD_PK_FTAB_INTS + 3 * K.nbooks;  // [4]: head bits, head's last (partial) word, residue bits
+  PhaseClock pc;
+  pc.start(d.dbg ? d.dbg + 72 : nullptr);
+  PackTabs T;
+  T.at(tabs);
+  for (int b = threadIdx.x; b < K.nbooks; b += blockDim.x) {  // (pack_book_table, both waves)
+    const vamd_book_tab &bk = K.books[b];
+    T.books[3 * b] = bk.entries;
+    T.books[3 * b + 1] = (int)bk.off_lengths;
+    T.books[3 * b + 2] = (int)bk.off_codes;
+  }
+  WAVE_FOR(i, VAMD_PK_RING) ring[i] = 0;
+  __syncthreads();
+  unsigned *row = packets + u * (long)stride_words;
+  BitRing r;
+  r.ring = ring;
+  r.bitpos = 0;
+  r.flushed = 0;
+  if (wave == 1) {
+    r.out = row;
+    r.out_words = stride_words;
+    {  // lib/mapping0.c:598-604, as pack_block
+      const int lW = d_lW(d, blk), nW = d_nW(d, blk);
+      unsigned hdr = (unsigned)W << 1;
+      int len = 1 + K.modebits;
+      if (W) {
+        hdr |= (unsigned)(lW ? 1 : 0) << len;
+        hdr |= (unsigned)(nW ? 1 : 0) << (len + 1);
+        len += 2;
+      }
+      ring_put(r, hdr, LANE == 0 ? len : 0);
+    }
+    for (int c = 0; c < ch; c++) {
+      const int sm = cm.sub[c];
+      pack_floor(K, T, sm, sm ? F1 : F0, posts + (u * ch + c) * VAMD_POSTS_STRIDE,
+                 wrapped ? wrapped + (u * ch + c) * VAMD_POSTS_STRIDE : nullptr, post_valid[u * ch + c], outv, r, pc);
+    }
+    ring_flush(r, r.bitpos >> 5);  // whole words out; the last, partial one goes to wave 0's first
+    if (LANE == 0) {
+      share[0] = (int)r.bitpos;
+      share[1] = (r.bitpos & 31) ? ring[(r.bitpos >> 5) & (VAMD_PK_RING - 1)] : 0;
+    }
+  } else {
+    r.out = row + K.head_words;
+    r.out_words = stride_words - K.head_words;
+    for (int sm = 0; sm < cm.submaps; sm++) {
+      const ResP &R = sm ? R1 : R0;
+      pack_residue(K, T, R, res_class + u * (cm.submaps * VAMD_RES_CLASS_STRIDE) + R.cls_base,
+                   res_entries + u * (long)ent_row + R.ent_base, res_books ? res_books + u * (long)ent_row + R.ent_base : nullptr,
+                   res_count + (u * cm.submaps + sm) * 2, cls, off, info, r, pc);
+    }
+    ring_flush(r, (r.bitpos + 31) >> 5);
+    if (LANE == 0) share[2] = (int)r.bitpos;
+  }
+  __syncthreads();  // (workgroup scope: wave 0's words in the row are visible to wave 1's lanes and the other way round)
+  const int headbits = share[0], resbits = share[2];
+  const unsigned headword = (unsigned)share[1];
+  const int total = headbits + resbits;
+  const int w0 = headbits >> 5, wend = (total + 31) >> 5;
+  const int delta = K.head_words * 32 - headbits;  // > 0: bits the residue part moves down by
+  const int dw = delta >> 5, sh = delta & 31;
+  const int src_end = K.head_words + ((resbits + 31) >> 5);  // the residue part's words are row[head_words, src_end)
+  for (int base = w0; base < src_end; base += (int)blockDim.x) {
+    const int w = base + (int)threadIdx.x;
+    unsigned val = 0;
+    if (w < wend) {
+      const int s0 = w + dw;
+      const unsigned lo = s0 >= K.head_words && s0 < src_end && s0 < stride_words ? row[s0] : 0u;
+      const unsigned hi = s0 + 1 >= K.head_words && s0 + 1 < src_end && s0 + 1 < stride_words ? row[s0 + 1] : 0u;
+      val = sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
+      if (w == w0) val |= headword;
+    }
+    __syncthreads();  // every source of this trip is read before any of its destinations is written
+    if (w < src_end && w < stride_words) row[w] = val;  // (past wend: what the move left behind, zeroed)
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) packet_bits[u] = total;
+  pc.mark(6);
+  pc.flush();
+}
+
 // ---------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------
@@ -1565,15 +1668,24 @@ static void launch_residue_pack(vamd_ctx *c, BatchRun *R, hipStream_t s, long un
                                 void *packets, int64_t packet_stride, int32_t *packet_bits) {
   const int W = R->W, ch = c->B.channels, n2 = c->B.xf[W].n / 2;
   const ChMap &cm = c->B.chmap[W];
+  static const long res_team_max = getenv("VAMD_RES_TEAM_MAX") ? atol(getenv("VAMD_RES_TEAM_MAX")) : 2048;
   for (int sm = 0; sm < cm.submaps; sm++)
-    // a stereo bundle's search keeps two waves busy, the five-channel bundle of the 5.1 layout four
-    hipLaunchKernelGGL(k_residue, dim3((unsigned)units), dim3(64 * (c->B.res[W][sm].bundle * n2 > 4096 ? VAMD_RES_WAVES : 2)),
+    // a stereo bundle's search keeps two waves busy, the five-channel bundle of the 5.1 layout four; a handful of units
+    // takes four either way (nothing else wants the CU, and a lone unit's latency is the caller's)
+    hipLaunchKernelGGL(k_residue, dim3((unsigned)units), dim3(64 * (c->B.res[W][sm].bundle * n2 > 4096 || units <= res_team_max ? VAMD_RES_WAVES : 2)),
                        (size_t)c->B.res[W][sm].lds_ints * 4, s, c->B.res[W][sm], cm, sm,
                        c->B.res_cap[W], R->d, ch, n2, iwork, nonzero, rb.cls, rb.entries, rb.count, packets ? rb.books : nullptr);
   prof_mark(c, VAMD_ST_RESIDUE);
   if (packets) {
     const size_t lds = ((size_t)VAMD_PK_RING + VAMD_POSTS_STRIDE + VAMD_RES_CLASS_STRIDE + 2 * (size_t)c->B.res_off_ints[W] +
                         VAMD_PK_FTAB_INTS + 3 * (size_t)c->B.pack[W].nbooks) * 4;
+    static const long pair_max = getenv("VAMD_PACK_PAIR_MAX") ? atol(getenv("VAMD_PACK_PAIR_MAX")) : 2048;
+    if (units <= pair_max && (int)(packet_stride / 4) > c->B.pack[W].head_words)  // a handful of packets: two waves each
+      hipLaunchKernelGGL(k_pack_pair, dim3((unsigned)units), dim3(128), lds + ((size_t)VAMD_PK_RING + 4) * 4, s, c->B.pack[W],
+                         c->B.floor[W][0], c->B.floor[W][1], c->B.res[W][0], c->B.res[W][1], cm, c->B.res_cap[W], c->B.res_off_ints[W],
+                         R->d, ch, W, nblobs, posts, wrapped, post_valid, rb.cls, rb.entries, rb.books, rb.count, (unsigned *)packets,
+                         (int)(packet_stride / 4), packet_bits);
+    else
     hipLaunchKernelGGL(k_pack, dim3((unsigned)units), dim3(64), lds, s, c->B.pack[W], c->B.floor[W][0], c->B.floor[W][1],
                        c->B.res[W][0], c->B.res[W][1], cm, c->B.res_cap[W], c->B.res_off_ints[W], R->d, ch, W, nblobs, posts,
                        wrapped, post_valid, rb.cls, rb.entries, rb.books, rb.count, (unsigned *)packets, (int)(packet_stride / 4), packet_bits);

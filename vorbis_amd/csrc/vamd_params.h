@@ -103,6 +103,7 @@ struct PackP {
   int modebits;                    // width of the mode number
   int qbits[VAMD_MAX_SUBMAPS];     // ilog(quant_q - 1): width of the two end posts
   int capacity;   // bytes the largest packet of this size class can take (multiple of 4); 0 = not assembled here
+  int head_words; // words that hold the longest header + floors part of a packet, plus one
 };
 
 // which submap (floor, residue) each channel belongs to: vorbis_info_mapping0.chmuxlist
