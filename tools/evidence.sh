@@ -1,0 +1,22 @@
+#!/bin/bash
+# Run on the GPU box (one gpurun call): everything a round's committed evidence is made from, on ONE build --
+# the GPU test suite, the soak, the counter / trace passes (tools/profile.sh), the bench lines, the batcher sweep and the
+# per-block path.  Outputs under gpurun_out/ (evidence/, profile/, soak.txt); tools/make_profiles.py and a few copies
+# turn them into profiles/rNN_*.
+R=${GRAFT_REPO_ROOT:-/root/repo}
+E=$R/gpurun_out/evidence
+rm -rf $E; mkdir -p $E
+cd $R
+python -c "import bench; print(bench.source_hash())" > $E/source_hash.txt
+timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -4 > $E/pytest_gpu.txt
+timeout 900 python tools/soak.py ${SOAK:-20000} $R/gpurun_out/soak.txt > /dev/null 2>&1
+tail -3 $R/gpurun_out/soak.txt > $E/soak_tail.txt
+bash tools/profile.sh > $E/profile.log 2>&1
+for w in c4 c5 c3 c2; do
+  timeout 900 python bench.py --workload $w > $E/bench_$w.json 2> $E/bench_$w.err
+done
+timeout 900 bash tools/batcher_sweep.sh > $E/batcher.txt 2>&1
+timeout 300 bash tools/kt_block.sh > $E/block_path.txt 2>&1
+timeout 300 python tools/gpu_block_latency.py >> $E/block_path.txt 2>/dev/null
+timeout 300 python tools/gpu_block_phases.py >> $E/block_path.txt 2>/dev/null
+ls -la $E
