@@ -210,6 +210,7 @@ struct NoiseGeom {
   static constexpr int NW = n2 >= 256 ? 4 : (n2 >= 64 ? n2 / 64 : 1);  // waves per team
   static constexpr int KPL = n2 / (64 * NW) > 0 ? n2 / (64 * NW) : 1;  // bins per lane
 };
+// the stage for the teams `first`, first + nteams, ... of the batch (k_noise: the whole grid; k_noise_tone: its first part)
 template <int LOGN2>
 __global__ __launch_bounds__(64 * NoiseGeom<LOGN2>::NW, NoiseGeom<LOGN2>::KPL <= 4 ? 8 : 4) void k_noise(PsyP P0, PsyP P1, DescP d, int ch, long ncb,
                                                                      const float *__restrict__ mdct_raw,
@@ -246,6 +247,34 @@ __global__ __launch_bounds__(64 * NoiseGeom<LOGN2>::NW, NoiseGeom<LOGN2>::KPL <=
     LANE_BINS(k, i, i0, KPL, n2) noise[cb * n2 + i] = o[k];
     LANE_BINS(k, i, i0, KPL, n2) lm[k] = mdct_raw[nb * n2 + i];
   }
+  pc.flush();
+}
+
+// The same stage for the one block of workgroup blockIdx.x (k_noise_tone).  A restatement of k_noise's body, not a function
+// the two share: the batch kernel sits exactly on its 64-register line, and as a caller of a shared
+// body it came out with six registers spilt.
+template <int LOGN2>
+__device__ __forceinline__ void noise_teams_once(const PsyP &P0, const PsyP &P1, const DescP &d, int ch, const float *__restrict__ mdct_raw,
+                                                 float *__restrict__ noise) {
+  constexpr int n2 = NoiseGeom<LOGN2>::n2, KPL = NoiseGeom<LOGN2>::KPL;
+  float *S = (float *)vamd_smem;  // the five running sums and nothing else: see VAMD_NZ_STRIDE
+  const int i0 = (threadIdx.x >> 6) * 64 * KPL;  // this wave's first bin
+  PhaseClock pc;
+  pc.start(d.dbg ? d.dbg + 16 : nullptr);
+  const long cb = blockIdx.x;
+  float lm[KPL], o[KPL];
+  int braw[KPL], bk[KPL];
+  LANE_BINS(k, i, i0, KPL, n2) lm[k] = mdct_raw[cb * n2 + i];
+  const PsyP &P = d_bt(d, (long)((unsigned)cb / (unsigned)ch)) ? P1 : P0;
+  noise_bark_fetch<KPL, LOGN2>(P, braw, i0);
+  noise_bark_edges<KPL, LOGN2>(P, braw, bk, i0);
+  const float compand_lane = LANE < VAMD_NOISE_COMPAND_LEVELS ? P.noisecompand[LANE] : 0.f;
+  LANE_BINS(k, i, i0, KPL, n2) lm[k] = todB_345(lm[k]);  // (the spectrum in dB, lib/mapping0.c:384-385)
+  noisemask_bins<ScanTeam, KPL, LOGN2>(
+      P, lm, bk, o, S,
+      [&](int dB) { return __int_as_float(__builtin_amdgcn_ds_bpermute(dB << 2, __float_as_int(compand_lane))); }, ScanTeam(), pc,
+      i0);
+  LANE_BINS(k, i, i0, KPL, n2) noise[cb * n2 + i] = o[k];
   pc.flush();
 }
 
@@ -370,13 +399,11 @@ __global__ __launch_bounds__(64) void k_tone_seed(PsyP P0, PsyP P1, DescP d, int
 // 9 us + k_tone_chase_wave 25 us -> this kernel's 14).  Every libvorbisenc setup has eight lines per window; others
 // take the two kernels.  LDS: the padded seed lines, then a 16-slot ring for the serial walk's fallback.
 template <int LP>
-__global__ __launch_bounds__(64) void k_tone_seed_chase(PsyP P0, PsyP P1, DescP d, int ch, int nlp, int nrp,
-                                                        const float *__restrict__ peaks,
-                                                        const float *__restrict__ local_ampmax,
-                                                        const float *__restrict__ ampmax_glob, float *__restrict__ ampmax_make,
-                                                        float *__restrict__ seed_g, unsigned short *__restrict__ surv,
-                                                        int *__restrict__ nsurv) {
-  const long cb = blockIdx.x;
+__device__ __forceinline__ void tone_seed_chase_run(const PsyP &P0, const PsyP &P1, const DescP &d, int ch, int nlp, int nrp,
+                                                    const float *__restrict__ peaks, const float *__restrict__ local_ampmax,
+                                                    const float *__restrict__ ampmax_glob, float *__restrict__ ampmax_make,
+                                                    float *__restrict__ seed_g, unsigned short *__restrict__ surv,
+                                                    int *__restrict__ nsurv, long cb) {
   const long blk = cb / ch;
   const PsyP &P = d_bt(d, blk) ? P1 : P0;
   float g_amp;  // (the block's ampmax: as k_tone_seed)
@@ -444,6 +471,35 @@ __global__ __launch_bounds__(64) void k_tone_seed_chase(PsyP P0, PsyP P1, DescP 
   }
   pc.mark(2);
   pc.flush();
+}
+template <int LP>
+__global__ __launch_bounds__(64) void k_tone_seed_chase(PsyP P0, PsyP P1, DescP d, int ch, int nlp, int nrp,
+                                                        const float *__restrict__ peaks,
+                                                        const float *__restrict__ local_ampmax,
+                                                        const float *__restrict__ ampmax_glob, float *__restrict__ ampmax_make,
+                                                        float *__restrict__ seed_g, unsigned short *__restrict__ surv,
+                                                        int *__restrict__ nsurv) {
+  tone_seed_chase_run<LP>(P0, P1, d, ch, nlp, nrp, peaks, local_ampmax, ampmax_glob, ampmax_make, seed_g, surv, nsurv, blockIdx.x);
+}
+
+// Both masks of a handful of blocks in ONE launch: workgroups [0, ncb) are the noise stage's teams, [ncb, 2 ncb) the tone
+// chain's waves (the first wave of the workgroup; the others leave).  The two stages need nothing of each other, and a
+// second stream with its event pair costs a lone block as much as it saves -- below 64 channel-blocks they used to run one
+// after the other (a stereo block: 13 + 24 us of its latency; here 24).
+template <int LOGN2, int LP>
+__global__ __launch_bounds__(64 * NoiseGeom<LOGN2>::NW) void k_noise_tone(PsyP P0, PsyP P1, DescP d, int ch, long ncb,
+                                                                          const float *__restrict__ mdct_raw, float *__restrict__ noise,
+                                                                          int nlp, int nrp, const float *__restrict__ peaks,
+                                                                          const float *__restrict__ local_ampmax,
+                                                                          const float *__restrict__ ampmax_glob, float *__restrict__ ampmax_make,
+                                                                          float *__restrict__ seed_g, unsigned short *__restrict__ surv,
+                                                                          int *__restrict__ nsurv) {
+  if ((long)blockIdx.x < ncb) {
+    noise_teams_once<LOGN2>(P0, P1, d, ch, mdct_raw, noise);
+  } else if (threadIdx.x < 64) {
+    tone_seed_chase_run<LP>(P0, P1, d, ch, nlp, nrp, peaks, local_ampmax, ampmax_glob, ampmax_make, seed_g, surv, nsurv,
+                            (long)blockIdx.x - ncb);
+  }
 }
 
 // one THREAD per channel-block: the ordered stack walk of seed_chase, VAMD_CHASE_LANES walks per wave.  (Measured
@@ -1752,7 +1808,34 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_
       (void)hipEventRecord(c->ev_fork, c->stream);
       (void)hipStreamWaitEvent(c->side, c->ev_fork, 0);
     }
-    {
+    const int nlp = VAMD_LINES_PAD(nl);
+    const size_t seed_lds = (size_t)(seed_pad_lo(P0.eighth_octave_lines) + nlp + seed_pad_hi(P0.eighth_octave_lines)) * 4;
+    // a lane per block for batches, a wave per block (the walk in 64 chunks) where that would leave the GPU to a
+    // handful of lanes walking ~800 lines each: the per-block entry points, the batcher's small batches
+    static const long wave_max_cb = getenv("VAMD_CHASE_WAVE_MAX") ? atol(getenv("VAMD_CHASE_WAVE_MAX")) : 32768;
+    const bool by_wave = (long)gcb <= wave_max_cb && P0.eighth_octave_lines <= 16 && nl <= 2048;
+    const bool lp8 = P0.eighth_octave_lines == 8 && P1.eighth_octave_lines == 8;
+    // a handful of blocks, no second stream: both masks in one launch, side by side (k_noise_tone)
+    static const bool merge_env = getenv("VAMD_MASKS_SEPARATE") == nullptr;
+    const bool merged = merge_env && !overlap && by_wave && lp8;
+    if (merged) {
+      const size_t nlds = (size_t)5 * VAMD_NZ_STRIDE(n2) * 4, tlds = seed_lds + (size_t)VAMD_RING * 8;
+#define VAMD_GO(L)                                                                                                          \
+  hipLaunchKernelGGL((k_noise_tone<L, 8>), dim3(2 * gcb), dim3(64 * NoiseGeom<L>::NW), nlds > tlds ? nlds : tlds, s, P0, P1, d, ch, \
+                     (long)gcb, p.mdct_raw, p.noise, nlp, run_peaks_stride(P0), p.peaks, p.local, p.ampglob,                  \
+                     R->make_ampmax ? p.ampglob : nullptr, p.seed, p.surv, p.nsurv)
+      switch (n2) {
+        case 32: VAMD_GO(5); break;
+        case 64: VAMD_GO(6); break;
+        case 128: VAMD_GO(7); break;
+        case 256: VAMD_GO(8); break;
+        case 512: VAMD_GO(9); break;
+        case 1024: VAMD_GO(10); break;
+        default: VAMD_GO(11); break;
+      }
+#undef VAMD_GO
+      prof_mark(c, VAMD_ST_NOISE);
+    } else {
       // persistent teams.  A CU's LDS and 32 wave slots hold 8 of them at 1024 bins (both exactly full) -- but then the
       // tone chain on the side stream finds no room until they retire and runs behind them.  Six teams (three quarters of
       // the wave slots) keep the vector units as busy -- the stage is issue-bound -- and leave eight slots and 40 KB in
@@ -1789,18 +1872,13 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_
         default: VAMD_GO(11); break;  // 2048 bins: the largest block size the context accepts
       }
 #undef VAMD_GO
+      prof_mark(c, VAMD_ST_NOISE);
     }
-    prof_mark(c, VAMD_ST_NOISE);
     if (overlap) s = c->side;
     {
-      const int nlp = VAMD_LINES_PAD(nl);
-      const size_t seed_lds = (size_t)(seed_pad_lo(P0.eighth_octave_lines) + nlp + seed_pad_hi(P0.eighth_octave_lines)) * 4;
-      // a lane per block for batches, a wave per block (the walk in 64 chunks) where that would leave the GPU to a
-      // handful of lanes walking ~800 lines each: the per-block entry points, the batcher's small batches
-      static const long wave_max_cb = getenv("VAMD_CHASE_WAVE_MAX") ? atol(getenv("VAMD_CHASE_WAVE_MAX")) : 32768;
-      const bool by_wave = (long)gcb <= wave_max_cb && P0.eighth_octave_lines <= 16 && nl <= 2048;
-      const bool lp8 = P0.eighth_octave_lines == 8 && P1.eighth_octave_lines == 8;
-      if (by_wave && lp8) {  // ... and seed + chase in one launch (k_tone_seed_chase)
+      if (merged) {
+        // (launched with the noise stage)
+      } else if (by_wave && lp8) {  // ... and seed + chase in one launch (k_tone_seed_chase)
         hipLaunchKernelGGL(k_tone_seed_chase<8>, dim3(gcb), dim3(64), seed_lds + (size_t)VAMD_RING * 8, s, P0, P1, d, ch, nlp,
                            run_peaks_stride(P0), p.peaks, p.local, p.ampglob, R->make_ampmax ? p.ampglob : nullptr, p.seed, p.surv,
                            p.nsurv);
