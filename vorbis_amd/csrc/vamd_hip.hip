@@ -1211,7 +1211,7 @@ struct vamd_ctx {
   // noise masking and tone masking read different inputs and write different outputs; the tone
   // kernels run on this library-owned side stream, forked from / joined back into `stream`
   hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;  // (ev_join2: the short size class of a mixed run)
   bool overlap = true;
   float couple_band = VAMD_COUPLE_BAND;  // k_couple.h, chan_bin_sure
   Bound B;                 // parameter structs bound to the HBM image
@@ -1354,6 +1354,7 @@ int vamd_create(vamd_ctx **out, const void *setup_blob, size_t blob_bytes, int d
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming);
   c->overlap = getenv("VAMD_NO_OVERLAP") == nullptr;
   // (test aid: k_couple's estimate-then-verify margin as a power of two; 1 sends every quad through the exact path)
   c->couple_band = getenv("VAMD_COUPLE_BAND_LOG2") ? ldexpf(1.f, atoi(getenv("VAMD_COUPLE_BAND_LOG2"))) : VAMD_COUPLE_BAND;
@@ -1365,6 +1366,7 @@ int vamd_create(vamd_ctx **out, const void *setup_blob, size_t blob_bytes, int d
   if (c->d_bound) (void)hipFree(c->d_bound);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
     if (c->side) (void)hipStreamDestroy(c->side);
     if (caller_device >= 0) (void)hipSetDevice(caller_device);
     delete c;
@@ -1381,6 +1383,7 @@ int vamd_create(vamd_ctx **out, const void *setup_blob, size_t blob_bytes, int d
     (void)hipFree(c->d_image);
     (void)hipEventDestroy(c->ev_fork);
     (void)hipEventDestroy(c->ev_join);
+    (void)hipEventDestroy(c->ev_join2);
     (void)hipStreamDestroy(c->side);
     if (caller_device >= 0) (void)hipSetDevice(caller_device);
     delete c;
@@ -1404,6 +1407,7 @@ void vamd_destroy(vamd_ctx *c) {
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
   if (c->side) (void)hipStreamDestroy(c->side);
   if (c->d_image) (void)hipFree(c->d_image);
   if (c->d_bound) (void)hipFree(c->d_bound);
@@ -1736,7 +1740,9 @@ static void launch_residue_pack(vamd_ctx *c, BatchRun *R, hipStream_t s, long un
     const size_t lds = ((size_t)VAMD_PK_RING + VAMD_POSTS_STRIDE + VAMD_RES_CLASS_STRIDE + 2 * (size_t)c->B.res_off_ints[W] +
                         VAMD_PK_FTAB_INTS + 3 * (size_t)c->B.pack[W].nbooks) * 4;
     static const long pair_max = getenv("VAMD_PACK_PAIR_MAX") ? atol(getenv("VAMD_PACK_PAIR_MAX")) : 2048;
-    if (units <= pair_max && (int)(packet_stride / 4) > c->B.pack[W].head_words)  // a handful of packets: two waves each
+    // a handful of packets: two waves each -- where the rows hold any packet (the residue part is assembled past the
+    // longest possible head and then moved down: in a shorter row the end of a cut-off packet would be lost on the way)
+    if (units <= pair_max && packet_stride >= c->B.pack[W].capacity)
       hipLaunchKernelGGL(k_pack_pair, dim3((unsigned)units), dim3(128), lds + ((size_t)VAMD_PK_RING + 4) * 4, s, c->B.pack[W],
                          c->B.floor[W][0], c->B.floor[W][1], c->B.res[W][0], c->B.res[W][1], cm, c->B.res_cap[W], c->B.res_off_ints[W],
                          R->d, ch, W, nblobs, posts, wrapped, post_valid, rb.cls, rb.entries, rb.books, rb.count, (unsigned *)packets,
@@ -1785,7 +1791,13 @@ static void launch_couple(vamd_ctx *c, BatchRun *R, hipStream_t s, long units, i
                        blob_base, nblobs, R->d, mdct, ilogmask, iwork, nonzero, c->couple_band);
 }
 
-static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_io *M = nullptr, ilog_t *m_ilogmask = nullptr) {
+//   part: 1 = the masks only (noise on the main stream, the tone chain beside it, their join left open), 2 = the rest
+//         (join, floor, couple, ...), 3 = both.  A mixed run issues both size classes' masks before either's rest, so that
+//         the short blocks' tone chain -- as long as the long blocks', beside a noise mask a fifth as long -- has the long
+//         blocks' noise mask and floor fits to run beside (C5: visible tone tail 1.08 -> see DESIGN section 6).
+//   forked: the side stream already waits for everything the tone chain needs (run_streams_mixed's ampmax chain)
+static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_io *M = nullptr, ilog_t *m_ilogmask = nullptr,
+                        int part = 3, bool forked = false) {
   if (R->nb == 0) return;
   const ResBufs &rb = R->rb;
   const int W = R->W, ch = c->B.channels;
@@ -1803,8 +1815,9 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_
   const int nlp_all = VAMD_LINES_PAD(nl);
   const size_t fold_lds = (size_t)(nlp_all + (P0.ngroups > P1.ngroups ? P0.ngroups : P1.ngroups)) * 4;
   const bool fold_in_floor = fold_env && level >= VAMD_LEVEL_FULL && !M && n2 <= 64 * 4 * VAMD_QPL;
-  if (level >= VAMD_LEVEL_PSY) {
-    if (overlap) {  // fork: the tone chain needs only what is already queued on `stream`
+  hipEvent_t ev_join = W ? c->ev_join : c->ev_join2;
+  if (level >= VAMD_LEVEL_PSY && (part & 1)) {
+    if (overlap && !forked) {  // fork: the tone chain needs only what is already queued on `stream`
       (void)hipEventRecord(c->ev_fork, c->stream);
       (void)hipStreamWaitEvent(c->side, c->ev_fork, 0);
     }
@@ -1901,11 +1914,12 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_
         hipLaunchKernelGGL(k_tone_fold, dim3(gcb), dim3(64), (size_t)(nlp + (P0.ngroups > P1.ngroups ? P0.ngroups : P1.ngroups)) * 4, s, P0, P1, d, ch, nlp, p.seed, p.surv,
                            p.nsurv, p.local, p.tone);
     }
-    if (overlap) {  // join
-      (void)hipEventRecord(c->ev_join, c->side);
-      s = c->stream;
-      (void)hipStreamWaitEvent(s, c->ev_join, 0);
-    }
+    if (overlap) (void)hipEventRecord(ev_join, c->side);
+    s = c->stream;
+  }
+  if (!(part & 2)) return;
+  if (level >= VAMD_LEVEL_PSY) {
+    if (overlap) (void)hipStreamWaitEvent(s, ev_join, 0);  // join
     prof_mark(c, VAMD_ST_TONE);
   }
   if (level >= VAMD_LEVEL_FULL && M) {
@@ -2154,8 +2168,15 @@ static int run_streams_mixed(vamd_ctx *c, const vamd_batch_desc *desc_short, con
   prof_mark(c, VAMD_ST_AMPMAX);
   R[0].d.ampmax_in = R[0].p.ampin;
   R[1].d.ampmax_in = R[1].p.ampin;
-  launch_rest(c, &R[0], VAMD_LEVEL_FULL);
-  launch_rest(c, &R[1], VAMD_LEVEL_FULL);
+  if (chain_on_side) {  // both classes' masks first, the long blocks' leading
+    launch_rest(c, &R[1], VAMD_LEVEL_FULL, nullptr, nullptr, 1, true);
+    launch_rest(c, &R[0], VAMD_LEVEL_FULL, nullptr, nullptr, 1, true);
+    launch_rest(c, &R[1], VAMD_LEVEL_FULL, nullptr, nullptr, 2, true);
+    launch_rest(c, &R[0], VAMD_LEVEL_FULL, nullptr, nullptr, 2, true);
+  } else {
+    launch_rest(c, &R[0], VAMD_LEVEL_FULL);
+    launch_rest(c, &R[1], VAMD_LEVEL_FULL);
+  }
   if (chain_on_side && R[0].nb == 0 && R[1].nb == 0) {  // (cannot happen -- nblocks_total > 0 -- but nothing may be left unjoined)
     (void)hipEventRecord(c->ev_join, c->side);
     (void)hipStreamWaitEvent(c->stream, c->ev_join, 0);
