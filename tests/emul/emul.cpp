@@ -66,14 +66,18 @@ struct EmulMTaps {  // per candidate packet of a bitrate-managed block, [15][ch]
 };
 
 // residue search + packet assembly of one packet, the way k_residue / k_pack run them
+//   wrapped: floor1_encode's out[] as the floor stage left it ([ch][VAMD_POSTS_STRIDE]) or null.  The packet is assembled the
+//   way the GPU library does it -- the floor's out[] handed over, every entry's book from the residue search -- and once
+//   more the other way (out[] formed again, books searched for); *packet_bits = -1 if the two differ.
 static void residue_and_pack(const Bound &B, int W, int lW, int nW, const int *iwork, const int *nonzero, const int *posts,
                              const int *post_valid, int *res_class, unsigned short *res_entries, int *res_count,
-                             unsigned char *packet, int *packet_bits) {
+                             unsigned char *packet, int *packet_bits, const int *wrapped = nullptr) {
   const int ch = B.channels, n2 = B.bs[W] / 2;
   const ChMap &cm = B.chmap[W];
   PhaseClock pc;
   pc.start(nullptr);
   std::vector<int> lds(B.res_lds_ints[W] + 16);
+  std::vector<unsigned char> books((size_t)B.res_cap[W] + 16, 255);
   for (int sm = 0; sm < cm.submaps; sm++) {
     const ResP &Rp = B.res[W][sm];
     int *work = lds.data(), *cls = work + Rp.bundle * n2, *off = cls + VAMD_RES_CLASS_STRIDE,
@@ -83,14 +87,20 @@ static void residue_and_pack(const Bound &B, int W, int lW, int nW, const int *i
     for (int c = 0; c < ch; c++)
       if (cm.sub[c] == sm) ip[nb] = iwork + c * n2, nz[nb] = nonzero[c], nb++;
     residue_block(Rp, n2, ip, nz, work, cls, off, info, res_class + Rp.cls_base, res_entries + Rp.ent_base, res_count + 2 * sm,
-                  pc);
+                  pc, books.data() + Rp.ent_base);
   }
   if (!packet) return;
   std::vector<int> ring(VAMD_PK_RING), outv(VAMD_POSTS_STRIDE), cls(VAMD_RES_CLASS_STRIDE), off(B.res_off_ints[W]),
       info(B.res_off_ints[W]), tabs(VAMD_PK_FTAB_INTS + 3 * B.pack[W].nbooks);
-  pack_block(B.pack[W], B.floor[W][0], B.floor[W][1], B.res[W][0], B.res[W][1], cm, ch, W, lW, nW, posts, nullptr, post_valid, res_class, res_entries, nullptr, res_count,
-             ring.data(), outv.data(), cls.data(), off.data(), info.data(), tabs.data(), (unsigned *)packet, B.pack[W].capacity / 4,
-             packet_bits, pc);
+  pack_block(B.pack[W], B.floor[W][0], B.floor[W][1], B.res[W][0], B.res[W][1], cm, ch, W, lW, nW, posts, wrapped, post_valid, res_class, res_entries,
+             books.data(), res_count, ring.data(), outv.data(), cls.data(), off.data(), info.data(), tabs.data(), (unsigned *)packet,
+             B.pack[W].capacity / 4, packet_bits, pc);
+  std::vector<unsigned> again(B.pack[W].capacity / 4 + 1, 0);
+  int bits2 = 0;
+  pack_block(B.pack[W], B.floor[W][0], B.floor[W][1], B.res[W][0], B.res[W][1], cm, ch, W, lW, nW, posts, nullptr, post_valid, res_class, res_entries,
+             nullptr, res_count, ring.data(), outv.data(), cls.data(), off.data(), info.data(), tabs.data(), again.data(),
+             B.pack[W].capacity / 4, &bits2, pc);
+  if (bits2 != *packet_bits || memcmp(again.data(), packet, (size_t)((bits2 + 7) / 8)) != 0) *packet_bits = -1;
 }
 
 // couple / quantise / normalise with whichever form the layout needs (as launch_couple picks the kernel)
@@ -166,7 +176,7 @@ static int analyze_core(void *h, const float *pcm, int lW, int W, int nW, int bl
   std::vector<float> A(VAMD_XF_A_FLOATS(n)), Bw(VAMD_XF_B_FLOATS(n));
   std::vector<float> mdct_raw(ch * n2), logfft(ch * n2), logmdct(ch * n2), noise(ch * n2), tone(ch * n2),
       logmask(ch * n2), mdct(ch * n2), lmd(n2), mask(n2);
-  std::vector<int> posts(ch * VAMD_POSTS_STRIDE), post_valid(ch), iwork(ch * n2), nonzero(ch);
+  std::vector<int> posts(ch * VAMD_POSTS_STRIDE), post_valid(ch), iwork(ch * n2), nonzero(ch), wrapped(ch * VAMD_POSTS_STRIDE);
   std::vector<ilog_t> ilogmask(ch * n2);
   std::vector<float> local(ch);
   std::vector<ilog_t> m_ilog;
@@ -212,7 +222,7 @@ static int analyze_core(void *h, const float *pcm, int lW, int W, int nW, int bl
         continue;
       }
       nonzero[i] = floor_fit_render_block(F, n2, (const unsigned short *)lmd.data(), &sc, &posts[i * VAMD_POSTS_STRIDE],
-                                          &post_valid[i], &ilogmask[i * n2], pc);
+                                          &post_valid[i], &ilogmask[i * n2], pc, &wrapped[i * VAMD_POSTS_STRIDE]);
     }
   }
   {
@@ -250,7 +260,7 @@ static int analyze_core(void *h, const float *pcm, int lW, int W, int nW, int bl
   if (t->res_entries && t->res_class && t->res_count) {
     if (!B.res_cap[W]) return -130;
     residue_and_pack(B, W, lW, nW, iwork.data(), nonzero.data(), posts.data(), post_valid.data(), t->res_class,
-                     t->res_entries, t->res_count, t->packet, t->packet_bits);
+                     t->res_entries, t->res_count, t->packet, t->packet_bits, wrapped.data());
   }
 #define OUT(name, vec, type) \
   if (t->name) memcpy(t->name, vec.data(), sizeof(type) * vec.size())
