@@ -121,3 +121,19 @@ def test_chunked_chase_equals_serial_walk():
                 assert accepted, (trial, n, L, rounds)
             if kind == 6 and n >= 784:
                 assert not accepted and rounds < 0     # routed to the serial walk before any chunk is walked
+    # the register form (eight lines per window: k_tone_seed_chase) at the other line counts it meets -- 585 (short blocks),
+    # and up to 2048, where a chunk is 32 lines, the most its popped-mask holds
+    rng = np.random.default_rng(4)
+    for trial in range(120):
+        n = int(rng.choice([585, 777, 1999, 2048, 2047, 1025]))
+        x = (rng.random(n) * 60 - 30).astype(np.float32)
+        if trial % 4 == 1:
+            x = np.round(x / 6) * 6
+        elif trial % 4 == 2:
+            x[rng.random(n) < 0.6] = -9999.0
+        elif trial % 4 == 3:
+            x = (np.sin(np.arange(n) * rng.random() * 3) * 20).astype(np.float32)
+        same, accepted, ns, rounds = em.chase_compare(x.astype(np.float32), 8)
+        assert same and ns > 0, (trial, n)
+        if trial % 4 != 2:
+            assert accepted, (trial, n, rounds)
