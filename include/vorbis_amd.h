@@ -35,10 +35,15 @@ extern "C" {
 #define VAMD_EIMPL    (-130) /* OV_EIMPL: setup/feature outside the covered path */
 #define VAMD_EINVAL   (-131) /* OV_EINVAL: bad argument */
 #define VAMD_EVERSION (-134) /* OV_EVERSION: setup blob version mismatch */
-/* NOT a libvorbis code: the input (not the call) was outside the domain the reference's own arithmetic is defined on ("Input
- * domain" below).  Kept apart from VAMD_EINVAL so that a binding can tell a poisoned stream -- which it reports as OV_EINVAL
- * out of vorbis_analysis() -- from a programming error in its own arguments, which it should not swallow. */
-#define VAMD_EDOMAIN  (-140)
+/* NOT libvorbis codes: the input (not the call) was outside the domain the reference's own arithmetic is defined on ("Input
+ * domain" below).  Kept apart from VAMD_EINVAL so that a binding can tell such a block -- which it reports as OV_EINVAL out
+ * of vorbis_analysis() -- from a programming error in its own arguments, which it should not swallow.
+ *   VAMD_EDOMAIN     finite samples, but a quantised value beyond the bound up to which the reference's integer arithmetic
+ *                    is defined by C (vamd_quant_limit()): THIS block has no defined result; the stream goes on
+ *   VAMD_ENONFINITE  a NaN / Inf sample: the reference's own state (ampmax chain, detector history) is not a number from
+ *                    here on, and the stream is over */
+#define VAMD_EDOMAIN    (-140)
+#define VAMD_ENONFINITE (-141)
 
 /* lib/codec_internal.h:23-26 */
 #define VAMD_BLOCKTYPE_IMPULSE    0
@@ -56,7 +61,13 @@ typedef struct vamd_ctx vamd_ctx;
  * produced by vamd_pack_setup() (integration/vamd_pack_setup.c), copies it to
  * HBM on `device` and derives the static index tables the kernels use.
  * `device` < 0 keeps the calling thread's current HIP device. */
-int vamd_create(vamd_ctx **ctx, const void *setup_blob, size_t blob_bytes, int device);
+int vamd_create_abi(vamd_ctx **ctx, const void *setup_blob, size_t blob_bytes, int device, int caller_abi_version);
+/* The entry point is vamd_create(); it hands the library the VAMD_ABI_VERSION of the header the CALLER was compiled
+ * against, and the library refuses any other than its own (VAMD_EVERSION): the descriptor structs below grow between
+ * releases, and a caller built against a shorter one would have the library read past the end of what it wrote.  (There
+ * is deliberately no plain `vamd_create` symbol: a binary built before this rule fails to link instead of to behave.) */
+#define vamd_create(ctx, setup_blob, blob_bytes, device) \
+  vamd_create_abi((ctx), (setup_blob), (blob_bytes), (device), VAMD_ABI_VERSION)
 
 /* Counterpart of vorbis_dsp_clear() (lib/block.c:340-388) for the GPU state. */
 void vamd_destroy(vamd_ctx *ctx);
@@ -156,7 +167,8 @@ typedef struct vamd_batch_io {
   uint8_t  *packets;      /* out [nb][packet_stride] bytes; the packet is the first (bits+7)/8 of a row */
   int32_t  *packet_bits;  /* out [nb] oggpack_bits(); > 8*packet_stride: the row was too short, packet cut off */
   int64_t   packet_stride;/* row length in bytes, a multiple of 4 (vamd_packet_capacity() always suffices) */
-  uint8_t  *status;       /* out [nb][ch] 1 where the channel-block was outside the input domain (below), else 0 */
+  uint8_t  *status;       /* out [nb][ch] 0, or a set of VAMD_STATUS_* bits where the channel-block was outside the input
+                             domain (below) */
   /* blocks read in place (ABI 7).  With pcm_src non-NULL the batch is NOT a packed [nb][ch][n] array: block b, channel c
    * starts at pcm + pcm_src[b] + c * pcm_channel_stride (floats; both multiples of 4, pcm 16-byte aligned) -- e.g. a
    * vamd_stream_plan's src[W] over the stream buffers themselves, which spares vamd_gather_blocks and its copy of every
@@ -165,42 +177,60 @@ typedef struct vamd_batch_io {
   int64_t   pcm_channel_stride; /* in  floats between a block's channels (only with pcm_src) */
 } vamd_batch_io;
 /* vamd_batch_desc / vamd_batch_io / vamd_managed_io MUST be zero-initialised by the caller (memset, = {0}) before the
- * fields it uses are set: members are appended at the END between releases (`status` came in with ABI 6), and a member
- * the caller does not know about is then a null pointer, which every entry point reads as "not wanted".  A caller built
- * against another header than the library it loads finds out with vamd_abi_version() != VAMD_ABI_VERSION. */
-#define VAMD_ABI_VERSION 7
+ * fields it uses are set: members are appended at the END between releases (`status` came in with ABI 6, `pcm_src` with
+ * 7), and a member the caller does not set is then a null pointer, which every entry point reads as "not wanted".  A
+ * caller built against another header than the library it loads is refused by vamd_create() (VAMD_EVERSION) and can ask
+ * beforehand with vamd_abi_version() != VAMD_ABI_VERSION. */
+#define VAMD_ABI_VERSION 8
 int vamd_abi_version(void);
+/* The environment knobs in force for a context, as "NAME=value" words (read once, at vamd_create; vorbis_amd/csrc/vamd_knobs.h).  The
+ * operating knobs (VAMD_VERBOSE, VAMD_BATCH_LANES / _EAGER / _JOIN / _SPIN_BELOW) are always honoured; the test knobs --
+ * kernel choices turned the other way, widened margins, occupancy caps, injected failures -- only beside
+ * VAMD_TEST_KNOBS=1, so that an inherited environment cannot change what a drop-in library does. */
+const char *vamd_config_string(const vamd_ctx *ctx);
 
 /* ---- Input domain ---------------------------------------------------------------------------------
- * libvorbis does not validate PCM: whatever floats arrive go through mapping0_forward.  Inside the
- * domain below this library reproduces the reference bit for bit -- denormals, signed zeros and signals
- * hundreds of times over full scale included (tests/soak_lib.py kinds 8-11).  Outside it the reference's
- * own result is not defined by C: its residue search and noise normalisation square quantised values in
- * `int` (lib/res0.c:361-364, lib/psy.c:985: signed overflow from values of 16 384 / 46 341 up), its
- * float -> int conversions overflow further out, and a NaN sample reaches those conversions too.  There
- * is then nothing to be identical to, and the library REPORTS such input instead of inventing an answer:
+ * libvorbis does not validate PCM: whatever floats arrive go through mapping0_forward.  Inside the domain below this
+ * library reproduces the reference bit for bit -- denormals, signed zeros and signals thousands of times over full
+ * scale included (tests/soak_lib.py kinds 8-13).  Outside it the reference's own result is not defined by C, there is
+ * nothing to be identical to, and the library REPORTS such input instead of inventing an answer.  The domain has two
+ * edges, and they are the reference's own:
  *
- *   domain: every sample finite, and the block's spectral peak (the reference's logfft scale, 0 dB = a
- *           full-scale sine, lib/mapping0.c:255-343, taken before the 0 dB clamp of :345) at most +60 dB,
- *           i.e. a signal up to 1000 x full scale (vorbis_amd/csrc/vamd_params.h derives the margin).  One
- *           NaN or +-Inf anywhere in a block's windowed span puts the peak above +330 dB, so the test costs
- *           one compare per channel-block.  (A sample the window zeroes -- lib/window.c:2117-2118 -- never
- *           enters the arithmetic, in the reference or here.)
+ *   (1) finite arithmetic.  A NaN or +-Inf sample inside a block's windowed span (a sample the window zeroes --
+ *       lib/window.c:2117-2118 -- never enters the arithmetic, in the reference or here) reaches the reference's
+ *       float -> int conversions (lib/psy.c:958-962) and stays in its ampmax chain and detector history for the rest
+ *       of the stream.  Finite samples do the same only beyond ~3e16 x full scale, where the reference's own fp32
+ *       power spectrum overflows to Inf (lib/mapping0.c:323-343).  Test: the block's spectral peak on the reference's
+ *       logfft scale (0 dB = a full-scale sine, before the clamp of :345) above +330 dB -- any NaN / Inf puts it
+ *       there, todB() reads a float's bits -- one compare per channel-block.  VAMD_STATUS_NONFINITE.
+ *   (2) the reference's integers.  Its residue search sums up to eight squared differences in an `int`
+ *       (lib/res0.c:361-364), noise normalisation squares a quantised value in an `int` (lib/psy.c:985), and the
+ *       quantised values are float -> int conversions: all of it is defined by C exactly while every quantised value
+ *       of the block stays within a bound Q that depends only on the setup's codebooks -- 16 383 less the lattice reach
+ *       of a residue class's cascade; vorbis_amd/csrc/vamd_bind.h: derive_quant_limit() holds the proof, and
+ *       vamd_quant_limit() returns Q (~10 000 for the libvorbisenc setups: spectra ~ +80 dB over full scale, e.g.
+ *       un-normalised int16-scale floats are beyond it).  Test: every value the coupling stage writes is held against
+ *       Q (level FULL; the levels below it form no integers).  VAMD_STATUS_RANGE.  Below Q everything is exact --
+ *       the old "+60 dB" line of ABI 7 was a sufficient margin, not the edge; the edge is now the arithmetic's own.
  *
- *   - the host-pointer calls (vamd_analyze_block*, vamd_encode_block, vamd_envelope_search,
- *     vamd_batcher_encode_block) return VAMD_EDOMAIN for a block / detector call outside the domain (their
- *     argument errors stay VAMD_EINVAL); through the binding, vorbis_analysis() returns OV_EINVAL for that
- *     block and for every later block of the stream.  THIS IS A DELIBERATE DEVIATION FROM UPSTREAM, and it is
- *     sticky: libvorbis itself encodes such input (into whatever its overflowing integers yield on the build's
- *     target) and carries on; a stream that holds, say, un-normalised int16-scale floats (+90 dB) ends here
- *     with an error instead.  README.md and INTEGRATION.md say so up front;
- *   - the device-pointer calls are asynchronous: they fill `status` (when given) and count;
- *     vamd_input_status() synchronises the context's stream, returns VAMD_EDOMAIN if anything issued since the
- *     previous call was outside the domain (how many channel-blocks / detector steps: the two optional
- *     outputs) and resets the counts.  Outputs of such blocks are deterministic but unspecified; every
- *     other block of the batch is unaffected.
- *   (The detector's test catches non-finite samples only; a finite stream is cut into the reference's
- *   blocks whatever its level, and the blocks' own test applies.) */
+ *   - the host-pointer calls (vamd_analyze_block*, vamd_encode_block, vamd_batcher_encode_block) return
+ *     VAMD_ENONFINITE for (1), VAMD_EDOMAIN for (2) (their argument errors stay VAMD_EINVAL); *ampmax_out is
+ *     delivered either way (it comes out of the block's FFT).  vamd_envelope_search knows (1) only: a finite stream is
+ *     cut into the reference's blocks whatever its level.  Through the binding (integration/mapping0_vamd.c)
+ *     vorbis_analysis() returns OV_EINVAL for a block outside the domain.  For (2) that is THIS block only: the
+ *     ampmax chain is carried over it and every later block of the stream is again the reference's, bit for bit.  For
+ *     (1) it is this block and every later one -- the deviation from upstream that remains deliberate: libvorbis goes
+ *     on encoding with NaN in its state; this back-end ends the stream;
+ *   - the device-pointer calls are asynchronous: they fill `status` (when given) and count; vamd_input_status()
+ *     synchronises the context's stream, returns VAMD_ENONFINITE / VAMD_EDOMAIN if anything issued since the previous
+ *     call was outside the domain (how many channel-blocks of either kind / detector steps: the two optional outputs;
+ *     the fifteen candidate packets of a bitrate-managed block may count one channel-block up to fifteen times) and
+ *     resets the counts.  Outputs of such blocks are deterministic but unspecified; every other block of the batch is
+ *     unaffected. */
+#define VAMD_STATUS_RANGE     1 /* bits of status[] */
+#define VAMD_STATUS_NONFINITE 2
+/* the bound Q of (2) for size class W */
+int vamd_quant_limit(const vamd_ctx *ctx, int W);
 int vamd_input_status(vamd_ctx *ctx, long *bad_channel_blocks, long *bad_detector_steps);
 
 #define VAMD_RES_CLASS_STRIDE 512 /* ints per block and submap in res_class[] (>= classified partitions) */
@@ -392,10 +422,11 @@ int vamd_plan_fetch(vamd_ctx *ctx, const vamd_stream_plan *plan, int32_t *const 
  * libvorbis' unit of work is one block of one stream (mapping0_forward, reference lib/mapping0.c:233-687); a
  * batcher coalesces concurrent vamd_batcher_encode_block() calls -- same contract as vamd_encode_block() for a VBR
  * encoder, callable from any number of threads, one stream per thread as libvorbis itself requires -- into batched
- * launches.  It owns a few LANES (VAMD_BATCH_LANES in the environment, default 4): a context, a HIP stream, staging
- * arenas and one library thread each.  A caller queues its block and sleeps; a lane that is idle takes everything pending
+ * launches.  It owns a few LANES (VAMD_BATCH_LANES in the environment, default 8, at most 16): a context, a HIP stream, a
+ * pinned staging arena and one library thread each.  A caller queues its block and sleeps; a lane that is idle takes everything pending
  * of one size class (at most `max_batch` blocks) at once, runs it as a single vamd_analyze_batch() with packet output
- * and wakes exactly the owners of those blocks; blocks that arrive while every lane is busy gather for the next one.
+ * and wakes exactly the owners of those blocks; blocks that arrive while every lane is busy gather for the next one
+ * (a lane that finds both size classes waiting takes the one it did not take last time, so neither waits for ever).
  * There is no timer (`max_wait_us` is accepted and unused since round 4: waiting for stragglers cost more than it
  * gathered).  vamd_batcher_attach / _detach announce a stream (a vorbis_dsp_state); they are bookkeeping only.
  * Errors: OV_*-valued as everywhere; the text of the last one with vamd_batcher_last_error().  vamd_batcher_context()

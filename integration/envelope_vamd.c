@@ -15,7 +15,6 @@
  * tests/test_gpu_dropin.py checks that streams with transients (short blocks, transitions)
  * still encode to byte-identical packets.
  */
-#include <stdio.h>
 #define _ve_envelope_search _ve_envelope_search_cpu
 #define _ve_envelope_clear _ve_envelope_clear_cpu
 #include "envelope.c" /* the reference's lib/envelope.c, found through -I$(REF)/lib */
@@ -29,7 +28,7 @@ extern vamd_ctx *vamd_ctx_for(vorbis_dsp_state *vd);
 extern vamd_envelope_state *vamd_envelope_state_for(vorbis_dsp_state *vd);
 extern void vamd_release_key(const void *key);
 extern int vamd_batching(void);
-extern void vamd_poison(vorbis_dsp_state *vd);
+extern void vamd_poison(vorbis_dsp_state *vd, int kind); /* mapping0_vamd.c: 1 = non-finite input, 2 = GPU failure */
 
 /* vorbis_dsp_clear() tears the detector down here (lib/block.c:325-328): the GPU context that
  * was created for this analysis state goes with it */
@@ -66,19 +65,16 @@ long _ve_envelope_search(vorbis_dsp_state *v) {
     int i, err = -1;
     for (i = 0; i < ve->ch; i++) chan[i] = v->pcm[i] + step * first;
     if (ctx && st) err = vamd_envelope_search(ctx, chan, nsteps, st, flags);
-    if (err == VAMD_EDOMAIN) {
-      /* a sample outside the input domain (NaN / Inf; vorbis_amd.h): no marks from these steps, and the stream is
-         flagged so that the next vorbis_analysis() returns OV_EINVAL (mapping0_vamd.c: vamd_poison).  An argument
-         error (VAMD_EINVAL) is NOT this case: it falls through to the hard stop below, as before */
-      memset(flags, 0, nsteps);
-      vamd_poison(v);
-      err = 0;
-    }
     if (err) {
-      /* this entry point has no error return (1 / 0 / -1 all mean something); like the
-         reference's own exit(1) sites, refuse to continue rather than silently diverge */
-      fprintf(stderr, "vorbis_amd: envelope search failed (%d): %s\n", err, ctx ? vamd_last_error(ctx) : "no GPU context");
-      abort();
+      /* This entry point has no error return (1 / 0 / -1 all mean something), and a shared library does not end its
+         host process.  The stream is flagged instead (mapping0_vamd.c: vamd_poison) and the NEXT vorbis_analysis()
+         reports it: OV_EINVAL for a sample outside the input domain (NaN / Inf, VAMD_ENONFINITE; vorbis_amd.h),
+         OV_EFAULT for anything else -- no context, device lost, out of memory, a HIP fault; the text stays with
+         vamd_last_error().  No marks come from these steps and the bookkeeping below carries on, so that the blocks
+         keep flowing and the caller meets the error at once, not at end of stream (returning -1, "need more data",
+         from here on would stall vorbis_analysis_blockout() until the input ends: lib/block.c:558-563). */
+      memset(flags, 0, nsteps);
+      vamd_poison(v, err == VAMD_ENONFINITE ? 1 : 2);
     }
     for (j = first; j < last; j++) { /* :241-258 */
       const int ret = flags[j - first];
@@ -92,7 +88,7 @@ long _ve_envelope_search(vorbis_dsp_state *v) {
         if (j > 0) ve->mark[j - 1] = 1;
       }
     }
-    ve->stretch = st->stretch;
+    if (!err && st) ve->stretch = st->stretch;
     _ogg_free(flags);
   }
   ve->current = last * step;

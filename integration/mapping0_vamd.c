@@ -25,8 +25,9 @@
  * the bitrate manager that picks one is untouched host code.
  * With VAMD_BATCH=<n> in the environment the VBR blocks of ALL encoder states that share a setup go through one
  * vamd_batcher (include/vorbis_amd.h): many application threads, each driving its own vorbis_dsp_state as libvorbis
- * allows, get their blocks analysed in shared GPU batches of up to n (VAMD_BATCH_WAIT_US, default 200, bounds how
- * long a batch waits for stragglers).  The block-switching detector then stays on the host (envelope_vamd.c).
+ * allows, get their blocks analysed in shared GPU batches of up to n.  (There is no gathering timer any more: blocks
+ * gather while the batcher's lanes are busy and leave at once when one is idle; VAMD_BATCH_WAIT_US is still read and
+ * handed on, and ignored by the batcher.)  The block-switching detector then stays on the host (envelope_vamd.c).
  * Channel counts above VAMD_MAX_CH are refused with OV_EIMPL (see mapping0_forward_vamd); errors
  * travel as OV_* return codes like everywhere else in libvorbis -- nothing is printed.
  */
@@ -63,7 +64,8 @@ typedef struct vamd_entry {
   vamd_ctx *ctx;   /* this state's own context (always in per-state mode; in batch mode only for what is not batched) */
   vamd_shared *shared; /* batch mode: the batcher this state submits to */
   vamd_envelope_state env; /* the block-switching detector's running state (envelope_vamd.c) */
-  int poisoned;            /* the stream held a sample outside the input domain (vorbis_amd.h): every later block is OV_EINVAL */
+  int poisoned;            /* the stream is over (vamd_poison): VAMD_POISON_NONFINITE -> every later block is OV_EINVAL,
+                              VAMD_POISON_FAULT -> OV_EFAULT */
 } vamd_entry;
 static pthread_mutex_t vamd_lock = PTHREAD_MUTEX_INITIALIZER;
 static vamd_entry **vamd_table = NULL;
@@ -175,17 +177,38 @@ vamd_envelope_state *vamd_envelope_state_for(vorbis_dsp_state *state) {
   return e ? &e->env : NULL;
 }
 
-/* Input outside the domain (a NaN / Inf sample, include/vorbis_amd.h "Input domain"): the reference's own output for
- * such a stream is not defined by C, so the encode ends here -- vorbis_analysis() returns OV_EINVAL for the block that
- * held the sample and for every block after it.  The detector has no error return (envelope_vamd.c), so it records
- * the fact here and lets the next vorbis_analysis() report it. */
-void vamd_poison(vorbis_dsp_state *state) {
+/* A stream that cannot go on.  Two ways in (include/vorbis_amd.h, "Input domain"):
+ *   VAMD_POISON_NONFINITE  a NaN / Inf sample: the reference's own ampmax chain and detector history are not numbers
+ *                          from here on, so the encode ends -- vorbis_analysis() returns OV_EINVAL for the block that
+ *                          held the sample and for every block after it;
+ *   VAMD_POISON_FAULT      the GPU side failed under the block-switching detector (device lost, out of memory, a HIP
+ *                          fault): OV_EFAULT from the next vorbis_analysis() on.
+ * The detector has no error return (envelope_vamd.c), so it records the fact here and lets the next vorbis_analysis()
+ * report it.  (A FINITE block beyond the integer bound is neither: OV_EINVAL for that block alone, below.) */
+#define VAMD_POISON_NONFINITE 1
+#define VAMD_POISON_FAULT 2
+void vamd_poison(vorbis_dsp_state *state, int kind) {
   vamd_entry *e = vamd_entry_for(state);
-  if (e) e->poisoned = 1;
+  if (e && !e->poisoned) e->poisoned = kind;
 }
 static int vamd_poisoned(vorbis_dsp_state *state) {
   vamd_entry *e = vamd_entry_for(state);
   return e ? e->poisoned : 0;
+}
+
+/* what vorbis_analysis() returns for a block the library found outside the input domain.  A non-finite sample ends
+ * the stream; a finite block beyond the integer bound has no defined result, but the stream's state does: the ampmax
+ * chain is carried over it (vamd_* deliver ampmax_out with the error) and the next block is the reference's again. */
+static int vamd_domain_verdict(vorbis_block *vb, int ret, float ampmax_out) {
+  if (ret == VAMD_ENONFINITE) {
+    vamd_poison(vb->vd, VAMD_POISON_NONFINITE);
+    return OV_EINVAL;
+  }
+  if (ret == VAMD_EDOMAIN) {
+    ((vorbis_block_internal *)vb->internal)->ampmax = ampmax_out; /* lib/mapping0.c:576 */
+    return OV_EINVAL;
+  }
+  return ret;
 }
 
 /* called by _ve_envelope_clear() (envelope_vamd.c) with the envelope_lookup being torn down */
@@ -311,7 +334,7 @@ static int mapping0_forward_vamd(vorbis_block *vb) {
   vamd_ctx *ctx;
   float *mdct;
   int *iwork, *posts, *post_valid, *nonzero, *scratch;
-  float ampmax_out;
+  float ampmax_out = 0.f;
   int k, ret, pkcap;
 
   /* more than VAMD_MAX_CH (8) channels -- no layout Vorbis I assigns a channel order to -- is outside the GPU
@@ -325,7 +348,7 @@ static int mapping0_forward_vamd(vorbis_block *vb) {
 #endif
   }
   vb->mode = vb->W;
-  if (vamd_poisoned(vd)) return OV_EINVAL;
+  if ((k = vamd_poisoned(vd))) return k == VAMD_POISON_FAULT ? OV_EFAULT : OV_EINVAL;
 
   /* ---- batch mode (VAMD_BATCH): the block joins whatever the other encoder threads have pending and comes back
      as its packet, exactly as from vamd_encode_block below */
@@ -338,11 +361,7 @@ static int mapping0_forward_vamd(vorbis_block *vb) {
       int32_t bits = 0;
       ret = vamd_batcher_encode_block(e->shared->batcher, (const float *const *)vb->pcm, vb->lW, vb->W, vb->nW,
                                       vbi->blocktype, vbi->ampmax, &ampmax_out, packet, pkcap, &bits);
-      if (ret == VAMD_EDOMAIN) {
-        vamd_poison(vd);
-        ret = OV_EINVAL; /* what vorbis_analysis() reports for it */
-      }
-      if (ret) return ret;
+      if (ret) return vamd_domain_verdict(vb, ret, ampmax_out);
       vbi->ampmax = ampmax_out; /* lib/mapping0.c:576 */
       oggpack_writecopy(vbi->packetblob[PACKETBLOBS / 2], packet, bits);
       return 0;
@@ -361,11 +380,7 @@ static int mapping0_forward_vamd(vorbis_block *vb) {
     int32_t *bits = _vorbis_block_alloc(vb, nk * sizeof(*bits));
     ret = vamd_encode_block(ctx, (const float *const *)vb->pcm, vb->lW, vb->W, vb->nW, vbi->blocktype, vbi->ampmax,
                             managed, &ampmax_out, packets, pkcap, bits);
-    if (ret == VAMD_EDOMAIN) {
-      vamd_poison(vd);
-      ret = OV_EINVAL; /* what vorbis_analysis() reports for it */
-    }
-    if (ret) return ret; /* an OV_* code, out through vorbis_analysis(); the text stays with vamd_last_error(ctx) */
+    if (ret) return vamd_domain_verdict(vb, ret, ampmax_out); /* an OV_* code, out through vorbis_analysis(); the text stays with vamd_last_error(ctx) */
     vbi->ampmax = ampmax_out; /* lib/mapping0.c:576 */
     for (k = 0; k < nk; k++) {
       if (bits[k] > 8 * pkcap) return OV_EFAULT; /* cannot happen: pkcap is the worst case */
@@ -390,11 +405,7 @@ static int mapping0_forward_vamd(vorbis_block *vb) {
   else
     ret = vamd_analyze_block(ctx, (const float *const *)vb->pcm, vb->lW, vb->W, vb->nW, vbi->blocktype, vbi->ampmax,
                              mdct, NULL, posts, post_valid, iwork, nonzero, &ampmax_out);
-  if (ret == VAMD_EDOMAIN) {
-    vamd_poison(vd);
-    ret = OV_EINVAL; /* what vorbis_analysis() reports for it */
-  }
-  if (ret) return ret;
+  if (ret) return vamd_domain_verdict(vb, ret, ampmax_out);
   vbi->ampmax = ampmax_out; /* lib/mapping0.c:576 */
   for (k = 0; k < nk; k++) {
     ret = vamd_write_packet(vb, managed ? k : PACKETBLOBS / 2, posts + k * ch * VAMD_POSTS_STRIDE, post_valid + k * ch,

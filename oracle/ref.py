@@ -102,6 +102,9 @@ def lib(hybrid=False):
         L.ref_tap_block.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                     C.POINTER(_Taps)]
         L.ref_encode_stream.restype = C.c_long
+        L.ref_encode_stream_ex.restype = C.c_long
+        L.ref_encode_stream_ex.argtypes = [C.c_void_p, _f32p, C.c_long, C.c_long, C.c_int, C.POINTER(_BlockRec), C.c_long,
+                                           _f32p, C.c_long, _u8p, C.c_long]
         L.ref_encode_stream.argtypes = [C.c_void_p, _f32p, C.c_long, C.POINTER(_BlockRec), C.c_long,
                                         _f32p, C.c_long, _u8p, C.c_long]
         L.ref_time_analysis.restype = C.c_double
@@ -298,9 +301,11 @@ class RefEncoder:
         o["packets_match_real"] = bool(m.packets_match_real)
         return o
 
-    def encode_stream(self, pcm, max_blocks=1 << 16):
+    def encode_stream(self, pcm, max_blocks=1 << 16, write_frames=1024, tolerate=False):
         """Run the whole application loop over planar pcm[ch][frames].  Consumes this
-        encoder state.  Returns a list of dicts (lW,W,nW,blocktype,ampmax_in,ampmax_out,pcm,packet)."""
+        encoder state.  Returns a list of dicts (lW,W,nW,blocktype,ampmax_in,ampmax_out,pcm,packet).
+        write_frames: samples per vorbis_analysis_wrote() call (the example's 1024; the API takes any amount).
+        tolerate: a failing vorbis_analysis() is recorded (`error` = its code, no packet) and the loop goes on."""
         pcm = np.ascontiguousarray(pcm, dtype=np.float32)
         ch, frames = pcm.shape
         assert ch == self.channels
@@ -309,8 +314,8 @@ class RefEncoder:
         pcm_out = np.zeros(pcm_cap, np.float32)
         pk_cap = max(1 << 20, frames * ch)
         pk_out = np.zeros(pk_cap, np.uint8)
-        nb = self.L.ref_encode_stream(self.h, _fp(pcm), frames, recs, max_blocks, _fp(pcm_out), pcm_cap,
-                                      pk_out.ctypes.data_as(_u8p), pk_cap)
+        nb = self.L.ref_encode_stream_ex(self.h, _fp(pcm), frames, int(write_frames), 1 if tolerate else 0, recs, max_blocks,
+                                         _fp(pcm_out), pcm_cap, pk_out.ctypes.data_as(_u8p), pk_cap)
         if nb < 0:
             raise RuntimeError("ref_encode_stream failed: %d" % nb)
         out = []
@@ -321,6 +326,7 @@ class RefEncoder:
                      ampmax_out=r.ampmax_out)
             d["pcm"] = pcm_out[r.pcm_offset:r.pcm_offset + ch * n].reshape(ch, n).copy() if r.pcm_offset >= 0 else None
             d["packet"] = bytes(pk_out[r.packet_offset:r.packet_offset + r.packet_bytes]) if r.packet_offset >= 0 else None
+            d["error"] = int(r.packet_bytes) if r.packet_bytes < 0 else 0
             out.append(d)
         return out
 

@@ -588,17 +588,22 @@ int ref_tap_block_managed(ref_enc *e, const float *pcm, int lW, int W, int nW, i
  * number of blocks (may exceed max_blocks: then only the first max_blocks are
  * recorded), or <0 on error.  The encoder state is consumed: open a fresh
  * ref_enc per stream. */
-long ref_encode_stream(ref_enc *e, const float *pcm, long frames, ref_block_rec *recs, long max_blocks,
-                       float *pcm_out, long pcm_cap, unsigned char *packets_out, long packets_cap) {
+/* `write_frames`: samples handed over per vorbis_analysis_wrote() call -- the example's READ is 1024
+ * (examples/encoder_example.c:38), but the API takes any amount (lib/block.c:390,470).  `tolerate`: a
+ * vorbis_analysis() that fails does not end the run; the block is recorded with packet_bytes = the error code
+ * (negative) and no packet, and the loop goes on as an application that ignores return codes would. */
+long ref_encode_stream_ex(ref_enc *e, const float *pcm, long frames, long write_frames, int tolerate, ref_block_rec *recs,
+                          long max_blocks, float *pcm_out, long pcm_cap, unsigned char *packets_out, long packets_cap) {
   vorbis_block vb;
   long fed = 0, nblocks = 0, pcm_used = 0, pkt_used = 0;
   int ch = e->channels, eos = 0, i;
+  if (write_frames < 1) write_frames = 1024;
   vorbis_block_init(&e->vd, &vb);
   while (!eos) {
     long chunk = frames - fed;
-    if (chunk > 1024) chunk = 1024;
+    if (chunk > write_frames) chunk = write_frames;
     if (chunk > 0) {
-      float **buf = vorbis_analysis_buffer(&e->vd, 1024);
+      float **buf = vorbis_analysis_buffer(&e->vd, (int)write_frames);
       for (i = 0; i < ch; i++) memcpy(buf[i], pcm + (size_t)i * frames + fed, chunk * sizeof(float));
       vorbis_analysis_wrote(&e->vd, (int)chunk);
       fed += chunk;
@@ -631,13 +636,13 @@ long ref_encode_stream(ref_enc *e, const float *pcm, long frames, ref_block_rec 
       } else {
         ret = vorbis_analysis(&vb, &op);
       }
-      if (ret) { vorbis_block_clear(&vb); return ret; }
+      if (ret && !tolerate) { vorbis_block_clear(&vb); return ret; }
       if (nblocks < max_blocks && recs) {
         ref_block_rec *r = recs + nblocks;
         r->ampmax_out = vbi->ampmax;
-        r->packet_bytes = op.bytes;
+        r->packet_bytes = ret ? ret : op.bytes;
         r->packet_offset = -1;
-        if (packets_out && pkt_used + op.bytes <= packets_cap) {
+        if (!ret && packets_out && pkt_used + op.bytes <= packets_cap) {
           r->packet_offset = pkt_used;
           memcpy(packets_out + pkt_used, op.packet, op.bytes);
           pkt_used += op.bytes;
@@ -651,6 +656,10 @@ long ref_encode_stream(ref_enc *e, const float *pcm, long frames, ref_block_rec 
   }
   vorbis_block_clear(&vb);
   return nblocks;
+}
+long ref_encode_stream(ref_enc *e, const float *pcm, long frames, ref_block_rec *recs, long max_blocks,
+                       float *pcm_out, long pcm_cap, unsigned char *packets_out, long packets_cap) {
+  return ref_encode_stream_ex(e, pcm, frames, 1024, 0, recs, max_blocks, pcm_out, pcm_cap, packets_out, packets_cap);
 }
 
 /* ---- many encoder threads, timed in C (profiles/rNN_batcher.txt) -----------------------

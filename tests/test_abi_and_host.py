@@ -15,6 +15,8 @@ from tests import checker
 
 ROOT = checker.ROOT
 LIB = os.path.join(ROOT, "vorbis_amd", "libvorbis_amd.so")
+# VAMD_ABI_VERSION of the header: what a caller compiled against it hands vamd_create() (the macro does it for C callers)
+ABI = int(re.search(r"#define VAMD_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "vorbis_amd.h")).read()).group(1))
 
 
 def declared_symbols():
@@ -36,18 +38,22 @@ def test_header_symbols_are_exported():
 def test_create_rejects_bad_blobs_without_touching_the_gpu():
     """Blob validation happens before any HIP call, so the error paths are testable here."""
     L = C.CDLL(LIB)
-    L.vamd_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_size_t, C.c_int]
+    L.vamd_create_abi.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_size_t, C.c_int, C.c_int]
     h = C.c_void_p()
     good = np.fromfile(os.path.join(ROOT, "vorbis_amd", "data", "setup_44k_stereo_q4.bin"), dtype=np.uint8)
-    assert L.vamd_create(C.byref(h), None, 0, -1) == -131                       # OV_EINVAL
+    assert L.vamd_create_abi(C.byref(h), None, 0, -1, ABI) == -131                       # OV_EINVAL
     bad = good.copy(); bad[0] ^= 0xff
-    assert L.vamd_create(C.byref(h), bad.ctypes.data_as(C.c_void_p), bad.size, -1) == -131
+    assert L.vamd_create_abi(C.byref(h), bad.ctypes.data_as(C.c_void_p), bad.size, -1, ABI) == -131
     ver = good.copy(); ver[8] = 99
-    assert L.vamd_create(C.byref(h), ver.ctypes.data_as(C.c_void_p), ver.size, -1) == -134  # OV_EVERSION
+    assert L.vamd_create_abi(C.byref(h), ver.ctypes.data_as(C.c_void_p), ver.size, -1, ABI) == -134  # OV_EVERSION
     trunc = good[:1000].copy()
-    assert L.vamd_create(C.byref(h), trunc.ctypes.data_as(C.c_void_p), trunc.size, -1) == -131
+    assert L.vamd_create_abi(C.byref(h), trunc.ctypes.data_as(C.c_void_p), trunc.size, -1, ABI) == -131
     chs = good.copy(); chs[16:20] = np.frombuffer(np.int32(9).tobytes(), np.uint8)   # beyond VAMD_MAX_CH
-    assert L.vamd_create(C.byref(h), chs.ctypes.data_as(C.c_void_p), chs.size, -1) == -130   # OV_EIMPL
+    assert L.vamd_create_abi(C.byref(h), chs.ctypes.data_as(C.c_void_p), chs.size, -1, ABI) == -130   # OV_EIMPL
+    # a caller built against another release of the header (its structs may be shorter than what the library reads) is
+    # refused before anything else is looked at -- and there is no un-versioned vamd_create symbol to slip through
+    assert L.vamd_create_abi(C.byref(h), good.ctypes.data_as(C.c_void_p), good.size, -1, ABI - 1) == -134  # OV_EVERSION
+    assert not hasattr(L, "vamd_create")
     assert not h.value
 
 
@@ -79,13 +85,13 @@ def test_create_rejects_truncated_stale_and_corrupt_tables():
     """Every table a kernel walks or indexes through is bounds- and range-checked at vamd_create(): a truncated,
     stale or bit-flipped blob comes back as OV_EINVAL instead of reading out of bounds on the device."""
     L = C.CDLL(LIB)
-    L.vamd_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_size_t, C.c_int]
+    L.vamd_create_abi.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_size_t, C.c_int, C.c_int]
     h = C.c_void_p()
     good = np.fromfile(os.path.join(ROOT, "vorbis_amd", "data", "setup_44k_stereo_q4.bin"), dtype=np.uint8)
     off = _header_layout()
 
     def create(b):
-        return L.vamd_create(C.byref(h), b.ctypes.data_as(C.c_void_p), b.size, -1)
+        return L.vamd_create_abi(C.byref(h), b.ctypes.data_as(C.c_void_p), b.size, -1, ABI)
 
     def put32(b, at, v):
         b[at:at + 4] = np.frombuffer(np.int32(v).tobytes(), np.uint8)
@@ -269,6 +275,11 @@ def test_abi_version_matches_the_header():
     L.vamd_abi_version.restype = C.c_int
     assert L.vamd_abi_version() == want
     assert "VAMD_EDOMAIN" in hdr and vorbis_amd.VAMD_EDOMAIN == int(re.search(r"#define VAMD_EDOMAIN\s+\((-\d+)\)", hdr).group(1))
+    assert vorbis_amd.VAMD_ENONFINITE == int(re.search(r"#define VAMD_ENONFINITE\s+\((-\d+)\)", hdr).group(1))
+    from vorbis_amd import api
+    assert api.ABI_VERSION == want      # the ctypes mirror was written against this header
+    assert api.STATUS_RANGE == int(re.search(r"#define VAMD_STATUS_RANGE\s+(\d+)", hdr).group(1))
+    assert api.STATUS_NONFINITE == int(re.search(r"#define VAMD_STATUS_NONFINITE\s+(\d+)", hdr).group(1))
 
 
 def test_bench_rooflines_read_the_committed_profiles():

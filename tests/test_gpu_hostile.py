@@ -1,15 +1,21 @@
 """GPU suite: the input domain (include/vorbis_amd.h, "Input domain").
 
-Inside the domain -- finite samples, spectral peak up to +60 dB over full scale, denormals and signed zeros included -- results are
-the reference's bit for bit: those signal kinds are part of every soak run (tests/soak_lib.py kinds 8-11,
-tests/test_gpu_soak.py).  Outside it (NaN, +-Inf, 1e30 ...) the reference's own result is not defined by C; this
-suite checks that the library REPORTS such blocks through every door -- the per-block status tensor, the context's
-counter, VAMD_EDOMAIN from the host-pointer calls, OV_EINVAL out of vorbis_analysis() in the drop-in -- that it neither
-crashes nor hangs, and that every other block of the same batch / the next stream is untouched."""
+Inside the domain -- finite samples, quantised values up to the setup's proven integer bound (vamd_quant_limit, spectra
+~ +85 dB over full scale), denormals and signed zeros included -- results are the reference's bit for bit: those signal
+kinds are part of every soak run (tests/soak_lib.py kinds 8-13, tests/test_gpu_soak.py).  Outside it (NaN, +-Inf, 1e30,
+a sine 94 dB over full scale ...) the reference's own result is not defined by C; this suite checks that the library
+REPORTS such blocks through every door -- the per-block status bits, the context's counter, VAMD_ENONFINITE /
+VAMD_EDOMAIN from the host-pointer calls, OV_EINVAL out of vorbis_analysis() in the drop-in (for the rest of the stream
+after a NaN, for the block alone when it is finite) -- that it neither crashes nor hangs, that a GPU failure is an
+error code and not an abort(), and that every other block of the same batch / the next stream is untouched."""
+import os
+
 import numpy as np
 import pytest
 
 from oracle import ref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = [pytest.mark.gpu,
               pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built (needs /root/reference at build time)")]
@@ -67,6 +73,57 @@ def test_dropin_returns_ov_einval_and_the_next_stream_is_clean():
     assert all(a["packet"] == b["packet"] for a, b in zip(want, got))
 
 
+@pytest.mark.skipif(not ref.hybrid_available(), reason="oracle/_ref/libvorbis_hybrid.so not built")
+def test_dropin_finite_block_beyond_the_bound_is_that_blocks_error_only():
+    """Through the hybrid libvorbis: a FINITE burst ~94 dB over full scale (quantised values past the setup's integer bound,
+    where lib/res0.c:361-364 leaves what C defines) makes vorbis_analysis() return OV_EINVAL for the blocks that hold it --
+    and only for them.  The stream is not ended: the ampmax chain is carried over those blocks, and every block before and
+    after them is the reference's, packet for packet (the +60 dB line used to end the stream)."""
+    rng = np.random.default_rng(10)
+    pcm = ((rng.random((2, 3 * 44100), dtype=np.float32) - 0.5) * 0.5).astype(np.float32)
+    t = np.arange(1500)
+    pcm[0, 60000:61500] += (5e4 * np.sin(0.3 * t)).astype(np.float32)
+    want = ref.RefEncoder(2, 44100, 0.4).encode_stream(pcm, tolerate=True)
+    got = ref.RefEncoder(2, 44100, 0.4, hybrid=True).encode_stream(pcm, tolerate=True)
+    assert len(want) == len(got) > 60 and not any(b["error"] for b in want)
+    refused = [k for k, b in enumerate(got) if b["error"]]
+    assert refused and all(got[k]["error"] == -131 for k in refused)                  # OV_EINVAL
+    assert refused[-1] - refused[0] < 12 and refused[-1] < len(got) - 20                # the burst's blocks, not the stream
+    for k, (a, b) in enumerate(zip(want, got)):
+        assert (a["lW"], a["W"], a["nW"], a["blocktype"]) == (b["lW"], b["W"], b["nW"], b["blocktype"]), k
+        assert np.float32(a["ampmax_in"]) == np.float32(b["ampmax_in"]), k             # the chain runs through the refused blocks
+        if k not in refused:
+            assert a["packet"] == b["packet"], k
+
+
+@pytest.mark.skipif(not ref.hybrid_available(), reason="oracle/_ref/libvorbis_hybrid.so not built")
+def test_dropin_gpu_failure_under_the_detector_is_an_error_code_not_an_abort():
+    """A GPU failure inside _ve_envelope_search (injected: VAMD_FAIL_ENVELOPE_AFTER, a test knob) used to abort() the host
+    process from inside the shared library.  Now the stream is flagged and the next vorbis_analysis()
+    returns OV_EFAULT (-129); the process lives, and an encoder opened afterwards works.  Run in a child process: the
+    knob is read per context, but the point of the test is that the process survives."""
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np\n"
+        "from oracle import ref\n"
+        "rng = np.random.default_rng(3)\n"
+        "pcm = (rng.random((2, 44100), dtype=np.float32) - 0.5)\n"
+        "try:\n"
+        "    ref.RefEncoder(2, 44100, 0.4, hybrid=True).encode_stream(pcm)\n"
+        "    print('NO ERROR')\n"
+        "except RuntimeError as e:\n"
+        "    print('ERROR', e)\n"
+        "got = ref.RefEncoder(2, 44100, 0.4, hybrid=True).encode_stream(pcm, tolerate=True)\n"
+        "print('LATER', len(got), sum(1 for b in got if b['error'] == -129))\n")
+    env = dict(os.environ, VAMD_TEST_KNOBS="1", VAMD_FAIL_ENVELOPE_AFTER="5", PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr                     # not killed by abort()
+    assert "ERROR" in r.stdout and "-129" in r.stdout.split("LATER")[0], r.stdout + r.stderr   # OV_EFAULT out of vorbis_analysis()
+    later = r.stdout.split("LATER")[1].split()
+    assert int(later[0]) > 20 and int(later[1]) >= int(later[0]) - 8, r.stdout  # (the knob keeps failing: every later stream reports it too)
+
+
 def test_stream_plan_path_reports_too():
     """The device-resident stream path (vamd_plan_streams -> gather -> vamd_analyze_streams_mixed, BASELINE config 5):
     a NaN in one of four streams is counted by the detector and by the blocks that hold it, per-block `status` names
@@ -97,8 +154,8 @@ def test_stream_plan_path_reports_too():
     assert st0 == (0, 0)
     L1, o1, st1 = run(poisoned)
     assert st1[0] >= 1 and st1[1] >= 1, st1            # blocks and detector steps outside the domain
-    flagged = sum(int(o1[W]["status"].sum()) for W in (0, 1))
-    assert flagged == st1[0]
+    flagged = sum(int((o1[W]["status"] != 0).sum()) for W in (0, 1))
+    assert flagged == st1[0] and an.last_input_code == vorbis_amd.VAMD_ENONFINITE
     # the flagged blocks all belong to stream 2, channel 1, and hold sample 30000
     n_per = 2 * ln
     for W in (0, 1):

@@ -50,7 +50,7 @@ def test_library_is_the_hip_build(torch_mod):
     import vorbis_amd
     L = vorbis_amd.load_library()
     assert os.path.samefile(vorbis_amd.library_path(), os.path.join(ROOT, "vorbis_amd", "libvorbis_amd.so"))
-    assert L.vamd_create and L.vamd_analyze_batch
+    assert L.vamd_create_abi and L.vamd_analyze_batch
 
 
 @pytest.mark.parametrize("name", list(checker.SETUPS))
@@ -140,12 +140,14 @@ def test_couple_estimate_band_does_not_show(torch_mod, name, monkeypatch):
         pcm[k] += (0.4 * np.sin(t * (0.02 + 0.003 * k)) + 0.2 * np.sin(t * (0.31 + 0.001 * k))).astype(np.float32)[None, :]
     P = torch.from_numpy(pcm).cuda()
     res = []
+    monkeypatch.setenv("VAMD_TEST_KNOBS", "1")   # (the margin is a test knob: ignored without this, vamd_knobs.h)
     for log2 in (None, "1", "-6"):
         if log2 is None:
             monkeypatch.delenv("VAMD_COUPLE_BAND_LOG2", raising=False)
         else:
             monkeypatch.setenv("VAMD_COUPLE_BAND_LOG2", log2)
         an = analyzer(name)
+        assert ("VAMD_COUPLE_BAND_LOG2=%s" % (log2 or "unset:0")) in an.config_string()   # the knob really is in force
         outs = an.analyze(P, W=1, want=("iwork", "nonzero"))
         torch.cuda.synchronize()
         res.append({k: v.cpu().numpy() for k, v in outs.items()})

@@ -1,4 +1,5 @@
 #!/bin/bash
+export VAMD_TEST_KNOBS=1  # the knobs below are test knobs: ignored without this (vorbis_amd/csrc/vamd_knobs.h)
 # Run on the GPU box: the GPU suite once more with every batch-size-dependent choice of kernel turned the other way (the
 # environment of INTEGRATION.md's last section), so that the kernels a default run of the suite reaches only at sizes it
 # does not use are held to the same oracle.

@@ -1,4 +1,5 @@
 #!/bin/bash
+export VAMD_TEST_KNOBS=1  # the knobs below are test knobs: ignored without this (vorbis_amd/csrc/vamd_knobs.h)
 # Run on the GPU box: k_floor's time against blocks in flight per CU (LDS padding limits residency).
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R

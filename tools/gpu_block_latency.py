@@ -1,5 +1,6 @@
 """Scratch: latency of the per-block host entry points (the compatibility path behind vorbis_analysis())."""
 import os, sys, time
+os.environ["VAMD_TEST_KNOBS"] = "1"  # (VAMD_NO_OVERLAP is a test knob: vorbis_amd/csrc/vamd_knobs.h)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import vorbis_amd

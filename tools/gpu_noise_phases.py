@@ -1,5 +1,6 @@
 """Scratch: k_noise's phase stopwatch (kcycles per wave and phase) and the stage times, for the environment as set."""
 import os, sys, time
+os.environ["VAMD_TEST_KNOBS"] = "1"  # (VAMD_NO_OVERLAP is a test knob: vorbis_amd/csrc/vamd_knobs.h)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import vorbis_amd

@@ -1,5 +1,6 @@
 """Scratch: the in-kernel phase stopwatch of every stage (shares of each kernel's ticks), serial mode."""
 import os, sys
+os.environ["VAMD_TEST_KNOBS"] = "1"  # (VAMD_NO_OVERLAP is a test knob: vorbis_amd/csrc/vamd_knobs.h)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["VAMD_NO_OVERLAP"] = "1"
 import torch

@@ -1,4 +1,5 @@
 #!/bin/bash
+export VAMD_TEST_KNOBS=1  # the knobs below are test knobs: ignored without this (vorbis_amd/csrc/vamd_knobs.h)
 # Run on the GPU box: per-kernel durations with the tone chain serialised behind k_noise (no co-residency),
 # which is what each kernel costs on its own.
 R=${GRAFT_REPO_ROOT:-/root/repo}

@@ -1,4 +1,5 @@
 #!/bin/bash
+export VAMD_TEST_KNOBS=1  # the knobs below are test knobs: ignored without this (vorbis_amd/csrc/vamd_knobs.h)
 # Run on the GPU box: bytes k_tone_chase fetches per stereo block, with the tone chain beside k_noise and after it
 # (FETCH_SIZE in the profile's units: x2 x 32 B per count on gfx950, tools/make_profiles.py)
 R=${GRAFT_REPO_ROOT:-/root/repo}

@@ -1,4 +1,5 @@
 #!/bin/bash
+export VAMD_TEST_KNOBS=1  # the knobs below are test knobs: ignored without this (vorbis_amd/csrc/vamd_knobs.h)
 # Run on the GPU box: one set of SQ counters per wave for the kernels matching a pattern.
 #   tools/pmc_set.sh "<kernel grep pattern>" COUNTER [COUNTER ...]
 R=${GRAFT_REPO_ROOT:-/root/repo}

@@ -9,9 +9,9 @@ without a GPU, every compute call raises.
 from .api import (Analyzer, VamdError, load_library, library_path, default_setup_blob, LEVEL_TRANSFORM,
                   LEVEL_PSY, LEVEL_FULL, POSTS_STRIDE, BLOCKTYPE_IMPULSE, BLOCKTYPE_PADDING,
                   BLOCKTYPE_TRANSITION, BLOCKTYPE_LONG, EXPORTED_SYMBOLS, EnvelopeState, envelope_marks, packet_bytes,
-                  VAMD_OK, VAMD_EFAULT, VAMD_EIMPL, VAMD_EINVAL, VAMD_EVERSION, VAMD_EDOMAIN)
+                  VAMD_OK, VAMD_EFAULT, VAMD_EIMPL, VAMD_EINVAL, VAMD_EVERSION, VAMD_EDOMAIN, VAMD_ENONFINITE)
 
 __all__ = ["Analyzer", "VamdError", "load_library", "library_path", "default_setup_blob", "LEVEL_TRANSFORM",
            "LEVEL_PSY", "LEVEL_FULL", "POSTS_STRIDE", "BLOCKTYPE_IMPULSE", "BLOCKTYPE_PADDING",
            "BLOCKTYPE_TRANSITION", "BLOCKTYPE_LONG", "EXPORTED_SYMBOLS", "EnvelopeState", "envelope_marks", "packet_bytes",
-           "VAMD_OK", "VAMD_EFAULT", "VAMD_EIMPL", "VAMD_EINVAL", "VAMD_EVERSION", "VAMD_EDOMAIN"]
+           "VAMD_OK", "VAMD_EFAULT", "VAMD_EIMPL", "VAMD_EINVAL", "VAMD_EVERSION", "VAMD_EDOMAIN", "VAMD_ENONFINITE"]

@@ -7,13 +7,15 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
-VAMD_OK, VAMD_EFAULT, VAMD_EIMPL, VAMD_EINVAL, VAMD_EVERSION, VAMD_EDOMAIN = 0, -129, -130, -131, -134, -140
+VAMD_OK, VAMD_EFAULT, VAMD_EIMPL, VAMD_EINVAL, VAMD_EVERSION, VAMD_EDOMAIN, VAMD_ENONFINITE = 0, -129, -130, -131, -134, -140, -141
+ABI_VERSION = 8             # VAMD_ABI_VERSION of the header this mirror was written against
+STATUS_RANGE, STATUS_NONFINITE = 1, 2   # bits of the `status` output (vorbis_amd.h, "Input domain")
 LEVEL_TRANSFORM, LEVEL_PSY, LEVEL_FULL = 1, 2, 3
 POSTS_STRIDE = 32
 BLOCKTYPE_IMPULSE, BLOCKTYPE_PADDING, BLOCKTYPE_TRANSITION, BLOCKTYPE_LONG = 0, 1, 0, 1
 
 # every symbol include/vorbis_amd.h declares
-EXPORTED_SYMBOLS = ["vamd_create", "vamd_destroy", "vamd_last_error", "vamd_set_stream", "vamd_reserve",
+EXPORTED_SYMBOLS = ["vamd_create_abi", "vamd_quant_limit", "vamd_config_string", "vamd_destroy", "vamd_last_error", "vamd_set_stream", "vamd_reserve",
                     "vamd_channels", "vamd_blocksize", "vamd_posts", "vamd_mdct_forward_batch",
                     "vamd_analyze_batch", "vamd_analyze_stream", "vamd_analyze_block", "vamd_profile",
                     "vamd_stage_ms", "vamd_debug_cycles", "vamd_analyze_stream_mixed", "vamd_envelope_search_batch",
@@ -91,7 +93,10 @@ def load_library():
     # sees no device.
     import torch  # noqa: F401
     L = C.CDLL(path)
-    L.vamd_create.argtypes = [C.POINTER(_vp), _vp, C.c_size_t, C.c_int]
+    L.vamd_create_abi.argtypes = [C.POINTER(_vp), _vp, C.c_size_t, C.c_int, C.c_int]
+    L.vamd_quant_limit.argtypes = [_vp, C.c_int]
+    L.vamd_config_string.argtypes = [_vp]
+    L.vamd_config_string.restype = C.c_char_p
     L.vamd_destroy.argtypes = [_vp]
     L.vamd_destroy.restype = None
     L.vamd_last_error.argtypes = [_vp]
@@ -158,7 +163,7 @@ class Analyzer:
         blob = np.ascontiguousarray(np.frombuffer(bytes(setup_blob), dtype=np.uint8) if not isinstance(setup_blob, np.ndarray)
                                     else setup_blob.astype(np.uint8))
         h = _vp()
-        r = self.L.vamd_create(C.byref(h), blob.ctypes.data_as(_vp), blob.size, self.device)
+        r = self.L.vamd_create_abi(C.byref(h), blob.ctypes.data_as(_vp), blob.size, self.device, ABI_VERSION)
         if r != VAMD_OK:
             raise VamdError(r, "vamd_create failed (see stderr)")
         self.h = h
@@ -235,13 +240,23 @@ class Analyzer:
 
     def input_status(self):
         """vamd_input_status(): synchronise, then (channel-blocks, detector steps) issued since the last call that
-        were outside the input domain (a NaN / Inf sample, or a signal ~1000 x over full scale); resets the counts.
-        (0, 0) means every result since then is the reference's, bit for bit."""
+        were outside the input domain (a NaN / Inf sample, or quantised values beyond quant_limit()); resets the
+        counts.  (0, 0) means every result since then is the reference's, bit for bit.  `last_input_code` keeps the
+        call's verdict: VAMD_OK, VAMD_EDOMAIN (finite, beyond the integer bound) or VAMD_ENONFINITE."""
         a, b = C.c_long(0), C.c_long(0)
         r = self.L.vamd_input_status(self.h, C.byref(a), C.byref(b))
-        if r not in (VAMD_OK, VAMD_EDOMAIN):
+        if r not in (VAMD_OK, VAMD_EDOMAIN, VAMD_ENONFINITE):
             self._check(r)
+        self.last_input_code = r
         return int(a.value), int(b.value)
+
+    def config_string(self):
+        """vamd_config_string(): the environment knobs this context read at vamd_create, as "NAME=value" words."""
+        return self.L.vamd_config_string(self.h).decode()
+
+    def quant_limit(self, W):
+        """vamd_quant_limit(): the largest |quantised value| up to which the reference's integer arithmetic is defined."""
+        return int(self.L.vamd_quant_limit(self.h, W))
 
     # mdct_forward(lookup, in, out) batched -- BASELINE config 2
     def mdct_forward(self, W, frames, out=None):
@@ -308,7 +323,7 @@ class Analyzer:
                 o[k] = t.zeros((nb, self.packet_capacity(W)), dtype=t.uint8, device=dev)
             elif k == "packet_bits":
                 o[k] = t.zeros((nb,), dtype=t.int32, device=dev)
-            elif k == "status":      # 1 = the channel-block was outside the input domain (vorbis_amd.h)
+            elif k == "status":      # STATUS_* bits: the channel-block was outside the input domain (vorbis_amd.h)
                 o[k] = t.zeros((nb, ch), dtype=t.uint8, device=dev)
             else:
                 raise KeyError(k)
@@ -599,7 +614,7 @@ class Analyzer:
 
     # ---- bitrate-managed blocks: fifteen candidate packets each (vamd_analyze_*_managed) ------------
     def analyze_managed(self, pcm, W=1, lW=1, nW=1, blocktype=BLOCKTYPE_LONG, ampmax_in=-9999.0, residue=False,
-                        packets=False):
+                        packets=False, want=()):
         """vamd_analyze_batch_managed.  pcm: cuda float32 [nblocks, ch, n].  Returns a dict: shared `mdct`,
         `logmask`, `ampmax_out`, and per candidate `m_posts` [nb,15,ch,32], `m_post_valid` / `m_nonzero`
         [nb,15,ch], `m_iwork` [nb,15,ch,n/2] (+ `m_res_class`, `m_res_entries`, `m_res_count` with residue=True)."""
@@ -608,7 +623,7 @@ class Analyzer:
         self._need_tensor(pcm, t.float32, "pcm")
         self._need(pcm.dim() == 3 and tuple(pcm.shape[1:]) == (self.channels, n), "pcm must be [blocks, %d, %d]" % (self.channels, n))
         nb, ch, n2, dev = pcm.shape[0], self.channels, n // 2, pcm.device
-        outs = self.alloc_outputs(W, nb, ("mdct", "logmask", "ampmax_out"))
+        outs = self.alloc_outputs(W, nb, ("mdct", "logmask", "ampmax_out") + tuple(want))  # (want: further shared outputs, e.g. "status")
         keep = []
         d = self._desc(W, nb, lW, nW, blocktype, ampmax_in, keep)
         io = self._io(pcm, outs)

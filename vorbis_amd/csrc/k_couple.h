@@ -303,6 +303,36 @@ VAMD_DEV void couple_bin_sure(ChanBin &M, ChanBin &A, int &iM, int &iA, int b, c
   M.re = re, M.qe = qe, M.fg = fg;
 }
 
+// The input domain's integer edge (include/vorbis_amd.h, vamd_params.h): a lane's running minimum and maximum of the
+// quantised values it writes for one channel.  The block is inside the domain while every value is within the
+// setup's bound (Bound::qmax: up to there lib/res0.c:361-364, lib/psy.c:985 and the float -> int conversions of
+// :958-962 are defined by C); an out-of-range float converts to INT_MIN / INT_MAX here, which the bound catches too.
+// One three-operand minimum and one maximum per pair of values.
+struct QuantSpan {
+  int lo = 0, hi = 0;
+  VAMD_MEM void take(int v) {
+    lo = v < lo ? v : lo;
+    hi = v > hi ? v : hi;
+  }
+  VAMD_MEM void take4(const int *v) {  // (the compiler pairs these into v_min3_i32 / v_max3_i32)
+    for (int c = 0; c < 4; c++) take(v[c]);
+  }
+  VAMD_MEM bool beyond(int qmax) const { return hi > qmax || lo < -qmax; }
+};
+// The ordered paths (noise normalisation's sort, layouts beyond stereo) leave their final values in HBM after a
+// wave-wide sync: one more pass over them, a lane's share of every channel (their time is the ordered walks').
+// In a coupling step the magnitude keeps the larger of its two inputs and the angle their difference
+// (lib/psy.c:1141-1166), so no intermediate value exceeds the largest final one.
+VAMD_DEV unsigned quant_span_reread(int ch, int n2, int *const *iwork, int qmax) {
+  unsigned over = 0;
+  for (int k = 0; k < ch; k++) {
+    QuantSpan sp;
+    WAVE_FOR(b, n2) sp.take(iwork[k][b]);
+    if (sp.beyond(qmax)) over |= 1u << k;
+  }
+  return over;
+}
+
 // The stage where nothing is ordered (noise normalisation inactive in this block size, e.g. q >= 0.4 at 44.1 kHz):
 // each lane takes quads of bins straight through quantise -> couple -> re-normalise with one 16-byte load per input
 // tensor, by estimate first (chan_bin_sure) and exactly where some lane of the wave is not sure.
@@ -311,7 +341,7 @@ template <bool ALL>
 VAMD_DEV void couple_quads(const CoupleP &C, int n2, const float *__restrict__ mdctM, const float *__restrict__ mdctA,
                            const ilog_t *__restrict__ ilogM, const ilog_t *__restrict__ ilogA, int *__restrict__ iworkM,
                            int *__restrict__ iworkA, int nzM_in, int nzA_in, bool two_in, bool coupled_in, int nstart,
-                           float band) {
+                           float band, QuantSpan &spM, QuantSpan &spA) {
   const int nzM = ALL ? 1 : nzM_in, nzA = ALL ? 1 : nzA_in;
   const bool two = ALL ? true : two_in, coupled = ALL ? true : coupled_in;
   // (two quads in flight, not WAVE_FOR's four: at four the kernel needs 110 VGPRs and the SIMD holds four waves)
@@ -346,9 +376,11 @@ VAMD_DEV void couple_quads(const CoupleP &C, int n2, const float *__restrict__ m
     I4 w0, w1;
     w0.x = o0[0]; w0.y = o0[1]; w0.z = o0[2]; w0.w = o0[3];
     ((I4 *)iworkM)[q] = w0;
+    spM.take4(o0);
     if (two) {
       w1.x = o1[0]; w1.y = o1[1]; w1.z = o1[2]; w1.w = o1[3];
       ((I4 *)iworkA)[q] = w1;
+      spA.take4(o1);
     }
     if (wave_any(unsure)) {
       // some bin of the wave's 64 quads sits on a step: the reference's own arithmetic, a bin at a time from the
@@ -363,8 +395,10 @@ VAMD_DEV void couple_quads(const CoupleP &C, int n2, const float *__restrict__ m
           iA = A.out;
           if (coupled) couple_bin(M, A, iM, iA, b, nstart, C);
           iworkA[b] = iA;
+          spA.take(iA);
         }
         iworkM[b] = iM;
+        spM.take(iM);
       }
     }
   }
@@ -377,10 +411,12 @@ VAMD_DEV void couple_quads(const CoupleP &C, int n2, const float *__restrict__ m
 // (one or two channels, at most one coupling step: every stereo and mono setup)
 // NORM = false: the caller knows noise normalisation is inactive for this size class (the launch picks the
 // instantiation): the ordered general path below is then not even compiled in, which halves the registers.
+//   qmax / over  the input domain's integer edge (QuantSpan): bit k of the returned `over` is set in a lane that wrote a
+//                value beyond +-qmax for channel k (the caller ORs the lanes)
 template <bool NORM = true>
 VAMD_DEV void couple_block(const CoupleP &C_set, const PsyP &P, int n2, const float *const *mdct,
                            const ilog_t *const *ilogmask, int *const *iwork, int *nonzero, const CoupleLds &L,
-                           PhaseClock &pc, float band = VAMD_COUPLE_BAND) {
+                           PhaseClock &pc, float band = VAMD_COUPLE_BAND, int qmax = 0x7fffffff, unsigned *over = nullptr) {
   const CoupleP C = C_set;  // (by value: the fields in scalar registers, not behind the set's run-time index)
   const int ch = C.ch;
   const int partition = P.normal_p ? P.normal_partition : 16;
@@ -396,12 +432,14 @@ VAMD_DEV void couple_block(const CoupleP &C_set, const PsyP &P, int n2, const fl
     const int Mi = C.coupling_steps == 1 ? C.mag[0] : 0, Ai = C.coupling_steps == 1 ? C.ang[0] : (ch > 1 ? 1 : 0);
     // (the usual block -- two channels, both with a floor, coupled -- gets a loop compiled for exactly that: the
     // wave-uniform tests on nonzero[] and on the channel count otherwise stand between every two bins)
+    QuantSpan spM, spA;
     if (ch > 1 && coupled && nz[Mi] && nz[Ai])
       couple_quads<true>(C, n2, mdct[Mi], mdct[Ai], ilogmask[Mi], ilogmask[Ai], iwork[Mi], iwork[Ai], 1, 1, true, true,
-                         nstart, band);
+                         nstart, band, spM, spA);
     else
       couple_quads<false>(C, n2, mdct[Mi], mdct[Ai], ilogmask[Mi], ilogmask[Ai], iwork[Mi], iwork[Ai], nz[Mi], nz[Ai],
-                          ch > 1, coupled, nstart, band);
+                          ch > 1, coupled, nstart, band, spM, spA);
+    if (over) *over = (spM.beyond(qmax) ? 1u << Mi : 0u) | (ch > 1 && spA.beyond(qmax) ? 1u << Ai : 0u);
     pc.mark(0);
     if (coupled) nz[C.mag[0]] = nz[C.ang[0]] = 1;  // lib/psy.c:1204-1212
     for (int k = 0; k < ch; k++) nonzero[k] = nz[k];
@@ -445,6 +483,7 @@ VAMD_DEV void couple_block(const CoupleP &C_set, const PsyP &P, int n2, const fl
     WAVE_SYNC_GLOBAL();
     nz[Mi] = nz[Ai] = 1;  // lib/psy.c:1204-1212
   }
+  if (over) *over = quant_span_reread(ch, n2, iwork, qmax);
   for (int k = 0; k < ch; k++) nonzero[k] = nz[k];
   pc.mark(1);
 }
@@ -467,7 +506,7 @@ struct CoupleState {
 
 VAMD_DEV void couple_block_general(const CoupleP &C, const PsyP &P, int n2, const float *const *mdct,
                                    const ilog_t *const *ilogmask, int *const *iwork, int *nonzero, const CoupleLds &L,
-                                   const CoupleState &S, PhaseClock &pc) {
+                                   const CoupleState &S, PhaseClock &pc, int qmax = 0x7fffffff, unsigned *over = nullptr) {
   const int ch = C.ch, steps = C.coupling_steps;
   const int partition = P.normal_p ? P.normal_partition : 16;
   const int nstart = P.normal_p ? P.normal_start : 0x7fffffff;
@@ -533,6 +572,7 @@ VAMD_DEV void couple_block_general(const CoupleP &C, const PsyP &P, int n2, cons
     pend[Ai] = 0;
   }
   pc.mark(1);
+  if (over) *over = quant_span_reread(ch, n2, iwork, qmax);
   for (int t = 0; t < steps; t++)  // lib/psy.c:1204-1212, in step order
     if (nz[C.mag[t]] || nz[C.ang[t]]) nz[C.mag[t]] = nz[C.ang[t]] = 1;
   for (int k = 0; k < ch; k++) nonzero[k] = nz[k];

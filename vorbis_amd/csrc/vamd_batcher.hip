@@ -11,7 +11,7 @@
 // 256 threads on a 16-CPU host it spent 0.56 ms of KERNEL time per block in futex traffic -- every submission woke the
 // gathering leader, every finished batch handed its owners the one mutex to queue on -- and nine gathers in ten ended
 // on the 200 us timer):
-//   * LANES (VAMD_BATCH_LANES, default 8): a context, a HIP stream, pinned + device staging arenas and ONE library
+//   * LANES (VAMD_BATCH_LANES, default 8): a context, a HIP stream, a pinned staging arena and ONE library
 //     thread each.  A lane sleeps while nothing is pending; woken, it takes EVERYTHING pending of one size class (up
 //     to max_batch), runs it as one vamd_analyze_batch() with packet output, hands the packets back and looks again.
 //     No timer: blocks gather by themselves while the lanes are busy (a batch is ~0.25 ms of latency on the GPU, not
@@ -44,6 +44,7 @@
 #include <sys/syscall.h>
 #include <unistd.h>
 #include "vorbis_amd.h"
+#include "vamd_knobs.h"
 
 namespace {
 
@@ -107,6 +108,7 @@ struct vamd_batcher {
   double t_stage = 0., t_gpu = 0., t_unpack = 0., t_wake = 0.;
   long size_hist[12] = {0};  // batches of 1, 2-3, 4-7, ... blocks
   std::string err;
+  vamd::Knobs K;  // the environment knobs, read once at vamd_batcher_create (vamd_knobs.h)
 };
 
 // may a lane of kind k (0: one of the first `eager`, 1: the others) start a batch now?  (pending: both size classes)
@@ -152,7 +154,8 @@ static int run_batch(vamd_batcher *b, Lane &L, int W, Request *const *reqs, size
     L.stage_bytes = 0;
     const size_t want = total + total / 2;
     e = hipHostMalloc(&L.h_stage, want, hipHostMallocDefault);
-    if (e == hipSuccess) e = hipMalloc(&L.d_stage, want);
+    // (the device arena serves the copy commands of VAMD_STAGE_COPIES only: the kernels read the pinned one in place)
+    if (e == hipSuccess && b->K.stage_copies) e = hipMalloc(&L.d_stage, want);
     if (e == hipSuccess) L.stage_bytes = want;
   }
   if (e != hipSuccess) {
@@ -172,7 +175,7 @@ static int run_batch(vamd_batcher *b, Lane &L, int W, Request *const *reqs, size
   // the kernels read samples and descriptors out of, and write packets into, the pinned arena itself (mapped into the
   // device's address space): no copy commands either side of the launches, and only the bytes a packet really has
   // cross the link.  VAMD_STAGE_COPIES=1 brings the two copies back (measurement aid).
-  static const bool staged_copies = getenv("VAMD_STAGE_COPIES") != nullptr;
+  const bool staged_copies = b->K.stage_copies;
   if (!staged_copies) {
     void *mapped = nullptr;
     e = hipHostGetDevicePointer(&mapped, hs, 0);
@@ -225,10 +228,11 @@ static int run_batch(vamd_batcher *b, Lane &L, int W, Request *const *reqs, size
   const double t_back = now_s();
   for (size_t k = 0; k < nb; k++) {
     Request &q = *reqs[k];
-    bool outside = false;  // this block's input was outside the domain (include/vorbis_amd.h): its own error, nobody else's
-    for (size_t c = 0; c < ch; c++) outside |= hs[o_st + k * ch + c] != 0;
+    unsigned outside = 0;  // this block's input was outside the domain (include/vorbis_amd.h): its own error, nobody else's
+    for (size_t c = 0; c < ch; c++) outside |= hs[o_st + k * ch + c];
     if (outside) {
-      q.status = VAMD_EDOMAIN;
+      if (q.ampmax_out) *q.ampmax_out = ((const float *)(hs + o_aout))[k];  // (comes out of the block's FFT: valid either way)
+      q.status = (outside & 2) ? VAMD_ENONFINITE : VAMD_EDOMAIN;  // VAMD_STATUS_NONFINITE / VAMD_STATUS_RANGE
       continue;
     }
     const int32_t bits = ((const int32_t *)(hs + o_bits))[k];
@@ -251,6 +255,7 @@ static void lane_main(vamd_batcher *b, Lane *lane) {
   (void)hipSetDevice(b->device);
   const int kind = (int)(lane - b->lanes.data()) < b->eager ? 0 : 1;
   std::vector<Request *> take;
+  int last_W = 0;  // the size class this lane served last
   for (;;) {
     if (b->stop.load()) break;
     const int seen = b->work[kind].load(std::memory_order_seq_cst);
@@ -264,8 +269,11 @@ static void lane_main(vamd_batcher *b, Lane *lane) {
       b->sleepers[kind].fetch_sub(1, std::memory_order_seq_cst);
       continue;
     }
-    // the size class with more blocks waiting goes first; the whole list in one exchange
-    const int W = n1 >= n0 ? 1 : 0;
+    // When both size classes wait, a lane takes the one it did NOT take last time (the whole list in one exchange): with
+    // few lanes, "the class with more blocks first" could pass a stream's lone short block over for as long as other
+    // streams kept submitting long ones -- there is no timer to bound that wait any more.
+    const int W = (n0 > 0 && n1 > 0) ? (last_W ^ 1) : (n1 > 0 ? 1 : 0);
+    last_W = W;
     Request *list = b->head[W].exchange(nullptr, std::memory_order_acquire);
     take.clear();
     for (Request *r = list; r;) {
@@ -330,10 +338,12 @@ int vamd_batcher_create(vamd_batcher **out, const void *setup_blob, size_t blob_
   if (!out) return VAMD_EINVAL;
   *out = nullptr;
   if (max_batch < 1 || max_wait_us < 0) return VAMD_EINVAL;
-  int nlanes = getenv("VAMD_BATCH_LANES") ? atoi(getenv("VAMD_BATCH_LANES")) : 8;
+  const vamd::Knobs K = vamd::read_knobs();
+  int nlanes = K.batch_lanes;
   if (nlanes < 1) nlanes = 1;
   if (nlanes > 16) nlanes = 16;
   vamd_batcher *b = new vamd_batcher;
+  b->K = K;
   int cur = 0;
   (void)hipGetDevice(&cur);
   b->device = device >= 0 ? device : cur;
@@ -363,10 +373,11 @@ int vamd_batcher_create(vamd_batcher **out, const void *setup_blob, size_t blob_
   }
   b->max_batch = max_batch;
   b->max_wait_us = max_wait_us;
-  if (getenv("VAMD_BATCH_SPIN_BELOW")) b->spin_below = atol(getenv("VAMD_BATCH_SPIN_BELOW"));
-  if (getenv("VAMD_BATCH_EAGER")) b->eager = atoi(getenv("VAMD_BATCH_EAGER"));
-  if (getenv("VAMD_BATCH_JOIN")) b->join_at = atoi(getenv("VAMD_BATCH_JOIN"));
+  if (K.batch_spin_below >= 0) b->spin_below = K.batch_spin_below;
+  if (K.batch_eager >= 0) b->eager = K.batch_eager;
+  if (K.batch_join >= 0) b->join_at = K.batch_join;
   if (b->eager < 1) b->eager = 1;
+  if (b->join_at < 1) b->join_at = 1;  // (0 would have the joining lanes spin on empty lists)
   if (r) {
     (void)hipSetDevice(b->device);
     free_lanes(b);
@@ -375,7 +386,15 @@ int vamd_batcher_create(vamd_batcher **out, const void *setup_blob, size_t blob_
     return r;
   }
   if (cur != b->device) (void)hipSetDevice(cur);
-  for (Lane &L : b->lanes) L.worker = std::thread(lane_main, b, &L);
+  try {
+    for (Lane &L : b->lanes) L.worker = std::thread(lane_main, b, &L);
+  } catch (...) {  // (std::system_error: no exception may leave an extern "C" entry point)
+    (void)hipSetDevice(b->device);
+    free_lanes(b);
+    (void)hipSetDevice(cur);
+    delete b;
+    return VAMD_EFAULT;
+  }
   *out = b;
   return VAMD_OK;
 }

@@ -3,6 +3,7 @@
 // address (the HBM copy for the product, the host copy for tests/emul).
 #pragma once
 #include <math.h>
+#include <stdlib.h>
 #include <stddef.h>
 #include <string.h>
 #include <algorithm>
@@ -32,6 +33,7 @@ struct Bound {
   int res_lds_ints[2];    // LDS ints k_residue needs for the largest submap of the mode
   int res_off_ints[2];    // largest stages*slots + 1 over the mode's submaps (k_pack's offset arrays)
   float ampmax_att_per_sec;
+  int qmax[2];            // the input domain's integer edge per size class (derive_quant_limit)
 };
 
 // Checks the blob and produces `image` = blob + derived tables (what gets copied to HBM).
@@ -424,6 +426,58 @@ inline void floor_derive_tests(FloorP *F) {
   F->under_i = F->int_tests ? (int)floorf(F->maxunder) + 1 : 0;
 }
 
+// The input domain's integer edge (include/vorbis_amd.h): the largest |quantised value| Q of a block for which every
+// integer the reference forms downstream of _vp_couple_quantize_normalize is defined by C, for THIS setup.
+//  * lib/psy.c:958-962,985: out = rint(sqrt(ve)) converted to int and squared in an int -- |out| <= 46340.  (A value
+//    the coupling stage leaves is never smaller than what it was first quantised to: a coupling step's magnitude keeps
+//    the larger of its two inputs, :1141-1166.)
+//  * lib/res0.c:322-382, local_book_besterror on a vector a of dim <= 8 values, stage after stage (:585-640).  With
+//    |a_j| <= A:  (a - minval + del/2) / del, v * del + minval and the index arithmetic stay below 2^31 for any A < 2^29;
+//    the exhaustive search (:349-376) sums (e_j - a_j)^2 over the dim coordinates for EVERY populated entry e, whose
+//    coordinates lie in [minval, minval + del * (quantvals - 1)], |e_j| <= E(book): the sum is at most
+//    dim * (A + E)^2, defined while A + E <= R(dim) = floor(sqrt((2^31 - 1) / dim)).  The stage then leaves a - p with
+//    p the (unclamped) nearest lattice point, |a_j - p_j| <= del <= max(A, E), or the best entry, |a_j - p_j| <= A + E:
+//    after the stages t < s of a class's cascade |a_j| <= Q + sum E(book_t).  So the cascade of class c is defined
+//    for Q <= min over its stages s of R(dim_s) - sum_{t <= s} E(book_t).  Which class a partition lands in depends on
+//    its values: every class but the last takes a partition only while its largest magnitudes are within the class's
+//    metrics (_2class :509-512: magmax <= classmetric1 && angmax <= classmetric2; _01class :447-450: max <=
+//    classmetric1), so such a class constrains Q only if values up to its own metrics could break its cascade (never,
+//    for libvorbisenc's books: checked here all the same); the last class takes whatever is left, and its cascade
+//    sets the bound.
+//  * _01class / _2class (:412-532) add up to `grouping` absolute values: far below 2^31 at these magnitudes.
+// For the libvorbisenc setups the last class's cascade starts on a two-dimensional book reaching a few thousand:
+// Q = 32 767 - ~2 000 ... 23 170 - ~10, spectra ~ +87 ... +90 dB over full scale.
+inline int derive_quant_limit(const vamd_setup_header &h, const vamd_book_tab *hb, int W) {
+  long q = 46340;
+  const int submaps = h.mode[W].submaps;
+  for (int sm = 0; sm < submaps && sm < VAMD_MAX_SUBMAPS; sm++) {
+    const vamd_residue_tab &r = h.res[W][sm];
+    for (int c = 0; c < r.partitions && c < VAMD_RES_MAXCLASS; c++) {
+      long reach = 0, qc = 46340;
+      for (int s = 0; s < r.stages && s < VAMD_RES_MAXSTAGE; s++) {
+        if (!((r.secondstages[c] >> s) & 1) || r.partbooks[c][s] < 0 || r.partbooks[c][s] >= h.nbooks) continue;
+        const vamd_book_tab &bk = hb[r.partbooks[c][s]];
+        const long lo = bk.minval, hi = (long)bk.minval + (long)bk.delta * (bk.quantvals - 1);
+        long e = std::max(std::labs(lo), std::labs(hi));
+        e = std::max(e, std::labs((long)bk.delta));
+        reach += e;
+        const int dim = bk.dim < 1 ? 1 : (bk.dim > 8 ? 8 : bk.dim);
+        long R = (long)floor(sqrt(2147483647.0 / dim));
+        while ((R + 1) * (R + 1) * dim <= 2147483647L) R++;
+        while (R * R * dim > 2147483647L) R--;
+        qc = std::min(qc, R - reach);
+      }
+      // the largest magnitude a partition of this class can hold; unbounded for the last class (and for a metric the
+      // format does not bound: a negative classmetric2 switches the second test off only for type 1, where it is a mean)
+      const bool last = c == r.partitions - 1;
+      long held = std::max(0, (int)r.classmetric1[c]);
+      if (r.type == 2) held = std::max(held, (long)std::max(0, (int)r.classmetric2[c]));
+      if (last || held > qc) q = std::min(q, qc);
+    }
+  }
+  return (int)std::max(q, 0L);
+}
+
 // Bind parameter structs to `base` (address of the image in the memory space
 // the kernels will read: device pointer for HIP, host pointer for tests/emul).
 inline void bind_params(const std::vector<unsigned char> &image, const std::vector<uint32_t> &derived_off,
@@ -544,6 +598,7 @@ inline void bind_params(const std::vector<unsigned char> &image, const std::vect
     }
   }
   const vamd_book_tab *hb = (const vamd_book_tab *)(image.data() + h.off_books);
+  for (int W = 0; W < 2; W++) B->qmax[W] = derive_quant_limit(h, hb, W);
   auto longest = [&](int bn) {  // longest codeword of a book
     int m = 0;
     if (bn < 0) return 0;

@@ -15,12 +15,14 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <new>
 #include <string>
 #include <vector>
 
 #include "vorbis_amd.h"
 #include "vamd_bind.h"
+#include "vamd_knobs.h"
 #include "k_transform.h"
 #include "k_noise.h"
 #include "k_tone.h"
@@ -42,6 +44,17 @@ __device__ __forceinline__ int d_lW(const DescP &d, long b) { return d.lW ? d.lW
 __device__ __forceinline__ int d_nW(const DescP &d, long b) { return d.nW ? d.nW[b] : d.u_nW; }
 __device__ __forceinline__ int d_bt(const DescP &d, long b) { return d.blocktype ? d.blocktype[b] : d.u_blocktype; }
 __device__ __forceinline__ float d_amp(const DescP &d, long b) { return d.ampmax_in ? d.ampmax_in[b] : d.u_ampmax_in; }
+// the input domain's integer edge (k_couple.h: QuantSpan): channel-block i holds a quantised value beyond the setup's
+// bound.  One lane per channel-block calls this; a channel-block k_transform has already flagged is not counted again.
+// (The fifteen candidate packets of a bitrate-managed block are fifteen units that may flag the same channel-block:
+// the byte is right either way, the count may then run up to fourteen high.)
+__device__ __forceinline__ void flag_range(const DescP &d, long i) {
+  const unsigned char old = d.status[i];
+  if (!(old & VAMD_STATUS_RANGE)) {
+    d.status[i] = old | VAMD_STATUS_RANGE;
+    if (!old) atomicAdd(d.bad, 1u);
+  }
+}
 
 // ---- transform kernels: persistent workgroups with the tables staged in LDS -------
 // One workgroup per CU, VAMD_XF_WAVES independent waves each owning one channel-block
@@ -191,9 +204,12 @@ __global__ __launch_bounds__(64 * VAMD_XF_WAVES) __attribute__((amdgpu_num_vgpr(
                                             peaks ? peaks + cb * nrp : nullptr);
     if (LANE == 0) {
       local_ampmax[cb] = amp;
-      const bool bad = raw > VAMD_INPUT_LIMIT_DB;  // outside the input domain: a non-finite or absurdly large sample
-      d.status[cb] = bad;
-      if (bad) atomicAdd(d.bad, 1u);
+      const bool bad = raw > VAMD_NONFINITE_DB;  // outside the input domain: the block's arithmetic is not finite
+      d.status[cb] = bad ? VAMD_STATUS_NONFINITE : 0;
+      if (bad) {
+        atomicAdd(d.bad, 1u);
+        atomicAdd(d.bad + 2, 1u);
+      }
     }
   }
   pc.flush();
@@ -658,7 +674,7 @@ __global__ void k_widen_ilog(long n, const ilog_t *__restrict__ in, int *__restr
 template <bool NORM>
 __global__ __launch_bounds__(256) void k_couple(PsyP P0, PsyP P1, CoupleSet CS, int blob_base, int nblobs, DescP d,
                                                const float *__restrict__ mdct, const ilog_t *__restrict__ ilogmask,
-                                               int *__restrict__ iwork, int *__restrict__ nonzero, float band) {
+                                               int *__restrict__ iwork, int *__restrict__ nonzero, float band, int qmax) {
   const long unit = blockIdx.x, mblk = unit / nblobs;
   const CoupleP &C = CS.c[blob_base + (int)(unit - mblk * nblobs)];
   const PsyP &P = d_bt(d, mblk) ? P1 : P0;
@@ -682,9 +698,14 @@ __global__ __launch_bounds__(256) void k_couple(PsyP P0, PsyP P1, CoupleSet CS, 
   WAVE_SYNC_GLOBAL();  // every lane has read nonzero[] before lane 0 rewrites it
   PhaseClock pc;
   pc.start(d.dbg ? d.dbg + 64 : nullptr);
-  couple_block<NORM>(C, P, n2, mp, ip, op, nz, L, pc, band);
+  unsigned over = 0;
+  couple_block<NORM>(C, P, n2, mp, ip, op, nz, L, pc, band, qmax, &over);
   if (TEAM_LEADER)
     for (int c = 0; c < ch; c++) nonzero[blk * ch + c] = nz[c];
+  for (int c = 0; c < ch; c++) {  // (the team's lanes each saw their own quads)
+    const int any = __syncthreads_or((int)((over >> c) & 1u));
+    if (TEAM_LEADER && any) flag_range(d, mblk * ch + c);
+  }
   pc.flush();
 }
 
@@ -694,7 +715,7 @@ __global__ __launch_bounds__(256) void k_couple(PsyP P0, PsyP P1, CoupleSet CS, 
 __global__ __launch_bounds__(64) void k_couple_general(PsyP P0, PsyP P1, CoupleSet CS, int blob_base, int nblobs, DescP d,
                                                        const float *__restrict__ mdct, const ilog_t *__restrict__ ilogmask,
                                                        int *__restrict__ iwork, int *__restrict__ nonzero,
-                                                       float *__restrict__ state) {
+                                                       float *__restrict__ state, int qmax) {
   const long unit = blockIdx.x, mblk = unit / nblobs;
   const CoupleP &C = CS.c[blob_base + (int)(unit - mblk * nblobs)];
   const PsyP &P = d_bt(d, mblk) ? P1 : P0;
@@ -722,9 +743,12 @@ __global__ __launch_bounds__(64) void k_couple_general(PsyP P0, PsyP P1, CoupleS
   WAVE_SYNC_GLOBAL();  // every lane has read nonzero[] before lane 0 rewrites it
   PhaseClock pc;
   pc.start(nullptr);
-  couple_block_general(C, P, n2, mp, ip, op, nz, L, S, pc);
+  unsigned over = 0;
+  couple_block_general(C, P, n2, mp, ip, op, nz, L, S, pc, qmax, &over);
   if (LANE == 0)
     for (int c = 0; c < ch; c++) nonzero[unit * ch + c] = nz[c];
+  for (int c = 0; c < ch; c++)
+    if (wave_any((int)((over >> c) & 1u)) && LANE == 0) flag_range(d, mblk * ch + c);
 }
 
 // stage 4 of a bitrate-managed batch: the same offset_and_mix, then three fits, twelve interpolated
@@ -1217,9 +1241,11 @@ struct vamd_ctx {
   Bound B;                 // parameter structs bound to the HBM image
   unsigned char *d_image = nullptr;
   Bound *d_bound = nullptr;  // c->B in HBM: kernels that would otherwise carry several parameter structs in SGPRs read it
-  unsigned int *d_bad = nullptr;  // [0] channel-blocks, [1] detector steps outside the input domain since vamd_input_status() (behind d_bound)
+  unsigned int *d_bad = nullptr;  // [0] channel-blocks, [1] detector steps outside the input domain since vamd_input_status(), [2] the non-finite ones among [0] (behind d_bound)
   size_t image_bytes = 0;
   std::string err;
+  Knobs K;           // the environment knobs, read once at vamd_create (vamd_knobs.h)
+  char config[1024]; // ... and as text (vamd_config_string)
   // workspace, grown on demand (vamd_reserve to pre-size)
   enum { WS_MDCT_RAW, WS_LOGMDCT, WS_LOGFFT, WS_NOISE, WS_TONE, WS_MDCT, WS_ILOGMASK, WS_IWORK, WS_POSTS, WS_POSTVALID,
          WS_NONZERO, WS_LOCAL, WS_AMPIN, WS_AMPGLOB, WS_PCM, WS_SEED, WS_SURV, WS_NSURV, WS_MISC,
@@ -1258,7 +1284,7 @@ static void prof_mark(vamd_ctx *c, int stage) {
 
 // waves per persistent transform workgroup: as many as fit beside the staged tables
 static int xf_waves(const vamd_ctx *c, const XformP &P) {
-  static const int cap = getenv("VAMD_XF_WAVES_CAP") ? atoi(getenv("VAMD_XF_WAVES_CAP")) : VAMD_XF_WAVES;  // (measurement aid)
+  const int cap = c->K.xf_waves_cap;  // (measurement aid, a test knob: vamd_knobs.h)
   int w = cap > 0 && cap < VAMD_XF_WAVES ? cap : VAMD_XF_WAVES;
   while (w > 1 && transform_lds_bytes(P, w) > c->lds_per_block) w--;
   return w;
@@ -1273,6 +1299,17 @@ static int fail(vamd_ctx *c, int code, const char *what, hipError_t e = hipSucce
     }
   }
   return code;
+}
+
+// what a host-pointer call makes of its block's status bytes (include/vorbis_amd.h, "Input domain")
+static int status_verdict(vamd_ctx *c, const unsigned char *st, size_t ch) {
+  unsigned any = 0;
+  for (size_t i = 0; i < ch; i++) any |= st[i];
+  if (any & VAMD_STATUS_NONFINITE)
+    return fail(c, VAMD_ENONFINITE, "input outside the domain: a NaN / Inf sample (or finite ones beyond ~3e16 x full scale, where the fp32 spectrum overflows)");
+  if (any & VAMD_STATUS_RANGE)
+    return fail(c, VAMD_EDOMAIN, "input outside the domain: a quantised value beyond the bound up to which the reference's integer arithmetic is defined (vamd_quant_limit)");
+  return VAMD_OK;
 }
 
 #define HIP_TRY(c, expr)                                              \
@@ -1312,11 +1349,20 @@ static int ws_get(vamd_ctx *c, int W, int which, size_t bytes, void **out) {
 
 extern "C" {
 
-int vamd_create(vamd_ctx **out, const void *setup_blob, size_t blob_bytes, int device) {
+const char *vamd_config_string(const vamd_ctx *c) { return c ? c->config : ""; }
+
+int vamd_create_abi(vamd_ctx **out, const void *setup_blob, size_t blob_bytes, int device, int caller_abi_version) {
   if (!out) return VAMD_EINVAL;
   *out = nullptr;
+  if (caller_abi_version != VAMD_ABI_VERSION) {
+    fprintf(stderr, "vamd_create: the caller was built against ABI %d of include/vorbis_amd.h, this library is ABI %d\n",
+            caller_abi_version, VAMD_ABI_VERSION);
+    return VAMD_EVERSION;
+  }
   vamd_ctx *c = new (std::nothrow) vamd_ctx;
   if (!c) return VAMD_EFAULT;
+  c->K = read_knobs();
+  knobs_string(c->K, c->config, sizeof(c->config));
   std::vector<unsigned char> image;
   std::vector<uint32_t> doff;
   std::vector<PsyDerived> derived;
@@ -1347,7 +1393,7 @@ int vamd_create(vamd_ctx **out, const void *setup_blob, size_t blob_bytes, int d
       VAMD_OPT_IN(0) VAMD_OPT_IN(8) VAMD_OPT_IN(9) VAMD_OPT_IN(10) VAMD_OPT_IN(11) VAMD_OPT_IN(12)
 #undef VAMD_OPT_IN
       (void)hipGetLastError();
-      if (getenv("VAMD_VERBOSE"))
+      if (c->K.verbose)
         fprintf(stderr, "vamd_create: %d CUs, %zu B LDS per workgroup\n", c->num_cus, c->lds_per_block);
     }
   }
@@ -1355,9 +1401,9 @@ int vamd_create(vamd_ctx **out, const void *setup_blob, size_t blob_bytes, int d
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming);
-  c->overlap = getenv("VAMD_NO_OVERLAP") == nullptr;
+  c->overlap = !c->K.no_overlap;
   // (test aid: k_couple's estimate-then-verify margin as a power of two; 1 sends every quad through the exact path)
-  c->couple_band = getenv("VAMD_COUPLE_BAND_LOG2") ? ldexpf(1.f, atoi(getenv("VAMD_COUPLE_BAND_LOG2"))) : VAMD_COUPLE_BAND;
+  c->couple_band = c->K.couple_band_set ? ldexpf(1.f, c->K.couple_band_log2) : VAMD_COUPLE_BAND;
   if (e == hipSuccess) e = hipMalloc((void **)&c->d_image, image.size());
   if (e == hipSuccess) e = hipMemcpy(c->d_image, image.data(), image.size(), hipMemcpyHostToDevice);
   if (e != hipSuccess) {
@@ -1428,15 +1474,18 @@ int vamd_set_stream(vamd_ctx *c, void *s) {
 int vamd_input_status(vamd_ctx *c, long *bad_channel_blocks, long *bad_detector_steps) {
   DeviceGuard dev_guard(c);
   if (!c) return VAMD_EINVAL;
-  unsigned int h[2] = {0, 0};
+  unsigned int h[3] = {0, 0, 0};
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipMemcpy(h, c->d_bad, sizeof(h), hipMemcpyDeviceToHost));
-  if (h[0] | h[1]) HIP_TRY(c, hipMemset(c->d_bad, 0, sizeof(h)));
+  if (h[0] | h[1] | h[2]) HIP_TRY(c, hipMemset(c->d_bad, 0, sizeof(h)));
   if (bad_channel_blocks) *bad_channel_blocks = (long)h[0];
   if (bad_detector_steps) *bad_detector_steps = (long)h[1];
-  if (h[0] | h[1]) return fail(c, VAMD_EDOMAIN, "input outside the domain: a non-finite sample, or a signal ~1000 x over full scale");
+  if (h[1] | h[2]) return fail(c, VAMD_ENONFINITE, "input outside the domain: NaN / Inf samples");
+  if (h[0]) return fail(c, VAMD_EDOMAIN, "input outside the domain: quantised values beyond the bound up to which the reference's integer arithmetic is defined (vamd_quant_limit)");
   return VAMD_OK;
 }
+
+int vamd_quant_limit(const vamd_ctx *c, int W) { return (c && (W == 0 || W == 1)) ? c->B.qmax[W] : VAMD_EINVAL; }
 
 int vamd_profile(vamd_ctx *c, int enable) {
   if (!c) return VAMD_EINVAL;
@@ -1520,14 +1569,16 @@ static int plan(vamd_ctx *c, int W, long nb, const vamd_batch_io *io, int level,
   const size_t per = (size_t)nb * ch * n2 * 4;
   p->wrapped = nullptr;
   void *v;
-#define PICK(field, user, slot, bytes)                  \
-  if (user) {                                           \
-    p->field = user;                                    \
-  } else {                                              \
-    int r__ = ws_get(c, W, vamd_ctx::slot, (bytes), &v); \
-    if (r__) return r__;                                \
-    p->field = (decltype(p->field))v;                   \
-  }
+#define PICK(field, user, slot, bytes)                     \
+  do {                                                     \
+    if (user) {                                            \
+      p->field = user;                                     \
+    } else {                                               \
+      int r__ = ws_get(c, W, vamd_ctx::slot, (bytes), &v); \
+      if (r__) return r__;                                 \
+      p->field = (decltype(p->field))v;                    \
+    }                                                      \
+  } while (0)
   PICK(mdct_raw, io ? io->mdct_raw : nullptr, WS_MDCT_RAW, per);
   p->logmdct = io ? io->logmdct : nullptr;  // a tap only: the later stages form it from mdct_raw
   p->logfft = io ? io->logfft : nullptr;  // a tap only: the tone stage reads the run peaks
@@ -1728,7 +1779,7 @@ static void launch_residue_pack(vamd_ctx *c, BatchRun *R, hipStream_t s, long un
                                 void *packets, int64_t packet_stride, int32_t *packet_bits) {
   const int W = R->W, ch = c->B.channels, n2 = c->B.xf[W].n / 2;
   const ChMap &cm = c->B.chmap[W];
-  static const long res_team_max = getenv("VAMD_RES_TEAM_MAX") ? atol(getenv("VAMD_RES_TEAM_MAX")) : 2048;
+  const long res_team_max = c->K.res_team_max;
   for (int sm = 0; sm < cm.submaps; sm++)
     // a stereo bundle's search keeps two waves busy, the five-channel bundle of the 5.1 layout four; a handful of units
     // takes four either way (nothing else wants the CU, and a lone unit's latency is the caller's)
@@ -1739,7 +1790,7 @@ static void launch_residue_pack(vamd_ctx *c, BatchRun *R, hipStream_t s, long un
   if (packets) {
     const size_t lds = ((size_t)VAMD_PK_RING + VAMD_POSTS_STRIDE + VAMD_RES_CLASS_STRIDE + 2 * (size_t)c->B.res_off_ints[W] +
                         VAMD_PK_FTAB_INTS + 3 * (size_t)c->B.pack[W].nbooks) * 4;
-    static const long pair_max = getenv("VAMD_PACK_PAIR_MAX") ? atol(getenv("VAMD_PACK_PAIR_MAX")) : 2048;
+    const long pair_max = c->K.pack_pair_max;
     // a handful of packets: two waves each -- where the rows hold any packet (the residue part is assembled past the
     // longest possible head and then moved down: in a shorter row the end of a cut-off packet would be lost on the way)
     if (units <= pair_max && packet_stride >= c->B.pack[W].capacity)
@@ -1777,7 +1828,7 @@ static void launch_couple(vamd_ctx *c, BatchRun *R, hipStream_t s, long units, i
   const int n2 = c->B.xf[W].n / 2;
   if (needs_general_couple(c, W)) {
     hipLaunchKernelGGL(k_couple_general, dim3((unsigned)units), dim3(64), (size_t)n2 * 12 + 1024, s, P0, P1, c->B.couple_all[W],
-                       blob_base, nblobs, R->d, mdct, ilogmask, iwork, nonzero, R->couple_state);
+                       blob_base, nblobs, R->d, mdct, ilogmask, iwork, nonzero, R->couple_state, c->B.qmax[W]);
     return;
   }
   // the LDS arrays serve noise normalisation's sort only (lib/psy.c:941-1010); without it the
@@ -1785,10 +1836,10 @@ static void launch_couple(vamd_ctx *c, BatchRun *R, hipStream_t s, long units, i
   const bool norm0 = P0.normal_p && P0.normal_start < n2, norm1 = P1.normal_p && P1.normal_start < n2;
   if (norm0 || norm1)
     hipLaunchKernelGGL(k_couple<true>, dim3((unsigned)units), dim3(64), (size_t)n2 * 12 + 1024, s, P0, P1, c->B.couple_all[W], blob_base,
-                       nblobs, R->d, mdct, ilogmask, iwork, nonzero, c->couple_band);
+                       nblobs, R->d, mdct, ilogmask, iwork, nonzero, c->couple_band, c->B.qmax[W]);
   else  // (a handful of blocks: four waves each)
     hipLaunchKernelGGL(k_couple<false>, dim3((unsigned)units), dim3(units <= 2048 && n2 >= 512 ? 256 : 64), 0, s, P0, P1, c->B.couple_all[W],
-                       blob_base, nblobs, R->d, mdct, ilogmask, iwork, nonzero, c->couple_band);
+                       blob_base, nblobs, R->d, mdct, ilogmask, iwork, nonzero, c->couple_band, c->B.qmax[W]);
 }
 
 //   part: 1 = the masks only (noise on the main stream, the tone chain beside it, their join left open), 2 = the rest
@@ -1811,7 +1862,7 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_
   // saves -- one stereo block 192 us with it, 181 without)
   const bool overlap = c->overlap && gcb > 64;
   // the VBR path's floor stage takes the tone chain's last step with it (k_floor)
-  static const bool fold_env = getenv("VAMD_FOLD_SEPARATE") == nullptr;
+  const bool fold_env = !c->K.fold_separate;
   const int nlp_all = VAMD_LINES_PAD(nl);
   const size_t fold_lds = (size_t)(nlp_all + (P0.ngroups > P1.ngroups ? P0.ngroups : P1.ngroups)) * 4;
   const bool fold_in_floor = fold_env && level >= VAMD_LEVEL_FULL && !M && n2 <= 64 * 4 * VAMD_QPL;
@@ -1825,11 +1876,11 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_
     const size_t seed_lds = (size_t)(seed_pad_lo(P0.eighth_octave_lines) + nlp + seed_pad_hi(P0.eighth_octave_lines)) * 4;
     // a lane per block for batches, a wave per block (the walk in 64 chunks) where that would leave the GPU to a
     // handful of lanes walking ~800 lines each: the per-block entry points, the batcher's small batches
-    static const long wave_max_cb = getenv("VAMD_CHASE_WAVE_MAX") ? atol(getenv("VAMD_CHASE_WAVE_MAX")) : 32768;
+    const long wave_max_cb = c->K.chase_wave_max;
     const bool by_wave = (long)gcb <= wave_max_cb && P0.eighth_octave_lines <= 16 && nl <= 2048;
     const bool lp8 = P0.eighth_octave_lines == 8 && P1.eighth_octave_lines == 8;
     // a handful of blocks, no second stream: both masks in one launch, side by side (k_noise_tone)
-    static const bool merge_env = getenv("VAMD_MASKS_SEPARATE") == nullptr;
+    const bool merge_env = !c->K.masks_separate;
     const bool merged = merge_env && !overlap && by_wave && lp8;
     if (merged) {
       const size_t nlds = (size_t)5 * VAMD_NZ_STRIDE(n2) * 4, tlds = seed_lds + (size_t)VAMD_RING * 8;
@@ -1859,7 +1910,7 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_
       const int nw = n2 >= 256 ? 4 : (n2 >= 64 ? n2 / 64 : 1);
       long per_cu = (long)(c->lds_per_block / lds);
       if (per_cu > 32 / nw) per_cu = 32 / nw;
-      static const int noise_cap = getenv("VAMD_NOISE_TEAMS") ? atoi(getenv("VAMD_NOISE_TEAMS")) : 0;  // (measurement aid)
+      const int noise_cap = c->K.noise_teams;  // (measurement aid)
       if (noise_cap > 0) {
         if (per_cu > noise_cap) per_cu = noise_cap;
       } else if (overlap) {
@@ -1934,7 +1985,7 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_
       launch_residue_pack(c, R, s, (long)gb * VAMD_PACKETBLOBS, VAMD_PACKETBLOBS, M->posts, nullptr, M->post_valid, M->iwork, M->nonzero, rb,
                           M->packets, M->packet_stride, M->packet_bits);
   } else if (level >= VAMD_LEVEL_FULL) {
-    static const size_t floor_pad = getenv("VAMD_FLOOR_LDS_PAD") ? (size_t)atoi(getenv("VAMD_FLOOR_LDS_PAD")) : 0;  // (experiment: occupancy)
+    const size_t floor_pad = (size_t)c->K.floor_lds_pad;  // (experiment: occupancy)
     size_t floor_lds = (size_t)((n2 + 15) & ~15) * 2 + sizeof(FloorScratch) + floor_pad;
     if (fold_in_floor && fold_lds > floor_lds) floor_lds = fold_lds;
     hipLaunchKernelGGL(k_floor, dim3(gcb), dim3(64), floor_lds, s,
@@ -2095,10 +2146,9 @@ int vamd_analyze_block_managed(vamd_ctx *c, const float *const *pcm, int lW, int
   if (r) return r;
   HIP_TRY(c, hipMemcpyAsync(hs + o_mdct, ds + o_mdct, total - o_mdct, hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
-  for (size_t i = 0; i < ch; i++)
-    if (hs[o_amp + 4 + i]) return fail(c, VAMD_EDOMAIN, "input outside the domain: a non-finite sample, or a signal ~1000 x over full scale");
+  if (ampmax_out) memcpy(ampmax_out, hs + o_amp, 4);  // (the block's ampmax comes out of its FFT: delivered with a domain error too)
+  if ((r = status_verdict(c, hs + o_amp + 4, ch))) return r;
   if (mdct) memcpy(mdct, hs + o_mdct, ch * n2 * 4);
-  if (ampmax_out) memcpy(ampmax_out, hs + o_amp, 4);
   if (posts) memcpy(posts, hs + o_posts, K * ch * VAMD_POSTS_STRIDE * 4);
   if (post_valid) memcpy(post_valid, hs + o_valid, K * ch * 4);
   if (nonzero) memcpy(nonzero, hs + o_nz, K * ch * 4);
@@ -2282,15 +2332,14 @@ int vamd_analyze_block_res(vamd_ctx *c, const float *const *pcm, int lW, int W, 
   if (r) return r;
   HIP_TRY(c, hipMemcpyAsync(hs + o_mdct, ds + o_mdct, total - o_mdct, hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
-  for (int i = 0; i < ch; i++)
-    if (hs[o_amp + 4 + i]) return fail(c, VAMD_EDOMAIN, "input outside the domain: a non-finite sample, or a signal ~1000 x over full scale");
+  if (ampmax_out) memcpy(ampmax_out, hs + o_amp, 4);  // (the block's ampmax comes out of its FFT: delivered with a domain error too)
+  if ((r = status_verdict(c, hs + o_amp + 4, (size_t)ch))) return r;
   if (mdct) memcpy(mdct, hs + o_mdct, (size_t)ch * n2 * 4);
   if (logmask) memcpy(logmask, hs + o_mask, (size_t)ch * n2 * 4);
   if (iwork) memcpy(iwork, hs + o_iwork, (size_t)ch * n2 * 4);
   if (posts) memcpy(posts, hs + o_posts, (size_t)ch * VAMD_POSTS_STRIDE * 4);
   if (post_valid) memcpy(post_valid, hs + o_valid, (size_t)ch * 4);
   if (nonzero) memcpy(nonzero, hs + o_nz, (size_t)ch * 4);
-  if (ampmax_out) memcpy(ampmax_out, hs + o_amp, 4);
   if (want_res) {
     if (res_count) memcpy(res_count, hs + o_rcnt, S * 8);
     if (res_class) memcpy(res_class, hs + o_rcls, S * VAMD_RES_CLASS_STRIDE * 4);
@@ -2314,6 +2363,10 @@ int vamd_encode_block(vamd_ctx *c, const float *const *pcm, int lW, int W, int n
   if (cap == 0)
     return fail(c, VAMD_EIMPL, "this mode's packets are not assembled on the GPU (its residue back-end is not covered)");
   if (packet_stride < 4) return fail(c, VAMD_EINVAL, "packet_stride too small");
+  if (c->K.fail_encode_after >= 0) {  // (test knob: a GPU failure under a block, for the binding's error path)
+    static std::atomic<long> calls{0};
+    if (calls.fetch_add(1) >= c->K.fail_encode_after) return fail(c, VAMD_EFAULT, "injected failure (VAMD_FAIL_ENCODE_AFTER)");
+  }
   const size_t ch = c->B.channels, n = c->B.bs[W], n2 = n / 2, K = managed ? VAMD_PACKETBLOBS : 1;
   const size_t row = cap < (size_t)packet_stride ? cap : ((size_t)packet_stride & ~(size_t)3);  // device row length
   auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
@@ -2341,7 +2394,7 @@ int vamd_encode_block(vamd_ctx *c, const float *const *pcm, int lW, int W, int n
   // device's address space): 16 KB in and a few hundred bytes out per block cross the link inside the first and the
   // last kernel instead of as two copy commands either side of them.  VAMD_STAGE_COPIES=1 brings the copies back
   // (measurement aid).
-  static const bool staged_copies = getenv("VAMD_STAGE_COPIES") != nullptr;
+  const bool staged_copies = c->K.stage_copies;
   unsigned char *io_base = ds;
   if (!staged_copies) {
     void *mapped = nullptr;
@@ -2383,9 +2436,8 @@ int vamd_encode_block(vamd_ctx *c, const float *const *pcm, int lW, int W, int n
   if (r) return r;
   if (staged_copies) HIP_TRY(c, hipMemcpyAsync(hs + o_amp, ds + o_amp, o_back - o_amp, hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
-  for (size_t i = 0; i < ch; i++)
-    if (hs[o_amp + 4 + i]) return fail(c, VAMD_EDOMAIN, "input outside the domain: a non-finite sample, or a signal ~1000 x over full scale");
-  if (ampmax_out) memcpy(ampmax_out, hs + o_amp, 4);
+  if (ampmax_out) memcpy(ampmax_out, hs + o_amp, 4);  // (the block's ampmax comes out of its FFT: delivered with a domain error too)
+  if ((r = status_verdict(c, hs + o_amp + 4, ch))) return r;
   memcpy(packet_bits, hs + o_bits, K * 4);
   for (size_t k = 0; k < K; k++) {
     size_t bytes = ((size_t)(packet_bits[k] > 0 ? packet_bits[k] : 0) + 7) / 8;
@@ -2447,7 +2499,7 @@ static int envelope_search_batch(vamd_ctx *c, const float *pcm, long stream_stri
     hipLaunchKernelGGL(k_env_spectrum, dim3((unsigned)(groups < cap ? groups : cap)), dim3(64 * VAMD_ENV_WAVES), lds, s, E,
                        ch, nstreams, nsteps, pcm, stream_stride, channel_stride, near, raw, bad);
   }
-  static const bool env_untiled = getenv("VAMD_ENV_UNTILED") != nullptr;  // (measurement aid: the thread-per-item forms)
+  const bool env_untiled = c->K.env_untiled;  // (measurement aid: the thread-per-item forms)
   const bool big = nstreams * nsteps > 65536 && !env_untiled;
   if (big) {
     const long tiles = (nsteps + VAMD_ENV_TJ - 1) / VAMD_ENV_TJ;
@@ -2486,6 +2538,10 @@ int vamd_envelope_search(vamd_ctx *c, const float *const *pcm, long nsteps, vamd
   if (nsteps < 0) return fail(c, VAMD_EINVAL, "negative step count");
   if (nsteps == 0) return VAMD_OK;
   if (!pcm || !state || !ret) return fail(c, VAMD_EINVAL, "null pcm / state / ret");
+  if (c->K.fail_envelope_after >= 0) {  // (test knob: a GPU failure under the detector, for the binding's error path)
+    static std::atomic<long> calls{0};
+    if (calls.fetch_add(1) >= c->K.fail_envelope_after) return fail(c, VAMD_EFAULT, "injected failure (VAMD_FAIL_ENVELOPE_AFTER)");
+  }
   const int ch = c->B.channels, n = c->B.env.mdct.n, step = c->B.env.searchstep;
   const long len = (nsteps - 1) * step + n;  // samples per channel the steps read
   // [pcm | state | bad (one word, zero on the way up) | ret]
@@ -2517,7 +2573,7 @@ int vamd_envelope_search(vamd_ctx *c, const float *const *pcm, long nsteps, vamd
   HIP_TRY(c, hipMemcpyAsync(hs + o_state, ds + o_state, total - o_state, hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
   if (*(const unsigned int *)(hs + o_bad))  // (the state is left as it was: the stream is over for this caller)
-    return fail(c, VAMD_EDOMAIN, "input outside the domain: a non-finite sample (include/vorbis_amd.h, Input domain)");
+    return fail(c, VAMD_ENONFINITE, "input outside the domain: a non-finite sample (include/vorbis_amd.h, Input domain)");
   memcpy(state, hs + o_state, sizeof(*state));
   memcpy(ret, hs + o_ret, (size_t)nsteps);
   return VAMD_OK;

@@ -158,9 +158,12 @@ struct DescP {
   int u_lW, u_nW, u_blocktype;
   float u_ampmax_in;
   unsigned long long *dbg;  // phase stopwatch slots (null = off), 16 per stage kernel
-  // input-domain report (include/vorbis_amd.h, "Input domain"): status[channel-block] = 1 where the block's spectral
-  // peak, before the 0 dB clamp of lib/mapping0.c:345, is above VAMD_INPUT_LIMIT_DB -- a non-finite sample or a signal
-  // ~1000 x over full scale; bad[0] counts such channel-blocks since vamd_input_status() last looked
+  // input-domain report (include/vorbis_amd.h, "Input domain"): status[channel-block] is a bit set --
+  // VAMD_STATUS_NONFINITE where the block's spectral peak, before the 0 dB clamp of lib/mapping0.c:345, is above
+  // VAMD_NONFINITE_DB (k_transform: a NaN / Inf sample, or finite ones so large that the reference's own fp32 spectrum
+  // overflows), VAMD_STATUS_RANGE where a quantised value of the channel is beyond the setup's proven integer bound
+  // (k_couple: Bound::qmax).  bad[0] counts flagged channel-blocks since vamd_input_status() last looked, bad[1]
+  // detector steps, bad[2] the non-finite ones among bad[0]
   unsigned char *status;
   unsigned int *bad;
   // blocks read in place (vamd_batch_io::pcm_src): block b, channel c at pcm + src[b] + c * cstride; null = packed
@@ -168,16 +171,19 @@ struct DescP {
   long cstride;
 };
 
-// The input domain (include/vorbis_amd.h).  Above this spectral peak (dB re a full-scale sine: the reference's logfft
-// scale, lib/mapping0.c:255-343) the reference's own INTEGER arithmetic leaves what C defines: its residue search sums
-// eight squared differences in an int (lib/res0.c:361-364: overflow from |value| ~ 16 384), noise_normalize squares
-// a quantised value in an int (lib/psy.c:985: from 46 341), and the float -> int conversions of the quantised
-// residue overflow from ~ +190 dB.  A quantised value is at most |mdct| / floor with floor <= 1, |mdct| stays
-// within ~1.6 x the FFT peak, and coupling can grow it by 2 * sqrt(2)^3 (three steps for the 5.1 left channel):
-// at +60 dB that is ~ 9 000, safely below the first of those limits.  Any NaN or Inf sample puts every FFT bin's
-// todB() above +330 dB (todB reads the float's BITS, lib/scales.h:43-51, so the dB value of a NaN is a large
-// finite number -- which is also why no NaN ever reaches the maximum in transform_logfft).
-#define VAMD_INPUT_LIMIT_DB 60.f
+// The input domain (include/vorbis_amd.h) has two edges.
+//  * NON-FINITE ARITHMETIC.  Any NaN or Inf sample puts every FFT bin's todB() above +330 dB (todB reads the float's
+//    BITS, lib/scales.h:43-51, so the dB value of a NaN is a large finite number -- which is also why no NaN ever
+//    reaches the maximum in transform_logfft); finite samples get there only from ~3e16 x full scale, where the
+//    reference's own fp32 power spectrum re*re + im*im overflows to Inf.  One compare per channel-block in k_transform.
+//  * THE REFERENCE'S INTEGERS.  Its residue search sums up to eight squared differences in an int
+//    (lib/res0.c:361-364), noise_normalize squares a quantised value in an int (lib/psy.c:985) and the quantised
+//    values themselves are float -> int conversions (:958-962): all defined by C while every quantised value stays
+//    within a bound that depends only on the setup's codebooks (derive_quant_limit, vamd_bind.h: ~10 000 for the
+//    libvorbisenc setups, i.e. spectra ~ +80 dB over full scale).  k_couple holds every value it writes against it.
+#define VAMD_NONFINITE_DB 330.f
+#define VAMD_STATUS_RANGE 1      // bits of status[]
+#define VAMD_STATUS_NONFINITE 2
 // the same test in the block-switching detector, on its unscaled 128-point spectra (todB(re^2+im^2)*.5): finite
 // samples inside the limit above stay below ~ +150 dB there, a NaN or Inf lands above +380
 #define VAMD_ENV_LIMIT_DB 300.f
