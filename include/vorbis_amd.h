@@ -100,6 +100,14 @@ int vamd_stage_ms(vamd_ctx *ctx, float *ms, int nstages, int *runs);
  * the slots accumulated so far are copied out first. */
 int vamd_debug_cycles(vamd_ctx *ctx, int enable, unsigned long long *out80);
 
+/* Measurement aid (no libvorbis counterpart): the shader clock while the chip is busy.  Launches, on a stream of the
+ * library's own and therefore beside whatever the context's stream is running, one wavefront that sleeps through
+ * `span_us` microseconds of the chip-wide 100 MHz clock and then adds the shader ticks that went by to acc3[0], the
+ * 100 MHz ticks to acc3[1] and 1 to acc3[2] (device memory, zeroed by the caller; asynchronous: read it after a device
+ * synchronise).  acc3[0] / acc3[1] x 100 MHz is the clock the vector units ran at -- what bench.py prices
+ * roofline.valu with, instead of a nominal figure. */
+int vamd_clock_probe(vamd_ctx *ctx, unsigned long long *acc3, int span_us);
+
 /* Calibration aid for counter passes (no libvorbis counterpart): copy `bytes` (a multiple of 16) from `src` to `dst`
  * (device pointers) with the library's own kernel k_calib_copy, 16 bytes per lane -- exactly `bytes` read and
  * `bytes` written under a name a profile can find, so that FETCH_SIZE / WRITE_SIZE are scaled by a measured factor
@@ -203,15 +211,23 @@ const char *vamd_config_string(const vamd_ctx *ctx);
  *       power spectrum overflows to Inf (lib/mapping0.c:323-343).  Test: the block's spectral peak on the reference's
  *       logfft scale (0 dB = a full-scale sine, before the clamp of :345) above +330 dB -- any NaN / Inf puts it
  *       there, todB() reads a float's bits -- one compare per channel-block.  VAMD_STATUS_NONFINITE.
- *   (2) the reference's integers.  Its residue search sums up to eight squared differences in an `int`
- *       (lib/res0.c:361-364), noise normalisation squares a quantised value in an `int` (lib/psy.c:985), and the
- *       quantised values are float -> int conversions: all of it is defined by C exactly while every quantised value
- *       of the block stays within a bound Q that depends only on the setup's codebooks -- 16 383 less the lattice reach
- *       of a residue class's cascade; vorbis_amd/csrc/vamd_bind.h: derive_quant_limit() holds the proof, and
- *       vamd_quant_limit() returns Q (~10 000 for the libvorbisenc setups: spectra ~ +80 dB over full scale, e.g.
- *       un-normalised int16-scale floats are beyond it).  Test: every value the coupling stage writes is held against
- *       Q (level FULL; the levels below it form no integers).  VAMD_STATUS_RANGE.  Below Q everything is exact --
- *       the old "+60 dB" line of ABI 7 was a sufficient margin, not the edge; the edge is now the arithmetic's own.
+ *   (2) the reference's integers.  Its quantised values are float -> int conversions (lib/psy.c:958-962): defined by C
+ *       below 2^31 (VAMD_QUANT_LIMIT_INT).  Where noise normalisation is at work (q < 0.4 at 44.1 kHz; bins from
+ *       normal_start on) it squares them in an `int` (:985): defined up to VAMD_QUANT_LIMIT_SQUARE = 46 340.  Its
+ *       residue search sums up to eight squared differences in an `int` (lib/res0.c:361-364): defined while every
+ *       value AT A POSITION THE RESIDUE CODES stays within a bound Q that depends only on the setup's codebooks --
+ *       floor(sqrt(INT_MAX / dim)) less the lattice reach of the last residue class's cascade:
+ *       vorbis_amd/csrc/vamd_bind.h, derive_quant_limit(), holds the proof, and vamd_quant_limit() returns Q with the
+ *       bins it holds at (13 000 - 32 000 for the libvorbisenc setups: spectra ~ +85 ... +90 dB over full scale;
+ *       un-normalised int16-scale floats are beyond it).  Tests: the coupling stage holds every value it writes
+ *       against the first two bounds (level FULL; the levels below it form no integers); the residue search holds
+ *       every value it loads from a coded position against the third (wherever it runs: res_* or packets asked for --
+ *       a caller that takes `iwork` to a residue coder of its own makes that test itself, as the binding does).
+ *       VAMD_STATUS_RANGE.  Up to the bounds everything is exact -- the "+60 dB" line of ABI 7 was a sufficient
+ *       margin, not the edge; the edge is now the arithmetic's own.  (Ordinary input gets nowhere near Q where a
+ *       codebook is searched; elsewhere it does: the reference's own test signal, a full-scale sine, quantises to
+ *       ~66 000 at q 0.85 in a 5.1 stream's LFE channel, whose floor and residue end at bin 12 -- coded by nobody, squared
+ *       by nobody, and the reference's defined result: tests/test_reference_matrix.py.)
  *
  *   - the host-pointer calls (vamd_analyze_block*, vamd_encode_block, vamd_batcher_encode_block) return
  *     VAMD_ENONFINITE for (1), VAMD_EDOMAIN for (2) (their argument errors stay VAMD_EINVAL); *ampmax_out is
@@ -229,8 +245,12 @@ const char *vamd_config_string(const vamd_ctx *ctx);
  *     unaffected. */
 #define VAMD_STATUS_RANGE     1 /* bits of status[] */
 #define VAMD_STATUS_NONFINITE 2
-/* the bound Q of (2) for size class W */
-int vamd_quant_limit(const vamd_ctx *ctx, int W);
+/* the bounds of (2) for size class W and channel `channel` (any pointer may be NULL): the return value Q holds at the
+ * bins [*first_bin, *end_bin) of the channel that its residue codes; VAMD_QUANT_LIMIT_SQUARE at the bins from
+ * *square_bin on (n/2: nowhere -- noise normalisation is off for this size class); VAMD_QUANT_LIMIT_INT everywhere. */
+#define VAMD_QUANT_LIMIT_SQUARE 46340
+#define VAMD_QUANT_LIMIT_INT 0x7fffff80
+int vamd_quant_limit(const vamd_ctx *ctx, int W, int channel, int *first_bin, int *end_bin, int *square_bin);
 int vamd_input_status(vamd_ctx *ctx, long *bad_channel_blocks, long *bad_detector_steps);
 
 #define VAMD_RES_CLASS_STRIDE 512 /* ints per block and submap in res_class[] (>= classified partitions) */

@@ -406,6 +406,18 @@ static int mapping0_forward_vamd(vorbis_block *vb) {
     ret = vamd_analyze_block(ctx, (const float *const *)vb->pcm, vb->lW, vb->W, vb->nW, vbi->blocktype, vbi->ampmax,
                              mdct, NULL, posts, post_valid, iwork, nonzero, &ampmax_out);
   if (ret) return vamd_domain_verdict(vb, ret, ampmax_out);
+  /* the residue coder below is the host's own: the input domain's test on the values it will search (vorbis_amd.h,
+     "Input domain" (2)) is then the caller's -- every quantised value at a bin the residue codes within the setup's bound */
+  for (k = 0; k < nk; k++) {
+    int c;
+    for (c = 0; c < ch; c++) {
+      int lo = 0, hi = 0, j;
+      const int q = vamd_quant_limit(ctx, vb->W, c, &lo, &hi, NULL);
+      const int *v = iwork + ((long)k * ch + c) * (n / 2);
+      for (j = lo; j < hi; j++)
+        if (v[j] > q || v[j] < -q) return vamd_domain_verdict(vb, VAMD_EDOMAIN, ampmax_out);
+    }
+  }
   vbi->ampmax = ampmax_out; /* lib/mapping0.c:576 */
   for (k = 0; k < nk; k++) {
     ret = vamd_write_packet(vb, managed ? k : PACKETBLOBS / 2, posts + k * ch * VAMD_POSTS_STRIDE, post_valid + k * ch,

@@ -25,6 +25,7 @@
 #define WAVE_FOR(i, count) for (int i = LANE; i < (count); i += NLANES)
 #define LANE_BINS(k, i, i0, KPL, n) for (int k = 0, i = (i0); k < (KPL) && i < (n); k++, i++)
 #define TEAM_FOR(i, count) for (int i = 0; i < (count); i++)
+#define TEAM_RANGE(i, lo, hi) for (int i = (lo); i < (hi); i++)
 #define TEAM_SYNC() ((void)0)
 #define TEAM_FIRST_WAVE 1
 #define TEAM_LEADER 1

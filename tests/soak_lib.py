@@ -109,13 +109,13 @@ def run(NB=300, managed=True, log=print):
             if flagged != (int((st != 0).sum()), 0):   # the two doors agree
                 bad += 1
                 log("FLAGGED count differs", (ch, rate, q, coupled), "W", W, flagged, int((st != 0).sum()))
-            qmax = an_q[W] = an.quant_limit(W)
+            an_q[W] = min(an.quant_limit(W, c)[0] for c in range(ch))
             rows, bits, amps = o["packets"].cpu().numpy(), o["packet_bits"].cpu().numpy(), o["ampmax_out"].cpu().numpy()
             for k in range(nb):
                 a = e.tap_block(x[k], int(lW[k]), W, int(nW[k]), int(bt[k]), float(amp_in[k]))
                 # every soak signal is finite; a block is outside the domain exactly where the reference's own quantised
                 # values pass the setup's bound (kinds 12 / 13 get there now and then) -- channel by channel
-                want_st = (np.abs(a["iwork"].astype(np.int64)).max(axis=1) > qmax).astype(np.uint8) * vorbis_amd.api.STATUS_RANGE
+                want_st = an.beyond_quant_limit(W, a["iwork"])
                 total += 1
                 if not np.array_equal(st[k], want_st):
                     bad += 1
@@ -154,12 +154,11 @@ def run(NB=300, managed=True, log=print):
             torch.cuda.synchronize()
             st = o["status"].cpu().numpy()
             an.input_status()
-            qmax = an.quant_limit(W)
             rows, bits = o["m_packets"].cpu().numpy(), o["m_packet_bits"].cpu().numpy()
             for k in range(nb):
                 a = e.tap_block_managed(x[k], int(lW[k]), W, int(nW[k]), 1 if W else 0)
                 # (a channel-block is beyond the bound when ANY of its fifteen candidates' values is)
-                want_st = (np.abs(a["m_iwork"].astype(np.int64)).max(axis=(0, 2)) > qmax).astype(np.uint8) * vorbis_amd.api.STATUS_RANGE
+                want_st = np.bitwise_or.reduce([an.beyond_quant_limit(W, a["m_iwork"][j]) for j in range(15)])
                 total += 1
                 if not np.array_equal(st[k], want_st):
                     bad += 1
@@ -236,7 +235,6 @@ def run_hostile(nb=48, log=print):
         for W in (1, 0):
             n = e.blocksize(W)
             x, lW, nW, want, loud = hostile_batch(rng, nb, ch, n, W)
-            qmax = an.quant_limit(W)
             o = an.analyze(torch.from_numpy(x).cuda(), W=W, lW=lW, nW=nW, blocktype=1 if W else 0,
                            want=("ampmax_out", "packets", "packet_bits", "status"))
             torch.cuda.synchronize()
@@ -251,15 +249,18 @@ def run_hostile(nb=48, log=print):
             if counted != (int((st != 0).sum()), 0) or an.last_input_code != vorbis_amd.VAMD_ENONFINITE or an.input_status() != (0, 0):
                 bad += 1
                 log("HOSTILE count differs", (ch, rate, q), "W", W, counted, int((st != 0).sum()), an.last_input_code)
+            beyond = set()   # the finite blocks the reference's own values put past a bound (the loud ones, if any)
             for k in range(nb):
                 if want[k].any():
                     continue   # (deterministic but unspecified; the range bit may come on top where saturated values spread by coupling)
                 a = e.tap_block(x[k], int(lW[k]), W, int(nW[k]), 1 if W else 0, -9999.0)
                 # the range bit: exactly the channels whose quantised values (the reference's own, defined up to here)
                 # pass the setup's bound
-                want_r = (np.abs(a["iwork"].astype(np.int64)).max(axis=1) > qmax).astype(np.uint8) * RANGE
+                want_r = an.beyond_quant_limit(W, a["iwork"])
                 checks += 1
-                if not np.array_equal(st[k], want_r) or (k in loud) != bool(want_r.any()):
+                if want_r.any():
+                    beyond.add(k)
+                if not np.array_equal(st[k], want_r) or (want_r.any() and k not in loud):
                     bad += 1
                     log("HOSTILE range status differs", (ch, rate, q), "W", W, "block", k, st[k].tolist(), want_r.tolist())
                 checks += 1
@@ -272,6 +273,10 @@ def run_hostile(nb=48, log=print):
                 if vorbis_amd.packet_bytes(rows[k], bits[k]) != a["packet"]:
                     bad += 1
                     log("HOSTILE clean block differs", (ch, rate, q), "W", W, "block", k)
+            checks += 1
+            if (ch, W) == (2, 1) and not beyond:      # (the loud kind is there to cross the bound: in stereo long blocks it must)
+                bad += 1
+                log("HOSTILE no block crossed the integer bound", (ch, rate, q), "W", W)
             # the host-pointer entry point says so itself, and which of the two it was
             for k in [0, 1, 3] + loud[:1]:
                 checks += 1
@@ -280,7 +285,7 @@ def run_hostile(nb=48, log=print):
                     an.analyze_block(x[k], int(lW[k]), W, int(nW[k]), 1 if W else 0, -9999.0)
                 except VamdError as err:
                     code = err.code
-                expect = vorbis_amd.VAMD_ENONFINITE if want[k].any() else (vorbis_amd.VAMD_EDOMAIN if k in loud else 0)
+                expect = vorbis_amd.VAMD_ENONFINITE if want[k].any() else (vorbis_amd.VAMD_EDOMAIN if k in beyond else 0)
                 if code != expect:
                     bad += 1
                     log("HOSTILE analyze_block verdict wrong", (ch, rate, q), "W", W, "block", k, code, expect)

@@ -5,7 +5,7 @@ cd $R
 python -c "import bench; print('# source_hash', bench.source_hash())"
 for w in c4 c5 c3 c2; do
   for rep in 1 2 3; do
-    python bench.py --workload $w --no-cpu-baseline --no-neighbours --no-parity-sample 2>/dev/null | python -c "
+    python bench.py --workload $w --no-cpu-baseline --no-neighbours --no-workloads --no-parity-sample 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 print('$w', 'value', round(d['value']), d['unit'], ' ms_per_step', round(d['ms_per_step'],3), ' frac', round(d['roofline']['frac'],4))"

@@ -9,7 +9,7 @@ O=$R/gpurun_out/profile
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 NB=${1:-131072}
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/kt_bench -o kt -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-neighbours > $O/bench_under_rocprof.json 2> $O/kt_bench.log
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/kt_bench -o kt -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-neighbours --no-workloads > $O/bench_under_rocprof.json 2> $O/kt_bench.log
 python $R/tools/prof_summary.py kt $O/kt_bench/kt_results.db > $O/kernel_trace_stats.txt 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/kt_c5 -o kt -- python $R/bench.py --workload c5 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_c5_under_rocprof.json 2> $O/kt_c5.log
 python $R/tools/prof_summary.py kt $O/kt_c5/kt_results.db > $O/kernel_trace_stats_c5.txt 2>&1

@@ -9,13 +9,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 VAMD_OK, VAMD_EFAULT, VAMD_EIMPL, VAMD_EINVAL, VAMD_EVERSION, VAMD_EDOMAIN, VAMD_ENONFINITE = 0, -129, -130, -131, -134, -140, -141
 ABI_VERSION = 8             # VAMD_ABI_VERSION of the header this mirror was written against
+QUANT_LIMIT_SQUARE, QUANT_LIMIT_INT = 46340, 0x7fffff80
 STATUS_RANGE, STATUS_NONFINITE = 1, 2   # bits of the `status` output (vorbis_amd.h, "Input domain")
 LEVEL_TRANSFORM, LEVEL_PSY, LEVEL_FULL = 1, 2, 3
 POSTS_STRIDE = 32
 BLOCKTYPE_IMPULSE, BLOCKTYPE_PADDING, BLOCKTYPE_TRANSITION, BLOCKTYPE_LONG = 0, 1, 0, 1
 
 # every symbol include/vorbis_amd.h declares
-EXPORTED_SYMBOLS = ["vamd_create_abi", "vamd_quant_limit", "vamd_config_string", "vamd_destroy", "vamd_last_error", "vamd_set_stream", "vamd_reserve",
+EXPORTED_SYMBOLS = ["vamd_create_abi", "vamd_clock_probe", "vamd_quant_limit", "vamd_config_string", "vamd_destroy", "vamd_last_error", "vamd_set_stream", "vamd_reserve",
                     "vamd_channels", "vamd_blocksize", "vamd_posts", "vamd_mdct_forward_batch",
                     "vamd_analyze_batch", "vamd_analyze_stream", "vamd_analyze_block", "vamd_profile",
                     "vamd_stage_ms", "vamd_debug_cycles", "vamd_analyze_stream_mixed", "vamd_envelope_search_batch",
@@ -94,7 +95,8 @@ def load_library():
     import torch  # noqa: F401
     L = C.CDLL(path)
     L.vamd_create_abi.argtypes = [C.POINTER(_vp), _vp, C.c_size_t, C.c_int, C.c_int]
-    L.vamd_quant_limit.argtypes = [_vp, C.c_int]
+    L.vamd_quant_limit.argtypes = [_vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.vamd_clock_probe.argtypes = [_vp, _vp, C.c_int]
     L.vamd_config_string.argtypes = [_vp]
     L.vamd_config_string.restype = C.c_char_p
     L.vamd_destroy.argtypes = [_vp]
@@ -223,6 +225,12 @@ class Analyzer:
         self._check(self.L.vamd_stage_ms(self.h, ms, 8, C.byref(runs)))
         return dict(zip(self.STAGES, [float(x) for x in ms])), runs.value
 
+    def clock_probe(self, acc, span_us=200):
+        """vamd_clock_probe(): one probe wave beside the running work; `acc` = a zeroed cuda int64 tensor of 3 (shader
+        ticks, 100 MHz ticks, probes).  After a synchronise: acc[0] / acc[1] * 0.1 = the shader clock in GHz."""
+        self._need_tensor(acc, self.torch.int64, "acc", numel=3)
+        self._check(self.L.vamd_clock_probe(self.h, _vp(acc.data_ptr()), int(span_us)))
+
     def debug_cycles(self, enable=True, read=False):
         """Arm/disarm the in-kernel phase stopwatch; with read=True returns the 5x16 tick sums first."""
         out = np.zeros(80, dtype=np.uint64)
@@ -254,9 +262,30 @@ class Analyzer:
         """vamd_config_string(): the environment knobs this context read at vamd_create, as "NAME=value" words."""
         return self.L.vamd_config_string(self.h).decode()
 
-    def quant_limit(self, W):
-        """vamd_quant_limit(): the largest |quantised value| up to which the reference's integer arithmetic is defined."""
-        return int(self.L.vamd_quant_limit(self.h, W))
+    def quant_limit(self, W, channel=0):
+        """vamd_quant_limit(): (Q, first_bin, end_bin, square_bin) -- Q bounds |quantised value| of `channel` at the bins
+        [first_bin, end_bin) its residue codes, QUANT_LIMIT_SQUARE those from square_bin on (noise normalisation),
+        QUANT_LIMIT_INT all of them: up to there the reference's integer arithmetic is defined."""
+        a, b, sq = C.c_int(0), C.c_int(0), C.c_int(0)
+        q = int(self.L.vamd_quant_limit(self.h, W, channel, C.byref(a), C.byref(b), C.byref(sq)))
+        self._need(q >= 0, "vamd_quant_limit(%d, %d)" % (W, channel))
+        return q, a.value, b.value, sq.value
+
+    def beyond_quant_limit(self, W, iwork, residue=True):
+        """Which channels of a block's quantised values iwork[ch][n/2] (a numpy array; e.g. the reference's own) lie
+        outside the input domain's integer edge: uint8 [ch] of STATUS_RANGE / 0 -- what `status` must say of them.
+        residue=False: the call ran no residue search (no res_* / packets asked for), so only the coupling stage's
+        bounds were tested."""
+        out = np.zeros(iwork.shape[0], np.uint8)
+        for c in range(iwork.shape[0]):
+            q, lo, hi, sq = self.quant_limit(W, c)
+            v = np.abs(iwork[c].astype(np.int64))
+            lim = np.full(v.shape, QUANT_LIMIT_INT, np.int64)
+            lim[sq:] = QUANT_LIMIT_SQUARE
+            if residue:
+                lim[lo:hi] = np.minimum(lim[lo:hi], q)
+            out[c] = STATUS_RANGE if (v > lim).any() else 0
+        return out
 
     # mdct_forward(lookup, in, out) batched -- BASELINE config 2
     def mdct_forward(self, W, frames, out=None):

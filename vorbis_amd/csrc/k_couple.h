@@ -303,11 +303,14 @@ VAMD_DEV void couple_bin_sure(ChanBin &M, ChanBin &A, int &iM, int &iA, int b, c
   M.re = re, M.qe = qe, M.fg = fg;
 }
 
-// The input domain's integer edge (include/vorbis_amd.h, vamd_params.h): a lane's running minimum and maximum of the
-// quantised values it writes for one channel.  The block is inside the domain while every value is within the
-// setup's bound (Bound::qmax: up to there lib/res0.c:361-364, lib/psy.c:985 and the float -> int conversions of
-// :958-962 are defined by C); an out-of-range float converts to INT_MIN / INT_MAX here, which the bound catches too.
-// One three-operand minimum and one maximum per pair of values.
+// The input domain's integer edge, first half (include/vorbis_amd.h, vamd_params.h): every value this stage writes is a
+// float -> int conversion (lib/psy.c:958-962: defined below 2^31, VAMD_QUANT_LIMIT_INT), and where noise normalisation is
+// at work -- from bin `nstart` on -- it is squared in an int (:985: defined up to VAMD_QUANT_LIMIT_SQUARE).  Held against
+// the FINAL values: in a coupling step the magnitude keeps the larger of its two inputs and the angle their difference
+// (:1141-1166), so no value of a block's first quantisation exceeds the largest final one, and a block none of whose
+// channels is flagged has met neither hazard.  (An out-of-range float converts to INT_MIN / INT_MAX here, which the
+// bound catches.)  The second half -- the residue search's own bound on the positions it codes -- is k_residue's.
+// A lane's running extremes for one channel: one three-operand minimum and one maximum per pair of values.
 struct QuantSpan {
   int lo = 0, hi = 0;
   VAMD_MEM void take(int v) {
@@ -317,18 +320,19 @@ struct QuantSpan {
   VAMD_MEM void take4(const int *v) {  // (the compiler pairs these into v_min3_i32 / v_max3_i32)
     for (int c = 0; c < 4; c++) take(v[c]);
   }
-  VAMD_MEM bool beyond(int qmax) const { return hi > qmax || lo < -qmax; }
+  VAMD_MEM bool beyond(int lim) const { return hi > lim || lo < -lim; }
 };
 // The ordered paths (noise normalisation's sort, layouts beyond stereo) leave their final values in HBM after a
 // wave-wide sync: one more pass over them, a lane's share of every channel (their time is the ordered walks').
-// In a coupling step the magnitude keeps the larger of its two inputs and the angle their difference
-// (lib/psy.c:1141-1166), so no intermediate value exceeds the largest final one.
-VAMD_DEV unsigned quant_span_reread(int ch, int n2, int *const *iwork, int qmax) {
+VAMD_DEV unsigned quant_span_reread(int ch, int n2, int *const *iwork, int nstart) {
   unsigned over = 0;
   for (int k = 0; k < ch; k++) {
-    QuantSpan sp;
-    WAVE_FOR(b, n2) sp.take(iwork[k][b]);
-    if (sp.beyond(qmax)) over |= 1u << k;
+    QuantSpan below, from;
+    WAVE_FOR(b, n2) {
+      const int v = iwork[k][b];
+      if (b < nstart) below.take(v); else from.take(v);
+    }
+    if (below.beyond(VAMD_QUANT_LIMIT_INT) || from.beyond(VAMD_QUANT_LIMIT_SQUARE)) over |= 1u << k;
   }
   return over;
 }
@@ -345,9 +349,9 @@ VAMD_DEV void couple_quads(const CoupleP &C, int n2, const float *__restrict__ m
   const int nzM = ALL ? 1 : nzM_in, nzA = ALL ? 1 : nzA_in;
   const bool two = ALL ? true : two_in, coupled = ALL ? true : coupled_in;
   // (two quads in flight, not WAVE_FOR's four: at four the kernel needs 110 VGPRs and the SIMD holds four waves)
-#pragma unroll 1
   // (the quads are dealt over the whole TEAM: for a handful of blocks the launch gives a block four waves, which
   // brings a lone block's 18 us down to 6)
+#pragma unroll 1
   TEAM_FOR(q, n2 >> 2) {
     float m0[4], m1[4];
     int l0[4], l1[4], o0[4], o1[4];
@@ -411,12 +415,12 @@ VAMD_DEV void couple_quads(const CoupleP &C, int n2, const float *__restrict__ m
 // (one or two channels, at most one coupling step: every stereo and mono setup)
 // NORM = false: the caller knows noise normalisation is inactive for this size class (the launch picks the
 // instantiation): the ordered general path below is then not even compiled in, which halves the registers.
-//   qmax / over  the input domain's integer edge (QuantSpan): bit k of the returned `over` is set in a lane that wrote a
-//                value beyond +-qmax for channel k (the caller ORs the lanes)
+//   over  the input domain's integer edge (QuantSpan): bit k of the returned `over` is set in a lane that wrote a value
+//         beyond its bound (QuantSpan above) for channel k (the caller ORs the lanes)
 template <bool NORM = true>
 VAMD_DEV void couple_block(const CoupleP &C_set, const PsyP &P, int n2, const float *const *mdct,
                            const ilog_t *const *ilogmask, int *const *iwork, int *nonzero, const CoupleLds &L,
-                           PhaseClock &pc, float band = VAMD_COUPLE_BAND, int qmax = 0x7fffffff, unsigned *over = nullptr) {
+                           PhaseClock &pc, float band = VAMD_COUPLE_BAND, unsigned *over = nullptr) {
   const CoupleP C = C_set;  // (by value: the fields in scalar registers, not behind the set's run-time index)
   const int ch = C.ch;
   const int partition = P.normal_p ? P.normal_partition : 16;
@@ -439,7 +443,8 @@ VAMD_DEV void couple_block(const CoupleP &C_set, const PsyP &P, int n2, const fl
     else
       couple_quads<false>(C, n2, mdct[Mi], mdct[Ai], ilogmask[Mi], ilogmask[Ai], iwork[Mi], iwork[Ai], nz[Mi], nz[Ai],
                           ch > 1, coupled, nstart, band, spM, spA);
-    if (over) *over = (spM.beyond(qmax) ? 1u << Mi : 0u) | (ch > 1 && spA.beyond(qmax) ? 1u << Ai : 0u);
+    // (this path runs where noise normalisation is not at work: no value is squared)
+    if (over) *over = (spM.beyond(VAMD_QUANT_LIMIT_INT) ? 1u << Mi : 0u) | (ch > 1 && spA.beyond(VAMD_QUANT_LIMIT_INT) ? 1u << Ai : 0u);
     pc.mark(0);
     if (coupled) nz[C.mag[0]] = nz[C.ang[0]] = 1;  // lib/psy.c:1204-1212
     for (int k = 0; k < ch; k++) nonzero[k] = nz[k];
@@ -483,7 +488,7 @@ VAMD_DEV void couple_block(const CoupleP &C_set, const PsyP &P, int n2, const fl
     WAVE_SYNC_GLOBAL();
     nz[Mi] = nz[Ai] = 1;  // lib/psy.c:1204-1212
   }
-  if (over) *over = quant_span_reread(ch, n2, iwork, qmax);
+  if (over) *over = quant_span_reread(ch, n2, iwork, nstart);
   for (int k = 0; k < ch; k++) nonzero[k] = nz[k];
   pc.mark(1);
 }
@@ -506,7 +511,7 @@ struct CoupleState {
 
 VAMD_DEV void couple_block_general(const CoupleP &C, const PsyP &P, int n2, const float *const *mdct,
                                    const ilog_t *const *ilogmask, int *const *iwork, int *nonzero, const CoupleLds &L,
-                                   const CoupleState &S, PhaseClock &pc, int qmax = 0x7fffffff, unsigned *over = nullptr) {
+                                   const CoupleState &S, PhaseClock &pc, unsigned *over = nullptr) {
   const int ch = C.ch, steps = C.coupling_steps;
   const int partition = P.normal_p ? P.normal_partition : 16;
   const int nstart = P.normal_p ? P.normal_start : 0x7fffffff;
@@ -572,7 +577,7 @@ VAMD_DEV void couple_block_general(const CoupleP &C, const PsyP &P, int n2, cons
     pend[Ai] = 0;
   }
   pc.mark(1);
-  if (over) *over = quant_span_reread(ch, n2, iwork, qmax);
+  if (over) *over = quant_span_reread(ch, n2, iwork, nstart);
   for (int t = 0; t < steps; t++)  // lib/psy.c:1204-1212, in step order
     if (nz[C.mag[t]] || nz[C.ang[t]]) nz[C.mag[t]] = nz[C.ang[t]] = 1;
   for (int k = 0; k < ch; k++) nonzero[k] = nz[k];

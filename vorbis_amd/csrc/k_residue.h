@@ -124,13 +124,18 @@ VAMD_DEV int residue_offsets(const ResP &R, int partvals, const int *cls, int *o
 //   class_out  HBM [VAMD_RES_CLASS_STRIDE]; entries_out HBM [R.cap]; count_out HBM [2] = {classes, entries}
 //   books_out  HBM [R.cap] or null: the book each entry belongs to, for the packet stage (k_pack.h: its fields then
 //              need no search for the (stage, slot) pair they come from)
+//   over       (optional) the input domain's integer edge, second half (include/vorbis_amd.h; the first is k_couple's):
+//              bit c is set in a lane that loaded, for the bundle's channel c, a value the search below will see --
+//              one at a position in [begin, end) -- beyond R.qmax, the bound up to which local_book_besterror's
+//              integer arithmetic is defined by C for this residue's codebooks (derive_quant_limit, vamd_bind.h)
 // A type-2 residue codes the bundle's channels interleaved as ONE stream (res2_class / res2_forward);
 // type 1 codes every channel whose floor is not all zero as a stream of its own (res1_class /
 // res1_forward, lib/res0.c:729-762), and _01forward then walks (stage, partition, stream, vector): a
 // "slot" below is a (partition, stream) pair, numbered partition-major.
 VAMD_DEV void residue_block(const ResP &R, int n2, const int *const *iwork, const int *nonzero, int *work, int *cls, int *off,
                             int *info, int *__restrict__ class_out, unsigned short *__restrict__ entries_out,
-                            int *__restrict__ count_out, PhaseClock &pc, unsigned char *__restrict__ books_out = nullptr) {
+                            int *__restrict__ count_out, PhaseClock &pc, unsigned char *__restrict__ books_out = nullptr,
+                            unsigned *over = nullptr) {
   const vamd_residue_tab &t = *R.tab;
   const int ch = R.bundle, spp = t.grouping, nparts = t.partitions, partvals = R.partvals, stages = t.stages;
   int ns = 0;  // streams
@@ -150,15 +155,27 @@ VAMD_DEV void residue_block(const ResP &R, int n2, const int *const *iwork, cons
   }
   if (t.type == 2) {
     // the interleaved work vector of res2_forward (:791-797)
+    unsigned bad = 0;
     TEAM_FOR(j, n2)
-      for (int c = 0; c < ch; c++) work[j * ch + c] = iwork[c][j];
+      for (int c = 0; c < ch; c++) {
+        const int v = iwork[c][j], i = j * ch + c;
+        work[i] = v;
+        if (i >= t.begin && i < t.end && (v > R.qmax || v < -R.qmax)) bad |= 1u << c;
+      }
+    if (over) *over = bad;
   } else {
     int sidx = 0;  // coded channels, packed in order (:738-739)
+    unsigned bad = 0;
     for (int c = 0; c < ch; c++)
       if (nonzero[c]) {
-        TEAM_FOR(j, n2) work[sidx * n2 + j] = iwork[c][j];
+        TEAM_FOR(j, n2) {
+          const int v = iwork[c][j];
+          work[sidx * n2 + j] = v;
+          if (j >= t.begin && j < t.end && (v > R.qmax || v < -R.qmax)) bad |= 1u << c;
+        }
         sidx++;
       }
+    if (over) *over = bad;
   }
   TEAM_SYNC();
   const int slots = partvals * ns;

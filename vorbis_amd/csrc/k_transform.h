@@ -24,6 +24,12 @@
 
 namespace vamd {
 
+// the fold of the size-specialised transform reads whole quads, one trip in flight (mdct_forward_wave); GPU only: the
+// one-lane test build keeps the plain loop
+#ifndef VAMD_XF_FOLD_QUADS
+#define VAMD_XF_FOLD_QUADS 0  // measured round 5 on this build: 1.513 against 1.482 ms (profiles/r05_xf_variants.txt); kept as a variant
+#endif
+
 #define VAMD_XF_A_FLOATS(n) (((n) + ((n) >> 5) + 4 + 3) & ~3)
 #define VAMD_XF_B_FLOATS(n) (((n) + ((n) >> 4) + 4 + 3) & ~3)
 
@@ -228,7 +234,10 @@ VAMD_DEV void fold_fetch(FoldOps<LOGN> &o, const float *in) {
 // FOLD_AHEAD: the block is read straight out of HBM (k_mdct_only) -- every fold operand of the lane is fetched before the
 // first is used.  Written as one loop the fold waits for its four words eight times over (n = 2048: a frame spent 10 of
 // its 13 us there, and the kernel sat at the bytes its sixteen waves per CU keep in flight: 3.8 TB/s); the three regimes
-// change at multiples of a wave's stride for n >= 512, so which quarters a trip folds is known when it is compiled.
+// change at the pairs n/16 and 3n/16, multiples of a wave's stride of 64 for n >= 1024, so which quarters a trip folds is
+// known when it is compiled.  (Round 5: the form used to be taken for n = 512 too, where the regimes change in the
+// middle of a trip -- found by the whole-quad variant below failing the 22 kHz short blocks; no shipped path reached
+// k_mdct_only at 512, and tests/test_gpu_parity.py::test_mdct_forward_every_size now does.)
 template <int LOGS = 0, int LOGN = 0, class Team = WaveTeam, bool PACKED = false, bool FOLD_AHEAD = false>
 VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in0, float *w0, float *out0, PhaseClock &pc,
                                 int in_stride = 0, int w_stride = 0, int out_stride = 0, const Team &tm = Team(),
@@ -250,7 +259,7 @@ VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in0, float *w0, fl
   // Pair p writes w2[2p], w2[2p+1]; the three loops differ in which input
   // quarter is folded with which sign.  x0[0],x0[2] / x1[0],x1[2] of the reference
   // are the .x,.z / .y,.w lanes of two aligned quads of the input.
-  if constexpr (FOLD_AHEAD && LOGN >= 9 && LOGN <= 11 && LOGS == 0) {  // (n = 4096: 64 operands per lane would spill)
+  if constexpr (FOLD_AHEAD && LOGN >= 10 && LOGN <= 11 && LOGS == 0) {  // (n = 4096: 64 operands per lane would spill; n = 512: below)
     // every operand of the lane first, then the arithmetic (`ahead`: a caller that fetched them earlier; `in_next`: the
     // block whose operands it wants requested as soon as these are consumed)
     constexpr int NT = FoldOps<LOGN>::NT;
@@ -278,6 +287,43 @@ VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in0, float *w0, fl
       *(F2 *)(w2 + VAMD_PW(2 * p)) = o;
     }
     if (in_next) fold_fetch<LOGN>(*ahead, in_next);
+  } else if constexpr (VAMD_XF_FOLD_QUADS && LOGN >= 10 && LOGS == 0) {  // (n = 512: the regimes change inside a wave's trip)
+    // The same fold out of LDS with WHOLE quads (round 5; measured round 4, profiles/r04_xf_phases.txt): a pair needs two
+    // words of each of its two quads, and the compiler narrows such a read to ds_read2_b32 -- lanes 16 bytes apart on a
+    // 4-byte access are a four-way bank conflict (two thirds of the fold's LDS cycles).  All four words through an
+    // opaque use make it a ds_read_b128, which the LDS serves 16 lanes at a time from all banks; one trip in flight
+    // (four would want 32 registers the kernel does not have: 7 spills, +2 %), the regimes known per trip as in the
+    // FOLD_AHEAD form.  Conflicts 30.6 -> 23.1 % of the kernel's LDS cycles; time 1.482 -> 1.513 ms (round 5) -- not the default.
+    constexpr int NT = (1 << LOGN) / 4 / 64;
+    float *w2 = w0 + n2;
+#pragma unroll 1
+    for (int k = 0; k < NT; k++) {
+      const int p = LANE + 64 * k;
+      const F2 T = *(const F2 *)(trig + n2 - 2 * (p + 1));
+      const float *q0, *q1;
+      const int regime = 2 * (64 * k) < n8 ? 0 : (2 * (64 * k) < n2 - n8 ? 1 : 2);  // (wave-uniform: n8 is a multiple of 128 for n >= 1024)
+      if (regime == 0) {
+        q0 = in0 + n2 + n4 - 4 * (p + 1), q1 = in0 + n2 + n4 + 4 * p;
+      } else if (regime == 1) {
+        q0 = in0 + n2 + n4 - 4 * (p + 1), q1 = in0 + 4 * (p - n8 / 2);
+      } else {
+        q0 = in0 + n - 4 * (p - (n2 - n8) / 2 + 1), q1 = in0 + 4 * (p - n8 / 2);
+      }
+      F4 x0 = *(const F4 *)q0, x1 = *(const F4 *)q1;
+      asm volatile("" : "+v"(x0.x), "+v"(x0.y), "+v"(x0.z), "+v"(x0.w), "+v"(x1.x), "+v"(x1.y), "+v"(x1.z), "+v"(x1.w));
+      float r0, r1;
+      if (regime == 0) {
+        r0 = x0.z + x1.y, r1 = x0.x + x1.w;
+      } else if (regime == 1) {
+        r0 = x0.z - x1.y, r1 = x0.x - x1.w;
+      } else {
+        r0 = -x0.z - x1.y, r1 = -x0.x - x1.w;
+      }
+      F2 o;
+      o.x = r1 * T.y + r0 * T.x;
+      o.y = r1 * T.x - r0 * T.y;
+      *(F2 *)(w2 + VAMD_PW(2 * p)) = o;
+    }
   } else
   TEAM_EACH(pp, n4 << LOGS, tm) {
     VAMD_MDCT_SPLIT(pp, log2n - 2)

@@ -33,7 +33,7 @@ struct Bound {
   int res_lds_ints[2];    // LDS ints k_residue needs for the largest submap of the mode
   int res_off_ints[2];    // largest stages*slots + 1 over the mode's submaps (k_pack's offset arrays)
   float ampmax_att_per_sec;
-  int qmax[2];            // the input domain's integer edge per size class (derive_quant_limit)
+  QLimitP qlimit[2];      // the input domain's integer edge per size class and channel (derive_quant_limit)
 };
 
 // Checks the blob and produces `image` = blob + derived tables (what gets copied to HBM).
@@ -428,9 +428,10 @@ inline void floor_derive_tests(FloorP *F) {
 
 // The input domain's integer edge (include/vorbis_amd.h): the largest |quantised value| Q of a block for which every
 // integer the reference forms downstream of _vp_couple_quantize_normalize is defined by C, for THIS setup.
-//  * lib/psy.c:958-962,985: out = rint(sqrt(ve)) converted to int and squared in an int -- |out| <= 46340.  (A value
-//    the coupling stage leaves is never smaller than what it was first quantised to: a coupling step's magnitude keeps
-//    the larger of its two inputs, :1141-1166.)
+//  * lib/psy.c:958-962: out = rint(sqrt(ve)) converted to int -- below 2^31 (VAMD_QUANT_LIMIT_INT) -- and, where noise
+//    normalisation is at work (normal_p, bins from normal_start on), squared in an int (:985) -- |out| <= 46340
+//    (VAMD_QUANT_LIMIT_SQUARE).  (A value the coupling stage leaves is never smaller than what it was first quantised
+//    to: a coupling step's magnitude keeps the larger of its two inputs, :1141-1166.)  Both are k_couple's to test.
 //  * lib/res0.c:322-382, local_book_besterror on a vector a of dim <= 8 values, stage after stage (:585-640).  With
 //    |a_j| <= A:  (a - minval + del/2) / del, v * del + minval and the index arithmetic stay below 2^31 for any A < 2^29;
 //    the exhaustive search (:349-376) sums (e_j - a_j)^2 over the dim coordinates for EVERY populated entry e, whose
@@ -443,17 +444,18 @@ inline void floor_derive_tests(FloorP *F) {
 //    metrics (_2class :509-512: magmax <= classmetric1 && angmax <= classmetric2; _01class :447-450: max <=
 //    classmetric1), so such a class constrains Q only if values up to its own metrics could break its cascade (never,
 //    for libvorbisenc's books: checked here all the same); the last class takes whatever is left, and its cascade
-//    sets the bound.
+//    sets the bound.  The search only ever sees the bins [begin, end) its residue codes (a 5.1 setup's LFE submap:
+//    bins 0..11 -- a full-scale sine above them quantises to ~24 000 against a floor of -140 dB, coded by nobody, and
+//    is the reference's defined result): elsewhere only the first bullet applies (QLimitP).
 //  * _01class / _2class (:412-532) add up to `grouping` absolute values: far below 2^31 at these magnitudes.
 // For the libvorbisenc setups the last class's cascade starts on a two-dimensional book reaching a few thousand:
 // Q = 32 767 - ~2 000 ... 23 170 - ~10, spectra ~ +87 ... +90 dB over full scale.
-inline int derive_quant_limit(const vamd_setup_header &h, const vamd_book_tab *hb, int W) {
-  long q = 46340;
-  const int submaps = h.mode[W].submaps;
-  for (int sm = 0; sm < submaps && sm < VAMD_MAX_SUBMAPS; sm++) {
+inline int derive_quant_limit(const vamd_setup_header &h, const vamd_book_tab *hb, int W, int sm) {
+  long q = VAMD_QUANT_LIMIT_INT;
+  {
     const vamd_residue_tab &r = h.res[W][sm];
     for (int c = 0; c < r.partitions && c < VAMD_RES_MAXCLASS; c++) {
-      long reach = 0, qc = 46340;
+      long reach = 0, qc = VAMD_QUANT_LIMIT_INT;
       for (int s = 0; s < r.stages && s < VAMD_RES_MAXSTAGE; s++) {
         if (!((r.secondstages[c] >> s) & 1) || r.partbooks[c][s] < 0 || r.partbooks[c][s] >= h.nbooks) continue;
         const vamd_book_tab &bk = hb[r.partbooks[c][s]];
@@ -598,7 +600,37 @@ inline void bind_params(const std::vector<unsigned char> &image, const std::vect
     }
   }
   const vamd_book_tab *hb = (const vamd_book_tab *)(image.data() + h.off_books);
-  for (int W = 0; W < 2; W++) B->qmax[W] = derive_quant_limit(h, hb, W);
+  for (int W = 0; W < 2; W++) {
+    // a channel's values meet the residue search only at the bins its submap's residue codes: [begin, end) of the
+    // channel's own bins for type 1, of the bundle's interleaved samples for type 2 (lib/res0.c:738-746,791-797)
+    QLimitP &Q = B->qlimit[W];
+    const vamd_mode_tab &md = h.mode[W];
+    // noise normalisation (lib/psy.c:941-1010) squares the values it leaves from normal_start on, when it is switched on
+    // at all; the two block types of a size class share the setting in every libvorbisenc setup (the earlier start
+    // otherwise)
+    Q.sq = h.blocksizes[W] / 2;
+    for (int bt = 0; bt < 2; bt++) {
+      const vamd_psy_tab &t = h.psy[2 * W + bt];
+      if (t.normal_p) Q.sq = std::max(0, std::min(Q.sq, (int)t.normal_start));
+    }
+    for (int c = 0; c < VAMD_MAX_CH; c++) {
+      Q.q[c] = VAMD_QUANT_LIMIT_INT, Q.lo[c] = Q.hi[c] = 0;
+      if (c >= h.channels) continue;
+      const int sm = md.chmuxlist[c] < md.submaps && md.chmuxlist[c] < VAMD_MAX_SUBMAPS ? md.chmuxlist[c] : 0;
+      const vamd_residue_tab &r = h.res[W][sm];
+      int bundle = 0;
+      for (int k = 0; k < h.channels; k++) bundle += md.chmuxlist[k] == sm;
+      const int per = r.type == 2 && bundle > 0 ? bundle : 1, n2 = h.blocksizes[W] / 2;
+      Q.q[c] = derive_quant_limit(h, hb, W, sm);
+      // channel c is the ci-th of its bundle: its bin j is the residue's position j * per + ci (type 2), or j (type 1)
+      int ci = 0;
+      for (int k = 0; k < c; k++) ci += md.chmuxlist[k] == md.chmuxlist[c];
+      const int off = per > 1 ? ci : 0;
+      auto ceil_div = [](int a, int b) { return a <= 0 ? 0 : (a + b - 1) / b; };
+      Q.lo[c] = (short)std::min(n2, ceil_div(r.begin - off, per));
+      Q.hi[c] = (short)std::min(n2, ceil_div(r.end - off, per));
+    }
+  }
   auto longest = [&](int bn) {  // longest codeword of a book
     int m = 0;
     if (bn < 0) return 0;
@@ -659,6 +691,7 @@ inline void bind_params(const std::vector<unsigned char> &image, const std::vect
       Rp.cls_base = sm * VAMD_RES_CLASS_STRIDE;
       Rp.ent_base = ent_base;
       Rp.lds_ints = bundle * n2 + VAMD_RES_CLASS_STRIDE + 2 * r.stages * Rp.slots + 1;
+      Rp.qmax = derive_quant_limit(h, hb, W, src);
       if (sm < m.submaps) {
         all_ok = all_ok && ok;
         ent_base += Rp.cap;

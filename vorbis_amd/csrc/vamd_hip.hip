@@ -672,9 +672,9 @@ __global__ void k_widen_ilog(long n, const ilog_t *__restrict__ in, int *__restr
 // same spectrum.  ilogmask / iwork / nonzero are indexed by unit, mdct by block.
 // NORM = false may be launched with several waves per unit (small batches: couple_block deals its quads over the team)
 template <bool NORM>
-__global__ __launch_bounds__(256) void k_couple(PsyP P0, PsyP P1, CoupleSet CS, int blob_base, int nblobs, DescP d,
-                                               const float *__restrict__ mdct, const ilog_t *__restrict__ ilogmask,
-                                               int *__restrict__ iwork, int *__restrict__ nonzero, float band, int qmax) {
+__device__ __forceinline__ void couple_unit(const PsyP &P0, const PsyP &P1, const CoupleSet &CS, int blob_base, int nblobs, const DescP &d,
+                                            const float *__restrict__ mdct, const ilog_t *__restrict__ ilogmask,
+                                            int *__restrict__ iwork, int *__restrict__ nonzero, float band) {
   const long unit = blockIdx.x, mblk = unit / nblobs;
   const CoupleP &C = CS.c[blob_base + (int)(unit - mblk * nblobs)];
   const PsyP &P = d_bt(d, mblk) ? P1 : P0;
@@ -699,7 +699,7 @@ __global__ __launch_bounds__(256) void k_couple(PsyP P0, PsyP P1, CoupleSet CS, 
   PhaseClock pc;
   pc.start(d.dbg ? d.dbg + 64 : nullptr);
   unsigned over = 0;
-  couple_block<NORM>(C, P, n2, mp, ip, op, nz, L, pc, band, qmax, &over);
+  couple_block<NORM>(C, P, n2, mp, ip, op, nz, L, pc, band, &over);
   if (TEAM_LEADER)
     for (int c = 0; c < ch; c++) nonzero[blk * ch + c] = nz[c];
   for (int c = 0; c < ch; c++) {  // (the team's lanes each saw their own quads)
@@ -708,6 +708,20 @@ __global__ __launch_bounds__(256) void k_couple(PsyP P0, PsyP P1, CoupleSet CS, 
   }
   pc.flush();
 }
+// Two kernels, one body: the usual one (no ordered path compiled in) and the one with noise normalisation's sort.
+// (The input domain's watch over the written values, round 5, is one pair of running extremes per channel: 78 / 127
+// registers, six / four waves per SIMD as before.  A watch that also knew the residue's coded bins cost a wave per SIMD
+// and 10 % of the stage's time; that half of the test went to k_residue, which reads those values anyway.)
+__global__ __launch_bounds__(256) void k_couple(PsyP P0, PsyP P1, CoupleSet CS, int blob_base, int nblobs, DescP d,
+                                               const float *__restrict__ mdct, const ilog_t *__restrict__ ilogmask,
+                                               int *__restrict__ iwork, int *__restrict__ nonzero, float band) {
+  couple_unit<false>(P0, P1, CS, blob_base, nblobs, d, mdct, ilogmask, iwork, nonzero, band);
+}
+__global__ __launch_bounds__(64) void k_couple_norm(PsyP P0, PsyP P1, CoupleSet CS, int blob_base, int nblobs, DescP d,
+                                               const float *__restrict__ mdct, const ilog_t *__restrict__ ilogmask,
+                                               int *__restrict__ iwork, int *__restrict__ nonzero, float band) {
+  couple_unit<true>(P0, P1, CS, blob_base, nblobs, d, mdct, ilogmask, iwork, nonzero, band);
+}
 
 // the same stage for layouts beyond stereo (more than two channels or more than one coupling step:
 // couple_block_general, k_couple.h).  LDS: cand/key/sgn [n2] each + the partitions' budgets; the channels'
@@ -715,7 +729,7 @@ __global__ __launch_bounds__(256) void k_couple(PsyP P0, PsyP P1, CoupleSet CS, 
 __global__ __launch_bounds__(64) void k_couple_general(PsyP P0, PsyP P1, CoupleSet CS, int blob_base, int nblobs, DescP d,
                                                        const float *__restrict__ mdct, const ilog_t *__restrict__ ilogmask,
                                                        int *__restrict__ iwork, int *__restrict__ nonzero,
-                                                       float *__restrict__ state, int qmax) {
+                                                       float *__restrict__ state) {
   const long unit = blockIdx.x, mblk = unit / nblobs;
   const CoupleP &C = CS.c[blob_base + (int)(unit - mblk * nblobs)];
   const PsyP &P = d_bt(d, mblk) ? P1 : P0;
@@ -744,7 +758,7 @@ __global__ __launch_bounds__(64) void k_couple_general(PsyP P0, PsyP P1, CoupleS
   PhaseClock pc;
   pc.start(nullptr);
   unsigned over = 0;
-  couple_block_general(C, P, n2, mp, ip, op, nz, L, S, pc, qmax, &over);
+  couple_block_general(C, P, n2, mp, ip, op, nz, L, S, pc, &over);
   if (LANE == 0)
     for (int c = 0; c < ch; c++) nonzero[unit * ch + c] = nz[c];
   for (int c = 0; c < ch; c++)
@@ -782,7 +796,7 @@ __global__ __launch_bounds__(64) void k_floor_managed(PsyP P0, PsyP P1, FloorP F
 // (k_residue.h).  Output rows of a unit: res_class [submaps][VAMD_RES_CLASS_STRIDE], res_entries [ent_row],
 // res_count [submaps][2]; this launch fills submap `sm`'s part.
 #define VAMD_RES_WAVES 4  // waves per unit: they share one LDS copy of the work vector
-__global__ __launch_bounds__(64 * VAMD_RES_WAVES) void k_residue(ResP R, ChMap cm, int sm, int ent_row, DescP d, int ch, int n2,
+__global__ __launch_bounds__(64 * VAMD_RES_WAVES) void k_residue(ResP R, ChMap cm, int sm, int ent_row, int nblobs, DescP d, int ch, int n2,
                                                 const int *__restrict__ iwork, const int *__restrict__ nonzero,
                                                 int *__restrict__ res_class, unsigned short *__restrict__ res_entries,
                                                 int *__restrict__ res_count, unsigned char *__restrict__ res_books) {
@@ -792,19 +806,27 @@ __global__ __launch_bounds__(64 * VAMD_RES_WAVES) void k_residue(ResP R, ChMap c
   int *off = cls + VAMD_RES_CLASS_STRIDE;       // [stages*slots + 1], then info [stages*slots]
   int *info = off + (R.tab->stages * R.slots + 1);
   const int *ip[VAMD_MAX_CH];
-  int nz[VAMD_MAX_CH];
+  int nz[VAMD_MAX_CH], chan[VAMD_MAX_CH];
   int nb = 0;
   for (int c = 0; c < ch; c++)
     if (cm.sub[c] == sm) {
       ip[nb] = iwork + (u * ch + c) * n2;
       nz[nb] = nonzero[u * ch + c];
+      chan[nb] = c;
       nb++;
     }
   PhaseClock pc;
   pc.start(d.dbg ? d.dbg + 72 : nullptr);
+  unsigned over = 0;
   residue_block(R, n2, ip, nz, work, cls, off, info, res_class + u * (cm.submaps * VAMD_RES_CLASS_STRIDE) + R.cls_base,
                 res_entries + u * (long)ent_row + R.ent_base, res_count + (u * cm.submaps + sm) * 2, pc,
-                res_books ? res_books + u * (long)ent_row + R.ent_base : nullptr);
+                res_books ? res_books + u * (long)ent_row + R.ent_base : nullptr, &over);
+  // the input domain's integer edge, the search's half (k_residue.h): the team's lanes each loaded their own values
+  const long blk = u / nblobs;
+  for (int k = 0; k < nb; k++) {
+    const int any = __syncthreads_or((int)((over >> k) & 1u));
+    if (TEAM_LEADER && any) flag_range(d, blk * ch + chan[k]);
+  }
   pc.flush();
 }
 
@@ -1218,6 +1240,24 @@ __global__ void k_gather_blocks(int ch, int n, long nb, const long long *__restr
 }
 
 // calibration copy for counter passes (vamd_calib_copy): exactly 16 bytes in and 16 bytes out per lane-trip
+// Measurement aid: the shader clock while the chip is busy.  One wave sleeps through `span` ticks of the chip-wide
+// 100 MHz clock (s_memrealtime) and adds how many shader ticks (s_memtime: the counter the issue costs of
+// tools/micro/chip_rate.hip are priced in) went by to acc[0], the real-time ticks to acc[1], one to acc[2].
+__global__ __launch_bounds__(64) void k_clock_probe(unsigned long long *acc, unsigned long long span) {
+  if (threadIdx.x) return;
+  const unsigned long long w0 = wall_clock64();
+  const long long t0 = clock64();
+  unsigned long long w1;
+  do {
+    __builtin_amdgcn_s_sleep(32);
+    w1 = wall_clock64();
+  } while (w1 - w0 < span);
+  const long long t1 = clock64();
+  atomicAdd(acc, (unsigned long long)(t1 - t0));
+  atomicAdd(acc + 1, w1 - w0);
+  atomicAdd(acc + 2, 1ull);
+}
+
 __global__ __launch_bounds__(256) void k_calib_copy(const F4 *__restrict__ src, F4 *__restrict__ dst, long n16) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x) dst[i] = src[i];
 }
@@ -1235,6 +1275,7 @@ struct vamd_ctx {
   // noise masking and tone masking read different inputs and write different outputs; the tone
   // kernels run on this library-owned side stream, forked from / joined back into `stream`
   hipStream_t side = nullptr;
+  hipStream_t probe = nullptr;  // vamd_clock_probe's own stream (created on first use): beside the work, never in its way
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;  // (ev_join2: the short size class of a mixed run)
   bool overlap = true;
   float couple_band = VAMD_COUPLE_BAND;  // k_couple.h, chan_bin_sure
@@ -1455,6 +1496,7 @@ void vamd_destroy(vamd_ctx *c) {
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
   if (c->side) (void)hipStreamDestroy(c->side);
+  if (c->probe) (void)hipStreamDestroy(c->probe);
   if (c->d_image) (void)hipFree(c->d_image);
   if (c->d_bound) (void)hipFree(c->d_bound);
   delete c;
@@ -1485,7 +1527,13 @@ int vamd_input_status(vamd_ctx *c, long *bad_channel_blocks, long *bad_detector_
   return VAMD_OK;
 }
 
-int vamd_quant_limit(const vamd_ctx *c, int W) { return (c && (W == 0 || W == 1)) ? c->B.qmax[W] : VAMD_EINVAL; }
+int vamd_quant_limit(const vamd_ctx *c, int W, int channel, int *first_bin, int *end_bin, int *square_bin) {
+  if (!c || (W != 0 && W != 1) || channel < 0 || channel >= c->B.channels) return VAMD_EINVAL;
+  if (first_bin) *first_bin = c->B.qlimit[W].lo[channel];
+  if (end_bin) *end_bin = c->B.qlimit[W].hi[channel];
+  if (square_bin) *square_bin = c->B.qlimit[W].sq;
+  return c->B.qlimit[W].q[channel];
+}
 
 int vamd_profile(vamd_ctx *c, int enable) {
   if (!c) return VAMD_EINVAL;
@@ -1519,6 +1567,15 @@ int vamd_calib_copy(vamd_ctx *c, void *dst, const void *src, size_t bytes) {
   if (!dst || !src || (bytes & 15) || (((uintptr_t)dst | (uintptr_t)src) & 15)) return fail(c, VAMD_EINVAL, "calibration copy: 16-byte aligned buffers and size");
   if (bytes == 0) return VAMD_OK;
   hipLaunchKernelGGL(k_calib_copy, dim3((unsigned)(c->num_cus * 16)), dim3(256), 0, c->stream, (const F4 *)src, (F4 *)dst, (long)(bytes / 16));
+  HIP_TRY(c, hipGetLastError());
+  return VAMD_OK;
+}
+
+int vamd_clock_probe(vamd_ctx *c, unsigned long long *acc3, int span_us) {
+  DeviceGuard dev_guard(c);
+  if (!c || !acc3 || span_us < 1 || span_us > 100000) return VAMD_EINVAL;
+  if (!c->probe) HIP_TRY(c, hipStreamCreateWithFlags(&c->probe, hipStreamNonBlocking));
+  hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, c->probe, acc3, (unsigned long long)span_us * 100ull);
   HIP_TRY(c, hipGetLastError());
   return VAMD_OK;
 }
@@ -1785,7 +1842,7 @@ static void launch_residue_pack(vamd_ctx *c, BatchRun *R, hipStream_t s, long un
     // takes four either way (nothing else wants the CU, and a lone unit's latency is the caller's)
     hipLaunchKernelGGL(k_residue, dim3((unsigned)units), dim3(64 * (c->B.res[W][sm].bundle * n2 > 4096 || units <= res_team_max ? VAMD_RES_WAVES : 2)),
                        (size_t)c->B.res[W][sm].lds_ints * 4, s, c->B.res[W][sm], cm, sm,
-                       c->B.res_cap[W], R->d, ch, n2, iwork, nonzero, rb.cls, rb.entries, rb.count, packets ? rb.books : nullptr);
+                       c->B.res_cap[W], nblobs, R->d, ch, n2, iwork, nonzero, rb.cls, rb.entries, rb.count, packets ? rb.books : nullptr);
   prof_mark(c, VAMD_ST_RESIDUE);
   if (packets) {
     const size_t lds = ((size_t)VAMD_PK_RING + VAMD_POSTS_STRIDE + VAMD_RES_CLASS_STRIDE + 2 * (size_t)c->B.res_off_ints[W] +
@@ -1828,18 +1885,18 @@ static void launch_couple(vamd_ctx *c, BatchRun *R, hipStream_t s, long units, i
   const int n2 = c->B.xf[W].n / 2;
   if (needs_general_couple(c, W)) {
     hipLaunchKernelGGL(k_couple_general, dim3((unsigned)units), dim3(64), (size_t)n2 * 12 + 1024, s, P0, P1, c->B.couple_all[W],
-                       blob_base, nblobs, R->d, mdct, ilogmask, iwork, nonzero, R->couple_state, c->B.qmax[W]);
+                       blob_base, nblobs, R->d, mdct, ilogmask, iwork, nonzero, R->couple_state);
     return;
   }
   // the LDS arrays serve noise normalisation's sort only (lib/psy.c:941-1010); without it the
   // stage is register-only and the CU holds twice as many of its waves
   const bool norm0 = P0.normal_p && P0.normal_start < n2, norm1 = P1.normal_p && P1.normal_start < n2;
   if (norm0 || norm1)
-    hipLaunchKernelGGL(k_couple<true>, dim3((unsigned)units), dim3(64), (size_t)n2 * 12 + 1024, s, P0, P1, c->B.couple_all[W], blob_base,
-                       nblobs, R->d, mdct, ilogmask, iwork, nonzero, c->couple_band, c->B.qmax[W]);
+    hipLaunchKernelGGL(k_couple_norm, dim3((unsigned)units), dim3(64), (size_t)n2 * 12 + 1024, s, P0, P1, c->B.couple_all[W], blob_base,
+                       nblobs, R->d, mdct, ilogmask, iwork, nonzero, c->couple_band);
   else  // (a handful of blocks: four waves each)
-    hipLaunchKernelGGL(k_couple<false>, dim3((unsigned)units), dim3(units <= 2048 && n2 >= 512 ? 256 : 64), 0, s, P0, P1, c->B.couple_all[W],
-                       blob_base, nblobs, R->d, mdct, ilogmask, iwork, nonzero, c->couple_band, c->B.qmax[W]);
+    hipLaunchKernelGGL(k_couple, dim3((unsigned)units), dim3(units <= 2048 && n2 >= 512 ? 256 : 64), 0, s, P0, P1, c->B.couple_all[W],
+                       blob_base, nblobs, R->d, mdct, ilogmask, iwork, nonzero, c->couple_band);
 }
 
 //   part: 1 = the masks only (noise on the main stream, the tone chain beside it, their join left open), 2 = the rest

@@ -92,6 +92,7 @@ struct ResP {
   int slots;                  // classified (partition, stream) pairs at most: partvals x streams
   int cls_base, ent_base;     // where this submap's rows start inside a block's res_class / res_entries rows
   int lds_ints;               // LDS ints k_residue needs for this submap
+  int qmax;                   // largest |value| in [begin, end) for which the search's integers are defined (derive_quant_limit)
 };
 
 // packet assembly (k_pack.h): the floor's class tables and the codebooks' codewords, in the HBM image
@@ -151,6 +152,19 @@ struct CoupleSet {
   CoupleP c[VAMD_PACKETBLOBS];
 };
 
+// The input domain's integer edge (include/vorbis_amd.h "Input domain" (2); derive_quant_limit, vamd_bind.h), channel by
+// channel: a quantised value of channel c at a bin in [lo[c], hi[c]) -- the bins its submap's residue codes -- must stay
+// within q[c] (lib/res0.c:361-364); one at a bin from sq on -- where noise normalisation is at work, sq = n/2 where it
+// is not -- within VAMD_QUANT_LIMIT_SQUARE (lib/psy.c:985 squares it in an int); and every one within VAMD_QUANT_LIMIT_INT
+// (:958-962 convert a float to int: the largest float below 2^31).
+#define VAMD_QUANT_LIMIT_SQUARE 46340
+#define VAMD_QUANT_LIMIT_INT 0x7fffff80
+struct QLimitP {
+  int q[VAMD_MAX_CH];
+  short lo[VAMD_MAX_CH], hi[VAMD_MAX_CH];
+  int sq;
+};
+
 // per-block descriptor source (arrays may be null -> uniform value)
 struct DescP {
   const int *lW, *nW, *blocktype;
@@ -162,7 +176,7 @@ struct DescP {
   // VAMD_STATUS_NONFINITE where the block's spectral peak, before the 0 dB clamp of lib/mapping0.c:345, is above
   // VAMD_NONFINITE_DB (k_transform: a NaN / Inf sample, or finite ones so large that the reference's own fp32 spectrum
   // overflows), VAMD_STATUS_RANGE where a quantised value of the channel is beyond the setup's proven integer bound
-  // (k_couple: Bound::qmax).  bad[0] counts flagged channel-blocks since vamd_input_status() last looked, bad[1]
+  // (k_couple: Bound::qlimit).  bad[0] counts flagged channel-blocks since vamd_input_status() last looked, bad[1]
   // detector steps, bad[2] the non-finite ones among bad[0]
   unsigned char *status;
   unsigned int *bad;

@@ -60,6 +60,7 @@
 // vectors is wide enough for several waves, and sharing one LDS copy of the work vector between them
 // keeps more units resident per CU).  With a 64-thread workgroup a team is a wave.
 #define TEAM_FOR(i, count) for (int i = (int)threadIdx.x; i < (count); i += (int)blockDim.x)
+#define TEAM_RANGE(i, lo, hi) for (int i = (lo) + (int)threadIdx.x; i < (hi); i += (int)blockDim.x)
 #define TEAM_SYNC() __syncthreads()
 #define TEAM_FIRST_WAVE (threadIdx.x < 64)
 #define TEAM_LEADER (threadIdx.x == 0)

@@ -12,14 +12,48 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend="nccl", use_cuda=True):
+# where the collectives' tensors live: the rank's device (RCCL), or host memory when the backend cannot take device
+# tensors (a gloo build without GPU support: found out on the first collective and remembered)
+_staging = {"host": False}
+
+
+def _coll(t):
+    return t.cpu() if _staging["host"] and t.is_cuda else t
+
+
+def _run(fn, t, *args, **kw):
+    """One collective on `t` (in place); if the backend refuses a device tensor, stage through host memory from now on."""
+    if t.is_cuda and not _staging["host"]:
+        try:
+            fn(t, *args, **kw)
+            return t
+        except RuntimeError:
+            if dist.get_backend() == "nccl":
+                raise
+            _staging["host"] = True
+    h = _coll(t)
+    fn(h, *args, **kw)
+    if h is not t:
+        t.copy_(h)
+    return t
+
+
+def collectives_on():
+    return "host" if _staging["host"] else "device"
+
+
+def init_from_env(backend="nccl", use_cuda=True, share_gpu=False):
     """Join the process group described by RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run).
-    Returns (rank, world, device).  A single process needs no group: (0, 1, device)."""
+    Returns (rank, world, device).  A single process needs no group: (0, 1, device).
+    share_gpu: every rank takes cuda:0 (the one-GPU rehearsal of the multi-rank path; not with nccl, which wants a
+    device per rank)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if share_gpu and backend == "nccl" and world > 1:
+        raise ValueError("--share-gpu needs --backend gloo: RCCL wants one device per rank")
     if use_cuda:
-        dev = torch.device("cuda", local_rank if world > 1 else 0)
+        dev = torch.device("cuda", local_rank if (world > 1 and not share_gpu) else 0)
         torch.cuda.set_device(dev)
     else:
         dev = torch.device("cpu")
@@ -54,10 +88,10 @@ def broadcast_blob(blob_or_none, device):
         size = torch.tensor([t.numel()], dtype=torch.int64, device=device)
     else:
         size = torch.zeros(1, dtype=torch.int64, device=device)
-    dist.broadcast(size, 0)
+    _run(dist.broadcast, size, 0)
     if rank != 0:
         t = torch.empty(int(size.item()), dtype=torch.uint8, device=device)
-    dist.broadcast(t, 0)
+    _run(dist.broadcast, t, 0)
     return t.cpu().numpy()
 
 
@@ -71,7 +105,7 @@ def max_over_ranks(value, device):
     if not active():
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    _run(dist.all_reduce, t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
@@ -79,7 +113,7 @@ def sum_over_ranks(value, device):
     if not active():
         return int(value)
     t = torch.tensor([int(value)], dtype=torch.int64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    _run(dist.all_reduce, t, op=dist.ReduceOp.SUM)
     return int(t.item())
 
 
