@@ -577,36 +577,32 @@ def spawn_ranks(a, argv):
 
 
 class ClockProbe:
-    """The shader clock over a timed region: a probe wave beside every step on a stream of the
-    library's own (vamd_clock_probe: s_memtime ticks per s_memrealtime tick of one wave that sleeps 200 us)."""
+    """The shader clock over a timed region: vamd_clock_probe -- the first wave of every step's tone
+    stack walk, which runs beside the noise mask, samples s_memtime against s_memrealtime over its own life."""
 
-    def __init__(self, R, dev, every=4, span_us=20):
+    def __init__(self, R, dev):
         self.an = getattr(R, "an", None)
         self.acc = torch.zeros(3, dtype=torch.int64, device=dev) if (self.an is not None and hasattr(self.an, "clock_probe")) else None
-        self.every, self.span_us, self.n = every, span_us, 0
 
-    def tick(self):
-        # a probe is a kernel on a third stream: kept short and rare (every 4th step, 20 us = 2000 ticks of the 100 MHz
-        # clock) -- the runtime maps streams onto four hardware queues, and a probe per step sleeping 200 us sat in front of
-        # the tone chain's side stream often enough to show (tone tail 0.42 -> 0.51 ms)
-        self.n += 1
-        if self.acc is not None and self.n % self.every == 1:
+    def begin(self):
+        if self.acc is not None:
             try:
-                self.an.clock_probe(self.acc, self.span_us)
+                self.an.clock_probe(self.acc)
             except Exception:
                 self.acc = None
 
     def result(self):
-        """{"ghz", "probes"} or None; call after a device synchronise"""
+        """{"ghz", "samples"} or None; call after a device synchronise"""
         if self.acc is None:
             return None
         torch.cuda.synchronize()
+        self.an.clock_probe(None)
         t, w, n = (int(x) for x in self.acc.cpu().tolist())
         if n == 0 or w == 0:
             return None
-        return {"ghz": t / w * 0.1, "probes": n,
-                "method": "s_memtime ticks per s_memrealtime (100 MHz) tick of a probe wave (%d us) launched beside every %dth step"
-                          % (self.span_us, self.every)}
+        return {"ghz": t / w * 0.1, "samples": n,
+                "method": "s_memtime ticks per s_memrealtime (100 MHz) tick over the life of the first wave of each step's "
+                          "tone stack walk (k_tone_chase: beside the noise mask)"}
 
 
 def timed_run(a, R, dev, world, probe=None):
@@ -619,10 +615,10 @@ def timed_run(a, R, dev, world, probe=None):
     R.sync()
     t0 = time.perf_counter()
     R.timed_begin()
+    if probe is not None:
+        probe.begin()
     for _ in range(a.steps):
         R.step()
-        if probe is not None:
-            probe.tick()
     R.timed_end()
     R.sync()
     sharding.barrier()

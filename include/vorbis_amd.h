@@ -100,13 +100,13 @@ int vamd_stage_ms(vamd_ctx *ctx, float *ms, int nstages, int *runs);
  * the slots accumulated so far are copied out first. */
 int vamd_debug_cycles(vamd_ctx *ctx, int enable, unsigned long long *out80);
 
-/* Measurement aid (no libvorbis counterpart): the shader clock while the chip is busy.  Launches, on a stream of the
- * library's own and therefore beside whatever the context's stream is running, one wavefront that sleeps through
- * `span_us` microseconds of the chip-wide 100 MHz clock and then adds the shader ticks that went by to acc3[0], the
- * 100 MHz ticks to acc3[1] and 1 to acc3[2] (device memory, zeroed by the caller; asynchronous: read it after a device
- * synchronise).  acc3[0] / acc3[1] x 100 MHz is the clock the vector units ran at -- what bench.py prices
- * roofline.valu with, instead of a nominal figure. */
-int vamd_clock_probe(vamd_ctx *ctx, unsigned long long *acc3, int span_us);
+/* Measurement aid (no libvorbis counterpart): the shader clock while the chip is busy.  While `acc3` (device memory,
+ * three 64-bit words zeroed by the caller) is set, every batch of more than a few thousand blocks at the masking level
+ * or above has the first wave of its tone stack walk -- which runs beside the noise mask, the path's longest stage --
+ * add the shader ticks of its own life (s_memtime) to acc3[0], the ticks of the chip-wide 100 MHz clock (s_memrealtime)
+ * to acc3[1] and 1 to acc3[2].  acc3[0] / acc3[1] x 100 MHz is the clock the vector units ran at -- what bench.py prices
+ * roofline.valu with instead of a nominal figure.  NULL switches it off.  No launch, no stream of its own. */
+int vamd_clock_probe(vamd_ctx *ctx, unsigned long long *acc3);
 
 /* Calibration aid for counter passes (no libvorbis counterpart): copy `bytes` (a multiple of 16) from `src` to `dst`
  * (device pointers) with the library's own kernel k_calib_copy, 16 bytes per lane -- exactly `bytes` read and

@@ -96,7 +96,7 @@ def load_library():
     L = C.CDLL(path)
     L.vamd_create_abi.argtypes = [C.POINTER(_vp), _vp, C.c_size_t, C.c_int, C.c_int]
     L.vamd_quant_limit.argtypes = [_vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
-    L.vamd_clock_probe.argtypes = [_vp, _vp, C.c_int]
+    L.vamd_clock_probe.argtypes = [_vp, _vp]
     L.vamd_config_string.argtypes = [_vp]
     L.vamd_config_string.restype = C.c_char_p
     L.vamd_destroy.argtypes = [_vp]
@@ -225,11 +225,14 @@ class Analyzer:
         self._check(self.L.vamd_stage_ms(self.h, ms, 8, C.byref(runs)))
         return dict(zip(self.STAGES, [float(x) for x in ms])), runs.value
 
-    def clock_probe(self, acc, span_us=200):
-        """vamd_clock_probe(): one probe wave beside the running work; `acc` = a zeroed cuda int64 tensor of 3 (shader
-        ticks, 100 MHz ticks, probes).  After a synchronise: acc[0] / acc[1] * 0.1 = the shader clock in GHz."""
-        self._need_tensor(acc, self.torch.int64, "acc", numel=3)
-        self._check(self.L.vamd_clock_probe(self.h, _vp(acc.data_ptr()), int(span_us)))
+    def clock_probe(self, acc):
+        """vamd_clock_probe(): while `acc` (a zeroed cuda int64 tensor of 3: shader ticks, 100 MHz ticks, samples) is
+        set, every large batch adds a sample of the shader clock taken beside its noise mask; None switches it off.
+        After a synchronise: acc[0] / acc[1] * 0.1 = the shader clock in GHz."""
+        if acc is not None:
+            self._need_tensor(acc, self.torch.int64, "acc", numel=3)
+        self._clk = acc   # (kept alive: the library holds the raw pointer)
+        self._check(self.L.vamd_clock_probe(self.h, _vp(acc.data_ptr()) if acc is not None else None))
 
     def debug_cycles(self, enable=True, read=False):
         """Arm/disarm the in-kernel phase stopwatch; with read=True returns the 5x16 tick sums first."""

@@ -531,8 +531,22 @@ __global__ __launch_bounds__(64) void k_tone_chase(int linesper, int nl, int nlp
   const long cb = (long)blockIdx.x * VAMD_CHASE_LANES + threadIdx.x;
   PhaseClock pc;
   pc.start(d.dbg ? d.dbg + 32 : nullptr);
+  // Measurement aid (vamd_clock_probe): the shader clock while the chip is busy.  The first wave of this launch --
+  // which runs beside the noise mask, the path's longest stage -- adds the shader ticks (s_memtime: the counter the
+  // issue costs of tools/micro/chip_rate.hip are priced in) and the ticks of the chip-wide 100 MHz clock
+  // (s_memrealtime) of its own life to the caller's accumulator.  No launch of its own: a probe kernel on a third stream
+  // sat in front of this very chain often enough to show (tone tail 0.42 -> 0.46-0.51 ms).
+  const bool probe = d.clk && blockIdx.x == 0 && threadIdx.x == 0;
+  unsigned long long w0 = 0;
+  long long t0 = 0;
+  if (probe) w0 = wall_clock64(), t0 = clock64();
   if (cb < ncb)
     nsurv[cb] = tone_chase_thread(seed_g + cb * nlp, linesper, nl, ring_amp, ring_pos, VAMD_CHASE_LANES, threadIdx.x, surv + cb * nlp);
+  if (probe) {
+    atomicAdd(d.clk, (unsigned long long)(clock64() - t0));
+    atomicAdd(d.clk + 1, wall_clock64() - w0);
+    atomicAdd(d.clk + 2, 1ull);
+  }
   pc.mark(2);
   pc.flush();
 }
@@ -1240,24 +1254,6 @@ __global__ void k_gather_blocks(int ch, int n, long nb, const long long *__restr
 }
 
 // calibration copy for counter passes (vamd_calib_copy): exactly 16 bytes in and 16 bytes out per lane-trip
-// Measurement aid: the shader clock while the chip is busy.  One wave sleeps through `span` ticks of the chip-wide
-// 100 MHz clock (s_memrealtime) and adds how many shader ticks (s_memtime: the counter the issue costs of
-// tools/micro/chip_rate.hip are priced in) went by to acc[0], the real-time ticks to acc[1], one to acc[2].
-__global__ __launch_bounds__(64) void k_clock_probe(unsigned long long *acc, unsigned long long span) {
-  if (threadIdx.x) return;
-  const unsigned long long w0 = wall_clock64();
-  const long long t0 = clock64();
-  unsigned long long w1;
-  do {
-    __builtin_amdgcn_s_sleep(32);
-    w1 = wall_clock64();
-  } while (w1 - w0 < span);
-  const long long t1 = clock64();
-  atomicAdd(acc, (unsigned long long)(t1 - t0));
-  atomicAdd(acc + 1, w1 - w0);
-  atomicAdd(acc + 2, 1ull);
-}
-
 __global__ __launch_bounds__(256) void k_calib_copy(const F4 *__restrict__ src, F4 *__restrict__ dst, long n16) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x) dst[i] = src[i];
 }
@@ -1275,7 +1271,7 @@ struct vamd_ctx {
   // noise masking and tone masking read different inputs and write different outputs; the tone
   // kernels run on this library-owned side stream, forked from / joined back into `stream`
   hipStream_t side = nullptr;
-  hipStream_t probe = nullptr;  // vamd_clock_probe's own stream (created on first use): beside the work, never in its way
+  unsigned long long *d_clk = nullptr;  // vamd_clock_probe's accumulator (the caller's, device memory), or null
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;  // (ev_join2: the short size class of a mixed run)
   bool overlap = true;
   float couple_band = VAMD_COUPLE_BAND;  // k_couple.h, chan_bin_sure
@@ -1496,7 +1492,6 @@ void vamd_destroy(vamd_ctx *c) {
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
   if (c->side) (void)hipStreamDestroy(c->side);
-  if (c->probe) (void)hipStreamDestroy(c->probe);
   if (c->d_image) (void)hipFree(c->d_image);
   if (c->d_bound) (void)hipFree(c->d_bound);
   delete c;
@@ -1571,12 +1566,9 @@ int vamd_calib_copy(vamd_ctx *c, void *dst, const void *src, size_t bytes) {
   return VAMD_OK;
 }
 
-int vamd_clock_probe(vamd_ctx *c, unsigned long long *acc3, int span_us) {
-  DeviceGuard dev_guard(c);
-  if (!c || !acc3 || span_us < 1 || span_us > 100000) return VAMD_EINVAL;
-  if (!c->probe) HIP_TRY(c, hipStreamCreateWithFlags(&c->probe, hipStreamNonBlocking));
-  hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, c->probe, acc3, (unsigned long long)span_us * 100ull);
-  HIP_TRY(c, hipGetLastError());
+int vamd_clock_probe(vamd_ctx *c, unsigned long long *acc3) {
+  if (!c) return VAMD_EINVAL;
+  c->d_clk = acc3;
   return VAMD_OK;
 }
 
@@ -1790,6 +1782,7 @@ static int prepare_run(vamd_ctx *c, const vamd_batch_desc *desc, const vamd_batc
   d.u_blocktype = desc->uniform_blocktype;
   d.u_ampmax_in = desc->uniform_ampmax_in;
   d.dbg = c->d_dbg;
+  d.clk = c->d_clk;
   d.status = R->p.status;
   d.bad = c->d_bad;
   d.src = nullptr;

@@ -172,6 +172,7 @@ struct DescP {
   int u_lW, u_nW, u_blocktype;
   float u_ampmax_in;
   unsigned long long *dbg;  // phase stopwatch slots (null = off), 16 per stage kernel
+  unsigned long long *clk;  // vamd_clock_probe's accumulator (null = off): {shader ticks, 100 MHz ticks, samples}
   // input-domain report (include/vorbis_amd.h, "Input domain"): status[channel-block] is a bit set --
   // VAMD_STATUS_NONFINITE where the block's spectral peak, before the 0 dB clamp of lib/mapping0.c:345, is above
   // VAMD_NONFINITE_DB (k_transform: a NaN / Inf sample, or finite ones so large that the reference's own fp32 spectrum
