@@ -59,6 +59,38 @@ typedef struct vamd_shared { /* one batcher per distinct setup (VAMD_BATCH mode)
   vamd_batcher *batcher;
   int users;
 } vamd_shared;
+/* ---- look-ahead inside one stream (round 5).  An application that hands vorbis_analysis_wrote() more than a block's
+ * worth of samples (the API takes any amount, lib/block.c:390,470; the example's READ 1024 is a choice,
+ * examples/encoder_example.c:38) has, by the time it asks for the first block, determined every block its buffer
+ * covers: the marks of _ve_envelope_search are there for all the buffered steps, and what vorbis_analysis_blockout will
+ * decide for the following blocks follows from them (lib/block.c:534-693, lib/envelope.c:262-353).  On a cache miss the
+ * binding therefore replays those decisions ahead of the reference's own blockout (vamd_plan_ahead: the same walk, in
+ * the buffer's current coordinates, nothing shifted), sends the block at hand AND the blocks to come through ONE
+ * launch sequence (vamd_encode_blocks: the ampmax chain between them on the device) and keeps the packets.  Each later
+ * vorbis_analysis() is then served from that cache -- after the block the reference's blockout really produced has been
+ * held against the planned one: sequence number, window flags, block type, the incoming ampmax bit for bit and every
+ * sample.  A packet is a pure function of exactly those, so a hit is the packet the single-block path would have
+ * produced; anything else (more data written in between and a decision changed, end of stream, a replay that went
+ * astray) is a miss, which costs the cache and nothing else.  One GPU round trip per buffered stretch instead of one per
+ * block.  VAMD_LOOKAHEAD=0 switches it off; VAMD_BATCH mode and bitrate-managed encoders do not use it. */
+#define VAMD_AHEAD_MAX 256
+typedef struct vamd_ahead_block {
+  long sequence;
+  int32_t lW, W, nW, blocktype;
+  float ampmax_in, ampmax_out;
+  int32_t verdict, bits;
+  long pcm_at; /* offset (floats) of the block's [ch][n] samples in vamd_ahead.pcm */
+} vamd_ahead_block;
+typedef struct vamd_ahead {
+  int count, next;                /* planned blocks held, and the one expected next */
+  vamd_ahead_block blk[VAMD_AHEAD_MAX];
+  float *pcm;                     /* the planned blocks' samples as they were sent (what a hit is verified against) */
+  long pcm_cap;
+  unsigned char *packets;         /* [VAMD_AHEAD_MAX][stride] */
+  long stride;
+  long hits, misses, batches;     /* (diagnostics: vamd_ahead_stats) */
+} vamd_ahead;
+
 typedef struct vamd_entry {
   const void *key; /* private_state.ve */
   vamd_ctx *ctx;   /* this state's own context (always in per-state mode; in batch mode only for what is not batched) */
@@ -66,8 +98,10 @@ typedef struct vamd_entry {
   vamd_envelope_state env; /* the block-switching detector's running state (envelope_vamd.c) */
   int poisoned;            /* the stream is over (vamd_poison): VAMD_POISON_NONFINITE -> every later block is OV_EINVAL,
                               VAMD_POISON_FAULT -> OV_EFAULT */
+  vamd_ahead *ahead;       /* the look-ahead cache (allocated on first use) */
 } vamd_entry;
 static pthread_mutex_t vamd_lock = PTHREAD_MUTEX_INITIALIZER;
+static long vamd_ahead_total[3]; /* look-ahead hits / misses / batches of the streams already closed (vamd_ahead_stats) */
 static vamd_entry **vamd_table = NULL;
 static int vamd_count = 0, vamd_cap = 0;
 static vamd_shared *vamd_shares[16];
@@ -232,6 +266,7 @@ void vamd_release_key(const void *key) {
         if (vamd_shares[i] == dead) vamd_shares[i] = vamd_shares[--vamd_nshares];
     }
   }
+  if (e && e->ahead) vamd_ahead_total[0] += e->ahead->hits, vamd_ahead_total[1] += e->ahead->misses, vamd_ahead_total[2] += e->ahead->batches;
   pthread_mutex_unlock(&vamd_lock);
   if (dead) {
     vamd_batcher_destroy(dead->batcher);
@@ -240,6 +275,11 @@ void vamd_release_key(const void *key) {
   }
   if (e) {
     if (e->ctx) vamd_destroy(e->ctx);
+    if (e->ahead) {
+      if (e->ahead->pcm) _ogg_free(e->ahead->pcm);
+      if (e->ahead->packets) _ogg_free(e->ahead->packets);
+      _ogg_free(e->ahead);
+    }
     _ogg_free(e);
   }
 }
@@ -273,6 +313,86 @@ long vamd_batch_trace(char *buf, long cap) {
 
 /* for a build WITHOUT envelope_vamd.c: call from vorbis_dsp_clear() before b->ve is freed */
 void vamd_release_state(vorbis_dsp_state *state) { vamd_release_key(vamd_key(state)); }
+
+/* VAMD_LOOKAHEAD=0 switches the look-ahead off (read once) */
+static int vamd_lookahead_on(void) {
+  static int mode = -1;
+  if (mode < 0) {
+    const char *v = getenv("VAMD_LOOKAHEAD");
+    mode = v ? (atoi(v) != 0) : 1;
+  }
+  return mode;
+}
+
+/* What vorbis_analysis_blockout() will decide for the blocks AFTER the one it has just handed out, as far as the buffered
+ * samples determine them: the state in `v` is already the next block's (lib/block.c:649-685), the marks of every buffered
+ * step are in ve->mark (the blockout that produced the current block ran _ve_envelope_search over all of them), and
+ * nothing is shifted here, so every position stays in the buffer's current coordinates -- shifting subtracts the same
+ * amount from both sides of every comparison below.  The cursor walk is lib/envelope.c:262-325, the size / window /
+ * blocktype decisions lib/block.c:552-611 with _ve_envelope_mark lib/envelope.c:329-353.  Stops where blockout would
+ * say "not enough data" -- and before anything the end of a stream changes (v->eofflag).  begin[k] = first sample of
+ * planned block k's window in v->pcm[]. */
+static int vamd_plan_ahead(vorbis_dsp_state *v, int max, vamd_ahead_block *out, long *begin) {
+  codec_setup_info *ci = v->vi->codec_setup;
+  envelope_lookup *ve = ((private_state *)v->backend_state)->ve;
+  const long step = ve->searchstep, current = ve->current;
+  const long bs[2] = {ci->blocksizes[0], ci->blocksizes[1]};
+  int W = (int)v->W, lW = (int)v->lW, n = 0;
+  long centerW = v->centerW, cursor = ve->cursor, curmark = ve->curmark, j;
+  if (v->eofflag || !v->preextrapolate) return 0;
+  while (n < max) {
+    const long testW = centerW + bs[W] / 4 + bs[1] / 2 + bs[0] / 4;
+    int bp = -1, nW, blocktype;
+    long centerNext;
+    for (j = cursor; j < current - step; j += step) {
+      if (j >= testW) {
+        bp = 1;
+        break;
+      }
+      cursor = j;
+      if (ve->mark[j / step] && j > centerW) {
+        curmark = j;
+        bp = j >= testW ? 1 : 0;
+        break;
+      }
+    }
+    if (bp < 0) break; /* lib/block.c:558-560 */
+    nW = bs[0] == bs[1] ? 0 : bp;
+    centerNext = centerW + bs[W] / 4 + bs[nW] / 4;
+    if (v->pcm_current < centerNext + bs[nW] / 2) break; /* :574-583 */
+    if (W) {
+      blocktype = (!lW || !nW) ? BLOCKTYPE_TRANSITION : BLOCKTYPE_LONG;
+    } else {
+      const long beginW = centerW - bs[0] / 4 - bs[0] / 4, endW = centerW + bs[0] / 4 + bs[0] / 4;
+      int hit = curmark >= beginW && curmark < endW;
+      long i;
+      for (i = beginW / step; !hit && i < endW / step; i++) hit = i >= 0 && i < ve->storage && ve->mark[i];
+      blocktype = hit ? BLOCKTYPE_IMPULSE : BLOCKTYPE_PADDING;
+    }
+    out[n].lW = lW, out[n].W = W, out[n].nW = nW, out[n].blocktype = blocktype;
+    begin[n] = centerW - bs[W] / 2;
+    if (begin[n] < 0 || begin[n] + bs[W] > v->pcm_current) break;
+    n++;
+    lW = W;
+    W = nW;
+    centerW = centerNext;
+  }
+  return n;
+}
+
+/* hits, misses and batches of every stream's look-ahead since the process started, closed streams included (diagnostics) */
+void vamd_ahead_stats(long *hits, long *misses, long *batches) {
+  int i;
+  pthread_mutex_lock(&vamd_lock);
+  *hits = vamd_ahead_total[0], *misses = vamd_ahead_total[1], *batches = vamd_ahead_total[2];
+  for (i = 0; i < vamd_count; i++)
+    if (vamd_table[i]->ahead) {
+      *hits += vamd_table[i]->ahead->hits;
+      *misses += vamd_table[i]->ahead->misses;
+      *batches += vamd_table[i]->ahead->batches;
+    }
+  pthread_mutex_unlock(&vamd_lock);
+}
 
 /* The bit-writing half for one candidate packet k where the GPU does not assemble packets (the mode's
  * residue back-end is not covered there): unchanged host code, lib/mapping0.c:596-687 -- packet header,
@@ -370,6 +490,89 @@ static int mapping0_forward_vamd(vorbis_block *vb) {
 
   ctx = vamd_ctx_for(vd);
   if (!ctx) return OV_EFAULT; /* no silent fallback: a missing GPU is an error */
+
+  /* ---- look-ahead inside one stream (the comment at vamd_ahead): serve this block from the packets planned earlier,
+     or plan the blocks the buffer already determines and run them with this one */
+  if (!managed && vamd_lookahead_on() && vamd_packet_capacity(ctx, 0) > 0 && vamd_packet_capacity(ctx, 1) > 0) {
+    vamd_entry *e = vamd_entry_for(vd);
+    vamd_ahead *A = e ? e->ahead : NULL;
+    const long bsz[2] = {((codec_setup_info *)vi->codec_setup)->blocksizes[0], ((codec_setup_info *)vi->codec_setup)->blocksizes[1]};
+    int i;
+    if (A && A->next < A->count) {
+      const vamd_ahead_block *p = &A->blk[A->next];
+      int same = p->sequence == (long)vb->sequence && p->W == vb->W && p->lW == vb->lW && p->nW == vb->nW &&
+                 p->blocktype == vbi->blocktype && !memcmp(&p->ampmax_in, &vbi->ampmax, sizeof(float));
+      for (i = 0; same && i < ch; i++) same = !memcmp(A->pcm + p->pcm_at + (long)i * n, vb->pcm[i], (size_t)n * sizeof(float));
+      if (same) {
+        A->next++;
+        A->hits++;
+        if (p->verdict) return vamd_domain_verdict(vb, p->verdict, p->ampmax_out);
+        vbi->ampmax = p->ampmax_out; /* lib/mapping0.c:576 */
+        oggpack_writecopy(vbi->packetblob[PACKETBLOBS / 2], A->packets + (long)(p - A->blk) * A->stride, p->bits);
+        return 0;
+      }
+      A->count = A->next = 0; /* the stream went another way than planned: the cache is worth nothing */
+      A->misses++;
+    }
+    if (e) {
+      vamd_ahead_block planned[VAMD_AHEAD_MAX];
+      long begin[VAMD_AHEAD_MAX];
+      const int np = vamd_plan_ahead(vd, VAMD_AHEAD_MAX - 1, planned + 1, begin + 1);
+      if (np > 0) {
+        const int nb = np + 1;
+        const float **ptr = _vorbis_block_alloc(vb, (long)nb * ch * sizeof(*ptr));
+        int32_t *dW = _vorbis_block_alloc(vb, 4L * nb * sizeof(*dW)), *dlW = dW + nb, *dnW = dW + 2 * nb, *dbt = dW + 3 * nb;
+        int32_t *bits = _vorbis_block_alloc(vb, 2L * nb * sizeof(*bits)), *verdict = bits + nb;
+        float *ain = _vorbis_block_alloc(vb, 2L * nb * sizeof(*ain)), *aout = ain + nb;
+        long need = 0, at = 0, stride = vamd_packet_capacity(ctx, 0);
+        int k;
+        if (vamd_packet_capacity(ctx, 1) > stride) stride = vamd_packet_capacity(ctx, 1);
+        if (!A) A = e->ahead = _ogg_calloc(1, sizeof(*A));
+        for (k = 1; k < nb; k++) need += (long)ch * bsz[planned[k].W];
+        if (A && A->pcm_cap < need) {
+          if (A->pcm) _ogg_free(A->pcm);
+          A->pcm = _ogg_malloc((size_t)(need + need / 2) * sizeof(float));
+          A->pcm_cap = A->pcm ? need + need / 2 : 0;
+        }
+        if (A && A->stride != stride) {
+          if (A->packets) _ogg_free(A->packets);
+          A->packets = _ogg_malloc((size_t)VAMD_AHEAD_MAX * stride);
+          A->stride = A->packets ? stride : 0;
+        }
+        if (A && A->pcm_cap >= need && A->stride == stride) {
+          planned[0].lW = vb->lW, planned[0].W = vb->W, planned[0].nW = vb->nW, planned[0].blocktype = vbi->blocktype;
+          for (i = 0; i < ch; i++) ptr[i] = vb->pcm[i];
+          for (k = 1; k < nb; k++) { /* the samples as they lie in the encoder's own buffer, kept for the comparison later */
+            const long nk = bsz[planned[k].W];
+            planned[k].pcm_at = at;
+            for (i = 0; i < ch; i++) {
+              memcpy(A->pcm + at, vd->pcm[i] + begin[k], (size_t)nk * sizeof(float));
+              ptr[(long)k * ch + i] = A->pcm + at;
+              at += nk;
+            }
+          }
+          for (k = 0; k < nb; k++) dlW[k] = planned[k].lW, dW[k] = planned[k].W, dnW[k] = planned[k].nW, dbt[k] = planned[k].blocktype;
+          ret = vamd_encode_blocks(ctx, nb, ptr, dlW, dW, dnW, dbt, vbi->ampmax, ain, aout, A->packets, stride, bits, verdict);
+          if (ret) return ret;
+          A->batches++;
+          A->count = A->next = 0;
+          for (k = 1; k < nb; k++) { /* (slot k of the cache = block k of the batch: its packet row is row k) */
+            vamd_ahead_block *q = &A->blk[k];
+            *q = planned[k];
+            q->sequence = (long)vb->sequence + k;
+            q->ampmax_in = ain[k], q->ampmax_out = aout[k], q->verdict = verdict[k], q->bits = bits[k];
+          }
+          A->next = 1;
+          A->count = nb;
+          if (verdict[0]) return vamd_domain_verdict(vb, verdict[0], aout[0]);
+          if (bits[0] > 8 * stride) return OV_EFAULT; /* cannot happen: stride is the worst case */
+          vbi->ampmax = aout[0]; /* lib/mapping0.c:576 */
+          oggpack_writecopy(vbi->packetblob[PACKETBLOBS / 2], A->packets, bits[0]);
+          return 0;
+        }
+      }
+    }
+  }
 
   /* ---- the whole of mapping0_forward in one call (lib/mapping0.c:254-687): the block's finished
      packet -- all PACKETBLOBS candidates for a bitrate-managed encoder, which lets

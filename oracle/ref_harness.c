@@ -675,7 +675,7 @@ long ref_encode_stream(ref_enc *e, const float *pcm, long frames, ref_block_rec 
 #include <sys/resource.h>
 typedef struct ref_tt_arg {
   int ch, passes;
-  long rate, frames, blocks;
+  long rate, frames, blocks, write_frames;
   float q;
   const float *pcm;
   ref_enc *first;
@@ -688,15 +688,16 @@ static void *ref_tt_run(void *v) {
   pthread_barrier_wait(a->line);
   for (p = 0; p < a->passes; p++) {
     ref_enc *e = p == 0 ? a->first : ref_open(a->ch, a->rate, a->q);
-    long nb = e ? ref_encode_stream(e, a->pcm, a->frames, NULL, 0, NULL, 0, NULL, 0) : -1;
+    long nb = e ? ref_encode_stream_ex(e, a->pcm, a->frames, a->write_frames, 0, NULL, 0, NULL, 0, NULL, 0) : -1;
     if (e) ref_close(e);
     if (nb < 0) { a->failed = 1; break; }
     a->blocks += nb;
   }
   return NULL;
 }
-double ref_time_threads(int nthreads, int ch, long rate, float q, const float *pcm, long frames, int passes,
-                        long *blocks_out, double *cpu_out) {
+/* write_frames: samples per vorbis_analysis_wrote() call (1024 = the example's READ) */
+double ref_time_threads_w(int nthreads, int ch, long rate, float q, const float *pcm, long frames, long write_frames, int passes,
+                          long *blocks_out, double *cpu_out) {
   pthread_t *th = (pthread_t *)calloc(nthreads, sizeof(*th));
   ref_tt_arg *args = (ref_tt_arg *)calloc(nthreads, sizeof(*args));
   pthread_barrier_t line;
@@ -710,7 +711,7 @@ double ref_time_threads(int nthreads, int ch, long rate, float q, const float *p
   pthread_attr_setstacksize(&attr, 1 << 20); /* mapping0_forward's alloca()s are a few hundred KB at most */
   for (i = 0; i < nthreads; i++) {
     args[i].ch = ch, args[i].rate = rate, args[i].q = q, args[i].pcm = pcm, args[i].frames = frames;
-    args[i].passes = passes, args[i].line = &line;
+    args[i].passes = passes, args[i].line = &line, args[i].write_frames = write_frames;
     args[i].first = ref_open(ch, rate, q);
     pthread_create(&th[i], &attr, ref_tt_run, &args[i]);
   }
@@ -731,6 +732,10 @@ double ref_time_threads(int nthreads, int ch, long rate, float q, const float *p
   free(th);
   free(args);
   return bad ? -1. : (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+}
+double ref_time_threads(int nthreads, int ch, long rate, float q, const float *pcm, long frames, int passes,
+                        long *blocks_out, double *cpu_out) {
+  return ref_time_threads_w(nthreads, ch, rate, q, pcm, frames, 1024, passes, blocks_out, cpu_out);
 }
 
 /* ---- the block-switching detector ------------------------------

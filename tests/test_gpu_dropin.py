@@ -51,6 +51,35 @@ def test_hybrid_encode_emits_reference_packets(ch, q, kind):
         assert sum(1 for b in want if b["W"] == 0) > 10
 
 
+@pytest.mark.parametrize("q,kind,write", [(0.4, "s16", 65536), (0.9, "gated", 65536), (0.4, "gated", 8192), (0.1, "gated", 30000)])
+def test_look_ahead_inside_one_stream_emits_reference_packets(q, kind, write):
+    """An application that writes more than a block's worth per vorbis_analysis_wrote() (the API takes any amount,
+    lib/block.c:390,470): the binding plans the blocks its buffer already determines, runs them as ONE batch
+    (vamd_encode_blocks, the ampmax chain on the device) and serves the following vorbis_analysis() calls from those
+    packets -- each only after the block the reference's own blockout produced has been held against the planned one,
+    sample for sample.  Every packet and every ampmax equals the pure CPU reference fed the same way; and the cache
+    really was what served them (hits >> batches)."""
+    import ctypes as C
+    L = ref.lib(hybrid=True)
+    h0 = [C.c_long(0) for _ in range(3)]
+    L.vamd_ahead_stats(*[C.byref(v) for v in h0])
+    pcm = _stream(2, 6.0, kind, seed=4242)
+    want = ref.RefEncoder(2, 44100, q).encode_stream(pcm, write_frames=write)
+    got = ref.RefEncoder(2, 44100, q, hybrid=True).encode_stream(pcm, write_frames=write)
+    h1 = [C.c_long(0) for _ in range(3)]
+    L.vamd_ahead_stats(*[C.byref(v) for v in h1])
+    hits, misses, batches = (b.value - a.value for a, b in zip(h0, h1))
+    assert len(want) == len(got) > 200
+    for k, (a, b) in enumerate(zip(want, got)):
+        assert (a["lW"], a["W"], a["nW"], a["blocktype"]) == (b["lW"], b["W"], b["nW"], b["blocktype"]), k
+        assert np.float32(a["ampmax_in"]) == np.float32(b["ampmax_in"]), k
+        assert np.float32(a["ampmax_out"]) == np.float32(b["ampmax_out"]), k
+        assert a["packet"] == b["packet"], "packet %d differs (W=%d)" % (k, a["W"])
+    if kind == "gated":
+        assert sum(1 for b in want if b["W"] == 0) > 30
+    assert hits > 0.8 * len(got) and batches < len(got) / 4 and misses <= batches, (hits, misses, batches, len(got))
+
+
 _BATCH_WORKER = r'''
 import sys, threading, time, json
 sys.path.insert(0, @ROOT@)

@@ -16,7 +16,7 @@ POSTS_STRIDE = 32
 BLOCKTYPE_IMPULSE, BLOCKTYPE_PADDING, BLOCKTYPE_TRANSITION, BLOCKTYPE_LONG = 0, 1, 0, 1
 
 # every symbol include/vorbis_amd.h declares
-EXPORTED_SYMBOLS = ["vamd_create_abi", "vamd_clock_probe", "vamd_quant_limit", "vamd_config_string", "vamd_destroy", "vamd_last_error", "vamd_set_stream", "vamd_reserve",
+EXPORTED_SYMBOLS = ["vamd_create_abi", "vamd_encode_blocks", "vamd_clock_probe", "vamd_quant_limit", "vamd_config_string", "vamd_destroy", "vamd_last_error", "vamd_set_stream", "vamd_reserve",
                     "vamd_channels", "vamd_blocksize", "vamd_posts", "vamd_mdct_forward_batch",
                     "vamd_analyze_batch", "vamd_analyze_stream", "vamd_analyze_block", "vamd_profile",
                     "vamd_stage_ms", "vamd_debug_cycles", "vamd_analyze_stream_mixed", "vamd_envelope_search_batch",

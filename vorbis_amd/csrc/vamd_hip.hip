@@ -331,14 +331,16 @@ __global__ void k_ampmax_stream_mixed(int ch, long ntotal, const int *__restrict
                                       float att, float state, const float *__restrict__ local0,
                                       const float *__restrict__ local1, float *__restrict__ in0,
                                       float *__restrict__ in1, float *__restrict__ glob0, float *__restrict__ glob1,
-                                      float *__restrict__ state_out) {
+                                      float *__restrict__ state_out, int first_given) {
   if (blockIdx.x || threadIdx.x) return;
   float amp = state;
   for (long k = 0; k < ntotal; k++) {
     const int o = order[k], W = (o >> 30) & 1;
     const long b = o & 0x3fffffff;
-    amp += (W ? secs1 : secs0) * att;  // _vp_ampmax_decay with vd->W = this block's size class
-    if (amp < -9999) amp = -9999;
+    if (!(first_given && k == 0)) {  // (first_given: `state` is what block 0 receives, already decayed by the caller's blockout)
+      amp += (W ? secs1 : secs0) * att;  // _vp_ampmax_decay with vd->W = this block's size class
+      if (amp < -9999) amp = -9999;
+    }
     (W ? in1 : in0)[b] = amp;
     const float *loc = W ? local1 : local0;
     for (int c = 0; c < ch; c++) {
@@ -2224,7 +2226,7 @@ int vamd_analyze_stream(vamd_ctx *c, const vamd_batch_desc *desc, const vamd_bat
 static int run_streams_mixed(vamd_ctx *c, const vamd_batch_desc *desc_short, const vamd_batch_io *io_short,
                              const vamd_batch_desc *desc_long, const vamd_batch_io *io_long, const int32_t *order,
                              long nblocks_total, float *ampmax_state, const int64_t *stream_start, long nstreams,
-                             float *states) {
+                             float *states, bool first_given = false) {
   if (desc_short->W != 0 || desc_long->W != 1) return fail(c, VAMD_EINVAL, "desc_short->W must be 0, desc_long->W 1");
   if (nblocks_total != desc_short->nblocks + desc_long->nblocks || (nblocks_total && !order))
     return fail(c, VAMD_EINVAL, "order[] must name every block of both batches exactly once");
@@ -2263,7 +2265,7 @@ static int run_streams_mixed(vamd_ctx *c, const vamd_batch_desc *desc_short, con
   else
     hipLaunchKernelGGL(k_ampmax_stream_mixed, dim3(1), dim3(1), 0, s, c->B.channels, nblocks_total, (const int *)order, secs0,
                        secs1, c->B.ampmax_att_per_sec, *ampmax_state, R[0].p.local, R[1].p.local, R[0].p.ampin,
-                       R[1].p.ampin, R[0].p.ampglob, R[1].p.ampglob, d_state);
+                       R[1].p.ampin, R[0].p.ampglob, R[1].p.ampglob, d_state, first_given ? 1 : 0);
   s = c->stream;
   prof_mark(c, VAMD_ST_AMPMAX);
   R[0].d.ampmax_in = R[0].p.ampin;
@@ -2493,6 +2495,122 @@ int vamd_encode_block(vamd_ctx *c, const float *const *pcm, int lW, int W, int n
     size_t bytes = ((size_t)(packet_bits[k] > 0 ? packet_bits[k] : 0) + 7) / 8;
     if (bytes > row) bytes = row;  // (cut off: packet_bits says so)
     memcpy(packets + k * (size_t)packet_stride, hs + o_pk + k * row, bytes);
+  }
+  return VAMD_OK;
+}
+
+// N consecutive blocks of ONE stream from host memory to their packets in one launch sequence (the binding's look-ahead,
+// integration/mapping0_vamd.c): what vamd_encode_block does for one block, with the ampmax chain between them on the device.
+int vamd_encode_blocks(vamd_ctx *c, long nblocks, const float *const *pcm, const int32_t *lW, const int32_t *W,
+                       const int32_t *nW, const int32_t *blocktype, float ampmax_in_first, float *ampmax_in, float *ampmax_out,
+                       uint8_t *packets, long packet_stride, int32_t *packet_bits, int32_t *verdict) {
+  DeviceGuard dev_guard(c);
+  if (!c) return VAMD_EINVAL;
+  if (nblocks < 0 || nblocks > 0x3fffffffL) return fail(c, VAMD_EINVAL, "nblocks out of range");
+  if (nblocks == 0) return VAMD_OK;
+  if (!pcm || !lW || !W || !nW || !blocktype || !packets || !packet_bits || !verdict) return fail(c, VAMD_EINVAL, "null argument");
+  if (packet_stride < 4) return fail(c, VAMD_EINVAL, "packet_stride too small");
+  const size_t ch = c->B.channels;
+  if (c->B.pack[0].capacity == 0 || c->B.pack[1].capacity == 0)
+    return fail(c, VAMD_EIMPL, "this mode's packets are not assembled on the GPU (its residue back-end is not covered)");
+  if (c->K.fail_encode_after >= 0) {  // (test knob, as in vamd_encode_block)
+    static std::atomic<long> calls{0};
+    if (calls.fetch_add(1) >= c->K.fail_encode_after) return fail(c, VAMD_EFAULT, "injected failure (VAMD_FAIL_ENCODE_AFTER)");
+  }
+  long nb[2] = {0, 0};
+  for (long b = 0; b < nblocks; b++) {
+    if (W[b] != 0 && W[b] != 1) return fail(c, VAMD_EINVAL, "W must be 0 or 1");
+    if ((lW[b] & ~1) || (nW[b] & ~1) || (blocktype[b] & ~1)) return fail(c, VAMD_EINVAL, "lW / nW / blocktype must be 0 or 1");
+    for (size_t k = 0; k < ch; k++)
+      if (!pcm[b * ch + k]) return fail(c, VAMD_EINVAL, "null channel pointer");
+    nb[W[b]]++;
+  }
+  auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
+  // one pinned arena, read and written in place by the kernels (mapped): per size class [pcm | lW | nW | blocktype |
+  // ampmax_out | bits | status | packets], then the stream order
+  size_t o_pcm[2], o_lW[2], o_nW[2], o_bt[2], o_amp[2], o_bits[2], o_st[2], o_pk[2], row[2], at = 0;
+  for (int w = 0; w < 2; w++) {
+    const size_t n = c->B.bs[w], cap = (size_t)c->B.pack[w].capacity;
+    row[w] = cap < (size_t)packet_stride ? cap : ((size_t)packet_stride & ~(size_t)3);
+    o_pcm[w] = at, at = al(at + (size_t)nb[w] * ch * n * 4);
+    o_lW[w] = at, at = al(at + (size_t)nb[w] * 4);
+    o_nW[w] = at, at = al(at + (size_t)nb[w] * 4);
+    o_bt[w] = at, at = al(at + (size_t)nb[w] * 4);
+    o_amp[w] = at, at = al(at + (size_t)nb[w] * 4);
+    o_bits[w] = at, at = al(at + (size_t)nb[w] * 4);
+    o_st[w] = at, at = al(at + (size_t)nb[w] * ch);
+    o_pk[w] = at, at = al(at + (size_t)nb[w] * row[w]);
+  }
+  const size_t o_order = at, total = al(o_order + (size_t)nblocks * 4);
+  if (c->h_stage_bytes < total) {
+    if (c->h_stage) HIP_TRY(c, hipHostFree(c->h_stage));
+    c->h_stage = nullptr;
+    c->h_stage_bytes = 0;
+    HIP_TRY(c, hipHostMalloc(&c->h_stage, total + total / 2, hipHostMallocDefault));
+    c->h_stage_bytes = total + total / 2;
+  }
+  unsigned char *hs = (unsigned char *)c->h_stage;
+  void *mapped = nullptr;
+  HIP_TRY(c, hipHostGetDevicePointer(&mapped, hs, 0));
+  unsigned char *ds = (unsigned char *)mapped;
+  std::vector<long> slot((size_t)nblocks);  // block b's index inside its size class
+  long seen[2] = {0, 0};
+  for (long b = 0; b < nblocks; b++) {
+    const int w = W[b];
+    const long i = seen[w]++;
+    const size_t n = c->B.bs[w];
+    slot[(size_t)b] = i;
+    for (size_t k = 0; k < ch; k++) memcpy(hs + o_pcm[w] + ((size_t)i * ch + k) * n * 4, pcm[b * ch + k], n * 4);
+    ((int32_t *)(hs + o_lW[w]))[i] = lW[b];
+    ((int32_t *)(hs + o_nW[w]))[i] = nW[b];
+    ((int32_t *)(hs + o_bt[w]))[i] = blocktype[b];
+    ((int32_t *)(hs + o_order))[b] = (int32_t)((w << 30) | (int)i);
+  }
+  vamd_batch_desc d[2];
+  vamd_batch_io io[2];
+  memset(d, 0, sizeof(d));
+  memset(io, 0, sizeof(io));
+  for (int w = 0; w < 2; w++) {
+    d[w].W = w;
+    d[w].nblocks = nb[w];
+    d[w].lW = (const int32_t *)(ds + o_lW[w]);
+    d[w].nW = (const int32_t *)(ds + o_nW[w]);
+    d[w].blocktype = (const int32_t *)(ds + o_bt[w]);
+    io[w].pcm = (const float *)(ds + o_pcm[w]);
+    io[w].ampmax_out = (float *)(ds + o_amp[w]);
+    io[w].status = ds + o_st[w];
+    io[w].packets = ds + o_pk[w];
+    io[w].packet_bits = (int32_t *)(ds + o_bits[w]);
+    io[w].packet_stride = (int64_t)row[w];
+  }
+  float state = ampmax_in_first;
+  int r = run_streams_mixed(c, &d[0], &io[0], &d[1], &io[1], (const int32_t *)(ds + o_order), nblocks, &state, nullptr, 0, nullptr,
+                            true);  // (synchronises: the chain's final state comes back)
+  if (r) return r;
+  const float att = c->B.ampmax_att_per_sec;
+  float prev_out = 0.f;
+  for (long b = 0; b < nblocks; b++) {
+    const int w = W[b];
+    const long i = slot[(size_t)b];
+    const float out = ((const float *)(hs + o_amp[w]))[i];
+    if (ampmax_in) {  // what the block received: the caller's figure, then _vp_ampmax_decay of its predecessor's (lib/psy.c:837-848)
+      float a = ampmax_in_first;
+      if (b > 0) {
+        a = prev_out + ((float)(c->B.bs[w] / 2) / (float)c->B.rate) * att;
+        if (a < -9999) a = -9999;
+      }
+      ampmax_in[b] = a;
+    }
+    prev_out = out;
+    if (ampmax_out) ampmax_out[b] = out;
+    unsigned any = 0;
+    for (size_t k = 0; k < ch; k++) any |= hs[o_st[w] + (size_t)i * ch + k];
+    verdict[b] = (any & VAMD_STATUS_NONFINITE) ? VAMD_ENONFINITE : ((any & VAMD_STATUS_RANGE) ? VAMD_EDOMAIN : VAMD_OK);
+    const int32_t bits = ((const int32_t *)(hs + o_bits[w]))[i];
+    packet_bits[b] = bits;
+    size_t bytes = ((size_t)(bits > 0 ? bits : 0) + 7) / 8;
+    if (bytes > row[w]) bytes = row[w];  // (cut off: packet_bits says so)
+    if (verdict[b] == VAMD_OK) memcpy(packets + (size_t)b * (size_t)packet_stride, hs + o_pk[w] + (size_t)i * row[w], bytes);
   }
   return VAMD_OK;
 }
