@@ -69,7 +69,7 @@ def source_hash():
     h = hashlib.sha256()
     for d in ("vorbis_amd/csrc", "include"):
         for f in sorted(os.listdir(os.path.join(ROOT, d))):
-            if f.endswith((".h", ".hip")):
+            if f.endswith((".h", ".hip", ".inc")):
                 h.update(f.encode())
                 h.update(open(os.path.join(ROOT, d, f), "rb").read())
     return h.hexdigest()[:16]

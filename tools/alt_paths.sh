@@ -10,3 +10,5 @@ run() { echo "== $*"; env "$@" timeout 900 python -m pytest tests -m gpu -q -x 2
 run VAMD_MASKS_SEPARATE=1 VAMD_PACK_PAIR_MAX=0 VAMD_RES_TEAM_MAX=0
 run VAMD_CHASE_WAVE_MAX=0 VAMD_NO_OVERLAP=1
 run VAMD_STAGE_COPIES=1 VAMD_FOLD_SEPARATE=1
+run VAMD_FLOOR_PAIR_MIN=0                    # two channels per wave in the floor stage at every size, both size classes
+run VAMD_FLOOR_PAIR_MIN=2000000000           # ... and never

@@ -89,56 +89,7 @@ VAMD_DEV void seed_curve_scatter(float *seed, const float *__restrict__ band_row
 //             therefore lines further on (linesper <= 16).  The one-lane test build, whose chunks are single entries,
 //             hands over a copy of the unpainted lines instead.
 //   posstack  the survivor list (HBM);  head  its first two chunks as fetched ahead by surv_head_load (optional)
-struct SurvHead {
-  int p1, np1, p2, np2;  // entries LANE, LANE + 1, LANE + NLANES, LANE + NLANES + 1, whatever the list's length
-};
-// (a block's list row is nlines entries long whatever the count, so reading past the count stays in the row: callers
-// keep two chunks + 1 entries readable)
-VAMD_DEV SurvHead surv_head_load(const unsigned short *__restrict__ posstack) {
-  SurvHead h;
-  h.p1 = posstack[LANE], h.np1 = posstack[LANE + 1];
-  h.p2 = posstack[LANE + NLANES], h.np2 = posstack[LANE + NLANES + 1];
-  return h;
-}
-VAMD_DEV void seed_chase_paint(float *seeds, const float *src, int linesper, int n, int stack,
-                               const unsigned short *__restrict__ posstack, const SurvHead *head = nullptr) {
-  int carry = 0;
-  // Software pipeline over the chunks of 64 survivors: the list entries are fetched two chunks ahead and the
-  // amplitudes they point at one chunk ahead, so that a chunk finds both in registers.
-  auto at = [&](int k) { return k < stack ? (int)posstack[k] : 0; };
-  int pos1, npos1, pos2, npos2;
-  if (head) {
-    pos1 = LANE < stack ? head->p1 : 0, npos1 = LANE + 1 < stack ? head->np1 : 0;
-    pos2 = LANE + NLANES < stack ? head->p2 : 0, npos2 = LANE + NLANES + 1 < stack ? head->np2 : 0;
-  } else {
-    pos1 = at(LANE), npos1 = at(LANE + 1);                    // chunk 0
-    pos2 = at(LANE + NLANES), npos2 = at(LANE + NLANES + 1);  // chunk 1
-  }
-  float a1 = src[pos1], an1 = src[npos1];
-  for (int base = 0; base < stack; base += NLANES) {
-    const int k = base + LANE;
-    const int pos = pos1, npos = npos1;
-    const float a = a1, an = an1;
-    pos1 = pos2, npos1 = npos2;
-    a1 = src[pos1], an1 = src[npos1];
-    pos2 = at(k + 2 * NLANES), npos2 = at(k + 2 * NLANES + 1);
-    int endpos = 0;
-    if (k < stack) {
-      endpos = pos + linesper + 1;
-      if (k < stack - 1 && an > a) endpos = npos;
-      if (endpos > n) endpos = n;
-    }
-    const int incl = wave_scan_max(endpos);
-    int start = wave_shift_up1(incl, 0);
-    if (start < carry) start = carry;
-    // (a wave's LDS accesses keep their order: the next chunk's amplitudes, asked for above, are read before this
-    // chunk's paint lands)
-    if (k < stack)
-      for (int p = start; p < endpos; p++) seeds[p] = a;
-    const int last = wave_last(incl);
-    if (last > carry) carry = last;
-  }
-}
+#include "k_tone_fold.inc"  // SurvHead, surv_head_load, seed_chase_paint, tone_fold_prepare, tone_ath_att, tone_fold_quad
 
 // Thread-per-block form of seed_chase part 1.  Only the top ~9 stack entries can
 // ever be popped or inspected (an entry more than `linesper` lines behind the
@@ -418,63 +369,6 @@ VAMD_DEV void tone_seed_block(const PsyP &P, const float *__restrict__ peaks, fl
   pc.mark(1);
 }
 
-// paint + fold half: seed[] (LDS, unpainted on entry), its unpainted HBM copy, the survivor
-// list -> tone curve
-// ... in two steps, so that a caller can take the curve quad by quad (k_floor mixes it without a trip through memory):
-// tone_fold_prepare leaves the painted lines and the groups' minima in LDS, tone_fold_quad forms four bins from them.
-VAMD_DEV void tone_fold_prepare(const PsyP &P, float *seed, const float *seed_src,
-                                const unsigned short *__restrict__ surv, int nsurv, float *gmin /* LDS [ngroups] */,
-                                PhaseClock &pc, int slot = 3, const SurvHead *head = nullptr) {
-  const int nlines = P.total_octave_lines;
-  seed_chase_paint(seed, seed_src, P.eighth_octave_lines, nlines, nsurv, surv, head);
-  WAVE_SYNC();
-  pc.mark(slot);
-
-  // max_seeds' fold, lib/psy.c:522-543.  Each outer-loop iteration ("group") of the
-  // reference starts from seed[p0] (capped at tone_abs_limit) and then keeps the lowest
-  // real (> NEGINF) value among the lines it scans -- a min, hence order-free: every
-  // line is folded into its group with an LDS float min, then every bin combines its
-  // group's start value and scanned minimum.  Work is balanced over lines and bins
-  // instead of leaving the few low bins with 70-line spans to single lanes.
-  WAVE_FOR(g, P.ngroups) gmin[g] = f_from_bits(0x7f800000u);  // +inf = "no real value scanned"
-  WAVE_SYNC();
-  WAVE_FOR(p, nlines) {
-    const int g = P.line_group[p];
-    const float s = seed[p];
-    if (g != 0xffff && s > VAMD_NEGINF) lds_atomic_min(gmin + g, s);
-  }
-  WAVE_SYNC();
-  pc.mark(slot + 1);
-}
-VAMD_DEV float tone_ath_att(const PsyP &P, float local_ampmax) {
-  float att = local_ampmax + P.ath_adjatt;
-  return att < P.ath_maxatt ? P.ath_maxatt : att;
-}
-VAMD_DEV void tone_fold_quad(const PsyP &P, float att, const float *seed, const float *gmin, int q, float *o) {
-  const int nlines = P.total_octave_lines;
-  const I4 bf = ((const I4 *)P.bin_fold)[q];
-  const int bfs[4] = {bf.x, bf.y, bf.z, bf.w};
-  float av[4];
-  f4_get(((const F4 *)P.ath)[q], av);
-#pragma unroll
-  for (int c = 0; c < 4; c++) {
-    const int i = (q << 2) + c;
-    float minV;
-    if (i >= P.tail_linpos) {
-      minV = seed[nlines - 1];
-    } else {
-      minV = seed[bfs[c] & 0xffff];
-      if (minV > P.tone_abs_limit) minV = P.tone_abs_limit;
-      const float rest = gmin[bfs[c] >> 16];
-      if (rest < f_from_bits(0x7f800000u)) {
-        if (minV == VAMD_NEGINF || rest < minV) minV = rest;
-      }
-    }
-    float v = av[c] + att;
-    if (v < minV) v = minV;
-    o[c] = v;
-  }
-}
 VAMD_DEV void tone_fold_block(const PsyP &P, float local_ampmax, float *seed, const float *seed_src,
                               const unsigned short *__restrict__ surv, int nsurv, float *gmin /* LDS [ngroups] */,
                               float *__restrict__ out, PhaseClock &pc) {

@@ -27,6 +27,7 @@
 #include "k_noise.h"
 #include "k_tone.h"
 #include "k_floor.h"
+#include "vamd_wave_pair.h"
 #include "k_couple.h"
 #include "k_envelope.h"
 #include "k_residue.h"
@@ -64,6 +65,19 @@ __device__ __forceinline__ void flag_range(const DescP &d, long i) {
 // Waves never synchronise with each other after the staging barrier (WAVE_SYNC is
 // wave-local), so they drift apart and overlap each other's memory phases.
 #define VAMD_XF_WAVES 8
+// channel-blocks from which the floor stage takes the two channels of a stereo block in one wave (k_floor_pair), per size
+// class.  Measured round 5 (profiles/r05_floor_pair.txt, tools/floor_pair_ab.sh): SHORT blocks gain -- their 128 bins and
+// 13 / 19 posts leave half of a wave's lanes idle in every phase of k_floor: C5's floor 3.80 -> 3.53 ms, the step
+// 11.38 -> 11.09 ms, at six waves per SIMD (77 registers) -- from a batch that fills the chip; LONG blocks lose at every
+// occupancy (1.96 -> 2.42 ms at best: 12 % fewer vector instructions per channel-block, but 9.6 KB of LDS per wave
+// hold the CU to sixteen waves, and the half-uniform reads of the ordered sections go through the LDS pipe where
+// v_readlane did not: 64 % of the issue slots used against 100 %) -- never.
+#ifndef VAMD_FLOOR_PAIR_MIN_LONG
+#define VAMD_FLOOR_PAIR_MIN_LONG 0x7fffffffL
+#endif
+#ifndef VAMD_FLOOR_PAIR_MIN_SHORT
+#define VAMD_FLOOR_PAIR_MIN_SHORT 16384L
+#endif
 
 struct XformLds {
   XformP P;       // table pointers rebound to the LDS copies
@@ -675,6 +689,53 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                                          ilogmask + cb * n2, pc, wrapped ? wrapped + cb * VAMD_POSTS_STRIDE : nullptr);
   if (LANE == 0) nonzero[cb] = nzf;
   pc.flush();
+}
+
+// The same stage with the two channels of a stereo block in ONE wave, 32 lanes each (vamd_wave_pair.h: the bodies of
+// k_floor.inc compiled against the half-wave vocabulary).  One pass through the ordered sections -- the greedy split loop,
+// the level loops -- serves both channels, and a short block's 128 bins fill a half where they left half a wave idle.
+// Launched for stereo setups whose two channels share a floor (launch_rest); everything per block (psy look, floor,
+// sizes) is wave-uniform as before, everything per channel lives in the half's lanes.  LDS: `half_bytes` per half.
+#ifndef VAMD_FLOOR_PAIR_WAVES
+#define VAMD_FLOOR_PAIR_WAVES 6  // waves per SIMD: 77 registers, nothing spilt (4 / 5 / 6 / 8 measured)
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VAMD_FLOOR_PAIR_WAVES, VAMD_FLOOR_PAIR_WAVES))) void k_floor_pair(const Bound *__restrict__ Bd, int W, DescP d, int half_bytes,
+                                                   const float *__restrict__ noise, float *__restrict__ tone,
+                                                   const float *__restrict__ seed_g, const unsigned short *__restrict__ surv,
+                                                   const int *__restrict__ nsurv, const float *__restrict__ local_ampmax, int nlp,
+                                                   const float *__restrict__ mdct_raw,
+                                                   float *__restrict__ mdct, float *__restrict__ logmask_out,
+                                                   int *__restrict__ posts, int *__restrict__ post_valid,
+                                                   ilog_t *__restrict__ ilogmask, int *__restrict__ nonzero,
+                                                   int *__restrict__ wrapped /* [cb][VAMD_POSTS_STRIDE] for k_pack, or null */) {
+  typedef vamd::pair::Bodies vp;
+  const long blk = blockIdx.x;
+  const long cb = blk * 2 + VAMD_PAIR_HALF;
+  const PsyP &P = Bd->psy[2 * W + (d_bt(d, blk) ? 1 : 0)];
+  const FloorP &F = Bd->floor[W][Bd->chmap[W].sub[0]];  // (both channels' floor: the launch checked)
+  const int n2 = P.n;
+  unsigned char *mine = vamd_smem + (size_t)VAMD_PAIR_HALF * half_bytes;
+  unsigned short *qc = (unsigned short *)mine;  // [n2 rounded up to 16]
+  vp::FloorScratch *sc = (vp::FloorScratch *)(qc + ((n2 + 15) & ~15));
+  PhaseClock pc;
+  pc.start(nullptr);
+  if (seed_g) {
+    float *seed = (float *)mine;  // [nlp], then the group minima
+    const bool ahead = nlp >= 2 * 32 + 2;
+    vp::SurvHead head;
+    if (ahead) head = vp::surv_head_load(surv + cb * nlp);
+    for (int q = (int)(threadIdx.x & 31); q < (nlp >> 2); q += 32) ((F4 *)seed)[q] = ((const F4 *)(seed_g + cb * nlp))[q];
+    WAVE_SYNC();
+    vp::tone_fold_prepare(P, seed, seed, surv + cb * nlp, nsurv[cb], seed + nlp, pc, 5, ahead ? &head : nullptr);
+    vp::fold_and_mix_wave(P, vp::tone_ath_att(P, local_ampmax[cb]), seed, seed + nlp, noise + cb * n2, tone ? tone + cb * n2 : nullptr,
+                          mdct_raw + cb * n2, mdct + cb * n2, logmask_out ? logmask_out + cb * n2 : nullptr, qc, F.twofitatten, pc);
+  } else {
+    vp::offset_and_mix_wave(P, noise + cb * n2, tone + cb * n2, mdct_raw + cb * n2, mdct + cb * n2,
+                            logmask_out ? logmask_out + cb * n2 : nullptr, qc, F.twofitatten, pc);
+  }
+  const int nzf = vp::floor_fit_render_block(F, n2, qc, sc, posts + cb * VAMD_POSTS_STRIDE, post_valid + cb,
+                                             ilogmask + cb * n2, pc, wrapped ? wrapped + cb * VAMD_POSTS_STRIDE : nullptr);
+  if ((threadIdx.x & 31) == 0) nonzero[cb] = nzf;
 }
 
 // the int32 `ilogmask` tap of the C ABI from the 16-bit curve the stages exchange
@@ -2040,6 +2101,19 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_
     const size_t floor_pad = (size_t)c->K.floor_lds_pad;  // (experiment: occupancy)
     size_t floor_lds = (size_t)((n2 + 15) & ~15) * 2 + sizeof(FloorScratch) + floor_pad;
     if (fold_in_floor && fold_lds > floor_lds) floor_lds = fold_lds;
+    // two channels per wave (k_floor_pair) for stereo setups whose channels share a floor of at most 32 posts, from
+    // `floor_pair_min` channel-blocks up (a test knob; the default is set by what was measured: DESIGN section 6)
+    const FloorP &F0 = c->B.floor[W][c->B.chmap[W].sub[0]];
+    const long pair_min = c->K.floor_pair_min >= 0 ? c->K.floor_pair_min : (W ? VAMD_FLOOR_PAIR_MIN_LONG : VAMD_FLOOR_PAIR_MIN_SHORT);
+    const bool paired = ch == 2 && c->B.chmap[W].sub[0] == c->B.chmap[W].sub[1] && F0.posts <= 32 && (long)gcb >= pair_min && pair_min >= 0 &&
+                        ((c->K.floor_pair_w >> W) & 1) &&
+                        n2 <= 32 * 4 * 8 && 2 * floor_lds <= c->lds_per_block;
+    if (paired)
+      hipLaunchKernelGGL(k_floor_pair, dim3(gb), dim3(64), 2 * floor_lds, s,
+                         (const Bound *)c->d_bound, W, d, (int)floor_lds, p.noise, fold_in_floor ? R->io->tone : p.tone, fold_in_floor ? p.seed : nullptr, p.surv, p.nsurv, p.local,
+                         nlp_all, p.mdct_raw, p.mdct,
+                         R->io->logmask, p.posts, p.post_valid, p.ilogmask, p.nonzero, p.wrapped);
+    else
     hipLaunchKernelGGL(k_floor, dim3(gcb), dim3(64), floor_lds, s,
                        (const Bound *)c->d_bound, W, d, ch, p.noise, fold_in_floor ? R->io->tone : p.tone, fold_in_floor ? p.seed : nullptr, p.surv, p.nsurv, p.local,
                        nlp_all, p.mdct_raw, p.mdct,

@@ -34,6 +34,7 @@ struct Knobs {
   int noise_teams = 0;           // VAMD_NOISE_TEAMS: noise teams per CU (0: chosen by the launch)
   long floor_lds_pad = 0;        // VAMD_FLOOR_LDS_PAD: extra LDS per k_floor wave (an occupancy experiment)
   long floor_pair_min = -1;      // VAMD_FLOOR_PAIR_MIN: channel-blocks from which k_floor pairs channels (-1: default)
+  int floor_pair_w = 3;          // VAMD_FLOOR_PAIR_W: size classes that may pair (bit 0 short, bit 1 long)
   bool stage_copies = false;     // VAMD_STAGE_COPIES: copy commands instead of the mapped pinned arena
   bool env_untiled = false;      // VAMD_ENV_UNTILED: the detector's thread-per-item kernels at every size
   int xf_variant = -1;           // VAMD_XF_VARIANT: transform kernel variant (-1: default)
@@ -66,6 +67,7 @@ inline Knobs read_knobs() {
       k.noise_teams = (int)num("VAMD_NOISE_TEAMS", 0);
       k.floor_lds_pad = num("VAMD_FLOOR_LDS_PAD", 0);
       k.floor_pair_min = num("VAMD_FLOOR_PAIR_MIN", -1);
+      k.floor_pair_w = (int)num("VAMD_FLOOR_PAIR_W", 3);
       k.stage_copies = on("VAMD_STAGE_COPIES");
       k.env_untiled = on("VAMD_ENV_UNTILED");
       k.xf_variant = (int)num("VAMD_XF_VARIANT", -1);
@@ -84,11 +86,11 @@ inline void knobs_string(const Knobs &k, char *buf, size_t cap) {
     snprintf(buf + n, cap - (size_t)n,
              " VAMD_NO_OVERLAP=%d VAMD_COUPLE_BAND_LOG2=%s%d VAMD_XF_WAVES_CAP=%d VAMD_RES_TEAM_MAX=%ld VAMD_PACK_PAIR_MAX=%ld"
              " VAMD_FOLD_SEPARATE=%d VAMD_CHASE_WAVE_MAX=%ld VAMD_MASKS_SEPARATE=%d VAMD_NOISE_TEAMS=%d VAMD_FLOOR_LDS_PAD=%ld"
-             " VAMD_FLOOR_PAIR_MIN=%ld VAMD_STAGE_COPIES=%d VAMD_ENV_UNTILED=%d VAMD_XF_VARIANT=%d VAMD_FAIL_ENVELOPE_AFTER=%ld"
+             " VAMD_FLOOR_PAIR_MIN=%ld VAMD_FLOOR_PAIR_W=%d VAMD_STAGE_COPIES=%d VAMD_ENV_UNTILED=%d VAMD_XF_VARIANT=%d VAMD_FAIL_ENVELOPE_AFTER=%ld"
              " VAMD_FAIL_ENCODE_AFTER=%ld",
              (int)k.no_overlap, k.couple_band_set ? "" : "unset:", k.couple_band_log2, k.xf_waves_cap, k.res_team_max,
              k.pack_pair_max, (int)k.fold_separate, k.chase_wave_max, (int)k.masks_separate, k.noise_teams, k.floor_lds_pad,
-             k.floor_pair_min, (int)k.stage_copies, (int)k.env_untiled, k.xf_variant, k.fail_envelope_after,
+             k.floor_pair_min, k.floor_pair_w, (int)k.stage_copies, (int)k.env_untiled, k.xf_variant, k.fail_envelope_after,
              k.fail_encode_after);
 }
 

@@ -113,6 +113,11 @@ VAMD_DEV int wave_scan_sum(int v) {  // inclusive prefix sum over the lanes
   return v;
 }
 VAMD_DEV int wave_any(int pred) { return __any(pred); }
+// the lanes for which `pred` holds, bit l = lane l; a value of lane `lane` (wave-uniform index: one v_readlane); a value
+// of a lane of each lane's own choosing (ds_bpermute)
+VAMD_DEV unsigned long long wave_ballot(bool pred) { return __ballot(pred); }
+VAMD_DEV int wave_read(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+VAMD_DEV int wave_gather(int v, int lane) { return __shfl(v, lane, 64); }
 VAMD_DEV unsigned long long wave_or64(unsigned long long x) {
   int lo = (int)(unsigned int)x, hi = (int)(unsigned int)(x >> 32);
   VAMD_DPP_SCAN_SELF(lo, VAMD_OP_OR)
