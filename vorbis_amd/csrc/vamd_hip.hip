@@ -169,7 +169,10 @@ __global__ __launch_bounds__(64 * VAMD_MD_WAVES) void k_mdct_only(XformP G, int 
 #define VAMD_XF_VGPRS 256
 #endif
 template <int LOGN>
-__global__ __launch_bounds__(64 * VAMD_XF_WAVES) __attribute__((amdgpu_num_vgpr(VAMD_XF_VGPRS))) void k_transform(XformP G, int W, DescP d, int ch, long ncb,
+#ifndef VAMD_XF_BOUND_WAVES  // (scratch builds: the register budget of a workgroup of this many waves, whatever is launched)
+#define VAMD_XF_BOUND_WAVES VAMD_XF_WAVES
+#endif
+__global__ __launch_bounds__(64 * VAMD_XF_BOUND_WAVES) __attribute__((amdgpu_num_vgpr(VAMD_XF_VGPRS))) void k_transform(XformP G, int W, DescP d, int ch, long ncb,
                                                                  const float *__restrict__ pcm,
                                                                  float *__restrict__ mdct_raw,
                                                                  float *__restrict__ logmdct,
@@ -204,12 +207,21 @@ __global__ __launch_bounds__(64 * VAMD_XF_WAVES) __attribute__((amdgpu_num_vgpr(
     pcm_fetch(tile, samples(cb, blk), n, tm);
   }
   for (; cb < ncb; cb += cstride) {
+#ifdef VAMD_XF_NO_PREFETCH  // (scratch builds, profiles/r05_xf_variants.txt: what the next block's samples in registers are worth)
+    {
+      const long blk0 = (long)((unsigned)cb / (unsigned)ch);
+      lW = d_lW(d, blk0), nW = d_nW(d, blk0);
+      pcm_fetch(tile, samples(cb, blk0), n, tm);
+    }
+#endif
     transform_window(P, W, lW, nW, tile, L.A, pc, tm);
+#ifndef VAMD_XF_NO_PREFETCH
     if (cb + cstride < ncb) {  // next block, one ahead
       const long blk = (long)((unsigned)(cb + cstride) / (unsigned)ch);
       lW = d_lW(d, blk), nW = d_nW(d, blk);
       pcm_fetch(tile, samples(cb + cstride, blk), n, tm);
     }
+#endif
     float raw;
     // (logfft goes out as what the tone stage reads of it -- its peak over each run of bins of one octave line, nrp
     // floats per channel-block -- and in full only where a caller taps it)
