@@ -75,9 +75,9 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-TRAFFIC_PROFILE = "profiles/r04_pmc_traffic.json"
-TRAFFIC_PROFILE_C5 = "profiles/r04_c5_pmc_traffic.json"
-VALU_PROFILE = "profiles/r04_pmc_valu.json"
+TRAFFIC_PROFILE = "profiles/r05_pmc_traffic.json"
+TRAFFIC_PROFILE_C5 = "profiles/r05_c5_pmc_traffic.json"
+VALU_PROFILE = "profiles/r05_pmc_valu.json"
 
 
 def measured_valu(workload, units, stage_ms, clock_ghz=None):
@@ -94,7 +94,7 @@ def measured_valu(workload, units, stage_ms, clock_ghz=None):
     if t.get("source_hash") != source_hash():
         return {"value": None, "note": "VALU profile %s was taken from other sources (%s, now %s): re-run tools/profile.sh"
                                        % (VALU_PROFILE, t.get("source_hash"), source_hash())}
-    stage_of = {"k_transform": "transform", "k_noise": "noisemask", "k_floor": "floor", "k_couple": "couple", "k_couple_norm": "couple",
+    stage_of = {"k_transform": "transform", "k_noise": "noisemask", "k_floor": "floor", "k_floor_pair": "floor", "k_couple": "couple", "k_couple_norm": "couple",
                 "k_tone_seed": "tonemask", "k_tone_chase": "tonemask", "k_tone_fold": "tonemask"}
     # SIMD cycles per second, whole chip: at the shader clock MEASURED over this run's timed region when there is one
     # (clock_probe below; the chip runs at 2.0-2.43 GHz depending on load), else at the profile's nominal figure
@@ -644,7 +644,7 @@ def roofline_of(a, R, stage_ms, clock):
     achieved = alg / (kernels_ms * 1e-3) / 1e9                # GB/s over the path's kernels
     dom_bytes = R.stage_bytes_total(dom)
     traffic, traffic_per, traffic_note = measured_traffic(a.workload, units, alg)
-    stage_of = {"k_transform": "transform", "k_noise": "noisemask", "k_floor": "floor", "k_couple": "couple", "k_couple_norm": "couple",
+    stage_of = {"k_transform": "transform", "k_noise": "noisemask", "k_floor": "floor", "k_floor_pair": "floor", "k_couple": "couple", "k_couple_norm": "couple",
                 "k_tone_seed": "tonemask", "k_tone_chase": "tonemask", "k_tone_fold": "tonemask", "k_tone": "tonemask"}
     dom_traffic = sum(v for k, v in traffic_per.items() if stage_of.get(k.split("<")[0]) == dom) or None
     return {

@@ -6,7 +6,7 @@ summaries under profiles/:  rNN_kernel_trace_stats.txt, rNN_pmc_hbm_traffic.txt,
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "profile")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"
 sys.path.insert(0, ROOT)
 import bench as bench_mod  # noqa: E402  (source_hash: the profile is stamped with the sources it was taken from)
 NB_PMC = int(sys.argv[2]) if len(sys.argv) > 2 else 131072  # tools/prof_run.py <NB> 1

@@ -1351,7 +1351,8 @@ static int envelope_search_batch(vamd_ctx *c, const float *pcm, long stream_stri
   if (nstreams * nsteps <= 65536)
     hipLaunchKernelGGL(k_env_bits, dim3((unsigned)((nstreams * nsteps * 16 + 255) / 256)), dim3(256), 0, s, E, ch, nstreams, nsteps,
                        amp, bits);
-  else if (!env_untiled) {
+  else if (!env_untiled && (size_t)4 * ch * VAMD_ENV_BROWS * 9 * 4 <= c->lds_per_block) {  // (the tile of 7.1 wants 88.7 KB: a part
+    // with 64 KB of LDS per workgroup takes the thread-per-step form below instead of failing the launch)
     const long items = nstreams * ((nsteps + 63) / 64);
     hipLaunchKernelGGL(k_env_bits_tiled, dim3((unsigned)((items + 3) / 4)), dim3(256), (size_t)4 * ch * VAMD_ENV_BROWS * 9 * 4, s, E, ch,
                        nstreams, nsteps, amp, bits);

@@ -191,11 +191,11 @@ struct DescP {
 //    BITS, lib/scales.h:43-51, so the dB value of a NaN is a large finite number -- which is also why no NaN ever
 //    reaches the maximum in transform_logfft); finite samples get there only from ~3e16 x full scale, where the
 //    reference's own fp32 power spectrum re*re + im*im overflows to Inf.  One compare per channel-block in k_transform.
-//  * THE REFERENCE'S INTEGERS.  Its residue search sums up to eight squared differences in an int
-//    (lib/res0.c:361-364), noise_normalize squares a quantised value in an int (lib/psy.c:985) and the quantised
-//    values themselves are float -> int conversions (:958-962): all defined by C while every quantised value stays
-//    within a bound that depends only on the setup's codebooks (derive_quant_limit, vamd_bind.h: ~10 000 for the
-//    libvorbisenc setups, i.e. spectra ~ +80 dB over full scale).  k_couple holds every value it writes against it.
+//  * THE REFERENCE'S INTEGERS.  Its quantised values are float -> int conversions (lib/psy.c:958-962), squared in an int
+//    where noise normalisation is at work (:985), and searched against codebooks with sums of squared differences in an
+//    int (lib/res0.c:361-364): defined by C while the values stay within the three bounds of QLimitP above (the last one
+//    13 000 - 32 000 for the libvorbisenc setups, i.e. spectra ~ +85 ... +90 dB over full scale).  k_couple holds every
+//    value it writes against the first two, k_residue every value it loads from a coded position against the third.
 #define VAMD_NONFINITE_DB 330.f
 #define VAMD_STATUS_RANGE 1      // bits of status[]
 #define VAMD_STATUS_NONFINITE 2
