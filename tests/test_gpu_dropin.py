@@ -51,8 +51,9 @@ def test_hybrid_encode_emits_reference_packets(ch, q, kind):
         assert sum(1 for b in want if b["W"] == 0) > 10
 
 
-@pytest.mark.parametrize("q,kind,write", [(0.4, "s16", 65536), (0.9, "gated", 65536), (0.4, "gated", 8192), (0.1, "gated", 30000)])
-def test_look_ahead_inside_one_stream_emits_reference_packets(q, kind, write):
+@pytest.mark.parametrize("ch,q,kind,write", [(2, 0.4, "s16", 65536), (2, 0.9, "gated", 65536), (2, 0.4, "gated", 8192),
+                                             (2, 0.1, "gated", 30000), (1, 0.5, "gated", 16384), (6, 0.3, "gated", 50000)])
+def test_look_ahead_inside_one_stream_emits_reference_packets(ch, q, kind, write):
     """An application that writes more than a block's worth per vorbis_analysis_wrote() (the API takes any amount,
     lib/block.c:390,470): the binding plans the blocks its buffer already determines, runs them as ONE batch
     (vamd_encode_blocks, the ampmax chain on the device) and serves the following vorbis_analysis() calls from those
@@ -63,9 +64,9 @@ def test_look_ahead_inside_one_stream_emits_reference_packets(q, kind, write):
     L = ref.lib(hybrid=True)
     h0 = [C.c_long(0) for _ in range(3)]
     L.vamd_ahead_stats(*[C.byref(v) for v in h0])
-    pcm = _stream(2, 6.0, kind, seed=4242)
-    want = ref.RefEncoder(2, 44100, q).encode_stream(pcm, write_frames=write)
-    got = ref.RefEncoder(2, 44100, q, hybrid=True).encode_stream(pcm, write_frames=write)
+    pcm = _stream(ch, 6.0, kind, seed=4242)
+    want = ref.RefEncoder(ch, 44100, q).encode_stream(pcm, write_frames=write)
+    got = ref.RefEncoder(ch, 44100, q, hybrid=True).encode_stream(pcm, write_frames=write)
     h1 = [C.c_long(0) for _ in range(3)]
     L.vamd_ahead_stats(*[C.byref(v) for v in h1])
     hits, misses, batches = (b.value - a.value for a, b in zip(h0, h1))

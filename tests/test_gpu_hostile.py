@@ -58,15 +58,20 @@ def test_mdct_only_path_propagates_like_ieee():
 
 
 @pytest.mark.skipif(not ref.hybrid_available(), reason="oracle/_ref/libvorbis_hybrid.so not built")
-def test_dropin_returns_ov_einval_and_the_next_stream_is_clean():
+@pytest.mark.parametrize("write", [1024, 20000])
+def test_dropin_returns_ov_einval_and_the_next_stream_is_clean(write):
     """Through the hybrid libvorbis: a stream with a NaN in it makes vorbis_analysis() return OV_EINVAL (-131) -- the
-    encode ends, as for any libvorbis error -- and an encoder opened afterwards emits the reference's packets."""
+    encode ends, as for any libvorbis error -- and an encoder opened afterwards emits the reference's packets.  (With
+    20 000-frame writes the verdict comes out of the look-ahead cache; sticky either way: every later block is refused.)"""
     rng = np.random.default_rng(9)
     pcm = (rng.random((2, 44100), dtype=np.float32) - 0.5)
     poisoned = pcm.copy()
     poisoned[1, 30000] = np.nan
     with pytest.raises(RuntimeError, match="-131"):
-        ref.RefEncoder(2, 44100, 0.4, hybrid=True).encode_stream(poisoned)
+        ref.RefEncoder(2, 44100, 0.4, hybrid=True).encode_stream(poisoned, write_frames=write)
+    seen = ref.RefEncoder(2, 44100, 0.4, hybrid=True).encode_stream(poisoned, write_frames=write, tolerate=True)
+    first = next(k for k, b in enumerate(seen) if b["error"])
+    assert first > 10 and all(b["error"] == -131 for b in seen[first:])
     want = ref.RefEncoder(2, 44100, 0.4).encode_stream(pcm)
     got = ref.RefEncoder(2, 44100, 0.4, hybrid=True).encode_stream(pcm)
     assert len(want) == len(got) > 20
@@ -74,7 +79,8 @@ def test_dropin_returns_ov_einval_and_the_next_stream_is_clean():
 
 
 @pytest.mark.skipif(not ref.hybrid_available(), reason="oracle/_ref/libvorbis_hybrid.so not built")
-def test_dropin_finite_block_beyond_the_bound_is_that_blocks_error_only():
+@pytest.mark.parametrize("write", [1024, 40000])
+def test_dropin_finite_block_beyond_the_bound_is_that_blocks_error_only(write):
     """Through the hybrid libvorbis: a FINITE burst ~94 dB over full scale (quantised values past the setup's integer bound,
     where lib/res0.c:361-364 leaves what C defines) makes vorbis_analysis() return OV_EINVAL for the blocks that hold it --
     and only for them.  The stream is not ended: the ampmax chain is carried over those blocks, and every block before and
@@ -83,8 +89,9 @@ def test_dropin_finite_block_beyond_the_bound_is_that_blocks_error_only():
     pcm = ((rng.random((2, 3 * 44100), dtype=np.float32) - 0.5) * 0.5).astype(np.float32)
     t = np.arange(1500)
     pcm[0, 60000:61500] += (5e4 * np.sin(0.3 * t)).astype(np.float32)
-    want = ref.RefEncoder(2, 44100, 0.4).encode_stream(pcm, tolerate=True)
-    got = ref.RefEncoder(2, 44100, 0.4, hybrid=True).encode_stream(pcm, tolerate=True)
+    # (write = 40000: the refused blocks come out of the binding's look-ahead cache, verdict and ampmax with them)
+    want = ref.RefEncoder(2, 44100, 0.4).encode_stream(pcm, tolerate=True, write_frames=write)
+    got = ref.RefEncoder(2, 44100, 0.4, hybrid=True).encode_stream(pcm, tolerate=True, write_frames=write)
     assert len(want) == len(got) > 60 and not any(b["error"] for b in want)
     refused = [k for k, b in enumerate(got) if b["error"]]
     assert refused and all(got[k]["error"] == -131 for k in refused)                  # OV_EINVAL
