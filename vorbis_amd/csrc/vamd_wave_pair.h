@@ -78,8 +78,23 @@ VAMD_DEV int wave_shift_up1(int v, int fill) {  // lane l of a half gets lane l-
   const int r = __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false);  // wave_shr:1 (lane 32 would get lane 31's)
   return (threadIdx.x & 31) == 0 ? fill : r;
 }
-// a value of lane `lane` of this lane's half; the index is the same for the lanes of a half, not for the wave
-VAMD_DEV int wave_read(int v, int lane) { return __shfl(v, VAMD_PAIR_BASE + lane, 64); }
+// a value of lane `lane` of this lane's half; the index is the same for the lanes of a half, not for the wave.
+// Two forms: through the LDS pipe (ds_bpermute: one instruction, a round trip of ~100 cycles on the ordered chain), or on
+// the vector unit alone -- the two halves' indices to scalar registers, two v_readlane, one select: five instructions,
+// no trip (VAMD_PAIR_READLANE; which one is measured in profiles/r05_floor_pair.txt)
+#ifndef VAMD_PAIR_READLANE
+#define VAMD_PAIR_READLANE 0
+#endif
+VAMD_DEV int half_read(int v, int lane) {
+#if VAMD_PAIR_READLANE
+  const int i0 = __builtin_amdgcn_readlane(lane, 0) & 31, i1 = __builtin_amdgcn_readlane(lane, 32) & 31;
+  const int a = __builtin_amdgcn_readlane(v, i0), b = __builtin_amdgcn_readlane(v, 32 + i1);
+  return VAMD_PAIR_HALF ? b : a;
+#else
+  return __shfl(v, VAMD_PAIR_BASE + lane, 64);
+#endif
+}
+VAMD_DEV int wave_read(int v, int lane) { return half_read(v, lane); }
 VAMD_DEV int wave_gather(int v, int lane) { return __shfl(v, VAMD_PAIR_BASE + lane, 64); }
 VAMD_DEV unsigned int load_uniform_u32(const unsigned int *p, int i) { return p[i]; }  // (half-uniform index: a vector load)
 VAMD_DEV void keep_opaque(int &v) { asm volatile("" : "+v"(v)); }
@@ -87,7 +102,7 @@ VAMD_DEV void keep_opaque(int &v) { asm volatile("" : "+v"(v)); }
 // A small array (<= 32 entries) kept one entry per lane of the half
 struct LaneInts {
   int v;
-  VAMD_MEM int get(int i) const { return __shfl(v, VAMD_PAIR_BASE + i, 64); }
+  VAMD_MEM int get(int i) const { return half_read(v, i); }
   VAMD_MEM void set(int i, int x) { v = ((int)(threadIdx.x & 31) == i) ? x : v; }
   VAMD_MEM void fill(int x) { v = x; }
   VAMD_MEM void load(const int *__restrict__ p, int count) { v = (int)(threadIdx.x & 31) < count ? p[threadIdx.x & 31] : 0; }
