@@ -28,7 +28,7 @@ def log(*a):
 
 log("# tools/soak.py %d : random-signal soak of the batch path against the reference's real vorbis_analysis()" % nb)
 log("# source_hash", bench.source_hash(), " started", time.strftime("%Y-%m-%d %H:%M:%S"))
-log("# signal kinds:", soak_lib.NKINDS, "(8-11: denormals, signed zeros, +30..+60 dB noise, +86 dB impulses)")
+log("# signal kinds:", soak_lib.NKINDS, "(8-11: denormals, signed zeros, +30..+60 dB noise, +86 dB impulses; 12-13: noise +60..+90 dB, a sine +70..+85 dB)")
 total, bad = soak_lib.run(nb, log=log)
 checks, hbad = soak_lib.run_hostile(48, log=log)
 log("SOAK", "FAILED" if bad else "OK", total, "blocks", bad, "mismatches")
