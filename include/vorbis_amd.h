@@ -401,19 +401,20 @@ int vamd_encode_block(vamd_ctx *ctx, const float *const *pcm, int lW, int W, int
 /* The same for `nblocks` CONSECUTIVE blocks of one stream, in stream order, in one launch sequence -- for a caller that
  * already holds the samples of several blocks: a libvorbis application that writes more than a block's worth per
  * vorbis_analysis_wrote() (lib/block.c:470-532) has determined every block its buffer covers, and the binding looks ahead
- * (integration/mapping0_vamd.c).  VBR encoders (one packet per block).  Host memory throughout:
+ * (integration/mapping0_vamd.c).  managed == 0: one packet per block (VBR); managed != 0: the fifteen
+ * candidate packets of a bitrate-managed block, as vamd_encode_block.  Host memory throughout:
  *   pcm[b * ch + c]   channel c of block b (blocksize[W[b]] samples), read during the call only
  *   lW / W / nW / blocktype [nblocks]   what vorbis_analysis_blockout decides per block (lib/block.c:589-611)
  *   ampmax_in_first   vbi->ampmax of block 0 as blockout left it; block b > 0 receives _vp_ampmax_decay of block b-1's
  *                     result exactly as the next blockout would hand it on (lib/block.c:626-628, lib/psy.c:837-848) --
  *                     ampmax_in[b] (optional out) is what each block received, ampmax_out[b] (optional) what it left
- *   packets [nblocks][packet_stride], packet_bits [nblocks]   as vamd_encode_block (rows need vamd_packet_capacity of
- *                     the larger size class)
+ *   packets [nblocks][1 or 15][packet_stride], packet_bits [nblocks][1 or 15]   as vamd_encode_block (rows need
+ *                     vamd_packet_capacity of the larger size class)
  *   verdict [nblocks] VAMD_OK, or VAMD_EDOMAIN / VAMD_ENONFINITE for a block outside the input domain (no packet; its
  *                     ampmax still feeds the chain, as the reference's would)
  * Returns VAMD_OK when the batch ran; per-block trouble is in verdict[]. */
 int vamd_encode_blocks(vamd_ctx *ctx, long nblocks, const float *const *pcm, const int32_t *lW, const int32_t *W,
-                       const int32_t *nW, const int32_t *blocktype, float ampmax_in_first, float *ampmax_in,
+                       const int32_t *nW, const int32_t *blocktype, float ampmax_in_first, int managed, float *ampmax_in,
                        float *ampmax_out, uint8_t *packets, long packet_stride, int32_t *packet_bits, int32_t *verdict);
 
 /* winlength / searchstep of the detector (128 / 64 in every libvorbis setup). */

@@ -72,13 +72,15 @@ typedef struct vamd_shared { /* one batcher per distinct setup (VAMD_BATCH mode)
  * sample.  A packet is a pure function of exactly those, so a hit is the packet the single-block path would have
  * produced; anything else (more data written in between and a decision changed, end of stream, a replay that went
  * astray) is a miss, which costs the cache and nothing else.  One GPU round trip per buffered stretch instead of one per
- * block.  VAMD_LOOKAHEAD=0 switches it off; VAMD_BATCH mode and bitrate-managed encoders do not use it. */
+ * block.  VBR and bitrate-managed encoders alike (a managed block's fifteen candidate packets ride the same batch; which
+ * one goes out is the bitrate manager's business afterwards, as before).  VAMD_LOOKAHEAD=0 switches it off; VAMD_BATCH
+ * mode does not use it. */
 #define VAMD_AHEAD_MAX 256
 typedef struct vamd_ahead_block {
   long sequence;
   int32_t lW, W, nW, blocktype;
   float ampmax_in, ampmax_out;
-  int32_t verdict, bits;
+  int32_t verdict;
   long pcm_at; /* offset (floats) of the block's [ch][n] samples in vamd_ahead.pcm */
 } vamd_ahead_block;
 typedef struct vamd_ahead {
@@ -86,8 +88,10 @@ typedef struct vamd_ahead {
   vamd_ahead_block blk[VAMD_AHEAD_MAX];
   float *pcm;                     /* the planned blocks' samples as they were sent (what a hit is verified against) */
   long pcm_cap;
-  unsigned char *packets;         /* [VAMD_AHEAD_MAX][stride] */
+  unsigned char *packets;         /* [VAMD_AHEAD_MAX][K][stride]: K = 1, or a bitrate-managed block's PACKETBLOBS candidates */
+  int32_t *bits;                  /* [VAMD_AHEAD_MAX][K] */
   long stride;
+  int K;
   long hits, misses, batches;     /* (diagnostics: vamd_ahead_stats) */
 } vamd_ahead;
 
@@ -278,6 +282,7 @@ void vamd_release_key(const void *key) {
     if (e->ahead) {
       if (e->ahead->pcm) _ogg_free(e->ahead->pcm);
       if (e->ahead->packets) _ogg_free(e->ahead->packets);
+      if (e->ahead->bits) _ogg_free(e->ahead->bits);
       _ogg_free(e->ahead);
     }
     _ogg_free(e);
@@ -493,13 +498,15 @@ static int mapping0_forward_vamd(vorbis_block *vb) {
 
   /* ---- look-ahead inside one stream (the comment at vamd_ahead): serve this block from the packets planned earlier,
      or plan the blocks the buffer already determines and run them with this one */
-  if (!managed && vamd_lookahead_on() && vamd_packet_capacity(ctx, 0) > 0 && vamd_packet_capacity(ctx, 1) > 0) {
+  if (vamd_lookahead_on() && vamd_packet_capacity(ctx, 0) > 0 && vamd_packet_capacity(ctx, 1) > 0) {
     vamd_entry *e = vamd_entry_for(vd);
     vamd_ahead *A = e ? e->ahead : NULL;
     const long bsz[2] = {((codec_setup_info *)vi->codec_setup)->blocksizes[0], ((codec_setup_info *)vi->codec_setup)->blocksizes[1]};
+    const int maxplan = managed ? 63 : VAMD_AHEAD_MAX - 1; /* (a managed block's packets are fifteen rows) */
     int i;
-    if (A && A->next < A->count) {
+    if (A && A->next < A->count && A->K == nk) {
       const vamd_ahead_block *p = &A->blk[A->next];
+      const long slot = (long)(p - A->blk);
       int same = p->sequence == (long)vb->sequence && p->W == vb->W && p->lW == vb->lW && p->nW == vb->nW &&
                  p->blocktype == vbi->blocktype && !memcmp(&p->ampmax_in, &vbi->ampmax, sizeof(float));
       for (i = 0; same && i < ch; i++) same = !memcmp(A->pcm + p->pcm_at + (long)i * n, vb->pcm[i], (size_t)n * sizeof(float));
@@ -508,7 +515,9 @@ static int mapping0_forward_vamd(vorbis_block *vb) {
         A->hits++;
         if (p->verdict) return vamd_domain_verdict(vb, p->verdict, p->ampmax_out);
         vbi->ampmax = p->ampmax_out; /* lib/mapping0.c:576 */
-        oggpack_writecopy(vbi->packetblob[PACKETBLOBS / 2], A->packets + (long)(p - A->blk) * A->stride, p->bits);
+        for (k = 0; k < nk; k++)
+          oggpack_writecopy(vbi->packetblob[managed ? k : PACKETBLOBS / 2], A->packets + (slot * nk + k) * A->stride,
+                            A->bits[slot * nk + k]);
         return 0;
       }
       A->count = A->next = 0; /* the stream went another way than planned: the cache is worth nothing */
@@ -517,57 +526,64 @@ static int mapping0_forward_vamd(vorbis_block *vb) {
     if (e) {
       vamd_ahead_block planned[VAMD_AHEAD_MAX];
       long begin[VAMD_AHEAD_MAX];
-      const int np = vamd_plan_ahead(vd, VAMD_AHEAD_MAX - 1, planned + 1, begin + 1);
+      const int np = vamd_plan_ahead(vd, maxplan, planned + 1, begin + 1);
       if (np > 0) {
         const int nb = np + 1;
         const float **ptr = _vorbis_block_alloc(vb, (long)nb * ch * sizeof(*ptr));
         int32_t *dW = _vorbis_block_alloc(vb, 4L * nb * sizeof(*dW)), *dlW = dW + nb, *dnW = dW + 2 * nb, *dbt = dW + 3 * nb;
-        int32_t *bits = _vorbis_block_alloc(vb, 2L * nb * sizeof(*bits)), *verdict = bits + nb;
+        int32_t *verdict = _vorbis_block_alloc(vb, (long)nb * sizeof(*verdict));
         float *ain = _vorbis_block_alloc(vb, 2L * nb * sizeof(*ain)), *aout = ain + nb;
         long need = 0, at = 0, stride = vamd_packet_capacity(ctx, 0);
-        int k;
+        int j;
         if (vamd_packet_capacity(ctx, 1) > stride) stride = vamd_packet_capacity(ctx, 1);
         if (!A) A = e->ahead = _ogg_calloc(1, sizeof(*A));
-        for (k = 1; k < nb; k++) need += (long)ch * bsz[planned[k].W];
+        for (j = 1; j < nb; j++) need += (long)ch * bsz[planned[j].W];
         if (A && A->pcm_cap < need) {
           if (A->pcm) _ogg_free(A->pcm);
           A->pcm = _ogg_malloc((size_t)(need + need / 2) * sizeof(float));
           A->pcm_cap = A->pcm ? need + need / 2 : 0;
         }
-        if (A && A->stride != stride) {
+        if (A && (A->stride != stride || A->K != nk)) {
           if (A->packets) _ogg_free(A->packets);
-          A->packets = _ogg_malloc((size_t)VAMD_AHEAD_MAX * stride);
-          A->stride = A->packets ? stride : 0;
+          if (A->bits) _ogg_free(A->bits);
+          A->packets = _ogg_malloc((size_t)(maxplan + 1) * nk * stride);
+          A->bits = _ogg_malloc((size_t)(maxplan + 1) * nk * sizeof(*A->bits));
+          A->stride = (A->packets && A->bits) ? stride : 0;
+          A->K = nk;
+          A->count = A->next = 0;
         }
-        if (A && A->pcm_cap >= need && A->stride == stride) {
+        if (A && A->pcm_cap >= need && A->stride == stride && A->K == nk) {
           planned[0].lW = vb->lW, planned[0].W = vb->W, planned[0].nW = vb->nW, planned[0].blocktype = vbi->blocktype;
           for (i = 0; i < ch; i++) ptr[i] = vb->pcm[i];
-          for (k = 1; k < nb; k++) { /* the samples as they lie in the encoder's own buffer, kept for the comparison later */
-            const long nk = bsz[planned[k].W];
-            planned[k].pcm_at = at;
+          for (j = 1; j < nb; j++) { /* the samples as they lie in the encoder's own buffer, kept for the comparison later */
+            const long nj = bsz[planned[j].W];
+            planned[j].pcm_at = at;
             for (i = 0; i < ch; i++) {
-              memcpy(A->pcm + at, vd->pcm[i] + begin[k], (size_t)nk * sizeof(float));
-              ptr[(long)k * ch + i] = A->pcm + at;
-              at += nk;
+              memcpy(A->pcm + at, vd->pcm[i] + begin[j], (size_t)nj * sizeof(float));
+              ptr[(long)j * ch + i] = A->pcm + at;
+              at += nj;
             }
           }
-          for (k = 0; k < nb; k++) dlW[k] = planned[k].lW, dW[k] = planned[k].W, dnW[k] = planned[k].nW, dbt[k] = planned[k].blocktype;
-          ret = vamd_encode_blocks(ctx, nb, ptr, dlW, dW, dnW, dbt, vbi->ampmax, ain, aout, A->packets, stride, bits, verdict);
+          for (j = 0; j < nb; j++) dlW[j] = planned[j].lW, dW[j] = planned[j].W, dnW[j] = planned[j].nW, dbt[j] = planned[j].blocktype;
+          A->count = A->next = 0;
+          ret = vamd_encode_blocks(ctx, nb, ptr, dlW, dW, dnW, dbt, vbi->ampmax, managed, ain, aout, A->packets, stride, A->bits,
+                                   verdict);
           if (ret) return ret;
           A->batches++;
-          A->count = A->next = 0;
-          for (k = 1; k < nb; k++) { /* (slot k of the cache = block k of the batch: its packet row is row k) */
-            vamd_ahead_block *q = &A->blk[k];
-            *q = planned[k];
-            q->sequence = (long)vb->sequence + k;
-            q->ampmax_in = ain[k], q->ampmax_out = aout[k], q->verdict = verdict[k], q->bits = bits[k];
+          for (j = 1; j < nb; j++) { /* (slot j of the cache = block j of the batch: its packet rows are rows j * nk ..) */
+            vamd_ahead_block *q = &A->blk[j];
+            *q = planned[j];
+            q->sequence = (long)vb->sequence + j;
+            q->ampmax_in = ain[j], q->ampmax_out = aout[j], q->verdict = verdict[j];
           }
           A->next = 1;
           A->count = nb;
           if (verdict[0]) return vamd_domain_verdict(vb, verdict[0], aout[0]);
-          if (bits[0] > 8 * stride) return OV_EFAULT; /* cannot happen: stride is the worst case */
           vbi->ampmax = aout[0]; /* lib/mapping0.c:576 */
-          oggpack_writecopy(vbi->packetblob[PACKETBLOBS / 2], A->packets, bits[0]);
+          for (k = 0; k < nk; k++) {
+            if (A->bits[k] > 8 * stride) return OV_EFAULT; /* cannot happen: stride is the worst case */
+            oggpack_writecopy(vbi->packetblob[managed ? k : PACKETBLOBS / 2], A->packets + (long)k * stride, A->bits[k]);
+          }
           return 0;
         }
       }

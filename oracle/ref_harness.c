@@ -682,12 +682,18 @@ typedef struct ref_tt_arg {
   pthread_barrier_t *line;
   int failed;
 } ref_tt_arg;
+/* ref_time_set_managed(nominal bitrate): the timed encoders are bitrate-managed (ABR at that rate) instead of VBR at q; 0 = VBR */
+static long ref_tt_nominal = 0;
+void ref_time_set_managed(long nominal) { ref_tt_nominal = nominal; }
+static ref_enc *ref_tt_open(int ch, long rate, float q) {
+  return ref_tt_nominal > 0 ? ref_open_managed(ch, rate, -1, ref_tt_nominal, -1) : ref_open(ch, rate, q);
+}
 static void *ref_tt_run(void *v) {
   ref_tt_arg *a = (ref_tt_arg *)v;
   int p;
   pthread_barrier_wait(a->line);
   for (p = 0; p < a->passes; p++) {
-    ref_enc *e = p == 0 ? a->first : ref_open(a->ch, a->rate, a->q);
+    ref_enc *e = p == 0 ? a->first : ref_tt_open(a->ch, a->rate, a->q);
     long nb = e ? ref_encode_stream_ex(e, a->pcm, a->frames, a->write_frames, 0, NULL, 0, NULL, 0, NULL, 0) : -1;
     if (e) ref_close(e);
     if (nb < 0) { a->failed = 1; break; }
@@ -712,7 +718,7 @@ double ref_time_threads_w(int nthreads, int ch, long rate, float q, const float 
   for (i = 0; i < nthreads; i++) {
     args[i].ch = ch, args[i].rate = rate, args[i].q = q, args[i].pcm = pcm, args[i].frames = frames;
     args[i].passes = passes, args[i].line = &line, args[i].write_frames = write_frames;
-    args[i].first = ref_open(ch, rate, q);
+    args[i].first = ref_tt_open(ch, rate, q);
     pthread_create(&th[i], &attr, ref_tt_run, &args[i]);
   }
   getrusage(RUSAGE_SELF, &r0);

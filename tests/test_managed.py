@@ -97,15 +97,18 @@ def test_gpu_matches_reference(rates):
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not ref.hybrid_available(), reason="hybrid library not built")
-@pytest.mark.parametrize("ch,rates", [(2, (-1, 96000, -1)), (2, (-1, 64000, -1)), (1, (-1, 64000, -1))])
-def test_hybrid_abr_encode_emits_reference_packets(ch, rates):
+@pytest.mark.parametrize("ch,rates,write", [(2, (-1, 96000, -1), 1024), (2, (-1, 64000, -1), 1024), (1, (-1, 64000, -1), 1024),
+                                            (2, (-1, 96000, -1), 30000), (2, (128000, 96000, 64000), 65536)])
+def test_hybrid_abr_encode_emits_reference_packets(ch, rates, write):
+    """(write > 1024: the binding's look-ahead -- the buffered blocks' fifteen candidate packets each come out of ONE batch,
+    vamd_encode_blocks(managed), and the bitrate manager picks among them block by block as before.)"""
     rng = np.random.default_rng(77)
-    frames = 44100 * 2
+    frames = 44100 * (2 if write == 1024 else 5)
     t = np.arange(frames)
     x = ((rng.random((ch, frames), dtype=np.float32) - 0.5) * 2 * np.where((t % 11025) < 1102, 0.5, 0.0005))
     x = np.ascontiguousarray(x, dtype=np.float32)
-    want = ref.RefEncoder(ch, 44100, managed=rates).encode_stream(x)
-    got = ref.RefEncoder(ch, 44100, managed=rates, hybrid=True).encode_stream(x)
+    want = ref.RefEncoder(ch, 44100, managed=rates).encode_stream(x, write_frames=write)
+    got = ref.RefEncoder(ch, 44100, managed=rates, hybrid=True).encode_stream(x, write_frames=write)
     assert len(want) == len(got) > 40
     assert [(b["lW"], b["W"], b["nW"], b["blocktype"]) for b in want] == \
            [(b["lW"], b["W"], b["nW"], b["blocktype"]) for b in got]

@@ -17,12 +17,14 @@ from tests.test_gpu_dropin import _stream  # noqa: E402
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 q = float(sys.argv[2]) if len(sys.argv) > 2 else 0.4
 kind = sys.argv[3] if len(sys.argv) > 3 else "s16"
+nominal = int(sys.argv[4]) if len(sys.argv) > 4 else 0      # > 0: bitrate-managed encoders (ABR at that rate) instead of VBR at q
 x = _stream(2, secs, kind, seed=77)
 xp = x.ctypes.data_as(C.POINTER(C.c_float))
 
 
 def timed(hybrid, write_frames, passes=1):
     L = ref.lib(hybrid)
+    L.ref_time_set_managed(C.c_long(nominal))
     L.ref_time_threads_w.restype = C.c_double
     L.ref_time_threads_w.argtypes = [C.c_int, C.c_int, C.c_long, C.c_float, C.POINTER(C.c_float), C.c_long, C.c_long, C.c_int,
                                      C.POINTER(C.c_long), C.POINTER(C.c_double)]
@@ -32,7 +34,8 @@ def timed(hybrid, write_frames, passes=1):
     return blocks.value, wall, cpu[0] + cpu[1]
 
 
-print("# one thread, one %s stereo stream of %.0f s at q %.1f; blocks/s wall (and per host-CPU-second)" % (kind, secs, q))
+print("# one thread, one %s stereo stream of %.0f s, %s; blocks/s wall (and per host-CPU-second)"
+      % (kind, secs, ("bitrate-managed, %d bit/s nominal (fifteen candidate packets per block)" % nominal) if nominal else "q %.1f" % q))
 print("# %10s %22s %22s %s" % ("write size", "reference (CPU)", "hybrid (GPU back-end)", "look-ahead hits / misses / batches"))
 Lh = ref.lib(True)
 for wf in (1024, 4096, 8192, 16384, 32768, 65536, 131072):

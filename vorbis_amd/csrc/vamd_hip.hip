@@ -896,7 +896,8 @@ int vamd_analyze_stream(vamd_ctx *c, const vamd_batch_desc *desc, const vamd_bat
 static int run_streams_mixed(vamd_ctx *c, const vamd_batch_desc *desc_short, const vamd_batch_io *io_short,
                              const vamd_batch_desc *desc_long, const vamd_batch_io *io_long, const int32_t *order,
                              long nblocks_total, float *ampmax_state, const int64_t *stream_start, long nstreams,
-                             float *states, bool first_given = false) {
+                             float *states, bool first_given = false, const vamd_managed_io *M0 = nullptr,
+                             const vamd_managed_io *M1 = nullptr) {
   if (desc_short->W != 0 || desc_long->W != 1) return fail(c, VAMD_EINVAL, "desc_short->W must be 0, desc_long->W 1");
   if (nblocks_total != desc_short->nblocks + desc_long->nblocks || (nblocks_total && !order))
     return fail(c, VAMD_EINVAL, "order[] must name every block of both batches exactly once");
@@ -907,7 +908,22 @@ static int run_streams_mixed(vamd_ctx *c, const vamd_batch_desc *desc_short, con
   BatchRun R[2];
   if ((r = prepare_run(c, desc_short, io_short, VAMD_LEVEL_FULL, &R[0]))) return r;
   if ((r = prepare_run(c, desc_long, io_long, VAMD_LEVEL_FULL, &R[1]))) return r;
-  if ((r = alloc_couple_state(c, &R[0], R[0].nb)) || (r = alloc_couple_state(c, &R[1], R[1].nb))) return r;
+  // bitrate-managed blocks (vamd_encode_blocks): fifteen candidate packets per block, as run_batch sets them up
+  const vamd_managed_io *MM[2] = {M0, M1};
+  ilog_t *m_ilog[2] = {nullptr, nullptr};
+  for (int W = 0; W < 2; W++) {
+    if (!MM[W] || R[W].nb == 0) continue;
+    void *v;
+    if ((r = ws_get(c, W, vamd_ctx::WS_M_ILOGMASK, (size_t)R[W].nb * VAMD_PACKETBLOBS * c->B.channels * (c->B.bs[W] / 2) * sizeof(ilog_t), &v)))
+      return r;
+    m_ilog[W] = (ilog_t *)v;
+    if ((MM[W]->res_entries || MM[W]->packets) &&
+        (r = res_bufs(c, W, R[W].nb * VAMD_PACKETBLOBS, MM[W]->res_class, MM[W]->res_entries, MM[W]->res_count, &R[W].rb)))
+      return r;
+  }
+  if ((r = alloc_couple_state(c, &R[0], MM[0] ? R[0].nb * VAMD_PACKETBLOBS : R[0].nb)) ||
+      (r = alloc_couple_state(c, &R[1], MM[1] ? R[1].nb * VAMD_PACKETBLOBS : R[1].nb)))
+    return r;
   // scratch for the chained state; an empty size class still needs valid (unused) pointers
   void *misc = nullptr;
   if ((r = ws_get(c, 0, vamd_ctx::WS_MISC, 256, &misc))) return r;
@@ -941,13 +957,13 @@ static int run_streams_mixed(vamd_ctx *c, const vamd_batch_desc *desc_short, con
   R[0].d.ampmax_in = R[0].p.ampin;
   R[1].d.ampmax_in = R[1].p.ampin;
   if (chain_on_side) {  // both classes' masks first, the long blocks' leading
-    launch_rest(c, &R[1], VAMD_LEVEL_FULL, nullptr, nullptr, 1, true);
-    launch_rest(c, &R[0], VAMD_LEVEL_FULL, nullptr, nullptr, 1, true);
-    launch_rest(c, &R[1], VAMD_LEVEL_FULL, nullptr, nullptr, 2, true);
-    launch_rest(c, &R[0], VAMD_LEVEL_FULL, nullptr, nullptr, 2, true);
+    launch_rest(c, &R[1], VAMD_LEVEL_FULL, MM[1], m_ilog[1], 1, true);
+    launch_rest(c, &R[0], VAMD_LEVEL_FULL, MM[0], m_ilog[0], 1, true);
+    launch_rest(c, &R[1], VAMD_LEVEL_FULL, MM[1], m_ilog[1], 2, true);
+    launch_rest(c, &R[0], VAMD_LEVEL_FULL, MM[0], m_ilog[0], 2, true);
   } else {
-    launch_rest(c, &R[0], VAMD_LEVEL_FULL);
-    launch_rest(c, &R[1], VAMD_LEVEL_FULL);
+    launch_rest(c, &R[0], VAMD_LEVEL_FULL, MM[0], m_ilog[0]);
+    launch_rest(c, &R[1], VAMD_LEVEL_FULL, MM[1], m_ilog[1]);
   }
   if (chain_on_side && R[0].nb == 0 && R[1].nb == 0) {  // (cannot happen -- nblocks_total > 0 -- but nothing may be left unjoined)
     (void)hipEventRecord(c->ev_join, c->side);
@@ -1172,8 +1188,8 @@ int vamd_encode_block(vamd_ctx *c, const float *const *pcm, int lW, int W, int n
 // N consecutive blocks of ONE stream from host memory to their packets in one launch sequence (the binding's look-ahead,
 // integration/mapping0_vamd.c): what vamd_encode_block does for one block, with the ampmax chain between them on the device.
 int vamd_encode_blocks(vamd_ctx *c, long nblocks, const float *const *pcm, const int32_t *lW, const int32_t *W,
-                       const int32_t *nW, const int32_t *blocktype, float ampmax_in_first, float *ampmax_in, float *ampmax_out,
-                       uint8_t *packets, long packet_stride, int32_t *packet_bits, int32_t *verdict) {
+                       const int32_t *nW, const int32_t *blocktype, float ampmax_in_first, int managed, float *ampmax_in,
+                       float *ampmax_out, uint8_t *packets, long packet_stride, int32_t *packet_bits, int32_t *verdict) {
   DeviceGuard dev_guard(c);
   if (!c) return VAMD_EINVAL;
   if (nblocks < 0 || nblocks > 0x3fffffffL) return fail(c, VAMD_EINVAL, "nblocks out of range");
@@ -1196,6 +1212,7 @@ int vamd_encode_blocks(vamd_ctx *c, long nblocks, const float *const *pcm, const
     nb[W[b]]++;
   }
   auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
+  const size_t K = managed ? VAMD_PACKETBLOBS : 1;  // packets per block: one, or a bitrate-managed block's fifteen candidates
   // one pinned arena, read and written in place by the kernels (mapped): per size class [pcm | lW | nW | blocktype |
   // ampmax_out | bits | status | packets], then the stream order
   size_t o_pcm[2], o_lW[2], o_nW[2], o_bt[2], o_amp[2], o_bits[2], o_st[2], o_pk[2], row[2], at = 0;
@@ -1207,9 +1224,9 @@ int vamd_encode_blocks(vamd_ctx *c, long nblocks, const float *const *pcm, const
     o_nW[w] = at, at = al(at + (size_t)nb[w] * 4);
     o_bt[w] = at, at = al(at + (size_t)nb[w] * 4);
     o_amp[w] = at, at = al(at + (size_t)nb[w] * 4);
-    o_bits[w] = at, at = al(at + (size_t)nb[w] * 4);
+    o_bits[w] = at, at = al(at + (size_t)nb[w] * K * 4);
     o_st[w] = at, at = al(at + (size_t)nb[w] * ch);
-    o_pk[w] = at, at = al(at + (size_t)nb[w] * row[w]);
+    o_pk[w] = at, at = al(at + (size_t)nb[w] * K * row[w]);
   }
   const size_t o_order = at, total = al(o_order + (size_t)nblocks * 4);
   if (c->h_stage_bytes < total) {
@@ -1238,8 +1255,11 @@ int vamd_encode_blocks(vamd_ctx *c, long nblocks, const float *const *pcm, const
   }
   vamd_batch_desc d[2];
   vamd_batch_io io[2];
+  vamd_managed_io m[2];
   memset(d, 0, sizeof(d));
   memset(io, 0, sizeof(io));
+  memset(m, 0, sizeof(m));
+  int r;
   for (int w = 0; w < 2; w++) {
     d[w].W = w;
     d[w].nblocks = nb[w];
@@ -1249,13 +1269,30 @@ int vamd_encode_blocks(vamd_ctx *c, long nblocks, const float *const *pcm, const
     io[w].pcm = (const float *)(ds + o_pcm[w]);
     io[w].ampmax_out = (float *)(ds + o_amp[w]);
     io[w].status = ds + o_st[w];
-    io[w].packets = ds + o_pk[w];
-    io[w].packet_bits = (int32_t *)(ds + o_bits[w]);
-    io[w].packet_stride = (int64_t)row[w];
+    if (!managed) {
+      io[w].packets = ds + o_pk[w];
+      io[w].packet_bits = (int32_t *)(ds + o_bits[w]);
+      io[w].packet_stride = (int64_t)row[w];
+    } else if (nb[w]) {
+      // the candidates' intermediates stay on the device (workspace); their packets go to the arena
+      const size_t n2 = (size_t)c->B.bs[w] / 2, units = (size_t)nb[w] * K;
+      const size_t q_posts = 0, q_valid = al(q_posts + units * ch * VAMD_POSTS_STRIDE * 4), q_nz = al(q_valid + units * ch * 4),
+                   q_iwork = al(q_nz + units * ch * 4), q_total = al(q_iwork + units * ch * n2 * 4);
+      void *dv;
+      if ((r = ws_get(c, w, vamd_ctx::WS_M_STAGE, q_total, &dv))) return r;
+      unsigned char *dm = (unsigned char *)dv;
+      m[w].posts = (int32_t *)(dm + q_posts);
+      m[w].post_valid = (int32_t *)(dm + q_valid);
+      m[w].nonzero = (int32_t *)(dm + q_nz);
+      m[w].iwork = (int32_t *)(dm + q_iwork);
+      m[w].packets = ds + o_pk[w];
+      m[w].packet_bits = (int32_t *)(ds + o_bits[w]);
+      m[w].packet_stride = (int64_t)row[w];
+    }
   }
   float state = ampmax_in_first;
-  int r = run_streams_mixed(c, &d[0], &io[0], &d[1], &io[1], (const int32_t *)(ds + o_order), nblocks, &state, nullptr, 0, nullptr,
-                            true);  // (synchronises: the chain's final state comes back)
+  r = run_streams_mixed(c, &d[0], &io[0], &d[1], &io[1], (const int32_t *)(ds + o_order), nblocks, &state, nullptr, 0, nullptr,
+                        true, managed && nb[0] ? &m[0] : nullptr, managed && nb[1] ? &m[1] : nullptr);  // (synchronises: the chain's final state comes back)
   if (r) return r;
   const float att = c->B.ampmax_att_per_sec;
   float prev_out = 0.f;
@@ -1276,11 +1313,14 @@ int vamd_encode_blocks(vamd_ctx *c, long nblocks, const float *const *pcm, const
     unsigned any = 0;
     for (size_t k = 0; k < ch; k++) any |= hs[o_st[w] + (size_t)i * ch + k];
     verdict[b] = (any & VAMD_STATUS_NONFINITE) ? VAMD_ENONFINITE : ((any & VAMD_STATUS_RANGE) ? VAMD_EDOMAIN : VAMD_OK);
-    const int32_t bits = ((const int32_t *)(hs + o_bits[w]))[i];
-    packet_bits[b] = bits;
-    size_t bytes = ((size_t)(bits > 0 ? bits : 0) + 7) / 8;
-    if (bytes > row[w]) bytes = row[w];  // (cut off: packet_bits says so)
-    if (verdict[b] == VAMD_OK) memcpy(packets + (size_t)b * (size_t)packet_stride, hs + o_pk[w] + (size_t)i * row[w], bytes);
+    for (size_t k = 0; k < K; k++) {
+      const int32_t bits = ((const int32_t *)(hs + o_bits[w]))[(size_t)i * K + k];
+      packet_bits[(size_t)b * K + k] = bits;
+      size_t bytes = ((size_t)(bits > 0 ? bits : 0) + 7) / 8;
+      if (bytes > row[w]) bytes = row[w];  // (cut off: packet_bits says so)
+      if (verdict[b] == VAMD_OK)
+        memcpy(packets + ((size_t)b * K + k) * (size_t)packet_stride, hs + o_pk[w] + ((size_t)i * K + k) * row[w], bytes);
+    }
   }
   return VAMD_OK;
 }
