@@ -301,11 +301,12 @@ class RefEncoder:
         o["packets_match_real"] = bool(m.packets_match_real)
         return o
 
-    def encode_stream(self, pcm, max_blocks=1 << 16, write_frames=1024, tolerate=False):
+    def encode_stream(self, pcm, max_blocks=1 << 16, write_frames=1024, tolerate=False, drain=0):
         """Run the whole application loop over planar pcm[ch][frames].  Consumes this
         encoder state.  Returns a list of dicts (lW,W,nW,blocktype,ampmax_in,ampmax_out,pcm,packet).
         write_frames: samples per vorbis_analysis_wrote() call (the example's 1024; the API takes any amount).
-        tolerate: a failing vorbis_analysis() is recorded (`error` = its code, no packet) and the loop goes on."""
+        tolerate: a failing vorbis_analysis() is recorded (`error` = its code, no packet) and the loop goes on.
+        drain: after each write pull at most this many blocks (0 = all): blocks pile up while more samples arrive."""
         pcm = np.ascontiguousarray(pcm, dtype=np.float32)
         ch, frames = pcm.shape
         assert ch == self.channels
@@ -314,8 +315,10 @@ class RefEncoder:
         pcm_out = np.zeros(pcm_cap, np.float32)
         pk_cap = max(1 << 20, frames * ch)
         pk_out = np.zeros(pk_cap, np.uint8)
+        self.L.ref_stream_set_drain(C.c_long(int(drain)))
         nb = self.L.ref_encode_stream_ex(self.h, _fp(pcm), frames, int(write_frames), 1 if tolerate else 0, recs, max_blocks,
                                          _fp(pcm_out), pcm_cap, pk_out.ctypes.data_as(_u8p), pk_cap)
+        self.L.ref_stream_set_drain(C.c_long(0))
         if nb < 0:
             raise RuntimeError("ref_encode_stream failed: %d" % nb)
         out = []

@@ -592,6 +592,11 @@ int ref_tap_block_managed(ref_enc *e, const float *pcm, int lW, int W, int nW, i
  * (examples/encoder_example.c:38), but the API takes any amount (lib/block.c:390,470).  `tolerate`: a
  * vorbis_analysis() that fails does not end the run; the block is recorded with packet_bytes = the error code
  * (negative) and no packet, and the loop goes on as an application that ignores return codes would. */
+/* ref_stream_set_drain(k): after each write the loop below pulls at most k blocks (0 = all of them, the default), so that
+ * blocks pile up in the encoder's buffer while more samples arrive -- an application is free to do that, and the blocks it
+ * gets must not depend on it. */
+static long ref_drain_limit = 0;
+void ref_stream_set_drain(long k) { ref_drain_limit = k; }
 long ref_encode_stream_ex(ref_enc *e, const float *pcm, long frames, long write_frames, int tolerate, ref_block_rec *recs,
                           long max_blocks, float *pcm_out, long pcm_cap, unsigned char *packets_out, long packets_cap) {
   vorbis_block vb;
@@ -610,12 +615,14 @@ long ref_encode_stream_ex(ref_enc *e, const float *pcm, long frames, long write_
     } else {
       vorbis_analysis_wrote(&e->vd, 0);
     }
-    while (vorbis_analysis_blockout(&e->vd, &vb) == 1) {
+    long pulled = 0;
+    while ((ref_drain_limit <= 0 || chunk <= 0 || pulled < ref_drain_limit) && vorbis_analysis_blockout(&e->vd, &vb) == 1) {
       ogg_packet op;
       vorbis_block_internal *vbi = (vorbis_block_internal *)vb.internal;
       int n = vb.pcmend;
       float ampmax_in = vbi->ampmax;
       int ret;
+      pulled++;
       if (nblocks < max_blocks && recs) {
         ref_block_rec *r = recs + nblocks;
         r->lW = (int)vb.lW; r->W = (int)vb.W; r->nW = (int)vb.nW; r->blocktype = vbi->blocktype;

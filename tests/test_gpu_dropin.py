@@ -81,6 +81,22 @@ def test_look_ahead_inside_one_stream_emits_reference_packets(ch, q, kind, write
     assert hits > 0.8 * len(got) and batches < len(got) / 4 and misses <= batches, (hits, misses, batches, len(got))
 
 
+@pytest.mark.parametrize("q,kind,write,drain", [(0.9, "gated", 5000, 2), (0.4, "gated", 3000, 1), (0.4, "s16", 20000, 7)])
+def test_look_ahead_survives_writes_between_the_blocks(q, kind, write, drain):
+    """An application may write more samples before it has pulled every block the buffer holds.  The binding's plan was
+    made on less data than the reference's blockout then decides on; whatever it planned is verified against the block
+    that really comes (and planned again on a miss), so the packets are the reference's all the same -- here with at most
+    `drain` blocks pulled after each write, so that blocks pile up and plans go stale."""
+    pcm = _stream(2, 8.0, kind, seed=99)
+    want = ref.RefEncoder(2, 44100, q).encode_stream(pcm, write_frames=write, drain=drain)
+    got = ref.RefEncoder(2, 44100, q, hybrid=True).encode_stream(pcm, write_frames=write, drain=drain)
+    assert len(want) == len(got) > 300
+    for k, (a, b) in enumerate(zip(want, got)):
+        assert (a["lW"], a["W"], a["nW"], a["blocktype"]) == (b["lW"], b["W"], b["nW"], b["blocktype"]), k
+        assert np.float32(a["ampmax_out"]) == np.float32(b["ampmax_out"]), k
+        assert a["packet"] == b["packet"], "packet %d differs (W=%d)" % (k, a["W"])
+
+
 _BATCH_WORKER = r'''
 import sys, threading, time, json
 sys.path.insert(0, @ROOT@)
