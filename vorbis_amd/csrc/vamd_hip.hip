@@ -748,7 +748,7 @@ static int run_batch(vamd_ctx *c, const vamd_batch_desc *desc, const vamd_batch_
   launch_transform(c, &R);
   if (stream_mode) {
     const float secs = (float)(c->B.xf[R.W].n / 2) / (float)c->B.rate;  // lib/psy.c:842-843
-    hipLaunchKernelGGL(k_ampmax_stream, dim3(1), dim3(1), 0, s, ch, R.nb, secs, c->B.ampmax_att_per_sec, *ampmax_state,
+    hipLaunchKernelGGL(k_ampmax_stream, dim3(1), dim3(64), 0, s, ch, R.nb, secs, c->B.ampmax_att_per_sec, *ampmax_state,
                        R.p.local, R.p.ampin, R.p.ampglob);
     R.d.ampmax_in = R.p.ampin;
   } else if (level >= VAMD_LEVEL_PSY) {
@@ -934,7 +934,7 @@ static int run_streams_mixed(vamd_ctx *c, const vamd_batch_desc *desc_short, con
   launch_transform(c, &R[0]);
   launch_transform(c, &R[1]);
   const float secs0 = (float)(c->B.bs[0] / 2) / (float)c->B.rate, secs1 = (float)(c->B.bs[1] / 2) / (float)c->B.rate;
-  // The chains' walk (a thread per stream, ~0.3 ms for a thousand streams of 130 blocks: latency, not load) feeds the tone
+  // The chains' walk (a wave per stream) feeds the tone
   // seeds and nothing else of the masking stage, so where the tone chain runs on the side stream the walk goes there
   // too, ahead of it, and the noise masks start at once on the main stream.
   const bool chain_on_side = nstreams && c->overlap && (R[0].nb == 0 || R[0].nb * c->B.channels > 64) &&
@@ -945,11 +945,11 @@ static int run_streams_mixed(vamd_ctx *c, const vamd_batch_desc *desc_short, con
     s = c->side;
   }
   if (nstreams)
-    hipLaunchKernelGGL(k_ampmax_streams_mixed, dim3((unsigned)((nstreams + 63) / 64)), dim3(64), 0, s, c->B.channels, nstreams,
+    hipLaunchKernelGGL(k_ampmax_streams_mixed, dim3((unsigned)nstreams), dim3(64), 0, s, c->B.channels, nstreams,
                        (const long long *)stream_start, (const int *)order, secs0, secs1, c->B.ampmax_att_per_sec, states,
                        R[0].p.local, R[1].p.local, R[0].p.ampin, R[1].p.ampin, R[0].p.ampglob, R[1].p.ampglob);
   else
-    hipLaunchKernelGGL(k_ampmax_stream_mixed, dim3(1), dim3(1), 0, s, c->B.channels, nblocks_total, (const int *)order, secs0,
+    hipLaunchKernelGGL(k_ampmax_stream_mixed, dim3(1), dim3(64), 0, s, c->B.channels, nblocks_total, (const int *)order, secs0,
                        secs1, c->B.ampmax_att_per_sec, *ampmax_state, R[0].p.local, R[1].p.local, R[0].p.ampin,
                        R[1].p.ampin, R[0].p.ampglob, R[1].p.ampglob, d_state, first_given ? 1 : 0);
   s = c->stream;

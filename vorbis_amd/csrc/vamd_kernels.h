@@ -301,72 +301,97 @@ __global__ void k_ampmax(DescP d, int ch, long nblocks, const float *__restrict_
 
 // stream mode: the ampmax recurrence across blocks, serial in fp32:
 // in_k = max(out_{k-1} + secs*att, -9999), out_k = max(in_k, locals_k)
-__global__ void k_ampmax_stream(int ch, long nblocks, float secs, float att, float state,
-                                const float *__restrict__ local_ampmax, float *__restrict__ ampmax_in,
-                                float *__restrict__ ampmax_glob) {
-  if (blockIdx.x || threadIdx.x) return;
-  float amp = state;
-  for (long b = 0; b < nblocks; b++) {
-    amp += secs * att;  // _vp_ampmax_decay, lib/psy.c:837-848
-    if (amp < -9999) amp = -9999;
-    ampmax_in[b] = amp;
-    for (int c = 0; c < ch; c++) {
-      const float l = local_ampmax[b * ch + c];
-      if (l > amp) amp = l;
+// A stream's ampmax chain (lib/psy.c:837-848 _vp_ampmax_decay, lib/mapping0.c:346,576): block k receives the running
+// value decayed by its own half-length, and hands on the larger of that and its channels' spectral peaks.  The float
+// additions make the order part of the result, so the chain is walked in order -- but by a WAVE: 64 links' block
+// indices, decays and peaks are fetched at once (one lane each: the thread-per-stream form paid two dependent trips to
+// memory per link, 1.5 us each, 0.39 ms for a stream of 250 blocks), the walk itself runs on registers (v_readlane with
+// the unrolled link number), and each lane keeps and stores its own link's two values.
+// order == nullptr: a stream of one size class, link k is block k.  first_given: `amp` is what link k0 receives.
+VAMD_DEV float ampmax_chain_wave(int ch, long long k0, long long k1, const int *__restrict__ order, float secs0, float secs1,
+                                 float att, float amp, const float *__restrict__ local0, const float *__restrict__ local1,
+                                 float *__restrict__ in0, float *__restrict__ in1, float *__restrict__ glob0,
+                                 float *__restrict__ glob1, int first_given) {
+  for (long long base = k0; base < k1; base += 64) {
+    const int cnt = (int)((k1 - base) < 64 ? (k1 - base) : 64);
+    int W = 0;
+    long b = 0;
+    float dec = 0.f, peak = VAMD_NEGINF;
+    if (LANE < cnt) {
+      const long long k = base + LANE;
+      if (order) {
+        const int o = order[k];
+        W = (o >> 30) & 1;
+        b = o & 0x3fffffff;
+      } else {
+        b = (long)k;
+      }
+      dec = (W ? secs1 : secs0) * att;
+      const float *loc = (W ? local1 : local0) + b * ch;
+      for (int c = 0; c < ch; c++) {  // (the larger of `amp` and every peak, whatever the order; a NaN peak never wins)
+        const float l = loc[c];
+        if (l > peak) peak = l;
+      }
     }
-    ampmax_glob[b] = amp;
+    const bool keep0 = first_given && base == k0;
+    float my_in = 0.f, my_out = 0.f;
+#pragma unroll
+    for (int j = 0; j < 64; j++) {
+      if (j >= cnt) break;
+      const float dj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dec), j));
+      const float lj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, peak), j));
+      if (!(j == 0 && keep0)) {
+        amp += dj;
+        if (amp < -9999) amp = -9999;
+      }
+      const float a_in = amp;
+      if (lj > amp) amp = lj;
+      if (LANE == j) {
+        my_in = a_in;
+        my_out = amp;
+      }
+    }
+    if (LANE < cnt) {
+      (W ? in1 : in0)[b] = my_in;
+      (W ? glob1 : glob0)[b] = my_out;
+    }
   }
+  return amp;
+}
+
+__global__ __launch_bounds__(64) void k_ampmax_stream(int ch, long nblocks, float secs, float att, float state,
+                                                      const float *__restrict__ local_ampmax,
+                                                      float *__restrict__ ampmax_in, float *__restrict__ ampmax_glob) {
+  (void)ampmax_chain_wave(ch, 0, nblocks, nullptr, secs, secs, att, state, local_ampmax, local_ampmax, ampmax_in, ampmax_in,
+                          ampmax_glob, ampmax_glob, 0);
 }
 
 // a stream that mixes both size classes: order[k] = W << 30 | index inside W's batch
-__global__ void k_ampmax_stream_mixed(int ch, long ntotal, const int *__restrict__ order, float secs0, float secs1,
-                                      float att, float state, const float *__restrict__ local0,
-                                      const float *__restrict__ local1, float *__restrict__ in0,
-                                      float *__restrict__ in1, float *__restrict__ glob0, float *__restrict__ glob1,
-                                      float *__restrict__ state_out, int first_given) {
-  if (blockIdx.x || threadIdx.x) return;
-  float amp = state;
-  for (long k = 0; k < ntotal; k++) {
-    const int o = order[k], W = (o >> 30) & 1;
-    const long b = o & 0x3fffffff;
-    if (!(first_given && k == 0)) {  // (first_given: `state` is what block 0 receives, already decayed by the caller's blockout)
-      amp += (W ? secs1 : secs0) * att;  // _vp_ampmax_decay with vd->W = this block's size class
-      if (amp < -9999) amp = -9999;
-    }
-    (W ? in1 : in0)[b] = amp;
-    const float *loc = W ? local1 : local0;
-    for (int c = 0; c < ch; c++) {
-      const float l = loc[b * ch + c];
-      if (l > amp) amp = l;
-    }
-    (W ? glob1 : glob0)[b] = amp;
-  }
-  *state_out = amp;
+__global__ __launch_bounds__(64) void k_ampmax_stream_mixed(int ch, long ntotal, const int *__restrict__ order, float secs0,
+                                                            float secs1, float att, float state,
+                                                            const float *__restrict__ local0,
+                                                            const float *__restrict__ local1, float *__restrict__ in0,
+                                                            float *__restrict__ in1, float *__restrict__ glob0,
+                                                            float *__restrict__ glob1, float *__restrict__ state_out,
+                                                            int first_given) {
+  const float amp = ampmax_chain_wave(ch, 0, ntotal, order, secs0, secs1, att, state, local0, local1, in0, in1, glob0, glob1,
+                                      first_given);
+  if (LANE == 0) *state_out = amp;
 }
 
-// many streams at once: thread s walks order[start[s] .. start[s+1]) with its own running state
-__global__ void k_ampmax_streams_mixed(int ch, long nstreams, const long long *__restrict__ start,
-                                       const int *__restrict__ order, float secs0, float secs1, float att,
-                                       float *__restrict__ states, const float *__restrict__ local0,
-                                       const float *__restrict__ local1, float *__restrict__ in0,
-                                       float *__restrict__ in1, float *__restrict__ glob0, float *__restrict__ glob1) {
-  const long sidx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+// many streams at once: wave s walks order[start[s] .. start[s+1]) with its own running state
+__global__ __launch_bounds__(64) void k_ampmax_streams_mixed(int ch, long nstreams, const long long *__restrict__ start,
+                                                             const int *__restrict__ order, float secs0, float secs1,
+                                                             float att, float *__restrict__ states,
+                                                             const float *__restrict__ local0,
+                                                             const float *__restrict__ local1, float *__restrict__ in0,
+                                                             float *__restrict__ in1, float *__restrict__ glob0,
+                                                             float *__restrict__ glob1) {
+  const long sidx = blockIdx.x;
   if (sidx >= nstreams) return;
-  float amp = states[sidx];
-  for (long long k = start[sidx]; k < start[sidx + 1]; k++) {
-    const int o = order[k], W = (o >> 30) & 1;
-    const long b = o & 0x3fffffff;
-    amp += (W ? secs1 : secs0) * att;
-    if (amp < -9999) amp = -9999;
-    (W ? in1 : in0)[b] = amp;
-    const float *loc = W ? local1 : local0;
-    for (int c = 0; c < ch; c++) {
-      const float l = loc[b * ch + c];
-      if (l > amp) amp = l;
-    }
-    (W ? glob1 : glob0)[b] = amp;
-  }
-  states[sidx] = amp;
+  const float amp = ampmax_chain_wave(ch, start[sidx], start[sidx + 1], order, secs0, secs1, att, states[sidx], local0, local1,
+                                      in0, in1, glob0, glob1, 0);
+  if (LANE == 0) states[sidx] = amp;
 }
 
 // stage 3: _vp_tonemask, in three launches (k_tone.h).  nlp = octave lines padded to 32 (VAMD_LINES_PAD).
