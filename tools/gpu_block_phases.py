@@ -15,6 +15,8 @@ N = 200
 for _ in range(N):
     an.encode_block(pcm)
 c = an.debug_cycles(False, read=True)
-# clock64 on gfx950 counts at 100 MHz
+# clock64 (s_memtime) counts shader-clock ticks on gfx950 (2.4 GHz measured over such runs: bench.py's shader_clock); a
+# slot sums the ticks of ALL the stage's waves (a lone stereo block: 2 for the floor, the kernels' teams elsewhere)
+GHZ = 2.4
 for name, row in zip(("transform", "noise", "tone", "floor", "couple/residue/pack"), c):
-    print("%-20s us per call by slot: %s" % (name, [round(float(x) / N / 100.0, 1) for x in row]))
+    print("%-20s us per call by slot, summed over the stage's waves: %s" % (name, [round(float(x) / N / (GHZ * 1e3), 1) for x in row]))
