@@ -301,12 +301,13 @@ class RefEncoder:
         o["packets_match_real"] = bool(m.packets_match_real)
         return o
 
-    def encode_stream(self, pcm, max_blocks=1 << 16, write_frames=1024, tolerate=False, drain=0):
+    def encode_stream(self, pcm, max_blocks=1 << 16, write_frames=1024, tolerate=False, drain=0, jitter=0):
         """Run the whole application loop over planar pcm[ch][frames].  Consumes this
         encoder state.  Returns a list of dicts (lW,W,nW,blocktype,ampmax_in,ampmax_out,pcm,packet).
         write_frames: samples per vorbis_analysis_wrote() call (the example's 1024; the API takes any amount).
         tolerate: a failing vorbis_analysis() is recorded (`error` = its code, no packet) and the loop goes on.
-        drain: after each write pull at most this many blocks (0 = all): blocks pile up while more samples arrive."""
+        drain: after each write pull at most this many blocks (0 = all): blocks pile up while more samples arrive.
+        jitter: a seed; every write is then a pseudo-random 1..write_frames samples, every pull 0..drain blocks."""
         pcm = np.ascontiguousarray(pcm, dtype=np.float32)
         ch, frames = pcm.shape
         assert ch == self.channels
@@ -316,9 +317,11 @@ class RefEncoder:
         pk_cap = max(1 << 20, frames * ch)
         pk_out = np.zeros(pk_cap, np.uint8)
         self.L.ref_stream_set_drain(C.c_long(int(drain)))
+        self.L.ref_stream_set_jitter(C.c_ulong(int(jitter)))
         nb = self.L.ref_encode_stream_ex(self.h, _fp(pcm), frames, int(write_frames), 1 if tolerate else 0, recs, max_blocks,
                                          _fp(pcm_out), pcm_cap, pk_out.ctypes.data_as(_u8p), pk_cap)
         self.L.ref_stream_set_drain(C.c_long(0))
+        self.L.ref_stream_set_jitter(C.c_ulong(0))
         if nb < 0:
             raise RuntimeError("ref_encode_stream failed: %d" % nb)
         out = []

@@ -593,20 +593,34 @@ int ref_tap_block_managed(ref_enc *e, const float *pcm, int lW, int W, int nW, i
  * vorbis_analysis() that fails does not end the run; the block is recorded with packet_bytes = the error code
  * (negative) and no packet, and the loop goes on as an application that ignores return codes would. */
 /* ref_stream_set_drain(k): after each write the loop below pulls at most k blocks (0 = all of them, the default), so that
- * blocks pile up in the encoder's buffer while more samples arrive -- an application is free to do that, and the blocks it
- * gets must not depend on it. */
+ * blocks pile up in the encoder's buffer while more samples arrive -- an application is free to do that (the reference's
+ * own output depends on the write pattern only in the stream's first block, whose pre-extrapolation takes in whatever
+ * is buffered when it is cut, lib/block.c:420-465,519-524). */
 static long ref_drain_limit = 0;
 void ref_stream_set_drain(long k) { ref_drain_limit = k; }
+/* ref_stream_set_jitter(seed): seed != 0 makes every write a pseudo-random 1 .. write_frames samples and every pull a
+ * pseudo-random 0 .. drain blocks (the same sequence for the same seed: the reference and the hybrid are driven alike) */
+static unsigned long ref_jitter_seed = 0;
+void ref_stream_set_jitter(unsigned long seed) { ref_jitter_seed = seed; }
+static unsigned long ref_jitter_next(unsigned long *st) {
+  *st = *st * 6364136223846793005UL + 1442695040888963407UL;
+  return *st >> 33;
+}
 long ref_encode_stream_ex(ref_enc *e, const float *pcm, long frames, long write_frames, int tolerate, ref_block_rec *recs,
                           long max_blocks, float *pcm_out, long pcm_cap, unsigned char *packets_out, long packets_cap) {
   vorbis_block vb;
   long fed = 0, nblocks = 0, pcm_used = 0, pkt_used = 0;
   int ch = e->channels, eos = 0, i;
+  unsigned long jit = ref_jitter_seed;
   if (write_frames < 1) write_frames = 1024;
   vorbis_block_init(&e->vd, &vb);
   while (!eos) {
-    long chunk = frames - fed;
-    if (chunk > write_frames) chunk = write_frames;
+    long chunk = frames - fed, this_write = write_frames, this_drain = ref_drain_limit;
+    if (ref_jitter_seed) {
+      this_write = 1 + (long)(ref_jitter_next(&jit) % (unsigned long)write_frames);
+      if (ref_drain_limit > 0) this_drain = (long)(ref_jitter_next(&jit) % (unsigned long)(ref_drain_limit + 1));
+    }
+    if (chunk > this_write) chunk = this_write;
     if (chunk > 0) {
       float **buf = vorbis_analysis_buffer(&e->vd, (int)write_frames);
       for (i = 0; i < ch; i++) memcpy(buf[i], pcm + (size_t)i * frames + fed, chunk * sizeof(float));
@@ -616,7 +630,7 @@ long ref_encode_stream_ex(ref_enc *e, const float *pcm, long frames, long write_
       vorbis_analysis_wrote(&e->vd, 0);
     }
     long pulled = 0;
-    while ((ref_drain_limit <= 0 || chunk <= 0 || pulled < ref_drain_limit) && vorbis_analysis_blockout(&e->vd, &vb) == 1) {
+    while ((ref_drain_limit <= 0 || chunk <= 0 || pulled < this_drain) && vorbis_analysis_blockout(&e->vd, &vb) == 1) {
       ogg_packet op;
       vorbis_block_internal *vbi = (vorbis_block_internal *)vb.internal;
       int n = vb.pcmend;

@@ -83,14 +83,34 @@ def test_look_ahead_inside_one_stream_emits_reference_packets(ch, q, kind, write
 
 @pytest.mark.parametrize("q,kind,write,drain", [(0.9, "gated", 5000, 2), (0.4, "gated", 3000, 1), (0.4, "s16", 20000, 7)])
 def test_look_ahead_survives_writes_between_the_blocks(q, kind, write, drain):
-    """An application may write more samples before it has pulled every block the buffer holds.  The binding's plan was
-    made on less data than the reference's blockout then decides on; whatever it planned is verified against the block
-    that really comes (and planned again on a miss), so the packets are the reference's all the same -- here with at most
-    `drain` blocks pulled after each write, so that blocks pile up and plans go stale."""
+    """An application may write more samples before it has pulled every block the buffer holds -- here at most `drain`
+    blocks are pulled after each write, so blocks pile up.  The binding's plan was made on less data than the reference's
+    blockout later decides on; it only ever covers blocks the data at hand already determines (it stops where the blockout
+    would wait), and whatever it planned is verified against the block that really comes, so the packets are the
+    reference's all the same."""
     pcm = _stream(2, 8.0, kind, seed=99)
     want = ref.RefEncoder(2, 44100, q).encode_stream(pcm, write_frames=write, drain=drain)
     got = ref.RefEncoder(2, 44100, q, hybrid=True).encode_stream(pcm, write_frames=write, drain=drain)
     assert len(want) == len(got) > 300
+    for k, (a, b) in enumerate(zip(want, got)):
+        assert (a["lW"], a["W"], a["nW"], a["blocktype"]) == (b["lW"], b["W"], b["nW"], b["blocktype"]), k
+        assert np.float32(a["ampmax_out"]) == np.float32(b["ampmax_out"]), k
+        assert a["packet"] == b["packet"], "packet %d differs (W=%d)" % (k, a["W"])
+
+
+@pytest.mark.parametrize("ch,q,managed,kind,write,drain,seed", [
+    (2, 0.4, None, "s16", 40000, 6, 11), (2, 0.9, None, "gated", 9000, 3, 12), (1, 0.5, None, "gated", 70000, 40, 13),
+    (6, 0.3, None, "gated", 30000, 5, 14), (2, None, (-1, 128000, -1), "gated", 25000, 4, 15)])
+def test_look_ahead_under_random_writes_and_pulls(ch, q, managed, kind, write, drain, seed):
+    """Every write a pseudo-random 1 .. `write` samples, every pull a pseudo-random 0 .. `drain` blocks (the harness's
+    jitter: the same sequence for the reference and the hybrid): hits, stale plans, single blocks and batches in whatever
+    order they fall -- and the packets are the reference's."""
+    pcm = _stream(ch, 6.0, kind, seed=seed)
+    kw = dict(managed=managed) if managed else {}
+    args = (ch, 44100) if managed else (ch, 44100, q)
+    want = ref.RefEncoder(*args, **kw).encode_stream(pcm, write_frames=write, drain=drain, jitter=seed)
+    got = ref.RefEncoder(*args, hybrid=True, **kw).encode_stream(pcm, write_frames=write, drain=drain, jitter=seed)
+    assert len(want) == len(got) > 200
     for k, (a, b) in enumerate(zip(want, got)):
         assert (a["lW"], a["W"], a["nW"], a["blocktype"]) == (b["lW"], b["W"], b["nW"], b["blocktype"]), k
         assert np.float32(a["ampmax_out"]) == np.float32(b["ampmax_out"]), k

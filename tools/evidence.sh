@@ -21,5 +21,6 @@ timeout 300 python tools/gpu_block_latency.py >> $E/block_path.txt 2>/dev/null
 timeout 300 python tools/gpu_block_phases.py >> $E/block_path.txt 2>/dev/null
 : > $E/lookahead.txt
 for k in "60 0.4 s16" "60 0.9 gated" "30 0.4 s16 128000"; do timeout 400 python tools/gpu_lookahead_bench.py $k >> $E/lookahead.txt 2>/dev/null; done
+timeout 600 python tools/soak_lookahead.py 60 $E/soak_lookahead.txt > /dev/null 2>&1
 timeout 900 bash tools/alt_paths.sh > $E/alt_paths.txt 2>&1
 ls -la $E
