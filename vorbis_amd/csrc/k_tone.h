@@ -347,6 +347,99 @@ VAMD_DEV int chase_flat_chunk(const float *seeds, int s, int e) {
 // scatter half: seed[] for one channel-block (LDS), lib/psy.c:417-452,762-771
 //   peaks  HBM [nruns]: the maximum of logfft over each run of bins that share an octave line (run_peak, formed by
 //          the transform stage while the block's logfft was in LDS): a float per run is all this stage needs of it
+//
+// Round 5.  A wave spent its life waiting: per trip of 64 runs it asked for the runs' records and peaks, waited, asked
+// for the chosen rows' fence posts, waited, and then for each of up to seven groups of points asked for the group and
+// waited before its eight maxima went out -- up to nine dependent trips to L1/L2 per 64 runs, forty-five per block, in a
+// kernel of 600 vector instructions (12 800 cycles per wave, 4 % of them issuing).  Now: the fence posts of all 136
+// rows sit in three registers per lane (fetched once, beside the first records; a row's pair comes out of the lanes
+// with ds_bpermute), the next trip's records and peaks are asked for before the current trip's rows, and the groups a
+// trip needs are asked for four and three at a time, all of a batch in flight together: two trips to memory per 64
+// runs instead of nine.
+#if VAMD_GPU
+VAMD_DEV int seed_level(float amp, float dBoffset) {
+  int choice = (int)(((double)(amp + dBoffset) - 30.) * (double).1f);
+  choice = choice < 0 ? 0 : choice;
+  return choice > VAMD_P_LEVELS - 1 ? VAMD_P_LEVELS - 1 : choice;
+}
+template <int LP = 0>
+VAMD_DEV void tone_seed_block(const PsyP &P, const float *__restrict__ peaks, float global_ampmax,
+                              float local_ampmax, float *seed, PhaseClock &pc) {
+  const int nlines = P.total_octave_lines, nruns = P.nruns;
+  const int linesper = LP ? LP : P.eighth_octave_lines;
+  const int stride = P.curve_stride;
+  float att = local_ampmax + P.ath_adjatt;
+  if (att < P.ath_maxatt) att = P.ath_maxatt;
+  // first trip's records and peaks, and the fence posts of every row: one trip to memory for all of it
+  I4 rec_n = {0, 0, 0, 0};
+  float mx_n = 0.f;
+  if (LANE < nruns) {
+    rec_n = ((const I4 *)P.runs)[LANE];
+    mx_n = peaks[LANE];
+  }
+  static_assert(VAMD_P_BANDS * VAMD_P_LEVELS <= 3 * 64, "the rows' fence posts are kept three per lane");
+  int posts_of[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const int e = LANE + 64 * k;
+    posts_of[k] = VAMD_EHMER_MAX;  // (first = 56, last + 1 = 0: nothing)
+    if (e < VAMD_P_BANDS * VAMD_P_LEVELS) {
+      const F2 pp = *(const F2 *)(P.curves64 + (size_t)e * stride + VAMD_EHMER_MAX);
+      posts_of[k] = (int)pp.x | ((int)pp.y << 8);
+    }
+  }
+  WAVE_FOR(i, nlines) seed[i] = VAMD_NEGINF;  // (the padding either side is write-only)
+  WAVE_SYNC();
+  pc.mark(0);
+  const float dBoffset = P.max_curve_dB - global_ampmax;
+  for (int r0 = 0; r0 < nruns; r0 += NLANES) {  // (wave-uniform: every lane makes every trip)
+    const I4 rec = rec_n;
+    const float mx = mx_n;
+    const bool valid = r0 + LANE < nruns;
+    if (r0 + NLANES + LANE < nruns) {
+      rec_n = ((const I4 *)P.runs)[r0 + NLANES + LANE];
+      mx_n = peaks[r0 + NLANES + LANE];
+    }
+    const bool active = valid && mx + 6.f > f_from_bits((uint32_t)rec.w) + att;
+    const int e = rec.z * VAMD_P_LEVELS + seed_level(mx, dBoffset);
+    const int g0 = wave_gather(posts_of[0], e & 63), g1 = wave_gather(posts_of[1], e & 63), g2 = wave_gather(posts_of[2], e & 63);
+    const int pk = e < 64 ? g0 : (e < 128 ? g1 : g2);
+    const int p0 = active ? (pk & 0xff) : VAMD_EHMER_MAX, p1 = active ? (pk >> 8) : 0;
+    const F4 *__restrict__ row = (const F4 *)(P.curves64 + (size_t)e * stride);
+    float *p = seed + (rec.y - VAMD_EHMER_OFFSET * linesper - (linesper >> 1));
+    // The rows are finite only between their fence posts -- 8 to 50 of the 56 points, 12 to 25 for most of the
+    // spectrum -- so the points go in seven groups of eight, and a group that holds no finite point for any lane of
+    // the wave is skipped (one wave-uniform branch per group: per-POINT skipping was measured slower than no skipping
+    // at all).  Inside a group everything stays straight-line with immediate offsets.
+    bool need[VAMD_EHMER_MAX / 8];
+#pragma unroll
+    for (int g = 0; g < VAMD_EHMER_MAX / 8; g++) need[g] = wave_any(p0 < 8 * g + 8 && p1 > 8 * g);
+#pragma unroll
+    for (int b0 = 0; b0 < VAMD_EHMER_MAX / 8; b0 += 4) {
+      F4 c[4][2];
+#pragma unroll
+      for (int g = b0; g < b0 + 4 && g < VAMD_EHMER_MAX / 8; g++)
+        if (need[g] && active) {
+          c[g - b0][0] = row[2 * g];
+          c[g - b0][1] = row[2 * g + 1];
+        }
+#pragma unroll
+      for (int g = b0; g < b0 + 4 && g < VAMD_EHMER_MAX / 8; g++)
+        if (need[g] && active) {
+          float v[8];
+          f4_get(c[g - b0][0], v);
+          f4_get(c[g - b0][1], v + 4);
+#pragma unroll
+          for (int i = 0; i < 8; i++) lds_atomic_max(p + (8 * g + i) * linesper, mx + v[i]);
+        }
+    }
+  }
+  WAVE_SYNC();
+  if (LANE == 0) seed[0] = VAMD_NEGINF;  // seedptr > 0, lib/psy.c:406
+  WAVE_SYNC();
+  pc.mark(1);
+}
+#else
 template <int LP = 0>
 VAMD_DEV void tone_seed_block(const PsyP &P, const float *__restrict__ peaks, float global_ampmax,
                               float local_ampmax, float *seed, PhaseClock &pc) {
@@ -368,6 +461,7 @@ VAMD_DEV void tone_seed_block(const PsyP &P, const float *__restrict__ peaks, fl
   WAVE_SYNC();
   pc.mark(1);
 }
+#endif
 
 VAMD_DEV void tone_fold_block(const PsyP &P, float local_ampmax, float *seed, const float *seed_src,
                               const unsigned short *__restrict__ surv, int nsurv, float *gmin /* LDS [ngroups] */,
