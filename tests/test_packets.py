@@ -271,3 +271,43 @@ def test_gpu_many_streams_in_one_call():
         for k, (b, o) in enumerate(zip(st, out)):
             assert vorbis_amd.packet_bytes(o["packets"], o["packet_bits"]) == b["packet"], (s, k, b["W"])
         assert np.float32(states[s]) == np.float32(st[-1]["ampmax_out"])
+
+
+@pytest.mark.gpu
+@needs_ref
+@pytest.mark.parametrize("ch,quality,managed", [(2, 0.9, None), (2, 0.4, None), (1, 0.5, None), (2, None, (-1, 128000, -1))])
+def test_gpu_encode_blocks_is_the_reference_stream(ch, quality, managed):
+    """vamd_encode_blocks through the C ABI: stretches of CONSECUTIVE blocks of a real stream (short, long and transition
+    blocks as the reference's blockout cut them), the first block's incoming ampmax given and the chain between the blocks
+    on the device.  VBR: packets and both ends of every block's ampmax equal the reference's own stream.  Managed: the
+    fifteen candidates of every block equal vamd_encode_block's, block by block along the same chain."""
+    kw = dict(managed=managed) if managed else {}
+    args = (ch, 44100) if managed else (ch, 44100, quality)
+    e = ref.RefEncoder(*args, **kw)
+    an = vorbis_amd.Analyzer(e.pack_setup(), 0)
+    rng = np.random.default_rng(77)
+    frames = 44100 * 3
+    t = np.arange(frames)
+    x = (rng.random((ch, frames), dtype=np.float32) - 0.5) * 2 * np.where((t % 9000) < 900, 0.5, 0.0005).astype(np.float32)
+    blocks = ref.RefEncoder(*args, **kw).encode_stream(np.ascontiguousarray(x, dtype=np.float32))
+    assert len(blocks) > 120 and {b["W"] for b in blocks} == {0, 1}
+    for lo, hi in ((0, 1), (1, 3), (3, 70), (70, 71), (71, len(blocks))):   # one block, a pair, 67, one, the rest
+        part = blocks[lo:hi]
+        if managed and len(part) > 63:
+            part = part[:63]
+        pk, ain, aout, verdict = an.encode_blocks([b["pcm"] for b in part], [b["lW"] for b in part], [b["W"] for b in part],
+                                                  [b["nW"] for b in part], [b["blocktype"] for b in part],
+                                                  ampmax_in_first=part[0]["ampmax_in"], managed=bool(managed))
+        assert not verdict.any()
+        for k, b in enumerate(part):
+            assert np.float32(ain[k]).tobytes() == np.float32(b["ampmax_in"]).tobytes(), (lo, k)
+            assert np.float32(aout[k]).tobytes() == np.float32(b["ampmax_out"]).tobytes(), (lo, k)
+            if managed:
+                one, amp = an.encode_block(b["pcm"], b["lW"], b["W"], b["nW"], b["blocktype"], ampmax_in=b["ampmax_in"], managed=True)
+                assert pk[k] == one, (lo, k)
+                assert b["packet"] in pk[k]       # the bitrate manager's choice is one of the fifteen
+            else:
+                assert pk[k] == [b["packet"]], (lo, k)
+    # nothing to do is not an error
+    pk, ain, aout, verdict = an.encode_blocks([], [], [], [], [])
+    assert pk == [] and len(verdict) == 0

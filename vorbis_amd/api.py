@@ -135,6 +135,8 @@ def load_library():
     L.vamd_residue_offset.argtypes = [_vp, C.c_int, C.c_int]
     L.vamd_encode_block.argtypes = [_vp, C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _vp, _vp,
                                     C.c_long, _vp]
+    L.vamd_encode_blocks.argtypes = [_vp, C.c_long, C.POINTER(_vp), _vp, _vp, _vp, _vp, C.c_float, C.c_int, _vp, _vp, _vp, C.c_long, _vp,
+                                     _vp]
     L.vamd_profile.argtypes = [_vp, C.c_int]
     L.vamd_stage_ms.argtypes = [_vp, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]
     _lib = L
@@ -725,6 +727,29 @@ class Analyzer:
                                              C.cast(C.byref(amp), _vp), _vp(pk.ctypes.data), C.c_long(pk.shape[1]),
                                              _vp(bits.ctypes.data)))
         return [packet_bytes(pk[k], bits[k]) for k in range(nk)], amp.value
+
+    def encode_blocks(self, pcm, lW, W, nW, blocktype, ampmax_in_first=-9999.0, managed=False):
+        """vamd_encode_blocks: consecutive blocks of ONE stream in one launch sequence.  pcm: list of host numpy
+        [ch][blocksize[W[b]]]; lW / W / nW / blocktype: per block.  Returns (packets[b][k] as bytes -- None where the
+        block's verdict is not VAMD_OK --, ampmax_in float32[nb], ampmax_out float32[nb], verdict int32[nb])."""
+        ch, nb = self.channels, len(pcm)
+        self._need(nb == len(lW) == len(W) == len(nW) == len(blocktype), "one lW / W / nW / blocktype per block")
+        keep = [np.ascontiguousarray(x, dtype=np.float32) for x in pcm]
+        for b in range(nb):
+            self._need(int(W[b]) in (0, 1) and keep[b].shape == (ch, self.blocksizes[int(W[b])]),
+                       "pcm[%d] must be [%d][blocksize[W]]" % (b, ch))
+        ptrs = (_vp * max(1, nb * ch))(*[_vp(keep[b][c].ctypes.data) for b in range(nb) for c in range(ch)])
+        arr = [np.ascontiguousarray(v, dtype=np.int32) for v in (lW, W, nW, blocktype)]
+        nk, cap = (PACKETBLOBS if managed else 1), max(self.packet_capacity(0), self.packet_capacity(1), 4)
+        pk, bits = np.zeros((max(nb, 1), nk, cap), np.uint8), np.zeros((max(nb, 1), nk), np.int32)
+        ain, aout, verdict = np.zeros(max(nb, 1), np.float32), np.zeros(max(nb, 1), np.float32), np.zeros(max(nb, 1), np.int32)
+        self._bind_stream()
+        self._check(self.L.vamd_encode_blocks(self.h, C.c_long(nb), ptrs, *[_vp(a.ctypes.data) for a in arr],
+                                              C.c_float(ampmax_in_first), 1 if managed else 0, _vp(ain.ctypes.data),
+                                              _vp(aout.ctypes.data), _vp(pk.ctypes.data), C.c_long(cap),
+                                              _vp(bits.ctypes.data), _vp(verdict.ctypes.data)))
+        packets = [[packet_bytes(pk[b, k], bits[b, k]) for k in range(nk)] if verdict[b] == 0 else None for b in range(nb)]
+        return packets, ain[:nb], aout[:nb], verdict[:nb]
 
     # ---- the block-switching detector (vamd_envelope_search*) ---------------------------------
     def envelope_geometry(self):
