@@ -335,8 +335,9 @@ static int vamd_lookahead_on(void) {
  * nothing is shifted here, so every position stays in the buffer's current coordinates -- shifting subtracts the same
  * amount from both sides of every comparison below.  The cursor walk is lib/envelope.c:262-325, the size / window /
  * blocktype decisions lib/block.c:552-611 with _ve_envelope_mark lib/envelope.c:329-353.  Stops where blockout would
- * say "not enough data" -- and before anything the end of a stream changes (v->eofflag).  begin[k] = first sample of
- * planned block k's window in v->pcm[]. */
+ * say "not enough data", or at the stream's last block once the application has written its last samples (an
+ * application that writes a whole clip, signals the end and only then pulls its blocks gets them all looked ahead).
+ * begin[k] = first sample of planned block k's window in v->pcm[]. */
 static int vamd_plan_ahead(vorbis_dsp_state *v, int max, vamd_ahead_block *out, long *begin) {
   codec_setup_info *ci = v->vi->codec_setup;
   envelope_lookup *ve = ((private_state *)v->backend_state)->ve;
@@ -344,7 +345,8 @@ static int vamd_plan_ahead(vorbis_dsp_state *v, int max, vamd_ahead_block *out, 
   const long bs[2] = {ci->blocksizes[0], ci->blocksizes[1]};
   int W = (int)v->W, lW = (int)v->lW, n = 0;
   long centerW = v->centerW, cursor = ve->cursor, curmark = ve->curmark, j;
-  if (v->eofflag || !v->preextrapolate) return 0;
+  const long eof = v->eofflag; /* > 0: the last real sample's position, once the application has written its last (:664-673) */
+  if (eof < 0 || !v->preextrapolate) return 0;
   while (n < max) {
     const long testW = centerW + bs[W] / 4 + bs[1] / 2 + bs[0] / 4;
     int bp = -1, nW, blocktype;
@@ -361,8 +363,8 @@ static int vamd_plan_ahead(vorbis_dsp_state *v, int max, vamd_ahead_block *out, 
         break;
       }
     }
-    if (bp < 0) break; /* lib/block.c:558-560 */
-    nW = bs[0] == bs[1] ? 0 : bp;
+    if (bp < 0 && !eof) break; /* lib/block.c:558-560: not enough data to search a full long block -- unless no more will come */
+    nW = (bp < 0 || bs[0] == bs[1]) ? 0 : bp; /* :561-568 */
     centerNext = centerW + bs[W] / 4 + bs[nW] / 4;
     if (v->pcm_current < centerNext + bs[nW] / 2) break; /* :574-583 */
     if (W) {
@@ -378,6 +380,7 @@ static int vamd_plan_ahead(vorbis_dsp_state *v, int max, vamd_ahead_block *out, 
     begin[n] = centerW - bs[W] / 2;
     if (begin[n] < 0 || begin[n] + bs[W] > v->pcm_current) break;
     n++;
+    if (eof && centerW >= eof) break; /* the stream's last block, :664-670 */
     lW = W;
     W = nW;
     centerW = centerNext;

@@ -117,6 +117,35 @@ def test_look_ahead_under_random_writes_and_pulls(ch, q, managed, kind, write, d
         assert a["packet"] == b["packet"], "packet %d differs (W=%d)" % (k, a["W"])
 
 
+def _ahead_stats():
+    import ctypes as C
+    h, m, b = C.c_long(), C.c_long(), C.c_long()
+    ref.lib(hybrid=True).vamd_ahead_stats(C.byref(h), C.byref(m), C.byref(b))
+    return h.value, m.value, b.value
+
+
+@pytest.mark.parametrize("ch,q,managed,kind", [(2, 0.4, None, "gated"), (1, 0.9, None, "gated"), (2, None, (-1, 96000, -1), "s16")])
+def test_look_ahead_runs_to_the_end_of_a_stream(ch, q, managed, kind):
+    """An application that writes a whole clip, signals the end (vorbis_analysis_wrote(v, 0)) and only then pulls its
+    blocks: everything is determined at the first pull, the end of the stream included (lib/block.c:561-568: no mark
+    found and no more to come means a short next block; :664-670: the block centred past the last real sample is the
+    last), so all of it is looked ahead -- and equals the reference driven the same way, to the last packet."""
+    pcm = _stream(ch, 5.0, kind, seed=5)
+    kw = dict(managed=managed) if managed else {}
+    args = (ch, 44100) if managed else (ch, 44100, q)
+    want = ref.RefEncoder(*args, **kw).encode_stream(pcm, write_frames=pcm.shape[1], drain=1)
+    h0, m0, b0 = _ahead_stats()
+    got = ref.RefEncoder(*args, hybrid=True, **kw).encode_stream(pcm, write_frames=pcm.shape[1], drain=1)
+    h1, m1, b1 = _ahead_stats()
+    assert len(want) == len(got) > 150
+    for k, (a, b) in enumerate(zip(want, got)):
+        assert (a["lW"], a["W"], a["nW"], a["blocktype"]) == (b["lW"], b["W"], b["nW"], b["blocktype"]), k
+        assert np.float32(a["ampmax_out"]) == np.float32(b["ampmax_out"]), k
+        assert a["packet"] == b["packet"], "packet %d differs (W=%d)" % (k, a["W"])
+    per_batch = 63 if managed else 255
+    assert m1 == m0 and h1 - h0 >= len(got) - 2 - (len(got) // per_batch + 1)   # all but the batches' own first blocks
+
+
 _BATCH_WORKER = r'''
 import sys, threading, time, json
 sys.path.insert(0, @ROOT@)
