@@ -171,6 +171,10 @@ def parse(argv=None):
     ap.add_argument("--no-neighbours", action="store_true", help="skip the informational extra stages (profiling runs)")
     ap.add_argument("--no-parity-sample", action="store_true", help="skip the post-run oracle check of the timed batch")
     ap.add_argument("--no-clock-probe", action="store_true", help="do not sample the shader clock beside the timed steps")
+    ap.add_argument("--host-fed-only", default=None, help="development aid: run only host_fed for 'c4' or 'c5' and print its dict")
+    ap.add_argument("--feed-streams", type=int, default=256)
+    ap.add_argument("--feed-groups", type=int, default=12)
+    ap.add_argument("--feed-lanes", type=int, default=3)
     ap.add_argument("--no-workloads", action="store_true",
                     help="default (c4) run only: skip the other BASELINE configs (c2, c3, c5) that are measured after the headline")
     ap.add_argument("--parity-blocks", type=int, default=256)
@@ -563,6 +567,96 @@ class StreamRunner:
                                                                                self.plan.nblocks[0], self.plan.nblocks[1]))
 
 
+def host_fed(setup, kind, device, streams_per_group=256, frames=131072, groups=12, lanes=3, parity_streams=2):
+    """The H2D/D2H-inclusive figure: whole streams from PINNED HOST memory as 16-bit interleaved samples
+    in, finished packets back in host memory, through vamd_feed (include/vorbis_amd.h) -- upload, 16-bit -> float, both
+    stream ends, detector, block walk, full analysis, residue search, packet assembly and the packets' way home all inside
+    the clock, `lanes` groups in flight so that one group's upload runs beside another's kernels.  kind "c4": white noise
+    (long blocks only: the C4 shape as streams); "c5": the gated noise of config 5 (mixed sizes).  The clock runs from
+    the first vamd_feed_wrote() to the last group's packets, after one untimed group per lane (allocations).  Returns the
+    dict that goes into the line as host_fed[kind]; its parity sample re-encodes `parity_streams` of the timed streams with
+    the reference's own application loop fed the same 16-bit samples."""
+    import vorbis_amd
+    blob = vorbis_amd.default_setup_blob(setup)
+    ch = 2
+    feed = vorbis_amd.Feed(blob, devices=[device], lanes_per_device=lanes, max_streams=streams_per_group, max_frames=frames)
+    rng = np.random.default_rng(20260 + (kind == "c5"))
+    n = streams_per_group * frames * ch
+    # one synthetic group per lane, generated straight into the lane's pinned arena (a caller's decoder writes there)
+    slots = []
+    for _ in range(lanes):
+        slot, buf = feed.buffer(ch, np.int16)
+        x = rng.random(n, dtype=np.float32) - np.float32(0.5)
+        if kind == "c5":
+            t = np.arange(frames, dtype=np.int64)
+            period = (6000 + 977 * np.arange(streams_per_group, dtype=np.int64) % 9000)[:, None]
+            gate = np.where((t[None, :] % period) < 600, 1.0, 0.001).astype(np.float32)
+            x = (x.reshape(streams_per_group, frames, ch) * gate[:, :, None]).reshape(-1)
+        buf[:n] = np.round(x * np.float32(32767.0)).astype(np.int16)
+        if not slots:
+            keep_pcm = buf[:n].reshape(streams_per_group, frames, ch)[:parity_streams].copy()
+        slots.append(slot)
+    for slot in slots:                                  # untimed: every lane allocates its HBM and grows its arenas
+        feed.wrote(slot, streams_per_group, frames, vorbis_amd.FEED_S16)
+    keep = None
+    for slot in slots:
+        r = feed.packets(slot, copy=False)
+        if keep is None:
+            keep = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in r.items()}
+    # the timed run: `groups` groups, at most `lanes` in flight
+    t0 = time.perf_counter()
+    inflight, blocks, out_bytes, up_ms, dev_ms, issued = [], 0, 0, 0.0, 0.0, 0
+    for slot in slots:
+        feed.release(slot)
+    while issued < groups or inflight:
+        while issued < groups and len(inflight) < lanes:
+            slot, _ = feed.buffer(ch, np.int16)          # (the lane's arena still holds its samples: a caller would refill it here)
+            feed.wrote(slot, streams_per_group, frames, vorbis_amd.FEED_S16)
+            inflight.append(slot)
+            issued += 1
+        slot = inflight.pop(0)
+        r = feed.packets(slot, copy=False)
+        blocks += r["nblocks"]
+        out_bytes += r["total_bytes"]
+        up_ms += r["upload_ms"]
+        dev_ms += r["device_ms"]
+        feed.release(slot)
+    elapsed = time.perf_counter() - t0
+    in_bytes = groups * n * 2
+    d = {"value": blocks / elapsed, "unit": "stereo blocks/s, host s16 in -> host packets out", "seconds": elapsed, "groups": groups,
+         "streams_per_group": streams_per_group, "frames_per_stream": frames, "lanes": lanes, "blocks": int(blocks),
+         "input": "%d B/s16 interleaved stereo from pinned host memory, %.1f MB per group" % (2, n * 2 / 1e6),
+         "output": "packets end to end in pinned host memory, %.1f bytes per block" % (out_bytes / max(blocks, 1)),
+         "pcie_GBps": {"up_sustained": in_bytes / elapsed / 1e9, "up_while_copying": in_bytes / max(up_ms * 1e-3, 1e-9) / 1e9,
+                       "down_sustained": out_bytes / elapsed / 1e9},
+         "device_ms_per_group": dev_ms / groups, "upload_ms_per_group": up_ms / groups, "setup": setup}
+    # parity: the reference's application loop over the same 16-bit samples
+    try:
+        from tests import checker
+        from oracle import ref
+        if ref.available() and keep is not None and keep_pcm is not None:
+            chn, rate, q = checker.SETUPS[setup]
+            bad = npk = 0
+            for s_ in range(parity_streams):
+                planar = np.ascontiguousarray((keep_pcm[s_].astype(np.float32) / np.float32(32768.0)).T)
+                want = ref.RefEncoder(chn, rate, q).encode_stream(planar)
+                lo, hi = int(keep["stream_start"][s_]), int(keep["stream_start"][s_ + 1])
+                npk += len(want)
+                if hi - lo != len(want):
+                    bad += abs(hi - lo - len(want)) + 1
+                    continue
+                for k, w in enumerate(want):
+                    o, bits = int(keep["offset"][lo + k]), int(keep["bits"][lo + k])
+                    bad += bytes(keep["bytes"][o:o + (bits + 7) // 8]) != w["packet"] or int(keep["granulepos"][lo + k]) != w["granulepos"]
+            d["parity_sample"] = {"streams": parity_streams, "packets": npk, "mismatches": int(bad), "checker": "reference",
+                                  "compared": "every packet of whole streams (bytes, granulepos), first block to last, against the "
+                                              "reference's application loop fed the same 16-bit samples"}
+    except Exception as e:
+        d["parity_sample"] = {"packets": 0, "mismatches": None, "error": repr(e)}
+    feed.close()
+    return d
+
+
 def spawn_ranks(a, argv):
     """`python bench.py --gpus N` with no process group in the environment: launch the N ranks ourselves, exactly as
     the driver does (torch.distributed.run, one process per GPU, rendezvous on 127.0.0.1), and hand back their exit
@@ -700,6 +794,10 @@ def main(argv=None, make_runner=None):
     (tests/test_abi_and_host.py, gloo, world size 2) passes one (or names one with --runner)."""
     argv = list(sys.argv[1:] if argv is None else argv)
     a = parse(argv)
+    if a.host_fed_only:
+        print(json.dumps(host_fed("44k_stereo_q9" if a.host_fed_only == "c5" else "44k_stereo_q4", a.host_fed_only, 0,
+                                  streams_per_group=a.feed_streams, frames=a.stream_samples, groups=a.feed_groups, lanes=a.feed_lanes)))
+        return 0
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and a.gpus > 1:
         return spawn_ranks(a, argv)           # --gpus N means N ranks: launch them

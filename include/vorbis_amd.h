@@ -189,7 +189,7 @@ typedef struct vamd_batch_io {
  * 7), and a member the caller does not set is then a null pointer, which every entry point reads as "not wanted".  A
  * caller built against another header than the library it loads is refused by vamd_create() (VAMD_EVERSION) and can ask
  * beforehand with vamd_abi_version() != VAMD_ABI_VERSION. */
-#define VAMD_ABI_VERSION 8
+#define VAMD_ABI_VERSION 9
 int vamd_abi_version(void);
 /* The environment knobs in force for a context, as "NAME=value" words (read once, at vamd_create; vorbis_amd/csrc/vamd_knobs.h).  The
  * operating knobs (VAMD_VERBOSE, VAMD_BATCH_LANES / _EAGER / _JOIN / _SPIN_BELOW) are always honoured; the test knobs --
@@ -452,6 +452,20 @@ int vamd_plan_streams(vamd_ctx *ctx, const float *pcm, long stream_stride, long 
                       long nsamples, vamd_envelope_state *states, vamd_stream_plan *plan);
 int vamd_gather_blocks(vamd_ctx *ctx, const vamd_stream_plan *plan, int W, const float *pcm, long channel_stride,
                        float *pcm_blocks);
+/* vamd_plan_streams for COMPLETE streams, the two ends included (ABI 9): what the application loop of
+ * examples/encoder_example.c:179-236 makes of a stream it writes 1024 frames at a time and then closes with
+ * vorbis_analysis_wrote(v, 0).  Stream s, channel c occupies pcm + s*stream_stride + c*channel_stride, laid out
+ *   [ blocksizes[1]/2 samples of room | nframes real samples | 3 * blocksizes[1] samples of room ]
+ * (channel_stride >= their sum).  The call fills the room in front with the reference's backward LPC extrapolation of
+ * the stream's first samples (_preextrapolate_helper, lib/block.c:417-458: order 16, from the first blocksizes[1] + 1024
+ * samples), the room behind with its forward extrapolation of the last ones (lib/block.c:474-512: order 32, from as much
+ * of the last long block as the encoder still holds when the stream is closed -- which depends on where its block walk
+ * stands, so the walk is run up to there first), takes the detector over all of it and plans every block up to and
+ * including the stream's last (vb->eofflag, lib/block.c:664-670).  lib/lpc.c's arithmetic -- serial fp64 sums,
+ * Levinson-Durbin, the fp32 predictor chain -- is reproduced operation for operation.  `states` as vamd_plan_streams
+ * (all-zero on entry). */
+int vamd_plan_streams_whole(vamd_ctx *ctx, float *pcm, long stream_stride, long channel_stride, long nstreams,
+                            long nframes, vamd_envelope_state *states, vamd_stream_plan *plan);
 /* A plan's lists copied to host arrays (any may be NULL): per size class W lW / nW / blocktype / src [nblocks[W]],
  * order [nblocks[0] + nblocks[1]], stream_start [nstreams + 1].  Synchronises. */
 int vamd_plan_fetch(vamd_ctx *ctx, const vamd_stream_plan *plan, int32_t *const lW[2], int32_t *const nW[2],
@@ -487,6 +501,57 @@ void vamd_batcher_stats(vamd_batcher *b, long *batches, long *blocks, double *ru
  * ended, batch-size histogram.  Returns the length written. */
 long vamd_batcher_report(vamd_batcher *b, char *buf, long cap);
 vamd_ctx *vamd_batcher_context(vamd_batcher *b);
+
+/* ---- the host-fed farm (ABI 9): whole streams in from HOST memory, finished packets back to host memory, over one
+ * or several GPUs (SURVEY.md 8d "report separately H2D/D2H-inclusive", 8e).  Everything above assumes samples that are
+ * already in HBM, or one block per call; an encoder farm holds decoded audio in host memory -- 16-bit interleaved, as
+ * examples/encoder_example.c:179-202 reads it -- and wants Ogg payloads back.  A vamd_feed owns LANES (per device: a
+ * context, a HIP stream, a library thread, pinned input and output arenas, the streams' HBM buffers); a GROUP of streams
+ * travels through one lane:
+ *     upload (one copy command out of the pinned arena) -> 16-bit to float on the device (x / 32768.f, exactly
+ *     encoder_example.c:197-202) -> vamd_plan_streams_whole (both stream ends, detector, block walk) -> full analysis of
+ *     every block where it lies in the stream buffers, 50 % overlap read in place, ampmax chains per stream ->
+ *     residue search + packet assembly -> the packets laid end to end, written straight into the pinned output arena
+ * and while one lane computes, the next group's upload runs beside it on another lane's stream (the link and the
+ * shader array are separate resources).  Only samples cross the link upwards (4 bytes per stereo frame: 4 KB per long
+ * stereo block) and only packet bytes downwards.  The call sequence mirrors libvorbis' own:
+ *     slot = vamd_feed_buffer(f, &pcm)     like vorbis_analysis_buffer(): where to put the next group's samples
+ *                                          (blocks while every lane is busy); interleaved [stream][frame][channel]
+ *     vamd_feed_wrote(f, slot, ...)        like vorbis_analysis_wrote(): the group is the library's; returns at once
+ *     vamd_feed_packets(f, slot, &out)     waits for the group; pointers into the lane's pinned output arena
+ *     vamd_feed_release(f, slot)           the lane may be handed out again
+ * Every stream of a group is complete and `frames` long (group streams of like length; a group per length otherwise).
+ * Per stream the packets are byte for byte what the reference encoder emits for the same samples written 1024 frames
+ * at a time and closed with vorbis_analysis_wrote(v, 0) -- first block to last (tests/test_feed.py).  VBR setups whose
+ * packets the GPU assembles (vamd_packet_capacity() > 0).  Thread rules: one thread drives a feed (or several, each
+ * with its own slots); the lanes' threads are the library's. */
+typedef struct vamd_feed vamd_feed;
+#define VAMD_FEED_S16 0 /* int16_t, interleaved; sample = x / 32768.f */
+#define VAMD_FEED_F32 1 /* float, interleaved, already scaled to +-1 */
+/* devices: HIP ordinals (NULL / 0: the calling thread's current device); lanes_per_device >= 1 (2 or 3 overlap upload,
+ * compute and hand-back); a group holds at most max_streams streams of at most max_frames frames each. */
+int vamd_feed_create(vamd_feed **out, const void *setup_blob, size_t blob_bytes, const int *devices, int ndevices,
+                     int lanes_per_device, long max_streams, long max_frames);
+void vamd_feed_destroy(vamd_feed *f);
+int vamd_feed_lanes(const vamd_feed *f);
+int vamd_feed_device(const vamd_feed *f, int slot);   /* the device lane `slot` runs on */
+int vamd_feed_buffer(vamd_feed *f, void **pcm);       /* >= 0: the slot; < 0: an OV_*-valued error */
+int vamd_feed_wrote(vamd_feed *f, int slot, long nstreams, long frames, int format);
+typedef struct vamd_feed_result {
+  int64_t nstreams, nblocks;      /* blocks == packets, all streams */
+  const int64_t *stream_start;    /* [nstreams + 1]: stream s owns packets [stream_start[s], stream_start[s+1]), in stream order */
+  const int64_t *offset;          /* [nblocks] where the packet starts in bytes[] (a multiple of 4) */
+  const int32_t *bits;            /* [nblocks] oggpack_bits() of the packet: (bits + 7) / 8 bytes; -1: no packet, see info */
+  const int64_t *granulepos;      /* [nblocks] ogg_packet.granulepos (vb->granulepos, lib/block.c:620) */
+  const uint8_t *info;            /* [nblocks] bit 0: vb->W; bit 1: last packet of its stream (op.e_o_s); bits 2-3: VAMD_STATUS_*
+                                     of a block outside the input domain (no packet) */
+  const uint8_t *bytes;           /* the packets, end to end */
+  int64_t total_bytes;
+  double upload_ms, device_ms, total_ms; /* of this group: the upload alone; upload to last kernel; wrote() to ready */
+} vamd_feed_result;
+int vamd_feed_packets(vamd_feed *f, int slot, vamd_feed_result *out);
+int vamd_feed_release(vamd_feed *f, int slot);
+const char *vamd_feed_last_error(const vamd_feed *f);
 
 #ifdef __cplusplus
 }

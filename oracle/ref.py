@@ -52,6 +52,7 @@ class _BlockRec(C.Structure):
         ("lW", C.c_int), ("W", C.c_int), ("nW", C.c_int), ("blocktype", C.c_int),
         ("ampmax_in", C.c_float), ("ampmax_out", C.c_float),
         ("pcm_offset", C.c_long), ("packet_offset", C.c_long), ("packet_bytes", C.c_long),
+        ("granulepos", C.c_long), ("eos", C.c_long),
     ]
 
 
@@ -329,7 +330,7 @@ class RefEncoder:
             r = recs[k]
             n = self.blocksize(r.W)
             d = dict(lW=r.lW, W=r.W, nW=r.nW, blocktype=r.blocktype, ampmax_in=r.ampmax_in,
-                     ampmax_out=r.ampmax_out)
+                     ampmax_out=r.ampmax_out, granulepos=int(r.granulepos), eos=int(r.eos))
             d["pcm"] = pcm_out[r.pcm_offset:r.pcm_offset + ch * n].reshape(ch, n).copy() if r.pcm_offset >= 0 else None
             d["packet"] = bytes(pk_out[r.packet_offset:r.packet_offset + r.packet_bytes]) if r.packet_offset >= 0 else None
             d["error"] = int(r.packet_bytes) if r.packet_bytes < 0 else 0

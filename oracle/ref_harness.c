@@ -542,6 +542,8 @@ typedef struct ref_block_rec {
   long pcm_offset;     /* offset (floats) of this block's [ch][n] PCM in pcm_out */
   long packet_offset;  /* offset of this block's packet in packets_out */
   long packet_bytes;
+  long granulepos;     /* ogg_packet.granulepos as vorbis_analysis() / vorbis_bitrate_flushpacket() set it */
+  long eos;            /* ogg_packet.e_o_s */
 } ref_block_rec;
 
 /* Managed-mode counterpart of ref_tap_block: runs the real vorbis_analysis(vb, NULL) first (the
@@ -661,6 +663,8 @@ long ref_encode_stream_ex(ref_enc *e, const float *pcm, long frames, long write_
       if (nblocks < max_blocks && recs) {
         ref_block_rec *r = recs + nblocks;
         r->ampmax_out = vbi->ampmax;
+        r->granulepos = ret ? -1 : (long)op.granulepos;
+        r->eos = ret ? 0 : (long)op.e_o_s;
         r->packet_bytes = ret ? ret : op.bytes;
         r->packet_offset = -1;
         if (!ret && packets_out && pkt_used + op.bytes <= packets_cap) {

@@ -8,7 +8,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 VAMD_OK, VAMD_EFAULT, VAMD_EIMPL, VAMD_EINVAL, VAMD_EVERSION, VAMD_EDOMAIN, VAMD_ENONFINITE = 0, -129, -130, -131, -134, -140, -141
-ABI_VERSION = 8             # VAMD_ABI_VERSION of the header this mirror was written against
+ABI_VERSION = 9             # VAMD_ABI_VERSION of the header this mirror was written against
 QUANT_LIMIT_SQUARE, QUANT_LIMIT_INT = 46340, 0x7fffff80
 STATUS_RANGE, STATUS_NONFINITE = 1, 2   # bits of the `status` output (vorbis_amd.h, "Input domain")
 LEVEL_TRANSFORM, LEVEL_PSY, LEVEL_FULL = 1, 2, 3
@@ -25,7 +25,9 @@ EXPORTED_SYMBOLS = ["vamd_create_abi", "vamd_encode_blocks", "vamd_clock_probe",
                     "vamd_plan_streams", "vamd_gather_blocks", "vamd_plan_fetch",
                     "vamd_batcher_create", "vamd_batcher_destroy", "vamd_batcher_attach", "vamd_batcher_detach",
                     "vamd_batcher_encode_block", "vamd_batcher_last_error", "vamd_batcher_stats", "vamd_batcher_context", "vamd_batcher_report",
-                    "vamd_input_status", "vamd_calib_copy", "vamd_abi_version"]
+                    "vamd_input_status", "vamd_calib_copy", "vamd_abi_version", "vamd_plan_streams_whole",
+                    "vamd_feed_create", "vamd_feed_destroy", "vamd_feed_lanes", "vamd_feed_device", "vamd_feed_buffer", "vamd_feed_wrote",
+                    "vamd_feed_packets", "vamd_feed_release", "vamd_feed_last_error"]
 PACKETBLOBS = 15
 
 _vp = C.c_void_p
@@ -34,6 +36,12 @@ _vp = C.c_void_p
 class _Plan(C.Structure):
     _fields_ = [("nstreams", C.c_int64), ("nblocks", C.c_int64 * 2), ("lW", _vp * 2), ("nW", _vp * 2), ("blocktype", _vp * 2),
                 ("src", _vp * 2), ("order", _vp), ("stream_start", _vp)]
+
+
+class _FeedResult(C.Structure):  # vamd_feed_result
+    _fields_ = [("nstreams", C.c_int64), ("nblocks", C.c_int64), ("stream_start", _vp), ("offset", _vp), ("bits", _vp),
+                ("granulepos", _vp), ("info", _vp), ("bytes", _vp), ("total_bytes", C.c_int64), ("upload_ms", C.c_double),
+                ("device_ms", C.c_double), ("total_ms", C.c_double)]
 
 
 class _Desc(C.Structure):
@@ -129,6 +137,18 @@ def load_library():
     L.vamd_analyze_block_managed.argtypes = [_vp, C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_float] + [_vp] * 9
     L.vamd_plan_streams.argtypes = [_vp, _vp, C.c_long, C.c_long, C.c_long, C.c_long, _vp, C.POINTER(_Plan)]
     L.vamd_gather_blocks.argtypes = [_vp, C.POINTER(_Plan), C.c_int, _vp, C.c_long, _vp]
+    L.vamd_plan_streams_whole.argtypes = [_vp, _vp, C.c_long, C.c_long, C.c_long, C.c_long, _vp, C.POINTER(_Plan)]
+    L.vamd_feed_create.argtypes = [C.POINTER(_vp), _vp, C.c_size_t, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_long, C.c_long]
+    L.vamd_feed_destroy.argtypes = [_vp]
+    L.vamd_feed_destroy.restype = None
+    L.vamd_feed_lanes.argtypes = [_vp]
+    L.vamd_feed_device.argtypes = [_vp, C.c_int]
+    L.vamd_feed_buffer.argtypes = [_vp, C.POINTER(_vp)]
+    L.vamd_feed_wrote.argtypes = [_vp, C.c_int, C.c_long, C.c_long, C.c_int]
+    L.vamd_feed_packets.argtypes = [_vp, C.c_int, C.POINTER(_FeedResult)]
+    L.vamd_feed_release.argtypes = [_vp, C.c_int]
+    L.vamd_feed_last_error.argtypes = [_vp]
+    L.vamd_feed_last_error.restype = C.c_char_p
     L.vamd_plan_fetch.argtypes = [_vp, C.POINTER(_Plan), _vp * 2, _vp * 2, _vp * 2, _vp * 2, _vp, _vp]
     L.vamd_packet_capacity.argtypes = [_vp, C.c_int]
     L.vamd_submaps.argtypes = [_vp, C.c_int]
@@ -549,6 +569,25 @@ class Analyzer:
                                              C.byref(plan)))
         return plan, states
 
+    def plan_streams_whole(self, streams, nframes, states=None):
+        """vamd_plan_streams_whole: COMPLETE streams.  streams: cuda float32 [nstreams, ch, row], every channel row laid
+        out [blocksizes[1]/2 of room | nframes real samples | >= 3 * blocksizes[1] of room]; the call fills the room
+        either end with the reference's LPC extrapolations (lib/block.c:417-458, :474-512), so `streams` is written.
+        Returns (plan, states) as plan_streams; the plan runs to each stream's last block."""
+        t = self.torch
+        self._need_tensor(streams, t.float32, "streams")
+        self._need(streams.dim() == 3 and streams.shape[1] == self.channels, "streams must be [nstreams, %d, row]" % self.channels)
+        ns, ch, ln = streams.shape
+        self._need(ln % 4 == 0 and ln >= self.blocksizes[1] // 2 + nframes + 3 * self.blocksizes[1],
+                   "a channel row needs blocksizes[1]/2 + nframes + 3 * blocksizes[1] samples (a multiple of 4)")
+        if states is None:
+            states = t.zeros((ns, C.sizeof(EnvelopeState)), dtype=t.uint8, device=self._dev())
+        plan = _Plan()
+        self._bind_stream()
+        self._check(self.L.vamd_plan_streams_whole(self.h, _vp(streams.data_ptr()), ch * ln, ln, ns, int(nframes), _vp(states.data_ptr()),
+                                                   C.byref(plan)))
+        return plan, states
+
     def plan_lists(self, plan):
         """A plan on the host: dict with per size class lW / nW / blocktype / src arrays, order and stream_start."""
         out = {}
@@ -798,6 +837,111 @@ class EnvelopeState(C.Structure):
     """vamd_envelope_state (include/vorbis_amd.h); all-zero = start of a stream."""
     _fields_ = [("steps", C.c_int64), ("stretch", C.c_int32), ("pad", C.c_int32),
                 ("near_hist", C.c_float * 30 * MAX_CH), ("amp_hist", C.c_float * 8 * 16 * MAX_CH)]
+
+
+FEED_S16, FEED_F32 = 0, 1
+
+
+class Feed:
+    """vamd_feed: whole streams from HOST memory in (interleaved int16 / float32), finished packets back to host
+    memory, over one or several GPUs (include/vorbis_amd.h, "the host-fed farm").  The call sequence is libvorbis'
+    own, for a group of streams: buffer() -> fill -> wrote() -> packets() -> release()."""
+
+    def __init__(self, setup_blob, devices=None, lanes_per_device=2, max_streams=256, max_frames=131072):
+        self.L = load_library()
+        blob = np.ascontiguousarray(setup_blob, dtype=np.uint8)
+        devs = list(devices) if devices else []
+        arr = (C.c_int * max(1, len(devs)))(*devs)
+        h = _vp()
+        r = self.L.vamd_feed_create(C.byref(h), _vp(blob.ctypes.data), blob.size, arr if devs else None, len(devs), lanes_per_device,
+                                    max_streams, max_frames)
+        if r:
+            raise VamdError(r, "vamd_feed_create failed (setup without GPU-assembled packets, bad arguments, or a HIP failure)")
+        self.h = h
+        self.max_streams, self.max_frames = max_streams, max_frames
+        self.lanes = self.L.vamd_feed_lanes(self.h)
+        # channels of the setup: the blob's header says so, but the library is the authority -- ask a throw-away question
+        self._in_bytes = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.vamd_feed_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, r):
+        if r < 0:
+            raise VamdError(r, self.L.vamd_feed_last_error(self.h).decode())
+        return r
+
+    def device(self, slot):
+        return self._check(self.L.vamd_feed_device(self.h, slot))
+
+    def buffer(self, channels, dtype=np.int16):
+        """-> (slot, array [max_streams * max_frames * channels] of dtype over the lane's pinned input arena)"""
+        p = _vp()
+        slot = self._check(self.L.vamd_feed_buffer(self.h, C.byref(p)))
+        n = self.max_streams * self.max_frames * channels
+        ct = C.c_int16 if np.dtype(dtype) == np.int16 else C.c_float
+        arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), shape=(n,))
+        return slot, arr
+
+    def wrote(self, slot, nstreams, frames, fmt=FEED_S16):
+        self._check(self.L.vamd_feed_wrote(self.h, slot, nstreams, frames, fmt))
+
+    def packets(self, slot, copy=True):
+        """Waits for the group.  -> dict: nstreams, nblocks, stream_start, offset, bits, granulepos, info (numpy views over
+        the lane's pinned output arena, or copies), bytes, total_bytes, upload_ms, device_ms, total_ms."""
+        r = _FeedResult()
+        self._check(self.L.vamd_feed_packets(self.h, slot, C.byref(r)))
+        nb, ns = int(r.nblocks), int(r.nstreams)
+
+        def view(p, ct, n):
+            if n == 0:
+                return np.zeros(0, np.dtype(ct))
+            a = np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), shape=(n,))
+            return a.copy() if copy else a
+        return {"nstreams": ns, "nblocks": nb, "stream_start": view(r.stream_start, C.c_int64, ns + 1),
+                "offset": view(r.offset, C.c_int64, nb), "bits": view(r.bits, C.c_int32, nb),
+                "granulepos": view(r.granulepos, C.c_int64, nb), "info": view(r.info, C.c_uint8, nb),
+                "bytes": view(r.bytes, C.c_uint8, int(r.total_bytes)), "total_bytes": int(r.total_bytes),
+                "upload_ms": r.upload_ms, "device_ms": r.device_ms, "total_ms": r.total_ms}
+
+    def release(self, slot):
+        self._check(self.L.vamd_feed_release(self.h, slot))
+
+    def encode(self, pcm, fmt=None):
+        """One group, synchronously: pcm [nstreams, frames, ch] int16 or float32 (host).  -> per stream a list of
+        (packet bytes, granulepos, W, e_o_s)."""
+        pcm = np.ascontiguousarray(pcm)
+        ns, frames, ch = pcm.shape
+        if fmt is None:
+            fmt = FEED_S16 if pcm.dtype == np.int16 else FEED_F32
+        slot, buf = self.buffer(ch, np.int16 if fmt == FEED_S16 else np.float32)
+        try:
+            buf[:pcm.size] = pcm.reshape(-1)
+            self.wrote(slot, ns, frames, fmt)
+            r = self.packets(slot)
+        finally:
+            try:
+                self.release(slot)
+            except VamdError:
+                pass
+        out = []
+        for s in range(ns):
+            row = []
+            for k in range(int(r["stream_start"][s]), int(r["stream_start"][s + 1])):
+                bits = int(r["bits"][k])
+                o = int(r["offset"][k])
+                data = bytes(r["bytes"][o:o + (bits + 7) // 8]) if bits >= 0 else None
+                row.append((data, int(r["granulepos"][k]), int(r["info"][k]) & 1, (int(r["info"][k]) >> 1) & 1))
+            out.append(row)
+        return out
 
 
 def envelope_marks(ret, first=0, marks=None):

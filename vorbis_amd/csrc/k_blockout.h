@@ -11,10 +11,12 @@
 // comparison, so the decisions are the same.  The one asymmetry -- ve->curmark stops being shifted once it
 // is negative, lib/envelope.c:372 -- only ever makes an already out-of-range mark stay out of range.
 //
-// What a plan covers: the blocks the reference would hand out while the data given suffices, i.e. with
-// v->eofflag == 0 throughout.  The end-of-stream padding and its forced short blocks (lib/block.c:486-532,
-// :558-563) depend on the LPC extrapolation of the tail, host code again: a caller that closes a stream
-// appends that tail to the buffer and plans over it.
+// What a plan covers: with BlockoutP::eof == 0 the blocks the reference would hand out while the data given suffices,
+// i.e. with v->eofflag == 0 throughout.  With eof > 0 the stream ENDS at that sample (v->eofflag of
+// vorbis_analysis_wrote(v, 0), lib/block.c:474-488, as an absolute index) and the buffer holds the reference's
+// three long blocks of LPC padding behind it (k_lpc.h): a cursor walk that runs out of steps then forces a short
+// next block instead of waiting (lib/block.c:558-563), and the block whose centre lies at or beyond eof is the
+// stream's last (:664-670).
 #pragma once
 #include "vamd_wave.h"
 
@@ -29,6 +31,7 @@ struct BlockoutP {
   long nsamples;    // samples per channel in each stream's buffer
   long nsteps;      // detector steps available per stream (flags[s][0 .. nsteps))
   int maxblocks;    // capacity of a stream's row in `blocks`
+  long eof;         // 0: the stream goes on (more data may come); > 0: v->eofflag as an absolute sample index
 };
 
 // one planned block: W | lW << 1 | nW << 2 | blocktype << 3 in `kind`, and where its window starts
@@ -58,8 +61,10 @@ VAMD_DEV long blockout_steps(const BlockoutP &B) {
 // The walk for one stream.  Returns the number of blocks planned (<= maxblocks) and counts per size class.
 //   marks  ve->mark[] of the steps [0, last) as bytes (mark_at applied by the caller's lanes; entries at and beyond
 //          `last` are 0: steps not taken yet)
+//   pending_center  (optional) centerW of the block the walk stopped in front of: where the reference's buffer would
+//          begin (centerW - blocksizes[1]/2) when vorbis_analysis_wrote(v, 0) pads the stream
 VAMD_DEV int plan_stream(const BlockoutP &B, const unsigned char *marks, PlannedBlock *__restrict__ out,
-                         int *count_short, int *count_long) {
+                         int *count_short, int *count_long, long *pending_center = nullptr) {
   const long step = B.searchstep;
   // vorbis_analysis_init / _ve_envelope_init: lib/block.c:211-213, lib/envelope.c:41
   int W = 0, lW = 0;
@@ -113,8 +118,8 @@ VAMD_DEV int plan_stream(const BlockoutP &B, const unsigned char *marks, Planned
       }
     }
 #endif
-    if (bp < 0) break;  // "not enough data currently to search for a full long block", lib/block.c:558-560
-    const int nW = B.bs[0] == B.bs[1] ? 0 : bp;
+    if (bp < 0 && !B.eof) break;  // "not enough data currently to search for a full long block", lib/block.c:558-560
+    const int nW = (bp < 0 || B.bs[0] == B.bs[1]) ? 0 : bp;  // (at the end of a stream: nW = 0, :561)
     const long centerNext = centerW + B.bs[W] / 4 + B.bs[nW] / 4;
     if (B.nsamples < centerNext + B.bs[nW] / 2) break;  // lib/block.c:574-583
     // ---- the block, lib/block.c:589-611
@@ -135,12 +140,16 @@ VAMD_DEV int plan_stream(const BlockoutP &B, const unsigned char *marks, Planned
 #endif
       blocktype = hit ? 0 /* BLOCKTYPE_IMPULSE */ : 1 /* BLOCKTYPE_PADDING */;
     }
-    if (LANE == 0) {
+    if (LANE == 0 && out) {
       out[n].kind = W | (lW << 1) | (nW << 2) | (blocktype << 3);
       out[n].begin = (int)(centerW - B.bs[W] / 2);
     }
     n++;
     if (W) n1++; else n0++;
+    if (B.eof && centerW >= B.eof) {  // the stream's last block (vb->eofflag = 1), lib/block.c:664-670
+      centerW = -1;
+      break;
+    }
     // ---- advance, lib/block.c:649-685 (positions stay absolute: nothing to shift)
     lW = W;
     W = nW;
@@ -148,6 +157,7 @@ VAMD_DEV int plan_stream(const BlockoutP &B, const unsigned char *marks, Planned
   }
   *count_short = n0;
   *count_long = n1;
+  if (pending_center) *pending_center = centerW;  // (-1: the stream is over)
   return n;
 }
 

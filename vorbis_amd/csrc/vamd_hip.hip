@@ -34,6 +34,7 @@
 #include "k_residue.h"
 #include "k_pack.h"
 #include "k_blockout.h"
+#include "k_lpc.h"
 
 using namespace vamd;
 
@@ -1458,8 +1459,10 @@ int vamd_envelope_search(vamd_ctx *c, const float *const *pcm, long nsteps, vamd
   return VAMD_OK;
 }
 
-int vamd_plan_streams(vamd_ctx *c, const float *pcm, long stream_stride, long channel_stride, long nstreams, long nsamples,
-                      vamd_envelope_state *states, vamd_stream_plan *plan) {
+// whole != 0: the streams are complete (vamd_plan_streams_whole) -- `nsamples` counts the space in front of the first
+// sample and the real samples; the buffers have room for the end-of-stream padding behind them
+static int plan_streams(vamd_ctx *c, float *pcm, long stream_stride, long channel_stride, long nstreams, long nsamples,
+                        vamd_envelope_state *states, vamd_stream_plan *plan, int whole) {
   DeviceGuard dev_guard(c);
   if (!c) return VAMD_EINVAL;
   if (!plan) return fail(c, VAMD_EINVAL, "null plan");
@@ -1470,32 +1473,70 @@ int vamd_plan_streams(vamd_ctx *c, const float *pcm, long stream_stride, long ch
   if ((stream_stride | channel_stride) & 3) return fail(c, VAMD_EINVAL, "stream / channel strides must be multiples of 4 samples");
   if (nstreams > 0x3fffffffL || nsamples > 0x3fffffffL) return fail(c, VAMD_EINVAL, "too many streams / samples for one plan");
   const EnvP &E = c->B.env;
+  const int ch = c->B.channels, head = c->B.bs[1] / 2, pad = whole ? 3 * c->B.bs[1] : 0;
+  if (whole && (nsamples < head || channel_stride < nsamples + pad))
+    return fail(c, VAMD_EINVAL, "whole streams: a channel needs blocksizes[1]/2 samples of room in front and 3 * blocksizes[1] behind its samples");
   BlockoutP B;
   B.bs[0] = c->B.bs[0];
   B.bs[1] = c->B.bs[1];
   B.searchstep = E.searchstep;
   B.nsamples = nsamples;
-  B.nsteps = nsamples / E.searchstep - VAMD_VE_WIN;  // the steps _ve_envelope_search takes with this much data (lib/envelope.c:223-224)
-  if (B.nsteps < 0) B.nsteps = 0;
-  B.maxblocks = (int)(nsamples / (B.bs[0] / 2)) + 2;  // a block advances the stream by at least blocksizes[0]/2
+  B.eof = 0;
+  // the steps _ve_envelope_search takes with this much data (lib/envelope.c:223-224); a whole stream's padding adds
+  // pad / searchstep more, taken in a second pass once the padding exists
+  long steps1 = nsamples / E.searchstep - VAMD_VE_WIN;
+  if (steps1 < 0) steps1 = 0;
+  long steps_all = (nsamples + pad) / E.searchstep - VAMD_VE_WIN;
+  if (steps_all < 0) steps_all = 0;
+  B.nsteps = steps1;
+  B.maxblocks = (int)((nsamples + pad) / (B.bs[0] / 2)) + 2;  // a block advances the stream by at least blocksizes[0]/2
   plan->nstreams = nstreams;
   void *v_flags, *v_blocks, *v_counts, *v_base;
   int r;
-  if ((r = ws_get(c, 0, vamd_ctx::WS_PLAN_FLAGS, (size_t)nstreams * (B.nsteps ? B.nsteps : 1), &v_flags))) return r;
+  if ((r = ws_get(c, 0, vamd_ctx::WS_PLAN_FLAGS, (size_t)nstreams * (steps_all ? steps_all : 1), &v_flags))) return r;
   if ((r = ws_get(c, 0, vamd_ctx::WS_PLAN_BLOCKS, (size_t)nstreams * B.maxblocks * sizeof(PlannedBlock), &v_blocks))) return r;
   if ((r = ws_get(c, 0, vamd_ctx::WS_PLAN_COUNTS, (size_t)nstreams * 2 * sizeof(int), &v_counts))) return r;
   if ((r = ws_get(c, 0, vamd_ctx::WS_PLAN_BASE, (size_t)(3 * nstreams + 1) * sizeof(long long), &v_base))) return r;
-  if (B.nsteps && (r = vamd_envelope_search_batch(c, pcm, stream_stride, channel_stride, nstreams, B.nsteps, states, (unsigned char *)v_flags)))
-    return r;
   hipStream_t s = c->stream;
-  const size_t plan_lds = (size_t)((B.nsteps + 4 + 15) & ~15L);
+  const size_t plan_lds = (size_t)((steps_all + 4 + 15) & ~15L);
   if (plan_lds > c->lds_per_block) return fail(c, VAMD_EINVAL, "streams too long for one plan (their marks must fit a workgroup's LDS)");
   // (above the default 64 KB of dynamic LDS the launch needs the opt-in, and a launch that fails leaves counts[] --
   // which sizes everything below -- uninitialised: hence the checks straight after it)
   HIP_TRY(c, hipFuncSetAttribute((const void *)k_plan_streams, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_per_block));
+  unsigned char *flags1 = (unsigned char *)v_flags, *flags2 = flags1 + (size_t)nstreams * steps1;
+  if (whole) {
+    // the start of a stream as the example's 1024-sample writes make it (lib/block.c:524-528: the helper runs after the
+    // first write that leaves more than blocksizes[1] samples beyond the centre, or when the stream is closed)
+    const long frames = nsamples - head;
+    long n_head = ((long)c->B.bs[1] / 1024 + 1) * 1024;
+    if (frames < n_head) n_head = frames;
+    const size_t lpc_lds = 80 * 8 + VAMD_LPC_MAX_ORDER * 4 + (size_t)(n_head + head > c->B.bs[1] + pad ? n_head + head : c->B.bs[1] + pad) * 4;
+    if (lpc_lds > c->lds_per_block) return fail(c, VAMD_EIMPL, "block size too large for the stream-end extrapolation");
+    HIP_TRY(c, hipFuncSetAttribute((const void *)k_lpc_head, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_per_block));
+    HIP_TRY(c, hipFuncSetAttribute((const void *)k_lpc_tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_per_block));
+    if (n_head > 32)
+      hipLaunchKernelGGL(k_lpc_head, dim3((unsigned)(nstreams * ch)), dim3(64), lpc_lds, s, ch, nstreams, pcm, stream_stride,
+                         channel_stride, head, (int)n_head);
+    if (steps1 && (r = vamd_envelope_search_batch(c, pcm, stream_stride, channel_stride, nstreams, steps1, states, flags1))) return r;
+    // where every stream's walk stands when the data runs out: the reference's buffer begins blocksizes[1]/2 before it
+    void *v_pending;
+    if ((r = ws_get(c, 0, vamd_ctx::WS_PLAN_PENDING, (size_t)nstreams * sizeof(long long), &v_pending))) return r;
+    hipLaunchKernelGGL(k_plan_streams, dim3((unsigned)nstreams), dim3(64), plan_lds, s, B, nstreams, flags1, steps1, flags2,
+                       (PlannedBlock *)nullptr, (int *)nullptr, (long long *)v_pending);
+    hipLaunchKernelGGL(k_lpc_tail, dim3((unsigned)(nstreams * ch)), dim3(64), lpc_lds, s, ch, nstreams, pcm, stream_stride,
+                       channel_stride, nsamples, c->B.bs[1], pad, (const long long *)v_pending);
+    HIP_TRY(c, hipGetLastError());
+    if (steps_all > steps1 &&
+        (r = vamd_envelope_search_batch(c, pcm + steps1 * E.searchstep, stream_stride, channel_stride, nstreams, steps_all - steps1, states, flags2)))
+      return r;
+    B.eof = nsamples;
+    B.nsamples = nsamples + pad;
+    B.nsteps = steps_all;
+  } else if (steps1 && (r = vamd_envelope_search_batch(c, pcm, stream_stride, channel_stride, nstreams, steps1, states, flags1)))
+    return r;
   HIP_TRY(c, hipMemsetAsync(v_counts, 0, (size_t)nstreams * 2 * sizeof(int), s));
-  hipLaunchKernelGGL(k_plan_streams, dim3((unsigned)nstreams), dim3(64), plan_lds, s, B, nstreams,
-                     (const unsigned char *)v_flags, (PlannedBlock *)v_blocks, (int *)v_counts);
+  hipLaunchKernelGGL(k_plan_streams, dim3((unsigned)nstreams), dim3(64), plan_lds, s, B, nstreams, flags1, steps1, flags2,
+                     (PlannedBlock *)v_blocks, (int *)v_counts, (long long *)nullptr);
   HIP_TRY(c, hipGetLastError());
   std::vector<int> counts((size_t)nstreams * 2);
   HIP_TRY(c, hipMemcpyAsync(counts.data(), v_counts, counts.size() * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1556,6 +1597,17 @@ int vamd_plan_streams(vamd_ctx *c, const float *pcm, long stream_stride, long ch
   plan->order = O.order;
   plan->stream_start = (const int64_t *)((const long long *)v_base + 2 * nstreams);
   return VAMD_OK;
+}
+
+int vamd_plan_streams(vamd_ctx *c, const float *pcm, long stream_stride, long channel_stride, long nstreams, long nsamples,
+                      vamd_envelope_state *states, vamd_stream_plan *plan) {
+  return plan_streams(c, (float *)pcm, stream_stride, channel_stride, nstreams, nsamples, states, plan, 0);
+}
+
+int vamd_plan_streams_whole(vamd_ctx *c, float *pcm, long stream_stride, long channel_stride, long nstreams, long nframes,
+                            vamd_envelope_state *states, vamd_stream_plan *plan) {
+  if (c && nframes < 0) return fail(c, VAMD_EINVAL, "negative frame count");
+  return plan_streams(c, pcm, stream_stride, channel_stride, nstreams, c ? c->B.bs[1] / 2 + nframes : 0, states, plan, 1);
 }
 
 int vamd_gather_blocks(vamd_ctx *c, const vamd_stream_plan *plan, int W, const float *pcm, long channel_stride,

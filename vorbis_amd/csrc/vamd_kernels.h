@@ -1251,19 +1251,83 @@ __global__ __launch_bounds__(64) void k_env_walk(int ch, long nstreams, long nst
 // one wave per stream: the lanes turn the stream's flags into its mark bytes in LDS (coalesced reads, ve->mark[] as
 // mark_at defines it), then one lane does the walk out of LDS -- a dependent chain of a few thousand steps that would
 // otherwise pay a trip to HBM at each of them
+// (flags: [nstreams][split] then, from `flags2` on, [nstreams][B.nsteps - split] -- the steps of a stream's end-of-stream
+// padding are taken in a second detector pass, vamd_plan_streams_whole; split == B.nsteps: one array.)
+// pending != null: a dry run -- nothing is emitted, pending[s] = centerW of the block the walk stopped in front of.
 __global__ __launch_bounds__(64) void k_plan_streams(BlockoutP B, long nstreams, const unsigned char *__restrict__ flags,
-                                                     PlannedBlock *__restrict__ blocks, int *__restrict__ counts) {
+                                                     long split, const unsigned char *__restrict__ flags2,
+                                                     PlannedBlock *__restrict__ blocks, int *__restrict__ counts,
+                                                     long long *__restrict__ pending) {
   unsigned char *marks = (unsigned char *)vamd_smem;  // [nsteps + 4]
   const long s = blockIdx.x;
   const long last = blockout_steps(B);
-  const unsigned char *f = flags + s * B.nsteps;
-  for (long p = threadIdx.x; p < B.nsteps + 4; p += 64) marks[p] = p < last ? (unsigned char)mark_at(f, last, p) : 0;
+  const unsigned char *f = flags + s * split, *f2 = flags2 + s * (B.nsteps - split);
+  auto flag = [&](long p) -> int { return p < split ? f[p] : f2[p - split]; };
+  for (long p = threadIdx.x; p < B.nsteps + 4; p += 64) {
+    int m = 0;  // mark_at(), over the two pieces
+    if (p < last) {
+      if (p >= 1) m |= flag(p - 1) & 1;
+      m |= flag(p) & 3;
+      if (p + 1 < last) m |= flag(p + 1) & 2;
+    }
+    marks[p] = (unsigned char)(m != 0);
+  }
   __syncthreads();
   int n0 = 0, n1 = 0;
-  plan_stream(B, marks, blocks + s * B.maxblocks, &n0, &n1);  // (the whole wave: it looks at 64 marks at a time)
+  long pc = 0;
+  plan_stream(B, marks, pending ? nullptr : blocks + s * B.maxblocks, &n0, &n1, &pc);  // (the whole wave: it looks at 64 marks at a time)
   if (threadIdx.x == 0) {
-    counts[2 * s] = n0;
-    counts[2 * s + 1] = n1;
+    if (pending) pending[s] = pc;
+    else {
+      counts[2 * s] = n0;
+      counts[2 * s + 1] = n1;
+    }
+  }
+}
+
+// ---- the two ends of a stream (k_lpc.h): what vorbis_analysis_wrote() extrapolates on the host in the reference ----
+// a wave per (stream, channel).  x = the channel's buffer: x[0, head) the (zero) space in front of the first sample,
+// x[head, head + n) the first n real samples.  lib/block.c:417-458.
+__global__ __launch_bounds__(64) void k_lpc_head(int ch, long nstreams, float *__restrict__ pcm, long stream_stride,
+                                                 long channel_stride, int head, int n) {
+  const long sc = blockIdx.x, s = sc / ch;
+  const int c = (int)(sc - s * ch);
+  float *x = pcm + s * stream_stride + (long)c * channel_stride;
+  double *aut = (double *)vamd_smem;                      // [2 * 16 + 1], padded to 80
+  float *coeff = (float *)(aut + 80);                     // [32]
+  float *work = coeff + VAMD_LPC_MAX_ORDER;               // [n + head]: the stream reversed, then what precedes it
+  const int order = 16;
+  WAVE_FOR(j, n) work[j] = x[head + n - 1 - j];
+  WAVE_SYNC();
+  lpc_from_data(work, n, order, aut, coeff);
+  lpc_predict(coeff, work + n - order, order, work + n, head);
+  WAVE_FOR(i, head) x[head - 1 - i] = work[n + i];
+}
+// the end: x[eof, eof + pad) from the last min(eof - start, bs1) samples before eof, start = where the reference's
+// buffer begins when the stream is closed (pending centre - bs1/2).  lib/block.c:474-512.
+__global__ __launch_bounds__(64) void k_lpc_tail(int ch, long nstreams, float *__restrict__ pcm, long stream_stride,
+                                                 long channel_stride, long eof, int bs1, int pad,
+                                                 const long long *__restrict__ pending) {
+  const long sc = blockIdx.x, s = sc / ch;
+  const int c = (int)(sc - s * ch);
+  float *x = pcm + s * stream_stride + (long)c * channel_stride;
+  double *aut = (double *)vamd_smem;                      // [2 * 32 + 1], padded to 80
+  float *coeff = (float *)(aut + 80);                     // [32]
+  float *data = coeff + VAMD_LPC_MAX_ORDER;               // [bs1]
+  float *out = data + bs1;                                // [pad]
+  const int order = 32;
+  long start = (long)pending[s] - bs1 / 2;
+  if (start < 0) start = 0;
+  const long have = eof - start;                          // v->eofflag in the reference's (shifted) coordinates
+  if (have > order * 2) {
+    const int n = have < bs1 ? (int)have : bs1;
+    WAVE_FOR(i, n) data[i] = x[eof - n + i];
+    WAVE_SYNC();
+    lpc_from_data(data, n, order, aut, coeff);
+    lpc_predict(coeff, data + n - order, order, out, pad);
+    WAVE_FOR(i, pad) x[eof + i] = out[i];
+  } else {
+    WAVE_FOR(i, pad) x[eof + i] = 0.f;                     // "not enough data to extrapolate ... zeroes will do"
   }
 }
 
