@@ -529,14 +529,16 @@ typedef struct vamd_feed vamd_feed;
 #define VAMD_FEED_S16 0 /* int16_t, interleaved; sample = x / 32768.f */
 #define VAMD_FEED_F32 1 /* float, interleaved, already scaled to +-1 */
 /* devices: HIP ordinals (NULL / 0: the calling thread's current device); lanes_per_device >= 1 (2 or 3 overlap upload,
- * compute and hand-back); a group holds at most max_streams streams of at most max_frames frames each. */
+ * compute and hand-back; 4-5 keep the shader array fed while the chains of small kernels at a group's start and end
+ * run); a group holds at most max_streams streams of at most max_frames frames each, all in `format`.  Pinned host
+ * memory per lane: the group's samples plus about a quarter of that for its packets. */
 int vamd_feed_create(vamd_feed **out, const void *setup_blob, size_t blob_bytes, const int *devices, int ndevices,
-                     int lanes_per_device, long max_streams, long max_frames);
+                     int lanes_per_device, long max_streams, long max_frames, int format /* VAMD_FEED_S16 / _F32 */);
 void vamd_feed_destroy(vamd_feed *f);
 int vamd_feed_lanes(const vamd_feed *f);
 int vamd_feed_device(const vamd_feed *f, int slot);   /* the device lane `slot` runs on */
 int vamd_feed_buffer(vamd_feed *f, void **pcm);       /* >= 0: the slot; < 0: an OV_*-valued error */
-int vamd_feed_wrote(vamd_feed *f, int slot, long nstreams, long frames, int format);
+int vamd_feed_wrote(vamd_feed *f, int slot, long nstreams, long frames);
 typedef struct vamd_feed_result {
   int64_t nstreams, nblocks;      /* blocks == packets, all streams */
   const int64_t *stream_start;    /* [nstreams + 1]: stream s owns packets [stream_start[s], stream_start[s+1]), in stream order */

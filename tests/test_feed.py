@@ -93,7 +93,8 @@ def test_short_streams(frames):
     assert not bad, "\n".join(bad)
 
 
-def test_groups_in_flight_and_float_input():
+@pytest.mark.parametrize("as_float", [False, True])
+def test_groups_in_flight(as_float):
     """Three lanes, seven groups of different sizes kept in flight; float input gives what 16-bit input gives."""
     import vorbis_amd
     from oracle import ref
@@ -101,7 +102,8 @@ def test_groups_in_flight_and_float_input():
         pytest.skip("needs the reference build")
     setup = "44k_stereo_q4"
     rng = np.random.default_rng(5)
-    feed = vorbis_amd.Feed(vorbis_amd.default_setup_blob(setup), lanes_per_device=3, max_streams=6, max_frames=20000)
+    feed = vorbis_amd.Feed(vorbis_amd.default_setup_blob(setup), lanes_per_device=3, max_streams=6, max_frames=20000,
+                           fmt=vorbis_amd.FEED_F32 if as_float else vorbis_amd.FEED_S16)
     groups = [s16_streams(rng, 2, fr, kinds) for fr, kinds in
               [(20000, ["noise", "gated"]), (9000, ["sine"]), (15000, ["clicks", "noise", "gated", "sine"]), (20000, ["gated"] * 6),
                (5000, ["noise"]), (12345, ["gated", "noise"]), (20000, ["sine", "silence"])]]
@@ -111,11 +113,10 @@ def test_groups_in_flight_and_float_input():
             g0, slot = pending.pop(0)
             results[g0] = feed.packets(slot)
             feed.release(slot)
-        as_float = gi % 2 == 1
-        slot, buf = feed.buffer(2, np.float32 if as_float else np.int16)
+        slot, buf = feed.buffer(2)
         flat = pcm.reshape(-1)
         buf[:flat.size] = (flat.astype(np.float32) / np.float32(32768.0)) if as_float else flat
-        feed.wrote(slot, pcm.shape[0], pcm.shape[1], vorbis_amd.FEED_F32 if as_float else vorbis_amd.FEED_S16)
+        feed.wrote(slot, pcm.shape[0], pcm.shape[1])
         pending.append((gi, slot))
     for g0, slot in pending:
         results[g0] = feed.packets(slot)

@@ -43,3 +43,23 @@ def test_two_ranks_of_the_real_runner_on_one_gpu():
     # two processes overlap each other's launch gaps, so somewhat more)
     assert 0.5 * one["value"] < two["value"] < 1.6 * one["value"], (one["value"], two["value"])
     assert two["roofline"]["kernels_ms_per_step"]["noisemask"] > 0
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
+def test_two_ranks_default_line_carries_c5_host_fed_and_cpu_baseline():
+    """The line a first multi-GPU run will print: with more than one rank the default run
+    still yields C5, the host-fed figure and the CPU baseline (rank 0) -- rehearsed with two ranks on one GPU at reduced
+    stream counts."""
+    two = _bench("--gpus", "2", "--backend", "gloo", "--share-gpu", "--steps", "3", "--warmup", "1", "--streams", "48",
+                 "--feed-streams", "16", "--feed-groups", "6", "--feed-lanes", "2", "--cpu-seconds", "2", "--no-neighbours")
+    assert two["n_gpus"] == 2 and two["share_gpu"] is True
+    c5 = two["workloads"]["c5"]
+    assert "error" not in c5 and c5["parity_sample"]["mismatches"] == 0 and c5["value"] > 0
+    assert set(two["workloads"]) == {"c5"}                     # (c2 / c3 are single-GPU lines)
+    hf = two["host_fed"]["c4"]
+    assert "error" not in hf and hf["n_gpus"] == 2 and hf["value"] > 0 and hf["parity_sample"]["mismatches"] == 0
+    assert two["cpu_baseline"]["value"] > 0 and two["cpu_baseline"]["kind"] == "reference"
+    # frac reproduces from the line's own figures (VERDICT r05 next 2)
+    for d in (two, c5):
+        r = d["roofline"]
+        assert abs(r["alg_bytes_per_step"] / (d["ms_per_step"] * 1e-3) / 1e9 / r["peak"] - r["frac"]) < 0.01 * r["frac"]

@@ -138,13 +138,13 @@ def load_library():
     L.vamd_plan_streams.argtypes = [_vp, _vp, C.c_long, C.c_long, C.c_long, C.c_long, _vp, C.POINTER(_Plan)]
     L.vamd_gather_blocks.argtypes = [_vp, C.POINTER(_Plan), C.c_int, _vp, C.c_long, _vp]
     L.vamd_plan_streams_whole.argtypes = [_vp, _vp, C.c_long, C.c_long, C.c_long, C.c_long, _vp, C.POINTER(_Plan)]
-    L.vamd_feed_create.argtypes = [C.POINTER(_vp), _vp, C.c_size_t, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_long, C.c_long]
+    L.vamd_feed_create.argtypes = [C.POINTER(_vp), _vp, C.c_size_t, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_long, C.c_long, C.c_int]
     L.vamd_feed_destroy.argtypes = [_vp]
     L.vamd_feed_destroy.restype = None
     L.vamd_feed_lanes.argtypes = [_vp]
     L.vamd_feed_device.argtypes = [_vp, C.c_int]
     L.vamd_feed_buffer.argtypes = [_vp, C.POINTER(_vp)]
-    L.vamd_feed_wrote.argtypes = [_vp, C.c_int, C.c_long, C.c_long, C.c_int]
+    L.vamd_feed_wrote.argtypes = [_vp, C.c_int, C.c_long, C.c_long]
     L.vamd_feed_packets.argtypes = [_vp, C.c_int, C.POINTER(_FeedResult)]
     L.vamd_feed_release.argtypes = [_vp, C.c_int]
     L.vamd_feed_last_error.argtypes = [_vp]
@@ -847,21 +847,20 @@ class Feed:
     memory, over one or several GPUs (include/vorbis_amd.h, "the host-fed farm").  The call sequence is libvorbis'
     own, for a group of streams: buffer() -> fill -> wrote() -> packets() -> release()."""
 
-    def __init__(self, setup_blob, devices=None, lanes_per_device=2, max_streams=256, max_frames=131072):
+    def __init__(self, setup_blob, devices=None, lanes_per_device=2, max_streams=256, max_frames=131072, fmt=FEED_S16):
         self.L = load_library()
         blob = np.ascontiguousarray(setup_blob, dtype=np.uint8)
         devs = list(devices) if devices else []
         arr = (C.c_int * max(1, len(devs)))(*devs)
         h = _vp()
         r = self.L.vamd_feed_create(C.byref(h), _vp(blob.ctypes.data), blob.size, arr if devs else None, len(devs), lanes_per_device,
-                                    max_streams, max_frames)
+                                    max_streams, max_frames, fmt)
         if r:
             raise VamdError(r, "vamd_feed_create failed (setup without GPU-assembled packets, bad arguments, or a HIP failure)")
         self.h = h
-        self.max_streams, self.max_frames = max_streams, max_frames
+        self.max_streams, self.max_frames, self.fmt = max_streams, max_frames, fmt
+        self.dtype = np.int16 if fmt == FEED_S16 else np.float32
         self.lanes = self.L.vamd_feed_lanes(self.h)
-        # channels of the setup: the blob's header says so, but the library is the authority -- ask a throw-away question
-        self._in_bytes = None
 
     def close(self):
         if getattr(self, "h", None):
@@ -882,17 +881,17 @@ class Feed:
     def device(self, slot):
         return self._check(self.L.vamd_feed_device(self.h, slot))
 
-    def buffer(self, channels, dtype=np.int16):
-        """-> (slot, array [max_streams * max_frames * channels] of dtype over the lane's pinned input arena)"""
+    def buffer(self, channels):
+        """-> (slot, array [max_streams * max_frames * channels] of the feed's sample type over the lane's pinned input arena)"""
         p = _vp()
         slot = self._check(self.L.vamd_feed_buffer(self.h, C.byref(p)))
         n = self.max_streams * self.max_frames * channels
-        ct = C.c_int16 if np.dtype(dtype) == np.int16 else C.c_float
+        ct = C.c_int16 if self.fmt == FEED_S16 else C.c_float
         arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), shape=(n,))
         return slot, arr
 
-    def wrote(self, slot, nstreams, frames, fmt=FEED_S16):
-        self._check(self.L.vamd_feed_wrote(self.h, slot, nstreams, frames, fmt))
+    def wrote(self, slot, nstreams, frames):
+        self._check(self.L.vamd_feed_wrote(self.h, slot, nstreams, frames))
 
     def packets(self, slot, copy=True):
         """Waits for the group.  -> dict: nstreams, nblocks, stream_start, offset, bits, granulepos, info (numpy views over
@@ -915,17 +914,15 @@ class Feed:
     def release(self, slot):
         self._check(self.L.vamd_feed_release(self.h, slot))
 
-    def encode(self, pcm, fmt=None):
-        """One group, synchronously: pcm [nstreams, frames, ch] int16 or float32 (host).  -> per stream a list of
+    def encode(self, pcm):
+        """One group, synchronously: pcm [nstreams, frames, ch] of the feed's sample type (host).  -> per stream a list of
         (packet bytes, granulepos, W, e_o_s)."""
-        pcm = np.ascontiguousarray(pcm)
+        pcm = np.ascontiguousarray(pcm, dtype=self.dtype)
         ns, frames, ch = pcm.shape
-        if fmt is None:
-            fmt = FEED_S16 if pcm.dtype == np.int16 else FEED_F32
-        slot, buf = self.buffer(ch, np.int16 if fmt == FEED_S16 else np.float32)
+        slot, buf = self.buffer(ch)
         try:
             buf[:pcm.size] = pcm.reshape(-1)
-            self.wrote(slot, ns, frames, fmt)
+            self.wrote(slot, ns, frames)
             r = self.packets(slot)
         finally:
             try:

@@ -7,8 +7,8 @@
 //   * autocorrelation: aut[j] = sum_{i=j}^{n-1} (double)data[i]*data[i-j], j = 0..m, each a serial fp64 sum in index
 //     order (the order is part of the result for float input).  Lane j owns lag j: m+1 <= 33 lanes walk the data --
 //     staged in LDS -- side by side; data[i] is a broadcast read, data[i-j] consecutive addresses.
-//   * Levinson-Durbin in fp64 (lib/lpc.c:80-114) and the damping (:119-126): a few hundred wave-uniform operations,
-//     every lane runs them on the same values.
+//   * Levinson-Durbin in fp64 (lib/lpc.c:80-114) and the damping (:119-126): a few hundred dependent operations on
+//     one lane, the arrays in LDS.
 //   * the predictor: y_i = -(sum_j work[i+j]*coeff[m-1-j]) with every product rounded to float and subtracted in
 //     order j = 0..m-1 (:150-158).  Output i's LAST term is output i-1, the term before it output i-2 ...: the chain
 //     from one output to the next is one multiply and one subtract, everything else of an output's sum only needs
@@ -31,7 +31,15 @@ VAMD_DEV void lpc_from_data(const float *data, int n, int m, double *aut, float 
   if (LANE <= m) {
     const int j = LANE;
     double d = 0.;
-    for (int i = j; i < n; i++) d += (double)data[i] * (double)data[i - j];
+    int i = j;
+    for (; i + 8 <= n; i += 8) {  // (eight terms' reads in flight; the sum itself stays in index order)
+      float a[8], b[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) a[k] = data[i + k], b[k] = data[i + k - j];
+#pragma unroll
+      for (int k = 0; k < 8; k++) d += (double)a[k] * (double)b[k];
+    }
+    for (; i < n; i++) d += (double)data[i] * (double)data[i - j];
     aut[j] = d;
   }
   WAVE_SYNC();
@@ -79,16 +87,28 @@ VAMD_DEV void lpc_from_data(const float *data, int n, int m, double *aut, float 
 VAMD_DEV void lpc_predict(const float *coeff, const float *prime, int m, float *out, int n) {
 #if VAMD_GPU
   const float c = LANE < m ? coeff[m - 1 - LANE] : 0.f;
-  float S = 0.f, newest = 0.f;
-  const int steps = n + m - 1;
-  for (int t = 0; t < steps; t++) {
-    const float wt = t < m ? prime[t] : newest;  // work[t]
+  const int primed = LANE < m ? __float_as_int(prime[LANE]) : 0;  // work[t], t < m, read with v_readlane
+  float S = 0.f, newest = 0.f, keep = 0.f;
+  // the steps that consume the primer (no output is complete before step m-1)
+  for (int t = 0; t < m; t++) {
+    const float wt = __int_as_float(wave_read(primed, t));
     const float below = __int_as_float(wave_shift_up1(__float_as_int(S), 0));  // lane 0 starts an output: y = 0
     const float p = wt * c;
     S = below - p;
-    newest = __int_as_float(wave_read(__float_as_int(S), m - 1));  // output t-m+1, complete (for t >= m-1)
-    if (t >= m - 1 && LANE == 0) out[t - m + 1] = newest;
   }
+  newest = __int_as_float(wave_read(__float_as_int(S), m - 1));  // output 0
+  if (LANE == 0) keep = newest;
+  // from here on every step consumes the newest output and completes the next one; outputs gather one per lane and
+  // leave for `out` sixty-four at a time (no LDS traffic inside the chain)
+  for (int i = 1; i < n; i++) {
+    const float below = __int_as_float(wave_shift_up1(__float_as_int(S), 0));
+    const float p = newest * c;
+    S = below - p;
+    newest = __int_as_float(wave_read(__float_as_int(S), m - 1));  // output i
+    if ((i & 63) == LANE) keep = newest;
+    if ((i & 63) == 63) out[i - 63 + LANE] = keep;
+  }
+  if ((n & 63) && LANE < (n & 63)) out[(n & ~63) + LANE] = keep;
   WAVE_SYNC();
 #else
   float work[VAMD_LPC_MAX_ORDER];

@@ -13,7 +13,7 @@ import torch.distributed as dist
 
 
 # where the collectives' tensors live: the rank's device (RCCL), or host memory when the backend cannot take device
-# tensors (a gloo build without GPU support: found out on the first collective and remembered)
+# tensors (a gloo build without GPU support: found out once, by all ranks together, when the group is formed)
 _staging = {"host": False}
 
 
@@ -22,20 +22,30 @@ def _coll(t):
 
 
 def _run(fn, t, *args, **kw):
-    """One collective on `t` (in place); if the backend refuses a device tensor, stage through host memory from now on."""
-    if t.is_cuda and not _staging["host"]:
-        try:
-            fn(t, *args, **kw)
-            return t
-        except RuntimeError:
-            if dist.get_backend() == "nccl":
-                raise
-            _staging["host"] = True
+    """One collective on `t` (in place), through host memory when the group decided so at start-up (_probe_device_collectives).
+    An error here is an error: every rank must be inside the same collective, so nothing is retried on another path."""
     h = _coll(t)
     fn(h, *args, **kw)
     if h is not t:
         t.copy_(h)
     return t
+
+
+def _probe_device_collectives(device):
+    """Can this backend take device tensors?  Decided ONCE, by all ranks together: each tries one all-reduce on a device
+    tensor, then the outcomes are agreed with an all-reduce on a HOST tensor (which every backend takes) -- if any rank
+    failed, all ranks stage through host memory from here on.  (Round 5 switched per rank, on the first failing
+    collective: a rank that failed alone would have re-entered a collective its peers had already left -- ADVICE r05.)"""
+    if dist.get_backend() == "nccl" or device.type != "cuda":
+        return
+    failed = 0
+    try:
+        dist.all_reduce(torch.zeros(1, device=device))
+    except RuntimeError:
+        failed = 1
+    flag = torch.tensor([failed], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    _staging["host"] = bool(flag.item())
 
 
 def collectives_on():
@@ -63,6 +73,7 @@ def init_from_env(backend="nccl", use_cuda=True, share_gpu=False):
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+            _probe_device_collectives(dev)
     return rank, world, dev
 
 
