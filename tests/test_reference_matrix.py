@@ -93,3 +93,27 @@ def test_gpu_backend_passes_the_reference_grid(ch):
             assert ok, "%s: decoded max_abs %f outside .95 +- allowable" % (tag, peak)
             cells += 1
     assert cells == 66
+
+
+@pytest.mark.gpu
+def test_every_grid_cell_takes_the_packet_path():
+    """Which setups does the binding serve with GPU-assembled packets (vamd_packet_capacity() > 0: vamd_encode_block,
+    integration/mapping0_vamd.c) and which through vamd_write_packet (the reference's own floor1_encode / res*_forward on
+    the host)?  Every cell of test/test.c's grid -- 1..8 channels x 11 qualities x 6 rates -- is asked; the answer is
+    written down here and in INTEGRATION.md: all of them take the packet path, both block sizes."""
+    import vorbis_amd
+    host_cells = []
+    cells = 0
+    for ch in range(1, 9):
+        for q in q_steps():
+            for rate in RATES:
+                e = ref.RefEncoder(ch, rate, q)
+                an = vorbis_amd.Analyzer(e.pack_setup(), 0)
+                caps = [an.packet_capacity(W) for W in (0, 1)] + [an.residue_capacity(W) for W in (0, 1)]
+                an.close()
+                e.close()
+                cells += 1
+                if min(caps) <= 0:
+                    host_cells.append((ch, rate, round(q, 2), caps))
+    assert cells == 528
+    assert not host_cells, "cells whose packets the host writes (vamd_write_packet): %s" % host_cells
