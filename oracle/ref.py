@@ -122,6 +122,8 @@ def lib(hybrid=False):
         L.ref_is_managed.argtypes = [C.c_void_p]
         L.ref_open_uncoupled.restype = C.c_void_p
         L.ref_open_uncoupled.argtypes = [C.c_int, C.c_long, C.c_float]
+        L.ref_open_ctl.restype = C.c_void_p
+        L.ref_open_ctl.argtypes = [C.c_int, C.c_long, C.c_float, C.c_double, C.c_double]
         L.ref_tap_block_managed.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                             C.POINTER(_Taps), C.POINTER(_MTaps)]
         L.ref_matrix_case.restype = C.c_long
@@ -142,11 +144,15 @@ def _ip(a):
 class RefEncoder:
     """One reference encoder state (vorbis_info + vorbis_dsp_state + a vorbis_block)."""
 
-    def __init__(self, channels=2, rate=44100, quality=0.4, hybrid=False, managed=None, coupled=True):
+    def __init__(self, channels=2, rate=44100, quality=0.4, hybrid=False, managed=None, coupled=True, lowpass_khz=None, iblock=None):
         """quality: libvorbisenc VBR quality; or managed=(max, nominal, min) bitrates for a
-        bitrate-managed encoder (vorbis_encode_init), whose blocks carry 15 candidate packets."""
+        bitrate-managed encoder (vorbis_encode_init), whose blocks carry 15 candidate packets.
+        lowpass_khz / iblock: vorbis_encode_ctl OV_ECTL_LOWPASS_SET / OV_ECTL_IBLOCK_SET before setup_init."""
         self.L = lib(hybrid)
-        if not coupled:
+        if lowpass_khz is not None or iblock is not None:
+            self.h = self.L.ref_open_ctl(channels, rate, quality, -1.0 if lowpass_khz is None else float(lowpass_khz),
+                                         1.0 if iblock is None else float(iblock))
+        elif not coupled:
             self.h = self.L.ref_open_uncoupled(channels, rate, quality)  # OV_ECTL_COUPLING_SET = 0
         elif managed is None:
             self.h = self.L.ref_open(channels, rate, quality)

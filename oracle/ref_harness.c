@@ -99,6 +99,30 @@ ref_enc *ref_open_uncoupled(int channels, long rate, float quality) {
   return e;
 }
 
+/* VBR with the other vorbis_encode_ctl() settings that reach the analysis path (lib/vorbisenc.c:1167-1191):
+ * OV_ECTL_LOWPASS_SET (kHz; moves floor1's n / the sliding lowpass, lib/vorbisenc.c:529,866-880) and OV_ECTL_IBLOCK_SET
+ * (the impulse blocks' noise tuning, :1183-1190, :797-812).  lowpass_khz <= 0 / iblock > 0: that one is left alone. */
+ref_enc *ref_open_ctl(int channels, long rate, float quality, double lowpass_khz, double iblock) {
+  ref_enc *e = (ref_enc *)calloc(1, sizeof(*e));
+  int bad;
+  if (!e) return NULL;
+  vorbis_info_init(&e->vi);
+  bad = vorbis_encode_setup_vbr(&e->vi, channels, rate, quality);
+  if (!bad && lowpass_khz > 0.) bad = vorbis_encode_ctl(&e->vi, OV_ECTL_LOWPASS_SET, &lowpass_khz);
+  if (!bad && iblock <= 0.) bad = vorbis_encode_ctl(&e->vi, OV_ECTL_IBLOCK_SET, &iblock);
+  if (!bad) bad = vorbis_encode_setup_init(&e->vi);
+  if (bad) {
+    vorbis_info_clear(&e->vi);
+    free(e);
+    return NULL;
+  }
+  vorbis_analysis_init(&e->vd, &e->vi);
+  vorbis_block_init(&e->vd, &e->vb);
+  e->channels = channels;
+  e->quality = quality;
+  return e;
+}
+
 int ref_is_managed(ref_enc *e) { return vorbis_bitrate_managed(&e->vb) ? 1 : 0; }
 
 void ref_close(ref_enc *e) {
