@@ -191,6 +191,9 @@ typedef struct vamd_batch_io {
  * beforehand with vamd_abi_version() != VAMD_ABI_VERSION. */
 #define VAMD_ABI_VERSION 9
 int vamd_abi_version(void);
+/* GPUs the HIP runtime shows this process (hipGetDeviceCount; < 0: an OV_*-valued error) -- for plain-C hosts that spread
+ * a vamd_feed / vamd_batcher over all of them without linking the runtime themselves. */
+int vamd_device_count(void);
 /* The environment knobs in force for a context, as "NAME=value" words (read once, at vamd_create; vorbis_amd/csrc/vamd_knobs.h).  The
  * operating knobs (VAMD_VERBOSE, VAMD_BATCH_LANES / _EAGER / _JOIN / _SPIN_BELOW) are always honoured; the test knobs --
  * kernel choices turned the other way, widened margins, occupancy caps, injected failures -- only beside
@@ -488,6 +491,11 @@ int vamd_plan_fetch(vamd_ctx *ctx, const vamd_stream_plan *plan, int32_t *const 
 typedef struct vamd_batcher vamd_batcher;
 int vamd_batcher_create(vamd_batcher **out, const void *setup_blob, size_t blob_bytes, int device, int max_batch,
                         int max_wait_us);
+/* The same over several GPUs (ABI 9): lanes are dealt round `devices` (HIP ordinals; at least one lane per device), each with
+ * its context, stream, arena and thread on its own device; a batch runs wherever its lane lives -- blocks are independent
+ * (SURVEY.md 8e), so nothing crosses between devices. */
+int vamd_batcher_create_multi(vamd_batcher **out, const void *setup_blob, size_t blob_bytes, const int *devices, int ndevices,
+                              int max_batch, int max_wait_us);
 void vamd_batcher_destroy(vamd_batcher *b);
 void vamd_batcher_attach(vamd_batcher *b);
 void vamd_batcher_detach(vamd_batcher *b);

@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = ["vamd_create_abi", "vamd_encode_blocks", "vamd_clock_probe",
                     "vamd_plan_streams", "vamd_gather_blocks", "vamd_plan_fetch",
                     "vamd_batcher_create", "vamd_batcher_destroy", "vamd_batcher_attach", "vamd_batcher_detach",
                     "vamd_batcher_encode_block", "vamd_batcher_last_error", "vamd_batcher_stats", "vamd_batcher_context", "vamd_batcher_report",
-                    "vamd_input_status", "vamd_calib_copy", "vamd_abi_version", "vamd_plan_streams_whole",
+                    "vamd_input_status", "vamd_calib_copy", "vamd_abi_version", "vamd_plan_streams_whole", "vamd_device_count", "vamd_batcher_create_multi",
                     "vamd_feed_create", "vamd_feed_destroy", "vamd_feed_lanes", "vamd_feed_device", "vamd_feed_buffer", "vamd_feed_wrote",
                     "vamd_feed_packets", "vamd_feed_release", "vamd_feed_last_error"]
 PACKETBLOBS = 15

@@ -75,6 +75,7 @@ inline void futex_post_done(std::atomic<int> *w) {
 
 // one context with its stream, staging arenas and thread: a batch runs on one lane
 struct Lane {
+  int device = 0;  // lanes are dealt round the batcher's devices (vamd_batcher_create_multi)
   vamd_ctx *ctx = nullptr;
   hipStream_t stream = nullptr;
   void *h_stage = nullptr, *d_stage = nullptr;
@@ -146,7 +147,7 @@ static int run_batch(vamd_batcher *b, Lane &L, int W, Request *const *reqs, size
   const size_t o_pcm = 0, o_lW = al16(nb * ch * n * 4), o_nW = al16(o_lW + nb * 4), o_bt = al16(o_nW + nb * 4),
                o_ain = al16(o_bt + nb * 4), o_out = al16(o_ain + nb * 4), o_aout = o_out, o_bits = al16(o_aout + nb * 4),
                o_st = al16(o_bits + nb * 4), o_pk = al16(o_st + nb * ch), total = al16(o_pk + nb * row);
-  hipError_t e = hipSuccess;  // (the lane's thread made b->device current when it started)
+  hipError_t e = hipSuccess;  // (the lane's thread made its own device current when it started)
   if (L.stage_bytes < total) {
     if (L.h_stage) (void)hipHostFree(L.h_stage);
     if (L.d_stage) (void)hipFree(L.d_stage);
@@ -252,7 +253,7 @@ static int run_batch(vamd_batcher *b, Lane &L, int W, Request *const *reqs, size
 
 // a lane's life: sleep until it may start, take all of one size class, run it, hand it back, look again
 static void lane_main(vamd_batcher *b, Lane *lane) {
-  (void)hipSetDevice(b->device);
+  (void)hipSetDevice(lane->device);
   const int kind = (int)(lane - b->lanes.data()) < b->eager ? 0 : 1;
   std::vector<Request *> take;
   int last_W = 0;  // the size class this lane served last
@@ -324,6 +325,7 @@ static void free_lanes(vamd_batcher *b) {
       t = nx;
     }
   for (Lane &L : b->lanes) {
+    (void)hipSetDevice(L.device);
     if (L.h_stage) (void)hipHostFree(L.h_stage);
     if (L.d_stage) (void)hipFree(L.d_stage);
     if (L.ctx) vamd_destroy(L.ctx);
@@ -335,24 +337,33 @@ static void free_lanes(vamd_batcher *b) {
 
 int vamd_batcher_create(vamd_batcher **out, const void *setup_blob, size_t blob_bytes, int device, int max_batch,
                         int max_wait_us) {
+  return vamd_batcher_create_multi(out, setup_blob, blob_bytes, &device, 1, max_batch, max_wait_us);
+}
+
+int vamd_batcher_create_multi(vamd_batcher **out, const void *setup_blob, size_t blob_bytes, const int *devices, int ndevices,
+                              int max_batch, int max_wait_us) {
   if (!out) return VAMD_EINVAL;
   *out = nullptr;
-  if (max_batch < 1 || max_wait_us < 0) return VAMD_EINVAL;
+  if (max_batch < 1 || max_wait_us < 0 || !devices || ndevices < 1 || ndevices > 64) return VAMD_EINVAL;
   const vamd::Knobs K = vamd::read_knobs();
   int nlanes = K.batch_lanes;
   if (nlanes < 1) nlanes = 1;
   if (nlanes > 16) nlanes = 16;
+  if (nlanes < ndevices) nlanes = ndevices < 16 ? ndevices : 16;  // every device at least one lane
   vamd_batcher *b = new vamd_batcher;
   b->K = K;
   int cur = 0;
   (void)hipGetDevice(&cur);
-  b->device = device >= 0 ? device : cur;
+  b->device = devices[0] >= 0 ? devices[0] : cur;
   b->lanes.resize((size_t)nlanes);
   int r = VAMD_OK;
+  size_t lane_no = 0;
   for (Lane &L : b->lanes) {
-    r = vamd_create(&L.ctx, setup_blob, blob_bytes, device);
+    const int d = devices[lane_no++ % (size_t)ndevices];
+    L.device = d >= 0 ? d : cur;
+    r = vamd_create(&L.ctx, setup_blob, blob_bytes, L.device);
     if (r) break;
-    hipError_t e = hipSetDevice(b->device);
+    hipError_t e = hipSetDevice(L.device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&L.done, hipEventBlockingSync | hipEventDisableTiming);
     if (e == hipSuccess && vamd_set_stream(L.ctx, L.stream) != VAMD_OK) e = hipErrorUnknown;
@@ -385,7 +396,7 @@ int vamd_batcher_create(vamd_batcher **out, const void *setup_blob, size_t blob_
     delete b;
     return r;
   }
-  if (cur != b->device) (void)hipSetDevice(cur);
+  (void)hipSetDevice(cur);
   try {
     for (Lane &L : b->lanes) L.worker = std::thread(lane_main, b, &L);
   } catch (...) {  // (std::system_error: no exception may leave an extern "C" entry point)

@@ -159,6 +159,11 @@ void vamd_destroy(vamd_ctx *c) {
 
 int vamd_abi_version(void) { return VAMD_ABI_VERSION; }
 
+int vamd_device_count(void) {
+  int n = 0;
+  return hipGetDeviceCount(&n) == hipSuccess ? n : VAMD_EFAULT;
+}
+
 const char *vamd_last_error(const vamd_ctx *c) { return c ? c->err.c_str() : "null context"; }
 
 int vamd_set_stream(vamd_ctx *c, void *s) {
