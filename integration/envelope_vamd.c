@@ -29,6 +29,7 @@ extern vamd_envelope_state *vamd_envelope_state_for(vorbis_dsp_state *vd);
 extern void vamd_release_key(const void *key);
 extern int vamd_batching(void);
 extern void vamd_poison(vorbis_dsp_state *vd, int kind); /* mapping0_vamd.c: 1 = non-finite input, 2 = GPU failure */
+extern int vamd_detector_dead(vorbis_dsp_state *vd, int set);
 
 /* vorbis_dsp_clear() tears the detector down here (lib/block.c:325-328): the GPU context that
  * was created for this analysis state goes with it */
@@ -64,12 +65,32 @@ long _ve_envelope_search(vorbis_dsp_state *v) {
     const float **chan = alloca(sizeof(*chan) * ve->ch);
     int i, err = -1;
     for (i = 0; i < ve->ch; i++) chan[i] = v->pcm[i] + step * first;
-    if (ctx && st) err = vamd_envelope_search(ctx, chan, nsteps, st, flags);
+    if (vamd_detector_dead(v, 0)) {
+      memset(flags, 0, nsteps); /* a non-finite sample lies behind: the stream ends at its block, no more steps are taken */
+      err = 0;
+    } else if (ctx && st)
+      err = vamd_envelope_search(ctx, chan, nsteps, st, flags);
+    if (err == VAMD_ENONFINITE) {
+      /* A NaN / Inf somewhere in these steps (include/vorbis_amd.h, "Input domain").  The blocks IN FRONT of it are
+         valid and their block-switching decisions need the marks of the clean steps: find the longest clean prefix
+         (the call leaves the state alone when it fails, so halving costs a dozen calls, once per stream), keep its
+         flags, and stop the detector.  The stream is not poisoned here: the block that holds the sample is refused by
+         its own verdict (mapping0_vamd.c: vamd_domain_verdict) -- and with it every later block. */
+      long lo = 0, hi = nsteps; /* [0, lo) is clean, step `hi - 1` (or an earlier one) is not */
+      vamd_envelope_state probe;
+      while (lo + 1 < hi) {
+        const long mid = (lo + hi) / 2;
+        probe = *st;
+        if (vamd_envelope_search(ctx, chan, mid, &probe, flags) == VAMD_OK) lo = mid; else hi = mid;
+      }
+      memset(flags, 0, nsteps);
+      err = lo > 0 ? vamd_envelope_search(ctx, chan, lo, st, flags) : 0;
+      vamd_detector_dead(v, 1);
+    }
     if (err) {
       /* This entry point has no error return (1 / 0 / -1 all mean something), and a shared library does not end its
          host process.  The stream is flagged instead (mapping0_vamd.c: vamd_poison) and the NEXT vorbis_analysis()
-         reports it: OV_EINVAL for a sample outside the input domain (NaN / Inf, VAMD_ENONFINITE; vorbis_amd.h),
-         OV_EFAULT for anything else -- no context, device lost, out of memory, a HIP fault; the text stays with
+         reports it: OV_EFAULT -- no context, device lost, out of memory, a HIP fault; the text stays with
          vamd_last_error().  No marks come from these steps and the bookkeeping below carries on, so that the blocks
          keep flowing and the caller meets the error at once, not at end of stream (returning -1, "need more data",
          from here on would stall vorbis_analysis_blockout() until the input ends: lib/block.c:558-563). */

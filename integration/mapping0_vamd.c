@@ -102,6 +102,8 @@ typedef struct vamd_entry {
   vamd_envelope_state env; /* the block-switching detector's running state (envelope_vamd.c) */
   int poisoned;            /* the stream is over (vamd_poison): VAMD_POISON_NONFINITE -> every later block is OV_EINVAL,
                               VAMD_POISON_FAULT -> OV_EFAULT */
+  int detector_dead;       /* a non-finite sample has reached the detector (envelope_vamd.c): no more steps are taken;
+                              the stream ends at the block that holds the sample (its own verdict poisons it) */
   vamd_ahead *ahead;       /* the look-ahead cache (allocated on first use) */
 } vamd_entry;
 static pthread_mutex_t vamd_lock = PTHREAD_MUTEX_INITIALIZER;
@@ -221,13 +223,23 @@ vamd_envelope_state *vamd_envelope_state_for(vorbis_dsp_state *state) {
  *                          held the sample and for every block after it;
  *   VAMD_POISON_FAULT      the GPU side failed under the block-switching detector (device lost, out of memory, a HIP
  *                          fault): OV_EFAULT from the next vorbis_analysis() on.
- * The detector has no error return (envelope_vamd.c), so it records the fact here and lets the next vorbis_analysis()
- * report it.  (A FINITE block beyond the integer bound is neither: OV_EINVAL for that block alone, below.) */
+ * The detector has no error return (envelope_vamd.c), so for a GPU failure it records the fact here and lets the next
+ * vorbis_analysis() report it.  A non-finite sample under the DETECTOR does not poison the stream by itself (round 5 did:
+ * with a 65 536-frame write the detector scans ~60 blocks ahead, and the valid blocks in front of the sample were
+ * refused with it -- ADVICE r05): the detector keeps the marks of the clean steps in front of the sample and stops, and
+ * the stream ends where include/vorbis_amd.h says -- at the block that holds the sample, by that block's own verdict.
+ * (A FINITE block beyond the integer bound is neither: OV_EINVAL for that block alone, below.) */
 #define VAMD_POISON_NONFINITE 1
 #define VAMD_POISON_FAULT 2
 void vamd_poison(vorbis_dsp_state *state, int kind) {
   vamd_entry *e = vamd_entry_for(state);
   if (e && !e->poisoned) e->poisoned = kind;
+}
+/* envelope_vamd.c: the detector met a non-finite sample (1: from now on it takes no steps) / is it dead? */
+int vamd_detector_dead(vorbis_dsp_state *state, int set) {
+  vamd_entry *e = vamd_entry_for(state);
+  if (e && set) e->detector_dead = 1;
+  return e ? e->detector_dead : 0;
 }
 static int vamd_poisoned(vorbis_dsp_state *state) {
   vamd_entry *e = vamd_entry_for(state);

@@ -58,7 +58,7 @@ def test_mdct_only_path_propagates_like_ieee():
 
 
 @pytest.mark.skipif(not ref.hybrid_available(), reason="oracle/_ref/libvorbis_hybrid.so not built")
-@pytest.mark.parametrize("write", [1024, 20000])
+@pytest.mark.parametrize("write", [1024, 20000, 44100])
 def test_dropin_returns_ov_einval_and_the_next_stream_is_clean(write):
     """Through the hybrid libvorbis: a stream with a NaN in it makes vorbis_analysis() return OV_EINVAL (-131) -- the
     encode ends, as for any libvorbis error -- and an encoder opened afterwards emits the reference's packets.  (With
@@ -72,6 +72,11 @@ def test_dropin_returns_ov_einval_and_the_next_stream_is_clean(write):
     seen = ref.RefEncoder(2, 44100, 0.4, hybrid=True).encode_stream(poisoned, write_frames=write, tolerate=True)
     first = next(k for k, b in enumerate(seen) if b["error"])
     assert first > 10 and all(b["error"] == -131 for b in seen[first:])
+    want = ref.RefEncoder(2, 44100, 0.4).encode_stream(pcm, write_frames=write)
+    # the error starts at the block that HOLDS the sample (include/vorbis_amd.h), not where the detector -- which scans a
+    # large write's whole buffer before the first block is cut -- met it: every block in front of it is the clean stream's
+    assert np.isnan(seen[first]["pcm"]).any() and not any(np.isnan(b["pcm"]).any() for b in seen[:first])
+    assert all(a["packet"] == b["packet"] for a, b in zip(want[:first], seen[:first]))
     want = ref.RefEncoder(2, 44100, 0.4).encode_stream(pcm)
     got = ref.RefEncoder(2, 44100, 0.4, hybrid=True).encode_stream(pcm)
     assert len(want) == len(got) > 20
