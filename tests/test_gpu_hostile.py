@@ -58,7 +58,8 @@ def test_mdct_only_path_propagates_like_ieee():
 
 
 @pytest.mark.skipif(not ref.hybrid_available(), reason="oracle/_ref/libvorbis_hybrid.so not built")
-@pytest.mark.parametrize("write", [1024, 20000, 44100])
+@pytest.mark.parametrize("write", [1024, 20000, 30000])   # (a first write that CONTAINS the sample puts NaN into block 0 in the
+# reference itself: its start-of-stream LPC extrapolation runs over everything written, lib/block.c:417-458)
 def test_dropin_returns_ov_einval_and_the_next_stream_is_clean(write):
     """Through the hybrid libvorbis: a stream with a NaN in it makes vorbis_analysis() return OV_EINVAL (-131) -- the
     encode ends, as for any libvorbis error -- and an encoder opened afterwards emits the reference's packets.  (With
