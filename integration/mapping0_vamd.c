@@ -91,6 +91,7 @@ typedef struct vamd_ahead {
   unsigned char *packets;         /* [VAMD_AHEAD_MAX][K][stride]: K = 1, or a bitrate-managed block's PACKETBLOBS candidates */
   int32_t *bits;                  /* [VAMD_AHEAD_MAX][K] */
   long stride;
+  long rows;                      /* packet rows (x K) allocated: grows with the plans the stream really makes */
   int K;
   long hits, misses, batches;     /* (diagnostics: vamd_ahead_stats) */
 } vamd_ahead;
@@ -340,6 +341,19 @@ static int vamd_lookahead_on(void) {
   }
   return mode;
 }
+/* VAMD_LOOKAHEAD_MAX=<blocks> bounds how far one plan reaches (default: as far as the cache's slots go -- 255 blocks, 63
+ * for a bitrate-managed encoder); what a stream's cache holds follows from it: packet rows and a copy of the planned
+ * blocks' samples for that many blocks, allocated for the plans the stream really makes (read once) */
+static int vamd_lookahead_max(void) {
+  static int cap = -1;
+  if (cap < 0) {
+    const char *v = getenv("VAMD_LOOKAHEAD_MAX");
+    cap = v ? atoi(v) : VAMD_AHEAD_MAX - 1;
+    if (cap < 1) cap = 1;
+    if (cap > VAMD_AHEAD_MAX - 1) cap = VAMD_AHEAD_MAX - 1;
+  }
+  return cap;
+}
 
 /* What vorbis_analysis_blockout() will decide for the blocks AFTER the one it has just handed out, as far as the buffered
  * samples determine them: the state in `v` is already the next block's (lib/block.c:649-685), the marks of every buffered
@@ -513,11 +527,11 @@ static int mapping0_forward_vamd(vorbis_block *vb) {
 
   /* ---- look-ahead inside one stream (the comment at vamd_ahead): serve this block from the packets planned earlier,
      or plan the blocks the buffer already determines and run them with this one */
-  if (vamd_lookahead_on() && vamd_packet_capacity(ctx, 0) > 0 && vamd_packet_capacity(ctx, 1) > 0) {
+  if (vamd_lookahead_on() && !vamd_batching() && vamd_packet_capacity(ctx, 0) > 0 && vamd_packet_capacity(ctx, 1) > 0) {
     vamd_entry *e = vamd_entry_for(vd);
     vamd_ahead *A = e ? e->ahead : NULL;
     const long bsz[2] = {((codec_setup_info *)vi->codec_setup)->blocksizes[0], ((codec_setup_info *)vi->codec_setup)->blocksizes[1]};
-    const int maxplan = managed ? 63 : VAMD_AHEAD_MAX - 1; /* (a managed block's packets are fifteen rows) */
+    const int maxplan = (managed && vamd_lookahead_max() > 63) ? 63 : vamd_lookahead_max(); /* (a managed block's packets are fifteen rows) */
     int i;
     if (A && A->next < A->count && A->K == nk) {
       const vamd_ahead_block *p = &A->blk[A->next];
@@ -558,16 +572,21 @@ static int mapping0_forward_vamd(vorbis_block *vb) {
           A->pcm = _ogg_malloc((size_t)(need + need / 2) * sizeof(float));
           A->pcm_cap = A->pcm ? need + need / 2 : 0;
         }
-        if (A && (A->stride != stride || A->K != nk)) {
+        if (A && (A->stride != stride || A->K != nk || A->rows < nb)) {
+          /* rows for the plans this stream really makes (round 5 took the worst case -- 256 rows, 64 x 15 for a managed
+             encoder: 5.6 MB a stream -- on the first plan of two blocks): what is needed now, doubled while it grows */
+          long rows = nb > 2 * A->rows ? nb : 2 * A->rows;
+          if (rows > maxplan + 1) rows = maxplan + 1;
           if (A->packets) _ogg_free(A->packets);
           if (A->bits) _ogg_free(A->bits);
-          A->packets = _ogg_malloc((size_t)(maxplan + 1) * nk * stride);
-          A->bits = _ogg_malloc((size_t)(maxplan + 1) * nk * sizeof(*A->bits));
+          A->packets = _ogg_malloc((size_t)rows * nk * stride);
+          A->bits = _ogg_malloc((size_t)rows * nk * sizeof(*A->bits));
           A->stride = (A->packets && A->bits) ? stride : 0;
+          A->rows = A->stride ? rows : 0;
           A->K = nk;
           A->count = A->next = 0;
         }
-        if (A && A->pcm_cap >= need && A->stride == stride && A->K == nk) {
+        if (A && A->pcm_cap >= need && A->stride == stride && A->K == nk && A->rows >= nb) {
           planned[0].lW = vb->lW, planned[0].W = vb->W, planned[0].nW = vb->nW, planned[0].blocktype = vbi->blocktype;
           for (i = 0; i < ch; i++) ptr[i] = vb->pcm[i];
           for (j = 1; j < nb; j++) { /* the samples as they lie in the encoder's own buffer, kept for the comparison later */
