@@ -19,6 +19,7 @@
 // against 2.3 ms, because the stage is bound by the CU's LDS pipe (92 % busy, half of it bank conflicts) and
 // not by any wave's latency -- and the test build runs everything in a single lane.
 #pragma once
+#include <type_traits>
 #include "vamd_wave.h"
 #include "vamd_params.h"
 
@@ -238,6 +239,38 @@ VAMD_DEV void fold_fetch(FoldOps<LOGN> &o, const float *in) {
 // known when it is compiled.  (Round 5: the form used to be taken for n = 512 too, where the regimes change in the
 // middle of a trip -- found by the whole-quad variant below failing the 22 kHz short blocks; no shipped path reached
 // k_mdct_only at 512, and tests/test_gpu_parity.py::test_mdct_forward_every_size now does.)
+// ---- round 6: the head of the 2048-sample transform without LDS ------------------------------
+// The stage is bound by the CU's LDS pipe; of the MDCT's six trips through it, two move data that never needs to leave
+// the wave's registers:
+//   * fold -> first butterfly trip.  The fold's item p = LANE + 64 k produces the pair (w2[2p], w2[2p+1]); the trip that
+//     fuses stages 0-2 has its item q gather the eight pairs 64 k + 63 - q, k = 0..7.  Run item q = 63 - LANE and those
+//     are the very pairs the lane has just formed: nothing to exchange.
+//   * first trip -> second trip (stages 3, 4).  Item (j, q) of the second trip -- sub-block j of 64 pairs, q < 16 --
+//     wants the pairs 64 j + (15 - q) + 16 m, m = 0..3: register E[j] of the four lanes (15 - q) + 16 m.  Give lane L the
+//     items with 15 - q = L & 15 and j = (L >> 4) + 4 i, i = 0, 1: what it needs sits in its own COLUMN of sixteenth-rows,
+//     and the exchange is a 4 x 4 transpose between the lane's bits 5:4 and the register index's bits 1:0 -- two rounds of
+//     gfx950's half-exchanges, v_permlane32_swap (lane bit 5 <-> register bit 1) and v_permlane16_swap (lane bit 4 <->
+//     register bit 0), sixteen VALU instructions on a vector unit that is half idle in this stage, in place of eight
+//     64-bit LDS stores and eight loads per lane on the pipe that binds it.
+// Same butterflies on the same operands in the same order (the expression trees are the reference's, lib/mdct.c:216-336);
+// only who holds a pair changes.  The second trip stores to LDS as before: the 32-point groups want sixteen consecutive
+// pairs in one lane, a transpose inside rows of sixteen lanes, which the DPP can only do a bit at a time.
+#ifndef VAMD_XF_HEAD_REGS
+#define VAMD_XF_HEAD_REGS 1
+#endif
+#if VAMD_GPU
+VAMD_DEV void swap_halves32(float &a, float &b) {  // a: [a.lo, b.lo], b: [a.hi, b.hi]  (lo = lanes 0-31)
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r[0]);
+  b = __uint_as_float(r[1]);
+}
+VAMD_DEV void swap_rows16(float &a, float &b) {  // a's odd rows of sixteen lanes <-> b's even rows
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r[0]);
+  b = __uint_as_float(r[1]);
+}
+#endif
+
 template <int LOGS = 0, int LOGN = 0, class Team = WaveTeam, bool PACKED = false, bool FOLD_AHEAD = false>
 VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in0, float *w0, float *out0, PhaseClock &pc,
                                 int in_stride = 0, int w_stride = 0, int out_stride = 0, const Team &tm = Team(),
@@ -255,6 +288,115 @@ VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in0, float *w0, fl
   float *out_lds = out0 + t_ * out_stride;                     \
   (void)in; (void)w; (void)w2; (void)out_lds;
 
+  // one butterfly: the upper pair takes the sum, the lower the difference rotated by T (lib/mdct.c:222-257)
+  auto bfly = [](F2 &a, F2 &b, const F2 T) {
+    const float r0 = a.x - b.x, r1 = a.y - b.y;
+    a.x += b.x;
+    a.y += b.y;
+    b.x = r1 * T.y + r0 * T.x;
+    b.y = r1 * T.x - r0 * T.y;
+  };
+  auto stage_trig = [&](int s, int q) {
+    return PACKED && s > 0 ? *(const F2 *)(P.tpack + (n4 - (n4 >> (s - 1))) + 2 * q) : *(const F2 *)(trig + (4 << s) * q);
+  };
+  int s = 0;
+#if VAMD_GPU
+  constexpr bool head_regs = VAMD_XF_HEAD_REGS && LOGN == 11 && LOGS == 0 && std::is_same<Team, WaveTeam>::value;
+#else
+  constexpr bool head_regs = false;
+#endif
+  if constexpr (head_regs) {
+#if VAMD_GPU
+    float *w2 = w0 + n2;
+    F2 E[8];  // pair 64 k + LANE
+    {
+      FoldOps<LOGN> mine;
+      if constexpr (FOLD_AHEAD) {
+        if (!ahead) {
+          fold_fetch<LOGN>(mine, in0);
+          ahead = &mine;
+        }
+      } else {
+        fold_fetch<LOGN>(mine, in0);  // (out of LDS: the windowed block)
+        ahead = &mine;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int p = LANE + 64 * k;
+        const F2 T = *(const F2 *)(trig + n2 - 2 * (p + 1));
+        float r0, r1;
+        if (2 * (64 * k) < n8) {
+          r0 = ahead->xa[k] + ahead->ya[k], r1 = ahead->xb[k] + ahead->yb[k];
+        } else if (2 * (64 * k) < n2 - n8) {
+          r0 = ahead->xa[k] - ahead->ya[k], r1 = ahead->xb[k] - ahead->yb[k];
+        } else {
+          r0 = -ahead->xa[k] - ahead->ya[k], r1 = -ahead->xb[k] - ahead->yb[k];
+        }
+        E[k].x = r1 * T.y + r0 * T.x;
+        E[k].y = r1 * T.x - r0 * T.y;
+      }
+      if constexpr (FOLD_AHEAD) {
+        if (in_next) fold_fetch<LOGN>(*ahead, in_next);
+      }
+    }
+    pc.mark(1);
+    {  // stages 0-2 on the lane's own eight pairs: item q = 63 - LANE of the three-stage trip below (pts = n2, j = 0)
+      const int q = 63 - LANE, h = n2 >> 4;
+      bfly(E[7], E[3], stage_trig(0, q));
+      bfly(E[6], E[2], stage_trig(0, q + h));
+      bfly(E[5], E[1], stage_trig(0, q + 2 * h));
+      bfly(E[4], E[0], stage_trig(0, q + 3 * h));
+      const F2 T1a = stage_trig(1, q), T1b = stage_trig(1, q + h);
+      bfly(E[7], E[5], T1a);
+      bfly(E[6], E[4], T1b);
+      bfly(E[3], E[1], T1a);
+      bfly(E[2], E[0], T1b);
+      const F2 T2 = stage_trig(2, q);
+      bfly(E[7], E[6], T2);
+      bfly(E[5], E[4], T2);
+      bfly(E[3], E[2], T2);
+      bfly(E[1], E[0], T2);
+    }
+    // the 4 x 4 transpose: lane bits 5:4 <-> register bits 1:0 (register bit 2 = which of the lane's two items)
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+#pragma unroll
+      for (int jl = 0; jl < 2; jl++) {
+        swap_halves32(E[4 * i + jl].x, E[4 * i + jl + 2].x);
+        swap_halves32(E[4 * i + jl].y, E[4 * i + jl + 2].y);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+#pragma unroll
+      for (int jh = 0; jh < 2; jh++) {
+        swap_rows16(E[4 * i + 2 * jh].x, E[4 * i + 2 * jh + 1].x);
+        swap_rows16(E[4 * i + 2 * jh].y, E[4 * i + 2 * jh + 1].y);
+      }
+    }
+    {  // stages 3, 4: the lane's two items (j = (LANE >> 4) + 4 i, q = 15 - (LANE & 15)); E[4 i + m] = pair 64 j + (15 - q) + 16 m
+      constexpr int pts = n2 >> 3;
+      const int q = 15 - (LANE & 15);
+      const F2 Tab = stage_trig(3, q), Tcd = stage_trig(3, q + (pts >> 3)), T1 = stage_trig(4, q);
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        const int j = (LANE >> 4) + 4 * i;
+        F2 &A = E[4 * i + 3], &B = E[4 * i + 1], &C = E[4 * i + 2], &D = E[4 * i + 0];
+        bfly(A, B, Tab);
+        bfly(C, D, Tcd);
+        bfly(A, C, T1);
+        bfly(B, D, T1);
+        const int base = pts * j - 2 - 2 * q;
+        *(F2 *)(w2 + VAMD_PW(base + pts)) = A;
+        *(F2 *)(w2 + VAMD_PW(base + (pts >> 1))) = B;
+        *(F2 *)(w2 + VAMD_PW(base + 3 * (pts >> 2))) = C;
+        *(F2 *)(w2 + VAMD_PW(base + (pts >> 2))) = D;
+      }
+    }
+    tm.sync();
+    s = 5;  // == nstages for n = 2048: the loops below have nothing left
+#endif
+  } else {
   // fold + pre-twiddle ("window + rotate + step 1"), lib/mdct.c:506-544.
   // Pair p writes w2[2p], w2[2p+1]; the three loops differ in which input
   // quarter is folded with which sign.  x0[0],x0[2] / x1[0],x1[2] of the reference
@@ -353,6 +495,7 @@ VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in0, float *w0, fl
   }
   tm.sync();
   pc.mark(1);
+  }
 
   // mdct_butterflies, lib/mdct.c:316-336, on x = w2, points = n2.
   // Stage s (s = 0 is mdct_butterfly_first, s >= 1 the generic passes) splits
@@ -360,18 +503,6 @@ VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in0, float *w0, fl
   // x[pts-2-2q] with x[pts/2-2-2q] and uses T[(4<<s)*q].  n2/4 = n/8 butterflies per
   // stage in total, all independent.
   const int nstages = log2n - 6;  // first + (log2n-7) generic passes
-  // one butterfly: the upper pair takes the sum, the lower the difference rotated by T (lib/mdct.c:222-257)
-  auto bfly = [](F2 &a, F2 &b, const F2 T) {
-    const float r0 = a.x - b.x, r1 = a.y - b.y;
-    a.x += b.x;
-    a.y += b.y;
-    b.x = r1 * T.y + r0 * T.x;
-    b.y = r1 * T.x - r0 * T.y;
-  };
-  auto stage_trig = [&](int s, int q) {
-    return PACKED && s > 0 ? *(const F2 *)(P.tpack + (n4 - (n4 >> (s - 1))) + 2 * q) : *(const F2 *)(trig + (4 << s) * q);
-  };
-  int s = 0;
   // Two stages per trip through LDS where there are two to take: the butterflies (A, B) and (C, D) of stage s -- A, C
   // in the upper half of a sub-block, a quarter apart, B, D below them -- feed exactly the butterflies (A, C) and
   // (B, D) of stage s+1, whose sub-blocks are those halves.  Same operations on the same operands; half the loads
