@@ -109,8 +109,9 @@ def measured_valu(workload, units, stage_ms, clock_ghz=None):
         st = stage_of.get(k.split("<")[0])
         if st is None or (workload == "c3" and st in ("floor", "couple")):
             continue
-        d = per_stage.setdefault(st, {"valu_insts_per_unit": 0.0, "issue_ms": 0.0})
+        d = per_stage.setdefault(st, {"valu_insts_per_unit": 0.0, "issue_ms": 0.0, "lane_insts_per_unit": 0.0})
         d["valu_insts_per_unit"] += v["valu_per_stereo_block"]
+        d["lane_insts_per_unit"] += v["valu_per_stereo_block"] * v.get("mean_lanes_live", 0.0)
         d["issue_ms"] += v["valu_per_stereo_block"] * units * v["cycles_per_inst_model"] / rate * 1e3
         insts += v["valu_per_stereo_block"]
     # the tone chain runs beside the noise mask: the pair is one segment of the step as far as issue slots go
@@ -125,8 +126,15 @@ def measured_valu(workload, units, stage_ms, clock_ghz=None):
             d["stage_ms"], d["frac_valu"] = ms, None
         else:
             d["stage_ms"], d["frac_valu"] = ms, (d["issue_ms"] / ms if ms else None)
+    # lane utilisation: of the 64 lanes a vector instruction could drive, the mean fraction whose exec
+    # bit was set -- SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU), calibrated on k_calib_copy (all lanes live: exactly 64)
+    lanes = 0.0
+    for d in per_stage.values():
+        li = d.pop("lane_insts_per_unit")
+        lanes += li
+        d["lane_utilisation"] = li / (64.0 * d["valu_insts_per_unit"]) if d["valu_insts_per_unit"] else None
     total = sum(d["issue_ms"] for d in per_stage.values())
-    return {"valu_insts_per_unit": insts, "cycles_per_inst": total * 1e-3 * rate / max(insts * units, 1.0), "simds": t["simds"],
+    return {"valu_insts_per_unit": insts, "lane_utilisation": lanes / (64.0 * insts) if insts else None, "cycles_per_inst": total * 1e-3 * rate / max(insts * units, 1.0), "simds": t["simds"],
             "clock_ghz": ghz, "clock_source": ("measured over the timed region (s_memtime / s_memrealtime)" if clock_ghz else "nominal"),
             "issue_ms_per_step": total, "frac_valu": total / max(sum(stage_ms.values()), 1e-9),
             "per_stage": per_stage, "source": t["source"],
