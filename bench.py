@@ -82,6 +82,7 @@ def source_hash():
 TRAFFIC_PROFILE = "profiles/r05_pmc_traffic.json"
 TRAFFIC_PROFILE_C5 = "profiles/r05_c5_pmc_traffic.json"
 VALU_PROFILE = "profiles/r05_pmc_valu.json"
+VALU_PROFILE_C5 = "profiles/r05_c5_pmc_valu.json"
 
 
 def measured_valu(workload, units, stage_ms, clock_ghz=None):
@@ -89,6 +90,8 @@ def measured_valu(workload, units, stage_ms, clock_ghz=None):
     pass (SQ_INSTS_VALU per kernel and its dynamic mix, hash-guarded like the traffic profile) and the price list of
     tools/micro/chip_rate.hip: vector instructions per unit x SIMD cycles per instruction / (1024 SIMDs x clock) = the time the
     instructions alone need on this chip, per stage and for the step, against the HIP-event time of the same stage."""
+    if workload == "c5":
+        return measured_valu_c5(units, stage_ms, clock_ghz)
     if workload not in ("c3", "c4"):
         return None
     try:
@@ -140,6 +143,51 @@ def measured_valu(workload, units, stage_ms, clock_ghz=None):
             "per_stage": per_stage, "source": t["source"],
             "definition": "vector instructions per unit (SQ_INSTS_VALU) x modelled SIMD cycles per instruction (the kernel's dynamic "
                           "mix priced with the measured whole-chip cost of each class) / (SIMDs x clock), against the summed stage events"}
+
+
+VALU_STAGE_OF = {"k_transform": "transform", "k_noise": "noisemask", "k_floor": "floor", "k_floor_pair": "floor", "k_couple": "couple",
+                 "k_couple_norm": "couple", "k_tone_seed": "tonemask", "k_tone_chase": "tonemask", "k_tone_fold": "tonemask",
+                 "k_tone_seed_chase": "tonemask", "k_ampmax_streams_mixed": "ampmax"}
+
+
+def measured_valu_c5(units, stage_ms, clock_ghz=None):
+    """roofline.valu for the mixed-size workload: one step of this very workload was counted (tools/prof_run_c5.py; a run with
+    other stream counts scales by its units).  Stages as the library's events cut them; the block-switching detector and the
+    plan (k_env_*, k_plan_*), which have no stage event, are listed under "detector_plan" with their issue time alone."""
+    try:
+        t = json.load(open(os.path.join(ROOT, VALU_PROFILE_C5)))
+    except Exception:
+        return {"value": None, "note": "no committed C5 VALU profile"}
+    if t.get("source_hash") != source_hash():
+        return {"value": None, "note": "VALU profile %s was taken from other sources (%s, now %s): re-run tools/profile.sh"
+                                       % (VALU_PROFILE_C5, t.get("source_hash"), source_hash())}
+    scale = units / float(t["short_blocks"] + t["long_blocks"])
+    ghz = clock_ghz or t["clock_ghz"]
+    rate = t["simds"] * ghz * 1e9
+    per_stage, insts, lanes = {}, 0.0, 0.0
+    for k, v in t["per_kernel"].items():
+        base = k.split("<")[0]
+        st = VALU_STAGE_OF.get(base, "detector_plan" if base.startswith(("k_env_", "k_plan_")) else None)
+        if st is None:
+            continue
+        d = per_stage.setdefault(st, {"valu_insts_per_step": 0.0, "issue_ms": 0.0, "lane_insts": 0.0})
+        n = v["valu_per_step"] * scale
+        d["valu_insts_per_step"] += n
+        d["issue_ms"] += n * v["cycles_per_inst_model"] / rate * 1e3
+        d["lane_insts"] += n * v.get("mean_lanes_live", 0.0)
+        insts += n
+        lanes += n * v.get("mean_lanes_live", 0.0)
+    for st, d in per_stage.items():
+        li = d.pop("lane_insts")
+        d["lane_utilisation"] = li / (64.0 * d["valu_insts_per_step"]) if d["valu_insts_per_step"] else None
+        ms = stage_ms.get(st)
+        d["stage_ms"], d["frac_valu"] = ms, (d["issue_ms"] / ms if ms else None)
+    total = sum(d["issue_ms"] for d in per_stage.values())
+    return {"valu_insts_per_unit": insts / max(units, 1), "lane_utilisation": lanes / (64.0 * insts) if insts else None, "simds": t["simds"],
+            "clock_ghz": ghz, "clock_source": ("measured over the timed region (s_memtime / s_memrealtime)" if clock_ghz else "nominal"),
+            "issue_ms_per_step": total, "per_stage": per_stage, "source": t["source"],
+            "definition": "vector instructions of one step (SQ_INSTS_VALU x waves per kernel) x modelled SIMD cycles per instruction / "
+                          "(SIMDs x clock); frac_valu per stage against that stage's event; the whole step's: issue_ms_per_step / ms_per_step"}
 
 
 def measured_traffic(workload, units, alg_bytes=None):

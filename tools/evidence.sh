@@ -23,4 +23,16 @@ timeout 300 python tools/gpu_block_phases.py >> $E/block_path.txt 2>/dev/null
 for k in "60 0.4 s16" "60 0.9 gated" "30 0.4 s16 128000"; do timeout 400 python tools/gpu_lookahead_bench.py $k >> $E/lookahead.txt 2>/dev/null; done
 timeout 600 python tools/soak_lookahead.py 60 $E/soak_lookahead.txt > /dev/null 2>&1
 timeout 900 bash tools/alt_paths.sh > $E/alt_paths.txt 2>&1
+# the host-fed farm (round 6): group size x lanes sweep, then a kernel trace of the default configuration
+HF_CFGS="256:3:60:8 256:5:60:8 512:3:60:8 512:5:100:8 512:5:100 1024:3:40:8" timeout 900 bash tools/hf_sweep.sh > $E/host_fed.txt 2>&1
+HF_KIND=c5 HF_CFGS="512:5:60:8" timeout 600 bash tools/hf_sweep.sh >> $E/host_fed.txt 2>&1
+( cd /tmp && export TMPDIR=/tmp GPU_MAX_HW_QUEUES=8 && timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/hf_prof -o hf -- \
+    python $R/bench.py --host-fed-only c4 --feed-streams 512 --feed-lanes 5 --feed-groups 30 > $E/host_fed_under_rocprof.json 2>/dev/null )
+python tools/prof_summary.py kt $R/gpurun_out/hf_prof/hf_results.db > $E/host_fed_kernel_trace_stats.txt 2>&1
+# the drop-in library driven by the C application (integration/encode_loop.c), against the unmodified reference beside it
+: > $E/encode_loop.txt
+for cfg in "1024 0.4 441000" "65536 0.4 441000" "1024 0.9 441000" "65536 0.9 441000"; do set -- $cfg
+  LD_LIBRARY_PATH=build/dropin/ref:build/dropin ./build/dropin/encode_loop $1 $2 $3 write /tmp/el.pkts 2>> $E/encode_loop.txt
+  LD_LIBRARY_PATH=build/dropin ./build/dropin/encode_loop $1 $2 $3 check /tmp/el.pkts 2>> $E/encode_loop.txt
+done
 ls -la $E

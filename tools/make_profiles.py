@@ -6,7 +6,7 @@ summaries under profiles/:  rNN_kernel_trace_stats.txt, rNN_pmc_hbm_traffic.txt,
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "profile")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r06"
 sys.path.insert(0, ROOT)
 import bench as bench_mod  # noqa: E402  (source_hash: the profile is stamped with the sources it was taken from)
 NB_PMC = int(sys.argv[2]) if len(sys.argv) > 2 else 131072  # tools/prof_run.py <NB> 1
@@ -179,3 +179,33 @@ if os.path.exists(mixf):
                 % (NB_PMC, bench_mod.source_hash()))
         f.write(open(mixf).read())
     print("valu: %.0f vector instructions per stereo block" % outv["valu_per_stereo_block"])
+    # ---- the same for one C5 step (roofline.valu for c5): instruction counts and live lanes from the C5
+    # counter passes; the cost per instruction of a kernel is the one its C4 mix gives (same code: k_transform<8> as
+    # k_transform<11>, k_noise<7> as k_noise<10>, k_floor_pair as k_floor), kernels C4 does not run at the list's OTHER price
+    c5ctr = os.path.join(SRC, "pmc_sq_counters_c5.txt")
+    if os.path.exists(c5ctr) and os.path.exists(os.path.join(SRC, "c5_step.json")):
+        rows5 = {}
+        for ln in open(c5ctr):
+            m = re.match(r"(k_[A-Za-z0-9_<>]+) waves (\d+) (\{.*\})", ln.strip())
+            if m:
+                d = rows5.setdefault(m.group(1), {"waves": int(m.group(2))})
+                d.update(ast.literal_eval(m.group(3)))
+        step5 = json.loads(open(os.path.join(SRC, "c5_step.json")).read().strip().splitlines()[-1])
+        family = {"k_floor_pair": "k_floor"}
+        per5v = {}
+        for k, d in rows5.items():
+            if k.startswith("k_calib_copy") or "SQ_INSTS_VALU" not in d:
+                continue
+            base = family.get(k.split("<")[0], k.split("<")[0])
+            like = next((v for kk, v in perk.items() if kk.split("<")[0] == base), None)
+            per5v[k] = {"valu_per_wave": d["SQ_INSTS_VALU"], "waves": d["waves"], "valu_per_step": d["SQ_INSTS_VALU"] * d["waves"],
+                        "mean_lanes_live": d.get("SQ_THREAD_CYCLES_VALU", 0.0) / max(d["SQ_INSTS_VALU"], 1.0),
+                        "cycles_per_inst_model": like["cycles_per_inst_model"] if like else PRICE["OTHER"],
+                        "priced_as": base if like else "OTHER"}
+        out5v = {"source_hash": bench_mod.source_hash(), "workload": "c5", "short_blocks": step5["short_blocks"], "long_blocks": step5["long_blocks"],
+                 "alg_bytes_per_step": step5["alg_bytes"], "simds": 1024, "clock_ghz": 2.25, "per_kernel": per5v,
+                 "source": "profiles/%s_pmc_sq_counters_c5.txt (one step of bench.py --workload c5), priced per kernel with the C4 mix of "
+                           "profiles/%s_pmc_valu_mix.txt" % (TAG, TAG),
+                 "valu_per_step": sum(v["valu_per_step"] for v in per5v.values())}
+        json.dump(out5v, open(os.path.join(ROOT, "profiles", TAG + "_c5_pmc_valu.json"), "w"), indent=1)
+        print("c5 valu: %.3g vector instructions per step" % out5v["valu_per_step"])

@@ -9,6 +9,7 @@ def kernel_stats(db):
     rows = con.execute("select name, total_calls, total_duration, average, percentage from top_kernels").fetchall()
     print("%-46s %6s %14s %12s %7s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
     for n, c, t, a, p in rows:
+        n = n.replace("(anonymous namespace)::", "")
         print("%-46s %6d %14.0f %12.0f %6.2f%%" % (n.split("(")[0][:46], c, t, a, p))
     try:  # the `kernels` view of rocpd: one row per dispatch with its code-object resources
         r = con.execute("select name, max(vgpr_count), max(accum_vgpr_count), max(sgpr_count), max(lds_size), max(scratch_size), "
@@ -17,6 +18,7 @@ def kernel_stats(db):
         print("# k_floor's 64 show as 32, k_transform's 232 as 116; tools/kernel_resources.py prints the compiler's own figures)")
         print("%-46s %6s %6s %6s %9s %8s %6s %10s" % ("kernel", "vgpr/2", "agpr", "sgpr", "lds_B", "scratch", "wg", "grid"))
         for n, v, a, sg, l, sc, w, g in r:
+            n = n.replace("(anonymous namespace)::", "")
             nm = n[5:] if n.startswith("void ") else n
             if nm.startswith("k_"):
                 print("%-46s %6s %6s %6s %9s %8s %6s %10s" % (nm.split("(")[0][:46], v, a, sg, l, sc, w, g))
