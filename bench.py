@@ -79,10 +79,10 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-TRAFFIC_PROFILE = "profiles/r05_pmc_traffic.json"
-TRAFFIC_PROFILE_C5 = "profiles/r05_c5_pmc_traffic.json"
-VALU_PROFILE = "profiles/r05_pmc_valu.json"
-VALU_PROFILE_C5 = "profiles/r05_c5_pmc_valu.json"
+TRAFFIC_PROFILE = "profiles/r06_pmc_traffic.json"
+TRAFFIC_PROFILE_C5 = "profiles/r06_c5_pmc_traffic.json"
+VALU_PROFILE = "profiles/r06_pmc_valu.json"
+VALU_PROFILE_C5 = "profiles/r06_c5_pmc_valu.json"
 
 
 def measured_valu(workload, units, stage_ms, clock_ghz=None):
