@@ -31,7 +31,7 @@ HF_KIND=c5 HF_CFGS="512:5:60:8" timeout 600 bash tools/hf_sweep.sh >> $E/host_fe
 python tools/prof_summary.py kt $R/gpurun_out/hf_prof/hf_results.db > $E/host_fed_kernel_trace_stats.txt 2>&1
 # the drop-in library driven by the C application (integration/encode_loop.c), against the unmodified reference beside it
 : > $E/encode_loop.txt
-for cfg in "1024 0.4 441000" "65536 0.4 441000" "1024 0.9 441000" "65536 0.9 441000"; do set -- $cfg
+for cfg in "1024 0.4 2646000" "4096 0.4 2646000" "65536 0.4 2646000" "1024 0.9 2646000" "65536 0.9 2646000"; do set -- $cfg
   LD_LIBRARY_PATH=build/dropin/ref:build/dropin ./build/dropin/encode_loop $1 $2 $3 write /tmp/el.pkts 2>> $E/encode_loop.txt
   LD_LIBRARY_PATH=build/dropin ./build/dropin/encode_loop $1 $2 $3 check /tmp/el.pkts 2>> $E/encode_loop.txt
 done
