@@ -182,6 +182,12 @@ def measured_valu_c5(units, stage_ms, clock_ghz=None):
         d["lane_utilisation"] = li / (64.0 * d["valu_insts_per_step"]) if d["valu_insts_per_step"] else None
         ms = stage_ms.get(st)
         d["stage_ms"], d["frac_valu"] = ms, (d["issue_ms"] / ms if ms else None)
+    if "noisemask" in per_stage and "tonemask" in per_stage:   # the tone chain runs beside the noise mask: one segment of the step
+        both = (stage_ms.get("noisemask") or 0.0) + (stage_ms.get("tonemask") or 0.0)
+        pair = per_stage["noisemask"]["issue_ms"] + per_stage["tonemask"]["issue_ms"]
+        per_stage["noisemask"]["stage_ms"], per_stage["noisemask"]["frac_valu"] = both, (pair / both if both else None)
+        per_stage["noisemask"]["note"] = "with the tone chain, which runs beside it"
+        per_stage["tonemask"]["frac_valu"] = None
     total = sum(d["issue_ms"] for d in per_stage.values())
     return {"valu_insts_per_unit": insts / max(units, 1), "lane_utilisation": lanes / (64.0 * insts) if insts else None, "simds": t["simds"],
             "clock_ghz": ghz, "clock_source": ("measured over the timed region (s_memtime / s_memrealtime)" if clock_ghz else "nominal"),
@@ -853,6 +859,8 @@ def roofline_of(a, R, stage_ms, clock, ms_per_step):
     }
     if a.workload == "c5":
         d["alg_bytes_rule"] = R.alg_rule()
+        if d["valu"] and d["valu"].get("issue_ms_per_step"):
+            d["valu"]["frac_valu"] = d["valu"]["issue_ms_per_step"] / ms_per_step   # (the step's wall time: detector and plan included)
     return d
 
 

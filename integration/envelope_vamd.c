@@ -22,6 +22,8 @@
 #undef _ve_envelope_clear
 
 #include "vorbis_amd.h"
+#include <string.h>
+#include <stdlib.h>
 
 /* mapping0_vamd.c owns the per-vorbis_dsp_state side table */
 extern vamd_ctx *vamd_ctx_for(vorbis_dsp_state *vd);
@@ -30,6 +32,32 @@ extern void vamd_release_key(const void *key);
 extern int vamd_batching(void);
 extern void vamd_poison(vorbis_dsp_state *vd, int kind); /* mapping0_vamd.c: 1 = non-finite input, 2 = GPU failure */
 extern int vamd_detector_dead(vorbis_dsp_state *vd, int set);
+extern int vamd_detector_mode(vorbis_dsp_state *vd, int set);
+
+/* Which detector serves a stream: VAMD_DETECTOR=gpu | host | auto (default auto; read once).
+ * A detector call is a GPU round trip (~43 us) whatever its size.  An application that writes 1024 frames at a time
+ * (the example's READ) asks for sixteen steps per block -- libvorbis' own _ve_amp does those in less time than the trip
+ * takes -- while one that writes 65 536 frames asks for a thousand at once.  auto: a stream whose FIRST detector call
+ * brings VAMD_DETECTOR_GPU_FROM (256) steps or more is served by the GPU for life, any other by the reference's own
+ * detector (this file includes lib/envelope.c unmodified; the same choice VAMD_BATCH mode makes for every stream).  The
+ * two keep their running state in different places, so a stream never changes sides. */
+static int vamd_detector_policy(void) {
+  static int policy = -1; /* 0 auto, 1 host, 2 gpu */
+  if (policy < 0) {
+    const char *v = getenv("VAMD_DETECTOR");
+    policy = !v ? 0 : (!strcmp(v, "host") ? 1 : (!strcmp(v, "gpu") ? 2 : 0));
+  }
+  return policy;
+}
+static long vamd_detector_gpu_from(void) {
+  static long n = -1;
+  if (n < 0) {
+    const char *v = getenv("VAMD_DETECTOR_GPU_FROM");
+    n = v ? atol(v) : 256;
+    if (n < 1) n = 1;
+  }
+  return n;
+}
 
 /* vorbis_dsp_clear() tears the detector down here (lib/block.c:325-328): the GPU context that
  * was created for this analysis state goes with it */
@@ -42,6 +70,18 @@ long _ve_envelope_search(vorbis_dsp_state *v) {
   /* batch mode (VAMD_BATCH, mapping0_vamd.c): the shared context belongs to the batcher's leader, and a detector
      round trip per blockout call is exactly what batching is there to avoid -- the reference's own detector runs */
   if (vamd_batching()) return _ve_envelope_search_cpu(v);
+  {
+    int mode = vamd_detector_mode(v, 0);
+    if (!mode) {
+      envelope_lookup *ve0 = ((private_state *)(v->backend_state))->ve;
+      long first0 = ve0->current / ve0->searchstep;
+      const long last0 = v->pcm_current / ve0->searchstep - VE_WIN;
+      if (first0 < 0) first0 = 0;
+      if (last0 > first0) /* the stream's first steps: decide */
+        mode = vamd_detector_mode(v, vamd_detector_policy() ? vamd_detector_policy() : (last0 - first0 >= vamd_detector_gpu_from() ? 2 : 1));
+    }
+    if (mode != 2) return _ve_envelope_search_cpu(v); /* (undecided: no step is due, the bookkeeping is the same either way) */
+  }
   {
   vorbis_info *vi = v->vi;
   codec_setup_info *ci = vi->codec_setup;

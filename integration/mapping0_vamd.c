@@ -103,6 +103,7 @@ typedef struct vamd_entry {
   vamd_envelope_state env; /* the block-switching detector's running state (envelope_vamd.c) */
   int poisoned;            /* the stream is over (vamd_poison): VAMD_POISON_NONFINITE -> every later block is OV_EINVAL,
                               VAMD_POISON_FAULT -> OV_EFAULT */
+  int detector_mode;       /* envelope_vamd.c: 0 undecided, 1 libvorbis' own detector on the host, 2 the GPU's -- per stream, for life */
   int detector_dead;       /* a non-finite sample has reached the detector (envelope_vamd.c): no more steps are taken;
                               the stream ends at the block that holds the sample (its own verdict poisons it) */
   vamd_ahead *ahead;       /* the look-ahead cache (allocated on first use) */
@@ -235,6 +236,12 @@ vamd_envelope_state *vamd_envelope_state_for(vorbis_dsp_state *state) {
 void vamd_poison(vorbis_dsp_state *state, int kind) {
   vamd_entry *e = vamd_entry_for(state);
   if (e && !e->poisoned) e->poisoned = kind;
+}
+/* envelope_vamd.c: which detector serves this stream (set != 0: decide) */
+int vamd_detector_mode(vorbis_dsp_state *state, int set) {
+  vamd_entry *e = vamd_entry_for(state);
+  if (e && set && !e->detector_mode) e->detector_mode = set;
+  return e ? e->detector_mode : 1;
 }
 /* envelope_vamd.c: the detector met a non-finite sample (1: from now on it takes no steps) / is it dead? */
 int vamd_detector_dead(vorbis_dsp_state *state, int set) {

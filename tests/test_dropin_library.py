@@ -42,8 +42,11 @@ def test_sonames_and_exports():
     assert ref_names <= _names(LIB) | {"_ve_envelope_search_cpu"} and not {n for n in extra if not n.endswith("_cpu")}, extra
 
 
-def _loop(libdirs, *args):
+def _loop(libdirs, *args, detector=None):
     env = dict(os.environ)
+    env.pop("VAMD_DETECTOR", None)        # the binding's default (auto), not the suite's (tests/conftest.py forces the GPU's)
+    if detector:
+        env["VAMD_DETECTOR"] = detector
     env["LD_LIBRARY_PATH"] = os.pathsep.join(libdirs + [env.get("LD_LIBRARY_PATH", "")])
     return subprocess.run([os.path.join(OUT, "encode_loop")] + [str(a) for a in args], env=env, capture_output=True, text=True, timeout=600)
 
@@ -61,12 +64,14 @@ def test_application_loop_on_the_reference_build(tmp_path):
 
 @needs_build
 @pytest.mark.gpu
+@pytest.mark.parametrize("detector", [None, "gpu", "host"])
 @pytest.mark.parametrize("read,quality,frames", [(1024, 0.4, 44100), (65536, 0.4, 44100), (4096, 0.9, 100000), (1024, 0.1, 30000)])
-def test_application_on_the_drop_in_matches_the_reference(tmp_path, read, quality, frames):
+def test_application_on_the_drop_in_matches_the_reference(tmp_path, read, quality, frames, detector):
     """C1 (1 s stereo white noise, 16-bit, q 0.4) at the example's READ 1024 and at 65 536-frame writes (the look-ahead's
-    case), and two more: the application's packets -- headers and audio -- are the reference's, byte for byte."""
+    case), and two more: the application's packets -- headers and audio -- are the reference's, byte for byte, whichever
+    detector serves the stream (VAMD_DETECTOR: the binding's own choice by the size of the first writes, the GPU's, libvorbis')."""
     f = tmp_path / "ref.pkts"
     r = _loop([os.path.join(OUT, "ref"), OUT], read, quality, frames, "write", f)
     assert r.returncode == 0, r.stderr
-    r = _loop([OUT], read, quality, frames, "check", f)
+    r = _loop([OUT], read, quality, frames, "check", f, detector=detector)
     assert r.returncode == 0 and "identical" in r.stderr, r.stdout + r.stderr
