@@ -469,6 +469,12 @@ int vamd_gather_blocks(vamd_ctx *ctx, const vamd_stream_plan *plan, int W, const
  * (all-zero on entry). */
 int vamd_plan_streams_whole(vamd_ctx *ctx, float *pcm, long stream_stride, long channel_stride, long nstreams,
                             long nframes, vamd_envelope_state *states, vamd_stream_plan *plan);
+/* The same for streams of UNEQUAL length: nframes[s] (HOST array [nstreams], each 1 .. max_frames) real samples in stream s,
+ * every buffer laid out for max_frames (the room behind a shorter stream's samples starts where ITS samples end and must be
+ * zero up to the buffer's end).  One launch sequence for all: every stream gets its own extrapolations, its own share of the
+ * detector's steps (the state a stream is left in is the state after exactly its steps) and its own walk. */
+int vamd_plan_streams_whole_v(vamd_ctx *ctx, float *pcm, long stream_stride, long channel_stride, long nstreams,
+                              long max_frames, const int64_t *nframes, vamd_envelope_state *states, vamd_stream_plan *plan);
 /* A plan's lists copied to host arrays (any may be NULL): per size class W lW / nW / blocktype / src [nblocks[W]],
  * order [nblocks[0] + nblocks[1]], stream_start [nstreams + 1].  Synchronises. */
 int vamd_plan_fetch(vamd_ctx *ctx, const vamd_stream_plan *plan, int32_t *const lW[2], int32_t *const nW[2],
@@ -528,7 +534,7 @@ vamd_ctx *vamd_batcher_context(vamd_batcher *b);
  *     vamd_feed_wrote(f, slot, ...)        like vorbis_analysis_wrote(): the group is the library's; returns at once
  *     vamd_feed_packets(f, slot, &out)     waits for the group; pointers into the lane's pinned output arena
  *     vamd_feed_release(f, slot)           the lane may be handed out again
- * Every stream of a group is complete and `frames` long (group streams of like length; a group per length otherwise).
+ * Every stream of a group is complete; vamd_feed_wrote() takes streams of one length, vamd_feed_wrote_v() of any lengths.
  * Per stream the packets are byte for byte what the reference encoder emits for the same samples written 1024 frames
  * at a time and closed with vorbis_analysis_wrote(v, 0) -- first block to last (tests/test_feed.py).  VBR setups whose
  * packets the GPU assembles (vamd_packet_capacity() > 0).  Thread rules: one thread drives a feed (or several, each
@@ -547,6 +553,9 @@ int vamd_feed_lanes(const vamd_feed *f);
 int vamd_feed_device(const vamd_feed *f, int slot);   /* the device lane `slot` runs on */
 int vamd_feed_buffer(vamd_feed *f, void **pcm);       /* >= 0: the slot; < 0: an OV_*-valued error */
 int vamd_feed_wrote(vamd_feed *f, int slot, long nstreams, long frames);
+/* streams of unequal length: frames[s] (host array, each 1 .. max_frames, their sum <= max_streams * max_frames) frames of
+ * stream s, the streams laid back to back in the arena (stream s starts at frame frames[0] + ... + frames[s-1]) */
+int vamd_feed_wrote_v(vamd_feed *f, int slot, long nstreams, const int64_t *frames);
 typedef struct vamd_feed_result {
   int64_t nstreams, nblocks;      /* blocks == packets, all streams */
   const int64_t *stream_start;    /* [nstreams + 1]: stream s owns packets [stream_start[s], stream_start[s+1]), in stream order */

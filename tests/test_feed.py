@@ -135,6 +135,29 @@ def test_groups_in_flight(as_float):
         assert not bad, "group %d\n" % gi + "\n".join(bad)
 
 
+@pytest.mark.parametrize("setup", ["44k_stereo_q4", "44k_stereo_q9"])
+def test_streams_of_unequal_length_in_one_group(setup):
+    """vamd_feed_wrote_v: eleven streams from 1 to 40 000 frames back to back in one group -- every stream gets its own LPC
+    ends, its own share of the detector's steps and its own walk, and emits what the reference emits for it alone."""
+    import vorbis_amd
+    from oracle import ref
+    if not ref.available():
+        pytest.skip("needs the reference build")
+    rng = np.random.default_rng(31)
+    lengths = [40000, 1, 33, 2049, 17000, 3072, 39999, 700, 25000, 4097, 12345]
+    kinds = ["gated", "noise", "sine", "clicks", "noise", "gated", "sine", "gated", "clicks", "noise", "gated"]
+    parts = [s16_streams(rng, 2, n, [k])[0] for n, k in zip(lengths, kinds)]
+    feed = vorbis_amd.Feed(vorbis_amd.default_setup_blob(setup), lanes_per_device=2, max_streams=16, max_frames=40000)
+    got = feed.encode(parts)
+    again = feed.encode(parts[::-1])[::-1]          # (the same streams in another order, on the other lane)
+    feed.close()
+    bad = []
+    for s, (pcm, g) in enumerate(zip(parts, got)):
+        bad += compare(setup, pcm[None], [g])
+        assert again[s] == g, "stream %d depends on its place in the group" % s
+    assert not bad, "\n".join(bad)
+
+
 def test_feed_argument_errors():
     import vorbis_amd
     feed = vorbis_amd.Feed(vorbis_amd.default_setup_blob("44k_stereo_q4"), lanes_per_device=1, max_streams=2, max_frames=4096)

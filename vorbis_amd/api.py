@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = ["vamd_create_abi", "vamd_encode_blocks", "vamd_clock_probe",
                     "vamd_plan_streams", "vamd_gather_blocks", "vamd_plan_fetch",
                     "vamd_batcher_create", "vamd_batcher_destroy", "vamd_batcher_attach", "vamd_batcher_detach",
                     "vamd_batcher_encode_block", "vamd_batcher_last_error", "vamd_batcher_stats", "vamd_batcher_context", "vamd_batcher_report",
-                    "vamd_input_status", "vamd_calib_copy", "vamd_abi_version", "vamd_plan_streams_whole", "vamd_device_count", "vamd_batcher_create_multi",
+                    "vamd_input_status", "vamd_calib_copy", "vamd_abi_version", "vamd_plan_streams_whole", "vamd_plan_streams_whole_v", "vamd_feed_wrote_v", "vamd_device_count", "vamd_batcher_create_multi",
                     "vamd_feed_create", "vamd_feed_destroy", "vamd_feed_lanes", "vamd_feed_device", "vamd_feed_buffer", "vamd_feed_wrote",
                     "vamd_feed_packets", "vamd_feed_release", "vamd_feed_last_error"]
 PACKETBLOBS = 15
@@ -138,6 +138,8 @@ def load_library():
     L.vamd_plan_streams.argtypes = [_vp, _vp, C.c_long, C.c_long, C.c_long, C.c_long, _vp, C.POINTER(_Plan)]
     L.vamd_gather_blocks.argtypes = [_vp, C.POINTER(_Plan), C.c_int, _vp, C.c_long, _vp]
     L.vamd_plan_streams_whole.argtypes = [_vp, _vp, C.c_long, C.c_long, C.c_long, C.c_long, _vp, C.POINTER(_Plan)]
+    L.vamd_plan_streams_whole_v.argtypes = [_vp, _vp, C.c_long, C.c_long, C.c_long, C.c_long, _vp, _vp, C.POINTER(_Plan)]
+    L.vamd_feed_wrote_v.argtypes = [_vp, C.c_int, C.c_long, _vp]
     L.vamd_feed_create.argtypes = [C.POINTER(_vp), _vp, C.c_size_t, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_long, C.c_long, C.c_int]
     L.vamd_feed_destroy.argtypes = [_vp]
     L.vamd_feed_destroy.restype = None
@@ -578,14 +580,20 @@ class Analyzer:
         self._need_tensor(streams, t.float32, "streams")
         self._need(streams.dim() == 3 and streams.shape[1] == self.channels, "streams must be [nstreams, %d, row]" % self.channels)
         ns, ch, ln = streams.shape
-        self._need(ln % 4 == 0 and ln >= self.blocksizes[1] // 2 + nframes + 3 * self.blocksizes[1],
+        self._need(ln % 4 == 0 and ln >= self.blocksizes[1] // 2 + int(np.max(nframes)) + 3 * self.blocksizes[1],
                    "a channel row needs blocksizes[1]/2 + nframes + 3 * blocksizes[1] samples (a multiple of 4)")
         if states is None:
             states = t.zeros((ns, C.sizeof(EnvelopeState)), dtype=t.uint8, device=self._dev())
         plan = _Plan()
         self._bind_stream()
-        self._check(self.L.vamd_plan_streams_whole(self.h, _vp(streams.data_ptr()), ch * ln, ln, ns, int(nframes), _vp(states.data_ptr()),
-                                                   C.byref(plan)))
+        if np.ndim(nframes) == 0:
+            self._check(self.L.vamd_plan_streams_whole(self.h, _vp(streams.data_ptr()), ch * ln, ln, ns, int(nframes), _vp(states.data_ptr()),
+                                                       C.byref(plan)))
+        else:  # streams of unequal length: every buffer laid out for the longest, zero behind a shorter stream's samples
+            fr = np.ascontiguousarray(nframes, dtype=np.int64)
+            self._need(fr.shape == (ns,), "nframes must hold one length per stream")
+            self._check(self.L.vamd_plan_streams_whole_v(self.h, _vp(streams.data_ptr()), ch * ln, ln, ns, int(fr.max()), _vp(fr.ctypes.data),
+                                                         _vp(states.data_ptr()), C.byref(plan)))
         return plan, states
 
     def plan_lists(self, plan):
@@ -891,7 +899,14 @@ class Feed:
         return slot, arr
 
     def wrote(self, slot, nstreams, frames):
-        self._check(self.L.vamd_feed_wrote(self.h, slot, nstreams, frames))
+        """frames: one length for every stream, or one per stream (the streams then lie back to back in the arena)"""
+        if np.ndim(frames) == 0:
+            self._check(self.L.vamd_feed_wrote(self.h, slot, nstreams, int(frames)))
+        else:
+            fr = np.ascontiguousarray(frames, dtype=np.int64)
+            if fr.shape != (nstreams,):
+                raise ValueError("frames must hold one length per stream")
+            self._check(self.L.vamd_feed_wrote_v(self.h, slot, nstreams, _vp(fr.ctypes.data)))
 
     def packets(self, slot, copy=True):
         """Waits for the group.  -> dict: nstreams, nblocks, stream_start, offset, bits, granulepos, info (numpy views over
@@ -915,13 +930,20 @@ class Feed:
         self._check(self.L.vamd_feed_release(self.h, slot))
 
     def encode(self, pcm):
-        """One group, synchronously: pcm [nstreams, frames, ch] of the feed's sample type (host).  -> per stream a list of
-        (packet bytes, granulepos, W, e_o_s)."""
-        pcm = np.ascontiguousarray(pcm, dtype=self.dtype)
-        ns, frames, ch = pcm.shape
+        """One group, synchronously: pcm [nstreams, frames, ch] of the feed's sample type (host), or a list of [frames_s, ch]
+        arrays of unequal length.  -> per stream a list of (packet bytes, granulepos, W, e_o_s)."""
+        if isinstance(pcm, (list, tuple)):
+            parts = [np.ascontiguousarray(x, dtype=self.dtype) for x in pcm]
+            ns, ch = len(parts), parts[0].shape[1]
+            frames = np.array([x.shape[0] for x in parts], np.int64)
+            flat = np.concatenate([x.reshape(-1) for x in parts])
+        else:
+            pcm = np.ascontiguousarray(pcm, dtype=self.dtype)
+            ns, frames, ch = pcm.shape
+            flat = pcm.reshape(-1)
         slot, buf = self.buffer(ch)
         try:
-            buf[:pcm.size] = pcm.reshape(-1)
+            buf[:flat.size] = flat
             self.wrote(slot, ns, frames)
             r = self.packets(slot)
         finally:

@@ -36,13 +36,15 @@ struct vamd_ctx {
          WS_NONZERO, WS_LOCAL, WS_AMPIN, WS_AMPGLOB, WS_PCM, WS_SEED, WS_SURV, WS_NSURV, WS_MISC,
          WS_ENV_NEAR, WS_ENV_RAW, WS_ENV_AMP, WS_ENV_BITS, WS_ENV_STAGE, WS_M_ILOGMASK, WS_M_STAGE,
          WS_RES_CLASS, WS_RES_ENTRIES, WS_RES_COUNT, WS_COUPLE_STATE,
-         WS_PLAN_FLAGS, WS_PLAN_BLOCKS, WS_PLAN_COUNTS, WS_PLAN_BASE, WS_PLAN_DESC, WS_PLAN_ORDER, WS_STATUS, WS_WRAPPED, WS_RES_BOOKS, WS_PLAN_PENDING, WS_COUNT };
+         WS_PLAN_FLAGS, WS_PLAN_BLOCKS, WS_PLAN_COUNTS, WS_PLAN_BASE, WS_PLAN_DESC, WS_PLAN_ORDER, WS_STATUS, WS_WRAPPED, WS_RES_BOOKS, WS_PLAN_PENDING, WS_PLAN_GEO, WS_COUNT };
   DevBuf ws[2][WS_COUNT];  // per size class (a mixed stream keeps both batches in flight)
   // pinned staging for the per-block host API
   void *h_stage = nullptr;
   size_t h_stage_bytes = 0;
   void *h_plan = nullptr;  // pinned: a stream plan's per-stream bases on their way up (vamd_plan_streams)
   size_t h_plan_bytes = 0;
+  void *h_geo = nullptr;   // pinned: per-stream geometry of whole streams of unequal length (vamd_plan_streams_whole_v)
+  size_t h_geo_bytes = 0;
   // optional per-stage timing (vamd_profile): one event before each stage + one after the last
   unsigned long long *d_dbg = nullptr;  // 80 phase-stopwatch slots when armed
   bool profile = false;

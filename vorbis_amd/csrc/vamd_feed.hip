@@ -40,21 +40,25 @@ size_t al(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // in [s][frame][c] (int16 or float) -> pcm[s * ss + c * cs + head + frame]; the room in front (head samples) and behind
 // (pad samples) zeroed, as the reference's calloc'ed / not yet written buffer is.  A thread takes four frames of every
 // channel: one 8 ch-byte (16-bit) or 16 ch-byte read, one 16-byte store per channel.
+// frames_of / first_of (optional): streams of unequal length laid back to back -- stream s has frames_of[s] <= frames frames
+// starting at frame first_of[s] of the arena; the rest of its buffer (laid out for `frames`) is zeroed.
 template <typename T>
 __global__ void k_feed_ingest(const T *__restrict__ in, int ch, long nstreams, long frames, int head, int pad,
                               float *__restrict__ pcm, long ss, long cs, float *__restrict__ amp,
-                              vamd_envelope_state *__restrict__ states) {
+                              vamd_envelope_state *__restrict__ states, const long long *__restrict__ frames_of,
+                              const long long *__restrict__ first_of) {
   const long quads = (frames + 3) >> 2, hq = head >> 2, pq = pad >> 2, per = hq + quads + pq, total = nstreams * per;
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
     const long s = t / per, q = t - s * per;
     float *row = pcm + s * ss;
+    const long mine = frames_of ? (long)frames_of[s] : frames, first = first_of ? (long)first_of[s] : s * frames;
     if (q < hq) {
       for (int c = 0; c < ch; c++) ((float4 *)(row + (long)c * cs))[q] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (q == 0) amp[s] = VAMD_AMPMAX_FLOOR;
     } else if (q < hq + quads) {
       const long f0 = (q - hq) << 2;
-      const T *src = in + (s * frames + f0) * ch;
-      const int live = frames - f0 < 4 ? (int)(frames - f0) : 4;
+      const T *src = in + (first + f0) * ch;
+      const int live = mine - f0 < 4 ? (mine > f0 ? (int)(mine - f0) : 0) : 4;
       for (int c = 0; c < ch; c++) {
         float v[4];
 #pragma unroll
@@ -89,6 +93,8 @@ struct FeedPlan {  // what the packing kernels need of a vamd_stream_plan and of
   int bs[2];
   int ch;
   int64_t stream_stride, eof;  // eof: first sample past the stream's real ones, in its buffer's coordinates
+  const long long *frames_of;  // streams of unequal length: eof = head + frames_of[s]
+  int head;
 };
 
 // a wave per stream: rel[k] = bytes (each packet rounded up to 4) of the stream's packets before packet k
@@ -172,7 +178,8 @@ __global__ __launch_bounds__(256) void k_feed_copy(FeedPlan P, long nstreams, lo
     const bool last = k + 1 == P.stream_start[s + 1];
     O.offset[k] = off;
     O.bits[k] = st ? -1 : bits;
-    O.granulepos[k] = (center < P.eof ? center : P.eof) - P.bs[1] / 2;
+    const int64_t eof = P.frames_of ? (int64_t)P.head + P.frames_of[s] : P.eof;
+    O.granulepos[k] = (center < eof ? center : eof) - P.bs[1] / 2;
     O.info[k] = (uint8_t)(W | (last ? 2 : 0) | ((st & 3) << 2));
   }
 }
@@ -213,12 +220,13 @@ struct FeedLane {
   Buf h_in, h_out, h_rec;                      // pinned: the group's samples; its packets; their records
   Buf d_in, d_pcm, d_states, d_amp;            // HBM: the samples as they came; as floats, planar; detector states; ampmax chains
   Buf d_pk[2], d_bits[2], d_status[2];         // the analysis' packet rows per size class
-  Buf d_rel, d_sid, d_sbytes, d_soff;
+  Buf d_rel, d_sid, d_sbytes, d_soff, d_len, h_len;  // (d_len / h_len: [frames_of | first_of] of a group of unequal streams)
   std::thread worker;
   std::mutex *upload_turn = nullptr;  // its device's (vamd_feed::upload_turns)
   // the job (guarded by vamd_feed::m)
   int state = LANE_FREE;
-  long nstreams = 0, frames = 0;
+  long nstreams = 0, frames = 0;  // frames: the group's longest stream
+  std::vector<int64_t> frames_of;  // empty: every stream is `frames` long
   int format = 0;
   int status = 0;
   std::string err;
@@ -263,13 +271,33 @@ static int run_group(vamd_feed *f, FeedLane &L) {
   const long ns = L.nstreams, frames = L.frames;
   const int ch = f->ch, head = f->bs[1] / 2, pad = 3 * f->bs[1];
   const size_t sample = L.format == VAMD_FEED_S16 ? 2 : 4;
-  const size_t in_bytes = (size_t)ns * frames * ch * sample;
+  const bool uneven = !L.frames_of.empty();
+  size_t in_frames = (size_t)ns * frames;
+  if (uneven) {
+    in_frames = 0;
+    for (long i = 0; i < ns; i++) in_frames += (size_t)L.frames_of[(size_t)i];
+  }
+  const size_t in_bytes = in_frames * ch * sample;
   const long cs = (long)al((size_t)head + ((frames + 3) & ~3L) + pad, 64), ss = cs * ch;
   hipStream_t st = L.stream;
   FEED_TRY(L.d_in.need(in_bytes ? in_bytes : 16));
   FEED_TRY(L.d_pcm.need((size_t)ns * ss * 4));
   FEED_TRY(L.d_states.need((size_t)ns * sizeof(vamd_envelope_state)));
   FEED_TRY(L.d_amp.need((size_t)ns * 4));
+  const long long *d_frames_of = nullptr, *d_first_of = nullptr;
+  if (uneven) {
+    FEED_TRY(L.h_len.need((size_t)ns * 16));
+    FEED_TRY(L.d_len.need((size_t)ns * 16));
+    long long *h = (long long *)L.h_len.p, at = 0;
+    for (long i = 0; i < ns; i++) {
+      h[i] = L.frames_of[(size_t)i];
+      h[ns + i] = at;
+      at += h[i];
+    }
+    FEED_TRY(hipMemcpyAsync(L.d_len.p, h, (size_t)ns * 16, hipMemcpyHostToDevice, st));
+    d_frames_of = (const long long *)L.d_len.p;
+    d_first_of = d_frames_of + ns;
+  }
   {
     // ONE upload at a time per device.  The link is a single resource: lanes that upload side by side each get a share
     // of it and all finish late together -- and then all compute together while the link idles (measured: three lanes
@@ -289,14 +317,17 @@ static int run_group(vamd_feed *f, FeedLane &L) {
     if (blocks < 1) blocks = 1;
     if (L.format == VAMD_FEED_S16)
       hipLaunchKernelGGL(k_feed_ingest<int16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const int16_t *)L.d_in.p, ch, ns, frames, head, pad,
-                         (float *)L.d_pcm.p, ss, cs, (float *)L.d_amp.p, (vamd_envelope_state *)L.d_states.p);
+                         (float *)L.d_pcm.p, ss, cs, (float *)L.d_amp.p, (vamd_envelope_state *)L.d_states.p, d_frames_of, d_first_of);
     else
       hipLaunchKernelGGL(k_feed_ingest<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float *)L.d_in.p, ch, ns, frames, head, pad,
-                         (float *)L.d_pcm.p, ss, cs, (float *)L.d_amp.p, (vamd_envelope_state *)L.d_states.p);
+                         (float *)L.d_pcm.p, ss, cs, (float *)L.d_amp.p, (vamd_envelope_state *)L.d_states.p, d_frames_of, d_first_of);
     FEED_TRY(hipGetLastError());
   }
   vamd_stream_plan plan;
-  FEED_CALL(vamd_plan_streams_whole(L.ctx, (float *)L.d_pcm.p, ss, cs, ns, frames, (vamd_envelope_state *)L.d_states.p, &plan));
+  if (uneven)
+    FEED_CALL(vamd_plan_streams_whole_v(L.ctx, (float *)L.d_pcm.p, ss, cs, ns, frames, L.frames_of.data(), (vamd_envelope_state *)L.d_states.p, &plan));
+  else
+    FEED_CALL(vamd_plan_streams_whole(L.ctx, (float *)L.d_pcm.p, ss, cs, ns, frames, (vamd_envelope_state *)L.d_states.p, &plan));
   const long nb = (long)(plan.nblocks[0] + plan.nblocks[1]);
   vamd_batch_desc desc[2];
   vamd_batch_io io[2];
@@ -337,7 +368,7 @@ static int run_group(vamd_feed *f, FeedLane &L) {
     P.src[W] = plan.src[W], P.bits[W] = (const int32_t *)L.d_bits[W].p, P.status[W] = (const uint8_t *)L.d_status[W].p;
     P.packets[W] = (const uint8_t *)L.d_pk[W].p, P.stride[W] = f->pkcap[W], P.bs[W] = f->bs[W];
   }
-  P.ch = ch, P.stream_stride = ss, P.eof = head + frames;
+  P.ch = ch, P.stream_stride = ss, P.eof = head + frames, P.frames_of = d_frames_of, P.head = head;
   for (int attempt = 0;; attempt++) {
     uint8_t *hrec = (uint8_t *)L.h_rec.p;
     void *drec = nullptr, *dbytes = nullptr;
@@ -413,7 +444,7 @@ static void feed_free(vamd_feed *f) {
     (void)hipSetDevice(L.device);
     if (L.stream) (void)hipStreamSynchronize(L.stream);
     if (L.ctx) vamd_destroy(L.ctx);
-    Buf *all[] = {&L.h_in, &L.h_out, &L.h_rec, &L.d_in, &L.d_pcm, &L.d_states, &L.d_amp, &L.d_pk[0], &L.d_pk[1], &L.d_bits[0],
+    Buf *all[] = {&L.d_len, &L.h_len, &L.h_in, &L.h_out, &L.h_rec, &L.d_in, &L.d_pcm, &L.d_states, &L.d_amp, &L.d_pk[0], &L.d_pk[1], &L.d_bits[0],
                   &L.d_bits[1], &L.d_status[0], &L.d_status[1], &L.d_rel, &L.d_sid, &L.d_sbytes, &L.d_soff};
     for (Buf *b : all) b->drop();
     if (L.ev0) (void)hipEventDestroy(L.ev0);
@@ -449,7 +480,7 @@ int vamd_feed_create(vamd_feed **out, const void *setup_blob, size_t blob_bytes,
     FeedLane &L = f->lanes[l];
     L.device = devs[l % devs.size()];
     L.upload_turn = f->upload_turns[l % devs.size()].get();
-    L.h_in.host = L.h_out.host = L.h_rec.host = true;
+    L.h_in.host = L.h_out.host = L.h_rec.host = L.h_len.host = true;
     r = vamd_create(&L.ctx, setup_blob, blob_bytes, L.device);
     if (r) break;
     hipError_t e = hipSetDevice(L.device);
@@ -530,6 +561,31 @@ int vamd_feed_wrote(vamd_feed *f, int slot, long nstreams, long frames) {
   FeedLane &L = f->lanes[(size_t)slot];
   if (L.state != LANE_FILLING) return VAMD_EINVAL;
   L.nstreams = nstreams, L.frames = frames, L.format = f->format;
+  L.frames_of.clear();
+  L.status = 0;
+  memset(&L.result, 0, sizeof(L.result));
+  L.t_wrote = now_s();
+  L.state = LANE_QUEUED;
+  f->cv_work.notify_all();
+  return VAMD_OK;
+}
+
+int vamd_feed_wrote_v(vamd_feed *f, int slot, long nstreams, const int64_t *frames) {
+  if (!f || !frames || slot < 0 || slot >= (int)f->lanes.size()) return VAMD_EINVAL;
+  if (nstreams < 1 || nstreams > f->max_streams) return VAMD_EINVAL;
+  long longest = 0;
+  long long total = 0;
+  for (long i = 0; i < nstreams; i++) {
+    if (frames[i] < 1 || frames[i] > f->max_frames) return VAMD_EINVAL;
+    if (frames[i] > longest) longest = (long)frames[i];
+    total += frames[i];
+  }
+  if (total > (long long)f->max_streams * f->max_frames) return VAMD_EINVAL;
+  std::lock_guard<std::mutex> g(f->m);
+  FeedLane &L = f->lanes[(size_t)slot];
+  if (L.state != LANE_FILLING) return VAMD_EINVAL;
+  L.nstreams = nstreams, L.frames = longest, L.format = f->format;
+  L.frames_of.assign(frames, frames + nstreams);
   L.status = 0;
   memset(&L.result, 0, sizeof(L.result));
   L.t_wrote = now_s();

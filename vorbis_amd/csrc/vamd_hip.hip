@@ -146,6 +146,7 @@ void vamd_destroy(vamd_ctx *c) {
       if (c->ws[W][i].p) (void)hipFree(c->ws[W][i].p);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->h_plan) (void)hipHostFree(c->h_plan);
+  if (c->h_geo) (void)hipHostFree(c->h_geo);
   if (c->d_dbg) (void)hipFree(c->d_dbg);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -1351,8 +1352,11 @@ int vamd_envelope_geometry(const vamd_ctx *c, int *winlength, int *searchstep) {
 }
 
 // `bad`: the word (device) that counts detector steps outside the input domain
+// count_of / first_of (device, optional): streams of unequal length in one launch -- stream s takes its first count_of[s] steps
+// only (its state is left after exactly those), and its first step starts first_of[s] samples into its buffer
 static int envelope_search_batch(vamd_ctx *c, const float *pcm, long stream_stride, long channel_stride, long nstreams,
-                                 long nsteps, vamd_envelope_state *states, unsigned char *ret, unsigned int *bad) {
+                                 long nsteps, vamd_envelope_state *states, unsigned char *ret, unsigned int *bad,
+                                 const int *count_of = nullptr, const long long *first_of = nullptr) {
   DeviceGuard dev_guard(c);
   if (!c) return VAMD_EINVAL;
   if (nstreams < 0 || nsteps < 0) return fail(c, VAMD_EINVAL, "negative stream / step count");
@@ -1381,7 +1385,7 @@ static int envelope_search_batch(vamd_ctx *c, const float *pcm, long stream_stri
     const long cap = (long)c->num_cus * 8;
     const size_t lds = (size_t)VAMD_ENV_WAVES * VAMD_ENV_STEPS * (n + n2 + VAMD_PW_SIZE(n2) + n2) * 4;
     hipLaunchKernelGGL(k_env_spectrum, dim3((unsigned)(groups < cap ? groups : cap)), dim3(64 * VAMD_ENV_WAVES), lds, s, E,
-                       ch, nstreams, nsteps, pcm, stream_stride, channel_stride, near, raw, bad);
+                       ch, nstreams, nsteps, pcm, stream_stride, channel_stride, near, raw, bad, first_of);
   }
   const bool env_untiled = c->K.env_untiled;  // (measurement aid: the thread-per-item forms)
   const bool big = nstreams * nsteps > 65536 && !env_untiled;
@@ -1406,7 +1410,7 @@ static int envelope_search_batch(vamd_ctx *c, const float *pcm, long stream_stri
     hipLaunchKernelGGL(k_env_bits_batch, dim3((unsigned)((nstreams * nsteps + 255) / 256)), dim3(256), 0, s, E, ch, nstreams,
                        nsteps, amp, bits);
   hipLaunchKernelGGL(k_env_walk, dim3((unsigned)nstreams), dim3(64), 0, s, ch, nstreams, nsteps, bits, near, amp,
-                     states, ret);
+                     states, ret, count_of);
   HIP_TRY(c, hipGetLastError());
   return VAMD_OK;
 }
@@ -1466,8 +1470,9 @@ int vamd_envelope_search(vamd_ctx *c, const float *const *pcm, long nsteps, vamd
 
 // whole != 0: the streams are complete (vamd_plan_streams_whole) -- `nsamples` counts the space in front of the first
 // sample and the real samples; the buffers have room for the end-of-stream padding behind them
+// frames_of (host, whole streams only): the streams' own lengths, each <= nsamples - blocksizes[1]/2
 static int plan_streams(vamd_ctx *c, float *pcm, long stream_stride, long channel_stride, long nstreams, long nsamples,
-                        vamd_envelope_state *states, vamd_stream_plan *plan, int whole) {
+                        vamd_envelope_state *states, vamd_stream_plan *plan, int whole, const int64_t *frames_of = nullptr) {
   DeviceGuard dev_guard(c);
   if (!c) return VAMD_EINVAL;
   if (!plan) return fail(c, VAMD_EINVAL, "null plan");
@@ -1509,6 +1514,46 @@ static int plan_streams(vamd_ctx *c, float *pcm, long stream_stride, long channe
   // which sizes everything below -- uninitialised: hence the checks straight after it)
   HIP_TRY(c, hipFuncSetAttribute((const void *)k_plan_streams, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_per_block));
   unsigned char *flags1 = (unsigned char *)v_flags, *flags2 = flags1 + (size_t)nstreams * steps1;
+  const PlanGeo *geo = nullptr;      // streams of unequal length: their own sample counts, step counts and first padding steps
+  const int *count1 = nullptr, *count2 = nullptr;
+  const long long *first2 = nullptr;
+  long steps2 = steps_all - steps1;  // steps of the second detector pass (the launch's: the longest stream's)
+  if (whole && frames_of) {
+    // [geo | count1 | count2 | first2] built on the host (a few words per stream) in a pinned buffer of the context's, one upload
+    const size_t o_c1 = (size_t)nstreams * sizeof(PlanGeo), o_c2 = o_c1 + (size_t)nstreams * 4, o_f2 = (o_c2 + (size_t)nstreams * 4 + 7) & ~(size_t)7,
+                 total = o_f2 + (size_t)nstreams * 8;
+    if (c->h_geo_bytes < total) {
+      if (c->h_geo) HIP_TRY(c, hipHostFree(c->h_geo));
+      c->h_geo = nullptr, c->h_geo_bytes = 0;
+      HIP_TRY(c, hipHostMalloc(&c->h_geo, total + total / 2, hipHostMallocDefault));
+      c->h_geo_bytes = total + total / 2;
+    }
+    void *v_geo;
+    if ((r = ws_get(c, 0, vamd_ctx::WS_PLAN_GEO, total, &v_geo))) return r;
+    // (the previous plan's upload out of this buffer has long been consumed: every plan ends with a stream synchronisation)
+    unsigned char *hg = (unsigned char *)c->h_geo;
+    PlanGeo *g = (PlanGeo *)hg;
+    int *c1 = (int *)(hg + o_c1), *c2 = (int *)(hg + o_c2);
+    long long *f2 = (long long *)(hg + o_f2);
+    steps2 = 0;
+    for (long i = 0; i < nstreams; i++) {
+      const long fr = (long)frames_of[i];
+      if (fr < 1 || head + fr > nsamples) return fail(c, VAMD_EINVAL, "whole streams: a stream's length must be 1 .. the launch's frame count");
+      long s1 = (head + fr) / E.searchstep - VAMD_VE_WIN, sa = (head + fr + pad) / E.searchstep - VAMD_VE_WIN;
+      if (s1 < 0) s1 = 0;
+      if (sa < s1) sa = s1;
+      g[i].nsamples = head + fr + pad, g[i].eof = head + fr, g[i].nsteps = (int)sa, g[i].split = (int)s1;
+      c1[i] = (int)s1, c2[i] = (int)(sa - s1), f2[i] = (long long)s1 * E.searchstep;
+      if (sa - s1 > steps2) steps2 = sa - s1;
+    }
+    HIP_TRY(c, hipMemcpyAsync(v_geo, hg, total, hipMemcpyHostToDevice, s));
+    geo = (const PlanGeo *)v_geo;
+    count1 = (const int *)((unsigned char *)v_geo + o_c1), count2 = (const int *)((unsigned char *)v_geo + o_c2);
+    first2 = (const long long *)((unsigned char *)v_geo + o_f2);
+    // flags2's rows are steps2 long; the flag buffer was sized for steps_all per stream: steps1 + steps2 may exceed it by VE_WIN
+    if ((r = ws_get(c, 0, vamd_ctx::WS_PLAN_FLAGS, (size_t)nstreams * (steps1 + steps2 + 1), &v_flags))) return r;
+    flags1 = (unsigned char *)v_flags, flags2 = flags1 + (size_t)nstreams * steps1;
+  }
   if (whole) {
     // the start of a stream as the example's 1024-sample writes make it (lib/block.c:524-528: the helper runs after the
     // first write that leaves more than blocksizes[1] samples beyond the centre, or when the stream is closed)
@@ -1521,18 +1566,20 @@ static int plan_streams(vamd_ctx *c, float *pcm, long stream_stride, long channe
     HIP_TRY(c, hipFuncSetAttribute((const void *)k_lpc_tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_per_block));
     if (n_head > 32)
       hipLaunchKernelGGL(k_lpc_head, dim3((unsigned)(nstreams * ch)), dim3(64), lpc_lds, s, ch, nstreams, pcm, stream_stride,
-                         channel_stride, head, (int)n_head);
-    if (steps1 && (r = vamd_envelope_search_batch(c, pcm, stream_stride, channel_stride, nstreams, steps1, states, flags1))) return r;
+                         channel_stride, head, (int)n_head, geo);
+    if (steps1 && (r = envelope_search_batch(c, pcm, stream_stride, channel_stride, nstreams, steps1, states, flags1, c->d_bad + 1, count1)))
+      return r;
     // where every stream's walk stands when the data runs out: the reference's buffer begins blocksizes[1]/2 before it
     void *v_pending;
     if ((r = ws_get(c, 0, vamd_ctx::WS_PLAN_PENDING, (size_t)nstreams * sizeof(long long), &v_pending))) return r;
-    hipLaunchKernelGGL(k_plan_streams, dim3((unsigned)nstreams), dim3(64), plan_lds, s, B, nstreams, flags1, steps1, flags2,
-                       (PlannedBlock *)nullptr, (int *)nullptr, (long long *)v_pending);
+    hipLaunchKernelGGL(k_plan_streams, dim3((unsigned)nstreams), dim3(64), plan_lds, s, B, nstreams, flags1, steps1, steps1, flags2, steps2,
+                       (PlannedBlock *)nullptr, (int *)nullptr, (long long *)v_pending, geo, 0);
     hipLaunchKernelGGL(k_lpc_tail, dim3((unsigned)(nstreams * ch)), dim3(64), lpc_lds, s, ch, nstreams, pcm, stream_stride,
-                       channel_stride, nsamples, c->B.bs[1], pad, (const long long *)v_pending);
+                       channel_stride, nsamples, c->B.bs[1], pad, (const long long *)v_pending, geo);
     HIP_TRY(c, hipGetLastError());
-    if (steps_all > steps1 &&
-        (r = vamd_envelope_search_batch(c, pcm + steps1 * E.searchstep, stream_stride, channel_stride, nstreams, steps_all - steps1, states, flags2)))
+    if (steps2 > 0 &&
+        (r = envelope_search_batch(c, geo ? pcm : pcm + steps1 * E.searchstep, stream_stride, channel_stride, nstreams, steps2, states, flags2,
+                                   c->d_bad + 1, count2, first2)))
       return r;
     B.eof = nsamples;
     B.nsamples = nsamples + pad;
@@ -1540,8 +1587,8 @@ static int plan_streams(vamd_ctx *c, float *pcm, long stream_stride, long channe
   } else if (steps1 && (r = vamd_envelope_search_batch(c, pcm, stream_stride, channel_stride, nstreams, steps1, states, flags1)))
     return r;
   HIP_TRY(c, hipMemsetAsync(v_counts, 0, (size_t)nstreams * 2 * sizeof(int), s));
-  hipLaunchKernelGGL(k_plan_streams, dim3((unsigned)nstreams), dim3(64), plan_lds, s, B, nstreams, flags1, steps1, flags2,
-                     (PlannedBlock *)v_blocks, (int *)v_counts, (long long *)nullptr);
+  hipLaunchKernelGGL(k_plan_streams, dim3((unsigned)nstreams), dim3(64), plan_lds, s, B, nstreams, flags1, steps1, steps1, flags2, steps2,
+                     (PlannedBlock *)v_blocks, (int *)v_counts, (long long *)nullptr, geo, 1);
   HIP_TRY(c, hipGetLastError());
   std::vector<int> counts((size_t)nstreams * 2);
   HIP_TRY(c, hipMemcpyAsync(counts.data(), v_counts, counts.size() * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1613,6 +1660,12 @@ int vamd_plan_streams_whole(vamd_ctx *c, float *pcm, long stream_stride, long ch
                             vamd_envelope_state *states, vamd_stream_plan *plan) {
   if (c && nframes < 0) return fail(c, VAMD_EINVAL, "negative frame count");
   return plan_streams(c, pcm, stream_stride, channel_stride, nstreams, c ? c->B.bs[1] / 2 + nframes : 0, states, plan, 1);
+}
+
+int vamd_plan_streams_whole_v(vamd_ctx *c, float *pcm, long stream_stride, long channel_stride, long nstreams, long max_frames,
+                              const int64_t *nframes, vamd_envelope_state *states, vamd_stream_plan *plan) {
+  if (c && (max_frames < 0 || !nframes)) return fail(c, VAMD_EINVAL, "negative frame count / null lengths");
+  return plan_streams(c, pcm, stream_stride, channel_stride, nstreams, c ? c->B.bs[1] / 2 + max_frames : 0, states, plan, 1, nframes);
 }
 
 int vamd_gather_blocks(vamd_ctx *c, const vamd_stream_plan *plan, int W, const float *pcm, long channel_stride,

@@ -1070,7 +1070,8 @@ __global__ void k_env_prolog(int ch, long nstreams, long nsteps, const vamd_enve
 __global__ __launch_bounds__(64 * VAMD_ENV_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_env_spectrum(EnvP E, int ch, long nstreams, long nsteps,
                                                                       const float *__restrict__ pcm, long stream_stride,
                                                                       long channel_stride, float *__restrict__ near,
-                                                                      float *__restrict__ raw, unsigned int *bad) {
+                                                                      float *__restrict__ raw, unsigned int *bad,
+                                                                      const long long *__restrict__ first_of) {
   const int n = E.mdct.n, n2 = n >> 1, wave = threadIdx.x >> 6;
   const int per_step = n + n2 + VAMD_PW_SIZE(n2) + n2;
   float *A = (float *)vamd_smem + (size_t)wave * per_step * VAMD_ENV_STEPS;
@@ -1086,7 +1087,8 @@ __global__ __launch_bounds__(64 * VAMD_ENV_WAVES) __attribute__((amdgpu_waves_pe
     const long s = sc / ch;
     const int c = (int)(sc - s * ch);
     count = nsteps - j < VAMD_ENV_STEPS ? (int)(nsteps - j) : VAMD_ENV_STEPS;
-    return pcm + s * stream_stride + c * channel_stride + j * E.searchstep;
+    // (first_of: streams whose steps start at different samples -- the end-of-stream pass of streams of unequal length)
+    return pcm + s * stream_stride + c * channel_stride + (first_of ? first_of[s] : 0) + j * E.searchstep;
   };
   const long stride = (long)gridDim.x * VAMD_ENV_WAVES;
   long it = (long)blockIdx.x * VAMD_ENV_WAVES + wave;
@@ -1229,20 +1231,23 @@ __global__ __launch_bounds__(256) void k_env_bits_tiled(EnvP E, int ch, long nst
 }
 
 // the stretch recurrence, one wave per stream; then the state's histories roll forward
+// (count_of: stream s takes only its first count_of[s] <= nsteps steps -- streams of unequal length in one launch; the
+// state it leaves is the state after exactly those)
 __global__ __launch_bounds__(64) void k_env_walk(int ch, long nstreams, long nsteps, const uint32_t *__restrict__ bits,
                                                  const float *__restrict__ near, const float *__restrict__ amp,
                                                  vamd_envelope_state *__restrict__ st,
-                                                 unsigned char *__restrict__ ret) {
+                                                 unsigned char *__restrict__ ret, const int *__restrict__ count_of) {
   const long s = blockIdx.x;
-  const int stretch = env_walk_wave(bits + s * nsteps, nsteps, st[s].stretch, ret + s * nsteps);
+  const long mine = count_of ? (long)count_of[s] : nsteps;
+  const int stretch = env_walk_wave(bits + s * nsteps, mine, st[s].stretch, ret + s * nsteps);
   if (LANE == 0) {
     st[s].stretch = stretch;
-    st[s].steps += nsteps;
+    st[s].steps += mine;
   }
   for (int c = 0; c < ch; c++) {
-    const float *nt = near + (s * ch + c) * (VAMD_VE_NEAR_HIST + nsteps) + nsteps;  // the last NEAR_HIST entries
+    const float *nt = near + (s * ch + c) * (VAMD_VE_NEAR_HIST + nsteps) + mine;  // the last NEAR_HIST entries
     WAVE_FOR(i, VAMD_VE_NEAR_HIST) st[s].near_hist[c][i] = nt[i];
-    const float *at = amp + ((s * ch + c) * (VAMD_VE_AMP_HIST + nsteps) + nsteps) * 8;
+    const float *at = amp + ((s * ch + c) * (VAMD_VE_AMP_HIST + nsteps) + mine) * 8;
     WAVE_FOR(i, VAMD_VE_AMP_HIST * 8) st[s].amp_hist[c][i >> 3][i & 7] = at[i];
   }
 }
@@ -1251,19 +1256,37 @@ __global__ __launch_bounds__(64) void k_env_walk(int ch, long nstreams, long nst
 // one wave per stream: the lanes turn the stream's flags into its mark bytes in LDS (coalesced reads, ve->mark[] as
 // mark_at defines it), then one lane does the walk out of LDS -- a dependent chain of a few thousand steps that would
 // otherwise pay a trip to HBM at each of them
-// (flags: [nstreams][split] then, from `flags2` on, [nstreams][B.nsteps - split] -- the steps of a stream's end-of-stream
-// padding are taken in a second detector pass, vamd_plan_streams_whole; split == B.nsteps: one array.)
-// pending != null: a dry run -- nothing is emitted, pending[s] = centerW of the block the walk stopped in front of.
-__global__ __launch_bounds__(64) void k_plan_streams(BlockoutP B, long nstreams, const unsigned char *__restrict__ flags,
-                                                     long split, const unsigned char *__restrict__ flags2,
+// flags: row s of `flags` holds the steps [0, split) at stride stride1, row s of `flags2` the steps from split on at stride2 (the
+// steps of a stream's end-of-stream padding are taken in a second detector pass, vamd_plan_streams_whole; split == B.nsteps:
+// one array).  pending != null: a dry run -- nothing is emitted, pending[s] = centerW of the block the walk stopped in front of.
+// geo != null: streams of unequal length -- geo[s] overrides B.nsamples, B.eof, B.nsteps and split for stream s.
+struct PlanGeo {
+  long long nsamples, eof;
+  int nsteps, split;
+};
+__global__ __launch_bounds__(64) void k_plan_streams(BlockoutP B, long nstreams, const unsigned char *__restrict__ flags, long stride1,
+                                                     long split, const unsigned char *__restrict__ flags2, long stride2,
                                                      PlannedBlock *__restrict__ blocks, int *__restrict__ counts,
-                                                     long long *__restrict__ pending) {
+                                                     long long *__restrict__ pending, const PlanGeo *__restrict__ geo,
+                                                     int with_eof) {
   unsigned char *marks = (unsigned char *)vamd_smem;  // [nsteps + 4]
   const long s = blockIdx.x;
+  const long lds_steps = B.nsteps;  // (the launch's LDS holds this many marks + 4)
+  if (geo) {
+    B.nsamples = geo[s].nsamples;
+    B.eof = geo[s].eof;
+    B.nsteps = geo[s].nsteps;
+    split = geo[s].split;
+    if (!with_eof) {  // the dry run: as far as the real samples go
+      B.nsamples = geo[s].eof;
+      B.eof = 0;
+      B.nsteps = split;
+    }
+  }
   const long last = blockout_steps(B);
-  const unsigned char *f = flags + s * split, *f2 = flags2 + s * (B.nsteps - split);
+  const unsigned char *f = flags + s * stride1, *f2 = flags2 + s * stride2;
   auto flag = [&](long p) -> int { return p < split ? f[p] : f2[p - split]; };
-  for (long p = threadIdx.x; p < B.nsteps + 4; p += 64) {
+  for (long p = threadIdx.x; p < lds_steps + 4; p += 64) {
     int m = 0;  // mark_at(), over the two pieces
     if (p < last) {
       if (p >= 1) m |= flag(p - 1) & 1;
@@ -1289,8 +1312,13 @@ __global__ __launch_bounds__(64) void k_plan_streams(BlockoutP B, long nstreams,
 // a wave per (stream, channel).  x = the channel's buffer: x[0, head) the (zero) space in front of the first sample,
 // x[head, head + n) the first n real samples.  lib/block.c:417-458.
 __global__ __launch_bounds__(64) void k_lpc_head(int ch, long nstreams, float *__restrict__ pcm, long stream_stride,
-                                                 long channel_stride, int head, int n) {
+                                                 long channel_stride, int head, int n, const PlanGeo *__restrict__ geo) {
   const long sc = blockIdx.x, s = sc / ch;
+  if (geo) {  // streams of unequal length: as many of the first samples as this stream has, up to n
+    const long long frames = geo[s].eof - head;
+    if (frames < n) n = (int)frames;
+  }
+  if (n <= 32) return;  // "if(v->pcm_current-v->centerW>order*2)", lib/block.c:427
   const int c = (int)(sc - s * ch);
   float *x = pcm + s * stream_stride + (long)c * channel_stride;
   double *aut = (double *)vamd_smem;                      // [2 * 16 + 1], padded to 80
@@ -1307,8 +1335,9 @@ __global__ __launch_bounds__(64) void k_lpc_head(int ch, long nstreams, float *_
 // buffer begins when the stream is closed (pending centre - bs1/2).  lib/block.c:474-512.
 __global__ __launch_bounds__(64) void k_lpc_tail(int ch, long nstreams, float *__restrict__ pcm, long stream_stride,
                                                  long channel_stride, long eof, int bs1, int pad,
-                                                 const long long *__restrict__ pending) {
+                                                 const long long *__restrict__ pending, const PlanGeo *__restrict__ geo) {
   const long sc = blockIdx.x, s = sc / ch;
+  if (geo) eof = (long)geo[s].eof;
   const int c = (int)(sc - s * ch);
   float *x = pcm + s * stream_stride + (long)c * channel_stride;
   double *aut = (double *)vamd_smem;                      // [2 * 32 + 1], padded to 80
