@@ -18,6 +18,7 @@
 #include "k_blockout.h"
 #include "k_residue.h"
 #include "k_pack.h"
+#include "k_lpc.h"
 
 using namespace vamd;
 
@@ -334,7 +335,9 @@ int emul_envelope_search(void *h, const float *pcm, long len, long nsteps, vamd_
 extern "C" {
 // blockout's decisions for one stream from its detector flags: what k_plan_streams does per stream (mark bytes via
 // mark_at, then plan_stream).  kind[], begin[] hold maxblocks entries; returns the number of blocks planned.
-int emul_plan_stream(void *h, const unsigned char *flags, long nsteps, long nsamples, int maxblocks, int *kind, int *begin) {
+// eof: 0, or the stream's end as k_blockout.h's BlockoutP::eof; pending (optional): where the walk stopped (centerW)
+int emul_plan_stream(void *h, const unsigned char *flags, long nsteps, long nsamples, int maxblocks, int *kind, int *begin, long eof,
+                     long *pending) {
   Emul *e = (Emul *)h;
   BlockoutP B;
   B.bs[0] = e->B.bs[0];
@@ -343,14 +346,46 @@ int emul_plan_stream(void *h, const unsigned char *flags, long nsteps, long nsam
   B.nsamples = nsamples;
   B.nsteps = nsteps;
   B.maxblocks = maxblocks;
+  B.eof = eof;
   const long last = blockout_steps(B);
   std::vector<unsigned char> marks((size_t)nsteps + 4, 0);
   for (long p = 0; p < nsteps + 4; p++) marks[p] = p < last ? (unsigned char)mark_at(flags, last, p) : 0;
   std::vector<PlannedBlock> out((size_t)maxblocks);
   int n0, n1;
-  const int n = plan_stream(B, marks.data(), out.data(), &n0, &n1);
+  long pc = 0;
+  const int n = plan_stream(B, marks.data(), out.data(), &n0, &n1, &pc);
+  if (pending) *pending = pc;
   for (int k = 0; k < n; k++) kind[k] = out[k].kind, begin[k] = out[k].begin;
   return n;
+}
+
+// The two ends of a stream as k_lpc_head / k_lpc_tail (vamd_kernels.h) form them, on one channel's buffer x:
+//   head: x[0, head) from the first n samples x[head, head + n)   (lib/block.c:417-458; nothing when n <= 32)
+//   tail: x[eof, eof + pad) from the last min(eof - start, bs1) samples before eof   (:474-512; zeros when eof - start <= 64)
+void emul_lpc_head(float *x, int head, int n) {
+  if (n <= 32) return;
+  const int order = 16;
+  std::vector<float> work((size_t)n + head), coeff(VAMD_LPC_MAX_ORDER);
+  std::vector<double> aut(2 * VAMD_LPC_MAX_ORDER + 1);
+  for (int j = 0; j < n; j++) work[j] = x[head + n - 1 - j];
+  lpc_from_data(work.data(), n, order, aut.data(), coeff.data());
+  lpc_predict(coeff.data(), work.data() + n - order, order, work.data() + n, head);
+  for (int i = 0; i < head; i++) x[head - 1 - i] = work[n + i];
+}
+void emul_lpc_tail(float *x, long eof, long start, int bs1, int pad) {
+  const int order = 32;
+  if (start < 0) start = 0;
+  const long have = eof - start;
+  if (have > order * 2) {
+    const int n = have < bs1 ? (int)have : bs1;
+    std::vector<float> coeff(VAMD_LPC_MAX_ORDER), out((size_t)pad);
+    std::vector<double> aut(2 * VAMD_LPC_MAX_ORDER + 1);
+    lpc_from_data(x + eof - n, n, order, aut.data(), coeff.data());
+    lpc_predict(coeff.data(), x + eof - order, order, out.data(), pad);
+    for (int i = 0; i < pad; i++) x[eof + i] = out[i];
+  } else {
+    for (int i = 0; i < pad; i++) x[eof + i] = 0.f;
+  }
 }
 }
 

@@ -67,7 +67,11 @@ class Emul:
         self.L.emul_submaps.argtypes = [C.c_void_p, C.c_int]
         self.L.emul_residue_offset.argtypes = [C.c_void_p, C.c_int, C.c_int]
         self.L.emul_envelope_search.argtypes = [C.c_void_p, _f32p, C.c_long, C.c_long, C.c_void_p, C.c_void_p]
-        self.L.emul_plan_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_void_p, C.c_void_p]
+        self.L.emul_plan_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_void_p, C.c_void_p, C.c_long, C.POINTER(C.c_long)]
+        self.L.emul_lpc_head.argtypes = [_f32p, C.c_int, C.c_int]
+        self.L.emul_lpc_head.restype = None
+        self.L.emul_lpc_tail.argtypes = [_f32p, C.c_long, C.c_long, C.c_int, C.c_int]
+        self.L.emul_lpc_tail.restype = None
         self.L.emul_chase_compare.argtypes = [_f32p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         blob = np.ascontiguousarray(blob, dtype=np.uint8)
         self.h = self.L.emul_open(blob.ctypes.data_as(C.c_void_p), blob.size)
@@ -157,15 +161,43 @@ class Emul:
         assert r == 0
         return ret
 
-    def plan_stream(self, flags, nsamples, maxblocks=4096):
+    def plan_stream(self, flags, nsamples, maxblocks=4096, eof=0, with_pending=False):
         """blockout's decisions for one stream from its detector flags (k_blockout.h compiled for the host).
-        Returns (kind[n], begin[n]): kind = W | lW << 1 | nW << 2 | blocktype << 3."""
+        Returns (kind[n], begin[n]): kind = W | lW << 1 | nW << 2 | blocktype << 3.  eof: the stream's end (BlockoutP::eof);
+        with_pending: also the centre of the block the walk stopped in front of."""
         flags = np.ascontiguousarray(flags, np.uint8)
         kind = np.zeros(maxblocks, np.int32)
         begin = np.zeros(maxblocks, np.int32)
+        pending = C.c_long(0)
         n = self.L.emul_plan_stream(self.h, flags.ctypes.data_as(C.c_void_p), C.c_long(len(flags)), C.c_long(nsamples),
-                                    maxblocks, kind.ctypes.data_as(C.c_void_p), begin.ctypes.data_as(C.c_void_p))
-        return kind[:n], begin[:n]
+                                    maxblocks, kind.ctypes.data_as(C.c_void_p), begin.ctypes.data_as(C.c_void_p), C.c_long(eof),
+                                    C.byref(pending))
+        return (kind[:n], begin[:n], int(pending.value)) if with_pending else (kind[:n], begin[:n])
+
+    def whole_stream(self, pcm, write_frames=1024):
+        """vamd_plan_streams_whole's sequence for ONE stream, every piece the product's own code compiled for the host: pcm
+        [ch][frames] -> (the stream's buffer with both LPC ends filled, kind[], begin[]).  The detector flags come from
+        envelope_search (k_envelope.h)."""
+        import vorbis_amd
+        pcm = np.ascontiguousarray(pcm, np.float32)
+        ch, frames = pcm.shape
+        bs1, head, pad = self.bs[1], self.bs[1] // 2, 3 * self.bs[1]
+        buf = np.zeros((ch, head + frames + pad + 64), np.float32)
+        buf[:, head:head + frames] = pcm
+        n_head = min(frames, (bs1 // write_frames + 1) * write_frames)
+        for c in range(ch):
+            self.L.emul_lpc_head(buf[c].ctypes.data_as(_f32p), head, n_head)
+        steps1 = max(0, (head + frames) // 64 - 4)
+        st = vorbis_amd.EnvelopeState()
+        flags1 = self.envelope_search(buf[:, :(steps1 - 1) * 64 + 128], steps1, st) if steps1 else np.zeros(0, np.uint8)
+        _, _, pending = self.plan_stream(flags1, head + frames, with_pending=True)
+        for c in range(ch):
+            self.L.emul_lpc_tail(buf[c].ctypes.data_as(_f32p), head + frames, pending - bs1 // 2, bs1, pad)
+        steps_all = (head + frames + pad) // 64 - 4
+        n2 = steps_all - steps1
+        flags2 = self.envelope_search(buf[:, steps1 * 64:steps1 * 64 + (n2 - 1) * 64 + 128], n2, st)
+        kind, begin = self.plan_stream(np.concatenate([flags1, flags2]), head + frames + pad, eof=head + frames)
+        return buf, kind, begin
 
     def fit_segments_mismatches(self):
         """accumulate_fit's static work list against the reference's loops (emul_fit_segments_check)."""
