@@ -563,8 +563,9 @@ static void launch_couple(vamd_ctx *c, BatchRun *R, hipStream_t s, long units, i
 //         the short blocks' tone chain -- as long as the long blocks', beside a noise mask a fifth as long -- has the long
 //         blocks' noise mask and floor fits to run beside (C5: visible tone tail 1.08 -> see DESIGN section 6).
 //   forked: the side stream already waits for everything the tone chain needs (run_streams_mixed's ampmax chain)
+//   alone: no other size class's masks and floors in this run for the tone chain to run beside
 static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_io *M = nullptr, ilog_t *m_ilogmask = nullptr,
-                        int part = 3, bool forked = false) {
+                        int part = 3, bool forked = false, bool alone = true) {
   if (R->nb == 0) return;
   const ResBufs &rb = R->rb;
   const int W = R->W, ch = c->B.channels;
@@ -634,7 +635,12 @@ static void launch_rest(vamd_ctx *c, BatchRun *R, int level, const vamd_managed_
         // bitrate-managed blocks) it needs half the CU to finish beside the noise mask: four teams.  65 536 stereo blocks
         // at the masks-only level: noise + visible tone tail 1.17 + 0.80 ms with seven teams, 1.25 + 0.64 with six,
         // 1.38 + 0.60 with five, 1.63 + 0.08 with four.
-        const long cap = (fold_in_floor ? 24 : 16) / nw;
+        // (round 6, with round 5's faster seeding: a run of ONE size class does better with five teams -- noise mask +
+        // visible tone tail per 131 072 stereo blocks 2.77 + 0.01 ms against 2.51 + 0.32 with six, 2.34 + 0.54 with seven,
+        // 2.16 + 0.93 with eight; a mixed run, whose chains also have the other class's masks and floor fits to run
+        // beside, keeps six: C5 11.25 ms against 11.34 with five.  profiles/r06_noise_teams.txt)
+        const int beside = c->K.noise_waves > 0 ? c->K.noise_waves : (alone ? 20 : 24);
+        const long cap = (fold_in_floor ? beside : 16) / nw;
         if (per_cu > cap) per_cu = cap > 0 ? cap : 1;
       }
       if (per_cu < 1) per_cu = 1;
@@ -964,13 +970,13 @@ static int run_streams_mixed(vamd_ctx *c, const vamd_batch_desc *desc_short, con
   R[0].d.ampmax_in = R[0].p.ampin;
   R[1].d.ampmax_in = R[1].p.ampin;
   if (chain_on_side) {  // both classes' masks first, the long blocks' leading
-    launch_rest(c, &R[1], VAMD_LEVEL_FULL, MM[1], m_ilog[1], 1, true);
-    launch_rest(c, &R[0], VAMD_LEVEL_FULL, MM[0], m_ilog[0], 1, true);
-    launch_rest(c, &R[1], VAMD_LEVEL_FULL, MM[1], m_ilog[1], 2, true);
-    launch_rest(c, &R[0], VAMD_LEVEL_FULL, MM[0], m_ilog[0], 2, true);
+    launch_rest(c, &R[1], VAMD_LEVEL_FULL, MM[1], m_ilog[1], 1, true, R[0].nb == 0);
+    launch_rest(c, &R[0], VAMD_LEVEL_FULL, MM[0], m_ilog[0], 1, true, R[1].nb == 0);
+    launch_rest(c, &R[1], VAMD_LEVEL_FULL, MM[1], m_ilog[1], 2, true, R[0].nb == 0);
+    launch_rest(c, &R[0], VAMD_LEVEL_FULL, MM[0], m_ilog[0], 2, true, R[1].nb == 0);
   } else {
-    launch_rest(c, &R[0], VAMD_LEVEL_FULL, MM[0], m_ilog[0]);
-    launch_rest(c, &R[1], VAMD_LEVEL_FULL, MM[1], m_ilog[1]);
+    launch_rest(c, &R[0], VAMD_LEVEL_FULL, MM[0], m_ilog[0], 3, false, R[1].nb == 0);
+    launch_rest(c, &R[1], VAMD_LEVEL_FULL, MM[1], m_ilog[1], 3, false, R[0].nb == 0);
   }
   if (chain_on_side && R[0].nb == 0 && R[1].nb == 0) {  // (cannot happen -- nblocks_total > 0 -- but nothing may be left unjoined)
     (void)hipEventRecord(c->ev_join, c->side);

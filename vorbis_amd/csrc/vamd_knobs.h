@@ -32,6 +32,7 @@ struct Knobs {
   long chase_wave_max = 32768;   // VAMD_CHASE_WAVE_MAX: channel-blocks up to which the stack walk takes a wave a block
   bool masks_separate = false;   // VAMD_MASKS_SEPARATE: never both masks in one launch
   int noise_teams = 0;           // VAMD_NOISE_TEAMS: noise teams per CU (0: chosen by the launch)
+  int noise_waves = 0;           // VAMD_NOISE_WAVES: the noise mask's waves per CU beside the tone chain (of 32; 0: chosen by the launch)
   long floor_lds_pad = 0;        // VAMD_FLOOR_LDS_PAD: extra LDS per k_floor wave (an occupancy experiment)
   long floor_pair_min = -1;      // VAMD_FLOOR_PAIR_MIN: channel-blocks from which k_floor pairs channels (-1: default)
   int floor_pair_w = 3;          // VAMD_FLOOR_PAIR_W: size classes that may pair (bit 0 short, bit 1 long)
@@ -65,6 +66,8 @@ inline Knobs read_knobs() {
       k.chase_wave_max = num("VAMD_CHASE_WAVE_MAX", k.chase_wave_max);
       k.masks_separate = on("VAMD_MASKS_SEPARATE");
       k.noise_teams = (int)num("VAMD_NOISE_TEAMS", 0);
+      k.noise_waves = (int)num("VAMD_NOISE_WAVES", k.noise_waves);
+      if (k.noise_waves < 4 || k.noise_waves > 32) k.noise_waves = 0;
       k.floor_lds_pad = num("VAMD_FLOOR_LDS_PAD", 0);
       k.floor_pair_min = num("VAMD_FLOOR_PAIR_MIN", -1);
       k.floor_pair_w = (int)num("VAMD_FLOOR_PAIR_W", 3);
@@ -85,11 +88,11 @@ inline void knobs_string(const Knobs &k, char *buf, size_t cap) {
   if (k.test && n > 0 && (size_t)n < cap)
     snprintf(buf + n, cap - (size_t)n,
              " VAMD_NO_OVERLAP=%d VAMD_COUPLE_BAND_LOG2=%s%d VAMD_XF_WAVES_CAP=%d VAMD_RES_TEAM_MAX=%ld VAMD_PACK_PAIR_MAX=%ld"
-             " VAMD_FOLD_SEPARATE=%d VAMD_CHASE_WAVE_MAX=%ld VAMD_MASKS_SEPARATE=%d VAMD_NOISE_TEAMS=%d VAMD_FLOOR_LDS_PAD=%ld"
+             " VAMD_FOLD_SEPARATE=%d VAMD_CHASE_WAVE_MAX=%ld VAMD_MASKS_SEPARATE=%d VAMD_NOISE_TEAMS=%d VAMD_NOISE_WAVES=%d VAMD_FLOOR_LDS_PAD=%ld"
              " VAMD_FLOOR_PAIR_MIN=%ld VAMD_FLOOR_PAIR_W=%d VAMD_STAGE_COPIES=%d VAMD_ENV_UNTILED=%d VAMD_XF_VARIANT=%d VAMD_FAIL_ENVELOPE_AFTER=%ld"
              " VAMD_FAIL_ENCODE_AFTER=%ld",
              (int)k.no_overlap, k.couple_band_set ? "" : "unset:", k.couple_band_log2, k.xf_waves_cap, k.res_team_max,
-             k.pack_pair_max, (int)k.fold_separate, k.chase_wave_max, (int)k.masks_separate, k.noise_teams, k.floor_lds_pad,
+             k.pack_pair_max, (int)k.fold_separate, k.chase_wave_max, (int)k.masks_separate, k.noise_teams, k.noise_waves, k.floor_lds_pad,
              k.floor_pair_min, k.floor_pair_w, (int)k.stage_copies, (int)k.env_untiled, k.xf_variant, k.fail_envelope_after,
              k.fail_encode_after);
 }
