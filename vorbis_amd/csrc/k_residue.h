@@ -249,4 +249,214 @@ VAMD_DEV void residue_block(const ResP &R, int n2, const int *const *iwork, cons
   pc.mark(1);
 }
 
+#if VAMD_GPU
+// ---- round 6: the stereo type-2 residue out of registers ---------------------------------------------------------------
+// residue_block above moves a block's values into LDS, classifies a partition per lane (32 reads each, all lanes on the
+// same banks), and searches stage after stage with a workgroup barrier between stages and a binary search per vector for
+// the partition it belongs to: 51 k + 28 k cycles per wave and block (tools/res_profile.py), most of them waiting.  None
+// of that is needed where the vectors tile runs of EIGHT interleaved values (every book's dim divides 8, the partitions
+// are 8, 16 or 32 values: ResP::chunked, vamd_bind.h): a stage only ever refines values another vector of the same run
+// left behind, so a lane that owns a run -- four bins of both channels, two 16-byte loads -- takes it through all the
+// stages in registers.  The partition's class is a max over the 1, 2 or 4 lanes that hold it (DPP quad_perm), the
+// emission offsets are the same prefix sum over the classes as before (residue_offsets), and a run's vectors of a stage
+// go to consecutive places behind its partition's.  No work vector in LDS, no barrier at all (a wave per block), no search.
+VAMD_DEV int quad_max(int v, int lanes) {  // max over the aligned group of `lanes` (1, 2, 4) lanes; every lane active
+  if (lanes >= 2) {
+    const int t = __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false);  // quad_perm [1,0,3,2]
+    v = v > t ? v : t;
+  }
+  if (lanes >= 4) {
+    const int t = __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false);  // quad_perm [2,3,0,1]
+    v = v > t ? v : t;
+  }
+  return v;
+}
+
+// local_book_besterror (lib/res0.c:322-382) on DIM values held in registers (`a`: constant indices once unrolled);
+// the book as the (class, stage) row of the LDS table holds it
+template <int DIM>
+VAMD_DEV int residue_besterror_regs(const ResP &R, const ResStage &bk, int *a) {
+  const int minval = bk.minval, del = bk.delta, qv = bk.quantvals, ze = qv >> 1;
+  const float rcp = div_rcp(del);
+  int index = 0;
+  int p[DIM];
+#pragma unroll
+  for (int o = DIM - 1; o >= 0; o--) {
+    const int num = a[o] - minval + (del != 1 ? (del >> 1) : 0);
+    int v;
+    if (del == 1) {
+      v = num;
+    } else {  // C's division truncates toward zero
+      const int mag = num < 0 ? -num : num;
+      const int q = mag < (1 << 24) ? div_small(mag, del, rcp) : mag / del;
+      v = num < 0 ? -q : q;
+    }
+    const int m = (v < ze ? ((ze - v) << 1) - 1 : ((v - ze) << 1));
+    index = index * qv + (m < 0 ? 0 : (m >= qv ? qv - 1 : m));
+    p[o] = v * del + minval;
+  }
+  if (!bk.full) {
+    const signed char *len = (const signed char *)(R.base + (unsigned)bk.off_lengths);
+    if (len[index] <= 0) {
+      // the lattice point is not a populated entry: exhaustive nearest search, in entry order (:349-376)
+      int best = -1;
+      int ev[DIM];
+#pragma unroll
+      for (int j = 0; j < DIM; j++) ev[j] = 0;
+      const int maxval = minval + del * (qv - 1);
+      for (int i = 0; i < bk.entries; i++) {
+        if (len[i] > 0) {
+          int dist = 0;
+#pragma unroll
+          for (int j = 0; j < DIM; j++) {
+            const int val = ev[j] - a[j];
+            dist += val * val;
+          }
+          if (best == -1 || dist < best) {
+#pragma unroll
+            for (int j = 0; j < DIM; j++) p[j] = ev[j];
+            best = dist;
+            index = i;
+          }
+        }
+        // the odometer over the lattice (:371-375): digits at their maximum wrap to zero, the first one that is not steps
+        bool carry = true;
+#pragma unroll
+        for (int j = 0; j < DIM; j++)
+          if (carry) {
+            if (ev[j] >= maxval) {
+              ev[j] = 0;
+            } else {
+              if (ev[j] >= 0) ev[j] += del;
+              ev[j] = -ev[j];
+              carry = false;
+            }
+          }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < DIM; i++) a[i] -= p[i];
+  return index;
+}
+
+// One block's search by ONE wave (k_residue_chunks: persistent waves, a block each at a time -- nothing to wait for but the
+// wave's own loads, and a CU holds as many blocks in flight as it has wave slots).
+//   iw0 / iw1  HBM [n2] the two channels' quantised (and coupled) residue
+//   tab        LDS [R.fast_ints]: R.fast, copied there by the caller once per workgroup
+//   cls [partvals], off [stages*partvals + 1]: this wave's LDS
+// The runs are fetched twice, 64 at a time -- once for the classes, once for the search (the second time out of the
+// caches): held in registers across the offsets' prefix sum, four passes of them cost the wave half its neighbours.
+// Returns the input domain's integer edge, second half (include/vorbis_amd.h): bit c set when channel c holds a value beyond R.qmax.
+VAMD_DEV void residue_run_fetch(const ResP &R, const int *__restrict__ iw0, const int *__restrict__ iw1, int it, int chunks, int *v) {
+  I4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
+  if (it < chunks) {
+    const int bin = (R.begin >> 1) + 4 * it;
+    a = *(const I4 *)(iw0 + bin);
+    b = *(const I4 *)(iw1 + bin);
+  }
+  v[0] = a.x, v[1] = b.x, v[2] = a.y, v[3] = b.y, v[4] = a.z, v[5] = b.z, v[6] = a.w, v[7] = b.w;
+}
+VAMD_DEV unsigned residue_wave_chunks(const ResP &R, const int *__restrict__ iw0, const int *__restrict__ iw1, int nz, const int *tab,
+                                      int *cls, int *off, int *__restrict__ class_out, unsigned short *__restrict__ entries_out,
+                                      int *__restrict__ count_out, PhaseClock &pc, unsigned char *__restrict__ books_out) {
+  if (!nz) {  // res2_class returns NULL and res2_forward writes nothing
+    if (LANE == 0) {
+      count_out[0] = 0;
+      count_out[1] = 0;
+    }
+    return 0;
+  }
+  const int spp = R.tab_grouping, nparts = R.nparts, partvals = R.partvals, stages = R.nstages;
+  const int g = spp >> 3, chunks = partvals * g;  // lanes per partition (1, 2 or 4); runs of eight in [begin, end)
+  const int *metric1 = tab, *metric2 = tab + nparts;
+  const ResStage *rows = (const ResStage *)(tab + ((2 * nparts + 3) & ~3));
+  unsigned bad = 0;
+  for (int base = 0; base < chunks; base += NLANES) {
+    const int it = base + LANE;
+    int v[8];
+    residue_run_fetch(R, iw0, iw1, it, chunks, v);
+    int mag = 0, ang = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+      const int m = v[k] < 0 ? -v[k] : v[k], an = v[k + 1] < 0 ? -v[k + 1] : v[k + 1];
+      mag = m > mag ? m : mag;
+      ang = an > ang ? an : ang;
+    }
+    // (zeros of the lanes past the end are inside the bound)
+    if (mag > R.qmax) bad |= 1u;
+    if (ang > R.qmax) bad |= 2u;
+    // _2class (:501-518): channel 0 of the bundle against classmetric1, channel 1 against classmetric2
+    mag = quad_max(mag, g);
+    ang = quad_max(ang, g);
+    int j = 0;
+    for (; j < nparts - 1; j++)
+      if (mag <= metric1[j] && ang <= metric2[j]) break;
+    if (it < chunks && (it & (g - 1)) == 0) {
+      cls[it / g] = j;
+      class_out[it / g] = j;
+    }
+  }
+  WAVE_SYNC();
+  // where a partition's vectors of a stage go: _01forward emits (stage, partition, vector) -- an exclusive prefix sum over
+  // the (stage, partition) counts, a wave-width at a time
+  const int items = stages * partvals;
+  int carry = 0;
+  for (int base = 0; base < items; base += NLANES) {
+    const int itx = base + LANE;
+    int c = 0;
+    if (itx < items) {
+      const int s = itx / partvals, i = itx - s * partvals;
+      const ResStage &st = rows[cls[i] * stages + s];
+      c = st.bn >= 0 ? st.nv : 0;
+    }
+    const int incl = wave_scan_sum(c);
+    if (itx < items) off[itx] = carry + incl - c;
+    carry += wave_last(incl);
+  }
+  if (LANE == 0) {
+    count_out[0] = partvals;
+    count_out[1] = carry;
+  }
+  WAVE_SYNC();
+  pc.mark(0);
+  // the search: a run through every stage its partition's class has a book for
+  for (int base = 0; base < chunks; base += NLANES) {
+    const int it = base + LANE;
+    int v[8];
+    residue_run_fetch(R, iw0, iw1, it, chunks, v);
+    if (it >= chunks) continue;
+    const int part = it / g, r = it & (g - 1);
+    const int mycls = cls[part];
+    for (int s = 0; s < stages; s++) {
+      const ResStage st = rows[mycls * stages + s];
+      if (st.bn < 0) continue;
+      const int dim = st.dim;
+      const int e0 = off[s * partvals + part] + r * (8 / dim);
+      auto emit = [&](int k, int entry) {
+        if (e0 + k < R.cap) {
+          entries_out[e0 + k] = (unsigned short)entry;
+          if (books_out) books_out[e0 + k] = (unsigned char)st.bn;  // (< 256 books: vamd_bind.h)
+        }
+      };
+      if (dim == 2) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) emit(k, residue_besterror_regs<2>(R, st, v + 2 * k));
+      } else if (dim == 4) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) emit(k, residue_besterror_regs<4>(R, st, v + 4 * k));
+      } else if (dim == 8) {
+        emit(0, residue_besterror_regs<8>(R, st, v));
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++) emit(k, residue_besterror_regs<1>(R, st, v + k));
+      }
+    }
+  }
+  WAVE_SYNC();  // (cls / off are the next block's from here)
+  pc.mark(1);
+  return bad;
+}
+#endif
+
 }  // namespace vamd

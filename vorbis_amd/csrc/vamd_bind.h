@@ -404,6 +404,42 @@ inline int build_image(const void *blob_v, size_t bytes, std::vector<unsigned ch
     const unsigned char *a = (const unsigned char *)rob.data();
     image->insert(image->end(), a, a + 2 * rob.size());
   }
+  for (int W = 0; W < 2; W++)
+    for (int sm = 0; sm < VAMD_MAX_SUBMAPS; sm++) {
+      // slots 39 + 2 W + sm: what the residue search needs of its tables, packed for one trip into LDS (residue_block_chunks,
+      // k_residue.h): classmetric1 [partitions], classmetric2 [partitions], then per (class, stage) a ResStage
+      const vamd_residue_tab &r = h.res[W][sm < h.mode[W].submaps ? sm : 0];
+      std::vector<int32_t> tab;
+      const int np = r.partitions >= 0 && r.partitions <= VAMD_RES_MAXCLASS ? r.partitions : 0;
+      const int nst = r.stages >= 0 && r.stages <= VAMD_RES_MAXSTAGE ? r.stages : 0;
+      for (int c = 0; c < np; c++) tab.push_back(r.classmetric1[c]);
+      for (int c = 0; c < np; c++) tab.push_back(r.classmetric2[c]);
+      while (tab.size() & 3) tab.push_back(0);
+      const vamd_book_tab *bks = (const vamd_book_tab *)(blob + h.off_books);
+      for (int c = 0; c < np; c++)
+        for (int st = 0; st < nst; st++) {
+          ResStage e;
+          memset(&e, 0, sizeof(e));
+          e.bn = -1;
+          const int bn = ((r.secondstages[c] >> st) & 1) ? r.partbooks[c][st] : -1;
+          if (bn >= 0 && bn < h.nbooks && bks[bn].dim >= 1 && (size_t)bks[bn].off_lengths + (size_t)bks[bn].entries <= h.total_bytes) {
+            const vamd_book_tab &bk = bks[bn];
+            e.bn = bn, e.dim = bk.dim, e.minval = bk.minval, e.delta = bk.delta, e.quantvals = bk.quantvals;
+            e.off_lengths = (int32_t)bk.off_lengths, e.entries = bk.entries;
+            e.nv = r.grouping / bk.dim;
+            const signed char *len = (const signed char *)(blob + bk.off_lengths);
+            e.full = 1;  // every entry populated: local_book_besterror never takes its exhaustive search
+            for (int i = 0; i < bk.entries; i++)
+              if (len[i] <= 0) e.full = 0;
+          }
+          const int32_t *w = (const int32_t *)&e;
+          tab.insert(tab.end(), w, w + sizeof(e) / 4);
+        }
+      while (image->size() & 15) image->push_back(0);
+      derived_off->push_back((uint32_t)image->size());
+      const unsigned char *a = (const unsigned char *)tab.data();
+      image->insert(image->end(), a, a + 4 * tab.size());
+    }
   while (image->size() & 15) image->push_back(0);
   return VAMD_OK;
 }
@@ -671,12 +707,16 @@ inline void bind_params(const std::vector<unsigned char> &image, const std::vect
                 (r.type != 2 || r.grouping % bundle == 0);
       int worst = 0;
       long worst_bits = 0;
+      // ... and, for residue_block_chunks: two channels interleaved, partitions of 8, 16 or 32 values starting on a
+      // multiple of eight, every book's dimension a divisor of eight
+      bool tiles8 = r.type == 2 && bundle == 2 && (r.grouping == 8 || r.grouping == 16 || r.grouping == 32) && (r.begin % 8) == 0;
       for (int c = 0; c < r.partitions && ok; c++) {
         int per = 0;
         long perb = 0;
         for (int s = 0; s < r.stages; s++)
           if (((r.secondstages[c] >> s) & 1) && r.partbooks[c][s] >= 0) {
             const vamd_book_tab &bk = hb[r.partbooks[c][s]];
+            if (bk.dim < 1 || 8 % bk.dim) tiles8 = false;
             if (bk.dim > 8 || bk.dim > r.grouping || bk.entries > 65535 || r.grouping % bk.dim) ok = false;
             else per += r.grouping / bk.dim, perb += (long)(r.grouping / bk.dim) * longest(r.partbooks[c][s]);
           }
@@ -692,6 +732,11 @@ inline void bind_params(const std::vector<unsigned char> &image, const std::vect
       Rp.ent_base = ent_base;
       Rp.lds_ints = bundle * n2 + VAMD_RES_CLASS_STRIDE + 2 * r.stages * Rp.slots + 1;
       Rp.qmax = derive_quant_limit(h, hb, W, src);
+      Rp.chunked = ok && tiles8 ? 1 : 0;
+      Rp.tab_grouping = r.grouping;
+      Rp.begin = r.begin, Rp.nparts = r.partitions, Rp.nstages = r.stages;
+      Rp.fast = (const int *)(base + derived_off[39 + 2 * W + sm]);
+      Rp.fast_ints = ((2 * r.partitions + 3) & ~3) + r.partitions * r.stages * (int)(sizeof(ResStage) / 4);
       if (sm < m.submaps) {
         all_ok = all_ok && ok;
         ent_base += Rp.cap;

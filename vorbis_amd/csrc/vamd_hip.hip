@@ -496,12 +496,27 @@ static void launch_residue_pack(vamd_ctx *c, BatchRun *R, hipStream_t s, long un
   const int W = R->W, ch = c->B.channels, n2 = c->B.xf[W].n / 2;
   const ChMap &cm = c->B.chmap[W];
   const long res_team_max = c->K.res_team_max;
-  for (int sm = 0; sm < cm.submaps; sm++)
+  for (int sm = 0; sm < cm.submaps; sm++) {
+    const ResP &Rs = c->B.res[W][sm];
+    // round 6: a stereo type-2 residue whose vectors tile runs of eight values is searched out of registers, a lane per
+    // run, a wave per block (k_residue_chunks: persistent waves)
+    const int chunks = Rs.chunked && !c->K.res_in_lds && ((uintptr_t)iwork & 15) == 0 && (n2 & 3) == 0
+                           ? Rs.partvals * (Rs.tab_grouping >> 3) : 0;
+    if (chunks > 0) {
+      const size_t per_wave = (size_t)((Rs.partvals + Rs.nstages * Rs.partvals + 1 + 3) & ~3);
+      const size_t lds = ((size_t)Rs.fast_ints + VAMD_RESC_WAVES * per_wave) * 4;
+      const long want = (units + VAMD_RESC_WAVES - 1) / VAMD_RESC_WAVES, fill = (long)c->num_cus * (32 / VAMD_RESC_WAVES);
+      const unsigned grid = (unsigned)(want < fill ? want : fill);
+      hipLaunchKernelGGL(k_residue_chunks, dim3(grid), dim3(64 * VAMD_RESC_WAVES), lds, s, Rs, cm, sm, c->B.res_cap[W], nblobs, R->d, ch,
+                         n2, units, iwork, nonzero, rb.cls, rb.entries, rb.count, packets ? rb.books : nullptr);
+      continue;
+    }
     // a stereo bundle's search keeps two waves busy, the five-channel bundle of the 5.1 layout four; a handful of units
     // takes four either way (nothing else wants the CU, and a lone unit's latency is the caller's)
     hipLaunchKernelGGL(k_residue, dim3((unsigned)units), dim3(64 * (c->B.res[W][sm].bundle * n2 > 4096 || units <= res_team_max ? VAMD_RES_WAVES : 2)),
                        (size_t)c->B.res[W][sm].lds_ints * 4, s, c->B.res[W][sm], cm, sm,
                        c->B.res_cap[W], nblobs, R->d, ch, n2, iwork, nonzero, rb.cls, rb.entries, rb.count, packets ? rb.books : nullptr);
+  }
   prof_mark(c, VAMD_ST_RESIDUE);
   if (packets) {
     const size_t lds = ((size_t)VAMD_PK_RING + VAMD_POSTS_STRIDE + VAMD_RES_CLASS_STRIDE + 2 * (size_t)c->B.res_off_ints[W] +

@@ -911,6 +911,43 @@ __global__ __launch_bounds__(64 * VAMD_RES_WAVES) void k_residue(ResP R, ChMap c
   pc.flush();
 }
 
+// The same stage for a stereo type-2 residue whose vectors tile runs of eight values (ResP::chunked): persistent waves, a
+// unit each at a time, the search out of registers (residue_wave_chunks, k_residue.h).  LDS: the search's tables once
+// per workgroup, then per wave cls [partvals] and off [stages * partvals + 1].
+#define VAMD_RESC_WAVES 4
+__global__ __launch_bounds__(64 * VAMD_RESC_WAVES, 8) void k_residue_chunks(ResP R, ChMap cm, int sm, int ent_row, int nblobs, DescP d, int ch, int n2,
+                                                       long units, const int *__restrict__ iwork, const int *__restrict__ nonzero,
+                                                       int *__restrict__ res_class, unsigned short *__restrict__ res_entries,
+                                                       int *__restrict__ res_count, unsigned char *__restrict__ res_books) {
+  int *tab = (int *)vamd_smem;
+  for (int i = threadIdx.x; i < (R.fast_ints >> 2); i += blockDim.x) ((I4 *)tab)[i] = ((const I4 *)R.fast)[i];
+  __syncthreads();
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int per_wave = (R.partvals + R.nstages * R.partvals + 1 + 3) & ~3;
+  int *cls = tab + R.fast_ints + wave * per_wave, *off = cls + R.partvals;
+  int c0 = -1, c1 = -1;  // the bundle's two channels
+  for (int c = 0; c < ch; c++)
+    if (cm.sub[c] == sm) {
+      if (c0 < 0) c0 = c;
+      else if (c1 < 0) c1 = c;
+    }
+  PhaseClock pc;
+  pc.start(d.dbg ? d.dbg + 72 : nullptr);
+  for (long u = (long)blockIdx.x * VAMD_RESC_WAVES + wave; u < units; u += (long)gridDim.x * VAMD_RESC_WAVES) {
+    const int nz = nonzero[u * ch + c0] | nonzero[u * ch + c1];
+    const unsigned over = residue_wave_chunks(R, iwork + (u * ch + c0) * n2, iwork + (u * ch + c1) * n2, nz, tab, cls, off,
+                                                      res_class + u * (cm.submaps * VAMD_RES_CLASS_STRIDE) + R.cls_base,
+                                                      res_entries + u * (long)ent_row + R.ent_base, res_count + (u * cm.submaps + sm) * 2, pc,
+                                                      res_books ? res_books + u * (long)ent_row + R.ent_base : nullptr);
+    // the input domain's integer edge, the search's half (k_residue.h)
+    const long blk = u / nblobs;
+    const int any0 = wave_any((int)(over & 1u)), any1 = wave_any((int)(over & 2u));
+    if (LANE == 0 && any0) flag_range(d, blk * ch + c0);
+    if (LANE == 0 && any1) flag_range(d, blk * ch + c1);
+  }
+  pc.flush();
+}
+
 // stage 7 (optional): packet assembly, one wave per packet (k_pack.h).  unit = block * nblobs + candidate
 __global__ __launch_bounds__(64) void k_pack(PackP K, FloorP F0, FloorP F1, ResP R0, ResP R1, ChMap cm, int ent_row, int lds_ints,
                                              DescP d, int ch, int W, int nblobs, const int *__restrict__ posts,

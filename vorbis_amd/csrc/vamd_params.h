@@ -81,6 +81,16 @@ struct EnvP {
 };
 
 // residue back-end of one mode and submap: tables stay in the HBM image
+// one (class, stage) of a residue as residue_block_chunks wants it: the book and what local_book_besterror reads of it
+struct ResStage {
+  int32_t bn;           // book number, -1: the class has no book at this stage
+  int32_t dim, minval, delta, quantvals;
+  int32_t off_lengths;  // the book's codeword lengths, relative to the image
+  int32_t full;         // every entry populated (no exhaustive search, the lengths are not looked at)
+  int32_t nv;           // vectors of a partition: grouping / dim
+  int32_t entries;
+  int32_t pad[3];
+};
 struct ResP {
   const vamd_residue_tab *tab;
   const vamd_book_tab *books;
@@ -93,6 +103,11 @@ struct ResP {
   int cls_base, ent_base;     // where this submap's rows start inside a block's res_class / res_entries rows
   int lds_ints;               // LDS ints k_residue needs for this submap
   int qmax;                   // largest |value| in [begin, end) for which the search's integers are defined (derive_quant_limit)
+  int chunked;                // 1: a stereo type-2 residue whose vectors tile runs of eight values (residue_block_chunks, k_residue.h)
+  int tab_grouping;           // tab->grouping, for the host (tab points into the HBM image)
+  int begin, nparts, nstages; // tab->begin / partitions / stages, as kernel arguments
+  const int *fast;            // classmetric1 [partitions], classmetric2 [partitions] (padded to 4), ResStage [partitions][stages] (vamd_bind.h)
+  int fast_ints;
 };
 
 // packet assembly (k_pack.h): the floor's class tables and the codebooks' codewords, in the HBM image
