@@ -225,18 +225,42 @@ VAMD_DEV void pack_floor(const PackP &K, PackTabs &T, int sm, const FloorP &F, c
 //   res_class / res_entries / res_count: what residue_block left for this submap (k_residue.h)
 //   cls LDS [slots]; off LDS [stages*slots + 1]; info LDS [stages*slots]
 //   res_books: the book of every entry as residue_block left it, or null (then it is searched for here)
+//   rtab: R.fast as the caller holds it in LDS (k_pack_waves), or null: the (class, stage) rows then come from the image
 VAMD_DEV void pack_residue(const PackP &K, const PackTabs &T, const ResP &R, const int *__restrict__ res_class,
                            const unsigned short *__restrict__ res_entries, const unsigned char *__restrict__ res_books,
-                           const int *__restrict__ res_count, int *cls, int *off, int *info, BitRing &r, PhaseClock &pc) {
+                           const int *__restrict__ res_count, int *cls, int *off, int *info, BitRing &r, PhaseClock &pc,
+                           const int *rtab = nullptr) {
   const vamd_residue_tab &t = *R.tab;
   const int slots = res_count[0];
   if (slots <= 0) return;  // nothing to code: res*_forward writes nothing
   const int partvals = R.partvals, ns = slots / partvals;  // streams: 1 (type 2) or the coded channels (type 1)
   WAVE_FOR(i, slots) cls[i] = res_class[i];
   WAVE_SYNC();
-  residue_offsets<true>(R, slots, cls, off, info);  // (one wave: k_pack's only one, k_pack_pair's first)
+  if (rtab) {
+    // residue_offsets out of the LDS copy of the rows: no trip to the image per (stage, slot)
+    const ResStage *rows = (const ResStage *)(rtab + ((2 * R.nparts + 3) & ~3));
+    const int stages = R.nstages, items = stages * slots;
+    int carry = 0;
+    for (int base = 0; base < items; base += NLANES) {
+      const int it = base + LANE;
+      int c = 0;
+      if (it < items) {
+        const int s = it / slots, i = it - s * slots;
+        const ResStage &st = rows[cls[i] * stages + s];
+        info[it] = st.bn;
+        c = st.bn >= 0 ? st.nv : 0;
+      }
+      const int incl = wave_scan_sum(c);
+      if (it < items) off[it] = carry + incl - c;
+      carry += wave_last(incl);
+    }
+    if (LANE == 0) off[items] = carry;
+    WAVE_SYNC();
+  } else {
+    residue_offsets<true>(R, slots, cls, off, info);  // (one wave: k_pack's only one, k_pack_pair's first)
+  }
   pc.mark(3);
-  const int ppw = t.groupbook_dim;
+  const int ppw = R.groupbook_dim;
   {
     // stage 0 also carries the phrase words: one per stream ahead of every group of ppw partitions
     const int *so = off;
@@ -261,10 +285,10 @@ VAMD_DEV void pack_residue(const PackP &K, const PackTabs &T, const ResP &R, con
         if (leads && k < ns) {  // stream k's classes of the group as one number, lib/res0.c:589-598
           int val = cls[i * ns + k];
           for (int p = 1; p < ppw; p++) {
-            val *= t.partitions;
+            val *= R.nparts;
             if (i + p < partvals) val += cls[(i + p) * ns + k];
           }
-          book_word(K, T, t.groupbook, val, code, len);
+          book_word(K, T, R.groupbook, val, code, len);
         } else {
           if (leads) k -= ns;
           const int e = so[q] + k;
@@ -281,7 +305,7 @@ VAMD_DEV void pack_residue(const PackP &K, const PackTabs &T, const ResP &R, con
     // seven).  Its book comes with it (res_books) -- or is that of the last (stage, slot) pair beginning at or before
     // it, a binary search of nine dependent LDS reads per field: a long block has some two thousand of them.  With the
     // book at hand a lane takes VAMD_PK_NF fields a trip, their lookups all in flight together.
-    const int first = slots, last = t.stages * slots, base = off[first], total = off[last] - base;
+    const int first = slots, last = R.nstages * slots, base = off[first], total = off[last] - base;
     for (int v0 = 0; v0 < total; v0 += NLANES * VAMD_PK_NF) {
       unsigned code[VAMD_PK_NF];
       int len[VAMD_PK_NF], entry[VAMD_PK_NF], book[VAMD_PK_NF];
@@ -314,23 +338,13 @@ VAMD_DEV void pack_residue(const PackP &K, const PackTabs &T, const ResP &R, con
   }
 }
 
-// One packet: header, the channels' floors, the submaps' residues.
-//   posts [ch][VAMD_POSTS_STRIDE], post_valid [ch]  as floor_encode_render left them
-//   res_class [submaps][VAMD_RES_CLASS_STRIDE], res_entries [row], res_count [submaps][2]: one block's rows;
-//   res_books [row] or null (pack_residue)
-//   packet HBM [out_words] words; bits_out <- oggpack_bits()
-//   wrapped [ch][VAMD_POSTS_STRIDE] or null: see pack_floor
-//   LDS: ring [VAMD_PK_RING] zeroed here, outv [VAMD_POSTS_STRIDE], cls/off/info as pack_residue,
-//        tabs [VAMD_PK_FTAB_INTS + 3 * K.nbooks] (PackTabs)
-VAMD_DEV void pack_block(const PackP &K, const FloorP &F0, const FloorP &F1, const ResP &R0, const ResP &R1, const ChMap &cm,
-                         int ch, int W, int lW, int nW, const int *__restrict__ posts, const int *__restrict__ wrapped,
-                         const int *__restrict__ post_valid, const int *__restrict__ res_class, const unsigned short *__restrict__ res_entries,
-                         const unsigned char *__restrict__ res_books, const int *__restrict__ res_count, int *ring, int *outv, int *cls, int *off, int *info, int *tabs,
-                         unsigned *__restrict__ packet, int out_words, int *__restrict__ bits_out, PhaseClock &pc) {
-  WAVE_FOR(i, VAMD_PK_RING) ring[i] = 0;
-  PackTabs T;
-  T.at(tabs);
-  pack_book_table(K, T);  // (ends with a WAVE_SYNC)
+// The packet itself, the ring zeroed and the tables in place (pack_block below; k_pack_waves, whose waves keep both across
+// packets).  rtab: see pack_residue.
+VAMD_DEV void pack_block_body(const PackP &K, PackTabs &T, const FloorP &F0, const FloorP &F1, const ResP &R0, const ResP &R1, const ChMap &cm,
+                              int ch, int W, int lW, int nW, const int *__restrict__ posts, const int *__restrict__ wrapped,
+                              const int *__restrict__ post_valid, const int *__restrict__ res_class, const unsigned short *__restrict__ res_entries,
+                              const unsigned char *__restrict__ res_books, const int *__restrict__ res_count, int *ring, int *outv, int *cls, int *off, int *info,
+                              unsigned *__restrict__ packet, int out_words, int *__restrict__ bits_out, PhaseClock &pc, const int *rtab) {
   BitRing r;
   r.ring = ring;
   r.out = packet;
@@ -355,11 +369,32 @@ VAMD_DEV void pack_block(const PackP &K, const FloorP &F0, const FloorP &F1, con
   for (int sm = 0; sm < cm.submaps; sm++) {
     const ResP &R = sm ? R1 : R0;
     pack_residue(K, T, R, res_class + R.cls_base, res_entries + R.ent_base, res_books ? res_books + R.ent_base : nullptr,
-                 res_count + 2 * sm, cls, off, info, r, pc);
+                 res_count + 2 * sm, cls, off, info, r, pc, sm == 0 ? rtab : nullptr);
   }
   ring_flush(r, (r.bitpos + 31) >> 5);
   if (LANE == 0) *bits_out = (int)r.bitpos;
   pc.mark(6);
+}
+
+// One packet: header, the channels' floors, the submaps' residues.
+//   posts [ch][VAMD_POSTS_STRIDE], post_valid [ch]  as floor_encode_render left them
+//   res_class [submaps][VAMD_RES_CLASS_STRIDE], res_entries [row], res_count [submaps][2]: one block's rows;
+//   res_books [row] or null (pack_residue)
+//   packet HBM [out_words] words; bits_out <- oggpack_bits()
+//   wrapped [ch][VAMD_POSTS_STRIDE] or null: see pack_floor
+//   LDS: ring [VAMD_PK_RING] zeroed here, outv [VAMD_POSTS_STRIDE], cls/off/info as pack_residue,
+//        tabs [VAMD_PK_FTAB_INTS + 3 * K.nbooks] (PackTabs)
+VAMD_DEV void pack_block(const PackP &K, const FloorP &F0, const FloorP &F1, const ResP &R0, const ResP &R1, const ChMap &cm,
+                         int ch, int W, int lW, int nW, const int *__restrict__ posts, const int *__restrict__ wrapped,
+                         const int *__restrict__ post_valid, const int *__restrict__ res_class, const unsigned short *__restrict__ res_entries,
+                         const unsigned char *__restrict__ res_books, const int *__restrict__ res_count, int *ring, int *outv, int *cls, int *off, int *info, int *tabs,
+                         unsigned *__restrict__ packet, int out_words, int *__restrict__ bits_out, PhaseClock &pc) {
+  WAVE_FOR(i, VAMD_PK_RING) ring[i] = 0;
+  PackTabs T;
+  T.at(tabs);
+  pack_book_table(K, T);  // (ends with a WAVE_SYNC)
+  pack_block_body(K, T, F0, F1, R0, R1, cm, ch, W, lW, nW, posts, wrapped, post_valid, res_class, res_entries, res_books, res_count, ring,
+                  outv, cls, off, info, packet, out_words, bits_out, pc, nullptr);
 }
 
 }  // namespace vamd

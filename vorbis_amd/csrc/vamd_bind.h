@@ -735,6 +735,7 @@ inline void bind_params(const std::vector<unsigned char> &image, const std::vect
       Rp.chunked = ok && tiles8 ? 1 : 0;
       Rp.tab_grouping = r.grouping;
       Rp.begin = r.begin, Rp.nparts = r.partitions, Rp.nstages = r.stages;
+      Rp.groupbook = r.groupbook, Rp.groupbook_dim = r.groupbook_dim;
       Rp.fast = (const int *)(base + derived_off[39 + 2 * W + sm]);
       Rp.fast_ints = ((2 * r.partitions + 3) & ~3) + r.partitions * r.stages * (int)(sizeof(ResStage) / 4);
       if (sm < m.submaps) {

@@ -505,7 +505,12 @@ static void launch_residue_pack(vamd_ctx *c, BatchRun *R, hipStream_t s, long un
     if (chunks > 0) {
       const size_t per_wave = (size_t)((Rs.partvals + Rs.nstages * Rs.partvals + 1 + 3) & ~3);
       const size_t lds = ((size_t)Rs.fast_ints + VAMD_RESC_WAVES * per_wave) * 4;
-      const long want = (units + VAMD_RESC_WAVES - 1) / VAMD_RESC_WAVES, fill = (long)c->num_cus * (32 / VAMD_RESC_WAVES);
+      int resident = 0;  // (persistent: as many workgroups as are resident at once)
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, (const void *)k_residue_chunks, 64 * VAMD_RESC_WAVES, lds) != hipSuccess || resident < 1) {
+        (void)hipGetLastError();
+        resident = 1;
+      }
+      const long want = (units + VAMD_RESC_WAVES - 1) / VAMD_RESC_WAVES, fill = (long)c->num_cus * resident;
       const unsigned grid = (unsigned)(want < fill ? want : fill);
       hipLaunchKernelGGL(k_residue_chunks, dim3(grid), dim3(64 * VAMD_RESC_WAVES), lds, s, Rs, cm, sm, c->B.res_cap[W], nblobs, R->d, ch,
                          n2, units, iwork, nonzero, rb.cls, rb.entries, rb.count, packets ? rb.books : nullptr);
@@ -529,7 +534,24 @@ static void launch_residue_pack(vamd_ctx *c, BatchRun *R, hipStream_t s, long un
                          c->B.floor[W][0], c->B.floor[W][1], c->B.res[W][0], c->B.res[W][1], cm, c->B.res_cap[W], c->B.res_off_ints[W],
                          R->d, ch, W, nblobs, posts, wrapped, post_valid, rb.cls, rb.entries, rb.books, rb.count, (unsigned *)packets,
                          (int)(packet_stride / 4), packet_bits);
-    else
+    else if (cm.submaps == 1 && units >= 4 * (long)c->num_cus && !c->K.pack_per_packet) {
+      // a batch of a one-submap mode: persistent waves over the packets, the tables staged once per workgroup (k_pack_waves)
+      const ResP &R0 = c->B.res[W][0];
+      const int per_wave_ints = (R0.slots + 2 * R0.nstages * R0.slots + 1 + 3) & ~3;
+      const size_t ldsw = ((size_t)((VAMD_PK_FTAB_INTS + 3 * c->B.pack[W].nbooks + 3) & ~3) + (size_t)R0.fast_ints +
+                           (size_t)VAMD_PKW_WAVES * ((size_t)VAMD_PK_RING + VAMD_POSTS_STRIDE + per_wave_ints)) * 4;
+      // (persistent: as many workgroups as are resident at once -- registers, not LDS, set that here)
+      int resident = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, (const void *)k_pack_waves, 64 * VAMD_PKW_WAVES, ldsw) != hipSuccess || resident < 1) {
+        (void)hipGetLastError();
+        resident = 1;
+      }
+      const long per_cu = resident;
+      const long want = (units + VAMD_PKW_WAVES - 1) / VAMD_PKW_WAVES, fill = per_cu * c->num_cus;
+      hipLaunchKernelGGL(k_pack_waves, dim3((unsigned)(want < fill ? want : fill)), dim3(64 * VAMD_PKW_WAVES), ldsw, s, c->B.pack[W],
+                         c->B.floor[W][0], R0, cm, c->B.res_cap[W], per_wave_ints, R->d, ch, W, nblobs, units, posts, wrapped, post_valid,
+                         rb.cls, rb.entries, rb.books, rb.count, (unsigned *)packets, (int)(packet_stride / 4), packet_bits);
+    } else
     hipLaunchKernelGGL(k_pack, dim3((unsigned)units), dim3(64), lds, s, c->B.pack[W], c->B.floor[W][0], c->B.floor[W][1],
                        c->B.res[W][0], c->B.res[W][1], cm, c->B.res_cap[W], c->B.res_off_ints[W], R->d, ch, W, nblobs, posts,
                        wrapped, post_valid, rb.cls, rb.entries, rb.books, rb.count, (unsigned *)packets, (int)(packet_stride / 4), packet_bits);

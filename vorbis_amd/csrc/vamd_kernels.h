@@ -974,6 +974,53 @@ __global__ __launch_bounds__(64) void k_pack(PackP K, FloorP F0, FloorP F1, ResP
   pc.flush();
 }
 
+// The same for a batch of a mode with ONE submap (mono, stereo): persistent waves, a packet each at a time.  k_pack sets a
+// packet's tables up per packet -- the books' sizes and offsets, the floor's class tables, the residue's (class, stage)
+// rows: 14 k of a packet's 64 k cycles, and its 9.4 KB of LDS hold a CU to seventeen one-wave workgroups.  Here a
+// workgroup's four waves share one copy made once, every wave keeps its own ring (all zero between packets: ring_flush
+// hands the slots back) and offsets arrays, and the emission offsets come out of the LDS rows (pack_residue's rtab).
+//   lds_ints: ints of cls + off + info per wave (slots + 2 * stages * slots + 1, rounded up to 4)
+#define VAMD_PKW_WAVES 4
+__global__ __launch_bounds__(64 * VAMD_PKW_WAVES) void k_pack_waves(PackP K, FloorP F0, ResP R0, ChMap cm, int ent_row, int lds_ints,
+                                                                  DescP d, int ch, int W, int nblobs, long units,
+                                                                  const int *__restrict__ posts, const int *__restrict__ wrapped,
+                                                                  const int *__restrict__ post_valid, const int *__restrict__ res_class,
+                                                                  const unsigned short *__restrict__ res_entries,
+                                                                  const unsigned char *__restrict__ res_books,
+                                                                  const int *__restrict__ res_count, unsigned *__restrict__ packets,
+                                                                  int stride_words, int *__restrict__ packet_bits) {
+  int *tabs = (int *)vamd_smem;                          // [VAMD_PK_FTAB_INTS + 3 * nbooks], PackTabs
+  int *rtab = tabs + ((VAMD_PK_FTAB_INTS + 3 * K.nbooks + 3) & ~3);  // [R0.fast_ints]
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  int *mine = rtab + R0.fast_ints + wave * (VAMD_PK_RING + VAMD_POSTS_STRIDE + lds_ints);
+  int *ring = mine;                                      // [VAMD_PK_RING]
+  int *outv = ring + VAMD_PK_RING;                       // [VAMD_POSTS_STRIDE]
+  int *cls = outv + VAMD_POSTS_STRIDE;                   // [slots], then off [stages*slots + 1], info [stages*slots]
+  int *off = cls + R0.slots;
+  int *info = off + R0.nstages * R0.slots + 1;
+  PackTabs T;
+  T.at(tabs);
+  for (int i = threadIdx.x; i < (R0.fast_ints >> 2); i += blockDim.x) ((I4 *)rtab)[i] = ((const I4 *)R0.fast)[i];
+  WAVE_FOR(i, VAMD_PK_RING) ring[i] = 0;
+  if (wave == 0) {
+    pack_book_table(K, T);
+    pack_floor_table(*K.ftab[0], 0, T);
+  }
+  __syncthreads();
+  T.floor_of = 0;  // (every wave: the shared copy holds submap 0's floor)
+  PhaseClock pc;
+  pc.start(d.dbg ? d.dbg + 72 : nullptr);
+  for (long u = (long)blockIdx.x * VAMD_PKW_WAVES + wave; u < units; u += (long)gridDim.x * VAMD_PKW_WAVES) {
+    const long blk = u / nblobs;
+    pack_block_body(K, T, F0, F0, R0, R0, cm, ch, W, d_lW(d, blk), d_nW(d, blk), posts + u * ch * VAMD_POSTS_STRIDE,
+                    wrapped ? wrapped + u * ch * VAMD_POSTS_STRIDE : nullptr, post_valid + u * ch,
+                    res_class + u * (cm.submaps * VAMD_RES_CLASS_STRIDE), res_entries + u * (long)ent_row,
+                    res_books ? res_books + u * (long)ent_row : nullptr, res_count + u * cm.submaps * 2, ring, outv, cls, off, info,
+                    packets + u * (long)stride_words, stride_words, packet_bits + u, pc, rtab);
+  }
+  pc.flush();
+}
+
 // The same for a handful of packets, TWO waves each: the header + floors part and the residue part of a packet are
 // looked up and packed at the same time -- wave 1 writes the former where it belongs; wave 0 assembles the latter
 // K.head_words into the row, past the longest head there can be, and when both are done the two waves move it down to

@@ -29,6 +29,7 @@ struct Knobs {
   long res_team_max = 2048;      // VAMD_RES_TEAM_MAX: units up to which the residue search takes four waves a unit
   bool res_in_lds = false;       // VAMD_RES_IN_LDS: the residue search through the work vector in LDS where runs of eight in registers would do
   long pack_pair_max = 2048;     // VAMD_PACK_PAIR_MAX: units up to which a packet is assembled by two waves
+  bool pack_per_packet = false;  // VAMD_PACK_PER_PACKET: a workgroup (and its tables) per packet at every batch size (k_pack, not k_pack_waves)
   bool fold_separate = false;    // VAMD_FOLD_SEPARATE: the tone fold as a launch of its own, not inside k_floor
   long chase_wave_max = 32768;   // VAMD_CHASE_WAVE_MAX: channel-blocks up to which the stack walk takes a wave a block
   bool masks_separate = false;   // VAMD_MASKS_SEPARATE: never both masks in one launch
@@ -64,6 +65,7 @@ inline Knobs read_knobs() {
       k.res_team_max = num("VAMD_RES_TEAM_MAX", k.res_team_max);
       k.res_in_lds = on("VAMD_RES_IN_LDS");
       k.pack_pair_max = num("VAMD_PACK_PAIR_MAX", k.pack_pair_max);
+      k.pack_per_packet = on("VAMD_PACK_PER_PACKET");
       k.fold_separate = on("VAMD_FOLD_SEPARATE");
       k.chase_wave_max = num("VAMD_CHASE_WAVE_MAX", k.chase_wave_max);
       k.masks_separate = on("VAMD_MASKS_SEPARATE");
@@ -89,12 +91,12 @@ inline void knobs_string(const Knobs &k, char *buf, size_t cap) {
                    (int)k.verbose, k.batch_lanes, k.batch_eager, k.batch_join, k.batch_spin_below, (int)k.test);
   if (k.test && n > 0 && (size_t)n < cap)
     snprintf(buf + n, cap - (size_t)n,
-             " VAMD_NO_OVERLAP=%d VAMD_COUPLE_BAND_LOG2=%s%d VAMD_XF_WAVES_CAP=%d VAMD_RES_TEAM_MAX=%ld VAMD_RES_IN_LDS=%d VAMD_PACK_PAIR_MAX=%ld"
+             " VAMD_NO_OVERLAP=%d VAMD_COUPLE_BAND_LOG2=%s%d VAMD_XF_WAVES_CAP=%d VAMD_RES_TEAM_MAX=%ld VAMD_RES_IN_LDS=%d VAMD_PACK_PAIR_MAX=%ld VAMD_PACK_PER_PACKET=%d"
              " VAMD_FOLD_SEPARATE=%d VAMD_CHASE_WAVE_MAX=%ld VAMD_MASKS_SEPARATE=%d VAMD_NOISE_TEAMS=%d VAMD_NOISE_WAVES=%d VAMD_FLOOR_LDS_PAD=%ld"
              " VAMD_FLOOR_PAIR_MIN=%ld VAMD_FLOOR_PAIR_W=%d VAMD_STAGE_COPIES=%d VAMD_ENV_UNTILED=%d VAMD_XF_VARIANT=%d VAMD_FAIL_ENVELOPE_AFTER=%ld"
              " VAMD_FAIL_ENCODE_AFTER=%ld",
              (int)k.no_overlap, k.couple_band_set ? "" : "unset:", k.couple_band_log2, k.xf_waves_cap, k.res_team_max, (int)k.res_in_lds,
-             k.pack_pair_max, (int)k.fold_separate, k.chase_wave_max, (int)k.masks_separate, k.noise_teams, k.noise_waves, k.floor_lds_pad,
+             k.pack_pair_max, (int)k.pack_per_packet, (int)k.fold_separate, k.chase_wave_max, (int)k.masks_separate, k.noise_teams, k.noise_waves, k.floor_lds_pad,
              k.floor_pair_min, k.floor_pair_w, (int)k.stage_copies, (int)k.env_untiled, k.xf_variant, k.fail_envelope_after,
              k.fail_encode_after);
 }

@@ -106,6 +106,7 @@ struct ResP {
   int chunked;                // 1: a stereo type-2 residue whose vectors tile runs of eight values (residue_block_chunks, k_residue.h)
   int tab_grouping;           // tab->grouping, for the host (tab points into the HBM image)
   int begin, nparts, nstages; // tab->begin / partitions / stages, as kernel arguments
+  int groupbook, groupbook_dim;  // tab->groupbook / groupbook_dim
   const int *fast;            // classmetric1 [partitions], classmetric2 [partitions] (padded to 4), ResStage [partitions][stages] (vamd_bind.h)
   int fast_ints;
 };
