@@ -78,7 +78,9 @@ VAMD_DEV void env_spectrum_wave(const EnvP &E, const float *__restrict__ pcm, in
     A[k] = t < count ? pcm[t * E.searchstep + i] * E.win[i] : 0.f;
   }
   WAVE_SYNC();
+  pc.mark(0);
   mdct_forward_wave<LOGS, ln>(E.mdct, A, Wk, spec, pc, n, n2 + VAMD_PW_SIZE(n2), n2);
+  pc.mark(5);
   WAVE_FOR(t, count) {
     // float temp=vec[0]*vec[0]+.7*vec[1]*vec[1]+.2*vec[2]*vec[2];  the literals make it fp64
     const float v0 = spec[t * n2], v1 = spec[t * n2 + 1], v2 = spec[t * n2 + 2];
@@ -97,6 +99,7 @@ VAMD_DEV void env_spectrum_wave(const EnvP &E, const float *__restrict__ pcm, in
   }
   if (bad && wave_any(top > VAMD_ENV_LIMIT_DB) && LANE == 0) lds_or_global_count(bad);
   WAVE_SYNC();
+  pc.mark(6);
 }
 
 // `decay` as _ve_amp leaves it at lib/envelope.c:143 for global step J.

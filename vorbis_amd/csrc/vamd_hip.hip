@@ -1424,11 +1424,12 @@ static int envelope_search_batch(vamd_ctx *c, const float *pcm, long stream_stri
   }
   {
     const long items = nsc * ((nsteps + VAMD_ENV_STEPS - 1) / VAMD_ENV_STEPS);
+    if (items > 0x7fffffffL) return fail(c, VAMD_EINVAL, "detector: more than 2^31 groups of steps in one call");
     const long groups = (items + VAMD_ENV_WAVES - 1) / VAMD_ENV_WAVES;
     const long cap = (long)c->num_cus * 8;
     const size_t lds = (size_t)VAMD_ENV_WAVES * VAMD_ENV_STEPS * (n + n2 + VAMD_PW_SIZE(n2) + n2) * 4;
     hipLaunchKernelGGL(k_env_spectrum, dim3((unsigned)(groups < cap ? groups : cap)), dim3(64 * VAMD_ENV_WAVES), lds, s, E,
-                       ch, nstreams, nsteps, pcm, stream_stride, channel_stride, near, raw, bad, first_of);
+                       ch, nstreams, nsteps, pcm, stream_stride, channel_stride, near, raw, bad, first_of, c->d_dbg);
   }
   const bool env_untiled = c->K.env_untiled;  // (measurement aid: the thread-per-item forms)
   const bool big = nstreams * nsteps > 65536 && !env_untiled;

@@ -1155,20 +1155,23 @@ __global__ __launch_bounds__(64 * VAMD_ENV_WAVES) __attribute__((amdgpu_waves_pe
                                                                       const float *__restrict__ pcm, long stream_stride,
                                                                       long channel_stride, float *__restrict__ near,
                                                                       float *__restrict__ raw, unsigned int *bad,
-                                                                      const long long *__restrict__ first_of) {
-  const int n = E.mdct.n, n2 = n >> 1, wave = threadIdx.x >> 6;
+                                                                      const long long *__restrict__ first_of, unsigned long long *dbg) {
+  // (the wave number in a scalar register: an item's place -- stream, channel, first step -- is then scalar arithmetic)
+  const int n = E.mdct.n, n2 = n >> 1, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int per_step = n + n2 + VAMD_PW_SIZE(n2) + n2;
   float *A = (float *)vamd_smem + (size_t)wave * per_step * VAMD_ENV_STEPS;
   float *Wk = A + n * VAMD_ENV_STEPS, *spec = Wk + (n2 + VAMD_PW_SIZE(n2)) * VAMD_ENV_STEPS;
   PhaseClock pc;
-  pc.start(nullptr);
+  pc.start(dbg);  // (the transform's slot set: tools/env_profile.py)
   const long groups = (nsteps + VAMD_ENV_STEPS - 1) / VAMD_ENV_STEPS, items = nstreams * ch * groups;
   // an item's samples are requested while the previous item is in its transform (a wave lives for ~130 items and has
   // three neighbours on its SIMD: the trip to memory at the head of every item was a fifth of its time)
   auto where = [&](long it, long &sc, long &j, int &count) -> const float * {
-    sc = it / groups;
+    // (32-bit quotients: the launch checks items < 2^31 -- a 64-bit division by a run-time value is some eighty vector
+    // instructions, two of them per item were a third of the kernel's)
+    sc = (long)((unsigned)it / (unsigned)groups);
     j = (it - sc * groups) * VAMD_ENV_STEPS;
-    const long s = sc / ch;
+    const long s = (long)((unsigned)sc / (unsigned)ch);
     const int c = (int)(sc - s * ch);
     count = nsteps - j < VAMD_ENV_STEPS ? (int)(nsteps - j) : VAMD_ENV_STEPS;
     // (first_of: streams whose steps start at different samples -- the end-of-stream pass of streams of unequal length)
@@ -1196,6 +1199,7 @@ __global__ __launch_bounds__(64 * VAMD_ENV_WAVES) __attribute__((amdgpu_waves_pe
                                      raw + (sc * nsteps + j) * VAMD_VE_SPREAD, pc, bad, &cur);
     cur = nxt, sc = sc2, j = j2, count = count2, src = src2;
   }
+  pc.flush();
 }
 
 __global__ void k_env_amp(EnvP E, long nsc /* streams x channels */, long nsteps,
