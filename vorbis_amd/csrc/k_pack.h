@@ -23,15 +23,15 @@ struct BitRing {
   int *ring;          // LDS [VAMD_PK_RING], all zero between packets
   unsigned *out;      // HBM row of the packet
   int out_words;      // its length; words past it are counted but dropped
-  long bitpos;        // bits written so far (wave-uniform)
-  long flushed;       // words already in HBM
+  int bitpos;         // bits written so far (wave-uniform; a packet is far below 2^31 bits: K.capacity bytes)
+  int flushed;        // words already in HBM
 };
 
 // words [flushed, upto) are complete: move them out and hand their ring slots back
-VAMD_DEV void ring_flush(BitRing &r, long upto) {
+VAMD_DEV void ring_flush(BitRing &r, int upto) {
   WAVE_SYNC();
-  for (long w = r.flushed + LANE; w < upto; w += NLANES) {
-    const int slot = (int)(w & (VAMD_PK_RING - 1));
+  for (int w = r.flushed + LANE; w < upto; w += NLANES) {
+    const int slot = w & (VAMD_PK_RING - 1);
     const unsigned u = (unsigned)r.ring[slot];
     r.ring[slot] = 0;
     if (w < r.out_words) r.out[w] = u;
@@ -44,12 +44,12 @@ VAMD_DEV void ring_flush(BitRing &r, long upto) {
 VAMD_DEV void ring_put(BitRing &r, unsigned code, int len) {
   const int incl = wave_scan_sum(len);
   const int total = wave_last(incl);
-  const long start = r.bitpos + incl - len;
+  const int start = r.bitpos + incl - len;
   if (((r.bitpos + total + 31) >> 5) - r.flushed > VAMD_PK_RING) ring_flush(r, r.bitpos >> 5);
   if (len > 0) {
     if (len < 32) code &= (1u << len) - 1u;
-    const long w = start >> 5;
-    const int sh = (int)(start & 31);
+    const int w = start >> 5;
+    const int sh = start & 31;
     lds_atomic_or(r.ring + (w & (VAMD_PK_RING - 1)), (int)(code << sh));
     if (sh + len > 32) lds_atomic_or(r.ring + ((w + 1) & (VAMD_PK_RING - 1)), (int)(code >> (32 - sh)));
   }
@@ -88,15 +88,15 @@ VAMD_DEV void ring_putn(BitRing &r, const unsigned *code, const int *len) {
   for (int k = 0; k < VAMD_PK_NF; k++) mine += len[k];
   const int incl = wave_scan_sum(mine);
   const int total = wave_last(incl);
-  long start = r.bitpos + incl - mine;
+  int start = r.bitpos + incl - mine;
   if (((r.bitpos + total + 31) >> 5) - r.flushed > VAMD_PK_RING) ring_flush(r, r.bitpos >> 5);
 #pragma unroll
   for (int k = 0; k < VAMD_PK_NF; k++) {
     if (len[k] > 0) {
       unsigned c = code[k];
       if (len[k] < 32) c &= (1u << len[k]) - 1u;
-      const long w = start >> 5;
-      const int sh = (int)(start & 31);
+      const int w = start >> 5;
+      const int sh = start & 31;
       lds_atomic_or(r.ring + (w & (VAMD_PK_RING - 1)), (int)(c << sh));
       if (sh + len[k] > 32) lds_atomic_or(r.ring + ((w + 1) & (VAMD_PK_RING - 1)), (int)(c >> (32 - sh)));
     }
@@ -372,7 +372,7 @@ VAMD_DEV void pack_block_body(const PackP &K, PackTabs &T, const FloorP &F0, con
                  res_count + 2 * sm, cls, off, info, r, pc, sm == 0 ? rtab : nullptr);
   }
   ring_flush(r, (r.bitpos + 31) >> 5);
-  if (LANE == 0) *bits_out = (int)r.bitpos;
+  if (LANE == 0) *bits_out = r.bitpos;
   pc.mark(6);
 }
 

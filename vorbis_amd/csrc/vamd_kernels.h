@@ -981,7 +981,7 @@ __global__ __launch_bounds__(64) void k_pack(PackP K, FloorP F0, FloorP F1, ResP
 // hands the slots back) and offsets arrays, and the emission offsets come out of the LDS rows (pack_residue's rtab).
 //   lds_ints: ints of cls + off + info per wave (slots + 2 * stages * slots + 1, rounded up to 4)
 #define VAMD_PKW_WAVES 4
-__global__ __launch_bounds__(64 * VAMD_PKW_WAVES) void k_pack_waves(PackP K, FloorP F0, ResP R0, ChMap cm, int ent_row, int lds_ints,
+__global__ __launch_bounds__(64 * VAMD_PKW_WAVES, 6) void k_pack_waves(PackP K, FloorP F0, ResP R0, ChMap cm, int ent_row, int lds_ints,
                                                                   DescP d, int ch, int W, int nblobs, long units,
                                                                   const int *__restrict__ posts, const int *__restrict__ wrapped,
                                                                   const int *__restrict__ post_valid, const int *__restrict__ res_class,
