@@ -221,30 +221,32 @@ def test_gpu_short_rows_and_argument_errors():
 @pytest.mark.gpu
 @needs_ref
 def test_gpu_large_batch_takes_the_one_wave_kernels():
-    """Past 2048 units the packets are assembled by one wave each (k_pack) and the residue search runs two waves per
-    unit; below, by two waves (k_pack_pair) and four.  The same blocks both ways give the same rows, and a sample of
-    them is the reference's."""
+    """Past 2048 units the stereo residue is searched out of registers by a wave per unit (k_residue_chunks: runs of
+    eight values, partitions of 32 values on long blocks and of 16 on short ones) and the packets are assembled by
+    persistent waves (k_pack_waves); below, by four waves a unit through LDS (k_residue) and by two waves a packet
+    (k_pack_pair).  The same blocks both ways give the same rows, and a sample of them is the reference's."""
     import torch
     e = ref.RefEncoder(2, 44100, 0.4)
     an = vorbis_amd.Analyzer(e.pack_setup(), 0)
     rng = np.random.default_rng(99)
     nb = 2304
-    amp = np.array([0.5, 0.01, 1.0, 0.0, 0.9, 0.2, 0.05])[np.arange(nb) % 7, None, None]
-    pcm = ((rng.random((nb, 2, an.blocksizes[1]), dtype=np.float32) - 0.5) * 2 * amp).astype(np.float32)
-    dev = torch.from_numpy(pcm).cuda()
-    big = an.analyze(dev, W=1, lW=1, nW=1, blocktype=1, want=("packets", "packet_bits"))
-    torch.cuda.synchronize()
-    rows, bits = big["packets"].cpu().numpy(), big["packet_bits"].cpu().numpy()
-    for lo in range(0, nb, 768):
-        part = an.analyze(dev[lo:lo + 768], W=1, lW=1, nW=1, blocktype=1, want=("packets", "packet_bits"))
+    for W in (1, 0):
+        amp = np.array([0.5, 0.01, 1.0, 0.0, 0.9, 0.2, 0.05])[np.arange(nb) % 7, None, None]
+        pcm = ((rng.random((nb, 2, an.blocksizes[W]), dtype=np.float32) - 0.5) * 2 * amp).astype(np.float32)
+        dev = torch.from_numpy(pcm).cuda()
+        big = an.analyze(dev, W=W, lW=W, nW=W, blocktype=1 if W else 0, want=("packets", "packet_bits"))
         torch.cuda.synchronize()
-        prow, pbits = part["packets"].cpu().numpy(), part["packet_bits"].cpu().numpy()
-        assert np.array_equal(pbits, bits[lo:lo + 768])
-        for k in range(768):
-            assert vorbis_amd.packet_bytes(prow[k], pbits[k]) == vorbis_amd.packet_bytes(rows[lo + k], bits[lo + k]), lo + k
-    for k in rng.choice(nb, 24, replace=False):
-        a = e.tap_block(pcm[k], 1, 1, 1, 1)
-        assert vorbis_amd.packet_bytes(rows[k], bits[k]) == a["packet"], k
+        rows, bits = big["packets"].cpu().numpy(), big["packet_bits"].cpu().numpy()
+        for lo in range(0, nb, 768):
+            part = an.analyze(dev[lo:lo + 768], W=W, lW=W, nW=W, blocktype=1 if W else 0, want=("packets", "packet_bits"))
+            torch.cuda.synchronize()
+            prow, pbits = part["packets"].cpu().numpy(), part["packet_bits"].cpu().numpy()
+            assert np.array_equal(pbits, bits[lo:lo + 768])
+            for k in range(768):
+                assert vorbis_amd.packet_bytes(prow[k], pbits[k]) == vorbis_amd.packet_bytes(rows[lo + k], bits[lo + k]), (W, lo + k)
+        for k in rng.choice(nb, 24, replace=False):
+            a = e.tap_block(pcm[k], W, W, W, 1 if W else 0)
+            assert vorbis_amd.packet_bytes(rows[k], bits[k]) == a["packet"], (W, k)
 
 
 @pytest.mark.gpu

@@ -500,7 +500,8 @@ static void launch_residue_pack(vamd_ctx *c, BatchRun *R, hipStream_t s, long un
     const ResP &Rs = c->B.res[W][sm];
     // round 6: a stereo type-2 residue whose vectors tile runs of eight values is searched out of registers, a lane per
     // run, a wave per block (k_residue_chunks: persistent waves)
-    const int chunks = Rs.chunked && !c->K.res_in_lds && ((uintptr_t)iwork & 15) == 0 && (n2 & 3) == 0
+    // (a handful of units keeps four waves a unit: a lone block's search is 3 us shorter that way)
+    const int chunks = Rs.chunked && units > res_team_max && !c->K.res_in_lds && ((uintptr_t)iwork & 15) == 0 && (n2 & 3) == 0
                            ? Rs.partvals * (Rs.tab_grouping >> 3) : 0;
     if (chunks > 0) {
       const size_t per_wave = (size_t)((Rs.partvals + Rs.nstages * Rs.partvals + 1 + 3) & ~3);
