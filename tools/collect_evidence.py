@@ -30,6 +30,8 @@ stamp(os.path.join(E, "alt_paths.txt"), "alt_paths.txt", "the GPU suite with eve
 stamp(os.path.join(E, "host_fed.txt"), "host_fed.txt", "the host-fed farm (vamd_feed): streams per group x lanes x groups [x GPU_MAX_HW_QUEUES]; 131072-frame stereo streams, s16 from pinned host memory in, packets in host memory out: tools/hf_sweep.sh")
 stamp(os.path.join(E, "host_fed_kernel_trace_stats.txt"), "host_fed_kernel_trace_stats.txt", "rocprofv3 --kernel-trace --stats -- python bench.py --host-fed-only c4 --feed-streams 512 --feed-lanes 5 --feed-groups 30 (GPU_MAX_HW_QUEUES=8); durations of kernels of five groups in flight overlap")
 stamp(os.path.join(E, "encode_loop.txt"), "encode_loop.txt", "integration/encode_loop.c (the call sequence of examples/encoder_example.c:140-236, 60 s of stereo 16-bit noise) on build/dropin/ref (write) and on the drop-in (check): READ, quality, blocks/s")
+stamp(os.path.join(E, "res_pack.txt"), "res_pack.txt", "the residue search and the packet assembly of 65 536 stereo long blocks (k_residue_chunks, k_pack_waves): tools/res_profile.py (stage ms per batch by HIP events, phase stopwatch), the road not taken beside it, then tools/pmc_res.sh (counters per wave: k_residue_chunks' waves take 8 blocks each, k_pack_waves' 10.7; FETCH_SIZE / WRITE_SIZE in counted KiB per wave, FETCH x 2 = bytes on gfx950)")
+stamp(os.path.join(E, "env_phases_run.txt"), "env_phases_run.txt", "tools/env_profile.py")
 stamp(os.path.join(E, "pytest_gpu.txt"), "pytest_gpu.txt", "python -m pytest tests -m gpu -q")
 soak = os.path.join(ROOT, "gpurun_out", "soak.txt")
 if os.path.exists(soak):

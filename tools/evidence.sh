@@ -23,6 +23,12 @@ timeout 300 python tools/gpu_block_phases.py >> $E/block_path.txt 2>/dev/null
 for k in "60 0.4 s16" "60 0.9 gated" "30 0.4 s16 128000"; do timeout 400 python tools/gpu_lookahead_bench.py $k >> $E/lookahead.txt 2>/dev/null; done
 timeout 600 python tools/soak_lookahead.py 60 $E/soak_lookahead.txt > /dev/null 2>&1
 timeout 900 bash tools/alt_paths.sh > $E/alt_paths.txt 2>&1
+# the residue search and the packet assembly of a batch (round 6: k_residue_chunks, k_pack_waves): stage times + phase stopwatch,
+# then their counters; the detector's spectrum kernel phase by phase
+{ timeout 300 python tools/res_profile.py 44k_stereo_q4 65536; echo "---- the same through the work vector in LDS and a workgroup per packet (VAMD_RES_IN_LDS, VAMD_PACK_PER_PACKET)";
+  VAMD_TEST_KNOBS=1 VAMD_RES_IN_LDS=1 VAMD_PACK_PER_PACKET=1 timeout 300 python tools/res_profile.py 44k_stereo_q4 65536; } > $E/res_pack.txt 2>/dev/null
+timeout 900 bash tools/pmc_res.sh >> $E/res_pack.txt 2>&1
+timeout 300 python tools/env_profile.py > $E/env_phases_run.txt 2>/dev/null
 # the host-fed farm (round 6): group size x lanes sweep, then a kernel trace of the default configuration
 HF_CFGS="256:3:60:8 256:5:60:8 512:3:60:8 512:5:100:8 512:5:100 1024:3:40:8" timeout 900 bash tools/hf_sweep.sh > $E/host_fed.txt 2>&1
 HF_KIND=c5 HF_CFGS="512:5:60:8" timeout 600 bash tools/hf_sweep.sh >> $E/host_fed.txt 2>&1
