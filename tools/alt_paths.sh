@@ -12,3 +12,4 @@ run VAMD_CHASE_WAVE_MAX=0 VAMD_NO_OVERLAP=1
 run VAMD_STAGE_COPIES=1 VAMD_FOLD_SEPARATE=1
 run VAMD_FLOOR_PAIR_MIN=0                    # two channels per wave in the floor stage at every size, both size classes
 run VAMD_FLOOR_PAIR_MIN=2000000000           # ... and never
+run VAMD_RES_IN_LDS=1 VAMD_PACK_PER_PACKET=1 VAMD_NOISE_WAVES=28   # round 6's batch kernels (k_residue_chunks, k_pack_waves) off; seven noise teams
