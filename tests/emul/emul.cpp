@@ -141,6 +141,51 @@ int emul_submaps(void *h, int W) { return ((Emul *)h)->B.chmap[W].submaps; }
 int emul_residue_offset(void *h, int W, int sm) { return ((Emul *)h)->B.res[W][sm].ent_base; }
 int emul_packet_capacity(void *h, int W) { return ((Emul *)h)->B.pack[W].capacity; }
 
+// The packed residue table of (W, sm) -- what k_residue_chunks / k_pack_waves copy into LDS (ResP::fast, built by
+// build_image) -- held against the blob's own tables, restated here field by field; and ResP::chunked against the
+// conditions under which a run of eight values is closed under every stage.  Returns 0, or the number of the first
+// check that fails.
+int emul_residue_fast_check(void *h, int W, int sm, int *chunked_out) {
+  Emul *e = (Emul *)h;
+  const unsigned char *img = e->image.data();
+  vamd_setup_header hd;
+  memcpy(&hd, img, sizeof(hd));
+  const ResP &R = e->B.res[W][sm];
+  if (chunked_out) *chunked_out = R.chunked;
+  if (sm >= hd.mode[W].submaps) return 0;
+  const vamd_residue_tab &r = hd.res[W][sm];
+  const vamd_book_tab *bk = (const vamd_book_tab *)(img + hd.off_books);
+  const int *tab = R.fast;
+  if (R.nparts != r.partitions || R.nstages != r.stages || R.begin != r.begin || R.tab_grouping != r.grouping) return 1;
+  if (R.groupbook != r.groupbook || R.groupbook_dim != r.groupbook_dim) return 2;
+  if (R.fast_ints != ((2 * r.partitions + 3) & ~3) + r.partitions * r.stages * (int)(sizeof(ResStage) / 4)) return 3;
+  for (int c = 0; c < r.partitions; c++)
+    if (tab[c] != r.classmetric1[c] || tab[r.partitions + c] != r.classmetric2[c]) return 4;
+  const ResStage *rows = (const ResStage *)(tab + ((2 * r.partitions + 3) & ~3));
+  bool dims_tile = true;
+  for (int c = 0; c < r.partitions; c++)
+    for (int s = 0; s < r.stages; s++) {
+      const ResStage &st = rows[c * r.stages + s];
+      const int bn = ((r.secondstages[c] >> s) & 1) ? r.partbooks[c][s] : -1;
+      if (st.bn != bn) return 5;
+      if (bn < 0) continue;
+      const vamd_book_tab &b = bk[bn];
+      if (st.dim != b.dim || st.minval != b.minval || st.delta != b.delta || st.quantvals != b.quantvals || st.entries != b.entries ||
+          (uint32_t)st.off_lengths != b.off_lengths)
+        return 6;
+      if (st.nv * b.dim != r.grouping) return 7;
+      const signed char *len = (const signed char *)(img + b.off_lengths);
+      int used = 0;
+      for (int i = 0; i < b.entries; i++) used += len[i] > 0;
+      if (st.full != (used == b.entries)) return 8;
+      if (8 % b.dim) dims_tile = false;
+    }
+  const bool want = R.covered && r.type == 2 && R.bundle == 2 && (r.grouping == 8 || r.grouping == 16 || r.grouping == 32) &&
+                    r.begin % 8 == 0 && dims_tile;
+  if ((R.chunked != 0) != want) return 9;
+  return 0;
+}
+
 int emul_mdct_forward(void *h, int W, const float *in, float *out) {
   Emul *e = (Emul *)h;
   const XformP &P = e->B.xf[W];

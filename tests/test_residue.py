@@ -88,6 +88,27 @@ def test_residue_tables_in_blob_are_consistent():
             assert cap <= 512 * 64
 
 
+def test_packed_residue_table_matches_the_blob():
+    """The (class, stage) rows k_residue_chunks / k_pack_waves keep in LDS (ResP::fast, built at bind time) against the blob's
+    residue and codebook tables field by field, and ResP::chunked against its conditions -- every shipped setup, every
+    libvorbisenc rate family through the reference where it is at hand.  The stereo setups must take the chunked search."""
+    from tests.emul.emul import Emul
+    import ctypes as C
+    blobs = [(name, blob_of(name)) for name in NAMES]
+    if ref.available():
+        for ch, rate, q in ((2, 8000, 0.3), (2, 22050, 0.5), (2, 32000, 0.1), (2, 48000, 0.9), (2, 96000, 0.5), (1, 44100, 0.4), (6, 44100, 0.3)):
+            blobs.append(("%dch %d q%.1f" % (ch, rate, q), ref.RefEncoder(ch, rate, q).pack_setup()))
+    for name, blob in blobs:
+        em = Emul(blob)
+        em.L.emul_residue_fast_check.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
+        for W in (0, 1):
+            for sm in range(em.L.emul_submaps(em.h, W)):
+                chunked = C.c_int(-1)
+                assert em.L.emul_residue_fast_check(em.h, W, sm, C.byref(chunked)) == 0, (name, W, sm)
+                if name.startswith("44k_stereo") or name.startswith("2ch"):
+                    assert chunked.value == 1, (name, W, sm)
+
+
 # ------------------------------------------------------------------------------------------
 # GPU suite (through the C ABI)
 # ------------------------------------------------------------------------------------------
