@@ -61,7 +61,8 @@ VAMD_DEV void env_fetch(EnvSamples<LOGS> &x, const float *__restrict__ pcm, int 
 template <int LOGS>
 VAMD_DEV void env_spectrum_wave(const EnvP &E, const float *__restrict__ pcm, int count, float *A, float *Wk,
                                 float *spec, float *__restrict__ near_out, float *__restrict__ raw_out,
-                                PhaseClock &pc, unsigned int *bad = nullptr, const EnvSamples<LOGS> *pre = nullptr) {
+                                PhaseClock &pc, unsigned int *bad = nullptr, const EnvSamples<LOGS> *pre = nullptr,
+                                int spec_stride = 64) {
   // (the detector's transform is 128 points whatever the setup -- vamd_bind refuses anything else -- so its size is a
   // compile-time constant here as the block transforms' are in k_transform: loop counts, strides and index arithmetic
   // fold away; the stage is bound by vector issue)
@@ -79,18 +80,20 @@ VAMD_DEV void env_spectrum_wave(const EnvP &E, const float *__restrict__ pcm, in
   }
   WAVE_SYNC();
   pc.mark(0);
-  mdct_forward_wave<LOGS, ln>(E.mdct, A, Wk, spec, pc, n, n2 + VAMD_PW_SIZE(n2), n2);
+  // (spec_stride: floats between the steps' spectra -- n2 for a buffer of their own, the work buffers' stride where the
+  // spectrum is left in a work buffer's plain half: spec == Wk)
+  mdct_forward_wave<LOGS, ln>(E.mdct, A, Wk, spec, pc, n, n2 + VAMD_PW_SIZE(n2), spec_stride);
   pc.mark(5);
   WAVE_FOR(t, count) {
     // float temp=vec[0]*vec[0]+.7*vec[1]*vec[1]+.2*vec[2]*vec[2];  the literals make it fp64
-    const float v0 = spec[t * n2], v1 = spec[t * n2 + 1], v2 = spec[t * n2 + 2];
+    const float v0 = spec[t * spec_stride], v1 = spec[t * spec_stride + 1], v2 = spec[t * spec_stride + 2];
     near_out[t] = (float)((double)(v0 * v0) + (.7 * (double)v1) * (double)v1 + (.2 * (double)v2) * (double)v2);
   }
   float top = -1e30f;  // the input-domain test (VAMD_ENV_LIMIT_DB, vamd_params.h): dB values are finite whatever the samples were
   WAVE_FOR(k, (n >> 2) << LOGS) {
     const int t = k >> (ln - 2), kk = k & ((n >> 2) - 1);
     if (t < count) {
-      const F2 z = *(const F2 *)(spec + t * n2 + 2 * kk);
+      const F2 z = *(const F2 *)(spec + t * spec_stride + 2 * kk);
       const float val = z.x * z.x + z.y * z.y;
       const float dB = todB(val) * .5f;
       raw_out[t * (n >> 2) + kk] = dB;

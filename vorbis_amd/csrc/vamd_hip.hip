@@ -1428,7 +1428,7 @@ static int envelope_search_batch(vamd_ctx *c, const float *pcm, long stream_stri
     if (items > 0x7fffffffL) return fail(c, VAMD_EINVAL, "detector: more than 2^31 groups of steps in one call");
     const long groups = (items + VAMD_ENV_WAVES - 1) / VAMD_ENV_WAVES;
     const long cap = (long)c->num_cus * 8;
-    const size_t lds = (size_t)VAMD_ENV_WAVES * VAMD_ENV_STEPS * (n + n2 + VAMD_PW_SIZE(n2) + n2) * 4;
+    const size_t lds = ((size_t)VAMD_ENV_WAVES * VAMD_ENV_STEPS * (n + n2 + VAMD_PW_SIZE(n2)) + (n + n / 4) + n + n / 4) * 4;  // + the transform's tables
     hipLaunchKernelGGL(k_env_spectrum, dim3((unsigned)(groups < cap ? groups : cap)), dim3(64 * VAMD_ENV_WAVES), lds, s, E,
                        ch, nstreams, nsteps, pcm, stream_stride, channel_stride, near, raw, bad, first_of, c->d_dbg);
   }

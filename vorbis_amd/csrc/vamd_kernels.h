@@ -1158,11 +1158,26 @@ __global__ __launch_bounds__(64 * VAMD_ENV_WAVES) __attribute__((amdgpu_waves_pe
                                                                       const long long *__restrict__ first_of, unsigned long long *dbg) {
   // (the wave number in a scalar register: an item's place -- stream, channel, first step -- is then scalar arithmetic)
   const int n = E.mdct.n, n2 = n >> 1, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int per_step = n + n2 + VAMD_PW_SIZE(n2) + n2;
+  // per step: the windowed samples, then the transform's work buffer, whose plain half takes the spectrum
+  const int per_step = n + n2 + VAMD_PW_SIZE(n2);
   float *A = (float *)vamd_smem + (size_t)wave * per_step * VAMD_ENV_STEPS;
-  float *Wk = A + n * VAMD_ENV_STEPS, *spec = Wk + (n2 + VAMD_PW_SIZE(n2)) * VAMD_ENV_STEPS;
+  float *Wk = A + n * VAMD_ENV_STEPS, *spec = Wk;
   PhaseClock pc;
   pc.start(dbg);  // (the transform's slot set: tools/env_profile.py)
+  // the transform's tables out of LDS, staged once per workgroup (a wave lives for ~130 items): every twiddle of every
+  // item used to be a trip to L1 with a 64-bit address formed in vector registers
+  {
+    float *ttrig = (float *)vamd_smem + (size_t)VAMD_ENV_WAVES * per_step * VAMD_ENV_STEPS;  // [n + n/4], then win [n], bitrev [n/4]
+    float *twin = ttrig + n + n / 4;
+    int *tbit = (int *)(twin + n);
+    for (int i = threadIdx.x; i < n + n / 4; i += blockDim.x) ttrig[i] = E.mdct.trig[i];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) twin[i] = E.win[i];
+    for (int i = threadIdx.x; i < n / 4; i += blockDim.x) tbit[i] = E.mdct.bitrev[i];
+    __syncthreads();
+    E.mdct.trig = ttrig;
+    E.win = twin;
+    E.mdct.bitrev = tbit;
+  }
   const long groups = (nsteps + VAMD_ENV_STEPS - 1) / VAMD_ENV_STEPS, items = nstreams * ch * groups;
   // an item's samples are requested while the previous item is in its transform (a wave lives for ~130 items and has
   // three neighbours on its SIMD: the trip to memory at the head of every item was a fifth of its time)
@@ -1196,7 +1211,7 @@ __global__ __launch_bounds__(64 * VAMD_ENV_WAVES) __attribute__((amdgpu_waves_pe
       env_fetch<VAMD_ENV_LOGS>(nxt, src2, count2, E.searchstep);
     }
     env_spectrum_wave<VAMD_ENV_LOGS>(E, src, count, A, Wk, spec, near + sc * (VAMD_VE_NEAR_HIST + nsteps) + VAMD_VE_NEAR_HIST + j,
-                                     raw + (sc * nsteps + j) * VAMD_VE_SPREAD, pc, bad, &cur);
+                                     raw + (sc * nsteps + j) * VAMD_VE_SPREAD, pc, bad, &cur, n2 + VAMD_PW_SIZE(n2));
     cur = nxt, sc = sc2, j = j2, count = count2, src = src2;
   }
   pc.flush();
