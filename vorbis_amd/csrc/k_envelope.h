@@ -58,7 +58,10 @@ VAMD_DEV void env_fetch(EnvSamples<LOGS> &x, const float *__restrict__ pcm, int 
   }
 }
 
-template <int LOGS>
+//   STAGED: `pcm` is the wave's staging buffer in LDS holding the item's samples as they came (k_env_spectrum: step t's
+//           start t * searchstep floats in); no windowed copy is made, the fold windows on the way in (mdct_forward_wave's WIN),
+//           and `A` is not used.  Steps past `count` then transform whatever the buffer holds; nothing of them is stored.
+template <int LOGS, bool STAGED = false>
 VAMD_DEV void env_spectrum_wave(const EnvP &E, const float *__restrict__ pcm, int count, float *A, float *Wk,
                                 float *spec, float *__restrict__ near_out, float *__restrict__ raw_out,
                                 PhaseClock &pc, unsigned int *bad = nullptr, const EnvSamples<LOGS> *pre = nullptr,
@@ -67,6 +70,11 @@ VAMD_DEV void env_spectrum_wave(const EnvP &E, const float *__restrict__ pcm, in
   // compile-time constant here as the block transforms' are in k_transform: loop counts, strides and index arithmetic
   // fold away; the stage is bound by vector issue)
   constexpr int ln = 7, n = 1 << ln, n2 = n >> 1;
+  if constexpr (STAGED) {
+    pc.mark(0);
+    mdct_forward_wave<LOGS, ln, WaveTeam, false, false, true>(E.mdct, pcm, Wk, spec, pc, E.searchstep, n2 + VAMD_PW_SIZE(n2), spec_stride,
+                                                             WaveTeam(), nullptr, nullptr, E.win);
+  } else {
 #if VAMD_GPU
   if (pre) {  // the samples are already in registers; a lane's window values are two (i = LANE, LANE + 64)
     const float w0 = E.win[LANE], w1 = E.win[LANE + 64];
@@ -83,6 +91,7 @@ VAMD_DEV void env_spectrum_wave(const EnvP &E, const float *__restrict__ pcm, in
   // (spec_stride: floats between the steps' spectra -- n2 for a buffer of their own, the work buffers' stride where the
   // spectrum is left in a work buffer's plain half: spec == Wk)
   mdct_forward_wave<LOGS, ln>(E.mdct, A, Wk, spec, pc, n, n2 + VAMD_PW_SIZE(n2), spec_stride);
+  }
   pc.mark(5);
   WAVE_FOR(t, count) {
     // float temp=vec[0]*vec[0]+.7*vec[1]*vec[1]+.2*vec[2]*vec[2];  the literals make it fp64

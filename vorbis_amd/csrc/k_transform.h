@@ -271,10 +271,15 @@ VAMD_DEV void swap_rows16(float &a, float &b) {  // a's odd rows of sixteen lane
 }
 #endif
 
-template <int LOGS = 0, int LOGN = 0, class Team = WaveTeam, bool PACKED = false, bool FOLD_AHEAD = false>
+// WIN: `in` holds the samples as they came, and the fold multiplies each by its window value `win[i]` on the way in (the
+// detector, k_env_spectrum: its steps overlap by half, so transform t's samples start in_stride = 64 floats after its
+// predecessor's and a windowed copy of every step would be twice the LDS).  x * win[i] is rounded as the separate
+// windowing pass rounds it; the sums the fold takes of such products are the same sums.
+template <int LOGS = 0, int LOGN = 0, class Team = WaveTeam, bool PACKED = false, bool FOLD_AHEAD = false, bool WIN = false>
 VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in0, float *w0, float *out0, PhaseClock &pc,
                                 int in_stride = 0, int w_stride = 0, int out_stride = 0, const Team &tm = Team(),
-                                FoldOps<LOGN> *ahead = nullptr, const float *in_next = nullptr) {
+                                FoldOps<LOGN> *ahead = nullptr, const float *in_next = nullptr, const float *win = nullptr) {
+  static_assert(!WIN || (!FOLD_AHEAD && !(VAMD_XF_FOLD_QUADS && LOGN >= 10 && LOGS == 0)), "the window in the fold: the generic fold only");
   const int n = LOGN ? (1 << LOGN) : P.n, n2 = n >> 1, n4 = n >> 2, n8 = n >> 3;
   const int log2n = LOGN ? LOGN : P.log2n;
   const float *__restrict__ trig = P.trig;
@@ -472,19 +477,28 @@ VAMD_DEV void mdct_forward_wave(const XformP &P, const float *in0, float *w0, fl
     const int p = g_;
     const F2 T = *(const F2 *)(trig + n2 - 2 * (p + 1));
     float r0, r1;
+    // (the two quads of the input a pair folds, windowed on the way in where the caller asked for that)
+    auto quad = [&](int at) {
+      F4 x = *(const F4 *)(in + at);
+      if constexpr (WIN) {
+        const F4 wv = *(const F4 *)(win + at);
+        x.x *= wv.x, x.y *= wv.y, x.z *= wv.z, x.w *= wv.w;
+      }
+      return x;
+    };
     if (2 * p < n8) {
-      const F4 x0 = *(const F4 *)(in + n2 + n4 - 4 * (p + 1));
-      const F4 x1 = *(const F4 *)(in + n2 + n4 + 4 * p);
+      const F4 x0 = quad(n2 + n4 - 4 * (p + 1));
+      const F4 x1 = quad(n2 + n4 + 4 * p);
       r0 = x0.z + x1.y;
       r1 = x0.x + x1.w;
     } else if (2 * p < n2 - n8) {
-      const F4 x0 = *(const F4 *)(in + n2 + n4 - 4 * (p + 1));
-      const F4 x1 = *(const F4 *)(in + 4 * (p - n8 / 2));
+      const F4 x0 = quad(n2 + n4 - 4 * (p + 1));
+      const F4 x1 = quad(4 * (p - n8 / 2));
       r0 = x0.z - x1.y;
       r1 = x0.x - x1.w;
     } else {
-      const F4 x0 = *(const F4 *)(in + n - 4 * (p - (n2 - n8) / 2 + 1));
-      const F4 x1 = *(const F4 *)(in + 4 * (p - n8 / 2));
+      const F4 x0 = quad(n - 4 * (p - (n2 - n8) / 2 + 1));
+      const F4 x1 = quad(4 * (p - n8 / 2));
       r0 = -x0.z - x1.y;
       r1 = -x0.x - x1.w;
     }

@@ -1427,8 +1427,13 @@ static int envelope_search_batch(vamd_ctx *c, const float *pcm, long stream_stri
     const long items = nsc * ((nsteps + VAMD_ENV_STEPS - 1) / VAMD_ENV_STEPS);
     if (items > 0x7fffffffL) return fail(c, VAMD_EINVAL, "detector: more than 2^31 groups of steps in one call");
     const long groups = (items + VAMD_ENV_WAVES - 1) / VAMD_ENV_WAVES;
-    const long cap = (long)c->num_cus * 8;
-    const size_t lds = ((size_t)VAMD_ENV_WAVES * VAMD_ENV_STEPS * (n + n2 + VAMD_PW_SIZE(n2)) + (n + n / 4) + n + n / 4) * 4;  // + the transform's tables
+    const size_t lds = ((size_t)VAMD_ENV_WAVES * (2 * VAMD_ENV_STAGE_FLOATS + VAMD_ENV_STEPS * (n2 + VAMD_PW_SIZE(n2))) + (n + n / 4) + n + n / 4) * 4;  // + the transform's tables
+    int resident = 0;  // (persistent: as many workgroups as are resident at once)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, (const void *)k_env_spectrum, 64 * VAMD_ENV_WAVES, lds) != hipSuccess || resident < 1) {
+      (void)hipGetLastError();
+      resident = 1;
+    }
+    const long cap = (long)c->num_cus * resident;
     hipLaunchKernelGGL(k_env_spectrum, dim3((unsigned)(groups < cap ? groups : cap)), dim3(64 * VAMD_ENV_WAVES), lds, s, E,
                        ch, nstreams, nsteps, pcm, stream_stride, channel_stride, near, raw, bad, first_of, c->d_dbg);
   }

@@ -1147,10 +1147,17 @@ __global__ void k_env_prolog(int ch, long nstreams, long nsteps, const vamd_enve
   }
 }
 
-// a wave takes VAMD_ENV_STEPS consecutive steps of one (stream, channel) at a time
-#define VAMD_ENV_LOGS 2
+// a wave takes VAMD_ENV_STEPS consecutive steps of one (stream, channel) at a time.  Eight (round 6): the 32-point groups of
+// the 128-point MDCT -- a lane a group: the reference spells each of their butterflies out with its own constants -- then
+// fill sixteen lanes instead of eight, and an item's bookkeeping is shared by twice the steps (profiles/r06_env_phases.txt:
+// 2 875 cycles per four steps behind the fetch instead of 5 200).  What made that possible is where the next item's
+// samples wait: not in sixteen registers per lane held across the item (the kernel then wanted more than 128), but in
+// LDS -- fetched there by global_load_lds, which needs no register for the data: the steps of an item overlap by half, so
+// its (steps + 1) * 64 samples are one contiguous run, a 256-byte chunk per instruction, lane l's float to word l.
+#define VAMD_ENV_LOGS 3
 #define VAMD_ENV_STEPS (1 << VAMD_ENV_LOGS)
 #define VAMD_ENV_WAVES 4
+#define VAMD_ENV_STAGE_FLOATS ((VAMD_ENV_STEPS + 1) * 64)  // an item's samples: (steps - 1) * searchstep + 128, searchstep 64
 __global__ __launch_bounds__(64 * VAMD_ENV_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_env_spectrum(EnvP E, int ch, long nstreams, long nsteps,
                                                                       const float *__restrict__ pcm, long stream_stride,
                                                                       long channel_stride, float *__restrict__ near,
@@ -1158,16 +1165,17 @@ __global__ __launch_bounds__(64 * VAMD_ENV_WAVES) __attribute__((amdgpu_waves_pe
                                                                       const long long *__restrict__ first_of, unsigned long long *dbg) {
   // (the wave number in a scalar register: an item's place -- stream, channel, first step -- is then scalar arithmetic)
   const int n = E.mdct.n, n2 = n >> 1, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  // per step: the windowed samples, then the transform's work buffer, whose plain half takes the spectrum
-  const int per_step = n + n2 + VAMD_PW_SIZE(n2);
-  float *A = (float *)vamd_smem + (size_t)wave * per_step * VAMD_ENV_STEPS;
-  float *Wk = A + n * VAMD_ENV_STEPS, *spec = Wk;
+  // per wave: two staging buffers (the item at hand, the next one's on their way), then per step the transform's work buffer,
+  // whose plain half takes the spectrum.  No windowed copy of the samples: the fold windows them on the way in.
+  const int per_step = n2 + VAMD_PW_SIZE(n2);
+  float *stage0 = (float *)vamd_smem + (size_t)wave * (2 * VAMD_ENV_STAGE_FLOATS + per_step * VAMD_ENV_STEPS);
+  float *Wk = stage0 + 2 * VAMD_ENV_STAGE_FLOATS, *spec = Wk;
   PhaseClock pc;
   pc.start(dbg);  // (the transform's slot set: tools/env_profile.py)
-  // the transform's tables out of LDS, staged once per workgroup (a wave lives for ~130 items): every twiddle of every
+  // the transform's tables out of LDS, staged once per workgroup (a wave lives for ~100 items): every twiddle of every
   // item used to be a trip to L1 with a 64-bit address formed in vector registers
   {
-    float *ttrig = (float *)vamd_smem + (size_t)VAMD_ENV_WAVES * per_step * VAMD_ENV_STEPS;  // [n + n/4], then win [n], bitrev [n/4]
+    float *ttrig = (float *)vamd_smem + (size_t)VAMD_ENV_WAVES * (2 * VAMD_ENV_STAGE_FLOATS + per_step * VAMD_ENV_STEPS);  // [n + n/4], then win [n], bitrev [n/4]
     float *twin = ttrig + n + n / 4;
     int *tbit = (int *)(twin + n);
     for (int i = threadIdx.x; i < n + n / 4; i += blockDim.x) ttrig[i] = E.mdct.trig[i];
@@ -1179,8 +1187,6 @@ __global__ __launch_bounds__(64 * VAMD_ENV_WAVES) __attribute__((amdgpu_waves_pe
     E.mdct.bitrev = tbit;
   }
   const long groups = (nsteps + VAMD_ENV_STEPS - 1) / VAMD_ENV_STEPS, items = nstreams * ch * groups;
-  // an item's samples are requested while the previous item is in its transform (a wave lives for ~130 items and has
-  // three neighbours on its SIMD: the trip to memory at the head of every item was a fifth of its time)
   auto where = [&](long it, long &sc, long &j, int &count) -> const float * {
     // (32-bit quotients: the launch checks items < 2^31 -- a 64-bit division by a run-time value is some eighty vector
     // instructions, two of them per item were a third of the kernel's)
@@ -1192,27 +1198,39 @@ __global__ __launch_bounds__(64 * VAMD_ENV_WAVES) __attribute__((amdgpu_waves_pe
     // (first_of: streams whose steps start at different samples -- the end-of-stream pass of streams of unequal length)
     return pcm + s * stream_stride + c * channel_stride + (first_of ? first_of[s] : 0) + j * E.searchstep;
   };
+  // an item's samples into the staging buffer: chunk c = samples [64 c, 64 c + 64), count + 1 of them
+  auto send_for = [&](const float *src, int count, float *stage) {
+    typedef const __attribute__((address_space(1))) void *gptr;
+    typedef __attribute__((address_space(3))) void *lptr;
+#pragma unroll
+    for (int c = 0; c <= VAMD_ENV_STEPS; c++)
+      if (c <= count) __builtin_amdgcn_global_load_lds((gptr)(src + 64 * c + LANE), (lptr)(stage + 64 * c), 4, 0, 0);
+  };
   const long stride = (long)gridDim.x * VAMD_ENV_WAVES;
   long it = (long)blockIdx.x * VAMD_ENV_WAVES + wave;
-  EnvSamples<VAMD_ENV_LOGS> cur, nxt;
   long sc, j;
   int count;
   const float *src = nullptr;
+  int cur = 0;  // which staging buffer holds the item at hand
   if (it < items) {
     src = where(it, sc, j, count);
-    env_fetch<VAMD_ENV_LOGS>(cur, src, count, E.searchstep);
+    send_for(src, count, stage0);
   }
   for (; it < items; it += stride) {
     long sc2 = 0, j2 = 0;
     int count2 = 0;
-    const float *src2 = nullptr;
-    if (it + stride < items) {
-      src2 = where(it + stride, sc2, j2, count2);
-      env_fetch<VAMD_ENV_LOGS>(nxt, src2, count2, E.searchstep);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this item's samples have landed (and nothing else is in flight)
+    WAVE_SYNC();
+    if (it + stride < items) {  // the next item's into the other buffer, on their way while this one is transformed
+      const float *src2 = where(it + stride, sc2, j2, count2);
+      send_for(src2, count2, stage0 + (cur ^ 1) * VAMD_ENV_STAGE_FLOATS);
     }
-    env_spectrum_wave<VAMD_ENV_LOGS>(E, src, count, A, Wk, spec, near + sc * (VAMD_VE_NEAR_HIST + nsteps) + VAMD_VE_NEAR_HIST + j,
-                                     raw + (sc * nsteps + j) * VAMD_VE_SPREAD, pc, bad, &cur, n2 + VAMD_PW_SIZE(n2));
-    cur = nxt, sc = sc2, j = j2, count = count2, src = src2;
+    env_spectrum_wave<VAMD_ENV_LOGS, true>(E, stage0 + cur * VAMD_ENV_STAGE_FLOATS, count, nullptr, Wk, spec,
+                                           near + sc * (VAMD_VE_NEAR_HIST + nsteps) + VAMD_VE_NEAR_HIST + j,
+                                           raw + (sc * nsteps + j) * VAMD_VE_SPREAD, pc, bad, (const EnvSamples<VAMD_ENV_LOGS> *)nullptr,
+                                           n2 + VAMD_PW_SIZE(n2));
+    sc = sc2, j = j2, count = count2;
+    cur ^= 1;
   }
   pc.flush();
 }
