@@ -387,7 +387,7 @@ int emul_plan_stream(void *h, const unsigned char *flags, long nsteps, long nsam
   BlockoutP B;
   B.bs[0] = e->B.bs[0];
   B.bs[1] = e->B.bs[1];
-  B.searchstep = e->B.env.searchstep;
+  blockout_set_step(B, e->B.env.searchstep);
   B.nsamples = nsamples;
   B.nsteps = nsteps;
   B.maxblocks = maxblocks;

@@ -32,7 +32,17 @@ struct BlockoutP {
   long nsteps;      // detector steps available per stream (flags[s][0 .. nsteps))
   int maxblocks;    // capacity of a stream's row in `blocks`
   long eof;         // 0: the stream goes on (more data may come); > 0: v->eofflag as an absolute sample index
+  int lstep;        // log2(searchstep) where that is a power of two (libvorbis: 64), else -1 (blockout_set_step)
 };
+// positions / searchstep for positions >= 0 (every one the walk divides): a shift where the step allows it -- a 64-bit
+// division by a run-time value is some eighty vector instructions, and the walk made three or four per block
+VAMD_DEV long blockout_div_step(const BlockoutP &B, long x) { return B.lstep >= 0 ? x >> B.lstep : x / B.searchstep; }
+VAMD_HOSTDEV void blockout_set_step(BlockoutP &B, int searchstep) {
+  B.searchstep = searchstep;
+  B.lstep = -1;
+  for (int l = 0; l < 30; l++)
+    if ((1 << l) == searchstep) B.lstep = l;
+}
 
 // one planned block: W | lW << 1 | nW << 2 | blocktype << 3 in `kind`, and where its window starts
 struct PlannedBlock {
@@ -53,7 +63,7 @@ VAMD_DEV int mark_at(const unsigned char *__restrict__ flags, long nsteps, long 
 }
 
 VAMD_DEV long blockout_steps(const BlockoutP &B) {
-  long last = B.nsamples / B.searchstep - VAMD_VE_WIN;
+  long last = blockout_div_step(B, B.nsamples) - VAMD_VE_WIN;
   if (last > B.nsteps) last = B.nsteps;
   return last < 0 ? 0 : last;
 }
@@ -87,7 +97,7 @@ VAMD_DEV int plan_stream(const BlockoutP &B, const unsigned char *marks, Planned
       const long j = base + (long)LANE * step;
       const bool visited = j < current - step;  // (the visited lanes are a prefix of the wave)
       const bool past = visited && j >= testW;
-      const bool marked = visited && !past && marks[j / step] && j > centerW;
+      const bool marked = visited && !past && marks[blockout_div_step(B, j)] && j > centerW;
       const unsigned long long stop = __ballot(past || marked);
       if (stop) {
         const int l = __builtin_ctzll(stop);
@@ -111,7 +121,7 @@ VAMD_DEV int plan_stream(const BlockoutP &B, const unsigned char *marks, Planned
         break;
       }
       cursor = j;
-      if (marks[j / step] && j > centerW) {
+      if (marks[blockout_div_step(B, j)] && j > centerW) {
         curmark = j;
         bp = j >= testW ? 1 : 0;
         break;
@@ -131,12 +141,13 @@ VAMD_DEV int plan_stream(const BlockoutP &B, const unsigned char *marks, Planned
       const long beginW = centerW - B.bs[0] / 4 - B.bs[0] / 4, endW = centerW + B.bs[0] / 4 + B.bs[0] / 4;
       int hit = curmark >= beginW && curmark < endW;
 #if VAMD_GPU
-      for (long i0 = beginW / step; !hit && i0 < endW / step; i0 += 64) {  // (a short block's span is a handful of steps: one trip)
+      const long i_begin = blockout_div_step(B, beginW), i_end = blockout_div_step(B, endW);  // (beginW >= 0: centerW >= blocksizes[1] / 2)
+      for (long i0 = i_begin; !hit && i0 < i_end; i0 += 64) {  // (a short block's span is a handful of steps: one trip)
         const long i = i0 + LANE;
-        hit = __ballot(i < endW / step && i >= 0 && i < last && marks[i]) != 0;
+        hit = __ballot(i < i_end && i >= 0 && i < last && marks[i]) != 0;
       }
 #else
-      for (long i = beginW / step; !hit && i < endW / step; i++) hit = i >= 0 && i < last && marks[i];
+      for (long i = blockout_div_step(B, beginW); !hit && i < blockout_div_step(B, endW); i++) hit = i >= 0 && i < last && marks[i];
 #endif
       blocktype = hit ? 0 /* BLOCKTYPE_IMPULSE */ : 1 /* BLOCKTYPE_PADDING */;
     }

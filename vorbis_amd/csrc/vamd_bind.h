@@ -232,8 +232,8 @@ inline int build_image(const void *blob_v, size_t bytes, std::vector<unsigned ch
   {
     const vamd_envelope_tab &e = h.env;
     const int n = e.winlength;
-    if (n != 128 || (1 << e.log2n) != n || e.searchstep < 1 || e.searchstep > n) {
-      *err = "envelope detector: only the 128-sample window of lib/envelope.c:35 is covered";
+    if (n != 128 || (1 << e.log2n) != n || e.searchstep != 64) {  // (k_env_spectrum stages an item's samples in 64-sample chunks)
+      *err = "envelope detector: only the 128-sample window and the 64-sample step of lib/envelope.c:35-37 are covered";
       return VAMD_EIMPL;
     }
     const uint64_t need[] = {(uint64_t)e.off_mdct_trig + 4ull * (n + n / 4), (uint64_t)e.off_mdct_bitrev + 4ull * (n / 4),

@@ -1539,7 +1539,7 @@ static int plan_streams(vamd_ctx *c, float *pcm, long stream_stride, long channe
   BlockoutP B;
   B.bs[0] = c->B.bs[0];
   B.bs[1] = c->B.bs[1];
-  B.searchstep = E.searchstep;
+  blockout_set_step(B, E.searchstep);
   B.nsamples = nsamples;
   B.eof = 0;
   // the steps _ve_envelope_search takes with this much data (lib/envelope.c:223-224); a whole stream's padding adds
