@@ -251,6 +251,43 @@ def test_gpu_large_batch_takes_the_one_wave_kernels():
 
 @pytest.mark.gpu
 @needs_ref
+@pytest.mark.parametrize("rate,quality", [(8000, 0.3), (22050, 0.5), (32000, 0.1), (44100, 1.0), (48000, 0.7), (96000, 0.5)])
+def test_gpu_batch_kernels_agree_across_rate_families(rate, quality):
+    """The batch kernels of round 6 (k_residue_chunks: a run of eight values per lane; k_pack_waves: persistent waves) against
+    the small-batch ones (k_residue: the work vector in LDS; k_pack_pair) on the same random blocks, both size classes, in
+    every libvorbisenc rate family -- other partition sizes, other books, other floors than the 44.1 kHz fixtures -- and a
+    sample of the rows against the reference."""
+    import torch
+    e = ref.RefEncoder(2, rate, quality)
+    an = vorbis_amd.Analyzer(e.pack_setup(), 0)
+    rng = np.random.default_rng(rate)
+    nb = 2560
+    for W in ((1, 0) if an.blocksizes[0] != an.blocksizes[1] else (0,)):  # (8 kHz: one block size, every block is W = 0)
+        amp = np.array([0.5, 0.003, 1.0, 0.0, 0.9, 0.1, 0.02, 0.3])[rng.integers(0, 8, nb), None, None]
+        pcm = ((rng.random((nb, 2, an.blocksizes[W]), dtype=np.float32) - 0.5) * 2 * amp).astype(np.float32)
+        dev = torch.from_numpy(pcm).cuda()
+        big = an.analyze(dev, W=W, lW=W, nW=W, blocktype=1 if W else 0, want=("packets", "packet_bits", "res_class", "res_entries", "res_count"))
+        torch.cuda.synchronize()
+        rows, bits = big["packets"].cpu().numpy(), big["packet_bits"].cpu().numpy()
+        cnt, ent = big["res_count"].cpu().numpy(), big["res_entries"].cpu().numpy()
+        for lo in range(0, nb, 640):
+            part = an.analyze(dev[lo:lo + 640], W=W, lW=W, nW=W, blocktype=1 if W else 0,
+                              want=("packets", "packet_bits", "res_class", "res_entries", "res_count"))
+            torch.cuda.synchronize()
+            assert np.array_equal(part["packet_bits"].cpu().numpy(), bits[lo:lo + 640]), (W, lo)
+            assert np.array_equal(part["res_count"].cpu().numpy(), cnt[lo:lo + 640]), (W, lo)
+            pr, pe = part["packets"].cpu().numpy(), part["res_entries"].cpu().numpy()
+            for k in range(640):
+                assert vorbis_amd.packet_bytes(pr[k], bits[lo + k]) == vorbis_amd.packet_bytes(rows[lo + k], bits[lo + k]), (W, lo + k)
+                n = int(cnt[lo + k].reshape(-1, 2)[:, 1].max())
+                assert np.array_equal(pe[k][:n], ent[lo + k][:n]), (W, lo + k)
+        for k in rng.choice(nb, 6, replace=False):
+            a = e.tap_block(pcm[k], W, W, W, 1 if W else 0)
+            assert vorbis_amd.packet_bytes(rows[k], bits[k]) == a["packet"], (W, k)
+
+
+@pytest.mark.gpu
+@needs_ref
 def test_gpu_many_streams_in_one_call():
     """An encoder farm's batch: four real streams (block decisions taken by the reference's own blockout, short and
     long blocks mixed, each with its own ampmax chain) analysed by ONE vamd_analyze_streams_mixed call, straight
