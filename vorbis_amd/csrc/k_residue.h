@@ -457,6 +457,101 @@ VAMD_DEV unsigned residue_wave_chunks(const ResP &R, const int *__restrict__ iw0
   pc.mark(1);
   return bad;
 }
+// The same for ONE block spread over a workgroup (a handful of units: the per-block entry points, the batcher's small
+// batches -- a lone block's latency is the caller's): a thread a run, the classes and offsets through LDS between two
+// barriers, the search out of registers as above.  chunks <= blockDim.x.
+//   tab [R.fast_ints], cls [partvals], off [stages * partvals + 1]: the workgroup's LDS
+VAMD_DEV unsigned residue_team_chunks(const ResP &R, const int *__restrict__ iw0, const int *__restrict__ iw1, int nz, int *tab, int *cls,
+                                      int *off, int *__restrict__ class_out, unsigned short *__restrict__ entries_out,
+                                      int *__restrict__ count_out, PhaseClock &pc, unsigned char *__restrict__ books_out) {
+  if (!nz) {
+    if (TEAM_LEADER) {
+      count_out[0] = 0;
+      count_out[1] = 0;
+    }
+    return 0;
+  }
+  const int spp = R.tab_grouping, nparts = R.nparts, partvals = R.partvals, stages = R.nstages;
+  const int g = spp >> 3, chunks = partvals * g;
+  const int it = (int)threadIdx.x;
+  TEAM_FOR(i, R.fast_ints >> 2)((I4 *)tab)[i] = ((const I4 *)R.fast)[i];  // the tables and the run: one trip to memory for both
+  int v[8];
+  residue_run_fetch(R, iw0, iw1, it, chunks, v);
+  TEAM_SYNC();
+  const int *metric1 = tab, *metric2 = tab + nparts;
+  const ResStage *rows = (const ResStage *)(tab + ((2 * nparts + 3) & ~3));
+  unsigned bad = 0;
+  int mag = 0, ang = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k += 2) {
+    const int m = v[k] < 0 ? -v[k] : v[k], an = v[k + 1] < 0 ? -v[k + 1] : v[k + 1];
+    mag = m > mag ? m : mag;
+    ang = an > ang ? an : ang;
+  }
+  if (mag > R.qmax) bad |= 1u;
+  if (ang > R.qmax) bad |= 2u;
+  mag = quad_max(mag, g);
+  ang = quad_max(ang, g);
+  int mycls = 0;
+  for (; mycls < nparts - 1; mycls++)
+    if (mag <= metric1[mycls] && ang <= metric2[mycls]) break;
+  if (it < chunks && (it & (g - 1)) == 0) {
+    cls[it / g] = mycls;
+    class_out[it / g] = mycls;
+  }
+  TEAM_SYNC();
+  const int items = stages * partvals;
+  if (TEAM_FIRST_WAVE) {
+    int carry = 0;
+    for (int base = 0; base < items; base += NLANES) {
+      const int itx = base + LANE;
+      int c = 0;
+      if (itx < items) {
+        const int s = itx / partvals, i = itx - s * partvals;
+        const ResStage &st = rows[cls[i] * stages + s];
+        c = st.bn >= 0 ? st.nv : 0;
+      }
+      const int incl = wave_scan_sum(c);
+      if (itx < items) off[itx] = carry + incl - c;
+      carry += wave_last(incl);
+    }
+    if (LANE == 0) {
+      count_out[0] = partvals;
+      count_out[1] = carry;
+    }
+  }
+  TEAM_SYNC();
+  pc.mark(0);
+  if (it < chunks) {
+    const int part = it / g, r = it & (g - 1);
+    for (int s = 0; s < stages; s++) {
+      const ResStage st = rows[mycls * stages + s];
+      if (st.bn < 0) continue;
+      const int dim = st.dim;
+      const int e0 = off[s * partvals + part] + r * (8 / dim);
+      auto emit = [&](int k, int entry) {
+        if (e0 + k < R.cap) {
+          entries_out[e0 + k] = (unsigned short)entry;
+          if (books_out) books_out[e0 + k] = (unsigned char)st.bn;
+        }
+      };
+      if (dim == 2) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) emit(k, residue_besterror_regs<2>(R, st, v + 2 * k));
+      } else if (dim == 4) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) emit(k, residue_besterror_regs<4>(R, st, v + 4 * k));
+      } else if (dim == 8) {
+        emit(0, residue_besterror_regs<8>(R, st, v));
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++) emit(k, residue_besterror_regs<1>(R, st, v + k));
+      }
+    }
+  }
+  pc.mark(1);
+  return bad;
+}
 #endif
 
 }  // namespace vamd

@@ -500,10 +500,16 @@ static void launch_residue_pack(vamd_ctx *c, BatchRun *R, hipStream_t s, long un
     const ResP &Rs = c->B.res[W][sm];
     // round 6: a stereo type-2 residue whose vectors tile runs of eight values is searched out of registers, a lane per
     // run, a wave per block (k_residue_chunks: persistent waves)
-    // (a handful of units keeps four waves a unit: a lone block's search is 3 us shorter that way)
-    const int chunks = Rs.chunked && units > res_team_max && !c->K.res_in_lds && ((uintptr_t)iwork & 15) == 0 && (n2 & 3) == 0
+    const int chunks = Rs.chunked && !c->K.res_in_lds && ((uintptr_t)iwork & 15) == 0 && (n2 & 3) == 0
                            ? Rs.partvals * (Rs.tab_grouping >> 3) : 0;
-    if (chunks > 0) {
+    if (chunks > 0 && units <= res_team_max && chunks <= 64 * VAMD_RES_WAVES) {
+      // a handful of units: a workgroup a unit, a thread a run (residue_team_chunks) -- a lone block's search in half the time
+      hipLaunchKernelGGL(k_residue, dim3((unsigned)units), dim3((chunks + 63) & ~63),
+                         (size_t)(Rs.lds_ints - Rs.bundle * n2 + Rs.fast_ints) * 4, s, Rs, cm, sm,
+                         c->B.res_cap[W], nblobs, R->d, ch, n2, iwork, nonzero, rb.cls, rb.entries, rb.count, packets ? rb.books : nullptr, 1);
+      continue;
+    }
+    if (chunks > 0 && units > res_team_max) {
       const size_t per_wave = (size_t)((Rs.partvals + Rs.nstages * Rs.partvals + 1 + 3) & ~3);
       const size_t lds = ((size_t)Rs.fast_ints + VAMD_RESC_WAVES * per_wave) * 4;
       int resident = 0;  // (persistent: as many workgroups as are resident at once)
@@ -521,7 +527,7 @@ static void launch_residue_pack(vamd_ctx *c, BatchRun *R, hipStream_t s, long un
     // takes four either way (nothing else wants the CU, and a lone unit's latency is the caller's)
     hipLaunchKernelGGL(k_residue, dim3((unsigned)units), dim3(64 * (c->B.res[W][sm].bundle * n2 > 4096 || units <= res_team_max ? VAMD_RES_WAVES : 2)),
                        (size_t)c->B.res[W][sm].lds_ints * 4, s, c->B.res[W][sm], cm, sm,
-                       c->B.res_cap[W], nblobs, R->d, ch, n2, iwork, nonzero, rb.cls, rb.entries, rb.count, packets ? rb.books : nullptr);
+                       c->B.res_cap[W], nblobs, R->d, ch, n2, iwork, nonzero, rb.cls, rb.entries, rb.count, packets ? rb.books : nullptr, 0);
   }
   prof_mark(c, VAMD_ST_RESIDUE);
   if (packets) {
@@ -531,7 +537,7 @@ static void launch_residue_pack(vamd_ctx *c, BatchRun *R, hipStream_t s, long un
     // a handful of packets: two waves each -- where the rows hold any packet (the residue part is assembled past the
     // longest possible head and then moved down: in a shorter row the end of a cut-off packet would be lost on the way)
     if (units <= pair_max && packet_stride >= c->B.pack[W].capacity)
-      hipLaunchKernelGGL(k_pack_pair, dim3((unsigned)units), dim3(128), lds + ((size_t)VAMD_PK_RING + 4) * 4, s, c->B.pack[W],
+      hipLaunchKernelGGL(k_pack_pair, dim3((unsigned)units), dim3(128), lds + ((size_t)VAMD_PK_RING + 4 + c->B.res[W][0].fast_ints) * 4, s, c->B.pack[W],
                          c->B.floor[W][0], c->B.floor[W][1], c->B.res[W][0], c->B.res[W][1], cm, c->B.res_cap[W], c->B.res_off_ints[W],
                          R->d, ch, W, nblobs, posts, wrapped, post_valid, rb.cls, rb.entries, rb.books, rb.count, (unsigned *)packets,
                          (int)(packet_stride / 4), packet_bits);

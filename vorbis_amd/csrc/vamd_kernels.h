@@ -877,13 +877,15 @@ __global__ __launch_bounds__(64) void k_floor_managed(PsyP P0, PsyP P1, FloorP F
 // (k_residue.h).  Output rows of a unit: res_class [submaps][VAMD_RES_CLASS_STRIDE], res_entries [ent_row],
 // res_count [submaps][2]; this launch fills submap `sm`'s part.
 #define VAMD_RES_WAVES 4  // waves per unit: they share one LDS copy of the work vector
+//   chunked: a stereo type-2 residue whose vectors tile runs of eight values (ResP::chunked), at most a run a thread: the
+//            search out of registers (residue_team_chunks), the search's tables where the work vector would be
 __global__ __launch_bounds__(64 * VAMD_RES_WAVES) void k_residue(ResP R, ChMap cm, int sm, int ent_row, int nblobs, DescP d, int ch, int n2,
                                                 const int *__restrict__ iwork, const int *__restrict__ nonzero,
                                                 int *__restrict__ res_class, unsigned short *__restrict__ res_entries,
-                                                int *__restrict__ res_count, unsigned char *__restrict__ res_books) {
+                                                int *__restrict__ res_count, unsigned char *__restrict__ res_books, int chunked) {
   const long u = blockIdx.x;
-  int *work = (int *)vamd_smem;                 // [bundle*n2]
-  int *cls = work + R.bundle * n2;              // [VAMD_RES_CLASS_STRIDE]
+  int *work = (int *)vamd_smem;                 // [bundle*n2] (chunked: the tables, [R.fast_ints])
+  int *cls = work + (chunked ? R.fast_ints : R.bundle * n2);  // [VAMD_RES_CLASS_STRIDE]
   int *off = cls + VAMD_RES_CLASS_STRIDE;       // [stages*slots + 1], then info [stages*slots]
   int *info = off + (R.tab->stages * R.slots + 1);
   const int *ip[VAMD_MAX_CH];
@@ -899,6 +901,11 @@ __global__ __launch_bounds__(64 * VAMD_RES_WAVES) void k_residue(ResP R, ChMap c
   PhaseClock pc;
   pc.start(d.dbg ? d.dbg + 72 : nullptr);
   unsigned over = 0;
+  if (chunked)
+    over = residue_team_chunks(R, ip[0], ip[1], nz[0] | nz[1], work, cls, off, res_class + u * (cm.submaps * VAMD_RES_CLASS_STRIDE) + R.cls_base,
+                               res_entries + u * (long)ent_row + R.ent_base, res_count + (u * cm.submaps + sm) * 2, pc,
+                               res_books ? res_books + u * (long)ent_row + R.ent_base : nullptr);
+  else
   residue_block(R, n2, ip, nz, work, cls, off, info, res_class + u * (cm.submaps * VAMD_RES_CLASS_STRIDE) + R.cls_base,
                 res_entries + u * (long)ent_row + R.ent_base, res_count + (u * cm.submaps + sm) * 2, pc,
                 res_books ? res_books + u * (long)ent_row + R.ent_base : nullptr, &over);
@@ -1044,10 +1051,12 @@ __global__ __launch_bounds__(128) void k_pack_pair(PackP K, FloorP F0, FloorP F1
   int *info = off + lds_ints;
   int *tabs = info + lds_ints;
   int *share = tabs + VAMD_PK_FTAB_INTS + 3 * K.nbooks;  // [4]: head bits, head's last (partial) word, residue bits
+  int *rtab = share + 4;                                 // [R0.fast_ints]: submap 0's (class, stage) rows (pack_residue's rtab)
   PhaseClock pc;
   pc.start(d.dbg ? d.dbg + 72 : nullptr);
   PackTabs T;
   T.at(tabs);
+  for (int i = threadIdx.x; i < R0.fast_ints; i += blockDim.x) rtab[i] = R0.fast[i];
   for (int b = threadIdx.x; b < K.nbooks; b += blockDim.x) {  // (pack_book_table, both waves)
     const vamd_book_tab &bk = K.books[b];
     T.books[3 * b] = bk.entries;
@@ -1092,7 +1101,7 @@ __global__ __launch_bounds__(128) void k_pack_pair(PackP K, FloorP F0, FloorP F1
       const ResP &R = sm ? R1 : R0;
       pack_residue(K, T, R, res_class + u * (cm.submaps * VAMD_RES_CLASS_STRIDE) + R.cls_base,
                    res_entries + u * (long)ent_row + R.ent_base, res_books ? res_books + u * (long)ent_row + R.ent_base : nullptr,
-                   res_count + (u * cm.submaps + sm) * 2, cls, off, info, r, pc);
+                   res_count + (u * cm.submaps + sm) * 2, cls, off, info, r, pc, sm == 0 ? rtab : nullptr);
     }
     ring_flush(r, (r.bitpos + 31) >> 5);
     if (LANE == 0) share[2] = (int)r.bitpos;
